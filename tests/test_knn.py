@@ -1,0 +1,169 @@
+"""Hamming kNN: oracle vs the real xflann (golden + live _ref), and HIP vs oracle (gpu)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "knn_golden.npz")
+CASES = ["rand", "ties", "desc", "tiny"]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("nn", [1, 2, 10])
+@pytest.mark.parametrize("s", [0, 1])
+def test_oracle_matches_reference_golden(oracle, case, nn, s):
+    g = np.load(GOLD)
+    idx, dist = oracle_lib.knn_search(oracle, g[f"{case}_train"], g[f"{case}_q"], nn, s)
+    np.testing.assert_array_equal(idx, g[f"{case}_nn{nn}_s{s}_idx"])
+    np.testing.assert_array_equal(dist, g[f"{case}_nn{nn}_s{s}_dist"])
+
+
+def test_oracle_matches_live_reference_build(oracle):
+    ref = oracle_lib.load_ref("xflann")
+    if ref is None:
+        pytest.skip("oracle/_ref not built (reference tree absent on this box)")
+    P = oracle_lib.P
+    for seed in range(3):
+        train, q = synth.match_set(150, 2000, seed=100 + seed)
+        for nn, s in [(2, 1), (10, 0), (7, 1)]:
+            i2 = np.empty((len(q), nn), np.int32)
+            d2 = np.empty_like(i2)
+            assert ref.xflann_ref_linear_search(P(train), len(train), P(q), len(q), nn, s, 1, P(i2), P(d2)) == 0
+            i1, d1 = oracle_lib.knn_search(oracle, train, q, nn, s)
+            np.testing.assert_array_equal(i1, i2)
+            np.testing.assert_array_equal(d1, d2)
+
+
+def test_oracle_shard_superset_property(oracle):
+    """Top-1 over the whole set == best of per-shard top-1 (lowest index wins ties): host logic of the sharded path."""
+    train, q = synth.tie_stress_set(40, 600, seed=5)
+    full_i, full_d = oracle_lib.knn_search(oracle, train, q, 1)
+    parts = [oracle_lib.knn_search(oracle, train, q, 1, t_begin=a, t_end=b) for a, b in [(0, 200), (200, 450), (450, 600)]]
+    best_d = np.minimum.reduce([p[1][:, 0] for p in parts])
+    np.testing.assert_array_equal(best_d, full_d[:, 0])
+    for r in range(len(q)):
+        cand = [p[0][r, 0] for p in parts if p[1][r, 0] == best_d[r]]
+        assert full_i[r, 0] == min(cand)
+
+
+# ------------------------------------------------------------------ GPU parity (through the C ABI)
+def _gpu_cases():
+    return {
+        "rand": synth.match_set(300, 3000, seed=21),
+        "ties": synth.tie_stress_set(200, 1500, seed=22),
+        "desc": synth.descending_set(8, 700, seed=23),
+        "tiny": synth.match_set(7, 3, seed=24),
+        "one": synth.match_set(65, 1, seed=25),
+        "ragged": synth.match_set(129, 257, seed=26),
+    }
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["rand", "ties", "desc", "tiny", "one", "ragged"])
+def test_hip_knn_bit_exact_host_api(hip_ctx, oracle, case):
+    from ucoslam_cv3_amd.knn import Index
+
+    train, q = _gpu_cases()[case]
+    index = Index(hip_ctx).build(train)
+    assert index.size() == len(train)
+    for nn in (1, 2, 10, 33):
+        for s in (0, 1):
+            idx, dist = index.search(q, nn, sorted=bool(s))
+            ri, rd = oracle_lib.knn_search(oracle, train, q, nn, s)
+            np.testing.assert_array_equal(idx, ri, err_msg=f"{case} nn={nn} sorted={s}")
+            np.testing.assert_array_equal(dist, rd)
+
+
+@pytest.mark.gpu
+def test_hip_knn_radius_bound_and_strided_rows(hip_ctx, oracle):
+    from ucoslam_cv3_amd.knn import Index
+
+    train, q = synth.match_set(100, 900, seed=31)
+    big_t = np.zeros((len(train), 48), np.uint8)
+    big_t[:, :32] = train
+    big_q = np.zeros((len(q), 40), np.uint8)
+    big_q[:, :32] = q
+    index = Index(hip_ctx).build(big_t[:, :32])
+    for md in (0, 60, 100, 120):
+        idx, dist = index.search(big_q[:, :32], 5, sorted=True, max_dist=md)
+        ri, rd = oracle_lib.knn_search(oracle, train, q, 5, 1, max_dist=md)
+        np.testing.assert_array_equal(idx, ri)
+        np.testing.assert_array_equal(dist, rd)
+
+
+@pytest.mark.gpu
+def test_hip_knn_full_size_properties(hip_ctx, oracle):
+    """BASELINE size (2000 x 10000): oracle on a query sample + size-independent properties on all rows."""
+    import torch
+
+    from ucoslam_cv3_amd.knn import Index
+
+    train, q = synth.match_set(2000, 10000, seed=0)
+    dt = torch.from_numpy(train).cuda()
+    dq = torch.from_numpy(q).cuda()
+    index = Index(hip_ctx).build(dt)
+    for nn in (2, 10):
+        idx, dist = index.search(dq, nn, sorted=True)
+        torch.cuda.synchronize()
+        idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+        sample = np.arange(0, 2000, 16)
+        ri, rd = oracle_lib.knn_search(oracle, train, q[sample], nn, 1)
+        np.testing.assert_array_equal(idx[sample], ri)
+        np.testing.assert_array_equal(dist[sample], rd)
+        # sortedness + distances recomputed independently + each row's indices distinct
+        assert (np.diff(dist, axis=1) >= 0).all()
+        xor = np.bitwise_xor(q[:, None, :], train[idx])
+        recomputed = np.unpackbits(xor, axis=2).sum(axis=2)
+        np.testing.assert_array_equal(recomputed, dist)
+        assert all(len(set(r)) == nn for r in idx)
+        # the k-th distance bounds every other row's distance from below (checked on a row sample)
+        for r in sample[:20]:
+            alld = np.unpackbits(np.bitwise_xor(q[r][None, :], train), axis=1).sum(axis=1)
+            assert np.sort(alld)[:nn].tolist() == dist[r].tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nshards,cap", [(2, 64), (8, 64), (3, 4)])
+def test_hip_knn_sharded_replay_equals_single(hip_ctx, oracle, nshards, cap):
+    """scan per shard -> concatenate candidate lists -> replay == unsharded reference (incl. cap overflow rescans)."""
+    import torch
+
+    from ucoslam_cv3_amd.knn import Index, shard_bounds
+
+    for train, q in (synth.match_set(130, 1200, seed=41), synth.tie_stress_set(70, 900, seed=42), synth.descending_set(4, 500, seed=43)):
+        dt, dq = torch.from_numpy(train).cuda(), torch.from_numpy(q).cuda()
+        index = Index(hip_ctx).build(dt)
+        b = shard_bounds(len(train), nshards)
+        for nn, s in [(2, 1), (10, 0)]:
+            cands, counts = [], []
+            for sh in range(nshards):
+                index.set_shard(b[sh], b[sh + 1])
+                c, n = index.scan_shard(dq, nn, cap)
+                cands.append(c)
+                counts.append(n)
+            index.set_shard(0, len(train))
+            idx, dist = index.replay(dq, nn, torch.stack(cands), torch.stack(counts), sorted=bool(s))
+            torch.cuda.synchronize()
+            ri, rd = oracle_lib.knn_search(oracle, train, q, nn, s)
+            np.testing.assert_array_equal(idx.cpu().numpy(), ri)
+            np.testing.assert_array_equal(dist.cpu().numpy(), rd)
+
+
+@pytest.mark.gpu
+def test_hip_knn_error_behaviour(hip_ctx):
+    import ucoslam_cv3_amd as u
+    from ucoslam_cv3_amd.knn import Index
+
+    index = Index(hip_ctx)
+    q = np.zeros((3, 32), np.uint8)
+    with pytest.raises(u.UcoslamHipError) as e:   # index.cpp:82-85: search on an unbuilt index fails
+        index.search(q, 2)
+    assert e.value.code == -3
+    index.build(np.zeros((0, 32), np.uint8))      # index.cpp:49: empty features leave it unbuilt
+    with pytest.raises(u.UcoslamHipError):
+        index.search(q, 2)
+    with pytest.raises(u.UcoslamHipError):        # only 32-byte descriptors
+        index.build(np.zeros((4, 61), np.uint8))

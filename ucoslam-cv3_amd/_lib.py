@@ -1,0 +1,114 @@
+"""ctypes binding of the C ABI in include/ucoslam_hip.h (libucoslam_hip.so, built in-tree by build.py).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is usable, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libucoslam_hip.so")
+
+UH_OK, UH_EINVAL, UH_ENODEVICE, UH_ENOTBUILT, UH_ENOMEM, UH_ECAPACITY = 0, -1, -2, -3, -4, -5
+
+
+class UcoslamHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library (importing torch first so both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UcoslamHipError(UH_ENODEVICE, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(the HIP extension is the product; there is no CPU path)")
+    try:
+        import torch  # noqa: F401  (loads libamdhip64 once for the whole process)
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    _declare(L)
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        raise UcoslamHipError(rc, lib().uh_last_error().decode("utf-8", "replace"))
+
+
+VP, I, SZ = C.c_void_p, C.c_int, C.c_size_t
+
+
+def _declare(L: C.CDLL):
+    def sig(name, restype, *argtypes):
+        fn = getattr(L, name)
+        fn.restype = restype
+        fn.argtypes = list(argtypes)
+
+    sig("uh_last_error", C.c_char_p)
+    sig("uh_version", I)
+    sig("uh_ctx_create", I, I, VP, C.POINTER(VP))
+    sig("uh_ctx_destroy", None, VP)
+    sig("uh_ctx_synchronize", I, VP)
+    sig("uh_ctx_stream", VP, VP)
+    # kNN
+    sig("uh_knn_create", I, VP, C.POINTER(VP))
+    sig("uh_knn_destroy", None, VP)
+    sig("uh_knn_build", I, VP, VP, I, SZ, I)
+    sig("uh_knn_build_dev", I, VP, VP, I)
+    sig("uh_knn_set_shard", I, VP, I, I)
+    sig("uh_knn_size", I, VP)
+    sig("uh_knn_search", I, VP, VP, I, SZ, I, VP, VP, I, I)
+    sig("uh_knn_search_dev", I, VP, VP, I, I, VP, VP, I, I)
+    sig("uh_knn_scan_shard_dev", I, VP, VP, I, I, I, VP, VP, I)
+    sig("uh_knn_replay_dev", I, VP, VP, I, I, I, I, VP, VP, I, I, VP, VP)
+    for extra in _EXTRA_DECLS:
+        extra(L, sig)
+
+
+_EXTRA_DECLS = []
+
+
+class Context:
+    """uh_ctx: one GPU + one HIP stream. `stream` may be a torch stream's `.cuda_stream` integer."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._h = VP()
+        check(lib().uh_ctx_create(device, VP(stream) if stream else None, C.byref(self._h)))
+        self.device = device
+
+    @property
+    def handle(self):
+        return self._h
+
+    def synchronize(self):
+        check(lib().uh_ctx_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            lib().uh_ctx_destroy(self._h)
+            self._h = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def np_ptr(a):
+    return a.ctypes.data_as(VP)
+
+
+def dev_ptr(t):
+    """Device pointer of a torch CUDA tensor."""
+    return VP(t.data_ptr())
