@@ -36,9 +36,11 @@ extern "C" {
 typedef struct uh_ctx uh_ctx;
 
 /* Context = one GPU + one HIP stream (+ scratch owned by the stage objects).
- * stream == NULL creates a private non-blocking stream; otherwise the given
- * hipStream_t is used (e.g. torch.cuda.current_stream().cuda_stream). */
+ * hip_stream is a hipStream_t; NULL means the device's default (null) stream, which is also
+ * what torch.cuda.current_stream().cuda_stream is (0) unless a side stream is current.
+ * uh_ctx_create_private() creates and owns a non-blocking stream instead. */
 int         uh_ctx_create(int device, void* hip_stream, uh_ctx** out);
+int         uh_ctx_create_private(int device, uh_ctx** out);
 void        uh_ctx_destroy(uh_ctx* ctx);
 int         uh_ctx_synchronize(uh_ctx* ctx);
 void*       uh_ctx_stream(uh_ctx* ctx);
@@ -90,6 +92,56 @@ int uh_knn_scan_shard_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn,
 int uh_knn_replay_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int sorted, int max_dist,
                       const uint64_t* d_cand_all, const int32_t* d_counts_all, int nshards, int cap,
                       int32_t* d_indices, int32_t* d_distances);
+
+/* ------------------------------------------------------------------------
+ * ORB extractor — replaces ucoslam::ORBextractor behind Feature2DSerializable:
+ *   src/featureextractors/feature2dserializable.h:30-95 (plugin surface, FeatParams :34-60)
+ *   src/featureextractors/ORBextractor.cpp:1139 detectAndCompute_impl -> :1247-1353 compute
+ * Output is layout-compatible with what the reference hands back:
+ *   uh_keypoint == cv::KeyPoint (7 x 4 bytes, ORBextractor.cpp:1297 memcpy), descriptors N x 32 CV_8U.
+ * Keypoints come in level order, within a level in the reference's cell-row-major /
+ * retainBest-permuted order.
+ * ------------------------------------------------------------------------ */
+typedef struct uh_orb uh_orb;
+
+typedef struct uh_keypoint {       /* cv::KeyPoint */
+    float x, y;                    /* pt, level-0 coordinates */
+    float size;                    /* 31 * scale[octave], truncated to int (ORBextractor.cpp:1046) */
+    float angle;                   /* degrees [0,360), cv::fastAtan2 of the intensity centroid */
+    float response;                /* FAST-9/16 corner score */
+    int32_t octave;
+    int32_t class_id;              /* -1 */
+} uh_keypoint;
+
+typedef struct uh_feat_params {    /* Feature2DSerializable::FeatParams (feature2dserializable.h:34-60) */
+    int32_t nthreads;              /* accepted for interface parity; the GPU path ignores it */
+    int32_t maxFeatures;           /* default 4000 */
+    int32_t nOctaveLevels;         /* default 8 */
+    float   scaleFactor;           /* default 1.2 */
+    float   sensitivity;           /* default 0 */
+} uh_feat_params;
+
+int  uh_orb_create(uh_ctx* ctx, uh_orb** out);
+void uh_orb_destroy(uh_orb* orb);
+/* detectAndCompute_impl re-runs precalculateParams when params change (:1142-1145); thresholds reset to 20/7 */
+int  uh_orb_set_params(uh_orb* orb, const uh_feat_params* params);
+int  uh_orb_get_params(const uh_orb* orb, uh_feat_params* params);
+int  uh_orb_set_blur(uh_orb* orb, int do_blur);            /* ORBextractor::doGaussianBlur() (ORBextractor.h:112) */
+int  uh_orb_set_sensitivity(uh_orb* orb, float v);         /* ORBextractor::setSensitivity (ORBextractor.cpp:457-466) */
+int  uh_orb_max_keypoints(const uh_orb* orb);              /* = maxFeatures: upper bound of *n_out */
+
+/* One frame, host buffers: img = h rows of w bytes (CV_8UC1), row stride in bytes.
+ * kps/desc must hold `cap` entries; *n_out receives the keypoint count (UH_ECAPACITY if n > cap).
+ * An empty image (NULL / w<=0 / h<=0) returns 0 keypoints silently (ORBextractor.cpp:1254). */
+int uh_orb_extract(uh_orb* orb, const uint8_t* img, int w, int h, size_t stride,
+                   uh_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+/* `batch` frames resident in HBM (frame f at d_imgs + f*frame_stride); outputs per frame at
+ * d_kps + f*cap_per_frame, d_desc + f*cap_per_frame*32, d_counts[f].  Asynchronous on the context stream. */
+int uh_orb_extract_dev(uh_orb* orb, const uint8_t* d_imgs, int w, int h, size_t stride, size_t frame_stride,
+                       int batch, uh_keypoint* d_kps, uint8_t* d_desc, int cap_per_frame, int32_t* d_counts);
+/* Verification tap: copy level `level` of frame `frame` (which: 0 pyramid, 1 FAST strength map) to `out`
+ * (w*h bytes, may be NULL to query the size). */
+int uh_orb_debug_level(uh_orb* orb, int frame, int level, int which, uint8_t* out, int* w_out, int* h_out);
 
 #ifdef __cplusplus
 }

@@ -48,3 +48,52 @@ def knn_search(L, train, queries, nn, sorted_=0, max_dist=-1, t_begin=0, t_end=-
                              queries.strides[0] if nq else 32, nn, int(sorted_), max_dist, t_begin, t_end, P(idx), P(dist))
     assert rc == 0
     return idx, dist
+
+
+# ------------------------------------------------------------------------------------------------ ORB
+import numpy as _np
+
+KEYPOINT_DTYPE = _np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                            ("octave", "<i4"), ("class_id", "<i4")])
+
+
+def orb_extract(L, img, maxFeatures=2000, nlevels=8, scaleFactor=1.2, blur=True):
+    cap = max(maxFeatures, 1)
+    kps = _np.zeros(cap, KEYPOINT_DTYPE)
+    desc = _np.zeros((cap, 32), _np.uint8)
+    L.oracle_orb_extract.restype = I
+    L.oracle_orb_extract.argtypes = [VP, I, I, SZ, I, I, C.c_float, I, VP, VP, I]
+    img = _np.ascontiguousarray(img)
+    n = L.oracle_orb_extract(P(img), img.shape[1], img.shape[0], img.strides[0], maxFeatures, nlevels, scaleFactor, int(blur),
+                             P(kps), P(desc), cap)
+    assert n >= 0, n
+    return kps[:n].copy(), desc[:n].copy()
+
+
+def orb_pyramid_level(L, img, level, nlevels=8, scaleFactor=1.2, blur=True):
+    img = _np.ascontiguousarray(img)
+    w, h = C.c_int(0), C.c_int(0)
+    L.oracle_orb_pyramid_level.argtypes = [VP, I, I, SZ, I, C.c_float, I, I, VP, C.POINTER(I), C.POINTER(I)]
+    assert L.oracle_orb_pyramid_level(P(img), img.shape[1], img.shape[0], img.strides[0], nlevels, scaleFactor, int(blur), level,
+                                      None, C.byref(w), C.byref(h)) == 0
+    out = _np.empty((h.value, w.value), _np.uint8)
+    L.oracle_orb_pyramid_level(P(img), img.shape[1], img.shape[0], img.strides[0], nlevels, scaleFactor, int(blur), level,
+                               P(out), C.byref(w), C.byref(h))
+    return out
+
+
+def fast_score_map(L, img):
+    img = _np.ascontiguousarray(img)
+    out = _np.empty_like(img)
+    L.oracle_fast_score_map.argtypes = [VP, I, I, I, VP]
+    L.oracle_fast_score_map(P(img), img.shape[1], img.shape[0], img.strides[0], P(out))
+    return out
+
+
+def fast_detect(L, img, threshold):
+    img = _np.ascontiguousarray(img)
+    cap = img.size // 4 + 16
+    xys = _np.empty((cap, 3), _np.int32)
+    L.oracle_fast_detect.argtypes = [VP, I, I, I, I, VP, I]
+    n = L.oracle_fast_detect(P(img), img.shape[1], img.shape[0], img.strides[0], threshold, P(xys), cap)
+    return xys[:n].copy()

@@ -42,3 +42,28 @@ def descending_set(nq=8, nt=700, seed=2):
     q = np.tile(q0, (nq, 1))
     q[:, 31] ^= np.arange(nq, dtype=np.uint8)
     return train, q
+
+
+def frame(w=1241, h=376, seed=0, nshapes=3000, shift=(0, 0)):
+    """Synthetic CV_8UC1 frame: low-frequency gradient + ~3000 random bright/dark rectangles and
+    discs (contrast 30..120) + Gaussian noise sigma 3, clipped. `shift` translates the scene (KITTI-like stream)."""
+    rng = np.random.default_rng(1234)            # the SCENE is fixed; `seed` only drives the noise
+    big_w, big_h = w + 256, h + 256
+    yy, xx = np.mgrid[0:big_h, 0:big_w].astype(np.float32)
+    img = 110 + 40 * np.sin(xx / 211.0) + 30 * np.cos(yy / 97.0)
+    for _ in range(nshapes):
+        cx, cy = rng.integers(0, big_w), rng.integers(0, big_h)
+        sx, sy = rng.integers(3, 28), rng.integers(3, 28)
+        c = float(rng.integers(30, 121)) * (1 if rng.random() < 0.5 else -1)
+        x0, x1 = max(cx - sx, 0), min(cx + sx, big_w)
+        y0, y1 = max(cy - sy, 0), min(cy + sy, big_h)
+        if rng.random() < 0.6:
+            img[y0:y1, x0:x1] += c
+        else:
+            r = min(sx, sy)
+            sub = (xx[y0:y1, x0:x1] - cx) ** 2 + (yy[y0:y1, x0:x1] - cy) ** 2 <= r * r
+            img[y0:y1, x0:x1] += c * sub
+    ox, oy = 128 + int(shift[0]), 128 + int(shift[1])
+    out = img[oy:oy + h, ox:ox + w]
+    noise = np.random.default_rng(seed).normal(0, 3, out.shape).astype(np.float32)
+    return np.clip(np.rint(out + noise), 0, 255).astype(np.uint8)

@@ -1,0 +1,95 @@
+"""ORB extractor: HIP path (through the C ABI) vs the CPU oracle — pyramid, FAST strength map, keypoints, descriptors."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import synth
+
+CONFIGS = [
+    # (w, h, maxFeatures, nlevels, scaleFactor, blur)
+    (640, 480, 2000, 8, 1.2, True),
+    (1241, 376, 2000, 8, 1.2, True),
+    (1241, 376, 4000, 8, 1.2, True),
+    (211, 167, 500, 5, 1.2, True),
+    (320, 240, 1000, 3, 1.5, False),
+    (97, 131, 300, 4, 1.3, True),
+]
+
+
+def _assert_same(kps, desc, rk, rd, tag):
+    assert len(kps) == len(rk), f"{tag}: {len(kps)} keypoints vs oracle {len(rk)}"
+    for f in ("octave", "class_id", "x", "y", "size", "response", "angle"):
+        np.testing.assert_array_equal(kps[f], rk[f], err_msg=f"{tag}: field {f}")
+    np.testing.assert_array_equal(desc, rd, err_msg=f"{tag}: descriptors")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"{c[0]}x{c[1]}_{c[2]}f_{c[3]}l")
+def test_hip_orb_bit_exact(hip_ctx, oracle, cfg):
+    from ucoslam_cv3_amd.orb import FeatParams, ORBextractor
+
+    w, h, nf, nl, sf, blur = cfg
+    ext = ORBextractor.create(hip_ctx)
+    ext.doGaussianBlur(blur)
+    for seed in (0, 1):
+        img = synth.frame(w, h, seed=seed)
+        kps, desc = ext.detectAndCompute(img, None, FeatParams(nf, nl, sf))
+        # stage parity first (pinpoints a failure): pyramid levels and the FAST strength map
+        for l in range(nl):
+            ref_level = oracle_lib.orb_pyramid_level(oracle, img, l, nl, sf, blur)
+            got_level = ext.debug_level(0, l, 0)
+            np.testing.assert_array_equal(got_level, ref_level, err_msg=f"pyramid level {l}")
+            np.testing.assert_array_equal(ext.debug_level(0, l, 1), oracle_lib.fast_score_map(oracle, ref_level),
+                                          err_msg=f"FAST strength map level {l}")
+        rk, rd = oracle_lib.orb_extract(oracle, img, nf, nl, sf, blur)
+        _assert_same(kps, desc, rk, rd, f"{cfg} seed {seed}")
+        assert len(kps) > 0.5 * nf or w < 200
+
+
+@pytest.mark.gpu
+def test_hip_orb_edge_inputs(hip_ctx, oracle):
+    from ucoslam_cv3_amd.orb import FeatParams, ORBextractor
+
+    ext = ORBextractor.create(hip_ctx)
+    fp = FeatParams(500, 4, 1.2)
+    # empty image -> silent empty result (ORBextractor.cpp:1254)
+    k, d = ext.detectAndCompute(np.zeros((0, 0), np.uint8), None, fp)
+    assert len(k) == 0 and d.shape == (0, 32)
+    # featureless image -> zero keypoints, as the oracle
+    flat = np.full((120, 160), 90, np.uint8)
+    k, d = ext.detectAndCompute(flat, None, fp)
+    rk, rd = oracle_lib.orb_extract(oracle, flat, 500, 4, 1.2)
+    assert len(k) == len(rk) == 0
+    # low-contrast texture forces the per-cell 20 -> 7 threshold fallback
+    rng = np.random.default_rng(5)
+    weak = (100 + rng.integers(0, 14, (200, 300))).astype(np.uint8)
+    weak[::17, ::13] += 25
+    k, d = ext.detectAndCompute(weak, None, fp)
+    rk, rd = oracle_lib.orb_extract(oracle, weak, 500, 4, 1.2)
+    _assert_same(k, d, rk, rd, "weak texture")
+    assert (rk["response"] < 20).any()
+    # strided host rows (cv::Mat ROI)
+    big = synth.frame(400, 300, seed=9)
+    roi = big[10:250, 20:340]
+    k, d = ext.detectAndCompute(roi, None, fp)
+    rk, rd = oracle_lib.orb_extract(oracle, np.ascontiguousarray(roi), 500, 4, 1.2)
+    _assert_same(k, d, rk, rd, "strided ROI")
+
+
+@pytest.mark.gpu
+def test_hip_orb_batch_resident_frames(hip_ctx, oracle):
+    """Frames resident in HBM, several per launch (the bench path): every frame equals its own oracle run."""
+    import torch
+
+    from ucoslam_cv3_amd.orb import KEYPOINT_DTYPE, FeatParams, ORBextractor
+
+    ext = ORBextractor.create(hip_ctx)
+    frames = np.stack([synth.frame(640, 480, seed=s, shift=(3 * s, s)) for s in range(3)])
+    kps, desc, counts = ext.extract_batch(torch.from_numpy(frames).cuda(), FeatParams(2000, 8, 1.2))
+    torch.cuda.synchronize()
+    kps, desc, counts = kps.cpu().numpy(), desc.cpu().numpy(), counts.cpu().numpy()
+    for f in range(3):
+        rk, rd = oracle_lib.orb_extract(oracle, frames[f], 2000, 8, 1.2)
+        n = counts[f]
+        got = kps[f, :n].copy().view(KEYPOINT_DTYPE).reshape(-1)
+        _assert_same(got, desc[f, :n], rk, rd, f"batch frame {f}")

@@ -57,6 +57,7 @@ def _declare(L: C.CDLL):
     sig("uh_last_error", C.c_char_p)
     sig("uh_version", I)
     sig("uh_ctx_create", I, I, VP, C.POINTER(VP))
+    sig("uh_ctx_create_private", I, I, C.POINTER(VP))
     sig("uh_ctx_destroy", None, VP)
     sig("uh_ctx_synchronize", I, VP)
     sig("uh_ctx_stream", VP, VP)
@@ -79,11 +80,15 @@ _EXTRA_DECLS = []
 
 
 class Context:
-    """uh_ctx: one GPU + one HIP stream. `stream` may be a torch stream's `.cuda_stream` integer."""
+    """uh_ctx: one GPU + one HIP stream. `stream` is a torch stream's `.cuda_stream` integer (0/None = the
+    default stream); private=True makes the context create and own a non-blocking stream."""
 
-    def __init__(self, device: int = 0, stream: int | None = None):
+    def __init__(self, device: int = 0, stream: int | None = None, private: bool = False):
         self._h = VP()
-        check(lib().uh_ctx_create(device, VP(stream) if stream else None, C.byref(self._h)))
+        if private:
+            check(lib().uh_ctx_create_private(device, C.byref(self._h)))
+        else:
+            check(lib().uh_ctx_create(device, VP(stream) if stream else None, C.byref(self._h)))
         self.device = device
 
     @property

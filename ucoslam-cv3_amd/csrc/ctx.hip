@@ -16,7 +16,7 @@ extern "C" {
 const char* uh_last_error(void) { return uh::g_err; }
 int uh_version(void) { return 100; }
 
-int uh_ctx_create(int device, void* hip_stream, uh_ctx** out) {
+static int ctx_create(int device, void* hip_stream, bool private_stream, uh_ctx** out) {
     UH_REQUIRE(out != nullptr, "uh_ctx_create: out is NULL");
     *out = nullptr;
     int ndev = 0;
@@ -30,8 +30,8 @@ int uh_ctx_create(int device, void* hip_stream, uh_ctx** out) {
     UH_HIP_CHECK(hipSetDevice(device));
     uh_ctx* c = new uh_ctx();
     c->device = device;
-    if (hip_stream) {
-        c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (!private_stream) {
+        c->stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = default stream
         c->owns_stream = false;
     } else {
         e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -43,6 +43,9 @@ int uh_ctx_create(int device, void* hip_stream, uh_ctx** out) {
     *out = c;
     return UH_OK;
 }
+
+int uh_ctx_create(int device, void* hip_stream, uh_ctx** out) { return ctx_create(device, hip_stream, false, out); }
+int uh_ctx_create_private(int device, uh_ctx** out) { return ctx_create(device, nullptr, true, out); }
 
 void uh_ctx_destroy(uh_ctx* ctx) {
     if (!ctx) return;

@@ -1,0 +1,137 @@
+// Selection with the exact permutation of libstdc++'s std::nth_element (GCC 11 <bits/stl_algo.h>,
+// __introselect: median-of-3 to first, unguarded Hoare partition, heap-select when the depth limit
+// 2*floor(log2(n)) is exhausted, insertion sort once the window is <= 3 elements).
+//
+// Why it exists: the reference truncates cv::KeyPointsFilter::retainBest's output right after its
+// std::nth_element (src/featureextractors/ORBextractor.cpp:1053-1055, :1071-1072), so WHICH tied
+// keypoints survive, and their ORDER, are defined by that algorithm's data movement.  The ORB stage runs
+// the same data movement on the GPU so that keypoint indices stay bit-exact without a host round trip.
+//
+// Elements are opaque 32-bit words; ordering is "greater response first" on key(e) = e >> 24
+// (the FAST score), exactly cv::KeypointResponseGreater on integral responses.
+// tests/test_introselect.py checks this header (compiled for the host) against std::nth_element.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define UH_HD __host__ __device__ __forceinline__
+#else
+#define UH_HD inline
+#endif
+
+namespace uh_sel {
+
+UH_HD uint32_t key(uint32_t e) { return e >> 24; }
+UH_HD bool before(uint32_t a, uint32_t b) { return key(a) > key(b); }   // comp(a,b): a has the larger response
+
+template <typename P> UH_HD void swp(P a, int i, int j) { uint32_t t = a[i]; a[i] = a[j]; a[j] = t; }
+
+// std::__move_median_to_first(result, a, b, c)
+template <typename P> UH_HD void median_to_first(P v, int result, int a, int b, int c) {
+    if (before(v[a], v[b])) {
+        if (before(v[b], v[c])) swp(v, result, b);
+        else if (before(v[a], v[c])) swp(v, result, c);
+        else swp(v, result, a);
+    } else if (before(v[a], v[c])) swp(v, result, a);
+    else if (before(v[b], v[c])) swp(v, result, c);
+    else swp(v, result, b);
+}
+
+// std::__unguarded_partition(first, last, pivot)
+template <typename P> UH_HD int unguarded_partition(P v, int first, int last, int pivot) {
+    const uint32_t pv = v[pivot];   // the pivot slot lies outside [first,last) and is never written here
+    for (;;) {
+        while (before(v[first], pv)) ++first;
+        --last;
+        while (before(pv, v[last])) --last;
+        if (!(first < last)) return first;
+        swp(v, first, last);
+        ++first;
+    }
+}
+
+// std::__adjust_heap + std::__push_heap on v[first .. first+len), comparator `before`
+template <typename P> UH_HD void adjust_heap(P v, int first, int hole, int len, uint32_t value) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (before(v[first + child], v[first + child - 1])) child--;
+        v[first + hole] = v[first + child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        v[first + hole] = v[first + child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && before(v[first + parent], value)) {
+        v[first + hole] = v[first + parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    v[first + hole] = value;
+}
+
+// std::__heap_select(first, middle, last)
+template <typename P> UH_HD void heap_select(P v, int first, int middle, int last) {
+    const int len = middle - first;
+    if (len >= 2) {   // std::__make_heap
+        int parent = (len - 2) / 2;
+        for (;;) {
+            uint32_t value = v[first + parent];
+            adjust_heap(v, first, parent, len, value);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    for (int i = middle; i < last; ++i) {
+        if (before(v[i], v[first])) {   // std::__pop_heap(first, middle, i)
+            uint32_t value = v[i];
+            v[i] = v[first];
+            adjust_heap(v, first, 0, len, value);
+        }
+    }
+}
+
+// std::__insertion_sort(first, last)
+template <typename P> UH_HD void insertion_sort(P v, int first, int last) {
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        uint32_t val = v[i];
+        if (before(val, v[first])) {
+            for (int j = i; j > first; --j) v[j] = v[j - 1];
+            v[first] = val;
+        } else {   // __unguarded_linear_insert
+            int j = i;
+            while (before(val, v[j - 1])) { v[j] = v[j - 1]; --j; }
+            v[j] = val;
+        }
+    }
+}
+
+UH_HD int floor_log2(int n) { int r = 0; while (n > 1) { n >>= 1; ++r; } return r; }
+
+// std::nth_element(v, v+nth, v+n, greater-response)
+template <typename P> UH_HD void nth_element_desc(P v, int n, int nth) {
+    if (n <= 0 || nth >= n) return;   // first == last || nth == last
+    int first = 0, last = n;
+    int depth_limit = 2 * floor_log2(n);
+    while (last - first > 3) {
+        if (depth_limit == 0) {
+            heap_select(v, first, nth + 1, last);
+            swp(v, first, nth);
+            return;
+        }
+        --depth_limit;
+        int mid = first + (last - first) / 2;
+        median_to_first(v, first, first + 1, mid, last - 1);
+        int cut = unguarded_partition(v, first + 1, last, first);
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    insertion_sort(v, first, last);
+}
+
+}  // namespace uh_sel

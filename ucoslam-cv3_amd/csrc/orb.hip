@@ -1,0 +1,802 @@
+// Multi-scale ORB extractor for MI355X (gfx950): the per-frame work of
+//   ucoslam::ORBextractor::detectAndCompute_impl / compute   src/featureextractors/ORBextractor.cpp:1139, :1247-1353
+// behind the C ABI of include/ucoslam_hip.h.  Everything after the input upload runs on the GPU; nothing is
+// read back until the keypoints/descriptors are final.
+//
+// Stage map (reference line -> kernel):
+//   GaussianBlur 7x7 sigma 2 of the input (:1261-1263)                      -> blur7_kernel        (fixed point, LDS tile)
+//   ComputePyramid: cubic resize chain level l-1 -> l (:1355-1393)          -> resize_cubic_kernel (11-bit taps from host tables)
+//   per-cell cv::FAST(thr 20 | 7, nonmax) (:899-987)                        -> fast_score_kernel   (threshold-free strength map)
+//                                                                              + cell_nms_kernel   (in-cell strict 3x3 maxima, raster-ordered compaction)
+//   quota redistribution + retainBest per cell and per level (:994-1073)    -> select_kernel       (libstdc++ introselect data movement, see introselect.hpp)
+//   IC_Angle (:79-106), rBRIEF (:113-153), border filter (:1120-1130),
+//   coordinate rescale (:1228-1229), level-order concatenation (:1278-1301) -> describe_kernel     (one wave per keypoint)
+//
+// Two observations keep this exact AND simple:
+//  (1) cornerScore<16> does not depend on the detection threshold once the pixel is a corner, and "corner at t" <=> score >= t.
+//      A neighbour that is not a corner at t scores < t <= own score, so zeroing it (what cv::FAST's row buffers do) cannot
+//      change the strict-maximum test.  Hence NMS is threshold-independent: a cell's keypoints at threshold t are its in-cell
+//      strict local maxima with score >= t, and the 20 -> 7 fallback is a filter on one candidate list.
+//  (2) the reference's 19-px reflected border around each level is never read (cells span [16,dim-16), the orientation disc
+//      and the rotated pattern stay >= 1 px inside), so levels are stored un-padded.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+#include "common.hpp"
+#include "introselect.hpp"
+#include "../../include/ucoslam_hip_orb_pattern.inc"
+
+namespace {
+
+constexpr int kMaxLevels = 16;
+constexpr int kMaxDim = 4095;          // candidate words pack x and y in 12 bits each
+constexpr int kMaxCellsPerLevel = 2048;
+constexpr int PATCH_SIZE = 31, HALF_PATCH = 15, EDGE = 19;
+
+struct LevelDesc {
+    int w, h, pitch;
+    int img_off;        // byte offset of the level inside one frame's pyramid (and score) buffer
+    int nDesired;
+    int nCells, cell_begin, cellCap, nfeaturesCell;
+    int cand_off;       // entry offset of the level's candidate area inside one frame's candidate buffer
+    int sel_off;        // entry offset of the level's selected list inside one frame's selection buffer
+    int work_cap;       // entries this level may need in the selection workspace (= nCells*cellCap)
+    int tiles_x, tiles_y, tile_begin;   // 64x16 tiles over the whole level
+    int xtap_off, ytap_off;             // offsets into the tap tables (level l reads level l-1)
+    int scaledPatchSize;
+    float scale;
+};
+
+struct CellDesc {       // FAST-scanned interior of one cell, level coordinates, [x0,x1) x [y0,y1)
+    short x0, y0, x1, y1;
+    int skipped;        // the reference's `continue` (hX<=0 / hY<=0): cell never counted in the first pass
+};
+
+struct Plan {           // uploaded once per (size, params)
+    int nlevels;
+    int iniTh, minTh;
+    int maxFeatures;
+    int total_tiles, total_cells;
+    LevelDesc lv[kMaxLevels];
+};
+
+__device__ const signed char d_pattern[1024] = {UH_ORB_PATTERN_VALUES};
+__device__ const int d_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+__device__ __forceinline__ int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------ blur
+// cv::GaussianBlur(8U, 7x7, sigma=2, BORDER_REFLECT_101), OpenCV >= 4.3 fixed-point path: taps {18,34,48,56,48,34,18}/256,
+// horizontal 8.8 accumulate, vertical 16.16 accumulate, (v + 2^15) >> 16.  Tile 64 x 16, halo 3.
+__global__ __launch_bounds__(256) void blur7_kernel(const uint8_t* __restrict__ src, int w, int h, size_t src_stride,
+                                                    size_t src_frame_stride, uint8_t* __restrict__ dst, int dst_pitch,
+                                                    size_t dst_frame_stride) {
+    constexpr int TW = 64, TH = 16, R = 3;
+    __shared__ uint8_t s_in[(TH + 2 * R)][TW + 2 * R + 2];
+    __shared__ uint16_t s_h[(TH + 2 * R)][TW];
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const uint8_t* in = src + (size_t)blockIdx.z * src_frame_stride;
+    uint8_t* out = dst + (size_t)blockIdx.z * dst_frame_stride;
+    for (int i = threadIdx.x; i < (TH + 2 * R) * (TW + 2 * R); i += 256) {
+        int ly = i / (TW + 2 * R), lx = i - ly * (TW + 2 * R);
+        int gy = reflect101(ty0 + ly - R, h), gx = reflect101(tx0 + lx - R, w);
+        s_in[ly][lx] = in[(size_t)gy * src_stride + gx];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (TH + 2 * R) * TW; i += 256) {
+        int ly = i / TW, lx = i - ly * TW;
+        const uint8_t* p = &s_in[ly][lx];
+        uint32_t s = 18u * (p[0] + p[6]) + 34u * (p[1] + p[5]) + 48u * (p[2] + p[4]) + 56u * p[3];
+        s_h[ly][lx] = (uint16_t)s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TH * TW; i += 256) {
+        int ly = i / TW, lx = i - ly * TW;
+        int gx = tx0 + lx, gy = ty0 + ly;
+        if (gx < w && gy < h) {
+            uint32_t s = 18u * ((uint32_t)s_h[ly][lx] + s_h[ly + 6][lx]) + 34u * ((uint32_t)s_h[ly + 1][lx] + s_h[ly + 5][lx]) +
+                         48u * ((uint32_t)s_h[ly + 2][lx] + s_h[ly + 4][lx]) + 56u * (uint32_t)s_h[ly + 3][lx];
+            out[(size_t)gy * dst_pitch + gx] = (uint8_t)((s + 32768u) >> 16);
+        }
+    }
+}
+
+// plain copy of the input into level 0 (doGaussianBlur == false)
+__global__ void copy_kernel(const uint8_t* __restrict__ src, int w, int h, size_t src_stride, size_t src_frame_stride,
+                            uint8_t* __restrict__ dst, int dst_pitch, size_t dst_frame_stride) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x < w) dst[(size_t)blockIdx.z * dst_frame_stride + (size_t)y * dst_pitch + x] =
+        src[(size_t)blockIdx.z * src_frame_stride + (size_t)y * src_stride + x];
+}
+
+// ------------------------------------------------------------------------------------------------ pyramid
+// cv::resize(INTER_CUBIC) 8UC1 reference path: int32 horizontal pass with 11-bit taps, int32 vertical pass,
+// (v + 2^21) >> 22, saturate.  Taps clamp at the source ROI edge.  ofs = floor(src coord), 4 shorts per output index.
+__global__ __launch_bounds__(256) void resize_cubic_kernel(const uint8_t* __restrict__ src, int sw, int sh, int spitch,
+                                                           uint8_t* __restrict__ dst, int dw, int dh, int dpitch,
+                                                           size_t frame_stride, const int* __restrict__ xofs,
+                                                           const short* __restrict__ xcoef, const int* __restrict__ yofs,
+                                                           const short* __restrict__ ycoef) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const uint8_t* S = src + (size_t)blockIdx.z * frame_stride;
+    int xo = xofs[x], yo = yofs[y];
+    int cx[4], cy[4], sx[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        cx[k] = xcoef[x * 4 + k];
+        cy[k] = ycoef[y * 4 + k];
+        sx[k] = min(max(xo - 1 + k, 0), sw - 1);
+    }
+    int acc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int sy = min(max(yo - 1 + k, 0), sh - 1);
+        const uint8_t* row = S + (size_t)sy * spitch;
+        int hsum = row[sx[0]] * cx[0] + row[sx[1]] * cx[1] + row[sx[2]] * cx[2] + row[sx[3]] * cx[3];
+        acc += hsum * cy[k];
+    }
+    int v = (acc + (1 << 21)) >> 22;
+    dst[(size_t)blockIdx.z * frame_stride + (size_t)y * dpitch + x] = (uint8_t)min(max(v, 0), 255);
+}
+
+// ------------------------------------------------------------------------------------------------ FAST strength map
+// score(p) = max over the 16 arcs of 9 contiguous circle pixels of min(|I_k - I_p| signed the same way) - 1, clamped to >= 0:
+// the value cv::cornerScore<16> returns for any threshold <= score.  Pixels closer than 3 to the level edge score 0.
+__device__ __forceinline__ int fast_strength(const int (&d)[25]) {
+    int best = 0;   // a0 starts at threshold 0
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        int a = min(min(min(d[k + 1], d[k + 2]), min(d[k + 3], d[k + 4])), min(min(d[k + 5], d[k + 6]), min(d[k + 7], d[k + 8])));
+        best = max(best, max(min(a, d[k]), min(a, d[k + 9])));
+        int b = max(max(max(d[k + 1], d[k + 2]), max(d[k + 3], d[k + 4])), max(max(d[k + 5], d[k + 6]), max(d[k + 7], d[k + 8])));
+        best = max(best, -min(max(b, d[k]), max(b, d[k + 9])));
+    }
+    return best - 1;
+}
+
+__global__ __launch_bounds__(256) void fast_score_kernel(const Plan* __restrict__ plan, const uint8_t* __restrict__ pyr,
+                                                         uint8_t* __restrict__ score, size_t frame_stride) {
+    constexpr int TW = 64, TH = 16, R = 3;
+    __shared__ uint8_t s_t[TH + 2 * R][TW + 2 * R + 2];
+    int lvl = 0;
+    const int tile = blockIdx.x;
+    while (lvl + 1 < plan->nlevels && tile >= plan->lv[lvl + 1].tile_begin) ++lvl;
+    const LevelDesc& L = plan->lv[lvl];
+    const int t = tile - L.tile_begin;
+    const int ty0 = (t / L.tiles_x) * TH, tx0 = (t % L.tiles_x) * TW;
+    const uint8_t* img = pyr + (size_t)blockIdx.y * frame_stride + L.img_off;
+    uint8_t* out = score + (size_t)blockIdx.y * frame_stride + L.img_off;
+    for (int i = threadIdx.x; i < (TH + 2 * R) * (TW + 2 * R); i += 256) {
+        int ly = i / (TW + 2 * R), lx = i - ly * (TW + 2 * R);
+        int gy = min(max(ty0 + ly - R, 0), L.h - 1), gx = min(max(tx0 + lx - R, 0), L.w - 1);
+        s_t[ly][lx] = img[(size_t)gy * L.pitch + gx];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int ly = (threadIdx.x >> 6) + 4 * r;
+        const int gx = tx0 + lx, gy = ty0 + ly;
+        if (gx >= L.w || gy >= L.h) continue;
+        int s = 0;
+        if (gx >= 3 && gy >= 3 && gx < L.w - 3 && gy < L.h - 3) {
+            const uint8_t* c = &s_t[ly + R][lx + R];
+            const int v = c[0];
+            int d[25];
+            constexpr int stride = TW + 2 * R + 2;
+            d[0] = v - c[3 * stride + 0];   d[1] = v - c[3 * stride + 1];   d[2] = v - c[2 * stride + 2];
+            d[3] = v - c[1 * stride + 3];   d[4] = v - c[3];                d[5] = v - c[-1 * stride + 3];
+            d[6] = v - c[-2 * stride + 2];  d[7] = v - c[-3 * stride + 1];  d[8] = v - c[-3 * stride];
+            d[9] = v - c[-3 * stride - 1];  d[10] = v - c[-2 * stride - 2]; d[11] = v - c[-1 * stride - 3];
+            d[12] = v - c[-3];              d[13] = v - c[1 * stride - 3];  d[14] = v - c[2 * stride - 2];
+            d[15] = v - c[3 * stride - 1];
+#pragma unroll
+            for (int k = 16; k < 25; k++) d[k] = d[k - 16];
+            s = max(fast_strength(d), 0);
+        }
+        out[(size_t)gy * L.pitch + gx] = (uint8_t)s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ per-cell NMS
+// One workgroup per (frame, cell).  Candidates = in-cell strict 3x3 maxima with score >= minTh, written in raster order as
+// (score<<24 | y<<12 | x) in level coordinates; n7 = their count, n20 = how many of them reach iniTh.
+__global__ __launch_bounds__(256) void cell_nms_kernel(const Plan* __restrict__ plan, const CellDesc* __restrict__ cells,
+                                                       const uint8_t* __restrict__ score, size_t frame_stride,
+                                                       uint32_t* __restrict__ cand, size_t cand_frame_stride,
+                                                       int* __restrict__ cell_counts /* [frame][cell][2] */) {
+    __shared__ int s_wave[4];
+    __shared__ int s_base, s_n20;
+    const int cell = blockIdx.x, frame = blockIdx.y;
+    int lvl = 0;
+    while (lvl + 1 < plan->nlevels && cell >= plan->lv[lvl + 1].cell_begin) ++lvl;
+    const LevelDesc& L = plan->lv[lvl];
+    const CellDesc C = cells[cell];
+    const uint8_t* sc = score + (size_t)frame * frame_stride + L.img_off;
+    uint32_t* out = cand + (size_t)frame * cand_frame_stride + L.cand_off + (size_t)(cell - L.cell_begin) * L.cellCap;
+    const int iw = C.x1 - C.x0, ih = C.y1 - C.y0;
+    const int npix = (iw > 0 && ih > 0 && !C.skipped) ? iw * ih : 0;
+    const int minTh = plan->minTh, iniTh = plan->iniTh;
+    if (threadIdx.x == 0) { s_base = 0; s_n20 = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int p0 = 0; p0 < npix; p0 += 256) {
+        const int p = p0 + threadIdx.x;
+        bool keep = false;
+        int s = 0, x = 0, y = 0;
+        if (p < npix) {
+            const int yy = p / iw, xx = p - yy * iw;
+            x = C.x0 + xx; y = C.y0 + yy;
+            s = sc[(size_t)y * L.pitch + x];
+            if (s >= minTh) {
+                keep = true;
+#pragma unroll
+                for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if (dx == 0 && dy == 0) continue;
+                        const int nx = x + dx, ny = y + dy;
+                        if (nx >= C.x0 && nx < C.x1 && ny >= C.y0 && ny < C.y1) keep = keep && (s > (int)sc[(size_t)ny * L.pitch + nx]);
+                    }
+            }
+        }
+        const uint64_t m = __ballot(keep);
+        const uint64_t m20 = __ballot(keep && s >= iniTh);
+        if (lane == 0) s_wave[wv] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int i = 0; i < wv; i++) off += s_wave[i];
+        if (keep) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1));
+            if (pos < L.cellCap) out[pos] = ((uint32_t)s << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+        }
+        if (lane == 0 && m20) atomicAdd(&s_n20, __popcll(m20));
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int* cc = cell_counts + ((size_t)frame * plan->total_cells + cell) * 2;
+        cc[0] = s_base;
+        cc[1] = s_n20;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ selection
+// One workgroup per (frame, level): quota redistribution (:994-1039), per-cell retainBest + truncate (:1053-1055),
+// concatenation in cell-row-major order (:1058-1065), level-wide retainBest + truncate (:1069-1073).
+// Workspace `work` holds the threshold-filtered cell lists back to back, `cat` the concatenation.
+__global__ __launch_bounds__(256) void select_kernel(const Plan* __restrict__ plan, const CellDesc* __restrict__ cells,
+                                                     const uint32_t* __restrict__ cand, size_t cand_frame_stride,
+                                                     const int* __restrict__ cell_counts, uint32_t* __restrict__ work_g,
+                                                     size_t work_frame_stride, uint32_t* __restrict__ sel,
+                                                     size_t sel_frame_stride, int* __restrict__ level_counts, int lds_entries) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    __shared__ int s_nkeys[kMaxCellsPerLevel];
+    __shared__ int s_ret[kMaxCellsPerLevel];
+    __shared__ int s_off[kMaxCellsPerLevel + 1];
+    __shared__ int s_out[kMaxCellsPerLevel + 1];
+    __shared__ int s_total;
+    const int lvl = blockIdx.x, frame = blockIdx.y;
+    const LevelDesc& L = plan->lv[lvl];
+    const int nCells = L.nCells;
+    const int* cc = cell_counts + ((size_t)frame * plan->total_cells + L.cell_begin) * 2;
+    const uint32_t* cbase = cand + (size_t)frame * cand_frame_stride + L.cand_off;
+    uint32_t* lsel = sel + (size_t)frame * sel_frame_stride + L.sel_off;
+    const int iniTh = plan->iniTh;
+
+    for (int c = threadIdx.x; c < nCells; c += 256) {
+        const int n7 = cc[2 * c], n20 = cc[2 * c + 1];
+        s_nkeys[c] = cells[L.cell_begin + c].skipped ? 0 : (n20 > 3 ? n20 : n7);   // :980-987
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nfeaturesCell = L.nfeaturesCell;
+        int nNoMore = 0, nToDistribute = 0;
+        // first pass (:989-1004): skipped cells are not visited; bNoMore is encoded as s_ret sign bit substitute below
+        for (int c = 0; c < nCells; c++) {
+            if (cells[L.cell_begin + c].skipped) { s_ret[c] = 0; s_off[c] = 0; continue; }   // s_off reused as bNoMore
+            const int nKeys = s_nkeys[c];
+            if (nKeys > nfeaturesCell) { s_ret[c] = nfeaturesCell; s_off[c] = 0; }
+            else { s_ret[c] = nKeys; nToDistribute += nfeaturesCell - nKeys; s_off[c] = 1; nNoMore++; }
+        }
+        while (nToDistribute > 0 && nNoMore < nCells) {
+            const int nNew = (int)((float)nfeaturesCell + ceilf((float)nToDistribute / (float)(nCells - nNoMore)));
+            nToDistribute = 0;
+            for (int c = 0; c < nCells; c++) {
+                if (s_off[c]) continue;
+                const int nTotal = s_nkeys[c];
+                if (nTotal > nNew) { s_ret[c] = nNew; }
+                else { s_ret[c] = nTotal; nToDistribute += nNew - nTotal; s_off[c] = 1; nNoMore++; }
+            }
+        }
+        int o = 0, q = 0;
+        for (int c = 0; c < nCells; c++) { s_off[c] = o; o += s_nkeys[c]; s_out[c] = q; q += s_ret[c]; }
+        s_off[nCells] = o;
+        s_out[nCells] = q;
+        s_total = q;
+    }
+    __syncthreads();
+    // workspace: LDS when the level's filtered candidates + concatenation fit, else HBM scratch
+    const int need = s_off[nCells] + s_out[nCells];
+    uint32_t* work = (need <= lds_entries) ? s_dyn : (work_g + (size_t)frame * work_frame_stride + 2 * (size_t)L.cand_off);
+    uint32_t* cat = work + s_off[nCells];
+
+    for (int c = threadIdx.x; c < nCells; c += 256) {
+        const int nk = s_nkeys[c], ret = s_ret[c];
+        if (nk == 0) continue;
+        const uint32_t* src = cbase + (size_t)c * L.cellCap;
+        uint32_t* w = work + s_off[c];
+        const int n7 = cc[2 * c], n20 = cc[2 * c + 1];
+        if (n20 > 3) { int k = 0; for (int i = 0; i < n7; i++) { uint32_t e = src[i]; if ((int)(e >> 24) >= iniTh) w[k++] = e; } }
+        else for (int i = 0; i < n7; i++) w[i] = src[i];
+        // KeyPointsFilter::retainBest(keysCell, ret) then resize(ret): only the nth_element data movement matters
+        if (ret > 0 && nk > ret) uh_sel::nth_element_desc(w, nk, ret - 1);
+        uint32_t* o = cat + s_out[c];
+        for (int i = 0; i < ret; i++) o[i] = w[i];
+    }
+    __syncthreads();
+    int total = s_total;
+    if (total > L.nDesired) {   // :1069-1073
+        if (threadIdx.x == 0) {
+            if (L.nDesired > 0) uh_sel::nth_element_desc(cat, total, L.nDesired - 1);
+        }
+        total = L.nDesired;
+        __syncthreads();
+    }
+    // computeDescriptors' border filter (:1124-1130), order preserving; the reference applies it before describing
+    if (threadIdx.x == 0) {
+        const int maxX = L.w - EDGE, maxY = L.h - EDGE;
+        int k = 0;
+        for (int i = 0; i < total; i++) {
+            const uint32_t e = cat[i];
+            const int x = e & 0xFFF, y = (e >> 12) & 0xFFF;
+            if (x < EDGE || y < EDGE || x > maxX || y > maxY) continue;
+            lsel[k++] = e;
+        }
+        level_counts[(size_t)frame * kMaxLevels + lvl] = k;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ orientation + rBRIEF
+struct KeyPointOut { float x, y, size, angle, response; int octave, class_id; };   // == cv::KeyPoint (28 bytes)
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {   // cv::fastAtan2 scalar path, un-fused
+    const float p1 = 0.9997878412794807f * (float)(180 / M_PI), p3 = -0.3258083974640975f * (float)(180 / M_PI);
+    const float p5 = 0.1555786518463281f * (float)(180 / M_PI), p7 = -0.04432655554792128f * (float)(180 / M_PI);
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One wave per output keypoint slot; 4 waves per block.
+__global__ __launch_bounds__(256) void describe_kernel(const Plan* __restrict__ plan, const uint8_t* __restrict__ pyr,
+                                                       size_t frame_stride, const uint32_t* __restrict__ sel,
+                                                       size_t sel_frame_stride, const int* __restrict__ level_counts,
+                                                       KeyPointOut* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                       int cap_per_frame, int* __restrict__ frame_counts) {
+    const int frame = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int* lc = level_counts + (size_t)frame * kMaxLevels;
+    int lvl = 0, base = 0, total = 0;
+    for (int l = 0; l < plan->nlevels; l++) total += lc[l];
+    if (slot == 0 && lane == 0) frame_counts[frame] = total;
+    if (slot >= total || slot >= cap_per_frame) return;
+    while (slot >= base + lc[lvl]) { base += lc[lvl]; ++lvl; }
+    const LevelDesc& L = plan->lv[lvl];
+    const uint32_t e = sel[(size_t)frame * sel_frame_stride + L.sel_off + (slot - base)];
+    const int cx = e & 0xFFF, cy = (e >> 12) & 0xFFF, resp = e >> 24;
+    const uint8_t* img = pyr + (size_t)frame * frame_stride + L.img_off;
+    const uint8_t* center = img + (size_t)cy * L.pitch + cx;
+    // IC_Angle: integer moments over the radius-15 disc, one row per lane
+    int m10 = 0, m01 = 0;
+    if (lane < 31) {
+        const int v = lane - HALF_PATCH;
+        const int d = d_umax[v < 0 ? -v : v];
+        const uint8_t* row = center + (ptrdiff_t)v * L.pitch;
+        int rs = 0;
+        for (int u = -d; u <= d; ++u) { const int val = row[u]; m10 += u * val; rs += val; }
+        m01 = v * rs;
+    }
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // rotated BRIEF: lane t evaluates tests 4t..4t+3
+    const float factorPI = (float)(M_PI / 180.f);
+    const float ang = angle * factorPI;
+    const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+    int nib = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const signed char* p = d_pattern + (lane * 4 + j) * 4;
+        const int x0 = p[0], y0 = p[1], x1 = p[2], y1 = p[3];
+        const int r0 = (int)rintf((float)x0 * b + (float)y0 * a), c0 = (int)rintf((float)x0 * a - (float)y0 * b);
+        const int r1 = (int)rintf((float)x1 * b + (float)y1 * a), c1 = (int)rintf((float)x1 * a - (float)y1 * b);
+        const int t0 = center[(ptrdiff_t)r0 * L.pitch + c0], t1 = center[(ptrdiff_t)r1 * L.pitch + c1];
+        nib |= (t0 < t1) << j;
+    }
+    const int hi = __shfl_down(nib, 1);
+    const size_t o = (size_t)frame * cap_per_frame + slot;
+    if ((lane & 1) == 0) desc[o * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+    if (lane == 0) {
+        KeyPointOut k;
+        k.x = (float)cx; k.y = (float)cy;
+        if (lvl != 0) { k.x = (k.x + 0.5f) * L.scale; k.y = (k.y + 0.5f) * L.scale; }   // :1228-1229
+        k.size = (float)L.scaledPatchSize;
+        k.angle = angle;
+        k.response = (float)resp;
+        k.octave = lvl;
+        k.class_id = -1;
+        kps[o] = k;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+inline int cvRoundf(float v) { return (int)lrintf(v); }
+inline int cvFloord(double v) { int i = (int)v; return i - (i > v); }
+
+void interpolate_cubic(float x, float* c) {
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+void cubic_taps(int ssize, int dsize, std::vector<int>& ofs, std::vector<short>& coef) {
+    const double inv_scale = (double)dsize / ssize;
+    const double scale = 1.0 / inv_scale;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = cvFloord(f);
+        f -= s;
+        float c[4];
+        interpolate_cubic(f, c);
+        ofs.push_back(s);
+        for (int k = 0; k < 4; k++) coef.push_back((short)std::min(std::max(cvRoundf(c[k] * 2048.f), -32768), 32767));
+    }
+}
+
+}  // namespace
+
+struct uh_orb {
+    uh_ctx* ctx = nullptr;
+    // plan key
+    int w = 0, h = 0, batch = 0;
+    uh_feat_params fp{-1, 4000, 8, 1.2f, 0.f};
+    bool planned = false;
+    bool blur_first = true;        // ORBextractor::doGaussianBlur()
+    int iniTh = 20, minTh = 7;     // precalculateParams resets these on every parameter change (:478-479)
+    Plan plan;
+    std::vector<CellDesc> cells;
+    size_t frame_stride = 0, cand_stride = 0, sel_stride = 0;
+    int lds_entries = 0;
+    uh::DevBuf d_plan, d_cells, d_xofs, d_xcoef, d_yofs, d_ycoef;
+    uh::DevBuf d_pyr, d_score, d_cand, d_work, d_sel, d_cell_counts, d_level_counts;
+    // staging for the host-pointer API
+    uh::DevBuf d_in, d_kps, d_desc, d_counts;
+};
+
+namespace {
+
+// Mirrors ORBextractor::precalculateParams (:468-515), ComputePyramid sizes (:1369-1370) and the cell geometry of
+// ComputeKeyPoints_thread (:899-976).
+int make_plan(uh_orb* o, int w, int h, int batch) {
+    const uh_feat_params& fp = o->fp;
+    UH_REQUIRE(fp.nOctaveLevels >= 1 && fp.nOctaveLevels <= kMaxLevels, "orb: nOctaveLevels=%d outside [1,%d]", fp.nOctaveLevels, kMaxLevels);
+    UH_REQUIRE(fp.scaleFactor > 1.0f, "orb: scaleFactor must be > 1");
+    UH_REQUIRE(fp.maxFeatures >= 0, "orb: maxFeatures < 0");
+    UH_REQUIRE(w >= 1 && h >= 1 && w <= kMaxDim && h <= kMaxDim, "orb: image %dx%d outside [1,%d]", w, h, kMaxDim);
+    Plan& P = o->plan;
+    std::memset(&P, 0, sizeof(P));
+    const int nl = fp.nOctaveLevels;
+    P.nlevels = nl;
+    P.iniTh = o->iniTh;
+    P.minTh = o->minTh;
+    P.maxFeatures = fp.maxFeatures;
+    std::vector<float> scale(nl, 1.f), inv(nl, 1.f);
+    for (int i = 1; i < nl; i++) scale[i] = scale[i - 1] * fp.scaleFactor;
+    for (int i = 0; i < nl; i++) inv[i] = 1.0f / scale[i];
+    std::vector<int> nFeat(nl, 0);
+    {
+        const float factor = 1.0f / fp.scaleFactor;
+        float nDesired = fp.maxFeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+        int sum = 0;
+        for (int l = 0; l < nl - 1; l++) { nFeat[l] = cvRoundf(nDesired); sum += nFeat[l]; nDesired *= factor; }
+        nFeat[nl - 1] = std::max(fp.maxFeatures - sum, 0);
+    }
+    o->cells.clear();
+    std::vector<int> xofs, yofs;
+    std::vector<short> xcoef, ycoef;
+    size_t img_off = 0, cand_off = 0, sel_off = 0;
+    int tile_begin = 0, cell_begin = 0;
+    const float imageRatio = (float)w / h;   // :900 (level 0 is the input size)
+    int max_level_need = 0;
+    for (int l = 0; l < nl; l++) {
+        LevelDesc& L = P.lv[l];
+        L.w = cvRoundf((float)w * inv[l]);
+        L.h = cvRoundf((float)h * inv[l]);
+        UH_REQUIRE(L.w >= 1 && L.h >= 1, "orb: pyramid level %d is empty (%dx%d)", l, L.w, L.h);
+        L.pitch = (L.w + 63) & ~63;
+        L.img_off = (int)img_off;
+        img_off += (size_t)L.pitch * L.h;
+        L.scale = scale[l];
+        L.scaledPatchSize = (int)(PATCH_SIZE * scale[l]);
+        L.nDesired = nFeat[l];
+        L.tiles_x = uh_div_up(L.w, 64);
+        L.tiles_y = uh_div_up(L.h, 16);
+        L.tile_begin = tile_begin;
+        tile_begin += L.tiles_x * L.tiles_y;
+        L.xtap_off = (int)xofs.size();
+        L.ytap_off = (int)yofs.size();
+        if (l > 0) {
+            cubic_taps(P.lv[l - 1].w, L.w, xofs, xcoef);
+            cubic_taps(P.lv[l - 1].h, L.h, yofs, ycoef);
+        }
+        // cell grid
+        const int levelCols = (int)std::sqrt((float)L.nDesired / (5 * imageRatio));
+        const int levelRows = (int)(imageRatio * levelCols);
+        L.cell_begin = cell_begin;
+        L.nCells = 0;
+        L.cellCap = 1;
+        L.nfeaturesCell = 0;
+        if (levelCols > 0 && levelRows > 0) {
+            const int minB = EDGE, maxBX = L.w - EDGE, maxBY = L.h - EDGE;
+            const int W = maxBX - minB, H = maxBY - minB;
+            const int cellW = (int)std::ceil((float)W / levelCols);
+            const int cellH = (int)std::ceil((float)H / levelRows);
+            const int nCells = levelRows * levelCols;
+            UH_REQUIRE(nCells <= kMaxCellsPerLevel, "orb: level %d needs %d cells (> %d)", l, nCells, kMaxCellsPerLevel);
+            L.nCells = nCells;
+            L.nfeaturesCell = (int)std::ceil((float)L.nDesired / nCells);
+            std::vector<int> iniXCol(levelCols);
+            float hY = cellH + 6;
+            int cap = 1;
+            for (int i = 0; i < levelRows; i++) {
+                const float iniY = minB + i * cellH - 3;
+                bool rowSkipped = false;
+                if (i == levelRows - 1) { hY = maxBY + 3 - iniY; if (hY <= 0) rowSkipped = true; }
+                float hX = cellW + 6;
+                for (int j = 0; j < levelCols; j++) {
+                    CellDesc C{0, 0, 0, 0, 0};
+                    float iniX;
+                    if (i == 0) { iniX = minB + j * cellW - 3; iniXCol[j] = (int)iniX; } else iniX = iniXCol[j];
+                    bool skipped = rowSkipped;
+                    if (!skipped && j == levelCols - 1) { hX = maxBX + 3 - iniX; if (hX <= 0) skipped = true; }
+                    if (skipped) C.skipped = 1;
+                    else {
+                        const int y0 = (int)iniY, y1 = (int)(iniY + hY), x0 = (int)iniX, x1 = (int)(iniX + hX);
+                        // a cell sub-image that leaves the level makes the reference's cv::Mat::rowRange/colRange throw
+                        UH_REQUIRE(x0 >= 0 && y0 >= 0 && x1 <= L.w && y1 <= L.h,
+                                   "orb: level %d cell (%d,%d) leaves the image (the reference throws cv::Exception here)", l, i, j);
+                        C.x0 = (short)(x0 + 3); C.x1 = (short)std::max(x1 - 3, x0 + 3);
+                        C.y0 = (short)(y0 + 3); C.y1 = (short)std::max(y1 - 3, y0 + 3);
+                        const int iw = C.x1 - C.x0, ih = C.y1 - C.y0;
+                        cap = std::max(cap, ((iw + 1) / 2) * ((ih + 1) / 2));
+                    }
+                    o->cells.push_back(C);
+                }
+            }
+            L.cellCap = cap;
+        }
+        cell_begin += L.nCells;
+        L.cand_off = (int)cand_off;
+        L.work_cap = L.nCells * L.cellCap;
+        cand_off += (size_t)L.work_cap;
+        L.sel_off = (int)sel_off;
+        sel_off += (size_t)std::max(L.nDesired, 1);
+        max_level_need = std::max(max_level_need, L.work_cap);
+    }
+    P.total_tiles = tile_begin;
+    P.total_cells = cell_begin;
+    o->frame_stride = (img_off + 255) & ~(size_t)255;
+    o->cand_stride = cand_off;
+    o->sel_stride = sel_off;
+    o->lds_entries = 12288;   // 48 KiB of dynamic LDS for the selection workspace
+    int rc;
+    UH_HIP_CHECK(hipSetDevice(o->ctx->device));
+    hipStream_t st = o->ctx->stream;
+    auto up = [&](uh::DevBuf& b, const void* src, size_t bytes) -> int {
+        int r = b.reserve(std::max(bytes, (size_t)16));
+        if (r) return r;
+        if (bytes) UH_HIP_CHECK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+        return UH_OK;
+    };
+    if ((rc = up(o->d_plan, &P, sizeof(P)))) return rc;
+    if ((rc = up(o->d_cells, o->cells.data(), o->cells.size() * sizeof(CellDesc)))) return rc;
+    if ((rc = up(o->d_xofs, xofs.data(), xofs.size() * sizeof(int)))) return rc;
+    if ((rc = up(o->d_xcoef, xcoef.data(), xcoef.size() * sizeof(short)))) return rc;
+    if ((rc = up(o->d_yofs, yofs.data(), yofs.size() * sizeof(int)))) return rc;
+    if ((rc = up(o->d_ycoef, ycoef.data(), ycoef.size() * sizeof(short)))) return rc;
+    UH_HIP_CHECK(hipStreamSynchronize(st));   // the host vectors die here
+    if ((rc = o->d_pyr.reserve(o->frame_stride * batch))) return rc;
+    if ((rc = o->d_score.reserve(o->frame_stride * batch))) return rc;
+    if ((rc = o->d_cand.reserve(std::max<size_t>(o->cand_stride, 1) * batch * 4))) return rc;
+    if ((rc = o->d_work.reserve(std::max<size_t>(o->cand_stride, 1) * batch * 8))) return rc;
+    if ((rc = o->d_sel.reserve(std::max<size_t>(o->sel_stride, 1) * batch * 4))) return rc;
+    if ((rc = o->d_cell_counts.reserve(std::max<size_t>(P.total_cells, 1) * batch * 8))) return rc;
+    if ((rc = o->d_level_counts.reserve((size_t)kMaxLevels * batch * 4))) return rc;
+    o->w = w; o->h = h; o->batch = batch;
+    o->planned = true;
+    return UH_OK;
+}
+
+int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, size_t img_frame_stride, int batch,
+               KeyPointOut* d_kps, uint8_t* d_desc, int cap_per_frame, int* d_counts) {
+    int rc;
+    if (!o->planned || o->w != w || o->h != h || o->batch < batch) {
+        if ((rc = make_plan(o, w, h, std::max(batch, o->planned && o->w == w && o->h == h ? o->batch : 0)))) return rc;
+    }
+    UH_HIP_CHECK(hipSetDevice(o->ctx->device));
+    hipStream_t st = o->ctx->stream;
+    const Plan& P = o->plan;
+    const Plan* dP = o->d_plan.as<Plan>();
+    uint8_t* pyr = o->d_pyr.as<uint8_t>();
+    const LevelDesc& L0 = P.lv[0];
+    if (o->blur_first) {
+        hipLaunchKernelGGL(blur7_kernel, dim3(uh_div_up(w, 64), uh_div_up(h, 16), batch), dim3(256), 0, st, d_imgs, w, h, stride,
+                           img_frame_stride, pyr + L0.img_off, L0.pitch, o->frame_stride);
+    } else {
+        hipLaunchKernelGGL(copy_kernel, dim3(uh_div_up(w, 256), h, batch), dim3(256), 0, st, d_imgs, w, h, stride,
+                           img_frame_stride, pyr + L0.img_off, L0.pitch, o->frame_stride);
+    }
+    for (int l = 1; l < P.nlevels; l++) {
+        const LevelDesc& S = P.lv[l - 1];
+        const LevelDesc& D = P.lv[l];
+        hipLaunchKernelGGL(resize_cubic_kernel, dim3(uh_div_up(D.w, 64), uh_div_up(D.h, 4), batch), dim3(256), 0, st,
+                           pyr + S.img_off, S.w, S.h, S.pitch, pyr + D.img_off, D.w, D.h, D.pitch, o->frame_stride,
+                           o->d_xofs.as<int>() + D.xtap_off, o->d_xcoef.as<short>() + (size_t)D.xtap_off * 4,
+                           o->d_yofs.as<int>() + D.ytap_off, o->d_ycoef.as<short>() + (size_t)D.ytap_off * 4);
+    }
+    hipLaunchKernelGGL(fast_score_kernel, dim3(P.total_tiles, batch), dim3(256), 0, st, dP, pyr, o->d_score.as<uint8_t>(),
+                       o->frame_stride);
+    if (P.total_cells > 0) {
+        hipLaunchKernelGGL(cell_nms_kernel, dim3(P.total_cells, batch), dim3(256), 0, st, dP, o->d_cells.as<CellDesc>(),
+                           o->d_score.as<uint8_t>(), o->frame_stride, o->d_cand.as<uint32_t>(), o->cand_stride,
+                           o->d_cell_counts.as<int>());
+    }
+    hipLaunchKernelGGL(select_kernel, dim3(P.nlevels, batch), dim3(256), (size_t)o->lds_entries * 4, st, dP,
+                       o->d_cells.as<CellDesc>(), o->d_cand.as<uint32_t>(), o->cand_stride, o->d_cell_counts.as<int>(),
+                       o->d_work.as<uint32_t>(), o->cand_stride * 2, o->d_sel.as<uint32_t>(), o->sel_stride,
+                       o->d_level_counts.as<int>(), o->lds_entries);
+    const int slots = std::min(std::max(P.maxFeatures, 1), std::max(cap_per_frame, 1));
+    hipLaunchKernelGGL(describe_kernel, dim3(uh_div_up(slots, 4), batch), dim3(256), 0, st, dP, pyr, o->frame_stride,
+                       o->d_sel.as<uint32_t>(), o->sel_stride, o->d_level_counts.as<int>(), d_kps, d_desc, cap_per_frame,
+                       d_counts);
+    UH_HIP_CHECK(hipGetLastError());
+    return UH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uh_orb_create(uh_ctx* ctx, uh_orb** out) {
+    UH_REQUIRE(ctx && out, "uh_orb_create: NULL argument");
+    uh_orb* o = new uh_orb();
+    o->ctx = ctx;
+    *out = o;
+    return UH_OK;
+}
+
+void uh_orb_destroy(uh_orb* o) { delete o; }
+
+int uh_orb_set_params(uh_orb* o, const uh_feat_params* fp) {
+    UH_REQUIRE(o && fp, "uh_orb_set_params: NULL argument");
+    // Feature2DSerializable::FeatParams::operator== ignores sensitivity (feature2dserializable.h:48)
+    const bool same = o->planned && o->fp.nthreads == fp->nthreads && o->fp.maxFeatures == fp->maxFeatures &&
+                      o->fp.nOctaveLevels == fp->nOctaveLevels && o->fp.scaleFactor == fp->scaleFactor;
+    o->fp = *fp;
+    if (!same) { o->planned = false; o->iniTh = 20; o->minTh = 7; }   // precalculateParams (:478-479)
+    return UH_OK;
+}
+
+int uh_orb_get_params(const uh_orb* o, uh_feat_params* fp) {
+    UH_REQUIRE(o && fp, "uh_orb_get_params: NULL argument");
+    *fp = o->fp;
+    return UH_OK;
+}
+
+int uh_orb_set_blur(uh_orb* o, int do_blur) {
+    UH_REQUIRE(o, "uh_orb_set_blur: NULL");
+    o->blur_first = do_blur != 0;
+    return UH_OK;
+}
+
+// ORBextractor::setSensitivity (:457-466)
+int uh_orb_set_sensitivity(uh_orb* o, float v) {
+    UH_REQUIRE(o, "uh_orb_set_sensitivity: NULL");
+    if (v > 1) v = 1;
+    if (v <= 0) v = 0;
+    o->fp.sensitivity = v;
+    v = 1 - v;
+    o->iniTh = (int)(v * 10 + 10);
+    o->minTh = (int)(v * 4 + 3);
+    o->planned = false;
+    return UH_OK;
+}
+
+int uh_orb_max_keypoints(const uh_orb* o) { return o ? std::max(o->fp.maxFeatures, 0) : 0; }
+
+int uh_orb_extract_dev(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, size_t frame_stride, int batch,
+                       uh_keypoint* d_kps, uint8_t* d_desc, int cap_per_frame, int32_t* d_counts) {
+    UH_REQUIRE(o, "uh_orb_extract_dev: NULL extractor");
+    UH_REQUIRE(batch >= 1, "uh_orb_extract_dev: batch < 1");
+    UH_REQUIRE(d_imgs && d_kps && d_desc && d_counts, "uh_orb_extract_dev: NULL buffer");
+    UH_REQUIRE(stride >= (size_t)w && cap_per_frame >= 1, "uh_orb_extract_dev: bad stride/capacity");
+    return run_frames(o, d_imgs, w, h, stride, frame_stride, batch, reinterpret_cast<KeyPointOut*>(d_kps), d_desc,
+                      cap_per_frame, d_counts);
+}
+
+int uh_orb_extract(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, uh_keypoint* kps, uint8_t* desc, int cap,
+                   int* n_out) {
+    UH_REQUIRE(o && n_out, "uh_orb_extract: NULL argument");
+    *n_out = 0;
+    if (img == nullptr || w <= 0 || h <= 0) return UH_OK;   // ORBextractor.cpp:1254 — empty image: silent return
+    UH_REQUIRE(stride >= (size_t)w, "uh_orb_extract: stride < width");
+    const int maxk = std::max(o->fp.maxFeatures, 1);
+    int rc;
+    UH_HIP_CHECK(hipSetDevice(o->ctx->device));
+    hipStream_t st = o->ctx->stream;
+    if ((rc = o->d_in.reserve((size_t)w * h))) return rc;
+    if ((rc = o->d_kps.reserve((size_t)maxk * sizeof(uh_keypoint)))) return rc;
+    if ((rc = o->d_desc.reserve((size_t)maxk * 32))) return rc;
+    if ((rc = o->d_counts.reserve(16))) return rc;
+    UH_HIP_CHECK(hipMemcpy2DAsync(o->d_in.p, w, img, stride, w, h, hipMemcpyHostToDevice, st));
+    rc = run_frames(o, o->d_in.as<uint8_t>(), w, h, w, (size_t)w * h, 1, o->d_kps.as<KeyPointOut>(), o->d_desc.as<uint8_t>(), maxk,
+                    o->d_counts.as<int>());
+    if (rc) return rc;
+    int n = 0;
+    UH_HIP_CHECK(hipMemcpyAsync(&n, o->d_counts.p, 4, hipMemcpyDeviceToHost, st));
+    UH_HIP_CHECK(hipStreamSynchronize(st));
+    *n_out = n;
+    if (n > cap) { uh::set_error("uh_orb_extract: %d keypoints but capacity %d", n, cap); return UH_ECAPACITY; }
+    if (n > 0) {
+        UH_REQUIRE(kps && desc, "uh_orb_extract: NULL output buffer");
+        UH_HIP_CHECK(hipMemcpyAsync(kps, o->d_kps.p, (size_t)n * sizeof(uh_keypoint), hipMemcpyDeviceToHost, st));
+        UH_HIP_CHECK(hipMemcpyAsync(desc, o->d_desc.p, (size_t)n * 32, hipMemcpyDeviceToHost, st));
+        UH_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    return UH_OK;
+}
+
+// Debug/verification taps (tests compare every stage with the oracle): copies one level of one frame's pyramid or
+// score map to the host.  which: 0 = pyramid, 1 = FAST strength map.
+int uh_orb_debug_level(uh_orb* o, int frame, int level, int which, uint8_t* out, int* w_out, int* h_out) {
+    UH_REQUIRE(o && o->planned, "uh_orb_debug_level: extractor has not run yet");
+    UH_REQUIRE(frame >= 0 && frame < o->batch && level >= 0 && level < o->plan.nlevels, "uh_orb_debug_level: bad frame/level");
+    const LevelDesc& L = o->plan.lv[level];
+    if (w_out) *w_out = L.w;
+    if (h_out) *h_out = L.h;
+    if (!out) return UH_OK;
+    const uint8_t* base = (which ? o->d_score.as<uint8_t>() : o->d_pyr.as<uint8_t>()) + (size_t)frame * o->frame_stride + L.img_off;
+    UH_HIP_CHECK(hipMemcpy2DAsync(out, L.w, base, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, o->ctx->stream));
+    UH_HIP_CHECK(hipStreamSynchronize(o->ctx->stream));
+    return UH_OK;
+}
+
+}  // extern "C"

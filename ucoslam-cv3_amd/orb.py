@@ -1,0 +1,138 @@
+"""Host-side mirror of the reference extractor plugin on top of the C ABI.
+
+Reference surface: `Feature2DSerializable` (src/featureextractors/feature2dserializable.h:30-95):
+`create(DescriptorTypes::DESC_ORB)`, `detectAndCompute(image, mask, keypoints, descriptors, FeatParams)`,
+`getParams`, `getMinDescDistance` (ORB: 50, ORBextractor.h:105), `setSensitivity`, `toStream/fromStream`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+
+import numpy as np
+
+from . import _lib
+from ._lib import I, SZ, VP, check, dev_ptr, lib, np_ptr
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                           ("octave", "<i4"), ("class_id", "<i4")])
+assert KEYPOINT_DTYPE.itemsize == 28
+
+
+class FeatParams(C.Structure):
+    """Feature2DSerializable::FeatParams (feature2dserializable.h:34-60), same defaults."""
+    _fields_ = [("nthreads", C.c_int32), ("maxFeatures", C.c_int32), ("nOctaveLevels", C.c_int32),
+                ("scaleFactor", C.c_float), ("sensitivity", C.c_float)]
+
+    def __init__(self, maxFeatures=4000, nOctaveLevels=8, scaleFactor=1.2, nthreads=-1, sensitivity=0.0):
+        super().__init__(nthreads, maxFeatures, nOctaveLevels, scaleFactor, sensitivity)
+
+
+def _declare(L, sig):
+    sig("uh_orb_create", I, VP, C.POINTER(VP))
+    sig("uh_orb_destroy", None, VP)
+    sig("uh_orb_set_params", I, VP, C.POINTER(FeatParams))
+    sig("uh_orb_get_params", I, VP, C.POINTER(FeatParams))
+    sig("uh_orb_set_blur", I, VP, I)
+    sig("uh_orb_set_sensitivity", I, VP, C.c_float)
+    sig("uh_orb_max_keypoints", I, VP)
+    sig("uh_orb_extract", I, VP, VP, I, I, SZ, VP, VP, I, C.POINTER(I))
+    sig("uh_orb_extract_dev", I, VP, VP, I, I, SZ, SZ, I, VP, VP, I, VP)
+    sig("uh_orb_debug_level", I, VP, I, I, I, VP, C.POINTER(I), C.POINTER(I))
+
+
+_lib._EXTRA_DECLS.append(_declare)
+
+
+class ORBextractor:
+    """GPU ORB extractor with the reference's Feature2DSerializable surface."""
+
+    F2D_ORB = 0                       # Feature2DSerializable::F2S_Type
+    STREAM_SIG = 1828374733           # feature2dserializable.cpp:78
+
+    def __init__(self, ctx: _lib.Context):
+        self.ctx = ctx
+        self._h = VP()
+        check(lib().uh_orb_create(ctx.handle, C.byref(self._h)))
+
+    @staticmethod
+    def create(ctx: _lib.Context, desc_type: str = "orb") -> "ORBextractor":
+        if desc_type != "orb":
+            raise RuntimeError("Invalid input descriptor")          # feature2dserializable.cpp:71
+        return ORBextractor(ctx)
+
+    def getMinDescDistance(self) -> float:
+        return 50.0
+
+    def getParams(self) -> FeatParams:
+        fp = FeatParams()
+        check(lib().uh_orb_get_params(self._h, C.byref(fp)))
+        return fp
+
+    def setSensitivity(self, v: float):
+        check(lib().uh_orb_set_sensitivity(self._h, float(v)))
+
+    def doGaussianBlur(self, flag: bool):
+        check(lib().uh_orb_set_blur(self._h, int(flag)))
+
+    # detectAndCompute(image, mask, keypoints, descriptors, params): mask is ignored (ORBextractor.cpp:1253)
+    def detectAndCompute(self, image, mask=None, params: FeatParams | None = None):
+        if params is not None:
+            check(lib().uh_orb_set_params(self._h, C.byref(params)))
+        img = np.asarray(image)
+        if img.size == 0:
+            return np.zeros(0, KEYPOINT_DTYPE), np.zeros((0, 32), np.uint8)
+        if img.dtype != np.uint8 or img.ndim != 2:
+            raise _lib.UcoslamHipError(_lib.UH_EINVAL, "image must be CV_8UC1 (2-D uint8)")   # assert at :1268
+        if img.strides[1] != 1:
+            img = np.ascontiguousarray(img)
+        cap = max(lib().uh_orb_max_keypoints(self._h), 1)
+        kps = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        check(lib().uh_orb_extract(self._h, np_ptr(img), img.shape[1], img.shape[0], img.strides[0], np_ptr(kps), np_ptr(desc),
+                                   cap, C.byref(n)))
+        return kps[: n.value].copy(), desc[: n.value].copy()
+
+    def extract_batch(self, frames, params: FeatParams | None = None, out=None):
+        """frames: torch uint8 CUDA tensor [B,H,W] (resident in HBM). Returns (kps [B,cap,7] f32 view, desc [B,cap,32], counts [B])."""
+        import torch
+
+        if params is not None:
+            check(lib().uh_orb_set_params(self._h, C.byref(params)))
+        assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 3
+        frames = frames.contiguous()
+        B, H, W = frames.shape
+        cap = max(lib().uh_orb_max_keypoints(self._h), 1)
+        if out is None:
+            kps = torch.empty((B, cap, 7), dtype=torch.float32, device=frames.device)
+            desc = torch.empty((B, cap, 32), dtype=torch.uint8, device=frames.device)
+            counts = torch.empty((B,), dtype=torch.int32, device=frames.device)
+        else:
+            kps, desc, counts = out
+        check(lib().uh_orb_extract_dev(self._h, dev_ptr(frames), W, H, W, W * H, B, dev_ptr(kps), dev_ptr(desc), cap, dev_ptr(counts)))
+        return kps, desc, counts
+
+    def debug_level(self, frame: int, level: int, which: int = 0):
+        w, h = C.c_int(0), C.c_int(0)
+        check(lib().uh_orb_debug_level(self._h, frame, level, which, None, C.byref(w), C.byref(h)))
+        out = np.empty((h.value, w.value), np.uint8)
+        check(lib().uh_orb_debug_level(self._h, frame, level, which, np_ptr(out), C.byref(w), C.byref(h)))
+        return out
+
+    # Feature2DSerializable::toStream (feature2dserializable.cpp:76-84) + ORBextractor::toStream_impl (:417-419)
+    def toStream(self, str_params: str = "") -> bytes:
+        fp = self.getParams()
+        sp = str_params.encode()
+        return (struct.pack("<QQ", self.STREAM_SIG, self.F2D_ORB) + struct.pack("<Q", len(sp)) + sp + bytes(fp))
+
+    def close(self):
+        if self._h:
+            lib().uh_orb_destroy(self._h)
+            self._h = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
