@@ -143,6 +143,55 @@ int uh_orb_extract_dev(uh_orb* orb, const uint8_t* d_imgs, int w, int h, size_t 
  * (w*h bytes, may be NULL to query the size). */
 int uh_orb_debug_level(uh_orb* orb, int frame, int level, int which, uint8_t* out, int* w_out, int* h_out);
 
+/* ------------------------------------------------------------------------
+ * Bundle adjustment — replaces GlobalOptimizerG2O behind the GlobalOptimizer plugin:
+ *   src/optimization/globaloptimizer.h:28-68       setParams / optimize(bool* stopASAP) / getResults
+ *   src/optimization/globaloptimizer_g2o.cpp:77-401 (graph build), :418-464 (two-pass LM), :466-537 (results)
+ *   3rdparty/g2o: Levenberg + BlockSolver_6_3 (Schur) + LinearSolverEigen (LDLT) + Huber
+ * The caller flattens the map exactly as setParams does (INTEGRATION.md shows the adaptor):
+ *   frames  : pose_f2g as the reference stores it (row-major 4x4 float, cv::Mat CV_32F), fixed flag
+ *             (FIXED_WITHPOINTS / FIXED_WITHOUTPOINTS both = 1), intrinsics fx fy cx cy
+ *   points  : float xyz (MapPoint::getCoordinates)
+ *   obs     : one monocular EdgeSE3ProjectXYZ per (point, frame): undistorted keypoint (float x,y) and
+ *             information scalar 1/scaleFactor[octave] (globaloptimizer_g2o.cpp:96-97,244)
+ * Arithmetic is fp64 like g2o; poses agree with the reference within 1e-6 (se3 state), see DESIGN.md.
+ * Limits this round: monocular edges only, <= 64 non-fixed frames.
+ * ------------------------------------------------------------------------ */
+typedef struct uh_ba uh_ba;
+
+typedef struct uh_ba_problem {
+    int32_t n_frames, n_points, n_obs;
+    const float*   poses_f2g;       /* n_frames x 16 */
+    const uint8_t* fixed;           /* n_frames */
+    const float*   intr;            /* n_frames x 4: fx fy cx cy */
+    const float*   points;          /* n_points x 3 */
+    const int32_t* obs_point;       /* n_obs */
+    const int32_t* obs_frame;       /* n_obs */
+    const float*   obs_uv;          /* n_obs x 2 */
+    const double*  obs_inv_sigma;   /* n_obs */
+} uh_ba_problem;
+
+typedef struct uh_ba_params {
+    int32_t n_iters;                /* ParamSet::nIters: pass 1 runs n_iters, pass 2 runs 2*n_iters (local BA: 5) */
+    double  huber_delta;            /* <= 0 -> sqrt(5.99) */
+    double  chi2_threshold;         /* <= 0 -> 5.99 */
+    float   min_chi2_between_iter;  /* SparseOptimizer::optimize(iters, minChi2BetweenIter): 1 from BA */
+} uh_ba_params;
+
+int  uh_ba_create(uh_ctx* ctx, uh_ba** out);
+void uh_ba_destroy(uh_ba* ba);
+/* = setParams: snapshots the problem into HBM; the caller's arrays may change afterwards. params may be NULL. */
+int  uh_ba_set_problem(uh_ba* ba, const uh_ba_problem* problem, const uh_ba_params* params);
+/* = optimize(bool* stopASAP): runs both passes from the snapshot; *stop_asap (may be NULL) is polled while waiting. */
+int  uh_ba_optimize(uh_ba* ba, const volatile uint8_t* stop_asap);
+/* pinned device-visible force-stop byte owned by the optimiser (write 1 from any thread to stop between trials) */
+uint8_t* uh_ba_stop_flag(uh_ba* ba);
+/* = getResults: poses n_frames x 16 float (fixed frames returned unchanged), points n_points x 3 float, per-observation
+ * chi2 (as last evaluated by the optimiser) and bad-association flag (chi2 > 5.99 or point behind the camera);
+ * iters_out[2] = outer iterations executed in pass 1 / pass 2.  Any output pointer may be NULL. */
+int  uh_ba_get_results(uh_ba* ba, float* poses_out, float* points_out, double* chi2_out, uint8_t* bad_out, int32_t* iters_out);
+int  uh_ba_get_pose_state(uh_ba* ba, double* pose7_out);   /* n_frames x (qx qy qz qw tx ty tz), fp64 */
+
 #ifdef __cplusplus
 }
 #endif

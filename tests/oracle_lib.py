@@ -97,3 +97,27 @@ def fast_detect(L, img, threshold):
     L.oracle_fast_detect.argtypes = [VP, I, I, I, I, VP, I]
     n = L.oracle_fast_detect(P(img), img.shape[1], img.shape[0], img.strides[0], threshold, P(xys), cap)
     return xys[:n].copy()
+
+
+# ------------------------------------------------------------------------------------------------ BA
+def _ba_call(fn, pr, nIters, with_stop):
+    K, Pn, E = pr["K"], pr["P"], pr["E"]
+    out = dict(poses=_np.zeros((K, 16), _np.float32), points=_np.zeros((Pn, 3), _np.float32), chi2=_np.zeros(E, _np.float64),
+               bad=_np.zeros(E, _np.uint8), iters=_np.zeros(2, _np.int32), state=_np.zeros((K, 7), _np.float64))
+    args = [K, Pn, E, P(pr["poses"]), P(pr["fixed"]), P(pr["intr"]), P(pr["points"]), P(pr["obs_pt"]), P(pr["obs_kf"]),
+            P(pr["obs_uv"]), P(pr["obs_w"]), nIters]
+    if with_stop:
+        args.append(None)
+    args += [P(out["poses"]), P(out["points"]), P(out["chi2"]), P(out["bad"]), P(out["iters"]), P(out["state"])]
+    fn.restype = I
+    rc = fn(*args)
+    assert rc == 0
+    return out
+
+
+def ba_optimize(L, pr, nIters=5):
+    return _ba_call(L.oracle_ba_optimize, pr, nIters, True)
+
+
+def ba_optimize_ref(R, pr, nIters=5):
+    return _ba_call(R.g2o_ref_ba_optimize, pr, nIters, False)

@@ -67,3 +67,71 @@ def frame(w=1241, h=376, seed=0, nshapes=3000, shift=(0, 0)):
     out = img[oy:oy + h, ox:ox + w]
     noise = np.random.default_rng(seed).normal(0, 3, out.shape).astype(np.float32)
     return np.clip(np.rint(out + noise), 0, 255).astype(np.uint8)
+
+
+def _se3_exp(d):
+    w, u = np.asarray(d[:3], float), np.asarray(d[3:], float)
+    th = np.linalg.norm(w)
+    O = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-5:
+        R = np.eye(3) + O + 0.5 * O @ O
+        V = np.eye(3) + 0.5 * O + O @ O / 6
+    else:
+        R = np.eye(3) + np.sin(th) / th * O + (1 - np.cos(th)) / th**2 * O @ O
+        V = np.eye(3) + (1 - np.cos(th)) / th**2 * O + (th - np.sin(th)) / th**3 * O @ O
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = V @ u
+    return T
+
+
+def ba_problem(K=10, P=3000, seed=0, nfixed=2, outlier_frac=0.02, pose_noise=0.01, point_noise=0.05, pix_noise=0.5,
+               w=1241, h=376):
+    """Synthetic local BA: K keyframes on a line (baseline 0.3 m), KITTI intrinsics, P points in front,
+    observations where in-frame, octave uniform 0..7 -> information 1.2^-octave, first `nfixed` keyframes fixed."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 718.856
+    cx, cy = 607.19, 185.22
+    Tgt = []
+    for k in range(K):
+        T = np.eye(4)
+        T[:3, 3] = -np.array([0.3 * k, 0.02 * np.sin(k), 0.0])
+        Tgt.append(_se3_exp(np.r_[0.0, 0.02 * np.sin(0.7 * k), 0.0, 0, 0, 0]) @ T)
+    z = rng.uniform(4, 40, P)
+    X = np.stack([(rng.uniform(0, w, P) - cx) / fx * z + 0.3 * K / 2, (rng.uniform(0, h, P) - cy) / fy * z, z], 1)
+    obs_pt, obs_kf, obs_uv, obs_w = [], [], [], []
+    for p in range(P):
+        for k in range(K):
+            pc = Tgt[k][:3, :3] @ X[p] + Tgt[k][:3, 3]
+            if pc[2] <= 0.5:
+                continue
+            u, v = fx * pc[0] / pc[2] + cx, fy * pc[1] / pc[2] + cy
+            if 0 <= u < w and 0 <= v < h and rng.random() < 0.9:
+                octave = int(rng.integers(0, 8))
+                noise = rng.normal(0, pix_noise, 2)
+                if rng.random() < outlier_frac:
+                    noise += rng.normal(0, 25, 2)
+                obs_pt.append(p); obs_kf.append(k); obs_uv.append([u + noise[0], v + noise[1]]); obs_w.append(1.0 / (1.2 ** octave))
+    poses = []
+    fixed = np.zeros(K, np.uint8)
+    fixed[:nfixed] = 1
+    for k in range(K):
+        T = Tgt[k] if fixed[k] else _se3_exp(rng.normal(0, pose_noise, 6)) @ Tgt[k]
+        poses.append(T.astype(np.float32))
+    # points need >= 2 observations (globaloptimizer_g2o.cpp:140); drop the others
+    obs_pt = np.array(obs_pt, np.int32)
+    cnt = np.bincount(obs_pt, minlength=P)
+    keep_pt = cnt >= 2
+    remap = -np.ones(P, np.int32)
+    remap[keep_pt] = np.arange(keep_pt.sum(), dtype=np.int32)
+    sel = keep_pt[obs_pt]
+    Xn = (X + rng.normal(0, point_noise, X.shape))[keep_pt]
+    return dict(
+        K=K, P=int(keep_pt.sum()), E=int(sel.sum()),
+        poses=np.ascontiguousarray(np.stack(poses).reshape(K, 16)), fixed=fixed,
+        intr=np.tile(np.array([fx, fy, cx, cy], np.float32), (K, 1)),
+        points=np.ascontiguousarray(Xn.astype(np.float32)),
+        obs_pt=np.ascontiguousarray(remap[obs_pt[sel]]), obs_kf=np.ascontiguousarray(np.array(obs_kf, np.int32)[sel]),
+        obs_uv=np.ascontiguousarray(np.array(obs_uv, np.float32)[sel]), obs_w=np.ascontiguousarray(np.array(obs_w, np.float64)[sel]),
+        poses_gt=np.stack(Tgt),
+    )

@@ -1,0 +1,113 @@
+"""Bundle adjustment: oracle vs real g2o (CPU), HIP vs oracle (gpu). Tolerances are stated in each assert."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import synth
+
+# fp64 everywhere; the only differences are summation order. Stated tolerance (BASELINE north_star "within a stated float
+# tolerance"): final se3 pose state (unit quaternion + translation) within 1e-6 absolute; observed ~1e-12.
+POSE_TOL = 1e-6
+
+
+def _se3_rmse(a, b):
+    return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+def test_oracle_matches_real_g2o(oracle):
+    ref = oracle_lib.load_ref("g2o")
+    if ref is None:
+        pytest.skip("oracle/_ref/libg2o_ref.so not built (reference tree absent on this box)")
+    for K, P, seed, nfix in [(10, 3000, 0, 2), (6, 400, 1, 1), (4, 150, 2, 2), (10, 800, 3, 2)]:
+        pr = synth.ba_problem(K, P, seed, nfixed=nfix)
+        a = oracle_lib.ba_optimize(oracle, pr, 5)
+        b = oracle_lib.ba_optimize_ref(ref, pr, 5)
+        assert a["iters"].tolist() == b["iters"].tolist()
+        assert np.abs(a["state"] - b["state"]).max() < 1e-9
+        assert np.abs(a["points"] - b["points"]).max() < 1e-5
+        assert np.abs(a["chi2"] - b["chi2"]).max() < 1e-6 * (1 + np.abs(b["chi2"]).max())
+        assert (a["bad"] == b["bad"]).mean() > 0.9999
+        # and the optimisation did its job
+        gt = pr["poses_gt"][:, :3, 3]
+        err0 = np.abs(pr["poses"].reshape(-1, 4, 4)[:, :3, 3] - gt).max()
+        err1 = np.abs(a["poses"].reshape(-1, 4, 4)[:, :3, 3] - gt).max()
+        assert err1 < 0.35 * err0
+
+
+def test_oracle_golden_from_real_g2o(oracle):
+    """Committed fixture generated from the real g2o (tests/golden/make_ba_golden.py): runs without /root/reference."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ba_golden.npz"))
+    pr = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    pr["K"], pr["P"], pr["E"] = len(pr["fixed"]), len(pr["points"]), len(pr["obs_pt"])
+    a = oracle_lib.ba_optimize(oracle, pr, 5)
+    assert a["iters"].tolist() == g["ref_iters"].tolist()
+    assert np.abs(a["state"] - g["ref_state"]).max() < 1e-9
+    np.testing.assert_array_equal(a["bad"], g["ref_bad"])
+    assert np.abs(a["points"] - g["ref_points"]).max() < 1e-5
+
+
+def test_oracle_edge_jacobian_finite_differences(oracle):
+    """The analytic Jacobians (typesg2o.h:275-314) against central differences of the error, via one LM-free evaluation:
+    a single Gauss-Newton-like probe is not exposed, so check convergence order instead — with exact Jacobians LM reaches
+    the noise floor in the iteration budget from a 10x larger perturbation."""
+    pr = synth.ba_problem(6, 300, 7, pose_noise=0.03, point_noise=0.15, outlier_frac=0.0)
+    a = oracle_lib.ba_optimize(oracle, pr, 10)
+    gt = pr["poses_gt"][:, :3, 3]
+    assert np.abs(a["poses"].reshape(-1, 4, 4)[:, :3, 3] - gt).max() < 0.02
+    assert a["bad"].mean() < 0.02
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(10, 3000, 0, 2), (6, 400, 1, 1), (4, 150, 2, 2), (12, 1500, 3, 3), (3, 60, 4, 3)],
+                         ids=lambda c: f"K{c[0]}_P{c[1]}_fix{c[3]}")
+def test_hip_ba_matches_oracle(hip_ctx, oracle, cfg):
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    K, P, seed, nfix = cfg
+    pr = synth.ba_problem(K, P, seed, nfixed=nfix)
+    opt = GlobalOptimizer.create(hip_ctx)
+    opt.setParams(pr, ParamSet(nIters=5))
+    opt.optimize()
+    got = opt.getResults()
+    ref = oracle_lib.ba_optimize(oracle, pr, 5)
+    assert got["iters"].tolist() == ref["iters"].tolist()
+    assert np.abs(got["state"] - ref["state"]).max() < POSE_TOL, np.abs(got["state"] - ref["state"]).max()
+    assert _se3_rmse(got["state"], ref["state"]) < POSE_TOL
+    assert np.abs(got["poses"] - ref["poses"]).max() < 1e-5          # float32 outputs
+    assert np.abs(got["points"] - ref["points"]).max() < 1e-4
+    assert np.abs(got["chi2"] - ref["chi2"]).max() < 1e-6 * (1 + np.abs(ref["chi2"]).max())
+    assert (got["bad"] == ref["bad"]).mean() > 0.9995
+    # fixed frames come back untouched (getResults skips them)
+    np.testing.assert_array_equal(got["poses"][pr["fixed"] == 1], pr["poses"][pr["fixed"] == 1])
+    # re-running from the same snapshot is deterministic
+    opt.optimize()
+    again = opt.getResults()
+    np.testing.assert_array_equal(again["state"], got["state"])
+    assert len(opt.getBadAssociations()) == int(got["bad"].sum())
+
+
+@pytest.mark.gpu
+def test_hip_ba_stop_flag_and_errors(hip_ctx, oracle):
+    import ucoslam_cv3_amd as u
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    pr = synth.ba_problem(5, 200, 9)
+    opt = GlobalOptimizer.create(hip_ctx)
+    with pytest.raises(u.UcoslamHipError):          # optimize before setParams
+        opt.optimize()
+    opt.setParams(pr, ParamSet(nIters=5))
+    stop = np.ones(1, np.uint8)                      # stopASAP already set: no iteration runs, poses unchanged
+    opt.optimize(stop)
+    got = opt.getResults()
+    assert got["iters"].tolist() == [0, 0]
+    assert np.abs(got["poses"] - pr["poses"]).max() < 1e-6
+    with pytest.raises(RuntimeError):               # globaloptimizer.cpp:27-33
+        GlobalOptimizer.create(hip_ctx, "ceres")
+    bad = dict(pr)
+    bad["obs_kf"] = pr["obs_kf"].copy()
+    bad["obs_kf"][0] = 99
+    with pytest.raises(u.UcoslamHipError):
+        opt.setParams(bad)

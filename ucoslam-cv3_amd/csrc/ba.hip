@@ -1,0 +1,930 @@
+// Levenberg–Marquardt / Schur-complement bundle adjustment on MI355X (gfx950), fp64, behind the C ABI (uh_ba_*).
+//
+// Semantic contract = what GlobalOptimizerG2O does with monocular reprojection edges (reference file:line):
+//   globaloptimizer_g2o.cpp:418-464  optimize(): optimize(nIters,1) -> edges with chi2>5.99 or depth<=0 to level 1, all
+//                                     kernels dropped -> optimize(2*nIters,1)
+//   globaloptimizer_g2o.cpp:466-537  getResults(): float poses/points + bad associations
+//   typesg2o.h:249-323               EdgeSE3ProjectXYZ error/Jacobians;  :51-55,:76-79 oplus
+//   g2o/core/sparse_optimizer.cpp:366-436                outer loop (stop when float chi2 drop <= minChi2BetweenIter)
+//   g2o/core/optimization_algorithm_levenberg.cpp:58-175 LM trial loop, lambda init 1e-5*max|diag|, rho, lambda update
+//   g2o/core/base_binary_edge.hpp:83-150                 Huber-weighted quadratic form (rho'' term dropped)
+//   g2o/core/block_solver.hpp:315-447,525-566            lambda on ALL diagonals, Schur complement, back substitution
+//
+// MI355X design.  The problem is tiny for this chip (~26k edges, 3000 landmarks, <=64 free poses), so the enemy is latency,
+// not bandwidth: the whole LM control flow lives in a device-resident state machine (BAState) and the host only enqueues a
+// fixed sequence of "steps" (one LM trial each) — no host synchronisation inside a pass.  Every kernel starts by reading the
+// state and returns immediately once the pass is done.  One step = 5 launches:
+//   lin     (only after an accepted trial)  per-landmark thread: errors, Huber weights, Hll, bl, per-edge Hpl blocks;
+//                                           per-free-camera workgroup: Hpp, bp (deterministic tree reduction)
+//   schur   one workgroup per (camera i1 <= i2) block of the reduced system: S = Hpp + lambda I - sum_l Hpl D^-1 Hpl^T
+//   solve   one workgroup: dense LDL^T of the <=384x384 reduced system in LDS, pose update T <- exp(dx) T into the trial buffer
+//   backsub per-landmark thread: dx_l = D^-1 (b_l - Hpl^T dx_p), trial point, trial errors, partial chi2 / scale sums
+//   decide  one thread: rho, accept (flip current<->trial buffers) or reject (lambda *= nu), iteration/termination logic
+// All reductions run in a fixed order, so results are run-to-run deterministic.  MFMA is not used: the only dense algebra is
+// 6x3·3x3·3x6 products per landmark pair (fp64) — far below any matrix-core tile; see DESIGN.md.
+#include <cfloat>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kMaxFree = 64;          // free (non-fixed) poses in the reduced system
+constexpr int kThreads = 256;
+
+struct BAState {
+    int phase;        // 0: next step linearises then runs a trial, 1: next step retries a trial (after a reject), 2: pass done
+    int iteration;    // outer iteration index i of SparseOptimizer::optimize
+    int max_iters;
+    int qmax;         // trials done inside the current lm solve
+    int cur;          // which of the two state buffers holds the current estimate
+    int solve_ok;
+    int iters_done;
+    int lin_ran;      // this step linearised (currentChi comes from the lin partial sums)
+    int stopped;      // force-stop flag observed
+    double lambda, ni, currentChi, lastChiRaw, rho;
+    float prevChi2, curChi2, minChi2;
+    int pad;
+};
+
+struct BADims {
+    int K, P, E, nfree, n;   // n = 6*nfree
+    int nPointBlocks;        // ceil(P / kThreads)
+    double delta, dsqr, chi2_th;
+};
+
+struct BAPtrs {
+    // problem (constant during optimize)
+    const int* pt_ptr;        // P+1, CSR of edges per point (edge ids in input order)
+    const int* pt_edges;      // E
+    const int* cam_ptr;       // nfree+1, CSR of edges per free camera
+    const int* cam_edges;     // edges of free cameras
+    const int* e_pt; const int* e_kf;
+    const double* e_uv; const double* e_w;
+    const int* slot;          // K: reduced-system slot or -1
+    const int* free_kf;       // nfree: frame index of slot s
+    const double* intr;       // K x 4
+    const int* edge_of;       // P x nfree: edge id of (point, slot) or -1
+    // state (two buffers each)
+    double* pose[2];          // K x 7 (qx qy qz qw tx ty tz)
+    double* poseR[2];         // K x 12 (R row-major 9, t 3)
+    double* pts[2];           // P x 3
+    unsigned char* e_active; unsigned char* e_robust;
+    double* e_err;            // E x 2
+    double* e_chi2;           // E
+    // system
+    double* Hll; double* bl;  // P x 9, P x 3
+    double* Hpl;              // E x 18 (6x3 row-major)
+    double* Hpp; double* bp;  // nfree x 36, nfree x 6
+    double* S; double* bs;    // n x n (upper blocks written), n
+    double* xp;               // n
+    double* part_lin_chi;     // nPointBlocks
+    double* part_maxdiag;     // nPointBlocks + nfree
+    double* part_chi; double* part_scale;   // nPointBlocks
+    BAState* st;
+    const volatile unsigned char* stop;     // pinned host flag (may be NULL)
+};
+
+// ------------------------------------------------------------------------------------------------ small fp64 helpers
+__device__ __forceinline__ void quat_to_R(const double* q, double* R) {
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+__device__ __forceinline__ void quat_from_R(const double* R, double* q) {   // Eigen::Quaternion(Matrix3)
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[i * 4]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+        q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+        q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+    }
+}
+__device__ __forceinline__ void quat_norm_pos(double* q) {
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+__device__ __forceinline__ void inv3(const double* M, double* I) {
+    const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+    const double id = 1.0 / (M[0] * c00 + M[1] * c01 + M[2] * c02);
+    I[0] = c00 * id; I[1] = (M[2] * M[7] - M[1] * M[8]) * id; I[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+    I[3] = c01 * id; I[4] = (M[0] * M[8] - M[2] * M[6]) * id; I[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+    I[6] = c02 * id; I[7] = (M[1] * M[6] - M[0] * M[7]) * id; I[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+}
+
+// deterministic block sum (fixed tree) of one double per thread; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* s_red) {
+    s_red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = kThreads / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const double r = s_red[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ double block_max(double v, double* s_red) {
+    s_red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = kThreads / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s_red[threadIdx.x] = fmax(s_red[threadIdx.x], s_red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    const double r = s_red[0];
+    __syncthreads();
+    return r;
+}
+
+struct EdgeLin {          // one edge's linearisation at a given state
+    double ex, ey, chi2, rho1, ww, r0, r1;
+    double A[6], B[12];
+    double robchi;
+};
+
+// error + Huber weight (+ Jacobians) of edge e with camera pose (R,t) and point X
+template <bool JAC>
+__device__ __forceinline__ void edge_eval(const BAPtrs& p, const BADims& d, int e, int k, const double* Rt, const double* X,
+                                          bool robust, EdgeLin& o) {
+    const double x = Rt[0] * X[0] + Rt[1] * X[1] + Rt[2] * X[2] + Rt[9];
+    const double y = Rt[3] * X[0] + Rt[4] * X[1] + Rt[5] * X[2] + Rt[10];
+    const double z = Rt[6] * X[0] + Rt[7] * X[1] + Rt[8] * X[2] + Rt[11];
+    const double fx = p.intr[4 * k], fy = p.intr[4 * k + 1], cx = p.intr[4 * k + 2], cy = p.intr[4 * k + 3];
+    o.ex = p.e_uv[2 * e] - ((x / z) * fx + cx);
+    o.ey = p.e_uv[2 * e + 1] - ((y / z) * fy + cy);
+    const double w = p.e_w[e];
+    o.chi2 = w * (o.ex * o.ex + o.ey * o.ey);
+    o.rho1 = 1.0;
+    o.robchi = o.chi2;
+    if (robust && o.chi2 > d.dsqr) {
+        const double sq = sqrt(o.chi2);
+        o.rho1 = d.delta / sq;
+        o.robchi = 2 * sq * d.delta - d.dsqr;
+    }
+    if (JAC) {
+        o.ww = o.rho1 * w;
+        o.r0 = -w * o.ex * o.rho1;
+        o.r1 = -w * o.ey * o.rho1;
+        const double z2 = z * z;
+        const double t02 = -x / z * fx, t12 = -y / z * fy, iz = -1. / z;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            o.A[c] = iz * (fx * Rt[c] + t02 * Rt[6 + c]);
+            o.A[3 + c] = iz * (fy * Rt[3 + c] + t12 * Rt[6 + c]);
+        }
+        o.B[0] = x * y / z2 * fx; o.B[1] = -(1 + (x * x / z2)) * fx; o.B[2] = y / z * fx; o.B[3] = -1. / z * fx; o.B[4] = 0; o.B[5] = x / z2 * fx;
+        o.B[6] = (1 + y * y / z2) * fy; o.B[7] = -x * y / z2 * fy; o.B[8] = -x / z * fy; o.B[9] = 0; o.B[10] = -1. / z * fy; o.B[11] = y / z2 * fy;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ lin
+// grid = nPointBlocks + nfree.  Blocks [0,nPointBlocks): one thread per landmark.  Blocks beyond: one per free camera.
+__global__ __launch_bounds__(kThreads) void ba_lin_kernel(BAPtrs p, BADims d) {
+    __shared__ double s_red[kThreads];
+    const BAState st = *p.st;
+    if (st.phase != 0) return;
+    const int cur = st.cur;
+    const double* poseR = p.poseR[cur];
+    const double* pts = p.pts[cur];
+    if ((int)blockIdx.x < d.nPointBlocks) {
+        const int pt = blockIdx.x * kThreads + threadIdx.x;
+        double chi_part = 0, maxd = 0;
+        if (pt < d.P) {
+            const double X[3] = {pts[3 * pt], pts[3 * pt + 1], pts[3 * pt + 2]};
+            double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+            bool any = false;
+            for (int i = p.pt_ptr[pt]; i < p.pt_ptr[pt + 1]; i++) {
+                const int e = p.pt_edges[i];
+                if (!p.e_active[e]) continue;
+                any = true;
+                const int k = p.e_kf[e];
+                EdgeLin L;
+                edge_eval<true>(p, d, e, k, poseR + 12 * k, X, p.e_robust[e] != 0, L);
+                p.e_err[2 * e] = L.ex; p.e_err[2 * e + 1] = L.ey;
+                p.e_chi2[e] = L.chi2;
+                chi_part += L.robchi;
+                H[0] += L.ww * (L.A[0] * L.A[0] + L.A[3] * L.A[3]); H[1] += L.ww * (L.A[0] * L.A[1] + L.A[3] * L.A[4]);
+                H[2] += L.ww * (L.A[0] * L.A[2] + L.A[3] * L.A[5]); H[3] += L.ww * (L.A[1] * L.A[1] + L.A[4] * L.A[4]);
+                H[4] += L.ww * (L.A[1] * L.A[2] + L.A[4] * L.A[5]); H[5] += L.ww * (L.A[2] * L.A[2] + L.A[5] * L.A[5]);
+                b[0] += L.A[0] * L.r0 + L.A[3] * L.r1; b[1] += L.A[1] * L.r0 + L.A[4] * L.r1; b[2] += L.A[2] * L.r0 + L.A[5] * L.r1;
+                if (p.slot[k] >= 0) {
+                    double* Hx = p.Hpl + 18 * (size_t)e;
+#pragma unroll
+                    for (int a = 0; a < 6; a++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) Hx[a * 3 + c] = L.ww * (L.B[a] * L.A[c] + L.B[6 + a] * L.A[3 + c]);
+                }
+            }
+            double* Hl = p.Hll + 9 * (size_t)pt;
+            Hl[0] = H[0]; Hl[1] = H[1]; Hl[2] = H[2]; Hl[3] = H[1]; Hl[4] = H[3]; Hl[5] = H[4]; Hl[6] = H[2]; Hl[7] = H[4]; Hl[8] = H[5];
+            p.bl[3 * pt] = b[0]; p.bl[3 * pt + 1] = b[1]; p.bl[3 * pt + 2] = b[2];
+            if (any) maxd = fmax(fabs(H[0]), fmax(fabs(H[3]), fabs(H[5])));
+        }
+        const double cs = block_sum(chi_part, s_red);
+        const double mx = block_max(maxd, s_red);
+        if (threadIdx.x == 0) { p.part_lin_chi[blockIdx.x] = cs; p.part_maxdiag[blockIdx.x] = mx; }
+    } else {
+        const int s = blockIdx.x - d.nPointBlocks;
+        const int k = p.free_kf[s];
+        double Rt[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) Rt[i] = poseR[12 * k + i];
+        double acc[27];
+#pragma unroll
+        for (int i = 0; i < 27; i++) acc[i] = 0;
+        for (int i = p.cam_ptr[s] + threadIdx.x; i < p.cam_ptr[s + 1]; i += kThreads) {
+            const int e = p.cam_edges[i];
+            if (!p.e_active[e]) continue;
+            const int pt = p.e_pt[e];
+            const double X[3] = {pts[3 * pt], pts[3 * pt + 1], pts[3 * pt + 2]};
+            EdgeLin L;
+            edge_eval<true>(p, d, e, k, Rt, X, p.e_robust[e] != 0, L);
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int c = a; c < 6; c++) acc[q++] += L.ww * (L.B[a] * L.B[c] + L.B[6 + a] * L.B[6 + c]);
+#pragma unroll
+            for (int a = 0; a < 6; a++) acc[21 + a] += L.B[a] * L.r0 + L.B[6 + a] * L.r1;
+        }
+        double red[27];
+#pragma unroll
+        for (int i = 0; i < 27; i++) red[i] = block_sum(acc[i], s_red);
+        if (threadIdx.x == 0) {
+            double* Hp = p.Hpp + 36 * (size_t)s;
+            int q = 0;
+            double mx = 0;
+            for (int a = 0; a < 6; a++)
+                for (int c = a; c < 6; c++) { Hp[a * 6 + c] = red[q]; Hp[c * 6 + a] = red[q]; if (a == c) mx = fmax(mx, fabs(red[q])); q++; }
+            for (int a = 0; a < 6; a++) p.bp[6 * s + a] = red[21 + a];
+            p.part_maxdiag[d.nPointBlocks + s] = mx;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ schur
+// grid = nfree*(nfree+1)/2 pairs (i1 <= i2).  The first pair block also publishes lambda at iteration 0.
+__global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d) {
+    __shared__ double s_red[kThreads];
+    const BAState st = *p.st;
+    if (st.phase == 2) return;
+    double lambda = st.lambda;
+    if (st.iteration == 0 && st.qmax == 0) {   // computeLambdaInit: tau * max |H_jj|
+        double m = 0;
+        for (int i = 0; i < d.nPointBlocks + d.nfree; i++) m = fmax(m, p.part_maxdiag[i]);
+        lambda = 1e-5 * m;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { p.st->lambda = lambda; p.st->ni = 2; }
+    }
+    // pair index -> (s1,s2)
+    int s1 = 0, rem = blockIdx.x;
+    while (rem >= d.nfree - s1) { rem -= d.nfree - s1; ++s1; }
+    const int s2 = s1 + rem;
+    const bool diag = s1 == s2;
+    double acc[36], accb[6];
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) accb[i] = 0;
+    for (int pt = threadIdx.x; pt < d.P; pt += kThreads) {
+        const int e1 = p.edge_of[(size_t)pt * d.nfree + s1];
+        if (e1 < 0 || !p.e_active[e1]) continue;
+        const int e2 = diag ? e1 : p.edge_of[(size_t)pt * d.nfree + s2];
+        if (e2 < 0 || !p.e_active[e2]) continue;
+        double D[9], Di[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) D[i] = p.Hll[9 * (size_t)pt + i];
+        D[0] += lambda; D[4] += lambda; D[8] += lambda;
+        inv3(D, Di);
+        const double* B1 = p.Hpl + 18 * (size_t)e1;
+        const double* B2 = p.Hpl + 18 * (size_t)e2;
+        double b2[18];
+#pragma unroll
+        for (int i = 0; i < 18; i++) b2[i] = B2[i];
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            const double b0 = B1[a * 3], b1 = B1[a * 3 + 1], b2v = B1[a * 3 + 2];
+            const double y0 = b0 * Di[0] + b1 * Di[3] + b2v * Di[6];
+            const double y1 = b0 * Di[1] + b1 * Di[4] + b2v * Di[7];
+            const double y2 = b0 * Di[2] + b1 * Di[5] + b2v * Di[8];
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[a * 6 + c] += y0 * b2[c * 3] + y1 * b2[c * 3 + 1] + y2 * b2[c * 3 + 2];
+            if (diag) {
+                const double l0 = p.bl[3 * pt], l1 = p.bl[3 * pt + 1], l2 = p.bl[3 * pt + 2];
+                accb[a] += y0 * l0 + y1 * l1 + y2 * l2;   // B1 * (Dinv * bl)
+            }
+        }
+    }
+    for (int i = 0; i < 36; i++) {
+        const double r = block_sum(acc[i], s_red);
+        if (threadIdx.x == 0) {
+            const int a = i / 6, c = i % 6;
+            double v = -r;
+            if (diag) v += p.Hpp[36 * (size_t)s1 + i] + (a == c ? lambda : 0.0);
+            p.S[(size_t)(6 * s1 + a) * d.n + 6 * s2 + c] = v;
+        }
+    }
+    if (diag)
+        for (int a = 0; a < 6; a++) {
+            const double r = block_sum(accb[a], s_red);
+            if (threadIdx.x == 0) p.bs[6 * s1 + a] = p.bp[6 * s1 + a] - r;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ solve + pose update
+// One workgroup.  Dense LDL^T (no pivoting; fails on a zero / non-finite pivot like Eigen's SimplicialLDLT) of the reduced
+// system, in LDS when it fits (n <= 128) else in place in HBM.  Then T_trial = exp(dx) * T_cur for the free poses.
+__global__ __launch_bounds__(kThreads) void ba_solve_kernel(BAPtrs p, BADims d, int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) double s_mat[];
+    __shared__ double s_x[6 * kMaxFree];
+    __shared__ double s_d[6 * kMaxFree];
+    __shared__ int s_ok;
+    const BAState st = *p.st;
+    if (st.phase == 2) return;
+    const int n = d.n;
+    double* M = use_lds ? s_mat : p.S;
+    const int tid = threadIdx.x;
+    // symmetric fill: lower <- upper (the schur kernel wrote block rows s1 <= s2 only)
+    for (int i = tid; i < n * n; i += kThreads) {
+        const int r = i / n, c = i - r * n;
+        const int br = r / 6, bc = c / 6;
+        double v;
+        if (br <= bc) v = p.S[(size_t)r * n + c]; else v = p.S[(size_t)c * n + r];
+        if (use_lds) M[i] = v;
+        else if (br > bc) M[i] = v;
+    }
+    if (tid == 0) s_ok = 1;
+    __syncthreads();
+    // right-looking LDL^T: after step j, column j of M below the diagonal holds L(:,j), M[j][j] = d_j
+    for (int j = 0; j < n; j++) {
+        const double dj = M[(size_t)j * n + j];
+        if (dj == 0.0 || !isfinite(dj)) { if (tid == 0) s_ok = 0; break; }   // uniform: every thread reads the same dj
+        for (int i = j + 1 + tid; i < n; i += kThreads) M[(size_t)i * n + j] = M[(size_t)i * n + j] / dj;
+        __syncthreads();
+        const int m = n - j - 1;
+        for (int t = tid; t < m * m; t += kThreads) {
+            const int r = j + 1 + t / m, c = j + 1 + t % m;
+            if (c <= r) M[(size_t)r * n + c] -= M[(size_t)r * n + j] * M[(size_t)c * n + j] * dj;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    const int ok = s_ok;
+    if (ok) {
+        for (int i = tid; i < n; i += kThreads) { s_x[i] = p.bs[i]; s_d[i] = M[(size_t)i * n + i]; }
+        __syncthreads();
+        for (int j = 0; j < n; j++) {            // L y = b (column oriented)
+            const double xj = s_x[j];
+            for (int i = j + 1 + tid; i < n; i += kThreads) s_x[i] -= M[(size_t)i * n + j] * xj;
+            __syncthreads();
+        }
+        for (int i = tid; i < n; i += kThreads) s_x[i] /= s_d[i];
+        __syncthreads();
+        for (int j = n - 1; j >= 0; j--) {       // L^T x = y
+            const double xj = s_x[j];
+            for (int i = tid; i < j; i += kThreads) s_x[i] -= M[(size_t)j * n + i] * xj;
+            __syncthreads();
+        }
+        for (int i = tid; i < n; i += kThreads) p.xp[i] = s_x[i];
+    } else {
+        for (int i = tid; i < n; i += kThreads) { p.xp[i] = 0.0; s_x[i] = 0.0; }
+    }
+    __syncthreads();
+    if (tid == 0) p.st->solve_ok = ok;
+    // pose update into the trial buffer (fixed poses are identical in both buffers and never touched)
+    const int cur = st.cur, trial = cur ^ 1;
+    if (tid < d.nfree) {
+        const int k = p.free_kf[tid];
+        const double* T = p.pose[cur] + 7 * k;
+        double q[4] = {T[0], T[1], T[2], T[3]}, t[3] = {T[4], T[5], T[6]};
+        if (ok) {
+            const double* dx = s_x + 6 * tid;
+            const double w0 = dx[0], w1 = dx[1], w2 = dx[2];
+            const double theta = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+            const double O[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+            double O2[9];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
+            double a, b, c1, c2;
+            if (theta < 0.00001) { a = 1; b = 0.5; c1 = 0.5; c2 = 1.0 / 6.0; }
+            else { a = sin(theta) / theta; b = (1 - cos(theta)) / (theta * theta); c1 = b; c2 = (theta - sin(theta)) / pow(theta, 3.0); }
+            double Rm[9], V[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) { const double I = (i % 4 == 0) ? 1.0 : 0.0; Rm[i] = I + a * O[i] + b * O2[i]; V[i] = I + c1 * O[i] + c2 * O2[i]; }
+            double qe[4];
+            quat_from_R(Rm, qe);
+            quat_norm_pos(qe);
+            double te[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) te[r] = V[r * 3] * dx[3] + V[r * 3 + 1] * dx[4] + V[r * 3 + 2] * dx[5];
+            double RE[9];
+            quat_to_R(qe, RE);
+            double qn[4];
+            qn[3] = qe[3] * q[3] - qe[0] * q[0] - qe[1] * q[1] - qe[2] * q[2];
+            qn[0] = qe[3] * q[0] + qe[0] * q[3] + qe[1] * q[2] - qe[2] * q[1];
+            qn[1] = qe[3] * q[1] + qe[1] * q[3] + qe[2] * q[0] - qe[0] * q[2];
+            qn[2] = qe[3] * q[2] + qe[2] * q[3] + qe[0] * q[1] - qe[1] * q[0];
+            double tn[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) tn[r] = RE[r * 3] * t[0] + RE[r * 3 + 1] * t[1] + RE[r * 3 + 2] * t[2] + te[r];
+            quat_norm_pos(qn);
+#pragma unroll
+            for (int i = 0; i < 4; i++) q[i] = qn[i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) t[i] = tn[i];
+        }
+        double* To = p.pose[trial] + 7 * k;
+        To[0] = q[0]; To[1] = q[1]; To[2] = q[2]; To[3] = q[3]; To[4] = t[0]; To[5] = t[1]; To[6] = t[2];
+        double* Ro = p.poseR[trial] + 12 * k;
+        quat_to_R(q, Ro);
+        Ro[9] = t[0]; Ro[10] = t[1]; Ro[11] = t[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backsub + trial errors
+__global__ __launch_bounds__(kThreads) void ba_backsub_kernel(BAPtrs p, BADims d) {
+    __shared__ double s_red[kThreads];
+    const BAState st = *p.st;
+    if (st.phase == 2) return;
+    const int cur = st.cur, trial = cur ^ 1;
+    const double lambda = st.lambda;
+    const int ok = st.solve_ok;
+    const int pt = blockIdx.x * kThreads + threadIdx.x;
+    double chi_part = 0, scale_part = 0;
+    if (pt < d.P) {
+        double X[3] = {p.pts[cur][3 * pt], p.pts[cur][3 * pt + 1], p.pts[cur][3 * pt + 2]};
+        const int b = p.pt_ptr[pt], e_end = p.pt_ptr[pt + 1];
+        bool any = false;
+        for (int i = b; i < e_end; i++) any = any || p.e_active[p.pt_edges[i]];
+        if (any && ok) {
+            double c[3] = {p.bl[3 * pt], p.bl[3 * pt + 1], p.bl[3 * pt + 2]};
+            for (int i = b; i < e_end; i++) {
+                const int e = p.pt_edges[i];
+                if (!p.e_active[e]) continue;
+                const int s = p.slot[p.e_kf[e]];
+                if (s < 0) continue;
+                const double* B1 = p.Hpl + 18 * (size_t)e;
+                const double* x = p.xp + 6 * s;
+#pragma unroll
+                for (int a = 0; a < 6; a++) { c[0] -= B1[a * 3] * x[a]; c[1] -= B1[a * 3 + 1] * x[a]; c[2] -= B1[a * 3 + 2] * x[a]; }
+            }
+            double D[9], Di[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) D[i] = p.Hll[9 * (size_t)pt + i];
+            D[0] += lambda; D[4] += lambda; D[8] += lambda;
+            inv3(D, Di);
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const double xl = Di[a * 3] * c[0] + Di[a * 3 + 1] * c[1] + Di[a * 3 + 2] * c[2];
+                scale_part += xl * (lambda * xl + p.bl[3 * pt + a]);
+                X[a] += xl;
+            }
+        }
+        p.pts[trial][3 * pt] = X[0]; p.pts[trial][3 * pt + 1] = X[1]; p.pts[trial][3 * pt + 2] = X[2];
+        const double* poseR = p.poseR[trial];
+        for (int i = b; i < e_end; i++) {
+            const int e = p.pt_edges[i];
+            if (!p.e_active[e]) continue;
+            const int k = p.e_kf[e];
+            EdgeLin L;
+            edge_eval<false>(p, d, e, k, poseR + 12 * k, X, p.e_robust[e] != 0, L);
+            p.e_err[2 * e] = L.ex; p.e_err[2 * e + 1] = L.ey;
+            p.e_chi2[e] = L.chi2;
+            chi_part += L.robchi;
+        }
+    }
+    const double cs = block_sum(chi_part, s_red);
+    const double ss = block_sum(scale_part, s_red);
+    if (threadIdx.x == 0) { p.part_chi[blockIdx.x] = cs; p.part_scale[blockIdx.x] = ss; }
+}
+
+// ------------------------------------------------------------------------------------------------ decide
+// One thread: the tail of OptimizationAlgorithmLevenberg::solve's do-while body plus SparseOptimizer::optimize's loop header.
+__global__ void ba_decide_kernel(BAPtrs p, BADims d) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    BAState st = *p.st;
+    if (st.phase == 2) return;
+    if (st.phase == 0) {   // this step linearised: currentChi = activeRobustChi2 at the current state
+        double c = 0;
+        for (int i = 0; i < d.nPointBlocks; i++) c += p.part_lin_chi[i];
+        st.currentChi = c;
+    }
+    double tempChi = 0, scale = 0;
+    for (int i = 0; i < d.nPointBlocks; i++) { tempChi += p.part_chi[i]; scale += p.part_scale[i]; }
+    st.lastChiRaw = tempChi;
+    const double lambda = st.lambda;
+    if (st.solve_ok)
+        for (int i = 0; i < d.n; i++) scale += p.xp[i] * (lambda * p.xp[i] + p.bp[i]);
+    if (!st.solve_ok) tempChi = DBL_MAX;
+    double rho = st.currentChi - tempChi;
+    scale += 1e-3;
+    rho /= scale;
+    bool lambda_finite = true;
+    if (rho > 0 && isfinite(tempChi)) {
+        double alpha = 1. - pow((2 * rho - 1), 3.0);
+        alpha = fmin(alpha, 2. / 3.);
+        const double sf = fmax(1. / 3., alpha);
+        st.lambda *= sf;
+        st.ni = 2;
+        st.currentChi = tempChi;
+        st.cur ^= 1;   // discardTop: the trial buffers become the current estimate
+    } else {
+        st.lambda *= st.ni;
+        st.ni *= 2;    // pop: the current buffers stay
+        if (!isfinite(st.lambda)) lambda_finite = false;
+    }
+    st.rho = rho;
+    const bool stop = p.stop && *p.stop;
+    if (stop) st.stopped = 1;
+    bool again = false;
+    if (lambda_finite) {
+        st.qmax++;
+        again = (rho < 0 && st.qmax < 10 && !stop);
+    }
+    if (again) {
+        st.phase = 1;
+    } else {
+        const bool terminate = (st.qmax == 10 || rho == 0 || !lambda_finite);
+        const bool ok = !terminate;
+        // SparseOptimizer::optimize: curChi2 = activeRobustChi2() of the LAST computed errors; Chi2Diff = prev - cur (float)
+        st.curChi2 = (float)st.lastChiRaw;
+        const float diff = st.prevChi2 - st.curChi2;
+        st.iters_done++;
+        st.iteration++;
+        const bool cont = st.iteration < st.max_iters && !stop && ok && diff > st.minChi2;
+        if (cont) {
+            const float t = st.prevChi2; st.prevChi2 = st.curChi2; st.curChi2 = t;   // swap at the next loop entry
+            st.phase = 0;
+            st.qmax = 0;
+        } else {
+            st.phase = 2;
+        }
+    }
+    *p.st = st;
+}
+
+// ------------------------------------------------------------------------------------------------ between / after passes
+// globaloptimizer_g2o.cpp:434-449: outliers to level 1, every robust kernel removed
+__global__ void ba_relabel_kernel(BAPtrs p, BADims d) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= d.E) return;
+    const int cur = p.st->cur;
+    const int k = p.e_kf[e], pt = p.e_pt[e];
+    const double* Rt = p.poseR[cur] + 12 * k;
+    const double* X = p.pts[cur] + 3 * pt;
+    const double z = Rt[6] * X[0] + Rt[7] * X[1] + Rt[8] * X[2] + Rt[11];
+    if (p.e_chi2[e] > d.chi2_th || !(z > 0.0)) p.e_active[e] = 0;
+    p.e_robust[e] = 0;
+}
+
+__global__ void ba_begin_pass_kernel(BAPtrs p, int max_iters, float minChi2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    BAState& st = *p.st;
+    st.phase = max_iters > 0 ? 0 : 2;
+    st.iteration = 0;
+    st.max_iters = max_iters;
+    st.qmax = 0;
+    st.solve_ok = 1;
+    st.iters_done = 0;
+    st.prevChi2 = FLT_MAX;   // swapped at loop entry: prev = cur = FLT_MAX before the first solve
+    st.curChi2 = FLT_MAX;
+    st.minChi2 = minChi2;
+    if (p.stop && *p.stop) { st.phase = 2; st.stopped = 1; }
+}
+
+// getResults (:466-537): float poses (free frames), float points, bad associations
+__global__ void ba_results_kernel(BAPtrs p, BADims d, const float* __restrict__ poses_in, float* __restrict__ poses_out,
+                                  float* __restrict__ points_out, unsigned char* __restrict__ bad_out, int stage) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cur = p.st->cur;
+    if (stage == 0) {
+        if (i < d.K) {
+            float* M = poses_out + 16 * i;
+            if (p.slot[i] < 0) { for (int j = 0; j < 16; j++) M[j] = poses_in[16 * i + j]; }
+            else {
+                const double* Rt = p.poseR[cur] + 12 * i;
+                for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) M[r * 4 + c] = (float)Rt[r * 3 + c]; M[r * 4 + 3] = (float)Rt[9 + r]; }
+                M[12] = M[13] = M[14] = 0.f; M[15] = 1.f;
+            }
+        }
+        if (i < 3 * d.P) points_out[i] = (float)p.pts[cur][i];
+    } else if (i < d.E) {
+        bool bad = p.e_chi2[i] > d.chi2_th;
+        if (!bad) {
+            const float* M = poses_out + 16 * p.e_kf[i];
+            const float* X = points_out + 3 * p.e_pt[i];
+            const float z = M[8] * X[0] + M[9] * X[1] + M[10] * X[2] + M[11];
+            if (z < 0) bad = true;
+        }
+        bad_out[i] = bad;
+    }
+}
+
+__global__ void ba_init_state_kernel(BAPtrs p, BADims d, const double* __restrict__ pose0, const double* __restrict__ pts0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.K) {
+        double q[4];
+        for (int j = 0; j < 7; j++) { const double v = pose0[7 * i + j]; p.pose[0][7 * i + j] = v; p.pose[1][7 * i + j] = v; if (j < 4) q[j] = v; }
+        double R[9];
+        quat_to_R(q, R);
+        for (int b = 0; b < 2; b++) {
+            for (int j = 0; j < 9; j++) p.poseR[b][12 * i + j] = R[j];
+            for (int j = 0; j < 3; j++) p.poseR[b][12 * i + 9 + j] = pose0[7 * i + 4 + j];
+        }
+    }
+    if (i < 3 * d.P) { p.pts[0][i] = pts0[i]; p.pts[1][i] = pts0[i]; }
+    if (i < d.E) { p.e_active[i] = 1; p.e_robust[i] = 1; p.e_chi2[i] = 0; p.e_err[2 * i] = 0; p.e_err[2 * i + 1] = 0; }
+    if (i == 0) { BAState z; memset(&z, 0, sizeof(z)); z.phase = 2; z.lambda = -1; z.ni = 2; *p.st = z; }
+}
+
+}  // namespace
+
+struct uh_ba {
+    uh_ctx* ctx = nullptr;
+    bool have_problem = false;
+    BADims dims{};
+    BAPtrs ptrs{};
+    uh_ba_params params{5, 0.0, 0.0, 1.0f};
+    std::vector<float> poses_in;          // K x 16 (fixed frames are returned unchanged)
+    std::vector<unsigned char> fixed;
+    uh::DevBuf arena;                     // one allocation for everything on the device
+    uh::DevBuf d_poses_in, d_poses_out, d_points_out, d_bad;
+    double* d_pose0 = nullptr; double* d_pts0 = nullptr;
+    unsigned char* h_stop = nullptr;      // pinned, device-visible force-stop flag
+    int iters[2] = {0, 0};
+    bool optimized = false;
+    ~uh_ba() { if (h_stop) (void)hipHostFree(h_stop); }
+};
+
+namespace {
+
+void quat_from_R_host(const double* R, double* q) {
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = std::sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[i * 4]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+        q[i] = 0.5 * t; t = 0.5 / t;
+        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t; q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t; q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+    }
+    if (q[3] < 0) for (int a = 0; a < 4; a++) q[a] = -q[a];
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int a = 0; a < 4; a++) q[a] /= n;
+}
+
+struct Arena {
+    size_t off = 0;
+    template <typename T> size_t take(size_t count) { off = (off + 255) & ~(size_t)255; size_t o = off; off += count * sizeof(T); return o; }
+};
+
+int enqueue_steps(uh_ba* b, int nsteps) {
+    hipStream_t st = b->ctx->stream;
+    const BADims& d = b->dims;
+    const int npairs = d.nfree * (d.nfree + 1) / 2;
+    const int use_lds = d.n <= 128 ? 1 : 0;
+    const size_t lds = use_lds ? (size_t)d.n * d.n * sizeof(double) : 0;
+    for (int s = 0; s < nsteps; s++) {
+        hipLaunchKernelGGL(ba_lin_kernel, dim3(d.nPointBlocks + d.nfree), dim3(kThreads), 0, st, b->ptrs, d);
+        if (npairs > 0) hipLaunchKernelGGL(ba_schur_kernel, dim3(npairs), dim3(kThreads), 0, st, b->ptrs, d);
+        hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(kThreads), lds, st, b->ptrs, d, use_lds);
+        hipLaunchKernelGGL(ba_backsub_kernel, dim3(d.nPointBlocks), dim3(kThreads), 0, st, b->ptrs, d);
+        hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(64), 0, st, b->ptrs, d);
+    }
+    UH_HIP_CHECK(hipGetLastError());
+    return UH_OK;
+}
+
+int run_pass(uh_ba* b, int max_iters, int* iters_done, const volatile uint8_t* stop_asap) {
+    hipStream_t st = b->ctx->stream;
+    hipLaunchKernelGGL(ba_begin_pass_kernel, dim3(1), dim3(64), 0, st, b->ptrs, max_iters, b->params.min_chi2_between_iter);
+    int budget = max_iters + 1;   // one step per outer iteration when no trial is rejected
+    BAState hs;
+    for (int round = 0; round < 64; round++) {
+        int rc = enqueue_steps(b, budget);
+        if (rc) return rc;
+        UH_HIP_CHECK(hipMemcpyAsync(&hs, b->ptrs.st, sizeof(BAState), hipMemcpyDeviceToHost, st));
+        if (stop_asap && b->h_stop) {   // keep forwarding the caller's flag to the device-visible one while waiting
+            hipEvent_t ev;
+            UH_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            UH_HIP_CHECK(hipEventRecord(ev, st));
+            while (hipEventQuery(ev) == hipErrorNotReady) if (*stop_asap) *b->h_stop = 1;
+            (void)hipEventDestroy(ev);
+        }
+        UH_HIP_CHECK(hipStreamSynchronize(st));
+        if (hs.phase == 2) break;
+        budget = 4;   // rejected trials consumed steps: keep going
+    }
+    *iters_done = hs.iters_done;
+    return UH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uh_ba_create(uh_ctx* ctx, uh_ba** out) {
+    UH_REQUIRE(ctx && out, "uh_ba_create: NULL argument");
+    uh_ba* b = new uh_ba();
+    b->ctx = ctx;
+    if (hipHostMalloc(reinterpret_cast<void**>(&b->h_stop), 64, hipHostMallocMapped) != hipSuccess) b->h_stop = nullptr;
+    if (b->h_stop) *b->h_stop = 0;
+    *out = b;
+    return UH_OK;
+}
+
+void uh_ba_destroy(uh_ba* b) { delete b; }
+
+// GlobalOptimizer::setParams: snapshot of everything the optimisation needs (the map may change afterwards)
+int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* params) {
+    UH_REQUIRE(b && pr, "uh_ba_set_problem: NULL argument");
+    b->have_problem = false;
+    b->optimized = false;
+    if (params) b->params = *params;
+    if (b->params.huber_delta <= 0) b->params.huber_delta = std::sqrt(5.99);
+    if (b->params.chi2_threshold <= 0) b->params.chi2_threshold = 5.99;
+    const int K = pr->n_frames, P = pr->n_points, E = pr->n_obs;
+    UH_REQUIRE(K >= 1 && P >= 0 && E >= 0, "uh_ba_set_problem: bad sizes K=%d P=%d E=%d", K, P, E);
+    UH_REQUIRE(pr->poses_f2g && pr->fixed && pr->intr, "uh_ba_set_problem: NULL frame arrays");
+    if (P > 0) UH_REQUIRE(pr->points, "uh_ba_set_problem: NULL points");
+    if (E > 0) UH_REQUIRE(pr->obs_point && pr->obs_frame && pr->obs_uv && pr->obs_inv_sigma, "uh_ba_set_problem: NULL observation arrays");
+    std::vector<int> slot(K, -1), free_kf;
+    for (int k = 0; k < K; k++) if (!pr->fixed[k]) { slot[k] = (int)free_kf.size(); free_kf.push_back(k); }
+    const int nfree = (int)free_kf.size();
+    UH_REQUIRE(nfree <= kMaxFree, "uh_ba_set_problem: %d free keyframes (this round supports <= %d)", nfree, kMaxFree);
+    for (int e = 0; e < E; e++)
+        UH_REQUIRE(pr->obs_point[e] >= 0 && pr->obs_point[e] < P && pr->obs_frame[e] >= 0 && pr->obs_frame[e] < K,
+                   "uh_ba_set_problem: observation %d references point %d / frame %d out of range", e, pr->obs_point[e], pr->obs_frame[e]);
+    // host-side graph structure
+    std::vector<int> pt_ptr(P + 1, 0), pt_edges(E), cam_ptr(nfree + 1, 0), cam_edges, edge_of((size_t)P * std::max(nfree, 1), -1);
+    for (int e = 0; e < E; e++) pt_ptr[pr->obs_point[e] + 1]++;
+    for (int p = 0; p < P; p++) pt_ptr[p + 1] += pt_ptr[p];
+    { std::vector<int> fill(pt_ptr.begin(), pt_ptr.end() - 1); for (int e = 0; e < E; e++) pt_edges[fill[pr->obs_point[e]]++] = e; }
+    for (int e = 0; e < E; e++) { const int s = slot[pr->obs_frame[e]]; if (s >= 0) cam_ptr[s + 1]++; }
+    for (int s = 0; s < nfree; s++) cam_ptr[s + 1] += cam_ptr[s];
+    cam_edges.resize(cam_ptr[nfree]);
+    { std::vector<int> fill(cam_ptr.begin(), cam_ptr.end() - 1);
+      for (int e = 0; e < E; e++) { const int s = slot[pr->obs_frame[e]]; if (s >= 0) { cam_edges[fill[s]++] = e;
+          UH_REQUIRE(edge_of[(size_t)pr->obs_point[e] * nfree + s] < 0, "uh_ba_set_problem: point %d observed twice by frame %d", pr->obs_point[e], pr->obs_frame[e]);
+          edge_of[(size_t)pr->obs_point[e] * nfree + s] = e; } } }
+    std::vector<double> pose0(7 * (size_t)K), pts0(3 * (size_t)P), intr(4 * (size_t)K), uv(2 * (size_t)E), w(E);
+    for (int k = 0; k < K; k++) {   // toSE3Quat (globaloptimizer_g2o.cpp:80-90): float 4x4 -> double R,t -> quaternion
+        const float* M = pr->poses_f2g + 16 * k;
+        const double R[9] = {M[0], M[1], M[2], M[4], M[5], M[6], M[8], M[9], M[10]};
+        quat_from_R_host(R, &pose0[7 * k]);
+        pose0[7 * k + 4] = M[3]; pose0[7 * k + 5] = M[7]; pose0[7 * k + 6] = M[11];
+        for (int j = 0; j < 4; j++) intr[4 * k + j] = pr->intr[4 * k + j];
+    }
+    for (size_t i = 0; i < pts0.size(); i++) pts0[i] = pr->points[i];
+    for (int e = 0; e < E; e++) { uv[2 * e] = pr->obs_uv[2 * e]; uv[2 * e + 1] = pr->obs_uv[2 * e + 1]; w[e] = pr->obs_inv_sigma[e]; }
+    b->poses_in.assign(pr->poses_f2g, pr->poses_f2g + 16 * (size_t)K);
+    b->fixed.assign(pr->fixed, pr->fixed + K);
+
+    BADims& d = b->dims;
+    d.K = K; d.P = P; d.E = E; d.nfree = nfree; d.n = 6 * nfree;
+    d.nPointBlocks = std::max(uh_div_up(P, kThreads), 1);
+    d.delta = b->params.huber_delta; d.dsqr = d.delta * d.delta; d.chi2_th = b->params.chi2_threshold;
+
+    // carve one arena
+    Arena A;
+    const size_t o_pt_ptr = A.take<int>(P + 1), o_pt_edges = A.take<int>(E), o_cam_ptr = A.take<int>(nfree + 1), o_cam_edges = A.take<int>(cam_edges.size());
+    const size_t o_e_pt = A.take<int>(E), o_e_kf = A.take<int>(E), o_uv = A.take<double>(2 * (size_t)E), o_w = A.take<double>(E);
+    const size_t o_slot = A.take<int>(K), o_free = A.take<int>(std::max(nfree, 1)), o_intr = A.take<double>(4 * (size_t)K), o_edge_of = A.take<int>(edge_of.size());
+    const size_t o_pose0 = A.take<double>(7 * (size_t)K), o_pts0 = A.take<double>(3 * (size_t)P);
+    size_t o_pose[2], o_poseR[2], o_pts[2];
+    for (int i = 0; i < 2; i++) { o_pose[i] = A.take<double>(7 * (size_t)K); o_poseR[i] = A.take<double>(12 * (size_t)K); o_pts[i] = A.take<double>(3 * (size_t)P); }
+    const size_t o_act = A.take<unsigned char>(E), o_rob = A.take<unsigned char>(E), o_err = A.take<double>(2 * (size_t)E), o_chi2 = A.take<double>(E);
+    const size_t o_Hll = A.take<double>(9 * (size_t)P), o_bl = A.take<double>(3 * (size_t)P), o_Hpl = A.take<double>(18 * (size_t)E);
+    const size_t o_Hpp = A.take<double>(36 * (size_t)std::max(nfree, 1)), o_bp = A.take<double>(std::max(d.n, 1));
+    const size_t o_S = A.take<double>((size_t)std::max(d.n, 1) * std::max(d.n, 1)), o_bs = A.take<double>(std::max(d.n, 1)), o_xp = A.take<double>(std::max(d.n, 1));
+    const size_t o_plc = A.take<double>(d.nPointBlocks), o_pmd = A.take<double>(d.nPointBlocks + nfree), o_pc = A.take<double>(d.nPointBlocks), o_ps = A.take<double>(d.nPointBlocks);
+    const size_t o_st = A.take<BAState>(1);
+    int rc = b->arena.reserve(A.off + 256);
+    if (rc) return rc;
+    UH_HIP_CHECK(hipSetDevice(b->ctx->device));
+    hipStream_t st = b->ctx->stream;
+    char* base = b->arena.as<char>();
+    auto up = [&](size_t off, const void* src, size_t bytes) -> int {
+        if (bytes) UH_HIP_CHECK(hipMemcpyAsync(base + off, src, bytes, hipMemcpyHostToDevice, st));
+        return UH_OK;
+    };
+    if ((rc = up(o_pt_ptr, pt_ptr.data(), pt_ptr.size() * 4))) return rc;
+    if ((rc = up(o_pt_edges, pt_edges.data(), pt_edges.size() * 4))) return rc;
+    if ((rc = up(o_cam_ptr, cam_ptr.data(), cam_ptr.size() * 4))) return rc;
+    if ((rc = up(o_cam_edges, cam_edges.data(), cam_edges.size() * 4))) return rc;
+    if ((rc = up(o_e_pt, pr->obs_point, (size_t)E * 4))) return rc;
+    if ((rc = up(o_e_kf, pr->obs_frame, (size_t)E * 4))) return rc;
+    if ((rc = up(o_uv, uv.data(), uv.size() * 8))) return rc;
+    if ((rc = up(o_w, w.data(), w.size() * 8))) return rc;
+    if ((rc = up(o_slot, slot.data(), slot.size() * 4))) return rc;
+    if ((rc = up(o_free, free_kf.data(), free_kf.size() * 4))) return rc;
+    if ((rc = up(o_intr, intr.data(), intr.size() * 8))) return rc;
+    if ((rc = up(o_edge_of, edge_of.data(), edge_of.size() * 4))) return rc;
+    if ((rc = up(o_pose0, pose0.data(), pose0.size() * 8))) return rc;
+    if ((rc = up(o_pts0, pts0.data(), pts0.size() * 8))) return rc;
+    if ((rc = b->d_poses_in.reserve(16 * (size_t)K * 4))) return rc;
+    if ((rc = b->d_poses_out.reserve(16 * (size_t)K * 4))) return rc;
+    if ((rc = b->d_points_out.reserve(std::max<size_t>(3 * (size_t)P * 4, 16)))) return rc;
+    if ((rc = b->d_bad.reserve(std::max<size_t>(E, 16)))) return rc;
+    UH_HIP_CHECK(hipMemcpyAsync(b->d_poses_in.p, pr->poses_f2g, 16 * (size_t)K * 4, hipMemcpyHostToDevice, st));
+    UH_HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors die here
+    BAPtrs& p = b->ptrs;
+    p.pt_ptr = (int*)(base + o_pt_ptr); p.pt_edges = (int*)(base + o_pt_edges); p.cam_ptr = (int*)(base + o_cam_ptr); p.cam_edges = (int*)(base + o_cam_edges);
+    p.e_pt = (int*)(base + o_e_pt); p.e_kf = (int*)(base + o_e_kf); p.e_uv = (double*)(base + o_uv); p.e_w = (double*)(base + o_w);
+    p.slot = (int*)(base + o_slot); p.free_kf = (int*)(base + o_free); p.intr = (double*)(base + o_intr); p.edge_of = (int*)(base + o_edge_of);
+    for (int i = 0; i < 2; i++) { p.pose[i] = (double*)(base + o_pose[i]); p.poseR[i] = (double*)(base + o_poseR[i]); p.pts[i] = (double*)(base + o_pts[i]); }
+    p.e_active = (unsigned char*)(base + o_act); p.e_robust = (unsigned char*)(base + o_rob); p.e_err = (double*)(base + o_err); p.e_chi2 = (double*)(base + o_chi2);
+    p.Hll = (double*)(base + o_Hll); p.bl = (double*)(base + o_bl); p.Hpl = (double*)(base + o_Hpl); p.Hpp = (double*)(base + o_Hpp); p.bp = (double*)(base + o_bp);
+    p.S = (double*)(base + o_S); p.bs = (double*)(base + o_bs); p.xp = (double*)(base + o_xp);
+    p.part_lin_chi = (double*)(base + o_plc); p.part_maxdiag = (double*)(base + o_pmd); p.part_chi = (double*)(base + o_pc); p.part_scale = (double*)(base + o_ps);
+    p.st = (BAState*)(base + o_st);
+    p.stop = nullptr;
+    if (b->h_stop) {
+        void* dflag = nullptr;
+        if (hipHostGetDevicePointer(&dflag, b->h_stop, 0) == hipSuccess) p.stop = (const volatile unsigned char*)dflag;
+    }
+    b->d_pose0 = (double*)(base + o_pose0);
+    b->d_pts0 = (double*)(base + o_pts0);
+    b->have_problem = true;
+    return UH_OK;
+}
+
+// GlobalOptimizer::optimize(bool* stopASAP).  The caller may flip *stop_asap asynchronously; it is sampled into a pinned,
+// device-visible flag before each pass and whenever the host waits, and the decide kernel reads that flag every trial.
+int uh_ba_optimize(uh_ba* b, const volatile uint8_t* stop_asap) {
+    UH_REQUIRE(b && b->have_problem, "uh_ba_optimize: no problem set (call uh_ba_set_problem first)");
+    UH_HIP_CHECK(hipSetDevice(b->ctx->device));
+    hipStream_t st = b->ctx->stream;
+    const BADims& d = b->dims;
+    if (b->h_stop) *b->h_stop = (stop_asap && *stop_asap) ? 1 : 0;
+    const int nmax = std::max(std::max(d.K, 3 * d.P), std::max(d.E, 1));
+    hipLaunchKernelGGL(ba_init_state_kernel, dim3(uh_div_up(nmax, 256)), dim3(256), 0, st, b->ptrs, d, b->d_pose0, b->d_pts0);
+    b->iters[0] = b->iters[1] = 0;
+    int rc = run_pass(b, b->params.n_iters, &b->iters[0], stop_asap);
+    if (rc) return rc;
+    bool cont = true;
+    if (stop_asap && *stop_asap) cont = false;
+    if (b->h_stop && *b->h_stop) cont = false;
+    if (cont) {
+        if (d.E > 0) hipLaunchKernelGGL(ba_relabel_kernel, dim3(uh_div_up(d.E, 256)), dim3(256), 0, st, b->ptrs, d);
+        if ((rc = run_pass(b, 2 * b->params.n_iters, &b->iters[1], stop_asap))) return rc;
+    }
+    b->optimized = true;
+    return UH_OK;
+}
+
+uint8_t* uh_ba_stop_flag(uh_ba* b) { return b ? b->h_stop : nullptr; }
+
+int uh_ba_get_results(uh_ba* b, float* poses_out, float* points_out, double* chi2_out, uint8_t* bad_out, int32_t* iters_out) {
+    UH_REQUIRE(b && b->have_problem && b->optimized, "uh_ba_get_results: optimize() has not run");
+    UH_HIP_CHECK(hipSetDevice(b->ctx->device));
+    hipStream_t st = b->ctx->stream;
+    const BADims& d = b->dims;
+    const int n0 = std::max(d.K, 3 * d.P);
+    hipLaunchKernelGGL(ba_results_kernel, dim3(uh_div_up(std::max(n0, 1), 256)), dim3(256), 0, st, b->ptrs, d, b->d_poses_in.as<float>(),
+                       b->d_poses_out.as<float>(), b->d_points_out.as<float>(), b->d_bad.as<unsigned char>(), 0);
+    if (d.E > 0)
+        hipLaunchKernelGGL(ba_results_kernel, dim3(uh_div_up(d.E, 256)), dim3(256), 0, st, b->ptrs, d, b->d_poses_in.as<float>(),
+                           b->d_poses_out.as<float>(), b->d_points_out.as<float>(), b->d_bad.as<unsigned char>(), 1);
+    if (poses_out) UH_HIP_CHECK(hipMemcpyAsync(poses_out, b->d_poses_out.p, 16 * (size_t)d.K * 4, hipMemcpyDeviceToHost, st));
+    if (points_out && d.P) UH_HIP_CHECK(hipMemcpyAsync(points_out, b->d_points_out.p, 3 * (size_t)d.P * 4, hipMemcpyDeviceToHost, st));
+    if (chi2_out && d.E) UH_HIP_CHECK(hipMemcpyAsync(chi2_out, b->ptrs.e_chi2, (size_t)d.E * 8, hipMemcpyDeviceToHost, st));
+    if (bad_out && d.E) UH_HIP_CHECK(hipMemcpyAsync(bad_out, b->d_bad.p, (size_t)d.E, hipMemcpyDeviceToHost, st));
+    UH_HIP_CHECK(hipStreamSynchronize(st));
+    if (iters_out) { iters_out[0] = b->iters[0]; iters_out[1] = b->iters[1]; }
+    return UH_OK;
+}
+
+// final pose state (qx qy qz qw tx ty tz per frame, fp64) — used by the parity tests to state the tolerance on se3
+int uh_ba_get_pose_state(uh_ba* b, double* pose7_out) {
+    UH_REQUIRE(b && b->have_problem && b->optimized && pose7_out, "uh_ba_get_pose_state: not ready");
+    BAState hs;
+    UH_HIP_CHECK(hipMemcpyAsync(&hs, b->ptrs.st, sizeof(BAState), hipMemcpyDeviceToHost, b->ctx->stream));
+    UH_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
+    UH_HIP_CHECK(hipMemcpyAsync(pose7_out, b->ptrs.pose[hs.cur], 7 * (size_t)b->dims.K * 8, hipMemcpyDeviceToHost, b->ctx->stream));
+    UH_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
+    return UH_OK;
+}
+
+}  // extern "C"
