@@ -1,0 +1,254 @@
+#!/usr/bin/env python
+"""bench.py — tracking frames/sec of the MI355X hot path (ORB extract + Hamming match + local BA), 1241x376 mono.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched under torch.distributed.run, one
+rank per GPU.  Prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json configs[1..3] combined = the metric's "ORB extract + match + local BA"):
+  one step = `frames_per_step` (4) synthetic 1241x376 frames already resident in HBM:
+     ORB extraction of the 4 frames in one batched launch set (8 levels, scale 1.2, 2000 features)
+     4 x brute-force Hamming kNN, 2000 query descriptors (the frame's own ORB output) vs a 10 000-descriptor map,
+         nn=10 unsorted — the FrameMatcher_Flann call shape (framematcher.cpp:213,239)
+     1 x local BA, 10 keyframes x 3000 landmarks (~26k observations), nIters=5 (+10), fp64 — one keyframe per 4 frames
+  value = frames / second over all ranks.  Multi-GPU: frame streams are independent, so every rank runs the same per-GPU
+  workload on its own frames ("weak" scaling, no data-path collective); only the timing reduction crosses ranks.
+Extra objects: "roofline" (dominant kernel, HIP events on the launch stream) and "cpu_baseline" (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+W, H = 1241, 376
+MAX_FEATURES, NLEVELS, SCALE = 2000, 8, 1.2
+NQ, NT, NN = 2000, 10000, 10
+BA_K, BA_P = 10, 3000
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+
+
+def level_sizes():
+    inv, s = [], 1.0
+    sc = np.float32(1.0)
+    out = []
+    for l in range(NLEVELS):
+        out.append((int(np.rint(np.float32(W) * (np.float32(1.0) / sc))), int(np.rint(np.float32(H) * (np.float32(1.0) / sc)))))
+        sc = np.float32(sc * np.float32(SCALE))
+    return out
+
+
+def algorithmic_bytes(frames_per_step, ba_E):
+    """Algorithmic (compulsory) bytes PER LAUNCH of each kernel for this workload; formulas are stated in DESIGN.md §5."""
+    lv = level_sizes()
+    px = [w * h for w, h in lv]
+    F = frames_per_step
+    sum_px = sum(px)
+    b = {
+        "blur7_kernel": F * 2 * px[0],                                  # read input, write level 0
+        "fast_score_kernel": F * 2 * sum_px,                            # read every level once, write its strength map
+        "cell_nms_kernel": F * (sum(max(w - 38, 0) * max(h - 38, 0) for w, h in lv)),   # read cell interiors (candidates are ~KBs)
+        "select_kernel": F * MAX_FEATURES * 4 * 4,                      # candidate words in, selected words out (order of magnitude)
+        "describe_kernel": F * MAX_FEATURES * (961 + 60),               # 31x31 patch per keypoint + 28 B keypoint + 32 B descriptor
+        "knn_search_kernel": (NQ + NT) * 32 + NQ * NN * 8,              # SURVEY §8(d) formula with k=10
+        # BA, per launch (E*32 obs + points/poses; per-kernel split in DESIGN.md)
+        "ba_lin_kernel": ba_E * (32 + 18 * 8) + BA_P * (24 + 96),
+        "ba_schur_kernel": ba_E * 18 * 8 + BA_P * 96,
+        "ba_solve_kernel": (6 * BA_K) ** 2 * 8,
+        "ba_backsub_kernel": ba_E * (18 * 8 + 32 + 24) + BA_P * (96 + 48),
+        "ba_decide_kernel": 1024,
+    }
+    # resize: the driver launches it once per level l>=1: read level l-1, write level l (average per launch)
+    b["resize_cubic_kernel"] = F * (sum(px[:-1]) + sum(px[1:])) / (NLEVELS - 1)
+    return b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames-per-step", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path is the product, there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import synth
+    import ucoslam_cv3_amd as u
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+    from ucoslam_cv3_amd.knn import Index
+    from ucoslam_cv3_amd.orb import FeatParams, ORBextractor
+
+    F = args.frames_per_step
+    dev = torch.device("cuda", local_rank)
+    ctx = u.Context(local_rank, torch.cuda.current_stream().cuda_stream)
+
+    # ---- synthetic inputs, resident in HBM before the timed region
+    frames_np = np.stack([synth.frame(W, H, seed=1000 * rank + f, shift=(2 * f, f)) for f in range(F)])
+    frames = torch.from_numpy(frames_np).to(dev)
+    map_desc_np, _ = synth.match_set(1, NT, seed=50 + rank)
+    map_desc = torch.from_numpy(map_desc_np).to(dev)
+    ba_pr = synth.ba_problem(BA_K, BA_P, seed=rank)
+
+    ext = ORBextractor.create(ctx)
+    fp = FeatParams(MAX_FEATURES, NLEVELS, SCALE)
+    orb_out = ext.extract_batch(frames, fp)
+    index = Index(ctx).build(map_desc)
+    ba = GlobalOptimizer.create(ctx)
+    ba.setParams(ba_pr, ParamSet(nIters=5))
+    knn_idx = torch.empty((F, NQ, NN), dtype=torch.int32, device=dev)
+    knn_dist = torch.empty((F, NQ, NN), dtype=torch.int32, device=dev)
+    L = u.lib()
+    from ucoslam_cv3_amd._lib import check, dev_ptr
+
+    def step():
+        kps, desc, counts = ext.extract_batch(frames, fp, orb_out)
+        for f in range(F):
+            check(L.uh_knn_search_dev(index._h, dev_ptr(desc[f]), NQ, NN, dev_ptr(knn_idx[f]), dev_ptr(knn_dist[f]), 0, -1))
+        ba.optimize()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        tt = torch.tensor([t_local], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_max = float(tt.item())
+    else:
+        t_max = t_local
+    counts = orb_out[2].cpu().numpy()
+    assert (counts == MAX_FEATURES).all(), f"synthetic frames must yield {MAX_FEATURES} keypoints, got {counts}"
+    total_frames = world * F * args.steps
+    value = total_frames / t_max
+    ms_per_step = 1e3 * t_max / args.steps
+
+    # ---- per-stage split and roofline (rank 0; separate passes so event overhead never enters the headline number)
+    roofline = None
+    stage_ms = {}
+    if rank == 0:
+        def timed(fn, reps):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t) / reps
+
+        stage_ms["orb_ms_per_frame"] = timed(lambda: ext.extract_batch(frames, fp, orb_out), 20) / F
+        stage_ms["match_ms_per_frame"] = timed(
+            lambda: check(L.uh_knn_search_dev(index._h, dev_ptr(orb_out[1][0]), NQ, NN, dev_ptr(knn_idx[0]), dev_ptr(knn_dist[0]), 0, -1)), 50)
+        stage_ms["ba_ms_per_keyframe"] = timed(lambda: ba.optimize(), 5)
+        if not args.no_roofline:
+            ctx.prof_enable(True)
+            ctx.prof_reset()
+            reps = 5
+            for _ in range(reps):
+                step()
+            rep = ctx.prof_report()
+            ctx.prof_enable(False)
+            ab = algorithmic_bytes(F, ba_pr["E"])
+            short = {k.split("::")[-1]: v for k, v in rep.items()}
+            dom = max(short.items(), key=lambda kv: kv[1][1])
+            name, (calls, tot_ms) = dom
+            avg_ms = tot_ms / max(calls, 1)
+            achieved = ab.get(name, 0) / (avg_ms * 1e-3) / 1e9
+            roofline = {
+                "bound": "hbm", "kernel": name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "avg_launch_us": round(avg_ms * 1e3, 3), "algorithmic_bytes_per_launch": int(ab.get(name, 0)),
+                "share_of_step_gpu_time": round(tot_ms / sum(v[1] for v in short.values()), 4),
+                "kernels_us": {k: round(1e3 * v[1] / max(v[0], 1), 2) for k, v in sorted(short.items())},
+            }
+
+    # ---- CPU baseline (rank 0, N=1 only): bounded sample of the same workload on the host cores
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_lib
+
+        O = oracle_lib.load_oracle()
+        n_orb, n_match, n_ba = 12, 10, 4
+        t = time.perf_counter()
+        for i in range(n_orb):
+            oracle_lib.orb_extract(O, frames_np[i % F], MAX_FEATURES, NLEVELS, SCALE)
+        t_orb = (time.perf_counter() - t) / n_orb
+        q = orb_out[1][0].cpu().numpy()
+        xf = oracle_lib.load_ref("xflann")
+        P = oracle_lib.P
+        t = time.perf_counter()
+        for i in range(n_match):
+            if xf is not None:
+                ii = np.empty((NQ, NN), np.int32)
+                dd = np.empty((NQ, NN), np.int32)
+                xf.xflann_ref_linear_search(P(map_desc_np), NT, P(q), NQ, NN, 0, 1, P(ii), P(dd))
+            else:
+                oracle_lib.knn_search(O, map_desc_np, q, NN, 0)
+        t_match = (time.perf_counter() - t) / n_match
+        g2o = oracle_lib.load_ref("g2o")
+        t = time.perf_counter()
+        for i in range(n_ba):
+            if g2o is not None:
+                oracle_lib.ba_optimize_ref(g2o, ba_pr, 5)
+            else:
+                oracle_lib.ba_optimize(O, ba_pr, 5)
+        t_ba = (time.perf_counter() - t) / n_ba
+        t_frame = t_orb + t_match + t_ba / F
+        cpu = {
+            "value": round(1.0 / t_frame, 4), "unit": "frames/s", "cores": 1,
+            "kind": "port",
+            "sample": (f"{n_orb} ORB frames (oracle port, {1e3*t_orb:.1f} ms/frame) + {n_match} matches 2000x10000 nn=10 "
+                       f"({'real xflann Linear (oracle/_ref)' if xf is not None else 'oracle port'}, {1e3*t_match:.1f} ms) + {n_ba} local BAs "
+                       f"({'real g2o (oracle/_ref)' if g2o is not None else 'oracle port'}, {1e3*t_ba:.1f} ms), one BA per {F} frames, single thread"),
+        }
+
+    if rank == 0:
+        line = {
+            "metric": "tracking frames/sec (ORB extract + match + local BA), 1241x376 mono",
+            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 (ORB, Hamming) + f64 (BA)", "data": "synthetic",
+            "config": {"workload": "orb1241x376_2000f_8lv + hamming_knn_2000x10000_nn10 + local_ba_10kf_3000pt",
+                       "frames_per_step": F, "frames_per_keyframe": F, "parallelism": f"frame-streams x{world} (replicas, no data-path collective)"},
+            "stages": {k: round(v, 4) for k, v in stage_ms.items()},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if cpu:
+            line["gpu_over_cpu"] = round(value / cpu["value"], 2)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

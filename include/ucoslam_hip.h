@@ -45,6 +45,11 @@ void        uh_ctx_destroy(uh_ctx* ctx);
 int         uh_ctx_synchronize(uh_ctx* ctx);
 void*       uh_ctx_stream(uh_ctx* ctx);
 const char* uh_last_error(void);
+/* Per-kernel timing for measurement (bench.py roofline leg): when enabled every kernel launch of the stage objects
+ * bound to this context is bracketed by HIP events on the context stream.  report: "<kernel> <calls> <total_ms>\n" lines. */
+int         uh_prof_enable(uh_ctx* ctx, int on);
+int         uh_prof_reset(uh_ctx* ctx);
+int         uh_prof_report(uh_ctx* ctx, char* buf, size_t cap);
 /* library/ABI version: major*10000 + minor*100 + patch */
 int         uh_version(void);
 

@@ -20,8 +20,25 @@ def run():
     torch.cuda.synchronize()
     ri, rd = oracle_lib.knn_search(L, train, q, 2, 1)
     assert (idx.cpu().numpy() == ri).all() and (dist.cpu().numpy() == rd).all(), "kNN mismatch vs oracle"
-    for hook in _EXTRA:
-        hook(ctx, L)
+    # --- ORB extractor (small frame, full pipeline) — bit-exact keypoints + descriptors
+    from ucoslam_cv3_amd.orb import FeatParams, ORBextractor
 
+    img = synth.frame(320, 240, seed=3)
+    ext = ORBextractor.create(ctx)
+    kps, desc = ext.detectAndCompute(img, None, FeatParams(600, 4, 1.2))
+    rk, rd = oracle_lib.orb_extract(L, img, 600, 4, 1.2)
+    assert len(kps) == len(rk) > 100, (len(kps), len(rk))
+    for f in ("x", "y", "angle", "response", "octave", "size"):
+        assert (kps[f] == rk[f]).all(), f"ORB keypoint field {f} differs from the oracle"
+    assert (desc == rd).all(), "ORB descriptors differ from the oracle"
+    # --- local BA (small), poses within the stated tolerance
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
 
-_EXTRA = []
+    pr = synth.ba_problem(5, 300, seed=4)
+    opt = GlobalOptimizer.create(ctx)
+    opt.setParams(pr, ParamSet(nIters=5))
+    opt.optimize()
+    got = opt.getResults()
+    ref = oracle_lib.ba_optimize(L, pr, 5)
+    assert got["iters"].tolist() == ref["iters"].tolist()
+    assert np.abs(got["state"] - ref["state"]).max() < 1e-6, "BA pose state differs from the oracle by more than 1e-6"

@@ -61,6 +61,9 @@ def _declare(L: C.CDLL):
     sig("uh_ctx_destroy", None, VP)
     sig("uh_ctx_synchronize", I, VP)
     sig("uh_ctx_stream", VP, VP)
+    sig("uh_prof_enable", I, VP, I)
+    sig("uh_prof_reset", I, VP)
+    sig("uh_prof_report", I, VP, C.c_char_p, SZ)
     # kNN
     sig("uh_knn_create", I, VP, C.POINTER(VP))
     sig("uh_knn_destroy", None, VP)
@@ -97,6 +100,24 @@ class Context:
 
     def synchronize(self):
         check(lib().uh_ctx_synchronize(self._h))
+
+    # per-kernel HIP-event timing on the context stream (measurement only)
+    def prof_enable(self, on: bool = True):
+        check(lib().uh_prof_enable(self._h, int(on)))
+
+    def prof_reset(self):
+        check(lib().uh_prof_reset(self._h))
+
+    def prof_report(self) -> dict:
+        """{kernel: (calls, total_ms)} accumulated since the last reset."""
+        n = lib().uh_prof_report(self._h, None, 0)
+        buf = C.create_string_buffer(max(n, 1) + 16)
+        lib().uh_prof_report(self._h, buf, len(buf))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, calls, ms = line.rsplit(" ", 2)
+            out[name] = (int(calls), float(ms))
+        return out
 
     def close(self):
         if self._h:

@@ -291,6 +291,7 @@ __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d) 
         lambda = 1e-5 * m;
         if (blockIdx.x == 0 && threadIdx.x == 0) { p.st->lambda = lambda; p.st->ni = 2; }
     }
+    if ((int)blockIdx.x >= d.nfree * (d.nfree + 1) / 2) return;   // structure-only BA: the launch exists for lambda
     // pair index -> (s1,s2)
     int s1 = 0, rem = blockIdx.x;
     while (rem >= d.nfree - s1) { rem -= d.nfree - s1; ++s1; }
@@ -706,11 +707,11 @@ int enqueue_steps(uh_ba* b, int nsteps) {
     const int use_lds = d.n <= 128 ? 1 : 0;
     const size_t lds = use_lds ? (size_t)d.n * d.n * sizeof(double) : 0;
     for (int s = 0; s < nsteps; s++) {
-        hipLaunchKernelGGL(ba_lin_kernel, dim3(d.nPointBlocks + d.nfree), dim3(kThreads), 0, st, b->ptrs, d);
-        if (npairs > 0) hipLaunchKernelGGL(ba_schur_kernel, dim3(npairs), dim3(kThreads), 0, st, b->ptrs, d);
-        hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(kThreads), lds, st, b->ptrs, d, use_lds);
-        hipLaunchKernelGGL(ba_backsub_kernel, dim3(d.nPointBlocks), dim3(kThreads), 0, st, b->ptrs, d);
-        hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(64), 0, st, b->ptrs, d);
+        UH_LAUNCH(b->ctx,ba_lin_kernel, dim3(d.nPointBlocks + d.nfree), dim3(kThreads), 0, b->ptrs, d);
+        UH_LAUNCH(b->ctx,ba_schur_kernel, dim3(std::max(npairs, 1)), dim3(kThreads), 0, b->ptrs, d);
+        UH_LAUNCH(b->ctx,ba_solve_kernel, dim3(1), dim3(kThreads), lds, b->ptrs, d, use_lds);
+        UH_LAUNCH(b->ctx,ba_backsub_kernel, dim3(d.nPointBlocks), dim3(kThreads), 0, b->ptrs, d);
+        UH_LAUNCH(b->ctx,ba_decide_kernel, dim3(1), dim3(64), 0, b->ptrs, d);
     }
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
@@ -718,7 +719,7 @@ int enqueue_steps(uh_ba* b, int nsteps) {
 
 int run_pass(uh_ba* b, int max_iters, int* iters_done, const volatile uint8_t* stop_asap) {
     hipStream_t st = b->ctx->stream;
-    hipLaunchKernelGGL(ba_begin_pass_kernel, dim3(1), dim3(64), 0, st, b->ptrs, max_iters, b->params.min_chi2_between_iter);
+    UH_LAUNCH(b->ctx,ba_begin_pass_kernel, dim3(1), dim3(64), 0, b->ptrs, max_iters, b->params.min_chi2_between_iter);
     int budget = max_iters + 1;   // one step per outer iteration when no trial is rejected
     BAState hs;
     for (int round = 0; round < 64; round++) {
@@ -879,7 +880,7 @@ int uh_ba_optimize(uh_ba* b, const volatile uint8_t* stop_asap) {
     const BADims& d = b->dims;
     if (b->h_stop) *b->h_stop = (stop_asap && *stop_asap) ? 1 : 0;
     const int nmax = std::max(std::max(d.K, 3 * d.P), std::max(d.E, 1));
-    hipLaunchKernelGGL(ba_init_state_kernel, dim3(uh_div_up(nmax, 256)), dim3(256), 0, st, b->ptrs, d, b->d_pose0, b->d_pts0);
+    UH_LAUNCH(b->ctx,ba_init_state_kernel, dim3(uh_div_up(nmax, 256)), dim3(256), 0, b->ptrs, d, b->d_pose0, b->d_pts0);
     b->iters[0] = b->iters[1] = 0;
     int rc = run_pass(b, b->params.n_iters, &b->iters[0], stop_asap);
     if (rc) return rc;
@@ -887,7 +888,7 @@ int uh_ba_optimize(uh_ba* b, const volatile uint8_t* stop_asap) {
     if (stop_asap && *stop_asap) cont = false;
     if (b->h_stop && *b->h_stop) cont = false;
     if (cont) {
-        if (d.E > 0) hipLaunchKernelGGL(ba_relabel_kernel, dim3(uh_div_up(d.E, 256)), dim3(256), 0, st, b->ptrs, d);
+        if (d.E > 0) UH_LAUNCH(b->ctx,ba_relabel_kernel, dim3(uh_div_up(d.E, 256)), dim3(256), 0, b->ptrs, d);
         if ((rc = run_pass(b, 2 * b->params.n_iters, &b->iters[1], stop_asap))) return rc;
     }
     b->optimized = true;
@@ -902,10 +903,10 @@ int uh_ba_get_results(uh_ba* b, float* poses_out, float* points_out, double* chi
     hipStream_t st = b->ctx->stream;
     const BADims& d = b->dims;
     const int n0 = std::max(d.K, 3 * d.P);
-    hipLaunchKernelGGL(ba_results_kernel, dim3(uh_div_up(std::max(n0, 1), 256)), dim3(256), 0, st, b->ptrs, d, b->d_poses_in.as<float>(),
+    UH_LAUNCH(b->ctx,ba_results_kernel, dim3(uh_div_up(std::max(n0, 1), 256)), dim3(256), 0, b->ptrs, d, b->d_poses_in.as<float>(),
                        b->d_poses_out.as<float>(), b->d_points_out.as<float>(), b->d_bad.as<unsigned char>(), 0);
     if (d.E > 0)
-        hipLaunchKernelGGL(ba_results_kernel, dim3(uh_div_up(d.E, 256)), dim3(256), 0, st, b->ptrs, d, b->d_poses_in.as<float>(),
+        UH_LAUNCH(b->ctx,ba_results_kernel, dim3(uh_div_up(d.E, 256)), dim3(256), 0, b->ptrs, d, b->d_poses_in.as<float>(),
                            b->d_poses_out.as<float>(), b->d_points_out.as<float>(), b->d_bad.as<unsigned char>(), 1);
     if (poses_out) UH_HIP_CHECK(hipMemcpyAsync(poses_out, b->d_poses_out.p, 16 * (size_t)d.K * 4, hipMemcpyDeviceToHost, st));
     if (points_out && d.P) UH_HIP_CHECK(hipMemcpyAsync(points_out, b->d_points_out.p, 3 * (size_t)d.P * 4, hipMemcpyDeviceToHost, st));

@@ -76,11 +76,53 @@ struct PinBuf {
 
 }  // namespace uh
 
+// Optional per-kernel timing with HIP events recorded on the context stream (bench.py's roofline leg).
+struct uh_prof {
+    bool on = false;
+    struct Rec { int id; hipEvent_t a, b; };
+    std::vector<std::string> names;
+    std::vector<double> total_ms;
+    std::vector<long> calls;
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    int id_of(const char* name) {
+        for (size_t i = 0; i < names.size(); i++) if (names[i] == name) return (int)i;
+        names.emplace_back(name); total_ms.push_back(0.0); calls.push_back(0);
+        return (int)names.size() - 1;
+    }
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+
 struct uh_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     int num_cus = 0;
+    uh_prof prof;
 };
+
+namespace uh {
+struct ProfScope {
+    uh_ctx* c; int id = -1; hipEvent_t a = nullptr;
+    ProfScope(uh_ctx* ctx, const char* name) : c(ctx) {
+        if (c->prof.on) { id = c->prof.id_of(name); a = c->prof.get(); (void)hipEventRecord(a, c->stream); }
+    }
+    ~ProfScope() {
+        if (id >= 0) { hipEvent_t b = c->prof.get(); (void)hipEventRecord(b, c->stream); c->prof.pending.push_back({id, a, b}); }
+    }
+};
+}  // namespace uh
+
+// launch `kernel` on the context stream; when profiling is on, bracket it with HIP events on that same stream
+#define UH_LAUNCH(ctx, kernel, grid, block, shmem, ...)                                        \
+    do {                                                                                        \
+        uh::ProfScope _ps((ctx), #kernel);                                                      \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);             \
+    } while (0)
 
 static inline int uh_div_up(int a, int b) { return (a + b - 1) / b; }

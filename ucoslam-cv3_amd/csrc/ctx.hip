@@ -1,4 +1,5 @@
 // Context + error plumbing of the C ABI (include/ucoslam_hip.h).
+#include <algorithm>
 #include "common.hpp"
 
 namespace uh {
@@ -57,6 +58,45 @@ int uh_ctx_synchronize(uh_ctx* ctx) {
     UH_REQUIRE(ctx != nullptr, "uh_ctx_synchronize: ctx is NULL");
     UH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return UH_OK;
+}
+
+int uh_prof_enable(uh_ctx* ctx, int on) {
+    UH_REQUIRE(ctx != nullptr, "uh_prof_enable: ctx is NULL");
+    ctx->prof.on = on != 0;
+    return UH_OK;
+}
+
+static void prof_drain(uh_ctx* ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& r : ctx->prof.pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { ctx->prof.total_ms[r.id] += ms; ctx->prof.calls[r.id]++; }
+        ctx->prof.pool.push_back(r.a);
+        ctx->prof.pool.push_back(r.b);
+    }
+    ctx->prof.pending.clear();
+}
+
+int uh_prof_reset(uh_ctx* ctx) {
+    UH_REQUIRE(ctx != nullptr, "uh_prof_reset: ctx is NULL");
+    prof_drain(ctx);
+    for (auto& v : ctx->prof.total_ms) v = 0.0;
+    for (auto& v : ctx->prof.calls) v = 0;
+    return UH_OK;
+}
+
+// text report, one line per kernel: "<name> <calls> <total_ms>\n"; returns bytes needed (incl. NUL)
+int uh_prof_report(uh_ctx* ctx, char* buf, size_t cap) {
+    UH_REQUIRE(ctx != nullptr, "uh_prof_report: ctx is NULL");
+    prof_drain(ctx);
+    std::string out;
+    char line[256];
+    for (size_t i = 0; i < ctx->prof.names.size(); i++) {
+        snprintf(line, sizeof(line), "%s %ld %.6f\n", ctx->prof.names[i].c_str(), ctx->prof.calls[i], ctx->prof.total_ms[i]);
+        out += line;
+    }
+    if (buf && cap) { size_t n = std::min(cap - 1, out.size()); memcpy(buf, out.data(), n); buf[n] = 0; }
+    return (int)out.size() + 1;
 }
 
 void* uh_ctx_stream(uh_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }

@@ -328,7 +328,7 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
     if (nq == 0) return UH_OK;
     UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
     dim3 grid(uh_div_up(nq, kWavesPerBlock)), block(kWave * kWavesPerBlock);
-    hipLaunchKernelGGL(knn_search_kernel, grid, block, 0, idx->ctx->stream, idx->d_train, idx->shard_begin,
+    UH_LAUNCH(idx->ctx,knn_search_kernel, grid, block, 0, idx->d_train, idx->shard_begin,
                        idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
@@ -363,7 +363,7 @@ int uh_knn_scan_shard_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn,
     if (nq == 0) return UH_OK;
     UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
     dim3 grid(uh_div_up(nq, kWavesPerBlock)), block(kWave * kWavesPerBlock);
-    hipLaunchKernelGGL(knn_scan_shard_kernel, grid, block, 0, idx->ctx->stream, idx->d_train, idx->shard_begin,
+    UH_LAUNCH(idx->ctx,knn_scan_shard_kernel, grid, block, 0, idx->d_train, idx->shard_begin,
                        idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
@@ -383,7 +383,7 @@ int uh_knn_replay_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
     for (int s = 0; s <= nshards; ++s) sb.b[s] = (int)((long long)idx->nt * s / nshards);
     UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
     dim3 grid(uh_div_up(nq, kWavesPerBlock)), block(kWave * kWavesPerBlock);
-    hipLaunchKernelGGL(knn_replay_kernel, grid, block, 0, idx->ctx->stream, idx->d_train, sb, d_queries, nq, nn,
+    UH_LAUNCH(idx->ctx,knn_replay_kernel, grid, block, 0, idx->d_train, sb, d_queries, nq, nn,
                        sorted ? 1 : 0, max_dist, d_cand_all, d_counts_all, cap, d_indices, d_distances);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;

@@ -658,33 +658,33 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
     uint8_t* pyr = o->d_pyr.as<uint8_t>();
     const LevelDesc& L0 = P.lv[0];
     if (o->blur_first) {
-        hipLaunchKernelGGL(blur7_kernel, dim3(uh_div_up(w, 64), uh_div_up(h, 16), batch), dim3(256), 0, st, d_imgs, w, h, stride,
+        UH_LAUNCH(o->ctx,blur7_kernel, dim3(uh_div_up(w, 64), uh_div_up(h, 16), batch), dim3(256), 0, d_imgs, w, h, stride,
                            img_frame_stride, pyr + L0.img_off, L0.pitch, o->frame_stride);
     } else {
-        hipLaunchKernelGGL(copy_kernel, dim3(uh_div_up(w, 256), h, batch), dim3(256), 0, st, d_imgs, w, h, stride,
+        UH_LAUNCH(o->ctx,copy_kernel, dim3(uh_div_up(w, 256), h, batch), dim3(256), 0, d_imgs, w, h, stride,
                            img_frame_stride, pyr + L0.img_off, L0.pitch, o->frame_stride);
     }
     for (int l = 1; l < P.nlevels; l++) {
         const LevelDesc& S = P.lv[l - 1];
         const LevelDesc& D = P.lv[l];
-        hipLaunchKernelGGL(resize_cubic_kernel, dim3(uh_div_up(D.w, 64), uh_div_up(D.h, 4), batch), dim3(256), 0, st,
+        UH_LAUNCH(o->ctx,resize_cubic_kernel, dim3(uh_div_up(D.w, 64), uh_div_up(D.h, 4), batch), dim3(256), 0,
                            pyr + S.img_off, S.w, S.h, S.pitch, pyr + D.img_off, D.w, D.h, D.pitch, o->frame_stride,
                            o->d_xofs.as<int>() + D.xtap_off, o->d_xcoef.as<short>() + (size_t)D.xtap_off * 4,
                            o->d_yofs.as<int>() + D.ytap_off, o->d_ycoef.as<short>() + (size_t)D.ytap_off * 4);
     }
-    hipLaunchKernelGGL(fast_score_kernel, dim3(P.total_tiles, batch), dim3(256), 0, st, dP, pyr, o->d_score.as<uint8_t>(),
+    UH_LAUNCH(o->ctx,fast_score_kernel, dim3(P.total_tiles, batch), dim3(256), 0, dP, pyr, o->d_score.as<uint8_t>(),
                        o->frame_stride);
     if (P.total_cells > 0) {
-        hipLaunchKernelGGL(cell_nms_kernel, dim3(P.total_cells, batch), dim3(256), 0, st, dP, o->d_cells.as<CellDesc>(),
+        UH_LAUNCH(o->ctx,cell_nms_kernel, dim3(P.total_cells, batch), dim3(256), 0, dP, o->d_cells.as<CellDesc>(),
                            o->d_score.as<uint8_t>(), o->frame_stride, o->d_cand.as<uint32_t>(), o->cand_stride,
                            o->d_cell_counts.as<int>());
     }
-    hipLaunchKernelGGL(select_kernel, dim3(P.nlevels, batch), dim3(256), (size_t)o->lds_entries * 4, st, dP,
+    UH_LAUNCH(o->ctx,select_kernel, dim3(P.nlevels, batch), dim3(256), (size_t)o->lds_entries * 4, dP,
                        o->d_cells.as<CellDesc>(), o->d_cand.as<uint32_t>(), o->cand_stride, o->d_cell_counts.as<int>(),
                        o->d_work.as<uint32_t>(), o->cand_stride * 2, o->d_sel.as<uint32_t>(), o->sel_stride,
                        o->d_level_counts.as<int>(), o->lds_entries);
     const int slots = std::min(std::max(P.maxFeatures, 1), std::max(cap_per_frame, 1));
-    hipLaunchKernelGGL(describe_kernel, dim3(uh_div_up(slots, 4), batch), dim3(256), 0, st, dP, pyr, o->frame_stride,
+    UH_LAUNCH(o->ctx,describe_kernel, dim3(uh_div_up(slots, 4), batch), dim3(256), 0, dP, pyr, o->frame_stride,
                        o->d_sel.as<uint32_t>(), o->sel_stride, o->d_level_counts.as<int>(), d_kps, d_desc, cap_per_frame,
                        d_counts);
     UH_HIP_CHECK(hipGetLastError());
