@@ -197,6 +197,59 @@ uint8_t* uh_ba_stop_flag(uh_ba* ba);
 int  uh_ba_get_results(uh_ba* ba, float* poses_out, float* points_out, double* chi2_out, uint8_t* bad_out, int32_t* iters_out);
 int  uh_ba_get_pose_state(uh_ba* ba, double* pose7_out);   /* n_frames x (qx qy qz qw tx ty tz), fp64 */
 
+/* ------------------------------------------------------------------------
+ * Bag of words — replaces fbow::Vocabulary::transform / fBow::score:
+ *   3rdparty/fbow/fbow/fbow.h:54-116 (class surface), fbow.cpp:51-90 (transform with level), :92-143 (normalised
+ *   transform), :171-190 (stream format), :192-243 (score); UcoSLAM call site keyframedatabase.cpp:310-322 (level 3).
+ * The GPU does the per-descriptor tree descent; the std::map containers of the reference API are assembled by the
+ * host adaptor from the per-descriptor triples, in feature order (keeps the reference's float summation order).
+ * ------------------------------------------------------------------------ */
+typedef struct uh_bow uh_bow;
+int  uh_bow_create(uh_ctx* ctx, uh_bow** out);
+void uh_bow_destroy(uh_bow* bow);
+/* Vocabulary::fromStream: `stream` = u64 signature 55824124 + raw params struct (120 bytes) + block blob */
+int  uh_bow_load(uh_bow* bow, const void* stream, size_t nbytes);
+/* same, from an already split params struct (fbow::Vocabulary::params, 120 bytes) and blob */
+int  uh_bow_set(uh_bow* bow, const void* params120, const void* blob);
+int  uh_bow_get_params(const uh_bow* bow, void* params120);
+/* per descriptor i: word[i] (0xFFFFFFFF if the descent ends without a leaf), weight[i], node[i] = node id at `level`
+ * (valid[i] = 0 if never recorded).  Empty input fails like the reference ("No input data"). */
+int  uh_bow_transform(uh_bow* bow, const uint8_t* desc, int n, size_t stride, int desc_bytes, int level,
+                      uint32_t* word, float* weight, uint32_t* node, uint8_t* valid);
+int  uh_bow_transform_dev(uh_bow* bow, const uint8_t* d_desc, int n, int level,
+                          uint32_t* d_word, float* d_weight, uint32_t* d_node, uint8_t* d_valid);
+double uh_bow_score(const uint32_t* ids1, const float* w1, int n1, const uint32_t* ids2, const float* w2, int n2);
+
+/* ------------------------------------------------------------------------
+ * FrameMatcher_Flann post-filter (host policy around the index) — src/utils/framematcher.cpp:228-319:
+ * per query best/second-best scan over the nn columns IN ROW ORDER (min distance gate, octave gap, optional epipolar
+ * gate 3.84*sigma^2, ratio test against a same-octave runner-up), filter_ambiguous_train (misc.cpp:153-185), then the
+ * 30-bin orientation histogram keeping the three dominant bins (:290-316, computeThreeMaxima :67-108).
+ * Returns the number of matches written (>= 0) or a negative UH_E* code.
+ * ------------------------------------------------------------------------ */
+typedef struct uh_dmatch {          /* cv::DMatch */
+    int32_t queryIdx, trainIdx, imgIdx;
+    float   distance;
+} uh_dmatch;
+
+typedef struct uh_match_filter_args {
+    int32_t nq, nn;
+    const int32_t* indices;         /* nq x nn rows of uh_knn_search (unsorted heap order, as FrameMatcher passes sorted=false) */
+    const int32_t* distances;
+    const uint32_t* map_idx_query;  /* row -> keypoint index of the query frame (manageMode), NULL = identity */
+    const uint32_t* map_idx_train;  /* index row -> keypoint index of the train frame, NULL = identity */
+    const int32_t* q_octave; const float* q_angle; const float* q_pt;   /* query und_kpts fields; q_pt (x,y) only for F12 */
+    const int32_t* t_octave; const float* t_angle; const float* t_pt;   /* train und_kpts fields */
+    const float* scale_factors;     /* query frame scaleFactors (only with F12) */
+    const float* F12;               /* row-major 3x3 fundamental matrix or NULL (no epipolar gate) */
+    float min_desc_dist, nn_match_ratio;
+    int32_t check_orientation, max_octave_diff;
+} uh_match_filter_args;
+
+int uh_match_filter(const uh_match_filter_args* args, uh_dmatch* out, int cap);
+/* filter_ambiguous_train (by_train != 0) / filter_ambiguous_query (by_train == 0), in place; returns the new count */
+int uh_filter_ambiguous(uh_dmatch* matches, int n, int by_train);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,3 +135,50 @@ def ba_problem(K=10, P=3000, seed=0, nfixed=2, outlier_frac=0.02, pose_noise=0.0
         obs_uv=np.ascontiguousarray(np.array(obs_uv, np.float32)[sel]), obs_w=np.ascontiguousarray(np.array(obs_w, np.float64)[sel]),
         poses_gt=np.stack(Tgt),
     )
+
+
+def vocabulary(k=10, depth=3, seed=0, aligment=8):
+    """Synthetic fbow vocabulary in the reference's binary block format (fbow.h:137-197, sizes from fbow.cpp:10-49):
+    a complete k-ary tree of `depth` levels; node descriptors = parent descriptor with random bit flips (so that descents are
+    meaningful), leaves get increasing word ids and random idf-like weights.  Returns (params120 bytes, blob bytes, meta)."""
+    import struct
+
+    rng = np.random.default_rng(seed)
+    nblocks = sum(k ** l for l in range(depth))
+    desc_wp = -(-32 // aligment) * aligment
+    feature_off = -(-8 // aligment) * aligment
+    child_off = feature_off + k * desc_wp
+    block_size = -(-(feature_off + k * (desc_wp + 8)) // aligment) * aligment
+    total = block_size * nblocks
+    blob = np.zeros(total, np.uint8)
+    # blocks in BFS order: block b's children blocks are first_child[b] + c
+    parent_desc = {0: rng.integers(0, 256, 32, dtype=np.uint8)}
+    next_block, word = 1, 0
+    level_of = {0: 0}
+    for b in range(nblocks):
+        base = b * block_size
+        lvl = level_of[b]
+        leaf_level = lvl == depth - 1
+        n_children = k if not (b % 7 == 3 and leaf_level) else k - 2      # a few ragged blocks (N < k)
+        blob[base:base + 2] = np.frombuffer(struct.pack("<H", n_children), np.uint8)
+        blob[base + 2:base + 4] = np.frombuffer(struct.pack("<H", 1 if leaf_level else 0), np.uint8)
+        for c in range(n_children):
+            flips = np.packbits(rng.random(256) < (0.30 / (lvl + 1)), bitorder="little")
+            d = parent_desc[b] ^ flips
+            if c == 1 and b % 5 == 0:
+                d = (parent_desc[b] ^ np.packbits(rng.random(256) < (0.30 / (lvl + 1)), bitorder="little"))
+            blob[base + feature_off + c * desc_wp: base + feature_off + c * desc_wp + 32] = d
+            info = base + child_off + c * 8
+            if leaf_level:
+                blob[info:info + 8] = np.frombuffer(struct.pack("<If", 0x80000000 | word, float(np.float32(rng.uniform(0.5, 6.0)))), np.uint8)
+                word += 1
+            else:
+                blob[info:info + 8] = np.frombuffer(struct.pack("<If", next_block, 0.0), np.uint8)
+                parent_desc[next_block] = d
+                level_of[next_block] = lvl + 1
+                next_block += 1
+        if n_children >= 2 and b % 4 == 1:      # duplicate child descriptors: the FIRST minimum must win
+            blob[base + feature_off + 1 * desc_wp: base + feature_off + 1 * desc_wp + 32] = blob[base + feature_off: base + feature_off + 32]
+    params = struct.pack("<50s2xII4xQQQQQiiI4x", b"orb", aligment, nblocks, desc_wp, block_size, feature_off, child_off, total, 0, 32, k)
+    assert len(params) == 120
+    return params, blob.tobytes(), dict(nblocks=nblocks, nwords=word, block_size=block_size)

@@ -76,12 +76,14 @@ struct BAPtrs {
     double* Hll; double* bl;  // P x 9, P x 3
     double* Hpl;              // E x 18 (6x3 row-major)
     double* Hpp; double* bp;  // nfree x 36, nfree x 6
-    double* S; double* bs;    // n x n (upper blocks written), n
+    double* S;                // (n x (n+1)) HBM workspace of the factorisation when it does not fit in LDS
+    double* Spart;            // nsplit x npairs x 42: schur partials (6x6 block + 6-vector)
     double* xp;               // n
     double* part_lin_chi;     // nPointBlocks
     double* part_maxdiag;     // nPointBlocks + nfree
     double* part_chi; double* part_scale;   // nPointBlocks
     BAState* st;
+    unsigned long long* dbg;   // 16 cycle stamps (instrumentation)
     const volatile unsigned char* stop;     // pinned host flag (may be NULL)
 };
 
@@ -140,6 +142,25 @@ __device__ __forceinline__ double block_sum(double v, double* s_red) {
     __syncthreads();
     return r;
 }
+// Deterministic block reduction of N values per thread in ONE barrier round: fixed xor-butterfly inside each wave, then
+// the four wave partials are added in wave order.  Results land in s_out[0..N) (valid for every thread after the call).
+template <int N>
+__device__ __forceinline__ void block_sum_vec(double (&v)[N], double* s_part /* 4*N */, double* s_out /* N */) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; i++) s_part[wv * N + i] = v[i];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < N) s_out[threadIdx.x] = ((s_part[threadIdx.x] + s_part[N + threadIdx.x]) + s_part[2 * N + threadIdx.x]) + s_part[3 * N + threadIdx.x];
+    __syncthreads();
+}
+
 __device__ __forceinline__ double block_max(double v, double* s_red) {
     s_red[threadIdx.x] = v;
     __syncthreads();
@@ -263,9 +284,10 @@ __global__ __launch_bounds__(kThreads) void ba_lin_kernel(BAPtrs p, BADims d) {
 #pragma unroll
             for (int a = 0; a < 6; a++) acc[21 + a] += L.B[a] * L.r0 + L.B[6 + a] * L.r1;
         }
-        double red[27];
-#pragma unroll
-        for (int i = 0; i < 27; i++) red[i] = block_sum(acc[i], s_red);
+        __shared__ double s_part[4 * 27];
+        __shared__ double s_out27[27];
+        block_sum_vec<27>(acc, s_part, s_out27);
+        const double* red = s_out27;
         if (threadIdx.x == 0) {
             double* Hp = p.Hpp + 36 * (size_t)s;
             int q = 0;
@@ -279,30 +301,32 @@ __global__ __launch_bounds__(kThreads) void ba_lin_kernel(BAPtrs p, BADims d) {
 }
 
 // ------------------------------------------------------------------------------------------------ schur
-// grid = nfree*(nfree+1)/2 pairs (i1 <= i2).  The first pair block also publishes lambda at iteration 0.
-__global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d) {
-    __shared__ double s_red[kThreads];
+// grid = npairs * nsplit.  Block (pair, chunk) accumulates the landmarks pt = chunk*256 + tid (+ nsplit*256 ...) of the
+// (i1 <= i2) block and writes a PARTIAL 6x6 (and, on diagonal pairs, a partial 6-vector); the solve kernel adds the
+// partials in chunk order.  The first block also publishes lambda at iteration 0 (computeLambdaInit).
+__global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, int nsplit) {
+    __shared__ double s_part[4 * 42];
+    __shared__ double s_out[42];
     const BAState st = *p.st;
     if (st.phase == 2) return;
     double lambda = st.lambda;
-    if (st.iteration == 0 && st.qmax == 0) {   // computeLambdaInit: tau * max |H_jj|
+    if (st.iteration == 0 && st.qmax == 0) {   // tau * max |H_jj| over poses and landmarks
         double m = 0;
         for (int i = 0; i < d.nPointBlocks + d.nfree; i++) m = fmax(m, p.part_maxdiag[i]);
         lambda = 1e-5 * m;
         if (blockIdx.x == 0 && threadIdx.x == 0) { p.st->lambda = lambda; p.st->ni = 2; }
     }
-    if ((int)blockIdx.x >= d.nfree * (d.nfree + 1) / 2) return;   // structure-only BA: the launch exists for lambda
-    // pair index -> (s1,s2)
-    int s1 = 0, rem = blockIdx.x;
+    const int npairs = d.nfree * (d.nfree + 1) / 2;
+    const int pair = blockIdx.x / nsplit, chunk = blockIdx.x - pair * nsplit;
+    if (pair >= npairs) return;   // structure-only BA: the launch exists only to publish lambda
+    int s1 = 0, rem = pair;
     while (rem >= d.nfree - s1) { rem -= d.nfree - s1; ++s1; }
     const int s2 = s1 + rem;
     const bool diag = s1 == s2;
-    double acc[36], accb[6];
+    double acc[42];
 #pragma unroll
-    for (int i = 0; i < 36; i++) acc[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) accb[i] = 0;
-    for (int pt = threadIdx.x; pt < d.P; pt += kThreads) {
+    for (int i = 0; i < 42; i++) acc[i] = 0;
+    for (int pt = chunk * kThreads + threadIdx.x; pt < d.P; pt += nsplit * kThreads) {
         const int e1 = p.edge_of[(size_t)pt * d.nfree + s1];
         if (e1 < 0 || !p.e_active[e1]) continue;
         const int e2 = diag ? e1 : p.edge_of[(size_t)pt * d.nfree + s2];
@@ -312,100 +336,185 @@ __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d) 
         for (int i = 0; i < 9; i++) D[i] = p.Hll[9 * (size_t)pt + i];
         D[0] += lambda; D[4] += lambda; D[8] += lambda;
         inv3(D, Di);
+        double b1[18], b2[18];
         const double* B1 = p.Hpl + 18 * (size_t)e1;
         const double* B2 = p.Hpl + 18 * (size_t)e2;
-        double b2[18];
 #pragma unroll
-        for (int i = 0; i < 18; i++) b2[i] = B2[i];
+        for (int i = 0; i < 18; i++) { b1[i] = B1[i]; b2[i] = B2[i]; }
+        double l0 = 0, l1 = 0, l2 = 0;
+        if (diag) { l0 = p.bl[3 * pt]; l1 = p.bl[3 * pt + 1]; l2 = p.bl[3 * pt + 2]; }
 #pragma unroll
         for (int a = 0; a < 6; a++) {
-            const double b0 = B1[a * 3], b1 = B1[a * 3 + 1], b2v = B1[a * 3 + 2];
-            const double y0 = b0 * Di[0] + b1 * Di[3] + b2v * Di[6];
-            const double y1 = b0 * Di[1] + b1 * Di[4] + b2v * Di[7];
-            const double y2 = b0 * Di[2] + b1 * Di[5] + b2v * Di[8];
+            const double y0 = b1[a * 3] * Di[0] + b1[a * 3 + 1] * Di[3] + b1[a * 3 + 2] * Di[6];
+            const double y1 = b1[a * 3] * Di[1] + b1[a * 3 + 1] * Di[4] + b1[a * 3 + 2] * Di[7];
+            const double y2 = b1[a * 3] * Di[2] + b1[a * 3 + 1] * Di[5] + b1[a * 3 + 2] * Di[8];
 #pragma unroll
             for (int c = 0; c < 6; c++) acc[a * 6 + c] += y0 * b2[c * 3] + y1 * b2[c * 3 + 1] + y2 * b2[c * 3 + 2];
-            if (diag) {
-                const double l0 = p.bl[3 * pt], l1 = p.bl[3 * pt + 1], l2 = p.bl[3 * pt + 2];
-                accb[a] += y0 * l0 + y1 * l1 + y2 * l2;   // B1 * (Dinv * bl)
-            }
+            acc[36 + a] += y0 * l0 + y1 * l1 + y2 * l2;   // B1 * (Dinv * bl), only meaningful on diagonal pairs
         }
     }
-    for (int i = 0; i < 36; i++) {
-        const double r = block_sum(acc[i], s_red);
-        if (threadIdx.x == 0) {
-            const int a = i / 6, c = i % 6;
-            double v = -r;
-            if (diag) v += p.Hpp[36 * (size_t)s1 + i] + (a == c ? lambda : 0.0);
-            p.S[(size_t)(6 * s1 + a) * d.n + 6 * s2 + c] = v;
-        }
-    }
-    if (diag)
-        for (int a = 0; a < 6; a++) {
-            const double r = block_sum(accb[a], s_red);
-            if (threadIdx.x == 0) p.bs[6 * s1 + a] = p.bp[6 * s1 + a] - r;
-        }
+    block_sum_vec<42>(acc, s_part, s_out);
+    if (threadIdx.x < 42) p.Spart[((size_t)chunk * npairs + pair) * 42 + threadIdx.x] = s_out[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------ solve + pose update
-// One workgroup.  Dense LDL^T (no pivoting; fails on a zero / non-finite pivot like Eigen's SimplicialLDLT) of the reduced
-// system, in LDS when it fits (n <= 128) else in place in HBM.  Then T_trial = exp(dx) * T_cur for the free poses.
-__global__ __launch_bounds__(kThreads) void ba_solve_kernel(BAPtrs p, BADims d, int use_lds) {
+// One workgroup.  Assembles S = Hpp + lambda I - sum of the schur partials (chunk order), factorises it as L D L^T (no
+// pivoting; fails on a zero / non-finite pivot like Eigen's SimplicialLDLT) in LDS when it fits (n <= 120) else in HBM,
+// substitutes, and writes T_trial = exp(dx) * T_cur for the free poses.  Row stride is n+1 doubles (odd) so that column
+// walks are LDS-bank-conflict free.
+template <bool USE_LDS>
+__global__ __launch_bounds__(kThreads) void ba_solve_kernel(BAPtrs p, BADims d, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) double s_mat[];
     __shared__ double s_x[6 * kMaxFree];
-    __shared__ double s_d[6 * kMaxFree];
     __shared__ int s_ok;
     const BAState st = *p.st;
     if (st.phase == 2) return;
-    const int n = d.n;
-    double* M = use_lds ? s_mat : p.S;
-    const int tid = threadIdx.x;
-    // symmetric fill: lower <- upper (the schur kernel wrote block rows s1 <= s2 only)
-    for (int i = tid; i < n * n; i += kThreads) {
-        const int r = i / n, c = i - r * n;
-        const int br = r / 6, bc = c / 6;
-        double v;
-        if (br <= bc) v = p.S[(size_t)r * n + c]; else v = p.S[(size_t)c * n + r];
-        if (use_lds) M[i] = v;
-        else if (br > bc) M[i] = v;
+    const int n = d.n, ld = n + 1;
+    const int npairs = d.nfree * (d.nfree + 1) / 2;
+    // the address space must be known at compile time: a generic pointer would turn every access into a flat_load
+    auto M = [&]() { if constexpr (USE_LDS) return s_mat; else return p.S; }();
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double lambda = st.lambda;
+#define STAMP(i) do { if (tid == 0) p.dbg[i] = __builtin_readcyclecounter(); } while (0)
+    STAMP(0);
+    // assemble the lower triangle (+ diagonal) from the pair partials (all partial loads of an element issue together)
+    __shared__ short s_pair[kMaxFree * (kMaxFree + 1) / 2][2];
+    for (int t = tid; t < npairs; t += kThreads) {
+        int s1 = 0, rem = t;
+        while (rem >= d.nfree - s1) { rem -= d.nfree - s1; ++s1; }
+        s_pair[t][0] = (short)s1; s_pair[t][1] = (short)(s1 + rem);
+    }
+    __syncthreads();
+    for (int t = tid; t < npairs * 42; t += kThreads) {
+        const int pair = t / 42, q = t - pair * 42;
+        const int s1 = s_pair[pair][0], s2 = s_pair[pair][1];
+        double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = p.Spart[((size_t)(k < nsplit ? k : 0) * npairs + pair) * 42 + q];
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (k < nsplit) v += x[k];
+        if (q >= 36) {   // b_schur = b_p - sum_l Hpl Dinv b_l (diagonal pairs carry it)
+            if (s1 == s2) s_x[6 * s1 + (q - 36)] = p.bp[6 * s1 + (q - 36)] - v;
+            continue;
+        }
+        const int a = q / 6, c = q - a * 6;
+        v = -v;
+        if (s1 == s2) v += p.Hpp[36 * (size_t)s1 + q] + (a == c ? lambda : 0.0);
+        const int r = 6 * s1 + a, cc = 6 * s2 + c;   // upper-block entry (r,cc); store it mirrored into the lower triangle
+        if (s1 == s2) { if (c <= a) M[(size_t)r * ld + cc] = v; }
+        else M[(size_t)cc * ld + r] = v;
     }
     if (tid == 0) s_ok = 1;
     __syncthreads();
-    // right-looking LDL^T: after step j, column j of M below the diagonal holds L(:,j), M[j][j] = d_j
-    for (int j = 0; j < n; j++) {
-        const double dj = M[(size_t)j * n + j];
-        if (dj == 0.0 || !isfinite(dj)) { if (tid == 0) s_ok = 0; break; }   // uniform: every thread reads the same dj
-        for (int i = j + 1 + tid; i < n; i += kThreads) M[(size_t)i * n + j] = M[(size_t)i * n + j] / dj;
-        __syncthreads();
-        const int m = n - j - 1;
-        for (int t = tid; t < m * m; t += kThreads) {
-            const int r = j + 1 + t / m, c = j + 1 + t % m;
-            if (c <= r) M[(size_t)r * n + c] -= M[(size_t)r * n + j] * M[(size_t)c * n + j] * dj;
+    STAMP(1);
+    // right-looking LDL^T on the lower triangle.  During the factorisation column j keeps L(i,j)*d_j (unscaled); all
+    // columns are scaled to L in one pass at the end, which leaves ONE barrier per elimination step.
+    if (n <= 64) {
+        // wave wv owns rows r = wv + 4q (q < 16); lane = column.  u[q] = M[r][j] are broadcast reads, the row updates touch
+        // distinct consecutive addresses (odd row stride) and are independent, so the LDS traffic pipelines.
+        const int lc = lane < n ? lane : n - 1;
+        int rowoff[16];   // 32-bit LDS element offsets of this wave's rows, hoisted out of the elimination loop
+#pragma unroll
+        for (int q = 0; q < 16; q++) { const int r = wv + 4 * q; rowoff[q] = (r < n ? r : n - 1) * ld; }
+        const int coloff = lc * ld;
+        bool failed = false;
+        for (int j = 0; j < n; j++) {
+            // every LDS read of the step (pivot, column j, own cells) is issued before anything depends on one of them
+            const double dj = M[j * ld + j];
+            const double colv = M[coloff + j];
+            double u[16], cur[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) { u[q] = M[rowoff[q] + j]; cur[q] = M[rowoff[q] + lc]; }
+            failed = failed || dj == 0.0 || !isfinite(dj);
+            const double inv = 1.0 / dj;
+            const bool col_live = lane > j && lane < n;
+            const double v = colv * inv;                                          // L(c,j), c = lane
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int r = wv + 4 * q;
+                if (r < n && lane < n) {   // each (r,lane) cell has exactly one owner thread; untouched cells are rewritten as is
+                    const bool act = r > j && col_live && lane <= r && !failed;
+                    M[rowoff[q] + lane] = act ? cur[q] - u[q] * v : cur[q];
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        if (failed && tid == 0) s_ok = 0;   // a zero / non-finite pivot froze the matrix; report the failure
+    } else {
+        for (int j = 0; j < n; j++) {
+            const double dj = M[(size_t)j * ld + j];
+            if (dj == 0.0 || !isfinite(dj)) { if (tid == 0) s_ok = 0; break; }   // uniform
+            const double inv = 1.0 / dj;
+            for (int r = j + 1 + wv; r < n; r += 4) {
+                const double lrj_d = M[(size_t)r * ld + j];
+                for (int c = j + 1 + lane; c <= r; c += 64) M[(size_t)r * ld + c] -= lrj_d * (M[(size_t)c * ld + j] * inv);
+            }
+            __syncthreads();
+        }
     }
     __syncthreads();
+    STAMP(2);
+    if (s_ok) {   // scale every column to L
+        for (int t = tid; t < n * n; t += kThreads) {
+            const int r = t / n, c = t - r * n;
+            if (c < r) M[(size_t)r * ld + c] = M[(size_t)r * ld + c] / M[(size_t)c * ld + c];
+        }
+    }
+    __syncthreads();
+    STAMP(3);
     const int ok = s_ok;
     if (ok) {
-        for (int i = tid; i < n; i += kThreads) { s_x[i] = p.bs[i]; s_d[i] = M[(size_t)i * n + i]; }
-        __syncthreads();
-        for (int j = 0; j < n; j++) {            // L y = b (column oriented)
-            const double xj = s_x[j];
-            for (int i = j + 1 + tid; i < n; i += kThreads) s_x[i] -= M[(size_t)i * n + j] * xj;
+        if (n <= 64) {
+            // one wave, x_i lives in lane i; column j of L is read conflict-free thanks to the odd row stride
+            if (wv == 0) {
+                double x = lane < n ? s_x[lane] : 0.0;
+                const int lr = lane < n ? lane : n - 1;
+                for (int j0 = 0; j0 < n; j0 += 8) {          // L y = b, 8 columns of L prefetched per round
+                    double l[8];
+#pragma unroll
+                    for (int t = 0; t < 8; t++) { const int jj = j0 + t < n ? j0 + t : n - 1; l[t] = M[(size_t)lr * ld + jj]; }
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        const int j = j0 + t;
+                        if (j < n) { const double xj = __shfl(x, j); if (lane > j && lane < n) x -= l[t] * xj; }
+                    }
+                }
+                if (lane < n) x /= M[(size_t)lane * ld + lane];
+                for (int j0 = n - 1; j0 >= 0; j0 -= 8) {     // L^T x = y
+                    double l[8];
+#pragma unroll
+                    for (int t = 0; t < 8; t++) { const int jj = j0 - t >= 0 ? j0 - t : 0; l[t] = M[(size_t)jj * ld + lr]; }
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        const int j = j0 - t;
+                        if (j >= 0) { const double xj = __shfl(x, j); if (lane < j) x -= l[t] * xj; }
+                    }
+                }
+                if (lane < n) { s_x[lane] = x; p.xp[lane] = x; }
+            }
+        } else {
+            for (int j = 0; j < n; j++) {
+                const double xj = s_x[j];
+                __syncthreads();
+                for (int i = j + 1 + tid; i < n; i += kThreads) s_x[i] -= M[(size_t)i * ld + j] * xj;
+                __syncthreads();
+            }
+            for (int i = tid; i < n; i += kThreads) s_x[i] /= M[(size_t)i * ld + i];
             __syncthreads();
+            for (int j = n - 1; j >= 0; j--) {
+                const double xj = s_x[j];
+                __syncthreads();
+                for (int i = tid; i < j; i += kThreads) s_x[i] -= M[(size_t)j * ld + i] * xj;
+                __syncthreads();
+            }
+            for (int i = tid; i < n; i += kThreads) p.xp[i] = s_x[i];
         }
-        for (int i = tid; i < n; i += kThreads) s_x[i] /= s_d[i];
-        __syncthreads();
-        for (int j = n - 1; j >= 0; j--) {       // L^T x = y
-            const double xj = s_x[j];
-            for (int i = tid; i < j; i += kThreads) s_x[i] -= M[(size_t)j * n + i] * xj;
-            __syncthreads();
-        }
-        for (int i = tid; i < n; i += kThreads) p.xp[i] = s_x[i];
     } else {
         for (int i = tid; i < n; i += kThreads) { p.xp[i] = 0.0; s_x[i] = 0.0; }
     }
     __syncthreads();
+    STAMP(4);
     if (tid == 0) p.st->solve_ok = ok;
     // pose update into the trial buffer (fixed poses are identical in both buffers and never touched)
     const int cur = st.cur, trial = cur ^ 1;
@@ -457,6 +566,7 @@ __global__ __launch_bounds__(kThreads) void ba_solve_kernel(BAPtrs p, BADims d, 
         quat_to_R(q, Ro);
         Ro[9] = t[0]; Ro[10] = t[1]; Ro[11] = t[2];
     }
+    STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------ backsub + trial errors
@@ -517,22 +627,33 @@ __global__ __launch_bounds__(kThreads) void ba_backsub_kernel(BAPtrs p, BADims d
 }
 
 // ------------------------------------------------------------------------------------------------ decide
-// One thread: the tail of OptimizationAlgorithmLevenberg::solve's do-while body plus SparseOptimizer::optimize's loop header.
-__global__ void ba_decide_kernel(BAPtrs p, BADims d) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    BAState st = *p.st;
-    if (st.phase == 2) return;
+// One wave: the tail of OptimizationAlgorithmLevenberg::solve's do-while body plus SparseOptimizer::optimize's loop header.
+__global__ __launch_bounds__(64) void ba_decide_kernel(BAPtrs p, BADims d) {
+    // the partial sums are fetched by all 64 lanes at once, then added by lane 0 in index order (deterministic)
+    __shared__ double s_lin[64], s_chi[64], s_scale[64], s_xs[6 * kMaxFree];
+    const BAState st0 = *p.st;
+    if (st0.phase == 2) return;
+    const int nb = d.nPointBlocks;
+    const int tid = threadIdx.x;
+    // nb may exceed 64 (large P): each lane pre-adds its strided share in a fixed order, lane 0 then adds the 64 lane sums
+    double l0 = 0, l1 = 0, l2 = 0;
+    for (int i = tid; i < nb; i += 64) { l0 += p.part_lin_chi[i]; l1 += p.part_chi[i]; l2 += p.part_scale[i]; }
+    s_lin[tid] = l0; s_chi[tid] = l1; s_scale[tid] = l2;
+    const double lambda0 = st0.lambda;
+    for (int i = tid; i < d.n; i += 64) { const double x = p.xp[i]; s_xs[i] = x * (lambda0 * x + p.bp[i]); }
+    __syncthreads();
+    if (tid != 0) return;
+    BAState st = st0;
     if (st.phase == 0) {   // this step linearised: currentChi = activeRobustChi2 at the current state
         double c = 0;
-        for (int i = 0; i < d.nPointBlocks; i++) c += p.part_lin_chi[i];
+        for (int i = 0; i < 64; i++) c += s_lin[i];
         st.currentChi = c;
     }
     double tempChi = 0, scale = 0;
-    for (int i = 0; i < d.nPointBlocks; i++) { tempChi += p.part_chi[i]; scale += p.part_scale[i]; }
+    for (int i = 0; i < 64; i++) { tempChi += s_chi[i]; scale += s_scale[i]; }
     st.lastChiRaw = tempChi;
-    const double lambda = st.lambda;
     if (st.solve_ok)
-        for (int i = 0; i < d.n; i++) scale += p.xp[i] * (lambda * p.xp[i] + p.bp[i]);
+        for (int i = 0; i < d.n; i++) scale += s_xs[i];
     if (!st.solve_ok) tempChi = DBL_MAX;
     double rho = st.currentChi - tempChi;
     scale += 1e-3;
@@ -670,6 +791,7 @@ struct uh_ba {
     double* d_pose0 = nullptr; double* d_pts0 = nullptr;
     unsigned char* h_stop = nullptr;      // pinned, device-visible force-stop flag
     int iters[2] = {0, 0};
+    int nsplit = 1;
     bool optimized = false;
     ~uh_ba() { if (h_stop) (void)hipHostFree(h_stop); }
 };
@@ -704,12 +826,13 @@ int enqueue_steps(uh_ba* b, int nsteps) {
     hipStream_t st = b->ctx->stream;
     const BADims& d = b->dims;
     const int npairs = d.nfree * (d.nfree + 1) / 2;
-    const int use_lds = d.n <= 128 ? 1 : 0;
-    const size_t lds = use_lds ? (size_t)d.n * d.n * sizeof(double) : 0;
+    const int use_lds = d.n <= 120 ? 1 : 0;
+    const size_t lds = use_lds ? (size_t)d.n * (d.n + 1) * sizeof(double) : 0;
     for (int s = 0; s < nsteps; s++) {
         UH_LAUNCH(b->ctx,ba_lin_kernel, dim3(d.nPointBlocks + d.nfree), dim3(kThreads), 0, b->ptrs, d);
-        UH_LAUNCH(b->ctx,ba_schur_kernel, dim3(std::max(npairs, 1)), dim3(kThreads), 0, b->ptrs, d);
-        UH_LAUNCH(b->ctx,ba_solve_kernel, dim3(1), dim3(kThreads), lds, b->ptrs, d, use_lds);
+        UH_LAUNCH(b->ctx,ba_schur_kernel, dim3(std::max(npairs, 1) * b->nsplit), dim3(kThreads), 0, b->ptrs, d, b->nsplit);
+        if (use_lds) UH_LAUNCH(b->ctx,ba_solve_kernel<true>, dim3(1), dim3(kThreads), lds, b->ptrs, d, b->nsplit);
+        else UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kThreads), lds, b->ptrs, d, b->nsplit);
         UH_LAUNCH(b->ctx,ba_backsub_kernel, dim3(d.nPointBlocks), dim3(kThreads), 0, b->ptrs, d);
         UH_LAUNCH(b->ctx,ba_decide_kernel, dim3(1), dim3(64), 0, b->ptrs, d);
     }
@@ -818,9 +941,12 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     const size_t o_act = A.take<unsigned char>(E), o_rob = A.take<unsigned char>(E), o_err = A.take<double>(2 * (size_t)E), o_chi2 = A.take<double>(E);
     const size_t o_Hll = A.take<double>(9 * (size_t)P), o_bl = A.take<double>(3 * (size_t)P), o_Hpl = A.take<double>(18 * (size_t)E);
     const size_t o_Hpp = A.take<double>(36 * (size_t)std::max(nfree, 1)), o_bp = A.take<double>(std::max(d.n, 1));
-    const size_t o_S = A.take<double>((size_t)std::max(d.n, 1) * std::max(d.n, 1)), o_bs = A.take<double>(std::max(d.n, 1)), o_xp = A.take<double>(std::max(d.n, 1));
+    const int npairs_h = nfree * (nfree + 1) / 2;
+    b->nsplit = std::max(1, std::min(8, d.nPointBlocks));
+    const size_t o_S = A.take<double>((size_t)std::max(d.n, 1) * (std::max(d.n, 1) + 1)), o_Sp = A.take<double>((size_t)b->nsplit * std::max(npairs_h, 1) * 42), o_xp = A.take<double>(std::max(d.n, 1));
     const size_t o_plc = A.take<double>(d.nPointBlocks), o_pmd = A.take<double>(d.nPointBlocks + nfree), o_pc = A.take<double>(d.nPointBlocks), o_ps = A.take<double>(d.nPointBlocks);
     const size_t o_st = A.take<BAState>(1);
+    const size_t o_dbg = A.take<unsigned long long>(16);
     int rc = b->arena.reserve(A.off + 256);
     if (rc) return rc;
     UH_HIP_CHECK(hipSetDevice(b->ctx->device));
@@ -857,9 +983,10 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     for (int i = 0; i < 2; i++) { p.pose[i] = (double*)(base + o_pose[i]); p.poseR[i] = (double*)(base + o_poseR[i]); p.pts[i] = (double*)(base + o_pts[i]); }
     p.e_active = (unsigned char*)(base + o_act); p.e_robust = (unsigned char*)(base + o_rob); p.e_err = (double*)(base + o_err); p.e_chi2 = (double*)(base + o_chi2);
     p.Hll = (double*)(base + o_Hll); p.bl = (double*)(base + o_bl); p.Hpl = (double*)(base + o_Hpl); p.Hpp = (double*)(base + o_Hpp); p.bp = (double*)(base + o_bp);
-    p.S = (double*)(base + o_S); p.bs = (double*)(base + o_bs); p.xp = (double*)(base + o_xp);
+    p.S = (double*)(base + o_S); p.Spart = (double*)(base + o_Sp); p.xp = (double*)(base + o_xp);
     p.part_lin_chi = (double*)(base + o_plc); p.part_maxdiag = (double*)(base + o_pmd); p.part_chi = (double*)(base + o_pc); p.part_scale = (double*)(base + o_ps);
     p.st = (BAState*)(base + o_st);
+    p.dbg = (unsigned long long*)(base + o_dbg);
     p.stop = nullptr;
     if (b->h_stop) {
         void* dflag = nullptr;
@@ -918,6 +1045,11 @@ int uh_ba_get_results(uh_ba* b, float* poses_out, float* points_out, double* chi
 }
 
 // final pose state (qx qy qz qw tx ty tz per frame, fp64) — used by the parity tests to state the tolerance on se3
+int uh_ba_debug_stamps(uh_ba* b, unsigned long long* out16) {
+    UH_HIP_CHECK(hipMemcpy(out16, b->ptrs.dbg, 16 * 8, hipMemcpyDeviceToHost));
+    return UH_OK;
+}
+
 int uh_ba_get_pose_state(uh_ba* b, double* pose7_out) {
     UH_REQUIRE(b && b->have_problem && b->optimized && pose7_out, "uh_ba_get_pose_state: not ready");
     BAState hs;

@@ -31,42 +31,24 @@ struct ShardBounds { int n; int b[kMaxShards + 1]; };
 
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
-// Lane-distributed ResultSet: lane j holds heap slot j.
+// Lane-distributed ResultSet: lane j holds heap slot j.  Every index below is wave-uniform (derived from ballots and
+// v_readlane results), so slot reads are single v_readlane_b32 and slot writes are v_cndmask selects — no exec-mask
+// branches inside a push.  The sifts use the "hole" formulation, which performs exactly the swaps of resultset.h.
 struct WaveHeap {
     int hd;    // per lane: distance of slot `lane`
     int hi;    // per lane: index of slot `lane`
     int size;  // wave-uniform
     int lane;
 
+    __device__ __forceinline__ void put(int slot, int d, int i) {
+        const bool m = lane == slot;
+        hd = m ? d : hd;
+        hi = m ? i : hi;
+    }
     __device__ __forceinline__ void swap(int a, int b) {
-        int da = rl(hd, a), db = rl(hd, b), ia = rl(hi, a), ib = rl(hi, b);
-        if (lane == a) { hd = db; hi = ib; }
-        if (lane == b) { hd = da; hi = ia; }
-    }
-    // resultset.h:93-100 ("down": sift a freshly appended slot towards the root)
-    __device__ __forceinline__ void sift_to_root(int index) {
-        while (index != 0) {
-            int parent = (index - 1) >> 1;
-            if (rl(hd, parent) < rl(hd, index)) { swap(index, parent); index = parent; }
-            else break;
-        }
-    }
-    // resultset.h:104-135 ("up": sift the root replacement towards the leaves)
-    __device__ __forceinline__ void sift_to_leaves(int index) {
-        for (;;) {
-            int left = 2 * index + 1, right = 2 * index + 2;
-            if (left >= size) return;
-            if (right >= size) {
-                if (rl(hd, index) < rl(hd, left)) swap(index, left);
-                return;
-            }
-            int dl = rl(hd, left), dr = rl(hd, right), di = rl(hd, index);
-            if (dr < dl) {
-                if (di < dl) { swap(index, left); index = left; } else return;
-            } else {
-                if (di < dr) { swap(index, right); index = right; } else return;
-            }
-        }
+        const int da = rl(hd, a), db = rl(hd, b), ia = rl(hi, a), ib = rl(hi, b);
+        put(a, db, ib);
+        put(b, da, ia);
     }
     // accept test of resultset.h:66-69 (radius bound, then "full and not better than the worst")
     __device__ __forceinline__ bool accepts(int d, int k, int maxd) const {
@@ -77,12 +59,43 @@ struct WaveHeap {
     // resultset.h:64-82, caller has already established accepts(d)
     __device__ __forceinline__ void push_accepted(int d, int idx, int k) {
         if (size >= k) {
-            swap(0, size - 1);
-            size--;
-            if (size > 1) sift_to_leaves(0);
+            // swap(0,size-1); size--; if (size>1) up(0): the old root moves to slot size-1, which the new element
+            // overwrites below, so only the old LAST element has to be re-seated from the root downwards ("up", :104-135)
+            const int last = size - 1;
+            const int md = rl(hd, last), mi = rl(hi, last);
+            size = last;
+            if (size >= 1) {
+                int pos = 0;
+                if (size > 1) {
+                    for (;;) {
+                        const int l = 2 * pos + 1, r = l + 1;
+                        if (l >= size) break;
+                        const int dl = rl(hd, l);
+                        if (r >= size) {
+                            if (md < dl) { put(pos, dl, rl(hi, l)); pos = l; }
+                            break;
+                        }
+                        const int dr = rl(hd, r);
+                        const int c = (dr < dl) ? l : r;
+                        const int dc = (dr < dl) ? dl : dr;
+                        if (!(md < dc)) break;
+                        put(pos, dc, rl(hi, c));
+                        pos = c;
+                    }
+                }
+                put(pos, md, mi);
+            }
         }
-        if (lane == size) { hd = d; hi = idx; }
-        if (size > 0) sift_to_root(size);
+        // append at slot `size` and sift towards the root ("down", :93-100)
+        int pos = size;
+        while (pos != 0) {
+            const int parent = (pos - 1) >> 1;
+            const int dp = rl(hd, parent);
+            if (!(dp < d)) break;
+            put(pos, dp, rl(hi, parent));
+            pos = parent;
+        }
+        put(pos, d, idx);
         size++;
     }
     __device__ __forceinline__ int threshold(int k) const { return size >= k ? rl(hd, 0) : 0x7fffffff; }

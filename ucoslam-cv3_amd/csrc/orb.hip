@@ -269,6 +269,55 @@ __global__ __launch_bounds__(256) void cell_nms_kernel(const Plan* __restrict__ 
     }
 }
 
+struct SelectArgs {
+    const LevelDesc* L;
+    const int* cc;
+    const uint32_t* cbase;
+    uint32_t* lsel;
+    int* level_count;
+    const int* s_nkeys; const int* s_ret; const int* s_off; const int* s_out;
+    int nCells, iniTh, total;
+};
+
+// per-cell retainBest + truncate (:1053-1055), concatenation (:1058-1065), level-wide retainBest + truncate (:1069-1073),
+// computeDescriptors' border filter (:1124-1130).  WorkPtr is either an LDS or a global pointer (static address space).
+template <typename WorkPtr>
+__device__ __forceinline__ void select_body(WorkPtr work, const SelectArgs& A) {
+    const LevelDesc& L = *A.L;
+    WorkPtr cat = work + A.s_off[A.nCells];
+    for (int c = threadIdx.x; c < A.nCells; c += 256) {
+        const int nk = A.s_nkeys[c], ret = A.s_ret[c];
+        if (nk == 0) continue;
+        const uint32_t* src = A.cbase + (size_t)c * L.cellCap;
+        WorkPtr w = work + A.s_off[c];
+        const int n7 = A.cc[2 * c], n20 = A.cc[2 * c + 1];
+        if (n20 > 3) { int k = 0; for (int i = 0; i < n7; i++) { uint32_t e = src[i]; if ((int)(e >> 24) >= A.iniTh) w[k++] = e; } }
+        else for (int i = 0; i < n7; i++) w[i] = src[i];
+        // KeyPointsFilter::retainBest(keysCell, ret) then resize(ret): only the nth_element data movement matters
+        if (ret > 0 && nk > ret) uh_sel::nth_element_desc(w, nk, ret - 1);
+        WorkPtr o = cat + A.s_out[c];
+        for (int i = 0; i < ret; i++) o[i] = w[i];
+    }
+    __syncthreads();
+    int total = A.total;
+    if (total > L.nDesired) {   // :1069-1073
+        if (threadIdx.x == 0 && L.nDesired > 0) uh_sel::nth_element_desc(cat, total, L.nDesired - 1);
+        total = L.nDesired;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {   // border filter, order preserving; the reference applies it before describing
+        const int maxX = L.w - EDGE, maxY = L.h - EDGE;
+        int k = 0;
+        for (int i = 0; i < total; i++) {
+            const uint32_t e = cat[i];
+            const int x = e & 0xFFF, y = (e >> 12) & 0xFFF;
+            if (x < EDGE || y < EDGE || x > maxX || y > maxY) continue;
+            A.lsel[k++] = e;
+        }
+        *A.level_count = k;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ selection
 // One workgroup per (frame, level): quota redistribution (:994-1039), per-cell retainBest + truncate (:1053-1055),
 // concatenation in cell-row-major order (:1058-1065), level-wide retainBest + truncate (:1069-1073).
@@ -324,45 +373,13 @@ __global__ __launch_bounds__(256) void select_kernel(const Plan* __restrict__ pl
         s_total = q;
     }
     __syncthreads();
-    // workspace: LDS when the level's filtered candidates + concatenation fit, else HBM scratch
+    // workspace: LDS when the level's filtered candidates + concatenation fit, else HBM scratch.  The two calls are
+    // separate instantiations so that the pointer's address space is static (a generic pointer would compile every
+    // access of the selection into a flat_load).
     const int need = s_off[nCells] + s_out[nCells];
-    uint32_t* work = (need <= lds_entries) ? s_dyn : (work_g + (size_t)frame * work_frame_stride + 2 * (size_t)L.cand_off);
-    uint32_t* cat = work + s_off[nCells];
-
-    for (int c = threadIdx.x; c < nCells; c += 256) {
-        const int nk = s_nkeys[c], ret = s_ret[c];
-        if (nk == 0) continue;
-        const uint32_t* src = cbase + (size_t)c * L.cellCap;
-        uint32_t* w = work + s_off[c];
-        const int n7 = cc[2 * c], n20 = cc[2 * c + 1];
-        if (n20 > 3) { int k = 0; for (int i = 0; i < n7; i++) { uint32_t e = src[i]; if ((int)(e >> 24) >= iniTh) w[k++] = e; } }
-        else for (int i = 0; i < n7; i++) w[i] = src[i];
-        // KeyPointsFilter::retainBest(keysCell, ret) then resize(ret): only the nth_element data movement matters
-        if (ret > 0 && nk > ret) uh_sel::nth_element_desc(w, nk, ret - 1);
-        uint32_t* o = cat + s_out[c];
-        for (int i = 0; i < ret; i++) o[i] = w[i];
-    }
-    __syncthreads();
-    int total = s_total;
-    if (total > L.nDesired) {   // :1069-1073
-        if (threadIdx.x == 0) {
-            if (L.nDesired > 0) uh_sel::nth_element_desc(cat, total, L.nDesired - 1);
-        }
-        total = L.nDesired;
-        __syncthreads();
-    }
-    // computeDescriptors' border filter (:1124-1130), order preserving; the reference applies it before describing
-    if (threadIdx.x == 0) {
-        const int maxX = L.w - EDGE, maxY = L.h - EDGE;
-        int k = 0;
-        for (int i = 0; i < total; i++) {
-            const uint32_t e = cat[i];
-            const int x = e & 0xFFF, y = (e >> 12) & 0xFFF;
-            if (x < EDGE || y < EDGE || x > maxX || y > maxY) continue;
-            lsel[k++] = e;
-        }
-        level_counts[(size_t)frame * kMaxLevels + lvl] = k;
-    }
+    SelectArgs A{&L, cc, cbase, lsel, level_counts + (size_t)frame * kMaxLevels + lvl, s_nkeys, s_ret, s_off, s_out, nCells, iniTh, s_total};
+    if (need <= lds_entries) select_body(s_dyn, A);
+    else select_body(work_g + (size_t)frame * work_frame_stride + 2 * (size_t)L.cand_off, A);
 }
 
 // ------------------------------------------------------------------------------------------------ orientation + rBRIEF
