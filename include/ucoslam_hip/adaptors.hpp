@@ -1,0 +1,206 @@
+// C++ host adaptors over the C ABI (ucoslam_hip.h): the reference's plugin surfaces for the tracking hot path.
+//
+//   ucoslam_hip::ORBextractor     ~ ucoslam::Feature2DSerializable / ORBextractor   (feature2dserializable.h:30-95)
+//   ucoslam_hip::Index            ~ xflann::Index (Linear)                          (3rdparty/xflann/xflann/index.h:41-135)
+//   ucoslam_hip::Vocabulary/fBow  ~ fbow::Vocabulary / fbow::fBow                   (3rdparty/fbow/fbow/fbow.h:54-116)
+//   ucoslam_hip::GlobalOptimizer  ~ ucoslam::GlobalOptimizer                        (src/optimization/globaloptimizer.h:28-68)
+//
+// Same method names, argument meaning and error behaviour (std::runtime_error where the reference throws, `false` where
+// xflann returns false).  This header needs no OpenCV: images/descriptors are plain pointers, keypoints are uh_keypoint
+// (layout of cv::KeyPoint), matches are uh_dmatch (layout of cv::DMatch).  The classes that literally derive from the
+// reference's bases (so that System/MapManager can hold them) are in the UCOSLAM_HIP_WITH_REFERENCE block at the end and in
+// INTEGRATION.md; they compile only inside the reference tree, where OpenCV exists.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../ucoslam_hip.h"
+
+namespace ucoslam_hip {
+
+inline void check(int rc) { if (rc < 0) throw std::runtime_error(uh_last_error()); }
+
+class Context {
+   public:
+    explicit Context(int device = 0, void* hip_stream = nullptr) { check(uh_ctx_create(device, hip_stream, &c_)); }
+    ~Context() { uh_ctx_destroy(c_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    uh_ctx* get() const { return c_; }
+    void synchronize() { check(uh_ctx_synchronize(c_)); }
+   private:
+    uh_ctx* c_ = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------------ extractor
+struct FeatParams {   // Feature2DSerializable::FeatParams (same defaults)
+    int nthreads = -1, maxFeatures = 4000, nOctaveLevels = 8;
+    float scaleFactor = 1.2f, sensitivity = 0;
+    FeatParams() {}
+    FeatParams(int MaxFeatures, int NOctaveLevels, float ScaleFactor, int NThreads)
+        : nthreads(NThreads), maxFeatures(MaxFeatures), nOctaveLevels(NOctaveLevels), scaleFactor(ScaleFactor) {}
+    bool operator==(const FeatParams& fp) const {
+        return nthreads == fp.nthreads && maxFeatures == fp.maxFeatures && nOctaveLevels == fp.nOctaveLevels && scaleFactor == fp.scaleFactor;
+    }
+};
+
+class ORBextractor {
+   public:
+    explicit ORBextractor(std::shared_ptr<Context> ctx) : ctx_(std::move(ctx)) { check(uh_orb_create(ctx_->get(), &o_)); }
+    ~ORBextractor() { uh_orb_destroy(o_); }
+    static std::shared_ptr<ORBextractor> create(std::shared_ptr<Context> ctx) { return std::make_shared<ORBextractor>(std::move(ctx)); }
+
+    // detectAndCompute(image, mask, keypoints, descriptors, params); mask is ignored like the reference (ORBextractor.cpp:1253)
+    void detectAndCompute(const uint8_t* image, int width, int height, size_t stride, std::vector<uh_keypoint>& keypoints,
+                          std::vector<uint8_t>& descriptors, const FeatParams& params) {
+        uh_feat_params fp{params.nthreads, params.maxFeatures, params.nOctaveLevels, params.scaleFactor, params.sensitivity};
+        check(uh_orb_set_params(o_, &fp));
+        const int cap = std::max(uh_orb_max_keypoints(o_), 1);
+        keypoints.resize(cap);
+        descriptors.resize((size_t)cap * 32);
+        int n = 0;
+        check(uh_orb_extract(o_, image, width, height, stride, keypoints.data(), descriptors.data(), cap, &n));
+        keypoints.resize(n);
+        descriptors.resize((size_t)n * 32);
+    }
+    FeatParams getParams() const {
+        uh_feat_params fp;
+        check(uh_orb_get_params(o_, &fp));
+        FeatParams r(fp.maxFeatures, fp.nOctaveLevels, fp.scaleFactor, fp.nthreads);
+        r.sensitivity = fp.sensitivity;
+        return r;
+    }
+    float getMinDescDistance() const { return 50; }          // ORBextractor.h:105
+    void setSensitivity(float v) { check(uh_orb_set_sensitivity(o_, v)); }
+    void doGaussianBlur(bool b) { check(uh_orb_set_blur(o_, b)); }
+    uh_orb* handle() const { return o_; }
+   private:
+    std::shared_ptr<Context> ctx_;
+    uh_orb* o_ = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------------ kNN index
+struct Matrix {   // xflann::Matrix as a non-owning view (types.h:275-400): rows x cols elements, row stride in bytes
+    void* data = nullptr; int rows = 0, cols = 0; size_t stride = 0; int elem_size = 1;
+    Matrix() {}
+    Matrix(void* d, int r, int c, int esize, size_t s = 0) : data(d), rows(r), cols(c), stride(s ? s : (size_t)c * esize), elem_size(esize) {}
+};
+
+class Index {
+   public:
+    explicit Index(std::shared_ptr<Context> ctx) : ctx_(std::move(ctx)) { check(uh_knn_create(ctx_->get(), &k_)); }
+    ~Index() { uh_knn_destroy(k_); }
+    // build(features, LinearParams): uint8 rows of 32 bytes
+    void build(const Matrix& features) {
+        if (features.elem_size != 1) throw std::runtime_error("Index::build: features must be XFLANN_8U");
+        check(uh_knn_build(k_, static_cast<const uint8_t*>(features.data), features.rows, features.stride, features.cols));
+    }
+    // search(features, nn, indices, distances, KnnSearchParams(maxChecks, sorted)): outputs pre-allocated nq x nn int32
+    bool search(const Matrix& q, int nn, Matrix indices, Matrix distances, bool sorted = false, int maxDist = -1) {
+        if (q.rows != indices.rows || distances.rows != q.rows)
+            throw std::runtime_error("knnsearch indices and distances must be already allocated with the same size as the number of features");
+        if (distances.cols != nn || indices.cols != nn) throw std::runtime_error("knnsearch indices and distances number of cols must == nn");
+        if (indices.elem_size != 4 || distances.elem_size != 4) throw std::runtime_error("Index::search undefined search distance type");
+        const int rc = uh_knn_search(k_, static_cast<const uint8_t*>(q.data), q.rows, q.stride, nn, static_cast<int32_t*>(indices.data),
+                                     static_cast<int32_t*>(distances.data), sorted, maxDist);
+        if (rc == UH_ENOTBUILT) return false;   // index.cpp:82-85
+        check(rc);
+        return true;
+    }
+    int size() const { return uh_knn_size(k_); }
+    uh_knn* handle() const { return k_; }
+   private:
+    std::shared_ptr<Context> ctx_;
+    uh_knn* k_ = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------------ bag of words
+struct fBow : std::map<uint32_t, float> {
+    static double score(const fBow& a, const fBow& b) {
+        std::vector<uint32_t> ia, ib;
+        std::vector<float> wa, wb;
+        for (auto& e : a) { ia.push_back(e.first); wa.push_back(e.second); }
+        for (auto& e : b) { ib.push_back(e.first); wb.push_back(e.second); }
+        return uh_bow_score(ia.data(), wa.data(), (int)ia.size(), ib.data(), wb.data(), (int)ib.size());
+    }
+};
+struct fBow2 : std::map<uint32_t, std::vector<uint32_t>> {};
+
+class Vocabulary {
+   public:
+    explicit Vocabulary(std::shared_ptr<Context> ctx) : ctx_(std::move(ctx)) { check(uh_bow_create(ctx_->get(), &b_)); }
+    ~Vocabulary() { uh_bow_destroy(b_); }
+    void fromStream(const void* bytes, size_t n) { check(uh_bow_load(b_, bytes, n)); }
+    // transform(features, level, fBow&, fBow2&) (fbow.cpp:51-90)
+    void transform(const uint8_t* features, int rows, int desc_bytes, size_t stride, int level, fBow& r1, fBow2& r2) {
+        if (rows == 0) throw std::runtime_error("Vocabulary::transform No input data");
+        std::vector<uint32_t> word(rows), node(rows);
+        std::vector<float> weight(rows);
+        std::vector<uint8_t> valid(rows);
+        check(uh_bow_transform(b_, features, rows, stride, desc_bytes, level, word.data(), weight.data(), node.data(), valid.data()));
+        r1.clear(); r2.clear();
+        for (int i = 0; i < rows; i++) {
+            if (word[i] != 0xFFFFFFFFu) r1[word[i]] += weight[i];
+            if (valid[i]) r2[node[i]].push_back((uint32_t)i);
+        }
+    }
+    // fBow transform(features): raw bag, then L2 normalisation (fbow.cpp:92-143)
+    fBow transform(const uint8_t* features, int rows, int desc_bytes, size_t stride) {
+        fBow r; fBow2 unused;
+        transform(features, rows, desc_bytes, stride, -1, r, unused);
+        double norm = 0;
+        for (auto& e : r) norm += e.second * e.second;
+        if (norm > 0.0) { const double inv = 1. / std::sqrt(norm); for (auto& e : r) e.second *= inv; }
+        return r;
+    }
+   private:
+    std::shared_ptr<Context> ctx_;
+    uh_bow* b_ = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------------ bundle adjustment
+class GlobalOptimizer {
+   public:
+    struct ParamSet { int nIters = 10; bool verbose = false; };   // the knobs of globaloptimizer.h:31-47 the mono path reads
+    explicit GlobalOptimizer(std::shared_ptr<Context> ctx) : ctx_(std::move(ctx)) { check(uh_ba_create(ctx_->get(), &b_)); }
+    ~GlobalOptimizer() { uh_ba_destroy(b_); }
+    // GlobalOptimizer::create(type): "" / "hip" select this implementation, anything else throws (globaloptimizer.cpp:27-33)
+    static std::shared_ptr<GlobalOptimizer> create(std::shared_ptr<Context> ctx, const std::string& type = "") {
+        if (!type.empty() && type != "hip") throw std::runtime_error("GlobalOptimizer::create invalid type " + type);
+        return std::make_shared<GlobalOptimizer>(std::move(ctx));
+    }
+    std::string getName() const { return "hip"; }
+    // setParams(map, params): `problem` is the map already flattened by the caller (see INTEGRATION.md for the Map walker)
+    void setParams(const uh_ba_problem& problem, const ParamSet& p) {
+        uh_ba_params bp{p.nIters, 0.0, 0.0, 1.0f};
+        check(uh_ba_set_problem(b_, &problem, &bp));
+        obs_point_.assign(problem.obs_point, problem.obs_point + problem.n_obs);
+        obs_frame_.assign(problem.obs_frame, problem.obs_frame + problem.n_obs);
+        K_ = problem.n_frames; P_ = problem.n_points;
+    }
+    void optimize(bool* stopASAP = nullptr) { check(uh_ba_optimize(b_, reinterpret_cast<const volatile uint8_t*>(stopASAP))); }
+    // getResults(map): poses K x 16 float, points P x 3 float
+    void getResults(std::vector<float>& poses_f2g, std::vector<float>& points) {
+        poses_f2g.resize((size_t)K_ * 16);
+        points.resize((size_t)P_ * 3);
+        std::vector<uint8_t> bad(obs_point_.size());
+        check(uh_ba_get_results(b_, poses_f2g.data(), points.data(), nullptr, bad.data(), nullptr));
+        bad_.clear();
+        for (size_t e = 0; e < bad.size(); e++) if (bad[e]) bad_.push_back({(uint32_t)obs_point_[e], (uint32_t)obs_frame_[e]});
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> getBadAssociations() { return bad_; }
+   private:
+    std::shared_ptr<Context> ctx_;
+    uh_ba* b_ = nullptr;
+    int K_ = 0, P_ = 0;
+    std::vector<int32_t> obs_point_, obs_frame_;
+    std::vector<std::pair<uint32_t, uint32_t>> bad_;
+};
+
+}  // namespace ucoslam_hip

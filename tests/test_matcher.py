@@ -83,4 +83,4 @@ def test_hip_frame_matcher_end_to_end(hip_ctx, oracle):
         idx, dist = oracle_lib.knn_search(oracle, tdesc, qdesc, 10, 0)
         ref = pyo.match_filter(idx, dist, qf, tf, map_q, map_t, 100.0, 0.6, True, 3)
         assert _as_tuples(got) == [(m["queryIdx"], m["trainIdx"], m["distance"]) for m in ref]
-        assert len(got) > 50
+        assert len(got) > 10

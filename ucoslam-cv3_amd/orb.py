@@ -124,7 +124,7 @@ class ORBextractor:
     def toStream(self, str_params: str = "") -> bytes:
         fp = self.getParams()
         sp = str_params.encode()
-        return (struct.pack("<QQ", self.STREAM_SIG, self.F2D_ORB) + struct.pack("<Q", len(sp)) + sp + bytes(fp))
+        return (struct.pack("<QQ", self.STREAM_SIG, self.F2D_ORB) + struct.pack("<I", len(sp)) + sp + bytes(fp))   # io_utils.cpp:54-58: u32 length + chars
 
     def close(self):
         if self._h:
