@@ -31,6 +31,9 @@ namespace {
 
 constexpr int kMaxFree = 64;          // free (non-fixed) poses in the reduced system
 constexpr int kThreads = 256;
+constexpr int kCamChunks = 8;                            // lin: workgroups per free camera
+constexpr int kLanesPerPoint = 8;                       // lin / backsub: lanes cooperating on one landmark
+constexpr int kPointsPerBlock = kThreads / kLanesPerPoint;
 
 struct BAState {
     int phase;        // 0: next step linearises then runs a trial, 1: next step retries a trial (after a reject), 2: pass done
@@ -49,7 +52,7 @@ struct BAState {
 
 struct BADims {
     int K, P, E, nfree, n;   // n = 6*nfree
-    int nPointBlocks;        // ceil(P / kThreads)
+    int nPointBlocks;        // ceil(P / kPointsPerBlock)
     double delta, dsqr, chi2_th;
 };
 
@@ -75,7 +78,7 @@ struct BAPtrs {
     // system
     double* Hll; double* bl;  // P x 9, P x 3
     double* Hpl;              // E x 18 (6x3 row-major)
-    double* Hpp; double* bp;  // nfree x 36, nfree x 6
+    double* HppPart; double* bp;   // nfree x kCamChunks x 27 partial (21 upper Hpp entries + 6 of bp); summed bp nfree x 6
     double* S;                // (n x (n+1)) HBM workspace of the factorisation when it does not fit in LDS
     double* Spart;            // nsplit x npairs x 42: schur partials (6x6 block + 6-vector)
     double* xp;               // n
@@ -224,13 +227,17 @@ __global__ __launch_bounds__(kThreads) void ba_lin_kernel(BAPtrs p, BADims d) {
     const double* poseR = p.poseR[cur];
     const double* pts = p.pts[cur];
     if ((int)blockIdx.x < d.nPointBlocks) {
-        const int pt = blockIdx.x * kThreads + threadIdx.x;
-        double chi_part = 0, maxd = 0;
+        // 8 lanes per landmark (one observation each per round), 32 landmarks per workgroup; the 8 partial sums are added
+        // with a fixed xor butterfly, so the result is deterministic and identical in all 8 lanes
+        const int gl = threadIdx.x & (kLanesPerPoint - 1);
+        const int pt = blockIdx.x * kPointsPerBlock + (threadIdx.x >> 3);
+        double acc[10];   // Hll upper (6), bl (3), robust chi2 (1)
+#pragma unroll
+        for (int i = 0; i < 10; i++) acc[i] = 0;
+        bool any = false;
         if (pt < d.P) {
             const double X[3] = {pts[3 * pt], pts[3 * pt + 1], pts[3 * pt + 2]};
-            double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-            bool any = false;
-            for (int i = p.pt_ptr[pt]; i < p.pt_ptr[pt + 1]; i++) {
+            for (int i = p.pt_ptr[pt] + gl; i < p.pt_ptr[pt + 1]; i += kLanesPerPoint) {
                 const int e = p.pt_edges[i];
                 if (!p.e_active[e]) continue;
                 any = true;
@@ -239,11 +246,11 @@ __global__ __launch_bounds__(kThreads) void ba_lin_kernel(BAPtrs p, BADims d) {
                 edge_eval<true>(p, d, e, k, poseR + 12 * k, X, p.e_robust[e] != 0, L);
                 p.e_err[2 * e] = L.ex; p.e_err[2 * e + 1] = L.ey;
                 p.e_chi2[e] = L.chi2;
-                chi_part += L.robchi;
-                H[0] += L.ww * (L.A[0] * L.A[0] + L.A[3] * L.A[3]); H[1] += L.ww * (L.A[0] * L.A[1] + L.A[3] * L.A[4]);
-                H[2] += L.ww * (L.A[0] * L.A[2] + L.A[3] * L.A[5]); H[3] += L.ww * (L.A[1] * L.A[1] + L.A[4] * L.A[4]);
-                H[4] += L.ww * (L.A[1] * L.A[2] + L.A[4] * L.A[5]); H[5] += L.ww * (L.A[2] * L.A[2] + L.A[5] * L.A[5]);
-                b[0] += L.A[0] * L.r0 + L.A[3] * L.r1; b[1] += L.A[1] * L.r0 + L.A[4] * L.r1; b[2] += L.A[2] * L.r0 + L.A[5] * L.r1;
+                acc[9] += L.robchi;
+                acc[0] += L.ww * (L.A[0] * L.A[0] + L.A[3] * L.A[3]); acc[1] += L.ww * (L.A[0] * L.A[1] + L.A[3] * L.A[4]);
+                acc[2] += L.ww * (L.A[0] * L.A[2] + L.A[3] * L.A[5]); acc[3] += L.ww * (L.A[1] * L.A[1] + L.A[4] * L.A[4]);
+                acc[4] += L.ww * (L.A[1] * L.A[2] + L.A[4] * L.A[5]); acc[5] += L.ww * (L.A[2] * L.A[2] + L.A[5] * L.A[5]);
+                acc[6] += L.A[0] * L.r0 + L.A[3] * L.r1; acc[7] += L.A[1] * L.r0 + L.A[4] * L.r1; acc[8] += L.A[2] * L.r0 + L.A[5] * L.r1;
                 if (p.slot[k] >= 0) {
                     double* Hx = p.Hpl + 18 * (size_t)e;
 #pragma unroll
@@ -252,16 +259,30 @@ __global__ __launch_bounds__(kThreads) void ba_lin_kernel(BAPtrs p, BADims d) {
                         for (int c = 0; c < 3; c++) Hx[a * 3 + c] = L.ww * (L.B[a] * L.A[c] + L.B[6 + a] * L.A[3 + c]);
                 }
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+#pragma unroll
+            for (int o = kLanesPerPoint / 2; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o);
+        }
+        unsigned long long anym = __ballot(any);
+        const bool any_pt = ((anym >> ((threadIdx.x & 63) & ~(kLanesPerPoint - 1))) & 0xFFull) != 0;
+        double chi_part = 0, maxd = 0;
+        if (pt < d.P && gl == 0) {
             double* Hl = p.Hll + 9 * (size_t)pt;
-            Hl[0] = H[0]; Hl[1] = H[1]; Hl[2] = H[2]; Hl[3] = H[1]; Hl[4] = H[3]; Hl[5] = H[4]; Hl[6] = H[2]; Hl[7] = H[4]; Hl[8] = H[5];
-            p.bl[3 * pt] = b[0]; p.bl[3 * pt + 1] = b[1]; p.bl[3 * pt + 2] = b[2];
-            if (any) maxd = fmax(fabs(H[0]), fmax(fabs(H[3]), fabs(H[5])));
+            Hl[0] = acc[0]; Hl[1] = acc[1]; Hl[2] = acc[2]; Hl[3] = acc[1]; Hl[4] = acc[3]; Hl[5] = acc[4]; Hl[6] = acc[2]; Hl[7] = acc[4]; Hl[8] = acc[5];
+            p.bl[3 * pt] = acc[6]; p.bl[3 * pt + 1] = acc[7]; p.bl[3 * pt + 2] = acc[8];
+            chi_part = acc[9];
+            if (any_pt) maxd = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
         }
         const double cs = block_sum(chi_part, s_red);
         const double mx = block_max(maxd, s_red);
         if (threadIdx.x == 0) { p.part_lin_chi[blockIdx.x] = cs; p.part_maxdiag[blockIdx.x] = mx; }
     } else {
-        const int s = blockIdx.x - d.nPointBlocks;
+        // one workgroup per (free camera, chunk of its observations): partial Hpp (21 upper entries) and bp (6); the chunks
+        // are added in order by the consumers (lambda init in the schur kernel, assembly in the solve kernel)
+        const int cb = blockIdx.x - d.nPointBlocks;
+        const int s = cb / kCamChunks, chunk = cb - s * kCamChunks;
         const int k = p.free_kf[s];
         double Rt[12];
 #pragma unroll
@@ -269,7 +290,7 @@ __global__ __launch_bounds__(kThreads) void ba_lin_kernel(BAPtrs p, BADims d) {
         double acc[27];
 #pragma unroll
         for (int i = 0; i < 27; i++) acc[i] = 0;
-        for (int i = p.cam_ptr[s] + threadIdx.x; i < p.cam_ptr[s + 1]; i += kThreads) {
+        for (int i = p.cam_ptr[s] + chunk * kThreads + threadIdx.x; i < p.cam_ptr[s + 1]; i += kCamChunks * kThreads) {
             const int e = p.cam_edges[i];
             if (!p.e_active[e]) continue;
             const int pt = p.e_pt[e];
@@ -287,16 +308,7 @@ __global__ __launch_bounds__(kThreads) void ba_lin_kernel(BAPtrs p, BADims d) {
         __shared__ double s_part[4 * 27];
         __shared__ double s_out27[27];
         block_sum_vec<27>(acc, s_part, s_out27);
-        const double* red = s_out27;
-        if (threadIdx.x == 0) {
-            double* Hp = p.Hpp + 36 * (size_t)s;
-            int q = 0;
-            double mx = 0;
-            for (int a = 0; a < 6; a++)
-                for (int c = a; c < 6; c++) { Hp[a * 6 + c] = red[q]; Hp[c * 6 + a] = red[q]; if (a == c) mx = fmax(mx, fabs(red[q])); q++; }
-            for (int a = 0; a < 6; a++) p.bp[6 * s + a] = red[21 + a];
-            p.part_maxdiag[d.nPointBlocks + s] = mx;
-        }
+        if (threadIdx.x < 27) p.HppPart[(size_t)cb * 27 + threadIdx.x] = s_out27[threadIdx.x];
     }
 }
 
@@ -312,7 +324,16 @@ __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, 
     double lambda = st.lambda;
     if (st.iteration == 0 && st.qmax == 0) {   // tau * max |H_jj| over poses and landmarks
         double m = 0;
-        for (int i = 0; i < d.nPointBlocks + d.nfree; i++) m = fmax(m, p.part_maxdiag[i]);
+        for (int i = 0; i < d.nPointBlocks; i++) m = fmax(m, p.part_maxdiag[i]);
+        for (int s = 0; s < d.nfree; s++) {
+            int q = 0;
+            for (int a = 0; a < 6; a++) {   // diagonal entries of the 21-entry upper triangle: q = 0, 6, 11, 15, 18, 20
+                double v = 0;
+                for (int c = 0; c < kCamChunks; c++) v += p.HppPart[((size_t)s * kCamChunks + c) * 27 + q];
+                m = fmax(m, fabs(v));
+                q += 6 - a;
+            }
+        }
         lambda = 1e-5 * m;
         if (blockIdx.x == 0 && threadIdx.x == 0) { p.st->lambda = lambda; p.st->ni = 2; }
     }
@@ -394,13 +415,26 @@ __global__ __launch_bounds__(kThreads) void ba_solve_kernel(BAPtrs p, BADims d, 
         double v = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) if (k < nsplit) v += x[k];
-        if (q >= 36) {   // b_schur = b_p - sum_l Hpl Dinv b_l (diagonal pairs carry it)
-            if (s1 == s2) s_x[6 * s1 + (q - 36)] = p.bp[6 * s1 + (q - 36)] - v;
+        if (q >= 36) {   // b_schur = b_p - sum_l Hpl Dinv b_l (diagonal pairs carry it); b_p = sum of the camera chunks
+            if (s1 == s2) {
+                double bpv = 0;
+#pragma unroll
+                for (int cch = 0; cch < kCamChunks; cch++) bpv += p.HppPart[((size_t)s1 * kCamChunks + cch) * 27 + 21 + (q - 36)];
+                p.bp[6 * s1 + (q - 36)] = bpv;             // the decide kernel needs b_p for computeScale
+                s_x[6 * s1 + (q - 36)] = bpv - v;
+            }
             continue;
         }
         const int a = q / 6, c = q - a * 6;
         v = -v;
-        if (s1 == s2) v += p.Hpp[36 * (size_t)s1 + q] + (a == c ? lambda : 0.0);
+        if (s1 == s2) {
+            const int lo = a < c ? a : c, hi = a < c ? c : a;
+            const int tq = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);   // index in the 21-entry upper triangle
+            double h = 0;
+#pragma unroll
+            for (int cch = 0; cch < kCamChunks; cch++) h += p.HppPart[((size_t)s1 * kCamChunks + cch) * 27 + tq];
+            v += h + (a == c ? lambda : 0.0);
+        }
         const int r = 6 * s1 + a, cc = 6 * s2 + c;   // upper-block entry (r,cc); store it mirrored into the lower triangle
         if (s1 == s2) { if (c <= a) M[(size_t)r * ld + cc] = v; }
         else M[(size_t)cc * ld + r] = v;
@@ -408,60 +442,74 @@ __global__ __launch_bounds__(kThreads) void ba_solve_kernel(BAPtrs p, BADims d, 
     if (tid == 0) s_ok = 1;
     __syncthreads();
     STAMP(1);
-    // right-looking LDL^T on the lower triangle.  During the factorisation column j keeps L(i,j)*d_j (unscaled); all
-    // columns are scaled to L in one pass at the end, which leaves ONE barrier per elimination step.
-    if (n <= 64) {
-        // wave wv owns rows r = wv + 4q (q < 16); lane = column.  u[q] = M[r][j] are broadcast reads, the row updates touch
-        // distinct consecutive addresses (odd row stride) and are independent, so the LDS traffic pipelines.
-        const int lc = lane < n ? lane : n - 1;
-        int rowoff[16];   // 32-bit LDS element offsets of this wave's rows, hoisted out of the elimination loop
+    // Right-looking LDL^T of the lower triangle, blocked by the 6x6 camera blocks (n = 6*nfree): per block column one
+    // in-register factorisation of the diagonal block (done redundantly by every thread: it is the dependent chain of six
+    // divisions), one panel solve (thread per row) and one rank-6 trailing update (wave per row, lane per column) — two
+    // barriers per camera instead of one per scalar column.  After it M holds L (unit lower, scaled) and d on the diagonal.
+    bool failed = false;
+    for (int k0 = 0; k0 < n; k0 += 6) {
+        // (a) diagonal block -> Lkk (strict lower), dk, 1/dk
+        double a[6][6], dk[6], ik[6];
 #pragma unroll
-        for (int q = 0; q < 16; q++) { const int r = wv + 4 * q; rowoff[q] = (r < n ? r : n - 1) * ld; }
-        const int coloff = lc * ld;
-        bool failed = false;
-        for (int j = 0; j < n; j++) {
-            // every LDS read of the step (pivot, column j, own cells) is issued before anything depends on one of them
-            const double dj = M[j * ld + j];
-            const double colv = M[coloff + j];
-            double u[16], cur[16];
+        for (int i = 0; i < 6; i++)
 #pragma unroll
-            for (int q = 0; q < 16; q++) { u[q] = M[rowoff[q] + j]; cur[q] = M[rowoff[q] + lc]; }
-            failed = failed || dj == 0.0 || !isfinite(dj);
-            const double inv = 1.0 / dj;
-            const bool col_live = lane > j && lane < n;
-            const double v = colv * inv;                                          // L(c,j), c = lane
+            for (int c = 0; c <= i; c++) a[i][c] = M[(k0 + i) * ld + k0 + c];
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int r = wv + 4 * q;
-                if (r < n && lane < n) {   // each (r,lane) cell has exactly one owner thread; untouched cells are rewritten as is
-                    const bool act = r > j && col_live && lane <= r && !failed;
-                    M[rowoff[q] + lane] = act ? cur[q] - u[q] * v : cur[q];
-                }
-            }
-            __syncthreads();
+        for (int j = 0; j < 6; j++) {
+            dk[j] = a[j][j];
+            failed = failed || dk[j] == 0.0 || !isfinite(dk[j]);
+            ik[j] = 1.0 / dk[j];
+            double lcol[6];
+#pragma unroll
+            for (int i = j + 1; i < 6; i++) lcol[i] = a[i][j] * ik[j];      // L(i,j); a[.][j] keeps L*d_j during the update
+#pragma unroll
+            for (int i = j + 1; i < 6; i++)
+#pragma unroll
+                for (int c = j + 1; c <= i; c++) a[i][c] -= lcol[i] * a[c][j];
+#pragma unroll
+            for (int i = j + 1; i < 6; i++) a[i][j] = lcol[i];
         }
-        if (failed && tid == 0) s_ok = 0;   // a zero / non-finite pivot froze the matrix; report the failure
-    } else {
-        for (int j = 0; j < n; j++) {
-            const double dj = M[(size_t)j * ld + j];
-            if (dj == 0.0 || !isfinite(dj)) { if (tid == 0) s_ok = 0; break; }   // uniform
-            const double inv = 1.0 / dj;
-            for (int r = j + 1 + wv; r < n; r += 4) {
-                const double lrj_d = M[(size_t)r * ld + j];
-                for (int c = j + 1 + lane; c <= r; c += 64) M[(size_t)r * ld + c] -= lrj_d * (M[(size_t)c * ld + j] * inv);
-            }
-            __syncthreads();
+        __syncthreads();   // every thread has read the block before it is overwritten
+        if (tid < 36) {
+            const int i = tid / 6, c = tid - 6 * i;
+            double v = 0;
+#pragma unroll
+            for (int ii = 0; ii < 6; ii++)
+#pragma unroll
+                for (int cc = 0; cc < 6; cc++) if (ii == i && cc == c) v = (cc < ii) ? a[ii][cc] : (cc == ii ? dk[ii] : 0.0);
+            if (c <= i) M[(k0 + i) * ld + k0 + c] = v;
         }
+        // (b) panel: L_rk = A_rk * Lkk^-T * Dk^-1, one thread per row
+        for (int r = k0 + 6 + tid; r < n; r += kThreads) {
+            double y[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) y[j] = M[r * ld + k0 + j];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+#pragma unroll
+                for (int t = 0; t < j; t++) y[j] -= y[t] * a[j][t];
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++) M[r * ld + k0 + j] = y[j] * ik[j];
+        }
+        __syncthreads();
+        // (c) trailing update A_rc -= sum_t L_rt d_t L_ct  (c <= r)
+        for (int c = k0 + 6 + lane; c < n; c += 64) {
+            double lc[6];
+#pragma unroll
+            for (int t = 0; t < 6; t++) lc[t] = M[c * ld + k0 + t] * dk[t];
+            for (int r = c + ((wv - (c & 3)) & 3); r < n; r += 4) {   // rows r >= c with r % 4 == wv
+                double acc = M[r * ld + c];
+#pragma unroll
+                for (int t = 0; t < 6; t++) acc -= M[r * ld + k0 + t] * lc[t];
+                M[r * ld + c] = acc;
+            }
+        }
+        __syncthreads();
     }
+    if (failed && tid == 0) s_ok = 0;   // zero / non-finite pivot (Eigen SimplicialLDLT would report failure)
     __syncthreads();
     STAMP(2);
-    if (s_ok) {   // scale every column to L
-        for (int t = tid; t < n * n; t += kThreads) {
-            const int r = t / n, c = t - r * n;
-            if (c < r) M[(size_t)r * ld + c] = M[(size_t)r * ld + c] / M[(size_t)c * ld + c];
-        }
-    }
-    __syncthreads();
     STAMP(3);
     const int ok = s_ok;
     if (ok) {
@@ -577,25 +625,37 @@ __global__ __launch_bounds__(kThreads) void ba_backsub_kernel(BAPtrs p, BADims d
     const int cur = st.cur, trial = cur ^ 1;
     const double lambda = st.lambda;
     const int ok = st.solve_ok;
-    const int pt = blockIdx.x * kThreads + threadIdx.x;
+    const int gl = threadIdx.x & (kLanesPerPoint - 1);
+    const int pt = blockIdx.x * kPointsPerBlock + (threadIdx.x >> 3);
     double chi_part = 0, scale_part = 0;
-    if (pt < d.P) {
-        double X[3] = {p.pts[cur][3 * pt], p.pts[cur][3 * pt + 1], p.pts[cur][3 * pt + 2]};
-        const int b = p.pt_ptr[pt], e_end = p.pt_ptr[pt + 1];
+    {
+        const bool live = pt < d.P;
+        const int ptc = live ? pt : 0;
+        double X[3] = {p.pts[cur][3 * ptc], p.pts[cur][3 * ptc + 1], p.pts[cur][3 * ptc + 2]};
+        const int b = live ? p.pt_ptr[pt] : 0, e_end = live ? p.pt_ptr[pt + 1] : 0;
+        // c = bl - sum_e Hpl_e^T xp, one observation per lane, fixed butterfly over the 8 lanes
+        double c[3] = {0, 0, 0};
         bool any = false;
-        for (int i = b; i < e_end; i++) any = any || p.e_active[p.pt_edges[i]];
-        if (any && ok) {
-            double c[3] = {p.bl[3 * pt], p.bl[3 * pt + 1], p.bl[3 * pt + 2]};
-            for (int i = b; i < e_end; i++) {
-                const int e = p.pt_edges[i];
-                if (!p.e_active[e]) continue;
-                const int s = p.slot[p.e_kf[e]];
-                if (s < 0) continue;
-                const double* B1 = p.Hpl + 18 * (size_t)e;
-                const double* x = p.xp + 6 * s;
+        for (int i = b + gl; i < e_end; i += kLanesPerPoint) {
+            const int e = p.pt_edges[i];
+            if (!p.e_active[e]) continue;
+            any = true;
+            const int s = p.slot[p.e_kf[e]];
+            if (s < 0) continue;
+            const double* B1 = p.Hpl + 18 * (size_t)e;
+            const double* x = p.xp + 6 * s;
 #pragma unroll
-                for (int a = 0; a < 6; a++) { c[0] -= B1[a * 3] * x[a]; c[1] -= B1[a * 3 + 1] * x[a]; c[2] -= B1[a * 3 + 2] * x[a]; }
-            }
+            for (int a = 0; a < 6; a++) { c[0] -= B1[a * 3] * x[a]; c[1] -= B1[a * 3 + 1] * x[a]; c[2] -= B1[a * 3 + 2] * x[a]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int o = kLanesPerPoint / 2; o > 0; o >>= 1) c[i] += __shfl_xor(c[i], o);
+        }
+        const unsigned long long anym = __ballot(any);
+        const bool any_pt = ((anym >> ((threadIdx.x & 63) & ~(kLanesPerPoint - 1))) & 0xFFull) != 0;
+        if (live && any_pt && ok) {   // every lane of the group computes the same step (identical inputs)
+            c[0] += p.bl[3 * pt]; c[1] += p.bl[3 * pt + 1]; c[2] += p.bl[3 * pt + 2];
             double D[9], Di[9];
 #pragma unroll
             for (int i = 0; i < 9; i++) D[i] = p.Hll[9 * (size_t)pt + i];
@@ -604,13 +664,13 @@ __global__ __launch_bounds__(kThreads) void ba_backsub_kernel(BAPtrs p, BADims d
 #pragma unroll
             for (int a = 0; a < 3; a++) {
                 const double xl = Di[a * 3] * c[0] + Di[a * 3 + 1] * c[1] + Di[a * 3 + 2] * c[2];
-                scale_part += xl * (lambda * xl + p.bl[3 * pt + a]);
+                if (gl == 0) scale_part += xl * (lambda * xl + p.bl[3 * pt + a]);
                 X[a] += xl;
             }
         }
-        p.pts[trial][3 * pt] = X[0]; p.pts[trial][3 * pt + 1] = X[1]; p.pts[trial][3 * pt + 2] = X[2];
+        if (live && gl == 0) { p.pts[trial][3 * pt] = X[0]; p.pts[trial][3 * pt + 1] = X[1]; p.pts[trial][3 * pt + 2] = X[2]; }
         const double* poseR = p.poseR[trial];
-        for (int i = b; i < e_end; i++) {
+        for (int i = b + gl; i < e_end; i += kLanesPerPoint) {
             const int e = p.pt_edges[i];
             if (!p.e_active[e]) continue;
             const int k = p.e_kf[e];
@@ -829,7 +889,7 @@ int enqueue_steps(uh_ba* b, int nsteps) {
     const int use_lds = d.n <= 120 ? 1 : 0;
     const size_t lds = use_lds ? (size_t)d.n * (d.n + 1) * sizeof(double) : 0;
     for (int s = 0; s < nsteps; s++) {
-        UH_LAUNCH(b->ctx,ba_lin_kernel, dim3(d.nPointBlocks + d.nfree), dim3(kThreads), 0, b->ptrs, d);
+        UH_LAUNCH(b->ctx,ba_lin_kernel, dim3(d.nPointBlocks + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d);
         UH_LAUNCH(b->ctx,ba_schur_kernel, dim3(std::max(npairs, 1) * b->nsplit), dim3(kThreads), 0, b->ptrs, d, b->nsplit);
         if (use_lds) UH_LAUNCH(b->ctx,ba_solve_kernel<true>, dim3(1), dim3(kThreads), lds, b->ptrs, d, b->nsplit);
         else UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kThreads), lds, b->ptrs, d, b->nsplit);
@@ -927,7 +987,7 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
 
     BADims& d = b->dims;
     d.K = K; d.P = P; d.E = E; d.nfree = nfree; d.n = 6 * nfree;
-    d.nPointBlocks = std::max(uh_div_up(P, kThreads), 1);
+    d.nPointBlocks = std::max(uh_div_up(P, kPointsPerBlock), 1);
     d.delta = b->params.huber_delta; d.dsqr = d.delta * d.delta; d.chi2_th = b->params.chi2_threshold;
 
     // carve one arena
@@ -940,11 +1000,11 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     for (int i = 0; i < 2; i++) { o_pose[i] = A.take<double>(7 * (size_t)K); o_poseR[i] = A.take<double>(12 * (size_t)K); o_pts[i] = A.take<double>(3 * (size_t)P); }
     const size_t o_act = A.take<unsigned char>(E), o_rob = A.take<unsigned char>(E), o_err = A.take<double>(2 * (size_t)E), o_chi2 = A.take<double>(E);
     const size_t o_Hll = A.take<double>(9 * (size_t)P), o_bl = A.take<double>(3 * (size_t)P), o_Hpl = A.take<double>(18 * (size_t)E);
-    const size_t o_Hpp = A.take<double>(36 * (size_t)std::max(nfree, 1)), o_bp = A.take<double>(std::max(d.n, 1));
+    const size_t o_Hpp = A.take<double>(27 * (size_t)kCamChunks * std::max(nfree, 1)), o_bp = A.take<double>(std::max(d.n, 1));
     const int npairs_h = nfree * (nfree + 1) / 2;
-    b->nsplit = std::max(1, std::min(8, d.nPointBlocks));
+    b->nsplit = std::max(1, std::min(8, uh_div_up(P, kThreads)));
     const size_t o_S = A.take<double>((size_t)std::max(d.n, 1) * (std::max(d.n, 1) + 1)), o_Sp = A.take<double>((size_t)b->nsplit * std::max(npairs_h, 1) * 42), o_xp = A.take<double>(std::max(d.n, 1));
-    const size_t o_plc = A.take<double>(d.nPointBlocks), o_pmd = A.take<double>(d.nPointBlocks + nfree), o_pc = A.take<double>(d.nPointBlocks), o_ps = A.take<double>(d.nPointBlocks);
+    const size_t o_plc = A.take<double>(d.nPointBlocks), o_pmd = A.take<double>(d.nPointBlocks), o_pc = A.take<double>(d.nPointBlocks), o_ps = A.take<double>(d.nPointBlocks);
     const size_t o_st = A.take<BAState>(1);
     const size_t o_dbg = A.take<unsigned long long>(16);
     int rc = b->arena.reserve(A.off + 256);
@@ -982,7 +1042,7 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     p.slot = (int*)(base + o_slot); p.free_kf = (int*)(base + o_free); p.intr = (double*)(base + o_intr); p.edge_of = (int*)(base + o_edge_of);
     for (int i = 0; i < 2; i++) { p.pose[i] = (double*)(base + o_pose[i]); p.poseR[i] = (double*)(base + o_poseR[i]); p.pts[i] = (double*)(base + o_pts[i]); }
     p.e_active = (unsigned char*)(base + o_act); p.e_robust = (unsigned char*)(base + o_rob); p.e_err = (double*)(base + o_err); p.e_chi2 = (double*)(base + o_chi2);
-    p.Hll = (double*)(base + o_Hll); p.bl = (double*)(base + o_bl); p.Hpl = (double*)(base + o_Hpl); p.Hpp = (double*)(base + o_Hpp); p.bp = (double*)(base + o_bp);
+    p.Hll = (double*)(base + o_Hll); p.bl = (double*)(base + o_bl); p.Hpl = (double*)(base + o_Hpl); p.HppPart = (double*)(base + o_Hpp); p.bp = (double*)(base + o_bp);
     p.S = (double*)(base + o_S); p.Spart = (double*)(base + o_Sp); p.xp = (double*)(base + o_xp);
     p.part_lin_chi = (double*)(base + o_plc); p.part_maxdiag = (double*)(base + o_pmd); p.part_chi = (double*)(base + o_pc); p.part_scale = (double*)(base + o_ps);
     p.st = (BAState*)(base + o_st);
