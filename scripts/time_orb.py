@@ -22,3 +22,10 @@ for B in (1, 8):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / N
     print(f"orb batch={B}: {ms*1000:.1f} us per launch-set, {ms*1000/B:.1f} us/frame, counts={out[2].cpu().numpy()[:4]}")
+for B in (1, 8):
+    frames = torch.from_numpy(np.stack([synth.frame(1241, 376, seed=s, shift=(2*s, s)) for s in range(B)])).cuda()
+    out = ext.extract_batch(frames, fp)
+    ctx.prof_enable(True); ctx.prof_reset()
+    for _ in range(10): ext.extract_batch(frames, fp, out)
+    rep = ctx.prof_report(); ctx.prof_enable(False)
+    print(f"B={B}", {k.split('::')[-1]: round(1e3*v[1]/v[0], 1) for k, v in rep.items()})

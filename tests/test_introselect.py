@@ -26,10 +26,12 @@ def _check(sel, oracle, keys, nth):
     keys = np.asarray(keys, np.int32)
     ref = np.empty(n, np.int32)
     oracle.oracle_nth_element_perm(oracle_lib.P(keys), n, nth, oracle_lib.P(ref))
-    packed = ((keys.astype(np.uint32) << 24) | np.arange(n, dtype=np.uint32)).astype(np.uint32)
-    sel.uh_host_nth_element(oracle_lib.P(packed), n, nth)
-    got = (packed & 0xFFFFFF).astype(np.int32)
-    np.testing.assert_array_equal(got, ref)
+    # both product formulations: the sequential one and the pairing form the wave-cooperative GPU partition implements
+    for fn in (sel.uh_host_nth_element, sel.uh_host_nth_element_pairing):
+        packed = ((keys.astype(np.uint32) << 24) | np.arange(n, dtype=np.uint32)).astype(np.uint32)
+        fn(oracle_lib.P(packed), n, nth)
+        got = (packed & 0xFFFFFF).astype(np.int32)
+        np.testing.assert_array_equal(got, ref)
 
 
 def test_random_with_ties(sel, oracle):

@@ -135,3 +135,126 @@ template <typename P> UH_HD void nth_element_desc(P v, int n, int nth) {
 }
 
 }  // namespace uh_sel
+
+// Host emulation of the pairing formulation used by the wave-cooperative partition below (test hook).
+#if !defined(__HIPCC__)
+#include <vector>
+namespace uh_sel {
+inline int partition_pairing_host(uint32_t* v, int first, int last, int pivot) {
+    const uint32_t kp = key(v[pivot]);
+    std::vector<int> L, R;
+    for (int i = first; i < last; i++) if (!(key(v[i]) > kp)) L.push_back(i);
+    for (int i = last - 1; i >= first; i--) if (!(kp > key(v[i]))) R.push_back(i);
+    int m = 0;
+    while (m < (int)L.size() && m < (int)R.size() && L[m] < R[m]) m++;
+    for (int i = 0; i < m; i++) swp(v, L[i], R[i]);
+    int cut = 0x7fffffff;
+    if (m < (int)L.size()) cut = L[m];
+    if (m > 0 && R[m - 1] < cut) cut = R[m - 1];
+    return cut;
+}
+inline void nth_element_desc_pairing_host(uint32_t* v, int n, int nth) {
+    if (n <= 0 || nth >= n) return;
+    int first = 0, last = n, depth_limit = 2 * floor_log2(n);
+    while (last - first > 3) {
+        if (depth_limit == 0) { heap_select(v, first, nth + 1, last); swp(v, first, nth); return; }
+        --depth_limit;
+        const int mid = first + (last - first) / 2;
+        median_to_first(v, first, first + 1, mid, last - 1);
+        const int cut = partition_pairing_host(v, first + 1, last, first);
+        if (cut <= nth) first = cut; else last = cut;
+    }
+    insertion_sort(v, first, last);
+}
+}  // namespace uh_sel
+#endif
+
+#if defined(__HIPCC__)
+// ------------------------------------------------------------------------------------------------------------------
+// Wave-cooperative version (64 lanes work on ONE array).  The sequential Hoare partition of libstdc++ is equivalent to:
+//   L = positions (ascending) whose element does NOT precede the pivot      (the left scan's stopping points)
+//   R = positions (descending) which the pivot does NOT precede             (the right scan's stopping points)
+//   swap the pairs (L_i, R_i) while L_i < R_i (m pairs);  cut = min(L_m, R_{m-1})
+// (no position can belong to two swapped pairs, so the swaps are independent).  The equivalence, including ties and the
+// crossing cases, is checked against std::nth_element by tests/test_introselect.py through the host emulation
+// uh_sel::partition_pairing_host.  Median-of-3, the <=3-element insertion sort and the depth-limit heap-select stay
+// sequential on lane 0 (a handful of elements).
+namespace uh_sel {
+
+__device__ __forceinline__ void wave_mem_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <typename P, typename S>
+__device__ __forceinline__ int wave_partition(P v, int first, int last, int pivot, S Lpos, S Rpos, int lane) {
+    const uint32_t kp = key(v[pivot]);
+    int nL = 0;
+    for (int s = first; s < last; s += 64) {
+        const int pos = s + lane;
+        const bool in = pos < last;
+        const uint32_t e = in ? v[pos] : 0u;
+        const bool isL = in && !(key(e) > kp);
+        const unsigned long long m = __ballot(isL);
+        if (isL) Lpos[nL + __popcll(m & ((1ull << lane) - 1ull))] = pos;
+        nL += __popcll(m);
+    }
+    int nR = 0;
+    for (int s = last; s > first; s -= 64) {
+        const int pos = s - 64 + lane;
+        const bool in = pos >= first;
+        const uint32_t e = in ? v[pos] : 0u;
+        const bool isR = in && !(kp > key(e));
+        const unsigned long long m = __ballot(isR);
+        if (isR) Rpos[nR + __popcll((m >> lane) >> 1)] = pos;   // rank counted from the top of the chunk
+        nR += __popcll(m);
+    }
+    wave_mem_sync();
+    const int np = nL < nR ? nL : nR;
+    int m = 0;
+    for (int i0 = 0; i0 < np; i0 += 64) {
+        const int i = i0 + lane;
+        const bool ok = i < np && Lpos[i] < Rpos[i];
+        const unsigned long long mk = __ballot(ok);
+        m += __popcll(mk);
+        if (mk != ~0ull) break;     // L ascending / R descending: once a pair fails all later pairs fail
+    }
+    for (int i = lane; i < m; i += 64) {
+        const int a = Lpos[i], b = Rpos[i];
+        const uint32_t va = v[a], vb = v[b];
+        v[a] = vb;
+        v[b] = va;
+    }
+    int cut = 0x7fffffff;
+    if (m < nL) cut = Lpos[m];
+    if (m > 0) { const int r = Rpos[m - 1]; cut = r < cut ? r : cut; }
+    wave_mem_sync();
+    return cut;
+}
+
+// std::nth_element(v, v+nth, v+n, greater-response), executed by a whole wave; Lpos/Rpos: scratch of >= n ints each
+template <typename P, typename S>
+__device__ __forceinline__ void wave_nth_element_desc(P v, int n, int nth, S Lpos, S Rpos, int lane) {
+    if (n <= 0 || nth >= n) return;
+    int first = 0, last = n;
+    int depth_limit = 2 * floor_log2(n);
+    while (last - first > 3) {
+        if (depth_limit == 0) {
+            if (lane == 0) { heap_select(v, first, nth + 1, last); swp(v, first, nth); }
+            wave_mem_sync();
+            return;
+        }
+        --depth_limit;
+        const int mid = first + (last - first) / 2;
+        if (lane == 0) median_to_first(v, first, first + 1, mid, last - 1);
+        wave_mem_sync();
+        const int cut = wave_partition(v, first + 1, last, first, Lpos, Rpos, lane);
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    if (lane == 0) insertion_sort(v, first, last);
+    wave_mem_sync();
+}
+
+}  // namespace uh_sel
+#endif  // __HIPCC__

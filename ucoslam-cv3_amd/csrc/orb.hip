@@ -32,6 +32,9 @@ namespace {
 constexpr int kMaxLevels = 16;
 constexpr int kMaxDim = 4095;          // candidate words pack x and y in 12 bits each
 constexpr int kMaxCellsPerLevel = 2048;
+constexpr int kNmsTileBytes = 16384;     // cell_nms: LDS staging of one cell's strength values
+constexpr int kSelThreads = 1024;       // selection workgroup: 16 waves share one level's cells
+constexpr int kSelWaves = kSelThreads / 64;
 constexpr int PATCH_SIZE = 31, HALF_PATCH = 15, EDGE = 19;
 
 struct LevelDesc {
@@ -161,14 +164,14 @@ __device__ __forceinline__ int fast_strength(const int (&d)[25]) {
     return best - 1;
 }
 
-__global__ __launch_bounds__(256) void fast_score_kernel(const Plan* __restrict__ plan, const uint8_t* __restrict__ pyr,
+__global__ __launch_bounds__(256) void fast_score_kernel(const Plan plan, const uint8_t* __restrict__ pyr,
                                                          uint8_t* __restrict__ score, size_t frame_stride) {
     constexpr int TW = 64, TH = 16, R = 3;
     __shared__ uint8_t s_t[TH + 2 * R][TW + 2 * R + 2];
     int lvl = 0;
     const int tile = blockIdx.x;
-    while (lvl + 1 < plan->nlevels && tile >= plan->lv[lvl + 1].tile_begin) ++lvl;
-    const LevelDesc& L = plan->lv[lvl];
+    while (lvl + 1 < plan.nlevels && tile >= plan.lv[lvl + 1].tile_begin) ++lvl;
+    const LevelDesc& L = plan.lv[lvl];
     const int t = tile - L.tile_begin;
     const int ty0 = (t / L.tiles_x) * TH, tx0 = (t % L.tiles_x) * TW;
     const uint8_t* img = pyr + (size_t)blockIdx.y * frame_stride + L.img_off;
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const Plan* __restrict_
 // ------------------------------------------------------------------------------------------------ per-cell NMS
 // One workgroup per (frame, cell).  Candidates = in-cell strict 3x3 maxima with score >= minTh, written in raster order as
 // (score<<24 | y<<12 | x) in level coordinates; n7 = their count, n20 = how many of them reach iniTh.
-__global__ __launch_bounds__(256) void cell_nms_kernel(const Plan* __restrict__ plan, const CellDesc* __restrict__ cells,
+__global__ __launch_bounds__(256) void cell_nms_kernel(const Plan plan, const CellDesc* __restrict__ cells,
                                                        const uint8_t* __restrict__ score, size_t frame_stride,
                                                        uint32_t* __restrict__ cand, size_t cand_frame_stride,
                                                        int* __restrict__ cell_counts /* [frame][cell][2] */) {
@@ -216,54 +219,127 @@ __global__ __launch_bounds__(256) void cell_nms_kernel(const Plan* __restrict__ 
     __shared__ int s_base, s_n20;
     const int cell = blockIdx.x, frame = blockIdx.y;
     int lvl = 0;
-    while (lvl + 1 < plan->nlevels && cell >= plan->lv[lvl + 1].cell_begin) ++lvl;
-    const LevelDesc& L = plan->lv[lvl];
+    while (lvl + 1 < plan.nlevels && cell >= plan.lv[lvl + 1].cell_begin) ++lvl;
+    const LevelDesc& L = plan.lv[lvl];
     const CellDesc C = cells[cell];
     const uint8_t* sc = score + (size_t)frame * frame_stride + L.img_off;
     uint32_t* out = cand + (size_t)frame * cand_frame_stride + L.cand_off + (size_t)(cell - L.cell_begin) * L.cellCap;
     const int iw = C.x1 - C.x0, ih = C.y1 - C.y0;
     const int npix = (iw > 0 && ih > 0 && !C.skipped) ? iw * ih : 0;
-    const int minTh = plan->minTh, iniTh = plan->iniTh;
+    const int minTh = plan.minTh, iniTh = plan.iniTh;
     if (threadIdx.x == 0) { s_base = 0; s_n20 = 0; }
+    // stage the cell's strength values in LDS with one fully overlapped pass (all loads in flight together); cells larger
+    // than the staging buffer (huge cells of tiny feature budgets) read HBM/L2 directly
+    __shared__ uint8_t s_tile[kNmsTileBytes];
+    const bool staged = npix > 0 && npix <= kNmsTileBytes;
+    if (staged)
+        for (int i = threadIdx.x; i < npix; i += 256) { const int yy = i / iw, xx = i - yy * iw; s_tile[i] = sc[(size_t)(C.y0 + yy) * L.pitch + C.x0 + xx]; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int p0 = 0; p0 < npix; p0 += 256) {
-        const int p = p0 + threadIdx.x;
-        bool keep = false;
-        int s = 0, x = 0, y = 0;
-        if (p < npix) {
-            const int yy = p / iw, xx = p - yy * iw;
-            x = C.x0 + xx; y = C.y0 + yy;
-            s = sc[(size_t)y * L.pitch + x];
-            if (s >= minTh) {
-                keep = true;
+    if (staged) {
+        // Fast path: each wave owns one contiguous quarter of the cell's raster, compacts its candidates into its own LDS
+        // list with no workgroup barrier inside the loop, then the four lists are concatenated in wave (= raster) order.
+        __shared__ uint32_t s_list[kNmsTileBytes / 2 + 4 * 64];
+        __shared__ int s_cnt[4], s_c20[4];
+        const int chunk = ((npix + 3) / 4 + 63) & ~63;            // pixels per wave, multiple of 64
+        uint32_t* mylist = s_list + wv * (chunk / 2 + 64);        // NMS packing bound: <= every other pixel of a range
+        const int pbeg = wv * chunk, pend = min(pbeg + chunk, npix);
+        int k = 0, k20 = 0;
+        for (int p0 = pbeg; p0 < pend; p0 += 64) {
+            const int pp = p0 + lane;
+            const bool live = pp < pend;
+            const int pc = live ? pp : pbeg;
+            const int yy = pc / iw, xx = pc - yy * iw;
+            const int sv = s_tile[pc];
+            int nmax = 0;
+#pragma unroll
+            for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                for (int dx = -1; dx <= 1; dx++) {
+                    if (dx == 0 && dy == 0) continue;
+                    const bool in = xx + dx >= 0 && xx + dx < iw && yy + dy >= 0 && yy + dy < ih;
+                    const int nv = s_tile[in ? pc + dy * iw + dx : pc];
+                    nmax = max(nmax, in ? nv : 0);
+                }
+            const bool keep = live && sv >= minTh && sv > nmax;
+            const unsigned long long m = __ballot(keep);
+            if (keep) mylist[k + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)sv << 24) | ((uint32_t)(C.y0 + yy) << 12) | (uint32_t)(C.x0 + xx);
+            k += __popcll(m);
+            k20 += __popcll(__ballot(keep && sv >= iniTh));
+        }
+        if (lane == 0) { s_cnt[wv] = k; s_c20[wv] = k20; }
+        __syncthreads();
+        int off = 0;
+        for (int i = 0; i < wv; i++) off += s_cnt[i];
+        for (int i = lane; i < k; i += 64) if (off + i < L.cellCap) out[off + i] = mylist[i];
+        if (threadIdx.x == 0) {
+            int* ccw = cell_counts + ((size_t)frame * plan.total_cells + cell) * 2;
+            ccw[0] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            ccw[1] = s_c20[0] + s_c20[1] + s_c20[2] + s_c20[3];
+        }
+        return;
+    }
+    // Large-cell path (strength values read from HBM/L2).: raster order = (thread, j) lexicographic, ranked with four ballots
+    for (int p0 = 0; p0 < npix; p0 += 1024) {
+        const int pbase = p0 + threadIdx.x * 4;
+        int yy = 0, xx = 0;
+        if (pbase < npix) { yy = pbase / iw; xx = pbase - yy * iw; }
+        bool keep[4];
+        uint32_t word[4];
+        int n20_local = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            keep[j] = false;
+            word[j] = 0;
+            if (pbase + j < npix) {
+                while (xx >= iw) { xx -= iw; ++yy; }
+                const int x = C.x0 + xx, y = C.y0 + yy;
+                const int sv = staged ? (int)s_tile[yy * iw + xx] : (int)sc[(size_t)y * L.pitch + x];
+                // all eight neighbours are fetched unconditionally (clamped address, masked value) so that the reads overlap;
+                // a short-circuit chain would serialise eight dependent LDS round trips per candidate
+                int nmax = 0;
 #pragma unroll
                 for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
                     for (int dx = -1; dx <= 1; dx++) {
                         if (dx == 0 && dy == 0) continue;
                         const int nx = x + dx, ny = y + dy;
-                        if (nx >= C.x0 && nx < C.x1 && ny >= C.y0 && ny < C.y1) keep = keep && (s > (int)sc[(size_t)ny * L.pitch + nx]);
+                        const bool in = nx >= C.x0 && nx < C.x1 && ny >= C.y0 && ny < C.y1;
+                        const int cy = in ? yy + dy : yy, cx = in ? xx + dx : xx;
+                        const int nv = staged ? (int)s_tile[cy * iw + cx] : (int)sc[(size_t)(C.y0 + cy) * L.pitch + C.x0 + cx];
+                        nmax = max(nmax, in ? nv : 0);
                     }
+                const bool k = sv >= minTh && sv > nmax;
+                keep[j] = k;
+                word[j] = ((uint32_t)sv << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+                if (k && sv >= iniTh) n20_local++;
             }
+            ++xx;
         }
-        const uint64_t m = __ballot(keep);
-        const uint64_t m20 = __ballot(keep && s >= iniTh);
-        if (lane == 0) s_wave[wv] = __popcll(m);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int before = 0, wave_total = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned long long m = __ballot(keep[j]);
+            before += __popcll(m & lt);
+            wave_total += __popcll(m);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) n20_local += __shfl_xor(n20_local, o);
+        if (lane == 0) { s_wave[wv] = wave_total; if (n20_local) atomicAdd(&s_n20, n20_local); }
         __syncthreads();
-        int off = s_base;
-        for (int i = 0; i < wv; i++) off += s_wave[i];
-        if (keep) {
-            const int pos = off + __popcll(m & ((1ull << lane) - 1));
-            if (pos < L.cellCap) out[pos] = ((uint32_t)s << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+        int pos = s_base + before;
+        for (int i = 0; i < wv; i++) pos += s_wave[i];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (keep[j]) { if (pos < L.cellCap) out[pos] = word[j]; ++pos; }
         }
-        if (lane == 0 && m20) atomicAdd(&s_n20, __popcll(m20));
         __syncthreads();
         if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        int* cc = cell_counts + ((size_t)frame * plan->total_cells + cell) * 2;
+        int* cc = cell_counts + ((size_t)frame * plan.total_cells + cell) * 2;
         cc[0] = s_base;
         cc[1] = s_n20;
     }
@@ -277,44 +353,70 @@ struct SelectArgs {
     int* level_count;
     const int* s_nkeys; const int* s_ret; const int* s_off; const int* s_out;
     int nCells, iniTh, total;
+    int scratch_ints;   // LDS path: ints available after work+cat for the partition scratch (0 = use the sequential routine)
 };
 
 // per-cell retainBest + truncate (:1053-1055), concatenation (:1058-1065), level-wide retainBest + truncate (:1069-1073),
 // computeDescriptors' border filter (:1124-1130).  WorkPtr is either an LDS or a global pointer (static address space).
+// Cells are spread over the 4 waves of the workgroup; each selection is wave-cooperative (introselect.hpp) when the LDS
+// scratch allows it and falls back to the sequential routine otherwise (same data movement either way).
 template <typename WorkPtr>
 __device__ __forceinline__ void select_body(WorkPtr work, const SelectArgs& A) {
     const LevelDesc& L = *A.L;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     WorkPtr cat = work + A.s_off[A.nCells];
-    for (int c = threadIdx.x; c < A.nCells; c += 256) {
+    int* scratch = reinterpret_cast<int*>(&cat[A.s_out[A.nCells]]);
+    const int per_wave = A.scratch_ints / kSelWaves;     // each wave: Lpos | Rpos halves
+    int* myL = scratch + wv * per_wave;
+    int* myR = myL + per_wave / 2;
+    for (int c = wv; c < A.nCells; c += kSelWaves) {
         const int nk = A.s_nkeys[c], ret = A.s_ret[c];
         if (nk == 0) continue;
         const uint32_t* src = A.cbase + (size_t)c * L.cellCap;
         WorkPtr w = work + A.s_off[c];
         const int n7 = A.cc[2 * c], n20 = A.cc[2 * c + 1];
-        if (n20 > 3) { int k = 0; for (int i = 0; i < n7; i++) { uint32_t e = src[i]; if ((int)(e >> 24) >= A.iniTh) w[k++] = e; } }
-        else for (int i = 0; i < n7; i++) w[i] = src[i];
+        // threshold filter of the cell's raster-ordered candidates (:980-987), order preserving
+        int k = 0;
+        for (int i0 = 0; i0 < n7; i0 += 64) {
+            const int i = i0 + lane;
+            const uint32_t e = i < n7 ? src[i] : 0u;
+            const bool keep = i < n7 && (n20 > 3 ? (int)(e >> 24) >= A.iniTh : true);
+            const unsigned long long m = __ballot(keep);
+            if (keep) w[k + __popcll(m & ((1ull << lane) - 1ull))] = e;
+            k += __popcll(m);
+        }
+        uh_sel::wave_mem_sync();
         // KeyPointsFilter::retainBest(keysCell, ret) then resize(ret): only the nth_element data movement matters
-        if (ret > 0 && nk > ret) uh_sel::nth_element_desc(w, nk, ret - 1);
+        if (ret > 0 && nk > ret) {
+            if (per_wave / 2 >= nk) uh_sel::wave_nth_element_desc(w, nk, ret - 1, myL, myR, lane);
+            else { if (lane == 0) uh_sel::nth_element_desc(w, nk, ret - 1); uh_sel::wave_mem_sync(); }
+        }
         WorkPtr o = cat + A.s_out[c];
-        for (int i = 0; i < ret; i++) o[i] = w[i];
+        for (int i = lane; i < ret; i += 64) o[i] = w[i];
     }
     __syncthreads();
     int total = A.total;
     if (total > L.nDesired) {   // :1069-1073
-        if (threadIdx.x == 0 && L.nDesired > 0) uh_sel::nth_element_desc(cat, total, L.nDesired - 1);
+        if (wv == 0 && L.nDesired > 0) {
+            if (A.scratch_ints / 2 >= total) uh_sel::wave_nth_element_desc(cat, total, L.nDesired - 1, scratch, scratch + A.scratch_ints / 2, lane);
+            else { if (lane == 0) uh_sel::nth_element_desc(cat, total, L.nDesired - 1); uh_sel::wave_mem_sync(); }
+        }
         total = L.nDesired;
         __syncthreads();
     }
-    if (threadIdx.x == 0) {   // border filter, order preserving; the reference applies it before describing
+    if (wv == 0) {   // border filter, order preserving; the reference applies it before describing
         const int maxX = L.w - EDGE, maxY = L.h - EDGE;
         int k = 0;
-        for (int i = 0; i < total; i++) {
-            const uint32_t e = cat[i];
+        for (int i0 = 0; i0 < total; i0 += 64) {
+            const int i = i0 + lane;
+            const uint32_t e = i < total ? cat[i] : 0u;
             const int x = e & 0xFFF, y = (e >> 12) & 0xFFF;
-            if (x < EDGE || y < EDGE || x > maxX || y > maxY) continue;
-            A.lsel[k++] = e;
+            const bool keep = i < total && !(x < EDGE || y < EDGE || x > maxX || y > maxY);
+            const unsigned long long m = __ballot(keep);
+            if (keep) A.lsel[k + __popcll(m & ((1ull << lane) - 1ull))] = e;
+            k += __popcll(m);
         }
-        *A.level_count = k;
+        if (lane == 0) *A.level_count = k;
     }
 }
 
@@ -322,7 +424,7 @@ __device__ __forceinline__ void select_body(WorkPtr work, const SelectArgs& A) {
 // One workgroup per (frame, level): quota redistribution (:994-1039), per-cell retainBest + truncate (:1053-1055),
 // concatenation in cell-row-major order (:1058-1065), level-wide retainBest + truncate (:1069-1073).
 // Workspace `work` holds the threshold-filtered cell lists back to back, `cat` the concatenation.
-__global__ __launch_bounds__(256) void select_kernel(const Plan* __restrict__ plan, const CellDesc* __restrict__ cells,
+__global__ __launch_bounds__(kSelThreads) void select_kernel(const Plan plan, const CellDesc* __restrict__ cells,
                                                      const uint32_t* __restrict__ cand, size_t cand_frame_stride,
                                                      const int* __restrict__ cell_counts, uint32_t* __restrict__ work_g,
                                                      size_t work_frame_stride, uint32_t* __restrict__ sel,
@@ -334,16 +436,19 @@ __global__ __launch_bounds__(256) void select_kernel(const Plan* __restrict__ pl
     __shared__ int s_out[kMaxCellsPerLevel + 1];
     __shared__ int s_total;
     const int lvl = blockIdx.x, frame = blockIdx.y;
-    const LevelDesc& L = plan->lv[lvl];
+    const LevelDesc& L = plan.lv[lvl];
     const int nCells = L.nCells;
-    const int* cc = cell_counts + ((size_t)frame * plan->total_cells + L.cell_begin) * 2;
+    const int* cc = cell_counts + ((size_t)frame * plan.total_cells + L.cell_begin) * 2;
     const uint32_t* cbase = cand + (size_t)frame * cand_frame_stride + L.cand_off;
     uint32_t* lsel = sel + (size_t)frame * sel_frame_stride + L.sel_off;
-    const int iniTh = plan->iniTh;
+    const int iniTh = plan.iniTh;
 
-    for (int c = threadIdx.x; c < nCells; c += 256) {
+    __shared__ unsigned char s_skipped[kMaxCellsPerLevel];
+    for (int c = threadIdx.x; c < nCells; c += kSelThreads) {
         const int n7 = cc[2 * c], n20 = cc[2 * c + 1];
-        s_nkeys[c] = cells[L.cell_begin + c].skipped ? 0 : (n20 > 3 ? n20 : n7);   // :980-987
+        const int sk = cells[L.cell_begin + c].skipped;
+        s_skipped[c] = (unsigned char)sk;
+        s_nkeys[c] = sk ? 0 : (n20 > 3 ? n20 : n7);   // :980-987
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -351,7 +456,7 @@ __global__ __launch_bounds__(256) void select_kernel(const Plan* __restrict__ pl
         int nNoMore = 0, nToDistribute = 0;
         // first pass (:989-1004): skipped cells are not visited; bNoMore is encoded as s_ret sign bit substitute below
         for (int c = 0; c < nCells; c++) {
-            if (cells[L.cell_begin + c].skipped) { s_ret[c] = 0; s_off[c] = 0; continue; }   // s_off reused as bNoMore
+            if (s_skipped[c]) { s_ret[c] = 0; s_off[c] = 0; continue; }   // s_off reused as bNoMore
             const int nKeys = s_nkeys[c];
             if (nKeys > nfeaturesCell) { s_ret[c] = nfeaturesCell; s_off[c] = 0; }
             else { s_ret[c] = nKeys; nToDistribute += nfeaturesCell - nKeys; s_off[c] = 1; nNoMore++; }
@@ -377,9 +482,13 @@ __global__ __launch_bounds__(256) void select_kernel(const Plan* __restrict__ pl
     // separate instantiations so that the pointer's address space is static (a generic pointer would compile every
     // access of the selection into a flat_load).
     const int need = s_off[nCells] + s_out[nCells];
-    SelectArgs A{&L, cc, cbase, lsel, level_counts + (size_t)frame * kMaxLevels + lvl, s_nkeys, s_ret, s_off, s_out, nCells, iniTh, s_total};
-    if (need <= lds_entries) select_body(s_dyn, A);
-    else select_body(work_g + (size_t)frame * work_frame_stride + 2 * (size_t)L.cand_off, A);
+    SelectArgs A{&L, cc, cbase, lsel, level_counts + (size_t)frame * kMaxLevels + lvl, s_nkeys, s_ret, s_off, s_out, nCells, iniTh, s_total, 0};
+    if (need <= lds_entries) {
+        A.scratch_ints = ((lds_entries - need) / (2 * kSelWaves)) * (2 * kSelWaves);   // whatever LDS is left becomes partition scratch
+        select_body(s_dyn, A);
+    } else {
+        select_body(work_g + (size_t)frame * work_frame_stride + 2 * (size_t)L.cand_off, A);   // HBM workspace, sequential selection
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ orientation + rBRIEF
@@ -410,7 +519,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 }
 
 // One wave per output keypoint slot; 4 waves per block.
-__global__ __launch_bounds__(256) void describe_kernel(const Plan* __restrict__ plan, const uint8_t* __restrict__ pyr,
+__global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const uint8_t* __restrict__ pyr,
                                                        size_t frame_stride, const uint32_t* __restrict__ sel,
                                                        size_t sel_frame_stride, const int* __restrict__ level_counts,
                                                        KeyPointOut* __restrict__ kps, uint8_t* __restrict__ desc,
@@ -420,11 +529,11 @@ __global__ __launch_bounds__(256) void describe_kernel(const Plan* __restrict__ 
     const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int* lc = level_counts + (size_t)frame * kMaxLevels;
     int lvl = 0, base = 0, total = 0;
-    for (int l = 0; l < plan->nlevels; l++) total += lc[l];
+    for (int l = 0; l < plan.nlevels; l++) total += lc[l];
     if (slot == 0 && lane == 0) frame_counts[frame] = total;
     if (slot >= total || slot >= cap_per_frame) return;
     while (slot >= base + lc[lvl]) { base += lc[lvl]; ++lvl; }
-    const LevelDesc& L = plan->lv[lvl];
+    const LevelDesc& L = plan.lv[lvl];
     const uint32_t e = sel[(size_t)frame * sel_frame_stride + L.sel_off + (slot - base)];
     const int cx = e & 0xFFF, cy = (e >> 12) & 0xFFF, resp = e >> 24;
     const uint8_t* img = pyr + (size_t)frame * frame_stride + L.img_off;
@@ -633,7 +742,8 @@ int make_plan(uh_orb* o, int w, int h, int batch) {
     o->frame_stride = (img_off + 255) & ~(size_t)255;
     o->cand_stride = cand_off;
     o->sel_stride = sel_off;
-    o->lds_entries = 12288;   // 48 KiB of dynamic LDS for the selection workspace
+    o->lds_entries = 24576;   // 96 KiB of dynamic LDS: selection workspace + partition scratch (one workgroup per level)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, o->lds_entries * 4);
     int rc;
     UH_HIP_CHECK(hipSetDevice(o->ctx->device));
     hipStream_t st = o->ctx->stream;
@@ -671,7 +781,6 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
     UH_HIP_CHECK(hipSetDevice(o->ctx->device));
     hipStream_t st = o->ctx->stream;
     const Plan& P = o->plan;
-    const Plan* dP = o->d_plan.as<Plan>();
     uint8_t* pyr = o->d_pyr.as<uint8_t>();
     const LevelDesc& L0 = P.lv[0];
     if (o->blur_first) {
@@ -689,19 +798,19 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
                            o->d_xofs.as<int>() + D.xtap_off, o->d_xcoef.as<short>() + (size_t)D.xtap_off * 4,
                            o->d_yofs.as<int>() + D.ytap_off, o->d_ycoef.as<short>() + (size_t)D.ytap_off * 4);
     }
-    UH_LAUNCH(o->ctx,fast_score_kernel, dim3(P.total_tiles, batch), dim3(256), 0, dP, pyr, o->d_score.as<uint8_t>(),
+    UH_LAUNCH(o->ctx,fast_score_kernel, dim3(P.total_tiles, batch), dim3(256), 0, P, pyr, o->d_score.as<uint8_t>(),
                        o->frame_stride);
     if (P.total_cells > 0) {
-        UH_LAUNCH(o->ctx,cell_nms_kernel, dim3(P.total_cells, batch), dim3(256), 0, dP, o->d_cells.as<CellDesc>(),
+        UH_LAUNCH(o->ctx,cell_nms_kernel, dim3(P.total_cells, batch), dim3(256), 0, P, o->d_cells.as<CellDesc>(),
                            o->d_score.as<uint8_t>(), o->frame_stride, o->d_cand.as<uint32_t>(), o->cand_stride,
                            o->d_cell_counts.as<int>());
     }
-    UH_LAUNCH(o->ctx,select_kernel, dim3(P.nlevels, batch), dim3(256), (size_t)o->lds_entries * 4, dP,
+    UH_LAUNCH(o->ctx,select_kernel, dim3(P.nlevels, batch), dim3(kSelThreads), (size_t)o->lds_entries * 4, P,
                        o->d_cells.as<CellDesc>(), o->d_cand.as<uint32_t>(), o->cand_stride, o->d_cell_counts.as<int>(),
                        o->d_work.as<uint32_t>(), o->cand_stride * 2, o->d_sel.as<uint32_t>(), o->sel_stride,
                        o->d_level_counts.as<int>(), o->lds_entries);
     const int slots = std::min(std::max(P.maxFeatures, 1), std::max(cap_per_frame, 1));
-    UH_LAUNCH(o->ctx,describe_kernel, dim3(uh_div_up(slots, 4), batch), dim3(256), 0, dP, pyr, o->frame_stride,
+    UH_LAUNCH(o->ctx,describe_kernel, dim3(uh_div_up(slots, 4), batch), dim3(256), 0, P, pyr, o->frame_stride,
                        o->d_sel.as<uint32_t>(), o->sel_stride, o->d_level_counts.as<int>(), d_kps, d_desc, cap_per_frame,
                        d_counts);
     UH_HIP_CHECK(hipGetLastError());
