@@ -60,7 +60,8 @@ def algorithmic_bytes(frames_per_step, ba_E):
         # BA, per launch (E*32 obs + points/poses; per-kernel split in DESIGN.md)
         "ba_lin_kernel": ba_E * (32 + 18 * 8) + BA_P * (24 + 96),
         "ba_schur_kernel": ba_E * 18 * 8 + BA_P * 96,
-        "ba_solve_kernel": (6 * BA_K) ** 2 * 8,
+        # solve: 36 pair partials x 8 chunks x 42 doubles + camera partials (8 free x 8 chunks x 27) + rhs/solution/poses
+        "ba_solve_kernel": 36 * 8 * 42 * 8 + 8 * 8 * 27 * 8 + 4 * 48 * 8 + 10 * 19 * 8,
         "ba_backsub_kernel": ba_E * (18 * 8 + 32 + 24) + BA_P * (96 + 48),
         "ba_decide_kernel": 1024,
     }
@@ -178,17 +179,31 @@ def main():
             rep = ctx.prof_report()
             ctx.prof_enable(False)
             ab = algorithmic_bytes(F, ba_pr["E"])
-            short = {k.split("::")[-1]: v for k, v in rep.items()}
+            import re as _re
+
+            short = {}
+            for kname, v in rep.items():          # "(anonymous namespace)::ba_solve_kernel<true>" -> "ba_solve_kernel"
+                n = _re.sub(r"<.*>", "", kname.split("::")[-1])
+                c0, t0_ = short.get(n, (0, 0.0))
+                short[n] = (c0 + v[0], t0_ + v[1])
             dom = max(short.items(), key=lambda kv: kv[1][1])
             name, (calls, tot_ms) = dom
             avg_ms = tot_ms / max(calls, 1)
             achieved = ab.get(name, 0) / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            try:   # HBM bytes per launch from the committed PMC passes (profiles/, scripts/collect_profiles.sh)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(name)
+                if pmc:
+                    traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
+            except Exception:
+                traffic = None
             roofline = {
                 "bound": "hbm", "kernel": name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "avg_launch_us": round(avg_ms * 1e3, 3), "algorithmic_bytes_per_launch": int(ab.get(name, 0)),
                 "share_of_step_gpu_time": round(tot_ms / sum(v[1] for v in short.values()), 4),
                 "kernels_us": {k: round(1e3 * v[1] / max(v[0], 1), 2) for k, v in sorted(short.items())},
+                "kernels_gbps": {k: round(ab.get(k, 0) / (1e-3 * v[1] / max(v[0], 1)) / 1e9, 2) for k, v in sorted(short.items()) if ab.get(k)},
             }
 
     # ---- CPU baseline (rank 0, N=1 only): bounded sample of the same workload on the host cores

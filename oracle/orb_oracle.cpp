@@ -76,18 +76,26 @@ void gaussian_blur7(const uint8_t* src, int w, int h, size_t stride, Image& dst)
     gaussian_kernel_fixed(7, 2.0, k);   // = {18,34,48,56,48,34,18}
     dst = Image(w, h);
     std::vector<uint32_t> tmp((size_t)w * h);
-    for (int y = 0; y < h; y++)
+    for (int y = 0; y < h; y++) {
+        const uint8_t* r = src + (size_t)y * stride;
+        uint32_t* o = &tmp[(size_t)y * w];
         for (int x = 0; x < w; x++) {
             uint32_t s = 0;
-            for (int i = 0; i < 7; i++) s += (uint32_t)k[i] * src[(size_t)y * stride + reflect101(x + i - 3, w)];
-            tmp[(size_t)y * w + x] = s;
+            if (x >= 3 && x + 3 < w) for (int i = 0; i < 7; i++) s += (uint32_t)k[i] * r[x + i - 3];     // interior: no reflection
+            else for (int i = 0; i < 7; i++) s += (uint32_t)k[i] * r[reflect101(x + i - 3, w)];
+            o[x] = s;
         }
-    for (int y = 0; y < h; y++)
+    }
+    for (int y = 0; y < h; y++) {
+        const uint32_t* rows[7];
+        for (int j = 0; j < 7; j++) rows[j] = &tmp[(size_t)reflect101(y + j - 3, h) * w];
+        uint8_t* o = dst.row(y);
         for (int x = 0; x < w; x++) {
             uint32_t s = 0;
-            for (int j = 0; j < 7; j++) s += (uint32_t)k[j] * tmp[(size_t)reflect101(y + j - 3, h) * w + x];
-            dst.row(y)[x] = (uint8_t)((s + 32768u) >> 16);
+            for (int j = 0; j < 7; j++) s += (uint32_t)k[j] * rows[j][x];
+            o[x] = (uint8_t)((s + 32768u) >> 16);
         }
+    }
 }
 
 // ---------------------------------------------------------------- cv::resize(INTER_CUBIC) on 8UC1
@@ -124,27 +132,28 @@ void resize_cubic(const Image& src, Image& dst, int dw, int dh) {
     cubic_taps(src.w, dw, xo, xa);
     cubic_taps(src.h, dh, yo, ya);
     std::vector<int> rows((size_t)src.h * dw);   // horizontal pass of every source row
+    std::vector<int> sxk((size_t)dw * 4);
+    for (int x = 0; x < dw; x++) for (int k = 0; k < 4; k++) sxk[(size_t)x * 4 + k] = std::min(std::max(xo[x] - 1 + k, 0), src.w - 1);   // taps clamp at the ROI edge
     for (int y = 0; y < src.h; y++) {
         const uint8_t* S = src.row(y);
+        int* o = &rows[(size_t)y * dw];
         for (int x = 0; x < dw; x++) {
-            int acc = 0;
-            for (int k = 0; k < 4; k++) {
-                int sx = std::min(std::max(xo[x] - 1 + k, 0), src.w - 1);   // taps clamp at the ROI edge
-                acc += S[sx] * xa[(size_t)x * 4 + k];
-            }
-            rows[(size_t)y * dw + x] = acc;
+            const int* sx = &sxk[(size_t)x * 4];
+            const short* a = &xa[(size_t)x * 4];
+            o[x] = S[sx[0]] * a[0] + S[sx[1]] * a[1] + S[sx[2]] * a[2] + S[sx[3]] * a[3];
         }
     }
-    for (int y = 0; y < dh; y++)
+    for (int y = 0; y < dh; y++) {
+        const int* r[4];
+        for (int k = 0; k < 4; k++) r[k] = &rows[(size_t)std::min(std::max(yo[y] - 1 + k, 0), src.h - 1) * dw];
+        const short* b = &ya[(size_t)y * 4];
+        uint8_t* o = dst.row(y);
         for (int x = 0; x < dw; x++) {
-            int acc = 0;
-            for (int k = 0; k < 4; k++) {
-                int sy = std::min(std::max(yo[y] - 1 + k, 0), src.h - 1);
-                acc += rows[(size_t)sy * dw + x] * ya[(size_t)y * 4 + k];
-            }
-            int v = (acc + (1 << 21)) >> 22;
-            dst.row(y)[x] = (uint8_t)std::min(std::max(v, 0), 255);
+            const int acc = r[0][x] * b[0] + r[1][x] * b[1] + r[2][x] * b[2] + r[3][x] * b[3];
+            const int v = (acc + (1 << 21)) >> 22;
+            o[x] = (uint8_t)std::min(std::max(v, 0), 255);
         }
+    }
 }
 
 // ---------------------------------------------------------------- cv::FAST(img, kps, thr, nonmax=true), TYPE_9_16
@@ -209,15 +218,30 @@ void fast9_16(const uint8_t* img, int cols, int rows, int step, int threshold, s
             for (int j = 3; j < cols - 3; j++, ptr++) {
                 int v = ptr[0];
                 int vt_lo = v - threshold, vt_hi = v + threshold;
+                // cv::FAST's pruning: a 9-arc contains one end of every diameter, so all eight diameters must have an end
+                // that is darker (bit 0) resp. brighter (bit 1) than the centre by more than the threshold
+                auto cls = [&](int k) { const int x = ptr[pixel[k]]; return x < vt_lo ? 1 : (x > vt_hi ? 2 : 0); };
+                int dmask = cls(0) | cls(8);
+                if (dmask == 0) continue;
+                dmask &= cls(2) | cls(10);
+                dmask &= cls(4) | cls(12);
+                dmask &= cls(6) | cls(14);
+                if (dmask == 0) continue;
+                dmask &= cls(1) | cls(9);
+                dmask &= cls(3) | cls(11);
+                dmask &= cls(5) | cls(13);
+                dmask &= cls(7) | cls(15);
                 bool found = false;
                 int count = 0;
-                for (int k = 0; k < N && !found; k++) {           // darker arc
-                    if (ptr[pixel[k]] < vt_lo) { if (++count > K) found = true; } else count = 0;
-                }
+                if (dmask & 1)
+                    for (int k = 0; k < N && !found; k++) {       // darker arc
+                        if (ptr[pixel[k]] < vt_lo) { if (++count > K) found = true; } else count = 0;
+                    }
                 count = 0;
-                for (int k = 0; k < N && !found; k++) {           // brighter arc
-                    if (ptr[pixel[k]] > vt_hi) { if (++count > K) found = true; } else count = 0;
-                }
+                if (dmask & 2)
+                    for (int k = 0; k < N && !found; k++) {       // brighter arc
+                        if (ptr[pixel[k]] > vt_hi) { if (++count > K) found = true; } else count = 0;
+                    }
                 if (found) {
                     cornerpos[ncorners++] = j;
                     curr[j] = (uint8_t)corner_score16(ptr, pixel, threshold);

@@ -86,7 +86,6 @@ struct BAPtrs {
     double* part_maxdiag;     // nPointBlocks + nfree
     double* part_chi; double* part_scale;   // nPointBlocks
     BAState* st;
-    unsigned long long* dbg;   // 16 cycle stamps (instrumentation)
     const volatile unsigned char* stop;     // pinned host flag (may be NULL)
 };
 
@@ -396,8 +395,6 @@ __global__ __launch_bounds__(kThreads) void ba_solve_kernel(BAPtrs p, BADims d, 
     auto M = [&]() { if constexpr (USE_LDS) return s_mat; else return p.S; }();
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double lambda = st.lambda;
-#define STAMP(i) do { if (tid == 0) p.dbg[i] = __builtin_readcyclecounter(); } while (0)
-    STAMP(0);
     // assemble the lower triangle (+ diagonal) from the pair partials (all partial loads of an element issue together)
     __shared__ short s_pair[kMaxFree * (kMaxFree + 1) / 2][2];
     for (int t = tid; t < npairs; t += kThreads) {
@@ -441,7 +438,6 @@ __global__ __launch_bounds__(kThreads) void ba_solve_kernel(BAPtrs p, BADims d, 
     }
     if (tid == 0) s_ok = 1;
     __syncthreads();
-    STAMP(1);
     // Right-looking LDL^T of the lower triangle, blocked by the 6x6 camera blocks (n = 6*nfree): per block column one
     // in-register factorisation of the diagonal block (done redundantly by every thread: it is the dependent chain of six
     // divisions), one panel solve (thread per row) and one rank-6 trailing update (wave per row, lane per column) — two
@@ -509,8 +505,7 @@ __global__ __launch_bounds__(kThreads) void ba_solve_kernel(BAPtrs p, BADims d, 
     }
     if (failed && tid == 0) s_ok = 0;   // zero / non-finite pivot (Eigen SimplicialLDLT would report failure)
     __syncthreads();
-    STAMP(2);
-    STAMP(3);
+
     const int ok = s_ok;
     if (ok) {
         if (n <= 64) {
@@ -562,7 +557,6 @@ __global__ __launch_bounds__(kThreads) void ba_solve_kernel(BAPtrs p, BADims d, 
         for (int i = tid; i < n; i += kThreads) { p.xp[i] = 0.0; s_x[i] = 0.0; }
     }
     __syncthreads();
-    STAMP(4);
     if (tid == 0) p.st->solve_ok = ok;
     // pose update into the trial buffer (fixed poses are identical in both buffers and never touched)
     const int cur = st.cur, trial = cur ^ 1;
@@ -614,7 +608,6 @@ __global__ __launch_bounds__(kThreads) void ba_solve_kernel(BAPtrs p, BADims d, 
         quat_to_R(q, Ro);
         Ro[9] = t[0]; Ro[10] = t[1]; Ro[11] = t[2];
     }
-    STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------ backsub + trial errors
@@ -1006,7 +999,6 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     const size_t o_S = A.take<double>((size_t)std::max(d.n, 1) * (std::max(d.n, 1) + 1)), o_Sp = A.take<double>((size_t)b->nsplit * std::max(npairs_h, 1) * 42), o_xp = A.take<double>(std::max(d.n, 1));
     const size_t o_plc = A.take<double>(d.nPointBlocks), o_pmd = A.take<double>(d.nPointBlocks), o_pc = A.take<double>(d.nPointBlocks), o_ps = A.take<double>(d.nPointBlocks);
     const size_t o_st = A.take<BAState>(1);
-    const size_t o_dbg = A.take<unsigned long long>(16);
     int rc = b->arena.reserve(A.off + 256);
     if (rc) return rc;
     UH_HIP_CHECK(hipSetDevice(b->ctx->device));
@@ -1046,7 +1038,6 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     p.S = (double*)(base + o_S); p.Spart = (double*)(base + o_Sp); p.xp = (double*)(base + o_xp);
     p.part_lin_chi = (double*)(base + o_plc); p.part_maxdiag = (double*)(base + o_pmd); p.part_chi = (double*)(base + o_pc); p.part_scale = (double*)(base + o_ps);
     p.st = (BAState*)(base + o_st);
-    p.dbg = (unsigned long long*)(base + o_dbg);
     p.stop = nullptr;
     if (b->h_stop) {
         void* dflag = nullptr;
@@ -1105,11 +1096,6 @@ int uh_ba_get_results(uh_ba* b, float* poses_out, float* points_out, double* chi
 }
 
 // final pose state (qx qy qz qw tx ty tz per frame, fp64) — used by the parity tests to state the tolerance on se3
-int uh_ba_debug_stamps(uh_ba* b, unsigned long long* out16) {
-    UH_HIP_CHECK(hipMemcpy(out16, b->ptrs.dbg, 16 * 8, hipMemcpyDeviceToHost));
-    return UH_OK;
-}
-
 int uh_ba_get_pose_state(uh_ba* b, double* pose7_out) {
     UH_REQUIRE(b && b->have_problem && b->optimized && pose7_out, "uh_ba_get_pose_state: not ready");
     BAState hs;

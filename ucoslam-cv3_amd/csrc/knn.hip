@@ -31,71 +31,114 @@ struct ShardBounds { int n; int b[kMaxShards + 1]; };
 
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
-// Lane-distributed ResultSet: lane j holds heap slot j.  Every index below is wave-uniform (derived from ballots and
-// v_readlane results), so slot reads are single v_readlane_b32 and slot writes are v_cndmask selects — no exec-mask
-// branches inside a push.  The sifts use the "hole" formulation, which performs exactly the swaps of resultset.h.
+// Lane-distributed ResultSet: lane j holds heap slot j.  A push is BRANCH-FREE VECTOR CODE with a short dependent chain
+// of cross-lane operations (the latency of those, not ALU work, is what a push costs):
+//  * removing the root ("up", resultset.h:104-135): every slot picks its bigger child with the reference's tie rule
+//    (dr < dl ? left : right) [1st cross-lane round]; a slot lies on the descent path iff each of its ancestors chose the
+//    next node of the chain — all ancestors' choices are fetched at once [2nd round, together with the child's index];
+//    the moving element (old last) passes every path slot whose value is > it, each such slot takes its bigger child's
+//    entry (or the moving element where the descent stops).  Heap order makes "value > moving" monotone along the path.
+//  * appending ("down", :93-100): the ancestors of the new slot whose value is < the new distance take their parent's
+//    entry (or the new element where the climb stops) [3rd round].
+// The result equals the sequential swaps of the reference (tests compare the unsorted heap rows bit for bit).
 struct WaveHeap {
     int hd;    // per lane: distance of slot `lane`
     int hi;    // per lane: index of slot `lane`
     int size;  // wave-uniform
     int lane;
 
-    __device__ __forceinline__ void put(int slot, int d, int i) {
-        const bool m = lane == slot;
-        hd = m ? d : hd;
-        hi = m ? i : hi;
-    }
-    __device__ __forceinline__ void swap(int a, int b) {
+    __device__ __forceinline__ void swap(int a, int b) {   // only used by the final exchange sort
         const int da = rl(hd, a), db = rl(hd, b), ia = rl(hi, a), ib = rl(hi, b);
-        put(a, db, ib);
-        put(b, da, ia);
+        const bool ma = lane == a, mb = lane == b;
+        hd = ma ? db : (mb ? da : hd);
+        hi = ma ? ib : (mb ? ia : hi);
     }
-    // accept test of resultset.h:66-69 (radius bound, then "full and not better than the worst")
-    __device__ __forceinline__ bool accepts(int d, int k, int maxd) const {
+    __device__ __forceinline__ bool accepts(int d, int k, int maxd) const {   // resultset.h:66-69
         if (maxd >= 0 && maxd < d) return false;
         if (size >= k) return d < rl(hd, 0);
         return true;
     }
     // resultset.h:64-82, caller has already established accepts(d)
     __device__ __forceinline__ void push_accepted(int d, int idx, int k) {
+        const int parent = lane > 0 ? (lane - 1) >> 1 : 0;
         if (size >= k) {
-            // swap(0,size-1); size--; if (size>1) up(0): the old root moves to slot size-1, which the new element
-            // overwrites below, so only the old LAST element has to be re-seated from the root downwards ("up", :104-135)
+            const int last = size - 1;
+            const int md = rl(hd, last), mi = rl(hi, last);   // the element that re-enters at the root
+            size = last;
+            if (size >= 1) {
+                const int l = 2 * lane + 1, r = l + 1;
+                const int vl = __shfl(hd, l), vr = __shfl(hd, r);
+                const bool hasL = l < size, hasR = r < size;
+                const bool pickL = !hasR || (vr < vl);
+                const int c = pickL ? l : r;
+                const int cv = pickL ? vl : vr;
+                const int ci = __shfl(hi, c);
+                bool onpath = lane < size;
+                int node = lane;
+#pragma unroll
+                for (int t = 0; t < 6; t++) {                 // heap depth <= 6 for k <= 64
+                    const int par = node > 0 ? (node - 1) >> 1 : 0;
+                    const int cpar = __shfl(c, par);          // independent of the other rounds: all in flight together
+                    onpath = onpath && (node == 0 || cpar == node);
+                    node = par;
+                }
+                const bool reached = onpath && (lane == 0 || hd > md);
+                const bool takeChild = hasL && cv > md;
+                hd = reached ? (takeChild ? cv : md) : hd;
+                hi = reached ? (takeChild ? ci : mi) : hi;
+            }
+        }
+        const int s = size;
+        bool onanc = false;
+        for (int x = s + 1; x > 0; x >>= 1) onanc = onanc || (x - 1 == lane);   // s and its ancestors
+        const int pv = __shfl(hd, parent), pi = __shfl(hi, parent);
+        const bool mine = onanc && (lane == s || hd < d);
+        const bool takeParent = lane > 0 && pv < d;
+        hd = mine ? (takeParent ? pv : d) : hd;
+        hi = mine ? (takeParent ? pi : idx) : hi;
+        size = s + 1;
+    }
+    // Alternative formulation: the same sifts walked by wave-uniform SCALAR code (v_readlane + s_cselect), predicated
+    // per level instead of branching, slot updates as v_cndmask.  No LDS-crossbar (ds_bpermute) latency on the path.
+    __device__ __forceinline__ void put_if(bool on, int slot, int d, int i) {
+        const bool m = on && lane == slot;
+        hd = m ? d : hd;
+        hi = m ? i : hi;
+    }
+    __device__ __forceinline__ void push_accepted_scalar(int d, int idx, int k) {
+        if (size >= k) {
             const int last = size - 1;
             const int md = rl(hd, last), mi = rl(hi, last);
             size = last;
             if (size >= 1) {
                 int pos = 0;
-                if (size > 1) {
-                    for (;;) {
-                        const int l = 2 * pos + 1, r = l + 1;
-                        if (l >= size) break;
-                        const int dl = rl(hd, l);
-                        if (r >= size) {
-                            if (md < dl) { put(pos, dl, rl(hi, l)); pos = l; }
-                            break;
-                        }
-                        const int dr = rl(hd, r);
-                        const int c = (dr < dl) ? l : r;
-                        const int dc = (dr < dl) ? dl : dr;
-                        if (!(md < dc)) break;
-                        put(pos, dc, rl(hi, c));
-                        pos = c;
-                    }
+                bool go = size > 1;
+#pragma unroll
+                for (int t = 0; t < 6; t++) {
+                    const int l = 2 * pos + 1, r = l + 1;
+                    const bool hasL = go && l < size, hasR = go && r < size;
+                    const int dl = rl(hd, hasL ? l : 0), dr = rl(hd, hasR ? r : 0);
+                    const bool pickL = !hasR || dr < dl;
+                    const int c = pickL ? l : r, dc = pickL ? dl : dr;
+                    const bool mv = hasL && md < dc;
+                    const int ic = rl(hi, mv ? c : 0);
+                    put_if(mv, pos, dc, ic);
+                    pos = mv ? c : pos;
+                    go = mv;
                 }
-                put(pos, md, mi);
+                put_if(true, pos, md, mi);
             }
         }
-        // append at slot `size` and sift towards the root ("down", :93-100)
         int pos = size;
-        while (pos != 0) {
-            const int parent = (pos - 1) >> 1;
-            const int dp = rl(hd, parent);
-            if (!(dp < d)) break;
-            put(pos, dp, rl(hi, parent));
-            pos = parent;
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+            const int parent = pos > 0 ? (pos - 1) >> 1 : 0;
+            const int dp = rl(hd, parent), ip = rl(hi, parent);
+            const bool mv = pos > 0 && dp < d;
+            put_if(mv, pos, dp, ip);
+            pos = mv ? parent : pos;
         }
-        put(pos, d, idx);
+        put_if(true, pos, d, idx);
         size++;
     }
     __device__ __forceinline__ int threshold(int k) const { return size >= k ? rl(hd, 0) : 0x7fffffff; }
@@ -149,11 +192,16 @@ __device__ __forceinline__ void scan_range(WaveHeap& h, const uint8_t* __restric
             a0[u] = p[0];
             a1[u] = p[1];
         }
+        // one scalar decision per UNROLL steps: almost every group has no row below the current threshold, and each
+        // VALU -> ballot -> branch round trip costs more than the 16 VALU ops of a distance
+        int d[UNROLL];
+        bool any = false;
+        const int thr = h.threshold(k);
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            int d = hamming256(a0[u], a1[u], q);
-            feed_step<EMIT>(h, d, base + u * kWave + lane, true, k, maxd, cand_row, ncand, cap);
-        }
+        for (int u = 0; u < UNROLL; ++u) { d[u] = hamming256(a0[u], a1[u], q); any = any || d[u] < thr; }
+        if (__ballot(any) == 0) continue;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) feed_step<EMIT>(h, d[u], base + u * kWave + lane, true, k, maxd, cand_row, ncand, cap);
     }
     for (; base < t1; base += kWave) {
         int t = base + lane;
@@ -253,6 +301,26 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_replay_kernel(
     finish_row(h, k, sorted, indices, distances, qi);
 }
 
+// Measurement aid (scripts/knn_push_bench.py): cycles of N always-accepted pushes on one wave, with and without the
+// surrounding feed_step loop, to separate the heap update from the scan/branch overhead around it.
+__global__ void knn_push_bench_kernel(int k, int n, long long* out) {
+    const int lane = threadIdx.x & 63;
+    WaveHeap h{0, -1, 0, lane};
+    for (int i = 0; i < k; i++) h.push_accepted(100000 - i, i, k);
+    long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < n; i++) h.push_accepted(90000 - i, k + i, k);      // strictly decreasing: always accepted
+    long long t1 = __builtin_readcyclecounter();
+    int dummy = 0;
+    for (int i = 0; i < n; i++) {                                         // same pushes through feed_step (lane 0 carries the candidate)
+        const int d = lane == (i & 63) ? 80000 - i : 0x7ffffff0;
+        feed_step<false>(h, d, i, true, k, -1, nullptr, dummy, 0);
+    }
+    long long t2 = __builtin_readcyclecounter();
+    for (int i = 0; i < n; i++) h.push_accepted_scalar(70000 - i, k + i, k);
+    long long t3 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = t2 - t1; out[2] = t3 - t2; out[3] = h.hd + h.hi; }
+}
+
 }  // namespace
 
 struct uh_knn {
@@ -321,6 +389,15 @@ int uh_knn_set_shard(uh_knn* idx, int begin, int end) {
 }
 
 int uh_knn_size(const uh_knn* idx) { return idx ? idx->nt : 0; }
+
+int uh_knn_debug_push_cycles(uh_knn* idx, int k, int n, long long* out3) {
+    long long* d = nullptr;
+    UH_HIP_CHECK(hipMalloc(&d, 64));
+    UH_LAUNCH(idx->ctx, knn_push_bench_kernel, dim3(1), dim3(64), 0, k, n, d);
+    UH_HIP_CHECK(hipMemcpy(out3, d, 32, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return UH_OK;
+}
 
 static int check_search_args(const uh_knn* idx, const void* q, int nq, int nn, const void* i, const void* d) {
     UH_REQUIRE(idx, "uh_knn_search: NULL index");
