@@ -24,6 +24,7 @@
 // 6x3·3x3·3x6 products per landmark pair (fp64) — far below any matrix-core tile; see DESIGN.md.
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -144,20 +145,43 @@ __device__ __forceinline__ double block_sum(double v, double* s_red) {
     __syncthreads();
     return r;
 }
-// Deterministic block reduction of N values per thread in ONE barrier round: fixed xor-butterfly inside each wave, then
-// the four wave partials are added in wave order.  Results land in s_out[0..N) (valid for every thread after the call).
+// Deterministic block reduction of N values per thread.  Inside a wave the N x 64 values are reduced with a butterfly
+// TRANSPOSE: at every step a lane keeps one half of its values, ships the other half to its partner (lane ^ bit) and adds
+// what it receives, so the number of live values per lane halves while the number of lanes sharing a sum doubles —
+// N-1 + (padding) cross-lane moves in total instead of 6*N for N independent butterflies.  After the six steps lane
+// `l` owns the wave total of value index off(l) (at most one per lane).  The four wave totals are then added in wave order.
+// Every addition has a fixed operand pairing, so the result is run-to-run deterministic.
+template <int N, int BIT>
+struct WaveTranspose {
+    static constexpr int H = (N + 1) / 2;
+    // `real` = how many of this lane's N slots carry real values (the rest is zero padding introduced by odd halvings)
+    __device__ static __forceinline__ void run(double (&v)[N < 1 ? 1 : N], int lane, int& off, int& real) {
+        const bool up = (lane & BIT) != 0;
+        double nv[H];
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            const double lo = v[i];
+            const double hi = (i + H < N) ? v[(i + H < N) ? i + H : 0] : 0.0;
+            const double keep = up ? hi : lo, send = up ? lo : hi;
+            nv[i] = keep + __shfl_xor(send, BIT);
+        }
+        if (up) { off += H; real = real - H > 0 ? real - H : 0; }
+        else real = real < H ? real : H;
+#pragma unroll
+        for (int i = 0; i < H; i++) v[i] = nv[i];
+        if constexpr (BIT > 1) {
+            double (&w)[H] = reinterpret_cast<double (&)[H]>(v);
+            WaveTranspose<H, BIT / 2>::run(w, lane, off, real);
+        }
+    }
+};
+
 template <int N>
 __device__ __forceinline__ void block_sum_vec(double (&v)[N], double* s_part /* 4*N */, double* s_out /* N */) {
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
-    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < N; i++) s_part[wv * N + i] = v[i];
-    }
+    int off = 0, real = N;
+    WaveTranspose<N, 32>::run(v, lane, off, real);
+    if (real >= 1) s_part[wv * N + off] = v[0];   // exactly one lane per value index ends with a real slot; the others hold padding
     __syncthreads();
     if ((int)threadIdx.x < N) s_out[threadIdx.x] = ((s_part[threadIdx.x] + s_part[N + threadIdx.x]) + s_part[2 * N + threadIdx.x]) + s_part[3 * N + threadIdx.x];
     __syncthreads();
@@ -996,6 +1020,7 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     const size_t o_Hpp = A.take<double>(27 * (size_t)kCamChunks * std::max(nfree, 1)), o_bp = A.take<double>(std::max(d.n, 1));
     const int npairs_h = nfree * (nfree + 1) / 2;
     b->nsplit = std::max(1, std::min(8, uh_div_up(P, kThreads)));
+    if (const char* e = getenv("UH_BA_NSPLIT")) b->nsplit = std::max(1, std::min(8, atoi(e)));   // tuning knob (measurement only)
     const size_t o_S = A.take<double>((size_t)std::max(d.n, 1) * (std::max(d.n, 1) + 1)), o_Sp = A.take<double>((size_t)b->nsplit * std::max(npairs_h, 1) * 42), o_xp = A.take<double>(std::max(d.n, 1));
     const size_t o_plc = A.take<double>(d.nPointBlocks), o_pmd = A.take<double>(d.nPointBlocks), o_pc = A.take<double>(d.nPointBlocks), o_ps = A.take<double>(d.nPointBlocks);
     const size_t o_st = A.take<BAState>(1);
