@@ -32,6 +32,8 @@ namespace {
 
 constexpr int kMaxFree = 64;          // free (non-fixed) poses in the reduced system
 constexpr int kThreads = 256;
+constexpr int kSolveThreads = 512;                      // solve: one workgroup of 8 waves
+constexpr int kSolveWaves = kSolveThreads / 64;
 constexpr int kCamChunks = 8;                            // lin: workgroups per free camera
 constexpr int kLanesPerPoint = 8;                       // lin / backsub: lanes cooperating on one landmark
 constexpr int kPointsPerBlock = kThreads / kLanesPerPoint;
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, 
 // substitutes, and writes T_trial = exp(dx) * T_cur for the free poses.  Row stride is n+1 doubles (odd) so that column
 // walks are LDS-bank-conflict free.
 template <bool USE_LDS>
-__global__ __launch_bounds__(kThreads) void ba_solve_kernel(BAPtrs p, BADims d, int nsplit) {
+__global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADims d, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) double s_mat[];
     __shared__ double s_x[6 * kMaxFree];
     __shared__ int s_ok;
@@ -421,13 +423,13 @@ __global__ __launch_bounds__(kThreads) void ba_solve_kernel(BAPtrs p, BADims d, 
     const double lambda = st.lambda;
     // assemble the lower triangle (+ diagonal) from the pair partials (all partial loads of an element issue together)
     __shared__ short s_pair[kMaxFree * (kMaxFree + 1) / 2][2];
-    for (int t = tid; t < npairs; t += kThreads) {
+    for (int t = tid; t < npairs; t += kSolveThreads) {
         int s1 = 0, rem = t;
         while (rem >= d.nfree - s1) { rem -= d.nfree - s1; ++s1; }
         s_pair[t][0] = (short)s1; s_pair[t][1] = (short)(s1 + rem);
     }
     __syncthreads();
-    for (int t = tid; t < npairs * 42; t += kThreads) {
+    for (int t = tid; t < npairs * 42; t += kSolveThreads) {
         const int pair = t / 42, q = t - pair * 42;
         const int s1 = s_pair[pair][0], s2 = s_pair[pair][1];
         double x[8];
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(kThreads) void ba_solve_kernel(BAPtrs p, BADims d, 
             if (c <= i) M[(k0 + i) * ld + k0 + c] = v;
         }
         // (b) panel: L_rk = A_rk * Lkk^-T * Dk^-1, one thread per row
-        for (int r = k0 + 6 + tid; r < n; r += kThreads) {
+        for (int r = k0 + 6 + tid; r < n; r += kSolveThreads) {
             double y[6];
 #pragma unroll
             for (int j = 0; j < 6; j++) y[j] = M[r * ld + k0 + j];
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(kThreads) void ba_solve_kernel(BAPtrs p, BADims d, 
             double lc[6];
 #pragma unroll
             for (int t = 0; t < 6; t++) lc[t] = M[c * ld + k0 + t] * dk[t];
-            for (int r = c + ((wv - (c & 3)) & 3); r < n; r += 4) {   // rows r >= c with r % 4 == wv
+            for (int r = c + ((wv - (c & (kSolveWaves - 1))) & (kSolveWaves - 1)); r < n; r += kSolveWaves) {   // rows r >= c with r % kSolveWaves == wv
                 double acc = M[r * ld + c];
 #pragma unroll
                 for (int t = 0; t < 6; t++) acc -= M[r * ld + k0 + t] * lc[t];
@@ -564,21 +566,21 @@ __global__ __launch_bounds__(kThreads) void ba_solve_kernel(BAPtrs p, BADims d, 
             for (int j = 0; j < n; j++) {
                 const double xj = s_x[j];
                 __syncthreads();
-                for (int i = j + 1 + tid; i < n; i += kThreads) s_x[i] -= M[(size_t)i * ld + j] * xj;
+                for (int i = j + 1 + tid; i < n; i += kSolveThreads) s_x[i] -= M[(size_t)i * ld + j] * xj;
                 __syncthreads();
             }
-            for (int i = tid; i < n; i += kThreads) s_x[i] /= M[(size_t)i * ld + i];
+            for (int i = tid; i < n; i += kSolveThreads) s_x[i] /= M[(size_t)i * ld + i];
             __syncthreads();
             for (int j = n - 1; j >= 0; j--) {
                 const double xj = s_x[j];
                 __syncthreads();
-                for (int i = tid; i < j; i += kThreads) s_x[i] -= M[(size_t)j * ld + i] * xj;
+                for (int i = tid; i < j; i += kSolveThreads) s_x[i] -= M[(size_t)j * ld + i] * xj;
                 __syncthreads();
             }
-            for (int i = tid; i < n; i += kThreads) p.xp[i] = s_x[i];
+            for (int i = tid; i < n; i += kSolveThreads) p.xp[i] = s_x[i];
         }
     } else {
-        for (int i = tid; i < n; i += kThreads) { p.xp[i] = 0.0; s_x[i] = 0.0; }
+        for (int i = tid; i < n; i += kSolveThreads) { p.xp[i] = 0.0; s_x[i] = 0.0; }
     }
     __syncthreads();
     if (tid == 0) p.st->solve_ok = ok;
@@ -908,8 +910,8 @@ int enqueue_steps(uh_ba* b, int nsteps) {
     for (int s = 0; s < nsteps; s++) {
         UH_LAUNCH(b->ctx,ba_lin_kernel, dim3(d.nPointBlocks + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d);
         UH_LAUNCH(b->ctx,ba_schur_kernel, dim3(std::max(npairs, 1) * b->nsplit), dim3(kThreads), 0, b->ptrs, d, b->nsplit);
-        if (use_lds) UH_LAUNCH(b->ctx,ba_solve_kernel<true>, dim3(1), dim3(kThreads), lds, b->ptrs, d, b->nsplit);
-        else UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kThreads), lds, b->ptrs, d, b->nsplit);
+        if (use_lds) UH_LAUNCH(b->ctx,ba_solve_kernel<true>, dim3(1), dim3(kSolveThreads), lds, b->ptrs, d, b->nsplit);
+        else UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kSolveThreads), lds, b->ptrs, d, b->nsplit);
         UH_LAUNCH(b->ctx,ba_backsub_kernel, dim3(d.nPointBlocks), dim3(kThreads), 0, b->ptrs, d);
         UH_LAUNCH(b->ctx,ba_decide_kernel, dim3(1), dim3(64), 0, b->ptrs, d);
     }
