@@ -170,6 +170,18 @@ def main():
         stage_ms["match_ms_per_frame"] = timed(
             lambda: check(L.uh_knn_search_dev(index._h, dev_ptr(orb_out[1][0]), NQ, NN, dev_ptr(knn_idx[0]), dev_ptr(knn_dist[0]), 0, -1)), 50)
         stage_ms["ba_ms_per_keyframe"] = timed(lambda: ba.optimize(), 5)
+        # not part of the metric's step (ORB + match + local BA): the per-frame pose-only solve (PnPSolver::solvePnp, 600 matches)
+        from ucoslam_cv3_amd.pnp import PnPSolver
+
+        pnp_pr = synth.pnp_problem(600, seed=3)
+        pnp = PnPSolver(ctx)
+        pd = {k: torch.from_numpy(np.ascontiguousarray(pnp_pr[k])).to(dev) for k in ("pose", "intr", "p3d", "kp", "invsig", "weight")}
+        pwork = torch.empty(600 * 11 + 64, dtype=torch.uint8, device=dev)
+        pout = (torch.empty(16, dtype=torch.float32, device=dev), torch.empty(600, dtype=torch.uint8, device=dev),
+                torch.empty(5, dtype=torch.int32, device=dev), torch.empty(7, dtype=torch.float64, device=dev))
+        stage_ms["pnp_ms_per_solve_600_matches"] = timed(lambda: check(L.uh_pnp_solve_dev(
+            pnp._h, dev_ptr(pd["pose"]), dev_ptr(pd["intr"]), 600, dev_ptr(pd["p3d"]), dev_ptr(pd["kp"]), dev_ptr(pd["invsig"]), dev_ptr(pd["weight"]),
+            dev_ptr(pwork), dev_ptr(pout[0]), dev_ptr(pout[1]), dev_ptr(pout[2]), dev_ptr(pout[3]))), 20)
         if not args.no_roofline:
             ctx.prof_enable(True)
             ctx.prof_reset()

@@ -250,6 +250,25 @@ int uh_match_filter(const uh_match_filter_args* args, uh_dmatch* out, int cap);
 /* filter_ambiguous_train (by_train != 0) / filter_ambiguous_query (by_train == 0), in place; returns the new count */
 int uh_filter_ambiguous(uh_dmatch* matches, int n, int by_train);
 
+/* ------------------------------------------------------------------------
+ * Pose-only optimisation — replaces PnPSolver::solvePnp (monocular matches, no markers):
+ *   src/optimization/pnpsolver.h:30-38, pnpsolver.cpp:116-409; edge type typesg2o.h:590-650; kernel :82-105.
+ * Inputs per match i: map point p3d[i] (float xyz, MapPoint::getCoordinates), undistorted keypoint kp[i] (float x,y),
+ * inv_sigma[i] = 1/scaleFactors[octave] (float, :230), weight[i] = 1 or 0.5 for unstable points (:215-216).
+ * Outputs: pose (row-major 4x4 float), bad[i] (1 = outlier: the reference marks DMatch::imgIdx = -1), outer iterations of the
+ * four rounds.  Returns the inlier count (>= 0, solvePnp's return value) or a negative UH_E* code.
+ * ------------------------------------------------------------------------ */
+typedef struct uh_pnp uh_pnp;
+int  uh_pnp_create(uh_ctx* ctx, uh_pnp** out);
+void uh_pnp_destroy(uh_pnp* pnp);
+int  uh_pnp_solve(uh_pnp* pnp, const float* pose_f2g, const float* intr4, int n, const float* p3d, const float* kp,
+                  const float* inv_sigma, const float* weight, float* pose_out, uint8_t* bad_out, int32_t* iters_out4,
+                  double* state_out7);
+/* device-resident form: d_work = n*11 bytes of scratch (8-byte aligned); d_result5 = {inliers, iters[4]}; one launch, async */
+int  uh_pnp_solve_dev(uh_pnp* pnp, const float* d_pose_f2g, const float* d_intr4, int n, const float* d_p3d, const float* d_kp,
+                      const float* d_inv_sigma, const float* d_weight, void* d_work, float* d_pose_out, uint8_t* d_bad_out,
+                      int32_t* d_result5, double* d_state7);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "g2o/core/base_binary_edge.h"
+#include "g2o/core/base_unary_edge.h"
 #include "g2o/core/base_vertex.h"
 #include "g2o/core/block_solver.h"
 #include "g2o/core/optimization_algorithm_levenberg.h"
@@ -157,4 +158,99 @@ extern "C" int g2o_ref_ba_optimize(int K, int P, int E, const float* poses_f2g, 
         bad_out[e] = bad;
     }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ pose-only PnP
+namespace {
+
+class PoseOnlyE : public g2o::BaseUnaryEdge<2, Eigen::Vector2d, PoseV> {   // same parameterisation as typesg2o.h:590-650
+   public:
+    EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+    Eigen::Vector3d Xw;
+    double fx = 1, fy = 1, cx = 0, cy = 0;
+    bool read(std::istream&) override { return false; }
+    bool write(std::ostream&) const override { return false; }
+    Eigen::Vector3d in_camera() const { return static_cast<const PoseV*>(_vertices[0])->estimate().map(Xw); }
+    void computeError() override {
+        const Eigen::Vector3d c = in_camera();
+        _error = _measurement - Eigen::Vector2d((c[0] / c[2]) * fx + cx, (c[1] / c[2]) * fy + cy);
+    }
+    void linearizeOplus() override {
+        const Eigen::Vector3d c = in_camera();
+        const double x = c[0], y = c[1], iz = 1.0 / c[2], iz2 = iz * iz;
+        _jacobianOplusXi << x * y * iz2 * fx, -(1 + (x * x * iz2)) * fx, y * iz * fx, -iz * fx, 0, x * iz2 * fx,
+            (1 + y * y * iz2) * fy, -x * y * iz2 * fy, -x * iz * fy, 0, -iz * fy, y * iz2 * fy;
+    }
+};
+
+class WeightedHuber : public g2o::RobustKernel {   // the weight scales rho only (typesg2o.h:82-105)
+   public:
+    double W = 1, D = 1;
+    void robustify(double e2, g2o::Vector3& rho) const override {
+        const double dsqr = D * D;
+        if (e2 <= dsqr) { rho[0] = W * e2; rho[1] = 1.; rho[2] = 0.; }
+        else { const double sq = std::sqrt(e2); rho[0] = W * (2 * sq * D - dsqr); rho[1] = D / sq; rho[2] = -0.5 * rho[1] / e2; }
+    }
+};
+
+}  // namespace
+
+extern "C" int g2o_ref_pnp_solve(const float* pose_f2g, const float* intr4, int n, const float* p3d, const float* kp, const float* invsigma,
+                                 const float* weight, float* pose_out, uint8_t* bad_out, int32_t* iters_out, double* state_out) {
+    g2o::SparseOptimizer opt;
+    auto linearSolver = g2o::make_unique<g2o::LinearSolverEigen<g2o::BlockSolver_6_3::PoseMatrixType>>();
+    opt.setAlgorithm(new g2o::OptimizationAlgorithmLevenberg(g2o::make_unique<g2o::BlockSolver_6_3>(std::move(linearSolver))));
+    auto toSE3 = [&]() {
+        Eigen::Matrix3d R;
+        R << pose_f2g[0], pose_f2g[1], pose_f2g[2], pose_f2g[4], pose_f2g[5], pose_f2g[6], pose_f2g[8], pose_f2g[9], pose_f2g[10];
+        return g2o::SE3Quat(R, Eigen::Vector3d(pose_f2g[3], pose_f2g[7], pose_f2g[11]));
+    };
+    auto* cam = new PoseV();
+    cam->setEstimate(toSE3());
+    cam->setId(0);
+    cam->setFixed(false);
+    opt.addVertex(cam);
+    const float Chi2D = 5.99f;
+    const float thHuber2D = std::sqrt(5.99);
+    std::vector<PoseOnlyE*> ed(n);
+    for (int i = 0; i < n; i++) {
+        auto* e = new PoseOnlyE();
+        e->Xw = Eigen::Vector3d(p3d[3 * i], p3d[3 * i + 1], p3d[3 * i + 2]);
+        e->fx = intr4[0]; e->fy = intr4[1]; e->cx = intr4[2]; e->cy = intr4[3];
+        e->setVertex(0, cam);
+        e->setMeasurement(Eigen::Vector2d(kp[2 * i], kp[2 * i + 1]));
+        e->setInformation(Eigen::Matrix2d::Identity() * invsigma[i]);
+        auto* rk = new WeightedHuber();
+        rk->D = thHuber2D; rk->W = weight[i];
+        e->setRobustKernel(rk);
+        opt.addEdge(e);
+        ed[i] = e;
+    }
+    std::vector<char> bad(n, 0);
+    for (int it = 0; it < 4; it++) iters_out[it] = 0;
+    if (n > 0)
+        for (int it = 0; it < 4; it++) {
+            cam->setEstimate(toSE3());
+            opt.initializeOptimization(0);
+            iters_out[it] = opt.optimize(10);
+            int nGood = 0;
+            for (int i = 0; i < n; i++) {
+                if (bad[i]) ed[i]->computeError();
+                bad[i] = ed[i]->chi2() > Chi2D;
+                ed[i]->setLevel(bad[i] ? 1 : 0);
+                if (it >= 2) ed[i]->setRobustKernel(nullptr);
+                if (!bad[i]) nGood++;
+            }
+            if (nGood < 10) break;
+        }
+    Eigen::Matrix<double, 4, 4> Hm = cam->estimate().to_homogeneous_matrix();
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) pose_out[i * 4 + j] = (float)Hm(i, j);
+    int good = 0;
+    for (int i = 0; i < n; i++) { bad_out[i] = bad[i]; good += !bad[i]; }
+    if (state_out) {
+        const g2o::SE3Quat& T = cam->estimate();
+        state_out[0] = T.rotation().x(); state_out[1] = T.rotation().y(); state_out[2] = T.rotation().z(); state_out[3] = T.rotation().w();
+        state_out[4] = T.translation()[0]; state_out[5] = T.translation()[1]; state_out[6] = T.translation()[2];
+    }
+    return good;
 }

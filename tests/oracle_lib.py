@@ -121,3 +121,22 @@ def ba_optimize(L, pr, nIters=5):
 
 def ba_optimize_ref(R, pr, nIters=5):
     return _ba_call(R.g2o_ref_ba_optimize, pr, nIters, False)
+
+
+# ------------------------------------------------------------------------------------------------ PnP
+def _pnp_call(fn, pr):
+    n = pr["n"]
+    out = dict(pose=_np.zeros(16, _np.float32), bad=_np.zeros(max(n, 1), _np.uint8), iters=_np.zeros(4, _np.int32), state=_np.zeros(7, _np.float64))
+    fn.restype = I
+    out["ngood"] = fn(P(pr["pose"]), P(pr["intr"]), n, P(pr["p3d"]), P(pr["kp"]), P(pr["invsig"]), P(pr["weight"]), P(out["pose"]), P(out["bad"]),
+                      P(out["iters"]), P(out["state"]))
+    out["bad"] = out["bad"][:n]
+    return out
+
+
+def pnp_solve(L, pr):
+    return _pnp_call(L.oracle_pnp_solve, pr)
+
+
+def pnp_solve_ref(R, pr):
+    return _pnp_call(R.g2o_ref_pnp_solve, pr)

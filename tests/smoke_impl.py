@@ -42,3 +42,10 @@ def run():
     ref = oracle_lib.ba_optimize(L, pr, 5)
     assert got["iters"].tolist() == ref["iters"].tolist()
     assert np.abs(got["state"] - ref["state"]).max() < 1e-6, "BA pose state differs from the oracle by more than 1e-6"
+    # --- per-frame pose-only solve
+    from ucoslam_cv3_amd.pnp import PnPSolver
+
+    pp = synth.pnp_problem(200, seed=5)
+    g = PnPSolver(ctx).solvePnp(pp["pose"], pp["intr"], pp["p3d"], pp["kp"], pp["invsig"], pp["weight"])
+    r = oracle_lib.pnp_solve(L, pp)
+    assert g["ngood"] == r["ngood"] and (g["bad"] == r["bad"]).all() and np.abs(g["state"] - r["state"]).max() < 1e-6, "PnP differs from the oracle"

@@ -182,3 +182,26 @@ def vocabulary(k=10, depth=3, seed=0, aligment=8):
     params = struct.pack("<50s2xII4xQQQQQiiI4x", b"orb", aligment, nblocks, desc_wp, block_size, feature_off, child_off, total, 0, 32, k)
     assert len(params) == 120
     return params, blob.tobytes(), dict(nblocks=nblocks, nwords=word, block_size=block_size)
+
+
+def pnp_problem(n=600, seed=0, outlier_frac=0.15, pose_noise=0.03, pix_noise=0.7, w=1241, h=376):
+    """Synthetic per-frame pose estimation (PnPSolver::solvePnp inputs): n map points seen by one frame, a perturbed initial
+    pose, pixel noise, gross outliers, octave-dependent information and some 'unstable' points with half weight."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 718.856
+    cx, cy = 607.19, 185.22
+    Tgt = _se3_exp(np.r_[0.01, -0.02, 0.005, 0, 0, 0]) @ np.eye(4)
+    Tgt[:3, 3] = [0.4, -0.1, 0.2]
+    z = rng.uniform(4, 40, n)
+    Xc = np.stack([(rng.uniform(20, w - 20, n) - cx) / fx * z, (rng.uniform(20, h - 20, n) - cy) / fy * z, z], 1)
+    Xw = (Xc - Tgt[:3, 3]) @ Tgt[:3, :3]          # R^T (Xc - t)
+    uv = np.stack([fx * Xc[:, 0] / z + cx, fy * Xc[:, 1] / z + cy], 1) + rng.normal(0, pix_noise, (n, 2))
+    out = rng.random(n) < outlier_frac
+    uv[out] += rng.normal(0, 30, (int(out.sum()), 2))
+    octave = rng.integers(0, 8, n)
+    invsig = (1.0 / (np.float32(1.2) ** octave.astype(np.float32))).astype(np.float32)
+    weight = np.where(rng.random(n) < 0.2, 0.5, 1.0).astype(np.float32)
+    T0 = (_se3_exp(rng.normal(0, pose_noise, 6)) @ Tgt).astype(np.float32)
+    return dict(pose=np.ascontiguousarray(T0.reshape(16)), intr=np.array([fx, fy, cx, cy], np.float32), n=n,
+                p3d=np.ascontiguousarray(Xw.astype(np.float32)), kp=np.ascontiguousarray(uv.astype(np.float32)), invsig=invsig, weight=weight,
+                pose_gt=Tgt, outlier=out)
