@@ -13,13 +13,20 @@
 // MI355X design.  The problem is tiny for this chip (~26k edges, 3000 landmarks, <=64 free poses), so the enemy is latency,
 // not bandwidth: the whole LM control flow lives in a device-resident state machine (BAState) and the host only enqueues a
 // fixed sequence of "steps" (one LM trial each) — no host synchronisation inside a pass.  Every kernel starts by reading the
-// state and returns immediately once the pass is done.  One step = 5 launches:
-//   lin     (only after an accepted trial)  per-landmark thread: errors, Huber weights, Hll, bl, per-edge Hpl blocks;
-//                                           per-free-camera workgroup: Hpp, bp (deterministic tree reduction)
-//   schur   one workgroup per (camera i1 <= i2) block of the reduced system: S = Hpp + lambda I - sum_l Hpl D^-1 Hpl^T
-//   solve   one workgroup: dense LDL^T of the <=384x384 reduced system in LDS, pose update T <- exp(dx) T into the trial buffer
-//   backsub per-landmark thread: dx_l = D^-1 (b_l - Hpl^T dx_p), trial point, trial errors, partial chi2 / scale sums
-//   decide  one thread: rho, accept (flip current<->trial buffers) or reject (lambda *= nu), iteration/termination logic
+// state and returns immediately once the pass is done.  One step = 4 launches (+ lin at the first trial of a pass):
+//   lin     (first trial of a pass only)  8 lanes per landmark: errors, Huber weights, Hll, bl, per-edge Hpl blocks;
+//                                          8 workgroups per free camera: Hpp, bp partials (deterministic tree reduction)
+//   schur   one workgroup per (camera i1 <= i2, landmark chunk): partial Hpl D^-1 Hpl^T blocks of the reduced system;
+//           plus the camera workgroups (Hpp, bp at the current estimate) on every trial but the first
+//   solve   one workgroup: S = Hpp + lambda I - sum of partials, dense blocked LDL^T of the <=384x384 system (LDS when
+//           n <= 120), pose update T <- exp(dx) T into the trial buffer
+//   backsub 8 lanes per landmark: dx_l = D^-1 (b_l - Hpl^T dx_p), trial point, trial errors, partial chi2 / scale sums, and
+//           speculatively the linearisation AT THE TRIAL estimate into the trial half of the double-buffered Hll/bl/Hpl:
+//           accepting a trial flips estimate and linearisation together, so no lin launch follows it
+//   decide  one wave: rho, accept (flip current<->trial buffers) or reject (lambda *= nu), iteration/termination logic
+// (Folding solve and decide into the last-finishing workgroup of their producer launch — the threadfence-reduction pattern —
+// was measured and rejected: the agent-scope fences write back / invalidate the per-XCD L2s once per workgroup and cost
+// 15 us per step, five times the kernel boundary they save.)
 // All reductions run in a fixed order, so results are run-to-run deterministic.  MFMA is not used: the only dense algebra is
 // 6x3·3x3·3x6 products per landmark pair (fp64) — far below any matrix-core tile; see DESIGN.md.
 #include <cfloat>
@@ -33,8 +40,9 @@ namespace {
 
 constexpr int kMaxFree = 64;          // free (non-fixed) poses in the reduced system
 constexpr int kThreads = 256;
-constexpr int kSolveThreads = 512;                      // solve: one workgroup of 8 waves
-constexpr int kSolveWaves = kSolveThreads / 64;
+constexpr int kSolveThreads = 256;                      // solve: one workgroup of 4 waves (one per SIMD)
+constexpr int kMaxSplit = 12;                           // schur: landmark chunks per camera pair (partials the solve adds)
+constexpr int kTrailU = 4;                              // solve: trailing-update elements in flight per thread
 constexpr int kCamChunks = 8;                            // lin: workgroups per free camera
 constexpr int kLanesPerPoint = 8;                       // lin / backsub: lanes cooperating on one landmark
 constexpr int kPointsPerBlock = kThreads / kLanesPerPoint;
@@ -47,7 +55,7 @@ struct BAState {
     int cur;          // which of the two state buffers holds the current estimate
     int solve_ok;
     int iters_done;
-    int lin_ran;      // this step linearised (currentChi comes from the lin partial sums)
+    int first_trial;  // first trial of the pass: the lin kernel linearises; afterwards the backsub kernel does it speculatively
     int stopped;      // force-stop flag observed
     double lambda, ni, currentChi, lastChiRaw, rho;
     float prevChi2, curChi2, minChi2;
@@ -80,8 +88,8 @@ struct BAPtrs {
     double* e_err;            // E x 2
     double* e_chi2;           // E
     // system
-    double* Hll; double* bl;  // P x 9, P x 3
-    double* Hpl;              // E x 18 (6x3 row-major)
+    double* Hll[2]; double* bl[2];   // P x 9, P x 3: linearisation at the estimate in state buffer 0 / 1
+    double* Hpl[2];           // E x 18 (6x3 row-major), per state buffer
     double* HppPart; double* bp;   // nfree x kCamChunks x 27 partial (21 upper Hpp entries + 6 of bp); summed bp nfree x 6
     double* S;                // (n x (n+1)) HBM workspace of the factorisation when it does not fit in LDS
     double* Spart;            // nsplit x npairs x 42: schur partials (6x6 block + 6-vector)
@@ -91,7 +99,11 @@ struct BAPtrs {
     double* part_chi; double* part_scale;   // nPointBlocks
     BAState* st;
     const volatile unsigned char* stop;     // pinned host flag (may be NULL)
+    long long* clk;           // 64 phase timestamps (100 MHz s_memrealtime) of the latest step, read by uh_ba_debug_clocks
 };
+
+#define UH_BA_CLK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) p.clk[i] = wall_clock64(); } while (0)
+#define UH_BA_CLKL(i) do { if (threadIdx.x == 0) { p.clk[i] = wall_clock64(); p.clk[32 + i] = clock64(); } } while (0)   // single-workgroup kernels
 
 // ------------------------------------------------------------------------------------------------ small fp64 helpers
 __device__ __forceinline__ void quat_to_R(const double* q, double* R) {
@@ -136,6 +148,22 @@ __device__ __forceinline__ void inv3(const double* M, double* I) {
     I[6] = c02 * id; I[7] = (M[1] * M[6] - M[0] * M[7]) * id; I[8] = (M[0] * M[4] - M[1] * M[3]) * id;
 }
 
+// 1/d by v_rcp_f64 + two Newton steps (about 1 ulp): the pivots of the LDL^T sit on its longest dependent chain, where the
+// IEEE division sequence (scale, rcp, 5 fma, fmas, fixup) costs twice as much.  Zero / non-finite d is tested by the caller.
+__device__ __forceinline__ double fast_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane_uniform) {   // lane index must be wave-uniform
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane_uniform);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane_uniform);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 struct EdgeLin {          // one edge's linearisation at a given state
     double ex, ey, chi2, rho1, ww, r0, r1;
     double A[6], B[12];
@@ -177,98 +205,115 @@ __device__ __forceinline__ void edge_eval(const BAPtrs& p, const BADims& d, int 
     }
 }
 
+// Linearisation of one landmark by its 8 lanes (one observation each per round; 32 landmarks per workgroup): errors, Huber
+// weights, Hll, bl and the per-edge Hpl blocks at pose set poseR / point X, written to linearisation buffer `buf`.  The 8 partial sums are added with a fixed xor
+// butterfly, so the result is deterministic and identical in all 8 lanes.  Lane gl==0 returns the landmark's robust chi2
+// and max |diag Hll| (others 0).  Used by the lin kernel (current estimate) and by the backsub kernel (trial estimate).
+__device__ __forceinline__ void linearize_point(const BAPtrs& p, const BADims& d, int buf, int pt, int gl, bool live,
+                                                const double* poseR, const double* X, double& chi_part, double& maxd) {
+    double acc[10];   // Hll upper (6), bl (3), robust chi2 (1)
+#pragma unroll
+    for (int i = 0; i < 10; i++) acc[i] = 0;
+    bool any = false;
+    if (live) {
+        for (int i = p.pt_ptr[pt] + gl; i < p.pt_ptr[pt + 1]; i += kLanesPerPoint) {
+            const int e = p.pt_edges[i];
+            if (!p.e_active[e]) continue;
+            any = true;
+            const int k = p.e_kf[e];
+            EdgeLin L;
+            edge_eval<true>(p, d, e, k, poseR + 12 * k, X, p.e_robust[e] != 0, L);
+            p.e_err[2 * e] = L.ex; p.e_err[2 * e + 1] = L.ey;
+            p.e_chi2[e] = L.chi2;
+            acc[9] += L.robchi;
+            acc[0] += L.ww * (L.A[0] * L.A[0] + L.A[3] * L.A[3]); acc[1] += L.ww * (L.A[0] * L.A[1] + L.A[3] * L.A[4]);
+            acc[2] += L.ww * (L.A[0] * L.A[2] + L.A[3] * L.A[5]); acc[3] += L.ww * (L.A[1] * L.A[1] + L.A[4] * L.A[4]);
+            acc[4] += L.ww * (L.A[1] * L.A[2] + L.A[4] * L.A[5]); acc[5] += L.ww * (L.A[2] * L.A[2] + L.A[5] * L.A[5]);
+            acc[6] += L.A[0] * L.r0 + L.A[3] * L.r1; acc[7] += L.A[1] * L.r0 + L.A[4] * L.r1; acc[8] += L.A[2] * L.r0 + L.A[5] * L.r1;
+            if (p.slot[k] >= 0) {
+                double* Hx = p.Hpl[buf] + 18 * (size_t)e;
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) Hx[a * 3 + c] = L.ww * (L.B[a] * L.A[c] + L.B[6 + a] * L.A[3 + c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+#pragma unroll
+        for (int o = kLanesPerPoint / 2; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o);
+    }
+    const unsigned long long anym = __ballot(any);
+    const bool any_pt = ((anym >> ((threadIdx.x & 63) & ~(kLanesPerPoint - 1))) & 0xFFull) != 0;
+    chi_part = 0; maxd = 0;
+    if (live && gl == 0) {
+        double* Hl = p.Hll[buf] + 9 * (size_t)pt;
+        Hl[0] = acc[0]; Hl[1] = acc[1]; Hl[2] = acc[2]; Hl[3] = acc[1]; Hl[4] = acc[3]; Hl[5] = acc[4]; Hl[6] = acc[2]; Hl[7] = acc[4]; Hl[8] = acc[5];
+        double* bo = p.bl[buf] + 3 * (size_t)pt;
+        bo[0] = acc[6]; bo[1] = acc[7]; bo[2] = acc[8];
+        chi_part = acc[9];
+        if (any_pt) maxd = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
+    }
+}
+
+// One (free camera, chunk of its observations) workgroup: partial Hpp (21 upper entries) and bp (6) at the CURRENT estimate;
+// the chunks are added in order by the consumers (lambda init in the schur kernel, assembly in the solve kernel).  Runs in
+// the lin launch when that kernel linearises, else as extra workgroups of the schur launch.
+__device__ __forceinline__ void camera_block(const BAPtrs& p, const BADims& d, int cb, const double* poseR, const double* pts) {
+    const int s = cb / kCamChunks, chunk = cb - s * kCamChunks;
+    const int k = p.free_kf[s];
+    double Rt[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) Rt[i] = poseR[12 * k + i];
+    double acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) acc[i] = 0;
+    for (int i = p.cam_ptr[s] + chunk * kThreads + threadIdx.x; i < p.cam_ptr[s + 1]; i += kCamChunks * kThreads) {
+        const int e = p.cam_edges[i];
+        if (!p.e_active[e]) continue;
+        const int pt = p.e_pt[e];
+        const double X[3] = {pts[3 * pt], pts[3 * pt + 1], pts[3 * pt + 2]};
+        EdgeLin L;
+        edge_eval<true>(p, d, e, k, Rt, X, p.e_robust[e] != 0, L);
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int c = a; c < 6; c++) acc[q++] += L.ww * (L.B[a] * L.B[c] + L.B[6 + a] * L.B[6 + c]);
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[21 + a] += L.B[a] * L.r0 + L.B[6 + a] * L.r1;
+    }
+    __shared__ double s_part[4 * 27];
+    __shared__ double s_out27[27];
+    block_sum_vec<27>(acc, s_part, s_out27);
+    if (threadIdx.x < 27) p.HppPart[(size_t)cb * 27 + threadIdx.x] = s_out27[threadIdx.x];
+}
+
 // ------------------------------------------------------------------------------------------------ lin
-// grid = nPointBlocks + nfree.  Blocks [0,nPointBlocks): one thread per landmark.  Blocks beyond: one per free camera.
+// grid = nPointBlocks + nfree*kCamChunks.  Launched once per pass (first trial); later linearisations come from backsub.
 __global__ __launch_bounds__(kThreads) void ba_lin_kernel(BAPtrs p, BADims d) {
     __shared__ double s_red[kThreads];
     const BAState st = *p.st;
-    if (st.phase != 0) return;
+    if (st.phase == 2 || !st.first_trial) return;
+    UH_BA_CLK(0);
     const int cur = st.cur;
     const double* poseR = p.poseR[cur];
     const double* pts = p.pts[cur];
     if ((int)blockIdx.x < d.nPointBlocks) {
-        // 8 lanes per landmark (one observation each per round), 32 landmarks per workgroup; the 8 partial sums are added
-        // with a fixed xor butterfly, so the result is deterministic and identical in all 8 lanes
         const int gl = threadIdx.x & (kLanesPerPoint - 1);
         const int pt = blockIdx.x * kPointsPerBlock + (threadIdx.x >> 3);
-        double acc[10];   // Hll upper (6), bl (3), robust chi2 (1)
-#pragma unroll
-        for (int i = 0; i < 10; i++) acc[i] = 0;
-        bool any = false;
-        if (pt < d.P) {
-            const double X[3] = {pts[3 * pt], pts[3 * pt + 1], pts[3 * pt + 2]};
-            for (int i = p.pt_ptr[pt] + gl; i < p.pt_ptr[pt + 1]; i += kLanesPerPoint) {
-                const int e = p.pt_edges[i];
-                if (!p.e_active[e]) continue;
-                any = true;
-                const int k = p.e_kf[e];
-                EdgeLin L;
-                edge_eval<true>(p, d, e, k, poseR + 12 * k, X, p.e_robust[e] != 0, L);
-                p.e_err[2 * e] = L.ex; p.e_err[2 * e + 1] = L.ey;
-                p.e_chi2[e] = L.chi2;
-                acc[9] += L.robchi;
-                acc[0] += L.ww * (L.A[0] * L.A[0] + L.A[3] * L.A[3]); acc[1] += L.ww * (L.A[0] * L.A[1] + L.A[3] * L.A[4]);
-                acc[2] += L.ww * (L.A[0] * L.A[2] + L.A[3] * L.A[5]); acc[3] += L.ww * (L.A[1] * L.A[1] + L.A[4] * L.A[4]);
-                acc[4] += L.ww * (L.A[1] * L.A[2] + L.A[4] * L.A[5]); acc[5] += L.ww * (L.A[2] * L.A[2] + L.A[5] * L.A[5]);
-                acc[6] += L.A[0] * L.r0 + L.A[3] * L.r1; acc[7] += L.A[1] * L.r0 + L.A[4] * L.r1; acc[8] += L.A[2] * L.r0 + L.A[5] * L.r1;
-                if (p.slot[k] >= 0) {
-                    double* Hx = p.Hpl + 18 * (size_t)e;
-#pragma unroll
-                    for (int a = 0; a < 6; a++)
-#pragma unroll
-                        for (int c = 0; c < 3; c++) Hx[a * 3 + c] = L.ww * (L.B[a] * L.A[c] + L.B[6 + a] * L.A[3 + c]);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 10; i++) {
-#pragma unroll
-            for (int o = kLanesPerPoint / 2; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o);
-        }
-        unsigned long long anym = __ballot(any);
-        const bool any_pt = ((anym >> ((threadIdx.x & 63) & ~(kLanesPerPoint - 1))) & 0xFFull) != 0;
-        double chi_part = 0, maxd = 0;
-        if (pt < d.P && gl == 0) {
-            double* Hl = p.Hll + 9 * (size_t)pt;
-            Hl[0] = acc[0]; Hl[1] = acc[1]; Hl[2] = acc[2]; Hl[3] = acc[1]; Hl[4] = acc[3]; Hl[5] = acc[4]; Hl[6] = acc[2]; Hl[7] = acc[4]; Hl[8] = acc[5];
-            p.bl[3 * pt] = acc[6]; p.bl[3 * pt + 1] = acc[7]; p.bl[3 * pt + 2] = acc[8];
-            chi_part = acc[9];
-            if (any_pt) maxd = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
-        }
+        const bool live = pt < d.P;
+        const int ptc = live ? pt : 0;
+        const double X[3] = {pts[3 * ptc], pts[3 * ptc + 1], pts[3 * ptc + 2]};
+        double chi_part, maxd;
+        linearize_point(p, d, cur, pt, gl, live, poseR, X, chi_part, maxd);
         const double cs = block_sum(chi_part, s_red);
         const double mx = block_max(maxd, s_red);
         if (threadIdx.x == 0) { p.part_lin_chi[blockIdx.x] = cs; p.part_maxdiag[blockIdx.x] = mx; }
+        UH_BA_CLK(1);
     } else {
-        // one workgroup per (free camera, chunk of its observations): partial Hpp (21 upper entries) and bp (6); the chunks
-        // are added in order by the consumers (lambda init in the schur kernel, assembly in the solve kernel)
-        const int cb = blockIdx.x - d.nPointBlocks;
-        const int s = cb / kCamChunks, chunk = cb - s * kCamChunks;
-        const int k = p.free_kf[s];
-        double Rt[12];
-#pragma unroll
-        for (int i = 0; i < 12; i++) Rt[i] = poseR[12 * k + i];
-        double acc[27];
-#pragma unroll
-        for (int i = 0; i < 27; i++) acc[i] = 0;
-        for (int i = p.cam_ptr[s] + chunk * kThreads + threadIdx.x; i < p.cam_ptr[s + 1]; i += kCamChunks * kThreads) {
-            const int e = p.cam_edges[i];
-            if (!p.e_active[e]) continue;
-            const int pt = p.e_pt[e];
-            const double X[3] = {pts[3 * pt], pts[3 * pt + 1], pts[3 * pt + 2]};
-            EdgeLin L;
-            edge_eval<true>(p, d, e, k, Rt, X, p.e_robust[e] != 0, L);
-            int q = 0;
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-                for (int c = a; c < 6; c++) acc[q++] += L.ww * (L.B[a] * L.B[c] + L.B[6 + a] * L.B[6 + c]);
-#pragma unroll
-            for (int a = 0; a < 6; a++) acc[21 + a] += L.B[a] * L.r0 + L.B[6 + a] * L.r1;
-        }
-        __shared__ double s_part[4 * 27];
-        __shared__ double s_out27[27];
-        block_sum_vec<27>(acc, s_part, s_out27);
-        if (threadIdx.x < 27) p.HppPart[(size_t)cb * 27 + threadIdx.x] = s_out27[threadIdx.x];
+        camera_block(p, d, blockIdx.x - d.nPointBlocks, poseR, pts);
     }
 }
 
@@ -279,8 +324,29 @@ __global__ __launch_bounds__(kThreads) void ba_lin_kernel(BAPtrs p, BADims d) {
 __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, int nsplit) {
     __shared__ double s_part[4 * 42];
     __shared__ double s_out[42];
+    // workgroup role and, for pair workgroups, the first landmark's edge ids and activity flags: none of it depends on the LM
+    // state, so these loads are in flight together with the state load instead of behind it (each dependent HBM round trip
+    // is ~1 us of this kernel's ~8)
+    const int npairs = d.nfree * (d.nfree + 1) / 2;
+    const int npairblocks = (npairs > 0 ? npairs : 1) * nsplit;
+    const bool cam_role = (int)blockIdx.x >= npairblocks;
+    const int pair = blockIdx.x / nsplit, chunk = blockIdx.x - pair * nsplit;
+    const bool have_pair = !cam_role && pair < npairs;   // structure-only BA: the single workgroup only publishes lambda
+    int s1 = 0, rem = have_pair ? pair : 0;
+    while (have_pair && rem >= d.nfree - s1) { rem -= d.nfree - s1; ++s1; }
+    const int s2 = s1 + rem;
+    const bool diag = s1 == s2;
+    const int pt0 = chunk * kThreads + threadIdx.x;
+    int e1n = -1, e2n = -1;
+    if (have_pair && pt0 < d.P) {
+        e1n = p.edge_of[(size_t)pt0 * d.nfree + s1];
+        e2n = diag ? e1n : p.edge_of[(size_t)pt0 * d.nfree + s2];
+    }
+    bool actn = e1n >= 0 && e2n >= 0;
+    if (actn) actn = (p.e_active[e1n] != 0) & (p.e_active[e2n] != 0);
     const BAState st = *p.st;
     if (st.phase == 2) return;
+    UH_BA_CLK(4);
     double lambda = st.lambda;
     if (st.iteration == 0 && st.qmax == 0) {   // tau * max |H_jj| over poses and landmarks
         double m = 0;
@@ -297,33 +363,35 @@ __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, 
         lambda = 1e-5 * m;
         if (blockIdx.x == 0 && threadIdx.x == 0) { p.st->lambda = lambda; p.st->ni = 2; }
     }
-    const int npairs = d.nfree * (d.nfree + 1) / 2;
-    const int pair = blockIdx.x / nsplit, chunk = blockIdx.x - pair * nsplit;
-    if (pair >= npairs) return;   // structure-only BA: the launch exists only to publish lambda
-    int s1 = 0, rem = pair;
-    while (rem >= d.nfree - s1) { rem -= d.nfree - s1; ++s1; }
-    const int s2 = s1 + rem;
-    const bool diag = s1 == s2;
+    if (cam_role) {   // camera workgroups: Hpp / bp partials (the lin kernel has them at the first trial)
+        if (!st.first_trial) camera_block(p, d, blockIdx.x - npairblocks, p.poseR[st.cur], p.pts[st.cur]);
+        return;
+    }
     double acc[42];
 #pragma unroll
     for (int i = 0; i < 42; i++) acc[i] = 0;
-    for (int pt = chunk * kThreads + threadIdx.x; pt < d.P; pt += nsplit * kThreads) {
-        const int e1 = p.edge_of[(size_t)pt * d.nfree + s1];
-        if (e1 < 0 || !p.e_active[e1]) continue;
-        const int e2 = diag ? e1 : p.edge_of[(size_t)pt * d.nfree + s2];
-        if (e2 < 0 || !p.e_active[e2]) continue;
+    for (int pt = pt0; have_pair && pt < d.P; pt += nsplit * kThreads) {
+        int e1 = e1n, e2 = e2n;
+        bool act = actn;
+        if (pt != pt0) {   // later rounds (P > nsplit*256 landmarks per pair)
+            e1 = p.edge_of[(size_t)pt * d.nfree + s1];
+            e2 = diag ? e1 : p.edge_of[(size_t)pt * d.nfree + s2];
+            act = e1 >= 0 && e2 >= 0;
+            if (act) act = (p.e_active[e1] != 0) & (p.e_active[e2] != 0);
+        }
+        if (!act) continue;
         double D[9], Di[9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) D[i] = p.Hll[9 * (size_t)pt + i];
+        for (int i = 0; i < 9; i++) D[i] = p.Hll[st.cur][9 * (size_t)pt + i];
         D[0] += lambda; D[4] += lambda; D[8] += lambda;
         inv3(D, Di);
         double b1[18], b2[18];
-        const double* B1 = p.Hpl + 18 * (size_t)e1;
-        const double* B2 = p.Hpl + 18 * (size_t)e2;
+        const double* B1 = p.Hpl[st.cur] + 18 * (size_t)e1;
+        const double* B2 = p.Hpl[st.cur] + 18 * (size_t)e2;
 #pragma unroll
         for (int i = 0; i < 18; i++) { b1[i] = B1[i]; b2[i] = B2[i]; }
         double l0 = 0, l1 = 0, l2 = 0;
-        if (diag) { l0 = p.bl[3 * pt]; l1 = p.bl[3 * pt + 1]; l2 = p.bl[3 * pt + 2]; }
+        if (diag) { const double* bi = p.bl[st.cur] + 3 * (size_t)pt; l0 = bi[0]; l1 = bi[1]; l2 = bi[2]; }
 #pragma unroll
         for (int a = 0; a < 6; a++) {
             const double y0 = b1[a * 3] * Di[0] + b1[a * 3 + 1] * Di[3] + b1[a * 3 + 2] * Di[6];
@@ -335,7 +403,8 @@ __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, 
         }
     }
     block_sum_vec<42>(acc, s_part, s_out);
-    if (threadIdx.x < 42) p.Spart[((size_t)chunk * npairs + pair) * 42 + threadIdx.x] = s_out[threadIdx.x];
+    if (have_pair && threadIdx.x < 42) p.Spart[((size_t)chunk * npairs + pair) * 42 + threadIdx.x] = s_out[threadIdx.x];
+    UH_BA_CLK(5);
 }
 
 // ------------------------------------------------------------------------------------------------ solve + pose update
@@ -344,19 +413,18 @@ __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, 
 // substitutes, and writes T_trial = exp(dx) * T_cur for the free poses.  Row stride is n+1 doubles (odd) so that column
 // walks are LDS-bank-conflict free.
 template <bool USE_LDS>
-__global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADims d, int nsplit) {
+__device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) double s_mat[];
     __shared__ double s_x[6 * kMaxFree];
     __shared__ int s_ok;
-    const BAState st = *p.st;
-    if (st.phase == 2) return;
     const int n = d.n, ld = n + 1;
     const int npairs = d.nfree * (d.nfree + 1) / 2;
     // the address space must be known at compile time: a generic pointer would turn every access into a flat_load
     auto M = [&]() { if constexpr (USE_LDS) return s_mat; else return p.S; }();
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const double lambda = st.lambda;
-    // assemble the lower triangle (+ diagonal) from the pair partials (all partial loads of an element issue together)
+    const long long clk_begin = wall_clock64();
+    // assemble the lower triangle (+ diagonal) from the pair partials.  Four elements per thread and round, every partial
+    // load of the four issued before the first add: the kernel is one workgroup, so exposed L2 latency is its whole cost
     __shared__ short s_pair[kMaxFree * (kMaxFree + 1) / 2][2];
     for (int t = tid; t < npairs; t += kSolveThreads) {
         int s1 = 0, rem = t;
@@ -364,45 +432,79 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADim
         s_pair[t][0] = (short)s1; s_pair[t][1] = (short)(s1 + rem);
     }
     __syncthreads();
-    for (int t = tid; t < npairs * 42; t += kSolveThreads) {
-        const int pair = t / 42, q = t - pair * 42;
-        const int s1 = s_pair[pair][0], s2 = s_pair[pair][1];
-        double x[8];
+    const int total = npairs * 42;
+    constexpr int kAsmU = 4;
+    // the LM state (lambda, current buffer, "pass finished") is requested together with the first round of partials
+    double lambda = 0;
+    int cur = 0;
+    bool have_state = false;
+    for (int t0 = tid; t0 < total; t0 += kSolveThreads * kAsmU) {
+        double xs[kAsmU][kMaxSplit], hs[kAsmU][kCamChunks];
+        int s1v[kAsmU], s2v[kAsmU], qv[kAsmU];
 #pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = p.Spart[((size_t)(k < nsplit ? k : 0) * npairs + pair) * 42 + q];
-        double v = 0;
+        for (int u = 0; u < kAsmU; u++) {
+            const int t = t0 + u * kSolveThreads;
+            const int tc = t < total ? t : 0;
+            const int pair = tc / 42, q = tc - pair * 42;
+            const int s1 = s_pair[pair][0], s2 = s_pair[pair][1];
+            s1v[u] = s1; s2v[u] = s2; qv[u] = t < total ? q : -1;
 #pragma unroll
-        for (int k = 0; k < 8; k++) if (k < nsplit) v += x[k];
-        if (q >= 36) {   // b_schur = b_p - sum_l Hpl Dinv b_l (diagonal pairs carry it); b_p = sum of the camera chunks
-            if (s1 == s2) {
-                double bpv = 0;
+            for (int k = 0; k < kMaxSplit; k++) xs[u][k] = p.Spart[((size_t)(k < nsplit ? k : 0) * npairs + pair) * 42 + q];
+            // camera-side entry that joins this element (diagonal pairs only): Hpp upper-triangle index or bp component
+            int hq = 0;
+            if (q >= 36) hq = 21 + (q - 36);
+            else { const int a = q / 6, c = q - a * 6, lo = a < c ? a : c, hi = a < c ? c : a; hq = lo * 6 - lo * (lo - 1) / 2 + (hi - lo); }
 #pragma unroll
-                for (int cch = 0; cch < kCamChunks; cch++) bpv += p.HppPart[((size_t)s1 * kCamChunks + cch) * 27 + 21 + (q - 36)];
-                p.bp[6 * s1 + (q - 36)] = bpv;             // the decide kernel needs b_p for computeScale
-                s_x[6 * s1 + (q - 36)] = bpv - v;
-            }
-            continue;
+            for (int cch = 0; cch < kCamChunks; cch++) hs[u][cch] = p.HppPart[((size_t)s1 * kCamChunks + cch) * 27 + hq];
         }
-        const int a = q / 6, c = q - a * 6;
-        v = -v;
-        if (s1 == s2) {
-            const int lo = a < c ? a : c, hi = a < c ? c : a;
-            const int tq = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);   // index in the 21-entry upper triangle
+        if (!have_state) {
+            const BAState st = *p.st;
+            if (st.phase == 2) return;   // uniform: nothing has been written yet
+            lambda = st.lambda; cur = st.cur; have_state = true;
+            if (tid == 0) p.clk[10] = clk_begin;
+        }
+#pragma unroll
+        for (int u = 0; u < kAsmU; u++) {
+            const int q = qv[u], s1 = s1v[u], s2 = s2v[u];
+            if (q < 0) continue;
+            double v = 0;
+#pragma unroll
+            for (int k = 0; k < kMaxSplit; k++) if (k < nsplit) v += xs[u][k];
             double h = 0;
 #pragma unroll
-            for (int cch = 0; cch < kCamChunks; cch++) h += p.HppPart[((size_t)s1 * kCamChunks + cch) * 27 + tq];
-            v += h + (a == c ? lambda : 0.0);
+            for (int cch = 0; cch < kCamChunks; cch++) h += hs[u][cch];
+            if (q >= 36) {   // b_schur = b_p - sum_l Hpl Dinv b_l (diagonal pairs carry it); b_p = sum of the camera chunks
+                if (s1 == s2) {
+                    p.bp[6 * s1 + (q - 36)] = h;             // the decide stage needs b_p for computeScale
+                    s_x[6 * s1 + (q - 36)] = h - v;
+                }
+                continue;
+            }
+            const int a = q / 6, c = q - a * 6;
+            v = -v;
+            if (s1 == s2) v += h + (a == c ? lambda : 0.0);
+            const int r = 6 * s1 + a, cc = 6 * s2 + c;   // upper-block entry (r,cc); store it mirrored into the lower triangle
+            if (s1 == s2) { if (c <= a) M[(size_t)r * ld + cc] = v; }
+            else M[(size_t)cc * ld + r] = v;
         }
-        const int r = 6 * s1 + a, cc = 6 * s2 + c;   // upper-block entry (r,cc); store it mirrored into the lower triangle
-        if (s1 == s2) { if (c <= a) M[(size_t)r * ld + cc] = v; }
-        else M[(size_t)cc * ld + r] = v;
+    }
+    if (!have_state) {   // no free pose: nothing was assembled
+        const BAState st = *p.st;
+        if (st.phase == 2) return;
+        lambda = st.lambda; cur = st.cur;
     }
     if (tid == 0) s_ok = 1;
     __syncthreads();
-    // Right-looking LDL^T of the lower triangle, blocked by the 6x6 camera blocks (n = 6*nfree): per block column one
+    UH_BA_CLKL(11);
+    // Right-looking LDL^T of the lower triangle, blocked by the 6x6 camera blocks (n = 6*nfree).  Per block column: an
     // in-register factorisation of the diagonal block (done redundantly by every thread: it is the dependent chain of six
-    // divisions), one panel solve (thread per row) and one rank-6 trailing update (wave per row, lane per column) — two
-    // barriers per camera instead of one per scalar column.  After it M holds L (unit lower, scaled) and d on the diagonal.
+    // reciprocals), a panel solve (thread per row) and a rank-6 trailing update (thread per element) — three barriers per
+    // camera instead of one per scalar column.  The phase is bound by the instruction count of one wave (fp64 ops issue
+    // at 4-8 cycles), hence explicit fma() everywhere, the panel kept twice (L in M, L*D in s_w: no multiply by d in the
+    // update) and a loop-invariant thread -> (row, column) mapping.  After it M holds L (unit lower) and d on the diagonal.
+    __shared__ double s_w[6 * kMaxFree][6];
+    constexpr int kTilesPerRound = kSolveThreads / 36;
+    const int tq = tid / 36, te = tid - 36 * tq, ti = te / 6, tj = te - 6 * ti;   // trailing update: tile slot, row, column
     bool failed = false;
     for (int k0 = 0; k0 < n; k0 += 6) {
         // (a) diagonal block -> Lkk (strict lower), dk, 1/dk
@@ -415,28 +517,27 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADim
         for (int j = 0; j < 6; j++) {
             dk[j] = a[j][j];
             failed = failed || dk[j] == 0.0 || !isfinite(dk[j]);
-            ik[j] = 1.0 / dk[j];
+            ik[j] = fast_rcp(dk[j]);
             double lcol[6];
 #pragma unroll
             for (int i = j + 1; i < 6; i++) lcol[i] = a[i][j] * ik[j];      // L(i,j); a[.][j] keeps L*d_j during the update
 #pragma unroll
             for (int i = j + 1; i < 6; i++)
 #pragma unroll
-                for (int c = j + 1; c <= i; c++) a[i][c] -= lcol[i] * a[c][j];
+                for (int c = j + 1; c <= i; c++) a[i][c] = fma(-lcol[i], a[c][j], a[i][c]);
 #pragma unroll
             for (int i = j + 1; i < 6; i++) a[i][j] = lcol[i];
         }
         __syncthreads();   // every thread has read the block before it is overwritten
-        if (tid < 36) {
-            const int i = tid / 6, c = tid - 6 * i;
-            double v = 0;
+        if (tid == 0) {
 #pragma unroll
-            for (int ii = 0; ii < 6; ii++)
+            for (int i = 0; i < 6; i++) {
 #pragma unroll
-                for (int cc = 0; cc < 6; cc++) if (ii == i && cc == c) v = (cc < ii) ? a[ii][cc] : (cc == ii ? dk[ii] : 0.0);
-            if (c <= i) M[(k0 + i) * ld + k0 + c] = v;
+                for (int c = 0; c < i; c++) M[(k0 + i) * ld + k0 + c] = a[i][c];
+                M[(k0 + i) * ld + k0 + i] = dk[i];
+            }
         }
-        // (b) panel: L_rk = A_rk * Lkk^-T * Dk^-1, one thread per row
+        // (b) panel: L_rk = A_rk * Lkk^-T * Dk^-1, one thread per row; y = L_rk * Dk goes to s_w
         for (int r = k0 + 6 + tid; r < n; r += kSolveThreads) {
             double y[6];
 #pragma unroll
@@ -444,22 +545,38 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADim
 #pragma unroll
             for (int j = 0; j < 6; j++) {
 #pragma unroll
-                for (int t = 0; t < j; t++) y[j] -= y[t] * a[j][t];
+                for (int t = 0; t < j; t++) y[j] = fma(-y[t], a[j][t], y[j]);
             }
 #pragma unroll
-            for (int j = 0; j < 6; j++) M[r * ld + k0 + j] = y[j] * ik[j];
+            for (int j = 0; j < 6; j++) { M[r * ld + k0 + j] = y[j] * ik[j]; s_w[r][j] = y[j]; }
         }
         __syncthreads();
-        // (c) trailing update A_rc -= sum_t L_rt d_t L_ct  (c <= r)
-        for (int c = k0 + 6 + lane; c < n; c += 64) {
-            double lc[6];
+        // (c) trailing update A_rc -= sum_t L_rt (d_t L_ct) for c <= r: the 6x6 tiles (s1 <= s2) behind block column kb are the
+        //     tail of the s1-major pair list; each thread owns one (row, column) of a tile slot, kTrailU tiles in flight
+        {
+            const int kb = k0 / 6;
+            const int tile0 = (kb + 1) * d.nfree - kb * (kb + 1) / 2;   // first pair with s1 > kb
+            const int ntile = npairs - tile0;
+            for (int tl = tq; tl < ntile && tq < kTilesPerRound; tl += kTrailU * kTilesPerRound) {
+                int rr[kTrailU], cc[kTrailU]; bool on[kTrailU];
+                double lr[kTrailU][6], wc[kTrailU][6], acc[kTrailU];
 #pragma unroll
-            for (int t = 0; t < 6; t++) lc[t] = M[c * ld + k0 + t] * dk[t];
-            for (int r = c + ((wv - (c & (kSolveWaves - 1))) & (kSolveWaves - 1)); r < n; r += kSolveWaves) {   // rows r >= c with r % kSolveWaves == wv
-                double acc = M[r * ld + c];
+                for (int u = 0; u < kTrailU; u++) {
+                    const int t_ = tl + u * kTilesPerRound;
+                    const int tc = t_ < ntile ? t_ : tl;
+                    const int s1 = s_pair[tile0 + tc][0], s2 = s_pair[tile0 + tc][1];
+                    rr[u] = 6 * s2 + ti; cc[u] = 6 * s1 + tj;
+                    on[u] = t_ < ntile && cc[u] <= rr[u];
 #pragma unroll
-                for (int t = 0; t < 6; t++) acc -= M[r * ld + k0 + t] * lc[t];
-                M[r * ld + c] = acc;
+                    for (int t = 0; t < 6; t++) { lr[u][t] = M[rr[u] * ld + k0 + t]; wc[u][t] = s_w[cc[u]][t]; }
+                    acc[u] = M[rr[u] * ld + cc[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < kTrailU; u++) {
+#pragma unroll
+                    for (int t = 0; t < 6; t++) acc[u] = fma(-lr[u][t], wc[u][t], acc[u]);
+                    if (on[u]) M[rr[u] * ld + cc[u]] = acc[u];
+                }
             }
         }
         __syncthreads();
@@ -468,32 +585,40 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADim
     __syncthreads();
 
     const int ok = s_ok;
+    UH_BA_CLKL(12);
     if (ok) {
         if (n <= 64) {
-            // one wave, x_i lives in lane i; column j of L is read conflict-free thanks to the odd row stride
+            // one wave, x_i lives in lane i; column j of L is read conflict-free thanks to the odd row stride.  x_j is
+            // broadcast with v_readlane (j is wave-uniform) and the 2n dependent steps are branch-free: a column outside the
+            // matrix, or a lane the step does not touch, multiplies by 0
             if (wv == 0) {
                 double x = lane < n ? s_x[lane] : 0.0;
                 const int lr = lane < n ? lane : n - 1;
-                for (int j0 = 0; j0 < n; j0 += 8) {          // L y = b, 8 columns of L prefetched per round
-                    double l[8];
+                double l[8], ln[8];
 #pragma unroll
-                    for (int t = 0; t < 8; t++) { const int jj = j0 + t < n ? j0 + t : n - 1; l[t] = M[(size_t)lr * ld + jj]; }
+                for (int t = 0; t < 8; t++) { const int jj = t < n ? t : n - 1; l[t] = M[(size_t)lr * ld + jj]; }
+                for (int j0 = 0; j0 < n; j0 += 8) {          // L y = b, 8 columns of L prefetched one round ahead
 #pragma unroll
-                    for (int t = 0; t < 8; t++) {
-                        const int j = j0 + t;
-                        if (j < n) { const double xj = __shfl(x, j); if (lane > j && lane < n) x -= l[t] * xj; }
-                    }
+                    for (int t = 0; t < 8; t++) { const int jj = j0 + 8 + t < n ? j0 + 8 + t : n - 1; ln[t] = M[(size_t)lr * ld + jj]; }
+#pragma unroll
+                    for (int t = 0; t < 8; t++) { const int j = j0 + t; l[t] = (lane > j && lane < n) ? l[t] : 0.0; }
+#pragma unroll
+                    for (int t = 0; t < 8; t++) x = fma(-l[t], readlane_f64(x, j0 + t < 63 ? j0 + t : 63), x);
+#pragma unroll
+                    for (int t = 0; t < 8; t++) l[t] = ln[t];
                 }
                 if (lane < n) x /= M[(size_t)lane * ld + lane];
+#pragma unroll
+                for (int t = 0; t < 8; t++) { const int jj = n - 1 - t >= 0 ? n - 1 - t : 0; l[t] = M[(size_t)jj * ld + lr]; }
                 for (int j0 = n - 1; j0 >= 0; j0 -= 8) {     // L^T x = y
-                    double l[8];
 #pragma unroll
-                    for (int t = 0; t < 8; t++) { const int jj = j0 - t >= 0 ? j0 - t : 0; l[t] = M[(size_t)jj * ld + lr]; }
+                    for (int t = 0; t < 8; t++) { const int jj = j0 - 8 - t >= 0 ? j0 - 8 - t : 0; ln[t] = M[(size_t)jj * ld + lr]; }
 #pragma unroll
-                    for (int t = 0; t < 8; t++) {
-                        const int j = j0 - t;
-                        if (j >= 0) { const double xj = __shfl(x, j); if (lane < j) x -= l[t] * xj; }
-                    }
+                    for (int t = 0; t < 8; t++) { const int j = j0 - t; l[t] = lane < j ? l[t] : 0.0; }
+#pragma unroll
+                    for (int t = 0; t < 8; t++) x = fma(-l[t], readlane_f64(x, j0 - t > 0 ? j0 - t : 0), x);
+#pragma unroll
+                    for (int t = 0; t < 8; t++) l[t] = ln[t];
                 }
                 if (lane < n) { s_x[lane] = x; p.xp[lane] = x; }
             }
@@ -518,9 +643,10 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADim
         for (int i = tid; i < n; i += kSolveThreads) { p.xp[i] = 0.0; s_x[i] = 0.0; }
     }
     __syncthreads();
+    UH_BA_CLKL(13);
     if (tid == 0) p.st->solve_ok = ok;
     // pose update into the trial buffer (fixed poses are identical in both buffers and never touched)
-    const int cur = st.cur, trial = cur ^ 1;
+    const int trial = cur ^ 1;
     if (tid < d.nfree) {
         const int k = p.free_kf[tid];
         const double* T = p.pose[cur] + 7 * k;
@@ -537,7 +663,11 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADim
                 for (int c = 0; c < 3; c++) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
             double a, b, c1, c2;
             if (theta < 0.00001) { a = 1; b = 0.5; c1 = 0.5; c2 = 1.0 / 6.0; }
-            else { a = sin(theta) / theta; b = (1 - cos(theta)) / (theta * theta); c1 = b; c2 = (theta - sin(theta)) / pow(theta, 3.0); }
+            else {
+                double sn, cs;
+                sincos(theta, &sn, &cs);
+                a = sn / theta; b = (1 - cs) / (theta * theta); c1 = b; c2 = (theta - sn) / (theta * theta * theta);
+            }
             double Rm[9], V[9];
 #pragma unroll
             for (int i = 0; i < 9; i++) { const double I = (i % 4 == 0) ? 1.0 : 0.0; Rm[i] = I + a * O[i] + b * O2[i]; V[i] = I + c1 * O[i] + c2 * O2[i]; }
@@ -569,125 +699,72 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADim
         quat_to_R(q, Ro);
         Ro[9] = t[0]; Ro[10] = t[1]; Ro[11] = t[2];
     }
+    UH_BA_CLKL(14);
 }
 
-// ------------------------------------------------------------------------------------------------ backsub + trial errors
-__global__ __launch_bounds__(kThreads) void ba_backsub_kernel(BAPtrs p, BADims d) {
-    __shared__ double s_red[kThreads];
-    const BAState st = *p.st;
-    if (st.phase == 2) return;
-    const int cur = st.cur, trial = cur ^ 1;
-    const double lambda = st.lambda;
-    const int ok = st.solve_ok;
-    const int gl = threadIdx.x & (kLanesPerPoint - 1);
-    const int pt = blockIdx.x * kPointsPerBlock + (threadIdx.x >> 3);
-    double chi_part = 0, scale_part = 0;
-    {
-        const bool live = pt < d.P;
-        const int ptc = live ? pt : 0;
-        double X[3] = {p.pts[cur][3 * ptc], p.pts[cur][3 * ptc + 1], p.pts[cur][3 * ptc + 2]};
-        const int b = live ? p.pt_ptr[pt] : 0, e_end = live ? p.pt_ptr[pt + 1] : 0;
-        // c = bl - sum_e Hpl_e^T xp, one observation per lane, fixed butterfly over the 8 lanes
-        double c[3] = {0, 0, 0};
-        bool any = false;
-        for (int i = b + gl; i < e_end; i += kLanesPerPoint) {
-            const int e = p.pt_edges[i];
-            if (!p.e_active[e]) continue;
-            any = true;
-            const int s = p.slot[p.e_kf[e]];
-            if (s < 0) continue;
-            const double* B1 = p.Hpl + 18 * (size_t)e;
-            const double* x = p.xp + 6 * s;
-#pragma unroll
-            for (int a = 0; a < 6; a++) { c[0] -= B1[a * 3] * x[a]; c[1] -= B1[a * 3 + 1] * x[a]; c[2] -= B1[a * 3 + 2] * x[a]; }
-        }
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-#pragma unroll
-            for (int o = kLanesPerPoint / 2; o > 0; o >>= 1) c[i] += __shfl_xor(c[i], o);
-        }
-        const unsigned long long anym = __ballot(any);
-        const bool any_pt = ((anym >> ((threadIdx.x & 63) & ~(kLanesPerPoint - 1))) & 0xFFull) != 0;
-        if (live && any_pt && ok) {   // every lane of the group computes the same step (identical inputs)
-            c[0] += p.bl[3 * pt]; c[1] += p.bl[3 * pt + 1]; c[2] += p.bl[3 * pt + 2];
-            double D[9], Di[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) D[i] = p.Hll[9 * (size_t)pt + i];
-            D[0] += lambda; D[4] += lambda; D[8] += lambda;
-            inv3(D, Di);
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                const double xl = Di[a * 3] * c[0] + Di[a * 3 + 1] * c[1] + Di[a * 3 + 2] * c[2];
-                if (gl == 0) scale_part += xl * (lambda * xl + p.bl[3 * pt + a]);
-                X[a] += xl;
-            }
-        }
-        if (live && gl == 0) { p.pts[trial][3 * pt] = X[0]; p.pts[trial][3 * pt + 1] = X[1]; p.pts[trial][3 * pt + 2] = X[2]; }
-        const double* poseR = p.poseR[trial];
-        for (int i = b + gl; i < e_end; i += kLanesPerPoint) {
-            const int e = p.pt_edges[i];
-            if (!p.e_active[e]) continue;
-            const int k = p.e_kf[e];
-            EdgeLin L;
-            edge_eval<false>(p, d, e, k, poseR + 12 * k, X, p.e_robust[e] != 0, L);
-            p.e_err[2 * e] = L.ex; p.e_err[2 * e + 1] = L.ey;
-            p.e_chi2[e] = L.chi2;
-            chi_part += L.robchi;
-        }
-    }
-    const double cs = block_sum(chi_part, s_red);
-    const double ss = block_sum(scale_part, s_red);
-    if (threadIdx.x == 0) { p.part_chi[blockIdx.x] = cs; p.part_scale[blockIdx.x] = ss; }
+template <bool USE_LDS>
+__global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADims d, int nsplit) {
+    solve_body<USE_LDS>(p, d, nsplit);
 }
 
 // ------------------------------------------------------------------------------------------------ decide
 // One wave: the tail of OptimizationAlgorithmLevenberg::solve's do-while body plus SparseOptimizer::optimize's loop header.
+__device__ __forceinline__ double wave_sum_fixed(double v) {   // xor butterfly: fixed order, identical in all lanes
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
 __global__ __launch_bounds__(64) void ba_decide_kernel(BAPtrs p, BADims d) {
-    // the partial sums are fetched by all 64 lanes at once, then added by lane 0 in index order (deterministic)
-    __shared__ double s_lin[64], s_chi[64], s_scale[64], s_xs[6 * kMaxFree];
-    const BAState st0 = *p.st;
-    if (st0.phase == 2) return;
-    const int nb = d.nPointBlocks;
+    // Everything the decision needs is requested up front — the force-stop flag lives in pinned host memory (a PCIe round
+    // trip), the state and the partial sums in HBM — so that the kernel pays one memory latency, not four in a row.
     const int tid = threadIdx.x;
-    // nb may exceed 64 (large P): each lane pre-adds its strided share in a fixed order, lane 0 then adds the 64 lane sums
+    const unsigned char stopv = p.stop ? *p.stop : (unsigned char)0;
+    const int nb = d.nPointBlocks;
+    // each lane pre-adds its strided share in a fixed order; the 64 lane sums are then added by a fixed butterfly
     double l0 = 0, l1 = 0, l2 = 0;
     for (int i = tid; i < nb; i += 64) { l0 += p.part_lin_chi[i]; l1 += p.part_chi[i]; l2 += p.part_scale[i]; }
-    s_lin[tid] = l0; s_chi[tid] = l1; s_scale[tid] = l2;
-    const double lambda0 = st0.lambda;
-    for (int i = tid; i < d.n; i += 64) { const double x = p.xp[i]; s_xs[i] = x * (lambda0 * x + p.bp[i]); }
-    __syncthreads();
+    double xv[6 * kMaxFree / 64], bv[6 * kMaxFree / 64];
+#pragma unroll
+    for (int k = 0; k < 6 * kMaxFree / 64; k++) {
+        const int i = tid + 64 * k;
+        xv[k] = i < d.n ? p.xp[i] : 0.0;
+        bv[k] = i < d.n ? p.bp[i] : 0.0;
+    }
+    const BAState st0 = *p.st;
+    if (st0.phase == 2) return;
+    UH_BA_CLKL(24);
+    double xs = 0;
+#pragma unroll
+    for (int k = 0; k < 6 * kMaxFree / 64; k++) xs += xv[k] * (st0.lambda * xv[k] + bv[k]);
+    const double sum_lin = wave_sum_fixed(l0), sum_chi = wave_sum_fixed(l1), sum_scale = wave_sum_fixed(l2), sum_xs = wave_sum_fixed(xs);
     if (tid != 0) return;
     BAState st = st0;
-    if (st.phase == 0) {   // this step linearised: currentChi = activeRobustChi2 at the current state
-        double c = 0;
-        for (int i = 0; i < 64; i++) c += s_lin[i];
-        st.currentChi = c;
-    }
-    double tempChi = 0, scale = 0;
-    for (int i = 0; i < 64; i++) { tempChi += s_chi[i]; scale += s_scale[i]; }
+    if (st.first_trial) st.currentChi = sum_lin;   // activeRobustChi2 at the pass's initial estimate (lin kernel); later the accepted tempChi
+    double tempChi = sum_chi, scale = sum_scale;
     st.lastChiRaw = tempChi;
-    if (st.solve_ok)
-        for (int i = 0; i < d.n; i++) scale += s_xs[i];
+    if (st.solve_ok) scale += sum_xs;
     if (!st.solve_ok) tempChi = DBL_MAX;
     double rho = st.currentChi - tempChi;
     scale += 1e-3;
     rho /= scale;
     bool lambda_finite = true;
     if (rho > 0 && isfinite(tempChi)) {
-        double alpha = 1. - pow((2 * rho - 1), 3.0);
+        const double t3 = 2 * rho - 1;
+        double alpha = 1. - t3 * t3 * t3;
         alpha = fmin(alpha, 2. / 3.);
         const double sf = fmax(1. / 3., alpha);
         st.lambda *= sf;
         st.ni = 2;
         st.currentChi = tempChi;
-        st.cur ^= 1;   // discardTop: the trial buffers become the current estimate
+        st.cur ^= 1;   // discardTop: the trial buffers (estimate AND its linearisation, see backsub) become the current ones
     } else {
         st.lambda *= st.ni;
         st.ni *= 2;    // pop: the current buffers stay
         if (!isfinite(st.lambda)) lambda_finite = false;
     }
     st.rho = rho;
-    const bool stop = p.stop && *p.stop;
+    const bool stop = stopv != 0;
     if (stop) st.stopped = 1;
     bool again = false;
     if (lambda_finite) {
@@ -713,7 +790,76 @@ __global__ __launch_bounds__(64) void ba_decide_kernel(BAPtrs p, BADims d) {
             st.phase = 2;
         }
     }
+    st.first_trial = 0;
     *p.st = st;
+    p.clk[25] = wall_clock64();
+}
+
+// ------------------------------------------------------------------------------------------------ backsub + trial errors
+__global__ __launch_bounds__(kThreads) void ba_backsub_kernel(BAPtrs p, BADims d) {
+    __shared__ double s_red[kThreads];
+    const BAState st = *p.st;
+    if (st.phase == 2) return;
+    const int cur = st.cur, trial = cur ^ 1;
+    const double lambda = st.lambda;
+    const int ok = st.solve_ok;
+    UH_BA_CLK(20);
+    const int gl = threadIdx.x & (kLanesPerPoint - 1);
+    const int pt = blockIdx.x * kPointsPerBlock + (threadIdx.x >> 3);
+    double chi_part = 0, scale_part = 0;
+    {
+        const bool live = pt < d.P;
+        const int ptc = live ? pt : 0;
+        double X[3] = {p.pts[cur][3 * ptc], p.pts[cur][3 * ptc + 1], p.pts[cur][3 * ptc + 2]};
+        const int b = live ? p.pt_ptr[pt] : 0, e_end = live ? p.pt_ptr[pt + 1] : 0;
+        // c = bl - sum_e Hpl_e^T xp, one observation per lane, fixed butterfly over the 8 lanes
+        double c[3] = {0, 0, 0};
+        bool any = false;
+        for (int i = b + gl; i < e_end; i += kLanesPerPoint) {
+            const int e = p.pt_edges[i];
+            if (!p.e_active[e]) continue;
+            any = true;
+            const int s = p.slot[p.e_kf[e]];
+            if (s < 0) continue;
+            const double* B1 = p.Hpl[cur] + 18 * (size_t)e;
+            const double* x = p.xp + 6 * s;
+#pragma unroll
+            for (int a = 0; a < 6; a++) { c[0] -= B1[a * 3] * x[a]; c[1] -= B1[a * 3 + 1] * x[a]; c[2] -= B1[a * 3 + 2] * x[a]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int o = kLanesPerPoint / 2; o > 0; o >>= 1) c[i] += __shfl_xor(c[i], o);
+        }
+        const unsigned long long anym = __ballot(any);
+        const bool any_pt = ((anym >> ((threadIdx.x & 63) & ~(kLanesPerPoint - 1))) & 0xFFull) != 0;
+        if (live && any_pt && ok) {   // every lane of the group computes the same step (identical inputs)
+            const double* bi = p.bl[cur] + 3 * (size_t)pt;
+            const double blv[3] = {bi[0], bi[1], bi[2]};
+            c[0] += blv[0]; c[1] += blv[1]; c[2] += blv[2];
+            double D[9], Di[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) D[i] = p.Hll[cur][9 * (size_t)pt + i];
+            D[0] += lambda; D[4] += lambda; D[8] += lambda;
+            inv3(D, Di);
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const double xl = Di[a * 3] * c[0] + Di[a * 3 + 1] * c[1] + Di[a * 3 + 2] * c[2];
+                if (gl == 0) scale_part += xl * (lambda * xl + blv[a]);
+                X[a] += xl;
+            }
+        }
+        if (live && gl == 0) { p.pts[trial][3 * pt] = X[0]; p.pts[trial][3 * pt + 1] = X[1]; p.pts[trial][3 * pt + 2] = X[2]; }
+        // trial errors — and, speculatively, the whole linearisation at the trial estimate, into the trial side of the
+        // double-buffered Hll/bl/Hpl: an accepted trial flips both and goes straight to the schur kernel, a rejected one keeps
+        // the current estimate with its linearisation intact.  The lin kernel is needed only once per pass.
+        double maxd_unused;
+        linearize_point(p, d, trial, pt, gl, live, p.poseR[trial], X, chi_part, maxd_unused);
+    }
+    const double cs = block_sum(chi_part, s_red);
+    const double ss = block_sum(scale_part, s_red);
+    if (threadIdx.x == 0) { p.part_chi[blockIdx.x] = cs; p.part_scale[blockIdx.x] = ss; }
+    UH_BA_CLK(21);
 }
 
 // ------------------------------------------------------------------------------------------------ between / after passes
@@ -738,6 +884,7 @@ __global__ void ba_begin_pass_kernel(BAPtrs p, int max_iters, float minChi2) {
     st.max_iters = max_iters;
     st.qmax = 0;
     st.solve_ok = 1;
+    st.first_trial = 1;
     st.iters_done = 0;
     st.prevChi2 = FLT_MAX;   // swapped at loop entry: prev = cur = FLT_MAX before the first solve
     st.curChi2 = FLT_MAX;
@@ -836,15 +983,15 @@ struct Arena {
     template <typename T> size_t take(size_t count) { off = (off + 255) & ~(size_t)255; size_t o = off; off += count * sizeof(T); return o; }
 };
 
-int enqueue_steps(uh_ba* b, int nsteps) {
+int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
     hipStream_t st = b->ctx->stream;
     const BADims& d = b->dims;
     const int npairs = d.nfree * (d.nfree + 1) / 2;
     const int use_lds = d.n <= 120 ? 1 : 0;
     const size_t lds = use_lds ? (size_t)d.n * (d.n + 1) * sizeof(double) : 0;
     for (int s = 0; s < nsteps; s++) {
-        UH_LAUNCH(b->ctx,ba_lin_kernel, dim3(d.nPointBlocks + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d);
-        UH_LAUNCH(b->ctx,ba_schur_kernel, dim3(std::max(npairs, 1) * b->nsplit), dim3(kThreads), 0, b->ptrs, d, b->nsplit);
+        if (pass_start && s == 0) UH_LAUNCH(b->ctx,ba_lin_kernel, dim3(d.nPointBlocks + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d);
+        UH_LAUNCH(b->ctx,ba_schur_kernel, dim3(std::max(npairs, 1) * b->nsplit + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d, b->nsplit);
         if (use_lds) UH_LAUNCH(b->ctx,ba_solve_kernel<true>, dim3(1), dim3(kSolveThreads), lds, b->ptrs, d, b->nsplit);
         else UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kSolveThreads), lds, b->ptrs, d, b->nsplit);
         UH_LAUNCH(b->ctx,ba_backsub_kernel, dim3(d.nPointBlocks), dim3(kThreads), 0, b->ptrs, d);
@@ -860,7 +1007,7 @@ int run_pass(uh_ba* b, int max_iters, int* iters_done, const volatile uint8_t* s
     int budget = max_iters + 1;   // one step per outer iteration when no trial is rejected
     BAState hs;
     for (int round = 0; round < 64; round++) {
-        int rc = enqueue_steps(b, budget);
+        int rc = enqueue_steps(b, budget, round == 0);
         if (rc) return rc;
         UH_HIP_CHECK(hipMemcpyAsync(&hs, b->ptrs.st, sizeof(BAState), hipMemcpyDeviceToHost, st));
         if (stop_asap && b->h_stop) {   // keep forwarding the caller's flag to the device-visible one while waiting
@@ -953,14 +1100,15 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     size_t o_pose[2], o_poseR[2], o_pts[2];
     for (int i = 0; i < 2; i++) { o_pose[i] = A.take<double>(7 * (size_t)K); o_poseR[i] = A.take<double>(12 * (size_t)K); o_pts[i] = A.take<double>(3 * (size_t)P); }
     const size_t o_act = A.take<unsigned char>(E), o_rob = A.take<unsigned char>(E), o_err = A.take<double>(2 * (size_t)E), o_chi2 = A.take<double>(E);
-    const size_t o_Hll = A.take<double>(9 * (size_t)P), o_bl = A.take<double>(3 * (size_t)P), o_Hpl = A.take<double>(18 * (size_t)E);
+    size_t o_Hll[2], o_bl[2], o_Hpl[2];
+    for (int i = 0; i < 2; i++) { o_Hll[i] = A.take<double>(9 * (size_t)P); o_bl[i] = A.take<double>(3 * (size_t)P); o_Hpl[i] = A.take<double>(18 * (size_t)E); }
     const size_t o_Hpp = A.take<double>(27 * (size_t)kCamChunks * std::max(nfree, 1)), o_bp = A.take<double>(std::max(d.n, 1));
     const int npairs_h = nfree * (nfree + 1) / 2;
-    b->nsplit = std::max(1, std::min(8, uh_div_up(P, kThreads)));
-    if (const char* e = getenv("UH_BA_NSPLIT")) b->nsplit = std::max(1, std::min(8, atoi(e)));   // tuning knob (measurement only)
+    b->nsplit = std::max(1, std::min(kMaxSplit, uh_div_up(P, kThreads)));
+    if (const char* e = getenv("UH_BA_NSPLIT")) b->nsplit = std::max(1, std::min(kMaxSplit, atoi(e)));   // tuning knob (measurement only)
     const size_t o_S = A.take<double>((size_t)std::max(d.n, 1) * (std::max(d.n, 1) + 1)), o_Sp = A.take<double>((size_t)b->nsplit * std::max(npairs_h, 1) * 42), o_xp = A.take<double>(std::max(d.n, 1));
     const size_t o_plc = A.take<double>(d.nPointBlocks), o_pmd = A.take<double>(d.nPointBlocks), o_pc = A.take<double>(d.nPointBlocks), o_ps = A.take<double>(d.nPointBlocks);
-    const size_t o_st = A.take<BAState>(1);
+    const size_t o_st = A.take<BAState>(1), o_clk = A.take<long long>(64);
     int rc = b->arena.reserve(A.off + 256);
     if (rc) return rc;
     UH_HIP_CHECK(hipSetDevice(b->ctx->device));
@@ -996,10 +1144,12 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     p.slot = (int*)(base + o_slot); p.free_kf = (int*)(base + o_free); p.intr = (double*)(base + o_intr); p.edge_of = (int*)(base + o_edge_of);
     for (int i = 0; i < 2; i++) { p.pose[i] = (double*)(base + o_pose[i]); p.poseR[i] = (double*)(base + o_poseR[i]); p.pts[i] = (double*)(base + o_pts[i]); }
     p.e_active = (unsigned char*)(base + o_act); p.e_robust = (unsigned char*)(base + o_rob); p.e_err = (double*)(base + o_err); p.e_chi2 = (double*)(base + o_chi2);
-    p.Hll = (double*)(base + o_Hll); p.bl = (double*)(base + o_bl); p.Hpl = (double*)(base + o_Hpl); p.HppPart = (double*)(base + o_Hpp); p.bp = (double*)(base + o_bp);
+    for (int i = 0; i < 2; i++) { p.Hll[i] = (double*)(base + o_Hll[i]); p.bl[i] = (double*)(base + o_bl[i]); p.Hpl[i] = (double*)(base + o_Hpl[i]); }
+    p.HppPart = (double*)(base + o_Hpp); p.bp = (double*)(base + o_bp);
     p.S = (double*)(base + o_S); p.Spart = (double*)(base + o_Sp); p.xp = (double*)(base + o_xp);
     p.part_lin_chi = (double*)(base + o_plc); p.part_maxdiag = (double*)(base + o_pmd); p.part_chi = (double*)(base + o_pc); p.part_scale = (double*)(base + o_ps);
     p.st = (BAState*)(base + o_st);
+    p.clk = (long long*)(base + o_clk);
     p.stop = nullptr;
     if (b->h_stop) {
         void* dflag = nullptr;
@@ -1032,6 +1182,14 @@ int uh_ba_optimize(uh_ba* b, const volatile uint8_t* stop_asap) {
         if ((rc = run_pass(b, 2 * b->params.n_iters, &b->iters[1], stop_asap))) return rc;
     }
     b->optimized = true;
+    return UH_OK;
+}
+
+// measurement hook: the 64 phase timestamps (10 ns ticks) written by the last executed LM step
+int uh_ba_debug_clocks(uh_ba* b, int64_t* out64) {
+    UH_REQUIRE(b && b->have_problem && out64, "uh_ba_debug_clocks: not ready");
+    UH_HIP_CHECK(hipMemcpyAsync(out64, b->ptrs.clk, 64 * sizeof(long long), hipMemcpyDeviceToHost, b->ctx->stream));
+    UH_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
     return UH_OK;
 }
 
