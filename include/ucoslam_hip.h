@@ -269,6 +269,52 @@ int  uh_pnp_solve_dev(uh_pnp* pnp, const float* d_pose_f2g, const float* d_intr4
                       const float* d_inv_sigma, const float* d_weight, void* d_work, float* d_pose_out, uint8_t* d_bad_out,
                       int32_t* d_result5, double* d_state7);
 
+/* ------------------------------------------------------------------------
+ * Projection matcher — replaces Map::matchFrameToMapPoints (src/map.cpp:651-770) on flattened inputs:
+ *   frame side  Frame::und_kpts / desc / scaleFactors / imageParams.CameraMatrix / minXY,maxXY (map_types/frame.h:60-81) and the
+ *               kd-tree over und_kpts (Frame::create_kdtree, frame.h:124; picoflann.h) — rebuilt bit-identically by set_frame
+ *   map side    the candidate map points AFTER the reference's id filtering (getMapPointsInFrames / lastFIdxSeen, map.cpp:657-668,
+ *               which stays host code): ids, getCoordinates(), normal, get{Min,Max}DistanceInvariance(), descriptor
+ * match() returns the DMatch list (queryIdx = keypoint, trainIdx = map point id, imgIdx = -1, distance = Hamming as float)
+ * after filter_ambiguous_query, in map-point order like the reference; optional per-point outputs: best keypoint before the
+ * ambiguity filter (-1 = none), its distance, and the "visible" flags (markMapPointsAsVisible: the caller applies
+ * MapPoint::setVisible() to the flagged points).  Returns the number of matches (>= 0) or a negative UH_E* code.
+ * ------------------------------------------------------------------------ */
+typedef struct uh_proj_frame {
+    const uh_keypoint* und_kpts;    /* cv::KeyPoint: pt and octave are read */
+    int32_t n_kpts;
+    const uint8_t* desc;            /* n_kpts x 32 */
+    const float* scale_factors;     /* Frame::scaleFactors */
+    int32_t n_levels;
+    float fx, fy, cx, cy;           /* CameraMatrix(0,0) (1,1) (0,2) (1,2) */
+    int32_t min_x, min_y, max_x, max_y;   /* Frame::minXY / maxXY (cv::Point, i.e. ints; defaults 0,0 / INT_MAX,INT_MAX) */
+} uh_proj_frame;
+
+typedef struct uh_map_points {
+    int32_t n;
+    const uint32_t* ids;            /* n */
+    const float* pos3d;             /* n x 3 */
+    const float* normal;            /* n x 3 */
+    const float* min_dist;          /* n */
+    const float* max_dist;          /* n */
+    const uint8_t* desc;            /* n x 32 */
+} uh_map_points;
+
+typedef struct uh_projmatch uh_projmatch;
+int  uh_projmatch_create(uh_ctx* ctx, uh_projmatch** out);
+void uh_projmatch_destroy(uh_projmatch* pm);
+int  uh_projmatch_set_frame(uh_projmatch* pm, const uh_proj_frame* frame);
+int  uh_projmatch_match(uh_projmatch* pm, const float* pose_f2g /* row-major 4x4 */, const uh_map_points* points,
+                        float min_desc_dist, float max_repj_dist, uh_dmatch* matches_out, int32_t cap,
+                        int32_t* best_kp_out /* n or NULL */, float* best_dist_out /* n or NULL */, uint8_t* visible_out /* n or NULL */);
+/* test hook: the flattened kd-tree of the current frame (24-byte nodes {float divlow, divhigh; int32 left, right, leaf_begin;
+ * int16 leaf_count, col}), the leaf index list, the root box {x.min, x.max, y.min, y.max} and the tree depth */
+int  uh_projmatch_debug_tree(uh_projmatch* pm, int32_t* n_nodes, const void** nodes24, const uint32_t** leaf_idx,
+                             double* root_box4, int32_t* max_depth);
+/* the same build as a host-only function (no GPU needed): nodes24_out has room for 2n+2 nodes, leaf_idx_out for n entries */
+int  uh_kdtree_build_host(const float* xy, int32_t n, int32_t* n_nodes, void* nodes24_out, uint32_t* leaf_idx_out,
+                          double* root_box4, int32_t* max_depth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,365 @@
+// TEST INFRASTRUCTURE ONLY — CPU oracle for the projection matcher.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this file.
+//
+// Restates, in plain sequential C++:
+//   src/map.cpp:651-770                     Map::matchFrameToMapPoints (the per-map-point loop and its acceptance rules)
+//   src/map_types/frame.cpp:102-115         Frame::getKeyPointsInRegion (radius search, octave window)
+//   src/map_types/frame.h:129-136           Frame::predictScale
+//   src/map_types/mappoint.h:99,146-177     MapPoint::getViewCos, getHammDescDistance_2 (returned as float)
+//   src/basictypes/se3transform.h:89-113    Se3Transform::inv / operator*(Point3f)
+//   src/basictypes/picoflann.h:150-163,238-345,347-391,411-447,545-590   KdTreeIndex build (mean/variance split, planeSplit,
+//                                           std::sort fallback), radius search and its traversal ORDER
+//   src/basictypes/misc.cpp:105-150         filter_ambiguous_query
+// The kd-tree part (build + radius search incl. result order) is pinned against the REAL picoflann.h compiled from the
+// reference (oracle/_ref/libpicoflann_ref.so, tests/test_projmatch_oracle.py).  The loop around it touches OpenCV value types
+// only (Point3f arithmetic, cv::norm), OpenCV is absent from this image => that part is "parity unpinned"; the arithmetic
+// conventions chosen are: float operations in source order without contraction, cv::norm(Point3f) = sqrt in double of the
+// double sum of squares, Point3f *= double via float(x * s), and logf(x) := float(log(double(x))) in predictScale
+// (so that the device can reproduce it exactly; glibc's logf differs from this only where it is not correctly rounded).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <utility>
+#include <vector>
+
+namespace {
+
+struct KdNode {
+    int col = 0;
+    float divlow = 0, divhigh = 0;
+    int left = -1, right = -1;
+    int leaf_begin = 0, leaf_count = 0;
+};
+
+struct KdTree {
+    std::vector<float> xy;            // n x 2
+    std::vector<KdNode> nodes;
+    std::vector<uint32_t> leaf_idx;
+    double root_bbox[2][2] = {{0, 0}, {0, 0}};   // [dim][first/second]
+    int n = 0;
+    // build scratch
+    std::vector<uint32_t> all;
+    float at(uint32_t i, int d) const { return xy[2 * (size_t)i + d]; }
+};
+
+typedef double BBox[2][2];
+
+void compute_bbox(const KdTree& t, BBox b, int start, int end) {   // picoflann.h:347-360
+    for (int d = 0; d < 2; d++) b[d][0] = b[d][1] = t.at(t.all[start], d);
+    for (int k = start + 1; k < end; k++)
+        for (int d = 0; d < 2; d++) {
+            const float v = t.at(t.all[k], d);
+            if (v < b[d][0]) b[d][0] = v;
+            if (v > b[d][1]) b[d][1] = v;
+        }
+}
+
+void mean_var(const KdTree& t, int start, int end, double var[2], double mean[2]) {   // :362-391
+    const int MAX_ELEM_MEAN = 100;
+    double sum2[2] = {0, 0};
+    mean[0] = mean[1] = 0;
+    int cnt = 0, inc = 1;
+    if (end - start >= 2 * MAX_ELEM_MEAN) inc = (end - start) / MAX_ELEM_MEAN;
+    for (int i = start; i < end; i += inc) {
+        for (int c = 0; c < 2; c++) {
+            const float val = t.at(t.all[i], c);
+            mean[c] += val;
+            sum2[c] += val * val;    // float product, double accumulation
+        }
+        cnt++;
+    }
+    const double inv = 1. / double(cnt);
+    for (int c = 0; c < 2; c++) {
+        mean[c] *= inv;
+        var[c] = sum2[c] * inv - mean[c] * mean[c];
+    }
+}
+
+void plane_split(const KdTree& t, uint32_t* ind, int count, int cutfeat, float cutval, int& lim1, int& lim2) {   // :403-424
+    int left = 0, right = count - 1;
+    for (;;) {
+        while (left <= right && t.at(ind[left], cutfeat) < cutval) ++left;
+        while (left <= right && t.at(ind[right], cutfeat) >= cutval) --right;
+        if (left > right) break;
+        std::swap(ind[left], ind[right]); ++left; --right;
+    }
+    lim1 = left;
+    right = count - 1;
+    for (;;) {
+        while (left <= right && t.at(ind[left], cutfeat) <= cutval) ++left;
+        while (left <= right && t.at(ind[right], cutfeat) > cutval) --right;
+        if (left > right) break;
+        std::swap(ind[left], ind[right]); ++left; --right;
+    }
+    lim2 = left;
+}
+
+void divide(KdTree& t, int node, int start, int end, BBox bbox) {   // :238-345
+    const int kMaxLeaf = 10;
+    const int count = end - start;
+    if (count <= kMaxLeaf) {
+        t.nodes[node].leaf_begin = (int)t.leaf_idx.size();
+        t.nodes[node].leaf_count = count;
+        for (int i = 0; i < count; i++) t.leaf_idx.push_back(t.all[start + i]);
+        compute_bbox(t, bbox, start, end);
+        return;
+    }
+    const int left = (int)t.nodes.size();
+    t.nodes.push_back(KdNode());
+    const int right = (int)t.nodes.size();
+    t.nodes.push_back(KdNode());
+    t.nodes[node].left = left;
+    t.nodes[node].right = right;
+    double var[2], mean[2];
+    mean_var(t, start, end, var, mean);
+    int col = 0;
+    if (var[1] > var[0]) col = 1;
+    double div_val = mean[col];
+    int lim1, lim2;
+    plane_split(t, &t.all[start], count, col, (float)div_val, lim1, lim2);
+    int split;
+    if (lim1 > count / 2) split = lim1;
+    else if (lim2 < count / 2) split = lim2;
+    else split = count / 2;
+    if (lim1 == count || lim2 == 0) split = count / 2;
+    if (split < kMaxLeaf || count - split < kMaxLeaf) {
+        std::sort(t.all.begin() + start, t.all.begin() + end, [&](const uint32_t& a, const uint32_t& b) { return t.at(a, col) < t.at(b, col); });
+        split = count / 2;
+        div_val = t.at(t.all[start + split], col);
+    }
+    BBox lb, rb;
+    std::memcpy(lb, bbox, sizeof(BBox));
+    lb[col][1] = div_val;
+    divide(t, left, start, start + split, lb);
+    lb[col][1] = div_val;
+    std::memcpy(rb, bbox, sizeof(BBox));
+    rb[col][0] = div_val;
+    divide(t, right, start + split, end, rb);
+    t.nodes[node].col = col;
+    t.nodes[node].divlow = (float)lb[col][1];
+    t.nodes[node].divhigh = (float)rb[col][0];
+    for (int d = 0; d < 2; d++) {
+        bbox[d][0] = std::min(lb[d][0], rb[d][0]);
+        bbox[d][1] = std::max(lb[d][1], rb[d][1]);
+    }
+}
+
+void kd_build(KdTree& t, const float* xy, int n) {   // :150-163
+    t.n = n;
+    t.xy.assign(xy, xy + 2 * (size_t)n);
+    t.nodes.clear();
+    t.leaf_idx.clear();
+    t.all.resize(n);
+    for (int i = 0; i < n; i++) t.all[i] = i;
+    if (n == 0) return;
+    compute_bbox(t, t.root_bbox, 0, n);
+    t.nodes.reserve(2 * (size_t)n + 2);
+    t.nodes.push_back(KdNode());
+    divide(t, 0, 0, n, t.root_bbox);
+}
+
+struct Hits {
+    std::vector<std::pair<uint32_t, double>> v;
+};
+
+// searchExactLevel with a radius ResultSet (worstDist() == r^2 constant; push appends), :545-590
+void kd_search(const KdTree& t, int node, float qx, float qy, double worst, double mindistsq, double dists[2], Hits& out) {
+    const KdNode& nd = t.nodes[node];
+    if (nd.left < 0 && nd.right < 0) {
+        for (int i = 0; i < nd.leaf_count; i++) {
+            const uint32_t id = t.leaf_idx[nd.leaf_begin + i];
+            // L2::compute_distance :130-140: float difference, double square/sum, early exit on > worst
+            double sqd = 0;
+            {
+                const double d = qx - t.at(id, 0);
+                sqd += d * d;
+                if (!(sqd > worst)) {
+                    const double e = qy - t.at(id, 1);
+                    sqd += e * e;
+                }
+            }
+            if (sqd < worst) out.v.push_back({id, sqd});
+        }
+        return;
+    }
+    const double val = nd.col == 0 ? qx : qy;
+    const double diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
+    int best, other;
+    double cut;
+    if (diff1 + diff2 < 0) { best = nd.left; other = nd.right; cut = diff2 * diff2; }
+    else { best = nd.right; other = nd.left; cut = diff1 * diff1; }
+    kd_search(t, best, qx, qy, worst, mindistsq, dists, out);
+    const float dst = (float)dists[nd.col];
+    mindistsq = mindistsq + cut - dst;
+    dists[nd.col] = cut;
+    if (mindistsq * 1.0 <= worst) kd_search(t, other, qx, qy, worst, mindistsq, dists, out);
+    dists[nd.col] = dst;
+}
+
+void kd_radius(const KdTree& t, float qx, float qy, double radius, Hits& out) {   // generalSearch :427-437 (sorted=false)
+    out.v.clear();
+    if (t.n == 0) return;   // an empty index has no node to visit (the reference would index an empty vector)
+    double dists[2] = {0, 0};
+    const double worst = radius > 0 ? radius * radius : -1.f;
+    // computeInitialDistances :411-426 (float accumulator)
+    float distsq = 0.0f;
+    const float q[2] = {qx, qy};
+    for (int i = 0; i < 2; i++) {
+        const double e = q[i];
+        if (e < t.root_bbox[i][0]) { const double d = e - t.root_bbox[i][0]; dists[i] = d * d; distsq += dists[i]; }
+        if (e > t.root_bbox[i][1]) { const double d = e - t.root_bbox[i][1]; dists[i] = d * d; distsq += dists[i]; }
+    }
+    if (worst <= 0) return;   // radius <= 0: the reference would fall into knn mode with maxNN=-1; not used by the path
+    kd_search(t, 0, qx, qy, worst, distsq, dists, out);
+}
+
+inline float hamming_f(const uint8_t* a, const uint8_t* b) {   // mappoint.h:146-163
+    uint64_t x[4], y[4];
+    std::memcpy(x, a, 32);
+    std::memcpy(y, b, 32);
+    return (float)(__builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) + __builtin_popcountll(x[2] ^ y[2]) +
+                   __builtin_popcountll(x[3] ^ y[3]));
+}
+
+inline float logf_cr(float x) { return (float)std::log((double)x); }
+
+struct DMatch { int32_t queryIdx, trainIdx, imgIdx; float distance; };
+
+}  // namespace
+
+extern "C" {
+
+struct oracle_keypoint { float x, y, size, angle, response; int32_t octave, class_id; };   // cv::KeyPoint, 28 bytes
+
+void* oracle_kd_build(const float* xy, int n) {
+    KdTree* t = new KdTree();
+    kd_build(*t, xy, n);
+    return t;
+}
+void oracle_kd_free(void* h) { delete static_cast<KdTree*>(h); }
+int oracle_kd_radius(void* h, float qx, float qy, double radius, uint32_t* idx_out, double* sqd_out, int cap) {
+    Hits hits;
+    kd_radius(*static_cast<KdTree*>(h), qx, qy, radius, hits);
+    int n = 0;
+    for (auto& r : hits.v) {
+        if (n < cap) { idx_out[n] = r.first; sqd_out[n] = r.second; }
+        n++;
+    }
+    return n;
+}
+// flattened tree, for comparing the product's host-side build with this one: returns node count; arrays sized >= 2n+2
+int oracle_kd_export(void* h, int32_t* col, float* divlow, float* divhigh, int32_t* left, int32_t* right, int32_t* leaf_begin,
+                     int32_t* leaf_count, uint32_t* leaf_idx, double* root_bbox4) {
+    KdTree* t = static_cast<KdTree*>(h);
+    for (size_t i = 0; i < t->nodes.size(); i++) {
+        const KdNode& nd = t->nodes[i];
+        col[i] = nd.col; divlow[i] = nd.divlow; divhigh[i] = nd.divhigh; left[i] = nd.left; right[i] = nd.right;
+        leaf_begin[i] = nd.leaf_begin; leaf_count[i] = nd.leaf_count;
+    }
+    for (size_t i = 0; i < t->leaf_idx.size(); i++) leaf_idx[i] = t->leaf_idx[i];
+    root_bbox4[0] = t->root_bbox[0][0]; root_bbox4[1] = t->root_bbox[0][1]; root_bbox4[2] = t->root_bbox[1][0]; root_bbox4[3] = t->root_bbox[1][1];
+    return (int)t->nodes.size();
+}
+
+// Map::matchFrameToMapPoints on flattened inputs.  Frame: und_kpts (cv::KeyPoint), desc (n_kpts x 32), scaleFactors, camera,
+// minXY/maxXY (cv::Point: ints).  Map points (already filtered by id, map.cpp:657-668): ids, pos3d, normal, min/max distance
+// invariance, descriptor.  Outputs: per map point best keypoint (-1 none) / distance BEFORE filter_ambiguous_query, the
+// visible flags (markMapPointsAsVisible), and the final DMatch list.  Returns the number of final matches.
+int oracle_proj_match(const oracle_keypoint* und_kpts, int n_kpts, const uint8_t* desc, const float* scale_factors, int n_levels,
+                      float fx, float fy, float cx, float cy, int min_x, int min_y, int max_x, int max_y, const float* pose_f2g,
+                      int n_pts, const uint32_t* ids, const float* pos3d, const float* normal, const float* min_dist,
+                      const float* max_dist, const uint8_t* mp_desc, float minDescDist, float maxRepjDist, int32_t* best_kp_out,
+                      float* best_dist_out, uint8_t* visible_out, int32_t* matches_out /* n x 4 words (cv::DMatch) */) {
+    KdTree kd;
+    {
+        std::vector<float> xy(2 * (size_t)n_kpts);
+        for (int i = 0; i < n_kpts; i++) { xy[2 * i] = und_kpts[i].x; xy[2 * i + 1] = und_kpts[i].y; }
+        kd_build(kd, xy.data(), n_kpts);
+    }
+    const float* T = pose_f2g;
+    // camCenter = pose_f2g.inv() * (0,0,0): se3transform.h:89-113
+    float Minv[12];
+    Minv[0] = T[0]; Minv[1] = T[4]; Minv[2] = T[8]; Minv[4] = T[1]; Minv[5] = T[5]; Minv[6] = T[9]; Minv[8] = T[2]; Minv[9] = T[6]; Minv[10] = T[10];
+    Minv[3] = -(T[3] * Minv[0] + T[7] * Minv[1] + T[11] * Minv[2]);
+    Minv[7] = -(T[3] * Minv[4] + T[7] * Minv[5] + T[11] * Minv[6]);
+    Minv[11] = -(T[3] * Minv[8] + T[7] * Minv[9] + T[11] * Minv[10]);
+    const float cc[3] = {Minv[0] * 0.f + Minv[1] * 0.f + Minv[2] * 0.f + Minv[3], Minv[4] * 0.f + Minv[5] * 0.f + Minv[6] * 0.f + Minv[7],
+                         Minv[8] * 0.f + Minv[9] * 0.f + Minv[10] * 0.f + Minv[11]};
+    const float logScale = n_levels > 1 ? logf_cr(scale_factors[1]) : 1.f;
+    std::vector<DMatch> matches;
+    Hits hits;
+    for (int m = 0; m < n_pts; m++) {
+        best_kp_out[m] = -1;
+        best_dist_out[m] = std::numeric_limits<float>::max();
+        if (visible_out) visible_out[m] = 0;
+        const float* P = pos3d + 3 * (size_t)m;
+        const float* N = normal + 3 * (size_t)m;
+        // getViewCos: v = camCenter - pos3d; v *= 1./cv::norm(v); return v.dot(normal)
+        float v[3] = {cc[0] - P[0], cc[1] - P[1], cc[2] - P[2]};
+        const double nv = std::sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]);
+        const double s = 1. / nv;
+        for (int i = 0; i < 3; i++) v[i] = (float)(v[i] * s);
+        const float viewCos = v[0] * N[0] + v[1] * N[1] + v[2] * N[2];
+        if (viewCos < 0.5) continue;
+        float p3[3] = {T[0] * P[0] + T[1] * P[1] + T[2] * P[2] + T[3], T[4] * P[0] + T[5] * P[1] + T[6] * P[2] + T[7],
+                       T[8] * P[0] + T[9] * P[1] + T[10] * P[2] + T[11]};
+        if (p3[2] < 0) continue;
+        const float distToPoint = (float)std::sqrt((double)p3[0] * p3[0] + (double)p3[1] * p3[1] + (double)p3[2] * p3[2]);
+        if (!(0.8f * min_dist[m] < distToPoint && distToPoint < 1.2f * max_dist[m])) continue;
+        p3[2] = (float)(1. / p3[2]);
+        const float p2x = p3[0] * fx * p3[2] + cx, p2y = p3[1] * fy * p3[2] + cy;
+        if (!(p2x > (float)min_x && p2y > (float)min_y && p2x < (float)max_x && p2y < (float)max_y)) continue;
+        if (visible_out) visible_out[m] = 1;
+        // predictScale(distToPoint, maxDistance): frame.h:129-136
+        int predicted;
+        {
+            const int ns = (int)std::ceil(logf_cr(max_dist[m] / distToPoint) / logScale);
+            if (ns < 0) predicted = 0;
+            else if (ns >= n_levels) predicted = n_levels - 1;
+            else predicted = ns;
+        }
+        float radius_scale = scale_factors[predicted];
+        if (viewCos < 0.98) radius_scale = (float)(radius_scale * 1.6);
+        float best_d = std::numeric_limits<float>::max(), second_d = std::numeric_limits<float>::max();
+        int best_kp = -1, bestLevel = 0, bestLevel2 = -1;
+        kd_radius(kd, p2x, p2y, (double)(radius_scale * maxRepjDist), hits);
+        for (auto& h : hits.v) {
+            const int oc = und_kpts[h.first].octave;
+            if (!(oc >= predicted - 1 && oc <= predicted)) continue;
+            const float dd = hamming_f(mp_desc + 32 * (size_t)m, desc + 32 * (size_t)h.first);
+            if (dd < minDescDist) {
+                if (dd < best_d) { best_d = dd; best_kp = (int)h.first; bestLevel = oc; }
+                else if (dd < second_d) { second_d = dd; bestLevel2 = oc; }
+            }
+        }
+        if (best_kp != -1) {
+            bool valid = true;
+            if (bestLevel2 == bestLevel && best_d > 0.8 * second_d) valid = false;
+            if (valid) {
+                best_kp_out[m] = best_kp;
+                best_dist_out[m] = best_d;
+                matches.push_back({best_kp, (int32_t)ids[m], -1, best_d});
+            }
+        }
+    }
+    // filter_ambiguous_query (misc.cpp:117-150) + remove_unused_matches (:105-107)
+    if (!matches.empty()) {
+        int maxT = -1;
+        for (auto& mm : matches) maxT = std::max(maxT, mm.queryIdx);
+        std::vector<int> used(maxT + 1, -1);
+        int idx = 0;
+        for (auto& match : matches) {
+            if (used[match.queryIdx] == -1) used[match.queryIdx] = idx;
+            else if (matches[used[match.queryIdx]].distance > match.distance) { matches[used[match.queryIdx]].queryIdx = -1; used[match.queryIdx] = idx; }
+            else match.queryIdx = -1;
+            idx++;
+        }
+        matches.erase(std::remove_if(matches.begin(), matches.end(), [](const DMatch& mm) { return mm.trainIdx == -1 || mm.queryIdx == -1; }), matches.end());
+    }
+    for (size_t i = 0; i < matches.size(); i++) std::memcpy(matches_out + 4 * i, &matches[i], 16);
+    return (int)matches.size();
+}
+
+}  // extern "C"

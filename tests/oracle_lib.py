@@ -140,3 +140,77 @@ def pnp_solve(L, pr):
 
 def pnp_solve_ref(R, pr):
     return _pnp_call(R.g2o_ref_pnp_solve, pr)
+
+
+# ------------------------------------------------------------------------------------------------ projection matcher (a27)
+class KdOracle:
+    """oracle_kd_* (restated picoflann) or picoflann_ref_* (the real header) behind one interface."""
+
+    def __init__(self, lib, prefix, xy):
+        import numpy as np
+
+        self.L, self.pre = lib, prefix
+        self.xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        b = getattr(lib, prefix + "_build")
+        b.restype = VP
+        b.argtypes = [VP, I]
+        r = getattr(lib, prefix + "_radius")
+        r.restype = I
+        r.argtypes = [VP, C.c_float, C.c_float, C.c_double, VP, VP, I]
+        getattr(lib, prefix + "_free").argtypes = [VP]
+        self.h = b(P(self.xy), len(self.xy))
+
+    def radius(self, qx, qy, radius):
+        import numpy as np
+
+        cap = max(len(self.xy), 1)
+        idx = np.empty(cap, np.uint32)
+        sqd = np.empty(cap, np.float64)
+        n = getattr(self.L, self.pre + "_radius")(self.h, float(qx), float(qy), float(radius), P(idx), P(sqd), cap)
+        return idx[:n].copy(), sqd[:n].copy()
+
+    def export(self):
+        import numpy as np
+
+        n = len(self.xy)
+        m = 2 * n + 2
+        a = dict(col=np.zeros(m, np.int32), divlow=np.zeros(m, np.float32), divhigh=np.zeros(m, np.float32), left=np.zeros(m, np.int32),
+                 right=np.zeros(m, np.int32), leaf_begin=np.zeros(m, np.int32), leaf_count=np.zeros(m, np.int32),
+                 leaf_idx=np.zeros(max(n, 1), np.uint32), root_bbox=np.zeros(4, np.float64))
+        f = self.L.oracle_kd_export
+        f.restype = I
+        f.argtypes = [VP] * 10
+        nn = f(self.h, *[P(a[k]) for k in ("col", "divlow", "divhigh", "left", "right", "leaf_begin", "leaf_count", "leaf_idx", "root_bbox")])
+        for k in ("col", "divlow", "divhigh", "left", "right", "leaf_begin", "leaf_count"):
+            a[k] = a[k][:nn]
+        a["leaf_idx"] = a["leaf_idx"][:n]
+        return a
+
+    def __del__(self):
+        try:
+            getattr(self.L, self.pre + "_free")(self.h)
+        except Exception:
+            pass
+
+
+def proj_match(L, fr, mp, pose, minDescDist, maxRepjDist):
+    """oracle_proj_match on the dicts made by synth.proj_problem; returns dict(best_kp, best_dist, visible, matches[n,4 int32 view])."""
+    import numpy as np
+
+    n = len(mp["ids"])
+    best_kp = np.empty(n, np.int32)
+    best_d = np.empty(n, np.float32)
+    vis = np.empty(n, np.uint8)
+    mout = np.zeros((max(n, 1), 4), np.int32)
+    f = L.oracle_proj_match
+    f.restype = I
+    F = C.c_float
+    f.argtypes = [VP, I, VP, VP, I, F, F, F, F, I, I, I, I, VP, I, VP, VP, VP, VP, VP, VP, F, F, VP, VP, VP, VP]
+    pose = np.ascontiguousarray(pose, np.float32)
+    k = f(P(fr["und_kpts"]), len(fr["und_kpts"]), P(fr["desc"]), P(fr["scale_factors"]), len(fr["scale_factors"]),
+          fr["fx"], fr["fy"], fr["cx"], fr["cy"], fr["min_xy"][0], fr["min_xy"][1], fr["max_xy"][0], fr["max_xy"][1], P(pose), n,
+          P(mp["ids"]), P(mp["pos3d"]), P(mp["normal"]), P(mp["min_dist"]), P(mp["max_dist"]), P(mp["desc"]), minDescDist, maxRepjDist,
+          P(best_kp), P(best_d), P(vis), P(mout))
+    dm = np.zeros(k, dtype=np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")]))
+    dm[:] = mout[:k].copy().view(dm.dtype).reshape(-1)
+    return dict(best_kp=best_kp, best_dist=best_d, visible=vis, matches=dm)

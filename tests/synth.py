@@ -205,3 +205,77 @@ def pnp_problem(n=600, seed=0, outlier_frac=0.15, pose_noise=0.03, pix_noise=0.7
     return dict(pose=np.ascontiguousarray(T0.reshape(16)), intr=np.array([fx, fy, cx, cy], np.float32), n=n,
                 p3d=np.ascontiguousarray(Xw.astype(np.float32)), kp=np.ascontiguousarray(uv.astype(np.float32)), invsig=invsig, weight=weight,
                 pose_gt=Tgt, outlier=out)
+
+
+def proj_problem(n_kpts=2000, n_pts=3000, seed=0, w=1241, h=376, n_levels=8, low_entropy=False, pose_noise=0.002):
+    """Inputs of Map::matchFrameToMapPoints (map.cpp:651-770): a frame (undistorted keypoints with octaves, descriptors, scale
+    factors, intrinsics) and candidate map points (position, mean viewing normal, distance-invariance window, descriptor).
+    Two thirds of the map points are back-projections of frame keypoints (descriptor = the keypoint's with a few flipped
+    bits), the rest are unrelated (behind the camera, outside the image, wrong scale, ...).  low_entropy=True makes most
+    descriptor distances collide so that the best / second-best bookkeeping and its candidate-order dependence are stressed."""
+    import oracle_lib
+
+    rng = np.random.default_rng(seed)
+    fx = fy = 718.856 if w > 1000 else 517.3
+    cx, cy = (607.19, 185.22) if w > 1000 else (318.6, 255.3)
+    scale = np.float32(1.2) ** np.arange(n_levels, dtype=np.float32)
+    sf = np.ones(n_levels, np.float32)
+    for i in range(1, n_levels):
+        sf[i] = sf[i - 1] * np.float32(1.2)            # the extractor's float chain (ORBextractor.cpp:468-515)
+    kp = np.zeros(n_kpts, oracle_lib.KEYPOINT_DTYPE)
+    octv = rng.integers(0, n_levels, n_kpts)
+    # level pixel grid positions scaled back to level 0, like the extractor's output (clustered: corners come in groups)
+    centers = rng.random((max(n_kpts // 12, 1), 2)) * [w - 60, h - 60] + 30
+    pos = centers[rng.integers(0, len(centers), n_kpts)] + rng.normal(0, 9, (n_kpts, 2))
+    pos = np.clip(pos, 19, [w - 20, h - 20])
+    lv = sf[octv]
+    pos = (np.round(pos / lv[:, None]) * lv[:, None]).astype(np.float32)
+    kp["x"], kp["y"], kp["octave"] = pos[:, 0], pos[:, 1], octv
+    kp["size"] = 31 * lv
+    kp["angle"] = rng.random(n_kpts) * 360
+    kp["response"] = rng.integers(7, 120, n_kpts)
+    if low_entropy:
+        desc = np.zeros((n_kpts, 32), np.uint8)
+        desc[:, :2] = rng.integers(0, 256, (n_kpts, 2))
+    else:
+        desc = rng.integers(0, 256, (n_kpts, 32), dtype=np.uint8)
+    Tgt = _se3_exp(np.r_[0.01, -0.015, 0.004, 0, 0, 0]) @ np.eye(4)
+    Tgt[:3, 3] = [0.3, -0.05, 0.1]
+    cam_c = -Tgt[:3, :3].T @ Tgt[:3, 3]
+    n_rel = (2 * n_pts) // 3
+    src = rng.integers(0, max(n_kpts, 1), n_rel) if n_kpts else np.zeros(0, np.int64)
+    z = rng.uniform(3, 45, n_rel)
+    uv = np.stack([kp["x"][src], kp["y"][src]], 1).astype(np.float64) + rng.normal(0, 1.5, (n_rel, 2)) if n_kpts else np.zeros((0, 2))
+    Xc = np.stack([(uv[:, 0] - cx) / fx * z, (uv[:, 1] - cy) / fy * z, z], 1)
+    Xw = (Xc - Tgt[:3, 3]) @ Tgt[:3, :3]
+    # distance-invariance window as Map::updatePointNormalAndDistances makes it: dist * scale[level] and that / scale[last]
+    d = np.linalg.norm(Xw - cam_c, axis=1)
+    lev = np.clip(kp["octave"][src] + rng.integers(-1, 2, n_rel), 0, n_levels - 1) if n_kpts else np.zeros(0, np.int64)
+    maxd = d * sf[lev] * rng.uniform(0.9, 1.1, n_rel)
+    mind = maxd / sf[n_levels - 1]
+    view = cam_c - Xw
+    view /= np.linalg.norm(view, axis=1, keepdims=True)
+    nrm = view + rng.normal(0, 0.45, (n_rel, 3))      # some beyond 60 degrees, many between cos 0.98 and 0.5
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    mdesc = desc[src].copy() if n_kpts else np.zeros((0, 32), np.uint8)
+    flips = rng.integers(0, 30 if not low_entropy else 3, n_rel)
+    for i in range(n_rel):
+        for b in rng.integers(0, 256 if not low_entropy else 16, flips[i]):
+            mdesc[i, b // 8] ^= 1 << (b % 8)
+    n_un = n_pts - n_rel
+    Xu = rng.normal(0, 20, (n_un, 3)) + [0, 0, 10]
+    du = np.linalg.norm(Xu - cam_c, axis=1)
+    maxu = du * rng.uniform(0.5, 3.0, n_un)
+    nu = rng.normal(0, 1, (n_un, 3))
+    nu /= np.linalg.norm(nu, axis=1, keepdims=True)
+    udesc = rng.integers(0, 256, (n_un, 32), dtype=np.uint8) if not low_entropy else np.zeros((n_un, 32), np.uint8)
+    perm = rng.permutation(n_pts)
+    mp = dict(ids=np.ascontiguousarray((rng.permutation(10 * n_pts)[:n_pts]).astype(np.uint32)),
+              pos3d=np.ascontiguousarray(np.concatenate([Xw, Xu])[perm].astype(np.float32)),
+              normal=np.ascontiguousarray(np.concatenate([nrm, nu])[perm].astype(np.float32)),
+              min_dist=np.ascontiguousarray(np.concatenate([mind, maxu / sf[n_levels - 1]])[perm].astype(np.float32)),
+              max_dist=np.ascontiguousarray(np.concatenate([maxd, maxu])[perm].astype(np.float32)),
+              desc=np.ascontiguousarray(np.concatenate([mdesc, udesc])[perm]))
+    fr = dict(und_kpts=kp, desc=np.ascontiguousarray(desc), scale_factors=sf, fx=fx, fy=fy, cx=cx, cy=cy, min_xy=(0, 0), max_xy=(w, h))
+    pose = (_se3_exp(rng.normal(0, pose_noise, 6)) @ Tgt).astype(np.float32)
+    return fr, mp, np.ascontiguousarray(pose.reshape(16))

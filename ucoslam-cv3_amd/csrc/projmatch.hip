@@ -1,0 +1,453 @@
+// Projection matcher on MI355X (gfx950) behind the C ABI (uh_projmatch_*): map points of the neighbouring keyframes are
+// projected into the current frame and matched to its keypoints inside a scale-dependent disc.
+//
+// Semantic contract (reference file:line):
+//   src/map.cpp:651-770                 Map::matchFrameToMapPoints: view-cosine >= 0.5, depth >= 0, distance-invariance window,
+//                                       in-image test, predicted octave, disc radius scale*maxRepjDist (x1.6 if cos < 0.98),
+//                                       octaves [p-1, p], best / second-best Hamming bookkeeping IN CANDIDATE ORDER, the 0.8
+//                                       ratio rule when both have the same octave, then filter_ambiguous_query
+//   src/map_types/frame.cpp:102-115     Frame::getKeyPointsInRegion (kd-tree radius search, unsorted, octave filter)
+//   src/map_types/frame.h:129-136       Frame::predictScale
+//   src/map_types/mappoint.h:99,146-177 getViewCos, getHammDescDistance_2 (float result)
+//   src/basictypes/picoflann.h          KdTreeIndex<2>: build :150-163,238-345 (mean/variance split on <=100 samples,
+//                                       planeSplit, std::sort fallback, leaves <= 10) and searchExactLevel :545-590
+//
+// The candidate ORDER is observable (a candidate that fails "d < best" updates the second-best, one that succeeds does not
+// demote the old best), so the disc search cannot be replaced by a grid: the kernel walks the SAME kd-tree in the SAME
+// order.  Division of work:
+//   host   (uh_projmatch_set_frame)  builds the tree exactly like picoflann does — the reference also builds it on the CPU,
+//          once per frame (Frame::create_kdtree, frame.h:124) — and uploads it flattened (24-byte nodes + leaf index list)
+//   device (projmatch_kernel)        one lane per map point: visibility tests, predicted octave, iterative tree walk with an
+//          explicit stack (the recursion's after-best-child / restore steps are stack records), Hamming distances against the
+//          frame's descriptors, best / second-best rule.  ~10^3..10^4 map points x a few dozen candidates each: the kernel is
+//          bound by dependent L2 round trips of the walk, not by bandwidth.
+//   host   orders the per-point results into the DMatch list and runs filter_ambiguous_query (matcher.hip).
+// Floating-point conventions are those of oracle/proj_oracle.cpp (float ops in source order, no contraction; cv::norm in
+// double; logf(x) := float(log(double(x)))).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+
+extern "C" int uh_filter_ambiguous(uh_dmatch* matches, int n, int by_train);
+
+namespace {
+
+constexpr int kLeafMax = 10;          // picoflann _maxLeafSize
+constexpr int kStackMax = 96;         // walk stack records: one per level on the path + the record being expanded
+constexpr int kMaxDepth = kStackMax - 4;
+constexpr int kPmThreads = 64;        // one wave per workgroup: divergent walks, many workgroups
+
+struct KdNodeDev {
+    float divlow, divhigh;
+    int left, right;        // -1/-1 = leaf
+    int leaf_begin;
+    short leaf_count, col;
+};
+static_assert(sizeof(KdNodeDev) == 24, "node layout");
+
+// ---------------------------------------------------------------------------------------------------------- host: tree build
+// Flat-array restatement of picoflann::KdTreeIndex<2>::build for (x,y) float points.  std::sort is used exactly where the
+// reference uses it (same libstdc++ => same permutation of equal keys).
+class KdBuilder {
+public:
+    std::vector<KdNodeDev> nodes;
+    std::vector<uint32_t> leaf_idx;
+    double root_box[4] = {0, 0, 0, 0};   // x.min x.max y.min y.max
+    int max_depth = 0;
+
+    void build(const float* xy, int n) {
+        xy_ = xy;
+        nodes.clear();
+        leaf_idx.clear();
+        leaf_idx.reserve(n);
+        order_.resize(n);
+        for (int i = 0; i < n; i++) order_[i] = (uint32_t)i;
+        max_depth = 0;
+        if (n == 0) return;
+        Box root;
+        bounds(0, n, root);
+        nodes.reserve(2 * (size_t)n + 2);
+        nodes.push_back(KdNodeDev{0, 0, -1, -1, 0, 0, 0});
+        split(0, 0, n, root, 1);
+        root_box[0] = root.lo[0]; root_box[1] = root.hi[0]; root_box[2] = root.lo[1]; root_box[3] = root.hi[1];
+    }
+
+private:
+    struct Box { double lo[2], hi[2]; };
+    const float* xy_ = nullptr;
+    std::vector<uint32_t> order_;
+    float coord(uint32_t i, int d) const { return xy_[2 * (size_t)i + d]; }
+
+    void bounds(int b, int e, Box& box) const {
+        for (int d = 0; d < 2; d++) box.lo[d] = box.hi[d] = coord(order_[b], d);
+        for (int k = b + 1; k < e; k++)
+            for (int d = 0; d < 2; d++) {
+                const float v = coord(order_[k], d);
+                if (v < box.lo[d]) box.lo[d] = v;
+                if (v > box.hi[d]) box.hi[d] = v;
+            }
+    }
+
+    // picoflann.h:362-391: mean / variance over at most ~100 evenly spaced samples (float squares, double sums)
+    void sample_moments(int b, int e, double mean[2], double var[2]) const {
+        double s1[2] = {0, 0}, s2[2] = {0, 0};
+        int step = 1, cnt = 0;
+        if (e - b >= 200) step = (e - b) / 100;
+        for (int i = b; i < e; i += step, cnt++)
+            for (int d = 0; d < 2; d++) {
+                const float v = coord(order_[i], d);
+                s1[d] += v;
+                s2[d] += v * v;
+            }
+        const double inv = 1. / double(cnt);
+        for (int d = 0; d < 2; d++) {
+            mean[d] = s1[d] * inv;
+            var[d] = s2[d] * inv - mean[d] * mean[d];
+        }
+    }
+
+    // picoflann.h:403-424: two Hoare passes -> [< cut | == cut | > cut]
+    void three_way(uint32_t* ind, int count, int dim, float cut, int& lim1, int& lim2) const {
+        int l = 0, r = count - 1;
+        for (;;) {
+            while (l <= r && coord(ind[l], dim) < cut) ++l;
+            while (l <= r && coord(ind[r], dim) >= cut) --r;
+            if (l > r) break;
+            std::swap(ind[l], ind[r]); ++l; --r;
+        }
+        lim1 = l;
+        r = count - 1;
+        for (;;) {
+            while (l <= r && coord(ind[l], dim) <= cut) ++l;
+            while (l <= r && coord(ind[r], dim) > cut) --r;
+            if (l > r) break;
+            std::swap(ind[l], ind[r]); ++l; --r;
+        }
+        lim2 = l;
+    }
+
+    // picoflann.h:238-345.  `box` is in/out: on return it is the tight box of the subtree.
+    void split(int node, int b, int e, Box& box, int depth) {
+        max_depth = std::max(max_depth, depth);
+        const int count = e - b;
+        if (count <= kLeafMax) {
+            nodes[node].leaf_begin = (int)leaf_idx.size();
+            nodes[node].leaf_count = (short)count;
+            for (int i = b; i < e; i++) leaf_idx.push_back(order_[i]);
+            bounds(b, e, box);
+            return;
+        }
+        const int lch = (int)nodes.size();
+        nodes.push_back(KdNodeDev{0, 0, -1, -1, 0, 0, 0});
+        nodes.push_back(KdNodeDev{0, 0, -1, -1, 0, 0, 0});
+        double mean[2], var[2];
+        sample_moments(b, e, mean, var);
+        const int dim = var[1] > var[0] ? 1 : 0;
+        double cut = mean[dim];
+        int lim1, lim2;
+        three_way(&order_[b], count, dim, (float)cut, lim1, lim2);
+        int at = count / 2;
+        if (lim1 > count / 2) at = lim1;
+        else if (lim2 < count / 2) at = lim2;
+        if (lim1 == count || lim2 == 0) at = count / 2;
+        if (at < kLeafMax || count - at < kLeafMax) {
+            std::sort(order_.begin() + b, order_.begin() + e, [&](const uint32_t& p, const uint32_t& q) { return coord(p, dim) < coord(q, dim); });
+            at = count / 2;
+            cut = coord(order_[b + at], dim);
+        }
+        Box lbox = box, rbox = box;
+        lbox.hi[dim] = cut;
+        split(lch, b, b + at, lbox, depth + 1);
+        lbox.hi[dim] = cut;
+        rbox.lo[dim] = cut;
+        split(lch + 1, b + at, e, rbox, depth + 1);
+        KdNodeDev& nd = nodes[node];
+        nd.left = lch; nd.right = lch + 1; nd.col = (short)dim;
+        nd.divlow = (float)lbox.hi[dim];
+        nd.divhigh = (float)rbox.lo[dim];
+        for (int d = 0; d < 2; d++) { box.lo[d] = std::min(lbox.lo[d], rbox.lo[d]); box.hi[d] = std::max(lbox.hi[d], rbox.hi[d]); }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------- device
+struct PmFrame {
+    const float2* kp_xy; const int* kp_octave; const uint64_t* kp_desc;   // n_kpts, n_kpts, n_kpts x 4
+    const KdNodeDev* nodes; const unsigned int* leaf_idx;
+    double box[4];
+    const float* scale; int n_levels; int n_kpts;
+    float fx, fy, cx, cy, min_x, min_y, max_x, max_y;
+    float log_scale;
+};
+
+struct PmPoints {
+    int n;
+    const float* pos3d; const float* normal; const float* min_dist; const float* max_dist; const uint64_t* desc;
+    int* best_kp; float* best_dist; unsigned char* visible;
+};
+
+struct PmPose { float T[12]; float cc[3]; };
+
+__device__ __forceinline__ float logf_cr(float x) { return (float)log((double)x); }
+
+struct WalkRec { int a; int kind; double m; };   // kind 0: visit node a (mindistsq m), 1: best child of node a done, 2: dists[a] = m
+
+__global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoints mp, PmPose ps, float minDescDist, float maxRepjDist, int* overflow) {
+    const int m = blockIdx.x * kPmThreads + threadIdx.x;
+    if (m >= mp.n) return;
+    int best_kp = -1;
+    float best_d = 3.402823466e+38f;
+    unsigned char vis = 0;
+    do {
+        const float P0 = mp.pos3d[3 * m], P1 = mp.pos3d[3 * m + 1], P2 = mp.pos3d[3 * m + 2];
+        // getViewCos
+        float v0 = ps.cc[0] - P0, v1 = ps.cc[1] - P1, v2 = ps.cc[2] - P2;
+        const double s = 1. / sqrt((double)v0 * v0 + (double)v1 * v1 + (double)v2 * v2);
+        v0 = (float)(v0 * s); v1 = (float)(v1 * s); v2 = (float)(v2 * s);
+        const float viewCos = v0 * mp.normal[3 * m] + v1 * mp.normal[3 * m + 1] + v2 * mp.normal[3 * m + 2];
+        if (viewCos < 0.5) break;
+        const float* T = ps.T;
+        const float x = T[0] * P0 + T[1] * P1 + T[2] * P2 + T[3];
+        const float y = T[4] * P0 + T[5] * P1 + T[6] * P2 + T[7];
+        const float z = T[8] * P0 + T[9] * P1 + T[10] * P2 + T[11];
+        if (z < 0) break;
+        const float dist = (float)sqrt((double)x * x + (double)y * y + (double)z * z);
+        const float maxd = mp.max_dist[m];
+        if (!(0.8f * mp.min_dist[m] < dist && dist < 1.2f * maxd)) break;
+        const float iz = (float)(1. / z);
+        const float px = x * f.fx * iz + f.cx, py = y * f.fy * iz + f.cy;
+        if (!(px > f.min_x && py > f.min_y && px < f.max_x && py < f.max_y)) break;
+        vis = 1;
+        int predicted;
+        {
+            const int ns = (int)ceilf(logf_cr(maxd / dist) / f.log_scale);
+            predicted = ns < 0 ? 0 : (ns >= f.n_levels ? f.n_levels - 1 : ns);
+        }
+        float radius_scale = f.scale[predicted];
+        if (viewCos < 0.98) radius_scale = (float)(radius_scale * 1.6);
+        const double radius = (double)(radius_scale * maxRepjDist);
+        if (f.n_kpts == 0) break;
+        const double worst = radius * radius;
+        const uint64_t q0 = mp.desc[4 * (size_t)m], q1 = mp.desc[4 * (size_t)m + 1], q2 = mp.desc[4 * (size_t)m + 2], q3 = mp.desc[4 * (size_t)m + 3];
+        // computeInitialDistances (float accumulator)
+        double dd0 = 0, dd1 = 0;
+        float distsq = 0.f;
+        {
+            const double ex = px, ey = py;
+            if (ex < f.box[0]) { const double d = ex - f.box[0]; dd0 = d * d; distsq += dd0; }
+            if (ex > f.box[1]) { const double d = ex - f.box[1]; dd0 = d * d; distsq += dd0; }
+            if (ey < f.box[2]) { const double d = ey - f.box[2]; dd1 = d * d; distsq += dd1; }
+            if (ey > f.box[3]) { const double d = ey - f.box[3]; dd1 = d * d; distsq += dd1; }
+        }
+        float second_d = 3.402823466e+38f;
+        int bestLevel = 0, bestLevel2 = -1;
+        WalkRec st[kStackMax];
+        int sp = 0;
+        st[sp++] = WalkRec{0, 0, (double)distsq};
+        bool ovf = false;
+        while (sp > 0) {
+            const WalkRec r = st[--sp];
+            if (r.kind == 2) { if (r.a == 0) dd0 = r.m; else dd1 = r.m; continue; }
+            const KdNodeDev nd = f.nodes[r.a];
+            if (nd.left < 0) {   // leaf (only reached with kind 0)
+                for (int i = 0; i < nd.leaf_count; i++) {
+                    const unsigned int id = f.leaf_idx[nd.leaf_begin + i];
+                    const float2 c = f.kp_xy[id];
+                    const double dx = px - c.x;
+                    double sqd = dx * dx;
+                    if (!(sqd > worst)) { const double dy = py - c.y; sqd += dy * dy; }
+                    if (!(sqd < worst)) continue;
+                    const int oc = f.kp_octave[id];
+                    if (!(oc >= predicted - 1 && oc <= predicted)) continue;
+                    const uint64_t* kd = f.kp_desc + 4 * (size_t)id;
+                    const float hd = (float)(__popcll(q0 ^ kd[0]) + __popcll(q1 ^ kd[1]) + __popcll(q2 ^ kd[2]) + __popcll(q3 ^ kd[3]));
+                    if (hd < minDescDist) {
+                        if (hd < best_d) { best_d = hd; best_kp = (int)id; bestLevel = oc; }
+                        else if (hd < second_d) { second_d = hd; bestLevel2 = oc; }
+                    }
+                }
+                continue;
+            }
+            const double val = nd.col == 0 ? px : py;
+            const double diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
+            const bool go_left = diff1 + diff2 < 0;
+            const double cut = go_left ? diff2 * diff2 : diff1 * diff1;
+            if (r.kind == 0) {
+                if (sp + 2 > kStackMax) { ovf = true; break; }
+                st[sp++] = WalkRec{r.a, 1, r.m};
+                st[sp++] = WalkRec{go_left ? nd.left : nd.right, 0, r.m};
+            } else {   // the best child's subtree is done: maybe the other one, then restore dists[col]
+                const float dst = (float)(nd.col == 0 ? dd0 : dd1);
+                const double m2 = r.m + cut - dst;
+                if (nd.col == 0) dd0 = cut; else dd1 = cut;
+                if (sp + 2 > kStackMax) { ovf = true; break; }
+                st[sp++] = WalkRec{nd.col, 2, (double)dst};
+                if (m2 * 1.0 <= worst) st[sp++] = WalkRec{go_left ? nd.right : nd.left, 0, m2};
+            }
+        }
+        if (ovf) { *overflow = 1; best_kp = -1; break; }
+        if (best_kp != -1 && bestLevel2 == bestLevel && best_d > 0.8 * second_d) best_kp = -1;
+    } while (false);
+    mp.best_kp[m] = best_kp;
+    mp.best_dist[m] = best_d;
+    if (mp.visible) mp.visible[m] = vis;
+}
+
+}  // namespace
+
+struct uh_projmatch {
+    uh_ctx* ctx = nullptr;
+    bool have_frame = false;
+    int n_kpts = 0, n_levels = 0;
+    PmFrame fr{};
+    uh::DevBuf d_frame;    // kp_xy | kp_octave | kp_desc | nodes | leaf_idx | scale
+    uh::DevBuf d_points;   // pos3d | normal | min | max | desc | best_kp | best_dist | visible | overflow
+    uh::PinBuf h_out;
+    KdBuilder kd;
+};
+
+extern "C" {
+
+int uh_projmatch_create(uh_ctx* ctx, uh_projmatch** out) {
+    UH_REQUIRE(ctx && out, "uh_projmatch_create: NULL argument");
+    uh_projmatch* h = new uh_projmatch();
+    h->ctx = ctx;
+    *out = h;
+    return UH_OK;
+}
+
+void uh_projmatch_destroy(uh_projmatch* h) { delete h; }
+
+int uh_projmatch_set_frame(uh_projmatch* h, const uh_proj_frame* f) {
+    UH_REQUIRE(h && f, "uh_projmatch_set_frame: NULL argument");
+    UH_REQUIRE(f->n_kpts >= 0 && (f->n_kpts == 0 || (f->und_kpts && f->desc)), "uh_projmatch_set_frame: keypoints / descriptors missing");
+    UH_REQUIRE(f->n_levels >= 1 && f->scale_factors, "uh_projmatch_set_frame: scale factors missing");
+    UH_HIP_CHECK(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    const int n = f->n_kpts;
+    std::vector<float> xy(2 * (size_t)std::max(n, 1));
+    std::vector<int> oct(std::max(n, 1));
+    for (int i = 0; i < n; i++) { xy[2 * i] = f->und_kpts[i].x; xy[2 * i + 1] = f->und_kpts[i].y; oct[i] = f->und_kpts[i].octave; }
+    h->kd.build(xy.data(), n);
+    UH_REQUIRE(h->kd.max_depth <= kMaxDepth, "uh_projmatch_set_frame: kd-tree depth %d exceeds the walk stack (%d levels)", h->kd.max_depth, kMaxDepth);
+    const size_t nn = h->kd.nodes.size();
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_xy = 0, o_oct = al(o_xy + 8 * (size_t)n), o_desc = al(o_oct + 4 * (size_t)n), o_nodes = al(o_desc + 32 * (size_t)n);
+    const size_t o_leaf = al(o_nodes + sizeof(KdNodeDev) * nn), o_scale = al(o_leaf + 4 * (size_t)n), total = al(o_scale + 4 * (size_t)f->n_levels);
+    int rc = h->d_frame.reserve(total + 256);
+    if (rc) return rc;
+    char* base = h->d_frame.as<char>();
+    if (n) {
+        UH_HIP_CHECK(hipMemcpyAsync(base + o_xy, xy.data(), 8 * (size_t)n, hipMemcpyHostToDevice, st));
+        UH_HIP_CHECK(hipMemcpyAsync(base + o_oct, oct.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
+        UH_HIP_CHECK(hipMemcpyAsync(base + o_desc, f->desc, 32 * (size_t)n, hipMemcpyHostToDevice, st));
+        UH_HIP_CHECK(hipMemcpyAsync(base + o_nodes, h->kd.nodes.data(), sizeof(KdNodeDev) * nn, hipMemcpyHostToDevice, st));
+        UH_HIP_CHECK(hipMemcpyAsync(base + o_leaf, h->kd.leaf_idx.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
+    }
+    UH_HIP_CHECK(hipMemcpyAsync(base + o_scale, f->scale_factors, 4 * (size_t)f->n_levels, hipMemcpyHostToDevice, st));
+    UH_HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors die here
+    PmFrame& d = h->fr;
+    d.kp_xy = (const float2*)(base + o_xy); d.kp_octave = (const int*)(base + o_oct); d.kp_desc = (const uint64_t*)(base + o_desc);
+    d.nodes = (const KdNodeDev*)(base + o_nodes); d.leaf_idx = (const unsigned int*)(base + o_leaf); d.scale = (const float*)(base + o_scale);
+    for (int i = 0; i < 4; i++) d.box[i] = h->kd.root_box[i];
+    d.n_levels = f->n_levels; d.n_kpts = n;
+    d.fx = f->fx; d.fy = f->fy; d.cx = f->cx; d.cy = f->cy;
+    d.min_x = (float)f->min_x; d.min_y = (float)f->min_y; d.max_x = (float)f->max_x; d.max_y = (float)f->max_y;
+    d.log_scale = f->n_levels > 1 ? (float)std::log((double)f->scale_factors[1]) : 1.f;
+    h->n_kpts = n; h->n_levels = f->n_levels;
+    h->have_frame = true;
+    return UH_OK;
+}
+
+// host-only test hook (no device call): the tree set_frame would build for these points.  nodes24_out: 2n+2 nodes of room.
+int uh_kdtree_build_host(const float* xy, int32_t n, int32_t* n_nodes, void* nodes24_out, uint32_t* leaf_idx_out, double* root_box4, int32_t* max_depth) {
+    UH_REQUIRE(n >= 0 && (n == 0 || xy) && n_nodes && nodes24_out && leaf_idx_out && root_box4, "uh_kdtree_build_host: bad arguments");
+    KdBuilder kd;
+    kd.build(xy, n);
+    *n_nodes = (int32_t)kd.nodes.size();
+    if (!kd.nodes.empty()) std::memcpy(nodes24_out, kd.nodes.data(), sizeof(KdNodeDev) * kd.nodes.size());
+    if (n) std::memcpy(leaf_idx_out, kd.leaf_idx.data(), 4 * (size_t)n);
+    std::memcpy(root_box4, kd.root_box, 32);
+    if (max_depth) *max_depth = kd.max_depth;
+    return UH_OK;
+}
+
+// flattened tree of the current frame (for tests: compared with the oracle's / the real picoflann's build)
+int uh_projmatch_debug_tree(uh_projmatch* h, int32_t* n_nodes, const void** nodes24, const uint32_t** leaf_idx, double* root_box4, int32_t* max_depth) {
+    UH_REQUIRE(h && h->have_frame, "uh_projmatch_debug_tree: no frame set");
+    if (n_nodes) *n_nodes = (int32_t)h->kd.nodes.size();
+    if (nodes24) *nodes24 = h->kd.nodes.data();
+    if (leaf_idx) *leaf_idx = h->kd.leaf_idx.data();
+    if (root_box4) std::memcpy(root_box4, h->kd.root_box, 32);
+    if (max_depth) *max_depth = h->kd.max_depth;
+    return UH_OK;
+}
+
+int uh_projmatch_match(uh_projmatch* h, const float* pose_f2g, const uh_map_points* mp, float min_desc_dist, float max_repj_dist,
+                       uh_dmatch* matches_out, int32_t cap, int32_t* best_kp_out, float* best_dist_out, uint8_t* visible_out) {
+    UH_REQUIRE(h && h->have_frame, "uh_projmatch_match: no frame set (call uh_projmatch_set_frame first)");
+    UH_REQUIRE(pose_f2g && mp && mp->n >= 0, "uh_projmatch_match: NULL / negative argument");
+    UH_REQUIRE(max_repj_dist > 0, "uh_projmatch_match: maxRepjDist must be > 0 (a non-positive radius turns the reference's search into an unbounded one)");
+    const int n = mp->n;
+    if (n == 0) return 0;
+    UH_REQUIRE(mp->ids && mp->pos3d && mp->normal && mp->min_dist && mp->max_dist && mp->desc, "uh_projmatch_match: map point arrays missing");
+    UH_REQUIRE(matches_out && cap >= 0, "uh_projmatch_match: output buffer missing");
+    UH_HIP_CHECK(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_pos = 0, o_nrm = al(o_pos + 12 * (size_t)n), o_min = al(o_nrm + 12 * (size_t)n), o_max = al(o_min + 4 * (size_t)n);
+    const size_t o_desc = al(o_max + 4 * (size_t)n), o_bk = al(o_desc + 32 * (size_t)n), o_bd = o_bk + 4 * (size_t)n, o_vis = o_bd + 4 * (size_t)n;
+    const size_t o_ovf = al(o_vis + (size_t)n), total = o_ovf + 256;
+    int rc = h->d_points.reserve(total);
+    if (rc) return rc;
+    const size_t out_bytes = o_ovf + 4 - o_bk;
+    if ((rc = h->h_out.reserve(out_bytes))) return rc;
+    char* base = h->d_points.as<char>();
+    UH_HIP_CHECK(hipMemcpyAsync(base + o_pos, mp->pos3d, 12 * (size_t)n, hipMemcpyHostToDevice, st));
+    UH_HIP_CHECK(hipMemcpyAsync(base + o_nrm, mp->normal, 12 * (size_t)n, hipMemcpyHostToDevice, st));
+    UH_HIP_CHECK(hipMemcpyAsync(base + o_min, mp->min_dist, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+    UH_HIP_CHECK(hipMemcpyAsync(base + o_max, mp->max_dist, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+    UH_HIP_CHECK(hipMemcpyAsync(base + o_desc, mp->desc, 32 * (size_t)n, hipMemcpyHostToDevice, st));
+    UH_HIP_CHECK(hipMemsetAsync(base + o_ovf, 0, 4, st));
+    PmPoints P;
+    P.n = n;
+    P.pos3d = (const float*)(base + o_pos); P.normal = (const float*)(base + o_nrm); P.min_dist = (const float*)(base + o_min);
+    P.max_dist = (const float*)(base + o_max); P.desc = (const uint64_t*)(base + o_desc);
+    P.best_kp = (int*)(base + o_bk); P.best_dist = (float*)(base + o_bd); P.visible = (unsigned char*)(base + o_vis);
+    PmPose ps;
+    const float* T = pose_f2g;
+    for (int i = 0; i < 12; i++) ps.T[i] = T[i];
+    {   // camCenter = pose_f2g.inv() * (0,0,0), se3transform.h:89-113
+        const float m0 = T[0], m1 = T[4], m2 = T[8], m4 = T[1], m5 = T[5], m6 = T[9], m8 = T[2], m9 = T[6], m10 = T[10];
+        const float m3 = -(T[3] * m0 + T[7] * m1 + T[11] * m2), m7 = -(T[3] * m4 + T[7] * m5 + T[11] * m6), m11 = -(T[3] * m8 + T[7] * m9 + T[11] * m10);
+        ps.cc[0] = m0 * 0.f + m1 * 0.f + m2 * 0.f + m3;
+        ps.cc[1] = m4 * 0.f + m5 * 0.f + m6 * 0.f + m7;
+        ps.cc[2] = m8 * 0.f + m9 * 0.f + m10 * 0.f + m11;
+    }
+    UH_LAUNCH(h->ctx, projmatch_kernel, dim3(uh_div_up(n, kPmThreads)), dim3(kPmThreads), 0, h->fr, P, ps, min_desc_dist, max_repj_dist, (int*)(base + o_ovf));
+    UH_HIP_CHECK(hipGetLastError());
+    char* ho = static_cast<char*>(h->h_out.p);
+    UH_HIP_CHECK(hipMemcpyAsync(ho, base + o_bk, out_bytes, hipMemcpyDeviceToHost, st));
+    UH_HIP_CHECK(hipStreamSynchronize(st));
+    const int* bk = (const int*)ho;
+    const float* bd = (const float*)(ho + (o_bd - o_bk));
+    const unsigned char* vis = (const unsigned char*)(ho + (o_vis - o_bk));
+    const int ovf = *(const int*)(ho + (o_ovf - o_bk));
+    UH_REQUIRE(!ovf, "uh_projmatch_match: kd-tree walk stack overflow");
+    if (best_kp_out) std::memcpy(best_kp_out, bk, 4 * (size_t)n);
+    if (best_dist_out) std::memcpy(best_dist_out, bd, 4 * (size_t)n);
+    if (visible_out) std::memcpy(visible_out, vis, (size_t)n);
+    std::vector<uh_dmatch> mm;
+    mm.reserve(n);
+    for (int i = 0; i < n; i++)
+        if (bk[i] >= 0) mm.push_back(uh_dmatch{bk[i], (int32_t)mp->ids[i], -1, bd[i]});
+    int k = mm.empty() ? 0 : uh_filter_ambiguous(mm.data(), (int)mm.size(), 0);
+    if (k < 0) return k;
+    UH_REQUIRE(k <= cap, "uh_projmatch_match: %d matches do not fit the output buffer (cap %d)", k, (int)cap);
+    if (k) std::memcpy(matches_out, mm.data(), sizeof(uh_dmatch) * (size_t)k);
+    return k;
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+"""Host-side mirror of ucoslam::Map::matchFrameToMapPoints on top of the C ABI (uh_projmatch_*).
+
+Reference: src/map.cpp:651-770 — `matchFrameToMapPoints(used_frames, curframe, pose_f2g, minDescDist, maxRepjDist,
+markMapPointsAsVisible, useAllPoints, excludedPoints)` returns vector<cv::DMatch> [queryIdx = keypoint, trainIdx = map point id].
+The selection of candidate map points (getMapPointsInFrames, lastFIdxSeen filter, :657-668) is map bookkeeping and stays with the
+caller; here the frame and the candidate points come flattened (see include/ucoslam_hip.h, uh_proj_frame / uh_map_points).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import I, VP, check, lib, np_ptr
+from .orb import KEYPOINT_DTYPE
+
+DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+
+
+class _ProjFrame(C.Structure):
+    _fields_ = [("und_kpts", VP), ("n_kpts", C.c_int32), ("desc", VP), ("scale_factors", VP), ("n_levels", C.c_int32),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("min_x", C.c_int32), ("min_y", C.c_int32), ("max_x", C.c_int32), ("max_y", C.c_int32)]
+
+
+class _MapPoints(C.Structure):
+    _fields_ = [("n", C.c_int32), ("ids", VP), ("pos3d", VP), ("normal", VP), ("min_dist", VP), ("max_dist", VP), ("desc", VP)]
+
+
+def _declare(L, sig):
+    sig("uh_projmatch_create", I, VP, C.POINTER(VP))
+    sig("uh_projmatch_destroy", None, VP)
+    sig("uh_projmatch_set_frame", I, VP, C.POINTER(_ProjFrame))
+    sig("uh_projmatch_match", I, VP, VP, C.POINTER(_MapPoints), C.c_float, C.c_float, VP, C.c_int32, VP, VP, VP)
+    sig("uh_projmatch_debug_tree", I, VP, C.POINTER(C.c_int32), C.POINTER(VP), C.POINTER(VP), VP, C.POINTER(C.c_int32))
+    sig("uh_kdtree_build_host", I, VP, C.c_int32, C.POINTER(C.c_int32), VP, VP, VP, C.POINTER(C.c_int32))
+
+
+_lib._EXTRA_DECLS.append(_declare)
+
+INT_MAX = 2 ** 31 - 1
+KDNODE_DTYPE = np.dtype([("divlow", "<f4"), ("divhigh", "<f4"), ("left", "<i4"), ("right", "<i4"), ("leaf_begin", "<i4"),
+                         ("leaf_count", "<i2"), ("col", "<i2")])
+
+
+def kdtree_build_host(xy):
+    """The kd-tree uh_projmatch_set_frame builds for these (x, y) points — host only, no GPU."""
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    n = len(xy)
+    nodes = np.zeros(2 * n + 2, KDNODE_DTYPE)
+    leaf = np.zeros(max(n, 1), np.uint32)
+    box = np.zeros(4, np.float64)
+    nn, depth = C.c_int32(), C.c_int32()
+    check(lib().uh_kdtree_build_host(np_ptr(xy) if n else None, n, C.byref(nn), np_ptr(nodes), np_ptr(leaf), np_ptr(box), C.byref(depth)))
+    return dict(nodes=nodes[:nn.value], leaf_idx=leaf[:n], root_box=box, depth=depth.value)
+
+
+class ProjectionMatcher:
+    def __init__(self, ctx: _lib.Context):
+        self.ctx = ctx
+        self._h = VP()
+        check(lib().uh_projmatch_create(ctx.handle, C.byref(self._h)))
+        self._keep = None
+
+    def setFrame(self, und_kpts, desc, scale_factors, fx, fy, cx, cy, min_xy=(0, 0), max_xy=(INT_MAX, INT_MAX)):
+        """und_kpts: KEYPOINT_DTYPE array (cv::KeyPoint layout); desc: [n,32] uint8."""
+        k = np.ascontiguousarray(und_kpts, KEYPOINT_DTYPE)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(len(k), 32) if len(k) else np.zeros((0, 32), np.uint8)
+        s = np.ascontiguousarray(scale_factors, np.float32)
+        f = _ProjFrame(np_ptr(k) if len(k) else None, len(k), np_ptr(d) if len(k) else None, np_ptr(s), len(s), fx, fy, cx, cy,
+                       int(min_xy[0]), int(min_xy[1]), int(max_xy[0]), int(max_xy[1]))
+        check(lib().uh_projmatch_set_frame(self._h, C.byref(f)))
+        self.n_kpts = len(k)
+
+    def matchFrameToMapPoints(self, pose_f2g, ids, pos3d, normal, min_dist, max_dist, mp_desc, minDescDist, maxRepjDist):
+        """Returns dict(matches DMATCH_DTYPE[k], best_kp int32[n], best_dist float32[n], visible uint8[n])."""
+        pose = np.ascontiguousarray(pose_f2g, np.float32).reshape(16)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        n = len(ids)
+        a = [np.ascontiguousarray(pos3d, np.float32).reshape(n, 3), np.ascontiguousarray(normal, np.float32).reshape(n, 3),
+             np.ascontiguousarray(min_dist, np.float32), np.ascontiguousarray(max_dist, np.float32),
+             np.ascontiguousarray(mp_desc, np.uint8).reshape(n, 32)]
+        mp = _MapPoints(n, np_ptr(ids) if n else None, *[np_ptr(x) if n else None for x in a])
+        out = np.zeros(max(n, 1), DMATCH_DTYPE)
+        best_kp = np.full(max(n, 1), -1, np.int32)
+        best_d = np.zeros(max(n, 1), np.float32)
+        vis = np.zeros(max(n, 1), np.uint8)
+        rc = lib().uh_projmatch_match(self._h, np_ptr(pose), C.byref(mp), float(minDescDist), float(maxRepjDist), np_ptr(out), len(out),
+                                      np_ptr(best_kp), np_ptr(best_d), np_ptr(vis))
+        if rc < 0:
+            check(rc)
+        return dict(matches=out[:rc].copy(), best_kp=best_kp[:n], best_dist=best_d[:n], visible=vis[:n])
+
+    def debug_tree(self):
+        nn, nodes, leaf, depth = C.c_int32(), VP(), VP(), C.c_int32()
+        box = np.zeros(4, np.float64)
+        check(lib().uh_projmatch_debug_tree(self._h, C.byref(nn), C.byref(nodes), C.byref(leaf), np_ptr(box), C.byref(depth)))
+        n = nn.value
+        nd = np.frombuffer((C.c_char * (24 * n)).from_address(nodes.value), KDNODE_DTYPE).copy() if n else np.zeros(0, KDNODE_DTYPE)
+        li = np.frombuffer((C.c_char * (4 * self.n_kpts)).from_address(leaf.value), np.uint32).copy() if self.n_kpts else np.zeros(0, np.uint32)
+        return dict(nodes=nd, leaf_idx=li, root_box=box, depth=depth.value)
+
+    def close(self):
+        if self._h:
+            lib().uh_projmatch_destroy(self._h)
+            self._h = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
