@@ -87,6 +87,21 @@ def test_hip_projmatch_matches_oracle(hip_ctx, oracle, cfg):
 
 
 @pytest.mark.gpu
+def test_hip_projmatch_big_frame_path(hip_ctx, oracle, monkeypatch):
+    """Frames too large for LDS walk the tree in HBM/L2 (forced here through the test knob)."""
+    from ucoslam_cv3_amd.projmatch import ProjectionMatcher
+
+    monkeypatch.setenv("UH_PROJMATCH_NO_LDS", "1")
+    fr, mp, pose = synth.proj_problem(2000, 3000, 8, low_entropy=True)
+    pm = ProjectionMatcher(hip_ctx)
+    pm.setFrame(fr["und_kpts"], fr["desc"], fr["scale_factors"], fr["fx"], fr["fy"], fr["cx"], fr["cy"], fr["min_xy"], fr["max_xy"])
+    got = pm.matchFrameToMapPoints(pose, mp["ids"], mp["pos3d"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], 8.0, 15.0)
+    ref = oracle_lib.proj_match(oracle, fr, mp, pose, 8.0, 15.0)
+    assert got["matches"].tobytes() == ref["matches"].tobytes() and len(ref["matches"]) > 100
+    np.testing.assert_array_equal(got["best_kp"], ref["best_kp"])
+
+
+@pytest.mark.gpu
 def test_hip_projmatch_edge_inputs(hip_ctx, oracle):
     import ucoslam_cv3_amd as u
     from ucoslam_cv3_amd.projmatch import ProjectionMatcher

@@ -25,7 +25,10 @@
 // Floating-point conventions are those of oracle/proj_oracle.cpp (float ops in source order, no contraction; cv::norm in
 // double; logf(x) := float(log(double(x)))).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -36,9 +39,13 @@ extern "C" int uh_filter_ambiguous(uh_dmatch* matches, int n, int by_train);
 namespace {
 
 constexpr int kLeafMax = 10;          // picoflann _maxLeafSize
-constexpr int kStackMax = 96;         // walk stack records: one per level on the path + the record being expanded
-constexpr int kMaxDepth = kStackMax - 4;
-constexpr int kPmThreads = 64;        // one wave per workgroup: divergent walks, many workgroups
+constexpr int kMaxDepth = 90;         // deeper trees (pathological inputs) are refused: the walk stacks live in LDS
+constexpr size_t kLdsBudget = 150 * 1024;   // of the CU's 160 KB
+constexpr int kPmThreads = 256;       // four waves share the LDS copy of the frame
+constexpr int kGroup = 16;            // lanes per map point (a leaf holds <= 10 keypoints)
+constexpr int kGroupsPerWave = kPmThreads / kGroup;   // groups (map points in flight) per workgroup
+constexpr int kPmMaxBlocks = 768;     // workgroups loop over chunks of 16 map points: the frame is staged once per workgroup
+constexpr int kCandCap = 128;         // per-point list of disc hits between two drains (a leaf adds at most 10)
 
 struct KdNodeDev {
     float divlow, divhigh;
@@ -192,45 +199,132 @@ struct PmPose { float T[12]; float cc[3]; };
 
 __device__ __forceinline__ float logf_cr(float x) { return (float)log((double)x); }
 
-struct WalkRec { int a; int kind; double m; };   // kind 0: visit node a (mindistsq m), 1: best child of node a done, 2: dists[a] = m
-
-__global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoints mp, PmPose ps, float minDescDist, float maxRepjDist, int* overflow) {
-    const int m = blockIdx.x * kPmThreads + threadIdx.x;
-    if (m >= mp.n) return;
-    int best_kp = -1;
-    float best_d = 3.402823466e+38f;
-    unsigned char vis = 0;
-    do {
-        const float P0 = mp.pos3d[3 * m], P1 = mp.pos3d[3 * m + 1], P2 = mp.pos3d[3 * m + 2];
-        // getViewCos
-        float v0 = ps.cc[0] - P0, v1 = ps.cc[1] - P1, v2 = ps.cc[2] - P2;
+// Walk records: rec = (a << 2) | kind with kind 1: best child of node a done (m = mindistsq on entry), 2: dists[a] = m; a
+// node to visit next is carried in registers (cur / cur_m), not pushed.  One record per tree level on the path.
+//
+// Work decomposition: kGroup = 16 lanes per map point, 4 points per wave, 4 waves per workgroup; a workgroup stages the frame
+// in LDS once and then loops over chunks of 16 map points.  The lanes of a group walk
+// the tree together (identical control flow); in a leaf each lane tests ONE of its <= 10 keypoints, the hits are appended in
+// leaf order (group ballot + prefix popcount) to the point's candidate list.  The list is drained by the 16 lanes in parallel
+// (descriptor fetch + Hamming), then scanned in order for the best / second-best rule.  Compared with one lane per point this
+// cuts the divergence (max over 4 instead of 64 walks per wave), parallelises the leaf and the L2 fetches, and fills 16x
+// more SIMDs.
+//
+// LDS layout of a workgroup: [nodes | kp_xy | leaf_idx | kp_octave(int8)] when the frame fits (IN_LDS), then per group the
+// walk stack (double m, int rec per level) and the candidate list ((keypoint << 4) | octave, then the Hamming distance).
+// A frame of 2000 keypoints is ~40 KB, of 4000 ~80 KB: every node / leaf / coordinate access of the walk is an LDS access;
+// only descriptors of disc hits come from L2.
+template <bool IN_LDS>
+__global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoints mp, PmPose ps, float minDescDist, float maxRepjDist,
+                                                               int n_nodes, int levels, int* overflow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x, g = lane / kGroup, gl = lane % kGroup, gw = (lane & 63) / kGroup;   // gw: group within its wave
+    const int n = f.n_kpts;
+    size_t off = 0;
+    KdNodeDev* s_nodes = reinterpret_cast<KdNodeDev*>(smem);
+    if (IN_LDS) off += ((size_t)n_nodes * sizeof(KdNodeDev) + 15) & ~(size_t)15;
+    float2* s_xy = reinterpret_cast<float2*>(smem + off);
+    if (IN_LDS) off += (size_t)n * 8;
+    unsigned int* s_leaf = reinterpret_cast<unsigned int*>(smem + off);
+    if (IN_LDS) off += (size_t)n * 4;
+    signed char* s_oct = reinterpret_cast<signed char*>(smem + off);
+    if (IN_LDS) off += ((size_t)n + 15) & ~(size_t)15;
+    double* st_m = reinterpret_cast<double*>(smem + off) + (size_t)g * levels;
+    off += (size_t)levels * kGroupsPerWave * 8;
+    int* st_rec = reinterpret_cast<int*>(smem + off) + (size_t)g * levels;
+    off += (size_t)levels * kGroupsPerWave * 4;
+    unsigned int* s_cand = reinterpret_cast<unsigned int*>(smem + off) + (size_t)g * kCandCap;
+    off += (size_t)kCandCap * kGroupsPerWave * 4;
+    int* s_hd = reinterpret_cast<int*>(smem + off) + (size_t)g * kCandCap;
+    if (IN_LDS) {
+        const unsigned int* gn = reinterpret_cast<const unsigned int*>(f.nodes);
+        unsigned int* sn = reinterpret_cast<unsigned int*>(s_nodes);
+        // eight independent loads in flight per lane and round (the plain loop is one L2 round trip per 64 words)
+        constexpr int U = 8;
+        for (int i0 = lane; i0 < n_nodes * 6; i0 += U * kPmThreads) {
+            unsigned int v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) { const int i = i0 + u * kPmThreads; v[u] = i < n_nodes * 6 ? gn[i] : 0u; }
+#pragma unroll
+            for (int u = 0; u < U; u++) { const int i = i0 + u * kPmThreads; if (i < n_nodes * 6) sn[i] = v[u]; }
+        }
+        for (int i0 = lane; i0 < n; i0 += U * kPmThreads) {
+            float2 a[U]; unsigned int b[U]; int c[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + u * kPmThreads, ic = i < n ? i : 0;
+                a[u] = f.kp_xy[ic]; b[u] = f.leaf_idx[ic]; c[u] = f.kp_octave[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + u * kPmThreads;
+                if (i < n) { s_xy[i] = a[u]; s_leaf[i] = b[u]; s_oct[i] = (signed char)c[u]; }
+            }
+        }
+        __syncthreads();
+    }
+  for (int chunk = blockIdx.x; chunk * kGroupsPerWave < mp.n; chunk += gridDim.x) {
+    const int m = chunk * kGroupsPerWave + g;
+    const bool live = m < mp.n;
+    const int mc = live ? m : 0;
+    // ---- visibility tests and search parameters (identical in the 16 lanes of the group)
+    bool vis = false;
+    float px = 0, py = 0;
+    int predicted = 0;
+    double worst = 0;
+    {
+        const float P0 = mp.pos3d[3 * mc], P1 = mp.pos3d[3 * mc + 1], P2 = mp.pos3d[3 * mc + 2];
+        float v0 = ps.cc[0] - P0, v1 = ps.cc[1] - P1, v2 = ps.cc[2] - P2;   // getViewCos
         const double s = 1. / sqrt((double)v0 * v0 + (double)v1 * v1 + (double)v2 * v2);
         v0 = (float)(v0 * s); v1 = (float)(v1 * s); v2 = (float)(v2 * s);
-        const float viewCos = v0 * mp.normal[3 * m] + v1 * mp.normal[3 * m + 1] + v2 * mp.normal[3 * m + 2];
-        if (viewCos < 0.5) break;
+        const float viewCos = v0 * mp.normal[3 * mc] + v1 * mp.normal[3 * mc + 1] + v2 * mp.normal[3 * mc + 2];
         const float* T = ps.T;
         const float x = T[0] * P0 + T[1] * P1 + T[2] * P2 + T[3];
         const float y = T[4] * P0 + T[5] * P1 + T[6] * P2 + T[7];
         const float z = T[8] * P0 + T[9] * P1 + T[10] * P2 + T[11];
-        if (z < 0) break;
         const float dist = (float)sqrt((double)x * x + (double)y * y + (double)z * z);
-        const float maxd = mp.max_dist[m];
-        if (!(0.8f * mp.min_dist[m] < dist && dist < 1.2f * maxd)) break;
+        const float maxd = mp.max_dist[mc];
         const float iz = (float)(1. / z);
-        const float px = x * f.fx * iz + f.cx, py = y * f.fy * iz + f.cy;
-        if (!(px > f.min_x && py > f.min_y && px < f.max_x && py < f.max_y)) break;
-        vis = 1;
-        int predicted;
-        {
+        px = x * f.fx * iz + f.cx; py = y * f.fy * iz + f.cy;
+        vis = live && !(viewCos < 0.5) && !(z < 0) && (0.8f * mp.min_dist[mc] < dist && dist < 1.2f * maxd) &&
+              (px > f.min_x && py > f.min_y && px < f.max_x && py < f.max_y);
+        if (vis) {
             const int ns = (int)ceilf(logf_cr(maxd / dist) / f.log_scale);
             predicted = ns < 0 ? 0 : (ns >= f.n_levels ? f.n_levels - 1 : ns);
+            float radius_scale = f.scale[predicted];
+            if (viewCos < 0.98) radius_scale = (float)(radius_scale * 1.6);
+            const double radius = (double)(radius_scale * maxRepjDist);
+            worst = radius * radius;
         }
-        float radius_scale = f.scale[predicted];
-        if (viewCos < 0.98) radius_scale = (float)(radius_scale * 1.6);
-        const double radius = (double)(radius_scale * maxRepjDist);
-        if (f.n_kpts == 0) break;
-        const double worst = radius * radius;
-        const uint64_t q0 = mp.desc[4 * (size_t)m], q1 = mp.desc[4 * (size_t)m + 1], q2 = mp.desc[4 * (size_t)m + 2], q3 = mp.desc[4 * (size_t)m + 3];
+    }
+    int best_kp = -1;
+    float best_d = 3.402823466e+38f, second_d = 3.402823466e+38f;
+    int bestLevel = 0, bestLevel2 = -1;
+    bool ovf = false;
+    const uint64_t* qd = mp.desc + 4 * (size_t)mc;
+    const uint64_t q0 = qd[0], q1 = qd[1], q2 = qd[2], q3 = qd[3];
+    int ncand = 0;
+    // drain: Hamming distances of the listed hits (16 lanes, one hit each per round), then the in-order best / second rule
+    auto drain = [&](int cnt) {
+        for (int k = gl; k < cnt; k += kGroup) {
+            const uint64_t* kd = f.kp_desc + 4 * (size_t)(s_cand[k] >> 4);
+            s_hd[k] = __popcll(q0 ^ kd[0]) + __popcll(q1 ^ kd[1]) + __popcll(q2 ^ kd[2]) + __popcll(q3 ^ kd[3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int k = 0; k < cnt; k++) {
+            const float hd = (float)s_hd[k];
+            const unsigned int e = s_cand[k];
+            const int oc = (int)(e & 15u);
+            const bool lt = hd < minDescDist;
+            const bool isbest = lt && hd < best_d, issecond = lt && !isbest && hd < second_d;
+            best_d = isbest ? hd : best_d; best_kp = isbest ? (int)(e >> 4) : best_kp; bestLevel = isbest ? oc : bestLevel;
+            second_d = issecond ? hd : second_d; bestLevel2 = issecond ? oc : bestLevel2;
+        }
+        __builtin_amdgcn_wave_barrier();   // the list is rewritten after this
+    };
+    if (vis && n > 0) {
         // computeInitialDistances (float accumulator)
         double dd0 = 0, dd1 = 0;
         float distsq = 0.f;
@@ -241,58 +335,71 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
             if (ey < f.box[2]) { const double d = ey - f.box[2]; dd1 = d * d; distsq += dd1; }
             if (ey > f.box[3]) { const double d = ey - f.box[3]; dd1 = d * d; distsq += dd1; }
         }
-        float second_d = 3.402823466e+38f;
-        int bestLevel = 0, bestLevel2 = -1;
-        WalkRec st[kStackMax];
         int sp = 0;
-        st[sp++] = WalkRec{0, 0, (double)distsq};
-        bool ovf = false;
-        while (sp > 0) {
-            const WalkRec r = st[--sp];
-            if (r.kind == 2) { if (r.a == 0) dd0 = r.m; else dd1 = r.m; continue; }
-            const KdNodeDev nd = f.nodes[r.a];
-            if (nd.left < 0) {   // leaf (only reached with kind 0)
-                for (int i = 0; i < nd.leaf_count; i++) {
-                    const unsigned int id = f.leaf_idx[nd.leaf_begin + i];
-                    const float2 c = f.kp_xy[id];
+        int cur = 0;                 // node to visit (-1: pop a record)
+        double cur_m = (double)distsq;
+        for (;;) {
+            int kind = 0, ra = cur;
+            double rm = cur_m;
+            if (cur < 0) {
+                if (sp == 0) break;
+                --sp;
+                const int rec = st_rec[sp];
+                rm = st_m[sp];
+                kind = rec & 3; ra = rec >> 2;
+                if (kind == 2) { if (ra == 0) dd0 = rm; else dd1 = rm; continue; }
+            }
+            KdNodeDev nd;
+            if (IN_LDS) nd = s_nodes[ra]; else nd = f.nodes[ra];
+            if (nd.left < 0) {   // leaf (kind 0): lane i of the group tests keypoint i; hits are appended in leaf order
+                bool hit = false;
+                unsigned int id = 0;
+                int oc = 0;
+                if (gl < nd.leaf_count) {
+                    id = IN_LDS ? s_leaf[nd.leaf_begin + gl] : f.leaf_idx[nd.leaf_begin + gl];
+                    const float2 c = IN_LDS ? s_xy[id] : f.kp_xy[id];
+                    oc = IN_LDS ? (int)s_oct[id] : f.kp_octave[id];
                     const double dx = px - c.x;
                     double sqd = dx * dx;
                     if (!(sqd > worst)) { const double dy = py - c.y; sqd += dy * dy; }
-                    if (!(sqd < worst)) continue;
-                    const int oc = f.kp_octave[id];
-                    if (!(oc >= predicted - 1 && oc <= predicted)) continue;
-                    const uint64_t* kd = f.kp_desc + 4 * (size_t)id;
-                    const float hd = (float)(__popcll(q0 ^ kd[0]) + __popcll(q1 ^ kd[1]) + __popcll(q2 ^ kd[2]) + __popcll(q3 ^ kd[3]));
-                    if (hd < minDescDist) {
-                        if (hd < best_d) { best_d = hd; best_kp = (int)id; bestLevel = oc; }
-                        else if (hd < second_d) { second_d = hd; bestLevel2 = oc; }
-                    }
+                    hit = sqd < worst && oc >= predicted - 1 && oc <= predicted;
                 }
+                const unsigned int gm = (unsigned int)((__ballot(hit) >> (gw * kGroup)) & ((1ull << kGroup) - 1ull));
+                if (hit) s_cand[ncand + __popc(gm & ((1u << gl) - 1u))] = (id << 4) | (unsigned int)oc;
+                ncand += __popc(gm);
+                if (ncand > kCandCap - kLeafMax) { drain(ncand); ncand = 0; }
+                cur = -1;
                 continue;
             }
             const double val = nd.col == 0 ? px : py;
             const double diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
             const bool go_left = diff1 + diff2 < 0;
             const double cut = go_left ? diff2 * diff2 : diff1 * diff1;
-            if (r.kind == 0) {
-                if (sp + 2 > kStackMax) { ovf = true; break; }
-                st[sp++] = WalkRec{r.a, 1, r.m};
-                st[sp++] = WalkRec{go_left ? nd.left : nd.right, 0, r.m};
+            if (sp + 1 > levels) { ovf = true; break; }
+            if (kind == 0) {
+                if (gl == 0) { st_rec[sp] = (ra << 2) | 1; st_m[sp] = rm; }
+                sp++;
+                cur = go_left ? nd.left : nd.right; cur_m = rm;
             } else {   // the best child's subtree is done: maybe the other one, then restore dists[col]
                 const float dst = (float)(nd.col == 0 ? dd0 : dd1);
-                const double m2 = r.m + cut - dst;
+                const double m2 = rm + cut - dst;
                 if (nd.col == 0) dd0 = cut; else dd1 = cut;
-                if (sp + 2 > kStackMax) { ovf = true; break; }
-                st[sp++] = WalkRec{nd.col, 2, (double)dst};
-                if (m2 * 1.0 <= worst) st[sp++] = WalkRec{go_left ? nd.right : nd.left, 0, m2};
+                if (gl == 0) { st_rec[sp] = ((int)nd.col << 2) | 2; st_m[sp] = (double)dst; }
+                sp++;
+                if (m2 * 1.0 <= worst) { cur = go_left ? nd.right : nd.left; cur_m = m2; }
+                else cur = -1;
             }
         }
-        if (ovf) { *overflow = 1; best_kp = -1; break; }
-        if (best_kp != -1 && bestLevel2 == bestLevel && best_d > 0.8 * second_d) best_kp = -1;
-    } while (false);
-    mp.best_kp[m] = best_kp;
-    mp.best_dist[m] = best_d;
-    if (mp.visible) mp.visible[m] = vis;
+    }
+    if (!ovf) drain(ncand);
+    if (ovf) { if (gl == 0) *overflow = 1; best_kp = -1; }
+    if (best_kp != -1 && bestLevel2 == bestLevel && best_d > 0.8 * second_d) best_kp = -1;
+    if (live && gl == 0) {
+        mp.best_kp[m] = best_kp;
+        mp.best_dist[m] = best_d;
+        if (mp.visible) mp.visible[m] = vis ? 1 : 0;
+    }
+  }
 }
 
 }  // namespace
@@ -304,8 +411,9 @@ struct uh_projmatch {
     PmFrame fr{};
     uh::DevBuf d_frame;    // kp_xy | kp_octave | kp_desc | nodes | leaf_idx | scale
     uh::DevBuf d_points;   // pos3d | normal | min | max | desc | best_kp | best_dist | visible | overflow
-    uh::PinBuf h_out;
+    uh::PinBuf h_in, h_out;
     KdBuilder kd;
+    bool attr_set = false;
 };
 
 extern "C" {
@@ -330,7 +438,9 @@ int uh_projmatch_set_frame(uh_projmatch* h, const uh_proj_frame* f) {
     std::vector<float> xy(2 * (size_t)std::max(n, 1));
     std::vector<int> oct(std::max(n, 1));
     for (int i = 0; i < n; i++) { xy[2 * i] = f->und_kpts[i].x; xy[2 * i + 1] = f->und_kpts[i].y; oct[i] = f->und_kpts[i].octave; }
+    const auto t0 = std::chrono::steady_clock::now();
     h->kd.build(xy.data(), n);
+    if (getenv("UH_PM_TIMING")) fprintf(stderr, "kd build: %.1f us (n=%d, depth %d, nodes %zu)\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), n, h->kd.max_depth, h->kd.nodes.size());
     UH_REQUIRE(h->kd.max_depth <= kMaxDepth, "uh_projmatch_set_frame: kd-tree depth %d exceeds the walk stack (%d levels)", h->kd.max_depth, kMaxDepth);
     const size_t nn = h->kd.nodes.size();
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -339,15 +449,21 @@ int uh_projmatch_set_frame(uh_projmatch* h, const uh_proj_frame* f) {
     int rc = h->d_frame.reserve(total + 256);
     if (rc) return rc;
     char* base = h->d_frame.as<char>();
-    if (n) {
-        UH_HIP_CHECK(hipMemcpyAsync(base + o_xy, xy.data(), 8 * (size_t)n, hipMemcpyHostToDevice, st));
-        UH_HIP_CHECK(hipMemcpyAsync(base + o_oct, oct.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
-        UH_HIP_CHECK(hipMemcpyAsync(base + o_desc, f->desc, 32 * (size_t)n, hipMemcpyHostToDevice, st));
-        UH_HIP_CHECK(hipMemcpyAsync(base + o_nodes, h->kd.nodes.data(), sizeof(KdNodeDev) * nn, hipMemcpyHostToDevice, st));
-        UH_HIP_CHECK(hipMemcpyAsync(base + o_leaf, h->kd.leaf_idx.data(), 4 * (size_t)n, hipMemcpyHostToDevice, st));
+    {   // one pinned staging block, one H2D copy
+        if ((rc = h->h_in.reserve(total))) return rc;
+        char* hi = static_cast<char*>(h->h_in.p);
+        if (n) {
+            std::memcpy(hi + o_xy, xy.data(), 8 * (size_t)n);
+            std::memcpy(hi + o_oct, oct.data(), 4 * (size_t)n);
+            std::memcpy(hi + o_desc, f->desc, 32 * (size_t)n);
+            std::memcpy(hi + o_nodes, h->kd.nodes.data(), sizeof(KdNodeDev) * nn);
+            std::memcpy(hi + o_leaf, h->kd.leaf_idx.data(), 4 * (size_t)n);
+        }
+        std::memcpy(hi + o_scale, f->scale_factors, 4 * (size_t)f->n_levels);
+        UH_HIP_CHECK(hipMemcpyAsync(base, hi, total, hipMemcpyHostToDevice, st));
+        UH_HIP_CHECK(hipStreamSynchronize(st));   // the staging block is reused by match()
     }
-    UH_HIP_CHECK(hipMemcpyAsync(base + o_scale, f->scale_factors, 4 * (size_t)f->n_levels, hipMemcpyHostToDevice, st));
-    UH_HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors die here
+    if (getenv("UH_PM_TIMING")) fprintf(stderr, "set_frame total: %.1f us (bytes %zu)\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), total);
     PmFrame& d = h->fr;
     d.kp_xy = (const float2*)(base + o_xy); d.kp_octave = (const int*)(base + o_oct); d.kp_desc = (const uint64_t*)(base + o_desc);
     d.nodes = (const KdNodeDev*)(base + o_nodes); d.leaf_idx = (const unsigned int*)(base + o_leaf); d.scale = (const float*)(base + o_scale);
@@ -402,15 +518,20 @@ int uh_projmatch_match(uh_projmatch* h, const float* pose_f2g, const uh_map_poin
     const size_t o_ovf = al(o_vis + (size_t)n), total = o_ovf + 256;
     int rc = h->d_points.reserve(total);
     if (rc) return rc;
-    const size_t out_bytes = o_ovf + 4 - o_bk;
+    const size_t out_bytes = o_ovf + 64 - o_bk;
     if ((rc = h->h_out.reserve(out_bytes))) return rc;
     char* base = h->d_points.as<char>();
-    UH_HIP_CHECK(hipMemcpyAsync(base + o_pos, mp->pos3d, 12 * (size_t)n, hipMemcpyHostToDevice, st));
-    UH_HIP_CHECK(hipMemcpyAsync(base + o_nrm, mp->normal, 12 * (size_t)n, hipMemcpyHostToDevice, st));
-    UH_HIP_CHECK(hipMemcpyAsync(base + o_min, mp->min_dist, 4 * (size_t)n, hipMemcpyHostToDevice, st));
-    UH_HIP_CHECK(hipMemcpyAsync(base + o_max, mp->max_dist, 4 * (size_t)n, hipMemcpyHostToDevice, st));
-    UH_HIP_CHECK(hipMemcpyAsync(base + o_desc, mp->desc, 32 * (size_t)n, hipMemcpyHostToDevice, st));
-    UH_HIP_CHECK(hipMemsetAsync(base + o_ovf, 0, 4, st));
+    {   // one pinned staging block, one H2D copy (five pageable copies cost more than the kernel)
+        if ((rc = h->h_in.reserve(o_bk))) return rc;
+        char* hi = static_cast<char*>(h->h_in.p);
+        std::memcpy(hi + o_pos, mp->pos3d, 12 * (size_t)n);
+        std::memcpy(hi + o_nrm, mp->normal, 12 * (size_t)n);
+        std::memcpy(hi + o_min, mp->min_dist, 4 * (size_t)n);
+        std::memcpy(hi + o_max, mp->max_dist, 4 * (size_t)n);
+        std::memcpy(hi + o_desc, mp->desc, 32 * (size_t)n);
+        UH_HIP_CHECK(hipMemcpyAsync(base, hi, o_desc + 32 * (size_t)n, hipMemcpyHostToDevice, st));
+    }
+    UH_HIP_CHECK(hipMemsetAsync(base + o_ovf, 0, 64, st));
     PmPoints P;
     P.n = n;
     P.pos3d = (const float*)(base + o_pos); P.normal = (const float*)(base + o_nrm); P.min_dist = (const float*)(base + o_min);
@@ -426,7 +547,20 @@ int uh_projmatch_match(uh_projmatch* h, const float* pose_f2g, const uh_map_poin
         ps.cc[1] = m4 * 0.f + m5 * 0.f + m6 * 0.f + m7;
         ps.cc[2] = m8 * 0.f + m9 * 0.f + m10 * 0.f + m11;
     }
-    UH_LAUNCH(h->ctx, projmatch_kernel, dim3(uh_div_up(n, kPmThreads)), dim3(kPmThreads), 0, h->fr, P, ps, min_desc_dist, max_repj_dist, (int*)(base + o_ovf));
+    {
+        const int n_nodes = (int)h->kd.nodes.size(), levels = h->kd.max_depth + 2;
+        const size_t stack_bytes = (size_t)levels * kGroupsPerWave * 12 + (size_t)kCandCap * kGroupsPerWave * 8 + 64;
+        const size_t tree_bytes = (((size_t)n_nodes * sizeof(KdNodeDev) + 15) & ~(size_t)15) + 12 * (size_t)h->n_kpts + (((size_t)h->n_kpts + 15) & ~(size_t)15);
+        const bool in_lds = tree_bytes + stack_bytes <= kLdsBudget && !getenv("UH_PROJMATCH_NO_LDS");   // env: test knob for the big-frame path
+        const size_t lds = stack_bytes + (in_lds ? tree_bytes : 0);
+        if (!h->attr_set) {
+            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(projmatch_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(projmatch_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+            h->attr_set = true;
+        }
+        if (in_lds) UH_LAUNCH(h->ctx, projmatch_kernel<true>, dim3(std::min(uh_div_up(n, kGroupsPerWave), kPmMaxBlocks)), dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, (int*)(base + o_ovf));
+        else UH_LAUNCH(h->ctx, projmatch_kernel<false>, dim3(std::min(uh_div_up(n, kGroupsPerWave), kPmMaxBlocks)), dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, (int*)(base + o_ovf));
+    }
     UH_HIP_CHECK(hipGetLastError());
     char* ho = static_cast<char*>(h->h_out.p);
     UH_HIP_CHECK(hipMemcpyAsync(ho, base + o_bk, out_bytes, hipMemcpyDeviceToHost, st));
