@@ -213,6 +213,15 @@ def main():
         stage_ms["pnp_ms_per_solve_600_matches"] = timed(lambda: check(L.uh_pnp_solve_dev(
             pnp._h, dev_ptr(pd["pose"]), dev_ptr(pd["intr"]), 600, dev_ptr(pd["p3d"]), dev_ptr(pd["kp"]), dev_ptr(pd["invsig"]), dev_ptr(pd["weight"]),
             dev_ptr(pwork), dev_ptr(pout[0]), dev_ptr(pout[1]), dev_ptr(pout[2]), dev_ptr(pout[3]))), 20)
+        # also outside the metric's step: the projection matcher (Map::matchFrameToMapPoints), 2000 keypoints x 3000 candidate
+        # map points, host buffers in and out as the reference's call site has them (includes one H2D and one D2H)
+        from ucoslam_cv3_amd.projmatch import ProjectionMatcher
+
+        pfr, pmp, ppose = synth.proj_problem(2000, 3000, 0)
+        pmatch = ProjectionMatcher(ctx)
+        pmatch.setFrame(pfr["und_kpts"], pfr["desc"], pfr["scale_factors"], pfr["fx"], pfr["fy"], pfr["cx"], pfr["cy"], pfr["min_xy"], pfr["max_xy"])
+        stage_ms["projmatch_ms_per_call_2000kp_3000pts"] = timed(lambda: pmatch.matchFrameToMapPoints(
+            ppose, pmp["ids"], pmp["pos3d"], pmp["normal"], pmp["min_dist"], pmp["max_dist"], pmp["desc"], 100.0, 15.0), 20)
         if not args.no_roofline:
             for c in (ctx, ctx_ba):
                 c.prof_enable(True)

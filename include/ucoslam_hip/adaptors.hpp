@@ -203,4 +203,52 @@ class GlobalOptimizer {
     std::vector<std::pair<uint32_t, uint32_t>> bad_;
 };
 
+// ---- ucoslam::PnPSolver::solvePnp (optimization/pnpsolver.h:30-38) on flattened matches ----------------------------------
+class PnPSolver {
+   public:
+    explicit PnPSolver(std::shared_ptr<Context> ctx) : ctx_(std::move(ctx)) { check(uh_pnp_create(ctx_->get(), &p_)); }
+    ~PnPSolver() { uh_pnp_destroy(p_); }
+    // pose_io: row-major 4x4 float, refined in place; bad[i] = 1 marks an outlier match (the reference sets imgIdx = -1);
+    // returns the number of inliers like solvePnp (pnpsolver.cpp:116-409)
+    int solvePnp(float* pose_io, const float intr4[4], int n, const float* p3d, const float* kp, const float* inv_sigma, const float* weight,
+                 std::vector<uint8_t>& bad) {
+        bad.assign(n > 0 ? n : 1, 0);
+        float out[16];
+        int32_t iters[4];
+        const int rc = uh_pnp_solve(p_, pose_io, intr4, n, p3d, kp, inv_sigma, weight, out, bad.data(), iters, nullptr);
+        if (rc < 0) check(rc);
+        std::copy(out, out + 16, pose_io);
+        bad.resize(n);
+        return rc;
+    }
+   private:
+    std::shared_ptr<Context> ctx_;
+    uh_pnp* p_ = nullptr;
+};
+
+// ---- ucoslam::Map::matchFrameToMapPoints (map.cpp:651-770) on a flattened frame / candidate list -------------------------
+class ProjectionMatcher {
+   public:
+    explicit ProjectionMatcher(std::shared_ptr<Context> ctx) : ctx_(std::move(ctx)) { check(uh_projmatch_create(ctx_->get(), &h_)); }
+    ~ProjectionMatcher() { uh_projmatch_destroy(h_); }
+    // once per frame, where the reference calls Frame::create_kdtree (frame.h:124)
+    void setFrame(const uh_proj_frame& f) { check(uh_projmatch_set_frame(h_, &f)); }
+    // returns the reference's vector<cv::DMatch> (uh_dmatch has cv::DMatch's layout); visible (optional) gets the
+    // markMapPointsAsVisible flags for the caller to apply MapPoint::setVisible()
+    std::vector<uh_dmatch> matchFrameToMapPoints(const float pose_f2g[16], const uh_map_points& pts, float minDescDist, float maxRepjDist,
+                                                 std::vector<uint8_t>* visible = nullptr) {
+        std::vector<uh_dmatch> out(pts.n > 0 ? pts.n : 1);
+        if (visible) visible->assign(pts.n > 0 ? pts.n : 1, 0);
+        const int k = uh_projmatch_match(h_, pose_f2g, &pts, minDescDist, maxRepjDist, out.data(), (int32_t)out.size(), nullptr, nullptr,
+                                         visible ? visible->data() : nullptr);
+        if (k < 0) check(k);
+        out.resize(k);
+        if (visible) visible->resize(pts.n);
+        return out;
+    }
+   private:
+    std::shared_ptr<Context> ctx_;
+    uh_projmatch* h_ = nullptr;
+};
+
 }  // namespace ucoslam_hip

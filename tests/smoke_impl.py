@@ -49,3 +49,12 @@ def run():
     g = PnPSolver(ctx).solvePnp(pp["pose"], pp["intr"], pp["p3d"], pp["kp"], pp["invsig"], pp["weight"])
     r = oracle_lib.pnp_solve(L, pp)
     assert g["ngood"] == r["ngood"] and (g["bad"] == r["bad"]).all() and np.abs(g["state"] - r["state"]).max() < 1e-6, "PnP differs from the oracle"
+    # --- projection matcher: identical matches (kd-tree order dependent)
+    from ucoslam_cv3_amd.projmatch import ProjectionMatcher
+
+    fr, mp, pose = synth.proj_problem(400, 500, seed=6)
+    pm = ProjectionMatcher(ctx)
+    pm.setFrame(fr["und_kpts"], fr["desc"], fr["scale_factors"], fr["fx"], fr["fy"], fr["cx"], fr["cy"], fr["min_xy"], fr["max_xy"])
+    gm = pm.matchFrameToMapPoints(pose, mp["ids"], mp["pos3d"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], 100.0, 15.0)
+    rm = oracle_lib.proj_match(L, fr, mp, pose, 100.0, 15.0)
+    assert gm["matches"].tobytes() == rm["matches"].tobytes() and len(rm["matches"]) > 20, "projection matcher differs from the oracle"
