@@ -85,6 +85,25 @@ int uh_knn_search(uh_knn* idx, const uint8_t* queries, int nq, size_t q_stride, 
 int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn,
                       int32_t* d_indices, int32_t* d_distances, int sorted, int max_dist);
 
+/* Hierarchical k-means form of the index — xflann::Index::build(features, HKMeansParams(k, maxIters)) (index.cpp:52-57,
+ * impl/kmeansindexcreator.{h,cpp}) and search(..., KnnSearchParams(maxChecks, sorted)) through KMeansIndex::_knnsearch_nn
+ * (impl/kmeansindex.h:356-410): the APPROXIMATE index FrameMatcher_Flann builds per train frame (framematcher.cpp:213 k=32,
+ * maxIters=0; :239 nn=10, maxChecks=16, unsorted).  Results are bit-identical to the reference: same tree (std::shuffle of a
+ * default std::mt19937 picks the centres), same best-bin-first order, same ResultSet rows; unfilled slots index -1, distance 0.
+ * build: host pointer, contiguous n x 32 bytes; only maxIters == 0; 2 <= k <= 64.  More than k identical descriptors make the
+ * reference recurse without end: reported as UH_EINVAL.  uh_knn_kmeans_blob exposes the block data in the reference's own
+ * serialised layout (the bytes KMeansIndex::toStream writes after its 48-byte header).
+ * search: maxChecks as the reference (<= 0 returns empty rows, like the reference's loop condition); the pairs (nn=1,maxChecks=1)
+ * and (nn=2,maxChecks<=2) select other code in the reference and are refused. */
+int uh_knn_build_kmeans(uh_knn* idx, const uint8_t* features, int n, int k, int max_iters);
+int uh_knn_kmeans_blob(uh_knn* idx, const uint8_t** data, uint64_t* size);
+/* host-only build (test hook, no GPU): writes min(cap, size) bytes of the block data to out, the full size to *size */
+int uh_knn_kmeans_build_host(const uint8_t* features, int n, int k, uint8_t* out, uint64_t cap, uint64_t* size);
+int uh_knn_search_kmeans(uh_knn* idx, const uint8_t* queries, int nq, int nn, int max_checks, int sorted,
+                         int32_t* indices, int32_t* distances);
+int uh_knn_search_kmeans_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int max_checks, int sorted,
+                             int32_t* d_indices, int32_t* d_distances);
+
 /* Sharded search (multi-GPU): phase 1 emits, per query, the candidates the local
  * heap ACCEPTED while scanning this shard, in train-index order (a superset of what
  * the global heap accepts).  cand = nq x cap entries, each (dist<<32 | global index);

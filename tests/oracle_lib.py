@@ -214,3 +214,59 @@ def proj_match(L, fr, mp, pose, minDescDist, maxRepjDist):
     dm = np.zeros(k, dtype=np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")]))
     dm[:] = mout[:k].copy().view(dm.dtype).reshape(-1)
     return dict(best_kp=best_kp, best_dist=best_d, visible=vis, matches=dm)
+
+
+# ------------------------------------------------------------------------------------------------ hierarchical k-means (a14)
+def hkmeans_blob(L, train, k=32, max_iters=0):
+    import numpy as np
+
+    f = L.oracle_hkmeans_blob
+    f.restype = C.c_long
+    f.argtypes = [VP, I, I, I, VP, C.c_long]
+    n = f(P(train), len(train), k, max_iters, None, 0)
+    if n < 0:
+        return int(n)
+    out = np.zeros(n, np.uint8)
+    f(P(train), len(train), k, max_iters, P(out), n)
+    return out
+
+
+def hkmeans_search(L, blob, queries, nn, max_checks, sorted_=0):
+    import numpy as np
+
+    nq = len(queries)
+    idx = np.empty((nq, nn), np.int32)
+    dist = np.empty((nq, nn), np.int32)
+    f = L.oracle_hkmeans_search
+    f.restype = I
+    f.argtypes = [VP, VP, I, I, I, I, VP, VP]
+    rc = f(P(blob), P(queries), nq, nn, max_checks, int(sorted_), P(idx), P(dist))
+    assert rc == 0
+    return idx, dist
+
+
+def ref_hkmeans_stream(R, train, k=32, max_iters=0):
+    import numpy as np
+
+    f = R.xflann_ref_hkmeans_stream
+    f.restype = C.c_long
+    f.argtypes = [VP, I, I, I, VP, C.c_long]
+    n = f(P(train), len(train), k, max_iters, None, 0)
+    assert n > 0
+    out = np.zeros(n, np.uint8)
+    f(P(train), len(train), k, max_iters, P(out), n)
+    return out
+
+
+def ref_hkmeans_search(R, train, queries, nn, k, max_iters, max_checks, sorted_=0):
+    import numpy as np
+
+    nq = len(queries)
+    idx = np.empty((nq, nn), np.int32)
+    dist = np.empty((nq, nn), np.int32)
+    f = R.xflann_ref_hkmeans_search
+    f.restype = I
+    f.argtypes = [VP, I, VP, I, I, I, I, I, I, VP, VP]
+    rc = f(P(train), len(train), P(queries), nq, nn, k, max_iters, max_checks, int(sorted_), P(idx), P(dist))
+    assert rc == 0
+    return idx, dist

@@ -19,6 +19,11 @@
 // its accept test is looser than the global one; it emits everything it accepted (a superset of
 // the global accept set, in index order).  Replaying the concatenated shard lists through the
 // same push routine reproduces the global heap bit for bit.
+#include <algorithm>
+#include <cstring>
+#include <random>
+#include <vector>
+
 #include "common.hpp"
 
 namespace {
@@ -301,6 +306,106 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_replay_kernel(
     finish_row(h, k, sorted, indices, distances, qi);
 }
 
+// ------------------------------------------------------------------------------------------------ hierarchical k-means search
+// KMeansIndex::_knnsearch_nn (impl/kmeansindex.h:356-410) on the reference's own block data (see uh_knn_build_kmeans): best-bin-first
+// with a branch min-heap (impl/heap.h) and the same ResultSet as the linear index.  One wave per query:
+//   * a block's <= 64 children: one lane each computes its Hamming distance (32-byte features straight from the block);
+//   * internal block: the reference's sequential "running best, push everything else" loop is replayed with wave-uniform
+//     v_readlane reads; the branch heap (dist, offset) lives in LDS and its sifts are executed by the whole wave on broadcast
+//     addresses (the order of equal-distance branches is observable, so the heap is the reference's, swap for swap);
+//   * leaf block: feed_step() = the ResultSet pushes in child order.
+// Bound by the dependent LDS round trips of ~31 heap pushes per internal block, not by bandwidth.
+constexpr int kBranchMax = 5000;   // impl/heap.h: Heap<T, maxSize = 5000>; a push beyond it is dropped ("Heap max size reached")
+constexpr int kKmWaves = 2;        // waves (queries) per workgroup: 2 x 16 KB of branch heap
+
+struct BranchHeapLds {
+    int* d; unsigned int* o;   // [cap] each, per wave; cap = min(kBranchMax, worst case of this search), sized by the host
+    int size;
+    __device__ __forceinline__ void push(int dist, unsigned int off) {   // heap.h push + "down"
+        if (size >= kBranchMax) return;
+        int i = size;
+        while (i != 0) {
+            const int p = (i - 1) >> 1;
+            const int dp = d[p];
+            if (dist < dp) { d[i] = dp; o[i] = o[p]; i = p; } else break;
+        }
+        d[i] = dist; o[i] = off;
+        size++;
+    }
+    __device__ __forceinline__ unsigned int pop() {                      // heap.h pop + "up"
+        const unsigned int res = o[0];
+        size--;
+        const int md = d[size];
+        const unsigned int mo = o[size];
+        if (size > 1) {   // the old last element enters at the root and sinks
+            int i = 0;
+            for (;;) {
+                const int l = 2 * i + 1, r = l + 1;
+                if (l >= size) break;
+                int c = l;
+                int dc = d[l];
+                if (r < size) { const int dr = d[r]; if (!(dc < dr)) { c = r; dc = dr; } }   // left only if strictly smaller
+                if (dc < md) { d[i] = dc; o[i] = o[c]; i = c; } else break;
+            }
+            d[i] = md; o[i] = mo;
+        } else if (size == 1) { d[0] = md; o[0] = mo; }
+        return res;
+    }
+};
+
+__global__ __launch_bounds__(kWave* kKmWaves) void knn_kmeans_search_kernel(
+    const uint8_t* __restrict__ blob, const uint8_t* __restrict__ queries, int nq, int k, int max_checks, int sorted,
+    int32_t* __restrict__ indices, int32_t* __restrict__ distances, int cap) {
+    extern __shared__ int s_heap[];   // per wave: cap distances, cap offsets
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const int qi = blockIdx.x * kKmWaves + wv;
+    if (qi >= nq) return;
+    uint32_t q[8];
+    load_query(queries, qi, q);
+    WaveHeap h{0, -1, 0, lane};
+    BranchHeapLds bh{s_heap + (size_t)wv * 2 * cap, reinterpret_cast<unsigned int*>(s_heap + (size_t)wv * 2 * cap + cap), 0};
+    bh.push(0, 0u);
+    int nchecks = 0, ncand = 0;
+    while (nchecks < max_checks && bh.size != 0) {
+        unsigned int off = bh.pop();
+        int n;
+        for (;;) {
+            const uint8_t* blk = blob + off;
+            const unsigned int hdr = *reinterpret_cast<const unsigned int*>(blk);          // u16 n | u8 isLeaf | pad
+            const unsigned int hs = *reinterpret_cast<const unsigned int*>(blk + 4);
+            n = (int)(hdr & 0xffffu);
+            const bool leaf = ((hdr >> 16) & 0xffu) != 0;
+            const bool on = lane < n;
+            uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+            unsigned int info = 0;
+            if (on) {   // blocks are 8-byte aligned: read the feature 8 bytes at a time
+                const uint2* f2 = reinterpret_cast<const uint2*>(blk + hs + 32 * (size_t)lane);
+                const uint2 w0 = f2[0], w1 = f2[1], w2 = f2[2], w3 = f2[3];
+                a0 = make_uint4(w0.x, w0.y, w1.x, w1.y); a1 = make_uint4(w2.x, w2.y, w3.x, w3.y);
+                info = reinterpret_cast<const unsigned int*>(blk + 8 + 8 * (size_t)lane)[0];   // low word: child offset / row index
+            }
+            const int dl = hamming256(a0, a1, q);
+            if (leaf) {
+                uint64_t* none = nullptr;
+                feed_step<false>(h, dl, (int)info, on, k, -1, none, ncand, 0);
+                break;
+            }
+            int bestd = 0x7fffffff, besto = -1;
+            for (int c = 0; c < n; c++) {
+                const int dc = rl(dl, c);
+                const int oc = rl((int)info, c);
+                if (dc < bestd) {
+                    if (besto != -1) bh.push(bestd, (unsigned int)besto);
+                    bestd = dc; besto = oc;
+                } else bh.push(dc, (unsigned int)oc);
+            }
+            off = (unsigned int)besto;
+        }
+        nchecks += n;
+    }
+    finish_row(h, k, sorted, indices, distances, qi);
+}
+
 // Measurement aid (scripts/knn_push_bench.py): cycles of N always-accepted pushes on one wave, with and without the
 // surrounding feed_step loop, to separate the heap update from the scan/branch overhead around it.
 __global__ void knn_push_bench_kernel(int k, int n, long long* out) {
@@ -323,6 +428,102 @@ __global__ void knn_push_bench_kernel(int k, int n, long long* out) {
 
 }  // namespace
 
+
+// ------------------------------------------------------------------------------------------------ hierarchical k-means build (host)
+// xflann::Index::build(features, HKMeansParams(k, 0)) = KMeansIndexCreator::build + convert (impl/kmeansindexcreator.{h,cpp}),
+// producing the reference's own serialised block data (8-byte block header {u16 n, u8 isLeaf, u32 header_size}, n 8-byte node
+// infos {child block offset | 1<<63 + row index}, n 32-byte features; blocks laid out breadth first).  It is built on the
+// host like the reference does — per train frame, ~0.1 ms for 2000 rows: std::shuffle of a default std::mt19937 decides the
+// centres, so the libstdc++ call itself is the specification — and searched on the GPU.
+namespace {
+
+struct KmBuildNode {
+    std::vector<uint32_t> rows;      // rows assigned to this node (leaf: kept; internal: moved to the children)
+    const uint8_t* centre = nullptr; // feature shown in the parent's block
+    int first_child = -1, n_children = 0;
+};
+
+inline int host_hamming32(const uint8_t* a, const uint8_t* b) {
+    uint64_t x[4], y[4];
+    std::memcpy(x, a, 32);
+    std::memcpy(y, b, 32);
+    return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) + __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
+}
+
+// returns UH_OK, or UH_EINVAL with the error text set.  depth_out: levels of internal blocks above the deepest leaf block.
+int kmeans_build_blob(const uint8_t* rows, int n, int k, std::vector<uint8_t>& blob, int& depth_out) {
+    std::vector<KmBuildNode> nodes(1);
+    std::vector<int> depth(1, 0);
+    nodes[0].rows.resize(n);
+    for (int i = 0; i < n; i++) nodes[0].rows[i] = (uint32_t)i;
+    depth_out = 0;
+    // nodes are appended child by child while the vector is walked front to back: index order == the breadth-first order of
+    // KMeansIndexCreator::convert, whatever order the reference's recursion created them in
+    for (size_t cur = 0; cur < nodes.size(); cur++) {
+        if (cur != 0 && (int)nodes[cur].rows.size() <= k) continue;   // leaf (the root is always split)
+        std::vector<uint32_t> rowsv;
+        rowsv.swap(nodes[cur].rows);
+        std::mt19937 gen;
+        std::shuffle(rowsv.begin(), rowsv.end(), gen);
+        std::vector<uint32_t> centres;   // first k mutually distinct rows
+        for (size_t next = 0; next < rowsv.size() && (int)centres.size() < k; next++) {
+            bool dup = false;
+            for (uint32_t c : centres) if (host_hamming32(rows + 32 * (size_t)rowsv[next], rows + 32 * (size_t)c) == 0) { dup = true; break; }
+            if (!dup) centres.push_back(rowsv[next]);
+        }
+        const int first = (int)nodes.size();
+        for (uint32_t c : centres) { nodes.emplace_back(); nodes.back().centre = rows + 32 * (size_t)c; depth.push_back(depth[cur] + 1); }
+        for (uint32_t r : rowsv) {   // nearest centre, first minimum; an exact hit ends the scan
+            int best = 0, bestd = 0x7fffffff;
+            for (int c = 0; c < (int)centres.size(); c++) {
+                const int d = host_hamming32(nodes[first + c].centre, rows + 32 * (size_t)r);
+                if (d < bestd) { bestd = d; best = c; }
+                if (bestd == 0) break;
+            }
+            nodes[first + best].rows.push_back(r);
+        }
+        // every centre owns at least itself, so no cluster is empty when maxIters == 0 (the reference's erase of empty
+        // children, kmeansindexcreator.h:268-271, never fires)
+        if (centres.size() == 1 && (int)rowsv.size() > k) {
+            uh::set_error("uh_knn_build_kmeans: more than k=%d identical descriptors: the reference's tree construction does not terminate on this input", k);
+            return UH_EINVAL;
+        }
+        nodes[cur].first_child = first;
+        nodes[cur].n_children = (int)centres.size();
+        depth_out = std::max(depth_out, depth[cur] + 1);
+    }
+    auto pad8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
+    std::vector<uint64_t> off(nodes.size());
+    uint64_t total = 0;
+    for (size_t i = 0; i < nodes.size(); i++) {
+        const size_t cnt = nodes[i].n_children ? (size_t)nodes[i].n_children : nodes[i].rows.size();
+        off[i] = total;
+        total += pad8(8 + 8 * cnt) + 32 * cnt;
+    }
+    if (total >= (1ull << 31)) { uh::set_error("uh_knn_build_kmeans: index of %llu bytes exceeds the 31-bit block offsets of the reference's search", (unsigned long long)total); return UH_EINVAL; }
+    blob.assign(total, 0);
+    for (size_t i = 0; i < nodes.size(); i++) {
+        const KmBuildNode& nd = nodes[i];
+        const bool leaf = nd.n_children == 0;
+        const uint32_t cnt = leaf ? (uint32_t)nd.rows.size() : (uint32_t)nd.n_children;
+        uint8_t* blk = blob.data() + off[i];
+        const uint16_t n16 = (uint16_t)cnt;
+        const uint32_t hs = (uint32_t)pad8(8 + 8 * (size_t)cnt);
+        std::memcpy(blk, &n16, 2);
+        blk[2] = leaf ? 1 : 0;
+        std::memcpy(blk + 4, &hs, 4);
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint64_t info = leaf ? ((uint64_t)nd.rows[j] | 0x8000000000000000ull) : off[nd.first_child + j];
+            const uint8_t* feat = leaf ? rows + 32 * (size_t)nd.rows[j] : nodes[nd.first_child + j].centre;
+            std::memcpy(blk + 8 + 8 * (size_t)j, &info, 8);
+            std::memcpy(blk + hs + 32 * (size_t)j, feat, 32);
+        }
+    }
+    return UH_OK;
+}
+
+}  // namespace
+
 struct uh_knn {
     uh_ctx* ctx = nullptr;
     uh::DevBuf train_store;       // owned copy (build from host)
@@ -330,6 +531,11 @@ struct uh_knn {
     int nt = 0;
     int shard_begin = 0, shard_end = 0;
     uh::DevBuf q_buf, idx_buf, dist_buf;  // staging for the host-pointer API
+    // hierarchical k-means form of the same index (uh_knn_build_kmeans)
+    std::vector<uint8_t> km_blob;
+    uh::DevBuf km_dev;
+    int km_k = 0, km_n = 0, km_depth = 0;
+    bool km_attr = false;
 };
 
 extern "C" {
@@ -476,6 +682,94 @@ int uh_knn_replay_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
     UH_LAUNCH(idx->ctx,knn_replay_kernel, grid, block, 0, idx->d_train, sb, d_queries, nq, nn,
                        sorted ? 1 : 0, max_dist, d_cand_all, d_counts_all, cap, d_indices, d_distances);
     UH_HIP_CHECK(hipGetLastError());
+    return UH_OK;
+}
+
+// ---- hierarchical k-means index
+int uh_knn_build_kmeans(uh_knn* idx, const uint8_t* features, int n, int k, int max_iters) {
+    UH_REQUIRE(idx, "uh_knn_build_kmeans: NULL index");
+    idx->km_blob.clear();
+    idx->km_n = 0;
+    if (n <= 0) return UH_OK;   // index.cpp:49 — empty features leave the index unbuilt
+    UH_REQUIRE(features != nullptr, "uh_knn_build_kmeans: NULL features");
+    UH_REQUIRE(k >= 2 && k <= kWave, "uh_knn_build_kmeans: k=%d outside [2,%d] (one lane per child)", k, kWave);
+    UH_REQUIRE(max_iters == 0, "uh_knn_build_kmeans: only maxIters = 0 (what FrameMatcher_Flann passes, framematcher.cpp:213) is implemented, got %d", max_iters);
+    int rc = kmeans_build_blob(features, n, k, idx->km_blob, idx->km_depth);
+    if (rc) { idx->km_blob.clear(); return rc; }
+    UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
+    if ((rc = idx->km_dev.reserve(idx->km_blob.size() + 64))) return rc;
+    UH_HIP_CHECK(hipMemcpyAsync(idx->km_dev.p, idx->km_blob.data(), idx->km_blob.size(), hipMemcpyHostToDevice, idx->ctx->stream));
+    UH_HIP_CHECK(hipStreamSynchronize(idx->ctx->stream));
+    idx->km_k = k;
+    idx->km_n = n;
+    return UH_OK;
+}
+
+// host-only form of the build (no GPU needed): writes min(cap, size) bytes of the block data, returns the full size in *size
+int uh_knn_kmeans_build_host(const uint8_t* features, int n, int k, uint8_t* out, uint64_t cap, uint64_t* size) {
+    UH_REQUIRE(features && n > 0 && k >= 2 && k <= kWave && size, "uh_knn_kmeans_build_host: bad arguments");
+    std::vector<uint8_t> blob;
+    int depth = 0;
+    const int rc = kmeans_build_blob(features, n, k, blob, depth);
+    if (rc) return rc;
+    *size = blob.size();
+    if (out && cap) std::memcpy(out, blob.data(), (size_t)std::min<uint64_t>(cap, blob.size()));
+    return UH_OK;
+}
+
+int uh_knn_kmeans_blob(uh_knn* idx, const uint8_t** data, uint64_t* size) {
+    UH_REQUIRE(idx && data && size, "uh_knn_kmeans_blob: NULL argument");
+    *data = idx->km_blob.empty() ? nullptr : idx->km_blob.data();
+    *size = idx->km_blob.size();
+    return UH_OK;
+}
+
+int uh_knn_search_kmeans_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int max_checks, int sorted, int32_t* d_indices,
+                             int32_t* d_distances) {
+    UH_REQUIRE(idx, "uh_knn_search_kmeans: NULL index");
+    if (idx->km_n == 0) {
+        uh::set_error("uh_knn_search_kmeans: could not run search because index not created");   // index.cpp:82-85
+        return UH_ENOTBUILT;
+    }
+    UH_REQUIRE(nq >= 0, "uh_knn_search_kmeans: negative query count");
+    UH_REQUIRE(nn >= 1 && nn <= kWave, "uh_knn_search_kmeans: nn=%d outside [1,%d]", nn, kWave);
+    UH_REQUIRE(!(nn == 1 && max_checks == 1) && !(nn == 2 && max_checks <= 2),
+               "uh_knn_search_kmeans: (nn=%d, maxChecks=%d) selects the reference's greedy 1-/2-nn descents (kmeansindex.h:216-224), which are not implemented", nn, max_checks);
+    if (nq == 0) return UH_OK;
+    UH_REQUIRE(d_queries && d_indices && d_distances, "uh_knn_search_kmeans: NULL buffer");
+    // worst case of the branch heap: every pop adds >= 1 check, every descent pushes <= (k-1) entries per level; beyond the
+    // reference's capacity its pushes are dropped, and so are ours
+    const long long worst = (long long)std::max(max_checks, 0) * std::max(idx->km_depth, 1) * (idx->km_k - 1) + 2;
+    const int cap = (int)std::min<long long>(worst, kBranchMax);
+    const size_t lds = (size_t)kKmWaves * 2 * cap * sizeof(int);
+    UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
+    if (!idx->km_attr) {
+        UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kmeans_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kKmWaves * 2 * kBranchMax * 4));
+        idx->km_attr = true;
+    }
+    UH_LAUNCH(idx->ctx, knn_kmeans_search_kernel, dim3(uh_div_up(nq, kKmWaves)), dim3(kWave * kKmWaves), lds, idx->km_dev.as<uint8_t>(), d_queries, nq,
+              nn, max_checks, sorted ? 1 : 0, d_indices, d_distances, cap);
+    UH_HIP_CHECK(hipGetLastError());
+    return UH_OK;
+}
+
+int uh_knn_search_kmeans(uh_knn* idx, const uint8_t* queries, int nq, int nn, int max_checks, int sorted, int32_t* indices, int32_t* distances) {
+    UH_REQUIRE(idx, "uh_knn_search_kmeans: NULL index");
+    if (nq > 0) UH_REQUIRE(queries && indices && distances, "uh_knn_search_kmeans: NULL buffer");
+    int rc;
+    hipStream_t st = idx->ctx->stream;
+    if (nq > 0) {
+        UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
+        if ((rc = idx->q_buf.reserve((size_t)nq * 32))) return rc;
+        if ((rc = idx->idx_buf.reserve((size_t)nq * std::max(nn, 1) * 4))) return rc;
+        if ((rc = idx->dist_buf.reserve((size_t)nq * std::max(nn, 1) * 4))) return rc;
+        UH_HIP_CHECK(hipMemcpyAsync(idx->q_buf.p, queries, (size_t)nq * 32, hipMemcpyHostToDevice, st));
+    }
+    rc = uh_knn_search_kmeans_dev(idx, idx->q_buf.as<uint8_t>(), nq, nn, max_checks, sorted, idx->idx_buf.as<int32_t>(), idx->dist_buf.as<int32_t>());
+    if (rc || nq == 0) return rc;
+    UH_HIP_CHECK(hipMemcpyAsync(indices, idx->idx_buf.p, (size_t)nq * nn * 4, hipMemcpyDeviceToHost, st));
+    UH_HIP_CHECK(hipMemcpyAsync(distances, idx->dist_buf.p, (size_t)nq * nn * 4, hipMemcpyDeviceToHost, st));
+    UH_HIP_CHECK(hipStreamSynchronize(st));
     return UH_OK;
 }
 

@@ -73,6 +73,42 @@ class Index:
         check(lib().uh_knn_search(self._h, np_ptr(q), nq, stride, nn, np_ptr(idx), np_ptr(dist), int(sorted), max_dist))
         return idx, dist
 
+    # -- xflann::Index::build(features, HKMeansParams(k, maxIters)) / search(KnnSearchParams(maxChecks, sorted)) -------------
+    def build_kmeans(self, features, k: int = 32, maxIters: int = 0):
+        """The approximate index FrameMatcher_Flann uses (framematcher.cpp:213).  features: uint8 [n,32] on the host."""
+        a = np.ascontiguousarray(np.asarray(features), np.uint8)
+        if a.ndim != 2 or (a.shape[0] and a.shape[1] != 32):
+            raise _lib.UcoslamHipError(_lib.UH_EINVAL, "features must be uint8 [n,32]")
+        self._km_rows = a
+        check(lib().uh_knn_build_kmeans(self._h, np_ptr(a) if a.shape[0] else None, a.shape[0], k, maxIters))
+        return self
+
+    def kmeans_blob(self) -> np.ndarray:
+        data, size = VP(), C.c_uint64()
+        check(lib().uh_knn_kmeans_blob(self._h, C.byref(data), C.byref(size)))
+        if not size.value:
+            return np.zeros(0, np.uint8)
+        return np.frombuffer((C.c_char * size.value).from_address(data.value), np.uint8).copy()
+
+    def search_kmeans(self, queries, nn: int, maxChecks: int = 16, sorted: bool = False):
+        if _is_torch(queries):
+            import torch
+
+            q = queries.contiguous()
+            nq = q.shape[0]
+            idx = torch.empty((nq, nn), dtype=torch.int32, device=q.device)
+            dist = torch.empty((nq, nn), dtype=torch.int32, device=q.device)
+            check(lib().uh_knn_search_kmeans_dev(self._h, dev_ptr(q), nq, nn, maxChecks, int(sorted), dev_ptr(idx), dev_ptr(dist)))
+            return idx, dist
+        q = np.ascontiguousarray(np.asarray(queries), np.uint8)
+        if q.ndim != 2 or (q.shape[0] and q.shape[1] != 32):
+            raise _lib.UcoslamHipError(_lib.UH_EINVAL, "queries must be uint8 [nq,32]")
+        nq = q.shape[0]
+        idx = np.empty((nq, nn), np.int32)
+        dist = np.empty((nq, nn), np.int32)
+        check(lib().uh_knn_search_kmeans(self._h, np_ptr(q) if nq else None, nq, nn, maxChecks, int(sorted), np_ptr(idx), np_ptr(dist)))
+        return idx, dist
+
     # -- sharded path (multi-GPU row of the scope table) -------------------------------------------
     def scan_shard(self, queries, nn: int, cap: int, max_dist: int = -1):
         import torch
@@ -109,6 +145,16 @@ class Index:
             self.close()
         except Exception:
             pass
+
+
+def kmeans_build_host(features, k: int = 32) -> np.ndarray:
+    """Block data of HKMeansParams(k, 0) over `features` — the host-side build alone, no GPU."""
+    a = np.ascontiguousarray(np.asarray(features), np.uint8)
+    size = C.c_uint64()
+    check(lib().uh_knn_kmeans_build_host(np_ptr(a), a.shape[0], k, None, 0, C.byref(size)))
+    out = np.zeros(size.value, np.uint8)
+    check(lib().uh_knn_kmeans_build_host(np_ptr(a), a.shape[0], k, np_ptr(out), size.value, C.byref(size)))
+    return out
 
 
 def _is_torch(x) -> bool:
