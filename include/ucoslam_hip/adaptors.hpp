@@ -113,11 +113,31 @@ class Index {
         check(rc);
         return true;
     }
+    // build(features, HKMeansParams(k, maxIters)) — the index FrameMatcher_Flann uses (framematcher.cpp:213); rows contiguous
+    void buildKMeans(const Matrix& features, int k = 32, int maxIters = 0) {
+        if (features.elem_size != 1 || features.cols != 32 || (features.rows > 1 && features.stride != 32))
+            throw std::runtime_error("Index::buildKMeans: features must be contiguous XFLANN_8U rows of 32 bytes");
+        check(uh_knn_build_kmeans(k_, static_cast<const uint8_t*>(features.data), features.rows, k, maxIters));
+        kmeans_ = features.rows > 0;
+    }
+    // search(features, nn, indices, distances, KnnSearchParams(maxChecks, sorted)) on the k-means form
+    bool searchKMeans(const Matrix& q, int nn, Matrix indices, Matrix distances, int maxChecks = 1, bool sorted = false) {
+        if (q.rows != indices.rows || distances.rows != q.rows)
+            throw std::runtime_error("KMeanIndex::knnsearch indices and distances must be already allocated with the same size as the number of features");
+        if (distances.cols != nn || indices.cols != nn) throw std::runtime_error("KMeanIndex::knnsearch indices and distances number of cols must == nn");
+        if (q.rows > 1 && q.stride != 32) throw std::runtime_error("Index::searchKMeans: query rows must be contiguous");
+        const int rc = uh_knn_search_kmeans(k_, static_cast<const uint8_t*>(q.data), q.rows, nn, maxChecks, sorted, static_cast<int32_t*>(indices.data),
+                                            static_cast<int32_t*>(distances.data));
+        if (rc == UH_ENOTBUILT) return false;   // index.cpp:82-85
+        check(rc);
+        return true;
+    }
     int size() const { return uh_knn_size(k_); }
     uh_knn* handle() const { return k_; }
    private:
     std::shared_ptr<Context> ctx_;
     uh_knn* k_ = nullptr;
+    bool kmeans_ = false;
 };
 
 // ------------------------------------------------------------------------------------------------ bag of words

@@ -67,20 +67,25 @@ def test_filter_known_answers():
 
 
 @pytest.mark.gpu
-def test_hip_frame_matcher_end_to_end(hip_ctx, oracle):
-    """kNN on the GPU (unsorted heap rows) + filter == oracle kNN + independent filter, with the ASSIGNED/UNASSIGNED modes."""
+@pytest.mark.parametrize("exact", [False, True], ids=["hkmeans32_maxchecks16", "exact_scan"])
+def test_hip_frame_matcher_end_to_end(hip_ctx, oracle, exact):
+    """Index search on the GPU (unsorted heap rows) + filter == oracle search + independent filter, with the ASSIGNED/UNASSIGNED
+    modes.  Default = the reference's own index (HKMeansParams(32,0), maxChecks=16); exact=True = brute-force scan."""
     from ucoslam_cv3_amd import matcher as M
 
     rng = np.random.default_rng(5)
     train, q = synth.match_set(400, 1500, seed=9)
     tf, qf = _frame(1500, rng, train), _frame(400, rng, q)
-    fm = M.FrameMatcher(hip_ctx)
+    fm = M.FrameMatcher(hip_ctx, exact=exact)
     for tmode, qmode in [(M.MODE_ALL, M.MODE_ALL), (M.MODE_ASSIGNED, M.MODE_ALL), (M.MODE_ALL, M.MODE_UNASSIGNED)]:
         fm.setParams(tf, tmode, 100.0, 0.6, True, 3)
         got = fm.match(qf, qmode)
         map_t, tdesc = M.manage_mode(tmode, tf)
         map_q, qdesc = M.manage_mode(qmode, qf)
-        idx, dist = oracle_lib.knn_search(oracle, tdesc, qdesc, 10, 0)
+        if exact:
+            idx, dist = oracle_lib.knn_search(oracle, tdesc, qdesc, 10, 0)
+        else:
+            idx, dist = oracle_lib.hkmeans_search(oracle, oracle_lib.hkmeans_blob(oracle, tdesc, 32, 0), qdesc, 10, 16, 0)
         ref = pyo.match_filter(idx, dist, qf, tf, map_q, map_t, 100.0, 0.6, True, 3)
         assert _as_tuples(got) == [(m["queryIdx"], m["trainIdx"], m["distance"]) for m in ref]
         assert len(got) > 10

@@ -3,8 +3,9 @@
 Reference: src/utils/framematcher.h:33-60, framematcher.cpp:140-319.  `setParams(trainFrame, mode, minDescDist,
 nn_match_ratio, checkOrientation, maxOctaveDiff)` builds the index over the selected train descriptors, `match(queryFrame,
 mode)` / `matchEpipolar(queryFrame, mode, F12)` search nn=10 neighbours (unsorted rows) and run the reference's filter chain.
-Difference, stated in DESIGN.md: the reference index is xflann HKMeans(32,0) with maxChecks=16 (approximate); this one is the
-exact brute-force scan, i.e. the candidate set the approximate search tries to recover.
+The index is the reference's: xflann HKMeans(32,0) searched with maxChecks=16 (approximate, framematcher.cpp:121-122,213,239),
+reproduced bit for bit (uh_knn_build_kmeans / uh_knn_search_kmeans).  `exact=True` swaps in the brute-force scan, i.e. the
+candidate set the approximate search tries to recover (a superset in quality, not the reference's rows).
 
 A frame is a dict with: desc [N,32] uint8, ids [N] uint32 (0xFFFFFFFF = unassigned), nonmaxima [N] bool (FLAG_NONMAXIMA),
 octave [N] int32, angle [N] float32, pt [N,2] float32 (und_kpts), scaleFactors [levels] float32.
@@ -76,18 +77,25 @@ def match_filter(indices, distances, query, train, map_q=None, map_t=None, min_d
 
 
 class FrameMatcher:
-    NN = 10   # framematcher.h: nn=10 nearest neighbours per query
+    NN = 10           # framematcher.cpp:122: nn=10 nearest neighbours per query
+    MAX_SEARCH = 16   # framematcher.cpp:121: maxChecks of the approximate search
 
-    def __init__(self, ctx: _lib.Context):
+    def __init__(self, ctx: _lib.Context, exact: bool = False):
         self.ctx = ctx
         self.index = Index(ctx)
+        self.exact = exact
         self._train = None
+        self._built = 0
 
     def setParams(self, trainFrame, mode=MODE_ALL, minDescDist=np.inf, nn_match_ratio=0.8, checkOrientation=True, maxOctaveDiff=1):
         self._p = dict(min_desc_dist=minDescDist, nn_match_ratio=nn_match_ratio, check_orientation=checkOrientation,
                        max_octave_diff=maxOctaveDiff)
         self._map_t, desc = manage_mode(mode, trainFrame)
-        self.index.build(desc)                      # reference: trainIndex.build(desc, HKMeansParams(32,0))
+        if self.exact:
+            self.index.build(desc)
+        else:
+            self.index.build_kmeans(desc, 32, 0)    # trainIndex.build(desc, xflann::HKMeansParams(32,0))
+        self._built = len(desc)
         self._train = trainFrame
 
     def match(self, queryFrame, mode=MODE_ALL):
@@ -95,7 +103,10 @@ class FrameMatcher:
 
     def matchEpipolar(self, queryFrame, mode=MODE_ALL, F12=None):
         map_q, qdesc = manage_mode(mode, queryFrame)
-        if self.index.size() == 0 or len(qdesc) == 0:
+        if self._built == 0 or len(qdesc) == 0:
             return np.zeros(0, DMATCH_DTYPE)        # search() returns false on an unbuilt index -> {} (framematcher.cpp:239-240)
-        idx, dist = self.index.search(qdesc, self.NN, sorted=False)
+        if self.exact:
+            idx, dist = self.index.search(qdesc, self.NN, sorted=False)
+        else:
+            idx, dist = self.index.search_kmeans(qdesc, self.NN, self.MAX_SEARCH, sorted=False)
         return match_filter(idx, dist, queryFrame, self._train, map_q, self._map_t, F12=F12, **self._p)
