@@ -43,7 +43,7 @@ def test_oracle_recovers_pose_and_outliers(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [(600, 0), (150, 1), (2000, 2), (40, 3), (12, 4), (9, 5), (3000, 6)], ids=lambda c: f"n{c[0]}")
+@pytest.mark.parametrize("cfg", [(600, 0), (150, 1), (2000, 2), (40, 3), (12, 4), (9, 5), (3000, 6), (3001, 7), (5000, 8)], ids=lambda c: f"n{c[0]}")
 def test_hip_pnp_matches_oracle(hip_ctx, oracle, cfg):
     from ucoslam_cv3_amd.pnp import PnPSolver
 

@@ -68,7 +68,11 @@ __device__ void p_oplus(PoseD& T, const double* d) {   // T <- exp(d) * T
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
     double a, b, c1, c2;
     if (theta < 0.00001) { a = 1; b = 0.5; c1 = 0.5; c2 = 1.0 / 6.0; }
-    else { a = sin(theta) / theta; b = (1 - cos(theta)) / (theta * theta); c1 = b; c2 = (theta - sin(theta)) / pow(theta, 3.0); }
+    else {
+        double sn, cs;
+        sincos(theta, &sn, &cs);
+        a = sn / theta; b = (1 - cs) / (theta * theta); c1 = b; c2 = (theta - sn) / (theta * theta * theta);
+    }
     double Rm[9], V[9];
     for (int i = 0; i < 9; i++) { const double I = (i % 4 == 0) ? 1.0 : 0.0; Rm[i] = I + a * O[i] + b * O2[i]; V[i] = I + c1 * O[i] + c2 * O2[i]; }
     double qe[4], te[3], RE[9];
@@ -102,7 +106,14 @@ __device__ bool p_solve6(const double* H, const double* b, double lam, double* x
     return true;
 }
 
+// CACHED: the per-match inputs (map point, keypoint, 1/sigma, weight), chi2 and the three flag bytes live in LDS for the
+// whole solve (44 bytes per match, n <= kPnpLdsMatches): the ~40 passes over the matches then cost LDS latency instead
+// of an L2 round trip each.  Larger n runs the same code on the HBM arrays.
+constexpr int kPnpLdsMatches = 3000;
+
+template <bool CACHED>
 __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_cache[];
     __shared__ double s_part[4 * 28], s_sum[28], s_red[kRedThreads];
     __shared__ PoseD s_T, s_T0, s_bak;
     __shared__ double s_H[36], s_b[6], s_x[6];
@@ -112,10 +123,27 @@ __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
     const int tid = threadIdx.x, n = A.n;
     const double fx = A.intr[0], fy = A.intr[1], cx = A.intr[2], cy = A.intr[3];
     const double delta = (double)sqrtf(5.99f), dsqr = delta * delta;
-    unsigned char* active = A.flags;
-    unsigned char* robust = A.flags + n;
-    unsigned char* bad = A.flags + 2 * (size_t)n;
-    for (int e = tid; e < n; e += kRedThreads) { active[e] = 1; robust[e] = 1; bad[e] = 0; A.e_chi2[e] = 0; }
+    // one set of names for both instantiations; in each the pointers have a single provenance (LDS or HBM), so the
+    // compiler emits ds_* or global_* accesses, never flat ones
+    double* e_chi2; const float* p3d; const float* kpt; const float* invsig; const float* weight;
+    unsigned char* active; unsigned char* robust; unsigned char* bad;
+    if constexpr (CACHED) {
+        e_chi2 = reinterpret_cast<double*>(s_cache);
+        float* c_p3d = reinterpret_cast<float*>(s_cache + 8 * (size_t)n);
+        float* c_kp = c_p3d + 3 * (size_t)n;
+        float* c_is = c_kp + 2 * (size_t)n;
+        float* c_w = c_is + n;
+        active = reinterpret_cast<unsigned char*>(c_w + n);
+        robust = active + n; bad = robust + n;
+        for (int i = tid; i < 3 * n; i += kRedThreads) c_p3d[i] = A.p3d[i];
+        for (int i = tid; i < 2 * n; i += kRedThreads) c_kp[i] = A.kp[i];
+        for (int i = tid; i < n; i += kRedThreads) { c_is[i] = A.invsig[i]; c_w[i] = A.weight[i]; }
+        p3d = c_p3d; kpt = c_kp; invsig = c_is; weight = c_w;
+    } else {
+        e_chi2 = A.e_chi2; p3d = A.p3d; kpt = A.kp; invsig = A.invsig; weight = A.weight;
+        active = A.flags; robust = A.flags + n; bad = A.flags + 2 * (size_t)n;
+    }
+    for (int e = tid; e < n; e += kRedThreads) { active[e] = 1; robust[e] = 1; bad[e] = 0; e_chi2[e] = 0; }
     if (tid == 0) {
         const float* M = A.pose_in;
         const double R0[9] = {M[0], M[1], M[2], M[4], M[5], M[6], M[8], M[9], M[10]};
@@ -129,16 +157,16 @@ __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
     __syncthreads();
 
     auto edge_err = [&](int e, const double* Rt, double& ex, double& ey, double* pc) {
-        const double X0 = A.p3d[3 * e], X1 = A.p3d[3 * e + 1], X2 = A.p3d[3 * e + 2];
+        const double X0 = p3d[3 * e], X1 = p3d[3 * e + 1], X2 = p3d[3 * e + 2];
         pc[0] = Rt[0] * X0 + Rt[1] * X1 + Rt[2] * X2 + Rt[9];
         pc[1] = Rt[3] * X0 + Rt[4] * X1 + Rt[5] * X2 + Rt[10];
         pc[2] = Rt[6] * X0 + Rt[7] * X1 + Rt[8] * X2 + Rt[11];
-        ex = (double)A.kp[2 * e] - ((pc[0] / pc[2]) * fx + cx);
-        ey = (double)A.kp[2 * e + 1] - ((pc[1] / pc[2]) * fy + cy);
+        ex = (double)kpt[2 * e] - ((pc[0] / pc[2]) * fx + cx);
+        ey = (double)kpt[2 * e + 1] - ((pc[1] / pc[2]) * fy + cy);
     };
     auto robchi = [&](int e, double c) -> double {
         if (!robust[e]) return c;
-        const double w = A.weight[e];
+        const double w = weight[e];
         return (c <= dsqr) ? w * c : w * (2 * sqrt(c) * delta - dsqr);
     };
 
@@ -160,9 +188,9 @@ __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
                     if (!active[e]) continue;
                     double ex, ey, pc[3];
                     edge_err(e, Rt, ex, ey, pc);
-                    const double w = A.invsig[e];
+                    const double w = invsig[e];
                     const double c = w * (ex * ex + ey * ey);
-                    A.e_chi2[e] = c;
+                    e_chi2[e] = c;
                     acc[27] += robchi(e, c);
                     const double X = pc[0], Y = pc[1], invz = 1.0 / pc[2], invz2 = invz * invz;
                     const double J[12] = {X * Y * invz2 * fx, -(1 + (X * X * invz2)) * fx, Y * invz * fx, -invz * fx, 0, X * invz2 * fx,
@@ -207,8 +235,8 @@ __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
                         if (!active[e]) continue;
                         double ex, ey, pc[3];
                         edge_err(e, Rt, ex, ey, pc);
-                        const double c = (double)A.invsig[e] * (ex * ex + ey * ey);
-                        A.e_chi2[e] = c;
+                        const double c = (double)invsig[e] * (ex * ex + ey * ey);
+                        e_chi2[e] = c;
                         part += robchi(e, c);
                     }
                 }
@@ -222,7 +250,8 @@ __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
                     r /= scale;
                     bool lam_finite = true;
                     if (r > 0 && isfinite(tempChi)) {
-                        double alpha = 1. - pow((2 * r - 1), 3.0);
+                        const double t3 = 2 * r - 1;
+                        double alpha = 1. - t3 * t3 * t3;
                         alpha = fmin(alpha, 2. / 3.);
                         s_lambda *= fmax(1. / 3., alpha);
                         s_ni = 2;
@@ -259,12 +288,12 @@ __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
 #pragma unroll
             for (int i = 0; i < 12; i++) Rt[i] = s_T.Rt[i];
             for (int e = tid; e < n; e += kRedThreads) {
-                double c = A.e_chi2[e];
+                double c = e_chi2[e];
                 if (bad[e]) {
                     double ex, ey, pc[3];
                     edge_err(e, Rt, ex, ey, pc);
-                    c = (double)A.invsig[e] * (ex * ex + ey * ey);
-                    A.e_chi2[e] = c;
+                    c = (double)invsig[e] * (ex * ex + ey * ey);
+                    e_chi2[e] = c;
                 }
                 const bool b = c > (double)5.99f;
                 bad[e] = b; active[e] = !b;
@@ -295,6 +324,7 @@ __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
 struct uh_pnp {
     uh_ctx* ctx = nullptr;
     uh::DevBuf d_in, d_work, d_out;
+    bool attr_set = false;
 };
 
 extern "C" {
@@ -321,7 +351,16 @@ int uh_pnp_solve_dev(uh_pnp* p, const float* d_pose_f2g, const float* d_intr4, i
     A.e_chi2 = reinterpret_cast<double*>(d_work);
     A.flags = reinterpret_cast<unsigned char*>(d_work) + (size_t)n * 8;
     A.pose_out = d_pose_out; A.bad_out = d_bad_out; A.result = d_result5; A.state_out = d_state7;
-    UH_LAUNCH(p->ctx, pnp_solve_kernel, dim3(1), dim3(kRedThreads), 0, A);
+    if (n <= kPnpLdsMatches) {
+        const size_t lds = (size_t)n * 44 + 16;
+        if (!p->attr_set) {
+            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pnp_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kPnpLdsMatches * 44 + 16));
+            p->attr_set = true;
+        }
+        UH_LAUNCH(p->ctx, pnp_solve_kernel<true>, dim3(1), dim3(kRedThreads), lds, A);
+    } else {
+        UH_LAUNCH(p->ctx, pnp_solve_kernel<false>, dim3(1), dim3(kRedThreads), 0, A);
+    }
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
 }
