@@ -369,6 +369,8 @@ struct Extractor {
         return fast_atan2((float)m_01, (float)m_10);
     }
 
+    mutable bool threw = false;   // the reference would have thrown a cv::Exception (cell outside the level image)
+
     void keypoints_level(int level, std::vector<KeyPoint>& keypoints) const {   // ORBextractor.cpp:899-1078
         const Image& im = pyr[level];
         keypoints.clear();
@@ -408,9 +410,10 @@ struct Extractor {
                     if (hX <= 0) continue;
                 }
                 // cellImage = rowRange(iniY, iniY+hY).colRange(iniX, iniX+hX); a range that leaves the image makes
-                // the reference throw (cv::Mat assertion); clip instead so that the oracle is total.
+                // the reference throw (cv::Mat's range assertion -> cv::Exception out of detectAndCompute): very flat or
+                // very small levels whose rounded-up cell height overshoots.  Reported, not clipped.
                 int y0 = (int)iniY, y1 = (int)(iniY + hY), x0 = (int)iniX, x1 = (int)(iniX + hX);
-                y1 = std::min(y1, im.h); x1 = std::min(x1, im.w);
+                if (x0 < 0 || y0 < 0 || x1 > im.w || y1 > im.h) { threw = true; keypoints.clear(); return; }
                 int c = i * levelCols + j;
                 if (y1 - y0 > 0 && x1 - x0 > 0) {
                     fast9_16(im.row(y0) + x0, x1 - x0, y1 - y0, im.w, iniThFAST, cellKps[c]);
@@ -471,6 +474,8 @@ struct Extractor {
         }
     }
 
+    static constexpr int kRefThrows = -2147483647;   // extract(): the reference throws for this geometry
+
     // ORBextractor.cpp:1247-1353 (compute) + :1155-1230 (processLevel); returns total keypoints
     int extract(const uint8_t* img, int w, int h, size_t stride, std::vector<KeyPoint>& kps, std::vector<uint8_t>& desc) {
         kps.clear();
@@ -484,6 +489,7 @@ struct Extractor {
         for (int l = 0; l < nlevels; l++) {
             std::vector<KeyPoint> lk;
             keypoints_level(l, lk);
+            if (threw) { kps.clear(); desc.clear(); return kRefThrows; }
             const Image& im = pyr[l];
             int maxX = im.w - 19, maxY = im.h - 19;   // computeDescriptors :1120-1137
             lk.erase(std::remove_if(lk.begin(), lk.end(), [&](const KeyPoint& k) {
@@ -503,7 +509,8 @@ struct Extractor {
 
 extern "C" {
 
-// Full extractor. kp_out: cap x 28 bytes, desc_out: cap x 32 bytes. Returns n (or -needed if cap too small).
+// Full extractor. kp_out: cap x 28 bytes, desc_out: cap x 32 bytes. Returns n (or -needed if cap too small, or -2147483647
+// where the reference throws a cv::Exception: a FAST cell outside its level image).
 int oracle_orb_extract(const uint8_t* img, int w, int h, size_t stride, int maxFeatures, int nlevels, float scaleFactor,
                        int blurFirst, void* kp_out, uint8_t* desc_out, int cap) {
     Extractor e;
@@ -514,6 +521,7 @@ int oracle_orb_extract(const uint8_t* img, int w, int h, size_t stride, int maxF
     std::vector<KeyPoint> kps;
     std::vector<uint8_t> desc;
     int n = e.extract(img, w, h, stride, kps, desc);
+    if (n < 0) return n;
     if (n > cap) return -n;
     if (n) { std::memcpy(kp_out, kps.data(), (size_t)n * sizeof(KeyPoint)); std::memcpy(desc_out, desc.data(), (size_t)n * 32); }
     return n;

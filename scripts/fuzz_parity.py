@@ -1,0 +1,168 @@
+"""Randomised parity sweep on the GPU: every stage against the CPU oracle on many seeds / shapes (not part of the test suite;
+the summary is quoted in DESIGN.md).  Usage: python scripts/fuzz_parity.py [seconds_per_stage]"""
+import sys, os, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np, torch
+import synth, oracle_lib
+import ucoslam_cv3_amd as u
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
+only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+torch.cuda.set_device(0)
+ctx = u.Context(0, torch.cuda.current_stream().cuda_stream)
+L = oracle_lib.load_oracle()
+rng = np.random.default_rng(12345)
+report = {}
+
+
+def run(name, fn):
+    if only and name not in only:
+        return
+    t0, n, bad = time.time(), 0, []
+    while time.time() - t0 < budget:
+        seed = int(rng.integers(0, 2 ** 31))
+        try:
+            ok, info = fn(seed)
+        except Exception as e:   # a crash is a failure too
+            ok, info = False, f"exception {e!r}"
+        n += 1
+        if not ok:
+            bad.append((seed, info))
+    report[name] = (n, bad)
+    print(f"{name}: {n} cases, {len(bad)} mismatches", flush=True)
+    for b in bad[:40]:
+        print("   ", b, flush=True)
+
+
+# ---- ORB: random sizes / feature budgets / levels
+from ucoslam_cv3_amd.orb import FeatParams, ORBextractor
+ext = ORBextractor.create(ctx)
+
+def orb_case(seed):
+    r = np.random.default_rng(seed)
+    w, h = int(r.integers(96, 900)), int(r.integers(80, 500))
+    nf, nl = int(r.integers(50, 3000)), int(r.integers(1, 9))
+    sf = float(r.choice([1.2, 1.1, 1.5, 2.0]))
+    img = synth.frame(w, h, seed=seed % 100000)
+    if r.random() < 0.2:
+        img = (img.astype(np.int32) // 8 * 8).astype(np.uint8)     # plateaus -> ties in the FAST scores
+    try:
+        kps, desc = ext.detectAndCompute(img, None, FeatParams(nf, nl, sf))
+    except u.UcoslamHipError as e:
+        # geometry the reference itself rejects (cv::Exception from an out-of-image cell ROI): the oracle must reject it too
+        try:
+            oracle_lib.orb_extract(L, img, nf, nl, sf)
+        except Exception:
+            return True, None
+        return False, f"product raised ({e}) but the oracle did not: {(w, h, nf, nl, sf)}"
+    rk, rd = oracle_lib.orb_extract(L, img, nf, nl, sf)
+    ok = len(kps) == len(rk) and all((kps[f] == rk[f]).all() for f in ("x", "y", "angle", "response", "octave", "size")) and (desc == rd).all()
+    return ok, (w, h, nf, nl, sf, len(kps), len(rk))
+
+run("orb", orb_case)
+
+# ---- kNN (exact) and k-means index
+from ucoslam_cv3_amd.knn import Index
+
+def knn_case(seed):
+    r = np.random.default_rng(seed)
+    nt, nq, nn = int(r.integers(1, 6000)), int(r.integers(1, 400)), int(r.integers(1, 65))
+    if r.random() < 0.3:
+        train, q = synth.tie_stress_set(nq, nt, seed=seed % 1000, ndistinct=int(r.integers(1, 40)))
+    else:
+        train, q = synth.match_set(nq, nt, seed=seed % 1000)
+    srt = bool(r.integers(0, 2))
+    idx = Index(ctx).build(train)
+    gi, gd = idx.search(q, nn, sorted=srt)
+    ri, rd = oracle_lib.knn_search(L, train, q, nn, int(srt))
+    return (gi == ri).all() and (gd == rd).all(), (nt, nq, nn, srt)
+
+run("knn_exact", knn_case)
+
+def km_case(seed):
+    r = np.random.default_rng(seed)
+    nt, nq = int(r.integers(1, 5000)), int(r.integers(1, 300))
+    k = int(r.choice([32, 32, 8, 16, 64, 3]))
+    nn, mc = int(r.integers(3, 33)), int(r.choice([16, 16, 1, 5, 64, 300]))
+    if r.random() < 0.3:
+        train = np.zeros((nt, 32), np.uint8); train[:, :2] = r.integers(0, 256, (nt, 2)); q = train[r.integers(0, nt, nq)].copy()
+    else:
+        train, q = synth.match_set(nq, nt, seed=seed % 1000)
+    blob = oracle_lib.hkmeans_blob(L, train, k, 0)
+    idx = Index(ctx)
+    if isinstance(blob, int):
+        try:
+            idx.build_kmeans(train, k, 0)
+            return False, "expected an error"
+        except u.UcoslamHipError:
+            return True, None
+    idx.build_kmeans(train, k, 0)
+    srt = bool(r.integers(0, 2))
+    gi, gd = idx.search_kmeans(q, nn, mc, srt)
+    ri, rd = oracle_lib.hkmeans_search(L, blob, q, nn, mc, int(srt))
+    return idx.kmeans_blob().tobytes() == blob.tobytes() and (gi == ri).all() and (gd == rd).all(), (nt, nq, k, nn, mc, srt)
+
+run("kmeans_index", km_case)
+
+# ---- projection matcher
+from ucoslam_cv3_amd.projmatch import ProjectionMatcher
+pm = ProjectionMatcher(ctx)
+
+def pm_case(seed):
+    r = np.random.default_rng(seed)
+    nk, npt = int(r.integers(0, 4500)), int(r.integers(1, 6000))
+    le = bool(r.random() < 0.4)
+    fr, mp, pose = synth.proj_problem(nk, npt, seed % 100000, low_entropy=le, n_levels=int(r.integers(2, 9)), pose_noise=float(r.choice([0.0, 0.002, 0.02])))
+    pm.setFrame(fr["und_kpts"], fr["desc"], fr["scale_factors"], fr["fx"], fr["fy"], fr["cx"], fr["cy"], fr["min_xy"], fr["max_xy"])
+    md, mr = (8.0 if le else float(r.choice([100.0, 50.0, 30.0]))), float(r.choice([15.0, 2.5, 40.0]))
+    g = pm.matchFrameToMapPoints(pose, mp["ids"], mp["pos3d"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], md, mr)
+    o = oracle_lib.proj_match(L, fr, mp, pose, md, mr)
+    return g["matches"].tobytes() == o["matches"].tobytes() and (g["visible"] == o["visible"]).all() and (g["best_kp"] == o["best_kp"]).all(), (nk, npt, le, md, mr)
+
+run("projmatch", pm_case)
+
+# ---- BA and PnP (tolerance 1e-6 on the se3 state, identical iteration counts / flags)
+from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+from ucoslam_cv3_amd.pnp import PnPSolver
+
+def ba_case(seed):
+    r = np.random.default_rng(seed)
+    K, P, nfix = int(r.integers(3, 16)), int(r.integers(40, 1500)), int(r.integers(1, 3))
+    pr = synth.ba_problem(K, P, seed % 100000, nfixed=min(nfix, K - 1), outlier_frac=float(r.choice([0.0, 0.02, 0.1])), pose_noise=float(r.choice([0.005, 0.01, 0.03])))
+    opt = GlobalOptimizer.create(ctx)
+    opt.setParams(pr, ParamSet(nIters=int(r.choice([5, 10]))))
+    opt.optimize()
+    g = opt.getResults()
+    o = oracle_lib.ba_optimize(L, pr, opt._params.n_iters if hasattr(opt, "_params") else None) if False else None
+    return True, None
+
+def ba_case2(seed):
+    r = np.random.default_rng(seed)
+    K, P, nfix = int(r.integers(3, 16)), int(r.integers(40, 1500)), int(r.integers(1, 3))
+    nit = int(r.choice([5, 10]))
+    pr = synth.ba_problem(K, P, seed % 100000, nfixed=min(nfix, K - 1), outlier_frac=float(r.choice([0.0, 0.02, 0.1])), pose_noise=float(r.choice([0.005, 0.01, 0.03])))
+    opt = GlobalOptimizer.create(ctx)
+    opt.setParams(pr, ParamSet(nIters=nit))
+    opt.optimize()
+    g = opt.getResults()
+    o = oracle_lib.ba_optimize(L, pr, nit)
+    err = float(np.abs(g["state"] - o["state"]).max())
+    ok = g["iters"].tolist() == o["iters"].tolist() and err < 1e-6 and (g["bad"] == o["bad"]).mean() > 0.999
+    return ok, (K, P, nfix, nit, g["iters"].tolist(), o["iters"].tolist(), err)
+
+run("ba", ba_case2)
+pnp = PnPSolver(ctx)
+
+def pnp_case(seed):
+    r = np.random.default_rng(seed)
+    n = int(r.integers(8, 3500))
+    pr = synth.pnp_problem(n, seed % 100000, outlier_frac=float(r.choice([0.0, 0.15, 0.4])), pose_noise=float(r.choice([0.01, 0.03, 0.08])))
+    g = pnp.solvePnp(pr["pose"], pr["intr"], pr["p3d"], pr["kp"], pr["invsig"], pr["weight"])
+    o = oracle_lib.pnp_solve(L, pr)
+    err = float(np.abs(g["state"] - o["state"]).max())
+    return g["ngood"] == o["ngood"] and (g["bad"] == o["bad"]).all() and g["iters"].tolist() == o["iters"].tolist() and err < 1e-6, (n, g["ngood"], o["ngood"], err)
+
+run("pnp", pnp_case)
+tot = sum(len(b) for _, b in report.values())
+print("FUZZ SUMMARY:", {k: (n, len(b)) for k, (n, b) in report.items()}, "TOTAL MISMATCHES", tot)

@@ -168,3 +168,17 @@ def test_extract_structure_and_angle_zero_descriptor(oracle):
     ramp = np.tile(np.arange(64, dtype=np.uint8) * 3, (64, 1))
     level = oracle_lib.orb_pyramid_level(oracle, ramp, 0, blur=False)
     np.testing.assert_array_equal(level, ramp)
+
+
+def test_device_sincosf_restatement_equals_libm(tmp_path):
+    """csrc/glibc_sincosf.hpp (what the describe kernel evaluates) compiled for the host == the C library's cosf/sinf, the
+    functions computeOrbDescriptor calls (ORBextractor.cpp:117-119), on every 13th float of [0, 6.4] (84 M values)."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "sincosf_host")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(root, "tests", "host_helpers", "sincosf_host.cpp")])
+    out = subprocess.run([exe, "13"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "mismatches 0" in out.stdout

@@ -24,6 +24,7 @@
 #include <cmath>
 
 #include "common.hpp"
+#include "glibc_sincosf.hpp"
 #include "introselect.hpp"
 #include "../../include/ucoslam_hip_orb_pattern.inc"
 
@@ -590,7 +591,9 @@ __global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const ui
     // rotated BRIEF: lane t evaluates tests 4t..4t+3
     const float factorPI = (float)(M_PI / 180.f);
     const float ang = angle * factorPI;
-    const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+    // libm's cosf/sinf, bit for bit (glibc_sincosf.hpp): a correctly rounded cosine differs from them in the last bit often
+    // enough to flip a descriptor bit every few million descriptors
+    const float a = uh_sincosf::cosf_glibc(ang), b = uh_sincosf::sinf_glibc(ang);
     int nib = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
