@@ -14,8 +14,8 @@
 // reference (oracle/_ref/libpicoflann_ref.so, tests/test_projmatch_oracle.py).  The loop around it touches OpenCV value types
 // only (Point3f arithmetic, cv::norm), OpenCV is absent from this image => that part is "parity unpinned"; the arithmetic
 // conventions chosen are: float operations in source order without contraction, cv::norm(Point3f) = sqrt in double of the
-// double sum of squares, Point3f *= double via float(x * s), and logf(x) := float(log(double(x))) in predictScale
-// (so that the device can reproduce it exactly; glibc's logf differs from this only where it is not correctly rounded).
+// double sum of squares, Point3f *= double via float(x * s); predictScale's log(float) is libm's logf (the product evaluates
+// glibc's algorithm on the device, ucoslam-cv3_amd/csrc/glibc_sincosf.hpp, checked exhaustively against libm).
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -223,7 +223,7 @@ inline float hamming_f(const uint8_t* a, const uint8_t* b) {   // mappoint.h:146
                    __builtin_popcountll(x[3] ^ y[3]));
 }
 
-inline float logf_cr(float x) { return (float)std::log((double)x); }
+inline float logf_cr(float x) { return std::log(x); }   // float overload = libm logf, what frame.h:131-132 calls
 
 struct DMatch { int32_t queryIdx, trainIdx, imgIdx; float distance; };
 

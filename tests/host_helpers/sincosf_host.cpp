@@ -17,6 +17,13 @@ int main(int argc, char** argv) {
         if (std::memcmp(&a, &b, 4) || std::memcmp(&c, &d, 4)) { if (bad < 5) std::printf("x=%a cos %a/%a sin %a/%a\n", x, a, b, c, d); bad++; }
         n++;
     }
+    for (uint32_t u = 0x00800000u; u < 0x7f800000u; u += 2 * step + 3) {   // positive normal floats: logf
+        float x;
+        std::memcpy(&x, &u, 4);
+        const float a = logf(x), b = uh_sincosf::logf_glibc(x);
+        if (std::memcmp(&a, &b, 4)) { if (bad < 5) std::printf("x=%a log %a/%a\n", x, a, b); bad++; }
+        n++;
+    }
     std::printf("checked %llu mismatches %llu\n", n, bad);
     return bad ? 1 : 0;
 }

@@ -85,4 +85,50 @@ UH_SC_HD float sinf_glibc(float y) {
     return poly(x * p.sign[n & 3], x * x, p, n);
 }
 
+// logf with the results of glibc >= 2.28 (sysdeps/ieee754/flt-32/e_logf.c + e_logf_data.c): Frame::predictScale
+// (src/map_types/frame.h:129-136) takes ceil(log(maxDist/dist) / log(scaleFactor)) with float arguments, i.e. libm's logf.
+// Table lookup on the top 4 mantissa bits (16 centres c: invc ~ 1/c, logc ~ log c), r = z*invc - 1, degree-3 polynomial
+// in double.  Positive normal arguments only (distances and ratios of distances); checked exhaustively against libm on all
+// 2 130 706 432 positive normal floats, with and without FMA contraction: no difference.
+UH_SC_HD float logf_glibc(float x) {
+    const double T[16][2] = {
+        {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2}, {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},
+        {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3}, {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+        {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4}, {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5},
+        {0x1p+0, 0x0p+0}, {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5}, {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+        {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3}, {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3}, {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},
+        {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+    const double Ln2 = 0x1.62e42fefa39efp-1;
+    const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
+    uint32_t ix;
+#if defined(__HIP_DEVICE_COMPILE__)
+    ix = __float_as_uint(x);
+#else
+    std::memcpy(&ix, &x, 4);
+#endif
+    if (ix == 0x3f800000u) return 0.f;
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) % 16u);
+    const int k = (int32_t)tmp >> 23;
+    const uint32_t iz = ix - (tmp & 0xff800000u);
+    float zf;
+#if defined(__HIP_DEVICE_COMPILE__)
+    zf = __uint_as_float(iz);
+#else
+    std::memcpy(&zf, &iz, 4);
+#endif
+    // the 16-entry table is indexed dynamically: select instead of a private array (which would live in scratch on the GPU)
+    double invc = T[0][0], logc = T[0][1];
+#pragma unroll
+    for (int t = 1; t < 16; t++) { invc = i == t ? T[t][0] : invc; logc = i == t ? T[t][1] : logc; }
+    const double z = zf;
+    const double r = z * invc - 1;
+    const double y0 = logc + (double)k * Ln2;
+    const double r2 = r * r;
+    double y = A1 * r + A2;
+    y = A0 * r2 + y;
+    y = y * r2 + (y0 + r);
+    return (float)y;
+}
+
 }  // namespace uh_sincosf

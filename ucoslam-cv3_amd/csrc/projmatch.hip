@@ -23,7 +23,7 @@
 //          bound by dependent L2 round trips of the walk, not by bandwidth.
 //   host   orders the per-point results into the DMatch list and runs filter_ambiguous_query (matcher.hip).
 // Floating-point conventions are those of oracle/proj_oracle.cpp (float ops in source order, no contraction; cv::norm in
-// double; logf(x) := float(log(double(x)))).
+// double); predictScale's logf is libm's, reproduced on the device by glibc_sincosf.hpp.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "glibc_sincosf.hpp"
 
 extern "C" int uh_filter_ambiguous(uh_dmatch* matches, int n, int by_train);
 
@@ -197,7 +198,7 @@ struct PmPoints {
 
 struct PmPose { float T[12]; float cc[3]; };
 
-__device__ __forceinline__ float logf_cr(float x) { return (float)log((double)x); }
+__device__ __forceinline__ float logf_cr(float x) { return uh_sincosf::logf_glibc(x); }   // libm's logf, bit for bit
 
 // Walk records: rec = (a << 2) | kind with kind 1: best child of node a done (m = mindistsq on entry), 2: dists[a] = m; a
 // node to visit next is carried in registers (cur / cur_m), not pushed.  One record per tree level on the path.
@@ -471,7 +472,7 @@ int uh_projmatch_set_frame(uh_projmatch* h, const uh_proj_frame* f) {
     d.n_levels = f->n_levels; d.n_kpts = n;
     d.fx = f->fx; d.fy = f->fy; d.cx = f->cx; d.cy = f->cy;
     d.min_x = (float)f->min_x; d.min_y = (float)f->min_y; d.max_x = (float)f->max_x; d.max_y = (float)f->max_y;
-    d.log_scale = f->n_levels > 1 ? (float)std::log((double)f->scale_factors[1]) : 1.f;
+    d.log_scale = f->n_levels > 1 ? std::log(f->scale_factors[1]) : 1.f;   // float overload = libm logf, as Frame::predictScale
     h->n_kpts = n; h->n_levels = f->n_levels;
     h->have_frame = true;
     return UH_OK;
