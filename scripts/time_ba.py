@@ -31,6 +31,6 @@ L.uh_ba_debug_clocks(opt._h, clk.ctypes.data)
 us = lambda a, b: (clk[b] - clk[a]) / 100.0
 print(f"lin block0 {us(0,1):.2f} us | schur block0 {us(4,5):.2f} | solve: assemble {us(10,11):.2f} factor {us(11,12):.2f} subst {us(12,13):.2f} update {us(13,14):.2f} "
       f"| backsub block0 {us(20,21):.2f} | decide {us(24,25):.2f}")
-print(f"gaps: lin_end->schur {us(1,4):.2f} schur_block0_end->solve {us(5,10):.2f} solve_end->backsub {us(14,20):.2f} backsub_block0_end->decide {us(21,24):.2f} | step (schur start -> decide end) {us(4,25):.2f}")
+print(f"schur block0 end -> solve start (same step, next launch) {us(5,10):.2f} us")
 if clk[32 + 12] and clk[32 + 11]:
     print(f"shader clock during solve factor phase: {(clk[32+12]-clk[32+11]) / us(11,12):.0f} cycles/us")

@@ -57,6 +57,8 @@ struct BAState {
     int iters_done;
     int first_trial;  // first trial of the pass: the lin kernel linearises; afterwards the backsub kernel does it speculatively
     int stopped;      // force-stop flag observed
+    int pending;      // a trial has been computed whose accept/reject decision has not been applied to this state yet
+    int stop_seen;    // force-stop flag as sampled by the backsub kernel of the pending trial
     double lambda, ni, currentChi, lastChiRaw, rho;
     float prevChi2, curChi2, minChi2;
     int pad;
@@ -97,13 +99,13 @@ struct BAPtrs {
     double* part_lin_chi;     // nPointBlocks
     double* part_maxdiag;     // nPointBlocks + nfree
     double* part_chi; double* part_scale;   // nPointBlocks
-    BAState* st;
+    BAState* st;              // two slots: step s reads slot s&1 and leaves the state it ran with in the other one
     const volatile unsigned char* stop;     // pinned host flag (may be NULL)
     long long* clk;           // 64 phase timestamps (100 MHz s_memrealtime) of the latest step, read by uh_ba_debug_clocks
 };
 
 #define UH_BA_CLK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) p.clk[i] = wall_clock64(); } while (0)
-#define UH_BA_CLKL(i) do { if (threadIdx.x == 0) { p.clk[i] = wall_clock64(); p.clk[32 + i] = clock64(); } } while (0)   // single-workgroup kernels
+#define UH_BA_CLKL(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { p.clk[i] = wall_clock64(); p.clk[32 + i] = clock64(); } } while (0)   // single-workgroup kernels
 
 // ------------------------------------------------------------------------------------------------ small fp64 helpers
 __device__ __forceinline__ void quat_to_R(const double* q, double* R) {
@@ -292,9 +294,9 @@ __device__ __forceinline__ void camera_block(const BAPtrs& p, const BADims& d, i
 
 // ------------------------------------------------------------------------------------------------ lin
 // grid = nPointBlocks + nfree*kCamChunks.  Launched once per pass (first trial); later linearisations come from backsub.
-__global__ __launch_bounds__(kThreads) void ba_lin_kernel(BAPtrs p, BADims d) {
+__global__ __launch_bounds__(kThreads) void ba_lin_kernel(BAPtrs p, BADims d, int slot) {
     __shared__ double s_red[kThreads];
-    const BAState st = *p.st;
+    const BAState st = p.st[slot];
     if (st.phase == 2 || !st.first_trial) return;
     UH_BA_CLK(0);
     const int cur = st.cur;
@@ -317,11 +319,103 @@ __global__ __launch_bounds__(kThreads) void ba_lin_kernel(BAPtrs p, BADims d) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ decide
+// One wave: the tail of OptimizationAlgorithmLevenberg::solve's do-while body plus SparseOptimizer::optimize's loop header.
+__device__ __forceinline__ double wave_sum_fixed(double v) {   // xor butterfly: fixed order, identical in all lanes
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+struct DecideSums { double lin, chi, scale, xs; };
+
+// The four sums a decision needs, gathered by ONE wave (all 64 lanes call this): each lane pre-adds its strided share in a
+// fixed order, the 64 lane sums are added by a fixed butterfly -> identical in every lane and in every workgroup that runs it.
+// All loads are issued before the first use so that the caller pays one memory latency.
+__device__ __forceinline__ DecideSums decide_sums(const BAPtrs& p, const BADims& d, int lane, double lambda0) {
+    const int nb = d.nPointBlocks;
+    double l0 = 0, l1 = 0, l2 = 0;
+    for (int i = lane; i < nb; i += 64) { l0 += p.part_lin_chi[i]; l1 += p.part_chi[i]; l2 += p.part_scale[i]; }
+    double xv[6 * kMaxFree / 64], bv[6 * kMaxFree / 64];
+#pragma unroll
+    for (int k = 0; k < 6 * kMaxFree / 64; k++) {
+        const int i = lane + 64 * k;
+        xv[k] = i < d.n ? p.xp[i] : 0.0;
+        bv[k] = i < d.n ? p.bp[i] : 0.0;
+    }
+    double xs = 0;
+#pragma unroll
+    for (int k = 0; k < 6 * kMaxFree / 64; k++) xs += xv[k] * (lambda0 * xv[k] + bv[k]);
+    DecideSums r;
+    r.lin = wave_sum_fixed(l0); r.chi = wave_sum_fixed(l1); r.scale = wave_sum_fixed(l2); r.xs = wave_sum_fixed(xs);
+    return r;
+}
+
+// The tail of OptimizationAlgorithmLevenberg::solve's do-while body plus SparseOptimizer::optimize's loop header, as a pure
+// function of the state the trial started from and the trial's sums.
+__device__ __forceinline__ BAState apply_decision(const BAState& st0, const DecideSums& sm, bool stop_flag) {
+    const double sum_lin = sm.lin, sum_chi = sm.chi, sum_scale = sm.scale, sum_xs = sm.xs;
+    BAState st = st0;
+    if (st.first_trial) st.currentChi = sum_lin;   // activeRobustChi2 at the pass's initial estimate (lin kernel); later the accepted tempChi
+    double tempChi = sum_chi, scale = sum_scale;
+    st.lastChiRaw = tempChi;
+    if (st.solve_ok) scale += sum_xs;
+    if (!st.solve_ok) tempChi = DBL_MAX;
+    double rho = st.currentChi - tempChi;
+    scale += 1e-3;
+    rho /= scale;
+    bool lambda_finite = true;
+    if (rho > 0 && isfinite(tempChi)) {
+        const double t3 = 2 * rho - 1;
+        double alpha = 1. - t3 * t3 * t3;
+        alpha = fmin(alpha, 2. / 3.);
+        const double sf = fmax(1. / 3., alpha);
+        st.lambda *= sf;
+        st.ni = 2;
+        st.currentChi = tempChi;
+        st.cur ^= 1;   // discardTop: the trial buffers (estimate AND its linearisation, see backsub) become the current ones
+    } else {
+        st.lambda *= st.ni;
+        st.ni *= 2;    // pop: the current buffers stay
+        if (!isfinite(st.lambda)) lambda_finite = false;
+    }
+    st.rho = rho;
+    const bool stop = stop_flag;
+    if (stop) st.stopped = 1;
+    bool again = false;
+    if (lambda_finite) {
+        st.qmax++;
+        again = (rho < 0 && st.qmax < 10 && !stop);
+    }
+    if (again) {
+        st.phase = 1;
+    } else {
+        const bool terminate = (st.qmax == 10 || rho == 0 || !lambda_finite);
+        const bool ok = !terminate;
+        // SparseOptimizer::optimize: curChi2 = activeRobustChi2() of the LAST computed errors; Chi2Diff = prev - cur (float)
+        st.curChi2 = (float)st.lastChiRaw;
+        const float diff = st.prevChi2 - st.curChi2;
+        st.iters_done++;
+        st.iteration++;
+        const bool cont = st.iteration < st.max_iters && !stop && ok && diff > st.minChi2;
+        if (cont) {
+            const float t = st.prevChi2; st.prevChi2 = st.curChi2; st.curChi2 = t;   // swap at the next loop entry
+            st.phase = 0;
+            st.qmax = 0;
+        } else {
+            st.phase = 2;
+        }
+    }
+    st.first_trial = 0;
+    st.pending = 0;
+    return st;
+}
+
 // ------------------------------------------------------------------------------------------------ schur
 // grid = npairs * nsplit.  Block (pair, chunk) accumulates the landmarks pt = chunk*256 + tid (+ nsplit*256 ...) of the
 // (i1 <= i2) block and writes a PARTIAL 6x6 (and, on diagonal pairs, a partial 6-vector); the solve kernel adds the
 // partials in chunk order.  The first block also publishes lambda at iteration 0 (computeLambdaInit).
-__global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, int nsplit) {
+__global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, int nsplit, int slot) {
     __shared__ double s_part[4 * 42];
     __shared__ double s_out[42];
     // workgroup role and, for pair workgroups, the first landmark's edge ids and activity flags: none of it depends on the LM
@@ -344,8 +438,21 @@ __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, 
     }
     bool actn = e1n >= 0 && e2n >= 0;
     if (actn) actn = (p.e_active[e1n] != 0) & (p.e_active[e2n] != 0);
-    const BAState st = *p.st;
-    if (st.phase == 2) return;
+    // The decision about the PREVIOUS trial is taken here, by every workgroup for itself (same inputs, same code, same
+    // result): the state the previous step left in slot `slot` plus that trial's sums give the state this step runs with.
+    // Workgroup 0 publishes it in the other slot, which this step's later kernels and the next step's schur kernel read.
+    __shared__ BAState s_state;
+    if (threadIdx.x < 64) {
+        const BAState st0 = p.st[slot];
+        const DecideSums sm = decide_sums(p, d, threadIdx.x, st0.lambda);
+        if (threadIdx.x == 0) s_state = (st0.phase != 2 && st0.pending) ? apply_decision(st0, sm, st0.stop_seen != 0) : st0;
+    }
+    __syncthreads();
+    BAState st = s_state;
+    if (st.phase == 2) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { st.pending = 0; p.st[slot ^ 1] = st; }
+        return;
+    }
     UH_BA_CLK(4);
     double lambda = st.lambda;
     if (st.iteration == 0 && st.qmax == 0) {   // tau * max |H_jj| over poses and landmarks
@@ -361,8 +468,9 @@ __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, 
             }
         }
         lambda = 1e-5 * m;
-        if (blockIdx.x == 0 && threadIdx.x == 0) { p.st->lambda = lambda; p.st->ni = 2; }
+        st.lambda = lambda; st.ni = 2;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { BAState pub = st; pub.pending = 1; pub.stop_seen = 0; p.st[slot ^ 1] = pub; }
     if (cam_role) {   // camera workgroups: Hpp / bp partials (the lin kernel has them at the first trial)
         if (!st.first_trial) camera_block(p, d, blockIdx.x - npairblocks, p.poseR[st.cur], p.pts[st.cur]);
         return;
@@ -412,11 +520,13 @@ __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, 
 // pivoting; fails on a zero / non-finite pivot like Eigen's SimplicialLDLT) in LDS when it fits (n <= 120) else in HBM,
 // substitutes, and writes T_trial = exp(dx) * T_cur for the free poses.  Row stride is n+1 doubles (odd) so that column
 // walks are LDS-bank-conflict free.
+struct SolveOut { bool done; int ok, cur; double lambda; };   // done: the pass had finished, nothing was computed
+
 template <bool USE_LDS>
-__device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int nsplit) {
+__device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int nsplit, int slot, double* s_x /* LDS, 6*kMaxFree */, SolveOut& out) {
     extern __shared__ __attribute__((aligned(16))) double s_mat[];
-    __shared__ double s_x[6 * kMaxFree];
     __shared__ int s_ok;
+    out.done = true;
     const int n = d.n, ld = n + 1;
     const int npairs = d.nfree * (d.nfree + 1) / 2;
     // the address space must be known at compile time: a generic pointer would turn every access into a flat_load
@@ -458,10 +568,10 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
             for (int cch = 0; cch < kCamChunks; cch++) hs[u][cch] = p.HppPart[((size_t)s1 * kCamChunks + cch) * 27 + hq];
         }
         if (!have_state) {
-            const BAState st = *p.st;
+            const BAState st = p.st[slot];
             if (st.phase == 2) return;   // uniform: nothing has been written yet
             lambda = st.lambda; cur = st.cur; have_state = true;
-            if (tid == 0) p.clk[10] = clk_begin;
+            if (tid == 0 && blockIdx.x == 0) p.clk[10] = clk_begin;
         }
 #pragma unroll
         for (int u = 0; u < kAsmU; u++) {
@@ -489,7 +599,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
         }
     }
     if (!have_state) {   // no free pose: nothing was assembled
-        const BAState st = *p.st;
+        const BAState st = p.st[slot];
         if (st.phase == 2) return;
         lambda = st.lambda; cur = st.cur;
     }
@@ -644,7 +754,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     }
     __syncthreads();
     UH_BA_CLKL(13);
-    if (tid == 0) p.st->solve_ok = ok;
+    if (tid == 0) p.st[slot].solve_ok = ok;
     // pose update into the trial buffer (fixed poses are identical in both buffers and never touched)
     const int trial = cur ^ 1;
     if (tid < d.nfree) {
@@ -700,109 +810,58 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
         Ro[9] = t[0]; Ro[10] = t[1]; Ro[11] = t[2];
     }
     UH_BA_CLKL(14);
+    out.done = false; out.ok = ok; out.cur = cur; out.lambda = lambda;
 }
 
+// stand-alone form: reduced systems too large for LDS (n > 120) factorise in the HBM workspace p.S, which only one
+// workgroup may use
 template <bool USE_LDS>
-__global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADims d, int nsplit) {
-    solve_body<USE_LDS>(p, d, nsplit);
+__global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADims d, int nsplit, int slot) {
+    __shared__ double s_x[6 * kMaxFree];
+    SolveOut o;
+    solve_body<USE_LDS>(p, d, nsplit, slot, s_x, o);
 }
 
-// ------------------------------------------------------------------------------------------------ decide
-// One wave: the tail of OptimizationAlgorithmLevenberg::solve's do-while body plus SparseOptimizer::optimize's loop header.
-__device__ __forceinline__ double wave_sum_fixed(double v) {   // xor butterfly: fixed order, identical in all lanes
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-__global__ __launch_bounds__(64) void ba_decide_kernel(BAPtrs p, BADims d) {
-    // Everything the decision needs is requested up front — the force-stop flag lives in pinned host memory (a PCIe round
-    // trip), the state and the partial sums in HBM — so that the kernel pays one memory latency, not four in a row.
-    const int tid = threadIdx.x;
+// Stand-alone decision: closes a round of enqueued steps (the decision of a step is otherwise applied by the NEXT step's
+// schur kernel).  One wave, state slot `slot`, in place.
+__global__ __launch_bounds__(64) void ba_decide_kernel(BAPtrs p, BADims d, int slot) {
     const unsigned char stopv = p.stop ? *p.stop : (unsigned char)0;
-    const int nb = d.nPointBlocks;
-    // each lane pre-adds its strided share in a fixed order; the 64 lane sums are then added by a fixed butterfly
-    double l0 = 0, l1 = 0, l2 = 0;
-    for (int i = tid; i < nb; i += 64) { l0 += p.part_lin_chi[i]; l1 += p.part_chi[i]; l2 += p.part_scale[i]; }
-    double xv[6 * kMaxFree / 64], bv[6 * kMaxFree / 64];
-#pragma unroll
-    for (int k = 0; k < 6 * kMaxFree / 64; k++) {
-        const int i = tid + 64 * k;
-        xv[k] = i < d.n ? p.xp[i] : 0.0;
-        bv[k] = i < d.n ? p.bp[i] : 0.0;
-    }
-    const BAState st0 = *p.st;
-    if (st0.phase == 2) return;
+    const BAState st0 = p.st[slot];
+    const DecideSums sm = decide_sums(p, d, threadIdx.x, st0.lambda);
+    if (st0.phase == 2 || !st0.pending || threadIdx.x != 0) return;
     UH_BA_CLKL(24);
-    double xs = 0;
-#pragma unroll
-    for (int k = 0; k < 6 * kMaxFree / 64; k++) xs += xv[k] * (st0.lambda * xv[k] + bv[k]);
-    const double sum_lin = wave_sum_fixed(l0), sum_chi = wave_sum_fixed(l1), sum_scale = wave_sum_fixed(l2), sum_xs = wave_sum_fixed(xs);
-    if (tid != 0) return;
-    BAState st = st0;
-    if (st.first_trial) st.currentChi = sum_lin;   // activeRobustChi2 at the pass's initial estimate (lin kernel); later the accepted tempChi
-    double tempChi = sum_chi, scale = sum_scale;
-    st.lastChiRaw = tempChi;
-    if (st.solve_ok) scale += sum_xs;
-    if (!st.solve_ok) tempChi = DBL_MAX;
-    double rho = st.currentChi - tempChi;
-    scale += 1e-3;
-    rho /= scale;
-    bool lambda_finite = true;
-    if (rho > 0 && isfinite(tempChi)) {
-        const double t3 = 2 * rho - 1;
-        double alpha = 1. - t3 * t3 * t3;
-        alpha = fmin(alpha, 2. / 3.);
-        const double sf = fmax(1. / 3., alpha);
-        st.lambda *= sf;
-        st.ni = 2;
-        st.currentChi = tempChi;
-        st.cur ^= 1;   // discardTop: the trial buffers (estimate AND its linearisation, see backsub) become the current ones
-    } else {
-        st.lambda *= st.ni;
-        st.ni *= 2;    // pop: the current buffers stay
-        if (!isfinite(st.lambda)) lambda_finite = false;
-    }
-    st.rho = rho;
-    const bool stop = stopv != 0;
-    if (stop) st.stopped = 1;
-    bool again = false;
-    if (lambda_finite) {
-        st.qmax++;
-        again = (rho < 0 && st.qmax < 10 && !stop);
-    }
-    if (again) {
-        st.phase = 1;
-    } else {
-        const bool terminate = (st.qmax == 10 || rho == 0 || !lambda_finite);
-        const bool ok = !terminate;
-        // SparseOptimizer::optimize: curChi2 = activeRobustChi2() of the LAST computed errors; Chi2Diff = prev - cur (float)
-        st.curChi2 = (float)st.lastChiRaw;
-        const float diff = st.prevChi2 - st.curChi2;
-        st.iters_done++;
-        st.iteration++;
-        const bool cont = st.iteration < st.max_iters && !stop && ok && diff > st.minChi2;
-        if (cont) {
-            const float t = st.prevChi2; st.prevChi2 = st.curChi2; st.curChi2 = t;   // swap at the next loop entry
-            st.phase = 0;
-            st.qmax = 0;
-        } else {
-            st.phase = 2;
-        }
-    }
-    st.first_trial = 0;
-    *p.st = st;
+    p.st[slot] = apply_decision(st0, sm, stopv != 0 || st0.stop_seen != 0);
     p.clk[25] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------ backsub + trial errors
-__global__ __launch_bounds__(kThreads) void ba_backsub_kernel(BAPtrs p, BADims d) {
+// FUSED (reduced system in LDS, n <= 120): every workgroup first solves the reduced system itself — the same assembly,
+// factorisation and substitution in all of them, ~22 us that would otherwise be a one-workgroup launch of its own — keeps dx_p
+// in LDS and goes on with its landmarks.  All workgroups write identical trial poses / xp / solve_ok.  Saves one kernel
+// boundary and the dependent reloads behind it per LM trial.
+template <bool FUSED>
+__global__ __launch_bounds__(kThreads) void ba_backsub_kernel(BAPtrs p, BADims d, int nsplit, int slot) {
     __shared__ double s_red[kThreads];
-    const BAState st = *p.st;
-    if (st.phase == 2) return;
-    const int cur = st.cur, trial = cur ^ 1;
-    const double lambda = st.lambda;
-    const int ok = st.solve_ok;
+    __shared__ double s_xp[6 * kMaxFree];
+    // the force-stop flag lives in pinned host memory (a PCIe round trip): one thread of the grid samples it, early, and
+    // leaves it in the state for the decision
+    unsigned char stopv = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.stop) stopv = *p.stop;
+    int cur, ok;
+    double lambda;
+    if constexpr (FUSED) {
+        SolveOut so;
+        solve_body<true>(p, d, nsplit, slot, s_xp, so);
+        if (so.done) return;
+        __syncthreads();   // trial poses (written to HBM by this workgroup) and s_xp are complete
+        cur = so.cur; ok = so.ok; lambda = so.lambda;
+    } else {
+        const BAState st = p.st[slot];
+        if (st.phase == 2) return;
+        cur = st.cur; lambda = st.lambda; ok = st.solve_ok;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && stopv) p.st[slot].stop_seen = 1;
+    const int trial = cur ^ 1;
     UH_BA_CLK(20);
     const int gl = threadIdx.x & (kLanesPerPoint - 1);
     const int pt = blockIdx.x * kPointsPerBlock + (threadIdx.x >> 3);
@@ -822,7 +881,9 @@ __global__ __launch_bounds__(kThreads) void ba_backsub_kernel(BAPtrs p, BADims d
             const int s = p.slot[p.e_kf[e]];
             if (s < 0) continue;
             const double* B1 = p.Hpl[cur] + 18 * (size_t)e;
-            const double* x = p.xp + 6 * s;
+            double x[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++) { if constexpr (FUSED) x[a] = s_xp[6 * s + a]; else x[a] = p.xp[6 * s + a]; }
 #pragma unroll
             for (int a = 0; a < 6; a++) { c[0] -= B1[a * 3] * x[a]; c[1] -= B1[a * 3 + 1] * x[a]; c[2] -= B1[a * 3 + 2] * x[a]; }
         }
@@ -864,10 +925,10 @@ __global__ __launch_bounds__(kThreads) void ba_backsub_kernel(BAPtrs p, BADims d
 
 // ------------------------------------------------------------------------------------------------ between / after passes
 // globaloptimizer_g2o.cpp:434-449: outliers to level 1, every robust kernel removed
-__global__ void ba_relabel_kernel(BAPtrs p, BADims d) {
+__global__ void ba_relabel_kernel(BAPtrs p, BADims d, int slot) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= d.E) return;
-    const int cur = p.st->cur;
+    const int cur = p.st[slot].cur;
     const int k = p.e_kf[e], pt = p.e_pt[e];
     const double* Rt = p.poseR[cur] + 12 * k;
     const double* X = p.pts[cur] + 3 * pt;
@@ -876,9 +937,11 @@ __global__ void ba_relabel_kernel(BAPtrs p, BADims d) {
     p.e_robust[e] = 0;
 }
 
-__global__ void ba_begin_pass_kernel(BAPtrs p, int max_iters, float minChi2) {
+__global__ void ba_begin_pass_kernel(BAPtrs p, int max_iters, float minChi2, int slot) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    BAState& st = *p.st;
+    BAState& st = p.st[slot];
+    st.pending = 0;
+    st.stop_seen = 0;
     st.phase = max_iters > 0 ? 0 : 2;
     st.iteration = 0;
     st.max_iters = max_iters;
@@ -894,9 +957,9 @@ __global__ void ba_begin_pass_kernel(BAPtrs p, int max_iters, float minChi2) {
 
 // getResults (:466-537): float poses (free frames), float points, bad associations
 __global__ void ba_results_kernel(BAPtrs p, BADims d, const float* __restrict__ poses_in, float* __restrict__ poses_out,
-                                  float* __restrict__ points_out, unsigned char* __restrict__ bad_out, int stage) {
+                                  float* __restrict__ points_out, unsigned char* __restrict__ bad_out, int stage, int slot) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int cur = p.st->cur;
+    const int cur = p.st[slot].cur;
     if (stage == 0) {
         if (i < d.K) {
             float* M = poses_out + 16 * i;
@@ -934,7 +997,7 @@ __global__ void ba_init_state_kernel(BAPtrs p, BADims d, const double* __restric
     }
     if (i < 3 * d.P) { p.pts[0][i] = pts0[i]; p.pts[1][i] = pts0[i]; }
     if (i < d.E) { p.e_active[i] = 1; p.e_robust[i] = 1; p.e_chi2[i] = 0; p.e_err[2 * i] = 0; p.e_err[2 * i + 1] = 0; }
-    if (i == 0) { BAState z; memset(&z, 0, sizeof(z)); z.phase = 2; z.lambda = -1; z.ni = 2; *p.st = z; }
+    if (i == 0) { BAState z; memset(&z, 0, sizeof(z)); z.phase = 2; z.lambda = -1; z.ni = 2; p.st[0] = z; p.st[1] = z; }
 }
 
 }  // namespace
@@ -953,6 +1016,7 @@ struct uh_ba {
     unsigned char* h_stop = nullptr;      // pinned, device-visible force-stop flag
     int iters[2] = {0, 0};
     int nsplit = 1;
+    int step = 0;                         // LM steps enqueued since uh_ba_optimize began: step s reads state slot s & 1
     bool optimized = false;
     ~uh_ba() { if (h_stop) (void)hipHostFree(h_stop); }
 };
@@ -990,26 +1054,32 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
     const int use_lds = d.n <= 120 ? 1 : 0;
     const size_t lds = use_lds ? (size_t)d.n * (d.n + 1) * sizeof(double) : 0;
     for (int s = 0; s < nsteps; s++) {
-        if (pass_start && s == 0) UH_LAUNCH(b->ctx,ba_lin_kernel, dim3(d.nPointBlocks + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d);
-        UH_LAUNCH(b->ctx,ba_schur_kernel, dim3(std::max(npairs, 1) * b->nsplit + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d, b->nsplit);
-        if (use_lds) UH_LAUNCH(b->ctx,ba_solve_kernel<true>, dim3(1), dim3(kSolveThreads), lds, b->ptrs, d, b->nsplit);
-        else UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kSolveThreads), lds, b->ptrs, d, b->nsplit);
-        UH_LAUNCH(b->ctx,ba_backsub_kernel, dim3(d.nPointBlocks), dim3(kThreads), 0, b->ptrs, d);
-        UH_LAUNCH(b->ctx,ba_decide_kernel, dim3(1), dim3(64), 0, b->ptrs, d);
+        const int slot = b->step & 1;   // state left by the previous step (or by begin_pass / the closing decide kernel)
+        if (pass_start && s == 0) UH_LAUNCH(b->ctx,ba_lin_kernel, dim3(d.nPointBlocks + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d, slot);
+        UH_LAUNCH(b->ctx,ba_schur_kernel, dim3(std::max(npairs, 1) * b->nsplit + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d, b->nsplit, slot);
+        if (use_lds) {
+            UH_LAUNCH(b->ctx,ba_backsub_kernel<true>, dim3(d.nPointBlocks), dim3(kThreads), lds, b->ptrs, d, b->nsplit, slot ^ 1);
+        } else {
+            UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kSolveThreads), 0, b->ptrs, d, b->nsplit, slot ^ 1);
+            UH_LAUNCH(b->ctx,ba_backsub_kernel<false>, dim3(d.nPointBlocks), dim3(kThreads), 0, b->ptrs, d, b->nsplit, slot ^ 1);
+        }
+        b->step++;
     }
+    // the last trial's decision (every other one is taken by the following step's schur kernel)
+    UH_LAUNCH(b->ctx,ba_decide_kernel, dim3(1), dim3(64), 0, b->ptrs, d, b->step & 1);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
 }
 
 int run_pass(uh_ba* b, int max_iters, int* iters_done, const volatile uint8_t* stop_asap) {
     hipStream_t st = b->ctx->stream;
-    UH_LAUNCH(b->ctx,ba_begin_pass_kernel, dim3(1), dim3(64), 0, b->ptrs, max_iters, b->params.min_chi2_between_iter);
+    UH_LAUNCH(b->ctx,ba_begin_pass_kernel, dim3(1), dim3(64), 0, b->ptrs, max_iters, b->params.min_chi2_between_iter, b->step & 1);
     int budget = max_iters + 1;   // one step per outer iteration when no trial is rejected
     BAState hs;
     for (int round = 0; round < 64; round++) {
         int rc = enqueue_steps(b, budget, round == 0);
         if (rc) return rc;
-        UH_HIP_CHECK(hipMemcpyAsync(&hs, b->ptrs.st, sizeof(BAState), hipMemcpyDeviceToHost, st));
+        UH_HIP_CHECK(hipMemcpyAsync(&hs, b->ptrs.st + (b->step & 1), sizeof(BAState), hipMemcpyDeviceToHost, st));
         if (stop_asap && b->h_stop) {   // keep forwarding the caller's flag to the device-visible one while waiting
             hipEvent_t ev;
             UH_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1108,7 +1178,7 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     if (const char* e = getenv("UH_BA_NSPLIT")) b->nsplit = std::max(1, std::min(kMaxSplit, atoi(e)));   // tuning knob (measurement only)
     const size_t o_S = A.take<double>((size_t)std::max(d.n, 1) * (std::max(d.n, 1) + 1)), o_Sp = A.take<double>((size_t)b->nsplit * std::max(npairs_h, 1) * 42), o_xp = A.take<double>(std::max(d.n, 1));
     const size_t o_plc = A.take<double>(d.nPointBlocks), o_pmd = A.take<double>(d.nPointBlocks), o_pc = A.take<double>(d.nPointBlocks), o_ps = A.take<double>(d.nPointBlocks);
-    const size_t o_st = A.take<BAState>(1), o_clk = A.take<long long>(64);
+    const size_t o_st = A.take<BAState>(2), o_clk = A.take<long long>(64);
     int rc = b->arena.reserve(A.off + 256);
     if (rc) return rc;
     UH_HIP_CHECK(hipSetDevice(b->ctx->device));
@@ -1172,13 +1242,14 @@ int uh_ba_optimize(uh_ba* b, const volatile uint8_t* stop_asap) {
     const int nmax = std::max(std::max(d.K, 3 * d.P), std::max(d.E, 1));
     UH_LAUNCH(b->ctx,ba_init_state_kernel, dim3(uh_div_up(nmax, 256)), dim3(256), 0, b->ptrs, d, b->d_pose0, b->d_pts0);
     b->iters[0] = b->iters[1] = 0;
+    b->step = 0;
     int rc = run_pass(b, b->params.n_iters, &b->iters[0], stop_asap);
     if (rc) return rc;
     bool cont = true;
     if (stop_asap && *stop_asap) cont = false;
     if (b->h_stop && *b->h_stop) cont = false;
     if (cont) {
-        if (d.E > 0) UH_LAUNCH(b->ctx,ba_relabel_kernel, dim3(uh_div_up(d.E, 256)), dim3(256), 0, b->ptrs, d);
+        if (d.E > 0) UH_LAUNCH(b->ctx,ba_relabel_kernel, dim3(uh_div_up(d.E, 256)), dim3(256), 0, b->ptrs, d, b->step & 1);
         if ((rc = run_pass(b, 2 * b->params.n_iters, &b->iters[1], stop_asap))) return rc;
     }
     b->optimized = true;
@@ -1202,10 +1273,10 @@ int uh_ba_get_results(uh_ba* b, float* poses_out, float* points_out, double* chi
     const BADims& d = b->dims;
     const int n0 = std::max(d.K, 3 * d.P);
     UH_LAUNCH(b->ctx,ba_results_kernel, dim3(uh_div_up(std::max(n0, 1), 256)), dim3(256), 0, b->ptrs, d, b->d_poses_in.as<float>(),
-                       b->d_poses_out.as<float>(), b->d_points_out.as<float>(), b->d_bad.as<unsigned char>(), 0);
+                       b->d_poses_out.as<float>(), b->d_points_out.as<float>(), b->d_bad.as<unsigned char>(), 0, b->step & 1);
     if (d.E > 0)
         UH_LAUNCH(b->ctx,ba_results_kernel, dim3(uh_div_up(d.E, 256)), dim3(256), 0, b->ptrs, d, b->d_poses_in.as<float>(),
-                           b->d_poses_out.as<float>(), b->d_points_out.as<float>(), b->d_bad.as<unsigned char>(), 1);
+                           b->d_poses_out.as<float>(), b->d_points_out.as<float>(), b->d_bad.as<unsigned char>(), 1, b->step & 1);
     if (poses_out) UH_HIP_CHECK(hipMemcpyAsync(poses_out, b->d_poses_out.p, 16 * (size_t)d.K * 4, hipMemcpyDeviceToHost, st));
     if (points_out && d.P) UH_HIP_CHECK(hipMemcpyAsync(points_out, b->d_points_out.p, 3 * (size_t)d.P * 4, hipMemcpyDeviceToHost, st));
     if (chi2_out && d.E) UH_HIP_CHECK(hipMemcpyAsync(chi2_out, b->ptrs.e_chi2, (size_t)d.E * 8, hipMemcpyDeviceToHost, st));
@@ -1219,7 +1290,7 @@ int uh_ba_get_results(uh_ba* b, float* poses_out, float* points_out, double* chi
 int uh_ba_get_pose_state(uh_ba* b, double* pose7_out) {
     UH_REQUIRE(b && b->have_problem && b->optimized && pose7_out, "uh_ba_get_pose_state: not ready");
     BAState hs;
-    UH_HIP_CHECK(hipMemcpyAsync(&hs, b->ptrs.st, sizeof(BAState), hipMemcpyDeviceToHost, b->ctx->stream));
+    UH_HIP_CHECK(hipMemcpyAsync(&hs, b->ptrs.st + (b->step & 1), sizeof(BAState), hipMemcpyDeviceToHost, b->ctx->stream));
     UH_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
     UH_HIP_CHECK(hipMemcpyAsync(pose7_out, b->ptrs.pose[hs.cur], 7 * (size_t)b->dims.K * 8, hipMemcpyDeviceToHost, b->ctx->stream));
     UH_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
