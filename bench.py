@@ -58,12 +58,16 @@ def algorithmic_bytes(frames_per_step, ba_E):
         "describe_kernel": F * MAX_FEATURES * (961 + 60),               # 31x31 patch per keypoint + 28 B keypoint + 32 B descriptor
         "knn_search_kernel": (F * NQ + NT) * 32 + F * NQ * NN * 8,      # SURVEY §8(d) formula with k=10, F frames per launch
         # BA, per launch (E*32 obs + points/poses; per-kernel split in DESIGN.md)
-        "ba_lin_kernel": ba_E * (32 + 18 * 8) + BA_P * (24 + 96),
-        "ba_schur_kernel": ba_E * 18 * 8 + BA_P * 96,
-        # solve: 36 pair partials x 8 chunks x 42 doubles + camera partials (8 free x 8 chunks x 27) + rhs/solution/poses
-        "ba_solve_kernel": 36 * 8 * 42 * 8 + 8 * 8 * 27 * 8 + 4 * 48 * 8 + 10 * 19 * 8,
-        "ba_backsub_kernel": ba_E * (18 * 8 + 32 + 24) + BA_P * (96 + 48),
-        "ba_decide_kernel": 1024,
+        "ba_lin_kernel": ba_E * (32 + 18 * 8) + BA_P * (24 + 96),       # once per pass: obs in, Hpl / Hll / bl out
+        # schur: per landmark pair blocks read Hpl (18 doubles per edge) and Hll/bl (12 per point); the camera workgroups
+        # re-read the observations (32 B) for Hpp/bp; + the previous trial's partial sums for the decision (~3 KB)
+        "ba_schur_kernel": ba_E * (18 * 8 + 32) + BA_P * 96 + 3072,
+        # backsub (with the reduced-system solve inside): pair partials 36 x 12 chunks x 42 doubles + camera partials
+        # 8 x 8 x 27 doubles, then per edge Hpl in (144 B), obs (32 B), errors/chi2 out (24 B) and the trial linearisation
+        # out (144 B), per point Hll/bl in (96 B), point in/out (48 B), Hll/bl out (96 B)
+        "ba_backsub_kernel": 36 * 12 * 42 * 8 + 8 * 8 * 27 * 8 + ba_E * (144 + 32 + 24 + 144) + BA_P * (96 + 48 + 96),
+        "ba_solve_kernel": 36 * 12 * 42 * 8 + 8 * 8 * 27 * 8 + 4 * 48 * 8 + 10 * 19 * 8,   # only for n > 120 (not this workload)
+        "ba_decide_kernel": 3072,
     }
     # resize: the driver launches it once per level l>=1: read level l-1, write level l (average per launch)
     b["resize_cubic_kernel"] = F * (sum(px[:-1]) + sum(px[1:])) / (NLEVELS - 1)
