@@ -607,89 +607,194 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     __syncthreads();
     UH_BA_CLKL(11);
     // Right-looking LDL^T of the lower triangle, blocked by the 6x6 camera blocks (n = 6*nfree).  Per block column: an
-    // in-register factorisation of the diagonal block (done redundantly by every thread: it is the dependent chain of six
-    // reciprocals), a panel solve (thread per row) and a rank-6 trailing update (thread per element) — three barriers per
-    // camera instead of one per scalar column.  The phase is bound by the instruction count of one wave (fp64 ops issue
-    // at 4-8 cycles), hence explicit fma() everywhere, the panel kept twice (L in M, L*D in s_w: no multiply by d in the
-    // update) and a loop-invariant thread -> (row, column) mapping.  After it M holds L (unit lower) and d on the diagonal.
-    __shared__ double s_w[6 * kMaxFree][6];
-    constexpr int kTilesPerRound = kSolveThreads / 36;
-    const int tq = tid / 36, te = tid - 36 * tq, ti = te / 6, tj = te - 6 * ti;   // trailing update: tile slot, row, column
+    // in-register factorisation of the diagonal block (the dependent chain of six reciprocals), a panel solve (thread per
+    // row) and a rank-6 trailing update (thread per element).  The phase is bound by the instruction count of one wave (fp64
+    // ops issue at 4-8 cycles), hence explicit fma() everywhere, the panel kept twice (L in M, L*D in s_w: no multiply by d
+    // in the update) and a loop-invariant thread -> (row, column) mapping.  After it M holds L (unit lower) and d on the
+    // diagonal.
     bool failed = false;
-    for (int k0 = 0; k0 < n; k0 += 6) {
-        // (a) diagonal block -> Lkk (strict lower), dk, 1/dk
-        double a[6][6], dk[6], ik[6];
+    if constexpr (USE_LDS) {
+        // LOOK-AHEAD form: panel kb is first applied to block column kb+1 alone, by all four waves; then wave 0 factorises that
+        // diagonal block and solves ITS panel while waves 1..3 apply panel kb to the tiles behind — the serial chain of
+        // reciprocals no longer waits for the bulk of the trailing update.  The L*D panel is double-buffered (s_w[kb & 1]).
+        __shared__ double s_w[2][120][6];
+        const int nb = n / 6;
+        auto diag_and_panel = [&](int kb) {   // wave 0 only: block column kb is fully updated
+            const int k0 = 6 * kb;
+            double a[6][6], dk[6], ik[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++)
+            for (int i = 0; i < 6; i++)
 #pragma unroll
-            for (int c = 0; c <= i; c++) a[i][c] = M[(k0 + i) * ld + k0 + c];
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            dk[j] = a[j][j];
-            failed = failed || dk[j] == 0.0 || !isfinite(dk[j]);
-            ik[j] = fast_rcp(dk[j]);
-            double lcol[6];
-#pragma unroll
-            for (int i = j + 1; i < 6; i++) lcol[i] = a[i][j] * ik[j];      // L(i,j); a[.][j] keeps L*d_j during the update
-#pragma unroll
-            for (int i = j + 1; i < 6; i++)
-#pragma unroll
-                for (int c = j + 1; c <= i; c++) a[i][c] = fma(-lcol[i], a[c][j], a[i][c]);
-#pragma unroll
-            for (int i = j + 1; i < 6; i++) a[i][j] = lcol[i];
-        }
-        __syncthreads();   // every thread has read the block before it is overwritten
-        if (tid == 0) {
-#pragma unroll
-            for (int i = 0; i < 6; i++) {
-#pragma unroll
-                for (int c = 0; c < i; c++) M[(k0 + i) * ld + k0 + c] = a[i][c];
-                M[(k0 + i) * ld + k0 + i] = dk[i];
-            }
-        }
-        // (b) panel: L_rk = A_rk * Lkk^-T * Dk^-1, one thread per row; y = L_rk * Dk goes to s_w
-        for (int r = k0 + 6 + tid; r < n; r += kSolveThreads) {
-            double y[6];
-#pragma unroll
-            for (int j = 0; j < 6; j++) y[j] = M[r * ld + k0 + j];
+                for (int c = 0; c <= i; c++) a[i][c] = M[(k0 + i) * ld + k0 + c];
 #pragma unroll
             for (int j = 0; j < 6; j++) {
+                dk[j] = a[j][j];
+                failed = failed || dk[j] == 0.0 || !isfinite(dk[j]);
+                ik[j] = fast_rcp(dk[j]);
+                double lcol[6];
 #pragma unroll
-                for (int t = 0; t < j; t++) y[j] = fma(-y[t], a[j][t], y[j]);
+                for (int i = j + 1; i < 6; i++) lcol[i] = a[i][j] * ik[j];
+#pragma unroll
+                for (int i = j + 1; i < 6; i++)
+#pragma unroll
+                    for (int c = j + 1; c <= i; c++) a[i][c] = fma(-lcol[i], a[c][j], a[i][c]);
+#pragma unroll
+                for (int i = j + 1; i < 6; i++) a[i][j] = lcol[i];
             }
+            __builtin_amdgcn_wave_barrier();   // every lane has read the block before lane 0 overwrites it
+            if (lane == 0) {
 #pragma unroll
-            for (int j = 0; j < 6; j++) { M[r * ld + k0 + j] = y[j] * ik[j]; s_w[r][j] = y[j]; }
-        }
-        __syncthreads();
-        // (c) trailing update A_rc -= sum_t L_rt (d_t L_ct) for c <= r: the 6x6 tiles (s1 <= s2) behind block column kb are the
-        //     tail of the s1-major pair list; each thread owns one (row, column) of a tile slot, kTrailU tiles in flight
-        {
-            const int kb = k0 / 6;
-            const int tile0 = (kb + 1) * d.nfree - kb * (kb + 1) / 2;   // first pair with s1 > kb
-            const int ntile = npairs - tile0;
-            for (int tl = tq; tl < ntile && tq < kTilesPerRound; tl += kTrailU * kTilesPerRound) {
-                int rr[kTrailU], cc[kTrailU]; bool on[kTrailU];
-                double lr[kTrailU][6], wc[kTrailU][6], acc[kTrailU];
+                for (int i = 0; i < 6; i++) {
 #pragma unroll
-                for (int u = 0; u < kTrailU; u++) {
-                    const int t_ = tl + u * kTilesPerRound;
-                    const int tc = t_ < ntile ? t_ : tl;
-                    const int s1 = s_pair[tile0 + tc][0], s2 = s_pair[tile0 + tc][1];
-                    rr[u] = 6 * s2 + ti; cc[u] = 6 * s1 + tj;
-                    on[u] = t_ < ntile && cc[u] <= rr[u];
-#pragma unroll
-                    for (int t = 0; t < 6; t++) { lr[u][t] = M[rr[u] * ld + k0 + t]; wc[u][t] = s_w[cc[u]][t]; }
-                    acc[u] = M[rr[u] * ld + cc[u]];
-                }
-#pragma unroll
-                for (int u = 0; u < kTrailU; u++) {
-#pragma unroll
-                    for (int t = 0; t < 6; t++) acc[u] = fma(-lr[u][t], wc[u][t], acc[u]);
-                    if (on[u]) M[rr[u] * ld + cc[u]] = acc[u];
+                    for (int c = 0; c < i; c++) M[(k0 + i) * ld + k0 + c] = a[i][c];
+                    M[(k0 + i) * ld + k0 + i] = dk[i];
                 }
             }
+            for (int r = k0 + 6 + lane; r < n; r += 64) {   // panel: L_rk = A_rk * Lkk^-T * Dk^-1; y = L_rk * Dk goes to s_w
+                double y[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++) y[j] = M[r * ld + k0 + j];
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+#pragma unroll
+                    for (int t = 0; t < j; t++) y[j] = fma(-y[t], a[j][t], y[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 6; j++) { M[r * ld + k0 + j] = y[j] * ik[j]; s_w[kb & 1][r][j] = y[j]; }
+            }
+        };
+        if (wv == 0 && nb > 0) diag_and_panel(0);
+        for (int kb = 0; kb < nb; kb++) {
+            __syncthreads();   // panel kb (M columns of block kb, s_w[kb & 1]) is complete; trailing update kb-1 is done
+            if (kb == nb - 1) break;
+            const int k0 = 6 * kb;
+            {   // block column kb+1 first, by everybody (one element per thread and round): wave 0 needs it to go on
+                const int c0 = k0 + 6, m = n - c0;
+                for (int e = tid; e < m * 6; e += kSolveThreads) {
+                    const int r = c0 + e / 6, c = c0 + e % 6;
+                    double acc = M[r * ld + c];
+                    double lr[6], wc[6];
+#pragma unroll
+                    for (int t = 0; t < 6; t++) { lr[t] = M[r * ld + k0 + t]; wc[t] = s_w[kb & 1][c][t]; }
+#pragma unroll
+                    for (int t = 0; t < 6; t++) acc = fma(-lr[t], wc[t], acc);
+                    if (c <= r) M[r * ld + c] = acc;
+                }
+            }
+            __syncthreads();
+            if (wv == 0) {
+                diag_and_panel(kb + 1);
+            } else {
+                // tiles (s1 <= s2) with s1 >= kb+2: the tail of the s1-major pair list; 5 tile slots of 36 threads
+                const int t3 = tid - 64;
+                const int tq = t3 / 36, te = t3 - 36 * tq, ti = te / 6, tj = te - 6 * ti;
+                constexpr int kSlots = (kSolveThreads - 64) / 36;
+                const int s1min = kb + 2;
+                const int tile0 = s1min * d.nfree - s1min * (s1min - 1) / 2;   // first pair with s1 >= kb+2
+                const int ntile = npairs - tile0;
+                for (int tl = tq; tl < ntile && tq < kSlots; tl += kTrailU * kSlots) {
+                    int rr[kTrailU], cc[kTrailU]; bool on[kTrailU];
+                    double lr[kTrailU][6], wc[kTrailU][6], acc[kTrailU];
+#pragma unroll
+                    for (int u = 0; u < kTrailU; u++) {
+                        const int t_ = tl + u * kSlots;
+                        const int tc = t_ < ntile ? t_ : tl;
+                        const int s1 = s_pair[tile0 + tc][0], s2 = s_pair[tile0 + tc][1];
+                        rr[u] = 6 * s2 + ti; cc[u] = 6 * s1 + tj;
+                        on[u] = t_ < ntile && cc[u] <= rr[u];
+#pragma unroll
+                        for (int t = 0; t < 6; t++) { lr[u][t] = M[rr[u] * ld + k0 + t]; wc[u][t] = s_w[kb & 1][cc[u]][t]; }
+                        acc[u] = M[rr[u] * ld + cc[u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kTrailU; u++) {
+#pragma unroll
+                        for (int t = 0; t < 6; t++) acc[u] = fma(-lr[u][t], wc[u][t], acc[u]);
+                        if (on[u]) M[rr[u] * ld + cc[u]] = acc[u];
+                    }
+                }
+            }
         }
-        __syncthreads();
+        if (wv != 0) failed = false;   // only wave 0 sees the pivots
+    } else {
+        __shared__ double s_w[6 * kMaxFree][6];
+        constexpr int kTilesPerRound = kSolveThreads / 36;
+        const int tq = tid / 36, te = tid - 36 * tq, ti = te / 6, tj = te - 6 * ti;   // trailing update: tile slot, row, column
+        for (int k0 = 0; k0 < n; k0 += 6) {
+            // (a) diagonal block -> Lkk (strict lower), dk, 1/dk
+            double a[6][6], dk[6], ik[6];
+    #pragma unroll
+            for (int i = 0; i < 6; i++)
+    #pragma unroll
+                for (int c = 0; c <= i; c++) a[i][c] = M[(k0 + i) * ld + k0 + c];
+    #pragma unroll
+            for (int j = 0; j < 6; j++) {
+                dk[j] = a[j][j];
+                failed = failed || dk[j] == 0.0 || !isfinite(dk[j]);
+                ik[j] = fast_rcp(dk[j]);
+                double lcol[6];
+    #pragma unroll
+                for (int i = j + 1; i < 6; i++) lcol[i] = a[i][j] * ik[j];      // L(i,j); a[.][j] keeps L*d_j during the update
+    #pragma unroll
+                for (int i = j + 1; i < 6; i++)
+    #pragma unroll
+                    for (int c = j + 1; c <= i; c++) a[i][c] = fma(-lcol[i], a[c][j], a[i][c]);
+    #pragma unroll
+                for (int i = j + 1; i < 6; i++) a[i][j] = lcol[i];
+            }
+            __syncthreads();   // every thread has read the block before it is overwritten
+            if (tid == 0) {
+    #pragma unroll
+                for (int i = 0; i < 6; i++) {
+    #pragma unroll
+                    for (int c = 0; c < i; c++) M[(k0 + i) * ld + k0 + c] = a[i][c];
+                    M[(k0 + i) * ld + k0 + i] = dk[i];
+                }
+            }
+            // (b) panel: L_rk = A_rk * Lkk^-T * Dk^-1, one thread per row; y = L_rk * Dk goes to s_w
+            for (int r = k0 + 6 + tid; r < n; r += kSolveThreads) {
+                double y[6];
+    #pragma unroll
+                for (int j = 0; j < 6; j++) y[j] = M[r * ld + k0 + j];
+    #pragma unroll
+                for (int j = 0; j < 6; j++) {
+    #pragma unroll
+                    for (int t = 0; t < j; t++) y[j] = fma(-y[t], a[j][t], y[j]);
+                }
+    #pragma unroll
+                for (int j = 0; j < 6; j++) { M[r * ld + k0 + j] = y[j] * ik[j]; s_w[r][j] = y[j]; }
+            }
+            __syncthreads();
+            // (c) trailing update A_rc -= sum_t L_rt (d_t L_ct) for c <= r: the 6x6 tiles (s1 <= s2) behind block column kb are the
+            //     tail of the s1-major pair list; each thread owns one (row, column) of a tile slot, kTrailU tiles in flight
+            {
+                const int kb = k0 / 6;
+                const int tile0 = (kb + 1) * d.nfree - kb * (kb + 1) / 2;   // first pair with s1 > kb
+                const int ntile = npairs - tile0;
+                for (int tl = tq; tl < ntile && tq < kTilesPerRound; tl += kTrailU * kTilesPerRound) {
+                    int rr[kTrailU], cc[kTrailU]; bool on[kTrailU];
+                    double lr[kTrailU][6], wc[kTrailU][6], acc[kTrailU];
+    #pragma unroll
+                    for (int u = 0; u < kTrailU; u++) {
+                        const int t_ = tl + u * kTilesPerRound;
+                        const int tc = t_ < ntile ? t_ : tl;
+                        const int s1 = s_pair[tile0 + tc][0], s2 = s_pair[tile0 + tc][1];
+                        rr[u] = 6 * s2 + ti; cc[u] = 6 * s1 + tj;
+                        on[u] = t_ < ntile && cc[u] <= rr[u];
+    #pragma unroll
+                        for (int t = 0; t < 6; t++) { lr[u][t] = M[rr[u] * ld + k0 + t]; wc[u][t] = s_w[cc[u]][t]; }
+                        acc[u] = M[rr[u] * ld + cc[u]];
+                    }
+    #pragma unroll
+                    for (int u = 0; u < kTrailU; u++) {
+    #pragma unroll
+                        for (int t = 0; t < 6; t++) acc[u] = fma(-lr[u][t], wc[u][t], acc[u]);
+                        if (on[u]) M[rr[u] * ld + cc[u]] = acc[u];
+                    }
+                }
+            }
+            __syncthreads();
+        }
     }
     if (failed && tid == 0) s_ok = 0;   // zero / non-finite pivot (Eigen SimplicialLDLT would report failure)
     __syncthreads();
