@@ -541,7 +541,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
         while (rem >= d.nfree - s1) { rem -= d.nfree - s1; ++s1; }
         s_pair[t][0] = (short)s1; s_pair[t][1] = (short)(s1 + rem);
     }
-    __syncthreads();
+    // (no barrier: the assembly decodes its pairs arithmetically; s_pair is first read after the barrier that ends it)
     const int total = npairs * 42;
     constexpr int kAsmU = 4;
     // the LM state (lambda, current buffer, "pass finished") is requested together with the first round of partials
@@ -556,7 +556,9 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
             const int t = t0 + u * kSolveThreads;
             const int tc = t < total ? t : 0;
             const int pair = tc / 42, q = tc - pair * 42;
-            const int s1 = s_pair[pair][0], s2 = s_pair[pair][1];
+            int s1 = 0, rem = pair;
+            while (rem >= d.nfree - s1) { rem -= d.nfree - s1; ++s1; }
+            const int s2 = s1 + rem;
             s1v[u] = s1; s2v[u] = s2; qv[u] = t < total ? q : -1;
 #pragma unroll
             for (int k = 0; k < kMaxSplit; k++) xs[u][k] = p.Spart[((size_t)(k < nsplit ? k : 0) * npairs + pair) * 42 + q];
