@@ -124,17 +124,18 @@ __device__ __forceinline__ void quat_from_R(const double* R, double* q) {   // E
         q[3] = 0.5 * t;
         t = 0.5 / t;
         q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
-    } else {
-        int i = 0;
-        if (R[4] > R[0]) i = 1;
-        if (R[8] > R[i * 4]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
-        q[i] = 0.5 * t;
-        t = 0.5 / t;
-        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
-        q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
-        q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+    } else if (!(R[4] > R[0]) && !(R[8] > R[0])) {   // i = 0, j = 1, k = 2   (static indices: a runtime-indexed R[] would live in scratch)
+        t = sqrt(R[0] - R[4] - R[8] + 1.0);
+        q[0] = 0.5 * t; t = 0.5 / t;
+        q[3] = (R[7] - R[5]) * t; q[1] = (R[3] + R[1]) * t; q[2] = (R[6] + R[2]) * t;
+    } else if (R[4] > R[0] && !(R[8] > R[4])) {    // i = 1, j = 2, k = 0
+        t = sqrt(R[4] - R[8] - R[0] + 1.0);
+        q[1] = 0.5 * t; t = 0.5 / t;
+        q[3] = (R[2] - R[6]) * t; q[2] = (R[7] + R[5]) * t; q[0] = (R[1] + R[3]) * t;
+    } else {                                     // i = 2, j = 0, k = 1
+        t = sqrt(R[8] - R[0] - R[4] + 1.0);
+        q[2] = 0.5 * t; t = 0.5 / t;
+        q[3] = (R[3] - R[1]) * t; q[0] = (R[2] + R[6]) * t; q[1] = (R[5] + R[7]) * t;
     }
 }
 __device__ __forceinline__ void quat_norm_pos(double* q) {

@@ -46,12 +46,23 @@ __device__ __forceinline__ void p_quat_to_R(const double* q, double* R) {
 }
 __device__ __forceinline__ void p_quat_from_R(const double* R, double* q) {
     double t = R[0] + R[4] + R[8];
-    if (t > 0) { t = sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t; q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t; }
-    else {
-        int i = 0; if (R[4] > R[0]) i = 1; if (R[8] > R[i * 4]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0); q[i] = 0.5 * t; t = 0.5 / t;
-        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t; q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t; q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+    } else if (!(R[4] > R[0]) && !(R[8] > R[0])) {   // i = 0, j = 1, k = 2   (static indices: a runtime-indexed R[] would live in scratch)
+        t = sqrt(R[0] - R[4] - R[8] + 1.0);
+        q[0] = 0.5 * t; t = 0.5 / t;
+        q[3] = (R[7] - R[5]) * t; q[1] = (R[3] + R[1]) * t; q[2] = (R[6] + R[2]) * t;
+    } else if (R[4] > R[0] && !(R[8] > R[4])) {    // i = 1, j = 2, k = 0
+        t = sqrt(R[4] - R[8] - R[0] + 1.0);
+        q[1] = 0.5 * t; t = 0.5 / t;
+        q[3] = (R[2] - R[6]) * t; q[2] = (R[7] + R[5]) * t; q[0] = (R[1] + R[3]) * t;
+    } else {                                     // i = 2, j = 0, k = 1
+        t = sqrt(R[8] - R[0] - R[4] + 1.0);
+        q[2] = 0.5 * t; t = 0.5 / t;
+        q[3] = (R[3] - R[1]) * t; q[0] = (R[2] + R[6]) * t; q[1] = (R[5] + R[7]) * t;
     }
 }
 __device__ __forceinline__ void p_quat_norm(double* q) {
@@ -65,7 +76,10 @@ __device__ void p_oplus(PoseD& T, const double* d) {   // T <- exp(d) * T
     const double theta = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
     const double O[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
     double O2[9];
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
     double a, b, c1, c2;
     if (theta < 0.00001) { a = 1; b = 0.5; c1 = 0.5; c2 = 1.0 / 6.0; }
     else {
@@ -74,35 +88,70 @@ __device__ void p_oplus(PoseD& T, const double* d) {   // T <- exp(d) * T
         a = sn / theta; b = (1 - cs) / (theta * theta); c1 = b; c2 = (theta - sn) / (theta * theta * theta);
     }
     double Rm[9], V[9];
+#pragma unroll
     for (int i = 0; i < 9; i++) { const double I = (i % 4 == 0) ? 1.0 : 0.0; Rm[i] = I + a * O[i] + b * O2[i]; V[i] = I + c1 * O[i] + c2 * O2[i]; }
     double qe[4], te[3], RE[9];
     p_quat_from_R(Rm, qe);
     p_quat_norm(qe);
+#pragma unroll
     for (int r = 0; r < 3; r++) te[r] = V[r * 3] * d[3] + V[r * 3 + 1] * d[4] + V[r * 3 + 2] * d[5];
     p_quat_to_R(qe, RE);
     const double* q = T.q;
     double qn[4] = {qe[3] * q[0] + qe[0] * q[3] + qe[1] * q[2] - qe[2] * q[1], qe[3] * q[1] + qe[1] * q[3] + qe[2] * q[0] - qe[0] * q[2],
                     qe[3] * q[2] + qe[2] * q[3] + qe[0] * q[1] - qe[1] * q[0], qe[3] * q[3] - qe[0] * q[0] - qe[1] * q[1] - qe[2] * q[2]};
     double tn[3];
+#pragma unroll
     for (int r = 0; r < 3; r++) tn[r] = RE[r * 3] * T.t[0] + RE[r * 3 + 1] * T.t[1] + RE[r * 3 + 2] * T.t[2] + te[r];
     p_quat_norm(qn);
+#pragma unroll
     for (int i = 0; i < 4; i++) T.q[i] = qn[i];
+#pragma unroll
     for (int i = 0; i < 3; i++) T.t[i] = tn[i];
     p_set_Rt(T);
 }
-__device__ bool p_solve6(const double* H, const double* b, double lam, double* x) {   // LDL^T, fails on a zero / non-finite pivot
-    double M[36], L[36], d[6];
-    for (int i = 0; i < 36; i++) { M[i] = H[i] + ((i % 7 == 0) ? lam : 0.0); L[i] = 0; }
+__device__ __forceinline__ bool p_solve6(const double* H, const double* b, double lam, double* x) {   // LDL^T, fails on a zero / non-finite pivot
+    // fully unrolled with compile-time indices: the 6x6 system stays in registers (runtime-indexed arrays live in scratch,
+    // one L2 round trip per access on the serial path of every LM trial)
+    double M[6][6], L[6][6], d[6], y[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) { M[i][j] = H[i * 6 + j] + (i == j ? lam : 0.0); L[i][j] = 0; }
+    bool ok = true;
+#pragma unroll
     for (int j = 0; j < 6; j++) {
-        double dj = M[j * 6 + j];
-        for (int k = 0; k < j; k++) dj -= L[j * 6 + k] * L[j * 6 + k] * d[k];
+        double dj = M[j][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) dj -= L[j][k] * L[j][k] * d[k];
         d[j] = dj;
-        if (dj == 0.0 || !isfinite(dj)) return false;
-        for (int i = j + 1; i < 6; i++) { double v = M[i * 6 + j]; for (int k = 0; k < j; k++) v -= L[i * 6 + k] * L[j * 6 + k] * d[k]; L[i * 6 + j] = v / dj; }
+        ok = ok && !(dj == 0.0 || !isfinite(dj));
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            double v = M[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k] * d[k];
+            L[i][j] = v / dj;
+        }
     }
-    for (int i = 0; i < 6; i++) { double v = b[i]; for (int k = 0; k < i; k++) v -= L[i * 6 + k] * x[k]; x[i] = v; }
-    for (int i = 0; i < 6; i++) x[i] /= d[i];
-    for (int i = 5; i >= 0; i--) { double v = x[i]; for (int k = i + 1; k < 6; k++) v -= L[k * 6 + i] * x[k]; x[i] = v; }
+    if (!ok) return false;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double v = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) v -= L[i][k] * y[k];
+        y[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) y[i] /= d[i];
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        double v = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) v -= L[k][i] * y[k];
+        y[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] = y[i];
     return true;
 }
 
