@@ -13,20 +13,24 @@
 // MI355X design.  The problem is tiny for this chip (~26k edges, 3000 landmarks, <=64 free poses), so the enemy is latency,
 // not bandwidth: the whole LM control flow lives in a device-resident state machine (BAState) and the host only enqueues a
 // fixed sequence of "steps" (one LM trial each) — no host synchronisation inside a pass.  Every kernel starts by reading the
-// state and returns immediately once the pass is done.  One step = 4 launches (+ lin at the first trial of a pass):
+// state and returns immediately once the pass is done.  One step = TWO launches (+ lin in front of a pass, decide behind a
+// round of steps); the state lives in two slots, step s reads slot s&1 and leaves the state it ran with in the other one:
 //   lin     (first trial of a pass only)  8 lanes per landmark: errors, Huber weights, Hll, bl, per-edge Hpl blocks;
 //                                          8 workgroups per free camera: Hpp, bp partials (deterministic tree reduction)
-//   schur   one workgroup per (camera i1 <= i2, landmark chunk): partial Hpl D^-1 Hpl^T blocks of the reduced system;
-//           plus the camera workgroups (Hpp, bp at the current estimate) on every trial but the first
-//   solve   one workgroup: S = Hpp + lambda I - sum of partials, dense blocked LDL^T of the <=384x384 system (LDS when
-//           n <= 120), pose update T <- exp(dx) T into the trial buffer
-//   backsub 8 lanes per landmark: dx_l = D^-1 (b_l - Hpl^T dx_p), trial point, trial errors, partial chi2 / scale sums, and
-//           speculatively the linearisation AT THE TRIAL estimate into the trial half of the double-buffered Hll/bl/Hpl:
-//           accepting a trial flips estimate and linearisation together, so no lin launch follows it
-//   decide  one wave: rho, accept (flip current<->trial buffers) or reject (lambda *= nu), iteration/termination logic
-// (Folding solve and decide into the last-finishing workgroup of their producer launch — the threadfence-reduction pattern —
+//   schur   prologue in EVERY workgroup: apply the accept/reject decision of the previous trial (rho, flip current<->trial
+//           or lambda *= nu, iteration/termination logic) to the state — same sums, same code, same result everywhere;
+//           workgroup 0 publishes it.  Then one workgroup per (camera i1 <= i2, landmark chunk): partial Hpl D^-1 Hpl^T
+//           blocks of the reduced system; plus the camera workgroups (Hpp, bp) on every trial but the first
+//   backsub prologue in EVERY workgroup (reduced system in LDS, n <= 120): S = Hpp + lambda I - sum of partials, blocked
+//           look-ahead LDL^T, substitution, pose update T <- exp(dx) T into the trial buffer — 94 identical solves in
+//           parallel instead of a one-workgroup launch.  Then 8 lanes per landmark: dx_l = D^-1 (b_l - Hpl^T dx_p), trial
+//           point, trial errors, partial chi2 / scale sums, and speculatively the linearisation AT THE TRIAL estimate into
+//           the trial half of the double-buffered Hll/bl/Hpl: accepting a trial flips estimate and linearisation together
+//   solve   stand-alone one-workgroup form of the solve for systems that need the HBM workspace (120 < n <= 384)
+//   decide  stand-alone form of the decision, closes a round of enqueued steps (one wave)
+// (Folding solve and decide into the LAST-FINISHING workgroup of their producer launch — the threadfence-reduction pattern —
 // was measured and rejected: the agent-scope fences write back / invalidate the per-XCD L2s once per workgroup and cost
-// 15 us per step, five times the kernel boundary they save.)
+// 15 us per step, five times the kernel boundary they save.  Redundant execution needs no fence.)
 // All reductions run in a fixed order, so results are run-to-run deterministic.  MFMA is not used: the only dense algebra is
 // 6x3·3x3·3x6 products per landmark pair (fp64) — far below any matrix-core tile; see DESIGN.md.
 #include <cfloat>
