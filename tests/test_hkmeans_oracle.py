@@ -48,3 +48,29 @@ def test_hkmeans_restatement_matches_real_xflann(oracle, name):
             i1, d1 = oracle_lib.ref_hkmeans_search(ref, train, queries, nn, k, 0, mc, srt)
             np.testing.assert_array_equal(i0, i1, err_msg=f"{name} k={k} nn={nn} maxChecks={mc} sorted={srt}")
             np.testing.assert_array_equal(d0, d1)
+
+
+GOLD = __import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "hkmeans_golden.npz")
+
+
+@pytest.mark.parametrize("case", ["rand", "low_entropy", "tiny", "k_plus_1"])
+def test_hkmeans_oracle_and_host_build_match_committed_golden(oracle, case):
+    """Same comparison against vectors recorded from the real xflann (tests/golden/make_hkmeans_golden.py): works where
+    /root/reference and oracle/_ref do not exist.  The product's host-side build is checked against the same bytes."""
+    import hashlib
+
+    from ucoslam_cv3_amd.knn import kmeans_build_host
+
+    g = np.load(GOLD)
+    train, q = g[f"{case}_train"], g[f"{case}_q"]
+    for k in (32, 8):
+        blob = oracle_lib.hkmeans_blob(oracle, train, k, 0)
+        assert len(blob) == int(g[f"{case}_k{k}_blob_size"][0])
+        assert hashlib.sha256(blob.tobytes()).digest() == g[f"{case}_k{k}_blob_sha256"].tobytes()
+        if f"{case}_k{k}_blob" in g.files:
+            assert blob.tobytes() == g[f"{case}_k{k}_blob"].tobytes()
+        assert kmeans_build_host(train, k).tobytes() == blob.tobytes()
+        for nn, mc, s in ((10, 16, 0), (10, 16, 1), (5, 1, 0), (3, 40, 0), (2, 3, 0)):
+            i, d = oracle_lib.hkmeans_search(oracle, blob, q, nn, mc, s)
+            np.testing.assert_array_equal(i, g[f"{case}_k{k}_nn{nn}_mc{mc}_s{s}_idx"])
+            np.testing.assert_array_equal(d, g[f"{case}_k{k}_nn{nn}_mc{mc}_s{s}_dist"])

@@ -55,3 +55,21 @@ def test_restated_kdtree_matches_real_picoflann(oracle, name):
         inside = np.nonzero(dx * dx + dy * dy < float(np.float32(r)) ** 2)[0]
         assert sorted(i0.tolist()) == inside.tolist()
     assert nhits > 0
+
+
+GOLD = __import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "kdtree_golden.npz")
+
+
+@pytest.mark.parametrize("case", ["uniform", "ties", "small"])
+def test_restated_kdtree_matches_committed_golden(oracle, case):
+    """Radius-search hits, ORDER and squared distances recorded from the real picoflann.h (tests/golden/make_kdtree_golden.py):
+    pins the restatement where /root/reference and oracle/_ref do not exist."""
+    g = np.load(GOLD)
+    xy = g[f"{case}_xy"]
+    kd = oracle_lib.KdOracle(oracle, "oracle_kd", xy)
+    off = g[f"{case}_off"]
+    for t, (q, r) in enumerate(zip(g[f"{case}_q"], g[f"{case}_r"])):
+        i, d = kd.radius(q[0], q[1], r)
+        assert i.tolist() == g[f"{case}_idx"][off[t]:off[t + 1]].tolist(), (case, t)
+        assert d.tolist() == g[f"{case}_sqd"][off[t]:off[t + 1]].tolist()
+    assert off[-1] > 100
