@@ -112,7 +112,7 @@ __device__ void p_oplus(PoseD& T, const double* d) {   // T <- exp(d) * T
 __device__ __forceinline__ bool p_solve6(const double* H, const double* b, double lam, double* x) {   // LDL^T, fails on a zero / non-finite pivot
     // fully unrolled with compile-time indices: the 6x6 system stays in registers (runtime-indexed arrays live in scratch,
     // one L2 round trip per access on the serial path of every LM trial)
-    double M[6][6], L[6][6], d[6], y[6];
+    double M[6][6], L[6][6], d[6], id[6], y[6];
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
@@ -125,12 +125,13 @@ __device__ __forceinline__ bool p_solve6(const double* H, const double* b, doubl
         for (int k = 0; k < j; k++) dj -= L[j][k] * L[j][k] * d[k];
         d[j] = dj;
         ok = ok && !(dj == 0.0 || !isfinite(dj));
+        id[j] = 1.0 / dj;   // one division per pivot; the column and the substitution multiply by it
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
             double v = M[i][j];
 #pragma unroll
             for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k] * d[k];
-            L[i][j] = v / dj;
+            L[i][j] = v * id[j];
         }
     }
     if (!ok) return false;
@@ -142,7 +143,7 @@ __device__ __forceinline__ bool p_solve6(const double* H, const double* b, doubl
         y[i] = v;
     }
 #pragma unroll
-    for (int i = 0; i < 6; i++) y[i] /= d[i];
+    for (int i = 0; i < 6; i++) y[i] *= id[i];
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
         double v = y[i];
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
     __shared__ double s_part[4 * 28], s_sum[28], s_red[kRedThreads];
     __shared__ PoseD s_T, s_T0, s_bak;
     __shared__ double s_H[36], s_b[6], s_x[6];
-    __shared__ double s_lambda, s_ni, s_currentChi, s_lastChiRaw;
+    __shared__ double s_lambda, s_ni, s_currentChi, s_lastChiRaw, s_rho;
     __shared__ int s_ok2, s_again, s_ok, s_iter_cont, s_good;
     __shared__ float s_prev, s_cur;
     const int tid = threadIdx.x, n = A.n;
@@ -310,11 +311,11 @@ __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
                         if (!isfinite(s_lambda)) lam_finite = false;
                     }
                     s_x[0] = s_x[0];
-                    s_red[0] = r;                    // publish rho
+                    s_rho = r;                       // publish rho
                     s_again = lam_finite ? 1 : 0;    // 0 -> break before qmax++
                 }
                 __syncthreads();
-                rho = s_red[0];
+                rho = s_rho;
                 const int lam_ok = s_again;
                 __syncthreads();
                 if (!lam_ok) break;

@@ -6,16 +6,18 @@ namespace {
 
 constexpr int kRedThreads = 256;
 
-// deterministic block sum (fixed tree) of one double per thread; result valid in thread 0
+// deterministic block sum of one double per thread, result valid in EVERY thread: xor butterfly inside each wave (fixed
+// pairing, all 64 lanes end with the wave total), then the wave totals are added in wave order.  Two barriers instead of the
+// nine of an LDS tree — the fp64 kernels call this on their serial paths.
 __device__ __forceinline__ double block_sum(double v, double* s_red) {
-    s_red[threadIdx.x] = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();   // a previous call's readers are done with s_red
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
     __syncthreads();
-    for (int o = kRedThreads / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
-        __syncthreads();
-    }
-    const double r = s_red[0];
-    __syncthreads();
+    double r = s_red[0];
+#pragma unroll
+    for (int w = 1; w < kRedThreads / 64; w++) r += s_red[w];
     return r;
 }
 // Deterministic block reduction of N values per thread.  Inside a wave the N x 64 values are reduced with a butterfly
@@ -61,16 +63,15 @@ __device__ __forceinline__ void block_sum_vec(double (&v)[N], double* s_part /* 
 }
 
 __device__ __forceinline__ double block_max(double v, double* s_red) {
-    s_red[threadIdx.x] = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     __syncthreads();
-    for (int o = kRedThreads / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) s_red[threadIdx.x] = fmax(s_red[threadIdx.x], s_red[threadIdx.x + o]);
-        __syncthreads();
-    }
-    const double r = s_red[0];
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
     __syncthreads();
+    double r = s_red[0];
+#pragma unroll
+    for (int w = 1; w < kRedThreads / 64; w++) r = fmax(r, s_red[w]);
     return r;
 }
-
 
 }  // namespace
