@@ -200,8 +200,9 @@ struct PmPose { float T[12]; float cc[3]; };
 
 __device__ __forceinline__ float logf_cr(float x) { return uh_sincosf::logf_glibc(x); }   // libm's logf, bit for bit
 
-// Walk records: rec = (a << 2) | kind with kind 1: best child of node a done (m = mindistsq on entry), 2: dists[a] = m; a
-// node to visit next is carried in registers (cur / cur_m), not pushed.  One record per tree level on the path.
+// Walk records (one per tree level at most): (other child << 2) | (col << 1) | state, with the other child's mindistsq, the
+// cut distance and the float dists[col] to restore; state 0 = other child still to be searched, 1 = being searched (restore
+// dists[col] when it is done).  The node to visit next is carried in registers (cur / cur_m), not pushed.
 //
 // Work decomposition: kGroup = 16 lanes per map point, 4 points per wave, 4 waves per workgroup; a workgroup stages the frame
 // in LDS once and then loops over chunks of 16 map points.  The lanes of a group walk
@@ -232,7 +233,11 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
     if (IN_LDS) off += ((size_t)n + 15) & ~(size_t)15;
     double* st_m = reinterpret_cast<double*>(smem + off) + (size_t)g * levels;
     off += (size_t)levels * kGroupsPerWave * 8;
+    double* st_c = reinterpret_cast<double*>(smem + off) + (size_t)g * levels;
+    off += (size_t)levels * kGroupsPerWave * 8;
     int* st_rec = reinterpret_cast<int*>(smem + off) + (size_t)g * levels;
+    off += (size_t)levels * kGroupsPerWave * 4;
+    float* st_d = reinterpret_cast<float*>(smem + off) + (size_t)g * levels;
     off += (size_t)levels * kGroupsPerWave * 4;
     unsigned int* s_cand = reinterpret_cast<unsigned int*>(smem + off) + (size_t)g * kCandCap;
     off += (size_t)kCandCap * kGroupsPerWave * 4;
@@ -336,23 +341,34 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
             if (ey < f.box[2]) { const double d = ey - f.box[2]; dd1 = d * d; distsq += dd1; }
             if (ey > f.box[3]) { const double d = ey - f.box[3]; dd1 = d * d; distsq += dd1; }
         }
+        // Iterative searchExactLevel.  At an internal node everything the recursion does AFTER its best child returns is
+        // already known when the node is entered: dst = (float)dists[col] (deeper levels only ever leave dists[col] rounded
+        // to float, which the (float) cast hides), hence mindistsq' = mindistsq + cut - dst and whether the other child
+        // will be searched at all.  Only nodes whose other child WILL be searched leave a record (most do not); the record
+        // is turned into "restore dists[col]" in place when the other child is entered.
         int sp = 0;
-        int cur = 0;                 // node to visit (-1: pop a record)
+        int cur = 0;                 // node to visit (-1: take the top record)
         double cur_m = (double)distsq;
         for (;;) {
-            int kind = 0, ra = cur;
-            double rm = cur_m;
             if (cur < 0) {
                 if (sp == 0) break;
-                --sp;
-                const int rec = st_rec[sp];
-                rm = st_m[sp];
-                kind = rec & 3; ra = rec >> 2;
-                if (kind == 2) { if (ra == 0) dd0 = rm; else dd1 = rm; continue; }
+                const int rec = st_rec[sp - 1];
+                const int col = (rec >> 1) & 1;
+                if (rec & 1) {       // the other child's subtree is done: dists[col] = dst
+                    const double dstd = (double)st_d[sp - 1];
+                    if (col == 0) dd0 = dstd; else dd1 = dstd;
+                    --sp;
+                    continue;
+                }
+                const double cutv = st_c[sp - 1];   // enter the other child: dists[col] = cut
+                if (col == 0) dd0 = cutv; else dd1 = cutv;
+                cur = rec >> 2;
+                cur_m = st_m[sp - 1];
+                if (gl == 0) st_rec[sp - 1] = rec | 1;
             }
             KdNodeDev nd;
-            if (IN_LDS) nd = s_nodes[ra]; else nd = f.nodes[ra];
-            if (nd.left < 0) {   // leaf (kind 0): lane i of the group tests keypoint i; hits are appended in leaf order
+            if (IN_LDS) nd = s_nodes[cur]; else nd = f.nodes[cur];
+            if (nd.left < 0) {   // leaf: lane i of the group tests keypoint i; hits are appended in leaf order
                 bool hit = false;
                 unsigned int id = 0;
                 int oc = 0;
@@ -376,20 +392,17 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
             const double diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
             const bool go_left = diff1 + diff2 < 0;
             const double cut = go_left ? diff2 * diff2 : diff1 * diff1;
-            if (sp + 1 > levels) { ovf = true; break; }
-            if (kind == 0) {
-                if (gl == 0) { st_rec[sp] = (ra << 2) | 1; st_m[sp] = rm; }
+            const float dst = (float)(nd.col == 0 ? dd0 : dd1);
+            const double m2 = cur_m + cut - dst;
+            if (m2 * 1.0 <= worst) {
+                if (sp + 1 > levels) { ovf = true; break; }
+                if (gl == 0) {
+                    st_rec[sp] = ((go_left ? nd.right : nd.left) << 2) | ((int)nd.col << 1);
+                    st_m[sp] = m2; st_c[sp] = cut; st_d[sp] = dst;
+                }
                 sp++;
-                cur = go_left ? nd.left : nd.right; cur_m = rm;
-            } else {   // the best child's subtree is done: maybe the other one, then restore dists[col]
-                const float dst = (float)(nd.col == 0 ? dd0 : dd1);
-                const double m2 = rm + cut - dst;
-                if (nd.col == 0) dd0 = cut; else dd1 = cut;
-                if (gl == 0) { st_rec[sp] = ((int)nd.col << 2) | 2; st_m[sp] = (double)dst; }
-                sp++;
-                if (m2 * 1.0 <= worst) { cur = go_left ? nd.right : nd.left; cur_m = m2; }
-                else cur = -1;
             }
+            cur = go_left ? nd.left : nd.right;   // best child, same mindistsq
         }
     }
     if (!ovf) drain(ncand);
@@ -550,7 +563,7 @@ int uh_projmatch_match(uh_projmatch* h, const float* pose_f2g, const uh_map_poin
     }
     {
         const int n_nodes = (int)h->kd.nodes.size(), levels = h->kd.max_depth + 2;
-        const size_t stack_bytes = (size_t)levels * kGroupsPerWave * 12 + (size_t)kCandCap * kGroupsPerWave * 8 + 64;
+        const size_t stack_bytes = (size_t)levels * kGroupsPerWave * 24 + (size_t)kCandCap * kGroupsPerWave * 8 + 64;
         const size_t tree_bytes = (((size_t)n_nodes * sizeof(KdNodeDev) + 15) & ~(size_t)15) + 12 * (size_t)h->n_kpts + (((size_t)h->n_kpts + 15) & ~(size_t)15);
         const bool in_lds = tree_bytes + stack_bytes <= kLdsBudget && !getenv("UH_PROJMATCH_NO_LDS");   // env: test knob for the big-frame path
         const size_t lds = stack_bytes + (in_lds ? tree_bytes : 0);
