@@ -152,6 +152,8 @@ int  uh_orb_set_params(uh_orb* orb, const uh_feat_params* params);
 int  uh_orb_get_params(const uh_orb* orb, uh_feat_params* params);
 int  uh_orb_set_blur(uh_orb* orb, int do_blur);            /* ORBextractor::doGaussianBlur() (ORBextractor.h:112) */
 int  uh_orb_set_sensitivity(uh_orb* orb, float v);         /* ORBextractor::setSensitivity (ORBextractor.cpp:457-466) */
+int  uh_orb_set_nonmaxima(uh_orb* orb, int on);            /* debug string "orb_nonmaxima" (ORBextractor.cpp:1146-1148,1176-1205): radius-3
+                                                              suppression per level before the descriptors; kept keypoints get class_id 1 */
 int  uh_orb_max_keypoints(const uh_orb* orb);              /* = maxFeatures: upper bound of *n_out */
 
 /* One frame, host buffers: img = h rows of w bytes (CV_8UC1), row stride in bytes.

@@ -370,6 +370,7 @@ struct Extractor {
     }
 
     mutable bool threw = false;   // the reference would have thrown a cv::Exception (cell outside the level image)
+    bool nonMaximaSuppression = false;   // ORBextractor.h:189, switched on by the debug string "orb_nonmaxima"
 
     void keypoints_level(int level, std::vector<KeyPoint>& keypoints) const {   // ORBextractor.cpp:899-1078
         const Image& im = pyr[level];
@@ -490,6 +491,24 @@ struct Extractor {
             std::vector<KeyPoint> lk;
             keypoints_level(l, lk);
             if (threw) { kps.clear(); desc.clear(); return kRefThrows; }
+            if (nonMaximaSuppression) {   // processLevel :1176-1205 (debug string "orb_nonmaxima")
+                // kdtree.radiusSearch(res, keypoints, keypoints[i], 3) = every keypoint with squared distance < 9 (picoflann's
+                // radius search returns exactly the brute-force disc, see proj_oracle.cpp / test_projmatch_oracle.py; the
+                // order inside `res` is irrelevant for a maximum and for marking all smaller ones)
+                for (KeyPoint& k : lk) k.class_id = 1;
+                for (size_t i = 0; i < lk.size(); i++) {
+                    if (!lk[i].class_id) continue;
+                    int maxResponse = 0;
+                    std::vector<size_t> res;
+                    for (size_t j = 0; j < lk.size(); j++) {
+                        const double dx = lk[i].x - lk[j].x, dy = lk[i].y - lk[j].y;
+                        if (dx * dx + dy * dy < 9.0) res.push_back(j);
+                    }
+                    for (size_t j : res) if (lk[j].response > maxResponse) maxResponse = lk[j].response;
+                    for (size_t j : res) if (lk[j].response < maxResponse) lk[j].class_id = 0;
+                }
+                lk.erase(std::remove_if(lk.begin(), lk.end(), [](const KeyPoint& k) { return k.class_id == 0; }), lk.end());
+            }
             const Image& im = pyr[l];
             int maxX = im.w - 19, maxY = im.h - 19;   // computeDescriptors :1120-1137
             lk.erase(std::remove_if(lk.begin(), lk.end(), [&](const KeyPoint& k) {
@@ -518,6 +537,24 @@ int oracle_orb_extract(const uint8_t* img, int w, int h, size_t stride, int maxF
     e.nlevels = nlevels;
     e.scaleFactor = scaleFactor;
     e.blurFirst = blurFirst != 0;
+    std::vector<KeyPoint> kps;
+    std::vector<uint8_t> desc;
+    int n = e.extract(img, w, h, stride, kps, desc);
+    if (n < 0) return n;
+    if (n > cap) return -n;
+    if (n) { std::memcpy(kp_out, kps.data(), (size_t)n * sizeof(KeyPoint)); std::memcpy(desc_out, desc.data(), (size_t)n * 32); }
+    return n;
+}
+
+// same with the "orb_nonmaxima" switch (radius-3 suppression per level, kept keypoints carry class_id 1)
+int oracle_orb_extract_nonmaxima(const uint8_t* img, int w, int h, size_t stride, int maxFeatures, int nlevels, float scaleFactor,
+                                 int blurFirst, void* kp_out, uint8_t* desc_out, int cap) {
+    Extractor e;
+    e.maxFeatures = maxFeatures;
+    e.nlevels = nlevels;
+    e.scaleFactor = scaleFactor;
+    e.blurFirst = blurFirst != 0;
+    e.nonMaximaSuppression = true;
     std::vector<KeyPoint> kps;
     std::vector<uint8_t> desc;
     int n = e.extract(img, w, h, stride, kps, desc);

@@ -57,15 +57,16 @@ KEYPOINT_DTYPE = _np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle
                             ("octave", "<i4"), ("class_id", "<i4")])
 
 
-def orb_extract(L, img, maxFeatures=2000, nlevels=8, scaleFactor=1.2, blur=True):
+def orb_extract(L, img, maxFeatures=2000, nlevels=8, scaleFactor=1.2, blur=True, nonmaxima=False):
     cap = max(maxFeatures, 1)
     kps = _np.zeros(cap, KEYPOINT_DTYPE)
     desc = _np.zeros((cap, 32), _np.uint8)
-    L.oracle_orb_extract.restype = I
-    L.oracle_orb_extract.argtypes = [VP, I, I, SZ, I, I, C.c_float, I, VP, VP, I]
+    fn = L.oracle_orb_extract_nonmaxima if nonmaxima else L.oracle_orb_extract
+    fn.restype = I
+    fn.argtypes = [VP, I, I, SZ, I, I, C.c_float, I, VP, VP, I]
     img = _np.ascontiguousarray(img)
-    n = L.oracle_orb_extract(P(img), img.shape[1], img.shape[0], img.strides[0], maxFeatures, nlevels, scaleFactor, int(blur),
-                             P(kps), P(desc), cap)
+    n = fn(P(img), img.shape[1], img.shape[0], img.strides[0], maxFeatures, nlevels, scaleFactor, int(blur),
+           P(kps), P(desc), cap)
     assert n >= 0, n
     return kps[:n].copy(), desc[:n].copy()
 

@@ -91,3 +91,29 @@ def test_hip_orb_batch_resident_frames(hip_ctx, oracle):
         n = counts[f]
         got = kps[f, :n].copy().view(KEYPOINT_DTYPE).reshape(-1)
         _assert_same(got, desc[f, :n], rk, rd, f"batch frame {f}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(640, 480, 2000, 8, 1.2, 1), (1241, 376, 4000, 8, 1.2, 2), (320, 240, 600, 4, 1.2, 3), (500, 400, 3000, 3, 1.5, 4)],
+                         ids=lambda c: f"{c[0]}x{c[1]}_n{c[2]}_l{c[3]}")
+def test_hip_orb_nonmaxima_switch_bit_exact(hip_ctx, oracle, cfg):
+    """debug string "orb_nonmaxima": the sequential, order-dependent radius-3 suppression per level (ORBextractor.cpp:1176-1205)."""
+    from ucoslam_cv3_amd.orb import FeatParams, ORBextractor
+
+    w, h, nf, nl, sf, seed = cfg
+    img = synth.frame(w, h, seed=seed)
+    if seed == 4:
+        img = (img.astype(np.int32) // 8 * 8).astype(np.uint8)    # plateaus: many equal responses next to each other
+    ext = ORBextractor.create(hip_ctx)
+    ext.setNonMaxima(True)
+    kps, desc = ext.detectAndCompute(img, None, FeatParams(nf, nl, sf))
+    rk, rd = oracle_lib.orb_extract(oracle, img, nf, nl, sf, nonmaxima=True)
+    assert len(kps) == len(rk) > 50
+    for f in ("x", "y", "angle", "response", "octave", "size", "class_id"):
+        np.testing.assert_array_equal(kps[f], rk[f], err_msg=f)
+    np.testing.assert_array_equal(desc, rd)
+    plain, _ = oracle_lib.orb_extract(oracle, img, nf, nl, sf)
+    assert len(rk) < len(plain)
+    ext.setNonMaxima(False)                                       # the switch can be cleared again here (sticky in the reference)
+    kps2, _ = ext.detectAndCompute(img, None, FeatParams(nf, nl, sf))
+    assert len(kps2) == len(plain) and (kps2["class_id"] == -1).all()

@@ -182,3 +182,23 @@ def test_device_sincosf_restatement_equals_libm(tmp_path):
     out = subprocess.run([exe, "13"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "mismatches 0" in out.stdout
+
+
+def test_orb_nonmaxima_switch(oracle):
+    """The "orb_nonmaxima" debug switch (ORBextractor.cpp:1176-1205): fewer keypoints, every survivor also present without the
+    switch (same position / response / descriptor), survivors carry class_id 1, and no survivor has a surviving strictly
+    stronger neighbour within radius 3 on its level."""
+    import synth
+
+    img = synth.frame(400, 300, seed=5)
+    k0, d0 = oracle_lib.orb_extract(oracle, img, 1500, 4, 1.2)
+    k1, d1 = oracle_lib.orb_extract(oracle, img, 1500, 4, 1.2, nonmaxima=True)
+    assert 50 < len(k1) < len(k0)
+    assert (k0["class_id"] == -1).all() and (k1["class_id"] == 1).all()
+    key0 = {(float(a["x"]), float(a["y"]), int(a["octave"])): i for i, a in enumerate(k0)}
+    for j, a in enumerate(k1):
+        i = key0[(float(a["x"]), float(a["y"]), int(a["octave"]))]
+        assert k0["response"][i] == a["response"] and (d0[i] == d1[j]).all()
+    # the surviving order is the original order
+    idx = [key0[(float(a["x"]), float(a["y"]), int(a["octave"]))] for a in k1]
+    assert idx == sorted(idx)

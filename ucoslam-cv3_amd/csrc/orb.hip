@@ -555,12 +555,66 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
+// ------------------------------------------------------------------------------------------------ optional radius-3 NMS
+// ORBextractor::processLevel with the debug switch "orb_nonmaxima" (ORBextractor.cpp:1146-1148,1176-1205): after the per-level
+// keypoint selection and before the descriptors, visit the level's keypoints IN ORDER; a keypoint that is still a possible
+// maximum looks at every keypoint within radius 3 of it (squared distance < 9, itself included; suppressed ones count too)
+// and marks all of them whose response is below the largest response found there.  The visiting order matters (a keypoint
+// suppressed before its turn never suppresses its own neighbourhood), so this is a sequential walk: one wave per (level,
+// frame), the 64 lanes scan the level's list for the disc of the current keypoint.  picoflann's radius search returns
+// exactly the brute-force disc (tests/test_projmatch_oracle.py), and max / mark-all do not depend on the order inside it.
+__global__ __launch_bounds__(64) void nonmax_kernel(const Plan plan, uint32_t* __restrict__ sel, size_t sel_frame_stride,
+                                                    int* __restrict__ level_counts) {
+    extern __shared__ uint32_t s_list[];   // n entries, then n class bytes
+    const int lvl = blockIdx.x, frame = blockIdx.y, lane = threadIdx.x;
+    int* cnt = level_counts + (size_t)frame * kMaxLevels + lvl;
+    const int n = *cnt;
+    if (n <= 0) return;
+    uint32_t* list = sel + (size_t)frame * sel_frame_stride + plan.lv[lvl].sel_off;
+    unsigned char* s_cls = reinterpret_cast<unsigned char*>(s_list + n);
+    for (int i = lane; i < n; i += 64) { s_list[i] = list[i]; s_cls[i] = 1; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = 0; i < n; i++) {
+        if (!s_cls[i]) continue;                       // wave-uniform
+        const uint32_t ei = s_list[i];
+        const int xi = ei & 0xFFF, yi = (ei >> 12) & 0xFFF;
+        int mx = 0;                                    // int maxResponse = 0
+        for (int j = lane; j < n; j += 64) {
+            const uint32_t e = s_list[j];
+            const int dx = xi - (int)(e & 0xFFF), dy = yi - (int)((e >> 12) & 0xFFF);
+            if (dx * dx + dy * dy < 9) mx = max(mx, (int)(e >> 24));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+        for (int j = lane; j < n; j += 64) {
+            const uint32_t e = s_list[j];
+            const int dx = xi - (int)(e & 0xFFF), dy = yi - (int)((e >> 12) & 0xFFF);
+            if (dx * dx + dy * dy < 9 && (int)(e >> 24) < mx) s_cls[j] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // std::remove_if: stable compaction
+    int kept = 0;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const bool keep = j < n && s_cls[j] != 0;
+        const unsigned long long m = __ballot(keep);
+        if (keep) list[kept + __popcll(m & ((1ull << lane) - 1ull))] = s_list[j];
+        kept += __popcll(m);
+    }
+    if (lane == 0) *cnt = kept;
+}
+
 // One wave per output keypoint slot; 4 waves per block.
 __global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const uint8_t* __restrict__ pyr,
                                                        size_t frame_stride, const uint32_t* __restrict__ sel,
                                                        size_t sel_frame_stride, const int* __restrict__ level_counts,
                                                        KeyPointOut* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                       int cap_per_frame, int* __restrict__ frame_counts) {
+                                                       int cap_per_frame, int* __restrict__ frame_counts, int class_id) {
     const int frame = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -615,7 +669,7 @@ __global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const ui
         k.angle = angle;
         k.response = (float)resp;
         k.octave = lvl;
-        k.class_id = -1;
+        k.class_id = class_id;   // -1; 1 when the radius-3 suppression ran (it uses class_id as its flag and leaves it, :1179)
         kps[o] = k;
     }
 }
@@ -655,6 +709,8 @@ struct uh_orb {
     uh_feat_params fp{-1, 4000, 8, 1.2f, 0.f};
     bool planned = false;
     bool blur_first = true;        // ORBextractor::doGaussianBlur()
+    bool nonmaxima = false;        // debug::Debug::isString("orb_nonmaxima") (ORBextractor.cpp:1146-1148)
+    bool nm_attr = false;
     int iniTh = 20, minTh = 7;     // precalculateParams resets these on every parameter change (:478-479)
     Plan plan;
     std::vector<CellDesc> cells;
@@ -848,10 +904,19 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
                        o->d_cells.as<CellDesc>(), o->d_cand.as<uint32_t>(), o->cand_stride, o->d_cell_counts.as<int>(),
                        o->d_work.as<uint32_t>(), o->cand_stride * 2, o->d_sel.as<uint32_t>(), o->sel_stride,
                        o->d_level_counts.as<int>(), o->lds_entries);
+    if (o->nonmaxima) {
+        const size_t lds = (size_t)std::max(P.maxFeatures, 1) * 5 + 64;
+        UH_REQUIRE(lds <= 150 * 1024, "orb: orb_nonmaxima with %d features per level does not fit LDS", P.maxFeatures);
+        if (!o->nm_attr) {
+            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(nonmax_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            o->nm_attr = true;
+        }
+        UH_LAUNCH(o->ctx,nonmax_kernel, dim3(P.nlevels, batch), dim3(64), lds, P, o->d_sel.as<uint32_t>(), o->sel_stride, o->d_level_counts.as<int>());
+    }
     const int slots = std::min(std::max(P.maxFeatures, 1), std::max(cap_per_frame, 1));
     UH_LAUNCH(o->ctx,describe_kernel, dim3(uh_div_up(slots, 4), batch), dim3(256), 0, P, pyr, o->frame_stride,
                        o->d_sel.as<uint32_t>(), o->sel_stride, o->d_level_counts.as<int>(), d_kps, d_desc, cap_per_frame,
-                       d_counts);
+                       d_counts, o->nonmaxima ? 1 : -1);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
 }
@@ -889,6 +954,13 @@ int uh_orb_get_params(const uh_orb* o, uh_feat_params* fp) {
 int uh_orb_set_blur(uh_orb* o, int do_blur) {
     UH_REQUIRE(o, "uh_orb_set_blur: NULL");
     o->blur_first = do_blur != 0;
+    return UH_OK;
+}
+
+// the reference's debug switch "orb_nonmaxima" (debug::Debug::addString, ORBextractor.cpp:1146-1148): radius-3 suppression per level
+int uh_orb_set_nonmaxima(uh_orb* o, int on) {
+    UH_REQUIRE(o, "uh_orb_set_nonmaxima: NULL");
+    o->nonmaxima = on != 0;
     return UH_OK;
 }
 

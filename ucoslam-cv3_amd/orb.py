@@ -35,6 +35,7 @@ def _declare(L, sig):
     sig("uh_orb_get_params", I, VP, C.POINTER(FeatParams))
     sig("uh_orb_set_blur", I, VP, I)
     sig("uh_orb_set_sensitivity", I, VP, C.c_float)
+    sig("uh_orb_set_nonmaxima", I, VP, I)
     sig("uh_orb_max_keypoints", I, VP)
     sig("uh_orb_extract", I, VP, VP, I, I, SZ, VP, VP, I, C.POINTER(I))
     sig("uh_orb_extract_dev", I, VP, VP, I, I, SZ, SZ, I, VP, VP, I, VP)
@@ -74,6 +75,10 @@ class ORBextractor:
 
     def doGaussianBlur(self, flag: bool):
         check(lib().uh_orb_set_blur(self._h, int(flag)))
+
+    def setNonMaxima(self, flag: bool):
+        """The reference's debug switch: debug::Debug::addString("orb_nonmaxima") (ORBextractor.cpp:1146-1148)."""
+        check(lib().uh_orb_set_nonmaxima(self._h, int(flag)))
 
     # detectAndCompute(image, mask, keypoints, descriptors, params): mask is ignored (ORBextractor.cpp:1253)
     def detectAndCompute(self, image, mask=None, params: FeatParams | None = None):
