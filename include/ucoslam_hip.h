@@ -90,15 +90,16 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn,
  * (impl/kmeansindex.h:356-410): the APPROXIMATE index FrameMatcher_Flann builds per train frame (framematcher.cpp:213 k=32,
  * maxIters=0; :239 nn=10, maxChecks=16, unsorted).  Results are bit-identical to the reference: same tree (std::shuffle of a
  * default std::mt19937 picks the centres), same best-bin-first order, same ResultSet rows; unfilled slots index -1, distance 0.
- * build: host pointer, contiguous n x 32 bytes; only maxIters == 0; 2 <= k <= 64.  More than k identical descriptors make the
- * reference recurse without end: reported as UH_EINVAL.  uh_knn_kmeans_blob exposes the block data in the reference's own
+ * build: host pointer, contiguous n x 32 bytes; 2 <= k <= 64; maxIters as HKMeansParams (0 = the matcher's setting, -1 = until
+ * convergence; rounds move the centres to the bitwise majority of their clusters).  More than k identical descriptors make
+ * the reference recurse without end: reported as UH_EINVAL.  uh_knn_kmeans_blob exposes the block data in the reference's own
  * serialised layout (the bytes KMeansIndex::toStream writes after its 48-byte header).
  * search: maxChecks as the reference (<= 0 returns empty rows, like the reference's loop condition); the pairs (nn=1,maxChecks=1)
  * and (nn=2,maxChecks<=2) select other code in the reference and are refused. */
 int uh_knn_build_kmeans(uh_knn* idx, const uint8_t* features, int n, int k, int max_iters);
 int uh_knn_kmeans_blob(uh_knn* idx, const uint8_t** data, uint64_t* size);
 /* host-only build (test hook, no GPU): writes min(cap, size) bytes of the block data to out, the full size to *size */
-int uh_knn_kmeans_build_host(const uint8_t* features, int n, int k, uint8_t* out, uint64_t cap, uint64_t* size);
+int uh_knn_kmeans_build_host(const uint8_t* features, int n, int k, int max_iters, uint8_t* out, uint64_t cap, uint64_t* size);
 int uh_knn_search_kmeans(uh_knn* idx, const uint8_t* queries, int nq, int nn, int max_checks, int sorted,
                          int32_t* indices, int32_t* distances);
 int uh_knn_search_kmeans_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int max_checks, int sorted,

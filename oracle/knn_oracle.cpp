@@ -110,7 +110,7 @@ namespace {
 struct KmNode {
     std::vector<std::unique_ptr<KmNode>> children;
     std::vector<uint32_t> assign;
-    const uint8_t* feature = nullptr;   // centre (a row of the train matrix when maxIters == 0)
+    uint8_t feature[32] = {0};   // centre: a train row, or the bitwise majority of the cluster after k-means rounds
 };
 
 struct KmBuilder {
@@ -118,6 +118,37 @@ struct KmBuilder {
     int k, max_iters;
     bool unbounded = false;   // > k identical rows: the reference recurses without end
     int depth_guard = 0;
+
+    void assign_points(KmNode* parent) {   // assignPointsToChildren, kmeansindexcreator.h:305-322
+        for (auto& ch : parent->children) ch->assign.clear();
+        for (auto fi : parent->assign) {
+            KmNode* best = nullptr;
+            float bestd = std::numeric_limits<float>::max();
+            for (auto& ch : parent->children) {
+                const int32_t d = hamming32(ch->feature, train + 32 * (size_t)fi);
+                if (d < bestd) { best = ch.get(); bestd = (float)d; }
+                if (bestd < 1e-16) break;
+            }
+            best->assign.push_back(fi);
+        }
+    }
+    static void majority(const uint8_t* train, const std::vector<uint32_t>& idx, uint8_t* out) {   // MC_binary_generic :390-422
+        int sum[256] = {0};
+        for (auto i : idx) {
+            const uint8_t* p = train + 32 * (size_t)i;
+            for (int j = 0; j < 32; j++)
+                for (int b = 0; b < 8; b++) if (p[j] & (128 >> b)) ++sum[j * 8 + b];
+        }
+        std::memset(out, 0, 32);
+        const int N2 = (int)idx.size() / 2 + (int)(idx.size() % 2);
+        for (int i = 0; i < 256; i++) if (sum[i] >= N2) out[i / 8] |= (uint8_t)(1 << (7 - (i % 8)));
+    }
+    static size_t vhash(const KmNode* parent) {   // kmeansindexcreator.cpp:199-205
+        size_t seed = 0;
+        for (auto& ch : parent->children)
+            for (auto id : ch->assign) seed ^= id + 0x9e3779b9 + (seed << 6) + (seed >> 2);
+        return seed;
+    }
 
     void create(KmNode* parent) {
         if (++depth_guard > 64) { unbounded = true; --depth_guard; return; }
@@ -140,23 +171,33 @@ struct KmBuilder {
         }
         for (auto c : centers) {
             parent->children.emplace_back(new KmNode());
-            parent->children.back()->feature = train + 32 * (size_t)c;
+            std::memcpy(parent->children.back()->feature, train + 32 * (size_t)c, 32);
         }
-        // assignPointsToChildren
-        for (auto fi : parent->assign) {
-            KmNode* best = nullptr;
-            float bestd = std::numeric_limits<float>::max();
+        assign_points(parent);
+        // k-means rounds (:245-262): move the centres to the bitwise majority of their clusters until the assignment hash repeats
+        size_t prev_hash = 0, cur_hash = 1, niters = 0;
+        while (cur_hash != prev_hash && ((max_iters == -1) || (max_iters != -1 && niters++ < (size_t)max_iters))) {
+            std::swap(prev_hash, cur_hash);
+            int ci = 0;
             for (auto& ch : parent->children) {
-                const int32_t d = hamming32(ch->feature, train + 32 * (size_t)fi);
-                if (d < bestd) { best = ch.get(); bestd = (float)d; }
-                if (bestd < 1e-16) break;
+                if (ch->assign.empty()) ch->assign.push_back(centers[ci]);
+                majority(train, ch->assign, ch->feature);
+                ci++;
             }
-            best->assign.push_back(fi);
+            assign_points(parent);
+            cur_hash = vhash(parent);
         }
-        // maxIters > 0 would move the centres to cluster means here (:245-262); the path uses maxIters = 0
         parent->assign.clear();
         for (auto it = parent->children.begin(); it != parent->children.end();) {
             if ((*it)->assign.empty()) it = parent->children.erase(it); else ++it;
+        }
+        if (parent->children.size() == 1 && (int)parent->children[0]->assign.size() > k) {
+            // all rows fell into one cluster: the same split would repeat for ever (identical rows, or a majority centre
+            // that attracts everything)
+            bool same = true;   // only identical rows repeat exactly; distinct rows get distinct centres next time
+            const uint32_t f0 = parent->children[0]->assign[0];
+            for (auto fi : parent->children[0]->assign) if (hamming32(train + 32 * (size_t)fi, train + 32 * (size_t)f0) != 0) { same = false; break; }
+            if (same) { unbounded = true; --depth_guard; return; }
         }
         for (auto& ch : parent->children)
             if ((int)ch->assign.size() > k) create(ch.get());
@@ -169,7 +210,7 @@ inline uint64_t km_block_size(uint32_t n) { return pad_to(8 + 8 * n, 8) + (uint6
 
 // block data exactly as KMeansIndex stores it (alignment 8 for binary descriptors)
 int km_build_blob(const uint8_t* train, int nt, int k, int max_iters, std::vector<uint8_t>& blob) {
-    if (nt <= 0 || k < 1 || max_iters != 0) return -1;
+    if (nt <= 0 || k < 1 || max_iters < -1) return -1;
     KmNode root;
     root.assign.resize(nt);
     for (int i = 0; i < nt; i++) root.assign[i] = i;
@@ -205,7 +246,7 @@ int km_build_blob(const uint8_t* train, int nt, int k, int max_iters, std::vecto
             uint64_t info;
             const uint8_t* feat;
             if (leaf) { info = (uint64_t)nd->assign[j] | 0x8000000000000000ull; feat = train + 32 * (size_t)nd->assign[j]; }
-            else { info = offs[next_child++].second; feat = nd->children[j]->feature; }
+            else { info = offs[next_child++].second; feat = nd->children[j]->feature; }   // centre (train row or majority vector)
             std::memcpy(blk + 8 + 8 * j, &info, 8);
             std::memcpy(blk + hs + 32 * (size_t)j, feat, 32);
         }

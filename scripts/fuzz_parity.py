@@ -89,19 +89,20 @@ def km_case(seed):
         train = np.zeros((nt, 32), np.uint8); train[:, :2] = r.integers(0, 256, (nt, 2)); q = train[r.integers(0, nt, nq)].copy()
     else:
         train, q = synth.match_set(nq, nt, seed=seed % 1000)
-    blob = oracle_lib.hkmeans_blob(L, train, k, 0)
+    mi = int(r.choice([0, 0, 0, 1, 11, -1]))
+    blob = oracle_lib.hkmeans_blob(L, train, k, mi)
     idx = Index(ctx)
     if isinstance(blob, int):
         try:
-            idx.build_kmeans(train, k, 0)
+            idx.build_kmeans(train, k, mi)
             return False, "expected an error"
         except u.UcoslamHipError:
             return True, None
-    idx.build_kmeans(train, k, 0)
+    idx.build_kmeans(train, k, mi)
     srt = bool(r.integers(0, 2))
     gi, gd = idx.search_kmeans(q, nn, mc, srt)
     ri, rd = oracle_lib.hkmeans_search(L, blob, q, nn, mc, int(srt))
-    return idx.kmeans_blob().tobytes() == blob.tobytes() and (gi == ri).all() and (gd == rd).all(), (nt, nq, k, nn, mc, srt)
+    return idx.kmeans_blob().tobytes() == blob.tobytes() and (gi == ri).all() and (gd == rd).all(), (nt, nq, k, mi, nn, mc, srt)
 
 run("kmeans_index", km_case)
 

@@ -14,13 +14,14 @@ def test_host_build_equals_oracle_blob(oracle, name):
 
     train = _sets()[name][0]
     for k in (32, 8, 2):
-        ref = oracle_lib.hkmeans_blob(oracle, train, k, 0)
-        if isinstance(ref, int):
-            assert ref == -2
-            with pytest.raises(u.UcoslamHipError, match="identical"):
-                kmeans_build_host(train, k)
-            continue
-        assert kmeans_build_host(train, k).tobytes() == ref.tobytes()
+        for mi in (0, 1, 11, -1):      # HKMeansParams maxIters: the matcher's 0, the library default 11, "until convergence"
+            ref = oracle_lib.hkmeans_blob(oracle, train, k, mi)
+            if isinstance(ref, int):
+                assert ref == -2
+                with pytest.raises(u.UcoslamHipError):
+                    kmeans_build_host(train, k, mi)
+                continue
+            assert kmeans_build_host(train, k, mi).tobytes() == ref.tobytes(), (k, mi)
 
 
 @pytest.mark.gpu
@@ -45,6 +46,17 @@ def test_hip_hkmeans_search_matches_oracle(hip_ctx, oracle, name):
             gi, gd = idx.search_kmeans(queries, nn, mc, bool(srt))
             np.testing.assert_array_equal(gi, ri, err_msg=f"{name} k={k} nn={nn} maxChecks={mc} sorted={srt}")
             np.testing.assert_array_equal(gd, rd)
+        # the library's default parameters (k-means rounds) on the same data
+        for mi in (11, -1):
+            rb = oracle_lib.hkmeans_blob(oracle, train, k, mi)
+            if isinstance(rb, int):
+                continue
+            idx2 = Index(hip_ctx).build_kmeans(train, k, mi)
+            assert idx2.kmeans_blob().tobytes() == rb.tobytes()
+            ri, rd = oracle_lib.hkmeans_search(oracle, rb, queries, 10, 16, 0)
+            gi, gd = idx2.search_kmeans(queries, 10, 16, False)
+            np.testing.assert_array_equal(gi, ri)
+            np.testing.assert_array_equal(gd, rd)
         # device-resident queries
         qd = torch.from_numpy(queries).cuda()
         gi, gd = idx.search_kmeans(qd, 10, 16, False)
@@ -65,8 +77,8 @@ def test_hip_hkmeans_errors(hip_ctx):
     idx = Index(hip_ctx)
     with pytest.raises(u.UcoslamHipError):          # not built: loud, like Index::_search (index.cpp:82-85)
         idx.search_kmeans(q, 10, 16)
-    with pytest.raises(u.UcoslamHipError):          # k-means rounds are not what the path uses
-        idx.build_kmeans(train, 32, 11)
+    with pytest.raises(u.UcoslamHipError):
+        idx.build_kmeans(train, 32, -5)
     idx.build_kmeans(train, 32, 0)
     for nn, mc in ((1, 1), (2, 2), (2, 1)):          # the reference's greedy shortcuts
         with pytest.raises(u.UcoslamHipError):

@@ -33,20 +33,20 @@ def test_hkmeans_restatement_matches_real_xflann(oracle, name):
     train, queries = (b, a) if name.startswith(("match", "ties")) else (a, b)   # synth returns (train, query) for match sets
     if name.startswith(("match", "ties")):
         train, queries = a, b
-    for k in (32, 8):
-        blob = oracle_lib.hkmeans_blob(oracle, train, k, 0)
+    for k, mi in ((32, 0), (8, 0), (32, 11), (8, 3), (8, -1)):
+        blob = oracle_lib.hkmeans_blob(oracle, train, k, mi)
         if isinstance(blob, int):
             assert blob == -2      # > k identical rows: the reference recurses without end; nothing to compare
             continue
-        stream = oracle_lib.ref_hkmeans_stream(ref, train, k, 0)
+        stream = oracle_lib.ref_hkmeans_stream(ref, train, k, mi)
         params = np.frombuffer(stream[24:64].tobytes(), np.uint32)
         assert params[0] == 8 and params[7] == 32 and params[8] == len(train)      # alignment, descriptor size, npoints
         assert int(np.frombuffer(stream[40:48].tobytes(), np.uint64)[0]) == len(blob)
         assert stream[64:].tobytes() == blob.tobytes()
         for nn, mc, srt in ((10, 16, 0), (10, 16, 1), (5, 1, 0), (3, 40, 0), (10, 200, 1), (2, 3, 0), (1, 2, 0), (10, -1, 0)):
             i0, d0 = oracle_lib.hkmeans_search(oracle, blob, queries, nn, mc, srt)
-            i1, d1 = oracle_lib.ref_hkmeans_search(ref, train, queries, nn, k, 0, mc, srt)
-            np.testing.assert_array_equal(i0, i1, err_msg=f"{name} k={k} nn={nn} maxChecks={mc} sorted={srt}")
+            i1, d1 = oracle_lib.ref_hkmeans_search(ref, train, queries, nn, k, mi, mc, srt)
+            np.testing.assert_array_equal(i0, i1, err_msg=f"{name} k={k} maxIters={mi} nn={nn} maxChecks={mc} sorted={srt}")
             np.testing.assert_array_equal(d0, d1)
 
 

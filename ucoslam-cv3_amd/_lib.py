@@ -75,7 +75,7 @@ def _declare(L: C.CDLL):
     sig("uh_knn_search_dev", I, VP, VP, I, I, VP, VP, I, I)
     sig("uh_knn_build_kmeans", I, VP, VP, I, I, I)
     sig("uh_knn_kmeans_blob", I, VP, C.POINTER(VP), C.POINTER(C.c_uint64))
-    sig("uh_knn_kmeans_build_host", I, VP, I, I, VP, C.c_uint64, C.POINTER(C.c_uint64))
+    sig("uh_knn_kmeans_build_host", I, VP, I, I, I, VP, C.c_uint64, C.POINTER(C.c_uint64))
     sig("uh_knn_search_kmeans", I, VP, VP, I, I, I, I, VP, VP)
     sig("uh_knn_search_kmeans_dev", I, VP, VP, I, I, I, I, VP, VP)
     sig("uh_knn_scan_shard_dev", I, VP, VP, I, I, I, VP, VP, I)

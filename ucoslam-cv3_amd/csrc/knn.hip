@@ -430,7 +430,7 @@ __global__ void knn_push_bench_kernel(int k, int n, long long* out) {
 
 
 // ------------------------------------------------------------------------------------------------ hierarchical k-means build (host)
-// xflann::Index::build(features, HKMeansParams(k, 0)) = KMeansIndexCreator::build + convert (impl/kmeansindexcreator.{h,cpp}),
+// xflann::Index::build(features, HKMeansParams(k, maxIters)) = KMeansIndexCreator::build + convert (impl/kmeansindexcreator.{h,cpp}),
 // producing the reference's own serialised block data (8-byte block header {u16 n, u8 isLeaf, u32 header_size}, n 8-byte node
 // infos {child block offset | 1<<63 + row index}, n 32-byte features; blocks laid out breadth first).  It is built on the
 // host like the reference does — per train frame, ~0.1 ms for 2000 rows: std::shuffle of a default std::mt19937 decides the
@@ -439,7 +439,7 @@ namespace {
 
 struct KmBuildNode {
     std::vector<uint32_t> rows;      // rows assigned to this node (leaf: kept; internal: moved to the children)
-    const uint8_t* centre = nullptr; // feature shown in the parent's block
+    uint8_t centre[32] = {0};        // feature shown in the parent's block: a train row, or the cluster's bitwise majority
     int first_child = -1, n_children = 0;
 };
 
@@ -451,7 +451,7 @@ inline int host_hamming32(const uint8_t* a, const uint8_t* b) {
 }
 
 // returns UH_OK, or UH_EINVAL with the error text set.  depth_out: levels of internal blocks above the deepest leaf block.
-int kmeans_build_blob(const uint8_t* rows, int n, int k, std::vector<uint8_t>& blob, int& depth_out) {
+int kmeans_build_blob(const uint8_t* rows, int n, int k, int max_iters, std::vector<uint8_t>& blob, int& depth_out) {
     std::vector<KmBuildNode> nodes(1);
     std::vector<int> depth(1, 0);
     nodes[0].rows.resize(n);
@@ -461,6 +461,10 @@ int kmeans_build_blob(const uint8_t* rows, int n, int k, std::vector<uint8_t>& b
     // KMeansIndexCreator::convert, whatever order the reference's recursion created them in
     for (size_t cur = 0; cur < nodes.size(); cur++) {
         if (cur != 0 && (int)nodes[cur].rows.size() <= k) continue;   // leaf (the root is always split)
+        if (depth[cur] > 64) {
+            uh::set_error("uh_knn_build_kmeans: the tree does not stop splitting (a cluster keeps collapsing into one child); the reference does not terminate on this input");
+            return UH_EINVAL;
+        }
         std::vector<uint32_t> rowsv;
         rowsv.swap(nodes[cur].rows);
         std::mt19937 gen;
@@ -471,25 +475,62 @@ int kmeans_build_blob(const uint8_t* rows, int n, int k, std::vector<uint8_t>& b
             for (uint32_t c : centres) if (host_hamming32(rows + 32 * (size_t)rowsv[next], rows + 32 * (size_t)c) == 0) { dup = true; break; }
             if (!dup) centres.push_back(rowsv[next]);
         }
-        const int first = (int)nodes.size();
-        for (uint32_t c : centres) { nodes.emplace_back(); nodes.back().centre = rows + 32 * (size_t)c; depth.push_back(depth[cur] + 1); }
-        for (uint32_t r : rowsv) {   // nearest centre, first minimum; an exact hit ends the scan
-            int best = 0, bestd = 0x7fffffff;
-            for (int c = 0; c < (int)centres.size(); c++) {
-                const int d = host_hamming32(nodes[first + c].centre, rows + 32 * (size_t)r);
-                if (d < bestd) { bestd = d; best = c; }
-                if (bestd == 0) break;
+        const int nc = (int)centres.size();
+        std::vector<KmBuildNode> kids(nc);
+        for (int c = 0; c < nc; c++) std::memcpy(kids[c].centre, rows + 32 * (size_t)centres[c], 32);
+        auto assign = [&]() {   // nearest centre, first minimum; an exact hit ends the scan
+            for (auto& kd : kids) kd.rows.clear();
+            for (uint32_t r : rowsv) {
+                int best = 0, bestd = 0x7fffffff;
+                for (int c = 0; c < nc; c++) {
+                    const int d = host_hamming32(kids[c].centre, rows + 32 * (size_t)r);
+                    if (d < bestd) { bestd = d; best = c; }
+                    if (bestd == 0) break;
+                }
+                kids[best].rows.push_back(r);
             }
-            nodes[first + best].rows.push_back(r);
+        };
+        assign();
+        // k-means rounds (HKMeansParams maxIters; -1 = until the assignment hash repeats): centres move to the bitwise majority of
+        // their clusters (kmeansindexcreator.h:245-262, 390-422)
+        size_t prev_hash = 0, cur_hash = 1, niters = 0;
+        while (cur_hash != prev_hash && (max_iters == -1 || niters++ < (size_t)max_iters)) {
+            std::swap(prev_hash, cur_hash);
+            for (int c = 0; c < nc; c++) {
+                if (kids[c].rows.empty()) kids[c].rows.push_back(centres[c]);
+                int sum[256] = {0};
+                for (uint32_t r : kids[c].rows) {
+                    const uint8_t* pr = rows + 32 * (size_t)r;
+                    for (int j = 0; j < 32; j++)
+                        for (int bit = 0; bit < 8; bit++) if (pr[j] & (128 >> bit)) ++sum[j * 8 + bit];
+                }
+                const int half = (int)kids[c].rows.size() / 2 + (int)(kids[c].rows.size() % 2);
+                std::memset(kids[c].centre, 0, 32);
+                for (int i = 0; i < 256; i++) if (sum[i] >= half) kids[c].centre[i / 8] |= (uint8_t)(1 << (7 - (i % 8)));
+            }
+            assign();
+            size_t seed = 0;
+            for (auto& kd : kids) for (uint32_t id : kd.rows) seed ^= id + 0x9e3779b9 + (seed << 6) + (seed >> 2);
+            cur_hash = seed;
         }
-        // every centre owns at least itself, so no cluster is empty when maxIters == 0 (the reference's erase of empty
-        // children, kmeansindexcreator.h:268-271, never fires)
-        if (centres.size() == 1 && (int)rowsv.size() > k) {
-            uh::set_error("uh_knn_build_kmeans: more than k=%d identical descriptors: the reference's tree construction does not terminate on this input", k);
-            return UH_EINVAL;
+        int nkept = 0;
+        for (auto& kd : kids) nkept += !kd.rows.empty();
+        if (nkept == 1 && (int)rowsv.size() > k) {
+            bool same = true;
+            for (uint32_t r : rowsv) if (host_hamming32(rows + 32 * (size_t)r, rows + 32 * (size_t)rowsv[0]) != 0) { same = false; break; }
+            if (same) {
+                uh::set_error("uh_knn_build_kmeans: more than k=%d identical descriptors: the reference's tree construction does not terminate on this input", k);
+                return UH_EINVAL;
+            }
+        }
+        const int first = (int)nodes.size();
+        for (auto& kd : kids) {   // empty clusters are dropped (:268-271)
+            if (kd.rows.empty()) continue;
+            nodes.push_back(std::move(kd));
+            depth.push_back(depth[cur] + 1);
         }
         nodes[cur].first_child = first;
-        nodes[cur].n_children = (int)centres.size();
+        nodes[cur].n_children = nkept;
         depth_out = std::max(depth_out, depth[cur] + 1);
     }
     auto pad8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
@@ -514,7 +555,7 @@ int kmeans_build_blob(const uint8_t* rows, int n, int k, std::vector<uint8_t>& b
         std::memcpy(blk + 4, &hs, 4);
         for (uint32_t j = 0; j < cnt; j++) {
             const uint64_t info = leaf ? ((uint64_t)nd.rows[j] | 0x8000000000000000ull) : off[nd.first_child + j];
-            const uint8_t* feat = leaf ? rows + 32 * (size_t)nd.rows[j] : nodes[nd.first_child + j].centre;
+            const uint8_t* feat = leaf ? rows + 32 * (size_t)nd.rows[j] : nodes[nd.first_child + j].centre;   // row, or centre
             std::memcpy(blk + 8 + 8 * (size_t)j, &info, 8);
             std::memcpy(blk + hs + 32 * (size_t)j, feat, 32);
         }
@@ -693,8 +734,8 @@ int uh_knn_build_kmeans(uh_knn* idx, const uint8_t* features, int n, int k, int 
     if (n <= 0) return UH_OK;   // index.cpp:49 — empty features leave the index unbuilt
     UH_REQUIRE(features != nullptr, "uh_knn_build_kmeans: NULL features");
     UH_REQUIRE(k >= 2 && k <= kWave, "uh_knn_build_kmeans: k=%d outside [2,%d] (one lane per child)", k, kWave);
-    UH_REQUIRE(max_iters == 0, "uh_knn_build_kmeans: only maxIters = 0 (what FrameMatcher_Flann passes, framematcher.cpp:213) is implemented, got %d", max_iters);
-    int rc = kmeans_build_blob(features, n, k, idx->km_blob, idx->km_depth);
+    UH_REQUIRE(max_iters >= -1, "uh_knn_build_kmeans: maxIters=%d (use -1 for 'until convergence')", max_iters);
+    int rc = kmeans_build_blob(features, n, k, max_iters, idx->km_blob, idx->km_depth);
     if (rc) { idx->km_blob.clear(); return rc; }
     UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
     if ((rc = idx->km_dev.reserve(idx->km_blob.size() + 64))) return rc;
@@ -706,11 +747,11 @@ int uh_knn_build_kmeans(uh_knn* idx, const uint8_t* features, int n, int k, int 
 }
 
 // host-only form of the build (no GPU needed): writes min(cap, size) bytes of the block data, returns the full size in *size
-int uh_knn_kmeans_build_host(const uint8_t* features, int n, int k, uint8_t* out, uint64_t cap, uint64_t* size) {
-    UH_REQUIRE(features && n > 0 && k >= 2 && k <= kWave && size, "uh_knn_kmeans_build_host: bad arguments");
+int uh_knn_kmeans_build_host(const uint8_t* features, int n, int k, int max_iters, uint8_t* out, uint64_t cap, uint64_t* size) {
+    UH_REQUIRE(features && n > 0 && k >= 2 && k <= kWave && max_iters >= -1 && size, "uh_knn_kmeans_build_host: bad arguments");
     std::vector<uint8_t> blob;
     int depth = 0;
-    const int rc = kmeans_build_blob(features, n, k, blob, depth);
+    const int rc = kmeans_build_blob(features, n, k, max_iters, blob, depth);
     if (rc) return rc;
     *size = blob.size();
     if (out && cap) std::memcpy(out, blob.data(), (size_t)std::min<uint64_t>(cap, blob.size()));

@@ -147,13 +147,13 @@ class Index:
             pass
 
 
-def kmeans_build_host(features, k: int = 32) -> np.ndarray:
-    """Block data of HKMeansParams(k, 0) over `features` — the host-side build alone, no GPU."""
+def kmeans_build_host(features, k: int = 32, maxIters: int = 0) -> np.ndarray:
+    """Block data of HKMeansParams(k, maxIters) over `features` — the host-side build alone, no GPU."""
     a = np.ascontiguousarray(np.asarray(features), np.uint8)
     size = C.c_uint64()
-    check(lib().uh_knn_kmeans_build_host(np_ptr(a), a.shape[0], k, None, 0, C.byref(size)))
+    check(lib().uh_knn_kmeans_build_host(np_ptr(a), a.shape[0], k, maxIters, None, 0, C.byref(size)))
     out = np.zeros(size.value, np.uint8)
-    check(lib().uh_knn_kmeans_build_host(np_ptr(a), a.shape[0], k, np_ptr(out), size.value, C.byref(size)))
+    check(lib().uh_knn_kmeans_build_host(np_ptr(a), a.shape[0], k, maxIters, np_ptr(out), size.value, C.byref(size)))
     return out
 
 
