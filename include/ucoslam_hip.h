@@ -95,7 +95,9 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn,
  * the reference recurse without end: reported as UH_EINVAL.  uh_knn_kmeans_blob exposes the block data in the reference's own
  * serialised layout (the bytes KMeansIndex::toStream writes after its 48-byte header).
  * search: maxChecks as the reference (<= 0 returns empty rows, like the reference's loop condition); the pairs (nn=1,maxChecks=1)
- * and (nn=2,maxChecks<=2) select other code in the reference and are refused. */
+ * and (nn=2,maxChecks<=2) select the reference's greedy descents (kmeansindex.h:226-352), which are defective for binary
+ * descriptors — their int32 "best distance" is initialised with uint32 max = -1, so no child ever compares smaller and every
+ * query returns the same row with distance -1 (observed on the real library) — and are refused here with UH_EINVAL. */
 int uh_knn_build_kmeans(uh_knn* idx, const uint8_t* features, int n, int k, int max_iters);
 int uh_knn_kmeans_blob(uh_knn* idx, const uint8_t** data, uint64_t* size);
 /* host-only build (test hook, no GPU): writes min(cap, size) bytes of the block data to out, the full size to *size */

@@ -775,7 +775,7 @@ int uh_knn_search_kmeans_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int 
     UH_REQUIRE(nq >= 0, "uh_knn_search_kmeans: negative query count");
     UH_REQUIRE(nn >= 1 && nn <= kWave, "uh_knn_search_kmeans: nn=%d outside [1,%d]", nn, kWave);
     UH_REQUIRE(!(nn == 1 && max_checks == 1) && !(nn == 2 && max_checks <= 2),
-               "uh_knn_search_kmeans: (nn=%d, maxChecks=%d) selects the reference's greedy 1-/2-nn descents (kmeansindex.h:216-224), which are not implemented", nn, max_checks);
+               "uh_knn_search_kmeans: (nn=%d, maxChecks=%d) selects the reference's greedy 1-/2-nn descents (kmeansindex.h:216-224), which return a constant row with distance -1 for binary descriptors; not reproduced", nn, max_checks);
     if (nq == 0) return UH_OK;
     UH_REQUIRE(d_queries && d_indices && d_distances, "uh_knn_search_kmeans: NULL buffer");
     // worst case of the branch heap: every pop adds >= 1 check, every descent pushes <= (k-1) entries per level; beyond the
