@@ -242,7 +242,7 @@ def proj_problem(n_kpts=2000, n_pts=3000, seed=0, w=1241, h=376, n_levels=8, low
     Tgt = _se3_exp(np.r_[0.01, -0.015, 0.004, 0, 0, 0]) @ np.eye(4)
     Tgt[:3, 3] = [0.3, -0.05, 0.1]
     cam_c = -Tgt[:3, :3].T @ Tgt[:3, 3]
-    n_rel = (2 * n_pts) // 3
+    n_rel = (2 * n_pts) // 3 if n_kpts else 0   # a frame without keypoints: only unrelated map points
     src = rng.integers(0, max(n_kpts, 1), n_rel) if n_kpts else np.zeros(0, np.int64)
     z = rng.uniform(3, 45, n_rel)
     uv = np.stack([kp["x"][src], kp["y"][src]], 1).astype(np.float64) + rng.normal(0, 1.5, (n_rel, 2)) if n_kpts else np.zeros((0, 2))
