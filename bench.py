@@ -129,37 +129,15 @@ def main():
     L = u.lib()
     from ucoslam_cv3_amd._lib import check, dev_ptr
 
-    # mapper thread: uh_ba_optimize blocks its caller between the two LM passes, so it gets the reference's own
-    # arrangement (a mapper thread beside the tracker, mapmanager.cpp:150 runThread); ctypes drops the GIL in the call
-    import threading
-    ba_go, ba_done, ba_quit = threading.Event(), threading.Event(), [False]
-    ba_err = []
-
-    def mapper():
-        torch.cuda.set_device(local_rank)
-        while True:
-            ba_go.wait()
-            ba_go.clear()
-            if ba_quit[0]:
-                return
-            try:
-                ba.optimize()
-            except Exception as e:   # surfaced by step()
-                ba_err.append(e)
-            ba_done.set()
-
-    mapper_thread = threading.Thread(target=mapper, daemon=True)
-    mapper_thread.start()
-
+    # mapper thread: uh_ba_optimize blocks its caller between the two LM passes, so it runs where the reference runs it — on a
+    # mapper thread beside the tracker (mapmanager.cpp:150 runThread) — here the worker thread of the BA object
+    # (uh_ba_optimize_async / uh_ba_wait), while this thread enqueues the tracking launches
     def step():
-        ba_go.set()
+        ba.optimize_async()
         kps, desc, counts = ext.extract_batch(frames, fp, orb_out)
         # the F frames' descriptor blocks are contiguous [F, 2000, 32]: one launch matches all F x 2000 queries against the map
         check(L.uh_knn_search_dev(index._h, dev_ptr(desc), F * NQ, NN, dev_ptr(knn_idx), dev_ptr(knn_dist), 0, -1))
-        ba_done.wait()
-        ba_done.clear()
-        if ba_err:
-            raise ba_err[0]
+        ba.wait()
 
     def sync_all():
         torch.cuda.synchronize()

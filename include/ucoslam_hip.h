@@ -214,6 +214,11 @@ int  uh_ba_set_problem(uh_ba* ba, const uh_ba_problem* problem, const uh_ba_para
 /* = optimize(bool* stopASAP): runs both passes from the snapshot; *stop_asap (may be NULL) is polled while waiting. */
 int  uh_ba_optimize(uh_ba* ba, const volatile uint8_t* stop_asap);
 /* pinned device-visible force-stop byte owned by the optimiser (write 1 from any thread to stop between trials) */
+/* asynchronous form: runs uh_ba_optimize on a worker thread owned by the object — the reference runs GlobalOptimizer::optimize
+ * on its mapper thread beside the tracker (mapmanager.cpp:150) — and uh_ba_wait returns its result (UH_OK or the error).
+ * One optimisation in flight per object; set_problem / get_results only between wait and the next optimize. */
+int  uh_ba_optimize_async(uh_ba* ba, const volatile uint8_t* stop_asap);
+int  uh_ba_wait(uh_ba* ba);
 uint8_t* uh_ba_stop_flag(uh_ba* ba);
 /* = getResults: poses n_frames x 16 float (fixed frames returned unchanged), points n_points x 3 float, per-observation
  * chi2 (as last evaluated by the optimiser) and bad-association flag (chi2 > 5.99 or point behind the camera);

@@ -111,3 +111,26 @@ def test_hip_ba_stop_flag_and_errors(hip_ctx, oracle):
     bad["obs_kf"][0] = 99
     with pytest.raises(u.UcoslamHipError):
         opt.setParams(bad)
+
+
+@pytest.mark.gpu
+def test_hip_ba_async_equals_sync(hip_ctx):
+    """uh_ba_optimize_async / uh_ba_wait (optimisation on the object's worker thread, like the reference's mapper thread)."""
+    import ucoslam_cv3_amd as u
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    pr = synth.ba_problem(6, 500, 11)
+    opt = GlobalOptimizer.create(hip_ctx)
+    opt.setParams(pr, ParamSet(nIters=5))
+    with pytest.raises(u.UcoslamHipError):
+        opt.wait()                               # nothing in flight
+    opt.optimize()
+    ref = opt.getResults()
+    for _ in range(3):
+        opt.optimize_async()
+        with pytest.raises(u.UcoslamHipError):
+            opt.optimize_async()                 # one optimisation in flight per object
+        opt.wait()
+        got = opt.getResults()
+        np.testing.assert_array_equal(got["state"], ref["state"])
+        assert got["iters"].tolist() == ref["iters"].tolist()

@@ -33,6 +33,8 @@ def _declare(L, sig):
     sig("uh_ba_destroy", None, VP)
     sig("uh_ba_set_problem", I, VP, C.POINTER(_Problem), C.POINTER(ParamSet))
     sig("uh_ba_optimize", I, VP, VP)
+    sig("uh_ba_optimize_async", I, VP, VP)
+    sig("uh_ba_wait", I, VP)
     sig("uh_ba_stop_flag", VP, VP)
     sig("uh_ba_get_results", I, VP, VP, VP, VP, VP, VP)
     sig("uh_ba_get_pose_state", I, VP, VP)
@@ -72,6 +74,14 @@ class GlobalOptimizer:
 
     def optimize(self, stop_asap: np.ndarray | None = None):
         check(lib().uh_ba_optimize(self._h, np_ptr(stop_asap) if stop_asap is not None else None))
+
+    def optimize_async(self, stop_asap: np.ndarray | None = None):
+        """Starts optimize() on the object's worker thread (the reference's mapper thread); wait() returns when it is done."""
+        self._stop_keep = stop_asap
+        check(lib().uh_ba_optimize_async(self._h, np_ptr(stop_asap) if stop_asap is not None else None))
+
+    def wait(self):
+        check(lib().uh_ba_wait(self._h))
 
     def getResults(self):
         K, P, E = self._dims

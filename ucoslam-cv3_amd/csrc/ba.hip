@@ -34,6 +34,10 @@
 // All reductions run in a fixed order, so results are run-to-run deterministic.  MFMA is not used: the only dense algebra is
 // 6x3·3x3·3x6 products per landmark pair (fp64) — far below any matrix-core tile; see DESIGN.md.
 #include <cfloat>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 
@@ -1130,7 +1134,22 @@ struct uh_ba {
     int nsplit = 1;
     int step = 0;                         // LM steps enqueued since uh_ba_optimize began: step s reads state slot s & 1
     bool optimized = false;
-    ~uh_ba() { if (h_stop) (void)hipHostFree(h_stop); }
+    // uh_ba_optimize_async: a persistent worker thread (the reference's mapper thread, mapmanager.cpp:150) runs uh_ba_optimize
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    int job = 0;                          // 0 idle, 1 requested, 2 running, 3 done (result in job_rc), -1 quit
+    int job_rc = 0;
+    std::string job_err;
+    const volatile uint8_t* job_stop = nullptr;
+    ~uh_ba() {
+        if (worker.joinable()) {
+            { std::lock_guard<std::mutex> lk(mu); job = -1; }
+            cv.notify_all();
+            worker.join();
+        }
+        if (h_stop) (void)hipHostFree(h_stop);
+    }
 };
 
 namespace {
@@ -1374,6 +1393,50 @@ int uh_ba_debug_clocks(uh_ba* b, int64_t* out64) {
     UH_HIP_CHECK(hipMemcpyAsync(out64, b->ptrs.clk, 64 * sizeof(long long), hipMemcpyDeviceToHost, b->ctx->stream));
     UH_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
     return UH_OK;
+}
+
+// Asynchronous form: the optimisation runs on a worker thread of the object (GlobalOptimizer::optimize is what the reference's
+// mapper thread spends its time in); uh_ba_wait returns its result.  The caller's thread is free to enqueue tracking work on
+// another stream in between.  One optimisation in flight per object.
+int uh_ba_optimize_async(uh_ba* b, const volatile uint8_t* stop_asap) {
+    UH_REQUIRE(b && b->have_problem, "uh_ba_optimize_async: no problem set (call uh_ba_set_problem first)");
+    std::unique_lock<std::mutex> lk(b->mu);
+    UH_REQUIRE(b->job == 0, "uh_ba_optimize_async: an optimisation is already in flight (call uh_ba_wait)");
+    if (!b->worker.joinable()) {
+        b->worker = std::thread([b]() {
+            std::unique_lock<std::mutex> l(b->mu);
+            for (;;) {
+                b->cv.wait(l, [b]() { return b->job == 1 || b->job == -1; });
+                if (b->job == -1) return;
+                b->job = 2;
+                const volatile uint8_t* stop = b->job_stop;
+                l.unlock();
+                const int rc = uh_ba_optimize(b, stop);
+                const std::string err = rc ? std::string(uh_last_error()) : std::string();   // thread-local: carry it over
+                l.lock();
+                b->job_rc = rc;
+                b->job_err = err;
+                b->job = 3;
+                b->cv.notify_all();
+            }
+        });
+    }
+    b->job_stop = stop_asap;
+    b->job = 1;
+    lk.unlock();
+    b->cv.notify_all();
+    return UH_OK;
+}
+
+int uh_ba_wait(uh_ba* b) {
+    UH_REQUIRE(b, "uh_ba_wait: NULL");
+    std::unique_lock<std::mutex> lk(b->mu);
+    UH_REQUIRE(b->job != 0, "uh_ba_wait: nothing in flight");
+    b->cv.wait(lk, [b]() { return b->job == 3; });
+    const int rc = b->job_rc;
+    b->job = 0;
+    if (rc) uh::set_error("%s", b->job_err.c_str());
+    return rc;
 }
 
 uint8_t* uh_ba_stop_flag(uh_ba* b) { return b ? b->h_stop : nullptr; }
