@@ -115,6 +115,11 @@ struct BAPtrs {
 #define UH_BA_CLK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) p.clk[i] = wall_clock64(); } while (0)
 #define UH_BA_CLKL(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { p.clk[i] = wall_clock64(); p.clk[32 + i] = clock64(); } } while (0)   // single-workgroup kernels
 
+// The BA launches are tiny and latency-bound, and they share the chip with the tracking stream's wide, VALU-saturating launches
+// (8000 kNN waves, tens of thousands of FAST tiles).  Raising the issue priority of their waves (s_setprio) keeps those
+// neighbours from taking eight ninths of a SIMD's issue slots away from a wave on the critical path.
+__device__ __forceinline__ void uh_latency_critical() { __builtin_amdgcn_s_setprio(3); }
+
 // ------------------------------------------------------------------------------------------------ small fp64 helpers
 __device__ __forceinline__ void quat_to_R(const double* q, double* R) {
     const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
@@ -304,6 +309,7 @@ __device__ __forceinline__ void camera_block(const BAPtrs& p, const BADims& d, i
 // ------------------------------------------------------------------------------------------------ lin
 // grid = nPointBlocks + nfree*kCamChunks.  Launched once per pass (first trial); later linearisations come from backsub.
 __global__ __launch_bounds__(kThreads) void ba_lin_kernel(BAPtrs p, BADims d, int slot) {
+    uh_latency_critical();
     __shared__ double s_red[kThreads];
     const BAState st = p.st[slot];
     if (st.phase == 2 || !st.first_trial) return;
@@ -425,6 +431,7 @@ __device__ __forceinline__ BAState apply_decision(const BAState& st0, const Deci
 // (i1 <= i2) block and writes a PARTIAL 6x6 (and, on diagonal pairs, a partial 6-vector); the solve kernel adds the
 // partials in chunk order.  The first block also publishes lambda at iteration 0 (computeLambdaInit).
 __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, int nsplit, int slot) {
+    uh_latency_critical();
     __shared__ double s_part[4 * 42];
     __shared__ double s_out[42];
     // workgroup role and, for pair workgroups, the first landmark's edge ids and activity flags: none of it depends on the LM
@@ -933,6 +940,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
 // workgroup may use
 template <bool USE_LDS>
 __global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADims d, int nsplit, int slot) {
+    uh_latency_critical();
     __shared__ double s_x[6 * kMaxFree];
     SolveOut o;
     solve_body<USE_LDS>(p, d, nsplit, slot, s_x, o);
@@ -941,6 +949,7 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADim
 // Stand-alone decision: closes a round of enqueued steps (the decision of a step is otherwise applied by the NEXT step's
 // schur kernel).  One wave, state slot `slot`, in place.
 __global__ __launch_bounds__(64) void ba_decide_kernel(BAPtrs p, BADims d, int slot) {
+    uh_latency_critical();
     const unsigned char stopv = p.stop ? *p.stop : (unsigned char)0;
     const BAState st0 = p.st[slot];
     const DecideSums sm = decide_sums(p, d, threadIdx.x, st0.lambda);
@@ -957,6 +966,7 @@ __global__ __launch_bounds__(64) void ba_decide_kernel(BAPtrs p, BADims d, int s
 // boundary and the dependent reloads behind it per LM trial.
 template <bool FUSED>
 __global__ __launch_bounds__(kThreads) void ba_backsub_kernel(BAPtrs p, BADims d, int nsplit, int slot) {
+    uh_latency_critical();
     __shared__ double s_red[kThreads];
     __shared__ double s_xp[6 * kMaxFree];
     // the force-stop flag lives in pinned host memory (a PCIe round trip): one thread of the grid samples it, early, and
