@@ -183,6 +183,22 @@ def main():
         stage_ms["match_ms_single_frame_launch"] = timed(
             lambda: check(L.uh_knn_search_dev(index._h, dev_ptr(orb_out[1][0]), NQ, NN, dev_ptr(knn_idx[0]), dev_ptr(knn_dist[0]), 0, -1)), 50)
         stage_ms["ba_ms_per_keyframe"] = timed(lambda: ba.optimize(), 5)
+        # the second frame size north_star asks for: the same step (4 frames, one kNN launch, one local BA) on 640x480 frames
+        fr2 = torch.from_numpy(np.stack([synth.frame(640, 480, seed=77 + f, shift=(2 * f, f)) for f in range(F)])).to(dev)
+        ext2 = ORBextractor.create(ctx)
+        out2 = ext2.extract_batch(fr2, fp)
+
+        def step_640():
+            ba.optimize_async()
+            ext2.extract_batch(fr2, fp, out2)
+            check(L.uh_knn_search_dev(index._h, dev_ptr(out2[1]), F * NQ, NN, dev_ptr(knn_idx), dev_ptr(knn_dist), 0, -1))
+            ba.wait()
+
+        for _ in range(3):
+            step_640()
+        stage_ms["step_ms_640x480"] = timed(step_640, 15)
+        stage_ms["frames_per_s_640x480"] = 1e3 * F / stage_ms["step_ms_640x480"]
+        stage_ms["orb_ms_per_frame_640x480"] = timed(lambda: ext2.extract_batch(fr2, fp, out2), 20) / F
         # not part of the metric's step (ORB + match + local BA): the per-frame pose-only solve (PnPSolver::solvePnp, 600 matches)
         from ucoslam_cv3_amd.pnp import PnPSolver
 
