@@ -34,6 +34,7 @@
 // All reductions run in a fixed order, so results are run-to-run deterministic.  MFMA is not used: the only dense algebra is
 // 6x3·3x3·3x6 products per landmark pair (fp64) — far below any matrix-core tile; see DESIGN.md.
 #include <cfloat>
+#include <cstdio>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -67,10 +68,16 @@ struct BAState {
     int stopped;      // force-stop flag observed
     int pending;      // a trial has been computed whose accept/reject decision has not been applied to this state yet
     int stop_seen;    // force-stop flag as sampled by the backsub kernel of the pending trial
-    double lambda, ni, currentChi, lastChiRaw, rho;
+    int gate;         // set between the passes: pass 1 was complete (and not stopped) when the pre-enqueued pass 2 began
+    double lambda, ni, currentChi, lastChiRaw;
     float prevChi2, curChi2, minChi2;
-    int pad;
+    int iters_pass1;  // outer iterations of pass 1 (iters_done is reset when pass 2 begins)
 };
+// Keep it small: measured on MI355X (A/B on the same box) a 96- or 104-byte state costs 0.79 ms per local BA, 112 bytes 1.05 ms
+// and 128 bytes 1.22 ms — every one of the ~40 launches got ~6-10 us slower.  The state is read at the top of every kernel
+// and copied through LDS in the schur prologue; past 104 bytes something in that path falls off a cliff (not investigated
+// further).  gate / iters_pass1 therefore sit in what used to be padding.
+static_assert(sizeof(BAState) == 96, "BAState layout");
 
 struct BADims {
     int K, P, E, nfree, n;   // n = 6*nfree
@@ -394,7 +401,6 @@ __device__ __forceinline__ BAState apply_decision(const BAState& st0, const Deci
         st.ni *= 2;    // pop: the current buffers stay
         if (!isfinite(st.lambda)) lambda_finite = false;
     }
-    st.rho = rho;
     const bool stop = stop_flag;
     if (stop) st.stopped = 1;
     bool again = false;
@@ -1051,9 +1057,19 @@ __global__ __launch_bounds__(kThreads) void ba_backsub_kernel(BAPtrs p, BADims d
 
 // ------------------------------------------------------------------------------------------------ between / after passes
 // globaloptimizer_g2o.cpp:434-449: outliers to level 1, every robust kernel removed
-__global__ void ba_relabel_kernel(BAPtrs p, BADims d, int slot) {
+// pass 2 is enqueued without a host round trip: the gate kernel decides on the device whether pass 1 really was complete
+__global__ void ba_gate_kernel(BAPtrs p, int slot) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    BAState& st = p.st[slot];
+    const bool stop = p.stop && *p.stop;
+    st.gate = (st.phase == 2 && !st.stopped && !stop && !st.pending) ? 1 : 0;
+    if (st.gate) st.iters_pass1 = st.iters_done;
+}
+
+__global__ void ba_relabel_kernel(BAPtrs p, BADims d, int slot, int gated) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= d.E) return;
+    if (gated && !p.st[slot].gate) return;
     const int cur = p.st[slot].cur;
     const int k = p.e_kf[e], pt = p.e_pt[e];
     const double* Rt = p.poseR[cur] + 12 * k;
@@ -1063,9 +1079,10 @@ __global__ void ba_relabel_kernel(BAPtrs p, BADims d, int slot) {
     p.e_robust[e] = 0;
 }
 
-__global__ void ba_begin_pass_kernel(BAPtrs p, int max_iters, float minChi2, int slot) {
+__global__ void ba_begin_pass_kernel(BAPtrs p, int max_iters, float minChi2, int slot, int gated) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     BAState& st = p.st[slot];
+    if (gated && !st.gate) return;   // pass 1 still running: the steps enqueued behind this launch simply continue it
     st.pending = 0;
     st.stop_seen = 0;
     st.phase = max_iters > 0 ? 0 : 2;
@@ -1212,27 +1229,28 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
     return UH_OK;
 }
 
-int run_pass(uh_ba* b, int max_iters, int* iters_done, const volatile uint8_t* stop_asap) {
+// waits for the stream and returns the state of the valid slot; keeps forwarding the caller's stop flag meanwhile
+int wait_state(uh_ba* b, BAState* hs, const volatile uint8_t* stop_asap) {
     hipStream_t st = b->ctx->stream;
-    UH_LAUNCH(b->ctx,ba_begin_pass_kernel, dim3(1), dim3(64), 0, b->ptrs, max_iters, b->params.min_chi2_between_iter, b->step & 1);
-    int budget = max_iters + 1;   // one step per outer iteration when no trial is rejected
-    BAState hs;
-    for (int round = 0; round < 64; round++) {
-        int rc = enqueue_steps(b, budget, round == 0);
-        if (rc) return rc;
-        UH_HIP_CHECK(hipMemcpyAsync(&hs, b->ptrs.st + (b->step & 1), sizeof(BAState), hipMemcpyDeviceToHost, st));
-        if (stop_asap && b->h_stop) {   // keep forwarding the caller's flag to the device-visible one while waiting
-            hipEvent_t ev;
-            UH_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            UH_HIP_CHECK(hipEventRecord(ev, st));
-            while (hipEventQuery(ev) == hipErrorNotReady) if (*stop_asap) *b->h_stop = 1;
-            (void)hipEventDestroy(ev);
-        }
-        UH_HIP_CHECK(hipStreamSynchronize(st));
-        if (hs.phase == 2) break;
-        budget = 4;   // rejected trials consumed steps: keep going
+    UH_HIP_CHECK(hipMemcpyAsync(hs, b->ptrs.st + (b->step & 1), sizeof(BAState), hipMemcpyDeviceToHost, st));
+    if (stop_asap && b->h_stop) {
+        hipEvent_t ev;
+        UH_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        UH_HIP_CHECK(hipEventRecord(ev, st));
+        while (hipEventQuery(ev) == hipErrorNotReady) if (*stop_asap) *b->h_stop = 1;
+        (void)hipEventDestroy(ev);
     }
-    *iters_done = hs.iters_done;
+    UH_HIP_CHECK(hipStreamSynchronize(st));
+    return UH_OK;
+}
+
+// rejected trials consumed steps of the budget: enqueue short rounds until the running pass is finished
+int finish_pass(uh_ba* b, BAState* hs, const volatile uint8_t* stop_asap) {
+    for (int round = 0; round < 64 && hs->phase != 2; round++) {
+        int rc = enqueue_steps(b, 4, false);
+        if (rc) return rc;
+        if ((rc = wait_state(b, hs, stop_asap))) return rc;
+    }
     return UH_OK;
 }
 
@@ -1377,21 +1395,44 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
 int uh_ba_optimize(uh_ba* b, const volatile uint8_t* stop_asap) {
     UH_REQUIRE(b && b->have_problem, "uh_ba_optimize: no problem set (call uh_ba_set_problem first)");
     UH_HIP_CHECK(hipSetDevice(b->ctx->device));
-    hipStream_t st = b->ctx->stream;
     const BADims& d = b->dims;
     if (b->h_stop) *b->h_stop = (stop_asap && *stop_asap) ? 1 : 0;
     const int nmax = std::max(std::max(d.K, 3 * d.P), std::max(d.E, 1));
+    const int n1 = b->params.n_iters, n2 = 2 * b->params.n_iters;
+    const float mc = b->params.min_chi2_between_iter;
     UH_LAUNCH(b->ctx,ba_init_state_kernel, dim3(uh_div_up(nmax, 256)), dim3(256), 0, b->ptrs, d, b->d_pose0, b->d_pts0);
     b->iters[0] = b->iters[1] = 0;
     b->step = 0;
-    int rc = run_pass(b, b->params.n_iters, &b->iters[0], stop_asap);
-    if (rc) return rc;
-    bool cont = true;
-    if (stop_asap && *stop_asap) cont = false;
-    if (b->h_stop && *b->h_stop) cont = false;
-    if (cont) {
-        if (d.E > 0) UH_LAUNCH(b->ctx,ba_relabel_kernel, dim3(uh_div_up(d.E, 256)), dim3(256), 0, b->ptrs, d, b->step & 1);
-        if ((rc = run_pass(b, 2 * b->params.n_iters, &b->iters[1], stop_asap))) return rc;
+    // Both passes are enqueued in one go (one step per outer iteration + 1: enough when no trial is rejected).  Between them the
+    // gate kernel checks on the device that pass 1 is complete and not stopped; if it is not, relabel / begin_pass do nothing
+    // and the steps enqueued for pass 2 simply continue pass 1.  The host looks at the state once, at the end.
+    int rc;
+    UH_LAUNCH(b->ctx,ba_begin_pass_kernel, dim3(1), dim3(64), 0, b->ptrs, n1, mc, b->step & 1, 0);
+    if ((rc = enqueue_steps(b, n1 + 1, true))) return rc;
+    UH_LAUNCH(b->ctx,ba_gate_kernel, dim3(1), dim3(64), 0, b->ptrs, b->step & 1);
+    if (d.E > 0) UH_LAUNCH(b->ctx,ba_relabel_kernel, dim3(uh_div_up(d.E, 256)), dim3(256), 0, b->ptrs, d, b->step & 1, 1);
+    UH_LAUNCH(b->ctx,ba_begin_pass_kernel, dim3(1), dim3(64), 0, b->ptrs, n2, mc, b->step & 1, 1);
+    if ((rc = enqueue_steps(b, n2 + 1, true))) return rc;
+    BAState hs;
+    if ((rc = wait_state(b, &hs, stop_asap))) return rc;
+    if (hs.gate) {                       // the common case: pass 2 is under way or done
+        b->iters[0] = hs.iters_pass1;
+        if ((rc = finish_pass(b, &hs, stop_asap))) return rc;
+        b->iters[1] = hs.iters_done;
+    } else {                             // pass 1 needed more steps than its budget, or a stop was requested
+        if ((rc = finish_pass(b, &hs, stop_asap))) return rc;
+        b->iters[0] = hs.iters_done;
+        bool cont = !hs.stopped;
+        if (stop_asap && *stop_asap) cont = false;
+        if (b->h_stop && *b->h_stop) cont = false;
+        if (cont) {
+            if (d.E > 0) UH_LAUNCH(b->ctx,ba_relabel_kernel, dim3(uh_div_up(d.E, 256)), dim3(256), 0, b->ptrs, d, b->step & 1, 0);
+            UH_LAUNCH(b->ctx,ba_begin_pass_kernel, dim3(1), dim3(64), 0, b->ptrs, n2, mc, b->step & 1, 0);
+            if ((rc = enqueue_steps(b, n2 + 1, true))) return rc;
+            if ((rc = wait_state(b, &hs, stop_asap))) return rc;
+            if ((rc = finish_pass(b, &hs, stop_asap))) return rc;
+            b->iters[1] = hs.iters_done;
+        }
     }
     b->optimized = true;
     return UH_OK;
