@@ -313,10 +313,16 @@ def main():
         }
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 2)
-        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio, which a pipe buffers until exit: drain it first so that the JSON
+        # line is the LAST line on stdout
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
