@@ -157,6 +157,12 @@ int  uh_orb_set_blur(uh_orb* orb, int do_blur);            /* ORBextractor::doGa
 int  uh_orb_set_sensitivity(uh_orb* orb, float v);         /* ORBextractor::setSensitivity (ORBextractor.cpp:457-466) */
 int  uh_orb_set_nonmaxima(uh_orb* orb, int on);            /* debug string "orb_nonmaxima" (ORBextractor.cpp:1146-1148,1176-1205): radius-3
                                                               suppression per level before the descriptors; kept keypoints get class_id 1 */
+/* Multi-GPU extraction of one frame ("pyramid levels sharded"): this instance extracts pyramid levels
+ * [first_level, end_level) only (end_level < 0: to the last level).  Per-level budgets, thresholds and cell grids stay those
+ * of the full level count (ORBextractor.cpp:501-513 fixes them per level), the resize chain is built redundantly up to
+ * end_level-1 (level l reads level l-1, :1379), so the shards' outputs concatenated in level order are the full extraction's
+ * rows, bit for bit.  An empty range yields zero keypoints. */
+int  uh_orb_set_level_range(uh_orb* orb, int first_level, int end_level);
 int  uh_orb_max_keypoints(const uh_orb* orb);              /* = maxFeatures: upper bound of *n_out */
 
 /* One frame, host buffers: img = h rows of w bytes (CV_8UC1), row stride in bytes.

@@ -79,6 +79,8 @@ class ORBextractor {
     float getMinDescDistance() const { return 50; }          // ORBextractor.h:105
     void setSensitivity(float v) { check(uh_orb_set_sensitivity(o_, v)); }
     void doGaussianBlur(bool b) { check(uh_orb_set_blur(o_, b)); }
+    // multi-GPU extraction of one frame: this instance extracts pyramid levels [first, end) (end < 0: all)
+    void setLevelRange(int first, int end) { check(uh_orb_set_level_range(o_, first, end)); }
     uh_orb* handle() const { return o_; }
    private:
     std::shared_ptr<Context> ctx_;

@@ -129,6 +129,21 @@ def _worker(rank, world, port, ok):
         idx, dd = _replay(cand_all.numpy(), counts_all.numpy(), nn, s)
         ri, rd = oracle_lib.knn_search(L, train, q, nn, s)
         assert (idx == ri).all() and (dd == rd).all(), f"rank {rank}: sharded replay != unsharded reference (sorted={s})"
+    # pyramid-level shards of ONE frame: every rank holds the rows of its contiguous level range (the oracle's rows with
+    # those octaves stand in for the per-rank GPU extraction); one gather + compaction in rank order = the full extraction
+    img = synth.frame(320, 240, seed=4)
+    nf, nl, sf = 600, 6, 1.2
+    rk, rd = oracle_lib.orb_extract(L, img, nf, nl, sf)
+    ranges = parallel.level_ranges(320, 240, nl, sf, world)
+    first, end = ranges[rank]
+    mine = (rk["octave"] >= first) & (rk["octave"] < end)
+    kp_blk = np.zeros((nf, 7), np.float32)
+    ds_blk = np.zeros((nf, 32), np.uint8)
+    n_mine = int(mine.sum())
+    kp_blk[:n_mine] = rk[mine].view(np.float32).reshape(-1, 7)
+    ds_blk[:n_mine] = rd[mine]
+    gk, gd = parallel.gather_level_shards(torch.from_numpy(kp_blk), torch.from_numpy(ds_blk), torch.tensor(n_mine, dtype=torch.int32))
+    assert gk.numpy().tobytes() == rk.tobytes() and (gd.numpy() == rd).all(), f"rank {rank}: gathered level shards != full extraction"
     fr = [list(parallel.frames_of_rank(10, r, world)) for r in range(world)]
     assert sum(fr, []) == list(range(10))
     t = torch.tensor([float(rank + 1)])
@@ -138,12 +153,83 @@ def _worker(rank, world, port, ok):
     dist.destroy_process_group()
 
 
+def test_level_ranges_cover_the_pyramid_in_order():
+    from ucoslam_cv3_amd import parallel
+
+    for (w, h, nl, sf) in ((1241, 376, 8, 1.2), (640, 480, 8, 1.2), (320, 240, 3, 1.5), (97, 131, 1, 1.2)):
+        for world in (1, 2, 3, 4, 8, 12):
+            r = parallel.level_ranges(w, h, nl, sf, world)
+            assert len(r) == world and r[0][0] == 0 and r[-1][1] == nl
+            assert all(a <= b for a, b in r) and all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+    # one level per rank once there are as many ranks as levels; level 0 (a third of the pixels) is never paired at 4+
+    assert parallel.level_ranges(1241, 376, 8, 1.2, 8) == [(i, i + 1) for i in range(8)]
+    assert parallel.level_ranges(1241, 376, 8, 1.2, 4)[0] == (0, 1)
+
+
 def test_gloo_world2_sharded_match_and_timing_reduction():
     world = 2
     port = 29500 + (os.getpid() % 2000)
     ok = mp.get_context("spawn").Array("i", [0] * world)
     mp.spawn(_worker, args=(world, port, ok), nprocs=world, join=True)
     assert list(ok) == [1] * world
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(1241, 376, 2000, 8, 1.2), (640, 480, 4000, 8, 1.2), (320, 240, 1000, 3, 1.5)], ids=lambda c: f"{c[0]}x{c[1]}_l{c[3]}")
+def test_level_shards_concatenate_to_the_full_extraction(hip_ctx, cfg):
+    """uh_orb_set_level_range: what ranks 0..world-1 of a 2/3/8/11-GPU extraction would each produce (run one after the other
+    on the one GPU here), concatenated in rank order, equals the single-GPU extraction (itself bit-exact vs the oracle)."""
+    import oracle_lib
+    import synth
+    from ucoslam_cv3_amd import parallel
+    from ucoslam_cv3_amd.orb import KEYPOINT_DTYPE, FeatParams, ORBextractor
+
+    w, h, nf, nl, sf = cfg
+    img = synth.frame(w, h, seed=21)
+    rk, rd = oracle_lib.orb_extract(oracle_lib.load_oracle(), img, nf, nl, sf)
+    frame = torch.from_numpy(img).cuda()
+    ext = ORBextractor.create(hip_ctx)
+    fp = FeatParams(nf, nl, sf)
+    for world in (1, 2, 3, 8, 11):
+        ks, ds = [], []
+        for first, end in parallel.level_ranges(w, h, nl, sf, world):
+            ext.setLevelRange(first, end)
+            kps, desc, counts = ext.extract_batch(frame[None], fp)
+            torch.cuda.synchronize()
+            n = int(counts[0])
+            got = kps[0, :n].cpu().numpy()
+            assert first < end or n == 0
+            if n:
+                oct_ = got.copy().view(KEYPOINT_DTYPE)["octave"]
+                assert oct_.min() >= first and oct_.max() < end
+            ks.append(got)
+            ds.append(desc[0, :n].cpu().numpy())
+        ext.setLevelRange(0, -1)
+        k_all, d_all = np.concatenate(ks), np.concatenate(ds)
+        assert k_all.tobytes() == rk.tobytes(), f"world {world}: keypoints of the level shards != full extraction"
+        np.testing.assert_array_equal(d_all, rd, err_msg=f"world {world}")
+
+
+@pytest.mark.gpu
+def test_sharded_extract_over_rccl_single_rank(hip_ctx):
+    """parallel.sharded_extract through the RCCL backend with world_size 1 (one device on the GPU box)."""
+    import oracle_lib
+    import synth
+    from ucoslam_cv3_amd import parallel
+    from ucoslam_cv3_amd.orb import FeatParams, ORBextractor
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        img = synth.frame(640, 480, seed=2)
+        ext = ORBextractor.create(hip_ctx)
+        gk, gd = parallel.sharded_extract(ext, torch.from_numpy(img).cuda(), FeatParams(2000, 8, 1.2))
+        torch.cuda.synchronize()
+        rk, rd = oracle_lib.orb_extract(oracle_lib.load_oracle(), img, 2000, 8, 1.2)
+        assert gk.cpu().numpy().tobytes() == rk.tobytes() and (gd.cpu().numpy() == rd).all()
+    finally:
+        dist.destroy_process_group()
 
 
 @pytest.mark.gpu

@@ -62,6 +62,7 @@ struct Plan {           // uploaded once per (size, params)
     int iniTh, minTh;
     int maxFeatures;
     int total_tiles, total_cells;
+    int lvl_end;        // levels >= lvl_end are not needed by this instance's shard: the resize chain stops before them
     LevelDesc lv[kMaxLevels];
 };
 
@@ -711,6 +712,7 @@ struct uh_orb {
     bool blur_first = true;        // ORBextractor::doGaussianBlur()
     bool nonmaxima = false;        // debug::Debug::isString("orb_nonmaxima") (ORBextractor.cpp:1146-1148)
     bool nm_attr = false;
+    int lvl_first = 0, lvl_end = -1;   // pyramid-level shard [first, end) this instance extracts (end < 0: all levels)
     int iniTh = 20, minTh = 7;     // precalculateParams resets these on every parameter change (:478-479)
     Plan plan;
     std::vector<CellDesc> cells;
@@ -750,6 +752,11 @@ int make_plan(uh_orb* o, int w, int h, int batch) {
         for (int l = 0; l < nl - 1; l++) { nFeat[l] = cvRoundf(nDesired); sum += nFeat[l]; nDesired *= factor; }
         nFeat[nl - 1] = std::max(fp.maxFeatures - sum, 0);
     }
+    // pyramid-level shard: the per-level budgets above are fixed by the FULL level count, so a level extracted
+    // alone yields exactly the rows the full extraction holds for it; levels outside the shard get no tiles, cells or budget
+    const int lvl_first = std::min(std::max(o->lvl_first, 0), nl);
+    const int lvl_end = o->lvl_end < 0 ? nl : std::min(std::max(o->lvl_end, lvl_first), nl);
+    P.lvl_end = lvl_end;
     o->cells.clear();
     std::vector<int> xofs, yofs;
     std::vector<short> xcoef, ycoef;
@@ -767,9 +774,10 @@ int make_plan(uh_orb* o, int w, int h, int batch) {
         img_off += (size_t)L.pitch * L.h;
         L.scale = scale[l];
         L.scaledPatchSize = (int)(PATCH_SIZE * scale[l]);
-        L.nDesired = nFeat[l];
-        L.tiles_x = uh_div_up(L.w, 64);
-        L.tiles_y = uh_div_up(L.h, 16);
+        const bool mine = l >= lvl_first && l < lvl_end;
+        L.nDesired = mine ? nFeat[l] : 0;
+        L.tiles_x = mine ? uh_div_up(L.w, 64) : 0;
+        L.tiles_y = mine ? uh_div_up(L.h, 16) : 0;
         L.tile_begin = tile_begin;
         tile_begin += L.tiles_x * L.tiles_y;
         L.xtap_off = (int)xofs.size();
@@ -878,6 +886,10 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
     const Plan& P = o->plan;
     uint8_t* pyr = o->d_pyr.as<uint8_t>();
     const LevelDesc& L0 = P.lv[0];
+    if (P.lvl_end == 0 || P.total_tiles == 0) {   // empty shard (more ranks than levels): no keypoints
+        UH_HIP_CHECK(hipMemsetAsync(d_counts, 0, sizeof(int) * batch, st));
+        return UH_OK;
+    }
     if (o->blur_first) {
         UH_LAUNCH(o->ctx,blur7_kernel, dim3(uh_div_up(w, 64), uh_div_up(h, 16), batch), dim3(256), 0, d_imgs, w, h, stride,
                            img_frame_stride, pyr + L0.img_off, L0.pitch, o->frame_stride);
@@ -885,7 +897,7 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
         UH_LAUNCH(o->ctx,copy_kernel, dim3(uh_div_up(w, 256), h, batch), dim3(256), 0, d_imgs, w, h, stride,
                            img_frame_stride, pyr + L0.img_off, L0.pitch, o->frame_stride);
     }
-    for (int l = 1; l < P.nlevels; l++) {
+    for (int l = 1; l < P.lvl_end; l++) {
         const LevelDesc& S = P.lv[l - 1];
         const LevelDesc& D = P.lv[l];
         UH_LAUNCH(o->ctx,resize_cubic_kernel, dim3(uh_div_up(D.w, 64), uh_div_up(D.h, 16), batch), dim3(256), 0,
@@ -974,6 +986,18 @@ int uh_orb_set_sensitivity(uh_orb* o, float v) {
     o->iniTh = (int)(v * 10 + 10);
     o->minTh = (int)(v * 4 + 3);
     o->planned = false;
+    return UH_OK;
+}
+
+// Pyramid-level shard for multi-GPU extraction of ONE frame: this instance extracts levels [first, end) only
+// (end < 0: up to the last level).  Level l depends on level l-1 (ORBextractor.cpp:1379), so the chain is built redundantly
+// up to end-1; keypoints and descriptors of the shards concatenated in level order equal the full extraction.
+int uh_orb_set_level_range(uh_orb* o, int first, int end) {
+    UH_REQUIRE(o, "uh_orb_set_level_range: NULL");
+    UH_REQUIRE(first >= 0 && (end < 0 || end >= first), "uh_orb_set_level_range: bad range [%d,%d)", first, end);
+    if (o->lvl_first != first || o->lvl_end != end) o->planned = false;
+    o->lvl_first = first;
+    o->lvl_end = end;
     return UH_OK;
 }
 

@@ -36,6 +36,7 @@ def _declare(L, sig):
     sig("uh_orb_set_blur", I, VP, I)
     sig("uh_orb_set_sensitivity", I, VP, C.c_float)
     sig("uh_orb_set_nonmaxima", I, VP, I)
+    sig("uh_orb_set_level_range", I, VP, I, I)
     sig("uh_orb_max_keypoints", I, VP)
     sig("uh_orb_extract", I, VP, VP, I, I, SZ, VP, VP, I, C.POINTER(I))
     sig("uh_orb_extract_dev", I, VP, VP, I, I, SZ, SZ, I, VP, VP, I, VP)
@@ -79,6 +80,10 @@ class ORBextractor:
     def setNonMaxima(self, flag: bool):
         """The reference's debug switch: debug::Debug::addString("orb_nonmaxima") (ORBextractor.cpp:1146-1148)."""
         check(lib().uh_orb_set_nonmaxima(self._h, int(flag)))
+
+    def setLevelRange(self, first: int = 0, end: int = -1):
+        """Pyramid-level shard [first, end) of a multi-GPU extraction (parallel.sharded_extract); (0, -1) = all levels."""
+        check(lib().uh_orb_set_level_range(self._h, first, end))
 
     # detectAndCompute(image, mask, keypoints, descriptors, params): mask is ignored (ORBextractor.cpp:1253)
     def detectAndCompute(self, image, mask=None, params: FeatParams | None = None):
