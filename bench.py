@@ -220,6 +220,9 @@ def main():
         pmatch.setFrame(pfr["und_kpts"], pfr["desc"], pfr["scale_factors"], pfr["fx"], pfr["fy"], pfr["cx"], pfr["cy"], pfr["min_xy"], pfr["max_xy"])
         stage_ms["projmatch_ms_per_call_2000kp_3000pts"] = timed(lambda: pmatch.matchFrameToMapPoints(
             ppose, pmp["ids"], pmp["pos3d"], pmp["normal"], pmp["min_dist"], pmp["max_dist"], pmp["desc"], 100.0, 15.0), 20)
+        # ... and the tracker's search against the previous frame (system.cpp:5930-6460), called with (1.5 * maxDescDistance, projDistThr)
+        stage_ms["projmatch_prev_ms_per_call_2000kp_3000pts"] = timed(lambda: pmatch.matchFrameToPrevFrame(
+            ppose, pmp["ids"], pmp["pos3d"], pmp["octave"], pmp["desc"], 75.0, 15.0), 20)
         if not args.no_roofline:
             for c in (ctx, ctx_ba):
                 c.prof_enable(True)

@@ -342,6 +342,24 @@ int  uh_projmatch_set_frame(uh_projmatch* pm, const uh_proj_frame* frame);
 int  uh_projmatch_match(uh_projmatch* pm, const float* pose_f2g /* row-major 4x4 */, const uh_map_points* points,
                         float min_desc_dist, float max_repj_dist, uh_dmatch* matches_out, int32_t cap,
                         int32_t* best_kp_out /* n or NULL */, float* best_dist_out /* n or NULL */, uint8_t* visible_out /* n or NULL */);
+/* The tracker's projection search against the PREVIOUS frame (src/utils/system.cpp:5930-6460, private member of System; the
+ * source is token-pasted, line numbers are statement starts after preprocessing; called at :6559-6565 with
+ * (maxDescDistance*1.5, projDistThr) before PnPSolver::solvePnp).  The caller flattens the loop header (:5969-6089): one item
+ * per keypoint i of the previous frame whose ids[i] names a valid, non-bad map point, in keypoint order — that point's id and
+ * coordinates, und_kpts[i].octave and descriptor row i.  Per item: Frame::project(p, true, true) (frame.h:140-161) with
+ * `pose_f2g` = the current frame's pose, radius maxRepjDist * scaleFactors[octave], candidates of exactly that octave in
+ * kd-tree order, best (from minDescDist + 0.01) / second WITHOUT demotion, accepted iff best < 0.7 * second; then
+ * filter_ambiguous_query.  The frame is the one given to uh_projmatch_set_frame.  Returns the number of matches or < 0. */
+typedef struct uh_prev_points {
+    int32_t n;
+    const uint32_t* ids;            /* n: map point ids (DMatch::trainIdx) */
+    const float* pos3d;             /* n x 3: MapPoint::getCoordinates() */
+    const int32_t* octave;          /* n: prev.und_kpts[i].octave, each in [0, n_levels) */
+    const uint8_t* desc;            /* n x 32: prev.desc rows */
+} uh_prev_points;
+int  uh_projmatch_match_prev(uh_projmatch* pm, const float* pose_f2g /* row-major 4x4 */, const uh_prev_points* points,
+                             float min_desc_dist, float max_repj_dist, uh_dmatch* matches_out, int32_t cap,
+                             int32_t* best_kp_out /* n or NULL */, float* best_dist_out /* n or NULL */);
 /* test hook: the flattened kd-tree of the current frame (24-byte nodes {float divlow, divhigh; int32 left, right, leaf_begin;
  * int16 leaf_count, col}), the leaf index list, the root box {x.min, x.max, y.min, y.max} and the tree depth */
 int  uh_projmatch_debug_tree(uh_projmatch* pm, int32_t* n_nodes, const void** nodes24, const uint32_t** leaf_idx,

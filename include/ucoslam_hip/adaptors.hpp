@@ -268,6 +268,15 @@ class ProjectionMatcher {
         if (visible) visible->resize(pts.n);
         return out;
     }
+    // the tracker's search against the previous frame (System's private member at system.cpp:5930-6460, called at :6559-6565):
+    // pose_f2g = the current frame's predicted pose, pts = the previous frame's keypoints that carry a good map point
+    std::vector<uh_dmatch> matchFrameToPrevFrame(const float pose_f2g[16], const uh_prev_points& pts, float minDescDist, float maxRepjDist) {
+        std::vector<uh_dmatch> out(pts.n > 0 ? pts.n : 1);
+        const int k = uh_projmatch_match_prev(h_, pose_f2g, &pts, minDescDist, maxRepjDist, out.data(), (int32_t)out.size(), nullptr, nullptr);
+        if (k < 0) check(k);
+        out.resize(k);
+        return out;
+    }
    private:
     std::shared_ptr<Context> ctx_;
     uh_projmatch* h_ = nullptr;

@@ -263,6 +263,22 @@ int oracle_kd_export(void* h, int32_t* col, float* divlow, float* divhigh, int32
     return (int)t->nodes.size();
 }
 
+// filter_ambiguous_query (misc.cpp:117-150) + remove_unused_matches (:105-107)
+static void filter_ambiguous_query_(std::vector<DMatch>& matches) {
+    if (matches.empty()) return;
+    int maxT = -1;
+    for (auto& mm : matches) maxT = std::max(maxT, mm.queryIdx);
+    std::vector<int> used(maxT + 1, -1);
+    int idx = 0;
+    for (auto& match : matches) {
+        if (used[match.queryIdx] == -1) used[match.queryIdx] = idx;
+        else if (matches[used[match.queryIdx]].distance > match.distance) { matches[used[match.queryIdx]].queryIdx = -1; used[match.queryIdx] = idx; }
+        else match.queryIdx = -1;
+        idx++;
+    }
+    matches.erase(std::remove_if(matches.begin(), matches.end(), [](const DMatch& mm) { return mm.trainIdx == -1 || mm.queryIdx == -1; }), matches.end());
+}
+
 // Map::matchFrameToMapPoints on flattened inputs.  Frame: und_kpts (cv::KeyPoint), desc (n_kpts x 32), scaleFactors, camera,
 // minXY/maxXY (cv::Point: ints).  Map points (already filtered by id, map.cpp:657-668): ids, pos3d, normal, min/max distance
 // invariance, descriptor.  Outputs: per map point best keypoint (-1 none) / distance BEFORE filter_ambiguous_query, the
@@ -344,20 +360,68 @@ int oracle_proj_match(const oracle_keypoint* und_kpts, int n_kpts, const uint8_t
             }
         }
     }
-    // filter_ambiguous_query (misc.cpp:117-150) + remove_unused_matches (:105-107)
-    if (!matches.empty()) {
-        int maxT = -1;
-        for (auto& mm : matches) maxT = std::max(maxT, mm.queryIdx);
-        std::vector<int> used(maxT + 1, -1);
-        int idx = 0;
-        for (auto& match : matches) {
-            if (used[match.queryIdx] == -1) used[match.queryIdx] = idx;
-            else if (matches[used[match.queryIdx]].distance > match.distance) { matches[used[match.queryIdx]].queryIdx = -1; used[match.queryIdx] = idx; }
-            else match.queryIdx = -1;
-            idx++;
-        }
-        matches.erase(std::remove_if(matches.begin(), matches.end(), [](const DMatch& mm) { return mm.trainIdx == -1 || mm.queryIdx == -1; }), matches.end());
+    filter_ambiguous_query_(matches);
+    for (size_t i = 0; i < matches.size(); i++) std::memcpy(matches_out + 4 * i, &matches[i], 16);
+    return (int)matches.size();
+}
+
+// The tracker's projection search against the PREVIOUS frame (src/utils/system.cpp:5930-6460; the file is token-pasted, line
+// numbers are statement starts after preprocessing; call site :6559-6565 with (maxDescDistance*1.5, projDistThr)).
+// For every keypoint i of the previous frame that carries a valid, non-bad map point (:6001-6089; flattened by the caller:
+// that point's id and coordinates, the keypoint's octave and descriptor row), in keypoint order:
+//   * p = curframe.project(point, true, true) (frame.h:140-161): depth < 0 -> skip; 1./z in double, ((fx*x)*iz)+cx in float;
+//     skip unless minXY <= p < maxXY (ints compared as floats);
+//   * candidates = getKeyPointsInRegion(p, maxRepjDist * scaleFactors[octave], octave, octave) (:6172-6177, frame.cpp:102-115);
+//   * best starts at (float)(minDescDist + 0.01), second at FLT_MAX; a candidate below best REPLACES it (the old best is not
+//     demoted), otherwise one below second replaces second (:6297-6352);
+//   * accepted iff a best exists and best < 0.7 * second in double (:6363-6394); DMatch{query = keypoint of the current frame,
+//     train = map point id, distance = best};
+// then filter_ambiguous_query (:6448).  Outputs as oracle_proj_match.
+int oracle_proj_match_prev(const oracle_keypoint* und_kpts, int n_kpts, const uint8_t* desc, const float* scale_factors, int n_levels,
+                           float fx, float fy, float cx, float cy, int min_x, int min_y, int max_x, int max_y, const float* pose_f2g,
+                           int n_pts, const uint32_t* ids, const float* pos3d, const int32_t* octave, const uint8_t* prev_desc,
+                           float minDescDist, float maxRepjDist, int32_t* best_kp_out, float* best_dist_out,
+                           int32_t* matches_out /* n x 4 words (cv::DMatch) */) {
+    KdTree kd;
+    {
+        std::vector<float> xy(2 * (size_t)n_kpts);
+        for (int i = 0; i < n_kpts; i++) { xy[2 * i] = und_kpts[i].x; xy[2 * i + 1] = und_kpts[i].y; }
+        kd_build(kd, xy.data(), n_kpts);
     }
+    const float* rt = pose_f2g;
+    std::vector<DMatch> matches;
+    Hits hits;
+    for (int m = 0; m < n_pts; m++) {
+        best_kp_out[m] = -1;
+        best_dist_out[m] = std::numeric_limits<float>::max();
+        const float* P = pos3d + 3 * (size_t)m;
+        const int oct = octave[m];
+        if (oct < 0 || oct >= n_levels) return -2147483647;   // scaleFactors[octave] out of range: undefined in the reference
+        float rz = P[0] * rt[8] + P[1] * rt[9] + P[2] * rt[10] + rt[11];
+        if (rz < 0) continue;
+        const float rx = P[0] * rt[0] + P[1] * rt[1] + P[2] * rt[2] + rt[3];
+        const float ry = P[0] * rt[4] + P[1] * rt[5] + P[2] * rt[6] + rt[7];
+        rz = (float)(1. / rz);
+        const float p2x = ((fx * rx) * rz) + cx, p2y = ((fy * ry) * rz) + cy;
+        if (!(p2x >= (float)min_x && p2y >= (float)min_y && p2x < (float)max_x && p2y < (float)max_y)) continue;
+        // (a NaN projection fails the test above, like the isnan check at :6108-6119)
+        const float sc = scale_factors[oct];
+        kd_radius(kd, p2x, p2y, (double)(maxRepjDist * sc), hits);
+        float best_d = (float)(minDescDist + 0.01), second_d = std::numeric_limits<float>::max();
+        int best_kp = -1;
+        for (auto& h : hits.v) {
+            if (und_kpts[h.first].octave != oct) continue;
+            const float dd = hamming_f(prev_desc + 32 * (size_t)m, desc + 32 * (size_t)h.first);
+            if (dd < best_d) { best_d = dd; best_kp = (int)h.first; }
+            else if (dd < second_d) second_d = dd;
+        }
+        if (best_kp != -1 && best_d < 0.7 * second_d) {
+            best_kp_out[m] = best_kp;
+            best_dist_out[m] = best_d;
+            matches.push_back({best_kp, (int32_t)ids[m], -1, best_d});
+        }
+    }
+    filter_ambiguous_query_(matches);
     for (size_t i = 0; i < matches.size(); i++) std::memcpy(matches_out + 4 * i, &matches[i], 16);
     return (int)matches.size();
 }

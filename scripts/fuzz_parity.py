@@ -123,6 +123,19 @@ def pm_case(seed):
 
 run("projmatch", pm_case)
 
+def pmprev_case(seed):   # the tracker's search against the previous frame (uh_projmatch_match_prev)
+    r = np.random.default_rng(seed)
+    nk, npt = int(r.integers(0, 4500)), int(r.integers(1, 6000))
+    le = bool(r.random() < 0.4)
+    fr, mp, pose = synth.proj_problem(nk, npt, seed % 100000, low_entropy=le, n_levels=int(r.integers(2, 9)), pose_noise=float(r.choice([0.0, 0.002, 0.02])))
+    pm.setFrame(fr["und_kpts"], fr["desc"], fr["scale_factors"], fr["fx"], fr["fy"], fr["cx"], fr["cy"], fr["min_xy"], fr["max_xy"])
+    md, mr = (float(r.choice([0.0, 3.0, 8.0])) if le else float(r.choice([100.0, 75.0, 30.0]))), float(r.choice([7.5, 15.0, 2.5, 40.0]))
+    g = pm.matchFrameToPrevFrame(pose, mp["ids"], mp["pos3d"], mp["octave"], mp["desc"], md, mr)
+    o = oracle_lib.proj_match_prev(L, fr, mp, pose, md, mr)
+    return g["matches"].tobytes() == o["matches"].tobytes() and (g["best_kp"] == o["best_kp"]).all() and (g["best_dist"] == o["best_dist"]).all(), (nk, npt, le, md, mr)
+
+run("projmatch_prev", pmprev_case)
+
 # ---- BA and PnP (tolerance 1e-6 on the se3 state, identical iteration counts / flags)
 from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
 from ucoslam_cv3_amd.pnp import PnPSolver

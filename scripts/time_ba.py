@@ -31,6 +31,7 @@ L.uh_ba_debug_clocks(opt._h, clk.ctypes.data)
 us = lambda a, b: (clk[b] - clk[a]) / 100.0
 print(f"lin block0 {us(0,1):.2f} us | schur block0 {us(4,5):.2f} | solve: assemble {us(10,11):.2f} factor {us(11,12):.2f} subst {us(12,13):.2f} update {us(13,14):.2f} "
       f"| backsub block0 {us(20,21):.2f} | decide {us(24,25):.2f}")
+print(f"assemble: issue {us(10,26):.2f} state {us(26,27):.2f} sums+stores {us(27,28):.2f} barrier {us(28,11):.2f}")
 print(f"schur block0 end -> solve start (same step, next launch) {us(5,10):.2f} us")
 if clk[32 + 12] and clk[32 + 11]:
     print(f"shader clock during solve factor phase: {(clk[32+12]-clk[32+11]) / us(11,12):.0f} cycles/us")

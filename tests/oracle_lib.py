@@ -217,6 +217,29 @@ def proj_match(L, fr, mp, pose, minDescDist, maxRepjDist):
     return dict(best_kp=best_kp, best_dist=best_d, visible=vis, matches=dm)
 
 
+def proj_match_prev(L, fr, mp, pose, minDescDist, maxRepjDist):
+    """oracle_proj_match_prev (tracker's search against the previous frame): mp needs ids, pos3d, octave, desc."""
+    import numpy as np
+
+    n = len(mp["ids"])
+    best_kp = np.empty(n, np.int32)
+    best_d = np.empty(n, np.float32)
+    mout = np.zeros((max(n, 1), 4), np.int32)
+    f = L.oracle_proj_match_prev
+    f.restype = I
+    F = C.c_float
+    f.argtypes = [VP, I, VP, VP, I, F, F, F, F, I, I, I, I, VP, I, VP, VP, VP, VP, F, F, VP, VP, VP]
+    pose = np.ascontiguousarray(pose, np.float32)
+    k = f(P(fr["und_kpts"]), len(fr["und_kpts"]), P(fr["desc"]), P(fr["scale_factors"]), len(fr["scale_factors"]),
+          fr["fx"], fr["fy"], fr["cx"], fr["cy"], fr["min_xy"][0], fr["min_xy"][1], fr["max_xy"][0], fr["max_xy"][1], P(pose), n,
+          P(mp["ids"]), P(mp["pos3d"]), P(np.ascontiguousarray(mp["octave"], np.int32)), P(mp["desc"]), minDescDist, maxRepjDist,
+          P(best_kp), P(best_d), P(mout))
+    assert k >= 0, k
+    dm = np.zeros(k, dtype=np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")]))
+    dm[:] = mout[:k].copy().view(dm.dtype).reshape(-1)
+    return dict(best_kp=best_kp, best_dist=best_d, matches=dm)
+
+
 # ------------------------------------------------------------------------------------------------ hierarchical k-means (a14)
 def hkmeans_blob(L, train, k=32, max_iters=0):
     import numpy as np

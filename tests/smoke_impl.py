@@ -58,3 +58,6 @@ def run():
     gm = pm.matchFrameToMapPoints(pose, mp["ids"], mp["pos3d"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], 100.0, 15.0)
     rm = oracle_lib.proj_match(L, fr, mp, pose, 100.0, 15.0)
     assert gm["matches"].tobytes() == rm["matches"].tobytes() and len(rm["matches"]) > 20, "projection matcher differs from the oracle"
+    gp = pm.matchFrameToPrevFrame(pose, mp["ids"], mp["pos3d"], mp["octave"], mp["desc"], 75.0, 15.0)
+    rp = oracle_lib.proj_match_prev(L, fr, mp, pose, 75.0, 15.0)
+    assert gp["matches"].tobytes() == rp["matches"].tobytes() and len(rp["matches"]) > 20, "previous-frame projection search differs from the oracle"

@@ -275,7 +275,10 @@ def proj_problem(n_kpts=2000, n_pts=3000, seed=0, w=1241, h=376, n_levels=8, low
               normal=np.ascontiguousarray(np.concatenate([nrm, nu])[perm].astype(np.float32)),
               min_dist=np.ascontiguousarray(np.concatenate([mind, maxu / sf[n_levels - 1]])[perm].astype(np.float32)),
               max_dist=np.ascontiguousarray(np.concatenate([maxd, maxu])[perm].astype(np.float32)),
-              desc=np.ascontiguousarray(np.concatenate([mdesc, udesc])[perm]))
+              desc=np.ascontiguousarray(np.concatenate([mdesc, udesc])[perm]),
+              # octave of the previous frame's keypoint that observed the point (tracker's prev-frame search, system.cpp:6150):
+              # the source keypoint's level +-1 for related points, anything for the rest (own generator: older streams unchanged)
+              octave=np.ascontiguousarray(np.concatenate([lev, np.random.default_rng(seed + 12345).integers(0, n_levels, n_un)])[perm].astype(np.int32)))
     fr = dict(und_kpts=kp, desc=np.ascontiguousarray(desc), scale_factors=sf, fx=fx, fy=fy, cx=cx, cy=cy, min_xy=(0, 0), max_xy=(w, h))
     pose = (_se3_exp(rng.normal(0, pose_noise, 6)) @ Tgt).astype(np.float32)
     return fr, mp, np.ascontiguousarray(pose.reshape(16))

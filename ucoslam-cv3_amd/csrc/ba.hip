@@ -564,64 +564,79 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
         s_pair[t][0] = (short)s1; s_pair[t][1] = (short)(s1 + rem);
     }
     // (no barrier: the assembly decodes its pairs arithmetically; s_pair is first read after the barrier that ends it)
-    const int total = npairs * 42;
-    constexpr int kAsmU = 4;
+    // Two consecutive elements per 16-byte load (42 is even, the partial blocks are 16-byte aligned), three such units per
+    // thread and round: with 8 free poses (36 pairs, 756 units) every partial of the reduced system is requested in ONE
+    // round — the data was written by the previous launch on other XCDs, so a round costs a full HBM/MALL round trip.
+    const int total = npairs * 21;
+    constexpr int kAsmU = 3;
     // the LM state (lambda, current buffer, "pass finished") is requested together with the first round of partials
     double lambda = 0;
     int cur = 0;
     bool have_state = false;
     for (int t0 = tid; t0 < total; t0 += kSolveThreads * kAsmU) {
-        double xs[kAsmU][kMaxSplit], hs[kAsmU][kCamChunks];
+        double2 xs[kAsmU][kMaxSplit];
+        double hs[kAsmU][2][kCamChunks];
         int s1v[kAsmU], s2v[kAsmU], qv[kAsmU];
 #pragma unroll
         for (int u = 0; u < kAsmU; u++) {
             const int t = t0 + u * kSolveThreads;
             const int tc = t < total ? t : 0;
-            const int pair = tc / 42, q = tc - pair * 42;
+            const int pair = tc / 21, q = 2 * (tc - pair * 21);
             int s1 = 0, rem = pair;
             while (rem >= d.nfree - s1) { rem -= d.nfree - s1; ++s1; }
             const int s2 = s1 + rem;
             s1v[u] = s1; s2v[u] = s2; qv[u] = t < total ? q : -1;
 #pragma unroll
-            for (int k = 0; k < kMaxSplit; k++) xs[u][k] = p.Spart[((size_t)(k < nsplit ? k : 0) * npairs + pair) * 42 + q];
-            // camera-side entry that joins this element (diagonal pairs only): Hpp upper-triangle index or bp component
-            int hq = 0;
-            if (q >= 36) hq = 21 + (q - 36);
-            else { const int a = q / 6, c = q - a * 6, lo = a < c ? a : c, hi = a < c ? c : a; hq = lo * 6 - lo * (lo - 1) / 2 + (hi - lo); }
+            for (int k = 0; k < kMaxSplit; k++)
+                xs[u][k] = *reinterpret_cast<const double2*>(p.Spart + ((size_t)(k < nsplit ? k : 0) * npairs + pair) * 42 + q);
+            // camera-side entries that join these elements (diagonal pairs only): Hpp upper-triangle index or bp component
 #pragma unroll
-            for (int cch = 0; cch < kCamChunks; cch++) hs[u][cch] = p.HppPart[((size_t)s1 * kCamChunks + cch) * 27 + hq];
+            for (int j = 0; j < 2; j++) {
+                const int qq = q + j;
+                int hq = 0;
+                if (qq >= 36) hq = 21 + (qq - 36);
+                else { const int a = qq / 6, c = qq - a * 6, lo = a < c ? a : c, hi = a < c ? c : a; hq = lo * 6 - lo * (lo - 1) / 2 + (hi - lo); }
+#pragma unroll
+                for (int cch = 0; cch < kCamChunks; cch++) hs[u][j][cch] = s1 == s2 ? p.HppPart[((size_t)s1 * kCamChunks + cch) * 27 + hq] : 0.0;
+            }
         }
+        const long long clk_issued = wall_clock64();
         if (!have_state) {
             const BAState st = p.st[slot];
             if (st.phase == 2) return;   // uniform: nothing has been written yet
             lambda = st.lambda; cur = st.cur; have_state = true;
-            if (tid == 0 && blockIdx.x == 0) p.clk[10] = clk_begin;
+            if (tid == 0 && blockIdx.x == 0) { p.clk[10] = clk_begin; p.clk[26] = clk_issued; p.clk[27] = wall_clock64(); }
         }
 #pragma unroll
         for (int u = 0; u < kAsmU; u++) {
-            const int q = qv[u], s1 = s1v[u], s2 = s2v[u];
-            if (q < 0) continue;
-            double v = 0;
+            const int s1 = s1v[u], s2 = s2v[u];
+            if (qv[u] < 0) continue;
 #pragma unroll
-            for (int k = 0; k < kMaxSplit; k++) if (k < nsplit) v += xs[u][k];
-            double h = 0;
+            for (int j = 0; j < 2; j++) {
+                const int q = qv[u] + j;
+                double v = 0;
 #pragma unroll
-            for (int cch = 0; cch < kCamChunks; cch++) h += hs[u][cch];
-            if (q >= 36) {   // b_schur = b_p - sum_l Hpl Dinv b_l (diagonal pairs carry it); b_p = sum of the camera chunks
-                if (s1 == s2) {
-                    p.bp[6 * s1 + (q - 36)] = h;             // the decide stage needs b_p for computeScale
-                    s_x[6 * s1 + (q - 36)] = h - v;
+                for (int k = 0; k < kMaxSplit; k++) if (k < nsplit) v += j ? xs[u][k].y : xs[u][k].x;
+                double h = 0;
+#pragma unroll
+                for (int cch = 0; cch < kCamChunks; cch++) h += hs[u][j][cch];
+                if (q >= 36) {   // b_schur = b_p - sum_l Hpl Dinv b_l (diagonal pairs carry it); b_p = sum of the camera chunks
+                    if (s1 == s2) {
+                        p.bp[6 * s1 + (q - 36)] = h;             // the decide stage needs b_p for computeScale
+                        s_x[6 * s1 + (q - 36)] = h - v;
+                    }
+                    continue;
                 }
-                continue;
+                const int a = q / 6, c = q - a * 6;
+                v = -v;
+                if (s1 == s2) v += h + (a == c ? lambda : 0.0);
+                const int r = 6 * s1 + a, cc = 6 * s2 + c;   // upper-block entry (r,cc); store it mirrored into the lower triangle
+                if (s1 == s2) { if (c <= a) M[(size_t)r * ld + cc] = v; }
+                else M[(size_t)cc * ld + r] = v;
             }
-            const int a = q / 6, c = q - a * 6;
-            v = -v;
-            if (s1 == s2) v += h + (a == c ? lambda : 0.0);
-            const int r = 6 * s1 + a, cc = 6 * s2 + c;   // upper-block entry (r,cc); store it mirrored into the lower triangle
-            if (s1 == s2) { if (c <= a) M[(size_t)r * ld + cc] = v; }
-            else M[(size_t)cc * ld + r] = v;
         }
     }
+    UH_BA_CLK(28);
     if (!have_state) {   // no free pose: nothing was assembled
         const BAState st = p.st[slot];
         if (st.phase == 2) return;

@@ -193,6 +193,7 @@ struct PmFrame {
 struct PmPoints {
     int n;
     const float* pos3d; const float* normal; const float* min_dist; const float* max_dist; const uint64_t* desc;
+    const int* octave;      // PREV mode: octave of the previous frame's keypoint
     int* best_kp; float* best_dist; unsigned char* visible;
 };
 
@@ -216,7 +217,10 @@ __device__ __forceinline__ float logf_cr(float x) { return uh_sincosf::logf_glib
 // walk stack (double m, int rec per level) and the candidate list ((keypoint << 4) | octave, then the Hamming distance).
 // A frame of 2000 keypoints is ~40 KB, of 4000 ~80 KB: every node / leaf / coordinate access of the walk is an LDS access;
 // only descriptors of disc hits come from L2.
-template <bool IN_LDS>
+// PREV = false: Map::matchFrameToMapPoints (map.cpp:689-759).  PREV = true: the tracker's search against the previous frame's
+// keypoints (system.cpp:5930-6460): Frame::project visibility, the keypoint's own octave as the only admissible level, radius
+// maxRepjDist * scaleFactors[octave], best/second without demotion from (float)(minDescDist + 0.01), accept best < 0.7 * second.
+template <bool IN_LDS, bool PREV>
 __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoints mp, PmPose ps, float minDescDist, float maxRepjDist,
                                                                int n_nodes, int levels, int* overflow) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -278,7 +282,21 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
     float px = 0, py = 0;
     int predicted = 0;
     double worst = 0;
-    {
+    if constexpr (PREV) {
+        const float P0 = mp.pos3d[3 * mc], P1 = mp.pos3d[3 * mc + 1], P2 = mp.pos3d[3 * mc + 2];
+        const float* T = ps.T;
+        const float z = P0 * T[8] + P1 * T[9] + P2 * T[10] + T[11];       // Frame::project (frame.h:140-161)
+        const float x = P0 * T[0] + P1 * T[1] + P2 * T[2] + T[3];
+        const float y = P0 * T[4] + P1 * T[5] + P2 * T[6] + T[7];
+        const float iz = (float)(1. / z);
+        px = ((f.fx * x) * iz) + f.cx; py = ((f.fy * y) * iz) + f.cy;
+        vis = live && !(z < 0) && (px >= f.min_x && py >= f.min_y && px < f.max_x && py < f.max_y);
+        predicted = mp.octave[mc];
+        if (vis) {
+            const double radius = (double)(maxRepjDist * f.scale[predicted]);
+            worst = radius * radius;
+        }
+    } else {
         const float P0 = mp.pos3d[3 * mc], P1 = mp.pos3d[3 * mc + 1], P2 = mp.pos3d[3 * mc + 2];
         float v0 = ps.cc[0] - P0, v1 = ps.cc[1] - P1, v2 = ps.cc[2] - P2;   // getViewCos
         const double s = 1. / sqrt((double)v0 * v0 + (double)v1 * v1 + (double)v2 * v2);
@@ -304,7 +322,8 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
         }
     }
     int best_kp = -1;
-    float best_d = 3.402823466e+38f, second_d = 3.402823466e+38f;
+    float best_d = PREV ? (float)(minDescDist + 0.01) : 3.402823466e+38f, second_d = 3.402823466e+38f;
+    const int oct_lo = PREV ? predicted : predicted - 1;
     int bestLevel = 0, bestLevel2 = -1;
     bool ovf = false;
     const uint64_t* qd = mp.desc + 4 * (size_t)mc;
@@ -323,7 +342,7 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
             const float hd = (float)s_hd[k];
             const unsigned int e = s_cand[k];
             const int oc = (int)(e & 15u);
-            const bool lt = hd < minDescDist;
+            const bool lt = PREV ? true : hd < minDescDist;
             const bool isbest = lt && hd < best_d, issecond = lt && !isbest && hd < second_d;
             best_d = isbest ? hd : best_d; best_kp = isbest ? (int)(e >> 4) : best_kp; bestLevel = isbest ? oc : bestLevel;
             second_d = issecond ? hd : second_d; bestLevel2 = issecond ? oc : bestLevel2;
@@ -379,7 +398,7 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
                     const double dx = px - c.x;
                     double sqd = dx * dx;
                     if (!(sqd > worst)) { const double dy = py - c.y; sqd += dy * dy; }
-                    hit = sqd < worst && oc >= predicted - 1 && oc <= predicted;
+                    hit = sqd < worst && oc >= oct_lo && oc <= predicted;
                 }
                 const unsigned int gm = (unsigned int)((__ballot(hit) >> (gw * kGroup)) & ((1ull << kGroup) - 1ull));
                 if (hit) s_cand[ncand + __popc(gm & ((1u << gl) - 1u))] = (id << 4) | (unsigned int)oc;
@@ -407,10 +426,11 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
     }
     if (!ovf) drain(ncand);
     if (ovf) { if (gl == 0) *overflow = 1; best_kp = -1; }
-    if (best_kp != -1 && bestLevel2 == bestLevel && best_d > 0.8 * second_d) best_kp = -1;
+    if constexpr (PREV) { if (best_kp != -1 && !(best_d < 0.7 * second_d)) best_kp = -1; }
+    else if (best_kp != -1 && bestLevel2 == bestLevel && best_d > 0.8 * second_d) best_kp = -1;
     if (live && gl == 0) {
         mp.best_kp[m] = best_kp;
-        mp.best_dist[m] = best_d;
+        mp.best_dist[m] = (PREV && best_kp < 0) ? 3.402823466e+38f : best_d;
         if (mp.visible) mp.visible[m] = vis ? 1 : 0;
     }
   }
@@ -515,15 +535,17 @@ int uh_projmatch_debug_tree(uh_projmatch* h, int32_t* n_nodes, const void** node
     return UH_OK;
 }
 
-int uh_projmatch_match(uh_projmatch* h, const float* pose_f2g, const uh_map_points* mp, float min_desc_dist, float max_repj_dist,
-                       uh_dmatch* matches_out, int32_t cap, int32_t* best_kp_out, float* best_dist_out, uint8_t* visible_out) {
-    UH_REQUIRE(h && h->have_frame, "uh_projmatch_match: no frame set (call uh_projmatch_set_frame first)");
-    UH_REQUIRE(pose_f2g && mp && mp->n >= 0, "uh_projmatch_match: NULL / negative argument");
-    UH_REQUIRE(max_repj_dist > 0, "uh_projmatch_match: maxRepjDist must be > 0 (a non-positive radius turns the reference's search into an unbounded one)");
-    const int n = mp->n;
-    if (n == 0) return 0;
-    UH_REQUIRE(mp->ids && mp->pos3d && mp->normal && mp->min_dist && mp->max_dist && mp->desc, "uh_projmatch_match: map point arrays missing");
-    UH_REQUIRE(matches_out && cap >= 0, "uh_projmatch_match: output buffer missing");
+}  // extern "C"
+
+namespace {
+
+// one implementation behind uh_projmatch_match (octave == nullptr) and uh_projmatch_match_prev (normal/min/max == nullptr)
+int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* ids, const float* pos3d, const float* normal,
+                 const float* mn_dist, const float* mx_dist, const uint8_t* desc, const int32_t* octave, float min_desc_dist,
+                 float max_repj_dist, uh_dmatch* matches_out, int32_t cap, int32_t* best_kp_out, float* best_dist_out, uint8_t* visible_out) {
+    const bool prev = octave != nullptr;
+    struct { int32_t n; const uint32_t* ids; const float* pos3d; const float* normal; const float* min_dist; const float* max_dist; const uint8_t* desc; }
+        mpv{n, ids, pos3d, normal, mn_dist, mx_dist, desc}, *mp = &mpv;
     UH_HIP_CHECK(hipSetDevice(h->ctx->device));
     hipStream_t st = h->ctx->stream;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -539,9 +561,12 @@ int uh_projmatch_match(uh_projmatch* h, const float* pose_f2g, const uh_map_poin
         if ((rc = h->h_in.reserve(o_bk))) return rc;
         char* hi = static_cast<char*>(h->h_in.p);
         std::memcpy(hi + o_pos, mp->pos3d, 12 * (size_t)n);
-        std::memcpy(hi + o_nrm, mp->normal, 12 * (size_t)n);
-        std::memcpy(hi + o_min, mp->min_dist, 4 * (size_t)n);
-        std::memcpy(hi + o_max, mp->max_dist, 4 * (size_t)n);
+        if (prev) std::memcpy(hi + o_min, octave, 4 * (size_t)n);   // the octaves travel in the min_dist slot
+        else {
+            std::memcpy(hi + o_nrm, mp->normal, 12 * (size_t)n);
+            std::memcpy(hi + o_min, mp->min_dist, 4 * (size_t)n);
+            std::memcpy(hi + o_max, mp->max_dist, 4 * (size_t)n);
+        }
         std::memcpy(hi + o_desc, mp->desc, 32 * (size_t)n);
         UH_HIP_CHECK(hipMemcpyAsync(base, hi, o_desc + 32 * (size_t)n, hipMemcpyHostToDevice, st));
     }
@@ -550,6 +575,7 @@ int uh_projmatch_match(uh_projmatch* h, const float* pose_f2g, const uh_map_poin
     P.n = n;
     P.pos3d = (const float*)(base + o_pos); P.normal = (const float*)(base + o_nrm); P.min_dist = (const float*)(base + o_min);
     P.max_dist = (const float*)(base + o_max); P.desc = (const uint64_t*)(base + o_desc);
+    P.octave = (const int*)(base + o_min);
     P.best_kp = (int*)(base + o_bk); P.best_dist = (float*)(base + o_bd); P.visible = (unsigned char*)(base + o_vis);
     PmPose ps;
     const float* T = pose_f2g;
@@ -568,12 +594,18 @@ int uh_projmatch_match(uh_projmatch* h, const float* pose_f2g, const uh_map_poin
         const bool in_lds = tree_bytes + stack_bytes <= kLdsBudget && !getenv("UH_PROJMATCH_NO_LDS");   // env: test knob for the big-frame path
         const size_t lds = stack_bytes + (in_lds ? tree_bytes : 0);
         if (!h->attr_set) {
-            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(projmatch_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(projmatch_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(projmatch_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(projmatch_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(projmatch_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(projmatch_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
             h->attr_set = true;
         }
-        if (in_lds) UH_LAUNCH(h->ctx, projmatch_kernel<true>, dim3(std::min(uh_div_up(n, kGroupsPerWave), kPmMaxBlocks)), dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, (int*)(base + o_ovf));
-        else UH_LAUNCH(h->ctx, projmatch_kernel<false>, dim3(std::min(uh_div_up(n, kGroupsPerWave), kPmMaxBlocks)), dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, (int*)(base + o_ovf));
+        const dim3 grid(std::min(uh_div_up(n, kGroupsPerWave), kPmMaxBlocks));
+        int* d_ovf = (int*)(base + o_ovf);
+        if (in_lds && !prev) UH_LAUNCH(h->ctx, (projmatch_kernel<true, false>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf);
+        else if (!prev) UH_LAUNCH(h->ctx, (projmatch_kernel<false, false>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf);
+        else if (in_lds) UH_LAUNCH(h->ctx, (projmatch_kernel<true, true>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf);
+        else UH_LAUNCH(h->ctx, (projmatch_kernel<false, true>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf);
     }
     UH_HIP_CHECK(hipGetLastError());
     char* ho = static_cast<char*>(h->h_out.p);
@@ -596,6 +628,36 @@ int uh_projmatch_match(uh_projmatch* h, const float* pose_f2g, const uh_map_poin
     UH_REQUIRE(k <= cap, "uh_projmatch_match: %d matches do not fit the output buffer (cap %d)", k, (int)cap);
     if (k) std::memcpy(matches_out, mm.data(), sizeof(uh_dmatch) * (size_t)k);
     return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uh_projmatch_match(uh_projmatch* h, const float* pose_f2g, const uh_map_points* mp, float min_desc_dist, float max_repj_dist,
+                       uh_dmatch* matches_out, int32_t cap, int32_t* best_kp_out, float* best_dist_out, uint8_t* visible_out) {
+    UH_REQUIRE(h && h->have_frame, "uh_projmatch_match: no frame set (call uh_projmatch_set_frame first)");
+    UH_REQUIRE(pose_f2g && mp && mp->n >= 0, "uh_projmatch_match: NULL / negative argument");
+    UH_REQUIRE(max_repj_dist > 0, "uh_projmatch_match: maxRepjDist must be > 0 (a non-positive radius turns the reference's search into an unbounded one)");
+    if (mp->n == 0) return 0;
+    UH_REQUIRE(mp->ids && mp->pos3d && mp->normal && mp->min_dist && mp->max_dist && mp->desc, "uh_projmatch_match: map point arrays missing");
+    UH_REQUIRE(matches_out && cap >= 0, "uh_projmatch_match: output buffer missing");
+    return match_common(h, pose_f2g, mp->n, mp->ids, mp->pos3d, mp->normal, mp->min_dist, mp->max_dist, mp->desc, nullptr, min_desc_dist,
+                        max_repj_dist, matches_out, cap, best_kp_out, best_dist_out, visible_out);
+}
+
+int uh_projmatch_match_prev(uh_projmatch* h, const float* pose_f2g, const uh_prev_points* pp, float min_desc_dist, float max_repj_dist,
+                            uh_dmatch* matches_out, int32_t cap, int32_t* best_kp_out, float* best_dist_out) {
+    UH_REQUIRE(h && h->have_frame, "uh_projmatch_match_prev: no frame set (call uh_projmatch_set_frame first)");
+    UH_REQUIRE(pose_f2g && pp && pp->n >= 0, "uh_projmatch_match_prev: NULL / negative argument");
+    UH_REQUIRE(max_repj_dist > 0, "uh_projmatch_match_prev: maxRepjDist must be > 0 (a non-positive radius turns the reference's search into an unbounded one)");
+    if (pp->n == 0) return 0;
+    UH_REQUIRE(pp->ids && pp->pos3d && pp->octave && pp->desc, "uh_projmatch_match_prev: point arrays missing");
+    UH_REQUIRE(matches_out && cap >= 0, "uh_projmatch_match_prev: output buffer missing");
+    for (int i = 0; i < pp->n; i++)   // Frame::scaleFactors[octave] (system.cpp:6130): out of range is undefined in the reference
+        UH_REQUIRE(pp->octave[i] >= 0 && pp->octave[i] < h->n_levels, "uh_projmatch_match_prev: octave %d of item %d outside [0,%d)", pp->octave[i], i, h->n_levels);
+    return match_common(h, pose_f2g, pp->n, pp->ids, pp->pos3d, nullptr, nullptr, nullptr, pp->desc, pp->octave, min_desc_dist,
+                        max_repj_dist, matches_out, cap, best_kp_out, best_dist_out, nullptr);
 }
 
 }  // extern "C"

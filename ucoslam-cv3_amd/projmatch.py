@@ -28,11 +28,16 @@ class _MapPoints(C.Structure):
     _fields_ = [("n", C.c_int32), ("ids", VP), ("pos3d", VP), ("normal", VP), ("min_dist", VP), ("max_dist", VP), ("desc", VP)]
 
 
+class _PrevPoints(C.Structure):
+    _fields_ = [("n", C.c_int32), ("ids", VP), ("pos3d", VP), ("octave", VP), ("desc", VP)]
+
+
 def _declare(L, sig):
     sig("uh_projmatch_create", I, VP, C.POINTER(VP))
     sig("uh_projmatch_destroy", None, VP)
     sig("uh_projmatch_set_frame", I, VP, C.POINTER(_ProjFrame))
     sig("uh_projmatch_match", I, VP, VP, C.POINTER(_MapPoints), C.c_float, C.c_float, VP, C.c_int32, VP, VP, VP)
+    sig("uh_projmatch_match_prev", I, VP, VP, C.POINTER(_PrevPoints), C.c_float, C.c_float, VP, C.c_int32, VP, VP)
     sig("uh_projmatch_debug_tree", I, VP, C.POINTER(C.c_int32), C.POINTER(VP), C.POINTER(VP), VP, C.POINTER(C.c_int32))
     sig("uh_kdtree_build_host", I, VP, C.c_int32, C.POINTER(C.c_int32), VP, VP, VP, C.POINTER(C.c_int32))
 
@@ -91,6 +96,26 @@ class ProjectionMatcher:
         if rc < 0:
             check(rc)
         return dict(matches=out[:rc].copy(), best_kp=best_kp[:n], best_dist=best_d[:n], visible=vis[:n])
+
+    def matchFrameToPrevFrame(self, pose_f2g, ids, pos3d, octave, prev_desc, minDescDist, maxRepjDist):
+        """The tracker's projection search against the previous frame (system.cpp:5930-6460; called with
+        maxDescDistance*1.5, projDistThr at :6559-6565).  One item per previous-frame keypoint that carries a valid, non-bad map
+        point: its id, coordinates, the keypoint's octave and descriptor.  The current frame is the one given to setFrame,
+        pose_f2g its (predicted) pose.  Returns dict(matches DMATCH_DTYPE[k], best_kp int32[n], best_dist float32[n])."""
+        pose = np.ascontiguousarray(pose_f2g, np.float32).reshape(16)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        n = len(ids)
+        a = [np.ascontiguousarray(pos3d, np.float32).reshape(n, 3), np.ascontiguousarray(octave, np.int32),
+             np.ascontiguousarray(prev_desc, np.uint8).reshape(n, 32)]
+        pp = _PrevPoints(n, np_ptr(ids) if n else None, *[np_ptr(x) if n else None for x in a])
+        out = np.zeros(max(n, 1), DMATCH_DTYPE)
+        best_kp = np.full(max(n, 1), -1, np.int32)
+        best_d = np.zeros(max(n, 1), np.float32)
+        rc = lib().uh_projmatch_match_prev(self._h, np_ptr(pose), C.byref(pp), float(minDescDist), float(maxRepjDist), np_ptr(out), len(out),
+                                           np_ptr(best_kp), np_ptr(best_d))
+        if rc < 0:
+            check(rc)
+        return dict(matches=out[:rc].copy(), best_kp=best_kp[:n], best_dist=best_d[:n])
 
     def debug_tree(self):
         nn, nodes, leaf, depth = C.c_int32(), VP(), VP(), C.c_int32()
