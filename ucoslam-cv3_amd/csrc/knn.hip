@@ -63,7 +63,9 @@ struct WaveHeap {
         if (size >= k) return d < rl(hd, 0);
         return true;
     }
-    // resultset.h:64-82, caller has already established accepts(d)
+    // resultset.h:64-82, caller has already established accepts(d).  LV = depth of the deepest heap slot (floor(log2(k)), 6 covers
+    // k <= 64): the ancestor walk of the root removal is that many cross-lane rounds.
+    template <int LV = 6>
     __device__ __forceinline__ void push_accepted(int d, int idx, int k) {
         const int parent = lane > 0 ? (lane - 1) >> 1 : 0;
         if (size >= k) {
@@ -81,7 +83,7 @@ struct WaveHeap {
                 bool onpath = lane < size;
                 int node = lane;
 #pragma unroll
-                for (int t = 0; t < 6; t++) {                 // heap depth <= 6 for k <= 64
+                for (int t = 0; t < LV; t++) {
                     const int par = node > 0 ? (node - 1) >> 1 : 0;
                     const int cpar = __shfl(c, par);          // independent of the other rounds: all in flight together
                     onpath = onpath && (node == 0 || cpar == node);
@@ -162,7 +164,7 @@ __device__ __forceinline__ int hamming256(const uint4& a0, const uint4& a1, cons
 }
 
 // Feed one step (64 candidates, one per lane, ascending index with lane) into the heap.
-template <bool EMIT>
+template <bool EMIT, int LV = 6>
 __device__ __forceinline__ void feed_step(WaveHeap& h, int d, int idx, bool valid, int k, int maxd,
                                           uint64_t* cand_row, int& ncand, int cap) {
     int thr = h.threshold(k);
@@ -178,11 +180,11 @@ __device__ __forceinline__ void feed_step(WaveHeap& h, int d, int idx, bool vali
             if (ncand < cap && h.lane == 0) cand_row[ncand] = ((uint64_t)(uint32_t)dl << 32) | (uint32_t)il;
             ncand++;
         }
-        h.push_accepted(dl, il, k);
+        h.template push_accepted<LV>(dl, il, k);
     }
 }
 
-template <bool EMIT>
+template <bool EMIT, int LV = 6>
 __device__ __forceinline__ void scan_range(WaveHeap& h, const uint8_t* __restrict__ train, int t0, int t1,
                                            const uint32_t (&q)[8], int k, int maxd,
                                            uint64_t* cand_row, int& ncand, int cap) {
@@ -206,7 +208,7 @@ __device__ __forceinline__ void scan_range(WaveHeap& h, const uint8_t* __restric
         for (int u = 0; u < UNROLL; ++u) { d[u] = hamming256(a0[u], a1[u], q); any = any || d[u] < thr; }
         if (__ballot(any) == 0) continue;
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) feed_step<EMIT>(h, d[u], base + u * kWave + lane, true, k, maxd, cand_row, ncand, cap);
+        for (int u = 0; u < UNROLL; ++u) feed_step<EMIT, LV>(h, d[u], base + u * kWave + lane, true, k, maxd, cand_row, ncand, cap);
     }
     for (; base < t1; base += kWave) {
         int t = base + lane;
@@ -218,7 +220,7 @@ __device__ __forceinline__ void scan_range(WaveHeap& h, const uint8_t* __restric
             a1 = p[1];
         }
         int d = hamming256(a0, a1, q);
-        feed_step<EMIT>(h, d, t, valid, k, maxd, cand_row, ncand, cap);
+        feed_step<EMIT, LV>(h, d, t, valid, k, maxd, cand_row, ncand, cap);
     }
 }
 
@@ -246,7 +248,8 @@ __device__ __forceinline__ void finish_row(WaveHeap& h, int k, int sorted, int32
     }
 }
 
-// One wave per query; whole train range; writes final rows.
+// One wave per query; whole train range; writes final rows.  LV: see WaveHeap::push_accepted (1: k <= 3, 3: k <= 15, 6: k <= 64).
+template <int LV>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_search_kernel(
     const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k,
     int sorted, int maxd, int32_t* __restrict__ indices, int32_t* __restrict__ distances) {
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_search_kernel(
     load_query(queries, qi, q);
     WaveHeap h{0, -1, 0, lane};
     int ncand = 0;
-    scan_range<false>(h, train, t0, t1, q, k, maxd, nullptr, ncand, 0);
+    scan_range<false, LV>(h, train, t0, t1, q, k, maxd, nullptr, ncand, 0);
     finish_row(h, k, sorted, indices, distances, qi);
 }
 
@@ -665,8 +668,9 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
     if (nq == 0) return UH_OK;
     UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
     dim3 grid(uh_div_up(nq, kWavesPerBlock)), block(kWave * kWavesPerBlock);
-    UH_LAUNCH(idx->ctx,knn_search_kernel, grid, block, 0, idx->d_train, idx->shard_begin,
-                       idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances);
+    if (nn <= 3) UH_LAUNCH(idx->ctx, knn_search_kernel<1>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances);
+    else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_search_kernel<3>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances);
+    else UH_LAUNCH(idx->ctx, knn_search_kernel<6>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
 }
