@@ -61,7 +61,7 @@ def test_oracle_edge_jacobian_finite_differences(oracle):
 
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [(10, 3000, 0, 2), (6, 400, 1, 1), (4, 150, 2, 2), (12, 1500, 3, 3), (3, 60, 4, 3), (30, 1200, 5, 2), (22, 900, 6, 2)],
+@pytest.mark.parametrize("cfg", [(10, 3000, 0, 2), (6, 400, 1, 1), (4, 150, 2, 2), (12, 1500, 3, 3), (3, 60, 4, 3), (30, 1200, 5, 2), (22, 900, 6, 2), (14, 700, 7, 2)],
                          ids=lambda c: f"K{c[0]}_P{c[1]}_fix{c[3]}")
 def test_hip_ba_matches_oracle(hip_ctx, oracle, cfg):
     from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet

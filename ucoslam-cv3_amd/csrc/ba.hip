@@ -624,6 +624,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                     if (s1 == s2) {
                         p.bp[6 * s1 + (q - 36)] = h;             // the decide stage needs b_p for computeScale
                         s_x[6 * s1 + (q - 36)] = h - v;
+                        if constexpr (USE_LDS) M[(size_t)n * ld + 6 * s1 + (q - 36)] = h - v;   // row n of the bordered matrix
                     }
                     continue;
                 }
@@ -656,8 +657,12 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
         // LOOK-AHEAD form: panel kb is first applied to block column kb+1 alone, by all four waves; then wave 0 factorises that
         // diagonal block and solves ITS panel while waves 1..3 apply panel kb to the tiles behind — the serial chain of
         // reciprocals no longer waits for the bulk of the trailing update.  The L*D panel is double-buffered (s_w[kb & 1]).
-        __shared__ double s_w[2][120][6];
+        // The right-hand side rides along as row n of the matrix ([S b; b^T .] = bordered system): its L entries are
+        // D^-1 L^-1 b, i.e. the forward substitution and the scaling by D^-1 come out of the panel solves and trailing
+        // updates the factorisation performs anyway (one more row among idle lanes); only L^T x = z is left afterwards.
+        __shared__ double s_w[2][121][6];
         const int nb = n / 6;
+        const int nrow = n + 1;
         auto diag_and_panel = [&](int kb) {   // wave 0 only: block column kb is fully updated
             const int k0 = 6 * kb;
             double a[6][6], dk[6], ik[6];
@@ -689,7 +694,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                     M[(k0 + i) * ld + k0 + i] = dk[i];
                 }
             }
-            for (int r = k0 + 6 + lane; r < n; r += 64) {   // panel: L_rk = A_rk * Lkk^-T * Dk^-1; y = L_rk * Dk goes to s_w
+            for (int r = k0 + 6 + lane; r < nrow; r += 64) {   // panel: L_rk = A_rk * Lkk^-T * Dk^-1; y = L_rk * Dk goes to s_w
                 double y[6];
 #pragma unroll
                 for (int j = 0; j < 6; j++) y[j] = M[r * ld + k0 + j];
@@ -708,7 +713,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
             if (kb == nb - 1) break;
             const int k0 = 6 * kb;
             {   // block column kb+1 first, by everybody (one element per thread and round): wave 0 needs it to go on
-                const int c0 = k0 + 6, m = n - c0;
+                const int c0 = k0 + 6, m = nrow - c0;
                 for (int e = tid; e < m * 6; e += kSolveThreads) {
                     const int r = c0 + e / 6, c = c0 + e % 6;
                     double acc = M[r * ld + c];
@@ -728,6 +733,13 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                 const int t3 = tid - 64;
                 const int tq = t3 / 36, te = t3 - 36 * tq, ti = te / 6, tj = te - 6 * ti;
                 constexpr int kSlots = (kSolveThreads - 64) / 36;
+                // the threads left over by the tile slots update the right-hand-side row behind block column kb+1
+                for (int c = 6 * (kb + 2) + (t3 - 36 * kSlots); t3 >= 36 * kSlots && c < n; c += kSolveThreads - 64 - 36 * kSlots) {
+                    double acc = M[(size_t)n * ld + c];
+#pragma unroll
+                    for (int t = 0; t < 6; t++) acc = fma(-M[(size_t)n * ld + k0 + t], s_w[kb & 1][c][t], acc);
+                    M[(size_t)n * ld + c] = acc;
+                }
                 const int s1min = kb + 2;
                 const int tile0 = s1min * d.nfree - s1min * (s1min - 1) / 2;   // first pair with s1 >= kb+2
                 const int ntile = npairs - tile0;
@@ -846,12 +858,12 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
             // broadcast with v_readlane (j is wave-uniform) and the 2n dependent steps are branch-free: a column outside the
             // matrix, or a lane the step does not touch, multiplies by 0
             if (wv == 0) {
-                double x = lane < n ? s_x[lane] : 0.0;
+                double x = lane < n ? (USE_LDS ? M[(size_t)n * ld + lane] : s_x[lane]) : 0.0;   // LDS path: z = D^-1 L^-1 b is row n
                 const int lr = lane < n ? lane : n - 1;
                 double l[8], ln[8];
 #pragma unroll
                 for (int t = 0; t < 8; t++) { const int jj = t < n ? t : n - 1; l[t] = M[(size_t)lr * ld + jj]; }
-                for (int j0 = 0; j0 < n; j0 += 8) {          // L y = b, 8 columns of L prefetched one round ahead
+                for (int j0 = 0; !USE_LDS && j0 < n; j0 += 8) {          // L y = b, 8 columns of L prefetched one round ahead
 #pragma unroll
                     for (int t = 0; t < 8; t++) { const int jj = j0 + 8 + t < n ? j0 + 8 + t : n - 1; ln[t] = M[(size_t)lr * ld + jj]; }
 #pragma unroll
@@ -861,7 +873,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
 #pragma unroll
                     for (int t = 0; t < 8; t++) l[t] = ln[t];
                 }
-                if (lane < n) x /= M[(size_t)lane * ld + lane];
+                if (!USE_LDS && lane < n) x /= M[(size_t)lane * ld + lane];
 #pragma unroll
                 for (int t = 0; t < 8; t++) { const int jj = n - 1 - t >= 0 ? n - 1 - t : 0; l[t] = M[(size_t)jj * ld + lr]; }
                 for (int j0 = n - 1; j0 >= 0; j0 -= 8) {     // L^T x = y
@@ -877,13 +889,17 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                 if (lane < n) { s_x[lane] = x; p.xp[lane] = x; }
             }
         } else {
-            for (int j = 0; j < n; j++) {
-                const double xj = s_x[j];
-                __syncthreads();
-                for (int i = j + 1 + tid; i < n; i += kSolveThreads) s_x[i] -= M[(size_t)i * ld + j] * xj;
-                __syncthreads();
+            if constexpr (USE_LDS) {   // z = D^-1 L^-1 b is row n of the bordered factorisation
+                for (int i = tid; i < n; i += kSolveThreads) s_x[i] = M[(size_t)n * ld + i];
+            } else {
+                for (int j = 0; j < n; j++) {
+                    const double xj = s_x[j];
+                    __syncthreads();
+                    for (int i = j + 1 + tid; i < n; i += kSolveThreads) s_x[i] -= M[(size_t)i * ld + j] * xj;
+                    __syncthreads();
+                }
+                for (int i = tid; i < n; i += kSolveThreads) s_x[i] /= M[(size_t)i * ld + i];
             }
-            for (int i = tid; i < n; i += kSolveThreads) s_x[i] /= M[(size_t)i * ld + i];
             __syncthreads();
             for (int j = n - 1; j >= 0; j--) {
                 const double xj = s_x[j];
@@ -1225,7 +1241,7 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
     const BADims& d = b->dims;
     const int npairs = d.nfree * (d.nfree + 1) / 2;
     const int use_lds = d.n <= 120 ? 1 : 0;
-    const size_t lds = use_lds ? (size_t)d.n * (d.n + 1) * sizeof(double) : 0;
+    const size_t lds = use_lds ? (size_t)(d.n + 1) * (d.n + 1) * sizeof(double) : 0;   // n rows of S + the right-hand-side row
     for (int s = 0; s < nsteps; s++) {
         const int slot = b->step & 1;   // state left by the previous step (or by begin_pass / the closing decide kernel)
         if (pass_start && s == 0) UH_LAUNCH(b->ctx,ba_lin_kernel, dim3(d.nPointBlocks + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d, slot);
