@@ -151,16 +151,20 @@ struct WaveHeap {
     __device__ __forceinline__ int threshold(int k) const { return size >= k ? rl(hd, 0) : 0x7fffffff; }
 };
 
+// v_bcnt_u32_b32 adds its second operand: a popcount that accumulates costs one instruction.  Written as asm because the
+// compiler otherwise splits the chain into zero-based counts plus v_add3 (19 instead of 17 VALU ops per 256-bit distance) — the scan
+// is bound by VALU issue, not by the latency of the chain.
+__device__ __forceinline__ int bcnt_acc(uint32_t x, int acc) {
+    int r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
 __device__ __forceinline__ int hamming256(const uint4& a0, const uint4& a1, const uint32_t (&q)[8]) {
-    int d = __popc(a0.x ^ q[0]);
-    d += __popc(a0.y ^ q[1]);
-    d += __popc(a0.z ^ q[2]);
-    d += __popc(a0.w ^ q[3]);
-    d += __popc(a1.x ^ q[4]);
-    d += __popc(a1.y ^ q[5]);
-    d += __popc(a1.z ^ q[6]);
-    d += __popc(a1.w ^ q[7]);
-    return d;
+    int d0 = __popc(a0.x ^ q[0]), d1 = __popc(a1.x ^ q[4]);
+    d0 = bcnt_acc(a0.y ^ q[1], d0); d1 = bcnt_acc(a1.y ^ q[5], d1);
+    d0 = bcnt_acc(a0.z ^ q[2], d0); d1 = bcnt_acc(a1.z ^ q[6], d1);
+    d0 = bcnt_acc(a0.w ^ q[3], d0); d1 = bcnt_acc(a1.w ^ q[7], d1);
+    return d0 + d1;
 }
 
 // Feed one step (64 candidates, one per lane, ascending index with lane) into the heap.
@@ -191,13 +195,21 @@ __device__ __forceinline__ void scan_range(WaveHeap& h, const uint8_t* __restric
     const int lane = h.lane;
     constexpr int UNROLL = 4;
     int base = t0;
+    // buffer loads: the per-lane part of the address (lane * 32 + a constant) never changes, the part that moves is wave-uniform
+    // and lives in an SGPR — the group loop spends no VALU instruction on addresses (the flat form needs four 64-bit ones per
+    // 64 rows).  0x00020000: raw 32-bit-format buffer descriptor word of gfx9-family parts.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(train), 0, t1 * 32, 0x00020000);
+    const int voff = lane * 32;
     for (; base + UNROLL * kWave <= t1; base += UNROLL * kWave) {
         uint4 a0[UNROLL], a1[UNROLL];
+        const int soff = __builtin_amdgcn_readfirstlane(base * 32);
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            const uint4* p = reinterpret_cast<const uint4*>(train + (size_t)(base + u * kWave + lane) * 32);
-            a0[u] = p[0];
-            a1[u] = p[1];
+            const u32x4 x0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + u * kWave * 32, soff, 0);
+            const u32x4 x1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + u * kWave * 32 + 16, soff, 0);
+            a0[u] = make_uint4(x0.x, x0.y, x0.z, x0.w);
+            a1[u] = make_uint4(x1.x, x1.y, x1.z, x1.w);
         }
         // one scalar decision per UNROLL steps: almost every group has no row below the current threshold, and each
         // VALU -> ballot -> branch round trip costs more than the 16 VALU ops of a distance
