@@ -95,6 +95,22 @@ def test_hip_knn_radius_bound_and_strided_rows(hip_ctx, oracle):
 
 
 @pytest.mark.gpu
+def test_hip_knn_large_map_and_widest_rows(hip_ctx, oracle):
+    """150 000 train rows (a large map), nn = 64 (the widest row the wave heap holds) and nn = 1, sorted and unsorted; a train
+    count that is not a multiple of the 256-row scan group."""
+    from ucoslam_cv3_amd.knn import Index
+
+    train, q = synth.match_set(300, 150003, seed=41)
+    index = Index(hip_ctx).build(train)
+    for nn in (64, 1, 17):
+        for s in (0, 1):
+            idx, dist = index.search(q, nn, sorted=bool(s))
+            ri, rd = oracle_lib.knn_search(oracle, train, q, nn, s)
+            np.testing.assert_array_equal(idx, ri, err_msg=f"nn={nn} sorted={s}")
+            np.testing.assert_array_equal(dist, rd)
+
+
+@pytest.mark.gpu
 def test_hip_knn_full_size_properties(hip_ctx, oracle):
     """BASELINE size (2000 x 10000): oracle on a query sample + size-independent properties on all rows."""
     import torch

@@ -117,3 +117,20 @@ def test_hip_orb_nonmaxima_switch_bit_exact(hip_ctx, oracle, cfg):
     ext.setNonMaxima(False)                                       # the switch can be cleared again here (sticky in the reference)
     kps2, _ = ext.detectAndCompute(img, None, FeatParams(nf, nl, sf))
     assert len(kps2) == len(plain) and (kps2["class_id"] == -1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(1920, 1080, 4000, 8, 1.2), (3000, 2000, 10000, 8, 1.2), (4095, 700, 6000, 10, 1.2), (2048, 1536, 20000, 4, 1.5)],
+                         ids=lambda c: f"{c[0]}x{c[1]}_{c[2]}f_{c[3]}l")
+def test_hip_orb_large_frames_bit_exact(hip_ctx, oracle, cfg):
+    """Sizes beyond the benchmark's: full-HD and multi-megapixel frames, feature budgets up to 20 000, the widest image the
+    12-bit candidate coordinates allow (4095)."""
+    from ucoslam_cv3_amd.orb import FeatParams, ORBextractor
+
+    w, h, nf, nl, sf = cfg
+    img = synth.frame(w, h, seed=77)
+    ext = ORBextractor.create(hip_ctx)
+    kps, desc = ext.detectAndCompute(img, None, FeatParams(nf, nl, sf))
+    rk, rd = oracle_lib.orb_extract(oracle, img, nf, nl, sf)
+    _assert_same(kps, desc, rk, rd, str(cfg))
+    assert len(kps) > 0.5 * nf
