@@ -368,6 +368,15 @@ int  uh_projmatch_debug_tree(uh_projmatch* pm, int32_t* n_nodes, const void** no
 int  uh_kdtree_build_host(const float* xy, int32_t n, int32_t* n_nodes, void* nodes24_out, uint32_t* leaf_idx_out,
                           double* root_box4, int32_t* max_depth);
 
+/* ------------------------------------------------------------------------
+ * Measurement hooks (used by scripts/time_ba.py and scripts/knn_push_bench.py; not part of the drop-in surface).
+ * uh_ba_debug_clocks: the 64 phase timestamps the BA kernels of the latest LM step left behind (100 MHz wall clock; slots in
+ * csrc/ba.hip, UH_BA_CLK).  uh_knn_debug_push_cycles: shader cycles of n heap pushes at row width k for the cross-lane and the
+ * scalar formulation of the result heap and an empty loop (out3[0..2]).
+ * ------------------------------------------------------------------------ */
+int uh_ba_debug_clocks(uh_ba* ba, int64_t* out64);
+int uh_knn_debug_push_cycles(uh_knn* knn, int k, int n, long long* out3);
+
 #ifdef __cplusplus
 }
 #endif
