@@ -160,11 +160,14 @@ __device__ __forceinline__ bool p_solve6(const double* H, const double* b, doubl
 // whole solve (44 bytes per match, n <= kPnpLdsMatches): the ~40 passes over the matches then cost LDS latency instead
 // of an L2 round trip each.  Larger n runs the same code on the HBM arrays.
 constexpr int kPnpLdsMatches = 3000;
+// 8 waves = two per SIMD of the one CU this kernel lives on: the per-match fp64 chains (two divisions, a square root) of one wave
+// fill the latency gaps of the other; 600 matches are then one or two per thread
+constexpr int kPnpThreads = 512, kPnpWaves = kPnpThreads / 64;
 
 template <bool CACHED>
-__global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
+__global__ __launch_bounds__(kPnpThreads) void pnp_solve_kernel(PnpArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_cache[];
-    __shared__ double s_part[4 * 28], s_sum[28], s_red[kRedThreads];
+    __shared__ double s_part[kPnpWaves * 28], s_sum[28], s_red[kPnpWaves];
     __shared__ PoseD s_T, s_T0, s_bak;
     __shared__ double s_H[36], s_b[6], s_x[6];
     __shared__ double s_lambda, s_ni, s_currentChi, s_lastChiRaw, s_rho;
@@ -185,15 +188,15 @@ __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
         float* c_w = c_is + n;
         active = reinterpret_cast<unsigned char*>(c_w + n);
         robust = active + n; bad = robust + n;
-        for (int i = tid; i < 3 * n; i += kRedThreads) c_p3d[i] = A.p3d[i];
-        for (int i = tid; i < 2 * n; i += kRedThreads) c_kp[i] = A.kp[i];
-        for (int i = tid; i < n; i += kRedThreads) { c_is[i] = A.invsig[i]; c_w[i] = A.weight[i]; }
+        for (int i = tid; i < 3 * n; i += kPnpThreads) c_p3d[i] = A.p3d[i];
+        for (int i = tid; i < 2 * n; i += kPnpThreads) c_kp[i] = A.kp[i];
+        for (int i = tid; i < n; i += kPnpThreads) { c_is[i] = A.invsig[i]; c_w[i] = A.weight[i]; }
         p3d = c_p3d; kpt = c_kp; invsig = c_is; weight = c_w;
     } else {
         e_chi2 = A.e_chi2; p3d = A.p3d; kpt = A.kp; invsig = A.invsig; weight = A.weight;
         active = A.flags; robust = A.flags + n; bad = A.flags + 2 * (size_t)n;
     }
-    for (int e = tid; e < n; e += kRedThreads) { active[e] = 1; robust[e] = 1; bad[e] = 0; e_chi2[e] = 0; }
+    for (int e = tid; e < n; e += kPnpThreads) { active[e] = 1; robust[e] = 1; bad[e] = 0; e_chi2[e] = 0; }
     if (tid == 0) {
         const float* M = A.pose_in;
         const double R0[9] = {M[0], M[1], M[2], M[4], M[5], M[6], M[8], M[9], M[10]};
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
                 double Rt[12];
 #pragma unroll
                 for (int i = 0; i < 12; i++) Rt[i] = s_T.Rt[i];
-                for (int e = tid; e < n; e += kRedThreads) {
+                for (int e = tid; e < n; e += kPnpThreads) {
                     if (!active[e]) continue;
                     double ex, ey, pc[3];
                     edge_err(e, Rt, ex, ey, pc);
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
                     for (int a = 0; a < 6; a++) acc[21 + a] -= rho1 * (J[a] * w * ex + J[6 + a] * w * ey);
                 }
             }
-            block_sum_vec<28>(acc, s_part, s_sum);
+            block_sum_vec<28, kPnpWaves>(acc, s_part, s_sum);
             if (tid == 0) {
                 int q = 0;
                 for (int a = 0; a < 6; a++) for (int cc = a; cc < 6; cc++) { s_H[a * 6 + cc] = s_sum[q]; s_H[cc * 6 + a] = s_sum[q]; q++; }
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
                     double Rt[12];
 #pragma unroll
                     for (int i = 0; i < 12; i++) Rt[i] = s_T.Rt[i];
-                    for (int e = tid; e < n; e += kRedThreads) {
+                    for (int e = tid; e < n; e += kPnpThreads) {
                         if (!active[e]) continue;
                         double ex, ey, pc[3];
                         edge_err(e, Rt, ex, ey, pc);
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
                         part += robchi(e, c);
                     }
                 }
-                const double tempRaw = block_sum(part, s_red);   // valid in every thread
+                const double tempRaw = block_sum<kPnpWaves>(part, s_red);   // valid in every thread
                 if (tid == 0) {
                     s_lastChiRaw = tempRaw;
                     double tempChi = s_ok2 ? tempRaw : DBL_MAX;
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
             double Rt[12];
 #pragma unroll
             for (int i = 0; i < 12; i++) Rt[i] = s_T.Rt[i];
-            for (int e = tid; e < n; e += kRedThreads) {
+            for (int e = tid; e < n; e += kPnpThreads) {
                 double c = e_chi2[e];
                 if (bad[e]) {
                     double ex, ey, pc[3];
@@ -351,15 +354,15 @@ __global__ __launch_bounds__(kRedThreads) void pnp_solve_kernel(PnpArgs A) {
                 good += !b;
             }
         }
-        const double gsum = block_sum((double)good, s_red);
+        const double gsum = block_sum<kPnpWaves>((double)good, s_red);
         if (tid == 0) { A.result[1 + round] = done; s_good = (int)gsum; }
         __syncthreads();
         if (s_good < 10) break;
     }
     __syncthreads();
     int good = 0;
-    for (int e = tid; e < n; e += kRedThreads) { A.bad_out[e] = bad[e]; good += !bad[e]; }
-    const double gsum = block_sum((double)good, s_red);
+    for (int e = tid; e < n; e += kPnpThreads) { A.bad_out[e] = bad[e]; good += !bad[e]; }
+    const double gsum = block_sum<kPnpWaves>((double)good, s_red);
     if (tid == 0) {
         A.result[0] = (int)gsum;
         float* M = A.pose_out;
@@ -407,9 +410,9 @@ int uh_pnp_solve_dev(uh_pnp* p, const float* d_pose_f2g, const float* d_intr4, i
             UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pnp_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kPnpLdsMatches * 44 + 16));
             p->attr_set = true;
         }
-        UH_LAUNCH(p->ctx, pnp_solve_kernel<true>, dim3(1), dim3(kRedThreads), lds, A);
+        UH_LAUNCH(p->ctx, pnp_solve_kernel<true>, dim3(1), dim3(kPnpThreads), lds, A);
     } else {
-        UH_LAUNCH(p->ctx, pnp_solve_kernel<false>, dim3(1), dim3(kRedThreads), 0, A);
+        UH_LAUNCH(p->ctx, pnp_solve_kernel<false>, dim3(1), dim3(kPnpThreads), 0, A);
     }
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;

@@ -1,4 +1,5 @@
-// Deterministic block reductions shared by the fp64 optimisation kernels (ba.hip, pnp.hip).  kThreads = 256.
+// Deterministic block reductions shared by the fp64 optimisation kernels (ba.hip: 256 threads = the default NW = 4 waves;
+// pnp.hip: 512 threads, NW = 8).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -9,6 +10,7 @@ constexpr int kRedThreads = 256;
 // deterministic block sum of one double per thread, result valid in EVERY thread: xor butterfly inside each wave (fixed
 // pairing, all 64 lanes end with the wave total), then the wave totals are added in wave order.  Two barriers instead of the
 // nine of an LDS tree — the fp64 kernels call this on their serial paths.
+template <int NW = 4>
 __device__ __forceinline__ double block_sum(double v, double* s_red) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -17,7 +19,7 @@ __device__ __forceinline__ double block_sum(double v, double* s_red) {
     __syncthreads();
     double r = s_red[0];
 #pragma unroll
-    for (int w = 1; w < kRedThreads / 64; w++) r += s_red[w];
+    for (int w = 1; w < NW; w++) r += s_red[w];
     return r;
 }
 // Deterministic block reduction of N values per thread.  Inside a wave the N x 64 values are reduced with a butterfly
@@ -51,14 +53,19 @@ struct WaveTranspose {
     }
 };
 
-template <int N>
-__device__ __forceinline__ void block_sum_vec(double (&v)[N], double* s_part /* 4*N */, double* s_out /* N */) {
+template <int N, int NW = 4>
+__device__ __forceinline__ void block_sum_vec(double (&v)[N], double* s_part /* NW*N */, double* s_out /* N */) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int off = 0, real = N;
     WaveTranspose<N, 32>::run(v, lane, off, real);
     if (real >= 1) s_part[wv * N + off] = v[0];   // exactly one lane per value index ends with a real slot; the others hold padding
     __syncthreads();
-    if ((int)threadIdx.x < N) s_out[threadIdx.x] = ((s_part[threadIdx.x] + s_part[N + threadIdx.x]) + s_part[2 * N + threadIdx.x]) + s_part[3 * N + threadIdx.x];
+    if ((int)threadIdx.x < N) {
+        double r = s_part[threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < NW; w++) r += s_part[w * N + threadIdx.x];   // wave order (for NW = 4: ((p0 + p1) + p2) + p3, as before)
+        s_out[threadIdx.x] = r;
+    }
     __syncthreads();
 }
 
