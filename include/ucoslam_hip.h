@@ -285,6 +285,36 @@ int uh_match_filter(const uh_match_filter_args* args, uh_dmatch* out, int cap);
 /* filter_ambiguous_train (by_train != 0) / filter_ambiguous_query (by_train == 0), in place; returns the new count */
 int uh_filter_ambiguous(uh_dmatch* matches, int n, int by_train);
 
+/* FrameMatcher_BoW::match / matchEpipolar (framematcher.cpp:395-535): features of the two frames that share a vocabulary node
+ * (Frame::bowvector_level, the fbow::fBow2 of uh_bow_transform at level 3) are compared all against all.  A frame comes as the
+ * node map in std::map order — ascending node ids, per node the feature indices in push_back order — plus the keypoint arrays
+ * and `used` = isUsed(frame, idx, mode) (:373-379: not FLAG_NONMAXIMA, and assigned / unassigned as the mode asks; NULL = all).
+ * Hamming distances and the order-dependent best / "last not better" bookkeeping (:441-476) run on the GPU, the acceptance
+ * rule, filter_ambiguous_train and the orientation histogram on the host.  Matches: queryIdx / trainIdx = keypoint indices.
+ * A node with an empty list is refused (the reference's loop would never advance past it, :436). */
+typedef struct uh_bow_frame {
+    int32_t n_nodes;
+    const uint32_t* node_ids;       /* n_nodes, ascending */
+    const int32_t* node_ptr;        /* n_nodes + 1 offsets into feat_idx */
+    const uint32_t* feat_idx;       /* keypoint indices, node lists back to back */
+    int32_t n_kpts;
+    const uint8_t* desc;            /* n_kpts x 32 */
+    const int32_t* octave; const float* angle;   /* und_kpts fields */
+    const float* pt;                /* n_kpts x 2 (x, y); only read with F12 */
+    const uint8_t* used;            /* n_kpts or NULL */
+} uh_bow_frame;
+typedef struct uh_bow_match_args {
+    uh_bow_frame query, train;
+    const float* scale_factors; int32_t n_levels;   /* query frame scaleFactors (only with F12) */
+    const float* F12;               /* row-major 3x3 fundamental matrix (getFund12) or NULL */
+    float min_desc_dist, nn_match_ratio;
+    int32_t check_orientation, max_octave_diff;
+} uh_bow_match_args;
+typedef struct uh_bowmatch uh_bowmatch;
+int  uh_bowmatch_create(uh_ctx* ctx, uh_bowmatch** out);
+void uh_bowmatch_destroy(uh_bowmatch* bm);
+int  uh_bowmatch_match(uh_bowmatch* bm, const uh_bow_match_args* args, uh_dmatch* out, int cap);
+
 /* ------------------------------------------------------------------------
  * Pose-only optimisation — replaces PnPSolver::solvePnp (monocular matches, no markers):
  *   src/optimization/pnpsolver.h:30-38, pnpsolver.cpp:116-409; edge type typesg2o.h:590-650; kernel :82-105.

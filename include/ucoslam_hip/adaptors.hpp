@@ -249,6 +249,23 @@ class PnPSolver {
 };
 
 // ---- ucoslam::Map::matchFrameToMapPoints (map.cpp:651-770) on a flattened frame / candidate list -------------------------
+// ucoslam::FrameMatcher (TYPE_BOW), framematcher.cpp:395-535, on flattened frames (see uh_bow_frame)
+class FrameMatcherBoW {
+   public:
+    explicit FrameMatcherBoW(std::shared_ptr<Context> ctx) : ctx_(std::move(ctx)) { check(uh_bowmatch_create(ctx_->get(), &h_)); }
+    ~FrameMatcherBoW() { uh_bowmatch_destroy(h_); }
+    std::vector<uh_dmatch> matchEpipolar(const uh_bow_match_args& args) {
+        std::vector<uh_dmatch> out(args.query.n_kpts > 0 ? args.query.n_kpts : 1);
+        const int k = uh_bowmatch_match(h_, &args, out.data(), (int)out.size());
+        if (k < 0) check(k);
+        out.resize(k);
+        return out;
+    }
+   private:
+    std::shared_ptr<Context> ctx_;
+    uh_bowmatch* h_ = nullptr;
+};
+
 class ProjectionMatcher {
    public:
     explicit ProjectionMatcher(std::shared_ptr<Context> ctx) : ctx_(std::move(ctx)) { check(uh_projmatch_create(ctx_->get(), &h_)); }

@@ -106,6 +106,39 @@ def km_case(seed):
 
 run("kmeans_index", km_case)
 
+# ---- BoW frame matcher (GPU distances + order-dependent bookkeeping, shared host tail) vs the pure-Python restatement
+import py_oracle_matcher as pyo
+from ucoslam_cv3_amd import matcher as MM
+bowm = MM.FrameMatcherBoW(ctx)
+
+def bowm_case(seed):
+    r = np.random.default_rng(seed)
+    nq, nt = int(r.integers(1, 300)), int(r.integers(1, 400))
+    le = bool(r.random() < 0.5)
+    train, q = synth.match_set(nq, nt, seed=seed % 100000)
+    if le:
+        train[:, 1:] = 0; q[:, 1:] = 0
+    def fr(n, desc):
+        return dict(desc=desc, ids=np.where(r.random(n) < 0.5, r.integers(0, 1000, n), 0xFFFFFFFF).astype(np.uint32), nonmaxima=r.random(n) < 0.05,
+                    octave=r.integers(0, 8, n).astype(np.int32), angle=(r.random(n) * 360).astype(np.float32), pt=(r.random((n, 2)) * 600).astype(np.float32),
+                    scaleFactors=(1.2 ** np.arange(8)).astype(np.float32))
+    tf, qf = fr(nt, train), fr(nq, q)
+    nn = int(r.integers(1, 40))
+    for f, n in ((tf, nt), (qf, nq)):
+        bv = {}
+        for i, nd in enumerate(r.integers(0, nn, n).tolist()):
+            bv.setdefault(int(nd) * 3, []).append(i)
+        f["bowvector_level"] = bv
+    tm, qm = int(r.integers(0, 3)), int(r.integers(0, 3))
+    md, ratio, co, mod = float(r.choice([3.0, 6.0] if le else [60.0, 100.0, 3e38])), float(r.choice([0.6, 0.8, 0.9])), bool(r.random() < 0.5), int(r.integers(0, 4))
+    F = (r.normal(0, 1, 9) * [1e-6, 1e-5, 1e-3, 1e-5, 1e-6, 1e-3, 1e-3, 1e-3, 1]).astype(np.float32) if r.random() < 0.4 else None
+    bowm.setParams(tf, tm, md, ratio, co, mod)
+    g = bowm.matchEpipolar(qf, qm, F)
+    o = pyo.bow_match(qf, tf, MM.is_used(qf, qm), MM.is_used(tf, tm), md, ratio, co, mod, F12=F)
+    return [(int(m["queryIdx"]), int(m["trainIdx"]), float(m["distance"])) for m in g] == [(m["queryIdx"], m["trainIdx"], m["distance"]) for m in o], (nq, nt, le, tm, qm, md, ratio, co, mod, F is not None)
+
+run("bow_matcher", bowm_case)
+
 # ---- projection matcher
 from ucoslam_cv3_amd.projmatch import ProjectionMatcher
 pm = ProjectionMatcher(ctx)

@@ -48,6 +48,12 @@ def match_filter(indices, distances, q, t, map_q, map_t, min_desc_dist, ratio, c
                     best2, oct2 = d, int(t["octave"][tk])
         if bq != -1 and not (oct2 == int(q["octave"][bq]) and best > best2 * F32(ratio)):
             matches.append(dict(queryIdx=bq, trainIdx=bt, distance=float(best)))
+    return finish(matches, q, t, check_orientation)
+
+
+def finish(matches, q, t, check_orientation):
+    """filter_ambiguous_train + orientation histogram (framematcher.cpp:288-316 and :504-531)"""
+    F32 = np.float32
     matches = filter_ambiguous(matches, "trainIdx")
     if check_orientation:
         hist = [[] for _ in range(30)]
@@ -81,3 +87,46 @@ def match_filter(indices, distances, q, t, map_q, map_t, min_desc_dist, ratio, c
                 matches[k]["queryIdx"] = matches[k]["trainIdx"] = -1
         matches = [m for m in matches if m["trainIdx"] != -1 and m["queryIdx"] != -1]
     return matches
+
+
+def epipolar_sq_dist(kp1, kp2, F):
+    """misc.h:72-81 in float arithmetic; F row-major 3x3 (flat)"""
+    F32 = np.float32
+    a = F32(F32(F32(kp1[0] * F[0]) + F32(kp1[1] * F[3])) + F[6])
+    b = F32(F32(F32(kp1[0] * F[1]) + F32(kp1[1] * F[4])) + F[7])
+    den = F32(F32(a * a) + F32(b * b))
+    if den == 0:
+        return np.finfo(np.float32).max
+    c = F32(F32(F32(kp1[0] * F[2]) + F32(kp1[1] * F[5])) + F[8])
+    num = F32(F32(F32(a * kp2[0]) + F32(b * kp2[1])) + c)
+    return F32(F32(num * num) / den)
+
+
+def bow_match(q, t, q_used, t_used, min_desc_dist, ratio, check_orientation, max_octave_diff, F12=None):
+    """FrameMatcher_BoW::matchEpipolar (framematcher.cpp:407-535) on frame dicts with `bowvector_level` {node: [kp idx]}."""
+    F32 = np.float32
+    matches = []
+    qb, tb = q["bowvector_level"], t["bowvector_level"]
+    sf2 = [F32(v * v) for v in q["scaleFactors"].astype(np.float32)]
+    for node in sorted(set(qb) & set(tb)):                      # the merge-join visits the common keys in ascending order
+        for qidx in qb[node]:
+            if not q_used[qidx]:
+                continue
+            best, best2 = F32(min_desc_dist), F32(np.finfo(np.float32).max)
+            bq = bt = -1
+            oct2 = -1
+            for tidx in tb[node]:
+                if not t_used[tidx]:
+                    continue
+                if abs(int(t["octave"][tidx]) - int(q["octave"][qidx])) > max_octave_diff:
+                    continue
+                if F12 is not None and float(epipolar_sq_dist(t["pt"][tidx], q["pt"][qidx], F12)) >= 3.84 * float(sf2[int(q["octave"][qidx])]):
+                    continue
+                d = F32(int(np.unpackbits(t["desc"][tidx] ^ q["desc"][qidx]).sum()))
+                if d < best:
+                    best, bq, bt = d, qidx, tidx
+                else:
+                    best2, oct2 = d, int(t["octave"][tidx])
+            if bq != -1 and not (oct2 == int(q["octave"][bq]) and best > F32(best2 * F32(ratio))):
+                matches.append(dict(queryIdx=int(bq), trainIdx=int(bt), distance=float(best)))
+    return finish(matches, q, t, check_orientation)

@@ -89,3 +89,110 @@ def test_hip_frame_matcher_end_to_end(hip_ctx, oracle, exact):
         ref = pyo.match_filter(idx, dist, qf, tf, map_q, map_t, 100.0, 0.6, True, 3)
         assert _as_tuples(got) == [(m["queryIdx"], m["trainIdx"], m["distance"]) for m in ref]
         assert len(got) > 10
+
+
+def _bow_frames(nq, nt, seed, n_nodes=120, low_entropy=False):
+    """Two frames whose features share vocabulary nodes: each query feature is a noisy copy of a train feature and mostly lands in
+    the same node (as a real vocabulary would put it), some land elsewhere; node lists in feature order like fBow2's push_back."""
+    rng = np.random.default_rng(seed)
+    train, q = synth.match_set(nq, nt, seed=seed)
+    if low_entropy:                                   # many equal distances: the "last not better" rule becomes order sensitive
+        train[:, 2:] = 0
+        q[:, 2:] = 0
+    tf, qf = _frame(nt, rng, train), _frame(nq, rng, q)
+    src = rng.integers(0, nt, nq)
+    qf["octave"] = np.clip(tf["octave"][src] + rng.integers(-1, 2, nq), 0, 7).astype(np.int32)
+    qf["angle"] = ((tf["angle"][src] + 25 + rng.normal(0, 4, nq)) % 360).astype(np.float32)
+    t_node = rng.integers(0, n_nodes, nt) * 7 + 3      # sparse, unsorted-looking node ids
+    q_node = np.where(rng.random(nq) < 0.8, t_node[src], rng.integers(0, n_nodes, nq) * 7 + 3)
+    for f, nodes in ((tf, t_node), (qf, q_node)):
+        bv = {}
+        for i, nd in enumerate(nodes.tolist()):
+            bv.setdefault(int(nd), []).append(i)
+        f["bowvector_level"] = bv
+    return qf, tf
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(400, 1500, 1, False), (2000, 2000, 2, False), (700, 900, 3, True), (1, 1, 4, False), (50, 3000, 5, True)],
+                         ids=lambda c: f"q{c[0]}_t{c[1]}{'_ties' if c[3] else ''}")
+def test_hip_bow_matcher_matches_independent_restatement(hip_ctx, cfg):
+    """FrameMatcher (TYPE_BOW): GPU distances + bookkeeping and the shared host tail vs the pure-Python restatement, all modes,
+    with and without the epipolar gate."""
+    from ucoslam_cv3_amd import matcher as M
+
+    nq, nt, seed, le = cfg
+    qf, tf = _bow_frames(nq, nt, seed, low_entropy=le)
+    fm = M.FrameMatcherBoW(hip_ctx)
+    rng = np.random.default_rng(seed)
+    F12 = (rng.normal(0, 1, 9) * [1e-6, 1e-5, 1e-3, 1e-5, 1e-6, 1e-3, 1e-3, 1e-3, 1]).astype(np.float32)
+    total = 0
+    for tmode, qmode, params, F in [(M.MODE_ALL, M.MODE_ALL, (100.0 if not le else 6.0, 0.6, True, 3), None),
+                                    (M.MODE_ASSIGNED, M.MODE_ALL, (60.0 if not le else 3.0, 0.8, False, 1), None),
+                                    (M.MODE_ALL, M.MODE_UNASSIGNED, (np.inf, 0.8, True, 1), None),
+                                    (M.MODE_ALL, M.MODE_ALL, (100.0 if not le else 6.0, 0.9, True, 2), F12)]:
+        fm.setParams(tf, tmode, *params)
+        got = fm.matchEpipolar(qf, qmode, F)
+        ref = pyo.bow_match(qf, tf, M.is_used(qf, qmode), M.is_used(tf, tmode), min(params[0], np.finfo(np.float32).max), *params[1:], F12=F)
+        assert _as_tuples(got) == [(m["queryIdx"], m["trainIdx"], m["distance"]) for m in ref]
+        total += len(got)
+    if nq >= 400:
+        assert total > 30
+
+
+@pytest.mark.gpu
+def test_hip_bow_matcher_known_answers_and_errors(hip_ctx):
+    import ucoslam_cv3_amd as u
+    from ucoslam_cv3_amd import matcher as M
+
+    z = np.zeros
+    d = np.zeros((4, 32), np.uint8)
+    d[1, 0] = 0b111          # distance 3 from descriptor 0
+    d[2, 0] = 0b1            # distance 1
+    d[3, 0] = 0b11           # distance 2
+    base = dict(ids=np.full(4, 0xFFFFFFFF, np.uint32), nonmaxima=z(4, bool), octave=z(4, np.int32), angle=z(4, np.float32),
+                pt=z((4, 2), np.float32), scaleFactors=np.ones(8, np.float32))
+    q = dict(base, desc=d[:1].copy(), ids=base["ids"][:1], nonmaxima=z(1, bool), octave=z(1, np.int32), angle=z(1, np.float32),
+             pt=z((1, 2), np.float32), bowvector_level={5: [0]})
+    fm = M.FrameMatcherBoW(hip_ctx)
+    # candidates at distances 3, 1, 2 in this order: best ends at 1; "second" is the LAST not-better one (2), not the smallest
+    # (3 was overwritten): 1 > 2 * 0.4 -> rejected; with the list order 2, 1, 3 the last not-better is 3: 1 > 3 * 0.4 is false -> accepted
+    t = dict(base, desc=d.copy(), bowvector_level={5: [1, 2, 3]})
+    fm.setParams(t, M.MODE_ALL, 100.0, 0.4, False, 1)
+    assert _as_tuples(fm.match(q)) == []
+    t["bowvector_level"] = {5: [3, 2, 1]}
+    assert _as_tuples(fm.match(q)) == [(0, 2, 1.0)]
+    # no common node -> nothing; a node with an empty list is refused
+    t["bowvector_level"] = {6: [1, 2, 3]}
+    assert _as_tuples(fm.match(q)) == []
+    t["bowvector_level"] = {5: []}
+    with pytest.raises(u.UcoslamHipError):
+        fm.match(q)
+
+
+@pytest.mark.gpu
+def test_hip_bow_matcher_end_to_end_with_vocabulary(hip_ctx):
+    """The chain the reference runs (keyframedatabase.cpp:319 -> FrameMatcher_BoW): Vocabulary::transform(desc, 3) on the GPU gives
+    each frame's fBow2, the BoW matcher consumes them; compared with the Python restatement fed the same maps."""
+    from ucoslam_cv3_amd import matcher as M
+    from ucoslam_cv3_amd.bow import Vocabulary, write_vocabulary_stream
+
+    params, blob, meta = synth.vocabulary(k=10, depth=4, seed=3, aligment=8)
+    voc = Vocabulary(hip_ctx).fromStream(write_vocabulary_stream(params, blob))
+    rng = np.random.default_rng(12)
+    nt, nq = 1500, 1200
+    train = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    src = rng.integers(0, nt, nq)
+    q = train[src] ^ np.packbits(rng.random((nq, 256)) < 0.03, axis=1, bitorder="little")
+    tf, qf = _frame(nt, rng, train), _frame(nq, rng, q)
+    qf["octave"] = tf["octave"][src]
+    qf["angle"] = ((tf["angle"][src] + 40 + rng.normal(0, 3, nq)) % 360).astype(np.float32)
+    for f in (tf, qf):
+        f["bowvector_level"] = voc.transform(f["desc"], 3)[1]
+    fm = M.FrameMatcherBoW(hip_ctx)
+    fm.setParams(tf, M.MODE_ALL, 100.0, 0.6, True, 1)
+    got = fm.match(qf, M.MODE_ALL)
+    ref = pyo.bow_match(qf, tf, M.is_used(qf, M.MODE_ALL), M.is_used(tf, M.MODE_ALL), 100.0, 0.6, True, 1)
+    assert _as_tuples(got) == [(m["queryIdx"], m["trainIdx"], m["distance"]) for m in ref]
+    right = sum(1 for m in got if src[m["queryIdx"]] == m["trainIdx"])
+    assert len(got) > 100 and right > 0.8 * len(got)

@@ -6,10 +6,19 @@
 // This is sequential policy over <= nq*nn candidates (microseconds on a host core); it stays on the host exactly like the
 // reference, consuming the (bit-exact, heap-ordered) rows of uh_knn_search.  The result depends on the column ORDER of the
 // unsorted rows, which is why uh_knn_search reproduces the reference heap layout.
+//
+// FrameMatcher_BoW (src/utils/framematcher.cpp:407-535): the second matcher type.  Features of the two frames that fell into
+// the same vocabulary node (fbow::fBow2 of Vocabulary::transform at level 3, keyframedatabase.cpp:319) are compared all against
+// all; the Hamming distances and the per-query-feature best / "last not better" bookkeeping run on the GPU (bow_match_kernel,
+// one lane per query feature, candidates in the node's list order — the rule is order dependent), the rest of the chain
+// (filter_ambiguous_train, orientation histogram) is the host code shared with the FLANN matcher.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <vector>
+
+#include <hip/hip_runtime.h>
 
 #include "common.hpp"
 
@@ -53,6 +62,97 @@ void filter_ambiguous(std::vector<uh_dmatch>& matches, bool by_train) {
         idx++;
     }
     if (needRemove) remove_unused(matches);
+}
+
+// the tail both matcher types share: filter_ambiguous_train, then the 30-bin orientation histogram keeping the three maxima
+// (framematcher.cpp:288-316 and :504-531)
+void finish_matches(std::vector<uh_dmatch>& matches, const float* t_angle, const float* q_angle, int check_orientation) {
+    filter_ambiguous(matches, true);
+    if (check_orientation) {
+        std::vector<std::vector<int>> rotHist(30);
+        const float factor = 1.0f / float(rotHist.size());
+        for (size_t midx = 0; midx < matches.size(); midx++) {
+            float rot = t_angle[matches[midx].trainIdx] - q_angle[matches[midx].queryIdx];
+            if (rot < 0.0) rot += 360.0f;
+            size_t bin = (size_t)std::round(rot * factor);
+            if (bin == rotHist.size()) bin = 0;
+            rotHist[bin].push_back((int)midx);
+        }
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        {   // computeThreeMaxima
+            int max1 = 0, max2 = 0, max3 = 0;
+            for (size_t i = 0; i < rotHist.size(); i++) {
+                const int s = (int)rotHist[i].size();
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = (int)i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = (int)i; }
+                else if (s > max3) { max3 = s; ind3 = (int)i; }
+            }
+            if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if (max3 < 0.1f * (float)max1) ind3 = -1;
+        }
+        for (int i = 0; i < (int)rotHist.size(); i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int midx : rotHist[i]) matches[midx].queryIdx = matches[midx].trainIdx = -1;
+        }
+        remove_unused(matches);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BoW matcher kernel
+struct BowMatchDev {
+    int n_entries;                   // query features listed under nodes both frames have, in (node, list) order
+    const unsigned int* q_feat;      // [n_entries] query keypoint index
+    const int* t_begin;              // [n_entries] first candidate in t_feat
+    const int* t_count;              // [n_entries]
+    const unsigned int* t_feat;      // candidates: train keypoint indices, node lists back to back
+    const uint64_t* q_desc; const uint64_t* t_desc;        // n x 4 words
+    const int* q_octave; const int* t_octave;
+    const float* q_pt; const float* t_pt;                  // (x, y) pairs, only read with F12
+    const unsigned char* q_used; const unsigned char* t_used;   // isUsed(frame, idx, mode) per keypoint
+    const float* scale2;             // scaleFactors[i]^2 of the query frame
+    float F[9]; int have_F;
+    float min_desc_dist; int max_octave_diff;
+    int* best_train; float* best_dist; float* best_dist2; int* octave_best2;   // [n_entries] outputs
+};
+
+__device__ __forceinline__ float epipolar_sq_dist_dev(const float* kp1, const float* kp2, const float* F) {   // misc.h:72-81
+    const float a = kp1[0] * F[0] + kp1[1] * F[3] + F[6];
+    const float b = kp1[0] * F[1] + kp1[1] * F[4] + F[7];
+    const float den = a * a + b * b;
+    if (den == 0) return 3.402823466e+38f;
+    const float c = kp1[0] * F[2] + kp1[1] * F[5] + F[8];
+    const float num = a * kp2[0] + b * kp2[1] + c;
+    return num * num / den;
+}
+
+// framematcher.cpp:441-476 for one query feature: candidates in list order; a candidate below the best REPLACES it, any other
+// one (that passed the gates) overwrites bestDist2 / octaveBest2 — "last not better", not "second best"
+__global__ __launch_bounds__(256) void bow_match_kernel(BowMatchDev a) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.n_entries) return;
+    const unsigned int qi = a.q_feat[e];
+    int bestTrain = -1, octaveBest2 = -1;
+    float bestDist = a.min_desc_dist, bestDist2 = 3.402823466e+38f;
+    if (a.q_used[qi]) {
+        const uint64_t* qd = a.q_desc + 4 * (size_t)qi;
+        const uint64_t q0 = qd[0], q1 = qd[1], q2 = qd[2], q3 = qd[3];
+        const int qo = a.q_octave[qi];
+        const int b = a.t_begin[e], n = a.t_count[e];
+        for (int j = 0; j < n; j++) {
+            const unsigned int ti = a.t_feat[b + j];
+            if (!a.t_used[ti]) continue;
+            const int to = a.t_octave[ti];
+            if (abs(to - qo) > a.max_octave_diff) continue;
+            if (a.have_F) {
+                if (epipolar_sq_dist_dev(a.t_pt + 2 * (size_t)ti, a.q_pt + 2 * (size_t)qi, a.F) >= 3.84 * (double)a.scale2[qo]) continue;
+            }
+            const uint64_t* td = a.t_desc + 4 * (size_t)ti;
+            const float dist = (float)(__popcll(q0 ^ td[0]) + __popcll(q1 ^ td[1]) + __popcll(q2 ^ td[2]) + __popcll(q3 ^ td[3]));
+            if (dist < bestDist) { bestDist = dist; bestTrain = (int)ti; }
+            else { bestDist2 = dist; octaveBest2 = to; }
+        }
+    }
+    a.best_train[e] = bestTrain; a.best_dist[e] = bestDist; a.best_dist2[e] = bestDist2; a.octave_best2[e] = octaveBest2;
 }
 
 }  // namespace
@@ -103,36 +203,135 @@ int uh_match_filter(const uh_match_filter_args* a, uh_dmatch* out, int cap) {
             }
         }
     }
-    filter_ambiguous(matches, true);
-    if (a->check_orientation) {
-        std::vector<std::vector<int>> rotHist(30);
-        const float factor = 1.0f / float(rotHist.size());
-        for (size_t midx = 0; midx < matches.size(); midx++) {
-            float rot = a->t_angle[matches[midx].trainIdx] - a->q_angle[matches[midx].queryIdx];
-            if (rot < 0.0) rot += 360.0f;
-            size_t bin = (size_t)std::round(rot * factor);
-            if (bin == rotHist.size()) bin = 0;
-            rotHist[bin].push_back((int)midx);
-        }
-        int ind1 = -1, ind2 = -1, ind3 = -1;
-        {   // computeThreeMaxima
-            int max1 = 0, max2 = 0, max3 = 0;
-            for (size_t i = 0; i < rotHist.size(); i++) {
-                const int s = (int)rotHist[i].size();
-                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = (int)i; }
-                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = (int)i; }
-                else if (s > max3) { max3 = s; ind3 = (int)i; }
-            }
-            if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-            else if (max3 < 0.1f * (float)max1) ind3 = -1;
-        }
-        for (int i = 0; i < (int)rotHist.size(); i++) {
-            if (i == ind1 || i == ind2 || i == ind3) continue;
-            for (int midx : rotHist[i]) matches[midx].queryIdx = matches[midx].trainIdx = -1;
-        }
-        remove_unused(matches);
-    }
+    finish_matches(matches, a->t_angle, a->q_angle, a->check_orientation);
     if ((int)matches.size() > cap) { uh::set_error("uh_match_filter: %zu matches but capacity %d", matches.size(), cap); return UH_ECAPACITY; }
+    std::copy(matches.begin(), matches.end(), out);
+    return (int)matches.size();
+}
+
+}  // extern "C"
+
+struct uh_bowmatch {
+    uh_ctx* ctx = nullptr;
+    uh::DevBuf d_buf;
+    uh::PinBuf h_in, h_out;
+};
+
+extern "C" {
+
+int uh_bowmatch_create(uh_ctx* ctx, uh_bowmatch** out) {
+    UH_REQUIRE(ctx && out, "uh_bowmatch_create: NULL argument");
+    uh_bowmatch* h = new uh_bowmatch();
+    h->ctx = ctx;
+    *out = h;
+    return UH_OK;
+}
+
+void uh_bowmatch_destroy(uh_bowmatch* h) { delete h; }
+
+static int check_bow_frame(const uh_bow_frame* f, const char* which) {
+    UH_REQUIRE(f->n_kpts >= 0 && f->n_nodes >= 0, "uh_bowmatch_match: %s frame: negative size", which);
+    if (f->n_nodes > 0) UH_REQUIRE(f->node_ids && f->node_ptr && f->feat_idx, "uh_bowmatch_match: %s frame: node lists missing", which);
+    if (f->n_kpts > 0) UH_REQUIRE(f->desc && f->octave && f->angle, "uh_bowmatch_match: %s frame: keypoint arrays missing", which);
+    for (int i = 0; i < f->n_nodes; i++) {
+        UH_REQUIRE(f->node_ptr[i + 1] > f->node_ptr[i], "uh_bowmatch_match: %s frame: node %d has an empty list (the reference's loop never advances past one)", which, i);
+        if (i) UH_REQUIRE(f->node_ids[i] > f->node_ids[i - 1], "uh_bowmatch_match: %s frame: node ids must ascend (std::map order)", which);
+    }
+    const int total = f->n_nodes ? f->node_ptr[f->n_nodes] : 0;
+    for (int i = 0; i < total; i++) UH_REQUIRE((int)f->feat_idx[i] < f->n_kpts, "uh_bowmatch_match: %s frame: feature index %u out of range", which, f->feat_idx[i]);
+    return UH_OK;
+}
+
+int uh_bowmatch_match(uh_bowmatch* h, const uh_bow_match_args* a, uh_dmatch* out, int cap) {
+    UH_REQUIRE(h && a && out, "uh_bowmatch_match: NULL argument");
+    const uh_bow_frame& Q = a->query;
+    const uh_bow_frame& T = a->train;
+    int rc;
+    if ((rc = check_bow_frame(&Q, "query"))) return rc;
+    if ((rc = check_bow_frame(&T, "train"))) return rc;
+    if (a->F12) UH_REQUIRE(Q.pt && T.pt && a->scale_factors && a->n_levels >= 1, "uh_bowmatch_match: epipolar gate needs points and scale factors");
+    // merge-join of the two node maps (framematcher.cpp:422-489): query features of common nodes, with their candidate ranges
+    std::vector<unsigned int> q_feat;
+    std::vector<int> t_begin, t_count;
+    {
+        int qi = 0, ti = 0;
+        while (qi < Q.n_nodes && ti < T.n_nodes) {
+            if (Q.node_ids[qi] == T.node_ids[ti]) {
+                for (int k = Q.node_ptr[qi]; k < Q.node_ptr[qi + 1]; k++) {
+                    q_feat.push_back(Q.feat_idx[k]);
+                    t_begin.push_back(T.node_ptr[ti]);
+                    t_count.push_back(T.node_ptr[ti + 1] - T.node_ptr[ti]);
+                }
+                ++qi; ++ti;
+            } else if (Q.node_ids[qi] < T.node_ids[ti]) ++qi;
+            else ++ti;
+        }
+    }
+    const int ne = (int)q_feat.size();
+    std::vector<uh_dmatch> matches;
+    if (ne > 0) {
+        if (a->F12) for (int i = 0; i < Q.n_kpts; i++) UH_REQUIRE(Q.octave[i] >= 0 && Q.octave[i] < a->n_levels, "uh_bowmatch_match: query octave %d outside the scale factors", Q.octave[i]);
+        UH_HIP_CHECK(hipSetDevice(h->ctx->device));
+        hipStream_t st = h->ctx->stream;
+        const int nt_feat = T.node_ptr[T.n_nodes];
+        auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off = al(off + bytes); return o; };
+        const size_t o_qf = take(4 * (size_t)ne), o_tb = take(4 * (size_t)ne), o_tc = take(4 * (size_t)ne), o_tf = take(4 * (size_t)nt_feat);
+        const size_t o_qd = take(32 * (size_t)Q.n_kpts), o_td = take(32 * (size_t)T.n_kpts), o_qo = take(4 * (size_t)Q.n_kpts), o_to = take(4 * (size_t)T.n_kpts);
+        const size_t o_qp = take(8 * (size_t)Q.n_kpts), o_tp = take(8 * (size_t)T.n_kpts), o_qu = take(Q.n_kpts), o_tu = take(T.n_kpts);
+        const size_t o_s2 = take(4 * (size_t)std::max(a->n_levels, 1));
+        const size_t in_bytes = off;
+        const size_t o_bt = take(4 * (size_t)ne), o_bd = take(4 * (size_t)ne), o_b2 = take(4 * (size_t)ne), o_o2 = take(4 * (size_t)ne);
+        const size_t out_bytes = off - o_bt;
+        if ((rc = h->d_buf.reserve(off))) return rc;
+        if ((rc = h->h_in.reserve(in_bytes))) return rc;
+        if ((rc = h->h_out.reserve(out_bytes))) return rc;
+        char* hi = static_cast<char*>(h->h_in.p);
+        std::memcpy(hi + o_qf, q_feat.data(), 4 * (size_t)ne);
+        std::memcpy(hi + o_tb, t_begin.data(), 4 * (size_t)ne);
+        std::memcpy(hi + o_tc, t_count.data(), 4 * (size_t)ne);
+        std::memcpy(hi + o_tf, T.feat_idx, 4 * (size_t)nt_feat);
+        std::memcpy(hi + o_qd, Q.desc, 32 * (size_t)Q.n_kpts);
+        std::memcpy(hi + o_td, T.desc, 32 * (size_t)T.n_kpts);
+        std::memcpy(hi + o_qo, Q.octave, 4 * (size_t)Q.n_kpts);
+        std::memcpy(hi + o_to, T.octave, 4 * (size_t)T.n_kpts);
+        if (a->F12) { std::memcpy(hi + o_qp, Q.pt, 8 * (size_t)Q.n_kpts); std::memcpy(hi + o_tp, T.pt, 8 * (size_t)T.n_kpts); }
+        if (Q.used) std::memcpy(hi + o_qu, Q.used, Q.n_kpts); else std::memset(hi + o_qu, 1, Q.n_kpts);
+        if (T.used) std::memcpy(hi + o_tu, T.used, T.n_kpts); else std::memset(hi + o_tu, 1, T.n_kpts);
+        if (a->F12) for (int i = 0; i < a->n_levels; i++) { const float v = a->scale_factors[i]; reinterpret_cast<float*>(hi + o_s2)[i] = v * v; }
+        char* base = h->d_buf.as<char>();
+        UH_HIP_CHECK(hipMemcpyAsync(base, hi, in_bytes, hipMemcpyHostToDevice, st));
+        BowMatchDev D{};
+        D.n_entries = ne;
+        D.q_feat = (const unsigned int*)(base + o_qf); D.t_begin = (const int*)(base + o_tb); D.t_count = (const int*)(base + o_tc);
+        D.t_feat = (const unsigned int*)(base + o_tf);
+        D.q_desc = (const uint64_t*)(base + o_qd); D.t_desc = (const uint64_t*)(base + o_td);
+        D.q_octave = (const int*)(base + o_qo); D.t_octave = (const int*)(base + o_to);
+        D.q_pt = (const float*)(base + o_qp); D.t_pt = (const float*)(base + o_tp);
+        D.q_used = (const unsigned char*)(base + o_qu); D.t_used = (const unsigned char*)(base + o_tu);
+        D.scale2 = (const float*)(base + o_s2);
+        D.have_F = a->F12 ? 1 : 0;
+        if (a->F12) for (int i = 0; i < 9; i++) D.F[i] = a->F12[i];
+        D.min_desc_dist = a->min_desc_dist; D.max_octave_diff = a->max_octave_diff;
+        D.best_train = (int*)(base + o_bt); D.best_dist = (float*)(base + o_bd); D.best_dist2 = (float*)(base + o_b2); D.octave_best2 = (int*)(base + o_o2);
+        UH_LAUNCH(h->ctx, bow_match_kernel, dim3(uh_div_up(ne, 256)), dim3(256), 0, D);
+        UH_HIP_CHECK(hipGetLastError());
+        char* ho = static_cast<char*>(h->h_out.p);
+        UH_HIP_CHECK(hipMemcpyAsync(ho, base + o_bt, out_bytes, hipMemcpyDeviceToHost, st));
+        UH_HIP_CHECK(hipStreamSynchronize(st));
+        const int* bt = (const int*)ho;
+        const float* bd = (const float*)(ho + (o_bd - o_bt));
+        const float* b2 = (const float*)(ho + (o_b2 - o_bt));
+        const int* o2 = (const int*)(ho + (o_o2 - o_bt));
+        for (int e = 0; e < ne; e++) {   // framematcher.cpp:477-487, in (node, list) order
+            if (bt[e] < 0) continue;
+            const int bq = (int)q_feat[e];
+            if (!(o2[e] == Q.octave[bq] && bd[e] > b2[e] * a->nn_match_ratio)) matches.push_back(uh_dmatch{bq, bt[e], -1, bd[e]});
+        }
+    }
+    finish_matches(matches, T.angle, Q.angle, a->check_orientation);
+    if ((int)matches.size() > cap) { uh::set_error("uh_bowmatch_match: %zu matches but capacity %d", matches.size(), cap); return UH_ECAPACITY; }
     std::copy(matches.begin(), matches.end(), out);
     return (int)matches.size();
 }

@@ -31,9 +31,22 @@ class _Args(C.Structure):
                 ("check_orientation", C.c_int32), ("max_octave_diff", C.c_int32)]
 
 
+class _BowFrame(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("node_ids", VP), ("node_ptr", VP), ("feat_idx", VP), ("n_kpts", C.c_int32), ("desc", VP),
+                ("octave", VP), ("angle", VP), ("pt", VP), ("used", VP)]
+
+
+class _BowArgs(C.Structure):
+    _fields_ = [("query", _BowFrame), ("train", _BowFrame), ("scale_factors", VP), ("n_levels", C.c_int32), ("F12", VP),
+                ("min_desc_dist", C.c_float), ("nn_match_ratio", C.c_float), ("check_orientation", C.c_int32), ("max_octave_diff", C.c_int32)]
+
+
 def _declare(L, sig):
     sig("uh_match_filter", I, C.POINTER(_Args), VP, I)
     sig("uh_filter_ambiguous", I, VP, I, I)
+    sig("uh_bowmatch_create", I, VP, C.POINTER(VP))
+    sig("uh_bowmatch_destroy", None, VP)
+    sig("uh_bowmatch_match", I, VP, C.POINTER(_BowArgs), VP, I)
 
 
 _lib._EXTRA_DECLS.append(_declare)
@@ -110,3 +123,71 @@ class FrameMatcher:
         else:
             idx, dist = self.index.search_kmeans(qdesc, self.NN, self.MAX_SEARCH, sorted=False)
         return match_filter(idx, dist, queryFrame, self._train, map_q, self._map_t, F12=F12, **self._p)
+
+
+def is_used(frame, mode):
+    """FrameMatcher_BoW::isUsed (framematcher.cpp:373-379) for every keypoint of a frame."""
+    used = ~frame["nonmaxima"].astype(bool)
+    if mode == MODE_ASSIGNED:
+        used &= frame["ids"] != 0xFFFFFFFF
+    elif mode == MODE_UNASSIGNED:
+        used &= frame["ids"] == 0xFFFFFFFF
+    return used.astype(np.uint8)
+
+
+class FrameMatcherBoW:
+    """ucoslam::FrameMatcher (TYPE_BOW): framematcher.cpp:395-535.  A frame is the dict FrameMatcher takes plus
+    `bowvector_level`: {node id: [keypoint indices]} — the fBow2 of Vocabulary.transform(desc, 3) (keyframedatabase.cpp:319)."""
+
+    def __init__(self, ctx: _lib.Context):
+        self.ctx = ctx
+        self._h = VP()
+        check(lib().uh_bowmatch_create(ctx.handle, C.byref(self._h)))
+        self._train = None
+
+    def setParams(self, trainFrame, mode=MODE_ALL, minDescDist=np.inf, nn_match_ratio=0.8, checkOrientation=True, maxOctaveDiff=1):
+        self._p = (float(min(minDescDist, np.finfo(np.float32).max)), float(nn_match_ratio), int(checkOrientation), int(maxOctaveDiff))
+        self._train, self._train_mode = trainFrame, mode
+
+    def match(self, queryFrame, mode=MODE_ALL):
+        return self.matchEpipolar(queryFrame, mode, None)
+
+    def matchEpipolar(self, queryFrame, mode=MODE_ALL, F12=None):
+        keep = []
+
+        def arr(a, dt):
+            a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            return np_ptr(a) if a.size else None
+
+        def frame(f, m):
+            bv = f["bowvector_level"]
+            ids = sorted(bv)                                    # std::map order
+            ptr = np.zeros(len(ids) + 1, np.int32)
+            for i, k in enumerate(ids):
+                ptr[i + 1] = ptr[i] + len(bv[k])
+            feat = np.concatenate([np.asarray(bv[k], np.uint32) for k in ids]) if ids else np.zeros(0, np.uint32)
+            n = len(f["desc"])
+            return _BowFrame(len(ids), arr(ids, np.uint32), arr(ptr, np.int32), arr(feat, np.uint32), n, arr(f["desc"], np.uint8),
+                             arr(f["octave"], np.int32), arr(f["angle"], np.float32), arr(f["pt"], np.float32), arr(is_used(f, m), np.uint8))
+
+        md, ratio, co, mod = self._p
+        sf = np.ascontiguousarray(queryFrame["scaleFactors"], np.float32)
+        args = _BowArgs(frame(queryFrame, mode), frame(self._train, self._train_mode), np_ptr(sf), len(sf),
+                        arr(F12, np.float32) if F12 is not None else None, md, ratio, co, mod)
+        out = np.zeros(max(len(queryFrame["desc"]), 1), DMATCH_DTYPE)
+        n = lib().uh_bowmatch_match(self._h, C.byref(args), np_ptr(out), len(out))
+        if n < 0:
+            check(n)
+        return out[:n].copy()
+
+    def close(self):
+        if self._h:
+            lib().uh_bowmatch_destroy(self._h)
+            self._h = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
