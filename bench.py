@@ -198,6 +198,31 @@ def main():
             step_640()
         stage_ms["step_ms_640x480"] = timed(step_640, 15)
         stage_ms["frames_per_s_640x480"] = 1e3 * F / stage_ms["step_ms_640x480"]
+        # headroom figure, NOT the metric: two independent sessions (two frame streams, two maps, two local BAs) on this one GPU —
+        # the latency-bound launch chains of the two BAs interleave, which one session cannot do with itself
+        ctx_ba2 = u.Context(local_rank, private=True)
+        ba2 = GlobalOptimizer.create(ctx_ba2)
+        ba2.setParams(synth.ba_problem(BA_K, BA_P, seed=rank + 100), ParamSet(nIters=5))
+        ctx_t2 = u.Context(local_rank, private=True)
+        ext_b = ORBextractor.create(ctx_t2)
+        idx_b = Index(ctx_t2).build(map_desc)
+        out_b = ext_b.extract_batch(frames, fp)
+        knn_idx_b, knn_dist_b = torch.empty_like(knn_idx), torch.empty_like(knn_dist)
+
+        def step_two_sessions():
+            ba.optimize_async()
+            ba2.optimize_async()
+            ext.extract_batch(frames, fp, orb_out)
+            ext_b.extract_batch(frames, fp, out_b)
+            check(L.uh_knn_search_dev(index._h, dev_ptr(orb_out[1]), F * NQ, NN, dev_ptr(knn_idx), dev_ptr(knn_dist), 0, -1))
+            check(L.uh_knn_search_dev(idx_b._h, dev_ptr(out_b[1]), F * NQ, NN, dev_ptr(knn_idx_b), dev_ptr(knn_dist_b), 0, -1))
+            ba.wait()
+            ba2.wait()
+
+        for _ in range(3):
+            step_two_sessions()
+        stage_ms["two_sessions_step_ms"] = timed(step_two_sessions, 15)
+        stage_ms["two_sessions_frames_per_s"] = 1e3 * 2 * F / stage_ms["two_sessions_step_ms"]
         stage_ms["orb_ms_per_frame_640x480"] = timed(lambda: ext2.extract_batch(fr2, fp, out2), 20) / F
         # not part of the metric's step (ORB + match + local BA): the per-frame pose-only solve (PnPSolver::solvePnp, 600 matches)
         from ucoslam_cv3_amd.pnp import PnPSolver
