@@ -190,7 +190,8 @@ int uh_orb_debug_level(uh_orb* orb, int frame, int level, int which, uint8_t* ou
  *   obs     : one monocular EdgeSE3ProjectXYZ per (point, frame): undistorted keypoint (float x,y) and
  *             information scalar 1/scaleFactor[octave] (globaloptimizer_g2o.cpp:96-97,244)
  * Arithmetic is fp64 like g2o; poses agree with the reference within 1e-6 (se3 state), see DESIGN.md.
- * Limits this round: monocular edges only, <= 64 non-fixed frames.
+ * Monocular edges only.  Up to 64 non-fixed frames run the local-BA form (two launches per LM trial, reduced system in one
+ * workgroup's LDS); more (global BA, up to 4096) run the wide form: sparse camera-pair lists, blocked dense LDL^T in HBM.
  * ------------------------------------------------------------------------ */
 typedef struct uh_ba uh_ba;
 

@@ -90,6 +90,34 @@ def test_hip_ba_matches_oracle(hip_ctx, oracle, cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(10, 3000, 0, 2, True), (6, 400, 1, 1, True), (3, 60, 4, 2, True), (30, 1200, 5, 2, True), (14, 700, 7, 2, True),
+                                 (80, 2500, 8, 2, False), (150, 4000, 9, 1, False)],
+                         ids=lambda c: f"K{c[0]}_P{c[1]}_fix{c[3]}{'_forced' if c[4] else ''}")
+def test_hip_ba_wide_form_matches_oracle(hip_ctx, oracle, cfg, monkeypatch):
+    """The form for more than 64 free keyframes (global BA: sparse camera-pair lists, blocked dense LDL^T in HBM): forced on the
+    small problems the other form solves (UH_BA_WIDE=1 is read by uh_ba_set_problem), and on 78 / 149 free keyframes."""
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    K, P, seed, nfix, forced = cfg
+    if forced:
+        monkeypatch.setenv("UH_BA_WIDE", "1")
+    pr = synth.ba_problem(K, P, seed, nfixed=nfix)
+    opt = GlobalOptimizer.create(hip_ctx)
+    opt.setParams(pr, ParamSet(nIters=5))
+    opt.optimize()
+    got = opt.getResults()
+    ref = oracle_lib.ba_optimize(oracle, pr, 5)
+    assert got["iters"].tolist() == ref["iters"].tolist()
+    assert np.abs(got["state"] - ref["state"]).max() < POSE_TOL, np.abs(got["state"] - ref["state"]).max()
+    assert np.abs(got["poses"] - ref["poses"]).max() < 1e-5
+    assert np.abs(got["points"] - ref["points"]).max() < 1e-4
+    assert (got["bad"] == ref["bad"]).mean() > 0.9995
+    np.testing.assert_array_equal(got["poses"][pr["fixed"] == 1], pr["poses"][pr["fixed"] == 1])
+    opt.optimize()
+    np.testing.assert_array_equal(opt.getResults()["state"], got["state"])
+
+
+@pytest.mark.gpu
 def test_hip_ba_stop_flag_and_errors(hip_ctx, oracle):
     import ucoslam_cv3_amd as u
     from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet

@@ -368,6 +368,7 @@ __device__ __forceinline__ DecideSums decide_sums(const BAPtrs& p, const BADims&
     double xs = 0;
 #pragma unroll
     for (int k = 0; k < 6 * kMaxFree / 64; k++) xs += xv[k] * (lambda0 * xv[k] + bv[k]);
+    for (int i = lane + 6 * kMaxFree; i < d.n; i += 64) { const double x = p.xp[i]; xs += x * (lambda0 * x + p.bp[i]); }   // wide problems
     DecideSums r;
     r.lin = wave_sum_fixed(l0); r.chi = wave_sum_fixed(l1); r.scale = wave_sum_fixed(l2); r.xs = wave_sum_fixed(xs);
     return r;
@@ -535,6 +536,62 @@ __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, 
     block_sum_vec<42>(acc, s_part, s_out);
     if (have_pair && threadIdx.x < 42) p.Spart[((size_t)chunk * npairs + pair) * 42 + threadIdx.x] = s_out[threadIdx.x];
     UH_BA_CLK(5);
+}
+
+// Pose update of free pose `s` into the trial buffer: T_trial = exp(dx) * T_cur (SE3Quat::exp, VertexSE3Expmap::oplusImpl);
+// with ok == 0 (the solve failed) the trial pose is the current one.  x: the solved increment (LDS or HBM).
+__device__ __forceinline__ void pose_update_one(const BAPtrs& p, int s, int cur, int ok, const double* x) {
+    const int trial = cur ^ 1;
+    const int k = p.free_kf[s];
+    const double* T = p.pose[cur] + 7 * k;
+    double q[4] = {T[0], T[1], T[2], T[3]}, t[3] = {T[4], T[5], T[6]};
+    if (ok) {
+        const double* dx = x + 6 * s;
+        const double w0 = dx[0], w1 = dx[1], w2 = dx[2];
+        const double theta = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+        const double O[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+        double O2[9];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
+        double a, b, c1, c2;
+        if (theta < 0.00001) { a = 1; b = 0.5; c1 = 0.5; c2 = 1.0 / 6.0; }
+        else {
+            double sn, cs;
+            sincos(theta, &sn, &cs);
+            a = sn / theta; b = (1 - cs) / (theta * theta); c1 = b; c2 = (theta - sn) / (theta * theta * theta);
+        }
+        double Rm[9], V[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) { const double I = (i % 4 == 0) ? 1.0 : 0.0; Rm[i] = I + a * O[i] + b * O2[i]; V[i] = I + c1 * O[i] + c2 * O2[i]; }
+        double qe[4];
+        quat_from_R(Rm, qe);
+        quat_norm_pos(qe);
+        double te[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) te[r] = V[r * 3] * dx[3] + V[r * 3 + 1] * dx[4] + V[r * 3 + 2] * dx[5];
+        double RE[9];
+        quat_to_R(qe, RE);
+        double qn[4];
+        qn[3] = qe[3] * q[3] - qe[0] * q[0] - qe[1] * q[1] - qe[2] * q[2];
+        qn[0] = qe[3] * q[0] + qe[0] * q[3] + qe[1] * q[2] - qe[2] * q[1];
+        qn[1] = qe[3] * q[1] + qe[1] * q[3] + qe[2] * q[0] - qe[0] * q[2];
+        qn[2] = qe[3] * q[2] + qe[2] * q[3] + qe[0] * q[1] - qe[1] * q[0];
+        double tn[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) tn[r] = RE[r * 3] * t[0] + RE[r * 3 + 1] * t[1] + RE[r * 3 + 2] * t[2] + te[r];
+        quat_norm_pos(qn);
+#pragma unroll
+        for (int i = 0; i < 4; i++) q[i] = qn[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) t[i] = tn[i];
+    }
+    double* To = p.pose[trial] + 7 * k;
+    To[0] = q[0]; To[1] = q[1]; To[2] = q[2]; To[3] = q[3]; To[4] = t[0]; To[5] = t[1]; To[6] = t[2];
+    double* Ro = p.poseR[trial] + 12 * k;
+    quat_to_R(q, Ro);
+    Ro[9] = t[0]; Ro[10] = t[1]; Ro[11] = t[2];
 }
 
 // ------------------------------------------------------------------------------------------------ solve + pose update
@@ -916,59 +973,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     UH_BA_CLKL(13);
     if (tid == 0) p.st[slot].solve_ok = ok;
     // pose update into the trial buffer (fixed poses are identical in both buffers and never touched)
-    const int trial = cur ^ 1;
-    if (tid < d.nfree) {
-        const int k = p.free_kf[tid];
-        const double* T = p.pose[cur] + 7 * k;
-        double q[4] = {T[0], T[1], T[2], T[3]}, t[3] = {T[4], T[5], T[6]};
-        if (ok) {
-            const double* dx = s_x + 6 * tid;
-            const double w0 = dx[0], w1 = dx[1], w2 = dx[2];
-            const double theta = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
-            const double O[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
-            double O2[9];
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
-            double a, b, c1, c2;
-            if (theta < 0.00001) { a = 1; b = 0.5; c1 = 0.5; c2 = 1.0 / 6.0; }
-            else {
-                double sn, cs;
-                sincos(theta, &sn, &cs);
-                a = sn / theta; b = (1 - cs) / (theta * theta); c1 = b; c2 = (theta - sn) / (theta * theta * theta);
-            }
-            double Rm[9], V[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) { const double I = (i % 4 == 0) ? 1.0 : 0.0; Rm[i] = I + a * O[i] + b * O2[i]; V[i] = I + c1 * O[i] + c2 * O2[i]; }
-            double qe[4];
-            quat_from_R(Rm, qe);
-            quat_norm_pos(qe);
-            double te[3];
-#pragma unroll
-            for (int r = 0; r < 3; r++) te[r] = V[r * 3] * dx[3] + V[r * 3 + 1] * dx[4] + V[r * 3 + 2] * dx[5];
-            double RE[9];
-            quat_to_R(qe, RE);
-            double qn[4];
-            qn[3] = qe[3] * q[3] - qe[0] * q[0] - qe[1] * q[1] - qe[2] * q[2];
-            qn[0] = qe[3] * q[0] + qe[0] * q[3] + qe[1] * q[2] - qe[2] * q[1];
-            qn[1] = qe[3] * q[1] + qe[1] * q[3] + qe[2] * q[0] - qe[0] * q[2];
-            qn[2] = qe[3] * q[2] + qe[2] * q[3] + qe[0] * q[1] - qe[1] * q[0];
-            double tn[3];
-#pragma unroll
-            for (int r = 0; r < 3; r++) tn[r] = RE[r * 3] * t[0] + RE[r * 3 + 1] * t[1] + RE[r * 3 + 2] * t[2] + te[r];
-            quat_norm_pos(qn);
-#pragma unroll
-            for (int i = 0; i < 4; i++) q[i] = qn[i];
-#pragma unroll
-            for (int i = 0; i < 3; i++) t[i] = tn[i];
-        }
-        double* To = p.pose[trial] + 7 * k;
-        To[0] = q[0]; To[1] = q[1]; To[2] = q[2]; To[3] = q[3]; To[4] = t[0]; To[5] = t[1]; To[6] = t[2];
-        double* Ro = p.poseR[trial] + 12 * k;
-        quat_to_R(q, Ro);
-        Ro[9] = t[0]; Ro[10] = t[1]; Ro[11] = t[2];
-    }
+    if (tid < d.nfree) pose_update_one(p, tid, cur, ok, s_x);
     UH_BA_CLKL(14);
     out.done = false; out.ok = ok; out.cur = cur; out.lambda = lambda;
 }
@@ -994,6 +999,281 @@ __global__ __launch_bounds__(64) void ba_decide_kernel(BAPtrs p, BADims d, int s
     UH_BA_CLKL(24);
     p.st[slot] = apply_decision(st0, sm, stopv != 0 || st0.stop_seen != 0);
     p.clk[25] = wall_clock64();
+}
+
+// ------------------------------------------------------------------------------------------------ wide problems
+// More than kMaxFree free keyframes (global BA, System::globalOptimization system.cpp:7809-7939): the dense "every camera pair x
+// every landmark" schur launch and the one-workgroup solve do not scale, so
+//   * the camera pairs that actually share landmarks are listed on the host (pair -> its (landmark, edge1, edge2) triples in
+//     landmark order, cut into work items of <= 256 triples); one workgroup per item writes a partial 6x6 (+6), one workgroup per
+//     pair adds its items in order into the dense reduced system S (lower triangle, row n = right-hand side: bordered form);
+//   * S is factorised as L D L^T in HBM by a right-looking blocked sweep (64-column panels: diagonal block in one workgroup's
+//     LDS, panel rows one per thread, trailing update in 64x64 tiles of register-blocked fp64 FMAs — fp64 MFMA has the same peak
+//     as vector FMA on gfx950, so it would buy nothing here), the border row comes out as D^-1 L^-1 b, and L^T x = z is solved
+//     block by block from the last panel upwards;
+//   * the LM decision that every schur workgroup of the small form takes for itself is one 64-lane launch (ba_advance_kernel).
+// Linearisation, back-substitution, relabelling and results are the kernels of the small form (they never depended on nfree).
+constexpr int kWNB = 64;   // panel width of the blocked factorisation
+
+struct BAWide {
+    int n_pairs, n_items, ld;
+    const int* pair_s1; const int* pair_s2; const int* pair_item_ptr;   // [n_pairs], [n_pairs], [n_pairs + 1]
+    const int* item_pair; const int* item_begin; const int* item_count;  // [n_items]
+    const int* tri_pt; const int* tri_e1; const int* tri_e2;             // triples, pair-major, landmark order inside a pair
+    double* Wpart;          // [n_items][42]
+    double* S;              // (n + 1) x ld, ld = n + 1; row n = right-hand side
+    double* Y;              // (n + 1) x kWNB: L*D of the current panel's rows
+    int* fail;              // set by the factorisation on a zero / non-finite pivot
+};
+
+// The prologue of ba_schur_kernel as a launch of its own: previous trial's decision, lambda at the first iteration, publish.
+__global__ __launch_bounds__(64) void ba_advance_kernel(BAPtrs p, BADims d, int slot) {
+    const int lane = threadIdx.x;
+    const BAState st0 = p.st[slot];
+    const DecideSums sm = decide_sums(p, d, lane, st0.lambda);
+    BAState st = (st0.phase != 2 && st0.pending) ? apply_decision(st0, sm, st0.stop_seen != 0) : st0;
+    if (st.phase == 2) {
+        if (lane == 0) { st.pending = 0; p.st[slot ^ 1] = st; }
+        return;
+    }
+    if (st.iteration == 0 && st.qmax == 0) {   // computeLambdaInit: tau * max |H_jj| over poses and landmarks
+        double m = 0;
+        for (int i = lane; i < d.nPointBlocks; i += 64) m = fmax(m, p.part_maxdiag[i]);
+        for (int i = lane; i < d.nfree * 6; i += 64) {
+            const int s = i / 6, a = i - 6 * s;
+            const int q = a * 6 - a * (a - 1) / 2;   // diagonal entries of the 21-entry upper triangle: 0, 6, 11, 15, 18, 20
+            double v = 0;
+            for (int c = 0; c < kCamChunks; c++) v += p.HppPart[((size_t)s * kCamChunks + c) * 27 + q];
+            m = fmax(m, fabs(v));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+        st.lambda = 1e-5 * m; st.ni = 2;
+    }
+    if (lane == 0) { BAState pub = st; pub.pending = 1; pub.stop_seen = 0; p.st[slot ^ 1] = pub; }
+}
+
+// grid = n_items + nfree * kCamChunks; `slot` = the state ba_advance_kernel published
+__global__ __launch_bounds__(kThreads) void ba_schurw_kernel(BAPtrs p, BADims d, BAWide w, int slot) {
+    __shared__ double s_part[4 * 42];
+    __shared__ double s_out[42];
+    const BAState st = p.st[slot];
+    if (st.phase == 2) return;
+    if ((int)blockIdx.x >= w.n_items) {
+        if (!st.first_trial) camera_block(p, d, blockIdx.x - w.n_items, p.poseR[st.cur], p.pts[st.cur]);
+        return;
+    }
+    const int item = blockIdx.x, pair = w.item_pair[item];
+    const bool diag = w.pair_s1[pair] == w.pair_s2[pair];
+    const double lambda = st.lambda;
+    double acc[42];
+#pragma unroll
+    for (int i = 0; i < 42; i++) acc[i] = 0;
+    if ((int)threadIdx.x < w.item_count[item]) {
+        const int t = w.item_begin[item] + threadIdx.x;
+        const int pt = w.tri_pt[t], e1 = w.tri_e1[t], e2 = w.tri_e2[t];
+        if ((p.e_active[e1] != 0) & (p.e_active[e2] != 0)) {
+            double D[9], Di[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) D[i] = p.Hll[st.cur][9 * (size_t)pt + i];
+            D[0] += lambda; D[4] += lambda; D[8] += lambda;
+            inv3(D, Di);
+            double b1[18], b2[18];
+            const double* B1 = p.Hpl[st.cur] + 18 * (size_t)e1;
+            const double* B2 = p.Hpl[st.cur] + 18 * (size_t)e2;
+#pragma unroll
+            for (int i = 0; i < 18; i++) { b1[i] = B1[i]; b2[i] = B2[i]; }
+            double l0 = 0, l1 = 0, l2 = 0;
+            if (diag) { const double* bi = p.bl[st.cur] + 3 * (size_t)pt; l0 = bi[0]; l1 = bi[1]; l2 = bi[2]; }
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                const double y0 = b1[a * 3] * Di[0] + b1[a * 3 + 1] * Di[3] + b1[a * 3 + 2] * Di[6];
+                const double y1 = b1[a * 3] * Di[1] + b1[a * 3 + 1] * Di[4] + b1[a * 3 + 2] * Di[7];
+                const double y2 = b1[a * 3] * Di[2] + b1[a * 3 + 1] * Di[5] + b1[a * 3 + 2] * Di[8];
+#pragma unroll
+                for (int c = 0; c < 6; c++) acc[a * 6 + c] += y0 * b2[c * 3] + y1 * b2[c * 3 + 1] + y2 * b2[c * 3 + 2];
+                acc[36 + a] += y0 * l0 + y1 * l1 + y2 * l2;
+            }
+        }
+    }
+    block_sum_vec<42>(acc, s_part, s_out);
+    if (threadIdx.x < 42) w.Wpart[(size_t)item * 42 + threadIdx.x] = s_out[threadIdx.x];
+}
+
+// grid = n_pairs, 64 threads (42 used): S block of the pair = [Hpp + lambda I on diagonal pairs] - sum of the pair's items (in
+// order), mirrored into the lower triangle; diagonal pairs also write b_p (for the decision) and the border row b_p - B D^-1 b_l
+__global__ __launch_bounds__(64) void ba_assemblew_kernel(BAPtrs p, BADims d, BAWide w, int slot) {
+    const BAState st = p.st[slot];
+    if (st.phase == 2) return;
+    const int pair = blockIdx.x, q = threadIdx.x;
+    if (q >= 42) return;
+    const int s1 = w.pair_s1[pair], s2 = w.pair_s2[pair];
+    double v = 0;
+    for (int it = w.pair_item_ptr[pair]; it < w.pair_item_ptr[pair + 1]; it++) v += w.Wpart[(size_t)it * 42 + q];
+    double h = 0;
+    if (s1 == s2) {
+        int hq;
+        if (q >= 36) hq = 21 + (q - 36);
+        else { const int a = q / 6, c = q - a * 6, lo = a < c ? a : c, hi = a < c ? c : a; hq = lo * 6 - lo * (lo - 1) / 2 + (hi - lo); }
+        for (int cch = 0; cch < kCamChunks; cch++) h += p.HppPart[((size_t)s1 * kCamChunks + cch) * 27 + hq];
+    }
+    const size_t ld = w.ld;
+    if (q >= 36) {
+        if (s1 == s2) { p.bp[6 * s1 + (q - 36)] = h; w.S[(size_t)d.n * ld + 6 * s1 + (q - 36)] = h - v; }
+        return;
+    }
+    const int a = q / 6, c = q - a * 6;
+    v = -v;
+    if (s1 == s2) v += h + (a == c ? st.lambda : 0.0);
+    const int r = 6 * s1 + a, cc = 6 * s2 + c;
+    if (s1 == s2) { if (c <= a) w.S[(size_t)r * ld + cc] = v; }
+    else w.S[(size_t)cc * ld + r] = v;
+}
+
+// diagonal block [k0, k0+nb) of the blocked LDL^T: one workgroup, block in LDS (row stride kWNB+1); afterwards S holds L (strict
+// lower) and d (diagonal) of the block
+__global__ __launch_bounds__(256) void ba_ldlw_diag_kernel(BAPtrs p, BAWide w, int slot, int k0, int nb) {
+    if (p.st[slot].phase == 2) return;
+    __shared__ double A[kWNB][kWNB + 1];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x;
+    const size_t ld = w.ld;
+    if (tid == 0) s_bad = 0;
+    for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, c = e - i * nb; if (c <= i) A[i][c] = w.S[(size_t)(k0 + i) * ld + k0 + c]; }
+    __syncthreads();
+    for (int j = 0; j < nb; j++) {
+        const double dj = A[j][j];
+        if (dj == 0.0 || !isfinite(dj)) { if (tid == 0) s_bad = 1; }
+        const double inv = 1.0 / dj;
+        // trailing update of the block with column j: A[i][c] -= (A[i][j] / d_j) * A[c][j], j < c <= i   (A[.][j] still holds L*d_j)
+        const int m = nb - 1 - j;
+        for (int e = tid; e < m * m; e += 256) {
+            const int i = j + 1 + e / m, c = j + 1 + e % m;
+            if (c <= i) A[i][c] = fma(-(A[i][j] * inv), A[c][j], A[i][c]);
+        }
+        __syncthreads();
+        for (int i = j + 1 + tid; i < nb; i += 256) A[i][j] *= inv;
+        __syncthreads();
+    }
+    for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, c = e - i * nb; if (c <= i) w.S[(size_t)(k0 + i) * ld + k0 + c] = A[i][c]; }
+    if (tid == 0 && s_bad) *w.fail = 1;
+}
+
+// panel rows r in [k0+nb, n] (the border row included), one per thread: Y_r = A_rk Lkk^-T (= L_rk D), L_rk = Y_r D^-1
+__global__ __launch_bounds__(256) void ba_ldlw_panel_kernel(BAPtrs p, BADims d, BAWide w, int slot, int k0, int nb) {
+    if (p.st[slot].phase == 2) return;
+    __shared__ double Lk[kWNB][kWNB + 1];
+    const int tid = threadIdx.x;
+    const size_t ld = w.ld;
+    for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, c = e - i * nb; if (c <= i) Lk[i][c] = w.S[(size_t)(k0 + i) * ld + k0 + c]; }
+    __syncthreads();
+    const int r = k0 + nb + blockIdx.x * 256 + tid;
+    if (r > d.n) return;
+    double y[kWNB];
+#pragma unroll
+    for (int j = 0; j < kWNB; j++) y[j] = j < nb ? w.S[(size_t)r * ld + k0 + j] : 0.0;
+#pragma unroll
+    for (int j = 0; j < kWNB; j++) {
+        if (j < nb) {
+            double a = y[j];
+#pragma unroll
+            for (int t = 0; t < j; t++) a = fma(-y[t], Lk[j][t], a);
+            y[j] = a;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kWNB; j++) {
+        if (j < nb) { w.Y[(size_t)r * kWNB + j] = y[j]; w.S[(size_t)r * ld + k0 + j] = y[j] / Lk[j][j]; }
+    }
+}
+
+// trailing update A_rc -= sum_t L_rt Y_ct over 64x64 tiles with tile column <= tile row; rows/columns start at k1 = k0 + nb, the
+// border row n is the last row.  256 threads, 4x4 outputs each, both operand tiles staged in LDS.
+__global__ __launch_bounds__(256) void ba_ldlw_update_kernel(BAPtrs p, BADims d, BAWide w, int slot, int k0, int nb, int ntile) {
+    if (p.st[slot].phase == 2) return;
+    // linear block index -> (tr, tc) with tc <= tr
+    int tr = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((tr + 1) * (tr + 2) / 2 <= (int)blockIdx.x) ++tr;
+    while (tr * (tr + 1) / 2 > (int)blockIdx.x) --tr;
+    const int tc = blockIdx.x - tr * (tr + 1) / 2;
+    const int k1 = k0 + nb, r0 = k1 + 64 * tr, c0 = k1 + 64 * tc;
+    __shared__ double Ls[64][kWNB + 1], Ys[64][kWNB + 1];
+    const int tid = threadIdx.x;
+    const size_t ld = w.ld;
+    for (int e = tid; e < 64 * nb; e += 256) {
+        const int i = e / nb, t = e - i * nb;
+        const int r = r0 + i, c = c0 + i;
+        Ls[i][t] = r <= d.n ? w.S[(size_t)r * ld + k0 + t] : 0.0;
+        Ys[i][t] = c < d.n ? w.Y[(size_t)c * kWNB + t] : 0.0;   // columns stop at n-1: the border row has no column
+    }
+    __syncthreads();
+    const int ti = (tid >> 4) * 4, tj = (tid & 15) * 4;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = 0;
+    for (int t = 0; t < nb; t++) {
+        double l[4], y[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) { l[a] = Ls[ti + a][t]; y[a] = Ys[tj + a][t]; }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) acc[a][b] = fma(l[a], y[b], acc[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int r = r0 + ti + a, c = c0 + tj + b;
+            if (r <= d.n && c < d.n && c <= r) w.S[(size_t)r * ld + c] -= acc[a][b];
+        }
+}
+
+// L^T x = z, one launch per panel from the last one upwards: every workgroup solves the panel's unit upper triangle for itself
+// (x_k from xp[k0..k0+nb)), workgroup 0 stores it, then each workgroup takes 256 earlier rows: xp_r -= sum_c L[k0+c][r] x_c
+__global__ __launch_bounds__(256) void ba_ldlw_back_kernel(BAPtrs p, BAWide w, int slot, int k0, int nb) {
+    if (p.st[slot].phase == 2) return;
+    __shared__ double xs[kWNB];
+    __shared__ double Lk[kWNB][kWNB + 1];
+    const int tid = threadIdx.x;
+    const size_t ld = w.ld;
+    for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, c = e - i * nb; if (c < i) Lk[i][c] = w.S[(size_t)(k0 + i) * ld + k0 + c]; }
+    // z lives in the border row of S (row n: D^-1 L^-1 b, updated by the panels behind this one), x goes to xp: nobody writes what
+    // another workgroup of this launch still has to read
+    double* z = w.S + (size_t)(w.ld - 1) * ld;
+    if (tid < nb) xs[tid] = z[k0 + tid];
+    __syncthreads();
+    if (tid < 64) {   // one wave: x_i = z_i - sum_{j > i} L_ji x_j, from the last row of the panel upwards
+        double x = tid < nb ? xs[tid] : 0.0;
+        for (int j = nb - 1; j > 0; j--) {
+            const double xj = __shfl(x, j);
+            if (tid < j) x = fma(-Lk[j][tid], xj, x);
+        }
+        if (tid < nb) xs[tid] = x;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < nb) p.xp[k0 + tid] = xs[tid];
+    const int r = blockIdx.x * 256 + tid;
+    if (r < k0) {
+        double a = z[r];
+        for (int c = 0; c < nb; c++) a = fma(-w.S[(size_t)(k0 + c) * ld + r], xs[c], a);
+        z[r] = a;
+    }
+}
+
+// trial poses of all free keyframes from the solved increment; publishes solve_ok in the state the step runs with
+__global__ __launch_bounds__(256) void ba_posew_kernel(BAPtrs p, BADims d, BAWide w, int slot) {
+    const BAState st = p.st[slot];
+    if (st.phase == 2) return;
+    const int ok = *w.fail ? 0 : 1;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s == 0) p.st[slot].solve_ok = ok;
+    if (s < d.nfree) {
+        if (!ok) for (int a = 0; a < 6; a++) p.xp[6 * s + a] = 0.0;
+        pose_update_one(p, s, st.cur, ok, p.xp);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ backsub + trial errors
@@ -1190,6 +1470,8 @@ struct uh_ba {
     unsigned char* h_stop = nullptr;      // pinned, device-visible force-stop flag
     int iters[2] = {0, 0};
     int nsplit = 1;
+    bool wide = false;                    // more than kMaxFree free keyframes: sparse pair lists + blocked dense LDL^T in HBM
+    BAWide wd{};
     int step = 0;                         // LM steps enqueued since uh_ba_optimize began: step s reads state slot s & 1
     bool optimized = false;
     // uh_ba_optimize_async: a persistent worker thread (the reference's mapper thread, mapmanager.cpp:150) runs uh_ba_optimize
@@ -1245,6 +1527,30 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
     for (int s = 0; s < nsteps; s++) {
         const int slot = b->step & 1;   // state left by the previous step (or by begin_pass / the closing decide kernel)
         if (pass_start && s == 0) UH_LAUNCH(b->ctx,ba_lin_kernel, dim3(d.nPointBlocks + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d, slot);
+        if (b->wide) {
+            const BAWide& W = b->wd;
+            const int run = slot ^ 1;   // the state this step runs with (published by the advance kernel)
+            UH_LAUNCH(b->ctx, ba_advance_kernel, dim3(1), dim3(64), 0, b->ptrs, d, slot);
+            UH_HIP_CHECK(hipMemsetAsync(W.S, 0, sizeof(double) * (size_t)W.ld * W.ld, st));
+            UH_HIP_CHECK(hipMemsetAsync(W.fail, 0, sizeof(int), st));
+            UH_LAUNCH(b->ctx, ba_schurw_kernel, dim3(W.n_items + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d, W, run);
+            UH_LAUNCH(b->ctx, ba_assemblew_kernel, dim3(W.n_pairs), dim3(64), 0, b->ptrs, d, W, run);
+            for (int k0 = 0; k0 < d.n; k0 += kWNB) {
+                const int nb = std::min(kWNB, d.n - k0), rows = d.n + 1 - (k0 + nb);   // rows behind the panel, border row included
+                UH_LAUNCH(b->ctx, ba_ldlw_diag_kernel, dim3(1), dim3(256), 0, b->ptrs, W, run, k0, nb);
+                UH_LAUNCH(b->ctx, ba_ldlw_panel_kernel, dim3(uh_div_up(rows, 256)), dim3(256), 0, b->ptrs, d, W, run, k0, nb);
+                const int ntile = uh_div_up(rows, 64);
+                if (k0 + nb < d.n) UH_LAUNCH(b->ctx, ba_ldlw_update_kernel, dim3(ntile * (ntile + 1) / 2), dim3(256), 0, b->ptrs, d, W, run, k0, nb, ntile);
+            }
+            for (int k0 = ((d.n - 1) / kWNB) * kWNB; k0 >= 0; k0 -= kWNB) {
+                const int nb = std::min(kWNB, d.n - k0);
+                UH_LAUNCH(b->ctx, ba_ldlw_back_kernel, dim3(std::max(uh_div_up(k0, 256), 1)), dim3(256), 0, b->ptrs, W, run, k0, nb);
+            }
+            UH_LAUNCH(b->ctx, ba_posew_kernel, dim3(uh_div_up(d.nfree, 256)), dim3(256), 0, b->ptrs, d, W, run);
+            UH_LAUNCH(b->ctx, ba_backsub_kernel<false>, dim3(d.nPointBlocks), dim3(kThreads), 0, b->ptrs, d, b->nsplit, run);
+            b->step++;
+            continue;
+        }
         UH_LAUNCH(b->ctx,ba_schur_kernel, dim3(std::max(npairs, 1) * b->nsplit + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d, b->nsplit, slot);
         if (use_lds) {
             UH_LAUNCH(b->ctx,ba_backsub_kernel<true>, dim3(d.nPointBlocks), dim3(kThreads), lds, b->ptrs, d, b->nsplit, slot ^ 1);
@@ -1317,12 +1623,17 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     std::vector<int> slot(K, -1), free_kf;
     for (int k = 0; k < K; k++) if (!pr->fixed[k]) { slot[k] = (int)free_kf.size(); free_kf.push_back(k); }
     const int nfree = (int)free_kf.size();
-    UH_REQUIRE(nfree <= kMaxFree, "uh_ba_set_problem: %d free keyframes (this round supports <= %d)", nfree, kMaxFree);
+    constexpr int kMaxFreeWide = 4096;
+    UH_REQUIRE(nfree <= kMaxFreeWide, "uh_ba_set_problem: %d free keyframes (supported: <= %d)", nfree, kMaxFreeWide);
+    // wide form: sparse camera-pair lists + blocked dense LDL^T in HBM (see "wide problems" above); UH_BA_WIDE=1 forces it for
+    // small problems (tests compare the two forms on the same inputs)
+    const bool wide = nfree > kMaxFree || (getenv("UH_BA_WIDE") && atoi(getenv("UH_BA_WIDE")) != 0 && nfree > 0);
+    b->wide = wide;
     for (int e = 0; e < E; e++)
         UH_REQUIRE(pr->obs_point[e] >= 0 && pr->obs_point[e] < P && pr->obs_frame[e] >= 0 && pr->obs_frame[e] < K,
                    "uh_ba_set_problem: observation %d references point %d / frame %d out of range", e, pr->obs_point[e], pr->obs_frame[e]);
     // host-side graph structure
-    std::vector<int> pt_ptr(P + 1, 0), pt_edges(E), cam_ptr(nfree + 1, 0), cam_edges, edge_of((size_t)P * std::max(nfree, 1), -1);
+    std::vector<int> pt_ptr(P + 1, 0), pt_edges(E), cam_ptr(nfree + 1, 0), cam_edges, edge_of(wide ? 1 : (size_t)P * std::max(nfree, 1), -1);
     for (int e = 0; e < E; e++) pt_ptr[pr->obs_point[e] + 1]++;
     for (int p = 0; p < P; p++) pt_ptr[p + 1] += pt_ptr[p];
     { std::vector<int> fill(pt_ptr.begin(), pt_ptr.end() - 1); for (int e = 0; e < E; e++) pt_edges[fill[pr->obs_point[e]]++] = e; }
@@ -1331,8 +1642,57 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     cam_edges.resize(cam_ptr[nfree]);
     { std::vector<int> fill(cam_ptr.begin(), cam_ptr.end() - 1);
       for (int e = 0; e < E; e++) { const int s = slot[pr->obs_frame[e]]; if (s >= 0) { cam_edges[fill[s]++] = e;
-          UH_REQUIRE(edge_of[(size_t)pr->obs_point[e] * nfree + s] < 0, "uh_ba_set_problem: point %d observed twice by frame %d", pr->obs_point[e], pr->obs_frame[e]);
-          edge_of[(size_t)pr->obs_point[e] * nfree + s] = e; } } }
+          if (!wide) {
+              UH_REQUIRE(edge_of[(size_t)pr->obs_point[e] * nfree + s] < 0, "uh_ba_set_problem: point %d observed twice by frame %d", pr->obs_point[e], pr->obs_frame[e]);
+              edge_of[(size_t)pr->obs_point[e] * nfree + s] = e; } } } }
+    // wide form: (s1 <= s2) camera pairs that share landmarks, their (landmark, edge1, edge2) triples in landmark order, <= 256 per item
+    std::vector<int> w_pair_s1, w_pair_s2, w_pair_item_ptr, w_item_pair, w_item_begin, w_item_count, w_tri_pt, w_tri_e1, w_tri_e2;
+    if (wide) {
+        // counting sort by pair key: pass 1 counts the triples of every (s1 <= s2), pass 2 drops them into place — landmarks
+        // are visited in ascending order both times, so a pair's triples end up in landmark order
+        std::vector<std::vector<std::pair<int, int>>> obs_of(P);
+        for (int pt = 0; pt < P; pt++) {
+            auto& obs = obs_of[pt];
+            for (int i = pt_ptr[pt]; i < pt_ptr[pt + 1]; i++) { const int e = pt_edges[i], s = slot[pr->obs_frame[e]]; if (s >= 0) obs.push_back({s, e}); }
+            std::sort(obs.begin(), obs.end());
+            for (size_t i = 1; i < obs.size(); i++)
+                UH_REQUIRE(obs[i].first != obs[i - 1].first, "uh_ba_set_problem: point %d observed twice by frame %d", pt, free_kf[obs[i].first]);
+        }
+        std::vector<size_t> key_count((size_t)nfree * nfree + 1, 0);
+        for (int pt = 0; pt < P; pt++) {
+            const auto& obs = obs_of[pt];
+            for (size_t i = 0; i < obs.size(); i++)
+                for (size_t j = i; j < obs.size(); j++) key_count[(size_t)obs[i].first * nfree + obs[j].first + 1]++;
+        }
+        for (size_t k = 0; k < (size_t)nfree * nfree; k++) key_count[k + 1] += key_count[k];
+        const size_t n_tri = key_count[(size_t)nfree * nfree];
+        UH_REQUIRE(n_tri < (size_t)1 << 31, "uh_ba_set_problem: %zu co-observation triples exceed the 32-bit index range", n_tri);
+        w_tri_pt.resize(n_tri); w_tri_e1.resize(n_tri); w_tri_e2.resize(n_tri);
+        {
+            std::vector<size_t> fill(key_count.begin(), key_count.end() - 1);
+            for (int pt = 0; pt < P; pt++) {
+                const auto& obs = obs_of[pt];
+                for (size_t i = 0; i < obs.size(); i++)
+                    for (size_t j = i; j < obs.size(); j++) {
+                        const size_t at = fill[(size_t)obs[i].first * nfree + obs[j].first]++;
+                        w_tri_pt[at] = pt; w_tri_e1[at] = obs[i].second; w_tri_e2[at] = obs[j].second;
+                    }
+            }
+        }
+        std::vector<char> have_diag(std::max(nfree, 1), 0);
+        auto add_pair = [&](int s1, int s2, int begin, int count) {
+            w_pair_s1.push_back(s1); w_pair_s2.push_back(s2); w_pair_item_ptr.push_back((int)w_item_pair.size());
+            for (int o = 0; o < count; o += kThreads) { w_item_pair.push_back((int)w_pair_s1.size() - 1); w_item_begin.push_back(begin + o); w_item_count.push_back(std::min(kThreads, count - o)); }
+            if (s1 == s2) have_diag[s1] = 1;
+        };
+        for (int s1 = 0; s1 < nfree; s1++)
+            for (int s2 = s1; s2 < nfree; s2++) {
+                const size_t k = (size_t)s1 * nfree + s2;
+                if (key_count[k + 1] > key_count[k]) add_pair(s1, s2, (int)key_count[k], (int)(key_count[k + 1] - key_count[k]));
+            }
+        for (int sfree = 0; sfree < nfree; sfree++) if (!have_diag[sfree]) add_pair(sfree, sfree, 0, 0);   // a camera without landmarks still owns its diagonal block
+        w_pair_item_ptr.push_back((int)w_item_pair.size());
+    }
     std::vector<double> pose0(7 * (size_t)K), pts0(3 * (size_t)P), intr(4 * (size_t)K), uv(2 * (size_t)E), w(E);
     for (int k = 0; k < K; k++) {   // toSE3Quat (globaloptimizer_g2o.cpp:80-90): float 4x4 -> double R,t -> quaternion
         const float* M = pr->poses_f2g + 16 * k;
@@ -1366,7 +1726,12 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     const int npairs_h = nfree * (nfree + 1) / 2;
     b->nsplit = std::max(1, std::min(kMaxSplit, uh_div_up(P, kThreads)));
     if (const char* e = getenv("UH_BA_NSPLIT")) b->nsplit = std::max(1, std::min(kMaxSplit, atoi(e)));   // tuning knob (measurement only)
-    const size_t o_S = A.take<double>((size_t)std::max(d.n, 1) * (std::max(d.n, 1) + 1)), o_Sp = A.take<double>((size_t)b->nsplit * std::max(npairs_h, 1) * 42), o_xp = A.take<double>(std::max(d.n, 1));
+    const size_t o_S = A.take<double>((size_t)(d.n + 1) * (d.n + 1)), o_Sp = A.take<double>(wide ? 42 : (size_t)b->nsplit * std::max(npairs_h, 1) * 42), o_xp = A.take<double>(std::max(d.n, 1));
+    const size_t wn_pairs = w_pair_s1.size(), wn_items = w_item_pair.size(), wn_tri = w_tri_pt.size();
+    const size_t o_wps1 = A.take<int>(wn_pairs + 1), o_wps2 = A.take<int>(wn_pairs + 1), o_wpip = A.take<int>(wn_pairs + 2);
+    const size_t o_wip = A.take<int>(wn_items + 1), o_wib = A.take<int>(wn_items + 1), o_wic = A.take<int>(wn_items + 1);
+    const size_t o_wtp = A.take<int>(wn_tri + 1), o_wt1 = A.take<int>(wn_tri + 1), o_wt2 = A.take<int>(wn_tri + 1);
+    const size_t o_wpart = A.take<double>((wn_items + 1) * 42), o_wY = A.take<double>(wide ? (size_t)(d.n + 1) * kWNB : 1), o_wfail = A.take<int>(4);
     const size_t o_plc = A.take<double>(d.nPointBlocks), o_pmd = A.take<double>(d.nPointBlocks), o_pc = A.take<double>(d.nPointBlocks), o_ps = A.take<double>(d.nPointBlocks);
     const size_t o_st = A.take<BAState>(2), o_clk = A.take<long long>(64);
     int rc = b->arena.reserve(A.off + 256);
@@ -1390,6 +1755,17 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     if ((rc = up(o_free, free_kf.data(), free_kf.size() * 4))) return rc;
     if ((rc = up(o_intr, intr.data(), intr.size() * 8))) return rc;
     if ((rc = up(o_edge_of, edge_of.data(), edge_of.size() * 4))) return rc;
+    if (wide) {
+        if ((rc = up(o_wps1, w_pair_s1.data(), wn_pairs * 4))) return rc;
+        if ((rc = up(o_wps2, w_pair_s2.data(), wn_pairs * 4))) return rc;
+        if ((rc = up(o_wpip, w_pair_item_ptr.data(), (wn_pairs + 1) * 4))) return rc;
+        if ((rc = up(o_wip, w_item_pair.data(), wn_items * 4))) return rc;
+        if ((rc = up(o_wib, w_item_begin.data(), wn_items * 4))) return rc;
+        if ((rc = up(o_wic, w_item_count.data(), wn_items * 4))) return rc;
+        if ((rc = up(o_wtp, w_tri_pt.data(), wn_tri * 4))) return rc;
+        if ((rc = up(o_wt1, w_tri_e1.data(), wn_tri * 4))) return rc;
+        if ((rc = up(o_wt2, w_tri_e2.data(), wn_tri * 4))) return rc;
+    }
     if ((rc = up(o_pose0, pose0.data(), pose0.size() * 8))) return rc;
     if ((rc = up(o_pts0, pts0.data(), pts0.size() * 8))) return rc;
     if ((rc = b->d_poses_in.reserve(16 * (size_t)K * 4))) return rc;
@@ -1407,6 +1783,14 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     for (int i = 0; i < 2; i++) { p.Hll[i] = (double*)(base + o_Hll[i]); p.bl[i] = (double*)(base + o_bl[i]); p.Hpl[i] = (double*)(base + o_Hpl[i]); }
     p.HppPart = (double*)(base + o_Hpp); p.bp = (double*)(base + o_bp);
     p.S = (double*)(base + o_S); p.Spart = (double*)(base + o_Sp); p.xp = (double*)(base + o_xp);
+    {
+        BAWide& W = b->wd;
+        W.n_pairs = (int)wn_pairs; W.n_items = (int)wn_items; W.ld = d.n + 1;
+        W.pair_s1 = (const int*)(base + o_wps1); W.pair_s2 = (const int*)(base + o_wps2); W.pair_item_ptr = (const int*)(base + o_wpip);
+        W.item_pair = (const int*)(base + o_wip); W.item_begin = (const int*)(base + o_wib); W.item_count = (const int*)(base + o_wic);
+        W.tri_pt = (const int*)(base + o_wtp); W.tri_e1 = (const int*)(base + o_wt1); W.tri_e2 = (const int*)(base + o_wt2);
+        W.Wpart = (double*)(base + o_wpart); W.S = p.S; W.Y = (double*)(base + o_wY); W.fail = (int*)(base + o_wfail);
+    }
     p.part_lin_chi = (double*)(base + o_plc); p.part_maxdiag = (double*)(base + o_pmd); p.part_chi = (double*)(base + o_pc); p.part_scale = (double*)(base + o_ps);
     p.st = (BAState*)(base + o_st);
     p.clk = (long long*)(base + o_clk);
