@@ -25,3 +25,15 @@ for K, P in ((100, 5000), (300, 20000), (600, 40000)):
         tc = time.perf_counter() - t
         line += f" | {'real g2o' if g2o is not None else 'oracle port'} {1e3*tc:.0f} ms, iters {ref['iters'].tolist()}, max |state diff| {np.abs(r['state'] - ref['state']).max():.2e}"
     print(line, flush=True)
+
+# per-kernel split of one optimize() of the middle problem (HIP events around every launch)
+pr = synth.ba_problem(300, 20000, seed=1, nfixed=2)
+opt = GlobalOptimizer.create(ctx)
+opt.setParams(pr, ParamSet(nIters=10))
+opt.optimize()
+ctx.prof_enable(True); ctx.prof_reset()
+opt.optimize()
+rep = ctx.prof_report(); ctx.prof_enable(False)
+tot = sum(v[1] for v in rep.values())
+for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1])[:10]:
+    print(f"  {k.split('::')[-1][:40]:40s} calls {v[0]:5d}  total {v[1]:8.2f} ms  ({100*v[1]/tot:4.1f} %)  avg {1e3*v[1]/v[0]:8.1f} us")
