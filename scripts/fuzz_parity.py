@@ -199,6 +199,22 @@ def ba_case2(seed):
     return ok, (K, P, nfix, nit, g["iters"].tolist(), o["iters"].tolist(), err)
 
 run("ba", ba_case2)
+
+def ba_wide_case(seed):   # more than 64 free keyframes: the wide form (sparse pair lists, blocked dense LDL^T in HBM)
+    r = np.random.default_rng(seed)
+    K, P, nfix = int(r.integers(67, 120)), int(r.integers(200, 1200)), int(r.integers(1, 3))
+    nit = int(r.choice([5, 10]))
+    pr = synth.ba_problem(K, P, seed % 100000, nfixed=nfix, outlier_frac=float(r.choice([0.0, 0.02, 0.1])), pose_noise=float(r.choice([0.005, 0.01, 0.03])))
+    opt = GlobalOptimizer.create(ctx)
+    opt.setParams(pr, ParamSet(nIters=nit))
+    opt.optimize()
+    g = opt.getResults()
+    o = oracle_lib.ba_optimize(L, pr, nit)
+    err = float(np.abs(g["state"] - o["state"]).max())
+    ok = g["iters"].tolist() == o["iters"].tolist() and err < 1e-6 and (g["bad"] == o["bad"]).mean() > 0.999
+    return ok, (K, P, nfix, nit, g["iters"].tolist(), o["iters"].tolist(), err)
+
+run("ba_wide", ba_wide_case)
 pnp = PnPSolver(ctx)
 
 def pnp_case(seed):
