@@ -198,6 +198,13 @@ def main():
             step_640()
         stage_ms["step_ms_640x480"] = timed(step_640, 15)
         stage_ms["frames_per_s_640x480"] = 1e3 * F / stage_ms["step_ms_640x480"]
+        # also outside the metric: a global BA (System::globalOptimization, nIters = 10) — 100 keyframes x 5000 landmarks, ~330k
+        # observations — through the wide form of the same plugin object (more than 64 free keyframes)
+        gba = GlobalOptimizer.create(ctx_ba)
+        gba.setParams(synth.ba_problem(100, 5000, seed=1, nfixed=2), ParamSet(nIters=10))
+        gba.optimize()
+        stage_ms["global_ba_ms_100kf_5000pt_330kobs"] = timed(lambda: gba.optimize(), 2)
+        del gba
         # headroom figure, NOT the metric: two independent sessions (two frame streams, two maps, two local BAs) on this one GPU —
         # the latency-bound launch chains of the two BAs interleave, which one session cannot do with itself
         ctx_ba2 = u.Context(local_rank, private=True)
