@@ -256,6 +256,21 @@ int  uh_bow_transform_dev(uh_bow* bow, const uint8_t* d_desc, int n, int level,
                           uint32_t* d_word, float* d_weight, uint32_t* d_node, uint8_t* d_valid);
 double uh_bow_score(const uint32_t* ids1, const float* w1, int n1, const uint32_t* ids2, const float* w2, int n2);
 
+/* KPFrameDataBase (src/map_types/keyframedatabase.cpp:150-238): the keyframes' bags of words resident in HBM.  add / del mirror
+ * KPFrameDataBase::add / del (the bag is the fBow of uh_bow_transform(desc, 3): words ascending, raw weights).  query is the
+ * first half of relocalizationCandidates (:195-238): per keyframe the number of query words it shares and fBow::score (one lane
+ * per keyframe, products added in ascending word order like the reference), then on the host maxCommonWords, the 0.8 cut and
+ * the min_score cut; it returns the surviving frames (`frame_score`) in ascending id order.  The covisibility accumulation that
+ * follows (:241-275) needs CovisGraph and stays with the caller (ucoslam_cv3_amd.bow.KPFrameDataBase shows it). */
+typedef struct uh_bowdb uh_bowdb;
+int  uh_bowdb_create(uh_ctx* ctx, uh_bowdb** out);
+void uh_bowdb_destroy(uh_bowdb* db);
+int  uh_bowdb_size(const uh_bowdb* db);
+int  uh_bowdb_add(uh_bowdb* db, uint32_t frame_id, const uint32_t* words, const float* weights, int n);
+int  uh_bowdb_del(uh_bowdb* db, uint32_t frame_id);
+int  uh_bowdb_query(uh_bowdb* db, const uint32_t* words, const float* weights, int n, const uint32_t* excluded, int n_excluded,
+                    float min_score, uint32_t* frame_ids_out, uint32_t* nobs_out, double* score_out, int cap);
+
 /* ------------------------------------------------------------------------
  * FrameMatcher_Flann post-filter (host policy around the index) — src/utils/framematcher.cpp:228-319:
  * per query best/second-best scan over the nn columns IN ROW ORDER (min distance gate, octave gap, optional epipolar

@@ -125,3 +125,92 @@ def test_hip_bow_errors(hip_ctx):
         voc.transform(np.zeros((0, 32), np.uint8), 3)
     with pytest.raises(u.UcoslamHipError):                      # descriptor size mismatch (fbow.cpp:54)
         voc.transform(np.zeros((4, 61), np.uint8), 3)
+
+
+def _py_reloc(db, query, covis, sorted_, min_score, excluded):
+    """Independent restatement of KPFrameDataBase::relocalizationCandidates (keyframedatabase.cpp:195-275) on plain dicts:
+    db = {frame id: fBow}, fBow = {word: float32}; the inverted word -> frames index is rebuilt like add() does."""
+    word_frames = {}
+    for f, bow in db.items():
+        for w in bow:
+            word_frames.setdefault(w, set()).add(f)
+    nobs, max_common = {}, 0
+    for w in sorted(query):
+        for f in sorted(word_frames.get(w, ())):
+            if f in excluded:
+                continue
+            nobs[f] = nobs.get(f, 0) + 1
+            max_common = max(max_common, nobs[f])
+    if not nobs:
+        return [], []
+    min_common = int(np.float32(max_common) * np.float32(0.8))
+    frame_score = {}
+    for f in sorted(nobs):
+        if nobs[f] > min_common:
+            s, a, b = 0.0, query, db[f]
+            for w in sorted(set(a) & set(b)):
+                s += float(np.float32(a[w]) * np.float32(b[w]))
+            s = 1.0 if s >= 1 else 1.0 - np.sqrt(1.0 - s)
+            if s > min_score:
+                frame_score[f] = s
+    scored = [(f, nobs[f], frame_score[f]) for f in sorted(frame_score)]
+    if len(frame_score) == 0:
+        return scored, []
+    if len(frame_score) == 1:
+        return scored, [next(iter(frame_score))]
+    acc, best = [], float(np.float32(min_score))
+    for f in sorted(frame_score):
+        a = frame_score[f]
+        for nb, _w in covis(f)[:10]:
+            if nb in frame_score:
+                a += frame_score[nb]
+        acc.append((f, a))
+        best = max(best, a)
+    keep = float(np.float32(0.75)) * best
+    acc = [fa for fa in acc if not fa[1] < keep]
+    if sorted_:
+        acc = sorted(acc, key=lambda fa: -fa[1])
+    return scored, [f for f, _ in acc]
+
+
+@pytest.mark.gpu
+def test_hip_keyframe_database_relocalization_candidates(hip_ctx):
+    """uh_bowdb_*: bags of words produced by the GPU vocabulary descent, common-word counts and fBow::score of every keyframe on
+    the GPU, cuts on the host; compared with the dict restatement (scores to the last bit: same products, same order)."""
+    from ucoslam_cv3_amd.bow import KPFrameDataBase, Vocabulary, write_vocabulary_stream
+
+    params, blob, meta = synth.vocabulary(k=10, depth=3, seed=5, aligment=8)
+    voc = Vocabulary(hip_ctx).fromStream(write_vocabulary_stream(params, blob))
+    rng = np.random.default_rng(3)
+    scene = rng.integers(0, 256, (4000, 32), dtype=np.uint8)          # a pool of "world" descriptors
+    def frame_desc(center, n=500):
+        idx = (center + rng.integers(0, 900, n)) % len(scene)         # keyframes see overlapping windows of the pool
+        return scene[idx] ^ np.packbits(rng.random((n, 256)) < 0.02, axis=1, bitorder="little")
+    db_py, db = {}, KPFrameDataBase(hip_ctx)
+    for k in range(60):
+        bow = voc.transform(frame_desc(60 * k), 3)[0]
+        fid = 3 * k + 1
+        db_py[fid] = dict(bow)
+        db.add(fid, bow)
+    assert db.size() == 60
+    nbrs = {f: [(g, 100 - abs(f - g)) for g in sorted(db_py, key=lambda g: abs(f - g)) if g != f][:14] for f in db_py}
+    covis = lambda f: nbrs[f]
+    for trial, (center, min_score, excluded, srt) in enumerate([(600, 0.0, (), True), (1500, 0.01, (76, 79), True), (3000, 0.0, (), False), (123, 0.3, (), True)]):
+        q = voc.transform(frame_desc(center, 450), 3)[0]
+        got_scored = db.scoredFrames(q, min_score, excluded)
+        ref_scored, ref_cand = _py_reloc(db_py, dict(q), covis, srt, min_score, set(excluded))
+        assert [(f, n) for f, n, _ in got_scored] == [(f, n) for f, n, _ in ref_scored]
+        assert [s for _, _, s in got_scored] == [s for _, _, s in ref_scored]
+        assert db.relocalizationCandidates(q, covis, srt, min_score, excluded) == ref_cand
+        if trial == 0:
+            assert len(ref_cand) >= 1 and abs(ref_cand[0] - (3 * 10 + 1)) <= 9       # the keyframes around window 600 win
+    # del: the frame disappears from the answers; deleting twice is an error
+    import ucoslam_cv3_amd as u
+    q = voc.transform(frame_desc(600, 450), 3)[0]
+    top = db.relocalizationCandidates(q, covis, True, 0.0)[0]
+    db.delete(top)
+    del db_py[top]
+    assert top not in [f for f, _, _ in db.scoredFrames(q)]
+    assert db.relocalizationCandidates(q, covis, True, 0.0) == _py_reloc(db_py, dict(q), covis, True, 0.0, set())[1]
+    with pytest.raises(u.UcoslamHipError):
+        db.delete(top)

@@ -28,6 +28,12 @@ def _declare(L, sig):
     sig("uh_bow_transform", I, VP, VP, I, SZ, I, I, VP, VP, VP, VP)
     sig("uh_bow_transform_dev", I, VP, VP, I, I, VP, VP, VP, VP)
     sig("uh_bow_score", C.c_double, VP, VP, I, VP, VP, I)
+    sig("uh_bowdb_create", I, VP, C.POINTER(VP))
+    sig("uh_bowdb_destroy", None, VP)
+    sig("uh_bowdb_size", I, VP)
+    sig("uh_bowdb_add", I, VP, C.c_uint32, VP, VP, I)
+    sig("uh_bowdb_del", I, VP, C.c_uint32)
+    sig("uh_bowdb_query", I, VP, VP, VP, I, VP, I, C.c_float, VP, VP, VP, I)
 
 
 _lib._EXTRA_DECLS.append(_declare)
@@ -133,6 +139,83 @@ class Vocabulary:
             self.close()
         except Exception:
             pass
+
+
+class KPFrameDataBase:
+    """ucoslam::KPFrameDataBase (src/map_types/keyframedatabase.cpp:150-275) over uh_bowdb_*: the keyframes' bags of words live
+    in HBM; add(frame_id, bow) / delete(frame_id) / relocalizationCandidates(bow, covis_neighbors, ...).  `bow` is the fBow of
+    Vocabulary.transform(desc, 3) (a dict word -> float32 weight).  `covis_neighbors(frame_id)` returns the (neighbour id, weight)
+    list of CovisGraph::getNeighborsWeights(id, true): sorted by decreasing weight."""
+
+    def __init__(self, ctx: _lib.Context):
+        self._h = VP()
+        check(lib().uh_bowdb_create(ctx.handle, C.byref(self._h)))
+
+    @staticmethod
+    def _arrays(bow):
+        ks = np.fromiter(sorted(bow), np.uint32, len(bow))
+        return ks, np.array([bow[int(k)] for k in ks], np.float32)
+
+    def add(self, frame_id: int, bow):
+        ks, ws = self._arrays(bow)
+        check(lib().uh_bowdb_add(self._h, frame_id, np_ptr(ks) if len(ks) else None, np_ptr(ws) if len(ks) else None, len(ks)))
+
+    def delete(self, frame_id: int):
+        check(lib().uh_bowdb_del(self._h, frame_id))
+
+    def size(self):
+        return lib().uh_bowdb_size(self._h)
+
+    def scoredFrames(self, bow, minScore=0.0, excludedFrames=()):
+        """relocalizationCandidates up to `frame_score` (:195-238): [(frame id, common words, score)] in ascending id order."""
+        ks, ws = self._arrays(bow)
+        ex = np.array(sorted(excludedFrames), np.uint32)
+        cap = max(self.size(), 1)
+        ids, nobs, sc = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32), np.zeros(cap, np.float64)
+        n = lib().uh_bowdb_query(self._h, np_ptr(ks) if len(ks) else None, np_ptr(ws) if len(ks) else None, len(ks),
+                                 np_ptr(ex) if len(ex) else None, len(ex), float(minScore), np_ptr(ids), np_ptr(nobs), np_ptr(sc), cap)
+        if n < 0:
+            check(n)
+        return [(int(ids[i]), int(nobs[i]), float(sc[i])) for i in range(n)]
+
+    def relocalizationCandidates(self, bow, covis_neighbors, sorted_=True, minScore=0.0, excludedFrames=()):
+        fs = self.scoredFrames(bow, minScore, excludedFrames)
+        if len(fs) == 0:
+            return []
+        if len(fs) == 1:
+            return [fs[0][0]]
+        frame_score = {f: s for f, _, s in fs}
+        acc, best = [], np.float64(np.float32(minScore))              # double bestAccScore = minScore (a float)
+        for f, _, s in fs:                                           # :241-256, frames in ascending id (std::map order)
+            a = s
+            for nb, _w in list(covis_neighbors(f))[:10]:
+                if nb in frame_score:
+                    a += frame_score[nb]
+            acc.append((f, a))
+            if a > best:
+                best = a
+        keep = np.float64(np.float32(0.75)) * best                   # 0.75f * bestAccScore
+        acc = [fa for fa in acc if not fa[1] < keep]
+        if sorted_:
+            acc = _stable_desc(acc)
+        return [f for f, _ in acc]
+
+    def close(self):
+        if self._h:
+            lib().uh_bowdb_destroy(self._h)
+            self._h = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _stable_desc(pairs):
+    """std::sort with a.second > b.second is not stable; equal accumulated scores are vanishingly rare for real bags, and the
+    reference's own order among them is unspecified — a stable sort is one of the valid outcomes."""
+    return sorted(pairs, key=lambda fa: -fa[1])
 
 
 def write_vocabulary_stream(params120: bytes, blob: bytes) -> bytes:

@@ -11,7 +11,11 @@
 // 32-byte read per lane, 8 x (xor + bcnt) and a wave arg-min that keeps the lowest child index among equal minima.
 // The vocabulary (a few MB) stays resident in HBM/L2; the maps of the reference API are assembled on the host from the
 // per-descriptor (word, weight, node) triples, in feature order, which preserves the reference's float summation order.
+#include <algorithm>
 #include <cmath>
+#include <map>
+#include <set>
+#include <vector>
 
 #include "common.hpp"
 
@@ -188,6 +192,151 @@ double uh_bow_score(const uint32_t* ids1, const float* w1, int n1, const uint32_
     }
     if (score >= 1) score = 1.0; else score = 1.0 - std::sqrt(1.0 - score);
     return score;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ keyframe database
+// KPFrameDataBase (src/map_types/keyframedatabase.cpp): the bags of words of the keyframes and the first half of
+// relocalizationCandidates (:195-238) — how many of the query's words every keyframe shares, and fBow::score against those
+// that share enough.  The reference walks an inverted word -> frames index on the host; here every keyframe's sorted bag is
+// resident in HBM and one lane per keyframe merge-joins it with the query (the products are added in ascending word order, as
+// fBow::score does, so the double sum is the reference's).  The covisibility accumulation that follows (:241-275) needs
+// CovisGraph and stays with the caller.
+namespace {
+
+struct BowDbDev {
+    int n_frames;
+    const int* ptr;              // n_frames + 1
+    const uint32_t* words; const float* weights;
+    int nq; const uint32_t* q_words; const float* q_weights;
+    uint32_t* nobs; double* score;
+};
+
+__global__ __launch_bounds__(64) void bowdb_query_kernel(BowDbDev a) {
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= a.n_frames) return;
+    int i = 0, j = a.ptr[f];
+    const int n1 = a.nq, n2 = a.ptr[f + 1];
+    double score = 0;
+    uint32_t common = 0;
+    while (i < n1 && j < n2) {
+        const uint32_t w1 = a.q_words[i], w2 = a.words[j];
+        if (w1 == w2) { score += a.q_weights[i] * a.weights[j]; ++common; ++i; ++j; }
+        else if (w1 < w2) ++i;
+        else ++j;
+    }
+    a.nobs[f] = common;
+    a.score[f] = score >= 1 ? 1.0 : 1.0 - sqrt(1.0 - score);
+}
+
+}  // namespace
+
+struct uh_bowdb {
+    uh_ctx* ctx = nullptr;
+    std::map<uint32_t, std::pair<std::vector<uint32_t>, std::vector<float>>> frames;   // ascending frame id, like the reference's maps
+    bool dirty = true;
+    uh::DevBuf d_db, d_q, d_out;
+    std::vector<uint32_t> ids;   // frame id of database row i (as uploaded)
+    std::vector<int> ptr;
+};
+
+extern "C" {
+
+int uh_bowdb_create(uh_ctx* ctx, uh_bowdb** out) {
+    UH_REQUIRE(ctx && out, "uh_bowdb_create: NULL argument");
+    uh_bowdb* d = new uh_bowdb();
+    d->ctx = ctx;
+    *out = d;
+    return UH_OK;
+}
+
+void uh_bowdb_destroy(uh_bowdb* d) { delete d; }
+
+int uh_bowdb_size(const uh_bowdb* d) { return d ? (int)d->frames.size() : 0; }
+
+// KPFrameDataBase::add (:150-161); the bag is the fBow of uh_bow_transform(desc, 3): words ascending, raw weights
+int uh_bowdb_add(uh_bowdb* d, uint32_t frame_id, const uint32_t* words, const float* weights, int n) {
+    UH_REQUIRE(d && n >= 0 && (n == 0 || (words && weights)), "uh_bowdb_add: bad arguments");
+    UH_REQUIRE(d->frames.count(frame_id) == 0, "uh_bowdb_add: frame %u is already in the database", frame_id);
+    for (int i = 1; i < n; i++) UH_REQUIRE(words[i] > words[i - 1], "uh_bowdb_add: words must ascend (std::map order)");
+    d->frames[frame_id] = {std::vector<uint32_t>(words, words + n), std::vector<float>(weights, weights + n)};
+    d->dirty = true;
+    return UH_OK;
+}
+
+// KPFrameDataBase::del (:163-180)
+int uh_bowdb_del(uh_bowdb* d, uint32_t frame_id) {
+    UH_REQUIRE(d, "uh_bowdb_del: NULL");
+    UH_REQUIRE(d->frames.erase(frame_id) == 1, "uh_bowdb_del: frame %u is not in the database", frame_id);
+    d->dirty = true;
+    return UH_OK;
+}
+
+// relocalizationCandidates :195-238: returns the frames of `frame_score` (more than 0.8 * max common words shared AND score >
+// min_score), ascending frame id, with their common-word counts and scores; < 0 on error
+int uh_bowdb_query(uh_bowdb* d, const uint32_t* words, const float* weights, int n, const uint32_t* excluded, int n_excluded,
+                   float min_score, uint32_t* frame_ids_out, uint32_t* nobs_out, double* score_out, int cap) {
+    UH_REQUIRE(d && n >= 0 && (n == 0 || (words && weights)) && n_excluded >= 0 && (n_excluded == 0 || excluded), "uh_bowdb_query: bad arguments");
+    const int nf = (int)d->frames.size();
+    if (nf == 0 || n == 0) return 0;
+    int rc;
+    UH_HIP_CHECK(hipSetDevice(d->ctx->device));
+    hipStream_t st = d->ctx->stream;
+    if (d->dirty) {
+        d->ids.clear(); d->ptr.assign(1, 0);
+        std::vector<uint32_t> w; std::vector<float> wt;
+        for (auto& kv : d->frames) {
+            d->ids.push_back(kv.first);
+            w.insert(w.end(), kv.second.first.begin(), kv.second.first.end());
+            wt.insert(wt.end(), kv.second.second.begin(), kv.second.second.end());
+            d->ptr.push_back((int)w.size());
+        }
+        const size_t o_w = ((size_t)(nf + 1) * 4 + 255) & ~(size_t)255, o_wt = (o_w + w.size() * 4 + 255) & ~(size_t)255;
+        if ((rc = d->d_db.reserve(o_wt + wt.size() * 4 + 256))) return rc;
+        char* base = d->d_db.as<char>();
+        UH_HIP_CHECK(hipMemcpyAsync(base, d->ptr.data(), (size_t)(nf + 1) * 4, hipMemcpyHostToDevice, st));
+        if (!w.empty()) {
+            UH_HIP_CHECK(hipMemcpyAsync(base + o_w, w.data(), w.size() * 4, hipMemcpyHostToDevice, st));
+            UH_HIP_CHECK(hipMemcpyAsync(base + o_wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice, st));
+        }
+        UH_HIP_CHECK(hipStreamSynchronize(st));   // the staging vectors die here
+        d->dirty = false;
+    }
+    const size_t total_words = (size_t)d->ptr.back();
+    const size_t o_w = ((size_t)(nf + 1) * 4 + 255) & ~(size_t)255, o_wt = (o_w + total_words * 4 + 255) & ~(size_t)255;
+    const size_t oq_w = 0, oq_wt = ((size_t)n * 4 + 255) & ~(size_t)255;
+    if ((rc = d->d_q.reserve(oq_wt + (size_t)n * 4 + 256))) return rc;
+    const size_t oo_s = ((size_t)nf * 4 + 255) & ~(size_t)255;
+    if ((rc = d->d_out.reserve(oo_s + (size_t)nf * 8 + 256))) return rc;
+    UH_HIP_CHECK(hipMemcpyAsync(d->d_q.as<char>() + oq_w, words, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    UH_HIP_CHECK(hipMemcpyAsync(d->d_q.as<char>() + oq_wt, weights, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    BowDbDev a;
+    char* base = d->d_db.as<char>();
+    a.n_frames = nf; a.ptr = (const int*)base; a.words = (const uint32_t*)(base + o_w); a.weights = (const float*)(base + o_wt);
+    a.nq = n; a.q_words = (const uint32_t*)(d->d_q.as<char>() + oq_w); a.q_weights = (const float*)(d->d_q.as<char>() + oq_wt);
+    a.nobs = (uint32_t*)d->d_out.as<char>(); a.score = (double*)(d->d_out.as<char>() + oo_s);
+    UH_LAUNCH(d->ctx, bowdb_query_kernel, dim3(uh_div_up(nf, 64)), dim3(64), 0, a);
+    UH_HIP_CHECK(hipGetLastError());
+    std::vector<uint32_t> nobs(nf);
+    std::vector<double> score(nf);
+    UH_HIP_CHECK(hipMemcpyAsync(nobs.data(), a.nobs, (size_t)nf * 4, hipMemcpyDeviceToHost, st));
+    UH_HIP_CHECK(hipMemcpyAsync(score.data(), a.score, (size_t)nf * 8, hipMemcpyDeviceToHost, st));
+    UH_HIP_CHECK(hipStreamSynchronize(st));
+    std::set<uint32_t> excl(excluded, excluded + n_excluded);
+    uint32_t maxCommon = 0;
+    for (int i = 0; i < nf; i++) if (nobs[i] > 0 && !excl.count(d->ids[i])) maxCommon = std::max(maxCommon, nobs[i]);
+    const uint32_t minCommon = (uint32_t)(maxCommon * 0.8f);   // :224
+    int k = 0;
+    for (int i = 0; i < nf; i++) {
+        if (nobs[i] == 0 || excl.count(d->ids[i])) continue;   // frame_nobs has an entry only for frames that share a word (:212-221)
+        if (nobs[i] > minCommon && score[i] > min_score) {
+            UH_REQUIRE(k < cap, "uh_bowdb_query: more than %d candidate frames", cap);
+            frame_ids_out[k] = d->ids[i]; if (nobs_out) nobs_out[k] = nobs[i]; if (score_out) score_out[k] = score[i];
+            k++;
+        }
+    }
+    return k;
 }
 
 }  // extern "C"
