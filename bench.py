@@ -119,6 +119,9 @@ def main():
     fp = FeatParams(MAX_FEATURES, NLEVELS, SCALE)
     orb_out = ext.extract_batch(frames, fp)
     index = Index(ctx).build(map_desc)
+    # the matcher runs beside the local BA: four queries per wave = a quarter of the L1/L2 streaming and of the resident waves; the
+    # search alone takes longer (250 instead of 163 us for the 4 x 2000 queries), the step is shorter
+    index.set_queries_per_wave(4)
     # the reference runs local BA on its mapper thread, concurrently with tracking (mapmanager.cpp:1550);
     # here BA gets its own HIP stream so that its latency-bound launch chain overlaps the tracking stream's kernels
     ctx_ba = u.Context(local_rank, private=True)

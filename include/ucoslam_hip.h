@@ -76,6 +76,11 @@ int uh_knn_build_dev(uh_knn* idx, const uint8_t* d_train, int nt);
  * indices stay global.  Default = [0,nt). */
 int uh_knn_set_shard(uh_knn* idx, int begin, int end);
 int uh_knn_size(const uh_knn* idx);
+/* Exact search: how many queries one wave serves (1 = default, 2, 4; rows with nn > 15 always use 1).  Results are identical.  With
+ * more queries per wave the search itself takes longer (8000 x 10 000 x nn=10: 163 / 185 / 250 us) but moves 1/2 or 1/4 of the
+ * L1/L2 traffic and keeps 1/2 or 1/4 of the waves resident — the setting for a matcher that runs beside latency-bound work on
+ * another stream (next to the local BA the whole tracking step is 6 % faster at 4). */
+int  uh_knn_set_queries_per_wave(uh_knn* index, int queries_per_wave);
 
 /* search: queries nq x 32 (row stride q_stride bytes), outputs nq x nn int32 row-major.
  * sorted: 0/1 as KnnSearchParams(maxChecks,sorted); max_dist: -1 = kNN, >=0 = radius bound
@@ -421,6 +426,9 @@ int  uh_kdtree_build_host(const float* xy, int32_t n, int32_t* n_nodes, void* no
  * scalar formulation of the result heap and an empty loop (out3[0..2]).
  * ------------------------------------------------------------------------ */
 int uh_ba_debug_clocks(uh_ba* ba, int64_t* out64);
+/* a background launch of a chosen character (0 sleeping waves, 1 integer VALU, 2 streaming loads over d_buf, 3 LDS traffic) on ctx's
+ * stream, for scripts/time_interference.py: what about a neighbouring launch slows the latency-bound BA chain down */
+int uh_debug_background(uh_ctx* ctx, int mode, int blocks, int iters, const void* d_buf, size_t buf_bytes, void* d_sink);
 int uh_knn_debug_push_cycles(uh_knn* knn, int k, int n, long long* out3);
 
 #ifdef __cplusplus

@@ -73,10 +73,11 @@ def knn_case(seed):
     else:
         train, q = synth.match_set(nq, nt, seed=seed % 1000)
     srt = bool(r.integers(0, 2))
-    idx = Index(ctx).build(train)
+    qpw = int(r.choice([1, 2, 4]))
+    idx = Index(ctx).build(train).set_queries_per_wave(qpw)
     gi, gd = idx.search(q, nn, sorted=srt)
     ri, rd = oracle_lib.knn_search(L, train, q, nn, int(srt))
-    return (gi == ri).all() and (gd == rd).all(), (nt, nq, nn, srt)
+    return (gi == ri).all() and (gd == rd).all(), (nt, nq, nn, srt, qpw)
 
 run("knn_exact", knn_case)
 

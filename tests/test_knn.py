@@ -95,6 +95,33 @@ def test_hip_knn_radius_bound_and_strided_rows(hip_ctx, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("qpw", [2, 4])
+def test_hip_knn_queries_per_wave_identical_rows(hip_ctx, oracle, qpw):
+    """uh_knn_set_queries_per_wave: 2 / 4 queries share the train rows a wave loads; rows (heap order included) stay the reference's,
+    for query counts that are not multiples of the group, tie-heavy sets, nn = 1 (depth-1 heap), 2, 10, 15 and a radius bound."""
+    from ucoslam_cv3_amd.knn import Index
+
+    for case, (train, q) in _gpu_cases().items():
+        index = Index(hip_ctx).build(train).set_queries_per_wave(qpw)
+        for nn in (1, 2, 10, 15, 33):            # 33 > 15: served by the one-query kernel
+            for s in (0, 1):
+                idx, dist = index.search(q, nn, sorted=bool(s))
+                ri, rd = oracle_lib.knn_search(oracle, train, q, nn, s)
+                np.testing.assert_array_equal(idx, ri, err_msg=f"{case} nn={nn} sorted={s} qpw={qpw}")
+                np.testing.assert_array_equal(dist, rd)
+    train, q = synth.match_set(1003, 9999, seed=77)
+    index = Index(hip_ctx).build(train).set_queries_per_wave(qpw)
+    for md in (-1, 70):
+        idx, dist = index.search(q, 10, sorted=False, max_dist=md)
+        ri, rd = oracle_lib.knn_search(oracle, train, q, 10, 0, max_dist=md)
+        np.testing.assert_array_equal(idx, ri)
+        np.testing.assert_array_equal(dist, rd)
+    import ucoslam_cv3_amd as u
+    with pytest.raises(u.UcoslamHipError):
+        index.set_queries_per_wave(3)
+
+
+@pytest.mark.gpu
 def test_hip_knn_large_map_and_widest_rows(hip_ctx, oracle):
     """150 000 train rows (a large map), nn = 64 (the widest row the wave heap holds) and nn = 1, sorted and unsorted; a train
     count that is not a multiple of the 256-row scan group."""

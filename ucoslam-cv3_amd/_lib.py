@@ -71,6 +71,7 @@ def _declare(L: C.CDLL):
     sig("uh_knn_build_dev", I, VP, VP, I)
     sig("uh_knn_set_shard", I, VP, I, I)
     sig("uh_knn_size", I, VP)
+    sig("uh_knn_set_queries_per_wave", I, VP, I)
     sig("uh_knn_search", I, VP, VP, I, SZ, I, VP, VP, I, I)
     sig("uh_knn_search_dev", I, VP, VP, I, I, VP, VP, I, I)
     sig("uh_knn_build_kmeans", I, VP, VP, I, I, I)

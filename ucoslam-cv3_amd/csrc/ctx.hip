@@ -105,6 +105,42 @@ int uh_prof_report(uh_ctx* ctx, char* buf, size_t cap) {
     return (int)out.size() + 1;
 }
 
+// Measurement hook (scripts/time_interference.py): a background kernel of a chosen character, to see WHAT about a neighbouring
+// launch slows the latency-bound BA chain down.  mode 0: waves that only sleep (occupy wave slots, nothing else); 1: dependent
+// integer VALU work; 2: streaming loads over `buf` (L1/L2/TA traffic); 3: LDS traffic.
+__global__ __launch_bounds__(256) void uh_debug_background_kernel(int mode, int iters, const unsigned int* buf, unsigned int words, unsigned int* sink) {
+    __shared__ unsigned int s_l[1024];
+    unsigned int acc = threadIdx.x;
+    if (mode == 0) {
+        for (int i = 0; i < iters; i++) __builtin_amdgcn_s_sleep(64);
+    } else if (mode == 1) {
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc = acc * 1664525u + 1013904223u;
+        }
+    } else if (mode == 2) {
+        unsigned int idx = (blockIdx.x * 256 + threadIdx.x) * 4;
+        for (int i = 0; i < iters; i++) {
+            const uint4 v = *reinterpret_cast<const uint4*>(buf + (idx % (words - 4)));
+            acc += v.x ^ v.y ^ v.z ^ v.w;
+            idx += 256 * 4 * 97;
+        }
+    } else {
+        s_l[threadIdx.x] = acc; s_l[threadIdx.x + 256] = acc; s_l[threadIdx.x + 512] = acc; s_l[threadIdx.x + 768] = acc;
+        __syncthreads();
+        for (int i = 0; i < iters; i++) acc += s_l[(acc + i) & 1023];
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+
+int uh_debug_background(uh_ctx* ctx, int mode, int blocks, int iters, const void* d_buf, size_t buf_bytes, void* d_sink) {
+    UH_REQUIRE(ctx && blocks >= 1 && iters >= 0 && d_sink, "uh_debug_background: bad arguments");
+    UH_HIP_CHECK(hipSetDevice(ctx->device));
+    UH_LAUNCH(ctx, uh_debug_background_kernel, dim3(blocks), dim3(256), 0, mode, iters, (const unsigned int*)d_buf, (unsigned int)(buf_bytes / 4), (unsigned int*)d_sink);
+    UH_HIP_CHECK(hipGetLastError());
+    return UH_OK;
+}
+
 void* uh_ctx_stream(uh_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
 
 }  // extern "C"

@@ -276,6 +276,68 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_search_kernel(
     finish_row(h, k, sorted, indices, distances, qi);
 }
 
+// QPW queries per wave: a group of train rows is loaded once and scored against QPW queries (their words live in SGPRs): 1/QPW of the
+// L2 -> CU traffic and 1/QPW of the resident waves of the one-query form; every query keeps its own heap (two VGPRs) and its pushes
+// happen in ascending row order exactly as in the one-query form.
+template <int LV, int QPW>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_search_mq_kernel(
+    const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k,
+    int sorted, int maxd, int32_t* __restrict__ indices, int32_t* __restrict__ distances) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int q0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * QPW);
+    if (q0 >= nq) return;
+    uint32_t q[QPW][8];
+    WaveHeap h[QPW];
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) {
+        load_query(queries, q0 + j < nq ? q0 + j : nq - 1, q[j]);
+        h[j] = WaveHeap{0, -1, 0, lane};
+    }
+    constexpr int UNROLL = 4;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(train), 0, t1 * 32, 0x00020000);
+    const int voff = lane * 32;
+    int dummy = 0;
+    int base = t0;
+    for (; base + UNROLL * kWave <= t1; base += UNROLL * kWave) {
+        uint4 a0[UNROLL], a1[UNROLL];
+        const int soff = __builtin_amdgcn_readfirstlane(base * 32);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const u32x4 x0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + u * kWave * 32, soff, 0);
+            const u32x4 x1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + u * kWave * 32 + 16, soff, 0);
+            a0[u] = make_uint4(x0.x, x0.y, x0.z, x0.w);
+            a1[u] = make_uint4(x1.x, x1.y, x1.z, x1.w);
+        }
+#pragma unroll
+        for (int j = 0; j < QPW; ++j) {
+            int d[UNROLL];
+            bool any = false;
+            const int thr = h[j].threshold(k);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) { d[u] = hamming256(a0[u], a1[u], q[j]); any = any || d[u] < thr; }
+            if (__ballot(any) == 0) continue;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) feed_step<false, LV>(h[j], d[u], base + u * kWave + lane, true, k, maxd, nullptr, dummy, 0);
+        }
+    }
+    for (; base < t1; base += kWave) {
+        const int t = base + lane;
+        const bool valid = t < t1;
+        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+        if (valid) {
+            const uint4* p = reinterpret_cast<const uint4*>(train + (size_t)t * 32);
+            a0 = p[0];
+            a1 = p[1];
+        }
+#pragma unroll
+        for (int j = 0; j < QPW; ++j) feed_step<false, LV>(h[j], hamming256(a0, a1, q[j]), t, valid, k, maxd, nullptr, dummy, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < QPW; ++j)
+        if (q0 + j < nq) finish_row(h[j], k, sorted, indices, distances, q0 + j);
+}
+
 // Shard scan: emits the locally accepted candidates in index order.
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_scan_shard_kernel(
     const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k,
@@ -586,6 +648,7 @@ struct uh_knn {
     const uint8_t* d_train = nullptr;
     int nt = 0;
     int shard_begin = 0, shard_end = 0;
+    int qpw = 1;                  // queries per wave of the exact search (uh_knn_set_queries_per_wave)
     uh::DevBuf q_buf, idx_buf, dist_buf;  // staging for the host-pointer API
     // hierarchical k-means form of the same index (uh_knn_build_kmeans)
     std::vector<uint8_t> km_blob;
@@ -652,6 +715,13 @@ int uh_knn_set_shard(uh_knn* idx, int begin, int end) {
 
 int uh_knn_size(const uh_knn* idx) { return idx ? idx->nt : 0; }
 
+int uh_knn_set_queries_per_wave(uh_knn* idx, int qpw) {
+    UH_REQUIRE(idx, "uh_knn_set_queries_per_wave: NULL index");
+    UH_REQUIRE(qpw == 1 || qpw == 2 || qpw == 4, "uh_knn_set_queries_per_wave: %d (supported: 1, 2, 4)", qpw);
+    idx->qpw = qpw;
+    return UH_OK;
+}
+
 int uh_knn_debug_push_cycles(uh_knn* idx, int k, int n, long long* out3) {
     long long* d = nullptr;
     UH_HIP_CHECK(hipMalloc(&d, 64));
@@ -680,6 +750,17 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
     if (nq == 0) return UH_OK;
     UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
     dim3 grid(uh_div_up(nq, kWavesPerBlock)), block(kWave * kWavesPerBlock);
+    // queries per wave (uh_knn_set_queries_per_wave): 2 or 4 queries share every train row a wave loads — the search itself gets
+    // slower (the pushes of a wave's queries serialise), its L1/L2 traffic and its resident waves drop to 1/2 or 1/4, which is what a
+    // latency-bound neighbour on another stream (the local BA) needs
+    const int qpw = nn <= 15 ? idx->qpw : 1;
+    if (qpw > 1) {
+        const dim3 gq(uh_div_up(nq, kWavesPerBlock * qpw));
+#define UH_KNN_MQ(LV, Q) UH_LAUNCH(idx->ctx, (knn_search_mq_kernel<LV, Q>), gq, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances)
+        if (nn <= 3) { if (qpw == 2) UH_KNN_MQ(1, 2); else UH_KNN_MQ(1, 4); }
+        else { if (qpw == 2) UH_KNN_MQ(3, 2); else UH_KNN_MQ(3, 4); }
+#undef UH_KNN_MQ
+    } else
     if (nn <= 3) UH_LAUNCH(idx->ctx, knn_search_kernel<1>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances);
     else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_search_kernel<3>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances);
     else UH_LAUNCH(idx->ctx, knn_search_kernel<6>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances);

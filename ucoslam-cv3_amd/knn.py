@@ -47,6 +47,12 @@ class Index:
     def set_shard(self, begin: int, end: int):
         check(lib().uh_knn_set_shard(self._h, begin, end))
 
+    def set_queries_per_wave(self, qpw: int):
+        """1 (default), 2 or 4 queries per wave in the exact search: identical rows; fewer, register-tiled waves move less L1/L2 traffic,
+        which is what latency-bound work on another stream (the local BA) needs — see uh_knn_set_queries_per_wave."""
+        check(lib().uh_knn_set_queries_per_wave(self._h, qpw))
+        return self
+
     def size(self) -> int:
         return lib().uh_knn_size(self._h)
 
