@@ -275,7 +275,9 @@ def main():
 
             short = {}
             for kname, v in rep.items():          # "(anonymous namespace)::ba_solve_kernel<true>" -> "ba_solve_kernel"
-                n = _re.sub(r"<.*>", "", kname.split("::")[-1])
+                n = _re.sub(r"<.*>", "", kname.split("::")[-1]).strip("()")
+                if n == "knn_search_mq_kernel":      # the queries-per-wave form of the same search
+                    n = "knn_search_kernel"
                 c0, t0_ = short.get(n, (0, 0.0))
                 short[n] = (c0 + v[0], t0_ + v[1])
             dom = max(short.items(), key=lambda kv: kv[1][1])
