@@ -1818,16 +1818,18 @@ int uh_ba_optimize(uh_ba* b, const volatile uint8_t* stop_asap) {
     UH_LAUNCH(b->ctx,ba_init_state_kernel, dim3(uh_div_up(nmax, 256)), dim3(256), 0, b->ptrs, d, b->d_pose0, b->d_pts0);
     b->iters[0] = b->iters[1] = 0;
     b->step = 0;
-    // Both passes are enqueued in one go (one step per outer iteration + 1: enough when no trial is rejected).  Between them the
+    // Both passes are enqueued in one go, one step per outer iteration: enough when no trial is rejected — a rejected trial is rare,
+    // and a spare step whose pass is already finished would still cost its two launches (~10 us per pass); finish_pass() adds steps
+    // when a pass needs them.  Between them the
     // gate kernel checks on the device that pass 1 is complete and not stopped; if it is not, relabel / begin_pass do nothing
     // and the steps enqueued for pass 2 simply continue pass 1.  The host looks at the state once, at the end.
     int rc;
     UH_LAUNCH(b->ctx,ba_begin_pass_kernel, dim3(1), dim3(64), 0, b->ptrs, n1, mc, b->step & 1, 0);
-    if ((rc = enqueue_steps(b, n1 + 1, true))) return rc;
+    if ((rc = enqueue_steps(b, n1, true))) return rc;
     UH_LAUNCH(b->ctx,ba_gate_kernel, dim3(1), dim3(64), 0, b->ptrs, b->step & 1);
     if (d.E > 0) UH_LAUNCH(b->ctx,ba_relabel_kernel, dim3(uh_div_up(d.E, 256)), dim3(256), 0, b->ptrs, d, b->step & 1, 1);
     UH_LAUNCH(b->ctx,ba_begin_pass_kernel, dim3(1), dim3(64), 0, b->ptrs, n2, mc, b->step & 1, 1);
-    if ((rc = enqueue_steps(b, n2 + 1, true))) return rc;
+    if ((rc = enqueue_steps(b, n2, true))) return rc;
     BAState hs;
     if ((rc = wait_state(b, &hs, stop_asap))) return rc;
     if (hs.gate) {                       // the common case: pass 2 is under way or done
