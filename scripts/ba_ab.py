@@ -1,0 +1,51 @@
+"""A/B of the two local-BA forms on the GPU: persistent one-launch kernel (default) vs legacy two-launches-per-trial
+(UH_BA_FORM=legacy), both against the CPU oracle; timing of optimize() and the persistent kernel's phase clocks.
+usage: python scripts/ba_ab.py [K P seed nfix]..."""
+import os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np, torch
+import synth, oracle_lib
+import ucoslam_cv3_amd as u
+from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+import ctypes as C
+
+torch.cuda.set_device(0)
+ctx = u.Context(0, torch.cuda.current_stream().cuda_stream)
+O = oracle_lib.load_oracle()
+L = u.lib()
+L.uh_ba_debug_clocks.argtypes = [C.c_void_p, C.c_void_p]; L.uh_ba_debug_clocks.restype = C.c_int
+cfgs = [(10, 3000, 0, 2), (6, 400, 1, 1), (4, 150, 2, 2), (10, 800, 3, 2), (9, 5000, 4, 1), (5, 33, 5, 2)]
+if len(sys.argv) > 4:
+    a = list(map(int, sys.argv[1:])); cfgs = [tuple(a[i:i + 4]) for i in range(0, len(a), 4)]
+for K, P, seed, nfix in cfgs:
+    pr = synth.ba_problem(K, P, seed, nfixed=nfix)
+    ref = oracle_lib.ba_optimize(O, pr, 5)
+    out = {}
+    for form in ("persist", "persist-valu", "legacy"):
+        os.environ["UH_BA_FORM"] = "legacy" if form == "legacy" else "persist"
+        os.environ["UH_BA_SCHUR"] = "valu" if form == "persist-valu" else "mfma"
+        opt = GlobalOptimizer.create(ctx)
+        opt.setParams(pr, ParamSet(nIters=5))
+        try:
+            opt.optimize()
+        except Exception as e:
+            print(form, "FAILED:", e); continue
+        got = opt.getResults()
+        for _ in range(3): opt.optimize()
+        torch.cuda.synchronize(); t = time.perf_counter(); N = 20
+        for _ in range(N): opt.optimize()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t) / N
+        again = opt.getResults()
+        det = np.array_equal(again["state"], got["state"])
+        err = np.abs(got["state"] - ref["state"]).max()
+        print(f"K{K} P{pr['P']} E{pr['E']} nfree{K-nfix} {form:13s}: {dt*1e3:7.3f} ms  iters {got['iters'].tolist()} (oracle {ref['iters'].tolist()})  |state-oracle| {err:.2e}  "
+              f"chi2 err {np.abs(got['chi2']-ref['chi2']).max():.2e}  bad== {(got['bad']==ref['bad']).mean():.5f}  deterministic {det}")
+        out[form] = got
+        if form.startswith("persist"):
+            clk = np.zeros(64, dtype=np.int64); L.uh_ba_debug_clocks(opt._h, clk.ctypes.data)
+            us = lambda a, b: (clk[b] - clk[a]) / 100.0
+            print(f"    last trial: phase1 {us(40,41):.2f} | A+slices+B {us(41,42):.2f} (wait A {us(41,50):.2f}, slice {us(50,51):.2f}, wait B {us(51,42):.2f}) | assemble {us(42,43):.2f} | factor {us(43,44):.2f} "
+                  f"| backsolve {us(44,45):.2f} | pose+backsub {us(45,46):.2f} | errors {us(46,47):.2f} | C {us(47,48):.2f} | decide {us(48,49):.2f} | total {us(40,49):.2f} us")
+    if "persist" in out and "legacy" in out:
+        print(f"    persist vs legacy |state| {np.abs(out['persist']['state']-out['legacy']['state']).max():.2e}")

@@ -41,6 +41,7 @@
 #include <thread>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 
 #include "common.hpp"
 #include "reduce.hpp"
@@ -194,23 +195,22 @@ struct EdgeLin {          // one edge's linearisation at a given state
 };
 
 // error + Huber weight (+ Jacobians) of edge e with camera pose (R,t) and point X
+// value form (observation, information scalar and intrinsics passed in): shared by the legacy kernels and the persistent kernel
 template <bool JAC>
-__device__ __forceinline__ void edge_eval(const BAPtrs& p, const BADims& d, int e, int k, const double* Rt, const double* X,
-                                          bool robust, EdgeLin& o) {
+__device__ __forceinline__ void edge_eval_v(double u, double v, double w, double fx, double fy, double cx, double cy, double delta, double dsqr,
+                                            const double* Rt, const double* X, bool robust, EdgeLin& o) {
     const double x = Rt[0] * X[0] + Rt[1] * X[1] + Rt[2] * X[2] + Rt[9];
     const double y = Rt[3] * X[0] + Rt[4] * X[1] + Rt[5] * X[2] + Rt[10];
     const double z = Rt[6] * X[0] + Rt[7] * X[1] + Rt[8] * X[2] + Rt[11];
-    const double fx = p.intr[4 * k], fy = p.intr[4 * k + 1], cx = p.intr[4 * k + 2], cy = p.intr[4 * k + 3];
-    o.ex = p.e_uv[2 * e] - ((x / z) * fx + cx);
-    o.ey = p.e_uv[2 * e + 1] - ((y / z) * fy + cy);
-    const double w = p.e_w[e];
+    o.ex = u - ((x / z) * fx + cx);
+    o.ey = v - ((y / z) * fy + cy);
     o.chi2 = w * (o.ex * o.ex + o.ey * o.ey);
     o.rho1 = 1.0;
     o.robchi = o.chi2;
-    if (robust && o.chi2 > d.dsqr) {
+    if (robust && o.chi2 > dsqr) {
         const double sq = sqrt(o.chi2);
-        o.rho1 = d.delta / sq;
-        o.robchi = 2 * sq * d.delta - d.dsqr;
+        o.rho1 = delta / sq;
+        o.robchi = 2 * sq * delta - dsqr;
     }
     if (JAC) {
         o.ww = o.rho1 * w;
@@ -226,6 +226,13 @@ __device__ __forceinline__ void edge_eval(const BAPtrs& p, const BADims& d, int 
         o.B[0] = x * y / z2 * fx; o.B[1] = -(1 + (x * x / z2)) * fx; o.B[2] = y / z * fx; o.B[3] = -1. / z * fx; o.B[4] = 0; o.B[5] = x / z2 * fx;
         o.B[6] = (1 + y * y / z2) * fy; o.B[7] = -x * y / z2 * fy; o.B[8] = -x / z * fy; o.B[9] = 0; o.B[10] = -1. / z * fy; o.B[11] = y / z2 * fy;
     }
+}
+
+template <bool JAC>
+__device__ __forceinline__ void edge_eval(const BAPtrs& p, const BADims& d, int e, int k, const double* Rt, const double* X,
+                                          bool robust, EdgeLin& o) {
+    edge_eval_v<JAC>(p.e_uv[2 * e], p.e_uv[2 * e + 1], p.e_w[e], p.intr[4 * k], p.intr[4 * k + 1], p.intr[4 * k + 2], p.intr[4 * k + 3],
+                     d.delta, d.dsqr, Rt, X, robust, o);
 }
 
 // Linearisation of one landmark by its 8 lanes (one observation each per round; 32 landmarks per workgroup): errors, Huber
@@ -540,58 +547,221 @@ __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, 
 
 // Pose update of free pose `s` into the trial buffer: T_trial = exp(dx) * T_cur (SE3Quat::exp, VertexSE3Expmap::oplusImpl);
 // with ok == 0 (the solve failed) the trial pose is the current one.  x: the solved increment (LDS or HBM).
+// T <- exp(dx) * T on (unit quaternion q, translation t): SE3Quat::exp (se3quat.h:276) and VertexSE3Expmap::oplusImpl
+__device__ __forceinline__ void se3_left_update(double (&q)[4], double (&t)[3], const double* dx) {
+    const double w0 = dx[0], w1 = dx[1], w2 = dx[2];
+    const double theta = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+    const double O[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+    double O2[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
+    double a, b, c1, c2;
+    if (theta < 0.00001) { a = 1; b = 0.5; c1 = 0.5; c2 = 1.0 / 6.0; }
+    else {
+        double sn, cs;
+        sincos(theta, &sn, &cs);
+        a = sn / theta; b = (1 - cs) / (theta * theta); c1 = b; c2 = (theta - sn) / (theta * theta * theta);
+    }
+    double Rm[9], V[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { const double I = (i % 4 == 0) ? 1.0 : 0.0; Rm[i] = I + a * O[i] + b * O2[i]; V[i] = I + c1 * O[i] + c2 * O2[i]; }
+    double qe[4];
+    quat_from_R(Rm, qe);
+    quat_norm_pos(qe);
+    double te[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) te[r] = V[r * 3] * dx[3] + V[r * 3 + 1] * dx[4] + V[r * 3 + 2] * dx[5];
+    double RE[9];
+    quat_to_R(qe, RE);
+    double qn[4];
+    qn[3] = qe[3] * q[3] - qe[0] * q[0] - qe[1] * q[1] - qe[2] * q[2];
+    qn[0] = qe[3] * q[0] + qe[0] * q[3] + qe[1] * q[2] - qe[2] * q[1];
+    qn[1] = qe[3] * q[1] + qe[1] * q[3] + qe[2] * q[0] - qe[0] * q[2];
+    qn[2] = qe[3] * q[2] + qe[2] * q[3] + qe[0] * q[1] - qe[1] * q[0];
+    double tn[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) tn[r] = RE[r * 3] * t[0] + RE[r * 3 + 1] * t[1] + RE[r * 3 + 2] * t[2] + te[r];
+    quat_norm_pos(qn);
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = qn[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) t[i] = tn[i];
+
+}
+
 __device__ __forceinline__ void pose_update_one(const BAPtrs& p, int s, int cur, int ok, const double* x) {
     const int trial = cur ^ 1;
     const int k = p.free_kf[s];
     const double* T = p.pose[cur] + 7 * k;
     double q[4] = {T[0], T[1], T[2], T[3]}, t[3] = {T[4], T[5], T[6]};
-    if (ok) {
-        const double* dx = x + 6 * s;
-        const double w0 = dx[0], w1 = dx[1], w2 = dx[2];
-        const double theta = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
-        const double O[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
-        double O2[9];
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
-        double a, b, c1, c2;
-        if (theta < 0.00001) { a = 1; b = 0.5; c1 = 0.5; c2 = 1.0 / 6.0; }
-        else {
-            double sn, cs;
-            sincos(theta, &sn, &cs);
-            a = sn / theta; b = (1 - cs) / (theta * theta); c1 = b; c2 = (theta - sn) / (theta * theta * theta);
-        }
-        double Rm[9], V[9];
-#pragma unroll
-        for (int i = 0; i < 9; i++) { const double I = (i % 4 == 0) ? 1.0 : 0.0; Rm[i] = I + a * O[i] + b * O2[i]; V[i] = I + c1 * O[i] + c2 * O2[i]; }
-        double qe[4];
-        quat_from_R(Rm, qe);
-        quat_norm_pos(qe);
-        double te[3];
-#pragma unroll
-        for (int r = 0; r < 3; r++) te[r] = V[r * 3] * dx[3] + V[r * 3 + 1] * dx[4] + V[r * 3 + 2] * dx[5];
-        double RE[9];
-        quat_to_R(qe, RE);
-        double qn[4];
-        qn[3] = qe[3] * q[3] - qe[0] * q[0] - qe[1] * q[1] - qe[2] * q[2];
-        qn[0] = qe[3] * q[0] + qe[0] * q[3] + qe[1] * q[2] - qe[2] * q[1];
-        qn[1] = qe[3] * q[1] + qe[1] * q[3] + qe[2] * q[0] - qe[0] * q[2];
-        qn[2] = qe[3] * q[2] + qe[2] * q[3] + qe[0] * q[1] - qe[1] * q[0];
-        double tn[3];
-#pragma unroll
-        for (int r = 0; r < 3; r++) tn[r] = RE[r * 3] * t[0] + RE[r * 3 + 1] * t[1] + RE[r * 3 + 2] * t[2] + te[r];
-        quat_norm_pos(qn);
-#pragma unroll
-        for (int i = 0; i < 4; i++) q[i] = qn[i];
-#pragma unroll
-        for (int i = 0; i < 3; i++) t[i] = tn[i];
-    }
+    if (ok) se3_left_update(q, t, x + 6 * s);
     double* To = p.pose[trial] + 7 * k;
     To[0] = q[0]; To[1] = q[1]; To[2] = q[2]; To[3] = q[3]; To[4] = t[0]; To[5] = t[1]; To[6] = t[2];
     double* Ro = p.poseR[trial] + 12 * k;
     quat_to_R(q, Ro);
     Ro[9] = t[0]; Ro[10] = t[1]; Ro[11] = t[2];
+}
+
+// Blocked look-ahead LDL^T of the bordered system [S b; b^T .] held as a lower triangle in LDS (row stride ld = n + 1, odd), shared by the
+// fused legacy solve and the persistent kernel.  Every thread of the workgroup calls it (it contains barriers); the first
+// kSolveThreads threads do the work.  Returns (in wave 0) whether a zero / non-finite pivot was met.
+__device__ __forceinline__ bool ldlt_bordered_lds(double* M, int n, int ld, int nfree, int npairs, const short (*s_pair)[2],
+                                                  double (*s_w)[121][6]) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool active = tid < kSolveThreads;
+    bool failed = false;
+    {
+        // LOOK-AHEAD form: panel kb is first applied to block column kb+1 alone, by all four waves; then wave 0 factorises that
+        // diagonal block and solves ITS panel while waves 1..3 apply panel kb to the tiles behind — the serial chain of
+        // reciprocals no longer waits for the bulk of the trailing update.  The L*D panel is double-buffered (s_w[kb & 1]).
+        // The right-hand side rides along as row n of the matrix ([S b; b^T .] = bordered system): its L entries are
+        // D^-1 L^-1 b, i.e. the forward substitution and the scaling by D^-1 come out of the panel solves and trailing
+        // updates the factorisation performs anyway (one more row among idle lanes); only L^T x = z is left afterwards.
+        const int nb = n / 6;
+        const int nrow = n + 1;
+        auto diag_and_panel = [&](int kb) {   // wave 0 only: block column kb is fully updated
+            const int k0 = 6 * kb;
+            double a[6][6], dk[6], ik[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int c = 0; c <= i; c++) a[i][c] = M[(k0 + i) * ld + k0 + c];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                dk[j] = a[j][j];
+                failed = failed || dk[j] == 0.0 || !isfinite(dk[j]);
+                ik[j] = fast_rcp(dk[j]);
+                double lcol[6];
+#pragma unroll
+                for (int i = j + 1; i < 6; i++) lcol[i] = a[i][j] * ik[j];
+#pragma unroll
+                for (int i = j + 1; i < 6; i++)
+#pragma unroll
+                    for (int c = j + 1; c <= i; c++) a[i][c] = fma(-lcol[i], a[c][j], a[i][c]);
+#pragma unroll
+                for (int i = j + 1; i < 6; i++) a[i][j] = lcol[i];
+            }
+            __builtin_amdgcn_wave_barrier();   // every lane has read the block before lane 0 overwrites it
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+#pragma unroll
+                    for (int c = 0; c < i; c++) M[(k0 + i) * ld + k0 + c] = a[i][c];
+                    M[(k0 + i) * ld + k0 + i] = dk[i];
+                }
+            }
+            for (int r = k0 + 6 + lane; r < nrow; r += 64) {   // panel: L_rk = A_rk * Lkk^-T * Dk^-1; y = L_rk * Dk goes to s_w
+                double y[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++) y[j] = M[r * ld + k0 + j];
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+#pragma unroll
+                    for (int t = 0; t < j; t++) y[j] = fma(-y[t], a[j][t], y[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 6; j++) { M[r * ld + k0 + j] = y[j] * ik[j]; s_w[kb & 1][r][j] = y[j]; }
+            }
+        };
+        if (wv == 0 && nb > 0) diag_and_panel(0);
+        for (int kb = 0; kb < nb; kb++) {
+            __syncthreads();   // panel kb (M columns of block kb, s_w[kb & 1]) is complete; trailing update kb-1 is done
+            if (kb == nb - 1) break;
+            const int k0 = 6 * kb;
+            {   // block column kb+1 first, by everybody (one element per thread and round): wave 0 needs it to go on
+                const int c0 = k0 + 6, m = nrow - c0;
+                for (int e = tid; active && e < m * 6; e += kSolveThreads) {
+                    const int r = c0 + e / 6, c = c0 + e % 6;
+                    double acc = M[r * ld + c];
+                    double lr[6], wc[6];
+#pragma unroll
+                    for (int t = 0; t < 6; t++) { lr[t] = M[r * ld + k0 + t]; wc[t] = s_w[kb & 1][c][t]; }
+#pragma unroll
+                    for (int t = 0; t < 6; t++) acc = fma(-lr[t], wc[t], acc);
+                    if (c <= r) M[r * ld + c] = acc;
+                }
+            }
+            __syncthreads();
+            if (wv == 0) {
+                diag_and_panel(kb + 1);
+            } else if (active) {
+                // tiles (s1 <= s2) with s1 >= kb+2: the tail of the s1-major pair list; 5 tile slots of 36 threads
+                const int t3 = tid - 64;
+                const int tq = t3 / 36, te = t3 - 36 * tq, ti = te / 6, tj = te - 6 * ti;
+                constexpr int kSlots = (kSolveThreads - 64) / 36;
+                // the threads left over by the tile slots update the right-hand-side row behind block column kb+1
+                for (int c = 6 * (kb + 2) + (t3 - 36 * kSlots); t3 >= 36 * kSlots && c < n; c += kSolveThreads - 64 - 36 * kSlots) {
+                    double acc = M[(size_t)n * ld + c];
+#pragma unroll
+                    for (int t = 0; t < 6; t++) acc = fma(-M[(size_t)n * ld + k0 + t], s_w[kb & 1][c][t], acc);
+                    M[(size_t)n * ld + c] = acc;
+                }
+                const int s1min = kb + 2;
+                const int tile0 = s1min * nfree - s1min * (s1min - 1) / 2;   // first pair with s1 >= kb+2
+                const int ntile = npairs - tile0;
+                for (int tl = tq; tl < ntile && tq < kSlots; tl += kTrailU * kSlots) {
+                    int rr[kTrailU], cc[kTrailU]; bool on[kTrailU];
+                    double lr[kTrailU][6], wc[kTrailU][6], acc[kTrailU];
+#pragma unroll
+                    for (int u = 0; u < kTrailU; u++) {
+                        const int t_ = tl + u * kSlots;
+                        const int tc = t_ < ntile ? t_ : tl;
+                        const int s1 = s_pair[tile0 + tc][0], s2 = s_pair[tile0 + tc][1];
+                        rr[u] = 6 * s2 + ti; cc[u] = 6 * s1 + tj;
+                        on[u] = t_ < ntile && cc[u] <= rr[u];
+#pragma unroll
+                        for (int t = 0; t < 6; t++) { lr[u][t] = M[rr[u] * ld + k0 + t]; wc[u][t] = s_w[kb & 1][cc[u]][t]; }
+                        acc[u] = M[rr[u] * ld + cc[u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kTrailU; u++) {
+#pragma unroll
+                        for (int t = 0; t < 6; t++) acc[u] = fma(-lr[u][t], wc[u][t], acc[u]);
+                        if (on[u]) M[rr[u] * ld + cc[u]] = acc[u];
+                    }
+                }
+            }
+        }
+        if (wv != 0) failed = false;   // only wave 0 sees the pivots
+    }
+    return failed;
+}
+
+// L^T x = z for the bordered factorisation above (z = D^-1 L^-1 b is row n of M); x goes to s_x.  n <= 64: one wave, x_i in lane i,
+// x_j broadcast with v_readlane; larger n: column sweeps with barriers.  Every thread of the workgroup calls it.
+__device__ __forceinline__ void backsolve_lds(const double* M, int n, int ld, double* s_x) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (n <= 64) {
+        if (wv == 0) {
+            double x = lane < n ? M[(size_t)n * ld + lane] : 0.0;
+            const int lr = lane < n ? lane : n - 1;
+            double l[8], ln[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) { const int jj = n - 1 - t >= 0 ? n - 1 - t : 0; l[t] = M[(size_t)jj * ld + lr]; }
+            for (int j0 = n - 1; j0 >= 0; j0 -= 8) {
+#pragma unroll
+                for (int t = 0; t < 8; t++) { const int jj = j0 - 8 - t >= 0 ? j0 - 8 - t : 0; ln[t] = M[(size_t)jj * ld + lr]; }
+#pragma unroll
+                for (int t = 0; t < 8; t++) { const int j = j0 - t; l[t] = lane < j ? l[t] : 0.0; }
+#pragma unroll
+                for (int t = 0; t < 8; t++) x = fma(-l[t], readlane_f64(x, j0 - t > 0 ? j0 - t : 0), x);
+#pragma unroll
+                for (int t = 0; t < 8; t++) l[t] = ln[t];
+            }
+            if (lane < n) s_x[lane] = x;
+        }
+    } else {
+        for (int i = tid; i < n; i += blockDim.x) s_x[i] = M[(size_t)n * ld + i];
+        __syncthreads();
+        for (int j = n - 1; j >= 0; j--) {
+            const double xj = s_x[j];
+            __syncthreads();
+            for (int i = tid; i < j; i += blockDim.x) s_x[i] -= M[(size_t)j * ld + i] * xj;
+            __syncthreads();
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ solve + pose update
@@ -711,119 +881,8 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     // diagonal.
     bool failed = false;
     if constexpr (USE_LDS) {
-        // LOOK-AHEAD form: panel kb is first applied to block column kb+1 alone, by all four waves; then wave 0 factorises that
-        // diagonal block and solves ITS panel while waves 1..3 apply panel kb to the tiles behind — the serial chain of
-        // reciprocals no longer waits for the bulk of the trailing update.  The L*D panel is double-buffered (s_w[kb & 1]).
-        // The right-hand side rides along as row n of the matrix ([S b; b^T .] = bordered system): its L entries are
-        // D^-1 L^-1 b, i.e. the forward substitution and the scaling by D^-1 come out of the panel solves and trailing
-        // updates the factorisation performs anyway (one more row among idle lanes); only L^T x = z is left afterwards.
         __shared__ double s_w[2][121][6];
-        const int nb = n / 6;
-        const int nrow = n + 1;
-        auto diag_and_panel = [&](int kb) {   // wave 0 only: block column kb is fully updated
-            const int k0 = 6 * kb;
-            double a[6][6], dk[6], ik[6];
-#pragma unroll
-            for (int i = 0; i < 6; i++)
-#pragma unroll
-                for (int c = 0; c <= i; c++) a[i][c] = M[(k0 + i) * ld + k0 + c];
-#pragma unroll
-            for (int j = 0; j < 6; j++) {
-                dk[j] = a[j][j];
-                failed = failed || dk[j] == 0.0 || !isfinite(dk[j]);
-                ik[j] = fast_rcp(dk[j]);
-                double lcol[6];
-#pragma unroll
-                for (int i = j + 1; i < 6; i++) lcol[i] = a[i][j] * ik[j];
-#pragma unroll
-                for (int i = j + 1; i < 6; i++)
-#pragma unroll
-                    for (int c = j + 1; c <= i; c++) a[i][c] = fma(-lcol[i], a[c][j], a[i][c]);
-#pragma unroll
-                for (int i = j + 1; i < 6; i++) a[i][j] = lcol[i];
-            }
-            __builtin_amdgcn_wave_barrier();   // every lane has read the block before lane 0 overwrites it
-            if (lane == 0) {
-#pragma unroll
-                for (int i = 0; i < 6; i++) {
-#pragma unroll
-                    for (int c = 0; c < i; c++) M[(k0 + i) * ld + k0 + c] = a[i][c];
-                    M[(k0 + i) * ld + k0 + i] = dk[i];
-                }
-            }
-            for (int r = k0 + 6 + lane; r < nrow; r += 64) {   // panel: L_rk = A_rk * Lkk^-T * Dk^-1; y = L_rk * Dk goes to s_w
-                double y[6];
-#pragma unroll
-                for (int j = 0; j < 6; j++) y[j] = M[r * ld + k0 + j];
-#pragma unroll
-                for (int j = 0; j < 6; j++) {
-#pragma unroll
-                    for (int t = 0; t < j; t++) y[j] = fma(-y[t], a[j][t], y[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < 6; j++) { M[r * ld + k0 + j] = y[j] * ik[j]; s_w[kb & 1][r][j] = y[j]; }
-            }
-        };
-        if (wv == 0 && nb > 0) diag_and_panel(0);
-        for (int kb = 0; kb < nb; kb++) {
-            __syncthreads();   // panel kb (M columns of block kb, s_w[kb & 1]) is complete; trailing update kb-1 is done
-            if (kb == nb - 1) break;
-            const int k0 = 6 * kb;
-            {   // block column kb+1 first, by everybody (one element per thread and round): wave 0 needs it to go on
-                const int c0 = k0 + 6, m = nrow - c0;
-                for (int e = tid; e < m * 6; e += kSolveThreads) {
-                    const int r = c0 + e / 6, c = c0 + e % 6;
-                    double acc = M[r * ld + c];
-                    double lr[6], wc[6];
-#pragma unroll
-                    for (int t = 0; t < 6; t++) { lr[t] = M[r * ld + k0 + t]; wc[t] = s_w[kb & 1][c][t]; }
-#pragma unroll
-                    for (int t = 0; t < 6; t++) acc = fma(-lr[t], wc[t], acc);
-                    if (c <= r) M[r * ld + c] = acc;
-                }
-            }
-            __syncthreads();
-            if (wv == 0) {
-                diag_and_panel(kb + 1);
-            } else {
-                // tiles (s1 <= s2) with s1 >= kb+2: the tail of the s1-major pair list; 5 tile slots of 36 threads
-                const int t3 = tid - 64;
-                const int tq = t3 / 36, te = t3 - 36 * tq, ti = te / 6, tj = te - 6 * ti;
-                constexpr int kSlots = (kSolveThreads - 64) / 36;
-                // the threads left over by the tile slots update the right-hand-side row behind block column kb+1
-                for (int c = 6 * (kb + 2) + (t3 - 36 * kSlots); t3 >= 36 * kSlots && c < n; c += kSolveThreads - 64 - 36 * kSlots) {
-                    double acc = M[(size_t)n * ld + c];
-#pragma unroll
-                    for (int t = 0; t < 6; t++) acc = fma(-M[(size_t)n * ld + k0 + t], s_w[kb & 1][c][t], acc);
-                    M[(size_t)n * ld + c] = acc;
-                }
-                const int s1min = kb + 2;
-                const int tile0 = s1min * d.nfree - s1min * (s1min - 1) / 2;   // first pair with s1 >= kb+2
-                const int ntile = npairs - tile0;
-                for (int tl = tq; tl < ntile && tq < kSlots; tl += kTrailU * kSlots) {
-                    int rr[kTrailU], cc[kTrailU]; bool on[kTrailU];
-                    double lr[kTrailU][6], wc[kTrailU][6], acc[kTrailU];
-#pragma unroll
-                    for (int u = 0; u < kTrailU; u++) {
-                        const int t_ = tl + u * kSlots;
-                        const int tc = t_ < ntile ? t_ : tl;
-                        const int s1 = s_pair[tile0 + tc][0], s2 = s_pair[tile0 + tc][1];
-                        rr[u] = 6 * s2 + ti; cc[u] = 6 * s1 + tj;
-                        on[u] = t_ < ntile && cc[u] <= rr[u];
-#pragma unroll
-                        for (int t = 0; t < 6; t++) { lr[u][t] = M[rr[u] * ld + k0 + t]; wc[u][t] = s_w[kb & 1][cc[u]][t]; }
-                        acc[u] = M[rr[u] * ld + cc[u]];
-                    }
-#pragma unroll
-                    for (int u = 0; u < kTrailU; u++) {
-#pragma unroll
-                        for (int t = 0; t < 6; t++) acc[u] = fma(-lr[u][t], wc[u][t], acc[u]);
-                        if (on[u]) M[rr[u] * ld + cc[u]] = acc[u];
-                    }
-                }
-            }
-        }
-        if (wv != 0) failed = false;   // only wave 0 sees the pivots
+        failed = ldlt_bordered_lds(M, n, ld, d.nfree, npairs, s_pair, s_w);
     } else {
         __shared__ double s_w[6 * kMaxFree][6];
         constexpr int kTilesPerRound = kSolveThreads / 36;
@@ -1454,6 +1513,8 @@ __global__ void ba_init_state_kernel(BAPtrs p, BADims d, const double* __restric
     if (i == 0) { BAState z; memset(&z, 0, sizeof(z)); z.phase = 2; z.lambda = -1; z.ni = 2; p.st[0] = z; p.st[1] = z; }
 }
 
+#include "ba_persist.hpp"
+
 }  // namespace
 
 struct uh_ba {
@@ -1471,6 +1532,10 @@ struct uh_ba {
     int iters[2] = {0, 0};
     int nsplit = 1;
     bool wide = false;                    // more than kMaxFree free keyframes: sparse pair lists + blocked dense LDL^T in HBM
+    bool persist = false;                 // 1..8 free keyframes: the whole optimisation is ONE persistent launch (ba_persist.hpp)
+    BAPersist pq{};
+    uh::DevBuf parena;                    // the persistent form's packed observations and exchange buffers
+    int p_lds = 0;
     BAWide wd{};
     int step = 0;                         // LM steps enqueued since uh_ba_optimize began: step s reads state slot s & 1
     bool optimized = false;
@@ -1570,11 +1635,19 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
 int wait_state(uh_ba* b, BAState* hs, const volatile uint8_t* stop_asap) {
     hipStream_t st = b->ctx->stream;
     UH_HIP_CHECK(hipMemcpyAsync(hs, b->ptrs.st + (b->step & 1), sizeof(BAState), hipMemcpyDeviceToHost, st));
-    if (stop_asap && b->h_stop) {
+    if (stop_asap && b->h_stop) {   // forward the caller's flag while the stream drains; the mapper thread yields between polls
         hipEvent_t ev;
         UH_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        UH_HIP_CHECK(hipEventRecord(ev, st));
-        while (hipEventQuery(ev) == hipErrorNotReady) if (*stop_asap) *b->h_stop = 1;
+        const hipError_t er = hipEventRecord(ev, st);
+        if (er != hipSuccess) {
+            (void)hipEventDestroy(ev);
+            uh::set_error("hipEventRecord failed: %s", hipGetErrorString(er));
+            return UH_ENODEVICE;
+        }
+        while (hipEventQuery(ev) == hipErrorNotReady) {
+            if (*stop_asap) *b->h_stop = 1;
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
         (void)hipEventDestroy(ev);
     }
     UH_HIP_CHECK(hipStreamSynchronize(st));
@@ -1588,6 +1661,45 @@ int finish_pass(uh_ba* b, BAState* hs, const volatile uint8_t* stop_asap) {
         if (rc) return rc;
         if ((rc = wait_state(b, hs, stop_asap))) return rc;
     }
+    if (hs->phase != 2) {   // cannot happen with <= 10 trials per iteration and <= 2*nIters iterations, but never report success on a running pass
+        uh::set_error("uh_ba_optimize: the LM pass did not finish within its step budget (phase %d, iteration %d)", hs->phase, hs->iteration);
+        return UH_EINVAL;
+    }
+    return UH_OK;
+}
+
+// Admission of persistent launches: their workgroups spin on each other, so every launch must become fully resident.  One CU holds
+// one such workgroup (LDS), hence at most 224 of the 256 CUs' worth of them are in flight per process at any time.
+struct PersistAdmission {
+    std::mutex m; std::condition_variable cv; int used = 0;
+    void acquire(int g) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&]() { return used == 0 || used + g <= 224; }); used += g; }
+    void release(int g) { { std::lock_guard<std::mutex> l(m); used -= g; } cv.notify_all(); }
+};
+PersistAdmission g_persist_adm;
+
+// GlobalOptimizerG2O::optimize as ONE launch (ba_persist.hpp): both passes, relabelling, every trial
+int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, float mc) {
+    hipStream_t st = b->ctx->stream;
+    BAPersist q = b->pq;
+    q.n1 = n1; q.n2 = n2; q.minChi2 = mc;
+    q.stop_at_begin = (b->h_stop && *b->h_stop) ? 1 : 0;
+    struct Hold { int g; Hold(int g_) : g(g_) { g_persist_adm.acquire(g); } ~Hold() { g_persist_adm.release(g); } } hold(q.G);
+    UH_HIP_CHECK(hipMemsetAsync(q.flags, 0, sizeof(unsigned) * (q.G + 1), st));
+    UH_LAUNCH(b->ctx, ba_persist_kernel<8>, dim3(q.G), dim3(kPThreads), (size_t)b->p_lds, b->ptrs, b->dims, q);
+    UH_HIP_CHECK(hipGetLastError());
+    BAState hs;
+    int rc = wait_state(b, &hs, stop_asap);
+    if (rc) return rc;
+    unsigned err = 0;
+    UH_HIP_CHECK(hipMemcpyAsync(&err, q.flags + q.G, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    UH_HIP_CHECK(hipStreamSynchronize(st));
+    if (err) {
+        uh::set_error("uh_ba_optimize: the persistent kernel's workgroups did not all become resident (%d workgroups, %d bytes of LDS each)", q.G, b->p_lds);
+        return UH_ENODEVICE;
+    }
+    b->iters[0] = hs.gate ? hs.iters_pass1 : hs.iters_done;
+    b->iters[1] = hs.gate ? hs.iters_done : 0;
+    b->optimized = true;
     return UH_OK;
 }
 
@@ -1773,6 +1885,90 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     if ((rc = b->d_points_out.reserve(std::max<size_t>(3 * (size_t)P * 4, 16)))) return rc;
     if ((rc = b->d_bad.reserve(std::max<size_t>(E, 16)))) return rc;
     UH_HIP_CHECK(hipMemcpyAsync(b->d_poses_in.p, pr->poses_f2g, 16 * (size_t)K * 4, hipMemcpyHostToDevice, st));
+    // ---- persistent form (ba_persist.hpp): 1..8 free keyframes, every landmark owned by one of <= 256 co-resident workgroups
+    b->persist = false;
+    {
+        constexpr int NF = 8;
+        const char* form = getenv("UH_BA_FORM");
+        const bool want = !(form && std::string(form) == "legacy");
+        constexpr int kLwMax = kPThreads / NF;   // one lane per (landmark, free-camera slot)
+        int Lw = std::max(8, std::min(kLwMax, uh_div_up(std::max(P, 1), 64)));
+        if (const char* e = getenv("UH_BA_LW")) Lw = std::max(1, std::min(kLwMax, atoi(e)));
+        const int G = uh_div_up(std::max(P, 1), Lw);
+        if (want && !wide && nfree >= 1 && nfree <= NF && P >= 1 && G <= 256) {
+            BAPersist& q = b->pq;
+            q = BAPersist{};
+            q.G = G; q.Lw = Lw; q.krows = (3 * Lw + 15) & ~15;
+            q.nelem = 6 * 256 + NF * 27 + 6 * NF + 4;
+            q.SL = (uh_div_up(q.nelem, G) + 1) & ~1;
+            const char* sch = getenv("UH_BA_SCHUR");
+            q.use_mfma = !(sch && std::string(sch) == "valu");
+            std::vector<double> h_uv(2 * (size_t)P * NF, 0.0), h_w((size_t)P * NF, 0.0), hx_uv, hx_w, h_R0(12 * (size_t)K);
+            std::vector<int> h_id((size_t)P * NF, -1), hx_ptr(P + 1, 0), hx_kf, hx_id;
+            for (int pt = 0; pt < P; pt++) {
+                for (int i = pt_ptr[pt]; i < pt_ptr[pt + 1]; i++) {
+                    const int e = pt_edges[i], sl = slot[pr->obs_frame[e]];
+                    if (sl >= 0) {
+                        const size_t at = (size_t)pt * NF + sl;
+                        h_id[at] = e; h_uv[2 * at] = uv[2 * e]; h_uv[2 * at + 1] = uv[2 * e + 1]; h_w[at] = w[e];
+                    } else {
+                        hx_uv.push_back(uv[2 * e]); hx_uv.push_back(uv[2 * e + 1]); hx_w.push_back(w[e]);
+                        hx_kf.push_back(pr->obs_frame[e]); hx_id.push_back(e);
+                    }
+                }
+                hx_ptr[pt + 1] = (int)hx_id.size();
+            }
+            int max_fix = 0;
+            for (int g = 0; g < G; g++) max_fix = std::max(max_fix, hx_ptr[std::min(P, (g + 1) * Lw)] - hx_ptr[g * Lw]);
+            q.max_fix = max_fix;
+            for (int k = 0; k < K; k++) {   // R | t of the snapshot, from the normalised quaternion like the legacy init kernel
+                const double* qq = &pose0[7 * k];
+                double* R = &h_R0[12 * k];
+                const double tx = 2 * qq[0], ty = 2 * qq[1], tz = 2 * qq[2];
+                const double twx = tx * qq[3], twy = ty * qq[3], twz = tz * qq[3];
+                const double txx = tx * qq[0], txy = ty * qq[0], txz = tz * qq[0];
+                const double tyy = ty * qq[1], tyz = tz * qq[1], tzz = tz * qq[2];
+                R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+                R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+                R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+                R[9] = pose0[7 * k + 4]; R[10] = pose0[7 * k + 5]; R[11] = pose0[7 * k + 6];
+            }
+            const PersistLds lay = persist_lds<NF>(q.krows, d.n, max_fix);
+            if (lay.total_bytes <= 160 * 1024) {
+                Arena PA;
+                const size_t nfx = hx_id.size();
+                const size_t o_fuv = PA.take<double>(2 * (size_t)P * NF), o_fw = PA.take<double>((size_t)P * NF), o_fid = PA.take<int>((size_t)P * NF);
+                const size_t o_xp = PA.take<int>(P + 1), o_xuv = PA.take<double>(2 * nfx + 2), o_xw = PA.take<double>(nfx + 1), o_xkf = PA.take<int>(nfx + 1), o_xid = PA.take<int>(nfx + 1);
+                const size_t o_R0 = PA.take<double>(12 * (size_t)K);
+                const size_t o_part = PA.take<double>((size_t)G * G * q.SL), o_red = PA.take<double>((size_t)G * q.SL), o_pc = PA.take<double>(4 * (size_t)G), o_fl = PA.take<unsigned>(G + 1);
+                if ((rc = b->parena.reserve(PA.off + 256))) return rc;
+                char* pb = b->parena.as<char>();
+                auto pup = [&](size_t off, const void* src, size_t bytes) -> int {
+                    if (bytes) UH_HIP_CHECK(hipMemcpyAsync(pb + off, src, bytes, hipMemcpyHostToDevice, st));
+                    return UH_OK;
+                };
+                if ((rc = pup(o_fuv, h_uv.data(), h_uv.size() * 8))) return rc;
+                if ((rc = pup(o_fw, h_w.data(), h_w.size() * 8))) return rc;
+                if ((rc = pup(o_fid, h_id.data(), h_id.size() * 4))) return rc;
+                if ((rc = pup(o_xp, hx_ptr.data(), hx_ptr.size() * 4))) return rc;
+                if ((rc = pup(o_xuv, hx_uv.data(), hx_uv.size() * 8))) return rc;
+                if ((rc = pup(o_xw, hx_w.data(), hx_w.size() * 8))) return rc;
+                if ((rc = pup(o_xkf, hx_kf.data(), hx_kf.size() * 4))) return rc;
+                if ((rc = pup(o_xid, hx_id.data(), hx_id.size() * 4))) return rc;
+                if ((rc = pup(o_R0, h_R0.data(), h_R0.size() * 8))) return rc;
+                UH_HIP_CHECK(hipStreamSynchronize(st));   // the staging vectors of this block die here
+                q.fe_uv = (const double2*)(pb + o_fuv); q.fe_w = (const double*)(pb + o_fw); q.fe_id = (const int*)(pb + o_fid);
+                q.fx_ptr = (const int*)(pb + o_xp); q.fx_uv = (const double2*)(pb + o_xuv); q.fx_w = (const double*)(pb + o_xw);
+                q.fx_kf = (const int*)(pb + o_xkf); q.fx_id = (const int*)(pb + o_xid);
+                q.poseR0 = (const double*)(pb + o_R0);
+                q.pose0 = (const double*)(base + o_pose0); q.pts0 = (const double*)(base + o_pts0);
+                q.part = (double*)(pb + o_part); q.red = (double*)(pb + o_red); q.partC = (double*)(pb + o_pc); q.flags = (unsigned*)(pb + o_fl);
+                b->p_lds = lay.total_bytes;
+                UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_persist_kernel<NF>), hipFuncAttributeMaxDynamicSharedMemorySize, lay.total_bytes));
+                b->persist = true;
+            }
+        }
+    }
     UH_HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors die here
     BAPtrs& p = b->ptrs;
     p.pt_ptr = (int*)(base + o_pt_ptr); p.pt_edges = (int*)(base + o_pt_edges); p.cam_ptr = (int*)(base + o_cam_ptr); p.cam_edges = (int*)(base + o_cam_edges);
@@ -1815,9 +2011,10 @@ int uh_ba_optimize(uh_ba* b, const volatile uint8_t* stop_asap) {
     const int nmax = std::max(std::max(d.K, 3 * d.P), std::max(d.E, 1));
     const int n1 = b->params.n_iters, n2 = 2 * b->params.n_iters;
     const float mc = b->params.min_chi2_between_iter;
-    UH_LAUNCH(b->ctx,ba_init_state_kernel, dim3(uh_div_up(nmax, 256)), dim3(256), 0, b->ptrs, d, b->d_pose0, b->d_pts0);
     b->iters[0] = b->iters[1] = 0;
     b->step = 0;
+    if (b->persist) return run_persistent(b, stop_asap, n1, n2, mc);
+    UH_LAUNCH(b->ctx,ba_init_state_kernel, dim3(uh_div_up(nmax, 256)), dim3(256), 0, b->ptrs, d, b->d_pose0, b->d_pts0);
     // Both passes are enqueued in one go, one step per outer iteration: enough when no trial is rejected — a rejected trial is rare,
     // and a spare step whose pass is already finished would still cost its two launches (~10 us per pass); finish_pass() adds steps
     // when a pass needs them.  Between them the

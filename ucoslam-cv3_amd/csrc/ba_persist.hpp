@@ -1,0 +1,629 @@
+// Persistent form of the local bundle adjustment (included by ba.hip inside its anonymous namespace).
+//
+// ONE launch runs the whole GlobalOptimizerG2O::optimize (globaloptimizer_g2o.cpp:418-464): both Levenberg passes, the outlier
+// relabelling between them and every LM trial (g2o/core/optimization_algorithm_levenberg.cpp:58-150) — where the legacy form
+// needs two launches per trial.  G <= 256 co-resident workgroups of 256 threads; workgroup g OWNS the <= 32 landmarks
+// [g*Lw, (g+1)*Lw) for the whole optimisation:
+//   * landmark coordinates (current + trial), the observations' constants, activity flags and last chi2 live in REGISTERS
+//     (one lane per (landmark, free camera): 8 lanes per landmark), the free poses in LDS (every workgroup keeps its own,
+//     bit-identical copy) — nothing of the estimate is re-read from HBM between trials;
+//   * the linearisation is never materialised: a trial recomputes the 2x3 / 2x6 Jacobians (typesg2o.h:275-314, ~150 flop) from
+//     the 24-byte observation, forms Hll, its Cholesky factor L (3x3) and the whitened blocks Y_e = Hpl_e L^-T straight into an
+//     LDS panel Yt[3*landmark + k][6*camera + a];
+//   * Schur complement (g2o/core/block_solver.hpp:341-392): sum_l Hpl D^-1 Hpl^T = Yt^T Yt, a dense 48 x 48 x (3*Lw) fp64 GEMM
+//     per workgroup — v_mfma_f64_16x16x4_f64 on the six upper 16x16 tiles, K split over the four waves (UH_BA_SCHUR=valu selects the
+//     register-tiled vector-FMA form of the same product for the A/B in DESIGN.md);  b_schur = Yt^T (L^-1 b_l);
+//   * back-substitution (block_solver.hpp:419-442): dx_l = L^-T (L^-1 b_l - Y_l^T dx_p) from the same panel;
+//   * workgroups exchange only reduction partials, through write-through (sc1) stores + one epoch flag per workgroup:
+//       A: every workgroup's partial (tiles, Hpp/bp sums, b_schur, chi2, max diag)  -> slice-wise reduction by all workgroups
+//       B: the reduced 1804 doubles -> EVERY workgroup assembles and factorises the 48x48 system itself (no broadcast hop)
+//       C: trial chi2 / scale partials -> every workgroup takes the accept / reject decision itself (apply_decision)
+//     so a trial costs three flag hand-offs instead of two kernel boundaries + launch ramps, and all summation orders are
+//     fixed: results are run-to-run deterministic and identical in every workgroup.
+#pragma once
+
+constexpr int kPThreads = 256;   // 4 waves, one per SIMD: each may use the whole 512-entry register file (256 VGPR + 256 AGPR)
+constexpr int kPWaves = kPThreads / 64;
+constexpr long long kPTimeoutTicks = 300000000ll;   // 3 s of the 100 MHz wall clock: a workgroup that never arrives
+
+struct BAPersist {
+    int G, Lw, krows, SL, nelem, max_fix;
+    int n1, n2, stop_at_begin, use_mfma;
+    float minChi2;
+    const double2* fe_uv; const double* fe_w; const int* fe_id;          // P x NF: the free cameras' observations, by (landmark, slot)
+    const int* fx_ptr; const double2* fx_uv; const double* fx_w; const int* fx_kf; const int* fx_id;   // CSR of fixed-camera observations
+    const double* pose0; const double* poseR0; const double* pts0;       // K x 7, K x 12, P x 3: the snapshot taken by setParams
+    double* part;        // [slice][workgroup][SL]
+    double* red;         // [G * SL]
+    double* partC;       // [G][4]: chi2, scale, (workgroup 0: stop flag), -
+    unsigned* flags;     // [G] epoch of the workgroup's latest publication, [G] = error word
+};
+
+struct PersistLds {      // offsets in doubles into the dynamic LDS block
+    int Yt, U, usz, out, x, bp, bs, bsp, wv, pose, poseR, red, sc, fxchi, fxact_bytes, pair_bytes, flag_bytes, total_bytes;
+};
+template <int NF>
+__host__ __device__ inline PersistLds persist_lds(int krows, int n, int max_fix) {
+    constexpr int NP = 6 * NF, YS = NP + 2, NT = (NP / 16) * (NP / 16 + 1) / 2;
+    PersistLds o;
+    int a = 0;
+    o.Yt = a; a += krows * YS;
+    o.U = a;
+    o.usz = (n + 1) * (n + 1) + 2 * 121 * 6;
+    if (o.usz < NT * 256 * 2) o.usz = NT * 256 * 2;
+    if (o.usz < kPWaves * NF * 27) o.usz = kPWaves * NF * 27;
+    if (o.usz < 2048) o.usz = 2048;
+    a += o.usz;
+    o.out = a; a += NF * 27 + NP + 4;
+    o.x = a; a += NP; o.bp = a; a += NP; o.bs = a; a += NP;
+    o.bsp = a; a += kPWaves * NP;
+    o.wv = a; a += krows;
+    o.pose = a; a += 2 * NF * 7; o.poseR = a; a += 2 * NF * 12;
+    o.red = a; a += 16; o.sc = a; a += 8;
+    o.fxchi = a; a += max_fix;
+    o.fxact_bytes = a * 8;
+    int b = o.fxact_bytes + ((max_fix + 15) & ~15);
+    o.pair_bytes = b; b += NF * (NF + 1) / 2 * 4;
+    b = (b + 15) & ~15;
+    o.flag_bytes = b; b += 16;
+    o.total_bytes = b;
+    return o;
+}
+
+__device__ __forceinline__ void xst(double* a, double v) { __hip_atomic_store(a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double xld(const double* a) { return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 1/sqrt(x) to the last bit or two: v_rsq_f64 (~2^-23) + two Newton steps; x <= 0 / NaN gives NaN / inf, which the reduced
+// system's factorisation then reports as a failed solve (g2o: a singular D^-1 poisons Hschur and LDLT reports failure)
+__device__ __forceinline__ double rsqrt_nr(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x, r * r, 1.5);
+    r = r * fma(-0.5 * x, r * r, 1.5);
+    return r;
+}
+
+typedef double pmf4 __attribute__((ext_vector_type(4)));
+
+template <int NW>
+__device__ __forceinline__ double block_max_n(double v, double* s_red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = s_red[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) r = fmax(r, s_red[w]);
+    return r;
+}
+
+template <int NF>
+__global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims d, BAPersist q) {
+    uh_latency_critical();
+    static_assert(NF == 8, "lanes per landmark = padded number of free cameras");
+    constexpr int NP = 6 * NF, T = NP / 16, NT = T * (T + 1) / 2, YS = NP + 2;
+    constexpr int LG = NF == 8 ? 3 : 4;
+    static_assert(T == 3, "tile bookkeeping below is written for three tile columns");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = blockIdx.x;
+    const int n = d.n, ld = n + 1, nfree = d.nfree, npairs = nfree * (nfree + 1) / 2;
+    const PersistLds o = persist_lds<NF>(q.krows, n, q.max_fix);
+    double* const Yt = lds + o.Yt;
+    double* const U = lds + o.U;
+    double* const Mm = U;
+    double (*const s_w)[121][6] = reinterpret_cast<double (*)[121][6]>(U + (size_t)ld * ld);
+    double* const s_out = lds + o.out;
+    double* const s_x = lds + o.x;
+    double* const s_bp = lds + o.bp;
+    double* const s_bs = lds + o.bs;
+    double* const s_bsp = lds + o.bsp;
+    double* const s_wv = lds + o.wv;
+    double* const s_pose = lds + o.pose;
+    double* const s_poseR = lds + o.poseR;
+    double* const s_red = lds + o.red;
+    double* const s_sc = lds + o.sc;
+    double* const s_fxchi = lds + o.fxchi;
+    unsigned char* const s_fxact = reinterpret_cast<unsigned char*>(lds) + o.fxact_bytes;
+    short (*const s_pair)[2] = reinterpret_cast<short (*)[2]>(reinterpret_cast<unsigned char*>(lds) + o.pair_bytes);
+    int* const s_flag = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + o.flag_bytes);   // [0] solve ok, [1] error
+
+    const int G = q.G, SL = q.SL;
+    constexpr int OFF_CAM = NT * 256, OFF_BS = OFF_CAM + NF * 27, OFF_SC = OFF_BS + NP;   // element offsets of a partial
+    const int l0 = g * q.Lw;
+    const int nl = min(q.Lw, d.P - l0);
+    const int ll = tid >> LG, s = tid & (NF - 1);
+    const bool live = ll < nl;
+    const int l = live ? l0 + ll : l0;
+    const int fb = q.fx_ptr[l0], fe = q.fx_ptr[l0 + nl];   // this workgroup's fixed-camera observations
+
+    // ---- lane-resident constants and state
+    int eid = -1;
+    if (live && s < nfree) eid = q.fe_id[(size_t)l * NF + s];
+    const bool has = eid >= 0;
+    double ou = 0, ov = 0, ow = 0, fxk = 1, fyk = 1, cxk = 0, cyk = 0;
+    if (has) { const double2 t = q.fe_uv[(size_t)l * NF + s]; ou = t.x; ov = t.y; ow = q.fe_w[(size_t)l * NF + s]; }
+    if (s < nfree) { const int k = p.free_kf[s]; fxk = p.intr[4 * k]; fyk = p.intr[4 * k + 1]; cxk = p.intr[4 * k + 2]; cyk = p.intr[4 * k + 3]; }
+    bool act = has;
+    double chi_e = 0;
+    double X[3] = {0, 0, 1}, Xt[3] = {0, 0, 1};
+    if (live) { X[0] = q.pts0[3 * (size_t)l]; X[1] = q.pts0[3 * (size_t)l + 1]; X[2] = q.pts0[3 * (size_t)l + 2]; }
+    double ci00 = 0, ci11 = 0, ci22 = 0, cl10 = 0, cl20 = 0, cl21 = 0, wl0 = 0, wl1 = 0, wl2 = 0, bl0 = 0, bl1 = 0, bl2 = 0;
+    bool any_pt = false;
+
+    for (int i = tid; i < q.krows * YS; i += kPThreads) Yt[i] = 0.0;
+    for (int i = tid; i < q.krows; i += kPThreads) s_wv[i] = 0.0;
+    for (int i = fb + tid; i < fe; i += kPThreads) { s_fxact[i - fb] = 1; s_fxchi[i - fb] = 0.0; }
+    if (tid < nfree) {
+        const int k = p.free_kf[tid];
+        for (int b = 0; b < 2; b++) {
+            for (int j = 0; j < 7; j++) s_pose[(b * NF + tid) * 7 + j] = q.pose0[7 * k + j];
+            for (int j = 0; j < 12; j++) s_poseR[(b * NF + tid) * 12 + j] = q.poseR0[12 * k + j];
+        }
+    }
+    for (int t = tid; t < npairs; t += kPThreads) {
+        int s1 = 0, rem = t;
+        while (rem >= nfree - s1) { rem -= nfree - s1; ++s1; }
+        s_pair[t][0] = (short)s1; s_pair[t][1] = (short)(s1 + rem);
+    }
+    if (tid == 0) { s_flag[0] = 1; s_flag[1] = 0; }
+    __syncthreads();
+
+    unsigned ep = 0;
+    auto publish = [&]() {
+        ++ep;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(q.flags + g, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto wait_all = [&]() -> bool {   // one wave polls the G epoch words; false: a workgroup never arrived (error word set)
+        if (wv == 0) {
+            const long long t0 = wall_clock64();
+            bool fail = false;
+            for (;;) {
+                bool ok = true;
+                for (int h = lane; h < G; h += 64)
+                    ok = ok && (int)(__hip_atomic_load(q.flags + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ep) >= 0;
+                if (__all(ok)) break;
+                if (__hip_atomic_load(q.flags + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > kPTimeoutTicks) { fail = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (fail && lane == 0) { s_flag[1] = 1; __hip_atomic_store(q.flags + G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        }
+        __syncthreads();
+        return s_flag[1] == 0;
+    };
+    auto part_addr = [&](int i) -> double* { const int sl = i / SL; return q.part + ((size_t)sl * G + g) * SL + (i - sl * SL); };
+
+    BAState st;
+    memset(&st, 0, sizeof(st));
+    st.phase = 2; st.lambda = -1; st.ni = 2;
+    bool robust = true;
+    double chi_lin_pass = 0;
+
+    // ================================================================================ phase 1: linearise + Schur partial
+    // first == true: the pass's opening evaluation at the current estimate (computeActiveErrors + computeLambdaInit): chi2 of
+    // every observation is recorded, the reduced-system product is skipped.
+    auto phase1 = [&](double lambda, bool first) {
+        const int cur = st.cur;
+        double acc[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) acc[i] = 0;
+        double hp[27];
+#pragma unroll
+        for (int i = 0; i < 27; i++) hp[i] = 0;
+        double H[18];
+#pragma unroll
+        for (int i = 0; i < 18; i++) H[i] = 0;
+        bool any = false;
+        const bool on = has && act;
+        if (on) {
+            EdgeLin L;
+            edge_eval_v<true>(ou, ov, ow, fxk, fyk, cxk, cyk, d.delta, d.dsqr, s_poseR + (cur * NF + s) * 12, X, robust, L);
+            any = true;
+            if (first) chi_e = L.chi2;
+            acc[9] = L.robchi;
+            acc[0] = L.ww * (L.A[0] * L.A[0] + L.A[3] * L.A[3]); acc[1] = L.ww * (L.A[0] * L.A[1] + L.A[3] * L.A[4]);
+            acc[2] = L.ww * (L.A[0] * L.A[2] + L.A[3] * L.A[5]); acc[3] = L.ww * (L.A[1] * L.A[1] + L.A[4] * L.A[4]);
+            acc[4] = L.ww * (L.A[1] * L.A[2] + L.A[4] * L.A[5]); acc[5] = L.ww * (L.A[2] * L.A[2] + L.A[5] * L.A[5]);
+            acc[6] = L.A[0] * L.r0 + L.A[3] * L.r1; acc[7] = L.A[1] * L.r0 + L.A[4] * L.r1; acc[8] = L.A[2] * L.r0 + L.A[5] * L.r1;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) H[a * 3 + c] = L.ww * (L.B[a] * L.A[c] + L.B[6 + a] * L.A[3 + c]);
+            int qq = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int c = a; c < 6; c++) hp[qq++] = L.ww * (L.B[a] * L.B[c] + L.B[6 + a] * L.B[6 + c]);
+#pragma unroll
+            for (int a = 0; a < 6; a++) hp[21 + a] = L.B[a] * L.r0 + L.B[6 + a] * L.r1;
+        }
+        // camera-side sums (Hpp upper triangle, bp) over this wave's landmarks: butterfly over the landmark bits of the lane index
+#pragma unroll
+        for (int i = 0; i < 27; i++) {
+#pragma unroll
+            for (int oo = NF; oo < 64; oo <<= 1) hp[i] += __shfl_xor(hp[i], oo);
+        }
+        if (lane < NF) {
+#pragma unroll
+            for (int i = 0; i < 27; i++) U[(wv * NF + s) * 27 + i] = hp[i];
+        }
+        if (live) {   // observations by fixed cameras: Hll, bl and chi2 only
+            for (int i = q.fx_ptr[l] + s; i < q.fx_ptr[l + 1]; i += NF) {
+                if (!s_fxact[i - fb]) continue;
+                any = true;
+                const int k = q.fx_kf[i];
+                const double2 uv = q.fx_uv[i];
+                EdgeLin L;
+                edge_eval_v<true>(uv.x, uv.y, q.fx_w[i], p.intr[4 * k], p.intr[4 * k + 1], p.intr[4 * k + 2], p.intr[4 * k + 3], d.delta, d.dsqr,
+                                  q.poseR0 + 12 * k, X, robust, L);
+                if (first) s_fxchi[i - fb] = L.chi2;
+                acc[9] += L.robchi;
+                acc[0] += L.ww * (L.A[0] * L.A[0] + L.A[3] * L.A[3]); acc[1] += L.ww * (L.A[0] * L.A[1] + L.A[3] * L.A[4]);
+                acc[2] += L.ww * (L.A[0] * L.A[2] + L.A[3] * L.A[5]); acc[3] += L.ww * (L.A[1] * L.A[1] + L.A[4] * L.A[4]);
+                acc[4] += L.ww * (L.A[1] * L.A[2] + L.A[4] * L.A[5]); acc[5] += L.ww * (L.A[2] * L.A[2] + L.A[5] * L.A[5]);
+                acc[6] += L.A[0] * L.r0 + L.A[3] * L.r1; acc[7] += L.A[1] * L.r0 + L.A[4] * L.r1; acc[8] += L.A[2] * L.r0 + L.A[5] * L.r1;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+#pragma unroll
+            for (int oo = NF / 2; oo > 0; oo >>= 1) acc[i] += __shfl_xor(acc[i], oo);
+        }
+        const unsigned long long anym = __ballot(any);
+        any_pt = ((anym >> (lane & ~(NF - 1))) & ((1ull << NF) - 1)) != 0;
+        bl0 = acc[6]; bl1 = acc[7]; bl2 = acc[8];
+        if (any_pt) {   // D = Hll + lambda I = L L^T
+            const double d00 = acc[0] + lambda, d11 = acc[3] + lambda, d22 = acc[5] + lambda;
+            ci00 = rsqrt_nr(d00);
+            cl10 = acc[1] * ci00; cl20 = acc[2] * ci00;
+            ci11 = rsqrt_nr(d11 - cl10 * cl10);
+            cl21 = (acc[4] - cl20 * cl10) * ci11;
+            ci22 = rsqrt_nr(d22 - cl20 * cl20 - cl21 * cl21);
+            wl0 = bl0 * ci00;
+            wl1 = (bl1 - cl10 * wl0) * ci11;
+            wl2 = (bl2 - cl20 * wl0 - cl21 * wl1) * ci22;
+        } else {
+            ci00 = ci11 = ci22 = cl10 = cl20 = cl21 = wl0 = wl1 = wl2 = 0;
+        }
+        if (3 * ll + 2 < q.krows) {   // whitened blocks Y_e = Hpl_e L^-T, transposed into the panel (zeros where there is no observation)
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                const double y0 = H[a * 3] * ci00;
+                const double y1 = (H[a * 3 + 1] - cl10 * y0) * ci11;
+                const double y2 = (H[a * 3 + 2] - cl20 * y0 - cl21 * y1) * ci22;
+                Yt[(3 * ll) * YS + 6 * s + a] = y0; Yt[(3 * ll + 1) * YS + 6 * s + a] = y1; Yt[(3 * ll + 2) * YS + 6 * s + a] = y2;
+            }
+            if (s == 0) { s_wv[3 * ll] = wl0; s_wv[3 * ll + 1] = wl1; s_wv[3 * ll + 2] = wl2; }
+        }
+        const double chi_part = (live && s == 0) ? acc[9] : 0.0;
+        const double maxd = (live && s == 0 && any_pt) ? fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5]))) : 0.0;
+        const double cs = block_sum<kPWaves>(chi_part, s_red);
+        const double mx = block_max_n<kPWaves>(maxd, s_red);   // (its barriers also publish Yt / s_wv / the camera sums)
+        if (tid < NF * 27) {
+            double r = U[tid];
+#pragma unroll
+            for (int w = 1; w < kPWaves; w++) r += U[w * NF * 27 + tid];
+            s_out[tid] = r;
+        }
+        if (tid == 0) { s_out[NF * 27 + NP] = cs; s_out[NF * 27 + NP + 1] = 0; s_out[NF * 27 + NP + 2] = mx; s_out[NF * 27 + NP + 3] = 0; }
+        pmf4 c[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) c[t] = pmf4{0, 0, 0, 0};
+        const int kq = wv;   // k-steps kq, kq+4, ... of the product belong to this wave
+        if (!first) {
+            // b_schur partial: Yt^T (L^-1 b_l), rows split over the waves
+            if (lane < NP) {
+                double r = 0;
+                for (int k = wv; k < 3 * nl; k += kPWaves) r = fma(Yt[k * YS + lane], s_wv[k], r);
+                s_bsp[wv * NP + lane] = r;
+            }
+            // S = Yt^T Yt, upper tiles (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+            const int nks = q.krows >> 2;
+            const int col = lane & 15, kr = lane >> 4;
+            if (q.use_mfma) {
+                for (int ks = kq; ks < nks; ks += kPWaves) {
+                    const double* row = Yt + (4 * ks + kr) * YS + col;
+                    const double y0 = row[0], y1 = row[16], y2 = row[32];
+                    c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, y0, c[0], 0, 0, 0);
+                    c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, y1, c[1], 0, 0, 0);
+                    c[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, y2, c[2], 0, 0, 0);
+                    c[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, y1, c[3], 0, 0, 0);
+                    c[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, y2, c[4], 0, 0, 0);
+                    c[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(y2, y2, c[5], 0, 0, 0);
+                }
+            } else {
+                // vector-FMA form of the same tiles in the same register layout: lane (col, kr) owns rows kr, kr+4, kr+8, kr+12
+                for (int ks = kq; ks < nks; ks += kPWaves) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        const double* row = Yt + (4 * ks + kk) * YS;
+                        const double b0 = row[col], b1 = row[16 + col], b2 = row[32 + col];
+#pragma unroll
+                        for (int v = 0; v < 4; v++) {
+                            const double a0 = row[kr + 4 * v], a1 = row[16 + kr + 4 * v], a2 = row[32 + kr + 4 * v];
+                            c[0][v] = fma(a0, b0, c[0][v]); c[1][v] = fma(a0, b1, c[1][v]); c[2][v] = fma(a0, b2, c[2][v]);
+                            c[3][v] = fma(a1, b1, c[3][v]); c[4][v] = fma(a1, b2, c[4][v]); c[5][v] = fma(a2, b2, c[5][v]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();   // camera sums read, Yt reads of the product done: U is free for the tile reduction
+        if (!first) {
+            if (tid < NP) {
+                double r = s_bsp[tid];
+#pragma unroll
+                for (int w = 1; w < kPWaves; w++) r += s_bsp[w * NP + tid];
+                s_out[NF * 27 + tid] = r;
+            }
+            // (k0 + k2) + (k1 + k3), fixed order; element index of (tile t, lane, v) = (t*64 + lane)*4 + v
+            if (kq >= 2) {
+                double* u = U + (kq - 2) * (NT * 256) + lane * 4;
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) u[t * 256 + v] = c[t][v];
+            }
+            __syncthreads();
+            if (kq < 2) {
+                const double* u = U + kq * (NT * 256) + lane * 4;
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) c[t][v] += u[t * 256 + v];
+            }
+            __syncthreads();
+            if (kq == 1) {
+                double* u = U + lane * 4;
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) u[t * 256 + v] = c[t][v];
+            }
+            __syncthreads();
+            if (kq == 0) {
+                const double* u = U + lane * 4;
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int v = 0; v < 4; v++) xst(part_addr(t * 256 + lane * 4 + v), c[t][v] + u[t * 256 + v]);
+            }
+        }
+        __syncthreads();   // s_out complete
+        for (int i = tid; i < NF * 27 + NP + 4; i += kPThreads) xst(part_addr(OFF_CAM + i), s_out[i]);
+    };
+
+    // ================================================================================ exchange A -> B: slice-wise reduction
+    auto reduce_slices = [&]() -> bool {
+        publish();
+        if (!wait_all()) return false;
+        UH_BA_CLK(50);
+        const int HG = G < 16 ? G : 16;
+        const double* src = q.part + (size_t)g * G * SL;
+        for (int idx = tid; idx < SL * HG; idx += kPThreads) {
+            const int hg = idx / SL, e = idx - hg * SL;
+            const bool is_max = g * SL + e == OFF_SC + 2;
+            double r = xld(src + (size_t)hg * SL + e);
+            for (int h = hg + HG; h < G; h += 4 * HG) {   // four loads in flight, added in ascending order
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = h + u * HG < G ? xld(src + (size_t)(h + u * HG) * SL + e) : (is_max ? r : 0.0);
+#pragma unroll
+                for (int u = 0; u < 4; u++) r = is_max ? fmax(r, v[u]) : r + v[u];
+            }
+            U[idx] = r;
+        }
+        __syncthreads();
+        for (int e = tid; e < SL; e += kPThreads) {
+            const bool is_max = g * SL + e == OFF_SC + 2;
+            double r = U[e];
+            for (int hg = 1; hg < HG; hg++) { const double v = U[hg * SL + e]; r = is_max ? fmax(r, v) : r + v; }
+            xst(q.red + (size_t)g * SL + e, r);
+        }
+        UH_BA_CLK(51);
+        publish();
+        return wait_all();
+    };
+
+    for (int pass = 0; pass < 2; pass++) {
+        // ---- begin_pass (legacy ba_begin_pass_kernel / ba_gate_kernel / ba_relabel_kernel)
+        if (pass == 1) {
+            if (st.stopped) break;
+            st.gate = 1;
+            st.iters_pass1 = st.iters_done;
+            // globaloptimizer_g2o.cpp:434-449: chi2 > 5.99 or non-positive depth -> level 1; every robust kernel dropped
+            if (has) {
+                const double* Rt = s_poseR + (st.cur * NF + s) * 12;
+                const double z = Rt[6] * X[0] + Rt[7] * X[1] + Rt[8] * X[2] + Rt[11];
+                if (chi_e > d.chi2_th || !(z > 0.0)) act = false;
+            }
+            if (live) {
+                for (int i = q.fx_ptr[l] + s; i < q.fx_ptr[l + 1]; i += NF) {
+                    const double* Rt = q.poseR0 + 12 * q.fx_kf[i];
+                    const double z = Rt[6] * X[0] + Rt[7] * X[1] + Rt[8] * X[2] + Rt[11];
+                    if (s_fxchi[i - fb] > d.chi2_th || !(z > 0.0)) s_fxact[i - fb] = 0;
+                }
+            }
+            robust = false;
+            __syncthreads();
+        }
+        const int max_iters = pass == 0 ? q.n1 : q.n2;
+        st.pending = 0; st.stop_seen = 0;
+        st.phase = max_iters > 0 ? 0 : 2;
+        st.iteration = 0; st.max_iters = max_iters; st.qmax = 0; st.solve_ok = 1; st.first_trial = 1; st.iters_done = 0;
+        st.prevChi2 = FLT_MAX; st.curChi2 = FLT_MAX; st.minChi2 = q.minChi2;
+        if (pass == 0 && q.stop_at_begin) { st.phase = 2; st.stopped = 1; }
+        if (st.phase == 2) continue;
+
+        // ---- opening evaluation: chi2 at the current estimate, lambda = tau * max |H_jj| (computeLambdaInit)
+        phase1(1.0, true);
+        if (!reduce_slices()) return;
+        {   // every wave for itself: one diagonal entry of Hpp per lane, max butterfly
+            double m = lane == 0 ? xld(q.red + OFF_SC + 2) : 0.0;
+            for (int i = lane; i < n; i += 64) {
+                const int sc = i / 6, a = i - 6 * sc;
+                m = fmax(m, fabs(xld(q.red + OFF_CAM + sc * 27 + (a * 6 - a * (a - 1) / 2))));   // diagonal of the 21-entry upper triangle
+            }
+            chi_lin_pass = xld(q.red + OFF_SC);
+#pragma unroll
+            for (int oo = 32; oo > 0; oo >>= 1) m = fmax(m, __shfl_xor(m, oo));
+            st.lambda = 1e-5 * m; st.ni = 2;
+        }
+
+        while (st.phase != 2) {
+            const double lambda = st.lambda;
+            const int cur = st.cur, trial = cur ^ 1;
+            UH_BA_CLK(40);
+            phase1(lambda, false);
+            UH_BA_CLK(41);
+            if (!reduce_slices()) return;
+            UH_BA_CLK(42);
+            // ---- assemble S = Hpp + lambda I - Yt^T Yt (lower triangle, bordered with b = bp - b_schur), factorise, substitute
+            for (int base = 0; base < q.nelem; base += 4 * kPThreads) {
+            double rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) rv[u] = base + tid + u * kPThreads < q.nelem ? xld(q.red + base + tid + u * kPThreads) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = base + tid + u * kPThreads;
+                const double v = rv[u];
+                if (idx >= q.nelem) continue;
+                if (idx < OFF_CAM) {
+                    const int ti = idx >> 8, lq = (idx >> 2) & 63, vv = idx & 3;
+                    const int tm = ti < 3 ? 0 : (ti < 5 ? 1 : 2), tn = ti < 3 ? ti : (ti < 5 ? ti - 2 : 2);
+                    const int row = 16 * tm + (lq >> 4) + 4 * vv, col = 16 * tn + (lq & 15);
+                    if (row <= col && col < n) Mm[col * ld + row] = -v;
+                } else if (idx < OFF_BS) s_out[idx - OFF_CAM] = v;
+                else if (idx < OFF_SC) s_bs[idx - OFF_BS] = v;
+            }
+            }
+            __syncthreads();
+            if (tid < nfree * 21) {
+                const int sc = tid / 21, qq = tid - 21 * sc;
+                int a = 0, rem = qq;
+                while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+                const int c = a + rem;
+                Mm[(6 * sc + c) * ld + 6 * sc + a] += s_out[sc * 27 + qq] + (a == c ? lambda : 0.0);
+            }
+            if (tid < n) {
+                const int sc = tid / 6, a = tid - 6 * sc;
+                const double bpv = s_out[sc * 27 + 21 + a];
+                s_bp[tid] = bpv;
+                Mm[(size_t)n * ld + tid] = bpv - s_bs[tid];
+            }
+            if (tid == 0) s_flag[0] = 1;
+            __syncthreads();
+            UH_BA_CLK(43);
+            const bool failed = ldlt_bordered_lds(Mm, n, ld, nfree, npairs, s_pair, s_w);
+            if (failed && tid == 0) s_flag[0] = 0;
+            __syncthreads();
+            UH_BA_CLK(44);
+            const int ok = s_flag[0];
+            if (ok) backsolve_lds(Mm, n, ld, s_x);
+            else for (int i = tid; i < n; i += kPThreads) s_x[i] = 0.0;
+            __syncthreads();
+            UH_BA_CLK(45);
+            if (wv == 0) {   // computeScale's pose part: sum x (lambda x + b)
+                double xs = 0;
+                for (int i = lane; i < n; i += 64) { const double x = s_x[i]; xs += x * (lambda * x + s_bp[i]); }
+                xs = wave_sum_fixed(xs);
+                if (lane == 0) s_sc[0] = xs;
+            }
+            if (wv == 1 && lane < nfree) {   // T_trial = exp(dx) T_cur
+                const double* Tc = s_pose + (cur * NF + lane) * 7;
+                double qv[4] = {Tc[0], Tc[1], Tc[2], Tc[3]}, tv[3] = {Tc[4], Tc[5], Tc[6]};
+                if (ok) se3_left_update(qv, tv, s_x + 6 * lane);
+                double* To = s_pose + (trial * NF + lane) * 7;
+                To[0] = qv[0]; To[1] = qv[1]; To[2] = qv[2]; To[3] = qv[3]; To[4] = tv[0]; To[5] = tv[1]; To[6] = tv[2];
+                double Rn[9];
+                quat_to_R(qv, Rn);
+                double* Ro = s_poseR + (trial * NF + lane) * 12;
+#pragma unroll
+                for (int i = 0; i < 9; i++) Ro[i] = Rn[i];
+                Ro[9] = tv[0]; Ro[10] = tv[1]; Ro[11] = tv[2];
+            }
+            // ---- back-substitution: dx_l = L^-T (L^-1 b_l - Y_l^T dx_p)
+            double t0 = 0, t1 = 0, t2 = 0;
+            if (3 * ll + 2 < q.krows) {
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+                    const double xa = s_x[6 * s + a];
+                    t0 = fma(Yt[(3 * ll) * YS + 6 * s + a], xa, t0);
+                    t1 = fma(Yt[(3 * ll + 1) * YS + 6 * s + a], xa, t1);
+                    t2 = fma(Yt[(3 * ll + 2) * YS + 6 * s + a], xa, t2);
+                }
+            }
+#pragma unroll
+            for (int oo = NF / 2; oo > 0; oo >>= 1) { t0 += __shfl_xor(t0, oo); t1 += __shfl_xor(t1, oo); t2 += __shfl_xor(t2, oo); }
+            double scale_part = 0;
+            Xt[0] = X[0]; Xt[1] = X[1]; Xt[2] = X[2];
+            if (live && any_pt && ok) {
+                const double r0 = wl0 - t0, r1 = wl1 - t1, r2 = wl2 - t2;
+                const double x2 = r2 * ci22;
+                const double x1 = (r1 - cl21 * x2) * ci11;
+                const double x0 = (r0 - cl10 * x1 - cl20 * x2) * ci00;
+                if (s == 0) scale_part = x0 * (lambda * x0 + bl0) + x1 * (lambda * x1 + bl1) + x2 * (lambda * x2 + bl2);
+                Xt[0] += x0; Xt[1] += x1; Xt[2] += x2;
+            }
+            __syncthreads();   // trial poses complete
+            UH_BA_CLK(46);
+            // ---- trial errors (computeActiveErrors at the trial estimate)
+            double chi_part = 0;
+            if (has && act) {
+                EdgeLin L;
+                edge_eval_v<false>(ou, ov, ow, fxk, fyk, cxk, cyk, d.delta, d.dsqr, s_poseR + (trial * NF + s) * 12, Xt, robust, L);
+                chi_e = L.chi2;
+                chi_part = L.robchi;
+            }
+            if (live) {
+                for (int i = q.fx_ptr[l] + s; i < q.fx_ptr[l + 1]; i += NF) {
+                    if (!s_fxact[i - fb]) continue;
+                    const int k = q.fx_kf[i];
+                    const double2 uv = q.fx_uv[i];
+                    EdgeLin L;
+                    edge_eval_v<false>(uv.x, uv.y, q.fx_w[i], p.intr[4 * k], p.intr[4 * k + 1], p.intr[4 * k + 2], p.intr[4 * k + 3], d.delta, d.dsqr,
+                                       q.poseR0 + 12 * k, Xt, robust, L);
+                    s_fxchi[i - fb] = L.chi2;
+                    chi_part += L.robchi;
+                }
+            }
+            const double cs = block_sum<kPWaves>(chi_part, s_red);
+            const double ss = block_sum<kPWaves>(scale_part, s_red);
+            if (tid == 0) {
+                xst(q.partC + 4 * g, cs); xst(q.partC + 4 * g + 1, ss);
+                if (g == 0) xst(q.partC + 2, (p.stop && *p.stop) ? 1.0 : 0.0);
+            }
+            UH_BA_CLK(47);
+            publish();
+            if (!wait_all()) return;
+            UH_BA_CLK(48);
+            // ---- decision (every wave of every workgroup, same inputs, same code)
+            {
+                double c = 0, sc = 0;
+                for (int h = lane; h < G; h += 64) { c += xld(q.partC + 4 * h); sc += xld(q.partC + 4 * h + 1); }
+                DecideSums sm;
+                sm.lin = chi_lin_pass; sm.chi = wave_sum_fixed(c); sm.scale = wave_sum_fixed(sc); sm.xs = s_sc[0];
+                const bool stopv = xld(q.partC + 2) != 0.0;
+                st.solve_ok = ok;
+                st.pending = 1;
+                st = apply_decision(st, sm, stopv);
+                if (st.cur != cur) { X[0] = Xt[0]; X[1] = Xt[1]; X[2] = Xt[2]; }
+            }
+            UH_BA_CLK(49);
+        }
+    }
+
+    // ================================================================================ results into the legacy buffers (slot 0)
+    if (live && s == 0) { double* o3 = p.pts[0] + 3 * (size_t)l; o3[0] = X[0]; o3[1] = X[1]; o3[2] = X[2]; }
+    if (has) p.e_chi2[eid] = chi_e;
+    for (int i = fb + tid; i < fe; i += kPThreads) p.e_chi2[q.fx_id[i]] = s_fxchi[i - fb];
+    if (g == 0) {
+        for (int k = tid; k < d.K; k += kPThreads) {
+            const int sl = p.slot[k];
+            for (int j = 0; j < 7; j++) p.pose[0][7 * k + j] = sl >= 0 ? s_pose[(st.cur * NF + sl) * 7 + j] : q.pose0[7 * k + j];
+            for (int j = 0; j < 12; j++) p.poseR[0][12 * k + j] = sl >= 0 ? s_poseR[(st.cur * NF + sl) * 12 + j] : q.poseR0[12 * k + j];
+        }
+        if (tid == 0) { BAState fin = st; fin.cur = 0; fin.pending = 0; p.st[0] = fin; p.st[1] = fin; }
+    }
+}
