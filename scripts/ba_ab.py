@@ -22,9 +22,9 @@ for K, P, seed, nfix in cfgs:
     pr = synth.ba_problem(K, P, seed, nfixed=nfix)
     ref = oracle_lib.ba_optimize(O, pr, 5)
     out = {}
-    for form in ("persist", "persist-valu", "legacy"):
+    for form in ("persist", "persist-mfma", "legacy"):
         os.environ["UH_BA_FORM"] = "legacy" if form == "legacy" else "persist"
-        os.environ["UH_BA_SCHUR"] = "valu" if form == "persist-valu" else "mfma"
+        os.environ["UH_BA_SCHUR"] = "mfma" if form == "persist-mfma" else "valu"
         opt = GlobalOptimizer.create(ctx)
         opt.setParams(pr, ParamSet(nIters=5))
         try:
@@ -47,5 +47,6 @@ for K, P, seed, nfix in cfgs:
             us = lambda a, b: (clk[b] - clk[a]) / 100.0
             print(f"    last trial: phase1 {us(40,41):.2f} | A+slices+B {us(41,42):.2f} (wait A {us(41,50):.2f}, slice {us(50,51):.2f}, wait B {us(51,42):.2f}) | assemble {us(42,43):.2f} | factor {us(43,44):.2f} "
                   f"| backsolve {us(44,45):.2f} | pose+backsub {us(45,46):.2f} | errors {us(46,47):.2f} | C {us(47,48):.2f} | decide {us(48,49):.2f} | total {us(40,49):.2f} us")
+            print(f"    phase1: edges {us(40,52):.2f} | butterfly+chol+Y {us(52,53):.2f} | block sums+camsum {us(53,54):.2f} | product+stores {us(54,55):.2f} | tail {us(55,41):.2f}")
     if "persist" in out and "legacy" in out:
         print(f"    persist vs legacy |state| {np.abs(out['persist']['state']-out['legacy']['state']).max():.2e}")

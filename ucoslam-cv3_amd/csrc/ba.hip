@@ -1902,9 +1902,12 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
             q.nelem = 6 * 256 + NF * 27 + 6 * NF + 4;
             q.SL = (uh_div_up(q.nelem, G) + 1) & ~1;
             const char* sch = getenv("UH_BA_SCHUR");
-            q.use_mfma = !(sch && std::string(sch) == "valu");
+            q.use_mfma = (sch && std::string(sch) == "mfma") ? 1 : 0;   // default: register-blocked vector FMA (faster on gfx950)
             std::vector<double> h_uv(2 * (size_t)P * NF, 0.0), h_w((size_t)P * NF, 0.0), hx_uv, hx_w, h_R0(12 * (size_t)K);
             std::vector<int> h_id((size_t)P * NF, -1), hx_ptr(P + 1, 0), hx_kf, hx_id;
+            std::vector<int> fix_slot(K, -1), fix_kf;   // fixed frames that observe something, in frame order
+            for (int e = 0; e < E; e++) if (slot[pr->obs_frame[e]] < 0) fix_slot[pr->obs_frame[e]] = 0;
+            for (int k = 0; k < K; k++) if (fix_slot[k] == 0) { fix_slot[k] = (int)fix_kf.size(); fix_kf.push_back(k); }
             for (int pt = 0; pt < P; pt++) {
                 for (int i = pt_ptr[pt]; i < pt_ptr[pt + 1]; i++) {
                     const int e = pt_edges[i], sl = slot[pr->obs_frame[e]];
@@ -1913,7 +1916,7 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
                         h_id[at] = e; h_uv[2 * at] = uv[2 * e]; h_uv[2 * at + 1] = uv[2 * e + 1]; h_w[at] = w[e];
                     } else {
                         hx_uv.push_back(uv[2 * e]); hx_uv.push_back(uv[2 * e + 1]); hx_w.push_back(w[e]);
-                        hx_kf.push_back(pr->obs_frame[e]); hx_id.push_back(e);
+                        hx_kf.push_back(fix_slot[pr->obs_frame[e]]); hx_id.push_back(e);
                     }
                 }
                 hx_ptr[pt + 1] = (int)hx_id.size();
@@ -1921,6 +1924,7 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
             int max_fix = 0;
             for (int g = 0; g < G; g++) max_fix = std::max(max_fix, hx_ptr[std::min(P, (g + 1) * Lw)] - hx_ptr[g * Lw]);
             q.max_fix = max_fix;
+            q.kfix = (int)fix_kf.size();
             for (int k = 0; k < K; k++) {   // R | t of the snapshot, from the normalised quaternion like the legacy init kernel
                 const double* qq = &pose0[7 * k];
                 double* R = &h_R0[12 * k];
@@ -1933,13 +1937,13 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
                 R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
                 R[9] = pose0[7 * k + 4]; R[10] = pose0[7 * k + 5]; R[11] = pose0[7 * k + 6];
             }
-            const PersistLds lay = persist_lds<NF>(q.krows, d.n, max_fix);
-            if (lay.total_bytes <= 160 * 1024) {
+            const PersistLds lay = persist_lds<NF>(q.krows, d.n, max_fix, q.kfix);
+            if (lay.total_bytes <= 160 * 1024 && q.kfix <= 255) {
                 Arena PA;
                 const size_t nfx = hx_id.size();
                 const size_t o_fuv = PA.take<double>(2 * (size_t)P * NF), o_fw = PA.take<double>((size_t)P * NF), o_fid = PA.take<int>((size_t)P * NF);
                 const size_t o_xp = PA.take<int>(P + 1), o_xuv = PA.take<double>(2 * nfx + 2), o_xw = PA.take<double>(nfx + 1), o_xkf = PA.take<int>(nfx + 1), o_xid = PA.take<int>(nfx + 1);
-                const size_t o_R0 = PA.take<double>(12 * (size_t)K);
+                const size_t o_R0 = PA.take<double>(12 * (size_t)K), o_fixkf = PA.take<int>(fix_kf.size() + 1);
                 const size_t o_part = PA.take<double>((size_t)G * G * q.SL), o_red = PA.take<double>((size_t)G * q.SL), o_pc = PA.take<double>(4 * (size_t)G), o_fl = PA.take<unsigned>(G + 1);
                 if ((rc = b->parena.reserve(PA.off + 256))) return rc;
                 char* pb = b->parena.as<char>();
@@ -1956,11 +1960,12 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
                 if ((rc = pup(o_xkf, hx_kf.data(), hx_kf.size() * 4))) return rc;
                 if ((rc = pup(o_xid, hx_id.data(), hx_id.size() * 4))) return rc;
                 if ((rc = pup(o_R0, h_R0.data(), h_R0.size() * 8))) return rc;
+                if ((rc = pup(o_fixkf, fix_kf.data(), fix_kf.size() * 4))) return rc;
                 UH_HIP_CHECK(hipStreamSynchronize(st));   // the staging vectors of this block die here
                 q.fe_uv = (const double2*)(pb + o_fuv); q.fe_w = (const double*)(pb + o_fw); q.fe_id = (const int*)(pb + o_fid);
                 q.fx_ptr = (const int*)(pb + o_xp); q.fx_uv = (const double2*)(pb + o_xuv); q.fx_w = (const double*)(pb + o_xw);
                 q.fx_kf = (const int*)(pb + o_xkf); q.fx_id = (const int*)(pb + o_xid);
-                q.poseR0 = (const double*)(pb + o_R0);
+                q.poseR0 = (const double*)(pb + o_R0); q.fix_kf = (const int*)(pb + o_fixkf);
                 q.pose0 = (const double*)(base + o_pose0); q.pts0 = (const double*)(base + o_pts0);
                 q.part = (double*)(pb + o_part); q.red = (double*)(pb + o_red); q.partC = (double*)(pb + o_pc); q.flags = (unsigned*)(pb + o_fl);
                 b->p_lds = lay.total_bytes;

@@ -27,11 +27,12 @@ constexpr int kPWaves = kPThreads / 64;
 constexpr long long kPTimeoutTicks = 300000000ll;   // 3 s of the 100 MHz wall clock: a workgroup that never arrives
 
 struct BAPersist {
-    int G, Lw, krows, SL, nelem, max_fix;
+    int G, Lw, krows, SL, nelem, max_fix, kfix;
     int n1, n2, stop_at_begin, use_mfma;
     float minChi2;
     const double2* fe_uv; const double* fe_w; const int* fe_id;          // P x NF: the free cameras' observations, by (landmark, slot)
-    const int* fx_ptr; const double2* fx_uv; const double* fx_w; const int* fx_kf; const int* fx_id;   // CSR of fixed-camera observations
+    const int* fx_ptr; const double2* fx_uv; const double* fx_w; const int* fx_kf; const int* fx_id;   // CSR of fixed-camera observations (fx_kf: index into fix_kf)
+    const int* fix_kf;   // [kfix] frame index of every fixed frame that observes something
     const double* pose0; const double* poseR0; const double* pts0;       // K x 7, K x 12, P x 3: the snapshot taken by setParams
     double* part;        // [slice][workgroup][SL]
     double* red;         // [G * SL]
@@ -40,10 +41,10 @@ struct BAPersist {
 };
 
 struct PersistLds {      // offsets in doubles into the dynamic LDS block
-    int Yt, U, usz, out, x, bp, bs, bsp, wv, pose, poseR, red, sc, fxchi, fxact_bytes, pair_bytes, flag_bytes, total_bytes;
+    int Yt, U, usz, out, x, bp, bs, bsp, wv, pose, poseR, red, sc, fxchi, fxobs, fxcam, fxact_bytes, fxk_bytes, pair_bytes, blk_bytes, flag_bytes, total_bytes;
 };
 template <int NF>
-__host__ __device__ inline PersistLds persist_lds(int krows, int n, int max_fix) {
+__host__ __device__ inline PersistLds persist_lds(int krows, int n, int max_fix, int kfix) {
     constexpr int NP = 6 * NF, YS = NP + 2, NT = (NP / 16) * (NP / 16 + 1) / 2;
     PersistLds o;
     int a = 0;
@@ -51,7 +52,7 @@ __host__ __device__ inline PersistLds persist_lds(int krows, int n, int max_fix)
     o.U = a;
     o.usz = (n + 1) * (n + 1) + 2 * 121 * 6;
     if (o.usz < NT * 256 * 2) o.usz = NT * 256 * 2;
-    if (o.usz < kPWaves * NF * 27) o.usz = kPWaves * NF * 27;
+    if (o.usz < kPWaves * NF * 33) o.usz = kPWaves * NF * 33;
     if (o.usz < 2048) o.usz = 2048;
     a += o.usz;
     o.out = a; a += NF * 27 + NP + 4;
@@ -61,10 +62,14 @@ __host__ __device__ inline PersistLds persist_lds(int krows, int n, int max_fix)
     o.pose = a; a += 2 * NF * 7; o.poseR = a; a += 2 * NF * 12;
     o.red = a; a += 16; o.sc = a; a += 8;
     o.fxchi = a; a += max_fix;
+    o.fxobs = a; a += 3 * max_fix;
+    o.fxcam = a; a += 16 * kfix;
     o.fxact_bytes = a * 8;
     int b = o.fxact_bytes + ((max_fix + 15) & ~15);
+    o.fxk_bytes = b; b += (max_fix + 15) & ~15;
     o.pair_bytes = b; b += NF * (NF + 1) / 2 * 4;
     b = (b + 15) & ~15;
+    o.blk_bytes = b; b += 80 * 2;
     o.flag_bytes = b; b += 16;
     o.total_bytes = b;
     return o;
@@ -81,6 +86,90 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
     r = r * fma(-0.5 * x, r * r, 1.5);
     return r;
 }
+
+// Edge evaluation of the persistent form: EdgeSE3ProjectXYZ::computeError / linearizeOplus (typesg2o.h:260-314) with ONE reciprocal
+// (v_rcp_f64 + two Newton steps, ~1 ulp) where the reference divides nine times, and the Huber weight through one reciprocal
+// square root: the nine IEEE division sequences (~40 dependent instructions each) were 60 % of the linearisation phase.  The results
+// differ from the division form in the last bit or two (state after a whole BA: ~1e-15, against a stated tolerance of 1e-6).
+// JAC: 0 = error only, 1 = error + point Jacobian A (fixed cameras), 2 = error + A + pose Jacobian B.
+template <int JAC>
+__device__ __forceinline__ void edge_eval_p(double u, double v, double w, double fx, double fy, double cx, double cy, double delta, double dsqr,
+                                            const double* Rt, const double* X, bool robust, EdgeLin& o) {
+    const double x = Rt[0] * X[0] + Rt[1] * X[1] + Rt[2] * X[2] + Rt[9];
+    const double y = Rt[3] * X[0] + Rt[4] * X[1] + Rt[5] * X[2] + Rt[10];
+    const double z = Rt[6] * X[0] + Rt[7] * X[1] + Rt[8] * X[2] + Rt[11];
+    const double iz = fast_rcp(z);
+    const double xz = x * iz, yz = y * iz;
+    o.ex = u - (xz * fx + cx);
+    o.ey = v - (yz * fy + cy);
+    o.chi2 = w * (o.ex * o.ex + o.ey * o.ey);
+    o.rho1 = 1.0;
+    o.robchi = o.chi2;
+    if (robust && o.chi2 > dsqr) {
+        const double rs = rsqrt_nr(o.chi2);
+        o.rho1 = delta * rs;
+        o.robchi = 2 * (o.chi2 * rs) * delta - dsqr;
+    }
+    if (JAC >= 1) {
+        o.ww = o.rho1 * w;
+        o.r0 = -w * o.ex * o.rho1;
+        o.r1 = -w * o.ey * o.rho1;
+        const double fxz = fx * iz, fyz = fy * iz;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            o.A[c] = -fxz * (Rt[c] - xz * Rt[6 + c]);
+            o.A[3 + c] = -fyz * (Rt[3 + c] - yz * Rt[6 + c]);
+        }
+        if (JAC >= 2) {
+            o.B[0] = xz * yz * fx; o.B[1] = -(1 + xz * xz) * fx; o.B[2] = yz * fx; o.B[3] = -fxz; o.B[4] = 0; o.B[5] = xz * fxz;
+            o.B[6] = (1 + yz * yz) * fy; o.B[7] = -xz * yz * fy; o.B[8] = -xz * fy; o.B[9] = 0; o.B[10] = -fyz; o.B[11] = yz * fyz;
+        }
+    }
+}
+
+// chi2 sum + max (or two sums) over the workgroup with ONE pair of barriers: the two butterflies interleave
+template <int NW, bool SECOND_IS_MAX>
+__device__ __forceinline__ void block_reduce2(double& a, double& b, double* s_red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ta = __shfl_xor(a, o), tb = __shfl_xor(b, o);
+        a += ta;
+        b = SECOND_IS_MAX ? fmax(b, tb) : b + tb;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = a; s_red[8 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    double ra = s_red[0], rb = s_red[8];
+#pragma unroll
+    for (int w = 1; w < NW; w++) { ra += s_red[w]; rb = SECOND_IS_MAX ? fmax(rb, s_red[8 + w]) : rb + s_red[8 + w]; }
+    a = ra; b = rb;
+}
+
+// Butterfly TRANSPOSE over the lane bits 32 .. STOP (reduce.hpp's WaveTranspose stopped early): lanes that differ only in those bits
+// end up owning disjoint index ranges [off, off + real) of the N sums over their group — N-1-ish cross-lane moves instead of 3N.
+template <int N, int BIT, int STOP>
+struct PartTranspose {
+    static constexpr int H = (N + 1) / 2;
+    __device__ static __forceinline__ void run(double (&v)[N], int lane, int& off, int& real) {
+        const bool up = (lane & BIT) != 0;
+        double nv[H];
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            const double lo = v[i];
+            const double hi = (i + H < N) ? v[(i + H < N) ? i + H : 0] : 0.0;
+            const double keep = up ? hi : lo, send = up ? lo : hi;
+            nv[i] = keep + __shfl_xor(send, BIT);
+        }
+        if (up) { off += H; real = real - H > 0 ? real - H : 0; }
+        else real = real < H ? real : H;
+#pragma unroll
+        for (int i = 0; i < H; i++) v[i] = nv[i];
+        if constexpr (BIT > STOP) {
+            double (&w)[H] = reinterpret_cast<double (&)[H]>(v);
+            PartTranspose<H, BIT / 2, STOP>::run(w, lane, off, real);
+        }
+    }
+};
 
 typedef double pmf4 __attribute__((ext_vector_type(4)));
 
@@ -106,8 +195,9 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     static_assert(T == 3, "tile bookkeeping below is written for three tile columns");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = blockIdx.x;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);   // the wave index as a scalar: wave-uniform branches become s_cbranch
     const int n = d.n, ld = n + 1, nfree = d.nfree, npairs = nfree * (nfree + 1) / 2;
-    const PersistLds o = persist_lds<NF>(q.krows, n, q.max_fix);
+    const PersistLds o = persist_lds<NF>(q.krows, n, q.max_fix, q.kfix);
     double* const Yt = lds + o.Yt;
     double* const U = lds + o.U;
     double* const Mm = U;
@@ -123,8 +213,12 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     double* const s_red = lds + o.red;
     double* const s_sc = lds + o.sc;
     double* const s_fxchi = lds + o.fxchi;
+    double* const s_fxobs = lds + o.fxobs;     // [max_fix][3]: u, v, information scalar
+    double* const s_fxcam = lds + o.fxcam;     // [kfix][16]: R | t (12) and fx fy cx cy of the fixed frames
     unsigned char* const s_fxact = reinterpret_cast<unsigned char*>(lds) + o.fxact_bytes;
+    unsigned char* const s_fxk = reinterpret_cast<unsigned char*>(lds) + o.fxk_bytes;
     short (*const s_pair)[2] = reinterpret_cast<short (*)[2]>(reinterpret_cast<unsigned char*>(lds) + o.pair_bytes);
+    unsigned char (*const s_blk)[2] = reinterpret_cast<unsigned char (*)[2]>(reinterpret_cast<unsigned char*>(lds) + o.blk_bytes);   // 4x4 block -> (bi, bj)
     int* const s_flag = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + o.flag_bytes);   // [0] solve ok, [1] error
 
     const int G = q.G, SL = q.SL;
@@ -151,8 +245,16 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     bool any_pt = false;
 
     for (int i = tid; i < q.krows * YS; i += kPThreads) Yt[i] = 0.0;
-    for (int i = tid; i < q.krows; i += kPThreads) s_wv[i] = 0.0;
-    for (int i = fb + tid; i < fe; i += kPThreads) { s_fxact[i - fb] = 1; s_fxchi[i - fb] = 0.0; }
+    for (int i = fb + tid; i < fe; i += kPThreads) {
+        s_fxact[i - fb] = 1; s_fxchi[i - fb] = 0.0; s_fxk[i - fb] = (unsigned char)q.fx_kf[i];
+        const double2 uv = q.fx_uv[i];
+        s_fxobs[3 * (i - fb)] = uv.x; s_fxobs[3 * (i - fb) + 1] = uv.y; s_fxobs[3 * (i - fb) + 2] = q.fx_w[i];
+    }
+    for (int i = tid; i < q.kfix * 16; i += kPThreads) {
+        const int k = q.fix_kf[i >> 4], j = i & 15;
+        s_fxcam[i] = j < 12 ? q.poseR0[12 * k + j] : p.intr[4 * k + (j - 12)];
+    }
+    const int fxb = live ? q.fx_ptr[l] - fb : 0, fxe = live ? q.fx_ptr[l + 1] - fb : 0;   // this landmark's fixed-camera observations
     if (tid < nfree) {
         const int k = p.free_kf[tid];
         for (int b = 0; b < 2; b++) {
@@ -164,6 +266,11 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         int s1 = 0, rem = t;
         while (rem >= nfree - s1) { rem -= nfree - s1; ++s1; }
         s_pair[t][0] = (short)s1; s_pair[t][1] = (short)(s1 + rem);
+    }
+    if (tid < 78) {
+        int bi = 0, rem = tid;
+        while (rem >= 12 - bi) { rem -= 12 - bi; ++bi; }
+        s_blk[tid][0] = (unsigned char)bi; s_blk[tid][1] = (unsigned char)(bi + rem);
     }
     if (tid == 0) { s_flag[0] = 1; s_flag[1] = 0; }
     __syncthreads();
@@ -208,9 +315,9 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         double acc[10];
 #pragma unroll
         for (int i = 0; i < 10; i++) acc[i] = 0;
-        double hp[27];
+        double hp[33];   // camera-side sums of this observation: Hpp upper triangle (21), bp (6), b_schur = Y_e (L^-1 b_l) (6)
 #pragma unroll
-        for (int i = 0; i < 27; i++) hp[i] = 0;
+        for (int i = 0; i < 33; i++) hp[i] = 0;
         double H[18];
 #pragma unroll
         for (int i = 0; i < 18; i++) H[i] = 0;
@@ -218,7 +325,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         const bool on = has && act;
         if (on) {
             EdgeLin L;
-            edge_eval_v<true>(ou, ov, ow, fxk, fyk, cxk, cyk, d.delta, d.dsqr, s_poseR + (cur * NF + s) * 12, X, robust, L);
+            edge_eval_p<2>(ou, ov, ow, fxk, fyk, cxk, cyk, d.delta, d.dsqr, s_poseR + (cur * NF + s) * 12, X, robust, L);
             any = true;
             if (first) chi_e = L.chi2;
             acc[9] = L.robchi;
@@ -238,26 +345,14 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
 #pragma unroll
             for (int a = 0; a < 6; a++) hp[21 + a] = L.B[a] * L.r0 + L.B[6 + a] * L.r1;
         }
-        // camera-side sums (Hpp upper triangle, bp) over this wave's landmarks: butterfly over the landmark bits of the lane index
-#pragma unroll
-        for (int i = 0; i < 27; i++) {
-#pragma unroll
-            for (int oo = NF; oo < 64; oo <<= 1) hp[i] += __shfl_xor(hp[i], oo);
-        }
-        if (lane < NF) {
-#pragma unroll
-            for (int i = 0; i < 27; i++) U[(wv * NF + s) * 27 + i] = hp[i];
-        }
-        if (live) {   // observations by fixed cameras: Hll, bl and chi2 only
-            for (int i = q.fx_ptr[l] + s; i < q.fx_ptr[l + 1]; i += NF) {
-                if (!s_fxact[i - fb]) continue;
+        {   // observations by fixed cameras (constants staged in LDS): Hll, bl and chi2 only
+            for (int i = fxb + s; i < fxe; i += NF) {
+                if (!s_fxact[i]) continue;
                 any = true;
-                const int k = q.fx_kf[i];
-                const double2 uv = q.fx_uv[i];
+                const double* C = s_fxcam + 16 * s_fxk[i];
                 EdgeLin L;
-                edge_eval_v<true>(uv.x, uv.y, q.fx_w[i], p.intr[4 * k], p.intr[4 * k + 1], p.intr[4 * k + 2], p.intr[4 * k + 3], d.delta, d.dsqr,
-                                  q.poseR0 + 12 * k, X, robust, L);
-                if (first) s_fxchi[i - fb] = L.chi2;
+                edge_eval_p<1>(s_fxobs[3 * i], s_fxobs[3 * i + 1], s_fxobs[3 * i + 2], C[12], C[13], C[14], C[15], d.delta, d.dsqr, C, X, robust, L);
+                if (first) s_fxchi[i] = L.chi2;
                 acc[9] += L.robchi;
                 acc[0] += L.ww * (L.A[0] * L.A[0] + L.A[3] * L.A[3]); acc[1] += L.ww * (L.A[0] * L.A[1] + L.A[3] * L.A[4]);
                 acc[2] += L.ww * (L.A[0] * L.A[2] + L.A[3] * L.A[5]); acc[3] += L.ww * (L.A[1] * L.A[1] + L.A[4] * L.A[4]);
@@ -265,6 +360,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 acc[6] += L.A[0] * L.r0 + L.A[3] * L.r1; acc[7] += L.A[1] * L.r0 + L.A[4] * L.r1; acc[8] += L.A[2] * L.r0 + L.A[5] * L.r1;
             }
         }
+        if (!first) UH_BA_CLK(52);
 #pragma unroll
         for (int i = 0; i < 10; i++) {
 #pragma unroll
@@ -293,103 +389,131 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 const double y1 = (H[a * 3 + 1] - cl10 * y0) * ci11;
                 const double y2 = (H[a * 3 + 2] - cl20 * y0 - cl21 * y1) * ci22;
                 Yt[(3 * ll) * YS + 6 * s + a] = y0; Yt[(3 * ll + 1) * YS + 6 * s + a] = y1; Yt[(3 * ll + 2) * YS + 6 * s + a] = y2;
+                hp[27 + a] = y0 * wl0 + y1 * wl1 + y2 * wl2;
             }
-            if (s == 0) { s_wv[3 * ll] = wl0; s_wv[3 * ll + 1] = wl1; s_wv[3 * ll + 2] = wl2; }
         }
+        // camera-side sums over this wave's landmarks: butterfly transpose over the landmark bits of the lane index — afterwards the
+        // 64 / NF lanes of a camera slot each own a few of its 33 sums
+        {
+            int off = 0, real = 33;
+            PartTranspose<33, 32, NF>::run(hp, lane, off, real);
+#pragma unroll
+            for (int i = 0; i < 5; i++) if (i < real) U[(wv * NF + s) * 33 + off + i] = hp[i];
+        }
+        if (!first) UH_BA_CLK(53);
         const double chi_part = (live && s == 0) ? acc[9] : 0.0;
         const double maxd = (live && s == 0 && any_pt) ? fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5]))) : 0.0;
-        const double cs = block_sum<kPWaves>(chi_part, s_red);
-        const double mx = block_max_n<kPWaves>(maxd, s_red);   // (its barriers also publish Yt / s_wv / the camera sums)
-        if (tid < NF * 27) {
-            double r = U[tid];
+        double cs = chi_part, mx = maxd;
+        block_reduce2<kPWaves, true>(cs, mx, s_red);   // (its barriers also publish Yt / s_wv / the camera sums)
+        for (int t = tid; t < NF * 33; t += kPThreads) {   // 264 sums, wave order
+            double r = U[t];
 #pragma unroll
-            for (int w = 1; w < kPWaves; w++) r += U[w * NF * 27 + tid];
-            s_out[tid] = r;
+            for (int w = 1; w < kPWaves; w++) r += U[w * NF * 33 + t];
+            const int sc = t / 33, i = t - 33 * sc;
+            s_out[i < 27 ? sc * 27 + i : NF * 27 + 6 * sc + (i - 27)] = r;
         }
         if (tid == 0) { s_out[NF * 27 + NP] = cs; s_out[NF * 27 + NP + 1] = 0; s_out[NF * 27 + NP + 2] = mx; s_out[NF * 27 + NP + 3] = 0; }
-        pmf4 c[NT];
+        if (!first) UH_BA_CLK(54);
+        // S = Yt^T Yt.  Default: vector FMA, 4x4 register blocks — the 78 upper blocks of the 12x12 block grid x 3 thirds of the K range =
+        // 234 lanes, 16 accumulators each, four ds_read_b128 per 16 FMAs; the thirds are added in order through LDS.  Measured on MI355X
+        // (scripts/micro/mfma_f64_rate.hip): v_fma_f64 sustains 9.1 FMA/clk/SIMD, v_mfma_f64_16x16x4_f64 issues every ~160 cycles = 6.4, so the
+        // MFMA form below (UH_BA_SCHUR=mfma: six upper 16x16 tiles split over the waves, accumulators resident in AGPRs) loses on gfx950.
+        if (!first && !q.use_mfma) {
+            const int kt = tid / 78, bq = tid - 78 * kt;
+            const bool onj = tid < 234;
+            const int bi = s_blk[onj ? bq : 0][0], bj = s_blk[onj ? bq : 0][1];
+            const int kc = (q.krows + 2) / 3;
+            const int kbeg = kt * kc, kend = onj ? min(q.krows, kbeg + kc) : 0;
+            double acc4[16];
 #pragma unroll
-        for (int t = 0; t < NT; t++) c[t] = pmf4{0, 0, 0, 0};
-        const int kq = wv;   // k-steps kq, kq+4, ... of the product belong to this wave
-        if (!first) {
-            // b_schur partial: Yt^T (L^-1 b_l), rows split over the waves
-            if (lane < NP) {
-                double r = 0;
-                for (int k = wv; k < 3 * nl; k += kPWaves) r = fma(Yt[k * YS + lane], s_wv[k], r);
-                s_bsp[wv * NP + lane] = r;
+            for (int i = 0; i < 16; i++) acc4[i] = 0;
+            const double* ra = Yt + 4 * bi, * rb = Yt + 4 * bj;
+            // four rows per iteration: their sixteen ds_read_b128 are issued together, so one LDS latency is paid per 64 FMAs
+            // (the compiler serialises load -> wait -> FMA inside an iteration and undoes hand-rotated prefetching)
+            for (int k = kbeg; k < kend; k += 4) {
+                double2 a01[4], a23[4], b01[4], b23[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int kk = k + u < kend ? k + u : kbeg;
+                    a01[u] = *reinterpret_cast<const double2*>(ra + kk * YS); a23[u] = *reinterpret_cast<const double2*>(ra + kk * YS + 2);
+                    b01[u] = *reinterpret_cast<const double2*>(rb + kk * YS); b23[u] = *reinterpret_cast<const double2*>(rb + kk * YS + 2);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const double z = k + u < kend ? 1.0 : 0.0;   // rows past the end contribute nothing
+                    const double av[4] = {a01[u].x * z, a01[u].y * z, a23[u].x * z, a23[u].y * z}, bv[4] = {b01[u].x, b01[u].y, b23[u].x, b23[u].y};
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+#pragma unroll
+                        for (int c = 0; c < 4; c++) acc4[r * 4 + c] = fma(av[r], bv[c], acc4[r * 4 + c]);
+                }
             }
-            // S = Yt^T Yt, upper tiles (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+            __syncthreads();   // the camera sums in U have been read (before the product): U is free
+            if (onj && kt > 0) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) U[(kt - 1) * 1248 + bq * 16 + i] = acc4[i];
+            }
+            __syncthreads();
+            if (onj && kt == 0) {
+                double u0[16], u1[16];   // all LDS reads first: interleaved with the write-through stores they serialise into 32 round trips
+#pragma unroll
+                for (int i = 0; i < 16; i++) { u0[i] = U[bq * 16 + i]; u1[i] = U[1248 + bq * 16 + i]; }
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc4[i] = (acc4[i] + u0[i]) + u1[i];
+                double* dst = part_addr(bq * 16);   // SL is even and 16-element runs may straddle a slice: address every element
+#pragma unroll
+                for (int i = 0; i < 16; i++) xst(part_addr(bq * 16 + i), acc4[i]);
+                (void)dst;
+            }
+        }
+        // MFMA form: wave 0: (0,0) (0,1), wave 1: (0,2) (1,1), wave 2: (1,2) + half of b_schur, wave 3: (2,2) + the other half — every wave
+        // runs the whole K range, so no reduction across waves is needed.
+        if (!first && q.use_mfma) {
             const int nks = q.krows >> 2;
             const int col = lane & 15, kr = lane >> 4;
-            if (q.use_mfma) {
-                for (int ks = kq; ks < nks; ks += kPWaves) {
-                    const double* row = Yt + (4 * ks + kr) * YS + col;
-                    const double y0 = row[0], y1 = row[16], y2 = row[32];
-                    c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, y0, c[0], 0, 0, 0);
-                    c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, y1, c[1], 0, 0, 0);
-                    c[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, y2, c[2], 0, 0, 0);
-                    c[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, y1, c[3], 0, 0, 0);
-                    c[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, y2, c[4], 0, 0, 0);
-                    c[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(y2, y2, c[5], 0, 0, 0);
-                }
-            } else {
-                // vector-FMA form of the same tiles in the same register layout: lane (col, kr) owns rows kr, kr+4, kr+8, kr+12
-                for (int ks = kq; ks < nks; ks += kPWaves) {
-#pragma unroll
-                    for (int kk = 0; kk < 4; kk++) {
-                        const double* row = Yt + (4 * ks + kk) * YS;
-                        const double b0 = row[col], b1 = row[16 + col], b2 = row[32 + col];
-#pragma unroll
-                        for (int v = 0; v < 4; v++) {
-                            const double a0 = row[kr + 4 * v], a1 = row[16 + kr + 4 * v], a2 = row[32 + kr + 4 * v];
-                            c[0][v] = fma(a0, b0, c[0][v]); c[1][v] = fma(a0, b1, c[1][v]); c[2][v] = fma(a0, b2, c[2][v]);
-                            c[3][v] = fma(a1, b1, c[3][v]); c[4][v] = fma(a1, b2, c[4][v]); c[5][v] = fma(a2, b2, c[5][v]);
-                        }
+            // column groups of the wave's tile(s): wave 0 (0,0)+(0,1), wave 1 (0,2)+(1,1), wave 2 (1,2), wave 3 (2,2)
+            const int ga = wvu == 0 ? 0 : (wvu == 1 ? 0 : (wvu == 2 ? 16 : 32)), gb = wvu == 0 ? 0 : 32;
+            const int gc = wvu == 0 ? 0 : 16, gd = 16;
+            pmf4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
+            {
+                // v_mfma_f64_16x16x4_f64 through inline asm with "+a": the accumulators stay in AGPRs for the whole loop (the builtin form
+                // made the compiler copy all eight registers VGPR <-> AGPR around every instruction).  Consecutive MFMAs never depend on
+                // each other: two tiles alternate (waves 0/1), or even / odd k-steps go to two accumulators (waves 2/3).
+                const double* row = Yt + kr * YS + col;
+                if (wvu < 2) {
+                    double ya = row[ga], yb = row[gb], yc = row[gc], yd = row[gd];
+                    for (int ks = 0; ks < nks; ks++) {
+                        const double* nrow = Yt + (4 * (ks + 1 < nks ? ks + 1 : ks) + kr) * YS + col;   // next k-step's operands while the MFMAs run
+                        const double na = nrow[ga], nb = nrow[gb], nc = nrow[gc], nd = nrow[gd];
+                        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(t0) : "v"(ya), "v"(yb));
+                        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(t1) : "v"(yc), "v"(yd));
+                        ya = na; yb = nb; yc = nc; yd = nd;
                     }
+                    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+                } else {
+                    for (int ks = 0; ks < nks; ks += 2) {
+                        const double* r0 = Yt + (4 * ks + kr) * YS + col;
+                        const double ya = r0[ga], yb = r0[gb], yc = r0[4 * YS + ga], yd = r0[4 * YS + gb];
+                        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(t0) : "v"(ya), "v"(yb));
+                        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(t1) : "v"(yc), "v"(yd));
+                    }
+                    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+                    for (int v = 0; v < 4; v++) t0[v] += t1[v];
                 }
             }
-        }
-        __syncthreads();   // camera sums read, Yt reads of the product done: U is free for the tile reduction
-        if (!first) {
-            if (tid < NP) {
-                double r = s_bsp[tid];
+            // element index of (tile t, lane, v) = (t*64 + lane)*4 + v; tile order (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+            const int ti0 = wvu == 0 ? 0 : (wvu == 1 ? 2 : (wvu == 2 ? 4 : 5)), ti1 = wvu == 0 ? 1 : 3;
 #pragma unroll
-                for (int w = 1; w < kPWaves; w++) r += s_bsp[w * NP + tid];
-                s_out[NF * 27 + tid] = r;
-            }
-            // (k0 + k2) + (k1 + k3), fixed order; element index of (tile t, lane, v) = (t*64 + lane)*4 + v
-            if (kq >= 2) {
-                double* u = U + (kq - 2) * (NT * 256) + lane * 4;
+            for (int v = 0; v < 4; v++) xst(part_addr(ti0 * 256 + lane * 4 + v), t0[v]);
+            if (wvu < 2) {
 #pragma unroll
-                for (int t = 0; t < NT; t++)
-#pragma unroll
-                    for (int v = 0; v < 4; v++) u[t * 256 + v] = c[t][v];
-            }
-            __syncthreads();
-            if (kq < 2) {
-                const double* u = U + kq * (NT * 256) + lane * 4;
-#pragma unroll
-                for (int t = 0; t < NT; t++)
-#pragma unroll
-                    for (int v = 0; v < 4; v++) c[t][v] += u[t * 256 + v];
-            }
-            __syncthreads();
-            if (kq == 1) {
-                double* u = U + lane * 4;
-#pragma unroll
-                for (int t = 0; t < NT; t++)
-#pragma unroll
-                    for (int v = 0; v < 4; v++) u[t * 256 + v] = c[t][v];
-            }
-            __syncthreads();
-            if (kq == 0) {
-                const double* u = U + lane * 4;
-#pragma unroll
-                for (int t = 0; t < NT; t++)
-#pragma unroll
-                    for (int v = 0; v < 4; v++) xst(part_addr(t * 256 + lane * 4 + v), c[t][v] + u[t * 256 + v]);
+                for (int v = 0; v < 4; v++) xst(part_addr(ti1 * 256 + lane * 4 + v), t1[v]);
             }
         }
+        if (!first) UH_BA_CLK(55);
+        __syncthreads();
+        if (!first) UH_BA_CLK(56);
         __syncthreads();   // s_out complete
         for (int i = tid; i < NF * 27 + NP + 4; i += kPThreads) xst(part_addr(OFF_CAM + i), s_out[i]);
     };
@@ -405,12 +529,12 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             const int hg = idx / SL, e = idx - hg * SL;
             const bool is_max = g * SL + e == OFF_SC + 2;
             double r = xld(src + (size_t)hg * SL + e);
-            for (int h = hg + HG; h < G; h += 4 * HG) {   // four loads in flight, added in ascending order
-                double v[4];
+            for (int h = hg + HG; h < G; h += 8 * HG) {   // eight loads in flight, added in ascending order
+                double v[8];
 #pragma unroll
-                for (int u = 0; u < 4; u++) v[u] = h + u * HG < G ? xld(src + (size_t)(h + u * HG) * SL + e) : (is_max ? r : 0.0);
+                for (int u = 0; u < 8; u++) v[u] = h + u * HG < G ? xld(src + (size_t)(h + u * HG) * SL + e) : (is_max ? r : 0.0);
 #pragma unroll
-                for (int u = 0; u < 4; u++) r = is_max ? fmax(r, v[u]) : r + v[u];
+                for (int u = 0; u < 8; u++) r = is_max ? fmax(r, v[u]) : r + v[u];
             }
             U[idx] = r;
         }
@@ -438,12 +562,10 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 const double z = Rt[6] * X[0] + Rt[7] * X[1] + Rt[8] * X[2] + Rt[11];
                 if (chi_e > d.chi2_th || !(z > 0.0)) act = false;
             }
-            if (live) {
-                for (int i = q.fx_ptr[l] + s; i < q.fx_ptr[l + 1]; i += NF) {
-                    const double* Rt = q.poseR0 + 12 * q.fx_kf[i];
-                    const double z = Rt[6] * X[0] + Rt[7] * X[1] + Rt[8] * X[2] + Rt[11];
-                    if (s_fxchi[i - fb] > d.chi2_th || !(z > 0.0)) s_fxact[i - fb] = 0;
-                }
+            for (int i = fxb + s; i < fxe; i += NF) {
+                const double* Rt = s_fxcam + 16 * s_fxk[i];
+                const double z = Rt[6] * X[0] + Rt[7] * X[1] + Rt[8] * X[2] + Rt[11];
+                if (s_fxchi[i] > d.chi2_th || !(z > 0.0)) s_fxact[i] = 0;
             }
             robust = false;
             __syncthreads();
@@ -480,19 +602,26 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             if (!reduce_slices()) return;
             UH_BA_CLK(42);
             // ---- assemble S = Hpp + lambda I - Yt^T Yt (lower triangle, bordered with b = bp - b_schur), factorise, substitute
-            for (int base = 0; base < q.nelem; base += 4 * kPThreads) {
-            double rv[4];
+            for (int base = 0; base < q.nelem; base += 8 * kPThreads) {
+            double rv[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) rv[u] = base + tid + u * kPThreads < q.nelem ? xld(q.red + base + tid + u * kPThreads) : 0.0;
+            for (int u = 0; u < 8; u++) rv[u] = base + tid + u * kPThreads < q.nelem ? xld(q.red + base + tid + u * kPThreads) : 0.0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 8; u++) {
                 const int idx = base + tid + u * kPThreads;
                 const double v = rv[u];
                 if (idx >= q.nelem) continue;
                 if (idx < OFF_CAM) {
-                    const int ti = idx >> 8, lq = (idx >> 2) & 63, vv = idx & 3;
-                    const int tm = ti < 3 ? 0 : (ti < 5 ? 1 : 2), tn = ti < 3 ? ti : (ti < 5 ? ti - 2 : 2);
-                    const int row = 16 * tm + (lq >> 4) + 4 * vv, col = 16 * tn + (lq & 15);
+                    int row, col;
+                    if (q.use_mfma) {   // (tile, lane, register) of the MFMA C layout: row = (lane >> 4) + 4 * reg, col = lane & 15
+                        const int ti = idx >> 8, lq = (idx >> 2) & 63, vv = idx & 3;
+                        const int tm = ti < 3 ? 0 : (ti < 5 ? 1 : 2), tn = ti < 3 ? ti : (ti < 5 ? ti - 2 : 2);
+                        row = 16 * tm + (lq >> 4) + 4 * vv; col = 16 * tn + (lq & 15);
+                    } else {            // (4x4 block of the upper block triangle, r, c)
+                        const int bq = idx >> 4, rr = (idx >> 2) & 3, cq = idx & 3;
+                        const int bc = bq < 78 ? bq : 0;
+                        row = 4 * s_blk[bc][0] + rr; col = bq < 78 ? 4 * s_blk[bc][1] + cq : n;   // (unused tail of the region: col = n)
+                    }
                     if (row <= col && col < n) Mm[col * ld + row] = -v;
                 } else if (idx < OFF_BS) s_out[idx - OFF_CAM] = v;
                 else if (idx < OFF_SC) s_bs[idx - OFF_BS] = v;
@@ -572,24 +701,20 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             double chi_part = 0;
             if (has && act) {
                 EdgeLin L;
-                edge_eval_v<false>(ou, ov, ow, fxk, fyk, cxk, cyk, d.delta, d.dsqr, s_poseR + (trial * NF + s) * 12, Xt, robust, L);
+                edge_eval_p<0>(ou, ov, ow, fxk, fyk, cxk, cyk, d.delta, d.dsqr, s_poseR + (trial * NF + s) * 12, Xt, robust, L);
                 chi_e = L.chi2;
                 chi_part = L.robchi;
             }
-            if (live) {
-                for (int i = q.fx_ptr[l] + s; i < q.fx_ptr[l + 1]; i += NF) {
-                    if (!s_fxact[i - fb]) continue;
-                    const int k = q.fx_kf[i];
-                    const double2 uv = q.fx_uv[i];
-                    EdgeLin L;
-                    edge_eval_v<false>(uv.x, uv.y, q.fx_w[i], p.intr[4 * k], p.intr[4 * k + 1], p.intr[4 * k + 2], p.intr[4 * k + 3], d.delta, d.dsqr,
-                                       q.poseR0 + 12 * k, Xt, robust, L);
-                    s_fxchi[i - fb] = L.chi2;
-                    chi_part += L.robchi;
-                }
+            for (int i = fxb + s; i < fxe; i += NF) {
+                if (!s_fxact[i]) continue;
+                const double* C = s_fxcam + 16 * s_fxk[i];
+                EdgeLin L;
+                edge_eval_p<0>(s_fxobs[3 * i], s_fxobs[3 * i + 1], s_fxobs[3 * i + 2], C[12], C[13], C[14], C[15], d.delta, d.dsqr, C, Xt, robust, L);
+                s_fxchi[i] = L.chi2;
+                chi_part += L.robchi;
             }
-            const double cs = block_sum<kPWaves>(chi_part, s_red);
-            const double ss = block_sum<kPWaves>(scale_part, s_red);
+            double cs = chi_part, ss = scale_part;
+            block_reduce2<kPWaves, false>(cs, ss, s_red);
             if (tid == 0) {
                 xst(q.partC + 4 * g, cs); xst(q.partC + 4 * g + 1, ss);
                 if (g == 0) xst(q.partC + 2, (p.stop && *p.stop) ? 1.0 : 0.0);
@@ -601,7 +726,13 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             // ---- decision (every wave of every workgroup, same inputs, same code)
             {
                 double c = 0, sc = 0;
-                for (int h = lane; h < G; h += 64) { c += xld(q.partC + 4 * h); sc += xld(q.partC + 4 * h + 1); }
+                {
+                    double cv[4], sv[4];   // G <= 256
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int h = lane + 64 * u; cv[u] = h < G ? xld(q.partC + 4 * h) : 0.0; sv[u] = h < G ? xld(q.partC + 4 * h + 1) : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { c += cv[u]; sc += sv[u]; }
+                }
                 DecideSums sm;
                 sm.lin = chi_lin_pass; sm.chi = wave_sum_fixed(c); sm.scale = wave_sum_fixed(sc); sm.xs = s_sc[0];
                 const bool stopv = xld(q.partC + 2) != 0.0;
