@@ -124,6 +124,14 @@ int uh_knn_scan_shard_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn,
 int uh_knn_replay_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int sorted, int max_dist,
                       const uint64_t* d_cand_all, const int32_t* d_counts_all, int nshards, int cap,
                       int32_t* d_indices, int32_t* d_distances);
+/* Ranks that hold ONLY their tile of a sharded train set ("each GPU emits local top-k per query with GLOBAL train
+ * indices"): the index is built over the tile's rows, uh_knn_set_row_offset gives row 0's global index (used by
+ * uh_knn_scan_shard_dev), and uh_knn_replay_tiles_dev replays the gathered lists without ever touching train rows — a list
+ * that overflowed its cap sets *d_overflow (device int32, zeroed by the caller) instead of being rescanned. */
+int uh_knn_set_row_offset(uh_knn* idx, int offset);
+int uh_knn_replay_tiles_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int sorted, int max_dist,
+                            const uint64_t* d_cand_all, const int32_t* d_counts_all, int nshards, int cap,
+                            int32_t* d_indices, int32_t* d_distances, int32_t* d_overflow);
 
 /* ------------------------------------------------------------------------
  * ORB extractor — replaces ucoslam::ORBextractor behind Feature2DSerializable:

@@ -252,3 +252,103 @@ def test_sharded_search_over_rccl_single_rank(hip_ctx):
         assert (idx.cpu().numpy() == ri).all() and (dd.cpu().numpy() == rd).all()
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ fused frame stream (one all-gather per frame)
+def _fused_worker(rank, world, port, ok):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ucoslam_cv3_amd import parallel
+
+    maxf, cap = 300, 16
+    lay = parallel.frame_message_layout(maxf, cap, with_bow=True)
+    assert all(o % 16 == 0 for k, (o, n) in ((k, v) for k, v in lay.items() if k != "total"))
+
+    def rank_data(r):   # what rank r contributes: deterministic, so that every rank can check everybody's part
+        g = np.random.default_rng(100 + r)
+        rows = 40 + 17 * r
+        kps = g.standard_normal((maxf, 7)).astype(np.float32)
+        desc = g.integers(0, 256, (maxf, 32), dtype=np.uint8)
+        nq = 123
+        cand = g.integers(0, 2 ** 62, (nq, cap), dtype=np.int64)
+        counts = g.integers(0, cap + 1, nq).astype(np.int32)
+        sl = parallel.shard_bounds(nq, world)
+        bow = g.integers(-2 ** 31, 2 ** 31 - 1, (sl[r + 1] - sl[r], 4)).astype(np.int32)
+        return rows, kps, desc, nq, cand, counts, bow
+
+    rows, kps, desc, nq, cand, counts, bow = rank_data(rank)
+    buf = torch.zeros(lay["total"], dtype=torch.uint8)
+    parallel.pack_frame_message(buf, lay, torch.from_numpy(kps), torch.from_numpy(desc), rows, torch.from_numpy(cand), torch.from_numpy(counts), nq,
+                                torch.from_numpy(bow))
+    msgs = parallel.gather_messages(buf)            # ONE collective
+    assert msgs.shape == (world, lay["total"])
+    u = parallel.unpack_frame_messages(msgs, lay, world, maxf, cap, parallel.shard_bounds(nq, world))
+    exp = [rank_data(r) for r in range(world)]
+    np.testing.assert_array_equal(u["kps"].numpy(), np.concatenate([e[1][: e[0]] for e in exp]))
+    np.testing.assert_array_equal(u["desc"].numpy(), np.concatenate([e[2][: e[0]] for e in exp]))
+    assert u["nq"] == nq
+    np.testing.assert_array_equal(u["cand_all"].numpy(), np.stack([e[4] for e in exp]))
+    np.testing.assert_array_equal(u["counts_all"].numpy(), np.stack([e[5] for e in exp]))
+    np.testing.assert_array_equal(u["bow"].numpy(), np.concatenate([e[6] for e in exp]))
+    ok[rank] = 1
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_fused_frame_message_one_collective():
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    ok = mp.get_context("spawn").Array("i", [0] * world)
+    mp.spawn(_fused_worker, args=(world, port, ok), nprocs=world, join=True)
+    assert list(ok) == [1] * world
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_frame_stream_equals_single_gpu(hip_ctx, world):
+    """ShardedFrameStream with `world` ranks simulated one after the other on this GPU (each with ONLY its tile of the map and its
+    level range; the all-gather replaced by stacking the messages): complete features of frame t, kNN rows and bag-of-words
+    triplets of frame t-1 — all identical to the single-GPU extraction / search / descent."""
+    import synth
+    from ucoslam_cv3_amd import parallel
+    from ucoslam_cv3_amd.bow import Vocabulary, write_vocabulary_stream
+    from ucoslam_cv3_amd.knn import Index
+    from ucoslam_cv3_amd.orb import FeatParams, ORBextractor
+
+    W, H, nf, nn = 640, 480, 1000, 10
+    fp = FeatParams(nf, 8, 1.2)
+    train, _ = synth.match_set(1, 3001, seed=5)
+    d_train = torch.from_numpy(train).cuda()
+    full = Index(hip_ctx).build(d_train)
+    params, blob, _ = synth.vocabulary(k=10, depth=4, seed=2)
+    voc = Vocabulary(hip_ctx).fromStream(write_vocabulary_stream(params, blob))
+    ext = ORBextractor.create(hip_ctx)
+    b = parallel.shard_bounds(len(train), world)
+    streams = []
+    for r in range(world):
+        tile = Index(hip_ctx).build(d_train[b[r]:b[r + 1]].clone()).set_row_offset(b[r])
+        streams.append(parallel.ShardedFrameStream(ext, fp, tile, nn, nf, cand_cap=96, vocabulary=voc, bow_level=3, rank=r, world=world))
+    prev_desc = None
+    for t in range(3):
+        frame = torch.from_numpy(synth.frame(W, H, seed=40 + t, shift=(3 * t, t))).cuda()
+        msgs = torch.stack([s.local(frame).clone() for s in streams])
+        res = [s.finish(msgs) for s in streams]
+        torch.cuda.synchronize()
+        kps, desc, counts = ext.extract_batch(frame[None], fp)
+        n = int(counts[0])
+        for r in res:
+            assert r["kps"].cpu().numpy().tobytes() == kps[0, :n].cpu().numpy().tobytes()
+            assert (r["desc"] == desc[0, :n]).all()
+        if prev_desc is not None:
+            ri, rd = full.search(prev_desc, nn, sorted=False)
+            trip = voc.transform_triplets(prev_desc, 3)
+            for r in res:
+                assert int(r["overflow"]) == 0
+                assert (r["prev_indices"] == ri).all() and (r["prev_distances"] == rd).all()
+                assert (r["prev_bow"] == trip).all()
+            f1, f2 = Vocabulary.maps_from_triplets(res[0]["prev_bow"].cpu().numpy())
+            g1, g2 = voc.transform(prev_desc.cpu().numpy(), 3)
+            assert f1 == g1 and f2 == g2
+        else:
+            assert all(r["prev_indices"] is None for r in res)
+        prev_desc = desc[0, :n].clone()

@@ -107,6 +107,43 @@ class Vocabulary:
                                      np_ptr(valid)))
         return word, weight, node, valid
 
+    def transform_triplets(self, d_features, level: int):
+        """The per-descriptor result of the tree descent for device-resident descriptors (torch uint8 CUDA [n,32]): int32 [n,4] =
+        (word id, float weight bits, node id at `level`, node valid).  This is what the ranks of a sharded transform exchange
+        ("gather (word, weight, node) triplets; host accumulates in feature order")."""
+        import torch
+
+        from ._lib import dev_ptr
+
+        f = d_features.contiguous()
+        n = f.shape[0]
+        out = torch.zeros((n, 4), dtype=torch.int32, device=f.device)
+        if n == 0:
+            return out
+        word = torch.empty(n, dtype=torch.int32, device=f.device)
+        weight = torch.empty(n, dtype=torch.float32, device=f.device)
+        node = torch.empty(n, dtype=torch.int32, device=f.device)
+        valid = torch.empty(n, dtype=torch.uint8, device=f.device)
+        check(lib().uh_bow_transform_dev(self._h, dev_ptr(f), n, level, dev_ptr(word), dev_ptr(weight), dev_ptr(node), dev_ptr(valid)))
+        out[:, 0] = word; out[:, 1] = weight.view(torch.int32); out[:, 2] = node; out[:, 3] = valid.to(torch.int32)
+        return out
+
+    @staticmethod
+    def maps_from_triplets(trip):
+        """(fBow, fBow2) of transform(features, level) from the [n,4] int32 triplets of ALL descriptors in feature order."""
+        t = np.ascontiguousarray(np.asarray(trip), np.int32)
+        word, weight = t[:, 0].view(np.uint32), t[:, 1].copy().view(np.float32)
+        node, valid = t[:, 2].view(np.uint32), t[:, 3]
+        r1 = fBow()
+        for w, wt in zip(word.tolist(), weight):
+            if w != 0xFFFFFFFF:
+                r1[w] = np.float32(r1.get(w, np.float32(0)) + wt)
+        r2 = {}
+        for i, (nd, ok) in enumerate(zip(node.tolist(), valid)):
+            if ok:
+                r2.setdefault(nd, []).append(i)
+        return r1, r2
+
     def transform(self, features, level: int | None = None):
         """transform(features) -> fBow (L2-normalised); transform(features, level) -> (fBow, fBow2) raw weights."""
         word, weight, node, valid = self._descend(features, -1 if level is None else level)

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_scan_shard_kernel(
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_replay_kernel(
     const uint8_t* __restrict__ train, ShardBounds sb, const uint8_t* __restrict__ queries, int nq, int k,
     int sorted, int maxd, const uint64_t* __restrict__ cand_all, const int32_t* __restrict__ counts_all, int cap,
-    int32_t* __restrict__ indices, int32_t* __restrict__ distances) {
+    int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ overflow) {
     const int lane = threadIdx.x & (kWave - 1);
     const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (qi >= nq) return;
@@ -368,6 +368,10 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_replay_kernel(
     int dummy = 0;
     for (int s = 0; s < sb.n; ++s) {
         int cnt = __builtin_amdgcn_readfirstlane(counts_all[(size_t)s * nq + qi]);
+        if (cnt > cap && overflow) {   // tile-only ranks cannot rescan another rank's rows: report, the caller retries with a larger cap
+            if (lane == 0) atomicOr(overflow, 1);
+            continue;
+        }
         if (cnt > cap) {
             scan_range<false>(h, train, sb.b[s], sb.b[s + 1], q, k, maxd, nullptr, dummy, 0);
             continue;
@@ -648,6 +652,7 @@ struct uh_knn {
     const uint8_t* d_train = nullptr;
     int nt = 0;
     int shard_begin = 0, shard_end = 0;
+    int row_offset = 0;           // global index of row 0 (uh_knn_set_row_offset): an index that holds only one tile of a sharded train set
     int qpw = 1;                  // queries per wave of the exact search (uh_knn_set_queries_per_wave)
     uh::DevBuf q_buf, idx_buf, dist_buf;  // staging for the host-pointer API
     // hierarchical k-means form of the same index (uh_knn_build_kmeans)
@@ -797,8 +802,10 @@ int uh_knn_scan_shard_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn,
     if (nq == 0) return UH_OK;
     UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
     dim3 grid(uh_div_up(nq, kWavesPerBlock)), block(kWave * kWavesPerBlock);
-    UH_LAUNCH(idx->ctx,knn_scan_shard_kernel, grid, block, 0, idx->d_train, idx->shard_begin,
-                       idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
+    // rows [shard_begin, shard_end) of this index carry the global indices row_offset + row: the kernel indexes a virtual base that
+    // lies row_offset rows in front of the tile (only rows inside the tile are ever addressed)
+    UH_LAUNCH(idx->ctx,knn_scan_shard_kernel, grid, block, 0, idx->d_train - (size_t)idx->row_offset * 32, idx->row_offset + idx->shard_begin,
+                       idx->row_offset + idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
 }
@@ -818,8 +825,34 @@ int uh_knn_replay_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
     UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
     dim3 grid(uh_div_up(nq, kWavesPerBlock)), block(kWave * kWavesPerBlock);
     UH_LAUNCH(idx->ctx,knn_replay_kernel, grid, block, 0, idx->d_train, sb, d_queries, nq, nn,
-                       sorted ? 1 : 0, max_dist, d_cand_all, d_counts_all, cap, d_indices, d_distances);
+                       sorted ? 1 : 0, max_dist, d_cand_all, d_counts_all, cap, d_indices, d_distances, (int*)nullptr);
     UH_HIP_CHECK(hipGetLastError());
+    return UH_OK;
+}
+
+// replay for ranks that hold only their own tile of the train set: no rescan; *d_overflow is OR-ed with 1 if some list overflowed
+int uh_knn_replay_tiles_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int sorted, int max_dist,
+                            const uint64_t* d_cand_all, const int32_t* d_counts_all, int nshards, int cap,
+                            int32_t* d_indices, int32_t* d_distances, int32_t* d_overflow) {
+    int rc = check_search_args(idx, d_queries, nq, nn, d_indices, d_distances);
+    if (rc) return rc;
+    UH_REQUIRE(nshards >= 1 && nshards <= kMaxShards, "uh_knn_replay_tiles_dev: nshards=%d outside [1,%d]", nshards, kMaxShards);
+    UH_REQUIRE(cap >= 1 && d_cand_all && d_counts_all && d_overflow, "uh_knn_replay_tiles_dev: bad candidate buffers");
+    if (nq == 0) return UH_OK;
+    ShardBounds sb;
+    sb.n = nshards;
+    for (int s = 0; s <= nshards; ++s) sb.b[s] = 0;   // never used: there is no rescan in this form
+    UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
+    dim3 grid(uh_div_up(nq, kWavesPerBlock)), block(kWave * kWavesPerBlock);
+    UH_LAUNCH(idx->ctx,knn_replay_kernel, grid, block, 0, idx->d_train, sb, d_queries, nq, nn,
+                       sorted ? 1 : 0, max_dist, d_cand_all, d_counts_all, cap, d_indices, d_distances, (int*)d_overflow);
+    UH_HIP_CHECK(hipGetLastError());
+    return UH_OK;
+}
+
+int uh_knn_set_row_offset(uh_knn* idx, int offset) {
+    UH_REQUIRE(idx && offset >= 0, "uh_knn_set_row_offset: bad argument");
+    idx->row_offset = offset;
     return UH_OK;
 }
 

@@ -141,6 +141,28 @@ class Index:
                                       dev_ptr(counts_all), nshards, cap, dev_ptr(idx), dev_ptr(dist)))
         return idx, dist
 
+    def set_row_offset(self, offset: int):
+        """This index holds ONE tile of a sharded train set: row 0 has the global index `offset` (used by scan_shard)."""
+        check(lib().uh_knn_set_row_offset(self._h, offset))
+        return self
+
+    def replay_tiles(self, queries, nn: int, cand_all, counts_all, sorted: bool = False, max_dist: int = -1):
+        """replay() for ranks that hold only their own tile: never rescans; returns (indices, distances, overflow) where the 1-element
+        int32 tensor `overflow` is non-zero if some gathered list exceeded its cap (retry the frame with a larger cap)."""
+        import torch
+
+        q = queries.contiguous()
+        nq = q.shape[0]
+        nshards, _, cap = cand_all.shape
+        cand_all = cand_all.contiguous()
+        counts_all = counts_all.contiguous()
+        idx = torch.empty((nq, nn), dtype=torch.int32, device=q.device)
+        dist = torch.empty((nq, nn), dtype=torch.int32, device=q.device)
+        overflow = torch.zeros((1,), dtype=torch.int32, device=q.device)
+        check(lib().uh_knn_replay_tiles_dev(self._h, dev_ptr(q), nq, nn, int(sorted), max_dist, dev_ptr(cand_all),
+                                            dev_ptr(counts_all), nshards, cap, dev_ptr(idx), dev_ptr(dist), dev_ptr(overflow)))
+        return idx, dist, overflow
+
     def close(self):
         if self._h:
             lib().uh_knn_destroy(self._h)

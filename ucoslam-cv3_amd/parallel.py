@@ -17,6 +17,11 @@ Two ways the hot path spreads over the GPUs of a node:
   + counts moves <= maxFeatures * 60 B per rank, and every rank compacts the blocks in rank (= level) order — rows identical
   to the single-GPU extraction.  Level 0 alone holds 32 % of the pyramid's pixels, so this form cannot scale beyond ~3x
   and costs a collective per frame; it exists for latency (one frame, many GPUs), not for throughput.
+* the fused frame stream (ShardedFrameStream, what `bench.py --gpus N` times beside the replicas): levels AND train tiles sharded,
+  every rank holding ONLY its tile of the map, ONE all-gather per frame.  Matching frame t needs all of frame t's descriptors on
+  every rank, i.e. it depends on the feature exchange; instead of a second collective per frame the stream is software-pipelined:
+  the message of step t carries {this rank's level rows of frame t, its tile's accept lists for frame t-1, its slice of frame
+  t-1's bag-of-words triplets} in one buffer, so results trail the input by one frame and every frame costs one collective.
 """
 from __future__ import annotations
 
@@ -137,3 +142,138 @@ def frames_of_rank(n_frames: int, rank: int, world: int):
     """Contiguous block of a frame stream handled by `rank` (frame-parallel extraction)."""
     b = shard_bounds(n_frames, world)
     return range(b[rank], b[rank + 1])
+
+
+# ------------------------------------------------------------------------------------------------ fused frame stream
+def frame_message_layout(max_features: int, cand_cap: int, with_bow: bool = False):
+    """Byte offsets of one rank's message (all multiples of 16).  Fields: header (int32: n level rows, n queries scanned),
+    keypoints [max_features, 28 B], descriptors [max_features, 32 B], accept counts [max_features] int32, accept lists
+    [max_features, cand_cap] uint64 (dist << 32 | global train index), optional bag-of-words triplets [max_features, 4] int32
+    (word id, float weight bits, level node id, node valid) of this rank's slice of the previous frame's descriptors."""
+    off, lay = 0, {}
+
+    def take(name, nbytes):
+        nonlocal off
+        lay[name] = (off, nbytes)
+        off += (nbytes + 15) & ~15
+
+    take("header", 16)
+    take("kps", max_features * 28)
+    take("desc", max_features * 32)
+    take("counts", max_features * 4)
+    take("cand", max_features * cand_cap * 8)
+    if with_bow:
+        take("bow", max_features * 16)
+    lay["total"] = off
+    return lay
+
+
+def pack_frame_message(buf, lay, kps, desc, n_rows: int, cand=None, counts=None, n_queries: int = 0, bow=None):
+    """Fills `buf` (uint8 [lay.total], same device as the inputs).  kps [cap,7] float32, desc [cap,32] uint8 (first n_rows valid);
+    cand [nq,cap] int64 / counts [nq] int32 for the PREVIOUS frame's queries (nq == n_queries), bow [slice,4] int32."""
+    import torch
+
+    hdr = torch.tensor([n_rows, n_queries, 0, 0], dtype=torch.int32).to(buf.device).view(torch.uint8)
+    o, n = lay["header"]; buf[o:o + 16] = hdr
+    o, n = lay["kps"]; buf[o:o + n_rows * 28] = kps[:n_rows].contiguous().view(torch.uint8).reshape(-1)
+    o, n = lay["desc"]; buf[o:o + n_rows * 32] = desc[:n_rows].contiguous().reshape(-1)
+    if n_queries:
+        o, n = lay["counts"]; buf[o:o + n_queries * 4] = counts[:n_queries].contiguous().view(torch.uint8).reshape(-1)
+        o, n = lay["cand"]; buf[o:o + cand[:n_queries].numel() * 8] = cand[:n_queries].contiguous().view(torch.uint8).reshape(-1)
+        if bow is not None and "bow" in lay:
+            o, n = lay["bow"]; buf[o:o + bow.numel() * 4] = bow.contiguous().view(torch.uint8).reshape(-1)
+    return buf
+
+
+def unpack_frame_messages(all_buf, lay, world: int, max_features: int, cand_cap: int, bow_slices=None):
+    """all_buf: uint8 [world, lay.total].  Returns dict(kps [n,7] float32, desc [n,32] uint8 — the level rows compacted in rank
+    (= level) order —, cand_all [world, nq, cap] int64, counts_all [world, nq] int32, nq, bow [nq,4] int32 or None)."""
+    import torch
+
+    hdr = torch.stack([all_buf[r, lay["header"][0]:lay["header"][0] + 16].view(torch.int32) for r in range(world)]).cpu().numpy()
+    rows, nq = hdr[:, 0].tolist(), int(hdr[0, 1])
+    ko, do = lay["kps"][0], lay["desc"][0]
+    kps = torch.cat([all_buf[r, ko:ko + rows[r] * 28].view(torch.float32).reshape(-1, 7) for r in range(world)], 0)
+    desc = torch.cat([all_buf[r, do:do + rows[r] * 32].reshape(-1, 32) for r in range(world)], 0)
+    out = {"kps": kps, "desc": desc, "nq": nq, "cand_all": None, "counts_all": None, "bow": None}
+    if nq:
+        co, ao = lay["counts"][0], lay["cand"][0]
+        out["counts_all"] = torch.stack([all_buf[r, co:co + nq * 4].view(torch.int32) for r in range(world)])
+        out["cand_all"] = torch.stack([all_buf[r, ao:ao + nq * cand_cap * 8].view(torch.int64).reshape(nq, cand_cap) for r in range(world)])
+        if bow_slices is not None and "bow" in lay:
+            bo = lay["bow"][0]
+            out["bow"] = torch.cat([all_buf[r, bo:bo + (bow_slices[r + 1] - bow_slices[r]) * 16].view(torch.int32).reshape(-1, 4) for r in range(world)], 0)
+    return out
+
+
+def gather_messages(buf, group=None):
+    """THE one collective of a frame: all-gather of the fixed-size message buffers -> uint8 [world, total]."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    out = torch.empty((world, buf.numel()), dtype=torch.uint8, device=buf.device)
+    dist.all_gather([out[r] for r in range(world)], buf, group=group)
+    return out
+
+
+class ShardedFrameStream:
+    """One frame stream over all ranks of `group` (BASELINE config 5): pyramid levels sharded, the map's train
+    descriptors sharded into contiguous tiles (rank r holds rows [nt*r/world, nt*(r+1)/world) and nothing else), one fused
+    all-gather per frame.  step(frame) returns the COMPLETE extraction of `frame` and the kNN rows (+ optional BoW triplets) of the
+    PREVIOUS frame — identical on every rank and identical to the single-GPU results.
+
+    tile_index: ucoslam_cv3_amd.knn.Index built over this rank's tile with set_row_offset(first global row).
+    rank / world default to the process group's; tests pass them explicitly and drive local() / finish() themselves."""
+
+    def __init__(self, extractor, params, tile_index, nn: int, max_features: int, cand_cap: int = 64, sorted: bool = False,
+                 vocabulary=None, bow_level: int = 3, group=None, rank: int | None = None, world: int | None = None):
+        self.ext, self.params, self.index, self.nn, self.sorted = extractor, params, tile_index, nn, sorted
+        self.cap, self.maxf, self.voc, self.bow_level, self.group = cand_cap, max_features, vocabulary, bow_level, group
+        if rank is None or world is None:
+            import torch.distributed as dist
+
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        self.rank, self.world = rank, world
+        self.lay = frame_message_layout(max_features, cand_cap, vocabulary is not None)
+        self.prev = None      # (kps, desc) of the previous frame, complete
+        self._buf = None
+        self._slices = None
+
+    def local(self, frame):
+        """This rank's share of step t: its levels of `frame`, its tile's accept lists and its BoW slice for frame t-1 -> message."""
+        import torch
+
+        H, W = frame.shape
+        first, end = level_ranges(W, H, self.params.nOctaveLevels, self.params.scaleFactor, self.world)[self.rank]
+        self.ext.setLevelRange(first, end)
+        try:
+            kps, desc, counts = self.ext.extract_batch(frame[None], self.params)
+        finally:
+            self.ext.setLevelRange(0, -1)
+        if self._buf is None:
+            self._buf = torch.zeros(self.lay["total"], dtype=torch.uint8, device=frame.device)
+        cand = ccounts = bow = None
+        nq, self._slices = 0, None
+        if self.prev is not None:
+            pq = self.prev[1]
+            nq = pq.shape[0]
+            cand, ccounts = self.index.scan_shard(pq, self.nn, self.cap)
+            if self.voc is not None:
+                self._slices = shard_bounds(nq, self.world)
+                bow = self.voc.transform_triplets(pq[self._slices[self.rank]:self._slices[self.rank + 1]], self.bow_level)
+        n_rows = int(counts[0])
+        return pack_frame_message(self._buf, self.lay, kps[0], desc[0], n_rows, cand, ccounts, nq, bow)
+
+    def finish(self, msgs):
+        """msgs: uint8 [world, total] = every rank's message in rank order."""
+        u = unpack_frame_messages(msgs, self.lay, self.world, self.maxf, self.cap, self._slices)
+        result = {"kps": u["kps"], "desc": u["desc"], "prev_indices": None, "prev_distances": None, "prev_bow": u["bow"], "overflow": None}
+        if u["nq"]:
+            idx, dd, ovf = self.index.replay_tiles(self.prev[1], self.nn, u["cand_all"], u["counts_all"], sorted=self.sorted)
+            result.update(prev_indices=idx, prev_distances=dd, overflow=ovf)
+        self.prev = (u["kps"], u["desc"])
+        return result
+
+    def step(self, frame):
+        return self.finish(gather_messages(self.local(frame), self.group))
