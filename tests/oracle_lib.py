@@ -62,8 +62,9 @@ def orb_extract(L, img, maxFeatures=2000, nlevels=8, scaleFactor=1.2, blur=True,
     kps = _np.zeros(cap, KEYPOINT_DTYPE)
     desc = _np.zeros((cap, 32), _np.uint8)
     fn = L.oracle_orb_extract_nonmaxima if nonmaxima else L.oracle_orb_extract
-    fn.restype = I
-    fn.argtypes = [VP, I, I, SZ, I, I, C.c_float, I, VP, VP, I]
+    if fn.argtypes is None:   # set once: bench.py calls this from several threads, and re-assigning argtypes races with a call in flight
+        fn.restype = I
+        fn.argtypes = [VP, I, I, SZ, I, I, C.c_float, I, VP, VP, I]
     img = _np.ascontiguousarray(img)
     n = fn(P(img), img.shape[1], img.shape[0], img.strides[0], maxFeatures, nlevels, scaleFactor, int(blur),
            P(kps), P(desc), cap)
