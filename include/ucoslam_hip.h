@@ -308,6 +308,8 @@ typedef struct uh_match_filter_args {
     const float* F12;               /* row-major 3x3 fundamental matrix or NULL (no epipolar gate) */
     float min_desc_dist, nn_match_ratio;
     int32_t check_orientation, max_octave_diff;
+    /* sizes of the arrays above; > 0: every mapped keypoint index / octave is range-checked (UH_EINVAL), 0: unchecked */
+    int32_t n_query_kpts, n_train_kpts, n_levels;
 } uh_match_filter_args;
 
 int uh_match_filter(const uh_match_filter_args* args, uh_dmatch* out, int cap);

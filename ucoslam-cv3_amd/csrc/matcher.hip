@@ -24,7 +24,8 @@
 
 namespace {
 
-inline float epipolar_sq_dist(const float* kp1, const float* kp2, const float* F) {   // misc.h:72-81, F row-major 3x3
+// squared distance of kp2 from the epipolar line that F assigns to kp1 (misc.h:72-81; F row-major 3x3, float throughout)
+inline float epipolar_sq_dist(const float* kp1, const float* kp2, const float* F) {
     const float a = kp1[0] * F[0] + kp1[1] * F[3] + F[6];
     const float b = kp1[0] * F[1] + kp1[1] * F[4] + F[7];
     const float den = a * a + b * b;
@@ -34,69 +35,96 @@ inline float epipolar_sq_dist(const float* kp1, const float* kp2, const float* F
     return num * num / den;
 }
 
-void remove_unused(std::vector<uh_dmatch>& m) {
-    m.erase(std::remove_if(m.begin(), m.end(), [](const uh_dmatch& x) { return x.trainIdx == -1 || x.queryIdx == -1; }), m.end());
+// ---- one-to-one filter --------------------------------------------------------------------------------------------------------
+// Contract (basictypes/misc.cpp:117-185, both directions): among the matches that share a key (their train index, or their query
+// index) only the one with the smallest distance survives; of several with that same smallest distance the EARLIEST in the list
+// survives; survivors keep their relative order.  Formulated as two flat passes: pass 1 records, per key, the position of the
+// group's stable minimum; pass 2 compacts the list to the positions that are their group's minimum.
+inline int key_of(const uh_dmatch& m, bool by_train) { return by_train ? m.trainIdx : m.queryIdx; }
+
+void keep_best_per_key(std::vector<uh_dmatch>& list, bool by_train) {
+    const int n = (int)list.size();
+    if (n == 0) return;
+    int key_span = 0;
+    for (const uh_dmatch& m : list) key_span = std::max(key_span, key_of(m, by_train) + 1);
+    std::vector<int> group_min(key_span, -1);   // position of the group's stable minimum so far
+    for (int pos = 0; pos < n; pos++) {
+        int& holder = group_min[key_of(list[pos], by_train)];
+        if (holder < 0 || list[pos].distance < list[holder].distance) holder = pos;   // strict '<': an equal later match never displaces
+    }
+    int kept = 0;
+    for (int pos = 0; pos < n; pos++)
+        if (group_min[key_of(list[pos], by_train)] == pos) list[kept++] = list[pos];
+    list.resize(kept);
 }
 
-void filter_ambiguous(std::vector<uh_dmatch>& matches, bool by_train) {
-    if (matches.empty()) return;
-    int maxT = -1;
-    for (const auto& m : matches) maxT = std::max(maxT, by_train ? m.trainIdx : m.queryIdx);
-    std::vector<int> used(maxT + 1, -1);
-    int idx = 0;
-    bool needRemove = false;
-    for (auto& match : matches) {
-        int& key = by_train ? match.trainIdx : match.queryIdx;
-        if (used[key] == -1) used[key] = idx;
-        else {
-            uh_dmatch& other = matches[used[key]];
-            if (other.distance > match.distance) {
-                (by_train ? other.trainIdx : other.queryIdx) = -1;   // annulate the other match
-                used[key] = idx;
-                needRemove = true;
-            } else {
-                key = -1;                                            // annulate this match
-                needRemove = true;
+// ---- orientation consensus ----------------------------------------------------------------------------------------------------
+// Contract (framematcher.cpp:290-316 with computeThreeMaxima :67-108): every match votes with the rotation train.angle - query.angle
+// (wrapped into [0, 360)) for slot round(rotation / 30) of a 30-slot table (slot 30 wraps to 0, so only slots 0..12 ever fill);
+// the three fullest slots win, an earlier slot beating a later one with the same count; the runner-up slots are dropped when they
+// hold less than a tenth of the winner (if the second falls, the third falls with it); matches outside the winning slots go.
+constexpr int kRotSlots = 30;
+
+void keep_dominant_rotations(std::vector<uh_dmatch>& list, const float* t_angle, const float* q_angle) {
+    const int n = (int)list.size();
+    std::vector<unsigned char> slot_of(n);
+    int votes[kRotSlots] = {0};
+    const float per_slot = 1.0f / float(kRotSlots);
+    for (int pos = 0; pos < n; pos++) {
+        float rot = t_angle[list[pos].trainIdx] - q_angle[list[pos].queryIdx];
+        if (rot < 0.0) rot += 360.0f;
+        size_t slot = (size_t)std::round(rot * per_slot);
+        if (slot == (size_t)kRotSlots) slot = 0;
+        slot_of[pos] = (unsigned char)slot;
+        votes[slot]++;
+    }
+    // podium of three: a slot enters at the first rank whose count it strictly exceeds and pushes the lower ranks down
+    int rank_slot[3] = {-1, -1, -1}, rank_votes[3] = {0, 0, 0};
+    for (int slot = 0; slot < kRotSlots; slot++) {
+        for (int r = 0; r < 3; r++) {
+            if (votes[slot] > rank_votes[r]) {
+                for (int d = 2; d > r; d--) { rank_votes[d] = rank_votes[d - 1]; rank_slot[d] = rank_slot[d - 1]; }
+                rank_votes[r] = votes[slot]; rank_slot[r] = slot;
+                break;
             }
         }
-        idx++;
     }
-    if (needRemove) remove_unused(matches);
+    const float tenth = 0.1f * (float)rank_votes[0];
+    if ((float)rank_votes[1] < tenth) rank_slot[1] = rank_slot[2] = -1;
+    else if ((float)rank_votes[2] < tenth) rank_slot[2] = -1;
+    bool winner[kRotSlots] = {false};
+    for (int r = 0; r < 3; r++) if (rank_slot[r] >= 0) winner[rank_slot[r]] = true;
+    int kept = 0;
+    for (int pos = 0; pos < n; pos++)
+        if (winner[slot_of[pos]]) list[kept++] = list[pos];
+    list.resize(kept);
 }
 
-// the tail both matcher types share: filter_ambiguous_train, then the 30-bin orientation histogram keeping the three maxima
-// (framematcher.cpp:288-316 and :504-531)
+// the tail both matcher types share (framematcher.cpp:288-316 and :504-531): one match per train keypoint, then the rotation consensus
 void finish_matches(std::vector<uh_dmatch>& matches, const float* t_angle, const float* q_angle, int check_orientation) {
-    filter_ambiguous(matches, true);
-    if (check_orientation) {
-        std::vector<std::vector<int>> rotHist(30);
-        const float factor = 1.0f / float(rotHist.size());
-        for (size_t midx = 0; midx < matches.size(); midx++) {
-            float rot = t_angle[matches[midx].trainIdx] - q_angle[matches[midx].queryIdx];
-            if (rot < 0.0) rot += 360.0f;
-            size_t bin = (size_t)std::round(rot * factor);
-            if (bin == rotHist.size()) bin = 0;
-            rotHist[bin].push_back((int)midx);
-        }
-        int ind1 = -1, ind2 = -1, ind3 = -1;
-        {   // computeThreeMaxima
-            int max1 = 0, max2 = 0, max3 = 0;
-            for (size_t i = 0; i < rotHist.size(); i++) {
-                const int s = (int)rotHist[i].size();
-                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = (int)i; }
-                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = (int)i; }
-                else if (s > max3) { max3 = s; ind3 = (int)i; }
-            }
-            if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-            else if (max3 < 0.1f * (float)max1) ind3 = -1;
-        }
-        for (int i = 0; i < (int)rotHist.size(); i++) {
-            if (i == ind1 || i == ind2 || i == ind3) continue;
-            for (int midx : rotHist[i]) matches[midx].queryIdx = matches[midx].trainIdx = -1;
-        }
-        remove_unused(matches);
-    }
+    keep_best_per_key(matches, true);
+    if (check_orientation) keep_dominant_rotations(matches, t_angle, q_angle);
 }
+
+// ---- choosing a query row's match from its kNN columns --------------------------------------------------------------------------
+// Contract (framematcher.cpp:248-286).  The columns are visited in the order the index returned them (unsorted heap order: the result
+// depends on it).  A column is considered only while its distance is below the current RIVAL distance; a considered
+// column that passes the gates either becomes the new LEADER (distance strictly below the leader's; the old leader is NOT demoted to
+// rival) or overwrites the rival.  The leader is accepted unless the rival has the query's own octave and the leader is not better
+// than ratio x rival.
+struct RowChoice {
+    float lead_dist, rival_dist = std::numeric_limits<float>::max();
+    int lead_train = -1, rival_octave = -1;
+    explicit RowChoice(float ceiling) : lead_dist(ceiling) {}
+    bool still_open(float dist) const { return dist < rival_dist; }
+    void offer(float dist, int train, int train_octave) {
+        if (dist < lead_dist) { lead_dist = dist; lead_train = train; }
+        else { rival_dist = dist; rival_octave = train_octave; }
+    }
+    bool accepted(int query_octave, float ratio) const {
+        return lead_train >= 0 && !(rival_octave == query_octave && lead_dist > rival_dist * ratio);
+    }
+};
 
 // ------------------------------------------------------------------------------------------------ BoW matcher kernel
 struct BowMatchDev {
@@ -162,7 +190,7 @@ extern "C" {
 int uh_filter_ambiguous(uh_dmatch* matches, int n, int by_train) {
     UH_REQUIRE(n >= 0 && (n == 0 || matches), "uh_filter_ambiguous: bad arguments");
     std::vector<uh_dmatch> v(matches, matches + n);
-    filter_ambiguous(v, by_train != 0);
+    keep_best_per_key(v, by_train != 0);
     std::copy(v.begin(), v.end(), matches);
     return (int)v.size();
 }
@@ -172,35 +200,35 @@ int uh_match_filter(const uh_match_filter_args* a, uh_dmatch* out, int cap) {
     UH_REQUIRE(a->nq >= 0 && a->nn >= 1 && a->indices && a->distances, "uh_match_filter: bad kNN rows");
     UH_REQUIRE(a->q_octave && a->q_angle && a->t_octave && a->t_angle, "uh_match_filter: keypoint arrays missing");
     if (a->F12) UH_REQUIRE(a->q_pt && a->t_pt && a->scale_factors, "uh_match_filter: epipolar gate needs points and scale factors");
+    // sizes of the keypoint arrays, when the caller states them (0 = unchecked, as in round 1): every index is validated before use
+    const int n_train = a->n_train_kpts, n_query = a->n_query_kpts, n_levels = a->n_levels;
     std::vector<uh_dmatch> matches;
-    for (int i = 0; i < a->nq; i++) {
-        float bestDist = a->min_desc_dist, bestDist2 = std::numeric_limits<float>::max();
-        long bestQuery = -1, bestTrain = -1;
-        int octaveBest2 = -1;
-        const int queryIndex = a->map_idx_query ? (int)a->map_idx_query[i] : i;
-        for (int j = 0; j < a->nn; j++) {
-            const float dist = (float)a->distances[(size_t)i * a->nn + j];   // distances.convertTo(CV_32F)
-            if (dist > a->min_desc_dist) continue;
-            if (dist < bestDist2) {
-                const int ti = a->indices[(size_t)i * a->nn + j];
-                // xflann leaves unfilled slots at index -1 (distance 0); the reference would index map_idx_trainkp[-1] here.
-                if (ti < 0) continue;
-                const int trainIdx = a->map_idx_train ? (int)a->map_idx_train[ti] : ti;
-                if (std::abs(a->t_octave[trainIdx] - a->q_octave[queryIndex]) > a->max_octave_diff) continue;
-                if (a->F12) {
-                    const float s = a->scale_factors[a->q_octave[queryIndex]];
-                    if (epipolar_sq_dist(a->t_pt + 2 * (size_t)trainIdx, a->q_pt + 2 * (size_t)queryIndex, a->F12) >= 3.84 * (double)(s * s)) continue;
-                }
-                if (dist < bestDist) { bestDist = dist; bestQuery = queryIndex; bestTrain = trainIdx; }
-                else { bestDist2 = dist; octaveBest2 = a->t_octave[trainIdx]; }
+    for (int row = 0; row < a->nq; row++) {
+        const int query = a->map_idx_query ? (int)a->map_idx_query[row] : row;
+        UH_REQUIRE(n_query <= 0 || (query >= 0 && query < n_query), "uh_match_filter: query keypoint %d outside [0,%d)", query, n_query);
+        const int query_octave = a->q_octave[query];
+        if (a->F12) UH_REQUIRE(n_levels <= 0 || (query_octave >= 0 && query_octave < n_levels), "uh_match_filter: octave %d outside [0,%d)", query_octave, n_levels);
+        RowChoice pick(a->min_desc_dist);
+        const int32_t* cols = a->indices + (size_t)row * a->nn;
+        const int32_t* dists = a->distances + (size_t)row * a->nn;
+        for (int c = 0; c < a->nn; c++) {
+            const float dist = (float)dists[c];                 // the reference converts the distance matrix to float first
+            if (dist > a->min_desc_dist || !pick.still_open(dist)) continue;
+            if (cols[c] < 0) continue;                          // unfilled slot of the index (-1, distance 0): nothing to map
+            const int train = a->map_idx_train ? (int)a->map_idx_train[cols[c]] : cols[c];
+            UH_REQUIRE(n_train <= 0 || (train >= 0 && train < n_train), "uh_match_filter: train keypoint %d outside [0,%d)", train, n_train);
+            const int train_octave = a->t_octave[train];
+            if (std::abs(train_octave - query_octave) > a->max_octave_diff) continue;
+            if (a->F12) {                                       // chi-square gate at the query keypoint's scale: 3.84 * sigma^2
+                const float sigma = a->scale_factors[query_octave];
+                if (epipolar_sq_dist(a->t_pt + 2 * (size_t)train, a->q_pt + 2 * (size_t)query, a->F12) >= 3.84 * (double)(sigma * sigma)) continue;
             }
+            pick.offer(dist, train, train_octave);
         }
-        if (bestQuery != -1) {
-            if (!(octaveBest2 == a->q_octave[bestQuery] && bestDist > bestDist2 * a->nn_match_ratio)) {
-                uh_dmatch m;
-                m.queryIdx = (int)bestQuery; m.trainIdx = (int)bestTrain; m.imgIdx = -1; m.distance = bestDist;
-                matches.push_back(m);
-            }
+        if (pick.accepted(query_octave, a->nn_match_ratio)) {
+            uh_dmatch m;
+            m.queryIdx = query; m.trainIdx = pick.lead_train; m.imgIdx = -1; m.distance = pick.lead_dist;
+            matches.push_back(m);
         }
     }
     finish_matches(matches, a->t_angle, a->q_angle, a->check_orientation);
@@ -238,7 +266,7 @@ static int check_bow_frame(const uh_bow_frame* f, const char* which) {
         if (i) UH_REQUIRE(f->node_ids[i] > f->node_ids[i - 1], "uh_bowmatch_match: %s frame: node ids must ascend (std::map order)", which);
     }
     const int total = f->n_nodes ? f->node_ptr[f->n_nodes] : 0;
-    for (int i = 0; i < total; i++) UH_REQUIRE((int)f->feat_idx[i] < f->n_kpts, "uh_bowmatch_match: %s frame: feature index %u out of range", which, f->feat_idx[i]);
+    for (int i = 0; i < total; i++) UH_REQUIRE(f->feat_idx[i] < (uint32_t)f->n_kpts, "uh_bowmatch_match: %s frame: feature index %u out of range", which, f->feat_idx[i]);   // unsigned compare: 2^31.. must not pass
     return UH_OK;
 }
 

@@ -471,7 +471,11 @@ int uh_projmatch_set_frame(uh_projmatch* h, const uh_proj_frame* f) {
     const int n = f->n_kpts;
     std::vector<float> xy(2 * (size_t)std::max(n, 1));
     std::vector<int> oct(std::max(n, 1));
-    for (int i = 0; i < n; i++) { xy[2 * i] = f->und_kpts[i].x; xy[2 * i + 1] = f->und_kpts[i].y; oct[i] = f->und_kpts[i].octave; }
+    for (int i = 0; i < n; i++) {
+        // the kernel packs a candidate's octave into 4 bits and an int8: anything outside [0,16) would silently corrupt bestLevel / bestLevel2
+        UH_REQUIRE(f->und_kpts[i].octave >= 0 && f->und_kpts[i].octave < 16, "uh_projmatch_set_frame: octave %d of keypoint %d outside [0,16)", f->und_kpts[i].octave, i);
+        xy[2 * i] = f->und_kpts[i].x; xy[2 * i + 1] = f->und_kpts[i].y; oct[i] = f->und_kpts[i].octave;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     h->kd.build(xy.data(), n);
     if (getenv("UH_PM_TIMING")) fprintf(stderr, "kd build: %.1f us (n=%d, depth %d, nodes %zu)\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), n, h->kd.max_depth, h->kd.nodes.size());

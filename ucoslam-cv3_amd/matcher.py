@@ -28,7 +28,8 @@ class _Args(C.Structure):
     _fields_ = [("nq", C.c_int32), ("nn", C.c_int32), ("indices", VP), ("distances", VP), ("map_idx_query", VP), ("map_idx_train", VP),
                 ("q_octave", VP), ("q_angle", VP), ("q_pt", VP), ("t_octave", VP), ("t_angle", VP), ("t_pt", VP),
                 ("scale_factors", VP), ("F12", VP), ("min_desc_dist", C.c_float), ("nn_match_ratio", C.c_float),
-                ("check_orientation", C.c_int32), ("max_octave_diff", C.c_int32)]
+                ("check_orientation", C.c_int32), ("max_octave_diff", C.c_int32),
+                ("n_query_kpts", C.c_int32), ("n_train_kpts", C.c_int32), ("n_levels", C.c_int32)]
 
 
 class _BowFrame(C.Structure):
@@ -81,7 +82,8 @@ def match_filter(indices, distances, query, train, map_q=None, map_t=None, min_d
                  arr(map_t, np.uint32) if map_t is not None else None, arr(query["octave"], np.int32), arr(query["angle"], np.float32),
                  arr(query["pt"], np.float32), arr(train["octave"], np.int32), arr(train["angle"], np.float32), arr(train["pt"], np.float32),
                  arr(query["scaleFactors"], np.float32), arr(F12, np.float32) if F12 is not None else None,
-                 float(min(min_desc_dist, np.finfo(np.float32).max)), float(nn_match_ratio), int(check_orientation), int(max_octave_diff))
+                 float(min(min_desc_dist, np.finfo(np.float32).max)), float(nn_match_ratio), int(check_orientation), int(max_octave_diff),
+                 len(query["octave"]), len(train["octave"]), len(query["scaleFactors"]))   # sizes: every mapped index is range-checked
     out = np.zeros(max(nq, 1), DMATCH_DTYPE)
     n = lib().uh_match_filter(C.byref(args), np_ptr(out), len(out))
     if n < 0:
