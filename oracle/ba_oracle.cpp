@@ -13,7 +13,7 @@
 //   3rdparty/g2o/g2o/core/robust_kernel_impl.cpp:65-78 Huber
 //   3rdparty/g2o/g2o/types/slam3d/se3quat.h:276-311    SE3 exponential, quaternion product + normalisation
 // The reduced pose system is solved with a dense LDL^T (g2o: Eigen SimplicialLDLT — same factorisation up to ordering).
-// Pinned against the real g2o build (oracle/_ref/libg2o_ref.so) by tests/test_ba_oracle.py (tolerance, not bit-exact:
+// Pinned against the real g2o build (oracle/_ref/libg2o_ref.so) by tests/test_ba.py (tolerance, not bit-exact:
 // floating-point summation order differs).
 #include <algorithm>
 #include <cmath>
@@ -122,6 +122,21 @@ bool inv3(const double* M, double* Inv) {   // Eigen 3x3 inverse (cofactors / de
     return true;
 }
 
+// EdgeSE3ProjectXYZ::linearizeOplus (typesg2o.h:275-314): A = d e / d X (2x3), B = d e / d pose (2x6: rotation first, then
+// translation) at camera-frame point pc = R X + t.  Checked against central differences of the error in tests/test_ba.py
+// (oracle_ba_edge_eval below).
+inline void edge_jacobians(const double* Rk, const double pc[3], double fx, double fy, double A[6], double B[12]) {
+    const double x = pc[0], y = pc[1], z = pc[2], z2 = z * z;
+    // Ji (2x3) = -1/z * [fx 0 -x/z fx; 0 fy -y/z fy] * R
+    const double t0[3] = {fx, 0, -x / z * fx}, t1[3] = {0, fy, -y / z * fy};
+    for (int c = 0; c < 3; c++) {
+        A[c] = -1. / z * (t0[0] * Rk[c] + t0[1] * Rk[3 + c] + t0[2] * Rk[6 + c]);
+        A[3 + c] = -1. / z * (t1[0] * Rk[c] + t1[1] * Rk[3 + c] + t1[2] * Rk[6 + c]);
+    }
+    B[0] = x * y / z2 * fx; B[1] = -(1 + (x * x / z2)) * fx; B[2] = y / z * fx; B[3] = -1. / z * fx; B[4] = 0; B[5] = x / z2 * fx;
+    B[6] = (1 + y * y / z2) * fy; B[7] = -x * y / z2 * fy; B[8] = -x / z * fy; B[9] = 0; B[10] = -1. / z * fy; B[11] = y / z2 * fy;
+}
+
 struct BA {
     int K = 0, P = 0, E = 0;
     std::vector<Pose> pose;
@@ -181,18 +196,8 @@ struct BA {
             const double* Rk = &R[9 * k];
             double pc[3];
             pose_map(pose[k], Rk, &pts[3 * p], pc);
-            const double x = pc[0], y = pc[1], z = pc[2], z2 = z * z;
-            const double fx = intr[4 * k], fy = intr[4 * k + 1];
-            // Ji (2x3) = -1/z * [fx 0 -x/z fx; 0 fy -y/z fy] * R
-            const double t0[3] = {fx, 0, -x / z * fx}, t1[3] = {0, fy, -y / z * fy};
-            double A[6];
-            for (int c = 0; c < 3; c++) {
-                A[c] = -1. / z * (t0[0] * Rk[c] + t0[1] * Rk[3 + c] + t0[2] * Rk[6 + c]);
-                A[3 + c] = -1. / z * (t1[0] * Rk[c] + t1[1] * Rk[3 + c] + t1[2] * Rk[6 + c]);
-            }
-            double B[12];
-            B[0] = x * y / z2 * fx; B[1] = -(1 + (x * x / z2)) * fx; B[2] = y / z * fx; B[3] = -1. / z * fx; B[4] = 0; B[5] = x / z2 * fx;
-            B[6] = (1 + y * y / z2) * fy; B[7] = -x * y / z2 * fy; B[8] = -x / z * fy; B[9] = 0; B[10] = -1. / z * fy; B[11] = y / z2 * fy;
+            double A[6], B[12];
+            edge_jacobians(Rk, pc, intr[4 * k], intr[4 * k + 1], A, B);
             double w = e_w[e];
             double rho1 = 1.0;
             if (e_robust[e]) { const double c = e_chi2[e]; if (c > dsqr) rho1 = delta / std::sqrt(c); }
@@ -442,3 +447,21 @@ int oracle_ba_optimize(int K, int P, int E, const float* poses_f2g, const uint8_
 }
 
 }  // extern "C"
+
+// One EdgeSE3ProjectXYZ at the state (exp(dpose) * T, X + dX): error (computeError, typesg2o.h:260-273) and the analytic Jacobians the
+// optimisation uses.  dpose / dX may be NULL (= zero).  pose7 = qx qy qz qw tx ty tz.  Test hook: central-difference Jacobian check.
+extern "C" void oracle_ba_edge_eval(const double* pose7, const double* X, const double* intr4, const double* uv, const double* dpose,
+                                    const double* dX, double* err2, double* A6, double* B12) {
+    Pose T;
+    for (int i = 0; i < 4; i++) T.q[i] = pose7[i];
+    for (int i = 0; i < 3; i++) T.t[i] = pose7[4 + i];
+    if (dpose) pose_oplus(T, dpose);
+    double Xp[3] = {X[0], X[1], X[2]};
+    if (dX) for (int i = 0; i < 3; i++) Xp[i] += dX[i];
+    double R[9], pc[3];
+    quat_to_R(T.q, R);
+    pose_map(T, R, Xp, pc);
+    err2[0] = uv[0] - ((pc[0] / pc[2]) * intr4[0] + intr4[2]);
+    err2[1] = uv[1] - ((pc[1] / pc[2]) * intr4[1] + intr4[3]);
+    if (A6 && B12) edge_jacobians(R, pc, intr4[0], intr4[1], A6, B12);
+}

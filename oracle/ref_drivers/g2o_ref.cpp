@@ -9,7 +9,7 @@
 // BlockSolver_6_3 + LinearSolverEigen + OptimizationAlgorithmLevenberg, Huber sqrt(5.99), info = I/scaleFactor[octave],
 // optimize(nIters,1) -> relabel chi2>5.99 / depth<=0 to level 1, drop kernels -> optimize(2*nIters,1).
 // Everything numerical that matters for parity (LM control, Schur complement, LDLT, robustification, SE3 exp) is the
-// reference's code; the edge Jacobian is cross-checked by finite differences in tests/test_ba_oracle.py.
+// reference's code; the edge Jacobian is cross-checked by central differences in tests/test_ba.py (test_oracle_edge_jacobian_central_differences).
 #include <cmath>
 #include <cstdint>
 #include <cstring>

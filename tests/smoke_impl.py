@@ -20,6 +20,13 @@ def run():
     torch.cuda.synchronize()
     ri, rd = oracle_lib.knn_search(L, train, q, 2, 1)
     assert (idx.cpu().numpy() == ri).all() and (dist.cpu().numpy() == rd).all(), "kNN mismatch vs oracle"
+    # ... and against rows recorded from the REAL xflann (tests/golden/knn_golden.npz): the unsorted heap order included
+    import os
+
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "knn_golden.npz"))
+    gi, gd = Index(ctx).build(torch.from_numpy(g["ties_train"]).cuda()).search(torch.from_numpy(g["ties_q"]).cuda(), 10, sorted=False)
+    assert (gi.cpu().numpy() == g["ties_nn10_s0_idx"]).all() and (gd.cpu().numpy() == g["ties_nn10_s0_dist"]).all(), "kNN rows differ from the real xflann's"
     # --- ORB extractor (small frame, full pipeline) — bit-exact keypoints + descriptors
     from ucoslam_cv3_amd.orb import FeatParams, ORBextractor
 
@@ -42,6 +49,14 @@ def run():
     ref = oracle_lib.ba_optimize(L, pr, 5)
     assert got["iters"].tolist() == ref["iters"].tolist()
     assert np.abs(got["state"] - ref["state"]).max() < 1e-6, "BA pose state differs from the oracle by more than 1e-6"
+    # ... and against the result of the REAL g2o on the committed problem (tests/golden/ba_golden.npz)
+    gb = np.load(os.path.join(gold, "ba_golden.npz"))
+    gpr = {k[3:]: gb[k] for k in gb.files if k.startswith("in_")}
+    opt.setParams(gpr, ParamSet(nIters=5))
+    opt.optimize()
+    gg = opt.getResults()
+    assert gg["iters"].tolist() == gb["ref_iters"].tolist() and np.abs(gg["state"] - gb["ref_state"]).max() < 1e-6 and (gg["bad"] == gb["ref_bad"]).all(), \
+        "BA differs from the real g2o's result"
     # --- per-frame pose-only solve
     from ucoslam_cv3_amd.pnp import PnPSolver
 

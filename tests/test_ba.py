@@ -14,6 +14,15 @@ def _se3_rmse(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)))
 
 
+def _assert_bad_flags_equal_up_to_the_boundary(got, ref, chi2_th=5.99):
+    """Bad-association flags (chi2 > 5.99 or point behind the camera, globaloptimizer_g2o.cpp:497-521) must be IDENTICAL, except for
+    an observation whose chi2 lies within the stated chi2 tolerance (1e-6 relative) of the 5.99 boundary itself — there the flag is
+    decided by the last bits of a sum whose order differs between the two implementations."""
+    diff = np.nonzero(got["bad"] != ref["bad"])[0]
+    on_boundary = np.abs(ref["chi2"][diff] - chi2_th) <= 1e-6 * (1 + chi2_th)
+    assert on_boundary.all(), f"{(~on_boundary).sum()} bad-association flags differ away from the chi2 = {chi2_th} boundary"
+
+
 def test_oracle_matches_real_g2o(oracle):
     ref = oracle_lib.load_ref("g2o")
     if ref is None:
@@ -26,7 +35,7 @@ def test_oracle_matches_real_g2o(oracle):
         assert np.abs(a["state"] - b["state"]).max() < 1e-9
         assert np.abs(a["points"] - b["points"]).max() < 1e-5
         assert np.abs(a["chi2"] - b["chi2"]).max() < 1e-6 * (1 + np.abs(b["chi2"]).max())
-        assert (a["bad"] == b["bad"]).mean() > 0.9999
+        _assert_bad_flags_equal_up_to_the_boundary(a, b)
         # and the optimisation did its job
         gt = pr["poses_gt"][:, :3, 3]
         err0 = np.abs(pr["poses"].reshape(-1, 4, 4)[:, :3, 3] - gt).max()
@@ -48,15 +57,48 @@ def test_oracle_golden_from_real_g2o(oracle):
     assert np.abs(a["points"] - g["ref_points"]).max() < 1e-5
 
 
-def test_oracle_edge_jacobian_finite_differences(oracle):
-    """The analytic Jacobians (typesg2o.h:275-314) against central differences of the error, via one LM-free evaluation:
-    a single Gauss-Newton-like probe is not exposed, so check convergence order instead — with exact Jacobians LM reaches
-    the noise floor in the iteration budget from a 10x larger perturbation."""
-    pr = synth.ba_problem(6, 300, 7, pose_noise=0.03, point_noise=0.15, outlier_frac=0.0)
-    a = oracle_lib.ba_optimize(oracle, pr, 10)
-    gt = pr["poses_gt"][:, :3, 3]
-    assert np.abs(a["poses"].reshape(-1, 4, 4)[:, :3, 3] - gt).max() < 0.02
-    assert a["bad"].mean() < 0.02
+def test_oracle_edge_jacobian_central_differences(oracle):
+    """The analytic Jacobians of EdgeSE3ProjectXYZ (typesg2o.h:275-314) as the oracle evaluates them (oracle_ba_edge_eval = the
+    function build_system calls) against central differences of computeError: d e / d X with X + h e_i, d e / d pose with
+    exp(h e_i) * T (VertexSE3Expmap::oplusImpl: rotation components first, then translation)."""
+    import ctypes as C
+
+    VP = oracle_lib.VP
+    oracle.oracle_ba_edge_eval.restype = None
+    oracle.oracle_ba_edge_eval.argtypes = [VP] * 9
+    P = oracle_lib.P
+    rng = np.random.default_rng(5)
+
+    def ev(pose, X, intr, uv, dpose=None, dX=None, jac=False):
+        e, A, B = np.zeros(2), np.zeros(6), np.zeros(12)
+        oracle.oracle_ba_edge_eval(P(pose), P(X), P(intr), P(uv), P(dpose) if dpose is not None else None, P(dX) if dX is not None else None,
+                                   P(e), P(A) if jac else None, P(B) if jac else None)
+        return e, A.reshape(2, 3), B.reshape(2, 6)
+
+    worst = 0.0
+    for _ in range(200):
+        q = rng.standard_normal(4); q /= np.linalg.norm(q)
+        if q[3] < 0:
+            q = -q
+        pose = np.r_[q, rng.uniform(-2, 2, 3)]
+        Rm = np.array([[1 - 2 * (q[1] ** 2 + q[2] ** 2), 2 * (q[0] * q[1] - q[2] * q[3]), 2 * (q[0] * q[2] + q[1] * q[3])],
+                       [2 * (q[0] * q[1] + q[2] * q[3]), 1 - 2 * (q[0] ** 2 + q[2] ** 2), 2 * (q[1] * q[2] - q[0] * q[3])],
+                       [2 * (q[0] * q[2] - q[1] * q[3]), 2 * (q[1] * q[2] + q[0] * q[3]), 1 - 2 * (q[0] ** 2 + q[1] ** 2)]])
+        pc = np.array([rng.uniform(-3, 3), rng.uniform(-2, 2), rng.uniform(2, 30)])      # in front of the camera
+        X = Rm.T @ (pc - pose[4:])
+        intr = np.array([718.856, 718.856, 607.19, 185.22])
+        uv = rng.uniform(0, 1000, 2)
+        e0, A, B = ev(pose, X, intr, uv, jac=True)
+        h = 1e-6
+        for i in range(3):
+            d = np.zeros(3); d[i] = h
+            num = (ev(pose, X, intr, uv, dX=d)[0] - ev(pose, X, intr, uv, dX=-d)[0]) / (2 * h)
+            worst = max(worst, np.abs(num - A[:, i]).max() / (1 + np.abs(A[:, i]).max()))
+        for i in range(6):
+            d = np.zeros(6); d[i] = h
+            num = (ev(pose, X, intr, uv, dpose=d)[0] - ev(pose, X, intr, uv, dpose=-d)[0]) / (2 * h)
+            worst = max(worst, np.abs(num - B[:, i]).max() / (1 + np.abs(B[:, i]).max()))
+    assert worst < 2e-6, worst          # central differences with h = 1e-6 in fp64: truncation ~h^2, round-off ~1e-10/h
 
 
 # ------------------------------------------------------------------------------------------------ GPU
@@ -79,7 +121,7 @@ def test_hip_ba_matches_oracle(hip_ctx, oracle, cfg):
     assert np.abs(got["poses"] - ref["poses"]).max() < 1e-5          # float32 outputs
     assert np.abs(got["points"] - ref["points"]).max() < 1e-4
     assert np.abs(got["chi2"] - ref["chi2"]).max() < 1e-6 * (1 + np.abs(ref["chi2"]).max())
-    assert (got["bad"] == ref["bad"]).mean() > 0.9995
+    _assert_bad_flags_equal_up_to_the_boundary(got, ref)
     # fixed frames come back untouched (getResults skips them)
     np.testing.assert_array_equal(got["poses"][pr["fixed"] == 1], pr["poses"][pr["fixed"] == 1])
     # re-running from the same snapshot is deterministic
@@ -111,7 +153,7 @@ def test_hip_ba_wide_form_matches_oracle(hip_ctx, oracle, cfg, monkeypatch):
     assert np.abs(got["state"] - ref["state"]).max() < POSE_TOL, np.abs(got["state"] - ref["state"]).max()
     assert np.abs(got["poses"] - ref["poses"]).max() < 1e-5
     assert np.abs(got["points"] - ref["points"]).max() < 1e-4
-    assert (got["bad"] == ref["bad"]).mean() > 0.9995
+    _assert_bad_flags_equal_up_to_the_boundary(got, ref)
     np.testing.assert_array_equal(got["poses"][pr["fixed"] == 1], pr["poses"][pr["fixed"] == 1])
     opt.optimize()
     np.testing.assert_array_equal(opt.getResults()["state"], got["state"])
