@@ -217,7 +217,8 @@ typedef struct uh_ba_problem {
     const int32_t* obs_point;       /* n_obs */
     const int32_t* obs_frame;       /* n_obs */
     const float*   obs_uv;          /* n_obs x 2 */
-    const double*  obs_inv_sigma;   /* n_obs */
+    const double*  obs_inv_sigma;   /* n_obs: (double)_InvScaleFactors[octave], i.e. (double)(float)(1. / scaleFactor[octave]) — the reference stores
+                                     * the inverse scale factors as float (globaloptimizer_g2o.h:76), g2o sees that value widened */
 } uh_ba_problem;
 
 typedef struct uh_ba_params {

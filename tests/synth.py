@@ -85,6 +85,14 @@ def _se3_exp(d):
     return T
 
 
+def _scale_f32(octave, scale_factor=1.2):
+    """Frame::scaleFactors[octave]: the float chain 1, 1.2f, 1.2f*1.2f, ... (ORBextractor.cpp:468-475)."""
+    s = np.float32(1.0)
+    for _ in range(octave):
+        s = np.float32(s * np.float32(scale_factor))
+    return s
+
+
 def ba_problem(K=10, P=3000, seed=0, nfixed=2, outlier_frac=0.02, pose_noise=0.01, point_noise=0.05, pix_noise=0.5,
                w=1241, h=376):
     """Synthetic local BA: K keyframes on a line (baseline 0.3 m), KITTI intrinsics, P points in front,
@@ -111,7 +119,7 @@ def ba_problem(K=10, P=3000, seed=0, nfixed=2, outlier_frac=0.02, pose_noise=0.0
                 noise = rng.normal(0, pix_noise, 2)
                 if rng.random() < outlier_frac:
                     noise += rng.normal(0, 25, 2)
-                obs_pt.append(p); obs_kf.append(k); obs_uv.append([u + noise[0], v + noise[1]]); obs_w.append(1.0 / (1.2 ** octave))
+                obs_pt.append(p); obs_kf.append(k); obs_uv.append([u + noise[0], v + noise[1]]); obs_w.append(float(np.float32(1.0 / float(_scale_f32(octave)))))   # (double)(float)(1./f): the reference's vector<float> _InvScaleFactors
     poses = []
     fixed = np.zeros(K, np.uint8)
     fixed[:nfixed] = 1

@@ -402,8 +402,10 @@ constexpr int kKmWaves = 2;        // waves (queries) per workgroup: 2 x 16 KB o
 struct BranchHeapLds {
     int* d; unsigned int* o;   // [cap] each, per wave; cap = min(kBranchMax, worst case of this search), sized by the host
     int size;
+    int cap;                   // the LDS region really holds `cap` entries: a push beyond it is dropped (== the reference whenever cap == kBranchMax,
+                               // and never an overrun into the neighbouring wave's heap should the host's worst-case bound ever be too small)
     __device__ __forceinline__ void push(int dist, unsigned int off) {   // heap.h push + "down"
-        if (size >= kBranchMax) return;
+        if (size >= cap) return;
         int i = size;
         while (i != 0) {
             const int p = (i - 1) >> 1;
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(kWave* kKmWaves) void knn_kmeans_search_kernel(
     uint32_t q[8];
     load_query(queries, qi, q);
     WaveHeap h{0, -1, 0, lane};
-    BranchHeapLds bh{s_heap + (size_t)wv * 2 * cap, reinterpret_cast<unsigned int*>(s_heap + (size_t)wv * 2 * cap + cap), 0};
+    BranchHeapLds bh{s_heap + (size_t)wv * 2 * cap, reinterpret_cast<unsigned int*>(s_heap + (size_t)wv * 2 * cap + cap), 0, cap};
     bh.push(0, 0u);
     int nchecks = 0, ncand = 0;
     while (nchecks < max_checks && bh.size != 0) {

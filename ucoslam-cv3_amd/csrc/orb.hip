@@ -649,19 +649,24 @@ __global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const ui
     // libm's cosf/sinf, bit for bit (glibc_sincosf.hpp): a correctly rounded cosine differs from them in the last bit often
     // enough to flip a descriptor bit every few million descriptors
     const float a = uh_sincosf::cosf_glibc(ang), b = uh_sincosf::sinf_glibc(ang);
-    int nib = 0;
+    // lane t evaluates tests t, 64 + t, 128 + t, 192 + t: the ballot of round j IS descriptor word j (bit i of byte b = test 8b + i,
+    // ORBextractor.cpp:129-150), so a keypoint's 32 bytes leave as four 8-byte stores from lanes 0..3 instead of 32 single-byte stores
+    // (round 1: WRITE_SIZE 37x the algorithmic bytes of this kernel)
+    unsigned long long word[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const signed char* p = d_pattern + (lane * 4 + j) * 4;
+        const signed char* p = d_pattern + (64 * j + lane) * 4;
         const int x0 = p[0], y0 = p[1], x1 = p[2], y1 = p[3];
         const int r0 = (int)rintf((float)x0 * b + (float)y0 * a), c0 = (int)rintf((float)x0 * a - (float)y0 * b);
         const int r1 = (int)rintf((float)x1 * b + (float)y1 * a), c1 = (int)rintf((float)x1 * a - (float)y1 * b);
         const int t0 = center[(ptrdiff_t)r0 * L.pitch + c0], t1 = center[(ptrdiff_t)r1 * L.pitch + c1];
-        nib |= (t0 < t1) << j;
+        word[j] = __ballot(t0 < t1);
     }
-    const int hi = __shfl_down(nib, 1);
     const size_t o = (size_t)frame * cap_per_frame + slot;
-    if ((lane & 1) == 0) desc[o * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+    if (lane < 4) {
+        const unsigned long long w = lane == 0 ? word[0] : (lane == 1 ? word[1] : (lane == 2 ? word[2] : word[3]));
+        reinterpret_cast<unsigned long long*>(desc + o * 32)[lane] = w;
+    }
     if (lane == 0) {
         KeyPointOut k;
         k.x = (float)cx; k.y = (float)cy;
@@ -712,6 +717,7 @@ struct uh_orb {
     bool blur_first = true;        // ORBextractor::doGaussianBlur()
     bool nonmaxima = false;        // debug::Debug::isString("orb_nonmaxima") (ORBextractor.cpp:1146-1148)
     bool nm_attr = false;
+    bool sel_attr = false;         // select_kernel's dynamic-LDS attribute has been set on this context's device
     int lvl_first = 0, lvl_end = -1;   // pyramid-level shard [first, end) this instance extracts (end < 0: all levels)
     int iniTh = 20, minTh = 7;     // precalculateParams resets these on every parameter change (:478-479)
     Plan plan;
@@ -846,9 +852,12 @@ int make_plan(uh_orb* o, int w, int h, int batch) {
     o->cand_stride = cand_off;
     o->sel_stride = sel_off;
     o->lds_entries = 24576;   // 96 KiB of dynamic LDS: selection workspace + partition scratch (one workgroup per level)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, o->lds_entries * 4);
     int rc;
-    UH_HIP_CHECK(hipSetDevice(o->ctx->device));
+    UH_HIP_CHECK(hipSetDevice(o->ctx->device));   // first: the attribute below belongs to the context's device, not to whatever the calling thread had current
+    if (!o->sel_attr) {   // once per object
+        UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, o->lds_entries * 4));
+        o->sel_attr = true;
+    }
     hipStream_t st = o->ctx->stream;
     auto up = [&](uh::DevBuf& b, const void* src, size_t bytes) -> int {
         int r = b.reserve(std::max(bytes, (size_t)16));
