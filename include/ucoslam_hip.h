@@ -128,6 +128,12 @@ int uh_knn_replay_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
  * indices"): the index is built over the tile's rows, uh_knn_set_row_offset gives row 0's global index (used by
  * uh_knn_scan_shard_dev), and uh_knn_replay_tiles_dev replays the gathered lists without ever touching train rows — a list
  * that overflowed its cap sets *d_overflow (device int32, zeroed by the caller) instead of being rescanned. */
+/* xflann::Index::toStream / fromStream (index.cpp:153-188) for the hierarchical k-means index: 8-byte signature 12837333433, 8-byte
+ * std::hash<std::string>("kmeans"), then KMeansIndex::toStream (kmeansindex.cpp:209-216) = signature 55824124 + 40-byte params + block
+ * data.  Byte-identical to what the real library writes for the same features (tests/golden/hkmeans_stream_golden.npz); a stream
+ * written by the real library loads and searches identically.  Linear has no stream form in the reference ("Not yet", linear.cpp:78). */
+int uh_knn_to_stream(uh_knn* idx, uint8_t* out, uint64_t cap, uint64_t* size);
+int uh_knn_from_stream(uh_knn* idx, const uint8_t* data, uint64_t nbytes);
 int uh_knn_set_row_offset(uh_knn* idx, int offset);
 int uh_knn_replay_tiles_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int sorted, int max_dist,
                             const uint64_t* d_cand_all, const int32_t* d_counts_all, int nshards, int cap,
@@ -166,6 +172,12 @@ void uh_orb_destroy(uh_orb* orb);
 /* detectAndCompute_impl re-runs precalculateParams when params change (:1142-1145); thresholds reset to 20/7 */
 int  uh_orb_set_params(uh_orb* orb, const uh_feat_params* params);
 int  uh_orb_get_params(const uh_orb* orb, uh_feat_params* params);
+/* Feature2DSerializable::toStream / fromStream (feature2dserializable.cpp:76-113) + ORBextractor::toStream_impl / fromStream_impl
+ * (ORBextractor.cpp:417-423): u64 signature 1828374733, u64 type tag (F2D_ORB = 0), parameter string (u32 length + bytes), raw FeatParams.
+ * to_stream with out == NULL only reports *size.  from_stream fails with the reference's message on a wrong signature and refuses
+ * the grid-extractor type tags. */
+int  uh_orb_to_stream(const uh_orb* orb, const char* str_params, uint8_t* out, uint64_t cap, uint64_t* size);
+int  uh_orb_from_stream(uh_orb* orb, const uint8_t* data, uint64_t nbytes, char* str_params_out, uint64_t str_cap, uint64_t* consumed);
 int  uh_orb_set_blur(uh_orb* orb, int do_blur);            /* ORBextractor::doGaussianBlur() (ORBextractor.h:112) */
 int  uh_orb_set_sensitivity(uh_orb* orb, float v);         /* ORBextractor::setSensitivity (ORBextractor.cpp:457-466) */
 int  uh_orb_set_nonmaxima(uh_orb* orb, int on);            /* debug string "orb_nonmaxima" (ORBextractor.cpp:1146-1148,1176-1205): radius-3

@@ -23,3 +23,13 @@ for nq in (2000, 8000):
         e1.record(); torch.cuda.synchronize()
         chk = int(r[0].sum().item()) ^ int(r[1].sum().item())
         print(f"nq={nq} nn={nn}: {e0.elapsed_time(e1)/30*1000:.1f} us per search  checksum {chk}")
+
+# per-kernel split of the two-phase search (HIP events on the context stream) and the queries-per-wave forms
+for qpw in (1, 2, 4):
+    index.set_queries_per_wave(qpw)
+    for _ in range(3): index.search(dq, 10, sorted=False)
+    ctx.prof_enable(True); ctx.prof_reset()
+    for _ in range(20): index.search(dq, 10, sorted=False)
+    torch.cuda.synchronize()
+    rep = ctx.prof_report(); ctx.prof_enable(False)
+    print(f"qpw={qpw} nq=8000 nn=10:", {k.split('::')[-1]: round(1e3 * v[1] / v[0], 1) for k, v in rep.items()}, "us per launch")

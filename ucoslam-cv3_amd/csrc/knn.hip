@@ -20,6 +20,10 @@
 // the global accept set, in index order).  Replaying the concatenated shard lists through the
 // same push routine reproduces the global heap bit for bit.
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <functional>
+#include <string>
 #include <cstring>
 #include <random>
 #include <vector>
@@ -264,16 +268,178 @@ __device__ __forceinline__ void finish_row(WaveHeap& h, int k, int sorted, int32
 template <int LV>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_search_kernel(
     const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k,
-    int sorted, int maxd, int32_t* __restrict__ indices, int32_t* __restrict__ distances) {
+    int sorted, int maxd, int32_t* __restrict__ indices, int32_t* __restrict__ distances, const int* __restrict__ only) {
     const int lane = threadIdx.x & (kWave - 1);
     const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (qi >= nq) return;
+    if (only && !only[qi]) return;   // second pass of the two-phase search: only the queries whose accept list overflowed
     uint32_t q[8];
     load_query(queries, qi, q);
     WaveHeap h{0, -1, 0, lane};
     int ncand = 0;
     scan_range<false, LV>(h, train, t0, t1, q, k, maxd, nullptr, ncand, 0);
     finish_row(h, k, sorted, indices, distances, qi);
+}
+
+// ------------------------------------------------------------------------------------------------ two-phase exact search (nn <= 16)
+// Round 1 replayed every accepted push on a lane-distributed heap inside the scanning wave: ~1000 cycles of dependent ds_bpermute
+// rounds per push, ~70 pushes per query (nn = 10, 10 000 rows) = 45-60 % of the search.  Here the scan only has to know the
+// THRESHOLD the reference's heap would have — its root when full = the k-th smallest distance seen so far — which needs no heap:
+// the k smallest distances sit one per lane in lanes 0..k-1 (any order), the threshold is their maximum (four DPP row operations,
+// no LDS crossbar), an accepted distance replaces a lane that holds the maximum.  Everything below the threshold at the start of a
+// 64-row step is appended to the query's accept list (a superset of what the reference's heap accepts, in index order; emitted by
+// all passing lanes at once).  Phase 2 replays the lists through the reference's ResultSet (resultset.h:64-135) exactly, ONE LANE
+// PER QUERY on heaps in LDS — 256 queries per workgroup replay in parallel instead of one push at a time per wave.  A list that
+// overflows its capacity (adversarial inputs: distances descending with the row index) sends that query to the one-wave kernel.
+__device__ __forceinline__ int row16_max(int v) {   // afterwards every lane of a 16-lane row holds the row's maximum
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]: lane ^ 1
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]: lane ^ 2
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));   // row_half_mirror: i <-> 7 - i
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true));   // row_mirror: i <-> 15 - i
+    return v;
+}
+
+struct AcceptSet {
+    int sv;     // lanes 0..k-1: the k smallest distances so far (INT_MAX while unfilled); other lanes INT_MIN
+    int thr;    // wave-uniform: max of the members
+    int lane;
+    __device__ __forceinline__ int threshold(int) const { return thr; }
+};
+
+template <bool EMIT, int LV>
+__device__ __forceinline__ void feed_step(AcceptSet& s, int d, int idx, bool valid, int k, int maxd, uint64_t* row, int& ncand, int cap) {
+    const bool pass = valid && (maxd < 0 || d <= maxd) && d < s.thr;
+    uint64_t m = __ballot(pass);
+    if (!m) return;
+    const int pos = ncand + __popcll(m & ((1ull << s.lane) - 1ull));
+    if (pass && pos < cap) row[pos] = ((uint64_t)(uint32_t)d << 32) | (uint32_t)idx;
+    ncand += __popcll(m);
+    while (m) {   // tighten the threshold with the step's passing rows (order does not matter for the set's maximum)
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        const int dl = rl(d, l);
+        if (dl >= s.thr) continue;
+        const int victim = __builtin_ctzll(__ballot(s.sv == s.thr));   // a lane that holds the maximum
+        s.sv = s.lane == victim ? dl : s.sv;
+        s.thr = __builtin_amdgcn_readfirstlane(row16_max(s.sv));
+    }
+}
+
+template <int QPW>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_accept_kernel(
+    const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k, int maxd,
+    uint64_t* __restrict__ cand, int32_t* __restrict__ counts, int cap) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int q0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * QPW);
+    if (q0 >= nq) return;
+    uint32_t q[QPW][8];
+    AcceptSet a[QPW];
+    int nc[QPW];
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) {
+        load_query(queries, q0 + j < nq ? q0 + j : nq - 1, q[j]);
+        a[j] = AcceptSet{lane < k ? 0x7fffffff : (int)0x80000000, 0x7fffffff, lane};
+        nc[j] = 0;
+    }
+    constexpr int UNROLL = 4;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(train), 0, t1 * 32, 0x00020000);
+    const int voff = lane * 32;
+    int base = t0;
+    for (; base + UNROLL * kWave <= t1; base += UNROLL * kWave) {
+        uint4 a0[UNROLL], a1[UNROLL];
+        const int soff = __builtin_amdgcn_readfirstlane(base * 32);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const u32x4 x0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + u * kWave * 32, soff, 0);
+            const u32x4 x1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + u * kWave * 32 + 16, soff, 0);
+            a0[u] = make_uint4(x0.x, x0.y, x0.z, x0.w);
+            a1[u] = make_uint4(x1.x, x1.y, x1.z, x1.w);
+        }
+#pragma unroll
+        for (int j = 0; j < QPW; ++j) {
+            int d[UNROLL];
+            bool any = false;
+            const int thr = a[j].thr;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) { d[u] = hamming256(a0[u], a1[u], q[j]); any = any || d[u] < thr; }
+            if (__ballot(any) == 0) continue;
+            uint64_t* row = cand + (size_t)(q0 + j < nq ? q0 + j : 0) * cap;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) feed_step<true, 0>(a[j], d[u], base + u * kWave + lane, q0 + j < nq, k, maxd, row, nc[j], cap);
+        }
+    }
+    for (; base < t1; base += kWave) {
+        const int t = base + lane;
+        const bool valid = t < t1;
+        uint4 x0 = make_uint4(0, 0, 0, 0), x1 = x0;
+        if (valid) {
+            const uint4* p = reinterpret_cast<const uint4*>(train + (size_t)t * 32);
+            x0 = p[0];
+            x1 = p[1];
+        }
+#pragma unroll
+        for (int j = 0; j < QPW; ++j)
+            feed_step<true, 0>(a[j], hamming256(x0, x1, q[j]), t, valid && q0 + j < nq, k, maxd, cand + (size_t)(q0 + j < nq ? q0 + j : 0) * cap, nc[j], cap);
+    }
+#pragma unroll
+    for (int j = 0; j < QPW; ++j)
+        if (q0 + j < nq && lane == 0) counts[q0 + j] = nc[j];
+}
+
+// Phase 2: one lane per query, the reference's ResultSet on LDS arrays hd / hi [slot][thread] (conflict-free while the lanes of a wave
+// touch the same slot, 2-4-way otherwise); then linear.h:82-85 (fill) + index.h:119-134 (exchange sort) and the row stores.
+constexpr int kRpThreads = 256, kRpK = 16;
+__global__ __launch_bounds__(kRpThreads) void knn_lane_replay_kernel(
+    const uint64_t* __restrict__ cand, const int32_t* __restrict__ counts, int nq, int k, int sorted, int maxd, int cap,
+    int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ redo) {
+    __shared__ int hd[kRpK][kRpThreads], hi[kRpK][kRpThreads];
+    const int t = threadIdx.x;
+    const int qi = blockIdx.x * kRpThreads + t;
+    if (qi >= nq) return;
+    const int cnt = counts[qi];
+    if (cnt > cap) { redo[qi] = 1; return; }
+    redo[qi] = 0;
+    const uint64_t* row = cand + (size_t)qi * cap;
+    int size = 0;
+    auto swp = [&](int x, int y) { const int dx = hd[x][t], ix = hi[x][t]; hd[x][t] = hd[y][t]; hi[x][t] = hi[y][t]; hd[y][t] = dx; hi[y][t] = ix; };
+    uint64_t nxt = cnt > 0 ? row[0] : 0;
+    for (int j = 0; j < cnt; j++) {
+        const uint64_t c = nxt;
+        if (j + 1 < cnt) nxt = row[j + 1];
+        const int d = (int)(c >> 32), idx = (int)(uint32_t)c;
+        if (maxd >= 0 && maxd < d) continue;                      // resultset.h:66
+        if (size >= k) {
+            if (!(d < hd[0][t])) continue;                        // :69
+            swp(0, size - 1);                                     // :70-72
+            size--;
+            if (size > 1) {                                       // up(0), :104-135
+                int i = 0;
+                for (;;) {
+                    const int l = 2 * i + 1, r = l + 1;
+                    if (l >= size) break;
+                    if (r >= size) { if (hd[i][t] < hd[l][t]) swp(i, l); break; }
+                    if (hd[r][t] < hd[l][t]) { if (hd[i][t] < hd[l][t]) { swp(i, l); i = l; } else break; }
+                    else { if (hd[i][t] < hd[r][t]) { swp(i, r); i = r; } else break; }
+                }
+            }
+        }
+        hd[size][t] = d; hi[size][t] = idx;                       // :77-78
+        for (int i = size; i > 0;) {                              // down(size), :93-100
+            const int p = (i - 1) / 2;
+            if (hd[p][t] < hd[i][t]) { swp(i, p); i = p; } else break;
+        }
+        size++;
+    }
+    for (int j = size; j < k; j++) { hd[j][t] = 0; hi[j][t] = -1; }
+    if (sorted) {
+        for (int i = 0; i < k - 1; ++i) {
+            if (hi[i][t] == -1) continue;
+            for (int j = i + 1; j < k; ++j)
+                if (hd[i][t] > hd[j][t]) swp(i, j);
+        }
+    }
+    for (int j = 0; j < k; j++) { indices[(size_t)qi * k + j] = hi[j][t]; distances[(size_t)qi * k + j] = hd[j][t]; }
 }
 
 // QPW queries per wave: a group of train rows is loaded once and scored against QPW queries (their words live in SGPRs): 1/QPW of the
@@ -656,6 +822,8 @@ struct uh_knn {
     int shard_begin = 0, shard_end = 0;
     int row_offset = 0;           // global index of row 0 (uh_knn_set_row_offset): an index that holds only one tile of a sharded train set
     int qpw = 1;                  // queries per wave of the exact search (uh_knn_set_queries_per_wave)
+    bool two_phase = true;        // nn <= 16: accept-list scan + lane-per-query replay (UH_KNN_FORM=wave: the round-1 one-kernel form)
+    uh::DevBuf list_buf;          // accept lists, counts and redo flags of the two-phase search
     uh::DevBuf q_buf, idx_buf, dist_buf;  // staging for the host-pointer API
     // hierarchical k-means form of the same index (uh_knn_build_kmeans)
     std::vector<uint8_t> km_blob;
@@ -670,6 +838,7 @@ int uh_knn_create(uh_ctx* ctx, uh_knn** out) {
     UH_REQUIRE(ctx && out, "uh_knn_create: NULL argument");
     uh_knn* k = new uh_knn();
     k->ctx = ctx;
+    if (const char* f = getenv("UH_KNN_FORM")) k->two_phase = std::string(f) != "wave";
     *out = k;
     return UH_OK;
 }
@@ -761,6 +930,28 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
     // slower (the pushes of a wave's queries serialise), its L1/L2 traffic and its resident waves drop to 1/2 or 1/4, which is what a
     // latency-bound neighbour on another stream (the local BA) needs
     const int qpw = nn <= 15 ? idx->qpw : 1;
+    if (nn <= kRpK && idx->two_phase) {
+        // accept-list capacity: the expected number of accepted pushes is k (1 + ln(N / k)) (a record process), its spread ~ sqrt of
+        // that; lists that still overflow (distances descending with the row index) are redone by the one-wave kernel below
+        const int nrows = std::max(idx->shard_end - idx->shard_begin, 1);
+        const double expect = nn * (1.0 + std::log(std::max((double)nrows / nn, 1.0)));
+        const int cap = std::min(std::max(((int)(1.6 * expect) + 32 + 31) & ~31, 32), std::max((nrows + 31) & ~31, 32));
+        int rc;
+        if ((rc = idx->list_buf.reserve((size_t)nq * cap * 8 + (size_t)nq * 8 + 256))) return rc;
+        uint64_t* d_cand = idx->list_buf.as<uint64_t>();
+        int32_t* d_counts = reinterpret_cast<int32_t*>(d_cand + (size_t)nq * cap);
+        int* d_redo = d_counts + nq;
+        const dim3 ga(uh_div_up(nq, kWavesPerBlock * qpw));
+        if (qpw == 4) UH_LAUNCH(idx->ctx, knn_accept_kernel<4>, ga, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
+        else if (qpw == 2) UH_LAUNCH(idx->ctx, knn_accept_kernel<2>, ga, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
+        else UH_LAUNCH(idx->ctx, knn_accept_kernel<1>, ga, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
+        UH_LAUNCH(idx->ctx, knn_lane_replay_kernel, dim3(uh_div_up(nq, kRpThreads)), dim3(kRpThreads), 0, d_cand, d_counts, nq, nn, sorted ? 1 : 0, max_dist, cap, d_indices, d_distances, d_redo);
+        if (nn <= 3) UH_LAUNCH(idx->ctx, knn_search_kernel<1>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo);
+        else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_search_kernel<3>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo);
+        else UH_LAUNCH(idx->ctx, knn_search_kernel<6>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo);
+        UH_HIP_CHECK(hipGetLastError());
+        return UH_OK;
+    }
     if (qpw > 1) {
         const dim3 gq(uh_div_up(nq, kWavesPerBlock * qpw));
 #define UH_KNN_MQ(LV, Q) UH_LAUNCH(idx->ctx, (knn_search_mq_kernel<LV, Q>), gq, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances)
@@ -768,9 +959,9 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
         else { if (qpw == 2) UH_KNN_MQ(3, 2); else UH_KNN_MQ(3, 4); }
 #undef UH_KNN_MQ
     } else
-    if (nn <= 3) UH_LAUNCH(idx->ctx, knn_search_kernel<1>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances);
-    else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_search_kernel<3>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances);
-    else UH_LAUNCH(idx->ctx, knn_search_kernel<6>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances);
+    if (nn <= 3) UH_LAUNCH(idx->ctx, knn_search_kernel<1>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)nullptr);
+    else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_search_kernel<3>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)nullptr);
+    else UH_LAUNCH(idx->ctx, knn_search_kernel<6>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)nullptr);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
 }
@@ -887,6 +1078,96 @@ int uh_knn_kmeans_build_host(const uint8_t* features, int n, int k, int max_iter
     if (rc) return rc;
     *size = blob.size();
     if (out && cap) std::memcpy(out, blob.data(), (size_t)std::min<uint64_t>(cap, blob.size()));
+    return UH_OK;
+}
+
+// ---- xflann::Index::toStream / fromStream (index.cpp:153-188) for the k-means index: u64 12837333433, u64 std::hash<std::string>("kmeans"),
+// then KMeansIndex::toStream (kmeansindex.cpp:209-216): u64 55824124, the 40-byte params struct, the block data.
+namespace {
+constexpr uint64_t kXflannSig = 12837333433ull, kKmeansSig = 55824124ull;
+struct KmStreamParams {   // KMeansIndex::params (kmeansindex.h:86-93), natural x86-64 layout
+    uint32_t aligment; uint32_t pad0; uint64_t desc_size_bytes_wp; uint64_t total_size; int32_t desc_type; uint32_t desc_size; uint32_t npoints; uint32_t pad1;
+};
+static_assert(sizeof(KmStreamParams) == 40, "KMeansIndex::params layout");
+uint64_t impl_hash(const char* name) { return (uint64_t)std::hash<std::string>()(std::string(name)); }   // libstdc++, like the reference's build
+
+// depth (levels of internal blocks above the deepest leaf block) and largest child count of a block-data blob; false if an offset leaves it
+bool km_blob_shape(const std::vector<uint8_t>& blob, int& depth, int& max_n) {
+    depth = 0; max_n = 0;
+    struct It { uint64_t off; int lvl; };
+    std::vector<It> todo{{0, 0}};
+    size_t visited = 0;
+    while (!todo.empty()) {
+        const It it = todo.back(); todo.pop_back();
+        if (++visited > blob.size() / 8 + 1) return false;                       // a cycle
+        if (it.off + 8 > blob.size()) return false;
+        uint32_t hdr, hs;
+        std::memcpy(&hdr, &blob[it.off], 4); std::memcpy(&hs, &blob[it.off + 4], 4);
+        const int n = (int)(hdr & 0xffffu);
+        const bool leaf = ((hdr >> 16) & 0xffu) != 0;
+        if (n > kWave || it.off + hs + 32ull * n > blob.size() || it.off + 8 + 8ull * n > blob.size()) return false;
+        max_n = std::max(max_n, n);
+        if (leaf) { depth = std::max(depth, it.lvl); continue; }
+        for (int c = 0; c < n; c++) {
+            uint64_t info;
+            std::memcpy(&info, &blob[it.off + 8 + 8ull * c], 8);
+            if (info >> 63) continue;                                            // a row index, not a child block
+            todo.push_back({info, it.lvl + 1});
+        }
+    }
+    return true;
+}
+}  // namespace
+
+int uh_knn_to_stream(uh_knn* idx, uint8_t* out, uint64_t cap, uint64_t* size) {
+    UH_REQUIRE(idx && size, "uh_knn_to_stream: NULL argument");
+    if (idx->km_n == 0 || idx->km_blob.empty()) {
+        // Index::toStream throws for an index that does not own its features; Linear::toStream is "Not yet" in the reference (linear.cpp:78-80)
+        uh::set_error("uh_knn_to_stream: only the hierarchical k-means index has a stream form (xflann: Linear::toStream is not implemented)");
+        return UH_ENOTBUILT;
+    }
+    *size = 64 + idx->km_blob.size();
+    if (!out || cap < *size) return out ? UH_ECAPACITY : UH_OK;
+    KmStreamParams P{};
+    P.aligment = 8; P.desc_size_bytes_wp = 32; P.total_size = idx->km_blob.size(); P.desc_type = 0 /* XFLANN_8U */; P.desc_size = 32; P.npoints = (uint32_t)idx->km_n;
+    const uint64_t h = impl_hash("kmeans");
+    std::memcpy(out, &kXflannSig, 8); std::memcpy(out + 8, &h, 8); std::memcpy(out + 16, &kKmeansSig, 8);
+    std::memcpy(out + 24, &P, 40);
+    std::memcpy(out + 64, idx->km_blob.data(), idx->km_blob.size());
+    return UH_OK;
+}
+
+int uh_knn_from_stream(uh_knn* idx, const uint8_t* data, uint64_t nbytes) {
+    UH_REQUIRE(idx && data, "uh_knn_from_stream: NULL argument");
+    UH_REQUIRE(nbytes >= 16, "uh_knn_from_stream: stream too short");
+    uint64_t sig, h;
+    std::memcpy(&sig, data, 8); std::memcpy(&h, data + 8, 8);
+    UH_REQUIRE(sig == kXflannSig, "Invalid signature in stream");                                       // index.cpp:173
+    if (h == impl_hash("linear") || h == impl_hash("kdtree")) {
+        uh::set_error("uh_knn_from_stream: the stream holds a %s index; only the k-means index is supported (the reference cannot stream Linear either)", h == impl_hash("linear") ? "linear" : "kd-tree");
+        return UH_EINVAL;
+    }
+    UH_REQUIRE(h == impl_hash("kmeans"), "Could not determine the type of implementation from the hash readed");   // index.cpp:184
+    UH_REQUIRE(nbytes >= 64, "uh_knn_from_stream: truncated k-means header");
+    uint64_t sig2;
+    std::memcpy(&sig2, data + 16, 8);
+    UH_REQUIRE(sig2 == kKmeansSig, "XFlann::fromStream invalid signature");                             // kmeansindex.cpp:223 (the reference only constructs the exception)
+    KmStreamParams P;
+    std::memcpy(&P, data + 24, 40);
+    UH_REQUIRE(P.desc_type == 0 && P.desc_size == 32 && P.desc_size_bytes_wp == 32, "uh_knn_from_stream: not a 32-byte binary-descriptor index (type %d, %u bytes)", P.desc_type, P.desc_size);
+    UH_REQUIRE(P.total_size <= nbytes - 64 && P.total_size > 0 && P.npoints > 0, "uh_knn_from_stream: block data truncated (%llu of %llu bytes)", (unsigned long long)(nbytes - 64), (unsigned long long)P.total_size);
+    std::vector<uint8_t> blob(data + 64, data + 64 + P.total_size);
+    int depth = 0, max_n = 0;
+    UH_REQUIRE(km_blob_shape(blob, depth, max_n) && max_n >= 1, "uh_knn_from_stream: inconsistent block data");
+    UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
+    int rc;
+    if ((rc = idx->km_dev.reserve(blob.size() + 64))) return rc;
+    UH_HIP_CHECK(hipMemcpyAsync(idx->km_dev.p, blob.data(), blob.size(), hipMemcpyHostToDevice, idx->ctx->stream));
+    UH_HIP_CHECK(hipStreamSynchronize(idx->ctx->stream));
+    idx->km_blob.swap(blob);
+    idx->km_depth = depth;
+    idx->km_k = std::max(max_n, 2);
+    idx->km_n = (int)P.npoints;
     return UH_OK;
 }
 

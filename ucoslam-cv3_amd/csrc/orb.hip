@@ -966,6 +966,49 @@ int uh_orb_set_params(uh_orb* o, const uh_feat_params* fp) {
     return UH_OK;
 }
 
+// ---- Feature2DSerializable::toStream / fromStream (feature2dserializable.cpp:76-113) for the ORB extractor: u64 signature 1828374733,
+// u64 type tag (F2D_ORB = 0), the parameter string as u32 length + bytes (io_utils: toStream__(std::string)), then
+// ORBextractor::toStream_impl (ORBextractor.cpp:417-419): the raw 20-byte FeatParams.
+int uh_orb_to_stream(const uh_orb* o, const char* str_params, uint8_t* out, uint64_t cap, uint64_t* size) {
+    UH_REQUIRE(o && size, "uh_orb_to_stream: NULL argument");
+    const size_t ls = str_params ? std::strlen(str_params) : 0;
+    *size = 8 + 8 + 4 + ls + sizeof(uh_feat_params);
+    if (!out) return UH_OK;
+    if (cap < *size) { uh::set_error("uh_orb_to_stream: %llu bytes needed, capacity %llu", (unsigned long long)*size, (unsigned long long)cap); return UH_ECAPACITY; }
+    const uint64_t sig = 1828374733ull, type = 0;
+    const uint32_t l32 = (uint32_t)ls;
+    uint8_t* w = out;
+    std::memcpy(w, &sig, 8); w += 8;
+    std::memcpy(w, &type, 8); w += 8;
+    std::memcpy(w, &l32, 4); w += 4;
+    if (ls) { std::memcpy(w, str_params, ls); w += ls; }
+    std::memcpy(w, &o->fp, sizeof(uh_feat_params));
+    return UH_OK;
+}
+
+// Reads such a stream into an existing extractor object.  str_params_out (may be NULL) receives the parameter string, NUL-terminated,
+// truncated to str_cap - 1 characters; *consumed (may be NULL) the number of bytes read.
+int uh_orb_from_stream(uh_orb* o, const uint8_t* data, uint64_t nbytes, char* str_params_out, uint64_t str_cap, uint64_t* consumed) {
+    UH_REQUIRE(o && data, "uh_orb_from_stream: NULL argument");
+    UH_REQUIRE(nbytes >= 20, "uh_orb_from_stream: stream too short");
+    uint64_t sig, type;
+    uint32_t ls;
+    std::memcpy(&sig, data, 8); std::memcpy(&type, data + 8, 8); std::memcpy(&ls, data + 16, 4);
+    UH_REQUIRE(sig == 1828374733ull, "Feature2DSerializable::fromStream signature error in stream");   // feature2dserializable.cpp:91-92
+    // F2D_ORB = 0; the GridExtractor types (AKAZE / BRISK / ORB-grid / FREAK / SURF) are out of scope
+    UH_REQUIRE(type == 0, "uh_orb_from_stream: extractor type %llu is not F2D_ORB (grid extractors are not supported)", (unsigned long long)type);
+    UH_REQUIRE((uint64_t)20 + ls + sizeof(uh_feat_params) <= nbytes, "uh_orb_from_stream: truncated stream");
+    if (str_params_out && str_cap) {
+        const size_t n = std::min<size_t>(ls, (size_t)str_cap - 1);
+        std::memcpy(str_params_out, data + 20, n);
+        str_params_out[n] = 0;
+    }
+    uh_feat_params fp;
+    std::memcpy(&fp, data + 20 + ls, sizeof(fp));
+    if (consumed) *consumed = 20 + ls + sizeof(fp);
+    return uh_orb_set_params(o, &fp);
+}
+
 int uh_orb_get_params(const uh_orb* o, uh_feat_params* fp) {
     UH_REQUIRE(o && fp, "uh_orb_get_params: NULL argument");
     *fp = o->fp;

@@ -96,6 +96,19 @@ class Index:
             return np.zeros(0, np.uint8)
         return np.frombuffer((C.c_char * size.value).from_address(data.value), np.uint8).copy()
 
+    # -- xflann::Index::toStream / fromStream (index.cpp:153-188), k-means index only (Linear has none in the reference) ---------
+    def toStream(self) -> bytes:
+        size = C.c_uint64()
+        check(lib().uh_knn_to_stream(self._h, None, 0, C.byref(size)))
+        out = np.zeros(size.value, np.uint8)
+        check(lib().uh_knn_to_stream(self._h, np_ptr(out), size.value, C.byref(size)))
+        return out.tobytes()
+
+    def fromStream(self, data: bytes):
+        buf = np.frombuffer(data, np.uint8)
+        check(lib().uh_knn_from_stream(self._h, np_ptr(buf), len(buf)))
+        return self
+
     def search_kmeans(self, queries, nn: int, maxChecks: int = 16, sorted: bool = False):
         if _is_torch(queries):
             import torch

@@ -29,6 +29,8 @@ class FeatParams(C.Structure):
 
 
 def _declare(L, sig):
+    sig("uh_orb_to_stream", I, VP, C.c_char_p, VP, C.c_uint64, C.POINTER(C.c_uint64))
+    sig("uh_orb_from_stream", I, VP, VP, C.c_uint64, VP, C.c_uint64, C.POINTER(C.c_uint64))
     sig("uh_orb_create", I, VP, C.POINTER(VP))
     sig("uh_orb_destroy", None, VP)
     sig("uh_orb_set_params", I, VP, C.POINTER(FeatParams))
@@ -130,11 +132,24 @@ class ORBextractor:
         check(lib().uh_orb_debug_level(self._h, frame, level, which, np_ptr(out), C.byref(w), C.byref(h)))
         return out
 
-    # Feature2DSerializable::toStream (feature2dserializable.cpp:76-84) + ORBextractor::toStream_impl (:417-419)
+    # Feature2DSerializable::toStream / fromStream (feature2dserializable.cpp:76-113) + ORBextractor::toStream_impl / fromStream_impl
     def toStream(self, str_params: str = "") -> bytes:
-        fp = self.getParams()
+        size = C.c_uint64()
         sp = str_params.encode()
-        return (struct.pack("<QQ", self.STREAM_SIG, self.F2D_ORB) + struct.pack("<I", len(sp)) + sp + bytes(fp))   # io_utils.cpp:54-58: u32 length + chars
+        check(lib().uh_orb_to_stream(self._h, sp, None, 0, C.byref(size)))
+        out = np.zeros(size.value, np.uint8)
+        check(lib().uh_orb_to_stream(self._h, sp, np_ptr(out), size.value, C.byref(size)))
+        return out.tobytes()
+
+    @staticmethod
+    def fromStream(ctx: _lib.Context, data: bytes):
+        """-> (extractor, str_params, bytes consumed); raises like the reference on a wrong signature."""
+        ext = ORBextractor(ctx)
+        buf = np.frombuffer(data, np.uint8)
+        sp = C.create_string_buffer(4096)
+        used = C.c_uint64()
+        check(lib().uh_orb_from_stream(ext._h, np_ptr(buf), len(buf), sp, len(sp), C.byref(used)))
+        return ext, sp.value.decode(), used.value
 
     def close(self):
         if self._h:
