@@ -1,0 +1,64 @@
+"""Stress of the persistent BA kernel's workgroup hand-offs under UNEVEN load: the committed golden problem (and the bench problem) are
+optimised over and over on one stream while a second stream keeps the chip busy with exact kNN searches and ORB extractions; every
+result must equal the first one bit for bit and match the real g2o's.  usage: python scripts/ba_stress.py [seconds]"""
+import os, sys, threading, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np, torch
+import synth
+import ucoslam_cv3_amd as u
+from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+from ucoslam_cv3_amd.knn import Index
+from ucoslam_cv3_amd.orb import FeatParams, ORBextractor
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+torch.cuda.set_device(0)
+ctx_ba = u.Context(0, private=True)
+ctx_bg = u.Context(0, private=True)
+g = np.load(os.path.join(R, "tests", "golden", "ba_golden.npz"))
+pr = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+big = synth.ba_problem(10, 3000, 0)
+stop = False
+
+
+def background():
+    torch.cuda.set_device(0)
+    train, q = synth.match_set(2000, 10000, seed=0)
+    index = Index(ctx_bg).build(torch.from_numpy(train).cuda())
+    dq = torch.from_numpy(np.concatenate([q] * 4)).cuda()
+    ext = ORBextractor.create(ctx_bg)
+    frames = torch.from_numpy(np.stack([synth.frame(1241, 376, seed=s) for s in range(4)])).cuda()
+    fp = FeatParams(2000, 8, 1.2)
+    i = 0
+    while not stop:
+        if i % 3 == 0:
+            time.sleep(0.0007 * (i % 5))          # uneven: bursts and gaps
+        index.search(dq, 10)
+        ext.extract_batch(frames, fp)
+        i += 1
+    ctx_bg.synchronize()
+
+
+th = threading.Thread(target=background)
+th.start()
+t0 = time.time()
+n, bad = 0, 0
+first = {}
+while time.time() - t0 < budget:
+    for name, prob in (("golden", pr), ("bench", big)):
+        opt = GlobalOptimizer.create(ctx_ba)
+        opt.setParams(prob, ParamSet(nIters=5))
+        opt.optimize()
+        got = opt.getResults()
+        key = (got["state"].tobytes(), got["iters"].tobytes(), got["bad"].tobytes(), got["chi2"].tobytes())
+        if name not in first:
+            first[name] = key
+            if name == "golden":
+                assert got["iters"].tolist() == g["ref_iters"].tolist() and np.abs(got["state"] - g["ref_state"]).max() < 1e-6 and (got["bad"] == g["ref_bad"]).all()
+        elif key != first[name]:
+            bad += 1
+            print(f"run {n} {name}: result differs from the first run: iters {got['iters'].tolist()}", flush=True)
+        n += 1
+stop = True
+th.join()
+print(f"{n} optimisations under load, {bad} differing results")

@@ -32,4 +32,4 @@ for qpw in (1, 2, 4):
     for _ in range(20): index.search(dq, 10, sorted=False)
     torch.cuda.synchronize()
     rep = ctx.prof_report(); ctx.prof_enable(False)
-    print(f"qpw={qpw} nq=8000 nn=10:", {k.split('::')[-1]: round(1e3 * v[1] / v[0], 1) for k, v in rep.items()}, "us per launch")
+    print(f"qpw={qpw} nq=8000 nn=10:", {k.split('::')[-1]: round(1e3 * v[1] / v[0], 1) for k, v in rep.items() if v[0]}, "us per launch")

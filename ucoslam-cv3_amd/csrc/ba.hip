@@ -42,6 +42,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <chrono>
+#include <atomic>
 
 #include "common.hpp"
 #include "reduce.hpp"
@@ -1684,15 +1685,18 @@ int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, 
     q.n1 = n1; q.n2 = n2; q.minChi2 = mc;
     q.stop_at_begin = (b->h_stop && *b->h_stop) ? 1 : 0;
     struct Hold { int g; Hold(int g_) : g(g_) { g_persist_adm.acquire(g); } ~Hold() { g_persist_adm.release(g); } } hold(q.G);
-    UH_HIP_CHECK(hipMemsetAsync(q.flags, 0, sizeof(unsigned) * (q.G + 1), st));
+    static std::atomic<unsigned> s_launch{0};
+    q.launch_id = ++s_launch;   // (never 0: memory that reads as zero carries no valid tag either)
+    UH_HIP_CHECK(hipMemsetAsync(q.flags, 0, sizeof(unsigned long long) * (q.G + 1), st));
     UH_LAUNCH(b->ctx, ba_persist_kernel<8>, dim3(q.G), dim3(kPThreads), (size_t)b->p_lds, b->ptrs, b->dims, q);
     UH_HIP_CHECK(hipGetLastError());
     BAState hs;
     int rc = wait_state(b, &hs, stop_asap);
     if (rc) return rc;
-    unsigned err = 0;
-    UH_HIP_CHECK(hipMemcpyAsync(&err, q.flags + q.G, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    unsigned long long errw = 0;
+    UH_HIP_CHECK(hipMemcpyAsync(&errw, q.flags + q.G, sizeof(errw), hipMemcpyDeviceToHost, st));
     UH_HIP_CHECK(hipStreamSynchronize(st));
+    const bool err = errw == (((unsigned long long)q.launch_id << 32) | 1ull);
     if (err) {
         uh::set_error("uh_ba_optimize: the persistent kernel's workgroups did not all become resident (%d workgroups, %d bytes of LDS each)", q.G, b->p_lds);
         return UH_ENODEVICE;
@@ -1944,7 +1948,7 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
                 const size_t o_fuv = PA.take<double>(2 * (size_t)P * NF), o_fw = PA.take<double>((size_t)P * NF), o_fid = PA.take<int>((size_t)P * NF);
                 const size_t o_xp = PA.take<int>(P + 1), o_xuv = PA.take<double>(2 * nfx + 2), o_xw = PA.take<double>(nfx + 1), o_xkf = PA.take<int>(nfx + 1), o_xid = PA.take<int>(nfx + 1);
                 const size_t o_R0 = PA.take<double>(12 * (size_t)K), o_fixkf = PA.take<int>(fix_kf.size() + 1);
-                const size_t o_part = PA.take<double>((size_t)G * G * q.SL), o_red = PA.take<double>((size_t)G * q.SL), o_pc = PA.take<double>(4 * (size_t)G), o_fl = PA.take<unsigned>(G + 1);
+                const size_t o_part = PA.take<double>((size_t)G * G * q.SL), o_red = PA.take<double>((size_t)G * q.SL), o_pc = PA.take<double>(4 * (size_t)G), o_fl = PA.take<unsigned long long>(G + 1);
                 if ((rc = b->parena.reserve(PA.off + 256))) return rc;
                 char* pb = b->parena.as<char>();
                 auto pup = [&](size_t off, const void* src, size_t bytes) -> int {
@@ -1967,7 +1971,7 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
                 q.fx_kf = (const int*)(pb + o_xkf); q.fx_id = (const int*)(pb + o_xid);
                 q.poseR0 = (const double*)(pb + o_R0); q.fix_kf = (const int*)(pb + o_fixkf);
                 q.pose0 = (const double*)(base + o_pose0); q.pts0 = (const double*)(base + o_pts0);
-                q.part = (double*)(pb + o_part); q.red = (double*)(pb + o_red); q.partC = (double*)(pb + o_pc); q.flags = (unsigned*)(pb + o_fl);
+                q.part = (double*)(pb + o_part); q.red = (double*)(pb + o_red); q.partC = (double*)(pb + o_pc); q.flags = (unsigned long long*)(pb + o_fl);
                 b->p_lds = lay.total_bytes;
                 UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_persist_kernel<NF>), hipFuncAttributeMaxDynamicSharedMemorySize, lay.total_bytes));
                 b->persist = true;

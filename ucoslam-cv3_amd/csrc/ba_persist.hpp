@@ -29,6 +29,7 @@ constexpr long long kPTimeoutTicks = 300000000ll;   // 3 s of the 100 MHz wall c
 struct BAPersist {
     int G, Lw, krows, SL, nelem, max_fix, kfix;
     int n1, n2, stop_at_begin, use_mfma;
+    unsigned launch_id;   // tags every epoch word of this launch: a word left behind by an earlier launch (recycled memory) never satisfies a wait
     float minChi2;
     const double2* fe_uv; const double* fe_w; const int* fe_id;          // P x NF: the free cameras' observations, by (landmark, slot)
     const int* fx_ptr; const double2* fx_uv; const double* fx_w; const int* fx_kf; const int* fx_id;   // CSR of fixed-camera observations (fx_kf: index into fix_kf)
@@ -37,7 +38,7 @@ struct BAPersist {
     double* part;        // [slice][workgroup][SL]
     double* red;         // [G * SL]
     double* partC;       // [G][4]: chi2, scale, (workgroup 0: stop flag), -
-    unsigned* flags;     // [G] epoch of the workgroup's latest publication, [G] = error word
+    unsigned long long* flags;   // [G] (launch id << 32 | epoch) of the workgroup's latest publication, [G] = error word (launch id << 32 | 1)
 };
 
 struct PersistLds {      // offsets in doubles into the dynamic LDS block
@@ -245,6 +246,16 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     bool any_pt = false;
 
     for (int i = tid; i < q.krows * YS; i += kPThreads) Yt[i] = 0.0;
+    // LDS arrives with whatever the previous workgroup on this CU left in it: every word that is read before this kernel writes it must
+    // be cleared here.  With fewer than NF free cameras the lanes of the unused slots read s_x[6 * nfree ..) in the back-substitution
+    // (multiplied by panel zeros, but 0 * NaN = NaN) — found by scripts/ba_stress.py: wrong results only with other kernels' garbage in LDS.
+    for (int i = tid; i < 3 * NP; i += kPThreads) s_x[i] = 0.0;          // s_x, s_bp, s_bs are contiguous
+    for (int i = tid; i < kPWaves * NP; i += kPThreads) s_bsp[i] = 0.0;
+    for (int i = tid; i < NF * 27 + NP + 4; i += kPThreads) s_out[i] = 0.0;
+    for (int i = tid; i < 2 * NF * 7; i += kPThreads) s_pose[i] = 0.0;
+    for (int i = tid; i < 2 * NF * 12; i += kPThreads) s_poseR[i] = 0.0;
+    if (tid < 8) s_sc[tid] = 0.0;
+    __syncthreads();
     for (int i = fb + tid; i < fe; i += kPThreads) {
         s_fxact[i - fb] = 1; s_fxchi[i - fb] = 0.0; s_fxk[i - fb] = (unsigned char)q.fx_kf[i];
         const double2 uv = q.fx_uv[i];
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         ++ep;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(q.flags + g, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(q.flags + g, ((unsigned long long)q.launch_id << 32) | ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto wait_all = [&]() -> bool {   // one wave polls the G epoch words; false: a workgroup never arrived (error word set)
         if (wv == 0) {
@@ -288,13 +299,16 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             bool fail = false;
             for (;;) {
                 bool ok = true;
-                for (int h = lane; h < G; h += 64)
-                    ok = ok && (int)(__hip_atomic_load(q.flags + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ep) >= 0;
+                for (int h = lane; h < G; h += 64) {
+                    const unsigned long long f = __hip_atomic_load(q.flags + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && (unsigned)(f >> 32) == q.launch_id && (int)((unsigned)f - ep) >= 0;   // this launch's word, at or past the epoch
+                }
                 if (__all(ok)) break;
-                if (__hip_atomic_load(q.flags + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > kPTimeoutTicks) { fail = true; break; }
+                if (__hip_atomic_load(q.flags + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (((unsigned long long)q.launch_id << 32) | 1ull) ||
+                    wall_clock64() - t0 > kPTimeoutTicks) { fail = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (fail && lane == 0) { s_flag[1] = 1; __hip_atomic_store(q.flags + G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (fail && lane == 0) { s_flag[1] = 1; __hip_atomic_store(q.flags + G, ((unsigned long long)q.launch_id << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
         __syncthreads();
         return s_flag[1] == 0;
@@ -674,7 +688,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             }
             // ---- back-substitution: dx_l = L^-T (L^-1 b_l - Y_l^T dx_p)
             double t0 = 0, t1 = 0, t2 = 0;
-            if (3 * ll + 2 < q.krows) {
+            if (3 * ll + 2 < q.krows && s < nfree) {
 #pragma unroll
                 for (int a = 0; a < 6; a++) {
                     const double xa = s_x[6 * s + a];

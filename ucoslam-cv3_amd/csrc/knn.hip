@@ -289,8 +289,11 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_search_kernel(
 // no LDS crossbar), an accepted distance replaces a lane that holds the maximum.  Everything below the threshold at the start of a
 // 64-row step is appended to the query's accept list (a superset of what the reference's heap accepts, in index order; emitted by
 // all passing lanes at once).  Phase 2 replays the lists through the reference's ResultSet (resultset.h:64-135) exactly, ONE LANE
-// PER QUERY on heaps in LDS — 256 queries per workgroup replay in parallel instead of one push at a time per wave.  A list that
-// overflows its capacity (adversarial inputs: distances descending with the row index) sends that query to the one-wave kernel.
+// PER QUERY... — that was the plan; measured on MI355X (8000 x 10 000, nn = 10): accept scan 84-94 us (1-2 queries per wave), replay by one
+// lane per query on LDS heaps 174 us (125 single waves, each a ~95-element serial chain of LDS round trips), replay by one WAVE per
+// query on the lane-distributed heap (the multi-GPU replay kernel) 107 us — 190+ us against 162 us for the fused round-1 kernel, whose
+// pushes partly overlap other waves' scans.  The two-phase form therefore stays OFF by default (UH_KNN_FORM=twophase selects accept scan +
+// wave replay); what it does establish is the split of the fused kernel's time: the scan alone is ~85 us, the ~600 k exact pushes ~100 us.
 __device__ __forceinline__ int row16_max(int v) {   // afterwards every lane of a 16-lane row holds the row's maximum
     v = max(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]: lane ^ 1
     v = max(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]: lane ^ 2
@@ -387,60 +390,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_accept_kernel(
         if (q0 + j < nq && lane == 0) counts[q0 + j] = nc[j];
 }
 
-// Phase 2: one lane per query, the reference's ResultSet on LDS arrays hd / hi [slot][thread] (conflict-free while the lanes of a wave
-// touch the same slot, 2-4-way otherwise); then linear.h:82-85 (fill) + index.h:119-134 (exchange sort) and the row stores.
-constexpr int kRpThreads = 256, kRpK = 16;
-__global__ __launch_bounds__(kRpThreads) void knn_lane_replay_kernel(
-    const uint64_t* __restrict__ cand, const int32_t* __restrict__ counts, int nq, int k, int sorted, int maxd, int cap,
-    int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ redo) {
-    __shared__ int hd[kRpK][kRpThreads], hi[kRpK][kRpThreads];
-    const int t = threadIdx.x;
-    const int qi = blockIdx.x * kRpThreads + t;
-    if (qi >= nq) return;
-    const int cnt = counts[qi];
-    if (cnt > cap) { redo[qi] = 1; return; }
-    redo[qi] = 0;
-    const uint64_t* row = cand + (size_t)qi * cap;
-    int size = 0;
-    auto swp = [&](int x, int y) { const int dx = hd[x][t], ix = hi[x][t]; hd[x][t] = hd[y][t]; hi[x][t] = hi[y][t]; hd[y][t] = dx; hi[y][t] = ix; };
-    uint64_t nxt = cnt > 0 ? row[0] : 0;
-    for (int j = 0; j < cnt; j++) {
-        const uint64_t c = nxt;
-        if (j + 1 < cnt) nxt = row[j + 1];
-        const int d = (int)(c >> 32), idx = (int)(uint32_t)c;
-        if (maxd >= 0 && maxd < d) continue;                      // resultset.h:66
-        if (size >= k) {
-            if (!(d < hd[0][t])) continue;                        // :69
-            swp(0, size - 1);                                     // :70-72
-            size--;
-            if (size > 1) {                                       // up(0), :104-135
-                int i = 0;
-                for (;;) {
-                    const int l = 2 * i + 1, r = l + 1;
-                    if (l >= size) break;
-                    if (r >= size) { if (hd[i][t] < hd[l][t]) swp(i, l); break; }
-                    if (hd[r][t] < hd[l][t]) { if (hd[i][t] < hd[l][t]) { swp(i, l); i = l; } else break; }
-                    else { if (hd[i][t] < hd[r][t]) { swp(i, r); i = r; } else break; }
-                }
-            }
-        }
-        hd[size][t] = d; hi[size][t] = idx;                       // :77-78
-        for (int i = size; i > 0;) {                              // down(size), :93-100
-            const int p = (i - 1) / 2;
-            if (hd[p][t] < hd[i][t]) { swp(i, p); i = p; } else break;
-        }
-        size++;
-    }
-    for (int j = size; j < k; j++) { hd[j][t] = 0; hi[j][t] = -1; }
-    if (sorted) {
-        for (int i = 0; i < k - 1; ++i) {
-            if (hi[i][t] == -1) continue;
-            for (int j = i + 1; j < k; ++j)
-                if (hd[i][t] > hd[j][t]) swp(i, j);
-        }
-    }
-    for (int j = 0; j < k; j++) { indices[(size_t)qi * k + j] = hi[j][t]; distances[(size_t)qi * k + j] = hd[j][t]; }
-}
+constexpr int kRpK = 16;   // the two-phase form keeps its k-set in one 16-lane DPP row
 
 // QPW queries per wave: a group of train rows is loaded once and scored against QPW queries (their words live in SGPRs): 1/QPW of the
 // L2 -> CU traffic and 1/QPW of the resident waves of the one-query form; every query keeps its own heap (two VGPRs) and its pushes
@@ -521,6 +471,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_scan_shard_kernel(
 
 // Replay the concatenated shard candidate lists (shard order = index order) through the exact heap.
 // A shard whose list overflowed (count > cap) is rescanned from the descriptors.
+template <int LV>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_replay_kernel(
     const uint8_t* __restrict__ train, ShardBounds sb, const uint8_t* __restrict__ queries, int nq, int k,
     int sorted, int maxd, const uint64_t* __restrict__ cand_all, const int32_t* __restrict__ counts_all, int cap,
@@ -539,7 +490,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_replay_kernel(
             continue;
         }
         if (cnt > cap) {
-            scan_range<false>(h, train, sb.b[s], sb.b[s + 1], q, k, maxd, nullptr, dummy, 0);
+            scan_range<false, LV>(h, train, sb.b[s], sb.b[s + 1], q, k, maxd, nullptr, dummy, 0);
             continue;
         }
         const uint64_t* row = cand_all + ((size_t)s * nq + qi) * cap;
@@ -547,7 +498,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_replay_kernel(
             int j = base + lane;
             bool valid = j < cnt;
             uint64_t c = valid ? row[j] : 0;
-            feed_step<false>(h, (int)(c >> 32), (int)(uint32_t)c, valid, k, maxd, nullptr, dummy, 0);
+            feed_step<false, LV>(h, (int)(c >> 32), (int)(uint32_t)c, valid, k, maxd, nullptr, dummy, 0);
         }
     }
     finish_row(h, k, sorted, indices, distances, qi);
@@ -822,7 +773,7 @@ struct uh_knn {
     int shard_begin = 0, shard_end = 0;
     int row_offset = 0;           // global index of row 0 (uh_knn_set_row_offset): an index that holds only one tile of a sharded train set
     int qpw = 1;                  // queries per wave of the exact search (uh_knn_set_queries_per_wave)
-    bool two_phase = true;        // nn <= 16: accept-list scan + lane-per-query replay (UH_KNN_FORM=wave: the round-1 one-kernel form)
+    bool two_phase = false;       // UH_KNN_FORM=twophase: accept-list scan + separate replay launch (measured slower than the fused form)
     uh::DevBuf list_buf;          // accept lists, counts and redo flags of the two-phase search
     uh::DevBuf q_buf, idx_buf, dist_buf;  // staging for the host-pointer API
     // hierarchical k-means form of the same index (uh_knn_build_kmeans)
@@ -832,13 +783,21 @@ struct uh_knn {
     bool km_attr = false;
 };
 
+// ancestor-walk depth of the lane-distributed heap by nn (see WaveHeap::push_accepted)
+static void launch_replay(uh_knn* idx, dim3 grid, dim3 block, const ShardBounds& sb, const uint8_t* d_queries, int nq, int nn, int sorted, int max_dist,
+                          const uint64_t* d_cand, const int32_t* d_counts, int cap, int32_t* d_indices, int32_t* d_distances, int* d_overflow) {
+    if (nn <= 3) UH_LAUNCH(idx->ctx, knn_replay_kernel<1>, grid, block, 0, idx->d_train, sb, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_cand, d_counts, cap, d_indices, d_distances, d_overflow);
+    else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_replay_kernel<3>, grid, block, 0, idx->d_train, sb, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_cand, d_counts, cap, d_indices, d_distances, d_overflow);
+    else UH_LAUNCH(idx->ctx, knn_replay_kernel<6>, grid, block, 0, idx->d_train, sb, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_cand, d_counts, cap, d_indices, d_distances, d_overflow);
+}
+
 extern "C" {
 
 int uh_knn_create(uh_ctx* ctx, uh_knn** out) {
     UH_REQUIRE(ctx && out, "uh_knn_create: NULL argument");
     uh_knn* k = new uh_knn();
     k->ctx = ctx;
-    if (const char* f = getenv("UH_KNN_FORM")) k->two_phase = std::string(f) != "wave";
+    if (const char* f = getenv("UH_KNN_FORM")) k->two_phase = std::string(f) == "twophase";
     *out = k;
     return UH_OK;
 }
@@ -935,20 +894,23 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
         // that; lists that still overflow (distances descending with the row index) are redone by the one-wave kernel below
         const int nrows = std::max(idx->shard_end - idx->shard_begin, 1);
         const double expect = nn * (1.0 + std::log(std::max((double)nrows / nn, 1.0)));
-        const int cap = std::min(std::max(((int)(1.6 * expect) + 32 + 31) & ~31, 32), std::max((nrows + 31) & ~31, 32));
+        const int cap = std::min(std::min(std::max(((int)(1.6 * expect) + 32 + 31) & ~31, 32), std::max((nrows + 31) & ~31, 32)), 256);   // 64 staged lists of cap + 1 entries must fit in LDS
         int rc;
         if ((rc = idx->list_buf.reserve((size_t)nq * cap * 8 + (size_t)nq * 8 + 256))) return rc;
         uint64_t* d_cand = idx->list_buf.as<uint64_t>();
         int32_t* d_counts = reinterpret_cast<int32_t*>(d_cand + (size_t)nq * cap);
-        int* d_redo = d_counts + nq;
         const dim3 ga(uh_div_up(nq, kWavesPerBlock * qpw));
         if (qpw == 4) UH_LAUNCH(idx->ctx, knn_accept_kernel<4>, ga, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
         else if (qpw == 2) UH_LAUNCH(idx->ctx, knn_accept_kernel<2>, ga, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
         else UH_LAUNCH(idx->ctx, knn_accept_kernel<1>, ga, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
-        UH_LAUNCH(idx->ctx, knn_lane_replay_kernel, dim3(uh_div_up(nq, kRpThreads)), dim3(kRpThreads), 0, d_cand, d_counts, nq, nn, sorted ? 1 : 0, max_dist, cap, d_indices, d_distances, d_redo);
-        if (nn <= 3) UH_LAUNCH(idx->ctx, knn_search_kernel<1>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo);
-        else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_search_kernel<3>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo);
-        else UH_LAUNCH(idx->ctx, knn_search_kernel<6>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo);
+        // phase 2: ONE wave per query replays its list through the lane-distributed ResultSet (the multi-GPU replay kernel with a single
+        // "shard"): the pushes cost what they cost in round 1 (~1000 cycles of dependent cross-lane rounds each), but a wave that only
+        // replays has nothing else to stall, and eight such waves per SIMD hide each other's latency — fused into the scan the same pushes
+        // serialised behind the wave's own loads.  A list that overflowed is rescanned from the rows by that wave.  (Measured and rejected:
+        // one LANE per query on heaps in LDS — 125 single waves each running a ~95-element serial chain: 174 us for 8000 queries.)
+        ShardBounds sb;
+        sb.n = 1; sb.b[0] = idx->shard_begin; sb.b[1] = idx->shard_end;
+        launch_replay(idx, grid, block, sb, d_queries, nq, nn, sorted, max_dist, d_cand, d_counts, cap, d_indices, d_distances, nullptr);
         UH_HIP_CHECK(hipGetLastError());
         return UH_OK;
     }
@@ -1017,8 +979,7 @@ int uh_knn_replay_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
     for (int s = 0; s <= nshards; ++s) sb.b[s] = (int)((long long)idx->nt * s / nshards);
     UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
     dim3 grid(uh_div_up(nq, kWavesPerBlock)), block(kWave * kWavesPerBlock);
-    UH_LAUNCH(idx->ctx,knn_replay_kernel, grid, block, 0, idx->d_train, sb, d_queries, nq, nn,
-                       sorted ? 1 : 0, max_dist, d_cand_all, d_counts_all, cap, d_indices, d_distances, (int*)nullptr);
+    launch_replay(idx, grid, block, sb, d_queries, nq, nn, sorted, max_dist, d_cand_all, d_counts_all, cap, d_indices, d_distances, nullptr);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
 }
@@ -1037,8 +998,7 @@ int uh_knn_replay_tiles_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int n
     for (int s = 0; s <= nshards; ++s) sb.b[s] = 0;   // never used: there is no rescan in this form
     UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
     dim3 grid(uh_div_up(nq, kWavesPerBlock)), block(kWave * kWavesPerBlock);
-    UH_LAUNCH(idx->ctx,knn_replay_kernel, grid, block, 0, idx->d_train, sb, d_queries, nq, nn,
-                       sorted ? 1 : 0, max_dist, d_cand_all, d_counts_all, cap, d_indices, d_distances, (int*)d_overflow);
+    launch_replay(idx, grid, block, sb, d_queries, nq, nn, sorted, max_dist, d_cand_all, d_counts_all, cap, d_indices, d_distances, (int*)d_overflow);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
 }
