@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel stats of the bench command + HBM traffic counters in separate passes
-# (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass).  Outputs land in gpurun_out/prof_r01/.
+# (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass).  Outputs land in gpurun_out/prof_${ROUND:-r02}/.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/prof_r01
+OUT=$R/gpurun_out/prof_${ROUND:-r02}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline"

@@ -28,6 +28,10 @@ UH_SC_HD Table table(int neg) {   // __sincosf_table[0] / [1] (negated cosine po
                  -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13};
 }
 
+// p.sign[n & 3] = {1, -1, -1, 1}[n & 3] as a select: indexing the by-value table dynamically put the whole struct into scratch memory
+// (120 bytes per lane in describe_kernel: the write amplification the round-1 counters showed)
+UH_SC_HD double quadrant_sign(int n) { return (((n & 3) == 1) || ((n & 3) == 2)) ? -1.0 : 1.0; }
+
 UH_SC_HD uint32_t abstop12(float x) {
     uint32_t u;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -70,7 +74,7 @@ UH_SC_HD float cosf_glibc(float y) {
     int n;
     x = reduce_fast(x, table(0), n);
     const Table p = table((n & 2) != 0);
-    return poly(x * p.sign[n & 3], x * x, p, n ^ 1);
+    return poly(x * quadrant_sign(n), x * x, p, n ^ 1);
 }
 
 UH_SC_HD float sinf_glibc(float y) {
@@ -82,7 +86,7 @@ UH_SC_HD float sinf_glibc(float y) {
     int n;
     x = reduce_fast(x, table(0), n);
     const Table p = table((n & 2) != 0);
-    return poly(x * p.sign[n & 3], x * x, p, n);
+    return poly(x * quadrant_sign(n), x * x, p, n);
 }
 
 // logf with the results of glibc >= 2.28 (sysdeps/ieee754/flt-32/e_logf.c + e_logf_data.c): Frame::predictScale

@@ -625,6 +625,10 @@ __global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const ui
     if (slot == 0 && lane == 0) frame_counts[frame] = total;
     if (slot >= total || slot >= cap_per_frame) return;
     while (slot >= base + lc[lvl]) { base += lc[lvl]; ++lvl; }
+    // the level is wave-uniform (slot is), but the compiler cannot see that: without the readfirstlane it copied the whole by-value Plan
+    // to scratch to index it per lane — 120 bytes of scratch per lane, the "37x write amplification" of this kernel in the round-1 counters
+    lvl = __builtin_amdgcn_readfirstlane(lvl);
+    base = __builtin_amdgcn_readfirstlane(base);
     const LevelDesc& L = plan.lv[lvl];
     const uint32_t e = sel[(size_t)frame * sel_frame_stride + L.sel_off + (slot - base)];
     const int cx = e & 0xFFF, cy = (e >> 12) & 0xFFF, resp = e >> 24;
