@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--knn-qpw", type=int, default=1, help="queries per wave of the exact matcher (1, 2, 4)")
+    ap.add_argument("--quick", action="store_true", help="headline step only: skip the per-stage and side measurements")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,9 +122,10 @@ def main():
     fp = FeatParams(MAX_FEATURES, NLEVELS, SCALE)
     orb_out = ext.extract_batch(frames, fp)
     index = Index(ctx).build(map_desc)
-    # the matcher runs beside the local BA: four queries per wave = a quarter of the L1/L2 streaming and of the resident waves; the
-    # search alone takes longer (250 instead of 163 us for the 4 x 2000 queries), the step is shorter
-    index.set_queries_per_wave(4)
+    # queries per wave of the exact matcher: round 1 used 4 (a quarter of the L1/L2 streaming beside the latency-bound BA launch chain);
+    # with the local BA as one persistent launch the step is bound by that launch alone and the plain one-query form is the fastest
+    # (0.740 / 0.750 / 0.751 ms per step at 1 / 2 / 4)
+    index.set_queries_per_wave(args.knn_qpw)
     # the reference runs local BA on its mapper thread, concurrently with tracking (mapmanager.cpp:1550);
     # here BA gets its own HIP stream so that its latency-bound launch chain overlaps the tracking stream's kernels
     ctx_ba = u.Context(local_rank, private=True)
@@ -172,6 +175,9 @@ def main():
     # ---- per-stage split and roofline (rank 0; separate passes so event overhead never enters the headline number)
     roofline = None
     stage_ms = {}
+    if rank == 0 and args.quick:
+        print(json.dumps({"value": round(value, 1), "ms_per_step": round(ms_per_step, 4), "knn_qpw": args.knn_qpw, "knn_form": os.environ.get("UH_KNN_FORM", "fused")}), flush=True)
+        return
     if rank == 0:
         def timed(fn, reps):
             torch.cuda.synchronize()

@@ -1686,16 +1686,15 @@ int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, 
     q.stop_at_begin = (b->h_stop && *b->h_stop) ? 1 : 0;
     struct Hold { int g; Hold(int g_) : g(g_) { g_persist_adm.acquire(g); } ~Hold() { g_persist_adm.release(g); } } hold(q.G);
     static std::atomic<unsigned> s_launch{0};
-    q.launch_id = ++s_launch;   // (never 0: memory that reads as zero carries no valid tag either)
-    UH_HIP_CHECK(hipMemsetAsync(q.flags, 0, sizeof(unsigned long long) * (q.G + 1), st));
+    q.launch_id = ++s_launch;   // (never 0) every epoch / error word of this launch carries it: words left in the buffer by an earlier launch, or by
+                                // whoever owned the memory before, can never satisfy a wait — no memset in front of the launch is needed
     UH_LAUNCH(b->ctx, ba_persist_kernel<8>, dim3(q.G), dim3(kPThreads), (size_t)b->p_lds, b->ptrs, b->dims, q);
     UH_HIP_CHECK(hipGetLastError());
+    unsigned long long errw = 0;
+    UH_HIP_CHECK(hipMemcpyAsync(&errw, q.flags + q.G, sizeof(errw), hipMemcpyDeviceToHost, st));   // completes with the state copy below: one host wait
     BAState hs;
     int rc = wait_state(b, &hs, stop_asap);
     if (rc) return rc;
-    unsigned long long errw = 0;
-    UH_HIP_CHECK(hipMemcpyAsync(&errw, q.flags + q.G, sizeof(errw), hipMemcpyDeviceToHost, st));
-    UH_HIP_CHECK(hipStreamSynchronize(st));
     const bool err = errw == (((unsigned long long)q.launch_id << 32) | 1ull);
     if (err) {
         uh::set_error("uh_ba_optimize: the persistent kernel's workgroups did not all become resident (%d workgroups, %d bytes of LDS each)", q.G, b->p_lds);

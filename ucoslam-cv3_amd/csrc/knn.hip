@@ -392,6 +392,99 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_accept_kernel(
 
 constexpr int kRpK = 16;   // the two-phase form keeps its k-set in one 16-lane DPP row
 
+// Replay of accept lists with FOUR queries per wave: every 16-lane row holds one query's ResultSet (lane = row * 16 + heap slot, k <= 16),
+// all cross-lane reads are row-local ds_bpermutes, so one instruction stream performs four pushes at once — the push itself is the
+// formulation of WaveHeap::push_accepted (root removal by "every slot picks its bigger child + ancestor walk", append by "ancestors
+// smaller than the new distance take their parent"), with a per-row size.  A row walks its own list; rows whose list is exhausted idle.
+// A list that overflowed its capacity is flagged in `redo` (that query is recomputed by the one-wave kernel afterwards).
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_replay4_kernel(
+    const uint64_t* __restrict__ cand, const int32_t* __restrict__ counts, int nq, int k, int sorted, int maxd, int cap,
+    int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ redo) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int slot = lane & 15, rowbase = lane & 48;
+    const int qi = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool haveq = qi < nq;
+    const int cnt_raw = haveq ? counts[qi] : 0;
+    const bool over = cnt_raw > cap;
+    if (haveq && slot == 0) redo[qi] = over ? 1 : 0;
+    const int cnt = over ? 0 : cnt_raw;
+    int maxcnt = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o));
+    const uint64_t* row = cand + (size_t)(haveq ? qi : 0) * cap;
+    int hd = 0, hi = -1, size = 0;
+    const int parent = slot > 0 ? (slot - 1) >> 1 : 0;
+    const int l = 2 * slot + 1, r = l + 1;
+    const int lsrc = rowbase + (l < 16 ? l : 15), rsrc = rowbase + (r < 16 ? r : 15);
+    for (int j0 = 0; j0 < maxcnt; j0 += 16) {
+        const uint64_t batch = j0 + slot < cnt ? row[j0 + slot] : 0;   // 16 list entries per row and batch, one per lane
+        const int blo = (int)(uint32_t)batch, bhi = (int)(batch >> 32);
+        const int nb = min(16, maxcnt - j0);
+        for (int e = 0; e < nb; e++) {
+            const int idx = __shfl(blo, rowbase + e), d = __shfl(bhi, rowbase + e);
+            const bool valid = j0 + e < cnt && !(maxd >= 0 && maxd < d);                  // resultset.h:66
+            const int root = __shfl(hd, rowbase);
+            const bool acc = valid && (size < k || d < root);                             // :67-69
+            if (!__any(acc)) continue;
+            // ---- root removal (:70-73) for the rows that are full
+            const bool pop = acc && size >= k;
+            const int ns = pop ? size - 1 : size;
+            const int lastsrc = rowbase + (ns < 16 ? ns : 15);
+            const int md = __shfl(hd, lastsrc), mi = __shfl(hi, lastsrc);
+            const int vl = __shfl(hd, lsrc), vr = __shfl(hd, rsrc);
+            const bool hasL = l < ns, hasR = r < ns;
+            const bool pickL = !hasR || (vr < vl);
+            const int c = pickL ? l : r;
+            const int cv = pickL ? vl : vr;
+            const int ci = __shfl(hi, rowbase + (c < 16 ? c : 15));
+            bool onpath = slot < ns;
+            int node = slot;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {                                                 // slot 15 lies four levels below the root
+                const int par = node > 0 ? (node - 1) >> 1 : 0;
+                const int cpar = __shfl(c, rowbase + par);
+                onpath = onpath && (node == 0 || cpar == node);
+                node = par;
+            }
+            const bool reached = pop && ns >= 1 && onpath && (slot == 0 || hd > md);
+            const bool takeChild = hasL && cv > md;
+            hd = reached ? (takeChild ? cv : md) : hd;
+            hi = reached ? (takeChild ? ci : mi) : hi;
+            size = ns;
+            // ---- append + climb (:77-79) for the rows that accept
+            bool onanc = false;
+#pragma unroll
+            for (int x = size + 1, t = 0; t < 5; t++, x >>= 1) onanc = onanc || (x > 0 && x - 1 == slot);   // the new slot and its ancestors
+            const int pv = __shfl(hd, rowbase + parent), pi = __shfl(hi, rowbase + parent);
+            const bool mine = acc && onanc && (slot == size || hd < d);
+            const bool takeParent = slot > 0 && pv < d;
+            hd = mine ? (takeParent ? pv : d) : hd;
+            hi = mine ? (takeParent ? pi : idx) : hi;
+            size = acc ? size + 1 : size;
+        }
+    }
+    // linear.h:82-85 (fill) + index.h:119-134 (exchange sort), per row
+    if (slot >= size) { hd = 0; hi = -1; }
+    if (sorted) {
+        for (int i = 0; i < k - 1; ++i) {
+            const int di = __shfl(hd, rowbase + i), ii = __shfl(hi, rowbase + i);
+            int cd = di, cidx = ii;                                                        // the value slot i currently holds (per row)
+            for (int j = i + 1; j < k; ++j) {
+                const int dj = __shfl(hd, rowbase + j), ij = __shfl(hi, rowbase + j);
+                const bool sw = ii != -1 && cd > dj;                                        // (index.h:123 tests idx[i] once, before the inner loop)
+                if (sw && slot == j) { hd = cd; hi = cidx; }
+                const int nd = sw ? dj : cd, ni = sw ? ij : cidx;
+                if (sw && slot == i) { hd = nd; hi = ni; }
+                cd = nd; cidx = ni;
+            }
+        }
+    }
+    if (haveq && !over && slot < k) {
+        indices[(size_t)qi * k + slot] = hi;
+        distances[(size_t)qi * k + slot] = hd;
+    }
+}
+
 // QPW queries per wave: a group of train rows is loaded once and scored against QPW queries (their words live in SGPRs): 1/QPW of the
 // L2 -> CU traffic and 1/QPW of the resident waves of the one-query form; every query keeps its own heap (two VGPRs) and its pushes
 // happen in ascending row order exactly as in the one-query form.
@@ -903,14 +996,14 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
         if (qpw == 4) UH_LAUNCH(idx->ctx, knn_accept_kernel<4>, ga, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
         else if (qpw == 2) UH_LAUNCH(idx->ctx, knn_accept_kernel<2>, ga, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
         else UH_LAUNCH(idx->ctx, knn_accept_kernel<1>, ga, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
-        // phase 2: ONE wave per query replays its list through the lane-distributed ResultSet (the multi-GPU replay kernel with a single
-        // "shard"): the pushes cost what they cost in round 1 (~1000 cycles of dependent cross-lane rounds each), but a wave that only
-        // replays has nothing else to stall, and eight such waves per SIMD hide each other's latency — fused into the scan the same pushes
-        // serialised behind the wave's own loads.  A list that overflowed is rescanned from the rows by that wave.  (Measured and rejected:
-        // one LANE per query on heaps in LDS — 125 single waves each running a ~95-element serial chain: 174 us for 8000 queries.)
-        ShardBounds sb;
-        sb.n = 1; sb.b[0] = idx->shard_begin; sb.b[1] = idx->shard_end;
-        launch_replay(idx, grid, block, sb, d_queries, nq, nn, sorted, max_dist, d_cand, d_counts, cap, d_indices, d_distances, nullptr);
+        // phase 2: four queries per wave, one 16-lane heap each (knn_replay4_kernel); then the one-wave kernel for the (rare) queries whose
+        // list overflowed.  (Measured and rejected: one LANE per query on heaps in LDS — 125 single waves each running a ~95-element serial
+        // chain, 174 us for 8000 queries; one WAVE per query on the 64-lane heap, 107 us.)
+        int* d_redo = d_counts + nq;
+        UH_LAUNCH(idx->ctx, knn_replay4_kernel, dim3(uh_div_up(nq, kWavesPerBlock * 4)), block, 0, d_cand, d_counts, nq, nn, sorted ? 1 : 0, max_dist, cap, d_indices, d_distances, d_redo);
+        if (nn <= 3) UH_LAUNCH(idx->ctx, knn_search_kernel<1>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo);
+        else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_search_kernel<3>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo);
+        else UH_LAUNCH(idx->ctx, knn_search_kernel<6>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo);
         UH_HIP_CHECK(hipGetLastError());
         return UH_OK;
     }
