@@ -1688,15 +1688,44 @@ int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, 
     static std::atomic<unsigned> s_launch{0};
     q.launch_id = ++s_launch;   // (never 0) every epoch / error word of this launch carries it: words left in the buffer by an earlier launch, or by
                                 // whoever owned the memory before, can never satisfy a wait — no memset in front of the launch is needed
+    BAState hs;
+    void* d_pin = nullptr;
+    const bool pinned = b->h_stop && hipHostGetDevicePointer(&d_pin, b->h_stop, 0) == hipSuccess;
+    volatile unsigned long long* h_done = reinterpret_cast<volatile unsigned long long*>(b->h_stop + 192);
+    if (pinned) {
+        q.host_state = reinterpret_cast<BAState*>(static_cast<unsigned char*>(d_pin) + 64);
+        q.host_done = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(d_pin) + 192);
+    }
     UH_LAUNCH(b->ctx, ba_persist_kernel<8>, dim3(q.G), dim3(kPThreads), (size_t)b->p_lds, b->ptrs, b->dims, q);
     UH_HIP_CHECK(hipGetLastError());
-    unsigned long long errw = 0;
-    UH_HIP_CHECK(hipMemcpyAsync(&errw, q.flags + q.G, sizeof(errw), hipMemcpyDeviceToHost, st));   // completes with the state copy below: one host wait
-    BAState hs;
-    int rc = wait_state(b, &hs, stop_asap);
-    if (rc) return rc;
-    const bool err = errw == (((unsigned long long)q.launch_id << 32) | 1ull);
+    bool err = false;
+    if (pinned) {
+        // the kernel's last act is a system-scope release store of (launch id << 32 | 1) behind the final state: polling that word costs
+        // a few hundred nanoseconds of latency, a stream synchronisation + two pageable D2H copies cost ~45 us per optimize()
+        const unsigned long long ok_word = ((unsigned long long)q.launch_id << 32) | 1ull, err_word = ok_word + 1;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 0;; ++spin) {
+            const unsigned long long w = *h_done;
+            if (w == ok_word) break;
+            if (w == err_word) { err = true; break; }
+            if (stop_asap && *stop_asap) *b->h_stop = 1;
+            __builtin_ia32_pause();
+            if ((spin & 1023) == 1023) {
+                if (hipStreamQuery(st) == hipSuccess && *h_done != ok_word && *h_done != err_word) { err = true; break; }   // the launch is gone without reporting
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) { err = true; break; }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        std::memcpy(&hs, b->h_stop + 64, sizeof(BAState));
+    } else {
+        unsigned long long errw = 0;
+        UH_HIP_CHECK(hipMemcpyAsync(&errw, q.flags + q.G, sizeof(errw), hipMemcpyDeviceToHost, st));
+        int rc = wait_state(b, &hs, stop_asap);
+        if (rc) return rc;
+        err = errw == (((unsigned long long)q.launch_id << 32) | 1ull);
+    }
     if (err) {
+        (void)hipStreamSynchronize(st);
         uh::set_error("uh_ba_optimize: the persistent kernel's workgroups did not all become resident (%d workgroups, %d bytes of LDS each)", q.G, b->p_lds);
         return UH_ENODEVICE;
     }
@@ -1714,8 +1743,9 @@ int uh_ba_create(uh_ctx* ctx, uh_ba** out) {
     UH_REQUIRE(ctx && out, "uh_ba_create: NULL argument");
     uh_ba* b = new uh_ba();
     b->ctx = ctx;
-    if (hipHostMalloc(reinterpret_cast<void**>(&b->h_stop), 64, hipHostMallocMapped) != hipSuccess) b->h_stop = nullptr;
-    if (b->h_stop) *b->h_stop = 0;
+    // one pinned, device-visible block: [0] force-stop byte, [64..) the final BAState of a persistent launch, [192] its completion word
+    if (hipHostMalloc(reinterpret_cast<void**>(&b->h_stop), 256, hipHostMallocMapped) != hipSuccess) b->h_stop = nullptr;
+    if (b->h_stop) std::memset(b->h_stop, 0, 256);
     *out = b;
     return UH_OK;
 }

@@ -38,6 +38,8 @@ struct BAPersist {
     double* part;        // [slice][workgroup][SL]
     double* red;         // [G * SL]
     double* partC;       // [G][4]: chi2, scale, (workgroup 0: stop flag), -
+    BAState* host_state;             // pinned, device-visible host memory: the final LM state ...
+    unsigned long long* host_done;   // ... and (launch id << 32 | 1 = finished, 2 = a workgroup never arrived), written last: the host polls this word
     unsigned long long* flags;   // [G] (launch id << 32 | epoch) of the workgroup's latest publication, [G] = error word (launch id << 32 | 1)
 };
 
@@ -308,7 +310,11 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                     wall_clock64() - t0 > kPTimeoutTicks) { fail = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (fail && lane == 0) { s_flag[1] = 1; __hip_atomic_store(q.flags + G, ((unsigned long long)q.launch_id << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (fail && lane == 0) {
+                s_flag[1] = 1;
+                __hip_atomic_store(q.flags + G, ((unsigned long long)q.launch_id << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (g == 0 && q.host_done) __hip_atomic_store(q.host_done, ((unsigned long long)q.launch_id << 32) | 2ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         __syncthreads();
         return s_flag[1] == 0;
@@ -769,6 +775,12 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             for (int j = 0; j < 7; j++) p.pose[0][7 * k + j] = sl >= 0 ? s_pose[(st.cur * NF + sl) * 7 + j] : q.pose0[7 * k + j];
             for (int j = 0; j < 12; j++) p.poseR[0][12 * k + j] = sl >= 0 ? s_poseR[(st.cur * NF + sl) * 12 + j] : q.poseR0[12 * k + j];
         }
-        if (tid == 0) { BAState fin = st; fin.cur = 0; fin.pending = 0; p.st[0] = fin; p.st[1] = fin; }
+        if (tid == 0) {
+            BAState fin = st; fin.cur = 0; fin.pending = 0; p.st[0] = fin; p.st[1] = fin;
+            if (q.host_state) {   // straight into pinned host memory: uh_ba_optimize polls host_done instead of synchronising the stream
+                *q.host_state = fin;
+                __hip_atomic_store(q.host_done, ((unsigned long long)q.launch_id << 32) | 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
