@@ -1,0 +1,61 @@
+// Times ldlt_bordered_lds (ba.hip) alone on one workgroup, with shader-clock stamps inside wave 0.
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -I ucoslam-cv3_amd/csrc scripts/micro/ldlt_time.hip -o /tmp/ldlt_time
+#include <hip/hip_runtime.h>
+__device__ long long g_clk[64];
+#define UH_LDLT_CLK(i) do { if (threadIdx.x == 0) g_clk[i] = clock64(); } while (0)
+#include "ba.hip"
+#include <cstdio>
+#include <vector>
+#include <random>
+__global__ __launch_bounds__(256) void k(const double* A, double* out, int n, int nfree, long long* clk, int reps) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int ld = n + 1;
+    double* M = lds;
+    double (*s_w)[121][6] = reinterpret_cast<double (*)[121][6]>(M + ld * ld);
+    __shared__ short s_pair[64][2];
+    const int npairs = nfree * (nfree + 1) / 2;
+    for (int t = threadIdx.x; t < npairs; t += 256) { int s1 = 0, rem = t; while (rem >= nfree - s1) { rem -= nfree - s1; ++s1; } s_pair[t][0] = s1; s_pair[t][1] = s1 + rem; }
+    long long best = 1ll << 60;
+    for (int r = 0; r < reps; r++) {
+        for (int i = threadIdx.x; i < ld * ld; i += 256) M[i] = A[i];
+        __syncthreads();
+        const long long t0 = clock64();
+        ldlt_bordered_lds(M, n, ld, nfree, npairs, s_pair, s_w);
+        __syncthreads();
+        const long long t1 = clock64();
+        if (t1 - t0 < best) best = t1 - t0;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { clk[0] = best; for (int i = 0; i < 64; i++) clk[1 + i] = g_clk[i]; }
+    for (int i = threadIdx.x; i < ld * ld; i += 256) out[i] = M[i];
+}
+int run(int nfree) {
+    const int n = 6 * nfree, ld = n + 1;
+    std::mt19937 rng(nfree); std::normal_distribution<double> N(0, 1);
+    std::vector<double> B(n * n), A(ld * ld, 0.0);
+    for (auto& v : B) v = N(rng);
+    for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) { double s = i == j ? 50.0 : 0.0; for (int k = 0; k < n; k++) s += B[i * n + k] * B[j * n + k]; A[i * ld + j] = s; }
+    for (int i = 0; i < n; i++) for (int j = i + 1; j < ld; j++) A[i * ld + j] = std::nan("");   // the upper triangle is never to be used
+    for (int j = 0; j < n; j++) A[n * ld + j] = N(rng);
+    double *dA, *dO; long long* dc;
+    hipMalloc(&dA, A.size() * 8); hipMalloc(&dO, A.size() * 8); hipMalloc(&dc, 65 * 8);
+    hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
+    const size_t lds = (ld * ld + 2 * 121 * 6) * 8;
+    hipLaunchKernelGGL(k, dim3(1), dim3(256), lds, 0, dA, dO, n, nfree, dc, 20);
+    hipDeviceSynchronize();
+    long long c[65]; hipMemcpy(c, dc, sizeof(c), hipMemcpyDeviceToHost);
+    std::vector<double> O(A.size()); hipMemcpy(O.data(), dO, O.size() * 8, hipMemcpyDeviceToHost);
+    double err = 0, errb = 0;
+    for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) { double s = 0; for (int k = 0; k <= j; k++) { const double li = k == i ? 1.0 : O[i * ld + k], lj = k == j ? 1.0 : O[j * ld + k]; s += li * O[k * ld + k] * lj; } err = fmax(err, fabs(s - A[i * ld + j])); }
+    for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k <= i; k++) s += (k == i ? 1.0 : O[i * ld + k]) * O[k * ld + k] * O[n * ld + k]; errb = fmax(errb, fabs(s - A[n * ld + i])); }   // L D z = b
+    printf("nfree %d: best %lld shader clocks (%.2f us at 2.39 GHz), |LDL^T - A| = %.3g, |L D z - b| = %.3g\n", nfree, c[0], c[0] / 2390.0, err, errb);
+    if (nfree == 8) for (int i = 0; i < 40; i++) if (c[1 + i]) printf("clk[%d] = +%lld\n", i, c[1 + i] - c[1]);
+    hipFree(dA); hipFree(dO); hipFree(dc);
+    return !(err < 1e-9 && errb < 1e-9);
+}
+int main() {
+    int bad = 0;
+    for (int nf : {1, 2, 3, 5, 7, 8}) bad += run(nf);
+    printf(bad ? "FAILED\n" : "ok\n");
+    return bad;
+}

@@ -605,11 +605,140 @@ __device__ __forceinline__ void pose_update_one(const BAPtrs& p, int s, int cur,
     Ro[9] = t[0]; Ro[10] = t[1]; Ro[11] = t[2];
 }
 
+#ifndef UH_LDLT_LEGACY
+#define UH_LDLT_LEGACY 0   // 1: keep the element-per-thread factorisation for every size (A/B in scripts/micro/ldlt_time.hip)
+#endif
+#ifndef UH_LDLT_CLK
+#define UH_LDLT_CLK(i)   // scripts/micro/ldlt_time.hip stamps the phases of the factorisation through this hook
+#endif
+// LDL^T of the bordered system [S b; b^T .] (lower triangle in LDS, row stride ld = n + 1) for n + 1 <= 64 rows: ROW PER LANE.
+// Wave 0 owns the serial chain; lane r keeps row r's six entries of the current block column in registers:
+//   C  apply the previous panel to block column kb: a_j -= sum_t l_prev[t] * y[k0 + j][t]   (own l from registers, y broadcast from LDS)
+//   DP right-looking elimination over the block's six columns, all rows at once: pivots and the block's own rows come from lanes
+//      k0 .. k0+5 with v_readlane; l = y D^-1 goes into M, y into the panel buffer s_y[kb & 1][t][row]
+// and meets the other waves at ONE barrier per block column; they apply panel kb to everything behind block column kb+1 (one thread per
+// row x six columns: 6 + 6 + 18 LDS reads for 36 FMAs) while wave 0 is already on block column kb+1.  Measured with
+// scripts/micro/ldlt_time.hip on MI355X for n = 48: 21.8 k shader clocks for the element-per-thread form below (two barriers per block
+// column, 13 LDS reads per 6 FMAs, 8-way bank conflicts on the panel writes), see DESIGN.md for this form.
+// The right-hand side rides along as row n; M ends up holding L (unit lower), D on the diagonal and D^-1 L^-1 b in row n.
+__device__ __forceinline__ bool ldlt_rowlane_lds(double* M, int n, int ld, int nfree, int npairs, const short (*s_pair)[2], double* s_y_raw) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nb = n / 6, nrow = n + 1;
+    // [2][6][64], 16-byte aligned.  (Pointer arithmetic, not an integer round trip: the latter loses the LDS address space and every access
+    // to the panel buffer becomes a flat_load / flat_store.)
+    double* const s_y = s_y_raw + ((reinterpret_cast<uintptr_t>(s_y_raw) >> 3) & 1);
+    bool failed = false;
+    double lprev[6] = {0, 0, 0, 0, 0, 0};
+    auto wave0_step = [&](int kb) {
+        const int k0 = 6 * kb;
+        const int r = lane < nrow ? lane : nrow - 1;   // idle lanes shadow the last row
+        double a[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) a[j] = M[r * ld + k0 + j];
+        if (kb > 0) {
+            const double* yb = s_y + ((kb - 1) & 1) * 384 + k0;
+            double2 yv[6][3];
+#pragma unroll
+            for (int t = 0; t < 6; t++)
+#pragma unroll
+                for (int h = 0; h < 3; h++) yv[t][h] = *reinterpret_cast<const double2*>(yb + t * 64 + 2 * h);
+            // all eighteen broadcast reads are in flight before the first FMA (the register allocator otherwise recycles three registers
+            // and the step pays six LDS round trips instead of one)
+#pragma unroll
+            for (int t = 0; t < 6; t++)
+                asm volatile("" : "+v"(yv[t][0].x), "+v"(yv[t][0].y), "+v"(yv[t][1].x), "+v"(yv[t][1].y), "+v"(yv[t][2].x), "+v"(yv[t][2].y));
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+                a[0] = fma(-lprev[t], yv[t][0].x, a[0]); a[1] = fma(-lprev[t], yv[t][0].y, a[1]); a[2] = fma(-lprev[t], yv[t][1].x, a[2]);
+                a[3] = fma(-lprev[t], yv[t][1].y, a[3]); a[4] = fma(-lprev[t], yv[t][2].x, a[4]); a[5] = fma(-lprev[t], yv[t][2].y, a[5]);
+            }
+        }
+        // the 36 FMAs above are six independent chains: forced to be complete here they issue back to back; left alone, the compiler sinks
+        // each chain in front of its first use, onto the serial pivot chain below
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]));
+        UH_LDLT_CLK(1 + 4 * kb);
+        // D + P fused: right-looking elimination over the block's six columns for ALL rows at once.  Column j: the pivot d_j sits in lane
+        // k0+j (v_readlane), every lane forms its own l_j = a_j / d_j, and a_c -= l_j * y_cj with y_cj = a_j of lane k0+c.  The cost of a
+        // wave instruction does not depend on how many lanes need it: factorising the 6x6 block redundantly in every lane (35 FMAs + 15
+        // multiplies) and then substituting (15 FMAs) issued twice the fp64 instructions of this form.
+        double dj[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            dj[j] = readlane_f64(a[j], k0 + j);
+            failed = failed || dj[j] == 0.0 || !isfinite(dj[j]);
+            // 1/d: v_rcp_f64 (2^29 ulp = 2^-23 relative) and ONE cubic step r0 (1 + e + e^2), e = 1 - d r0: error e^3 = 2^-69, three
+            // dependent operations on the pivot chain instead of the four of two Newton steps
+            const double r0 = __builtin_amdgcn_rcp(dj[j]);
+            const double e = fma(-dj[j], r0, 1.0);
+            const double ikj = fma(fma(e, e, e), r0, r0);
+            lprev[j] = a[j] * ikj;
+            // the next pivot's column is updated as a - (a_j y) / d: the product does not wait for the reciprocal, so the chain from pivot
+            // to pivot is rcp, 3 x fma, fma instead of rcp, 3 x fma, mul, fma
+            if (j + 1 < 6) a[j + 1] = fma(-(a[j] * readlane_f64(a[j], k0 + j + 1)), ikj, a[j + 1]);
+#pragma unroll
+            for (int c = j + 2; c < 6; c++) a[c] = fma(-lprev[j], readlane_f64(a[j], k0 + c), a[c]);
+        }
+        // Every lane stores, no lane is masked: rows above the block (and entries right of the diagonal inside it) land in M's upper
+        // triangle, which nobody reads; idle lanes repeat the last row's values; panel rows k0 .. k0+5 of s_y are never read.  Without
+        // the twelve conditional stores the whole step is one basic block for the scheduler.
+        const int ri = lane - k0;
+        double* yo = s_y + (kb & 1) * 384 + lane;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            M[r * ld + k0 + j] = ri == j ? dj[j] : lprev[j];
+            yo[j * 64] = a[j];
+        }
+        UH_LDLT_CLK(3 + 4 * kb);
+    };
+    auto trailing = [&](int kb) {   // waves 1..3: panel kb onto the tiles (s1 <= s2) with s1 >= kb + 2 and the right-hand-side row
+        const int k0 = 6 * kb, J0 = kb + 2;
+        if (J0 >= nb) return;
+        const int tile0 = J0 * nfree - J0 * (J0 - 1) / 2;   // first pair with s1 >= J0 in the s1-major pair list
+        const int ntile = npairs - tile0;
+        const int nunits = 6 * ntile + (nb - J0);
+        const double* yb = s_y + (kb & 1) * 384;
+        for (int u = tid - 64; u < nunits; u += kSolveThreads - 64) {
+            int r, c0;
+            bool diag = false;
+            if (u < 6 * ntile) {
+                const int tile = u / 6, s1 = s_pair[tile0 + tile][0], s2 = s_pair[tile0 + tile][1];
+                r = 6 * s2 + (u - 6 * tile); c0 = 6 * s1; diag = s1 == s2;
+            } else { r = n; c0 = 6 * (J0 + (u - 6 * ntile)); }
+            double lr[6], acc[6];
+#pragma unroll
+            for (int t = 0; t < 6; t++) lr[t] = M[r * ld + k0 + t];
+#pragma unroll
+            for (int j = 0; j < 6; j++) acc[j] = M[r * ld + c0 + j];
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+                const double2 y01 = *reinterpret_cast<const double2*>(yb + t * 64 + c0), y23 = *reinterpret_cast<const double2*>(yb + t * 64 + c0 + 2),
+                              y45 = *reinterpret_cast<const double2*>(yb + t * 64 + c0 + 4);
+                acc[0] = fma(-lr[t], y01.x, acc[0]); acc[1] = fma(-lr[t], y01.y, acc[1]); acc[2] = fma(-lr[t], y23.x, acc[2]);
+                acc[3] = fma(-lr[t], y23.y, acc[3]); acc[4] = fma(-lr[t], y45.x, acc[4]); acc[5] = fma(-lr[t], y45.y, acc[5]);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++) if (!diag || c0 + j <= r) M[r * ld + c0 + j] = acc[j];
+        }
+    };
+    UH_LDLT_CLK(0);
+    if (wv == 0 && nb > 0) wave0_step(0);
+    for (int kb = 0; kb < nb; kb++) {
+        __syncthreads();   // panel kb is in M / s_y[kb & 1]; the trailing update of panel kb-1 is complete
+        UH_LDLT_CLK(4 + 4 * kb);
+        if (kb == nb - 1) break;
+        if (wv == 0) wave0_step(kb + 1);
+        else if (tid < kSolveThreads) trailing(kb);
+    }
+    if (wv != 0) failed = false;   // only wave 0 sees the pivots
+    return failed;
+}
+
 // Blocked look-ahead LDL^T of the bordered system [S b; b^T .] held as a lower triangle in LDS (row stride ld = n + 1, odd), shared by the
 // fused legacy solve and the persistent kernel.  Every thread of the workgroup calls it (it contains barriers); the first
 // kSolveThreads threads do the work.  Returns (in wave 0) whether a zero / non-finite pivot was met.
 __device__ __forceinline__ bool ldlt_bordered_lds(double* M, int n, int ld, int nfree, int npairs, const short (*s_pair)[2],
                                                   double (*s_w)[121][6]) {
+    if (n + 1 <= 64 && !UH_LDLT_LEGACY) return ldlt_rowlane_lds(M, n, ld, nfree, npairs, s_pair, &s_w[0][0][0]);   // (uniform)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool active = tid < kSolveThreads;
     bool failed = false;
@@ -644,6 +773,7 @@ __device__ __forceinline__ bool ldlt_bordered_lds(double* M, int n, int ld, int 
 #pragma unroll
                 for (int i = j + 1; i < 6; i++) a[i][j] = lcol[i];
             }
+            UH_LDLT_CLK(3 + 4 * kb);
             __builtin_amdgcn_wave_barrier();   // every lane has read the block before lane 0 overwrites it
             if (lane == 0) {
 #pragma unroll
@@ -665,10 +795,13 @@ __device__ __forceinline__ bool ldlt_bordered_lds(double* M, int n, int ld, int 
 #pragma unroll
                 for (int j = 0; j < 6; j++) { M[r * ld + k0 + j] = y[j] * ik[j]; s_w[kb & 1][r][j] = y[j]; }
             }
+            UH_LDLT_CLK(4 + 4 * kb);
         };
+        UH_LDLT_CLK(0);
         if (wv == 0 && nb > 0) diag_and_panel(0);
         for (int kb = 0; kb < nb; kb++) {
             __syncthreads();   // panel kb (M columns of block kb, s_w[kb & 1]) is complete; trailing update kb-1 is done
+            UH_LDLT_CLK(5 + 4 * kb);
             if (kb == nb - 1) break;
             const int k0 = 6 * kb;
             {   // block column kb+1 first, by everybody (one element per thread and round): wave 0 needs it to go on
@@ -685,6 +818,7 @@ __device__ __forceinline__ bool ldlt_bordered_lds(double* M, int n, int ld, int 
                 }
             }
             __syncthreads();
+            UH_LDLT_CLK(6 + 4 * kb);
             if (wv == 0) {
                 diag_and_panel(kb + 1);
             } else if (active) {
@@ -1536,6 +1670,8 @@ struct uh_ba {
     bool persist = false;                 // 1..8 free keyframes: the whole optimisation is ONE persistent launch (ba_persist.hpp)
     BAPersist pq{};
     uh::DevBuf parena;                    // the persistent form's packed observations and exchange buffers
+    size_t p_xoff = 0, p_xbytes = 0;      // the exchange region inside parena
+    unsigned p_seq = 0;                   // launches of the persistent kernel by this optimizer: 20 bits of it tag the exchanged words
     int p_lds = 0;
     BAWide wd{};
     int step = 0;                         // LM steps enqueued since uh_ba_optimize began: step s reads state slot s & 1
@@ -1686,8 +1822,14 @@ int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, 
     q.stop_at_begin = (b->h_stop && *b->h_stop) ? 1 : 0;
     struct Hold { int g; Hold(int g_) : g(g_) { g_persist_adm.acquire(g); } ~Hold() { g_persist_adm.release(g); } } hold(q.G);
     static std::atomic<unsigned> s_launch{0};
-    q.launch_id = ++s_launch;   // (never 0) every epoch / error word of this launch carries it: words left in the buffer by an earlier launch, or by
-                                // whoever owned the memory before, can never satisfy a wait — no memset in front of the launch is needed
+    q.launch_id = ++s_launch;   // (never 0) the error and completion words of this launch carry it
+    // exchanged data words carry 20 bits of this optimizer's own launch count (+ 12 bits of round number): the region was zeroed when it
+    // was laid out, every launch rewrites what it reads, and when the 20 bits wrap the region is zeroed again
+    if (((++b->p_seq) & 0xFFFFFu) == 0) {
+        ++b->p_seq;
+        UH_HIP_CHECK(hipMemsetAsync(b->parena.as<char>() + b->p_xoff, 0, b->p_xbytes, st));
+    }
+    q.tag_base = (b->p_seq & 0xFFFFFu) << 12;
     BAState hs;
     void* d_pin = nullptr;
     const bool pinned = b->h_stop && hipHostGetDevicePointer(&d_pin, b->h_stop, 0) == hipSuccess;
@@ -1932,10 +2074,10 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
             BAPersist& q = b->pq;
             q = BAPersist{};
             q.G = G; q.Lw = Lw; q.krows = (3 * Lw + 15) & ~15;
-            q.nelem = 6 * 256 + NF * 27 + 6 * NF + 4;
-            q.SL = (uh_div_up(q.nelem, G) + 1) & ~1;
             const char* sch = getenv("UH_BA_SCHUR");
-            q.use_mfma = (sch && std::string(sch) == "mfma") ? 1 : 0;   // default: register-blocked vector FMA (faster on gfx950)
+            q.use_mfma = (sch && std::string(sch) == "mfma") ? 1 : 0;   // default: register-blocked vector FMA
+            q.nelem = (q.use_mfma ? 6 * 256 : 78 * 16) + NF * 27 + 6 * NF + 4;
+            q.SL = (uh_div_up(q.nelem, G) + 1) & ~1;
             std::vector<double> h_uv(2 * (size_t)P * NF, 0.0), h_w((size_t)P * NF, 0.0), hx_uv, hx_w, h_R0(12 * (size_t)K);
             std::vector<int> h_id((size_t)P * NF, -1), hx_ptr(P + 1, 0), hx_kf, hx_id;
             std::vector<int> fix_slot(K, -1), fix_kf;   // fixed frames that observe something, in frame order
@@ -1977,9 +2119,14 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
                 const size_t o_fuv = PA.take<double>(2 * (size_t)P * NF), o_fw = PA.take<double>((size_t)P * NF), o_fid = PA.take<int>((size_t)P * NF);
                 const size_t o_xp = PA.take<int>(P + 1), o_xuv = PA.take<double>(2 * nfx + 2), o_xw = PA.take<double>(nfx + 1), o_xkf = PA.take<int>(nfx + 1), o_xid = PA.take<int>(nfx + 1);
                 const size_t o_R0 = PA.take<double>(12 * (size_t)K), o_fixkf = PA.take<int>(fix_kf.size() + 1);
-                const size_t o_part = PA.take<double>((size_t)G * G * q.SL), o_red = PA.take<double>((size_t)G * q.SL), o_pc = PA.take<double>(4 * (size_t)G), o_fl = PA.take<unsigned long long>(G + 1);
+                // exchange buffers: tagged doubles (two 64-bit words each, ba_persist.hpp)
+                const size_t o_part = PA.take<unsigned long long>(2 * (size_t)G * G * q.SL), o_red = PA.take<unsigned long long>(2 * (size_t)G * q.SL);
+                const size_t o_pc = PA.take<unsigned long long>(2 * 4 * (size_t)G), o_fl = PA.take<unsigned long long>(G + 1);
                 if ((rc = b->parena.reserve(PA.off + 256))) return rc;
                 char* pb = b->parena.as<char>();
+                // no word of a fresh (or re-laid-out) exchange region may look like a tagged datum of a coming launch
+                UH_HIP_CHECK(hipMemsetAsync(pb + o_part, 0, PA.off - o_part, st));
+                b->p_xoff = o_part; b->p_xbytes = PA.off - o_part;
                 auto pup = [&](size_t off, const void* src, size_t bytes) -> int {
                     if (bytes) UH_HIP_CHECK(hipMemcpyAsync(pb + off, src, bytes, hipMemcpyHostToDevice, st));
                     return UH_OK;
@@ -2000,7 +2147,8 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
                 q.fx_kf = (const int*)(pb + o_xkf); q.fx_id = (const int*)(pb + o_xid);
                 q.poseR0 = (const double*)(pb + o_R0); q.fix_kf = (const int*)(pb + o_fixkf);
                 q.pose0 = (const double*)(base + o_pose0); q.pts0 = (const double*)(base + o_pts0);
-                q.part = (double*)(pb + o_part); q.red = (double*)(pb + o_red); q.partC = (double*)(pb + o_pc); q.flags = (unsigned long long*)(pb + o_fl);
+                q.part = (unsigned long long*)(pb + o_part); q.red = (unsigned long long*)(pb + o_red); q.partC = (unsigned long long*)(pb + o_pc);
+                q.flags = (unsigned long long*)(pb + o_fl);
                 b->p_lds = lay.total_bytes;
                 UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_persist_kernel<NF>), hipFuncAttributeMaxDynamicSharedMemorySize, lay.total_bytes));
                 b->persist = true;

@@ -14,11 +14,13 @@
 //     per workgroup — v_mfma_f64_16x16x4_f64 on the six upper 16x16 tiles, K split over the four waves (UH_BA_SCHUR=valu selects the
 //     register-tiled vector-FMA form of the same product for the A/B in DESIGN.md);  b_schur = Yt^T (L^-1 b_l);
 //   * back-substitution (block_solver.hpp:419-442): dx_l = L^-T (L^-1 b_l - Y_l^T dx_p) from the same panel;
-//   * workgroups exchange only reduction partials, through write-through (sc1) stores + one epoch flag per workgroup:
+//   * workgroups exchange only reduction partials, through write-through (sc1) stores of SELF-VALIDATING words: every double travels
+//     as two 64-bit words (32 payload bits | 32-bit tag = launch sequence and exchange round), so a reader polls the data itself —
+//     one memory round trip (~1.5 us on MI355X) per exchange instead of drain + flag + flag poll + data load:
 //       A: every workgroup's partial (tiles, Hpp/bp sums, b_schur, chi2, max diag)  -> slice-wise reduction by all workgroups
 //       B: the reduced 1804 doubles -> EVERY workgroup assembles and factorises the 48x48 system itself (no broadcast hop)
 //       C: trial chi2 / scale partials -> every workgroup takes the accept / reject decision itself (apply_decision)
-//     so a trial costs three flag hand-offs instead of two kernel boundaries + launch ramps, and all summation orders are
+//     so a trial costs three data hand-offs instead of two kernel boundaries + launch ramps, and all summation orders are
 //     fixed: results are run-to-run deterministic and identical in every workgroup.
 #pragma once
 
@@ -29,18 +31,20 @@ constexpr long long kPTimeoutTicks = 300000000ll;   // 3 s of the 100 MHz wall c
 struct BAPersist {
     int G, Lw, krows, SL, nelem, max_fix, kfix;
     int n1, n2, stop_at_begin, use_mfma;
-    unsigned launch_id;   // tags every epoch word of this launch: a word left behind by an earlier launch (recycled memory) never satisfies a wait
+    unsigned launch_id;   // tags the error / completion words of this launch
+    unsigned tag_base;    // (launch sequence of this optimizer & 0xFFFFF) << 12: the upper bits of every exchanged word's tag.  The exchange
+                          // buffers are zeroed whenever they are (re)allocated and whenever the sequence wraps, so a stale word never matches.
     float minChi2;
     const double2* fe_uv; const double* fe_w; const int* fe_id;          // P x NF: the free cameras' observations, by (landmark, slot)
     const int* fx_ptr; const double2* fx_uv; const double* fx_w; const int* fx_kf; const int* fx_id;   // CSR of fixed-camera observations (fx_kf: index into fix_kf)
     const int* fix_kf;   // [kfix] frame index of every fixed frame that observes something
     const double* pose0; const double* poseR0; const double* pts0;       // K x 7, K x 12, P x 3: the snapshot taken by setParams
-    double* part;        // [slice][workgroup][SL]
-    double* red;         // [G * SL]
-    double* partC;       // [G][4]: chi2, scale, (workgroup 0: stop flag), -
+    unsigned long long* part;        // [slice][workgroup][SL] tagged doubles (two words each)
+    unsigned long long* red;         // [G * SL]
+    unsigned long long* partC;       // [G][4]: chi2, scale, (workgroup 0: stop flag), -
     BAState* host_state;             // pinned, device-visible host memory: the final LM state ...
     unsigned long long* host_done;   // ... and (launch id << 32 | 1 = finished, 2 = a workgroup never arrived), written last: the host polls this word
-    unsigned long long* flags;   // [G] (launch id << 32 | epoch) of the workgroup's latest publication, [G] = error word (launch id << 32 | 1)
+    unsigned long long* flags;   // [G] = error word (launch id << 32 | 1): some workgroup gave up waiting
 };
 
 struct PersistLds {      // offsets in doubles into the dynamic LDS block
@@ -54,7 +58,7 @@ __host__ __device__ inline PersistLds persist_lds(int krows, int n, int max_fix,
     o.Yt = a; a += krows * YS;
     o.U = a;
     o.usz = (n + 1) * (n + 1) + 2 * 121 * 6;
-    if (o.usz < NT * 256 * 2) o.usz = NT * 256 * 2;
+    if (o.usz < NT * 256 + 1856) o.usz = NT * 256 + 1856;   // the staged product (<= 1536) + the slice reduction's scratch (SL * min(G, 16) <= 1832)
     if (o.usz < kPWaves * NF * 33) o.usz = kPWaves * NF * 33;
     if (o.usz < 2048) o.usz = 2048;
     a += o.usz;
@@ -78,8 +82,24 @@ __host__ __device__ inline PersistLds persist_lds(int krows, int n, int max_fix,
     return o;
 }
 
-__device__ __forceinline__ void xst(double* a, double v) { __hip_atomic_store(a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double xld(const double* a) { return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Tagged exchange words.  Element i of a buffer = words 2i (low 32 payload bits) and 2i+1 (high 32 bits), each with the round's tag in
+// its upper half; both are single-copy-atomic 64-bit write-through stores / L2-bypassing loads, so a word whose tag matches IS the
+// datum: no flag, no store drain, no ordering between words is needed.
+typedef unsigned long long pword;
+struct TWord { pword lo, hi; };
+__device__ __forceinline__ void tst(pword* base, size_t i, double v, unsigned tag) {
+    const pword b = (pword)__double_as_longlong(v), t = (pword)tag << 32;
+    __hip_atomic_store(base + 2 * i, (b & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(base + 2 * i + 1, (b >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ TWord tld_raw(const pword* base, size_t i) {
+    TWord w;
+    w.lo = __hip_atomic_load(base + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w.hi = __hip_atomic_load(base + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return w;
+}
+__device__ __forceinline__ bool tok(const TWord& w, unsigned tag) { return (unsigned)(w.lo >> 32) == tag && (unsigned)(w.hi >> 32) == tag; }
+__device__ __forceinline__ double tval(const TWord& w) { return __longlong_as_double((long long)((w.hi << 32) | (w.lo & 0xffffffffull))); }
 
 // 1/sqrt(x) to the last bit or two: v_rsq_f64 (~2^-23) + two Newton steps; x <= 0 / NaN gives NaN / inf, which the reduced
 // system's factorisation then reports as a failed solve (g2o: a singular D^-1 poisons Hschur and LDLT reports failure)
@@ -225,7 +245,8 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     int* const s_flag = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + o.flag_bytes);   // [0] solve ok, [1] error
 
     const int G = q.G, SL = q.SL;
-    constexpr int OFF_CAM = NT * 256, OFF_BS = OFF_CAM + NF * 27, OFF_SC = OFF_BS + NP;   // element offsets of a partial
+    // element offsets of a partial: the product (six 16x16 MFMA tiles, or the 78 upper 4x4 blocks of the vector-FMA form), camera sums, scalars
+    const int OFF_CAM = q.use_mfma ? NT * 256 : 78 * 16, OFF_BS = OFF_CAM + NF * 27, OFF_SC = OFF_BS + NP;
     const int l0 = g * q.Lw;
     const int nl = min(q.Lw, d.P - l0);
     const int ll = tid >> LG, s = tid & (NF - 1);
@@ -288,38 +309,44 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     if (tid == 0) { s_flag[0] = 1; s_flag[1] = 0; }
     __syncthreads();
 
-    unsigned ep = 0;
-    auto publish = [&]() {
-        ++ep;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(q.flags + g, ((unsigned long long)q.launch_id << 32) | ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto wait_all = [&]() -> bool {   // one wave polls the G epoch words; false: a workgroup never arrived (error word set)
-        if (wv == 0) {
-            const long long t0 = wall_clock64();
-            bool fail = false;
-            for (;;) {
-                bool ok = true;
-                for (int h = lane; h < G; h += 64) {
-                    const unsigned long long f = __hip_atomic_load(q.flags + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = ok && (unsigned)(f >> 32) == q.launch_id && (int)((unsigned)f - ep) >= 0;   // this launch's word, at or past the epoch
-                }
-                if (__all(ok)) break;
-                if (__hip_atomic_load(q.flags + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (((unsigned long long)q.launch_id << 32) | 1ull) ||
-                    wall_clock64() - t0 > kPTimeoutTicks) { fail = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (fail && lane == 0) {
-                s_flag[1] = 1;
-                __hip_atomic_store(q.flags + G, ((unsigned long long)q.launch_id << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (g == 0 && q.host_done) __hip_atomic_store(q.host_done, ((unsigned long long)q.launch_id << 32) | 2ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+    // ---- exchange rounds: every workgroup runs the same sequence of rounds, so the round counter doubles as the tag
+    unsigned ep = 0, tagA = 0;
+    auto next_tag = [&]() -> unsigned { ++ep; return q.tag_base | (ep & 0xFFFu); };
+    const pword err_word = ((pword)q.launch_id << 32) | 1ull;
+    // a reader that has waited 3 s (a workgroup never became resident), or sees that somebody else gave up: flag it, everybody leaves
+    // at the next uniform check of s_flag[1]
+    auto give_up = [&](long long& t0) -> bool {
+        if (t0 == 0) t0 = wall_clock64();
+        if (__hip_atomic_load(q.flags + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == err_word || wall_clock64() - t0 > kPTimeoutTicks) {
+            s_flag[1] = 1;
+            __hip_atomic_store(q.flags + G, err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g == 0 && q.host_done) __hip_atomic_store(q.host_done, ((unsigned long long)q.launch_id << 32) | 2ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return true;
         }
-        __syncthreads();
-        return s_flag[1] == 0;
+        __builtin_amdgcn_s_sleep(1);
+        return false;
     };
-    auto part_addr = [&](int i) -> double* { const int sl = i / SL; return q.part + ((size_t)sl * G + g) * SL + (i - sl * SL); };
+    // up to eight tagged elements (first, first + stride, ...), all loads in flight together; spins until every tag matches
+    auto tload8 = [&](const pword* base, size_t first, size_t stride, int cnt, unsigned tag, double (&v)[8]) {
+        long long t0 = 0;
+        for (;;) {
+            TWord w[8];
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (u < cnt) w[u] = tld_raw(base, first + u * stride);
+#pragma unroll
+            for (int u = 0; u < 8; u++) { if (u < cnt) { ok = ok && tok(w[u], tag); v[u] = tval(w[u]); } else v[u] = 0.0; }
+            if (ok || give_up(t0)) return;
+        }
+    };
+    auto tload1 = [&](const pword* base, size_t i, unsigned tag) -> double {
+        long long t0 = 0;
+        for (;;) {
+            const TWord w = tld_raw(base, i);
+            if (tok(w, tag) || give_up(t0)) return tval(w);
+        }
+    };
+    auto part_at = [&](int i) -> size_t { const int sl = i / SL; return ((size_t)sl * G + g) * SL + (i - sl * SL); };   // element i of this workgroup's partial
 
     BAState st;
     memset(&st, 0, sizeof(st));
@@ -332,6 +359,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     // every observation is recorded, the reduced-system product is skipped.
     auto phase1 = [&](double lambda, bool first) {
         const int cur = st.cur;
+        tagA = next_tag();
         double acc[10];
 #pragma unroll
         for (int i = 0; i < 10; i++) acc[i] = 0;
@@ -479,11 +507,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
 #pragma unroll
                 for (int i = 0; i < 16; i++) { u0[i] = U[bq * 16 + i]; u1[i] = U[1248 + bq * 16 + i]; }
 #pragma unroll
-                for (int i = 0; i < 16; i++) acc4[i] = (acc4[i] + u0[i]) + u1[i];
-                double* dst = part_addr(bq * 16);   // SL is even and 16-element runs may straddle a slice: address every element
-#pragma unroll
-                for (int i = 0; i < 16; i++) xst(part_addr(bq * 16 + i), acc4[i]);
-                (void)dst;
+                for (int i = 0; i < 16; i++) U[bq * 16 + i] = (acc4[i] + u0[i]) + u1[i];   // staged: the stores below go out coalesced
             }
         }
         // MFMA form: wave 0: (0,0) (0,1), wave 1: (0,2) (1,1), wave 2: (1,2) + half of b_schur, wave 3: (2,2) + the other half — every wave
@@ -524,50 +548,56 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             }
             // element index of (tile t, lane, v) = (t*64 + lane)*4 + v; tile order (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
             const int ti0 = wvu == 0 ? 0 : (wvu == 1 ? 2 : (wvu == 2 ? 4 : 5)), ti1 = wvu == 0 ? 1 : 3;
+            __syncthreads();   // the camera sums in U have been read: U is free
 #pragma unroll
-            for (int v = 0; v < 4; v++) xst(part_addr(ti0 * 256 + lane * 4 + v), t0[v]);
+            for (int v = 0; v < 4; v++) U[ti0 * 256 + lane * 4 + v] = t0[v];
             if (wvu < 2) {
 #pragma unroll
-                for (int v = 0; v < 4; v++) xst(part_addr(ti1 * 256 + lane * 4 + v), t1[v]);
+                for (int v = 0; v < 4; v++) U[ti1 * 256 + lane * 4 + v] = t1[v];
             }
         }
         if (!first) UH_BA_CLK(55);
         __syncthreads();
         if (!first) UH_BA_CLK(56);
         __syncthreads();   // s_out complete
-        for (int i = tid; i < NF * 27 + NP + 4; i += kPThreads) xst(part_addr(OFF_CAM + i), s_out[i]);
+        // the partial goes out with consecutive lanes on consecutive words (one element per lane and instruction was 64 cache lines per store)
+        for (int i = tid; i < NF * 27 + NP + 4; i += kPThreads) tst(q.part, part_at(OFF_CAM + i), s_out[i], tagA);
+        for (int i = tid; i < OFF_CAM; i += kPThreads) tst(q.part, part_at(i), first ? 0.0 : U[i], tagA);   // (opening evaluation: no product, but the round's tag)
     };
 
     // ================================================================================ exchange A -> B: slice-wise reduction
+    unsigned tagB = 0;
     auto reduce_slices = [&]() -> bool {
-        publish();
-        if (!wait_all()) return false;
-        UH_BA_CLK(50);
+        tagB = next_tag();
         const int HG = G < 16 ? G : 16;
-        const double* src = q.part + (size_t)g * G * SL;
+        double* const R = U + NT * 256;          // behind the staged product, which other waves may still be sending
+        const size_t src = (size_t)g * G * SL;   // slice g of every workgroup's partial
         for (int idx = tid; idx < SL * HG; idx += kPThreads) {
             const int hg = idx / SL, e = idx - hg * SL;
             const bool is_max = g * SL + e == OFF_SC + 2;
-            double r = xld(src + (size_t)hg * SL + e);
-            for (int h = hg + HG; h < G; h += 8 * HG) {   // eight loads in flight, added in ascending order
+            const bool used = g * SL + e < q.nelem;   // (the last slice is padded: nobody writes or needs those elements)
+            double r = used ? tload1(q.part, src + (size_t)hg * SL + e, tagA) : 0.0;
+            for (int h = hg + HG; used && h < G; h += 8 * HG) {   // eight elements in flight, added in ascending order
                 double v[8];
+                const int cnt = min(8, (G - h + HG - 1) / HG);
+                tload8(q.part, src + (size_t)h * SL + e, (size_t)HG * SL, cnt, tagA, v);
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = h + u * HG < G ? xld(src + (size_t)(h + u * HG) * SL + e) : (is_max ? r : 0.0);
-#pragma unroll
-                for (int u = 0; u < 8; u++) r = is_max ? fmax(r, v[u]) : r + v[u];
+                for (int u = 0; u < 8; u++) r = is_max ? (u < cnt ? fmax(r, v[u]) : r) : r + v[u];
             }
-            U[idx] = r;
+            R[idx] = r;
         }
+        UH_BA_CLK(50);
         __syncthreads();
+        if (s_flag[1]) return false;
         for (int e = tid; e < SL; e += kPThreads) {
             const bool is_max = g * SL + e == OFF_SC + 2;
-            double r = U[e];
-            for (int hg = 1; hg < HG; hg++) { const double v = U[hg * SL + e]; r = is_max ? fmax(r, v) : r + v; }
-            xst(q.red + (size_t)g * SL + e, r);
+            double r = R[e];
+            for (int hg = 1; hg < HG; hg++) { const double v = R[hg * SL + e]; r = is_max ? fmax(r, v) : r + v; }
+            tst(q.red, (size_t)g * SL + e, r, tagB);
         }
         UH_BA_CLK(51);
-        publish();
-        return wait_all();
+        __syncthreads();   // U is free again
+        return true;
     };
 
     for (int pass = 0; pass < 2; pass++) {
@@ -602,16 +632,18 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         phase1(1.0, true);
         if (!reduce_slices()) return;
         {   // every wave for itself: one diagonal entry of Hpp per lane, max butterfly
-            double m = lane == 0 ? xld(q.red + OFF_SC + 2) : 0.0;
+            double m = lane == 0 ? tload1(q.red, OFF_SC + 2, tagB) : 0.0;
             for (int i = lane; i < n; i += 64) {
                 const int sc = i / 6, a = i - 6 * sc;
-                m = fmax(m, fabs(xld(q.red + OFF_CAM + sc * 27 + (a * 6 - a * (a - 1) / 2))));   // diagonal of the 21-entry upper triangle
+                m = fmax(m, fabs(tload1(q.red, OFF_CAM + sc * 27 + (a * 6 - a * (a - 1) / 2), tagB)));   // diagonal of the 21-entry upper triangle
             }
-            chi_lin_pass = xld(q.red + OFF_SC);
+            chi_lin_pass = tload1(q.red, OFF_SC, tagB);
 #pragma unroll
             for (int oo = 32; oo > 0; oo >>= 1) m = fmax(m, __shfl_xor(m, oo));
             st.lambda = 1e-5 * m; st.ni = 2;
         }
+        __syncthreads();
+        if (s_flag[1]) return;
 
         while (st.phase != 2) {
             const double lambda = st.lambda;
@@ -624,8 +656,11 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             // ---- assemble S = Hpp + lambda I - Yt^T Yt (lower triangle, bordered with b = bp - b_schur), factorise, substitute
             for (int base = 0; base < q.nelem; base += 8 * kPThreads) {
             double rv[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) rv[u] = base + tid + u * kPThreads < q.nelem ? xld(q.red + base + tid + u * kPThreads) : 0.0;
+            {
+                const int left = q.nelem - (base + tid);
+                const int cnt = left <= 0 ? 0 : min(8, (left + kPThreads - 1) / kPThreads);
+                tload8(q.red, (size_t)base + tid, kPThreads, cnt, tagB, rv);
+            }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int idx = base + tid + u * kPThreads;
@@ -648,6 +683,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             }
             }
             __syncthreads();
+            if (s_flag[1]) return;
             if (tid < nfree * 21) {
                 const int sc = tid / 21, qq = tid - 21 * sc;
                 int a = 0, rem = qq;
@@ -735,32 +771,34 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             }
             double cs = chi_part, ss = scale_part;
             block_reduce2<kPWaves, false>(cs, ss, s_red);
+            const unsigned tagC = next_tag();
             if (tid == 0) {
-                xst(q.partC + 4 * g, cs); xst(q.partC + 4 * g + 1, ss);
-                if (g == 0) xst(q.partC + 2, (p.stop && *p.stop) ? 1.0 : 0.0);
+                tst(q.partC, 4 * (size_t)g, cs, tagC); tst(q.partC, 4 * (size_t)g + 1, ss, tagC);
+                if (g == 0) tst(q.partC, 2, (p.stop && *p.stop) ? 1.0 : 0.0, tagC);
             }
             UH_BA_CLK(47);
-            publish();
-            if (!wait_all()) return;
-            UH_BA_CLK(48);
             // ---- decision (every wave of every workgroup, same inputs, same code)
             {
                 double c = 0, sc = 0;
                 {
-                    double cv[4], sv[4];   // G <= 256
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { const int h = lane + 64 * u; cv[u] = h < G ? xld(q.partC + 4 * h) : 0.0; sv[u] = h < G ? xld(q.partC + 4 * h + 1) : 0.0; }
+                    double cv[8], sv[8];   // G <= 256: workgroups lane, lane + 64, ...
+                    const int cnt = lane < G ? (G - lane + 63) / 64 : 0;
+                    tload8(q.partC, 4 * (size_t)lane, 4 * 64, cnt, tagC, cv);
+                    tload8(q.partC, 4 * (size_t)lane + 1, 4 * 64, cnt, tagC, sv);
 #pragma unroll
                     for (int u = 0; u < 4; u++) { c += cv[u]; sc += sv[u]; }
                 }
+                UH_BA_CLK(48);
                 DecideSums sm;
                 sm.lin = chi_lin_pass; sm.chi = wave_sum_fixed(c); sm.scale = wave_sum_fixed(sc); sm.xs = s_sc[0];
-                const bool stopv = xld(q.partC + 2) != 0.0;
+                const bool stopv = tload1(q.partC, 2, tagC) != 0.0;
                 st.solve_ok = ok;
                 st.pending = 1;
                 st = apply_decision(st, sm, stopv);
                 if (st.cur != cur) { X[0] = Xt[0]; X[1] = Xt[1]; X[2] = Xt[2]; }
             }
+            __syncthreads();   // (a wave that gave up waiting has decided on garbage: everybody leaves together)
+            if (s_flag[1]) return;
             UH_BA_CLK(49);
         }
     }

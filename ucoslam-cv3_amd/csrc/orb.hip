@@ -22,6 +22,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
+#include <string>
 
 #include "common.hpp"
 #include "glibc_sincosf.hpp"
@@ -489,31 +491,71 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(const Plan plan, co
         s_nkeys[c] = sk ? 0 : (n20 > 3 ? n20 : n7);   // :980-987
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int nfeaturesCell = L.nfeaturesCell;
-        int nNoMore = 0, nToDistribute = 0;
-        // first pass (:989-1004): skipped cells are not visited; bNoMore is encoded as s_ret sign bit substitute below
-        for (int c = 0; c < nCells; c++) {
-            if (s_skipped[c]) { s_ret[c] = 0; s_off[c] = 0; continue; }   // s_off reused as bNoMore
+    // Quota redistribution (:989-1039) and the two exclusive scans, one thread per cell (round 1 ran them on thread 0: ~80 cells x 3-4
+    // sweeps of dependent LDS reads = half of this kernel's 60 us).  A sweep's decision for a cell depends only on the sweep's quota and
+    // the cell's own count, and the sweep's results are integer sums — the order of the cells does not matter.
+    __shared__ int s_ws[2][kSelWaves];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto block_sum2 = [&](int a, int b, int& ra, int& rb) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        __syncthreads();   // previous readers of s_ws are done; the cell flags written above are visible afterwards
+        if (lane == 0) { s_ws[0][wave] = a; s_ws[1][wave] = b; }
+        __syncthreads();
+        ra = 0; rb = 0;
+#pragma unroll
+        for (int w = 0; w < kSelWaves; w++) { ra += s_ws[0][w]; rb += s_ws[1][w]; }
+    };
+    const int nfeaturesCell = L.nfeaturesCell;
+    int nNoMore = 0, nToDistribute = 0;
+    {
+        int dist = 0, nom = 0;   // first pass: skipped cells are not visited (their bNoMore stays false); s_off doubles as bNoMore
+        for (int c = threadIdx.x; c < nCells; c += kSelThreads) {
+            if (s_skipped[c]) { s_ret[c] = 0; s_off[c] = 0; continue; }
             const int nKeys = s_nkeys[c];
             if (nKeys > nfeaturesCell) { s_ret[c] = nfeaturesCell; s_off[c] = 0; }
-            else { s_ret[c] = nKeys; nToDistribute += nfeaturesCell - nKeys; s_off[c] = 1; nNoMore++; }
+            else { s_ret[c] = nKeys; dist += nfeaturesCell - nKeys; s_off[c] = 1; nom++; }
         }
-        while (nToDistribute > 0 && nNoMore < nCells) {
-            const int nNew = (int)((float)nfeaturesCell + ceilf((float)nToDistribute / (float)(nCells - nNoMore)));
-            nToDistribute = 0;
-            for (int c = 0; c < nCells; c++) {
-                if (s_off[c]) continue;
-                const int nTotal = s_nkeys[c];
-                if (nTotal > nNew) { s_ret[c] = nNew; }
-                else { s_ret[c] = nTotal; nToDistribute += nNew - nTotal; s_off[c] = 1; nNoMore++; }
-            }
+        block_sum2(dist, nom, nToDistribute, nNoMore);
+    }
+    while (nToDistribute > 0 && nNoMore < nCells) {   // (uniform: every thread holds the same sums)
+        const int nNew = (int)((float)nfeaturesCell + ceilf((float)nToDistribute / (float)(nCells - nNoMore)));
+        int dist = 0, nom = 0;
+        for (int c = threadIdx.x; c < nCells; c += kSelThreads) {
+            if (s_off[c]) continue;
+            const int nTotal = s_nkeys[c];
+            if (nTotal > nNew) { s_ret[c] = nNew; }
+            else { s_ret[c] = nTotal; dist += nNew - nTotal; s_off[c] = 1; nom++; }
         }
-        int o = 0, q = 0;
-        for (int c = 0; c < nCells; c++) { s_off[c] = o; o += s_nkeys[c]; s_out[c] = q; q += s_ret[c]; }
-        s_off[nCells] = o;
-        s_out[nCells] = q;
-        s_total = q;
+        int sd, sn;
+        block_sum2(dist, nom, sd, sn);
+        nToDistribute = sd;
+        nNoMore += sn;
+    }
+    __syncthreads();
+    {   // exclusive scans of the candidate counts (-> s_off) and of the quotas (-> s_out): two cells per thread
+        const int c0 = 2 * threadIdx.x, c1 = c0 + 1;
+        const int a0 = c0 < nCells ? s_nkeys[c0] : 0, a1 = c1 < nCells ? s_nkeys[c1] : 0;
+        const int b0 = c0 < nCells ? s_ret[c0] : 0, b1 = c1 < nCells ? s_ret[c1] : 0;
+        int ia = a0 + a1, ib = b0 + b1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int ua = __shfl_up(ia, o), ub = __shfl_up(ib, o);
+            if (lane >= o) { ia += ua; ib += ub; }
+        }
+        __syncthreads();   // everybody has read s_ret / s_nkeys and the bNoMore flags in s_off are dead
+        if (lane == 63) { s_ws[0][wave] = ia; s_ws[1][wave] = ib; }
+        __syncthreads();
+        int pa = 0, pb = 0, ta = 0, tb = 0;
+#pragma unroll
+        for (int w = 0; w < kSelWaves; w++) {
+            if (w < wave) { pa += s_ws[0][w]; pb += s_ws[1][w]; }
+            ta += s_ws[0][w]; tb += s_ws[1][w];
+        }
+        const int ea = pa + ia - (a0 + a1), eb = pb + ib - (b0 + b1);
+        if (c0 < nCells) { s_off[c0] = ea; s_out[c0] = eb; }
+        if (c1 < nCells) { s_off[c1] = ea + a0; s_out[c1] = eb + b0; }
+        if (threadIdx.x == 0) { s_off[nCells] = ta; s_out[nCells] = tb; s_total = tb; }
     }
     __syncthreads();
     // workspace: LDS when the level's filtered candidates + concatenation fit, else HBM scratch.  The two calls are
