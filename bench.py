@@ -66,12 +66,13 @@ MATCH_KERNELS = ("knn_search_kernel", "knn_search_mq_kernel")
 
 def persistent_ba_exchange_bytes(ba_P, trials):
     """What the persistent BA kernel moves BY DESIGN per launch (csrc/ba_persist.hpp): the observations once, then per LM trial the
-    reduction partials between its workgroups (G partials of 1804 doubles written, read slice-wise, the reduced vector read by every
-    workgroup, chi2 partials) — all of it write-through stores / L1-bypassing loads, served by L2 / MALL."""
+    reduction partials between its workgroups (G partials of 1516 doubles written, read slice-wise, the reduced vector read by every
+    workgroup, chi2 partials) — all of it write-through stores / L1-bypassing loads, served by L2 / MALL.  Every exchanged double
+    travels as two tagged 64-bit words (16 bytes)."""
     lw = max(8, min(32, -(-ba_P // 64)))
     g = -(-ba_P // lw)
-    nelem = 1804
-    per_trial = g * nelem * 8 * 2 + g * nelem * 8 + nelem * 8 + g * 32 * (1 + g)
+    nelem = 78 * 16 + 8 * 27 + 48 + 4
+    per_trial = g * nelem * 16 * 2 + g * nelem * 16 + nelem * 16 + g * 64 * (1 + g)
     return int(ba_P * 8 * 28 + trials * per_trial), g
 
 

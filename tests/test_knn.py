@@ -122,6 +122,49 @@ def test_hip_knn_queries_per_wave_identical_rows(hip_ctx, oracle, qpw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("accept_qpw", ["1", "2"])
+def test_hip_knn_two_phase_form_every_k(hip_ctx, oracle, accept_qpw, monkeypatch):
+    """The accept-list scan + lane-per-query replay (default from 6000 queries on, forced here for every size): every k the register heap is
+    instantiated for (1..16), sorted and unsorted, ties, distances descending with the row index (every accept list overflows its
+    capacity: the redo kernel), sets smaller than k, ragged query counts, a radius bound; one and two queries per scanning wave."""
+    from ucoslam_cv3_amd.knn import Index
+
+    monkeypatch.setenv("UH_KNN_FORM", "twophase")
+    monkeypatch.setenv("UH_KNN_ACCEPT_QPW", accept_qpw)
+    for case, (train, q) in _gpu_cases().items():
+        index = Index(hip_ctx).build(train)
+        for nn in range(1, 17):
+            for s in (0, 1):
+                idx, dist = index.search(q, nn, sorted=bool(s))
+                ri, rd = oracle_lib.knn_search(oracle, train, q, nn, s)
+                np.testing.assert_array_equal(idx, ri, err_msg=f"{case} nn={nn} sorted={s}")
+                np.testing.assert_array_equal(dist, rd)
+    train, q = synth.match_set(1003, 9999, seed=78)
+    index = Index(hip_ctx).build(train)
+    for nn, md in ((10, -1), (10, 70), (2, -1), (2, 55), (16, 90)):
+        idx, dist = index.search(q, nn, sorted=True, max_dist=md)
+        ri, rd = oracle_lib.knn_search(oracle, train, q, nn, 1, max_dist=md)
+        np.testing.assert_array_equal(idx, ri, err_msg=f"nn={nn} max_dist={md}")
+        np.testing.assert_array_equal(dist, rd)
+    # a long descending run: row i is closer to every query than row i-1 -> every row is accepted, every list overflows
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, 32, dtype=np.uint8)
+    n = 700
+    train = np.repeat(base[None, :], n, 0)
+    bits = np.unpackbits(train, axis=1)
+    for i in range(n):
+        bits[i, : max(0, 250 - i // 3)] ^= 1
+    train = np.packbits(bits, axis=1)
+    q = np.repeat(base[None, :], 70, 0)
+    index = Index(hip_ctx).build(train)
+    for nn in (3, 10):
+        idx, dist = index.search(q, nn, sorted=False)
+        ri, rd = oracle_lib.knn_search(oracle, train, q, nn, 0)
+        np.testing.assert_array_equal(idx, ri)
+        np.testing.assert_array_equal(dist, rd)
+
+
+@pytest.mark.gpu
 def test_hip_knn_large_map_and_widest_rows(hip_ctx, oracle):
     """150 000 train rows (a large map), nn = 64 (the widest row the wave heap holds) and nn = 1, sorted and unsorted; a train
     count that is not a multiple of the 256-row scan group."""

@@ -648,6 +648,10 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         while (st.phase != 2) {
             const double lambda = st.lambda;
             const int cur = st.cur, trial = cur ^ 1;
+            // the force-stop byte lives in pinned HOST memory: a PCIe round trip.  It is requested here, a whole trial before its value is
+            // sent with the chi2 partials, instead of on the hand-off itself (1.5 - 3 us in front of every decision)
+            unsigned char stop_byte = 0;
+            if (g == 0 && tid == 0 && p.stop) stop_byte = *p.stop;
             UH_BA_CLK(40);
             phase1(lambda, false);
             UH_BA_CLK(41);
@@ -774,7 +778,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             const unsigned tagC = next_tag();
             if (tid == 0) {
                 tst(q.partC, 4 * (size_t)g, cs, tagC); tst(q.partC, 4 * (size_t)g + 1, ss, tagC);
-                if (g == 0) tst(q.partC, 2, (p.stop && *p.stop) ? 1.0 : 0.0, tagC);
+                if (g == 0) tst(q.partC, 2, stop_byte ? 1.0 : 0.0, tagC);
             }
             UH_BA_CLK(47);
             // ---- decision (every wave of every workgroup, same inputs, same code)

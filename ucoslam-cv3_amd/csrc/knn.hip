@@ -26,6 +26,7 @@
 #include <string>
 #include <cstring>
 #include <random>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -268,11 +269,10 @@ __device__ __forceinline__ void finish_row(WaveHeap& h, int k, int sorted, int32
 template <int LV>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_search_kernel(
     const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k,
-    int sorted, int maxd, int32_t* __restrict__ indices, int32_t* __restrict__ distances, const int* __restrict__ only) {
+    int sorted, int maxd, int32_t* __restrict__ indices, int32_t* __restrict__ distances) {
     const int lane = threadIdx.x & (kWave - 1);
     const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (qi >= nq) return;
-    if (only && !only[qi]) return;   // second pass of the two-phase search: only the queries whose accept list overflowed
     uint32_t q[8];
     load_query(queries, qi, q);
     WaveHeap h{0, -1, 0, lane};
@@ -282,68 +282,83 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_search_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ two-phase exact search (nn <= 16)
-// Round 1 replayed every accepted push on a lane-distributed heap inside the scanning wave: ~1000 cycles of dependent ds_bpermute
-// rounds per push, ~70 pushes per query (nn = 10, 10 000 rows) = 45-60 % of the search.  Here the scan only has to know the
-// THRESHOLD the reference's heap would have — its root when full = the k-th smallest distance seen so far — which needs no heap:
-// the k smallest distances sit one per lane in lanes 0..k-1 (any order), the threshold is their maximum (four DPP row operations,
-// no LDS crossbar), an accepted distance replaces a lane that holds the maximum.  Everything below the threshold at the start of a
-// 64-row step is appended to the query's accept list (a superset of what the reference's heap accepts, in index order; emitted by
-// all passing lanes at once).  Phase 2 replays the lists through the reference's ResultSet (resultset.h:64-135) exactly, ONE LANE
-// PER QUERY... — that was the plan; measured on MI355X (8000 x 10 000, nn = 10): accept scan 84-94 us (1-2 queries per wave), replay by one
-// lane per query on LDS heaps 174 us (125 single waves, each a ~95-element serial chain of LDS round trips), replay by one WAVE per
-// query on the lane-distributed heap (the multi-GPU replay kernel) 107 us — 190+ us against 162 us for the fused round-1 kernel, whose
-// pushes partly overlap other waves' scans.  The two-phase form therefore stays OFF by default (UH_KNN_FORM=twophase selects accept scan +
-// wave replay); what it does establish is the split of the fused kernel's time: the scan alone is ~85 us, the ~600 k exact pushes ~100 us.
-__device__ __forceinline__ int row16_max(int v) {   // afterwards every lane of a 16-lane row holds the row's maximum
-    v = max(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]: lane ^ 1
-    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]: lane ^ 2
-    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));   // row_half_mirror: i <-> 7 - i
-    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true));   // row_mirror: i <-> 15 - i
-    return v;
-}
-
-struct AcceptSet {
-    int sv;     // lanes 0..k-1: the k smallest distances so far (INT_MAX while unfilled); other lanes INT_MIN
-    int thr;    // wave-uniform: max of the members
-    int lane;
-    __device__ __forceinline__ int threshold(int) const { return thr; }
-};
-
-template <bool EMIT, int LV>
-__device__ __forceinline__ void feed_step(AcceptSet& s, int d, int idx, bool valid, int k, int maxd, uint64_t* row, int& ncand, int cap) {
-    const bool pass = valid && (maxd < 0 || d <= maxd) && d < s.thr;
-    uint64_t m = __ballot(pass);
-    if (!m) return;
-    const int pos = ncand + __popcll(m & ((1ull << s.lane) - 1ull));
-    if (pass && pos < cap) row[pos] = ((uint64_t)(uint32_t)d << 32) | (uint32_t)idx;
-    ncand += __popcll(m);
-    while (m) {   // tighten the threshold with the step's passing rows (order does not matter for the set's maximum)
-        const int l = __builtin_ctzll(m);
-        m &= m - 1;
-        const int dl = rl(d, l);
-        if (dl >= s.thr) continue;
-        const int victim = __builtin_ctzll(__ballot(s.sv == s.thr));   // a lane that holds the maximum
-        s.sv = s.lane == victim ? dl : s.sv;
-        s.thr = __builtin_amdgcn_readfirstlane(row16_max(s.sv));
-    }
-}
-
+// The fused kernel above replays every accepted push on a lane-distributed heap inside the scanning wave: ~1000 cycles of dependent
+// ds_bpermute rounds per push, ~70 pushes per query (nn = 10, 10 000 rows) — more than the scan itself.  The two-phase form splits it:
+//
+//  Phase 1 (knn_accept_kernel) only needs the THRESHOLD the reference's heap would have — its root when full = the k-th smallest
+//  distance seen so far.  The smallest distances are kept SORTED along the lanes of a 16-lane DPP row: an accepted distance d is inserted
+//  with one row_shr:1 + compare + max + select, the threshold is lane k-1 (one v_readlane).  Rows below the threshold at the start of
+//  a 64-row step are appended to the query's accept list by all passing lanes at once (a superset of what the reference's heap accepts,
+//  in index order).  Two queries per wave share every loaded row (one query per wave is L1-bandwidth bound: 76 us of scan against 50 us,
+//  MI355X, 8000 x 10 000).  History of the k-set: unordered in a DPP row, replace-the-maximum + 4-step DPP max + readfirstlane + ballot =
+//  25 vector instructions per accepted row: 88 us (38 us of it maintenance); a sorted list in SGPRs updated by 2 k scalar min / max: 100 us
+//  (the CU's one scalar unit issues for all four SIMDs, so a scalar instruction costs as much CU time as a vector one).
+//
+//  Phase 2 (knn_replay_lane_kernel) replays the lists through the reference's ResultSet (resultset.h:64-135) with ONE LANE PER QUERY and the
+//  heap in REGISTERS, K a template parameter: every heap index is a compile-time constant (the sift-down selects among the nodes of one
+//  level, the sift-up walks the fixed ancestor chain of slot K-1), no LDS, no cross-lane traffic; 64 queries advance per instruction.
+//  History: heaps in LDS, one lane per query: 174 us (a ~95-element chain of LDS round trips per wave); one WAVE per query on the
+//  lane-distributed heap: 107 us; four queries per wave in 16-lane rows with row-local ds_bpermute: 63 us.
+//
+//  Lists that overflow their capacity (distances descending with the row index) are collected and recomputed by knn_redo_kernel.
 template <int QPW>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_accept_kernel(
     const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k, int maxd,
-    uint64_t* __restrict__ cand, int32_t* __restrict__ counts, int cap) {
+    uint64_t* __restrict__ cand, int32_t* __restrict__ counts, int cap, int* __restrict__ redo_count) {
     const int lane = threadIdx.x & (kWave - 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *redo_count = 0;   // (the replay launch behind this one counts the overflowed lists)
     const int q0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * QPW);
     if (q0 >= nq) return;
     uint32_t q[QPW][8];
-    AcceptSet a[QPW];
+    int sv[QPW];    // every 16-lane row: the smallest distances so far, ascending with the lane (INT_MAX where nothing has been seen yet)
+    int thr[QPW];   // wave-uniform: the k-th smallest = lane k-1 of a row
     int nc[QPW];
 #pragma unroll
     for (int j = 0; j < QPW; ++j) {
         load_query(queries, q0 + j < nq ? q0 + j : nq - 1, q[j]);
-        a[j] = AcceptSet{lane < k ? 0x7fffffff : (int)0x80000000, 0x7fffffff, lane};
+        sv[j] = 0x7fffffff; thr[j] = 0x7fffffff;
         nc[j] = 0;
     }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // sorted insert of an accepted distance: every lane whose value exceeds d takes max(left neighbour, d) — its neighbour's value if that
+    // also exceeds d, else d itself; the largest value falls off the end of the row.  Four vector instructions + one v_readlane.
+    auto tighten = [&](int j, int dl) {
+        const int left = __builtin_amdgcn_update_dpp(0, sv[j], 0x111, 0xF, 0xF, false);   // row_shr:1 (lane 0 of a row: 0)
+        sv[j] = sv[j] > dl ? max(left, dl) : sv[j];
+        thr[j] = rl(sv[j], k - 1);
+    };
+    // one 64-row step of query j.  Lists are ENTRY-major (entry e of query q at cand[e * nq + q]): the replay reads them one lane per query.
+    // The first step of a scan is taken row by row, exactly as the reference accepts (its 64 rows all lie below the initial threshold:
+    // emitting them wholesale made every list 64 - k (1 + ln(64 / k)) entries longer); afterwards all rows below the threshold at the
+    // start of the step are appended at once, then the threshold is tightened with them.
+    auto feed = [&](int j, int d, int idx, bool valid, int qj, bool exact) {
+        const bool pass = valid && (maxd < 0 || d <= maxd) && d < thr[j];
+        uint64_t m = __ballot(pass);
+        if (!m) return;
+        if (exact) {
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const int dl = rl(d, l);
+                if (dl >= thr[j]) continue;
+                const int il = rl(idx, l);
+                if (lane == 0 && nc[j] < cap) cand[(size_t)nc[j] * nq + qj] = ((uint64_t)(uint32_t)dl << 32) | (uint32_t)il;
+                nc[j]++;
+                tighten(j, dl);
+            }
+            return;
+        }
+        const int pos = nc[j] + __popcll(m & lt);
+        if (pass && pos < cap) cand[(size_t)pos * nq + qj] = ((uint64_t)(uint32_t)d << 32) | (uint32_t)idx;
+        nc[j] += __popcll(m);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const int dl = rl(d, l);
+            if (dl >= thr[j]) continue;
+            tighten(j, dl);
+        }
+    };
     constexpr int UNROLL = 4;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(train), 0, t1 * 32, 0x00020000);
@@ -363,13 +378,12 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_accept_kernel(
         for (int j = 0; j < QPW; ++j) {
             int d[UNROLL];
             bool any = false;
-            const int thr = a[j].thr;
+            const int tj = thr[j];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) { d[u] = hamming256(a0[u], a1[u], q[j]); any = any || d[u] < thr; }
+            for (int u = 0; u < UNROLL; ++u) { d[u] = hamming256(a0[u], a1[u], q[j]); any = any || d[u] < tj; }
             if (__ballot(any) == 0) continue;
-            uint64_t* row = cand + (size_t)(q0 + j < nq ? q0 + j : 0) * cap;
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) feed_step<true, 0>(a[j], d[u], base + u * kWave + lane, q0 + j < nq, k, maxd, row, nc[j], cap);
+            for (int u = 0; u < UNROLL; ++u) feed(j, d[u], base + u * kWave + lane, q0 + j < nq, q0 + j < nq ? q0 + j : 0, u == 0 && base == t0);
         }
     }
     for (; base < t1; base += kWave) {
@@ -382,106 +396,222 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_accept_kernel(
             x1 = p[1];
         }
 #pragma unroll
-        for (int j = 0; j < QPW; ++j)
-            feed_step<true, 0>(a[j], hamming256(x0, x1, q[j]), t, valid && q0 + j < nq, k, maxd, cand + (size_t)(q0 + j < nq ? q0 + j : 0) * cap, nc[j], cap);
+        for (int j = 0; j < QPW; ++j) feed(j, hamming256(x0, x1, q[j]), t, valid && q0 + j < nq, q0 + j < nq ? q0 + j : 0, base == t0);
     }
 #pragma unroll
     for (int j = 0; j < QPW; ++j)
         if (q0 + j < nq && lane == 0) counts[q0 + j] = nc[j];
 }
 
-constexpr int kRpK = 16;   // the two-phase form keeps its k-set in one 16-lane DPP row
+constexpr int kRpK = 16;   // the two-phase form serves k <= 16
 
-// Replay of accept lists with FOUR queries per wave: every 16-lane row holds one query's ResultSet (lane = row * 16 + heap slot, k <= 16),
-// all cross-lane reads are row-local ds_bpermutes, so one instruction stream performs four pushes at once — the push itself is the
-// formulation of WaveHeap::push_accepted (root removal by "every slot picks its bigger child + ancestor walk", append by "ancestors
-// smaller than the new distance take their parent"), with a per-row size.  A row walks its own list; rows whose list is exhausted idle.
-// A list that overflowed its capacity is flagged in `redo` (that query is recomputed by the one-wave kernel afterwards).
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_replay4_kernel(
-    const uint64_t* __restrict__ cand, const int32_t* __restrict__ counts, int nq, int k, int sorted, int maxd, int cap,
-    int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ redo) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int slot = lane & 15, rowbase = lane & 48;
-    const int qi = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+// ---- ResultSet in the registers of one lane (K = the search's k): resultset.h:64-135, the sequential swaps of the reference.
+// Every index below is a compile-time constant (static_for / template recursion, not unrolled loops with early exits): one index the
+// optimiser cannot fold sends the whole heap to scratch memory.
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+// sift the new element up from STATIC slot P (:93-100)
+template <int K, int P>
+__device__ __forceinline__ void heap_append_step(int (&hd)[K], int (&hi)[K], bool up, int d, int idx) {
+    if constexpr (P == 0) {
+        hd[0] = up ? d : hd[0];
+        hi[0] = up ? idx : hi[0];
+    } else {
+        constexpr int par = (P - 1) >> 1;
+        const bool mv = up && hd[par] < d;
+        hd[P] = up ? (mv ? hd[par] : d) : hd[P];
+        hi[P] = up ? (mv ? hi[par] : idx) : hi[P];
+        heap_append_step<K, par>(hd, hi, mv, d, idx);
+    }
+}
+template <int K, int S>
+__device__ __forceinline__ void heap_append_at(int (&hd)[K], int (&hi)[K], bool acc, int d, int idx) { heap_append_step<K, S>(hd, hi, acc, d, idx); }
+// remove the root of a FULL heap (:104-135): the last element re-enters at the root and sinks; nodes 0 .. K-2 take part.  Level by
+// level: the lane's position is one of the level's nodes, its children are selected from the next level.
+template <int K, int LVL>
+__device__ __forceinline__ void heap_pop_level(int (&hd)[K], int (&hi)[K], int md, int mi, int pos, bool go) {
+    constexpr int NS = K - 1, first = (1 << LVL) - 1;
+    if constexpr (first < NS) {
+        constexpr int last = 2 * first < NS - 1 ? 2 * first : NS - 1;
+        int dl = 0, dr = 0, il = 0, ir = 0;
+        bool hasL = false, hasR = false;
+        static_for<first, last + 1>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            const bool at = pos == n;
+            if constexpr (2 * n + 1 < NS) { dl = at ? hd[2 * n + 1] : dl; il = at ? hi[2 * n + 1] : il; hasL = hasL || at; }
+            if constexpr (2 * n + 2 < NS) { dr = at ? hd[2 * n + 2] : dr; ir = at ? hi[2 * n + 2] : ir; hasR = hasR || at; }
+        });
+        const bool pickL = !hasR || dr < dl;
+        const int dc = pickL ? dl : dr, ic = pickL ? il : ir;
+        const bool mv = go && hasL && md < dc;
+        static_for<first, last + 1>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            const bool w = go && pos == n;
+            hd[n] = w ? (mv ? dc : md) : hd[n];
+            hi[n] = w ? (mv ? ic : mi) : hi[n];
+        });
+        heap_pop_level<K, LVL + 1>(hd, hi, md, mi, mv ? (pickL ? 2 * pos + 1 : 2 * pos + 2) : pos, mv);
+    }
+}
+template <int K>
+__device__ __forceinline__ void heap_pop_full(int (&hd)[K], int (&hi)[K], bool acc) {
+    if constexpr (K >= 2) heap_pop_level<K, 0>(hd, hi, hd[K - 1], hi[K - 1], 0, acc);
+}
+// any mixture of sizes inside the wave (lists of different lengths, max_dist): dynamic positions through select chains
+template <int K>
+__device__ __forceinline__ int heap_get(const int (&a)[K], int i) {
+    int r = a[0];
+    static_for<1, K>([&](auto nc) { constexpr int n = decltype(nc)::value; r = i == n ? a[n] : r; });
+    return r;
+}
+template <int K>
+__device__ __forceinline__ void heap_put(int (&a)[K], int i, bool on, int v) {
+    static_for<0, K>([&](auto nc) { constexpr int n = decltype(nc)::value; a[n] = (on && i == n) ? v : a[n]; });
+}
+// append only (no accepting lane is full yet — the first K entries of the lists): sift up from the lane's own size
+template <int K>
+__device__ __forceinline__ void heap_append_generic(int (&hd)[K], int (&hi)[K], int& size, bool acc, int d, int idx) {
+    int pos = size;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int parent = pos > 0 ? (pos - 1) >> 1 : 0;
+        const int dp = heap_get<K>(hd, parent), ip = heap_get<K>(hi, parent);
+        const bool mv = acc && pos > 0 && dp < d;
+        heap_put<K>(hd, pos, mv, dp);
+        heap_put<K>(hi, pos, mv, ip);
+        pos = mv ? parent : pos;
+    }
+    heap_put<K>(hd, pos, acc, d);
+    heap_put<K>(hi, pos, acc, idx);
+    size = acc ? size + 1 : size;
+}
+template <int K>
+__device__ __forceinline__ void heap_push_generic(int (&hd)[K], int (&hi)[K], int& size, bool acc, int d, int idx) {
+    const bool pop = acc && size >= K;
+    const int ns = pop ? size - 1 : size;
+    const int md = heap_get<K>(hd, ns < K ? ns : K - 1), mi = heap_get<K>(hi, ns < K ? ns : K - 1);
+    int pos = 0;
+    bool go = pop && ns > 1;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int l = 2 * pos + 1, r = l + 1;
+        const bool hasL = go && l < ns, hasR = go && r < ns;
+        const int dl = heap_get<K>(hd, l < K ? l : K - 1), dr = heap_get<K>(hd, r < K ? r : K - 1);
+        const bool pickL = !hasR || dr < dl;
+        const int c = pickL ? l : r, dc = pickL ? dl : dr;
+        const bool mv = hasL && md < dc;
+        const int ic = heap_get<K>(hi, c < K ? c : K - 1);
+        heap_put<K>(hd, pos, mv, dc);
+        heap_put<K>(hi, pos, mv, ic);
+        pos = mv ? c : pos;
+        go = mv;
+    }
+    heap_put<K>(hd, pos, pop && ns >= 1, md);
+    heap_put<K>(hi, pos, pop && ns >= 1, mi);
+    size = ns;
+    pos = size;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int parent = pos > 0 ? (pos - 1) >> 1 : 0;
+        const int dp = heap_get<K>(hd, parent), ip = heap_get<K>(hi, parent);
+        const bool mv = acc && pos > 0 && dp < d;
+        heap_put<K>(hd, pos, mv, dp);
+        heap_put<K>(hi, pos, mv, ip);
+        pos = mv ? parent : pos;
+    }
+    heap_put<K>(hd, pos, acc, d);
+    heap_put<K>(hi, pos, acc, idx);
+    size = acc ? size + 1 : size;
+}
+
+template <int K>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) void knn_replay_lane_kernel(
+    const uint64_t* __restrict__ cand, const int32_t* __restrict__ counts, int nq, int sorted, int maxd, int cap,
+    int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ redo_list, int* __restrict__ redo_count) {
+    extern __shared__ uint64_t s_list[];   // [cap][64]: this wave's 64 lists, staged with every load in flight at once
+    const int qi = blockIdx.x * kWave + threadIdx.x;
     const bool haveq = qi < nq;
     const int cnt_raw = haveq ? counts[qi] : 0;
     const bool over = cnt_raw > cap;
-    if (haveq && slot == 0) redo[qi] = over ? 1 : 0;
+    if (over) redo_list[atomicAdd(redo_count, 1)] = qi;
     const int cnt = over ? 0 : cnt_raw;
     int maxcnt = cnt;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o));
-    const uint64_t* row = cand + (size_t)(haveq ? qi : 0) * cap;
-    int hd = 0, hi = -1, size = 0;
-    const int parent = slot > 0 ? (slot - 1) >> 1 : 0;
-    const int l = 2 * slot + 1, r = l + 1;
-    const int lsrc = rowbase + (l < 16 ? l : 15), rsrc = rowbase + (r < 16 ? r : 15);
-    for (int j0 = 0; j0 < maxcnt; j0 += 16) {
-        const uint64_t batch = j0 + slot < cnt ? row[j0 + slot] : 0;   // 16 list entries per row and batch, one per lane
-        const int blo = (int)(uint32_t)batch, bhi = (int)(batch >> 32);
-        const int nb = min(16, maxcnt - j0);
-        for (int e = 0; e < nb; e++) {
-            const int idx = __shfl(blo, rowbase + e), d = __shfl(bhi, rowbase + e);
-            const bool valid = j0 + e < cnt && !(maxd >= 0 && maxd < d);                  // resultset.h:66
-            const int root = __shfl(hd, rowbase);
-            const bool acc = valid && (size < k || d < root);                             // :67-69
-            if (!__any(acc)) continue;
-            // ---- root removal (:70-73) for the rows that are full
-            const bool pop = acc && size >= k;
-            const int ns = pop ? size - 1 : size;
-            const int lastsrc = rowbase + (ns < 16 ? ns : 15);
-            const int md = __shfl(hd, lastsrc), mi = __shfl(hi, lastsrc);
-            const int vl = __shfl(hd, lsrc), vr = __shfl(hd, rsrc);
-            const bool hasL = l < ns, hasR = r < ns;
-            const bool pickL = !hasR || (vr < vl);
-            const int c = pickL ? l : r;
-            const int cv = pickL ? vl : vr;
-            const int ci = __shfl(hi, rowbase + (c < 16 ? c : 15));
-            bool onpath = slot < ns;
-            int node = slot;
+    maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);   // (tell the compiler: the loop below is wave-uniform)
+    const uint64_t* col = cand + (haveq ? qi : 0);   // entry e of this lane's query: col[e * nq] (coalesced across the wave)
+    int hd[K], hi[K];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {                                                 // slot 15 lies four levels below the root
-                const int par = node > 0 ? (node - 1) >> 1 : 0;
-                const int cpar = __shfl(c, rowbase + par);
-                onpath = onpath && (node == 0 || cpar == node);
-                node = par;
-            }
-            const bool reached = pop && ns >= 1 && onpath && (slot == 0 || hd > md);
-            const bool takeChild = hasL && cv > md;
-            hd = reached ? (takeChild ? cv : md) : hd;
-            hi = reached ? (takeChild ? ci : mi) : hi;
-            size = ns;
-            // ---- append + climb (:77-79) for the rows that accept
-            bool onanc = false;
+    for (int i = 0; i < K; i++) { hd[i] = 0; hi[i] = -1; }
+    int size = 0;
+    // Stage the lists in LDS first: maxcnt coalesced loads (512 bytes each), all in flight together = ONE memory round trip per wave.
+    // Read inside the push loop (even four entries ahead) the loads cost more than the pushes: 34 of 57 us were memory stalls.
+    for (int e0 = 0; e0 < maxcnt; e0 += 16) {
+        uint64_t v[16];
 #pragma unroll
-            for (int x = size + 1, t = 0; t < 5; t++, x >>= 1) onanc = onanc || (x > 0 && x - 1 == slot);   // the new slot and its ancestors
-            const int pv = __shfl(hd, rowbase + parent), pi = __shfl(hi, rowbase + parent);
-            const bool mine = acc && onanc && (slot == size || hd < d);
-            const bool takeParent = slot > 0 && pv < d;
-            hd = mine ? (takeParent ? pv : d) : hd;
-            hi = mine ? (takeParent ? pi : idx) : hi;
-            size = acc ? size + 1 : size;
+        for (int u = 0; u < 16; u++) v[u] = col[(size_t)min(e0 + u, cap - 1) * nq];
+#pragma unroll
+        for (int u = 0; u < 16; u++) if (e0 + u < maxcnt) s_list[(e0 + u) * kWave + threadIdx.x] = v[u];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the lane reads back only what it wrote itself
+    uint64_t nxt = s_list[threadIdx.x];
+    for (int e = 0; e < maxcnt; e++) {
+        const uint64_t cur = nxt;
+        nxt = s_list[min(e + 1, maxcnt - 1) * kWave + threadIdx.x];
+        const int idx = (int)(uint32_t)cur, d = (int)(cur >> 32);
+        const bool valid = e < cnt && !(maxd >= 0 && maxd < d);     // resultset.h:66
+        const bool acc = valid && (size < K || d < hd[0]);          // :67-69
+        const unsigned long long am = __ballot(acc);
+        if (!am) continue;
+        if (__ballot(acc && size != K) == 0) {                      // steady state: every accepting lane's heap is full
+            heap_pop_full<K>(hd, hi, acc);
+            heap_append_at<K, K - 1>(hd, hi, acc, d, idx);
+        } else if (__ballot(acc && size >= K) == 0) {               // filling: nobody has to remove a root (select chains, no dynamic index:
+            heap_append_generic<K>(hd, hi, size, acc, d, idx);      // a dispatch on the common size ends up as an indexed store to scratch)
+        } else {
+            heap_push_generic<K>(hd, hi, size, acc, d, idx);
         }
     }
-    // linear.h:82-85 (fill) + index.h:119-134 (exchange sort), per row
-    if (slot >= size) { hd = 0; hi = -1; }
+    // linear.h:82-85 (fill) + index.h:119-134 (exchange sort; idx[i] is tested once, before the inner loop)
+#pragma unroll
+    for (int i = 0; i < K; i++) if (i >= size) { hd[i] = 0; hi[i] = -1; }
     if (sorted) {
-        for (int i = 0; i < k - 1; ++i) {
-            const int di = __shfl(hd, rowbase + i), ii = __shfl(hi, rowbase + i);
-            int cd = di, cidx = ii;                                                        // the value slot i currently holds (per row)
-            for (int j = i + 1; j < k; ++j) {
-                const int dj = __shfl(hd, rowbase + j), ij = __shfl(hi, rowbase + j);
-                const bool sw = ii != -1 && cd > dj;                                        // (index.h:123 tests idx[i] once, before the inner loop)
-                if (sw && slot == j) { hd = cd; hi = cidx; }
-                const int nd = sw ? dj : cd, ni = sw ? ij : cidx;
-                if (sw && slot == i) { hd = nd; hi = ni; }
-                cd = nd; cidx = ni;
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) {
+            const bool on = hi[i] != -1;
+#pragma unroll
+            for (int j = i + 1; j < K; ++j) {
+                const bool sw = on && hd[i] > hd[j];
+                const int td = hd[i], ti = hi[i];
+                hd[i] = sw ? hd[j] : td; hi[i] = sw ? hi[j] : ti;
+                hd[j] = sw ? td : hd[j]; hi[j] = sw ? ti : hi[j];
             }
         }
     }
-    if (haveq && !over && slot < k) {
-        indices[(size_t)qi * k + slot] = hi;
-        distances[(size_t)qi * k + slot] = hd;
+    if (haveq && !over) {
+#pragma unroll
+        for (int i = 0; i < K; i++) { indices[(size_t)qi * K + i] = hi[i]; distances[(size_t)qi * K + i] = hd[i]; }
+    }
+}
+
+// the (rare) queries whose accept list overflowed: the fused one-wave search, over a compacted list
+template <int LV>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_redo_kernel(
+    const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int k, int sorted, int maxd,
+    int32_t* __restrict__ indices, int32_t* __restrict__ distances, const int* __restrict__ redo_list, const int* __restrict__ redo_count) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int n = __builtin_amdgcn_readfirstlane(*redo_count);
+    const int nw = gridDim.x * kWavesPerBlock;
+    for (int j = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)); j < n; j += nw) {
+        const int qi = __builtin_amdgcn_readfirstlane(redo_list[j]);
+        uint32_t q[8];
+        load_query(queries, qi, q);
+        WaveHeap h{0, -1, 0, lane};
+        int ncand = 0;
+        scan_range<false, LV>(h, train, t0, t1, q, k, maxd, nullptr, ncand, 0);
+        finish_row(h, k, sorted, indices, distances, qi);
     }
 }
 
@@ -866,7 +996,10 @@ struct uh_knn {
     int shard_begin = 0, shard_end = 0;
     int row_offset = 0;           // global index of row 0 (uh_knn_set_row_offset): an index that holds only one tile of a sharded train set
     int qpw = 1;                  // queries per wave of the exact search (uh_knn_set_queries_per_wave)
-    bool two_phase = false;       // UH_KNN_FORM=twophase: accept-list scan + separate replay launch (measured slower than the fused form)
+    int two_phase_min_nq = 6000;  // exact search, nn <= 16: accept-list scan + lane-per-query replay from this many queries on, the fused one-kernel
+                                  // form below it (the replay is a fixed ~60 us chain per wave: 8000 x 10 000 x nn 10 = 147 vs 163 us, 2000 queries = 106
+                                  // vs 77 us).  UH_KNN_FORM=twophase / fused forces one form.
+    int accept_qpw = 2;           // queries per wave of the accept scan (UH_KNN_ACCEPT_QPW=1 for the A/B)
     uh::DevBuf list_buf;          // accept lists, counts and redo flags of the two-phase search
     uh::DevBuf q_buf, idx_buf, dist_buf;  // staging for the host-pointer API
     // hierarchical k-means form of the same index (uh_knn_build_kmeans)
@@ -890,7 +1023,8 @@ int uh_knn_create(uh_ctx* ctx, uh_knn** out) {
     UH_REQUIRE(ctx && out, "uh_knn_create: NULL argument");
     uh_knn* k = new uh_knn();
     k->ctx = ctx;
-    if (const char* f = getenv("UH_KNN_FORM")) k->two_phase = std::string(f) == "twophase";
+    if (const char* f = getenv("UH_KNN_FORM")) k->two_phase_min_nq = std::string(f) == "fused" ? 0x7fffffff : (std::string(f) == "twophase" ? 0 : k->two_phase_min_nq);
+    if (const char* f = getenv("UH_KNN_ACCEPT_QPW")) k->accept_qpw = atoi(f) == 1 ? 1 : 2;
     *out = k;
     return UH_OK;
 }
@@ -982,28 +1116,37 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
     // slower (the pushes of a wave's queries serialise), its L1/L2 traffic and its resident waves drop to 1/2 or 1/4, which is what a
     // latency-bound neighbour on another stream (the local BA) needs
     const int qpw = nn <= 15 ? idx->qpw : 1;
-    if (nn <= kRpK && idx->two_phase) {
+    if (nn <= kRpK && nq >= idx->two_phase_min_nq) {
         // accept-list capacity: the expected number of accepted pushes is k (1 + ln(N / k)) (a record process), its spread ~ sqrt of
-        // that; lists that still overflow (distances descending with the row index) are redone by the one-wave kernel below
+        // that; lists that still overflow (distances descending with the row index) are redone by knn_redo_kernel
         const int nrows = std::max(idx->shard_end - idx->shard_begin, 1);
         const double expect = nn * (1.0 + std::log(std::max((double)nrows / nn, 1.0)));
-        const int cap = std::min(std::min(std::max(((int)(1.6 * expect) + 32 + 31) & ~31, 32), std::max((nrows + 31) & ~31, 32)), 256);   // 64 staged lists of cap + 1 entries must fit in LDS
+        const int cap = std::min(std::min(std::max(((int)(1.6 * expect) + 32 + 31) & ~31, 32), std::max((nrows + 31) & ~31, 32)), 256);
         int rc;
         if ((rc = idx->list_buf.reserve((size_t)nq * cap * 8 + (size_t)nq * 8 + 256))) return rc;
         uint64_t* d_cand = idx->list_buf.as<uint64_t>();
         int32_t* d_counts = reinterpret_cast<int32_t*>(d_cand + (size_t)nq * cap);
-        const dim3 ga(uh_div_up(nq, kWavesPerBlock * qpw));
-        if (qpw == 4) UH_LAUNCH(idx->ctx, knn_accept_kernel<4>, ga, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
-        else if (qpw == 2) UH_LAUNCH(idx->ctx, knn_accept_kernel<2>, ga, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
-        else UH_LAUNCH(idx->ctx, knn_accept_kernel<1>, ga, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
-        // phase 2: four queries per wave, one 16-lane heap each (knn_replay4_kernel); then the one-wave kernel for the (rare) queries whose
-        // list overflowed.  (Measured and rejected: one LANE per query on heaps in LDS — 125 single waves each running a ~95-element serial
-        // chain, 174 us for 8000 queries; one WAVE per query on the 64-lane heap, 107 us.)
-        int* d_redo = d_counts + nq;
-        UH_LAUNCH(idx->ctx, knn_replay4_kernel, dim3(uh_div_up(nq, kWavesPerBlock * 4)), block, 0, d_cand, d_counts, nq, nn, sorted ? 1 : 0, max_dist, cap, d_indices, d_distances, d_redo);
-        if (nn <= 3) UH_LAUNCH(idx->ctx, knn_search_kernel<1>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo);
-        else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_search_kernel<3>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo);
-        else UH_LAUNCH(idx->ctx, knn_search_kernel<6>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo);
+        int* d_redo = d_counts + nq;       // [nq] compacted list of overflowed queries, [nq] their number
+        int* d_nredo = d_redo + nq;
+        const int aq = idx->accept_qpw;   // queries per wave of the accept scan (default 2: one is L1-bandwidth bound)
+        const dim3 ga(uh_div_up(nq, kWavesPerBlock * aq));
+#define UH_KNN_ACCEPT(Q) UH_LAUNCH(idx->ctx, knn_accept_kernel<Q>, ga, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap, d_nredo)
+        if (aq == 1) UH_KNN_ACCEPT(1); else UH_KNN_ACCEPT(2);
+#undef UH_KNN_ACCEPT
+        const dim3 gr(uh_div_up(nq, kWave));
+        const size_t lds_lists = (size_t)cap * kWave * 8;   // cap <= 256: at most 128 KB
+#define UH_KNN_REPLAY(K) case K: UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_replay_lane_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lists)); \
+        UH_LAUNCH(idx->ctx, knn_replay_lane_kernel<K>, gr, dim3(kWave), lds_lists, d_cand, d_counts, nq, sorted ? 1 : 0, max_dist, cap, d_indices, d_distances, d_redo, d_nredo); break
+        switch (nn) {
+            UH_KNN_REPLAY(1); UH_KNN_REPLAY(2); UH_KNN_REPLAY(3); UH_KNN_REPLAY(4); UH_KNN_REPLAY(5); UH_KNN_REPLAY(6); UH_KNN_REPLAY(7); UH_KNN_REPLAY(8);
+            UH_KNN_REPLAY(9); UH_KNN_REPLAY(10); UH_KNN_REPLAY(11); UH_KNN_REPLAY(12); UH_KNN_REPLAY(13); UH_KNN_REPLAY(14); UH_KNN_REPLAY(15); UH_KNN_REPLAY(16);
+            default: break;
+        }
+#undef UH_KNN_REPLAY
+        const dim3 gd(64);
+        if (nn <= 3) UH_LAUNCH(idx->ctx, knn_redo_kernel<1>, gd, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo, (const int*)d_nredo);
+        else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_redo_kernel<3>, gd, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo, (const int*)d_nredo);
+        else UH_LAUNCH(idx->ctx, knn_redo_kernel<6>, gd, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo, (const int*)d_nredo);
         UH_HIP_CHECK(hipGetLastError());
         return UH_OK;
     }
@@ -1014,9 +1157,9 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
         else { if (qpw == 2) UH_KNN_MQ(3, 2); else UH_KNN_MQ(3, 4); }
 #undef UH_KNN_MQ
     } else
-    if (nn <= 3) UH_LAUNCH(idx->ctx, knn_search_kernel<1>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)nullptr);
-    else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_search_kernel<3>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)nullptr);
-    else UH_LAUNCH(idx->ctx, knn_search_kernel<6>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)nullptr);
+    if (nn <= 3) UH_LAUNCH(idx->ctx, knn_search_kernel<1>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances);
+    else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_search_kernel<3>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances);
+    else UH_LAUNCH(idx->ctx, knn_search_kernel<6>, grid, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
 }
