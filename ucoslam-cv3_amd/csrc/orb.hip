@@ -65,6 +65,7 @@ struct Plan {           // uploaded once per (size, params)
     int maxFeatures;
     int total_tiles, total_cells;
     int lvl_end;        // levels >= lvl_end are not needed by this instance's shard: the resize chain stops before them
+    int sel_wg_begin[kMaxLevels + 1];   // select_kernel: level l is served by workgroups [sel_wg_begin[l], sel_wg_begin[l+1]) of a frame
     LevelDesc lv[kMaxLevels];
 };
 
@@ -389,31 +390,29 @@ struct SelectArgs {
     const LevelDesc* L;
     const int* cc;
     const uint32_t* cbase;
-    uint32_t* lsel;
-    int* level_count;
     const int* s_nkeys; const int* s_ret; const int* s_off; const int* s_out;
-    int nCells, iniTh, total;
-    int scratch_ints;   // LDS path: ints available after work+cat for the partition scratch (0 = use the sequential routine)
+    int nCells, iniTh;
+    int c_lo, c_hi;     // this workgroup's cells
+    int scratch_ints;   // LDS path: ints available behind the cells' lists for the partition scratch (0 = use the sequential routine)
 };
 
-// per-cell retainBest + truncate (:1053-1055), concatenation (:1058-1065), level-wide retainBest + truncate (:1069-1073),
-// computeDescriptors' border filter (:1124-1130).  WorkPtr is either an LDS or a global pointer (static address space).
-// Cells are spread over the 4 waves of the workgroup; each selection is wave-cooperative (introselect.hpp) when the LDS
-// scratch allows it and falls back to the sequential routine otherwise (same data movement either way).
+// Phase 1, this workgroup's cells [c_lo, c_hi): per-cell retainBest + truncate (:1053-1055); the survivors go to their place in the level's
+// concatenation (:1058-1065) in HBM.  WorkPtr is either an LDS or a global pointer (static address space); `work` addresses the
+// filtered list of cell c at s_off[c] - s_off[c_lo].  Cells are spread over the waves; each selection is wave-cooperative
+// (introselect.hpp) when the LDS scratch allows it and falls back to the sequential routine otherwise (same data movement either way).
 template <typename WorkPtr>
-__device__ __forceinline__ void select_body(WorkPtr work, const SelectArgs& A) {
+__device__ __forceinline__ void select_cells(WorkPtr work, int* scratch, uint32_t* __restrict__ cat_g, const SelectArgs& A) {
     const LevelDesc& L = *A.L;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    WorkPtr cat = work + A.s_off[A.nCells];
-    int* scratch = reinterpret_cast<int*>(&cat[A.s_out[A.nCells]]);
     const int per_wave = A.scratch_ints / kSelWaves;     // each wave: Lpos | Rpos halves
     int* myL = scratch + wv * per_wave;
     int* myR = myL + per_wave / 2;
-    for (int c = wv; c < A.nCells; c += kSelWaves) {
+    const int off0 = A.s_off[A.c_lo];
+    for (int c = A.c_lo + wv; c < A.c_hi; c += kSelWaves) {
         const int nk = A.s_nkeys[c], ret = A.s_ret[c];
         if (nk == 0) continue;
         const uint32_t* src = A.cbase + (size_t)c * L.cellCap;
-        WorkPtr w = work + A.s_off[c];
+        WorkPtr w = work + (A.s_off[c] - off0);
         const int n7 = A.cc[2 * c], n20 = A.cc[2 * c + 1];
         // threshold filter of the cell's raster-ordered candidates (:980-987), order preserving
         int k = 0;
@@ -431,51 +430,61 @@ __device__ __forceinline__ void select_body(WorkPtr work, const SelectArgs& A) {
             if (per_wave / 2 >= nk) uh_sel::wave_nth_element_desc(w, nk, ret - 1, myL, myR, lane);
             else { if (lane == 0) uh_sel::nth_element_desc(w, nk, ret - 1); uh_sel::wave_mem_sync(); }
         }
-        WorkPtr o = cat + A.s_out[c];
-        for (int i = lane; i < ret; i += 64) o[i] = w[i];
-    }
-    __syncthreads();
-    int total = A.total;
-    if (total > L.nDesired) {   // :1069-1073
-        if (wv == 0 && L.nDesired > 0) {
-            if (A.scratch_ints / 2 >= total) uh_sel::wave_nth_element_desc(cat, total, L.nDesired - 1, scratch, scratch + A.scratch_ints / 2, lane);
-            else { if (lane == 0) uh_sel::nth_element_desc(cat, total, L.nDesired - 1); uh_sel::wave_mem_sync(); }
-        }
-        total = L.nDesired;
-        __syncthreads();
-    }
-    if (wv == 0) {   // border filter, order preserving; the reference applies it before describing
-        const int maxX = L.w - EDGE, maxY = L.h - EDGE;
-        int k = 0;
-        for (int i0 = 0; i0 < total; i0 += 64) {
-            const int i = i0 + lane;
-            const uint32_t e = i < total ? cat[i] : 0u;
-            const int x = e & 0xFFF, y = (e >> 12) & 0xFFF;
-            const bool keep = i < total && !(x < EDGE || y < EDGE || x > maxX || y > maxY);
-            const unsigned long long m = __ballot(keep);
-            if (keep) A.lsel[k + __popcll(m & ((1ull << lane) - 1ull))] = e;
-            k += __popcll(m);
-        }
-        if (lane == 0) *A.level_count = k;
+        uint32_t* o = cat_g + A.s_out[c];   // write-through stores: the level's last workgroup may sit on another XCD (non-coherent L2)
+        for (int i = lane; i < ret; i += 64) __hip_atomic_store(o + i, (uint32_t)w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
+// Phase 2, the workgroup that finishes a level last: level-wide retainBest + truncate (:1069-1073) over the concatenation, then
+// computeDescriptors' border filter (:1124-1130), order preserving (the reference applies it before describing).
+template <typename CatPtr>
+__device__ __forceinline__ void select_level(CatPtr cat, int* scratch, int scratch_ints, int total, const LevelDesc& L, uint32_t* __restrict__ lsel,
+                                             int* __restrict__ level_count) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (wv != 0) return;
+    if (total > L.nDesired) {
+        if (L.nDesired > 0) {
+            if (scratch_ints / 2 >= total) uh_sel::wave_nth_element_desc(cat, total, L.nDesired - 1, scratch, scratch + scratch_ints / 2, lane);
+            else { if (lane == 0) uh_sel::nth_element_desc(cat, total, L.nDesired - 1); uh_sel::wave_mem_sync(); }
+        }
+        total = L.nDesired;
+    }
+    const int maxX = L.w - EDGE, maxY = L.h - EDGE;
+    int k = 0;
+    for (int i0 = 0; i0 < total; i0 += 64) {
+        const int i = i0 + lane;
+        const uint32_t e = i < total ? cat[i] : 0u;
+        const int x = e & 0xFFF, y = (e >> 12) & 0xFFF;
+        const bool keep = i < total && !(x < EDGE || y < EDGE || x > maxX || y > maxY);
+        const unsigned long long m = __ballot(keep);
+        if (keep) lsel[k + __popcll(m & ((1ull << lane) - 1ull))] = e;
+        k += __popcll(m);
+    }
+    if (lane == 0) *level_count = k;
+}
+
 // ------------------------------------------------------------------------------------------------ selection
-// One workgroup per (frame, level): quota redistribution (:994-1039), per-cell retainBest + truncate (:1053-1055),
-// concatenation in cell-row-major order (:1058-1065), level-wide retainBest + truncate (:1069-1073).
-// Workspace `work` holds the threshold-filtered cell lists back to back, `cat` the concatenation.
+// Several workgroups per (frame, level) — one per 64 cells: every one of them repeats the level's quota redistribution (:994-1039, a few
+// parallel sweeps), then selects inside ITS cells (per-cell retainBest + truncate, :1053-1055) and writes the survivors to their place
+// in the level's concatenation (cell-row-major order, :1058-1065).  The workgroup that finishes a level last (a ticket counter, nobody
+// waits) runs the level-wide retainBest + truncate (:1069-1073) and the border filter.  One workgroup per level spent 40 of its 49 us
+// walking level 0's ~490 cells with 16 waves.
 __global__ __launch_bounds__(kSelThreads) void select_kernel(const Plan plan, const CellDesc* __restrict__ cells,
                                                      const uint32_t* __restrict__ cand, size_t cand_frame_stride,
                                                      const int* __restrict__ cell_counts, uint32_t* __restrict__ work_g,
                                                      size_t work_frame_stride, uint32_t* __restrict__ sel,
-                                                     size_t sel_frame_stride, int* __restrict__ level_counts, int lds_entries) {
+                                                     size_t sel_frame_stride, int* __restrict__ level_counts, int lds_entries,
+                                                     int* __restrict__ tickets) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     __shared__ int s_nkeys[kMaxCellsPerLevel];
     __shared__ int s_ret[kMaxCellsPerLevel];
     __shared__ int s_off[kMaxCellsPerLevel + 1];
     __shared__ int s_out[kMaxCellsPerLevel + 1];
     __shared__ int s_total;
-    const int lvl = blockIdx.x, frame = blockIdx.y;
+    const int frame = blockIdx.y;
+    int lvl = 0;
+    while (lvl + 1 < plan.nlevels && (int)blockIdx.x >= plan.sel_wg_begin[lvl + 1]) ++lvl;
+    const int part = blockIdx.x - plan.sel_wg_begin[lvl], nparts = plan.sel_wg_begin[lvl + 1] - plan.sel_wg_begin[lvl];
     const LevelDesc& L = plan.lv[lvl];
     const int nCells = L.nCells;
     const int* cc = cell_counts + ((size_t)frame * plan.total_cells + L.cell_begin) * 2;
@@ -558,16 +567,38 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(const Plan plan, co
         if (threadIdx.x == 0) { s_off[nCells] = ta; s_out[nCells] = tb; s_total = tb; }
     }
     __syncthreads();
-    // workspace: LDS when the level's filtered candidates + concatenation fit, else HBM scratch.  The two calls are
-    // separate instantiations so that the pointer's address space is static (a generic pointer would compile every
-    // access of the selection into a flat_load).
-    const int need = s_off[nCells] + s_out[nCells];
-    SelectArgs A{&L, cc, cbase, lsel, level_counts + (size_t)frame * kMaxLevels + lvl, s_nkeys, s_ret, s_off, s_out, nCells, iniTh, s_total, 0};
+    // ---- phase 1: this workgroup's cells.  Workspace: LDS when their filtered candidates fit, else the level's HBM scratch (the two
+    // calls are separate instantiations so that the pointer's address space is static: a generic pointer would compile every access of
+    // the selection into a flat_load).
+    uint32_t* const work_lvl = work_g + (size_t)frame * work_frame_stride + 2 * (size_t)L.cand_off;   // [filtered lists | concatenation]
+    uint32_t* const cat_g = work_lvl + s_off[nCells];
+    const int chunk = (nCells + nparts - 1) / nparts;
+    SelectArgs A{&L, cc, cbase, s_nkeys, s_ret, s_off, s_out, nCells, iniTh, min(part * chunk, nCells), min((part + 1) * chunk, nCells), 0};
+    const int need = s_off[A.c_hi] - s_off[A.c_lo];
     if (need <= lds_entries) {
         A.scratch_ints = ((lds_entries - need) / (2 * kSelWaves)) * (2 * kSelWaves);   // whatever LDS is left becomes partition scratch
-        select_body(s_dyn, A);
+        select_cells(s_dyn, reinterpret_cast<int*>(s_dyn + need), cat_g, A);
     } else {
-        select_body(work_g + (size_t)frame * work_frame_stride + 2 * (size_t)L.cand_off, A);   // HBM workspace, sequential selection
+        select_cells(work_lvl + s_off[A.c_lo], static_cast<int*>(nullptr), cat_g, A);   // sequential selection in HBM
+    }
+    // ---- ticket: the last workgroup of the level goes on
+    __shared__ int s_ticket;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's write-through stores have landed before the ticket is drawn
+    __syncthreads();                                   // (a device-wide fence here costs a whole L2 write-back: 6 us, measured)
+    int* const ticket = tickets + (size_t)frame * kMaxLevels + lvl;
+    if (threadIdx.x == 0) s_ticket = nparts > 1 ? atomicAdd(ticket, 1) : 0;
+    __syncthreads();
+    if (s_ticket != nparts - 1) return;
+    if (threadIdx.x == 0 && nparts > 1) *ticket = 0;   // ready for the next launch
+    // ---- phase 2: the whole level
+    const int total = s_total;
+    int* const lc = level_counts + (size_t)frame * kMaxLevels + lvl;
+    if (total <= lds_entries) {
+        for (int i = threadIdx.x; i < total; i += kSelThreads) s_dyn[i] = __hip_atomic_load(cat_g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (L2-bypassing)
+        __syncthreads();
+        select_level(s_dyn, reinterpret_cast<int*>(s_dyn + total), ((lds_entries - total) / 2) * 2, total, L, lsel, lc);
+    } else {
+        select_level(cat_g, static_cast<int*>(nullptr), 0, total, L, lsel, lc);
     }
 }
 
@@ -772,6 +803,7 @@ struct uh_orb {
     int lds_entries = 0;
     uh::DevBuf d_plan, d_cells, d_xofs, d_xcoef, d_yofs, d_ycoef;
     uh::DevBuf d_pyr, d_score, d_cand, d_work, d_sel, d_cell_counts, d_level_counts;
+    uh::DevBuf d_tickets;   // select_kernel: workgroups of a (frame, level) that have finished their cells
     // staging for the host-pointer API
     uh::DevBuf d_in, d_kps, d_desc, d_counts;
 };
@@ -894,6 +926,19 @@ int make_plan(uh_orb* o, int w, int h, int batch) {
     }
     P.total_tiles = tile_begin;
     P.total_cells = cell_begin;
+    // selection workgroups per level: one per 16 cells (a cell per wave) while the launch stays within one workgroup per CU; large
+    // batches fall back towards one workgroup per level (every workgroup repeats the level's quota redistribution)
+    {
+        int want = 0;
+        for (int l = 0; l < P.nlevels; l++) want += std::max(1, std::min(32, uh_div_up(std::max(P.lv[l].nCells, 1), kSelWaves)));
+        const double f = std::min(1.0, 256.0 / ((double)std::max(want, 1) * std::max(batch, 1)));
+        P.sel_wg_begin[0] = 0;
+        for (int l = 0; l < kMaxLevels; l++) {
+            int parts = 0;
+            if (l < P.nlevels) parts = std::max(1, (int)(f * std::max(1, std::min(32, uh_div_up(std::max(P.lv[l].nCells, 1), kSelWaves)))));
+            P.sel_wg_begin[l + 1] = P.sel_wg_begin[l] + parts;
+        }
+    }
     o->frame_stride = (img_off + 255) & ~(size_t)255;
     o->cand_stride = cand_off;
     o->sel_stride = sel_off;
@@ -925,6 +970,12 @@ int make_plan(uh_orb* o, int w, int h, int batch) {
     if ((rc = o->d_sel.reserve(std::max<size_t>(o->sel_stride, 1) * batch * 4))) return rc;
     if ((rc = o->d_cell_counts.reserve(std::max<size_t>(P.total_cells, 1) * batch * 8))) return rc;
     if ((rc = o->d_level_counts.reserve((size_t)kMaxLevels * batch * 4))) return rc;
+    {   // select_kernel's ticket counters: zero between launches (the last workgroup of a level puts its counter back)
+        const size_t tb = (size_t)kMaxLevels * batch * 4;
+        const bool fresh = o->d_tickets.cap < tb;
+        if ((rc = o->d_tickets.reserve(tb))) return rc;
+        if (fresh) UH_HIP_CHECK(hipMemsetAsync(o->d_tickets.p, 0, o->d_tickets.cap, o->ctx->stream));
+    }
     o->w = w; o->h = h; o->batch = batch;
     o->planned = true;
     return UH_OK;
@@ -967,10 +1018,10 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
                            o->d_score.as<uint8_t>(), o->frame_stride, o->d_cand.as<uint32_t>(), o->cand_stride,
                            o->d_cell_counts.as<int>());
     }
-    UH_LAUNCH(o->ctx,select_kernel, dim3(P.nlevels, batch), dim3(kSelThreads), (size_t)o->lds_entries * 4, P,
+    UH_LAUNCH(o->ctx,select_kernel, dim3(P.sel_wg_begin[P.nlevels], batch), dim3(kSelThreads), (size_t)o->lds_entries * 4, P,
                        o->d_cells.as<CellDesc>(), o->d_cand.as<uint32_t>(), o->cand_stride, o->d_cell_counts.as<int>(),
                        o->d_work.as<uint32_t>(), o->cand_stride * 2, o->d_sel.as<uint32_t>(), o->sel_stride,
-                       o->d_level_counts.as<int>(), o->lds_entries);
+                       o->d_level_counts.as<int>(), o->lds_entries, o->d_tickets.as<int>());
     if (o->nonmaxima) {
         const size_t lds = (size_t)std::max(P.maxFeatures, 1) * 5 + 64;
         UH_REQUIRE(lds <= 150 * 1024, "orb: orb_nonmaxima with %d features per level does not fit LDS", P.maxFeatures);
