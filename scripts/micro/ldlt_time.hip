@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void k(const double* A, double* out, int n, in
     __shared__ short s_pair[64][2];
     const int npairs = nfree * (nfree + 1) / 2;
     for (int t = threadIdx.x; t < npairs; t += 256) { int s1 = 0, rem = t; while (rem >= nfree - s1) { rem -= nfree - s1; ++s1; } s_pair[t][0] = s1; s_pair[t][1] = s1 + rem; }
-    long long best = 1ll << 60;
+    long long best = 1ll << 60, bestb = 1ll << 60;
     for (int r = 0; r < reps; r++) {
         for (int i = threadIdx.x; i < ld * ld; i += 256) M[i] = A[i];
         __syncthreads();
@@ -25,8 +25,16 @@ __global__ __launch_bounds__(256) void k(const double* A, double* out, int n, in
         const long long t1 = clock64();
         if (t1 - t0 < best) best = t1 - t0;
         __syncthreads();
+        __shared__ double s_x[64];
+        const long long t2 = clock64();
+        backsolve_lds(M, n, ld, s_x);
+        __syncthreads();
+        const long long t3 = clock64();
+        if (t3 - t2 < bestb) bestb = t3 - t2;
+        if (threadIdx.x < n) out[ld * ld + threadIdx.x] = s_x[threadIdx.x];
+        __syncthreads();
     }
-    if (threadIdx.x == 0) { clk[0] = best; for (int i = 0; i < 64; i++) clk[1 + i] = g_clk[i]; }
+    if (threadIdx.x == 0) { clk[0] = best; clk[64] = bestb; for (int i = 0; i < 63; i++) clk[1 + i] = g_clk[i]; }
     for (int i = threadIdx.x; i < ld * ld; i += 256) out[i] = M[i];
 }
 int run(int nfree) {
@@ -38,20 +46,23 @@ int run(int nfree) {
     for (int i = 0; i < n; i++) for (int j = i + 1; j < ld; j++) A[i * ld + j] = std::nan("");   // the upper triangle is never to be used
     for (int j = 0; j < n; j++) A[n * ld + j] = N(rng);
     double *dA, *dO; long long* dc;
-    hipMalloc(&dA, A.size() * 8); hipMalloc(&dO, A.size() * 8); hipMalloc(&dc, 65 * 8);
+    hipMalloc(&dA, A.size() * 8); hipMalloc(&dO, (A.size() + 64) * 8); hipMalloc(&dc, 65 * 8);
     hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
     const size_t lds = (ld * ld + 2 * 121 * 6) * 8;
     hipLaunchKernelGGL(k, dim3(1), dim3(256), lds, 0, dA, dO, n, nfree, dc, 20);
     hipDeviceSynchronize();
     long long c[65]; hipMemcpy(c, dc, sizeof(c), hipMemcpyDeviceToHost);
-    std::vector<double> O(A.size()); hipMemcpy(O.data(), dO, O.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> O(A.size() + 64); hipMemcpy(O.data(), dO, O.size() * 8, hipMemcpyDeviceToHost);
     double err = 0, errb = 0;
     for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) { double s = 0; for (int k = 0; k <= j; k++) { const double li = k == i ? 1.0 : O[i * ld + k], lj = k == j ? 1.0 : O[j * ld + k]; s += li * O[k * ld + k] * lj; } err = fmax(err, fabs(s - A[i * ld + j])); }
     for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k <= i; k++) s += (k == i ? 1.0 : O[i * ld + k]) * O[k * ld + k] * O[n * ld + k]; errb = fmax(errb, fabs(s - A[n * ld + i])); }   // L D z = b
+    double errx = 0;   // S x = b with the original matrix
+    for (int i = 0; i < n; i++) { double sx = 0; for (int j = 0; j < n; j++) sx += (j <= i ? A[i * ld + j] : A[j * ld + i]) * O[ld * ld + j]; errx = fmax(errx, fabs(sx - A[n * ld + i])); }
+    printf("   backsolve %lld clocks (%.2f us), |S x - b| = %.3g\n", c[64], c[64] / 2390.0, errx);
     printf("nfree %d: best %lld shader clocks (%.2f us at 2.39 GHz), |LDL^T - A| = %.3g, |L D z - b| = %.3g\n", nfree, c[0], c[0] / 2390.0, err, errb);
-    if (nfree == 8) for (int i = 0; i < 40; i++) if (c[1 + i]) printf("clk[%d] = +%lld\n", i, c[1 + i] - c[1]);
+    if (false) for (int i = 0; i < 40; i++) if (c[1 + i]) printf("clk[%d] = +%lld\n", i, c[1 + i] - c[1]);
     hipFree(dA); hipFree(dO); hipFree(dc);
-    return !(err < 1e-9 && errb < 1e-9);
+    return !(err < 1e-9 && errb < 1e-9 && errx < 1e-9);
 }
 int main() {
     int bad = 0;

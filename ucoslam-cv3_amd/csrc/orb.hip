@@ -36,6 +36,7 @@ constexpr int kMaxLevels = 16;
 constexpr int kMaxDim = 4095;          // candidate words pack x and y in 12 bits each
 constexpr int kMaxCellsPerLevel = 2048;
 constexpr int kNmsTileBytes = 16384;     // cell_nms: LDS staging of one cell's strength values
+constexpr int kNmsPatchBytes = 20480;    // cell_nms (fused with the FAST strength): the cell's pixels + a 3-pixel frame
 constexpr int kSelThreads = 1024;       // selection workgroup: 16 waves share one level's cells
 constexpr int kSelWaves = kSelThreads / 64;
 constexpr int PATCH_SIZE = 31, HALF_PATCH = 15, EDGE = 19;
@@ -252,8 +253,12 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const Plan plan, const 
 // ------------------------------------------------------------------------------------------------ per-cell NMS
 // One workgroup per (frame, cell).  Candidates = in-cell strict 3x3 maxima with score >= minTh, written in raster order as
 // (score<<24 | y<<12 | x) in level coordinates; n7 = their count, n20 = how many of them reach iniTh.
+// FUSED: the strength values of the cell are computed here, from the pyramid level (the cell's pixels + a 3-pixel frame staged in LDS) —
+// every pixel belongs to exactly one cell, so nothing is computed twice, and the strength map (one launch, one write and one read of
+// every level) disappears from the extractor's chain.  Plans with a cell too large for the staging buffers keep the two-launch form.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void cell_nms_kernel(const Plan plan, const CellDesc* __restrict__ cells,
-                                                       const uint8_t* __restrict__ score, size_t frame_stride,
+                                                       const uint8_t* __restrict__ score /* FUSED: the pyramid */, size_t frame_stride,
                                                        uint32_t* __restrict__ cand, size_t cand_frame_stride,
                                                        int* __restrict__ cell_counts /* [frame][cell][2] */) {
     __shared__ int s_wave[4];
@@ -272,15 +277,51 @@ __global__ __launch_bounds__(256) void cell_nms_kernel(const Plan plan, const Ce
     // stage the cell's strength values in LDS with one fully overlapped pass (all loads in flight together); cells larger
     // than the staging buffer (huge cells of tiny feature budgets) read HBM/L2 directly
     __shared__ uint8_t s_tile[kNmsTileBytes];
-    const bool staged = npix > 0 && npix <= kNmsTileBytes;
-    if (staged)
-        for (int i = threadIdx.x; i < npix; i += 256) { const int yy = i / iw, xx = i - yy * iw; s_tile[i] = sc[(size_t)(C.y0 + yy) * L.pitch + C.x0 + xx]; }
+    // the image patch (FUSED) and the candidate lists never live at the same time: one LDS region
+    constexpr int kListInts = kNmsTileBytes / 2 + 4 * 64;
+    __shared__ __attribute__((aligned(16))) uint32_t s_un[(FUSED ? (kNmsPatchBytes > kListInts * 4 ? kNmsPatchBytes : kListInts * 4) : kListInts * 4) / 4];
+    const bool staged = FUSED ? npix > 0 : (npix > 0 && npix <= kNmsTileBytes);   // (FUSED plans only hold cells that fit)
+    if constexpr (FUSED) {
+        if (npix > 0) {
+            uint8_t* s_img = reinterpret_cast<uint8_t*>(s_un);
+            const int pw = iw + 6, ph = ih + 6;
+            for (int i = threadIdx.x; i < pw * ph; i += 256) {
+                const int py = i / pw, px = i - py * pw;
+                const int gy = min(max(C.y0 + py - 3, 0), L.h - 1), gx = min(max(C.x0 + px - 3, 0), L.w - 1);
+                s_img[i] = sc[(size_t)gy * L.pitch + gx];
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < npix; i += 256) {
+                const int yy = i / iw, xx = i - yy * iw;
+                const int gx = C.x0 + xx, gy = C.y0 + yy;
+                int sv = 0;
+                if (gx >= 3 && gy >= 3 && gx < L.w - 3 && gy < L.h - 3) {   // (fast_score_kernel's rule: the level's 3-pixel rim scores 0)
+                    const uint8_t* c = s_img + (yy + 3) * pw + xx + 3;
+                    const int v = c[0];
+                    int d[25];
+                    d[0] = v - c[3 * pw + 0];   d[1] = v - c[3 * pw + 1];   d[2] = v - c[2 * pw + 2];
+                    d[3] = v - c[1 * pw + 3];   d[4] = v - c[3];            d[5] = v - c[-1 * pw + 3];
+                    d[6] = v - c[-2 * pw + 2];  d[7] = v - c[-3 * pw + 1];  d[8] = v - c[-3 * pw];
+                    d[9] = v - c[-3 * pw - 1];  d[10] = v - c[-2 * pw - 2]; d[11] = v - c[-1 * pw - 3];
+                    d[12] = v - c[-3];          d[13] = v - c[1 * pw - 3];  d[14] = v - c[2 * pw - 2];
+                    d[15] = v - c[3 * pw - 1];
+#pragma unroll
+                    for (int k = 16; k < 25; k++) d[k] = d[k - 16];
+                    sv = max(fast_strength(d), 0);
+                }
+                s_tile[i] = (uint8_t)sv;
+            }
+        }
+    } else {
+        if (staged)
+            for (int i = threadIdx.x; i < npix; i += 256) { const int yy = i / iw, xx = i - yy * iw; s_tile[i] = sc[(size_t)(C.y0 + yy) * L.pitch + C.x0 + xx]; }
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (staged) {
         // Fast path: each wave owns one contiguous quarter of the cell's raster, compacts its candidates into its own LDS
         // list with no workgroup barrier inside the loop, then the four lists are concatenated in wave (= raster) order.
-        __shared__ uint32_t s_list[kNmsTileBytes / 2 + 4 * 64];
+        uint32_t* const s_list = s_un;
         __shared__ int s_cnt[4], s_c20[4];
         const int chunk = ((npix + 3) / 4 + 63) & ~63;            // pixels per wave, multiple of 64
         uint32_t* mylist = s_list + wv * (chunk / 2 + 64);        // NMS packing bound: <= every other pixel of a range
@@ -804,6 +845,8 @@ struct uh_orb {
     uh::DevBuf d_plan, d_cells, d_xofs, d_xcoef, d_yofs, d_ycoef;
     uh::DevBuf d_pyr, d_score, d_cand, d_work, d_sel, d_cell_counts, d_level_counts;
     uh::DevBuf d_tickets;   // select_kernel: workgroups of a (frame, level) that have finished their cells
+    bool fuse_fast = false;        // every cell fits cell_nms_kernel<true>'s staging buffers: no strength map, no fast_score launch
+    bool score_valid = false;      // d_score holds the last extraction's strength maps (uh_orb_debug_level computes them on demand)
     // staging for the host-pointer API
     uh::DevBuf d_in, d_kps, d_desc, d_counts;
 };
@@ -926,6 +969,16 @@ int make_plan(uh_orb* o, int w, int h, int batch) {
     }
     P.total_tiles = tile_begin;
     P.total_cells = cell_begin;
+    {   // the FAST strength is computed inside cell_nms_kernel when every cell fits its staging buffers (UH_ORB_FAST=map: the two-launch form)
+        bool fits = true;
+        for (const CellDesc& C : o->cells) {
+            const int iw = C.x1 - C.x0, ih = C.y1 - C.y0;
+            if (C.skipped || iw <= 0 || ih <= 0) continue;
+            fits = fits && iw * ih <= kNmsTileBytes && (iw + 6) * (ih + 6) <= kNmsPatchBytes;
+        }
+        const char* e = getenv("UH_ORB_FAST");
+        o->fuse_fast = fits && !(e && std::string(e) == "map");
+    }
     // selection workgroups per level: one per 16 cells (a cell per wave) while the launch stays within one workgroup per CU; large
     // batches fall back towards one workgroup per level (every workgroup repeats the level's quota redistribution)
     {
@@ -1011,12 +1064,20 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
                            o->d_xofs.as<int>() + D.xtap_off, o->d_xcoef.as<short>() + (size_t)D.xtap_off * 4,
                            o->d_yofs.as<int>() + D.ytap_off, o->d_ycoef.as<short>() + (size_t)D.ytap_off * 4);
     }
-    UH_LAUNCH(o->ctx,fast_score_kernel, dim3(P.total_tiles, batch), dim3(256), 0, P, pyr, o->d_score.as<uint8_t>(),
-                       o->frame_stride);
+    o->score_valid = !o->fuse_fast;
+    if (!o->fuse_fast) {
+        UH_LAUNCH(o->ctx,fast_score_kernel, dim3(P.total_tiles, batch), dim3(256), 0, P, pyr, o->d_score.as<uint8_t>(),
+                           o->frame_stride);
+    }
     if (P.total_cells > 0) {
-        UH_LAUNCH(o->ctx,cell_nms_kernel, dim3(P.total_cells, batch), dim3(256), 0, P, o->d_cells.as<CellDesc>(),
-                           o->d_score.as<uint8_t>(), o->frame_stride, o->d_cand.as<uint32_t>(), o->cand_stride,
-                           o->d_cell_counts.as<int>());
+        if (o->fuse_fast) {
+            UH_LAUNCH(o->ctx,cell_nms_kernel<true>, dim3(P.total_cells, batch), dim3(256), 0, P, o->d_cells.as<CellDesc>(),
+                               (const uint8_t*)pyr, o->frame_stride, o->d_cand.as<uint32_t>(), o->cand_stride, o->d_cell_counts.as<int>());
+        } else {
+            UH_LAUNCH(o->ctx,cell_nms_kernel<false>, dim3(P.total_cells, batch), dim3(256), 0, P, o->d_cells.as<CellDesc>(),
+                               (const uint8_t*)o->d_score.as<uint8_t>(), o->frame_stride, o->d_cand.as<uint32_t>(), o->cand_stride,
+                               o->d_cell_counts.as<int>());
+        }
     }
     UH_LAUNCH(o->ctx,select_kernel, dim3(P.sel_wg_begin[P.nlevels], batch), dim3(kSelThreads), (size_t)o->lds_entries * 4, P,
                        o->d_cells.as<CellDesc>(), o->d_cand.as<uint32_t>(), o->cand_stride, o->d_cell_counts.as<int>(),
@@ -1203,6 +1264,12 @@ int uh_orb_debug_level(uh_orb* o, int frame, int level, int which, uint8_t* out,
     if (w_out) *w_out = L.w;
     if (h_out) *h_out = L.h;
     if (!out) return UH_OK;
+    if (which && !o->score_valid) {   // the fused extraction keeps no strength map: compute it from the pyramid of the last extraction
+        UH_HIP_CHECK(hipSetDevice(o->ctx->device));
+        UH_LAUNCH(o->ctx, fast_score_kernel, dim3(o->plan.total_tiles, o->batch), dim3(256), 0, o->plan, (const uint8_t*)o->d_pyr.as<uint8_t>(),
+                  o->d_score.as<uint8_t>(), o->frame_stride);
+        o->score_valid = true;
+    }
     const uint8_t* base = (which ? o->d_score.as<uint8_t>() : o->d_pyr.as<uint8_t>()) + (size_t)frame * o->frame_stride + L.img_off;
     UH_HIP_CHECK(hipMemcpy2DAsync(out, L.w, base, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, o->ctx->stream));
     UH_HIP_CHECK(hipStreamSynchronize(o->ctx->stream));
