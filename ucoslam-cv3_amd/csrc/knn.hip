@@ -412,118 +412,102 @@ template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
+// An entry is ONE 32-bit word, distance << 23 | row index (distance <= 256, fewer than 2^23 rows — the host checks): every move of the
+// sifts is one select instead of two.  The heap orders by distance alone (ties never move an entry): d(a) < d(b) <=> a < (b & kDistMask).
+constexpr unsigned kDistMask = 0xFF800000u;
+__device__ __forceinline__ bool dist_less(unsigned a, unsigned b) { return a < (b & kDistMask); }
+
 // sift the new element up from STATIC slot P (:93-100)
 template <int K, int P>
-__device__ __forceinline__ void heap_append_step(int (&hd)[K], int (&hi)[K], bool up, int d, int idx) {
+__device__ __forceinline__ void heap_append_step(unsigned (&hw)[K], bool up, unsigned cw) {
     if constexpr (P == 0) {
-        hd[0] = up ? d : hd[0];
-        hi[0] = up ? idx : hi[0];
+        hw[0] = up ? cw : hw[0];
     } else {
         constexpr int par = (P - 1) >> 1;
-        const bool mv = up && hd[par] < d;
-        hd[P] = up ? (mv ? hd[par] : d) : hd[P];
-        hi[P] = up ? (mv ? hi[par] : idx) : hi[P];
-        heap_append_step<K, par>(hd, hi, mv, d, idx);
+        const bool mv = up && dist_less(hw[par], cw);
+        hw[P] = up ? (mv ? hw[par] : cw) : hw[P];
+        heap_append_step<K, par>(hw, mv, cw);
     }
 }
-template <int K, int S>
-__device__ __forceinline__ void heap_append_at(int (&hd)[K], int (&hi)[K], bool acc, int d, int idx) { heap_append_step<K, S>(hd, hi, acc, d, idx); }
 // remove the root of a FULL heap (:104-135): the last element re-enters at the root and sinks; nodes 0 .. K-2 take part.  Level by
 // level: the lane's position is one of the level's nodes, its children are selected from the next level.
 template <int K, int LVL>
-__device__ __forceinline__ void heap_pop_level(int (&hd)[K], int (&hi)[K], int md, int mi, int pos, bool go) {
+__device__ __forceinline__ void heap_pop_level(unsigned (&hw)[K], unsigned mw, int pos, bool go) {
     constexpr int NS = K - 1, first = (1 << LVL) - 1;
     if constexpr (first < NS) {
         constexpr int last = 2 * first < NS - 1 ? 2 * first : NS - 1;
-        int dl = 0, dr = 0, il = 0, ir = 0;
+        unsigned wl = 0, wr = 0;
         bool hasL = false, hasR = false;
         static_for<first, last + 1>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
             const bool at = pos == n;
-            if constexpr (2 * n + 1 < NS) { dl = at ? hd[2 * n + 1] : dl; il = at ? hi[2 * n + 1] : il; hasL = hasL || at; }
-            if constexpr (2 * n + 2 < NS) { dr = at ? hd[2 * n + 2] : dr; ir = at ? hi[2 * n + 2] : ir; hasR = hasR || at; }
+            if constexpr (2 * n + 1 < NS) { wl = at ? hw[2 * n + 1] : wl; hasL = hasL || at; }
+            if constexpr (2 * n + 2 < NS) { wr = at ? hw[2 * n + 2] : wr; hasR = hasR || at; }
         });
-        const bool pickL = !hasR || dr < dl;
-        const int dc = pickL ? dl : dr, ic = pickL ? il : ir;
-        const bool mv = go && hasL && md < dc;
+        const bool pickL = !hasR || dist_less(wr, wl);
+        const unsigned wc = pickL ? wl : wr;
+        const bool mv = go && hasL && dist_less(mw, wc);
+        const unsigned put = mv ? wc : mw;
         static_for<first, last + 1>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
-            const bool w = go && pos == n;
-            hd[n] = w ? (mv ? dc : md) : hd[n];
-            hi[n] = w ? (mv ? ic : mi) : hi[n];
+            hw[n] = (go && pos == n) ? put : hw[n];
         });
-        heap_pop_level<K, LVL + 1>(hd, hi, md, mi, mv ? (pickL ? 2 * pos + 1 : 2 * pos + 2) : pos, mv);
+        heap_pop_level<K, LVL + 1>(hw, mw, mv ? (pickL ? 2 * pos + 1 : 2 * pos + 2) : pos, mv);
     }
 }
 template <int K>
-__device__ __forceinline__ void heap_pop_full(int (&hd)[K], int (&hi)[K], bool acc) {
-    if constexpr (K >= 2) heap_pop_level<K, 0>(hd, hi, hd[K - 1], hi[K - 1], 0, acc);
+__device__ __forceinline__ void heap_pop_full(unsigned (&hw)[K], bool acc) {
+    if constexpr (K >= 2) heap_pop_level<K, 0>(hw, hw[K - 1], 0, acc);
 }
 // any mixture of sizes inside the wave (lists of different lengths, max_dist): dynamic positions through select chains
 template <int K>
-__device__ __forceinline__ int heap_get(const int (&a)[K], int i) {
-    int r = a[0];
+__device__ __forceinline__ unsigned heap_get(const unsigned (&a)[K], int i) {
+    unsigned r = a[0];
     static_for<1, K>([&](auto nc) { constexpr int n = decltype(nc)::value; r = i == n ? a[n] : r; });
     return r;
 }
 template <int K>
-__device__ __forceinline__ void heap_put(int (&a)[K], int i, bool on, int v) {
+__device__ __forceinline__ void heap_put(unsigned (&a)[K], int i, bool on, unsigned v) {
     static_for<0, K>([&](auto nc) { constexpr int n = decltype(nc)::value; a[n] = (on && i == n) ? v : a[n]; });
 }
 // append only (no accepting lane is full yet — the first K entries of the lists): sift up from the lane's own size
 template <int K>
-__device__ __forceinline__ void heap_append_generic(int (&hd)[K], int (&hi)[K], int& size, bool acc, int d, int idx) {
+__device__ __forceinline__ void heap_append_generic(unsigned (&hw)[K], int& size, bool acc, unsigned cw) {
     int pos = size;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const int parent = pos > 0 ? (pos - 1) >> 1 : 0;
-        const int dp = heap_get<K>(hd, parent), ip = heap_get<K>(hi, parent);
-        const bool mv = acc && pos > 0 && dp < d;
-        heap_put<K>(hd, pos, mv, dp);
-        heap_put<K>(hi, pos, mv, ip);
+        const unsigned wp = heap_get<K>(hw, parent);
+        const bool mv = acc && pos > 0 && dist_less(wp, cw);
+        heap_put<K>(hw, pos, mv, wp);
         pos = mv ? parent : pos;
     }
-    heap_put<K>(hd, pos, acc, d);
-    heap_put<K>(hi, pos, acc, idx);
+    heap_put<K>(hw, pos, acc, cw);
     size = acc ? size + 1 : size;
 }
 template <int K>
-__device__ __forceinline__ void heap_push_generic(int (&hd)[K], int (&hi)[K], int& size, bool acc, int d, int idx) {
+__device__ __forceinline__ void heap_push_generic(unsigned (&hw)[K], int& size, bool acc, unsigned cw) {
     const bool pop = acc && size >= K;
     const int ns = pop ? size - 1 : size;
-    const int md = heap_get<K>(hd, ns < K ? ns : K - 1), mi = heap_get<K>(hi, ns < K ? ns : K - 1);
+    const unsigned mw = heap_get<K>(hw, ns < K ? ns : K - 1);
     int pos = 0;
     bool go = pop && ns > 1;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const int l = 2 * pos + 1, r = l + 1;
         const bool hasL = go && l < ns, hasR = go && r < ns;
-        const int dl = heap_get<K>(hd, l < K ? l : K - 1), dr = heap_get<K>(hd, r < K ? r : K - 1);
-        const bool pickL = !hasR || dr < dl;
-        const int c = pickL ? l : r, dc = pickL ? dl : dr;
-        const bool mv = hasL && md < dc;
-        const int ic = heap_get<K>(hi, c < K ? c : K - 1);
-        heap_put<K>(hd, pos, mv, dc);
-        heap_put<K>(hi, pos, mv, ic);
+        const unsigned wl = heap_get<K>(hw, l < K ? l : K - 1), wr = heap_get<K>(hw, r < K ? r : K - 1);
+        const bool pickL = !hasR || dist_less(wr, wl);
+        const int c = pickL ? l : r;
+        const unsigned wc = pickL ? wl : wr;
+        const bool mv = hasL && dist_less(mw, wc);
+        heap_put<K>(hw, pos, mv, wc);
         pos = mv ? c : pos;
         go = mv;
     }
-    heap_put<K>(hd, pos, pop && ns >= 1, md);
-    heap_put<K>(hi, pos, pop && ns >= 1, mi);
+    heap_put<K>(hw, pos, pop && ns >= 1, mw);
     size = ns;
-    pos = size;
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const int parent = pos > 0 ? (pos - 1) >> 1 : 0;
-        const int dp = heap_get<K>(hd, parent), ip = heap_get<K>(hi, parent);
-        const bool mv = acc && pos > 0 && dp < d;
-        heap_put<K>(hd, pos, mv, dp);
-        heap_put<K>(hi, pos, mv, ip);
-        pos = mv ? parent : pos;
-    }
-    heap_put<K>(hd, pos, acc, d);
-    heap_put<K>(hi, pos, acc, idx);
-    size = acc ? size + 1 : size;
+    heap_append_generic<K>(hw, size, acc, cw);
 }
 
 template <int K>
@@ -542,12 +526,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     for (int o = 32; o > 0; o >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o));
     maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);   // (tell the compiler: the loop below is wave-uniform)
     const uint64_t* col = cand + (haveq ? qi : 0);   // entry e of this lane's query: col[e * nq] (coalesced across the wave)
-    int hd[K], hi[K];
+    unsigned hw[K];
 #pragma unroll
-    for (int i = 0; i < K; i++) { hd[i] = 0; hi[i] = -1; }
+    for (int i = 0; i < K; i++) hw[i] = 0;
     int size = 0;
-    // Stage the lists in LDS first: maxcnt coalesced loads (512 bytes each), all in flight together = ONE memory round trip per wave.
-    // Read inside the push loop (even four entries ahead) the loads cost more than the pushes: 34 of 57 us were memory stalls.
+    // Stage the lists in LDS first: maxcnt coalesced loads (512 bytes each), all in flight together = one memory round trip per wave.
     for (int e0 = 0; e0 < maxcnt; e0 += 16) {
         uint64_t v[16];
 #pragma unroll
@@ -560,23 +543,25 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     for (int e = 0; e < maxcnt; e++) {
         const uint64_t cur = nxt;
         nxt = s_list[min(e + 1, maxcnt - 1) * kWave + threadIdx.x];
-        const int idx = (int)(uint32_t)cur, d = (int)(cur >> 32);
+        const int d = (int)(cur >> 32);
+        const unsigned cw = ((unsigned)d << 23) | (unsigned)(uint32_t)cur;
         const bool valid = e < cnt && !(maxd >= 0 && maxd < d);     // resultset.h:66
-        const bool acc = valid && (size < K || d < hd[0]);          // :67-69
+        const bool acc = valid && (size < K || dist_less(cw, hw[0]));   // :67-69
         const unsigned long long am = __ballot(acc);
         if (!am) continue;
         if (__ballot(acc && size != K) == 0) {                      // steady state: every accepting lane's heap is full
-            heap_pop_full<K>(hd, hi, acc);
-            heap_append_at<K, K - 1>(hd, hi, acc, d, idx);
+            heap_pop_full<K>(hw, acc);
+            heap_append_step<K, K - 1>(hw, acc, cw);
         } else if (__ballot(acc && size >= K) == 0) {               // filling: nobody has to remove a root (select chains, no dynamic index:
-            heap_append_generic<K>(hd, hi, size, acc, d, idx);      // a dispatch on the common size ends up as an indexed store to scratch)
+            heap_append_generic<K>(hw, size, acc, cw);              // a dispatch on the common size ends up as an indexed store to scratch)
         } else {
-            heap_push_generic<K>(hd, hi, size, acc, d, idx);
+            heap_push_generic<K>(hw, size, acc, cw);
         }
     }
     // linear.h:82-85 (fill) + index.h:119-134 (exchange sort; idx[i] is tested once, before the inner loop)
+    int hd[K], hi[K];
 #pragma unroll
-    for (int i = 0; i < K; i++) if (i >= size) { hd[i] = 0; hi[i] = -1; }
+    for (int i = 0; i < K; i++) { const bool on = i < size; hd[i] = on ? (int)(hw[i] >> 23) : 0; hi[i] = on ? (int)(hw[i] & 0x7FFFFFu) : -1; }
     if (sorted) {
 #pragma unroll
         for (int i = 0; i < K - 1; ++i) {
@@ -1116,7 +1101,7 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
     // slower (the pushes of a wave's queries serialise), its L1/L2 traffic and its resident waves drop to 1/2 or 1/4, which is what a
     // latency-bound neighbour on another stream (the local BA) needs
     const int qpw = nn <= 15 ? idx->qpw : 1;
-    if (nn <= kRpK && nq >= idx->two_phase_min_nq) {
+    if (nn <= kRpK && nq >= idx->two_phase_min_nq && idx->shard_end <= (1 << 23)) {   // (the replay packs distance and row index into 32 bits)
         // accept-list capacity: the expected number of accepted pushes is k (1 + ln(N / k)) (a record process), its spread ~ sqrt of
         // that; lists that still overflow (distances descending with the row index) are redone by knn_redo_kernel
         const int nrows = std::max(idx->shard_end - idx->shard_begin, 1);
