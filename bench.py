@@ -59,9 +59,9 @@ def survey_8d_bytes(n_kpts, ba_E, ba_P=BA_P, ba_K=BA_K):
     return {"orb_per_frame": b_orb, "match_per_frame": b_match, "ba_per_lm_iteration": b_ba}
 
 
-ORB_KERNELS = ("blur7_kernel", "resize_cubic_kernel", "fast_score_kernel", "cell_nms_kernel", "select_kernel", "describe_kernel", "nonmax_kernel",
-               "pyramid_kernel", "detect_kernel")
-MATCH_KERNELS = ("knn_search_kernel", "knn_search_mq_kernel")
+ORB_KERNELS = ("blur7_kernel", "copy_kernel", "resize_cubic_kernel", "fast_score_kernel", "cell_nms_kernel", "select_kernel", "describe_kernel",
+               "nonmax_kernel")
+MATCH_KERNELS = ("knn_search_kernel", "knn_search_mq_kernel", "knn_accept_kernel", "knn_replay_lane_kernel", "knn_redo_kernel")
 
 
 def persistent_ba_exchange_bytes(ba_P, trials):

@@ -13,15 +13,19 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ
   timeout 300 rocprofv3 --pmc $grp --kernel-trace -f csv -d $OUT/g$i -o knn -- $CMD > $OUT/g$i.log 2>&1
 done
 python - <<PY
-import csv, glob, collections
+import csv, glob, collections, json, re
+out = {"what": "rocprofv3 --pmc passes over scripts/time_knn.py (exact kNN, 10000 train rows; 2000 queries: fused kernel, 8000 queries: accept scan + lane replay), per-launch averages per kernel; scripts/knn_pmc.sh", "kernels": {}}
 for g in sorted(glob.glob("$OUT/g*/")):
     for f in glob.glob(g + "**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"]
-            if "knn_search_kernel" not in k: continue
-            key = k.split("(")[0][-28:]
+            m = re.search(r"(knn_\w+_kernel(<[^>]*>)?)", r["Kernel_Name"])
+            if not m: continue
+            key = m.group(1)
             acc[key][r["Counter_Name"]] += float(r["Counter_Value"]); n[(key, r["Counter_Name"])] += 1
         for key in acc:
-            print(g.split("/")[-2], key, {c: round(v / n[(key, c)]) for c, v in acc[key].items()})
+            out["kernels"].setdefault(key, {}).update({c: round(v / n[(key, c)]) for c, v in acc[key].items()})
+            out["kernels"][key]["launches_sampled"] = max(n[(key, c)] for c in acc[key])
+json.dump(out, open("$OUT/knn_pmc.json", "w"), indent=1)
+print(json.dumps(out["kernels"], indent=0)[:3000])
 PY
