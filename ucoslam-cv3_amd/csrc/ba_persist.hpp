@@ -354,26 +354,27 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     bool robust = true;
     double chi_lin_pass = 0;
 
-    // ================================================================================ phase 1: linearise + Schur partial
-    // first == true: the pass's opening evaluation at the current estimate (computeActiveErrors + computeLambdaInit): chi2 of
-    // every observation is recorded, the reduced-system product is skipped.
-    auto phase1 = [&](double lambda, bool first) {
-        const int cur = st.cur;
-        tagA = next_tag();
-        double acc[10];
+    // ================================================================================ linearisation at a given estimate
+    // The lambda-independent part of a linearisation: this lane's observation (+ its share of the landmark's fixed-camera observations)
+    // evaluated at pose buffer `buf` and point Xp, into acc / hp / H.  Called at the top of a trial — or, speculatively, at the TRIAL
+    // estimate while the chi2 hand-off (C) is in flight: if the trial is accepted (the normal case) the next trial starts with its
+    // linearisation already in registers, the 1.6 us of edge evaluation having run inside a wait that was idle before.
+    double acc[10];
+    double hp[33];   // camera-side sums of this observation: Hpp upper triangle (21), bp (6), b_schur = Y_e (L^-1 b_l) (6)
+    double H[18];
+    bool any = false;
+    auto lin_eval = [&](int buf, const double (&Xp)[3], bool first) {
 #pragma unroll
         for (int i = 0; i < 10; i++) acc[i] = 0;
-        double hp[33];   // camera-side sums of this observation: Hpp upper triangle (21), bp (6), b_schur = Y_e (L^-1 b_l) (6)
 #pragma unroll
         for (int i = 0; i < 33; i++) hp[i] = 0;
-        double H[18];
 #pragma unroll
         for (int i = 0; i < 18; i++) H[i] = 0;
-        bool any = false;
+        any = false;
         const bool on = has && act;
         if (on) {
             EdgeLin L;
-            edge_eval_p<2>(ou, ov, ow, fxk, fyk, cxk, cyk, d.delta, d.dsqr, s_poseR + (cur * NF + s) * 12, X, robust, L);
+            edge_eval_p<2>(ou, ov, ow, fxk, fyk, cxk, cyk, d.delta, d.dsqr, s_poseR + (buf * NF + s) * 12, Xp, robust, L);
             any = true;
             if (first) chi_e = L.chi2;
             acc[9] = L.robchi;
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 any = true;
                 const double* C = s_fxcam + 16 * s_fxk[i];
                 EdgeLin L;
-                edge_eval_p<1>(s_fxobs[3 * i], s_fxobs[3 * i + 1], s_fxobs[3 * i + 2], C[12], C[13], C[14], C[15], d.delta, d.dsqr, C, X, robust, L);
+                edge_eval_p<1>(s_fxobs[3 * i], s_fxobs[3 * i + 1], s_fxobs[3 * i + 2], C[12], C[13], C[14], C[15], d.delta, d.dsqr, C, Xp, robust, L);
                 if (first) s_fxchi[i] = L.chi2;
                 acc[9] += L.robchi;
                 acc[0] += L.ww * (L.A[0] * L.A[0] + L.A[3] * L.A[3]); acc[1] += L.ww * (L.A[0] * L.A[1] + L.A[3] * L.A[4]);
@@ -408,6 +409,13 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 acc[6] += L.A[0] * L.r0 + L.A[3] * L.r1; acc[7] += L.A[1] * L.r0 + L.A[4] * L.r1; acc[8] += L.A[2] * L.r0 + L.A[5] * L.r1;
             }
         }
+    };
+    // ================================================================================ phase 1: linearise + Schur partial
+    // first == true: the pass's opening evaluation at the current estimate (computeActiveErrors + computeLambdaInit): chi2 of
+    // every observation is recorded, the reduced-system product is skipped.  have_lin: acc / hp / H already hold this estimate's values.
+    auto phase1 = [&](double lambda, bool first, bool have_lin) {
+        tagA = next_tag();
+        if (!have_lin) lin_eval(st.cur, X, first);
         if (!first) UH_BA_CLK(52);
 #pragma unroll
         for (int i = 0; i < 10; i++) {
@@ -629,7 +637,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         if (st.phase == 2) continue;
 
         // ---- opening evaluation: chi2 at the current estimate, lambda = tau * max |H_jj| (computeLambdaInit)
-        phase1(1.0, true);
+        phase1(1.0, true, false);
         if (!reduce_slices()) return;
         {   // every wave for itself: one diagonal entry of Hpp per lane, max butterfly
             double m = lane == 0 ? tload1(q.red, OFF_SC + 2, tagB) : 0.0;
@@ -645,6 +653,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         __syncthreads();
         if (s_flag[1]) return;
 
+        bool spec_lin = false;   // acc / hp / H hold the linearisation at the current estimate (left by the previous trial's speculation)
         while (st.phase != 2) {
             const double lambda = st.lambda;
             const int cur = st.cur, trial = cur ^ 1;
@@ -653,7 +662,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             unsigned char stop_byte = 0;
             if (g == 0 && tid == 0 && p.stop) stop_byte = *p.stop;
             UH_BA_CLK(40);
-            phase1(lambda, false);
+            phase1(lambda, false, spec_lin);
             UH_BA_CLK(41);
             if (!reduce_slices()) return;
             UH_BA_CLK(42);
@@ -781,6 +790,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 if (g == 0) tst(q.partC, 2, stop_byte ? 1.0 : 0.0, tagC);
             }
             UH_BA_CLK(47);
+            lin_eval(trial, Xt, false);   // speculation: the next trial's linearisation if this one is accepted (runs inside the hand-off's latency)
             // ---- decision (every wave of every workgroup, same inputs, same code)
             {
                 double c = 0, sc = 0;
@@ -799,6 +809,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 st.solve_ok = ok;
                 st.pending = 1;
                 st = apply_decision(st, sm, stopv);
+                spec_lin = st.cur != cur;   // accepted: the estimate IS the trial point the speculation was evaluated at
                 if (st.cur != cur) { X[0] = Xt[0]; X[1] = Xt[1]; X[2] = Xt[2]; }
             }
             __syncthreads();   // (a wave that gave up waiting has decided on garbage: everybody leaves together)
