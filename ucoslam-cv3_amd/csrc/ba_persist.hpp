@@ -577,20 +577,29 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     unsigned tagB = 0;
     auto reduce_slices = [&]() -> bool {
         tagB = next_tag();
-        const int HG = G < 16 ? G : 16;
+        // HG groups of sources per element, chosen so that one pass of the workgroup covers the slice (SL * HG <= 256 threads) and a
+        // thread's sources (~G / HG <= 8) go out as ONE batch of loads: every extra pass or batch is a memory round trip (~1.5 us)
+        const int HG = max(1, min(G, kPThreads / SL));
         double* const R = U + NT * 256;          // behind the staged product, which other waves may still be sending
         const size_t src = (size_t)g * G * SL;   // slice g of every workgroup's partial
         for (int idx = tid; idx < SL * HG; idx += kPThreads) {
             const int hg = idx / SL, e = idx - hg * SL;
             const bool is_max = g * SL + e == OFF_SC + 2;
             const bool used = g * SL + e < q.nelem;   // (the last slice is padded: nobody writes or needs those elements)
-            double r = used ? tload1(q.part, src + (size_t)hg * SL + e, tagA) : 0.0;
-            for (int h = hg + HG; used && h < G; h += 8 * HG) {   // eight elements in flight, added in ascending order
+            // every source of this element in ONE batch of loads where possible (G <= 128: at most eight per thread): a separate load
+            // for the first source put a second memory round trip (~1.5 us) in front of every slice reduction
+            double r = 0.0;
+            bool have = false;
+            for (int h = hg; used && h < G; h += 8 * HG) {   // eight elements in flight, added in ascending order
                 double v[8];
                 const int cnt = min(8, (G - h + HG - 1) / HG);
                 tload8(q.part, src + (size_t)h * SL + e, (size_t)HG * SL, cnt, tagA, v);
 #pragma unroll
-                for (int u = 0; u < 8; u++) r = is_max ? (u < cnt ? fmax(r, v[u]) : r) : r + v[u];
+                for (int u = 0; u < 8; u++) {
+                    if (u >= cnt) continue;
+                    r = !have ? v[u] : (is_max ? fmax(r, v[u]) : r + v[u]);
+                    have = true;
+                }
             }
             R[idx] = r;
         }
@@ -640,12 +649,20 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         phase1(1.0, true, false);
         if (!reduce_slices()) return;
         {   // every wave for itself: one diagonal entry of Hpp per lane, max butterfly
-            double m = lane == 0 ? tload1(q.red, OFF_SC + 2, tagB) : 0.0;
-            for (int i = lane; i < n; i += 64) {
-                const int sc = i / 6, a = i - 6 * sc;
-                m = fmax(m, fabs(tload1(q.red, OFF_CAM + sc * 27 + (a * 6 - a * (a - 1) / 2), tagB)));   // diagonal of the 21-entry upper triangle
+            // (n <= 48 < 64: one diagonal entry per lane; its three words go out as one batch, not three dependent round trips)
+            double m = 0.0;
+            {
+                const int sc = lane / 6, a = lane - 6 * sc;
+                const size_t i_diag = lane < n ? (size_t)(OFF_CAM + sc * 27 + (a * 6 - a * (a - 1) / 2)) : (size_t)OFF_SC;   // diagonal of the 21-entry upper triangle
+                long long t0 = 0;
+                for (;;) {
+                    const TWord wm = tld_raw(q.red, OFF_SC + 2), wd = tld_raw(q.red, i_diag), wc = tld_raw(q.red, OFF_SC);
+                    m = lane == 0 ? tval(wm) : 0.0;
+                    if (lane < n) m = fmax(m, fabs(tval(wd)));
+                    chi_lin_pass = tval(wc);
+                    if ((tok(wm, tagB) && tok(wd, tagB) && tok(wc, tagB)) || give_up(t0)) break;
+                }
             }
-            chi_lin_pass = tload1(q.red, OFF_SC, tagB);
 #pragma unroll
             for (int oo = 32; oo > 0; oo >>= 1) m = fmax(m, __shfl_xor(m, oo));
             st.lambda = 1e-5 * m; st.ni = 2;
@@ -794,18 +811,28 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             // ---- decision (every wave of every workgroup, same inputs, same code)
             {
                 double c = 0, sc = 0;
-                {
-                    double cv[8], sv[8];   // G <= 256: workgroups lane, lane + 64, ...
+                bool stopv = false;
+                {   // chi2 and scale partials of workgroups lane, lane + 64, ... (G <= 256) and the stop word: ONE batch of loads — three
+                    // separate ones were three dependent memory round trips in front of every decision
                     const int cnt = lane < G ? (G - lane + 63) / 64 : 0;
-                    tload8(q.partC, 4 * (size_t)lane, 4 * 64, cnt, tagC, cv);
-                    tload8(q.partC, 4 * (size_t)lane + 1, 4 * 64, cnt, tagC, sv);
+                    long long t0 = 0;
+                    for (;;) {
+                        TWord wc[4], ws[4];
+                        bool okw = true;
 #pragma unroll
-                    for (int u = 0; u < 4; u++) { c += cv[u]; sc += sv[u]; }
+                        for (int u = 0; u < 4; u++) if (u < cnt) { wc[u] = tld_raw(q.partC, 4 * (size_t)(lane + 64 * u)); ws[u] = tld_raw(q.partC, 4 * (size_t)(lane + 64 * u) + 1); }
+                        const TWord wst = tld_raw(q.partC, 2);
+                        c = 0; sc = 0;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) if (u < cnt) { okw = okw && tok(wc[u], tagC) && tok(ws[u], tagC); c += tval(wc[u]); sc += tval(ws[u]); }
+                        okw = okw && tok(wst, tagC);
+                        stopv = tval(wst) != 0.0;
+                        if (okw || give_up(t0)) break;
+                    }
                 }
                 UH_BA_CLK(48);
                 DecideSums sm;
                 sm.lin = chi_lin_pass; sm.chi = wave_sum_fixed(c); sm.scale = wave_sum_fixed(sc); sm.xs = s_sc[0];
-                const bool stopv = tload1(q.partC, 2, tagC) != 0.0;
                 st.solve_ok = ok;
                 st.pending = 1;
                 st = apply_decision(st, sm, stopv);
