@@ -531,12 +531,13 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     for (int i = 0; i < K; i++) hw[i] = 0;
     int size = 0;
     // Stage the lists in LDS first: maxcnt coalesced loads (512 bytes each), all in flight together = one memory round trip per wave.
-    for (int e0 = 0; e0 < maxcnt; e0 += 16) {
-        uint64_t v[16];
+    // (64 entries per batch: a batch is one memory round trip however many loads it holds, and the wave has the register file to itself)
+    for (int e0 = 0; e0 < maxcnt; e0 += 64) {
+        uint64_t v[64];
 #pragma unroll
-        for (int u = 0; u < 16; u++) v[u] = col[(size_t)min(e0 + u, cap - 1) * nq];
+        for (int u = 0; u < 64; u++) v[u] = col[(size_t)min(e0 + u, cap - 1) * nq];
 #pragma unroll
-        for (int u = 0; u < 16; u++) if (e0 + u < maxcnt) s_list[(e0 + u) * kWave + threadIdx.x] = v[u];
+        for (int u = 0; u < 64; u++) if (e0 + u < maxcnt) s_list[(e0 + u) * kWave + threadIdx.x] = v[u];
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the lane reads back only what it wrote itself
     uint64_t nxt = s_list[threadIdx.x];
