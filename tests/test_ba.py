@@ -207,6 +207,40 @@ def test_hip_ba_async_equals_sync(hip_ctx):
 
 
 @pytest.mark.gpu
+def test_hip_ba_persistent_exchange_tags_survive_the_sequence_wrap(hip_ctx, monkeypatch):
+    """The persistent kernel's exchange words carry 20 bits of the optimizer's launch count; when they wrap the exchange region is zeroed
+    again (ba.hip run_persistent).  An optimizer started three launches before the wrap (UH_BA_SEQ0) must give the same bytes on every
+    one of eight optimisations across it, on the problem it was set up with and on a re-laid-out one."""
+    import os
+
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ba_golden.npz"))
+    pr_a = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    pr_b = synth.ba_problem(10, 1500, 3)
+
+    def sig(opt):
+        r = opt.getResults()
+        return r["state"].tobytes() + r["iters"].tobytes() + r["bad"].tobytes() + r["chi2"].tobytes()
+
+    ref = {}
+    for name, pr in (("a", pr_a), ("b", pr_b)):
+        opt = GlobalOptimizer.create(hip_ctx)
+        opt.setParams(pr, ParamSet(nIters=5))
+        opt.optimize()
+        ref[name] = sig(opt)
+    monkeypatch.setenv("UH_BA_SEQ0", str(0xFFFFF - 3))
+    opt = GlobalOptimizer.create(hip_ctx)
+    monkeypatch.delenv("UH_BA_SEQ0")
+    opt.setParams(pr_a, ParamSet(nIters=5))
+    for i in range(8):
+        if i == 5:
+            opt.setParams(pr_b, ParamSet(nIters=5))
+        opt.optimize()
+        assert sig(opt) == ref["a" if i < 5 else "b"], f"optimisation {i} after the tag wrap differs"
+
+
+@pytest.mark.gpu
 def test_hip_ba_persistent_is_exact_under_uneven_background_load(hip_ctx):
     """The persistent kernel's workgroup hand-offs and its LDS hygiene under UNEVEN load (scripts/ba_stress.py, shortened): problems with
     fewer free cameras than lane slots (6 of 8) and with all 8 are optimised repeatedly on a private stream while another stream

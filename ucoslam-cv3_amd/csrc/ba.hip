@@ -1888,6 +1888,7 @@ int uh_ba_create(uh_ctx* ctx, uh_ba** out) {
     // one pinned, device-visible block: [0] force-stop byte, [64..) the final BAState of a persistent launch, [192] its completion word
     if (hipHostMalloc(reinterpret_cast<void**>(&b->h_stop), 256, hipHostMallocMapped) != hipSuccess) b->h_stop = nullptr;
     if (b->h_stop) std::memset(b->h_stop, 0, 256);
+    if (const char* e = getenv("UH_BA_SEQ0")) b->p_seq = (unsigned)strtoul(e, nullptr, 0);   // tests: start next to the wrap of the exchange tags
     *out = b;
     return UH_OK;
 }
