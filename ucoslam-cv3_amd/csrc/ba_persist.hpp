@@ -20,6 +20,8 @@
 //       A: every workgroup's partial (tiles, Hpp/bp sums, b_schur, chi2, max diag)  -> slice-wise reduction by all workgroups
 //       B: the reduced 1804 doubles -> EVERY workgroup assembles and factorises the 48x48 system itself (no broadcast hop)
 //       C: trial chi2 / scale partials -> every workgroup takes the accept / reject decision itself (apply_decision)
+//     (each of them ONE batch of L2-bypassing loads per thread = one memory round trip; while C is in flight a workgroup already
+//     evaluates the next trial's linearisation at the trial estimate, used if the trial is accepted)
 //     so a trial costs three data hand-offs instead of two kernel boundaries + launch ramps, and all summation orders are
 //     fixed: results are run-to-run deterministic and identical in every workgroup.
 #pragma once

@@ -15,6 +15,9 @@
 // in lane (= train index) order, on a heap that is DISTRIBUTED OVER LANES (lane j = heap slot j)
 // and manipulated with v_readlane / masked moves -- no LDS, no scratch, wave-uniform control flow.
 //
+// Large query sets (>= 6000 queries, k <= 16) take the two-phase form further down: an accept-list scan with two queries per wave and
+// a replay with one lane per query on register heaps ("two-phase exact search").
+//
 // Sharding (multi-GPU, row (e) of the scope table): a shard scan starts from an empty heap, so
 // its accept test is looser than the global one; it emits everything it accepted (a superset of
 // the global accept set, in index order).  Replaying the concatenated shard lists through the
