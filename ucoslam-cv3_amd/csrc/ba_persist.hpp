@@ -619,6 +619,31 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         return true;
     };
 
+    // Where the elements this thread fetches from the reduced vector go (the same every trial): an offset into `lds` (doubles), with bit 24
+    // set for the entries that are copied (camera sums -> s_out, b_schur -> s_bs) and clear for the Schur product's entries, which
+    // enter the lower triangle of S negated; -1: nothing to store.
+    int asm_dst[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int idx = tid + u * kPThreads;
+        int t = -1;
+        if (idx < q.nelem) {
+            if (idx < OFF_CAM) {
+                int row, col;
+                if (q.use_mfma) {   // (tile, lane, register) of the MFMA C layout: row = (lane >> 4) + 4 * reg, col = lane & 15
+                    const int ti = idx >> 8, lq = (idx >> 2) & 63, vv = idx & 3;
+                    const int tm = ti < 3 ? 0 : (ti < 5 ? 1 : 2), tn = ti < 3 ? ti : (ti < 5 ? ti - 2 : 2);
+                    row = 16 * tm + (lq >> 4) + 4 * vv; col = 16 * tn + (lq & 15);
+                } else {            // (4x4 block of the upper block triangle, r, c)
+                    const int bq = idx >> 4, rr = (idx >> 2) & 3, cq = idx & 3;
+                    row = 4 * s_blk[bq][0] + rr; col = 4 * s_blk[bq][1] + cq;
+                }
+                if (row <= col && col < n) t = o.U + col * ld + row;
+            } else if (idx < OFF_BS) t = (o.out + (idx - OFF_CAM)) | (1 << 24);
+            else if (idx < OFF_SC) t = (o.bs + (idx - OFF_BS)) | (1 << 24);
+        }
+        asm_dst[u] = t;
+    }
     for (int pass = 0; pass < 2; pass++) {
         // ---- begin_pass (legacy ba_begin_pass_kernel / ba_gate_kernel / ba_relabel_kernel)
         if (pass == 1) {
@@ -686,33 +711,16 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             if (!reduce_slices()) return;
             UH_BA_CLK(42);
             // ---- assemble S = Hpp + lambda I - Yt^T Yt (lower triangle, bordered with b = bp - b_schur), factorise, substitute
-            for (int base = 0; base < q.nelem; base += 8 * kPThreads) {
-            double rv[8];
-            {
-                const int left = q.nelem - (base + tid);
+            {   // (q.nelem <= 8 * kPThreads: one batch per thread; where each element goes was worked out once, before the passes)
+                double rv[8];
+                const int left = q.nelem - tid;
                 const int cnt = left <= 0 ? 0 : min(8, (left + kPThreads - 1) / kPThreads);
-                tload8(q.red, (size_t)base + tid, kPThreads, cnt, tagB, rv);
-            }
+                tload8(q.red, (size_t)tid, kPThreads, cnt, tagB, rv);
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int idx = base + tid + u * kPThreads;
-                const double v = rv[u];
-                if (idx >= q.nelem) continue;
-                if (idx < OFF_CAM) {
-                    int row, col;
-                    if (q.use_mfma) {   // (tile, lane, register) of the MFMA C layout: row = (lane >> 4) + 4 * reg, col = lane & 15
-                        const int ti = idx >> 8, lq = (idx >> 2) & 63, vv = idx & 3;
-                        const int tm = ti < 3 ? 0 : (ti < 5 ? 1 : 2), tn = ti < 3 ? ti : (ti < 5 ? ti - 2 : 2);
-                        row = 16 * tm + (lq >> 4) + 4 * vv; col = 16 * tn + (lq & 15);
-                    } else {            // (4x4 block of the upper block triangle, r, c)
-                        const int bq = idx >> 4, rr = (idx >> 2) & 3, cq = idx & 3;
-                        const int bc = bq < 78 ? bq : 0;
-                        row = 4 * s_blk[bc][0] + rr; col = bq < 78 ? 4 * s_blk[bc][1] + cq : n;   // (unused tail of the region: col = n)
-                    }
-                    if (row <= col && col < n) Mm[col * ld + row] = -v;
-                } else if (idx < OFF_BS) s_out[idx - OFF_CAM] = v;
-                else if (idx < OFF_SC) s_bs[idx - OFF_BS] = v;
-            }
+                for (int u = 0; u < 8; u++) {
+                    const int t = asm_dst[u];
+                    if (t >= 0) lds[t & 0xFFFFFF] = (t >> 24) ? rv[u] : -rv[u];   // bit 24: camera sums / b_schur keep their sign, product entries enter S negated
+                }
             }
             __syncthreads();
             if (s_flag[1]) return;
