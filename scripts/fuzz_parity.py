@@ -81,6 +81,28 @@ def knn_case(seed):
 
 run("knn_exact", knn_case)
 
+
+def knn2_case(seed):   # the accept-list scan + lane replay (default only from 6000 queries on), forced for every size
+    r = np.random.default_rng(seed)
+    nt, nq, nn = int(r.integers(1, 6000)), int(r.integers(1, 400)), int(r.integers(1, 17))
+    if r.random() < 0.3:
+        train, q = synth.tie_stress_set(nq, nt, seed=seed % 1000, ndistinct=int(r.integers(1, 40)))
+    else:
+        train, q = synth.match_set(nq, nt, seed=seed % 1000)
+    srt = bool(r.integers(0, 2))
+    md = int(r.choice([-1, -1, 40, 90, 120]))
+    os.environ["UH_KNN_FORM"] = "twophase"
+    os.environ["UH_KNN_ACCEPT_QPW"] = str(int(r.choice([1, 2])))
+    try:
+        idx = Index(ctx).build(train)
+    finally:
+        del os.environ["UH_KNN_FORM"], os.environ["UH_KNN_ACCEPT_QPW"]
+    gi, gd = idx.search(q, nn, sorted=srt, max_dist=md)
+    ri, rd = oracle_lib.knn_search(L, train, q, nn, int(srt), max_dist=md)
+    return (gi == ri).all() and (gd == rd).all(), (nt, nq, nn, srt, md)
+
+run("knn_twophase", knn2_case)
+
 def km_case(seed):
     r = np.random.default_rng(seed)
     nt, nq = int(r.integers(1, 5000)), int(r.integers(1, 300))
