@@ -995,11 +995,16 @@ int make_plan(uh_orb* o, int w, int h, int batch) {
     o->frame_stride = (img_off + 255) & ~(size_t)255;
     o->cand_stride = cand_off;
     o->sel_stride = sel_off;
-    o->lds_entries = 24576;   // 96 KiB of dynamic LDS: selection workspace + partition scratch (one workgroup per level)
+    {   // dynamic LDS of select_kernel: a workgroup's filtered cell lists + partition scratch, and the level's concatenation in the level-wide
+        // pass (a few times nDesired): 32 KiB for the usual budgets (four workgroups fit a CU), up to 96 KiB for large ones
+        int most = 1;
+        for (int l = 0; l < P.nlevels; l++) most = std::max(most, P.lv[l].nDesired);
+        o->lds_entries = std::min(24576, std::max(8192, ((6 * most + 2047) / 2048) * 2048));
+    }
     int rc;
     UH_HIP_CHECK(hipSetDevice(o->ctx->device));   // first: the attribute below belongs to the context's device, not to whatever the calling thread had current
     if (!o->sel_attr) {   // once per object
-        UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, o->lds_entries * 4));
+        UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 4));   // (the largest plan's need)
         o->sel_attr = true;
     }
     hipStream_t st = o->ctx->stream;
