@@ -28,4 +28,4 @@ for B in (1, 8, 64):
     ctx.prof_enable(True); ctx.prof_reset()
     for _ in range(10): ext.extract_batch(frames, fp, out)
     rep = ctx.prof_report(); ctx.prof_enable(False)
-    print(f"B={B}", {k.split('::')[-1]: round(1e3*v[1]/v[0], 1) for k, v in rep.items()})
+    print(f"B={B}", {k.split('::')[-1]: round(1e3*v[1]/v[0], 1) for k, v in rep.items() if v[0]})

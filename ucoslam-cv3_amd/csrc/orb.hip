@@ -130,17 +130,20 @@ __global__ void copy_kernel(const uint8_t* __restrict__ src, int w, int h, size_
 // LDS with coalesced row loads, the horizontal pass writes int32 rows to LDS once per SOURCE row (shared by the ~1.2
 // output rows that use it), the vertical pass reads four of them per output pixel: ~14 LDS reads per pixel instead of 16
 // uncoalesced byte loads from L1/L2.  Arithmetic is exactly the fixed-point reference path (see the oracle).
-__global__ __launch_bounds__(256) void resize_cubic_kernel(const uint8_t* __restrict__ src, int sw, int sh, int spitch,
-                                                           uint8_t* __restrict__ dst, int dw, int dh, int dpitch,
-                                                           size_t frame_stride, const int* __restrict__ xofs,
-                                                           const short* __restrict__ xcoef, const int* __restrict__ yofs,
-                                                           const short* __restrict__ ycoef) {
+template <int HW>
+struct ResizeLds {   // staging of one 64 x 16 output tile: source footprint + horizontal pass (HW columns)
+    uint8_t src[40][144];
+    int h[40][HW];
+};
+struct ResizePairLds : ResizeLds<96> {   // the pair kernel adds the rectangle of the intermediate level
+    uint8_t mid[40][96];
+};
+template <typename LdsT>
+__device__ __forceinline__ void resize_cubic_tile(LdsT& L, const uint8_t* __restrict__ S, int sw, int sh, int spitch,
+                                                  uint8_t* __restrict__ D, int dw, int dh, int dpitch, const int* __restrict__ xofs,
+                                                  const short* __restrict__ xcoef, const int* __restrict__ yofs,
+                                                  const short* __restrict__ ycoef, int tx0, int ty0) {
     constexpr int TW = 64, TH = 16, SWMAX = 144, SHMAX = 40;
-    __shared__ uint8_t s_src[SHMAX][SWMAX];
-    __shared__ int s_h[SHMAX][TW];
-    const uint8_t* S = src + (size_t)blockIdx.z * frame_stride;
-    uint8_t* D = dst + (size_t)blockIdx.z * frame_stride;
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
     const int xl = min(tx0 + TW, dw) - 1, yl = min(ty0 + TH, dh) - 1;
     const int rx0 = min(max(xofs[tx0] - 1, 0), sw - 1), rx1 = min(max(xofs[xl] + 2, 0), sw - 1);
     const int ry0 = min(max(yofs[ty0] - 1, 0), sh - 1), ry1 = min(max(yofs[yl] + 2, 0), sh - 1);
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void resize_cubic_kernel(const uint8_t* __rest
         return;
     }
     for (int r = ly; r < srch; r += 4)
-        for (int c = lx; c < srcw; c += 64) s_src[r][c] = S[(size_t)(ry0 + r) * spitch + rx0 + c];
+        for (int c = lx; c < srcw; c += 64) L.src[r][c] = S[(size_t)(ry0 + r) * spitch + rx0 + c];
     __syncthreads();
     if (gx < dw) {   // horizontal pass: this thread's column, every staged source row
         const int xo = xofs[gx];
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256) void resize_cubic_kernel(const uint8_t* __rest
 #pragma unroll
         for (int k = 0; k < 4; k++) { c[k] = xcoef[gx * 4 + k]; sx[k] = min(max(xo - 1 + k, 0), sw - 1) - rx0; }
         for (int r = ly; r < srch; r += 4)
-            s_h[r][lx] = s_src[r][sx[0]] * c[0] + s_src[r][sx[1]] * c[1] + s_src[r][sx[2]] * c[2] + s_src[r][sx[3]] * c[3];
+            L.h[r][lx] = L.src[r][sx[0]] * c[0] + L.src[r][sx[1]] * c[1] + L.src[r][sx[2]] * c[2] + L.src[r][sx[3]] * c[3];
     }
     __syncthreads();
     if (gx < dw) {
@@ -184,9 +187,100 @@ __global__ __launch_bounds__(256) void resize_cubic_kernel(const uint8_t* __rest
             const int yo = yofs[gy];
             int acc = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) acc += s_h[min(max(yo - 1 + k, 0), sh - 1) - ry0][lx] * ycoef[gy * 4 + k];
+            for (int k = 0; k < 4; k++) acc += L.h[min(max(yo - 1 + k, 0), sh - 1) - ry0][lx] * ycoef[gy * 4 + k];
             const int v = (acc + (1 << 21)) >> 22;
             D[(size_t)gy * dpitch + gx] = (uint8_t)min(max(v, 0), 255);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void resize_cubic_kernel(const uint8_t* __restrict__ src, int sw, int sh, int spitch,
+                                                           uint8_t* __restrict__ dst, int dw, int dh, int dpitch,
+                                                           size_t frame_stride, const int* __restrict__ xofs,
+                                                           const short* __restrict__ xcoef, const int* __restrict__ yofs,
+                                                           const short* __restrict__ ycoef) {
+    __shared__ ResizeLds<64> L;
+    resize_cubic_tile(L, src + (size_t)blockIdx.z * frame_stride, sw, sh, spitch, dst + (size_t)blockIdx.z * frame_stride, dw, dh, dpitch,
+                      xofs, xcoef, yofs, ycoef, blockIdx.x * 64, blockIdx.y * 16);
+}
+
+// TWO levels per launch: levels a and a+1 from level a-1.  A dependent launch costs ~9.5 us on MI355X whatever it computes (a HIP graph does
+// not change that), and the seven resizes of the pyramid were 66 of the extractor's 186 us per 4-frame launch set.  Workgroups
+// [0, tilesA) compute the tiles of level a as before; workgroups [tilesA, tilesA + tilesB) compute a tile of level a+1 WITHOUT waiting for
+// level a: they rebuild the rectangle of level a their tile reads (<= 96 x 40 pixels) in LDS from level a-1 — the same taps, the same
+// fixed-point arithmetic, hence the same bytes the other workgroups write — and resize that.  Level a is computed 2.2 times, level a+1 once;
+// the chain is four launches instead of seven.  Measured (1241x376, 8 levels): one frame 123 -> 112 us per extraction (8 launches), but
+// 187 -> 193 us for four frames and 266 -> 290 us for eight — the recomputation outweighs three saved launches as soon as the resizes have
+// real work — so the host takes this path for batches of at most two frames (the single-camera tracking case).  (Two earlier fusions
+// are in DESIGN.md: four levels per launch recomputed 3.5 times the pyramid; one cooperative launch with barriers between levels lost to
+// the L2-bypassing loads it needs.)
+struct LevelTaps { const int* xofs; const short* xcoef; const int* yofs; const short* ycoef; };
+__global__ __launch_bounds__(256) void resize_pair_kernel(const uint8_t* __restrict__ pyr, size_t frame_stride, LevelDesc S0, LevelDesc LA, LevelDesc LB,
+                                                          LevelTaps ta, LevelTaps tb, int tilesA) {
+    __shared__ ResizePairLds L;
+    const uint8_t* F = pyr + (size_t)blockIdx.z * frame_stride;
+    uint8_t* Fw = const_cast<uint8_t*>(F);
+    if ((int)blockIdx.x < tilesA) {
+        const int tx = (LA.w + 63) / 64, t = blockIdx.x, ty = t / tx;
+        resize_cubic_tile(L, F + S0.img_off, S0.w, S0.h, S0.pitch, Fw + LA.img_off, LA.w, LA.h, LA.pitch, ta.xofs, ta.xcoef, ta.yofs, ta.ycoef,
+                          (t - ty * tx) * 64, ty * 16);
+        return;
+    }
+    constexpr int TW = 64, TH = 16;
+    const int txb = (LB.w + 63) / 64, t = blockIdx.x - tilesA, tyb = t / txb;
+    const int tx0 = (t - tyb * txb) * TW, ty0 = tyb * TH;
+    const int xl = min(tx0 + TW, LB.w) - 1, yl = min(ty0 + TH, LB.h) - 1;
+    // the rectangle of level a this tile reads, and the rectangle of level a-1 THAT reads (the host checked that both fit the staging area)
+    const int ax0 = min(max(tb.xofs[tx0] - 1, 0), LA.w - 1), ax1 = min(max(tb.xofs[xl] + 2, 0), LA.w - 1);
+    const int ay0 = min(max(tb.yofs[ty0] - 1, 0), LA.h - 1), ay1 = min(max(tb.yofs[yl] + 2, 0), LA.h - 1);
+    const int aw = ax1 - ax0 + 1, ah = ay1 - ay0 + 1;
+    const int sx0 = min(max(ta.xofs[ax0] - 1, 0), S0.w - 1), sx1 = min(max(ta.xofs[ax1] + 2, 0), S0.w - 1);
+    const int sy0 = min(max(ta.yofs[ay0] - 1, 0), S0.h - 1), sy1 = min(max(ta.yofs[ay1] + 2, 0), S0.h - 1);
+    const int sw0 = sx1 - sx0 + 1, sh0 = sy1 - sy0 + 1;
+    const uint8_t* S = F + S0.img_off;
+    for (int i = threadIdx.x; i < sw0 * sh0; i += 256) { const int r = i / sw0, c = i - r * sw0; L.src[r][c] = S[(size_t)(sy0 + r) * S0.pitch + sx0 + c]; }
+    __syncthreads();
+    // level a, horizontal: column ax0 + c of every staged source row
+    for (int i = threadIdx.x; i < aw * sh0; i += 256) {
+        const int r = i / aw, c = i - r * aw, gx = ax0 + c;
+        const int xo = ta.xofs[gx];
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc += L.src[r][min(max(xo - 1 + k, 0), S0.w - 1) - sx0] * ta.xcoef[gx * 4 + k];
+        L.h[r][c] = acc;
+    }
+    __syncthreads();
+    // level a, vertical -> the rectangle's bytes
+    for (int i = threadIdx.x; i < aw * ah; i += 256) {
+        const int r = i / aw, c = i - r * aw, gy = ay0 + r;
+        const int yo = ta.yofs[gy];
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc += L.h[min(max(yo - 1 + k, 0), S0.h - 1) - sy0][c] * ta.ycoef[gy * 4 + k];
+        L.mid[r][c] = (uint8_t)min(max((acc + (1 << 21)) >> 22, 0), 255);
+    }
+    __syncthreads();
+    // level a+1 from the rectangle: horizontal (64 columns x ah rows), then vertical
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6, gx = tx0 + lx;
+    if (gx < LB.w) {
+        const int xo = tb.xofs[gx];
+        int c[4], sx[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { c[k] = tb.xcoef[gx * 4 + k]; sx[k] = min(max(xo - 1 + k, 0), LA.w - 1) - ax0; }
+        for (int r = ly; r < ah; r += 4)
+            L.h[r][lx] = L.mid[r][sx[0]] * c[0] + L.mid[r][sx[1]] * c[1] + L.mid[r][sx[2]] * c[2] + L.mid[r][sx[3]] * c[3];
+    }
+    __syncthreads();
+    if (gx < LB.w) {
+        uint8_t* D = Fw + LB.img_off;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int gy = ty0 + ly + 4 * j;
+            if (gy >= LB.h) continue;
+            const int yo = tb.yofs[gy];
+            int acc = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc += L.h[min(max(yo - 1 + k, 0), LA.h - 1) - ay0][lx] * tb.ycoef[gy * 4 + k];
+            D[(size_t)gy * LB.pitch + gx] = (uint8_t)min(max((acc + (1 << 21)) >> 22, 0), 255);
         }
     }
 }
@@ -845,6 +939,8 @@ struct uh_orb {
     uh::DevBuf d_plan, d_cells, d_xofs, d_xcoef, d_yofs, d_ycoef;
     uh::DevBuf d_pyr, d_score, d_cand, d_work, d_sel, d_cell_counts, d_level_counts;
     uh::DevBuf d_tickets;   // select_kernel: workgroups of a (frame, level) that have finished their cells
+    bool pair_ok[kMaxLevels] = {};  // levels l and l+1 can be built by one resize_pair_kernel launch (the footprints fit its staging area)
+    bool pair_fusion = true;       // UH_ORB_PYRAMID=chain: one launch per level
     bool fuse_fast = false;        // every cell fits cell_nms_kernel<true>'s staging buffers: no strength map, no fast_score launch
     bool score_valid = false;      // d_score holds the last extraction's strength maps (uh_orb_debug_level computes them on demand)
     // staging for the host-pointer API
@@ -969,6 +1065,31 @@ int make_plan(uh_orb* o, int w, int h, int batch) {
     }
     P.total_tiles = tile_begin;
     P.total_cells = cell_begin;
+    {   // resize_pair_kernel: do the rectangles a tile of level l+1 needs (of level l, and of level l-1 behind it) fit the staging area?
+        const char* e = getenv("UH_ORB_PYRAMID");
+        o->pair_fusion = !(e && std::string(e) == "chain");
+        auto clampi = [](int v, int lo, int hi) { return std::min(std::max(v, lo), hi); };
+        for (int l = 0; l < kMaxLevels; l++) o->pair_ok[l] = false;
+        for (int l = 1; l + 1 < nl; l++) {
+            const LevelDesc& S0 = P.lv[l - 1]; const LevelDesc& A = P.lv[l]; const LevelDesc& B = P.lv[l + 1];
+            const int* ax = xofs.data() + A.xtap_off; const int* ay = yofs.data() + A.ytap_off;
+            const int* bx = xofs.data() + B.xtap_off; const int* by = yofs.data() + B.ytap_off;
+            bool fits = true;
+            for (int tx0 = 0; tx0 < B.w && fits; tx0 += 64) {
+                const int xl = std::min(tx0 + 64, B.w) - 1;
+                const int a0 = clampi(bx[tx0] - 1, 0, A.w - 1), a1 = clampi(bx[xl] + 2, 0, A.w - 1);
+                const int s0 = clampi(ax[a0] - 1, 0, S0.w - 1), s1 = clampi(ax[a1] + 2, 0, S0.w - 1);
+                fits = a1 - a0 + 1 <= 96 && s1 - s0 + 1 <= 144;
+            }
+            for (int ty0 = 0; ty0 < B.h && fits; ty0 += 16) {
+                const int yl = std::min(ty0 + 16, B.h) - 1;
+                const int a0 = clampi(by[ty0] - 1, 0, A.h - 1), a1 = clampi(by[yl] + 2, 0, A.h - 1);
+                const int s0 = clampi(ay[a0] - 1, 0, S0.h - 1), s1 = clampi(ay[a1] + 2, 0, S0.h - 1);
+                fits = a1 - a0 + 1 <= 40 && s1 - s0 + 1 <= 40;
+            }
+            o->pair_ok[l] = fits;
+        }
+    }
     {   // the FAST strength is computed inside cell_nms_kernel when every cell fits its staging buffers (UH_ORB_FAST=map: the two-launch form)
         bool fits = true;
         for (const CellDesc& C : o->cells) {
@@ -1064,6 +1185,17 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
     for (int l = 1; l < P.lvl_end; l++) {
         const LevelDesc& S = P.lv[l - 1];
         const LevelDesc& D = P.lv[l];
+        if (o->pair_fusion && batch <= 2 && l + 1 < P.lvl_end && o->pair_ok[l]) {   // two levels per launch (one or two frames: pure launch latency)
+            const LevelDesc& E = P.lv[l + 1];
+            const LevelTaps ta{o->d_xofs.as<int>() + D.xtap_off, o->d_xcoef.as<short>() + (size_t)D.xtap_off * 4,
+                               o->d_yofs.as<int>() + D.ytap_off, o->d_ycoef.as<short>() + (size_t)D.ytap_off * 4};
+            const LevelTaps tb{o->d_xofs.as<int>() + E.xtap_off, o->d_xcoef.as<short>() + (size_t)E.xtap_off * 4,
+                               o->d_yofs.as<int>() + E.ytap_off, o->d_ycoef.as<short>() + (size_t)E.ytap_off * 4};
+            const int tilesA = uh_div_up(D.w, 64) * uh_div_up(D.h, 16), tilesB = uh_div_up(E.w, 64) * uh_div_up(E.h, 16);
+            UH_LAUNCH(o->ctx, resize_pair_kernel, dim3(tilesA + tilesB, 1, batch), dim3(256), 0, (const uint8_t*)pyr, o->frame_stride, S, D, E, ta, tb, tilesA);
+            ++l;
+            continue;
+        }
         UH_LAUNCH(o->ctx,resize_cubic_kernel, dim3(uh_div_up(D.w, 64), uh_div_up(D.h, 16), batch), dim3(256), 0,
                            pyr + S.img_off, S.w, S.h, S.pitch, pyr + D.img_off, D.w, D.h, D.pitch, o->frame_stride,
                            o->d_xofs.as<int>() + D.xtap_off, o->d_xcoef.as<short>() + (size_t)D.xtap_off * 4,
