@@ -988,6 +988,7 @@ struct uh_knn {
     int two_phase_min_nq = 6000;  // exact search, nn <= 16: accept-list scan + lane-per-query replay from this many queries on, the fused one-kernel
                                   // form below it (the replay is a fixed ~60 us chain per wave: 8000 x 10 000 x nn 10 = 147 vs 163 us, 2000 queries = 106
                                   // vs 77 us).  UH_KNN_FORM=twophase / fused forces one form.
+    unsigned replay_attr = 0;     // bit k: knn_replay_lane_kernel<k>'s dynamic-LDS attribute has been set on this index's device
     int accept_qpw = 2;           // queries per wave of the accept scan (UH_KNN_ACCEPT_QPW=1 for the A/B)
     uh::DevBuf list_buf;          // accept lists, counts and redo flags of the two-phase search
     uh::DevBuf q_buf, idx_buf, dist_buf;  // staging for the host-pointer API
@@ -1124,7 +1125,8 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
 #undef UH_KNN_ACCEPT
         const dim3 gr(uh_div_up(nq, kWave));
         const size_t lds_lists = (size_t)cap * kWave * 8;   // cap <= 256: at most 128 KB
-#define UH_KNN_REPLAY(K) case K: UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_replay_lane_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lists)); \
+        // (the attribute is raised once per k to the largest list area the replay may ask for: 256 entries x 64 lanes x 8 bytes)
+#define UH_KNN_REPLAY(K) case K: if (!(idx->replay_attr & (1u << K))) { UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_replay_lane_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * kWave * 8)); idx->replay_attr |= 1u << K; } \
         UH_LAUNCH(idx->ctx, knn_replay_lane_kernel<K>, gr, dim3(kWave), lds_lists, d_cand, d_counts, nq, sorted ? 1 : 0, max_dist, cap, d_indices, d_distances, d_redo, d_nredo); break
         switch (nn) {
             UH_KNN_REPLAY(1); UH_KNN_REPLAY(2); UH_KNN_REPLAY(3); UH_KNN_REPLAY(4); UH_KNN_REPLAY(5); UH_KNN_REPLAY(6); UH_KNN_REPLAY(7); UH_KNN_REPLAY(8);
