@@ -354,7 +354,7 @@ template <bool FUSED>
 __global__ __launch_bounds__(256) void cell_nms_kernel(const Plan plan, const CellDesc* __restrict__ cells,
                                                        const uint8_t* __restrict__ score /* FUSED: the pyramid */, size_t frame_stride,
                                                        uint32_t* __restrict__ cand, size_t cand_frame_stride,
-                                                       int* __restrict__ cell_counts /* [frame][cell][2] */) {
+                                                       int* __restrict__ cell_counts /* [frame][cell][2] */, int tile_bytes) {
     __shared__ int s_wave[4];
     __shared__ int s_base, s_n20;
     const int cell = blockIdx.x, frame = blockIdx.y;
@@ -370,10 +370,16 @@ __global__ __launch_bounds__(256) void cell_nms_kernel(const Plan plan, const Ce
     if (threadIdx.x == 0) { s_base = 0; s_n20 = 0; }
     // stage the cell's strength values in LDS with one fully overlapped pass (all loads in flight together); cells larger
     // than the staging buffer (huge cells of tiny feature budgets) read HBM/L2 directly
-    __shared__ uint8_t s_tile[kNmsTileBytes];
-    // the image patch (FUSED) and the candidate lists never live at the same time: one LDS region
+    // Staging: the cell's strength values (s_tile) and one region shared by the image patch (FUSED) and the candidate lists, which never
+    // live at the same time.  FUSED: dynamic LDS sized by the plan's largest cell (a 30 x 30 cell needs 5 KB, not the 36 KB of the
+    // worst case: eight workgroups per CU instead of three — the kernel was occupancy bound from four frames on); the map form keeps
+    // static worst-case arrays.
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_nms_dyn[];
     constexpr int kListInts = kNmsTileBytes / 2 + 4 * 64;
-    __shared__ __attribute__((aligned(16))) uint32_t s_un[(FUSED ? (kNmsPatchBytes > kListInts * 4 ? kNmsPatchBytes : kListInts * 4) : kListInts * 4) / 4];
+    __shared__ uint8_t s_tile_st[FUSED ? 16 : kNmsTileBytes];
+    __shared__ __attribute__((aligned(16))) uint32_t s_un_st[FUSED ? 4 : kListInts];
+    uint8_t* const s_tile = FUSED ? s_nms_dyn : s_tile_st;
+    uint32_t* const s_un = FUSED ? reinterpret_cast<uint32_t*>(s_nms_dyn + tile_bytes) : s_un_st;
     const bool staged = FUSED ? npix > 0 : (npix > 0 && npix <= kNmsTileBytes);   // (FUSED plans only hold cells that fit)
     if constexpr (FUSED) {
         if (npix > 0) {
@@ -942,6 +948,7 @@ struct uh_orb {
     bool pair_ok[kMaxLevels] = {};  // levels l and l+1 can be built by one resize_pair_kernel launch (the footprints fit its staging area)
     bool pair_fusion = true;       // UH_ORB_PYRAMID=chain: one launch per level
     bool fuse_fast = false;        // every cell fits cell_nms_kernel<true>'s staging buffers: no strength map, no fast_score launch
+    int nms_tile_bytes = 0, nms_lds_bytes = 0;   // cell_nms_kernel<true>'s dynamic LDS: strength tile | patch / candidate lists
     bool score_valid = false;      // d_score holds the last extraction's strength maps (uh_orb_debug_level computes them on demand)
     // staging for the host-pointer API
     uh::DevBuf d_in, d_kps, d_desc, d_counts;
@@ -1099,6 +1106,17 @@ int make_plan(uh_orb* o, int w, int h, int batch) {
         }
         const char* e = getenv("UH_ORB_FAST");
         o->fuse_fast = fits && !(e && std::string(e) == "map");
+        int most_px = 1, most_patch = 1;
+        for (const CellDesc& C : o->cells) {
+            const int iw = C.x1 - C.x0, ih = C.y1 - C.y0;
+            if (C.skipped || iw <= 0 || ih <= 0) continue;
+            most_px = std::max(most_px, iw * ih);
+            most_patch = std::max(most_patch, (iw + 6) * (ih + 6));
+        }
+        // candidate lists of the four waves: each <= half of its quarter of the raster (rounded up to 64) + 64
+        const int list_bytes = 4 * ((((most_px + 3) / 4 + 63) & ~63) / 2 + 64) * 4;
+        o->nms_tile_bytes = (most_px + 15) & ~15;
+        o->nms_lds_bytes = o->nms_tile_bytes + ((std::max(most_patch, list_bytes) + 15) & ~15);
     }
     // selection workgroups per level: one per 16 cells (a cell per wave) while the launch stays within one workgroup per CU; large
     // batches fall back towards one workgroup per level (every workgroup repeats the level's quota redistribution)
@@ -1208,12 +1226,13 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
     }
     if (P.total_cells > 0) {
         if (o->fuse_fast) {
-            UH_LAUNCH(o->ctx,cell_nms_kernel<true>, dim3(P.total_cells, batch), dim3(256), 0, P, o->d_cells.as<CellDesc>(),
-                               (const uint8_t*)pyr, o->frame_stride, o->d_cand.as<uint32_t>(), o->cand_stride, o->d_cell_counts.as<int>());
+            UH_LAUNCH(o->ctx,cell_nms_kernel<true>, dim3(P.total_cells, batch), dim3(256), (size_t)o->nms_lds_bytes, P, o->d_cells.as<CellDesc>(),
+                               (const uint8_t*)pyr, o->frame_stride, o->d_cand.as<uint32_t>(), o->cand_stride, o->d_cell_counts.as<int>(),
+                               o->nms_tile_bytes);
         } else {
             UH_LAUNCH(o->ctx,cell_nms_kernel<false>, dim3(P.total_cells, batch), dim3(256), 0, P, o->d_cells.as<CellDesc>(),
                                (const uint8_t*)o->d_score.as<uint8_t>(), o->frame_stride, o->d_cand.as<uint32_t>(), o->cand_stride,
-                               o->d_cell_counts.as<int>());
+                               o->d_cell_counts.as<int>(), 0);
         }
     }
     UH_LAUNCH(o->ctx,select_kernel, dim3(P.sel_wg_begin[P.nlevels], batch), dim3(kSelThreads), (size_t)o->lds_entries * 4, P,
