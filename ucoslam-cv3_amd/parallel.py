@@ -173,10 +173,19 @@ def pack_frame_message(buf, lay, kps, desc, n_rows: int, cand=None, counts=None,
     cand [nq,cap] int64 / counts [nq] int32 for the PREVIOUS frame's queries (nq == n_queries), bow [slice,4] int32."""
     import torch
 
-    hdr = torch.tensor([n_rows, n_queries, 0, 0], dtype=torch.int32).to(buf.device).view(torch.uint8)
-    o, n = lay["header"]; buf[o:o + 16] = hdr
-    o, n = lay["kps"]; buf[o:o + n_rows * 28] = kps[:n_rows].contiguous().view(torch.uint8).reshape(-1)
-    o, n = lay["desc"]; buf[o:o + n_rows * 32] = desc[:n_rows].contiguous().reshape(-1)
+    o, n = lay["header"]
+    if torch.is_tensor(n_rows):   # a device count (the extractor's own output): no host round trip, the whole capacity is copied
+        hdr = buf[o:o + 16].view(torch.int32)
+        hdr[0:1] = n_rows.reshape(1).to(torch.int32)
+        hdr[1:2].fill_(n_queries)
+        hdr[2:4].zero_()
+        cap_rows = min(kps.shape[0], lay["kps"][1] // 28)
+        o, n = lay["kps"]; buf[o:o + cap_rows * 28] = kps[:cap_rows].contiguous().view(torch.uint8).reshape(-1)
+        o, n = lay["desc"]; buf[o:o + cap_rows * 32] = desc[:cap_rows].contiguous().reshape(-1)
+    else:
+        buf[o:o + 16] = torch.tensor([n_rows, n_queries, 0, 0], dtype=torch.int32).to(buf.device).view(torch.uint8)
+        o, n = lay["kps"]; buf[o:o + n_rows * 28] = kps[:n_rows].contiguous().view(torch.uint8).reshape(-1)
+        o, n = lay["desc"]; buf[o:o + n_rows * 32] = desc[:n_rows].contiguous().reshape(-1)
     if n_queries:
         o, n = lay["counts"]; buf[o:o + n_queries * 4] = counts[:n_queries].contiguous().view(torch.uint8).reshape(-1)
         o, n = lay["cand"]; buf[o:o + cand[:n_queries].numel() * 8] = cand[:n_queries].contiguous().view(torch.uint8).reshape(-1)
@@ -236,6 +245,7 @@ class ShardedFrameStream:
             rank, world = dist.get_rank(group), dist.get_world_size(group)
         self.rank, self.world = rank, world
         self.lay = frame_message_layout(max_features, cand_cap, vocabulary is not None)
+        self._device_counts = True   # the level-row count travels as a device value (False: read back, rows copied exactly — tests)
         self.prev = None      # (kps, desc) of the previous frame, complete
         self._buf = None
         self._slices = None
@@ -262,7 +272,7 @@ class ShardedFrameStream:
             if self.voc is not None:
                 self._slices = shard_bounds(nq, self.world)
                 bow = self.voc.transform_triplets(pq[self._slices[self.rank]:self._slices[self.rank + 1]], self.bow_level)
-        n_rows = int(counts[0])
+        n_rows = counts[0] if self._device_counts else int(counts[0])   # (device count: no synchronisation before the collective)
         return pack_frame_message(self._buf, self.lay, kps[0], desc[0], n_rows, cand, ccounts, nq, bow)
 
     def finish(self, msgs):
