@@ -152,6 +152,78 @@ __device__ __forceinline__ void edge_eval_p(double u, double v, double w, double
     }
 }
 
+// T_trial = exp(dx) T_cur (SE3Quat::exp and the quaternion product of VertexSE3Expmap::oplusImpl) for the persistent kernel: the same
+// formulas as se3_left_update (ba.hip), with every IEEE division and square root replaced by rsqrt_nr / fast_rcp and multiplications
+// (~13 divisions + 3 square roots of ~35 dependent instructions each sit on ONE lone wave per workgroup here: the pose update was
+// most of the 2.2 us between the back substitution and the trial errors).  Last-bit differences against the division form.
+__device__ __forceinline__ void quat_norm_pos_p(double (&q)[4]) {
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double rn = rsqrt_nr(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] *= rn; q[1] *= rn; q[2] *= rn; q[3] *= rn;
+}
+__device__ __forceinline__ void quat_from_R_p(const double (&R)[9], double (&q)[4]) {   // Eigen::Quaternion(Matrix3), 1/sqrt form
+    const double tr = R[0] + R[4] + R[8];
+    if (tr > 0) {
+        const double x = tr + 1.0, r = rsqrt_nr(x), h = 0.5 * r;   // sqrt(x) = x r, 0.5 / sqrt(x) = 0.5 r
+        q[3] = 0.5 * (x * r);
+        q[0] = (R[7] - R[5]) * h; q[1] = (R[2] - R[6]) * h; q[2] = (R[3] - R[1]) * h;
+    } else if (!(R[4] > R[0]) && !(R[8] > R[0])) {
+        const double x = R[0] - R[4] - R[8] + 1.0, r = rsqrt_nr(x), h = 0.5 * r;
+        q[0] = 0.5 * (x * r);
+        q[3] = (R[7] - R[5]) * h; q[1] = (R[3] + R[1]) * h; q[2] = (R[6] + R[2]) * h;
+    } else if (R[4] > R[0] && !(R[8] > R[4])) {
+        const double x = R[4] - R[8] - R[0] + 1.0, r = rsqrt_nr(x), h = 0.5 * r;
+        q[1] = 0.5 * (x * r);
+        q[3] = (R[2] - R[6]) * h; q[2] = (R[7] + R[5]) * h; q[0] = (R[1] + R[3]) * h;
+    } else {
+        const double x = R[8] - R[0] - R[4] + 1.0, r = rsqrt_nr(x), h = 0.5 * r;
+        q[2] = 0.5 * (x * r);
+        q[3] = (R[3] - R[1]) * h; q[0] = (R[2] + R[6]) * h; q[1] = (R[5] + R[7]) * h;
+    }
+}
+__device__ __forceinline__ void se3_left_update_p(double (&q)[4], double (&t)[3], const double* dx) {
+    const double w0 = dx[0], w1 = dx[1], w2 = dx[2];
+    const double th2 = w0 * w0 + w1 * w1 + w2 * w2;
+    const double O[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+    double O2[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
+    double a, b, c2;
+    if (!(th2 >= 1e-10)) { a = 1; b = 0.5; c2 = 1.0 / 6.0; }   // theta < 1e-5 (also th2 == 0, where 1/theta does not exist)
+    else {
+        const double rth = rsqrt_nr(th2), theta = th2 * rth, rth2 = rth * rth;
+        double sn, cs;
+        sincos(theta, &sn, &cs);   // (a Taylor branch for small angles beside this call made the phase slower: 1.88 -> 2.72 us)
+        a = sn * rth; b = (1 - cs) * rth2; c2 = (theta - sn) * (rth2 * rth);
+    }
+    double Rm[9], V[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { const double I = (i % 4 == 0) ? 1.0 : 0.0; Rm[i] = I + a * O[i] + b * O2[i]; V[i] = I + b * O[i] + c2 * O2[i]; }
+    double qe[4];
+    quat_from_R_p(Rm, qe);
+    quat_norm_pos_p(qe);
+    double te[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) te[r] = V[r * 3] * dx[3] + V[r * 3 + 1] * dx[4] + V[r * 3 + 2] * dx[5];
+    double RE[9];
+    quat_to_R(qe, RE);
+    double qn[4];
+    qn[3] = qe[3] * q[3] - qe[0] * q[0] - qe[1] * q[1] - qe[2] * q[2];
+    qn[0] = qe[3] * q[0] + qe[0] * q[3] + qe[1] * q[2] - qe[2] * q[1];
+    qn[1] = qe[3] * q[1] + qe[1] * q[3] + qe[2] * q[0] - qe[0] * q[2];
+    qn[2] = qe[3] * q[2] + qe[2] * q[3] + qe[0] * q[1] - qe[1] * q[0];
+    double tn[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) tn[r] = RE[r * 3] * t[0] + RE[r * 3 + 1] * t[1] + RE[r * 3 + 2] * t[2] + te[r];
+    quat_norm_pos_p(qn);
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = qn[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) t[i] = tn[i];
+}
+
 // chi2 sum + max (or two sums) over the workgroup with ONE pair of barriers: the two butterflies interleave
 template <int NW, bool SECOND_IS_MAX>
 __device__ __forceinline__ void block_reduce2(double& a, double& b, double* s_red) {
@@ -758,7 +830,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             if (wv == 1 && lane < nfree) {   // T_trial = exp(dx) T_cur
                 const double* Tc = s_pose + (cur * NF + lane) * 7;
                 double qv[4] = {Tc[0], Tc[1], Tc[2], Tc[3]}, tv[3] = {Tc[4], Tc[5], Tc[6]};
-                if (ok) se3_left_update(qv, tv, s_x + 6 * lane);
+                if (ok) se3_left_update_p(qv, tv, s_x + 6 * lane);
                 double* To = s_pose + (trial * NF + lane) * 7;
                 To[0] = qv[0]; To[1] = qv[1]; To[2] = qv[2]; To[3] = qv[3]; To[4] = tv[0]; To[5] = tv[1]; To[6] = tv[2];
                 double Rn[9];
