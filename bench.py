@@ -177,7 +177,7 @@ def main():
     roofline = None
     stage_ms = {}
     if rank == 0 and args.quick:
-        print(json.dumps({"value": round(value, 1), "ms_per_step": round(ms_per_step, 4), "knn_qpw": args.knn_qpw, "knn_form": os.environ.get("UH_KNN_FORM", "auto (two-phase from 6000 queries)")}), flush=True)
+        print(json.dumps({"value": round(value, 1), "ms_per_step": round(ms_per_step, 4), "knn_qpw": args.knn_qpw, "knn_form": os.environ.get("UH_KNN_FORM", "auto (accept-list forms from 3000 queries)")}), flush=True)
         return
     if rank == 0:
         def timed(fn, reps):

@@ -82,7 +82,7 @@ def knn_case(seed):
 run("knn_exact", knn_case)
 
 
-def knn2_case(seed):   # the accept-list scan + lane replay (default only from 6000 queries on), forced for every size
+def knn2_case(seed, form="twophase"):   # the accept-list scan + lane replay (default only from 3000 queries on), forced for every size
     r = np.random.default_rng(seed)
     nt, nq, nn = int(r.integers(1, 6000)), int(r.integers(1, 400)), int(r.integers(1, 17))
     if r.random() < 0.3:
@@ -91,8 +91,8 @@ def knn2_case(seed):   # the accept-list scan + lane replay (default only from 6
         train, q = synth.match_set(nq, nt, seed=seed % 1000)
     srt = bool(r.integers(0, 2))
     md = int(r.choice([-1, -1, 40, 90, 120]))
-    os.environ["UH_KNN_FORM"] = "twophase"
-    os.environ["UH_KNN_ACCEPT_QPW"] = str(int(r.choice([1, 2])))
+    os.environ["UH_KNN_FORM"] = form
+    os.environ["UH_KNN_ACCEPT_QPW"] = str(int(r.choice([1, 2]))) if form == "twophase" else "2"
     try:
         idx = Index(ctx).build(train)
     finally:
@@ -102,6 +102,25 @@ def knn2_case(seed):   # the accept-list scan + lane replay (default only from 6
     return (gi == ri).all() and (gd == rd).all(), (nt, nq, nn, srt, md)
 
 run("knn_twophase", knn2_case)
+
+
+def knn3_case(seed):   # scan and replay in one launch (default from 3000 queries on, nn >= 6); every third case large enough for many workgroups
+    if seed % 3:
+        return knn2_case(seed, "stream")
+    r = np.random.default_rng(seed)
+    nt, nq, nn = int(r.integers(500, 4000)), int(r.integers(3000, 9000)), int(r.integers(1, 17))
+    train, q = synth.match_set(nq, nt, seed=seed % 1000)
+    srt = bool(r.integers(0, 2))
+    os.environ["UH_KNN_FORM"] = "stream"
+    try:
+        idx = Index(ctx).build(train)
+    finally:
+        del os.environ["UH_KNN_FORM"]
+    gi, gd = idx.search(q, nn, sorted=srt)
+    ri, rd = oracle_lib.knn_search(L, train, q, nn, int(srt))
+    return (gi == ri).all() and (gd == rd).all(), (nt, nq, nn, srt)
+
+run("knn_stream", knn3_case)
 
 def km_case(seed):
     r = np.random.default_rng(seed)

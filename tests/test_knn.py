@@ -122,14 +122,15 @@ def test_hip_knn_queries_per_wave_identical_rows(hip_ctx, oracle, qpw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("accept_qpw", ["1", "2"])
-def test_hip_knn_two_phase_form_every_k(hip_ctx, oracle, accept_qpw, monkeypatch):
-    """The accept-list scan + lane-per-query replay (default from 6000 queries on, forced here for every size): every k the register heap is
-    instantiated for (1..16), sorted and unsorted, ties, distances descending with the row index (every accept list overflows its
-    capacity: the redo kernel), sets smaller than k, ragged query counts, a radius bound; one and two queries per scanning wave."""
+@pytest.mark.parametrize("form,accept_qpw", [("twophase", "1"), ("twophase", "2"), ("stream", "2")])
+def test_hip_knn_two_phase_form_every_k(hip_ctx, oracle, form, accept_qpw, monkeypatch):
+    """The accept-list scan + lane-per-query replay (default from 6000 queries on, forced here for every size), as two launches and as
+    one launch whose replay waves consume the lists while the scan appends to them: every k the register heap is instantiated for
+    (1..16), sorted and unsorted, ties, distances descending with the row index (every accept list overflows its capacity: the redo
+    kernel), sets smaller than k, ragged query counts, a radius bound; one and two queries per scanning wave."""
     from ucoslam_cv3_amd.knn import Index
 
-    monkeypatch.setenv("UH_KNN_FORM", "twophase")
+    monkeypatch.setenv("UH_KNN_FORM", form)
     monkeypatch.setenv("UH_KNN_ACCEPT_QPW", accept_qpw)
     for case, (train, q) in _gpu_cases().items():
         index = Index(hip_ctx).build(train)
@@ -161,6 +162,23 @@ def test_hip_knn_two_phase_form_every_k(hip_ctx, oracle, accept_qpw, monkeypatch
         idx, dist = index.search(q, nn, sorted=False)
         ri, rd = oracle_lib.knn_search(oracle, train, q, nn, 0)
         np.testing.assert_array_equal(idx, ri)
+        np.testing.assert_array_equal(dist, rd)
+
+
+@pytest.mark.gpu
+def test_hip_knn_stream_form_many_workgroups_and_tag_wrap(hip_ctx, oracle, monkeypatch):
+    """The one-launch form at the size it is the default for (8000+ queries: 32 replay workgroups beside 1000 scanning ones), repeated
+    launches on one index with changing query counts (stale words of earlier launches carry other tags), and the launch tag running over
+    2^32 (the list buffer is cleared and the tags start over)."""
+    from ucoslam_cv3_amd.knn import Index
+
+    monkeypatch.setenv("UH_KNN_TAG0", str(0xFFFFFFFC))
+    train, q = synth.match_set(8003, 3001, seed=91)
+    index = Index(hip_ctx).build(train)
+    for rep, (nq, nn) in enumerate(((8003, 10), (7001, 10), (8003, 2), (6500, 16), (8003, 10), (8000, 5))):
+        idx, dist = index.search(q[:nq], nn, sorted=bool(rep & 1))
+        ri, rd = oracle_lib.knn_search(oracle, train, q[:nq], nn, rep & 1)
+        np.testing.assert_array_equal(idx, ri, err_msg=f"launch {rep}: nq={nq} nn={nn}")
         np.testing.assert_array_equal(dist, rd)
 
 

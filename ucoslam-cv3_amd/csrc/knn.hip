@@ -304,14 +304,21 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_search_kernel(
 //  lane-distributed heap: 107 us; four queries per wave in 16-lane rows with row-local ds_bpermute: 63 us.
 //
 //  Lists that overflow their capacity (distances descending with the row index) are collected and recomputed by knn_redo_kernel.
-template <int QPW>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_accept_kernel(
+// STREAM (knn_stream_kernel): the lists are consumed WHILE they grow, by replay waves of the same launch on other CUs.  An entry is then
+// launch tag << 32 | distance << 23 | row (a reader validates the tag: no flags, no ordering between words, nothing to clear between
+// launches), stored write-through; after every step that appended, and at the end with bit 31 set, the query's progress word
+// prog[q] = tag << 32 | entries so far follows.
+template <int QPW, bool STREAM>
+__device__ __forceinline__ void accept_scan(
     const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k, int maxd,
-    uint64_t* __restrict__ cand, int32_t* __restrict__ counts, int cap, int* __restrict__ redo_count) {
+    uint64_t* __restrict__ cand, int32_t* __restrict__ counts, int cap, int wave, uint64_t* __restrict__ prog, unsigned tag) {
     const int lane = threadIdx.x & (kWave - 1);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *redo_count = 0;   // (the replay launch behind this one counts the overflowed lists)
-    const int q0 = __builtin_amdgcn_readfirstlane((blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * QPW);
+    const int q0 = __builtin_amdgcn_readfirstlane(wave * QPW);
     if (q0 >= nq) return;
+    auto put = [&](size_t at, int d, int idx) {
+        if constexpr (STREAM) __hip_atomic_store(cand + at, ((uint64_t)tag << 32) | ((uint64_t)(uint32_t)d << 23) | (uint32_t)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else cand[at] = ((uint64_t)(uint32_t)d << 32) | (uint32_t)idx;
+    };
     uint32_t q[QPW][8];
     int sv[QPW];    // every 16-lane row: the smallest distances so far, ascending with the lane (INT_MAX where nothing has been seen yet)
     int thr[QPW];   // wave-uniform: the k-th smallest = lane k-1 of a row
@@ -345,14 +352,14 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_accept_kernel(
                 const int dl = rl(d, l);
                 if (dl >= thr[j]) continue;
                 const int il = rl(idx, l);
-                if (lane == 0 && nc[j] < cap) cand[(size_t)nc[j] * nq + qj] = ((uint64_t)(uint32_t)dl << 32) | (uint32_t)il;
+                if (lane == 0 && nc[j] < cap) put((size_t)nc[j] * nq + qj, dl, il);
                 nc[j]++;
                 tighten(j, dl);
             }
             return;
         }
         const int pos = nc[j] + __popcll(m & lt);
-        if (pass && pos < cap) cand[(size_t)pos * nq + qj] = ((uint64_t)(uint32_t)d << 32) | (uint32_t)idx;
+        if (pass && pos < cap) put((size_t)pos * nq + qj, d, idx);
         nc[j] += __popcll(m);
         while (m) {
             const int l = __builtin_ctzll(m);
@@ -367,16 +374,20 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_accept_kernel(
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(train), 0, t1 * 32, 0x00020000);
     const int voff = lane * 32;
     int base = t0;
-    for (; base + UNROLL * kWave <= t1; base += UNROLL * kWave) {
-        uint4 a0[UNROLL], a1[UNROLL];
-        const int soff = __builtin_amdgcn_readfirstlane(base * 32);
+    constexpr int G = UNROLL * kWave;
+    // Two groups of 256 rows alternate: while one is scored the other's eight 16-byte loads are in flight (the wave used to wait a
+    // whole L1 / L2 latency at the top of every group, hidden only by the three other waves of its SIMD).
+    auto fetch = [&](int b, uint4 (&x0)[UNROLL], uint4 (&x1)[UNROLL]) {
+        const int soff = __builtin_amdgcn_readfirstlane(b * 32);
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            const u32x4 x0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + u * kWave * 32, soff, 0);
-            const u32x4 x1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + u * kWave * 32 + 16, soff, 0);
-            a0[u] = make_uint4(x0.x, x0.y, x0.z, x0.w);
-            a1[u] = make_uint4(x1.x, x1.y, x1.z, x1.w);
+            const u32x4 y0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + u * kWave * 32, soff, 0);
+            const u32x4 y1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + u * kWave * 32 + 16, soff, 0);
+            x0[u] = make_uint4(y0.x, y0.y, y0.z, y0.w);
+            x1[u] = make_uint4(y1.x, y1.y, y1.z, y1.w);
         }
+    };
+    auto score = [&](int b, const uint4 (&a0)[UNROLL], const uint4 (&a1)[UNROLL]) {
 #pragma unroll
         for (int j = 0; j < QPW; ++j) {
             int d[UNROLL];
@@ -385,9 +396,24 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_accept_kernel(
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) { d[u] = hamming256(a0[u], a1[u], q[j]); any = any || d[u] < tj; }
             if (__ballot(any) == 0) continue;
+            const int before = nc[j];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) feed(j, d[u], base + u * kWave + lane, q0 + j < nq, q0 + j < nq ? q0 + j : 0, u == 0 && base == t0);
+            for (int u = 0; u < UNROLL; ++u) feed(j, d[u], b + u * kWave + lane, q0 + j < nq, q0 + j < nq ? q0 + j : 0, u == 0 && b == t0);
+            if constexpr (STREAM)
+                if (nc[j] != before && lane == 0 && q0 + j < nq)
+                    __hip_atomic_store(prog + q0 + j, ((uint64_t)tag << 32) | (uint32_t)nc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    };
+    {
+        uint4 a0[UNROLL], a1[UNROLL], b0[UNROLL], b1[UNROLL];
+        if (base + G <= t1) fetch(base, a0, a1);
+        for (; base + 2 * G <= t1; base += 2 * G) {
+            fetch(base + G, b0, b1);
+            score(base, a0, a1);
+            fetch(min(base + 2 * G, t1 - G), a0, a1);   // (clamped: the wave-uniform part of the address is not bounds-checked)
+            score(base + G, b0, b1);
+        }
+        if (base + G <= t1) { score(base, a0, a1); base += G; }
     }
     for (; base < t1; base += kWave) {
         const int t = base + lane;
@@ -403,7 +429,17 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_accept_kernel(
     }
 #pragma unroll
     for (int j = 0; j < QPW; ++j)
-        if (q0 + j < nq && lane == 0) counts[q0 + j] = nc[j];
+        if (q0 + j < nq && lane == 0) {
+            if constexpr (STREAM) __hip_atomic_store(prog + q0 + j, ((uint64_t)tag << 32) | 0x80000000u | (uint32_t)nc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else counts[q0 + j] = nc[j];
+        }
+}
+template <int QPW>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_accept_kernel(
+    const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k, int maxd,
+    uint64_t* __restrict__ cand, int32_t* __restrict__ counts, int cap, int* __restrict__ redo_count) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *redo_count = 0;   // (the replay launch behind this one counts the overflowed lists)
+    accept_scan<QPW, false>(train, t0, t1, queries, nq, k, maxd, cand, counts, cap, blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nullptr, 0u);
 }
 
 constexpr int kRpK = 16;   // the two-phase form serves k <= 16
@@ -420,47 +456,52 @@ __device__ __forceinline__ void static_for(F&& f) {
 constexpr unsigned kDistMask = 0xFF800000u;
 __device__ __forceinline__ bool dist_less(unsigned a, unsigned b) { return a < (b & kDistMask); }
 
-// sift the new element up from STATIC slot P (:93-100)
+// sift the new element up from STATIC slot P (:93-100).  cmz = the new word's distance bits for the lanes that push, 0 for the others:
+// "parent < new" is then false by itself in a lane that does not push, and in a pushing lane the heap order (a parent is never closer
+// than its child) makes "the climb reached this slot" redundant — d(parent) < d(new) implies d(child) < d(new) — so no step needs the
+// conjunction of two lane masks (a scalar instruction between two vector ones, on a wave whose every instruction is latency).
 template <int K, int P>
-__device__ __forceinline__ void heap_append_step(unsigned (&hw)[K], bool up, unsigned cw) {
+__device__ __forceinline__ void heap_append_step(unsigned (&hw)[K], bool up, unsigned cw, unsigned cmz) {
     if constexpr (P == 0) {
         hw[0] = up ? cw : hw[0];
     } else {
         constexpr int par = (P - 1) >> 1;
-        const bool mv = up && dist_less(hw[par], cw);
+        const bool mv = hw[par] < cmz;
         hw[P] = up ? (mv ? hw[par] : cw) : hw[P];
-        heap_append_step<K, par>(hw, mv, cw);
+        heap_append_step<K, par>(hw, mv, cw, cmz);
     }
 }
 // remove the root of a FULL heap (:104-135): the last element re-enters at the root and sinks; nodes 0 .. K-2 take part.  Level by
-// level: the lane's position is one of the level's nodes, its children are selected from the next level.
+// level: the lane's position `pos` is one of the level's nodes (or -1: the lane does not pop, or its element has come to rest), its
+// children are selected from the next level.  A child that does not exist reads as the word 0 (distance 0): nothing is closer than
+// it, so the element never moves there, and "right child closer than left" is false for it — exactly the reference's bounds tests,
+// without a mask to carry: the only predicates are pos == n (one compare, three selects per node) and the two distance compares.
 template <int K, int LVL>
-__device__ __forceinline__ void heap_pop_level(unsigned (&hw)[K], unsigned mw, int pos, bool go) {
+__device__ __forceinline__ void heap_pop_level(unsigned (&hw)[K], unsigned mw, int pos) {
     constexpr int NS = K - 1, first = (1 << LVL) - 1;
     if constexpr (first < NS) {
         constexpr int last = 2 * first < NS - 1 ? 2 * first : NS - 1;
+        constexpr bool kids = 2 * first + 1 < NS;
         unsigned wl = 0, wr = 0;
-        bool hasL = false, hasR = false;
         static_for<first, last + 1>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
-            const bool at = pos == n;
-            if constexpr (2 * n + 1 < NS) { wl = at ? hw[2 * n + 1] : wl; hasL = hasL || at; }
-            if constexpr (2 * n + 2 < NS) { wr = at ? hw[2 * n + 2] : wr; hasR = hasR || at; }
+            if constexpr (2 * n + 1 < NS) wl = pos == n ? hw[2 * n + 1] : wl;
+            if constexpr (2 * n + 2 < NS) wr = pos == n ? hw[2 * n + 2] : wr;
         });
-        const bool pickL = !hasR || dist_less(wr, wl);
+        const bool pickL = dist_less(wr, wl);   // :113 (dr < dl ? left : right); only a left child: wr = 0 picks it unless d(left) = 0, and then nothing moves
         const unsigned wc = pickL ? wl : wr;
-        const bool mv = go && hasL && dist_less(mw, wc);
+        const bool mv = dist_less(mw, wc);
         const unsigned put = mv ? wc : mw;
         static_for<first, last + 1>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
-            hw[n] = (go && pos == n) ? put : hw[n];
+            hw[n] = pos == n ? put : hw[n];
         });
-        heap_pop_level<K, LVL + 1>(hw, mw, mv ? (pickL ? 2 * pos + 1 : 2 * pos + 2) : pos, mv);
+        if constexpr (kids) heap_pop_level<K, LVL + 1>(hw, mw, mv ? 2 * pos + (pickL ? 1 : 2) : -1);
     }
 }
 template <int K>
 __device__ __forceinline__ void heap_pop_full(unsigned (&hw)[K], bool acc) {
-    if constexpr (K >= 2) heap_pop_level<K, 0>(hw, hw[K - 1], 0, acc);
+    if constexpr (K >= 2) heap_pop_level<K, 0>(hw, hw[K - 1], acc ? 0 : -1);
 }
 // any mixture of sizes inside the wave (lists of different lengths, max_dist): dynamic positions through select chains
 template <int K>
@@ -513,6 +554,166 @@ __device__ __forceinline__ void heap_push_generic(unsigned (&hw)[K], int& size, 
     heap_append_generic<K>(hw, size, acc, cw);
 }
 
+// one entry for every lane of the wave (acc: the lanes whose entry passes resultset.h:66-69)
+template <int K>
+__device__ __forceinline__ void heap_push_wave(unsigned (&hw)[K], int& size, bool acc, unsigned cw) {
+    if (__ballot(acc && size != K) == 0) {                      // steady state: every accepting lane's heap is full
+        heap_pop_full<K>(hw, acc);
+        heap_append_step<K, K - 1>(hw, acc, cw, acc ? cw & kDistMask : 0u);
+    } else if (__ballot(acc && size >= K) == 0) {               // filling: nobody has to remove a root (select chains, no dynamic index:
+        heap_append_generic<K>(hw, size, acc, cw);              // a dispatch on the common size ends up as an indexed store to scratch)
+    } else {
+        heap_push_generic<K>(hw, size, acc, cw);
+    }
+}
+// linear.h:82-85 (fill) + index.h:119-134 (exchange sort; idx[i] is tested once, before the inner loop)
+template <int K>
+__device__ __forceinline__ void heap_write_row(const unsigned (&hw)[K], int size, int sorted, bool on_q, int qi, int32_t* __restrict__ indices,
+                                               int32_t* __restrict__ distances) {
+    int hd[K], hi[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) { const bool on = i < size; hd[i] = on ? (int)(hw[i] >> 23) : 0; hi[i] = on ? (int)(hw[i] & 0x7FFFFFu) : -1; }
+    if (sorted) {
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) {
+            const bool on = hi[i] != -1;
+#pragma unroll
+            for (int j = i + 1; j < K; ++j) {
+                const bool sw = on && hd[i] > hd[j];
+                const int td = hd[i], ti = hi[i];
+                hd[i] = sw ? hd[j] : td; hi[i] = sw ? hi[j] : ti;
+                hd[j] = sw ? td : hd[j]; hi[j] = sw ? ti : hi[j];
+            }
+        }
+    }
+    if (on_q) {
+#pragma unroll
+        for (int i = 0; i < K; i++) { indices[(size_t)qi * K + i] = hi[i]; distances[(size_t)qi * K + i] = hd[i]; }
+    }
+}
+
+// A wave's staged entries (LDS, entry u of the lane's query at stage[u * 64]; kNoEntry where the lane has none), pushed in order
+// (resultset.h:66-69; the radius bound of :66 has been applied by the scan).  Two loops: while some lane that still expects entries is
+// not full, the general push; from then on — every list after its first K entries — the steady-state form whose every step is one
+// compare + branch when no lane accepts and root removal + append otherwise, with nothing else in the loop: on a wave that owns its
+// SIMD's issue slot every instruction of the step costs ~10 cycles, loop bookkeeping included.
+constexpr unsigned kNoEntry = 0xFFFFFFFFu;   // (distance 511: closer than nothing)
+template <int K>
+__device__ __forceinline__ void replay_staged(unsigned (&hw)[K], int& size, const unsigned* stage, int steps, bool live) {
+    if (steps <= 0) return;
+    int u = 0;
+    unsigned nxt = stage[0];
+    if (__ballot(live && size != K) != 0) {
+        for (; u < steps;) {
+            const unsigned cw = nxt;
+            ++u;
+            nxt = stage[min(u, steps - 1) * kWave];
+            const bool acc = cw != kNoEntry && (size < K || dist_less(cw, hw[0]));
+            if (__ballot(acc)) heap_push_wave<K>(hw, size, acc, cw);
+            if (__ballot(live && size != K) == 0) break;
+        }
+    }
+    for (; u < steps;) {
+        const unsigned cw = nxt;
+        ++u;
+        nxt = stage[min(u, steps - 1) * kWave];
+        const bool acc = dist_less(cw, hw[0]);
+        if (!__ballot(acc)) continue;
+        heap_pop_full<K>(hw, acc);
+        heap_append_step<K, K - 1>(hw, acc, cw, acc ? cw & kDistMask : 0u);
+    }
+}
+
+// Accept scan and replay in ONE launch of one-wave workgroups: the first `nrep` replay (64 queries each, one lane per query, the
+// register heap of knn_replay_lane_kernel), the others scan two queries each (accept_scan<2, true>).  The replay of a query is a chain
+// of ~k (1 + ln(N/k)) pushes of ~0.4 us each whatever the number of queries (47 us behind an 87 us scan in the two-launch form, on 125
+// of the chip's 1024 SIMDs); here a replay lane consumes its query's list while the scan is still appending to it, and the launch ends
+// a few microseconds after the last scan wave (8000 x 10 000, nn 10: scan waves end at 43..98 us — the SIMDs serve their oldest wave
+// first —, the replay waves 2..28 us behind their last one, the launch at 105 us; nn 2: 1..4 us behind).  What it costs: the replay
+// waves run at raised priority beside scan waves and take issue slots from them, the lists travel as write-through stores, and the
+// scan's registers are capped by the replay's: the streaming scan alone is ~8 % slower than knn_accept_kernel, which is why short
+// replays (nn <= 5) keep the two launches.  One-wave workgroups: with 4125 workgroups the dispatcher evens out the SIMDs (four-wave
+// workgroups left some CUs a fifth one and the launch 20 us longer).
+// The scanning waves wait for nobody, the replay workgroups are a small fixed part of the grid and come FIRST (resident before any
+// scan workgroup could crowd them out), so the launch always makes progress; a replay lane that sees no progress for two seconds hands
+// its query to knn_redo_kernel (as it does with an overflowed list), so even then the rows are right.
+// Protocol: accept_scan<., true>.  A replay wave polls its 64 progress words (one coalesced load), fetches the entries that are new
+// (at most kStreamStage per lane and round, all loads in flight together), keeps the prefix whose tags match, stages it in LDS and pushes it.
+constexpr int kStreamStage = 16;
+constexpr long long kStreamTimeout = 200000000ll;   // 2 s of the 100 MHz wall clock
+template <int K>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5, 5))) void knn_stream_kernel(
+    const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int sorted, int maxd,
+    uint64_t* __restrict__ cand, uint64_t* __restrict__ prog, int cap, unsigned tag, int nrep,
+    int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ redo_list, int* __restrict__ redo_count, int* __restrict__ redo_next) {
+    if ((int)blockIdx.x >= nrep) {
+        accept_scan<2, true>(train, t0, t1, queries, nq, K, maxd, cand, nullptr, cap, (int)blockIdx.x - nrep, prog, tag);
+        return;
+    }
+    __shared__ unsigned s_stage[kStreamStage * kWave];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *redo_next = 0;   // the NEXT launch's overflow counter (this launch's was cleared by the previous one)
+    __builtin_amdgcn_s_setprio(3);                              // a dependent chain beside throughput-bound scan waves: issue first
+    const int lane = threadIdx.x & (kWave - 1);
+    unsigned* stage = s_stage + lane;
+    const int qi = blockIdx.x * kWave + threadIdx.x;
+    const bool haveq = qi < nq;
+    const uint64_t* col = cand + (haveq ? qi : 0);
+    const uint64_t* pq = prog + (haveq ? qi : 0);
+    unsigned hw[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) hw[i] = 0;
+    int size = 0, e = 0;
+    bool fin = !haveq, over = false;
+    long long tlast = wall_clock64();
+    while (__ballot(!fin) != 0) {
+        const uint64_t pw = __hip_atomic_load(pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ok = !fin && (unsigned)(pw >> 32) == tag;
+        const int nc = ok ? (int)((unsigned)pw & 0x7fffffffu) : 0;
+        const bool closed = ok && ((unsigned)pw & 0x80000000u) != 0;
+        if (closed && nc > cap) { over = true; fin = true; }
+        const int want = fin ? 0 : min(nc, cap) - e;
+        int most = want;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) most = max(most, __shfl_xor(most, o));
+        most = __builtin_amdgcn_readfirstlane(most);
+        if (most == 0) {
+            fin = fin || closed;
+            if (wall_clock64() - tlast > kStreamTimeout) { over = over || !fin; fin = true; }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        uint64_t v[kStreamStage];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = __hip_atomic_load(col + (size_t)min(e + u, cap - 1) * nq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (most > 4) {   // (a wave that keeps up with its scans sees a few new entries per round)
+#pragma unroll
+            for (int u = 4; u < kStreamStage; u++) v[u] = __hip_atomic_load(col + (size_t)min(e + u, cap - 1) * nq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+#pragma unroll
+            for (int u = 4; u < kStreamStage; u++) v[u] = 0;
+        }
+        int np = 0;
+        bool run = true;
+#pragma unroll
+        for (int u = 0; u < kStreamStage; u++) {
+            run = run && u < want && (unsigned)(v[u] >> 32) == tag;
+            np += run ? 1 : 0;
+            stage[u * kWave] = run ? (unsigned)v[u] : kNoEntry;
+        }
+        int steps = np;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) steps = max(steps, __shfl_xor(steps, o));
+        steps = __builtin_amdgcn_readfirstlane(steps);
+        if (steps) tlast = wall_clock64();
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): a lane reads back only what it staged itself
+        replay_staged<K>(hw, size, stage, steps, !fin);
+        e += np;
+        if (closed && e >= min(nc, cap)) fin = true;
+    }
+    if (over) redo_list[atomicAdd(redo_count, 1)] = qi;
+    heap_write_row<K>(hw, size, sorted, haveq && !over, qi, indices, distances);
+}
+
 template <int K>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) void knn_replay_lane_kernel(
     const uint64_t* __restrict__ cand, const int32_t* __restrict__ counts, int nq, int sorted, int maxd, int cap,
@@ -551,38 +752,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
         const unsigned cw = ((unsigned)d << 23) | (unsigned)(uint32_t)cur;
         const bool valid = e < cnt && !(maxd >= 0 && maxd < d);     // resultset.h:66
         const bool acc = valid && (size < K || dist_less(cw, hw[0]));   // :67-69
-        const unsigned long long am = __ballot(acc);
-        if (!am) continue;
-        if (__ballot(acc && size != K) == 0) {                      // steady state: every accepting lane's heap is full
-            heap_pop_full<K>(hw, acc);
-            heap_append_step<K, K - 1>(hw, acc, cw);
-        } else if (__ballot(acc && size >= K) == 0) {               // filling: nobody has to remove a root (select chains, no dynamic index:
-            heap_append_generic<K>(hw, size, acc, cw);              // a dispatch on the common size ends up as an indexed store to scratch)
-        } else {
-            heap_push_generic<K>(hw, size, acc, cw);
-        }
+        if (!__ballot(acc)) continue;
+        heap_push_wave<K>(hw, size, acc, cw);
     }
-    // linear.h:82-85 (fill) + index.h:119-134 (exchange sort; idx[i] is tested once, before the inner loop)
-    int hd[K], hi[K];
-#pragma unroll
-    for (int i = 0; i < K; i++) { const bool on = i < size; hd[i] = on ? (int)(hw[i] >> 23) : 0; hi[i] = on ? (int)(hw[i] & 0x7FFFFFu) : -1; }
-    if (sorted) {
-#pragma unroll
-        for (int i = 0; i < K - 1; ++i) {
-            const bool on = hi[i] != -1;
-#pragma unroll
-            for (int j = i + 1; j < K; ++j) {
-                const bool sw = on && hd[i] > hd[j];
-                const int td = hd[i], ti = hi[i];
-                hd[i] = sw ? hd[j] : td; hi[i] = sw ? hi[j] : ti;
-                hd[j] = sw ? td : hd[j]; hi[j] = sw ? ti : hi[j];
-            }
-        }
-    }
-    if (haveq && !over) {
-#pragma unroll
-        for (int i = 0; i < K; i++) { indices[(size_t)qi * K + i] = hi[i]; distances[(size_t)qi * K + i] = hd[i]; }
-    }
+    heap_write_row<K>(hw, size, sorted, haveq && !over, qi, indices, distances);
 }
 
 // the (rare) queries whose accept list overflowed: the fused one-wave search, over a compacted list
@@ -985,11 +1158,18 @@ struct uh_knn {
     int shard_begin = 0, shard_end = 0;
     int row_offset = 0;           // global index of row 0 (uh_knn_set_row_offset): an index that holds only one tile of a sharded train set
     int qpw = 1;                  // queries per wave of the exact search (uh_knn_set_queries_per_wave)
-    int two_phase_min_nq = 6000;  // exact search, nn <= 16: accept-list scan + lane-per-query replay from this many queries on, the fused one-kernel
-                                  // form below it (the replay is a fixed ~60 us chain per wave: 8000 x 10 000 x nn 10 = 147 vs 163 us, 2000 queries = 106
-                                  // vs 77 us).  UH_KNN_FORM=twophase / fused forces one form.
+    // Exact search, nn <= 16, which kernels run (MI355X, 10 000 train rows; scripts/knn_forms.py): below 3000 queries the fused one-wave-per-query
+    // search (2000 x nn 10: 73 us, the list forms ~75-90); from 3000 queries on the accept-list forms — nn >= 6: scan and replay in ONE launch
+    // (knn_stream_kernel; 8000 x nn 10: 105 us against 126 as two launches and 154 fused), nn <= 5: two launches (the replay is short and the
+    // plain scan faster than the streaming one: 8000 x nn 2: 73 against 81 us).  UH_KNN_FORM=fused | twophase | stream forces one form.
+    int two_phase_min_nq = 3000;
+    int stream_min_nn = 6;
     unsigned replay_attr = 0;     // bit k: knn_replay_lane_kernel<k>'s dynamic-LDS attribute has been set on this index's device
     int accept_qpw = 2;           // queries per wave of the accept scan (UH_KNN_ACCEPT_QPW=1 for the A/B)
+    unsigned stream_tag = 0;      // launch tag of the streamed lists (0 = the value freshly cleared memory holds, never used)
+    unsigned stream_tag0 = 0;     // UH_KNN_TAG0: first tag of a fresh buffer (test hook for the wrap)
+    uh::DevBuf redo_buf;
+    const void* stream_buf = nullptr;   // the list buffer the tags refer to (a new allocation is cleared and starts over)
     uh::DevBuf list_buf;          // accept lists, counts and redo flags of the two-phase search
     uh::DevBuf q_buf, idx_buf, dist_buf;  // staging for the host-pointer API
     // hierarchical k-means form of the same index (uh_knn_build_kmeans)
@@ -1013,8 +1193,14 @@ int uh_knn_create(uh_ctx* ctx, uh_knn** out) {
     UH_REQUIRE(ctx && out, "uh_knn_create: NULL argument");
     uh_knn* k = new uh_knn();
     k->ctx = ctx;
-    if (const char* f = getenv("UH_KNN_FORM")) k->two_phase_min_nq = std::string(f) == "fused" ? 0x7fffffff : (std::string(f) == "twophase" ? 0 : k->two_phase_min_nq);
+    if (const char* e = getenv("UH_KNN_FORM")) {
+        const std::string f(e);
+        if (f == "fused") k->two_phase_min_nq = 0x7fffffff;
+        else if (f == "twophase") { k->two_phase_min_nq = 0; k->stream_min_nn = 0x7fffffff; }
+        else if (f == "stream") { k->two_phase_min_nq = 0; k->stream_min_nn = 0; }
+    }
     if (const char* f = getenv("UH_KNN_ACCEPT_QPW")) k->accept_qpw = atoi(f) == 1 ? 1 : 2;
+    if (const char* f = getenv("UH_KNN_TAG0")) k->stream_tag0 = (unsigned)strtoul(f, nullptr, 0);
     *out = k;
     return UH_OK;
 }
@@ -1113,7 +1299,40 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
         const double expect = nn * (1.0 + std::log(std::max((double)nrows / nn, 1.0)));
         const int cap = std::min(std::min(std::max(((int)(1.6 * expect) + 32 + 31) & ~31, 32), std::max((nrows + 31) & ~31, 32)), 256);
         int rc;
-        if ((rc = idx->list_buf.reserve((size_t)nq * cap * 8 + (size_t)nq * 8 + 256))) return rc;
+        if ((rc = idx->list_buf.reserve((size_t)nq * cap * 8 + (size_t)nq * 16 + 256))) return rc;
+        if (nn >= idx->stream_min_nn && idx->accept_qpw == 2) {
+            uint64_t* d_cand = idx->list_buf.as<uint64_t>();
+            uint64_t* d_prog = d_cand + (size_t)nq * cap;          // (list_buf holds tagged words only: any layout of an earlier launch is harmless)
+            const void* had = idx->redo_buf.p;
+            if ((rc = idx->redo_buf.reserve((size_t)(nq + 2) * 4))) return rc;
+            int* d_nredo = idx->redo_buf.as<int>();                // two counters (launch parity), then the compacted list of the queries to redo
+            int* d_redo = d_nredo + 2;
+            if (had != idx->redo_buf.p) UH_HIP_CHECK(hipMemsetAsync(d_nredo, 0, 8, idx->ctx->stream));
+            if (idx->stream_buf != idx->list_buf.p || idx->stream_tag == 0xFFFFFFFFu) {   // new memory, or the tag wraps: no stale word may match
+                UH_HIP_CHECK(hipMemsetAsync(idx->list_buf.p, 0, idx->list_buf.cap, idx->ctx->stream));
+                idx->stream_tag = idx->stream_buf == idx->list_buf.p ? 0 : idx->stream_tag0;
+                idx->stream_buf = idx->list_buf.p;
+            }
+            const unsigned tag = ++idx->stream_tag;
+            const int nrep = uh_div_up(nq, kWave);
+            const dim3 gs(nrep + uh_div_up(nq, 2));
+#define UH_KNN_STREAM(K) case K: UH_LAUNCH(idx->ctx, knn_stream_kernel<K>, gs, dim3(kWave), 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, sorted ? 1 : 0, max_dist, \
+            d_cand, d_prog, cap, tag, nrep, d_indices, d_distances, d_redo, d_nredo + (tag & 1u), d_nredo + ((tag + 1u) & 1u)); break
+            switch (nn) {
+                UH_KNN_STREAM(1); UH_KNN_STREAM(2); UH_KNN_STREAM(3); UH_KNN_STREAM(4); UH_KNN_STREAM(5); UH_KNN_STREAM(6); UH_KNN_STREAM(7); UH_KNN_STREAM(8);
+                UH_KNN_STREAM(9); UH_KNN_STREAM(10); UH_KNN_STREAM(11); UH_KNN_STREAM(12); UH_KNN_STREAM(13); UH_KNN_STREAM(14); UH_KNN_STREAM(15); UH_KNN_STREAM(16);
+                default: break;
+            }
+#undef UH_KNN_STREAM
+            const dim3 gd(64);
+            const int* nr = d_nredo + (tag & 1u);
+            if (nn <= 3) UH_LAUNCH(idx->ctx, knn_redo_kernel<1>, gd, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo, nr);
+            else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_redo_kernel<3>, gd, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo, nr);
+            else UH_LAUNCH(idx->ctx, knn_redo_kernel<6>, gd, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo, nr);
+            UH_HIP_CHECK(hipGetLastError());
+            return UH_OK;
+        }
+        idx->stream_buf = nullptr;   // (the two-launch form writes untagged words into the same buffer)
         uint64_t* d_cand = idx->list_buf.as<uint64_t>();
         int32_t* d_counts = reinterpret_cast<int32_t*>(d_cand + (size_t)nq * cap);
         int* d_redo = d_counts + nq;       // [nq] compacted list of overflowed queries, [nq] their number
