@@ -285,6 +285,7 @@ __device__ __forceinline__ double block_max_n(double v, double* s_red) {
 
 template <int NF>
 __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims d, BAPersist q) {
+    UH_BA_CLK(0);
     uh_latency_critical();
     static_assert(NF == 8, "lanes per landmark = padded number of free cameras");
     constexpr int NP = 6 * NF, T = NP / 16, NT = T * (T + 1) / 2, YS = NP + 2;
@@ -716,7 +717,9 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         }
         asm_dst[u] = t;
     }
+    UH_BA_CLK(1);
     for (int pass = 0; pass < 2; pass++) {
+        UH_BA_CLK(2 + 3 * pass);
         // ---- begin_pass (legacy ba_begin_pass_kernel / ba_gate_kernel / ba_relabel_kernel)
         if (pass == 1) {
             if (st.stopped) break;
@@ -769,6 +772,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         __syncthreads();
         if (s_flag[1]) return;
 
+        UH_BA_CLK(3 + 3 * pass);
         bool spec_lin = false;   // acc / hp / H hold the linearisation at the current estimate (left by the previous trial's speculation)
         while (st.phase != 2) {
             const double lambda = st.lambda;
@@ -927,6 +931,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         }
     }
 
+    UH_BA_CLK(8);
     // ================================================================================ results into the legacy buffers (slot 0)
     if (live && s == 0) { double* o3 = p.pts[0] + 3 * (size_t)l; o3[0] = X[0]; o3[1] = X[1]; o3[2] = X[2]; }
     if (has) p.e_chi2[eid] = chi_e;
