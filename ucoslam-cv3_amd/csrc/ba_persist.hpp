@@ -750,6 +750,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         // ---- opening evaluation: chi2 at the current estimate, lambda = tau * max |H_jj| (computeLambdaInit)
         phase1(1.0, true, false);
         if (!reduce_slices()) return;
+        lin_eval(st.cur, X, false);   // the first trial's linearisation (same estimate), inside the latency of the reduced vector's hand-off
         {   // every wave for itself: one diagonal entry of Hpp per lane, max butterfly
             // (n <= 48 < 64: one diagonal entry per lane; its three words go out as one batch, not three dependent round trips)
             double m = 0.0;
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         if (s_flag[1]) return;
 
         UH_BA_CLK(3 + 3 * pass);
-        bool spec_lin = false;   // acc / hp / H hold the linearisation at the current estimate (left by the previous trial's speculation)
+        bool spec_lin = true;   // acc / hp / H hold the linearisation at the current estimate (left by the opening, then by every trial's speculation)
         while (st.phase != 2) {
             const double lambda = st.lambda;
             const int cur = st.cur, trial = cur ^ 1;
