@@ -1680,7 +1680,7 @@ struct uh_ba {
     std::thread worker;
     std::mutex mu;
     std::condition_variable cv;
-    int job = 0;                          // 0 idle, 1 requested, 2 running, 3 done (result in job_rc), -1 quit
+    std::atomic<int> job{0};              // 0 idle, 1 requested, 2 running, 3 done (result in job_rc), -1 quit; written under `mu`, spun on without it
     int job_rc = 0;
     std::string job_err;
     const volatile uint8_t* job_stop = nullptr;
@@ -1878,6 +1878,16 @@ int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, 
 }
 
 }  // namespace
+
+// spin (with the CPU's pause hint) until `done()` or for at most `us` microseconds
+template <typename F>
+static inline void spin_until(F&& done, int us) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; !done(); ++i) {
+        __builtin_ia32_pause();
+        if ((i & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(us)) return;
+    }
+}
 
 extern "C" {
 
@@ -2258,6 +2268,11 @@ int uh_ba_optimize_async(uh_ba* b, const volatile uint8_t* stop_asap) {
         b->worker = std::thread([b]() {
             std::unique_lock<std::mutex> l(b->mu);
             for (;;) {
+                // a mapper that is handed a keyframe every half millisecond: spin briefly for the next request before sleeping on the
+                // condition variable (a futex wake-up is ~10-20 us on the hand-over in each direction, 4 % of a 0.5 ms optimisation)
+                l.unlock();
+                spin_until([b]() { const int j = b->job.load(std::memory_order_acquire); return j == 1 || j == -1; }, 300);
+                l.lock();
                 b->cv.wait(l, [b]() { return b->job == 1 || b->job == -1; });
                 if (b->job == -1) return;
                 b->job = 2;
@@ -2282,8 +2297,9 @@ int uh_ba_optimize_async(uh_ba* b, const volatile uint8_t* stop_asap) {
 
 int uh_ba_wait(uh_ba* b) {
     UH_REQUIRE(b, "uh_ba_wait: NULL");
+    UH_REQUIRE(b->job.load() != 0, "uh_ba_wait: nothing in flight");
+    spin_until([b]() { return b->job.load(std::memory_order_acquire) == 3; }, 2000);   // (an optimisation is a fraction of a millisecond: usually no sleep at all)
     std::unique_lock<std::mutex> lk(b->mu);
-    UH_REQUIRE(b->job != 0, "uh_ba_wait: nothing in flight");
     b->cv.wait(lk, [b]() { return b->job == 3; });
     const int rc = b->job_rc;
     b->job = 0;
