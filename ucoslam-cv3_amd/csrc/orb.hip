@@ -344,6 +344,11 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const Plan plan, const 
     }
 }
 
+// i / d for i < 2^16 <= 2^32 / d with the reciprocal worked out once per workgroup (m = ceil(2^32 / d); d = 1: m wraps to 0): one
+// v_mul_hi_u32 instead of the ~25-instruction division sequence, which the cell kernel ran a dozen times per thread.
+__device__ __forceinline__ unsigned div_magic(int d) { return (unsigned)(0xFFFFFFFFu / (unsigned)d) + 1u; }
+__device__ __forceinline__ int div_by(int i, int d, unsigned m) { return d == 1 ? i : (int)__umulhi((unsigned)i, m); }
+
 // ------------------------------------------------------------------------------------------------ per-cell NMS
 // One workgroup per (frame, cell).  Candidates = in-cell strict 3x3 maxima with score >= minTh, written in raster order as
 // (score<<24 | y<<12 | x) in level coordinates; n7 = their count, n20 = how many of them reach iniTh.
@@ -385,32 +390,64 @@ __global__ __launch_bounds__(256) void cell_nms_kernel(const Plan plan, const Ce
         if (npix > 0) {
             uint8_t* s_img = reinterpret_cast<uint8_t*>(s_un);
             const int pw = iw + 6, ph = ih + 6;
+            const unsigned m_pw = div_magic(pw), m_iw = div_magic(iw);
             for (int i = threadIdx.x; i < pw * ph; i += 256) {
-                const int py = i / pw, px = i - py * pw;
+                const int py = div_by(i, pw, m_pw), px = i - py * pw;
                 const int gy = min(max(C.y0 + py - 3, 0), L.h - 1), gx = min(max(C.x0 + px - 3, 0), L.w - 1);
                 s_img[i] = sc[(size_t)gy * L.pitch + gx];
             }
             __syncthreads();
-            for (int i = threadIdx.x; i < npix; i += 256) {
-                const int yy = i / iw, xx = i - yy * iw;
-                const int gx = C.x0 + xx, gy = C.y0 + yy;
-                int sv = 0;
-                if (gx >= 3 && gy >= 3 && gx < L.w - 3 && gy < L.h - 3) {   // (fast_score_kernel's rule: the level's 3-pixel rim scores 0)
-                    const uint8_t* c = s_img + (yy + 3) * pw + xx + 3;
-                    const int v = c[0];
-                    int d[25];
-                    d[0] = v - c[3 * pw + 0];   d[1] = v - c[3 * pw + 1];   d[2] = v - c[2 * pw + 2];
-                    d[3] = v - c[1 * pw + 3];   d[4] = v - c[3];            d[5] = v - c[-1 * pw + 3];
-                    d[6] = v - c[-2 * pw + 2];  d[7] = v - c[-3 * pw + 1];  d[8] = v - c[-3 * pw];
-                    d[9] = v - c[-3 * pw - 1];  d[10] = v - c[-2 * pw - 2]; d[11] = v - c[-1 * pw - 3];
-                    d[12] = v - c[-3];          d[13] = v - c[1 * pw - 3];  d[14] = v - c[2 * pw - 2];
-                    d[15] = v - c[3 * pw - 1];
+            // Only strengths >= minTh matter below (a candidate needs sv >= minTh, and a neighbour below minTh loses against it whatever
+            // its exact value), so a pixel that cannot reach minTh is stored as 0 without being scored.  strength >= minTh needs an arc of
+            // 9 contiguous circle pixels all darker than v - minTh (d > minTh) or all brighter (d < -minTh); an arc of 9 holds one pixel of
+            // every opposite pair, so "one of (k, k + 8) is darker, for k = 0, 2, 4, 6" — or the same for brighter — is necessary: eight
+            // of the sixteen reads and ~25 instructions instead of ~210.  The pixels that pass (a few per cent of an image) are queued per
+            // wave and scored 64 at a time, so the full score runs on full waves.
+            __shared__ uint16_t s_queue[4][128];
+            const int lane_ = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+            uint16_t* const queue = s_queue[wv_];
+            auto score_at = [&](int i) {
+                const int yy = div_by(i, iw, m_iw), xx = i - yy * iw;
+                const uint8_t* c = s_img + (yy + 3) * pw + xx + 3;
+                const int v = c[0];
+                int d[25];
+                d[0] = v - c[3 * pw + 0];   d[1] = v - c[3 * pw + 1];   d[2] = v - c[2 * pw + 2];
+                d[3] = v - c[1 * pw + 3];   d[4] = v - c[3];            d[5] = v - c[-1 * pw + 3];
+                d[6] = v - c[-2 * pw + 2];  d[7] = v - c[-3 * pw + 1];  d[8] = v - c[-3 * pw];
+                d[9] = v - c[-3 * pw - 1];  d[10] = v - c[-2 * pw - 2]; d[11] = v - c[-1 * pw - 3];
+                d[12] = v - c[-3];          d[13] = v - c[1 * pw - 3];  d[14] = v - c[2 * pw - 2];
+                d[15] = v - c[3 * pw - 1];
 #pragma unroll
-                    for (int k = 16; k < 25; k++) d[k] = d[k - 16];
-                    sv = max(fast_strength(d), 0);
+                for (int k = 16; k < 25; k++) d[k] = d[k - 16];
+                s_tile[i] = (uint8_t)max(fast_strength(d), 0);
+            };
+            int qn = 0;   // wave-uniform
+            for (int i0 = wv_ * 64; i0 < npix; i0 += 256) {
+                const int i = i0 + lane_;
+                bool pass = false;
+                if (i < npix) {
+                    const int yy = div_by(i, iw, m_iw), xx = i - yy * iw;
+                    const int gx = C.x0 + xx, gy = C.y0 + yy;
+                    if (gx >= 3 && gy >= 3 && gx < L.w - 3 && gy < L.h - 3) {   // (fast_score_kernel's rule: the level's 3-pixel rim scores 0)
+                        const uint8_t* c = s_img + (yy + 3) * pw + xx + 3;
+                        const int v = c[0];
+                        const int d0 = v - c[3 * pw], d8 = v - c[-3 * pw], d4 = v - c[3], d12 = v - c[-3];
+                        const int d2 = v - c[2 * pw + 2], d10 = v - c[-2 * pw - 2], d6 = v - c[-2 * pw + 2], d14 = v - c[2 * pw - 2];
+                        const int dark = min(min(max(d0, d8), max(d4, d12)), min(max(d2, d10), max(d6, d14)));
+                        const int bright = max(max(min(d0, d8), min(d4, d12)), max(min(d2, d10), min(d6, d14)));
+                        pass = dark > minTh || bright < -minTh;
+                    }
+                    s_tile[i] = 0;
                 }
-                s_tile[i] = (uint8_t)sv;
+                const unsigned long long m = __ballot(pass);
+                if (pass) queue[qn + __popcll(m & ((1ull << lane_) - 1ull))] = (uint16_t)i;
+                qn += __popcll(m);
+                if (qn >= 64) {
+                    qn -= 64;
+                    score_at(queue[qn + lane_]);
+                }
             }
+            if (lane_ < qn) score_at(queue[lane_]);
         }
     } else {
         if (staged)
@@ -423,6 +460,7 @@ __global__ __launch_bounds__(256) void cell_nms_kernel(const Plan plan, const Ce
         // list with no workgroup barrier inside the loop, then the four lists are concatenated in wave (= raster) order.
         uint32_t* const s_list = s_un;
         __shared__ int s_cnt[4], s_c20[4];
+        const unsigned m_iw2 = div_magic(iw);
         const int chunk = ((npix + 3) / 4 + 63) & ~63;            // pixels per wave, multiple of 64
         uint32_t* mylist = s_list + wv * (chunk / 2 + 64);        // NMS packing bound: <= every other pixel of a range
         const int pbeg = wv * chunk, pend = min(pbeg + chunk, npix);
@@ -431,7 +469,7 @@ __global__ __launch_bounds__(256) void cell_nms_kernel(const Plan plan, const Ce
             const int pp = p0 + lane;
             const bool live = pp < pend;
             const int pc = live ? pp : pbeg;
-            const int yy = pc / iw, xx = pc - yy * iw;
+            const int yy = div_by(pc, iw, m_iw2), xx = pc - yy * iw;
             const int sv = s_tile[pc];
             int nmax = 0;
 #pragma unroll
