@@ -396,6 +396,9 @@ __global__ __launch_bounds__(256) void cell_nms_kernel(const Plan plan, const Ce
                 const int gy = min(max(C.y0 + py - 3, 0), L.h - 1), gx = min(max(C.x0 + px - 3, 0), L.w - 1);
                 s_img[i] = sc[(size_t)gy * L.pitch + gx];
             }
+            // the strength tile carries a one-pixel frame of zeros (stride iw + 2): the 3x3 maximum below reads its eight neighbours
+            // without a bounds test; everything starts as 0 and only the pixels that are scored are written
+            for (int i = threadIdx.x; i < ((iw + 2) * (ih + 2) + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(s_tile)[i] = 0u;
             __syncthreads();
             // Only strengths >= minTh matter below (a candidate needs sv >= minTh, and a neighbour below minTh loses against it whatever
             // its exact value), so a pixel that cannot reach minTh is stored as 0 without being scored.  strength >= minTh needs an arc of
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(256) void cell_nms_kernel(const Plan plan, const Ce
                 d[15] = v - c[3 * pw - 1];
 #pragma unroll
                 for (int k = 16; k < 25; k++) d[k] = d[k - 16];
-                s_tile[i] = (uint8_t)max(fast_strength(d), 0);
+                s_tile[(yy + 1) * (iw + 2) + xx + 1] = (uint8_t)max(fast_strength(d), 0);
             };
             int qn = 0;   // wave-uniform
             for (int i0 = wv_ * 64; i0 < npix; i0 += 256) {
@@ -437,7 +440,6 @@ __global__ __launch_bounds__(256) void cell_nms_kernel(const Plan plan, const Ce
                         const int bright = max(max(min(d0, d8), min(d4, d12)), max(min(d2, d10), min(d6, d14)));
                         pass = dark > minTh || bright < -minTh;
                     }
-                    s_tile[i] = 0;
                 }
                 const unsigned long long m = __ballot(pass);
                 if (pass) queue[qn + __popcll(m & ((1ull << lane_) - 1ull))] = (uint16_t)i;
@@ -470,17 +472,24 @@ __global__ __launch_bounds__(256) void cell_nms_kernel(const Plan plan, const Ce
             const bool live = pp < pend;
             const int pc = live ? pp : pbeg;
             const int yy = div_by(pc, iw, m_iw2), xx = pc - yy * iw;
-            const int sv = s_tile[pc];
-            int nmax = 0;
+            int sv, nmax = 0;
+            if constexpr (FUSED) {   // zero-framed tile
+                const int tw = iw + 2;
+                const uint8_t* c = s_tile + (yy + 1) * tw + xx + 1;
+                sv = c[0];
+                nmax = max(max(max((int)c[-tw - 1], (int)c[-tw]), max((int)c[-tw + 1], (int)c[-1])), max(max((int)c[1], (int)c[tw - 1]), max((int)c[tw], (int)c[tw + 1])));
+            } else {
+                sv = s_tile[pc];
 #pragma unroll
-            for (int dy = -1; dy <= 1; dy++)
+                for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
-                for (int dx = -1; dx <= 1; dx++) {
-                    if (dx == 0 && dy == 0) continue;
-                    const bool in = xx + dx >= 0 && xx + dx < iw && yy + dy >= 0 && yy + dy < ih;
-                    const int nv = s_tile[in ? pc + dy * iw + dx : pc];
-                    nmax = max(nmax, in ? nv : 0);
-                }
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if (dx == 0 && dy == 0) continue;
+                        const bool in = xx + dx >= 0 && xx + dx < iw && yy + dy >= 0 && yy + dy < ih;
+                        const int nv = s_tile[in ? pc + dy * iw + dx : pc];
+                        nmax = max(nmax, in ? nv : 0);
+                    }
+            }
             const bool keep = live && sv >= minTh && sv > nmax;
             const unsigned long long m = __ballot(keep);
             if (keep) mylist[k + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)sv << 24) | ((uint32_t)(C.y0 + yy) << 12) | (uint32_t)(C.x0 + xx);
@@ -1140,20 +1149,21 @@ int make_plan(uh_orb* o, int w, int h, int batch) {
         for (const CellDesc& C : o->cells) {
             const int iw = C.x1 - C.x0, ih = C.y1 - C.y0;
             if (C.skipped || iw <= 0 || ih <= 0) continue;
-            fits = fits && iw * ih <= kNmsTileBytes && (iw + 6) * (ih + 6) <= kNmsPatchBytes;
+            fits = fits && (iw + 2) * (ih + 2) <= kNmsTileBytes && (iw + 6) * (ih + 6) <= kNmsPatchBytes;
         }
         const char* e = getenv("UH_ORB_FAST");
         o->fuse_fast = fits && !(e && std::string(e) == "map");
-        int most_px = 1, most_patch = 1;
+        int most_px = 1, most_patch = 1, most_tile = 16;
         for (const CellDesc& C : o->cells) {
             const int iw = C.x1 - C.x0, ih = C.y1 - C.y0;
             if (C.skipped || iw <= 0 || ih <= 0) continue;
             most_px = std::max(most_px, iw * ih);
             most_patch = std::max(most_patch, (iw + 6) * (ih + 6));
+            most_tile = std::max(most_tile, (iw + 2) * (ih + 2));   // (the tile's frame of zeros)
         }
         // candidate lists of the four waves: each <= half of its quarter of the raster (rounded up to 64) + 64
         const int list_bytes = 4 * ((((most_px + 3) / 4 + 63) & ~63) / 2 + 64) * 4;
-        o->nms_tile_bytes = (most_px + 15) & ~15;
+        o->nms_tile_bytes = (most_tile + 15) & ~15;
         o->nms_lds_bytes = o->nms_tile_bytes + ((std::max(most_patch, list_bytes) + 15) & ~15);
     }
     // selection workgroups per level: one per 16 cells (a cell per wave) while the launch stays within one workgroup per CU; large
