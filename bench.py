@@ -61,7 +61,7 @@ def survey_8d_bytes(n_kpts, ba_E, ba_P=BA_P, ba_K=BA_K):
 
 ORB_KERNELS = ("blur7_kernel", "copy_kernel", "resize_cubic_kernel", "fast_score_kernel", "cell_nms_kernel", "select_kernel", "describe_kernel",
                "nonmax_kernel")
-MATCH_KERNELS = ("knn_search_kernel", "knn_search_mq_kernel", "knn_accept_kernel", "knn_replay_lane_kernel", "knn_redo_kernel")
+MATCH_KERNELS = ("knn_search_kernel", "knn_search_mq_kernel", "knn_accept_kernel", "knn_replay_lane_kernel", "knn_stream_kernel", "knn_redo_kernel")
 
 
 def persistent_ba_exchange_bytes(ba_P, trials):
