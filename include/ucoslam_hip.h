@@ -249,7 +249,10 @@ int  uh_ba_optimize(uh_ba* ba, const volatile uint8_t* stop_asap);
 /* pinned device-visible force-stop byte owned by the optimiser (write 1 from any thread to stop between trials) */
 /* asynchronous form: runs uh_ba_optimize on a worker thread owned by the object — the reference runs GlobalOptimizer::optimize
  * on its mapper thread beside the tracker (mapmanager.cpp:150) — and uh_ba_wait returns its result (UH_OK or the error).
- * One optimisation in flight per object; set_problem / get_results only between wait and the next optimize. */
+ * One optimisation in flight per object; set_problem / get_results only between wait and the next optimize.
+ * Both sides of the hand-over spin before they sleep (the worker for the next request: <= 0.3 ms; uh_ba_wait for the result: <= 2 ms),
+ * because an optimisation is half a millisecond and a futex wake-up is 10-20 us of it: a caller that wants its core back while a
+ * long (global) optimisation runs should do other work before calling uh_ba_wait, not rely on uh_ba_wait to block at once. */
 int  uh_ba_optimize_async(uh_ba* ba, const volatile uint8_t* stop_asap);
 int  uh_ba_wait(uh_ba* ba);
 uint8_t* uh_ba_stop_flag(uh_ba* ba);

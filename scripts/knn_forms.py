@@ -1,3 +1,5 @@
+"""HIP-event timing of the exact kNN forms (UH_KNN_FORM=fused|twophase|stream, or the default policy) over k and the query count,
+10 000 train rows; the table behind the form policy in csrc/knn.hip (uh_knn::two_phase_min_nq / stream_min_nn)."""
 import sys, os
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import torch, numpy as np, synth
