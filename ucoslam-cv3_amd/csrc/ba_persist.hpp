@@ -286,6 +286,8 @@ __device__ __forceinline__ double block_max_n(double v, double* s_red) {
 template <int NF>
 __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims d, BAPersist q) {
     UH_BA_CLK(0);
+    // one wave per SIMD, every instruction on the critical path: when the tracking stream's waves share the SIMD, this wave issues first
+    __builtin_amdgcn_s_setprio(3);
     uh_latency_critical();
     static_assert(NF == 8, "lanes per landmark = padded number of free cameras");
     constexpr int NP = 6 * NF, T = NP / 16, NT = T * (T + 1) / 2, YS = NP + 2;
