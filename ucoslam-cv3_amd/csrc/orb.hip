@@ -994,6 +994,7 @@ struct uh_orb {
     uh::DevBuf d_tickets;   // select_kernel: workgroups of a (frame, level) that have finished their cells
     bool pair_ok[kMaxLevels] = {};  // levels l and l+1 can be built by one resize_pair_kernel launch (the footprints fit its staging area)
     bool pair_fusion = true;       // UH_ORB_PYRAMID=chain: one launch per level
+    int pair_from = 4;             // three to six frames: levels >= pair_from are built two per launch (UH_ORB_PAIR_FROM for the A/B)
     bool fuse_fast = false;        // every cell fits cell_nms_kernel<true>'s staging buffers: no strength map, no fast_score launch
     int nms_tile_bytes = 0, nms_lds_bytes = 0;   // cell_nms_kernel<true>'s dynamic LDS: strength tile | patch / candidate lists
     bool score_valid = false;      // d_score holds the last extraction's strength maps (uh_orb_debug_level computes them on demand)
@@ -1122,6 +1123,7 @@ int make_plan(uh_orb* o, int w, int h, int batch) {
     {   // resize_pair_kernel: do the rectangles a tile of level l+1 needs (of level l, and of level l-1 behind it) fit the staging area?
         const char* e = getenv("UH_ORB_PYRAMID");
         o->pair_fusion = !(e && std::string(e) == "chain");
+        if (const char* pf = getenv("UH_ORB_PAIR_FROM")) o->pair_from = std::max(1, atoi(pf));
         auto clampi = [](int v, int lo, int hi) { return std::min(std::max(v, lo), hi); };
         for (int l = 0; l < kMaxLevels; l++) o->pair_ok[l] = false;
         for (int l = 1; l + 1 < nl; l++) {
@@ -1251,7 +1253,9 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
     for (int l = 1; l < P.lvl_end; l++) {
         const LevelDesc& S = P.lv[l - 1];
         const LevelDesc& D = P.lv[l];
-        if (o->pair_fusion && batch <= 2 && l + 1 < P.lvl_end && o->pair_ok[l]) {   // two levels per launch (one or two frames: pure launch latency)
+        // two levels per launch: for one or two frames everywhere (pure launch latency); up to 16 frames six only above level 3, where the
+        // rebuilt rectangles are a few dozen tiles and a saved launch (~9.5 us) is worth more than their recomputation
+        if (o->pair_fusion && (batch <= 2 || (batch <= 6 && l >= o->pair_from)) && l + 1 < P.lvl_end && o->pair_ok[l]) {
             const LevelDesc& E = P.lv[l + 1];
             const LevelTaps ta{o->d_xofs.as<int>() + D.xtap_off, o->d_xcoef.as<short>() + (size_t)D.xtap_off * 4,
                                o->d_yofs.as<int>() + D.ytap_off, o->d_ycoef.as<short>() + (size_t)D.ytap_off * 4};
