@@ -171,6 +171,11 @@ __global__ void copy_kernel(const uint8_t* __restrict__ src, int w, int h, size_
         src[(size_t)blockIdx.z * src_frame_stride + (size_t)y * src_stride + x];
 }
 
+// i / d for i < 2^16 <= 2^32 / d with the reciprocal worked out once per workgroup (m = ceil(2^32 / d); d = 1: m wraps to 0): one
+// v_mul_hi_u32 instead of the ~25-instruction division sequence, which the cell kernel ran a dozen times per thread.
+__device__ __forceinline__ unsigned div_magic(int d) { return (unsigned)(0xFFFFFFFFu / (unsigned)d) + 1u; }
+__device__ __forceinline__ int div_by(int i, int d, unsigned m) { return d == 1 ? i : (int)__umulhi((unsigned)i, m); }
+
 // ------------------------------------------------------------------------------------------------ pyramid
 // cv::resize(INTER_CUBIC) 8UC1 reference path: int32 horizontal pass with 11-bit taps, int32 vertical pass,
 // (v + 2^21) >> 22, saturate.  Taps clamp at the source ROI edge.  ofs = floor(src coord), 4 shorts per output index.
@@ -300,21 +305,27 @@ __global__ __launch_bounds__(256) void resize_pair_kernel(const uint8_t* __restr
     const int sy0 = min(max(ta.yofs[ay0] - 1, 0), S0.h - 1), sy1 = min(max(ta.yofs[ay1] + 2, 0), S0.h - 1);
     const int sw0 = sx1 - sx0 + 1, sh0 = sy1 - sy0 + 1;
     const uint8_t* S = F + S0.img_off;
-    for (int i = threadIdx.x; i < sw0 * sh0; i += 256) { const int r = i / sw0, c = i - r * sw0; L.src[r][c] = S[(size_t)(sy0 + r) * S0.pitch + sx0 + c]; }
+    (void)sw0;
+    const int sx0a = sx0 & ~3, ndw = ((sx1 - sx0a) >> 2) + 1;   // (dword staging from a 4-aligned column, as in resize_cubic_tile)
+    const unsigned m_ndw = div_magic(ndw), m_aw = div_magic(aw);
+    for (int i = threadIdx.x; i < sh0 * ndw; i += 256) {
+        const int r = div_by(i, ndw, m_ndw), c4 = i - r * ndw;
+        reinterpret_cast<uint32_t*>(&L.src[r][0])[c4] = *reinterpret_cast<const u32_unaligned*>(S + (size_t)(sy0 + r) * S0.pitch + sx0a + 4 * c4);
+    }
     __syncthreads();
     // level a, horizontal: column ax0 + c of every staged source row
     for (int i = threadIdx.x; i < aw * sh0; i += 256) {
-        const int r = i / aw, c = i - r * aw, gx = ax0 + c;
+        const int r = div_by(i, aw, m_aw), c = i - r * aw, gx = ax0 + c;
         const int xo = ta.xofs[gx];
         int acc = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) acc += L.src[r][min(max(xo - 1 + k, 0), S0.w - 1) - sx0] * ta.xcoef[gx * 4 + k];
+        for (int k = 0; k < 4; k++) acc += L.src[r][min(max(xo - 1 + k, 0), S0.w - 1) - sx0a] * ta.xcoef[gx * 4 + k];
         L.h[r][c] = acc;
     }
     __syncthreads();
     // level a, vertical -> the rectangle's bytes
     for (int i = threadIdx.x; i < aw * ah; i += 256) {
-        const int r = i / aw, c = i - r * aw, gy = ay0 + r;
+        const int r = div_by(i, aw, m_aw), c = i - r * aw, gy = ay0 + r;
         const int yo = ta.yofs[gy];
         int acc = 0;
 #pragma unroll
@@ -333,17 +344,27 @@ __global__ __launch_bounds__(256) void resize_pair_kernel(const uint8_t* __restr
             L.h[r][lx] = L.mid[r][sx[0]] * c[0] + L.mid[r][sx[1]] * c[1] + L.mid[r][sx[2]] * c[2] + L.mid[r][sx[3]] * c[3];
     }
     __syncthreads();
-    if (gx < LB.w) {
-        uint8_t* D = Fw + LB.img_off;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int gy = ty0 + ly + 4 * j;
-            if (gy >= LB.h) continue;
+    {   // vertical: four neighbouring pixels of one row per thread, one dword store
+        const int ry = threadIdx.x >> 4, cg = threadIdx.x & 15;
+        const int gy = ty0 + ry, gx0 = tx0 + 4 * cg;
+        if (gy < LB.h && gx0 < LB.w) {
             const int yo = tb.yofs[gy];
-            int acc = 0;
+            int acc[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int k = 0; k < 4; k++) acc += L.h[min(max(yo - 1 + k, 0), LA.h - 1) - ay0][lx] * tb.ycoef[gy * 4 + k];
-            D[(size_t)gy * LB.pitch + gx] = (uint8_t)min(max((acc + (1 << 21)) >> 22, 0), 255);
+            for (int k = 0; k < 4; k++) {
+                const int4 hv = *reinterpret_cast<const int4*>(&L.h[min(max(yo - 1 + k, 0), LA.h - 1) - ay0][4 * cg]);
+                const int cy = tb.ycoef[gy * 4 + k];
+                acc[0] += hv.x * cy; acc[1] += hv.y * cy; acc[2] += hv.z * cy; acc[3] += hv.w * cy;
+            }
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = (uint32_t)min(max((acc[j] + (1 << 21)) >> 22, 0), 255);
+            uint8_t* op = Fw + LB.img_off + (size_t)gy * LB.pitch + gx0;
+            if (gx0 + 3 < LB.w) *reinterpret_cast<u32_unaligned*>(op) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (gx0 + j < LB.w) op[j] = (uint8_t)o[j];
+            }
         }
     }
 }
@@ -406,11 +427,6 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const Plan plan, const 
         out[(size_t)gy * L.pitch + gx] = (uint8_t)s;
     }
 }
-
-// i / d for i < 2^16 <= 2^32 / d with the reciprocal worked out once per workgroup (m = ceil(2^32 / d); d = 1: m wraps to 0): one
-// v_mul_hi_u32 instead of the ~25-instruction division sequence, which the cell kernel ran a dozen times per thread.
-__device__ __forceinline__ unsigned div_magic(int d) { return (unsigned)(0xFFFFFFFFu / (unsigned)d) + 1u; }
-__device__ __forceinline__ int div_by(int i, int d, unsigned m) { return d == 1 ? i : (int)__umulhi((unsigned)i, m); }
 
 // ------------------------------------------------------------------------------------------------ per-cell NMS
 // One workgroup per (frame, cell).  Candidates = in-cell strict 3x3 maxima with score >= minTh, written in raster order as
