@@ -262,6 +262,54 @@ uint8_t* uh_ba_stop_flag(uh_ba* ba);
 int  uh_ba_get_results(uh_ba* ba, float* poses_out, float* points_out, double* chi2_out, uint8_t* bad_out, int32_t* iters_out);
 int  uh_ba_get_pose_state(uh_ba* ba, double* pose7_out);   /* n_frames x (qx qy qz qw tx ty tz), fp64 */
 
+/* ---- the same three phases without a host copy on either side (what the C++ adaptor's flatten_for_ba / getResults use).
+ * A local BA is a NEW problem per keyframe (mapmanager.cpp:11388-11405 setParams + optimize on the mapper thread, :1267-1305
+ * getResults on the tracker thread), so setParams and getResults are on the clock as much as optimize:
+ *   uh_ba_map_staging   the optimiser owns ONE pinned, device-visible staging block; the caller writes the flattened problem straight
+ *                       into it (observations as 24-byte records) — capacities are rounded up and kept across problems
+ *   uh_ba_set_problem_staged   = setParams on what the staging block holds: one H2D copy + one kernel that scatters the observation
+ *                       indices into a (point x frame) table in HBM; nothing is built on the host, nothing is synchronised.
+ *                       An observation whose point / frame index is out of range is refused here; a (point, frame) pair that
+ *                       occurs twice is detected by that kernel and reported by the following uh_ba_optimize (UH_EINVAL).
+ *   uh_ba_results_view  = getResults in place: pointers into the pinned result block the optimisation kernel wrote (valid until the
+ *                       next set_problem on this object); uh_ba_get_results copies from the same block.
+ * uh_ba_set_problem (arrays anywhere in host memory) converts into the staging block and takes the same path. */
+typedef struct uh_ba_obs {          /* one monocular EdgeSE3ProjectXYZ (globaloptimizer_g2o.cpp:224-249) */
+    int32_t point, frame;           /* indices into points / frames of this problem */
+    float   u, v;                   /* undistorted keypoint */
+    double  inv_sigma;              /* (double)_InvScaleFactors[octave] */
+} uh_ba_obs;                        /* 24 bytes */
+
+typedef struct uh_ba_staging {
+    float*     poses_f2g;           /* cap_frames x 16 */
+    uint8_t*   fixed;               /* cap_frames */
+    float*     intr;                /* cap_frames x 4 */
+    float*     points;              /* cap_points x 3 */
+    uh_ba_obs* obs;                 /* cap_obs */
+    int32_t    cap_frames, cap_points, cap_obs;
+} uh_ba_staging;
+
+typedef struct uh_ba_results_view {
+    const float*   poses;           /* n_frames x 16 (fixed frames unchanged) */
+    const float*   points;          /* n_points x 3 */
+    const double*  chi2;            /* n_obs */
+    const uint8_t* bad;             /* n_obs */
+    const double*  pose_state;      /* n_frames x 7 (qx qy qz qw tx ty tz) */
+    int32_t        iters[2];
+    int32_t        n_frames, n_points, n_obs;
+} uh_ba_results_view;
+
+int  uh_ba_map_staging(uh_ba* ba, int n_frames, int n_points, int max_obs, uh_ba_staging* out);
+int  uh_ba_set_problem_staged(uh_ba* ba, int n_frames, int n_points, int n_obs, const uh_ba_params* params);
+int  uh_ba_results_view_get(uh_ba* ba, uh_ba_results_view* out);
+/* setParams + optimize on the object's worker thread (the reference's mapper thread does exactly these two calls back to back);
+ * problem == NULL: the staging block (n_frames / n_points / n_obs as given).  The caller's arrays must stay valid until uh_ba_wait. */
+int  uh_ba_solve_async(uh_ba* ba, const uh_ba_problem* problem, int n_frames, int n_points, int n_obs, const uh_ba_params* params,
+                       const volatile uint8_t* stop_asap);
+/* which form the current problem runs in: 0 launch chain (9+ free keyframes that do not fit the persistent form), 1 persistent
+ * one-launch kernel, 2 wide (global BA); *lanes_per_landmark_out (may be NULL) = the persistent form's padded number of free cameras */
+int  uh_ba_form(uh_ba* ba, int* lanes_per_landmark_out);
+
 /* ------------------------------------------------------------------------
  * Bag of words — replaces fbow::Vocabulary::transform / fBow::score:
  *   3rdparty/fbow/fbow/fbow.h:54-116 (class surface), fbow.cpp:51-90 (transform with level), :92-143 (normalised

@@ -301,3 +301,127 @@ def test_hip_ba_persistent_is_exact_under_uneven_background_load(hip_ctx):
     finally:
         stop.append(1)
         th.join()
+
+
+# ------------------------------------------------------------------------------------------------ the plugin protocol per keyframe
+def _sig(r):
+    return r["state"].tobytes() + r["iters"].tobytes() + r["bad"].tobytes() + r["chi2"].tobytes() + r["poses"].tobytes() + r["points"].tobytes()
+
+
+@pytest.mark.gpu
+def test_hip_ba_fresh_problem_per_keyframe(hip_ctx, oracle):
+    """A local BA is a NEW problem per keyframe (mapmanager.cpp:11388-11405 setParams + optimize, :1267-1305 getResults): ONE optimizer
+    object takes a stream of different windows — sizes growing and shrinking, persistent form and launch chain alternating, staging
+    blocks regrown, the (point x frame) table reused without clearing — and every result equals a fresh object's result on the
+    same problem bit for bit, and the oracle within the stated tolerance."""
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    stream = [(10, 3000, 0, 2), (6, 400, 1, 1), (12, 1500, 3, 3), (10, 3000, 5, 2), (4, 150, 2, 2), (10, 3400, 7, 2), (9, 900, 8, 1), (5, 33, 5, 2),
+              (10, 3000, 0, 2)]
+    opt = GlobalOptimizer.create(hip_ctx)
+    forms = []
+    for K, P, seed, nfix in stream:
+        pr = synth.ba_problem(K, P, seed, nfixed=nfix)
+        opt.setParams(pr, ParamSet(nIters=5))
+        forms.append(opt.form())
+        opt.optimize()
+        got = opt.getResults()
+        fresh = GlobalOptimizer.create(hip_ctx)
+        fresh.setParams(pr, ParamSet(nIters=5))
+        fresh.optimize()
+        assert _sig(fresh.getResults()) == _sig(got), f"problem {(K, P, seed, nfix)} in the stream differs from a fresh optimizer"
+        ref = oracle_lib.ba_optimize(oracle, pr, 5)
+        assert got["iters"].tolist() == ref["iters"].tolist()
+        assert np.abs(got["state"] - ref["state"]).max() < POSE_TOL
+        _assert_bad_flags_equal_up_to_the_boundary(got, ref)
+    assert any(f.startswith("persist") for f in forms) and "chain" in forms
+
+
+@pytest.mark.gpu
+def test_hip_ba_staged_protocol_equals_array_protocol(hip_ctx):
+    """uh_ba_map_staging / uh_ba_set_problem_staged / uh_ba_results_view_get (no host copy on either side) against
+    uh_ba_set_problem / uh_ba_get_results on the same problems, incl. a window the persistent form does not take (staged -> tables)."""
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    a, b = GlobalOptimizer.create(hip_ctx), GlobalOptimizer.create(hip_ctx)
+    for K, P, seed, nfix in [(10, 3000, 0, 2), (7, 500, 3, 1), (10, 3000, 4, 2), (13, 800, 5, 2)]:
+        pr = synth.ba_problem(K, P, seed, nfixed=nfix)
+        a.setParams(pr, ParamSet(nIters=5)); a.optimize()
+        want = a.getResults()
+        dims = b.fillStaging(pr)
+        b.setParamsStaged(*dims, ParamSet(nIters=5)); b.optimize()
+        got = b.getResults()
+        assert _sig(got) == _sig(want)
+        if b.form().startswith("persist"):
+            v = b.resultsView()
+            for k in ("poses", "points", "chi2", "bad", "state", "iters"):
+                np.testing.assert_array_equal(v[k], want[k])
+
+
+@pytest.mark.gpu
+def test_hip_ba_duplicate_and_out_of_range_observations(hip_ctx):
+    """A (point, frame) pair that occurs twice is found by the ingest kernel and reported by optimize(); an index out of range is
+    refused by setParams itself (both entry points); the object stays usable."""
+    import ucoslam_cv3_amd as u
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    pr = synth.ba_problem(6, 300, 2)
+    opt = GlobalOptimizer.create(hip_ctx)
+    dup = dict(pr)
+    for k in ("obs_pt", "obs_kf", "obs_uv", "obs_w"):
+        dup[k] = np.concatenate([pr[k], pr[k][17:18]])
+    dup["E"] = pr["E"] + 1
+    opt.setParams(dup, ParamSet(nIters=5))
+    with pytest.raises(u.UcoslamHipError, match="observed twice"):
+        opt.optimize()
+    bad = dict(pr)
+    bad["obs_pt"] = pr["obs_pt"].copy(); bad["obs_pt"][5] = pr["P"]
+    with pytest.raises(u.UcoslamHipError, match="out of range"):
+        opt.setParams(bad)
+    dims = opt.fillStaging(bad)
+    with pytest.raises(u.UcoslamHipError, match="out of range"):
+        opt.setParamsStaged(*dims)
+    opt.setParams(pr, ParamSet(nIters=5)); opt.optimize()
+    fresh = GlobalOptimizer.create(hip_ctx)
+    fresh.setParams(pr, ParamSet(nIters=5)); fresh.optimize()
+    assert _sig(opt.getResults()) == _sig(fresh.getResults())
+
+
+@pytest.mark.gpu
+def test_hip_ba_solve_async_runs_setparams_and_optimize_on_the_worker(hip_ctx):
+    """uh_ba_solve_async: the mapper thread's two calls (setParams + optimize) on the object's worker; getResults on the caller's thread."""
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    opt, ref = GlobalOptimizer.create(hip_ctx), GlobalOptimizer.create(hip_ctx)
+    ps = ParamSet(nIters=5)
+    for seed in range(4):
+        pr = synth.ba_problem(10, 1200 + 200 * seed, seed)
+        ref.setParams(pr, ps); ref.optimize()
+        want = _sig(ref.getResults())
+        opt.solve_async(pr, ps)
+        opt.wait()
+        assert _sig(opt.getResults()) == want
+        dims = opt.fillStaging(pr)
+        opt.solve_async(None, ps, dims=dims)
+        opt.wait()
+        assert _sig(opt.getResults()) == want
+
+
+@pytest.mark.gpu
+def test_hip_ba_table_sequence_wrap(hip_ctx):
+    """The (point x frame) table is never cleared between problems: its cells carry 12 bits of problem sequence.  4100 setParams on one
+    object cross the wrap (the table is zeroed there); a problem whose cells were written 4095 problems earlier must not be seen."""
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    small = synth.ba_problem(5, 40, 1)
+    big = synth.ba_problem(8, 300, 2)
+    opt, fresh = GlobalOptimizer.create(hip_ctx), GlobalOptimizer.create(hip_ctx)
+    fresh.setParams(big, ParamSet(nIters=5)); fresh.optimize()
+    want = _sig(fresh.getResults())
+    opt.setParams(big, ParamSet(nIters=5))
+    for i in range(4100):
+        opt.setParams(small, ParamSet(nIters=2))
+        if i % 1024 == 1023:
+            opt.optimize()
+    opt.setParams(big, ParamSet(nIters=5)); opt.optimize()
+    assert _sig(opt.getResults()) == want

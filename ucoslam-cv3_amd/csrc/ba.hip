@@ -1648,9 +1648,40 @@ __global__ void ba_init_state_kernel(BAPtrs p, BADims d, const double* __restric
     if (i == 0) { BAState z; memset(&z, 0, sizeof(z)); z.phase = 2; z.lambda = -1; z.ni = 2; p.st[0] = z; p.st[1] = z; }
 }
 
+// setParams on the device (the staged form of uh_ba_set_problem): every observation drops (problem sequence | its index + 1) into the
+// (point x frame) table the persistent kernel's lanes look their observation up in.  Cells of older problems carry older sequence
+// numbers and read as empty, so the table is never cleared between problems (only when it is reallocated or the 12 bits wrap).
+// A (point, frame) pair that occurs twice (g2o would add two edges; this solver owns one lane per pair) and an index out of range
+// are reported through a pinned word the host reads after the optimisation: err[0] = 1 out of range / 2 duplicate, err[1] = observation.
+__global__ __launch_bounds__(256) void ba_ingest_kernel(const uh_ba_obs* __restrict__ obs, int E, int P, int K, unsigned* __restrict__ T, unsigned tseq,
+                                                        unsigned* err) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int pt = obs[e].point, kf = obs[e].frame;
+    unsigned code = 0;
+    if ((unsigned)pt >= (unsigned)P || (unsigned)kf >= (unsigned)K) code = 1;
+    else {
+        const unsigned old = atomicExch(T + (size_t)pt * K + kf, tseq | (unsigned)(e + 1));
+        if ((old & 0xFFF00000u) == tseq) code = 2;
+    }
+    if (code) {
+        __hip_atomic_store(err + 1, (unsigned)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 #include "ba_persist.hpp"
 
 }  // namespace
+
+// Staging block of the staged setParams (pinned host memory and its mirror in HBM): byte offsets, fixed by the capacities
+struct StageLayout {
+    size_t pose0, poseR0, intr, slot, free_kf, fix_kf;   // derived on the host per problem (K-sized)
+    size_t poses_in, fixed, intr_f;                      // the caller's frame arrays
+    size_t points, obs;                                  // P x 3 float, then E x uh_ba_obs: the copy ends behind the last observation
+};
+// Result block (pinned host memory the kernel's tail writes): byte offsets
+struct ResLayout { size_t poses, state, points, chi2, bad, bytes; };
 
 struct uh_ba {
     uh_ctx* ctx = nullptr;
@@ -1669,8 +1700,31 @@ struct uh_ba {
     bool wide = false;                    // more than kMaxFree free keyframes: sparse pair lists + blocked dense LDL^T in HBM
     bool persist = false;                 // 1..8 free keyframes: the whole optimisation is ONE persistent launch (ba_persist.hpp)
     BAPersist pq{};
-    uh::DevBuf parena;                    // the persistent form's packed observations and exchange buffers
-    size_t p_xoff = 0, p_xbytes = 0;      // the exchange region inside parena
+    uh::DevBuf parena;                    // the persistent form's exchange buffers (tagged words only; [0, 64): the error word)
+    unsigned parena_gen = ~0u;            // the allocation the exchange tags refer to (a new one is zeroed)
+    // ---- staged setParams / in-place getResults (the persistent form's whole host side)
+    unsigned char* h_stage = nullptr;     // pinned, device-visible: derived header | caller's frame arrays | points | observations
+    size_t h_stage_bytes = 0;
+    int cap_K = 0, cap_P = 0, cap_E = 0;
+    StageLayout slay{};
+    uh::DevBuf dstage;                    // its mirror in HBM (same layout), filled by ONE H2D copy per problem
+    hipEvent_t ev_stage = nullptr;        // recorded behind that copy: the staging block may be rewritten once it has completed
+    bool stage_in_flight = false;
+    uh::DevBuf dT;                        // (point x frame) -> problem sequence << 20 | observation index + 1
+    unsigned dT_gen = ~0u, tseq = 0;
+    uh::DevBuf dscratch;                  // BAState[2], 64 phase clocks, completion counter
+    unsigned done_base = 0;               // what the completion counter holds before the next launch
+    unsigned char* h_res = nullptr;       // pinned, device-visible result block: the kernel's tail writes getResults' outputs here
+    size_t h_res_bytes = 0;
+    ResLayout rlay{};
+    bool fast = false;                    // the current problem was set through the staged path (persistent form)
+    int p_nf = 0;                         // lanes per landmark of the persistent instantiation in use
+    int p_lds_set[4] = {0, 0, 0, 0};      // dynamic LDS already granted to the instantiations (hipFuncSetAttribute once, not per problem)
+    int max_lds = 0;                      // hipDeviceAttributeMaxSharedMemoryPerBlock of the device
+    int job_kind = 0;                     // worker: 0 optimize, 1 setParams + optimize (uh_ba_solve_async)
+    const uh_ba_problem* job_problem = nullptr; uh_ba_problem job_problem_copy{};
+    int job_dims[3] = {0, 0, 0};
+    uh_ba_params job_params{}; bool job_has_params = false;
     unsigned p_seq = 0;                   // launches of the persistent kernel by this optimizer: 20 bits of it tag the exchanged words
     int p_lds = 0;
     BAWide wd{};
@@ -1691,6 +1745,9 @@ struct uh_ba {
             worker.join();
         }
         if (h_stop) (void)hipHostFree(h_stop);
+        if (h_stage) (void)hipHostFree(h_stage);
+        if (h_res) (void)hipHostFree(h_res);
+        if (ev_stage) (void)hipEventDestroy(ev_stage);
     }
 };
 
@@ -1806,13 +1863,14 @@ int finish_pass(uh_ba* b, BAState* hs, const volatile uint8_t* stop_asap) {
 }
 
 // Admission of persistent launches: their workgroups spin on each other, so every launch must become fully resident.  One CU holds
-// one such workgroup (LDS), hence at most 224 of the 256 CUs' worth of them are in flight per process at any time.
+// one such workgroup (LDS), hence at most 7/8 of the device's CUs' worth of them are in flight per device at any time (process-local:
+// two PROCESSES sharing one GPU can still starve each other into the 3 s time-out — see INTEGRATION.md).
 struct PersistAdmission {
     std::mutex m; std::condition_variable cv; int used = 0;
-    void acquire(int g) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&]() { return used == 0 || used + g <= 224; }); used += g; }
+    void acquire(int g, int budget) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&]() { return used == 0 || used + g <= budget; }); used += g; }
     void release(int g) { { std::lock_guard<std::mutex> l(m); used -= g; } cv.notify_all(); }
 };
-PersistAdmission g_persist_adm;
+PersistAdmission g_persist_adm[16];   // per device (index & 15)
 
 // GlobalOptimizerG2O::optimize as ONE launch (ba_persist.hpp): both passes, relabelling, every trial
 int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, float mc) {
@@ -1820,30 +1878,34 @@ int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, 
     BAPersist q = b->pq;
     q.n1 = n1; q.n2 = n2; q.minChi2 = mc;
     q.stop_at_begin = (b->h_stop && *b->h_stop) ? 1 : 0;
-    struct Hold { int g; Hold(int g_) : g(g_) { g_persist_adm.acquire(g); } ~Hold() { g_persist_adm.release(g); } } hold(q.G);
+    PersistAdmission& adm = g_persist_adm[b->ctx->device & 15];
+    const int budget = std::max(q.G, (b->ctx->num_cus > 0 ? b->ctx->num_cus : 256) * 7 / 8);
+    struct Hold { PersistAdmission& a; int g; Hold(PersistAdmission& a_, int g_, int bud) : a(a_), g(g_) { a.acquire(g, bud); } ~Hold() { a.release(g); } } hold(adm, q.G, budget);
     static std::atomic<unsigned> s_launch{0};
     q.launch_id = ++s_launch;   // (never 0) the error and completion words of this launch carry it
-    // exchanged data words carry 20 bits of this optimizer's own launch count (+ 12 bits of round number): the region was zeroed when it
-    // was laid out, every launch rewrites what it reads, and when the 20 bits wrap the region is zeroed again
+    // exchanged data words carry 20 bits of this optimizer's own launch count (+ 12 bits of round number): the buffer was zeroed when it
+    // was allocated, every launch rewrites what it reads, and when the 20 bits wrap it is zeroed again
     if (((++b->p_seq) & 0xFFFFFu) == 0) {
         ++b->p_seq;
-        UH_HIP_CHECK(hipMemsetAsync(b->parena.as<char>() + b->p_xoff, 0, b->p_xbytes, st));
+        UH_HIP_CHECK(hipMemsetAsync(b->parena.p, 0, b->parena.cap, st));
     }
     q.tag_base = (b->p_seq & 0xFFFFFu) << 12;
+    q.done_target = b->done_base + (unsigned)q.G;
     BAState hs;
     void* d_pin = nullptr;
-    const bool pinned = b->h_stop && hipHostGetDevicePointer(&d_pin, b->h_stop, 0) == hipSuccess;
+    UH_HIP_CHECK(hipHostGetDevicePointer(&d_pin, b->h_stop, 0));
     volatile unsigned long long* h_done = reinterpret_cast<volatile unsigned long long*>(b->h_stop + 192);
-    if (pinned) {
-        q.host_state = reinterpret_cast<BAState*>(static_cast<unsigned char*>(d_pin) + 64);
-        q.host_done = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(d_pin) + 192);
+    q.host_state = reinterpret_cast<BAState*>(static_cast<unsigned char*>(d_pin) + 64);
+    q.host_done = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(d_pin) + 192);
+    switch (b->p_nf) {
+        case 8: UH_LAUNCH(b->ctx, ba_persist_kernel<8>, dim3(q.G), dim3(kPThreads), (size_t)b->p_lds, b->ptrs, b->dims, q); break;
+        default: uh::set_error("uh_ba_optimize: no persistent instantiation for %d lanes per landmark", b->p_nf); return UH_EINVAL;
     }
-    UH_LAUNCH(b->ctx, ba_persist_kernel<8>, dim3(q.G), dim3(kPThreads), (size_t)b->p_lds, b->ptrs, b->dims, q);
     UH_HIP_CHECK(hipGetLastError());
     bool err = false;
-    if (pinned) {
-        // the kernel's last act is a system-scope release store of (launch id << 32 | 1) behind the final state: polling that word costs
-        // a few hundred nanoseconds of latency, a stream synchronisation + two pageable D2H copies cost ~45 us per optimize()
+    {
+        // the kernel's last act is a system-scope release store of (launch id << 32 | 1) behind the results and the final state: polling
+        // that word costs a few hundred nanoseconds of latency, a stream synchronisation + pageable D2H copies cost ~45 us per optimize()
         const unsigned long long ok_word = ((unsigned long long)q.launch_id << 32) | 1ull, err_word = ok_word + 1;
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spin = 0;; ++spin) {
@@ -1859,17 +1921,23 @@ int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, 
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         std::memcpy(&hs, b->h_stop + 64, sizeof(BAState));
-    } else {
-        unsigned long long errw = 0;
-        UH_HIP_CHECK(hipMemcpyAsync(&errw, q.flags + q.G, sizeof(errw), hipMemcpyDeviceToHost, st));
-        int rc = wait_state(b, &hs, stop_asap);
-        if (rc) return rc;
-        err = errw == (((unsigned long long)q.launch_id << 32) | 1ull);
     }
+    b->stage_in_flight = false;   // (the kernel ran behind the staging copy on the same stream)
     if (err) {
         (void)hipStreamSynchronize(st);
+        (void)hipMemsetAsync(b->dscratch.as<char>() + 768, 0, 4, st);   // the completion count of an aborted launch is meaningless
+        b->done_base = 0;
         uh::set_error("uh_ba_optimize: the persistent kernel's workgroups did not all become resident (%d workgroups, %d bytes of LDS each)", q.G, b->p_lds);
         return UH_ENODEVICE;
+    }
+    b->done_base = q.done_target;
+    const unsigned* h_err = reinterpret_cast<const unsigned*>(b->h_stop + 200);
+    if (h_err[0]) {   // left by ba_ingest_kernel (it ran in front of this launch on the same stream)
+        const uh_ba_obs* ob = reinterpret_cast<const uh_ba_obs*>(b->h_stage + b->slay.obs);
+        const unsigned e = h_err[1] < (unsigned)b->dims.E ? h_err[1] : 0;
+        if (h_err[0] == 2) uh::set_error("uh_ba_set_problem: point %d observed twice by frame %d (observation %u)", ob[e].point, ob[e].frame, e);
+        else uh::set_error("uh_ba_set_problem: observation %u references point %d / frame %d out of range", e, ob[e].point, ob[e].frame);
+        return UH_EINVAL;
     }
     b->iters[0] = hs.gate ? hs.iters_pass1 : hs.iters_done;
     b->iters[1] = hs.gate ? hs.iters_done : 0;
@@ -1905,19 +1973,13 @@ int uh_ba_create(uh_ctx* ctx, uh_ba** out) {
 
 void uh_ba_destroy(uh_ba* b) { delete b; }
 
-// GlobalOptimizer::setParams: snapshot of everything the optimisation needs (the map may change afterwards)
-int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* params) {
-    UH_REQUIRE(b && pr, "uh_ba_set_problem: NULL argument");
-    b->have_problem = false;
-    b->optimized = false;
-    if (params) b->params = *params;
-    if (b->params.huber_delta <= 0) b->params.huber_delta = std::sqrt(5.99);
-    if (b->params.chi2_threshold <= 0) b->params.chi2_threshold = 5.99;
+}  // extern "C"
+
+// setParams for the forms that keep host-built tables: the launch chain (more free keyframes than the persistent kernel is
+// instantiated for, or a window whose fixed frames do not fit its LDS) and the wide form (global BA).  Arrays anywhere in host memory.
+static int set_problem_tables(uh_ba* b, const uh_ba_problem* pr) {
+    b->fast = false;
     const int K = pr->n_frames, P = pr->n_points, E = pr->n_obs;
-    UH_REQUIRE(K >= 1 && P >= 0 && E >= 0, "uh_ba_set_problem: bad sizes K=%d P=%d E=%d", K, P, E);
-    UH_REQUIRE(pr->poses_f2g && pr->fixed && pr->intr, "uh_ba_set_problem: NULL frame arrays");
-    if (P > 0) UH_REQUIRE(pr->points, "uh_ba_set_problem: NULL points");
-    if (E > 0) UH_REQUIRE(pr->obs_point && pr->obs_frame && pr->obs_uv && pr->obs_inv_sigma, "uh_ba_set_problem: NULL observation arrays");
     std::vector<int> slot(K, -1), free_kf;
     for (int k = 0; k < K; k++) if (!pr->fixed[k]) { slot[k] = (int)free_kf.size(); free_kf.push_back(k); }
     const int nfree = (int)free_kf.size();
@@ -2071,101 +2133,7 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     if ((rc = b->d_points_out.reserve(std::max<size_t>(3 * (size_t)P * 4, 16)))) return rc;
     if ((rc = b->d_bad.reserve(std::max<size_t>(E, 16)))) return rc;
     UH_HIP_CHECK(hipMemcpyAsync(b->d_poses_in.p, pr->poses_f2g, 16 * (size_t)K * 4, hipMemcpyHostToDevice, st));
-    // ---- persistent form (ba_persist.hpp): 1..8 free keyframes, every landmark owned by one of <= 256 co-resident workgroups
     b->persist = false;
-    {
-        constexpr int NF = 8;
-        const char* form = getenv("UH_BA_FORM");
-        const bool want = !(form && std::string(form) == "legacy");
-        constexpr int kLwMax = kPThreads / NF;   // one lane per (landmark, free-camera slot)
-        int Lw = std::max(8, std::min(kLwMax, uh_div_up(std::max(P, 1), 64)));
-        if (const char* e = getenv("UH_BA_LW")) Lw = std::max(1, std::min(kLwMax, atoi(e)));
-        const int G = uh_div_up(std::max(P, 1), Lw);
-        if (want && !wide && nfree >= 1 && nfree <= NF && P >= 1 && G <= 256) {
-            BAPersist& q = b->pq;
-            q = BAPersist{};
-            q.G = G; q.Lw = Lw; q.krows = (3 * Lw + 15) & ~15;
-            const char* sch = getenv("UH_BA_SCHUR");
-            q.use_mfma = (sch && std::string(sch) == "mfma") ? 1 : 0;   // default: register-blocked vector FMA
-            q.nelem = (q.use_mfma ? 6 * 256 : 78 * 16) + NF * 27 + 6 * NF + 4;
-            q.SL = (uh_div_up(q.nelem, G) + 1) & ~1;
-            std::vector<double> h_uv(2 * (size_t)P * NF, 0.0), h_w((size_t)P * NF, 0.0), hx_uv, hx_w, h_R0(12 * (size_t)K);
-            std::vector<int> h_id((size_t)P * NF, -1), hx_ptr(P + 1, 0), hx_kf, hx_id;
-            std::vector<int> fix_slot(K, -1), fix_kf;   // fixed frames that observe something, in frame order
-            for (int e = 0; e < E; e++) if (slot[pr->obs_frame[e]] < 0) fix_slot[pr->obs_frame[e]] = 0;
-            for (int k = 0; k < K; k++) if (fix_slot[k] == 0) { fix_slot[k] = (int)fix_kf.size(); fix_kf.push_back(k); }
-            for (int pt = 0; pt < P; pt++) {
-                for (int i = pt_ptr[pt]; i < pt_ptr[pt + 1]; i++) {
-                    const int e = pt_edges[i], sl = slot[pr->obs_frame[e]];
-                    if (sl >= 0) {
-                        const size_t at = (size_t)pt * NF + sl;
-                        h_id[at] = e; h_uv[2 * at] = uv[2 * e]; h_uv[2 * at + 1] = uv[2 * e + 1]; h_w[at] = w[e];
-                    } else {
-                        hx_uv.push_back(uv[2 * e]); hx_uv.push_back(uv[2 * e + 1]); hx_w.push_back(w[e]);
-                        hx_kf.push_back(fix_slot[pr->obs_frame[e]]); hx_id.push_back(e);
-                    }
-                }
-                hx_ptr[pt + 1] = (int)hx_id.size();
-            }
-            int max_fix = 0;
-            for (int g = 0; g < G; g++) max_fix = std::max(max_fix, hx_ptr[std::min(P, (g + 1) * Lw)] - hx_ptr[g * Lw]);
-            q.max_fix = max_fix;
-            q.kfix = (int)fix_kf.size();
-            for (int k = 0; k < K; k++) {   // R | t of the snapshot, from the normalised quaternion like the legacy init kernel
-                const double* qq = &pose0[7 * k];
-                double* R = &h_R0[12 * k];
-                const double tx = 2 * qq[0], ty = 2 * qq[1], tz = 2 * qq[2];
-                const double twx = tx * qq[3], twy = ty * qq[3], twz = tz * qq[3];
-                const double txx = tx * qq[0], txy = ty * qq[0], txz = tz * qq[0];
-                const double tyy = ty * qq[1], tyz = tz * qq[1], tzz = tz * qq[2];
-                R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
-                R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
-                R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
-                R[9] = pose0[7 * k + 4]; R[10] = pose0[7 * k + 5]; R[11] = pose0[7 * k + 6];
-            }
-            const PersistLds lay = persist_lds<NF>(q.krows, d.n, max_fix, q.kfix);
-            if (lay.total_bytes <= 160 * 1024 && q.kfix <= 255) {
-                Arena PA;
-                const size_t nfx = hx_id.size();
-                const size_t o_fuv = PA.take<double>(2 * (size_t)P * NF), o_fw = PA.take<double>((size_t)P * NF), o_fid = PA.take<int>((size_t)P * NF);
-                const size_t o_xp = PA.take<int>(P + 1), o_xuv = PA.take<double>(2 * nfx + 2), o_xw = PA.take<double>(nfx + 1), o_xkf = PA.take<int>(nfx + 1), o_xid = PA.take<int>(nfx + 1);
-                const size_t o_R0 = PA.take<double>(12 * (size_t)K), o_fixkf = PA.take<int>(fix_kf.size() + 1);
-                // exchange buffers: tagged doubles (two 64-bit words each, ba_persist.hpp)
-                const size_t o_part = PA.take<unsigned long long>(2 * (size_t)G * G * q.SL), o_red = PA.take<unsigned long long>(2 * (size_t)G * q.SL);
-                const size_t o_pc = PA.take<unsigned long long>(2 * 4 * (size_t)G), o_fl = PA.take<unsigned long long>(G + 1);
-                if ((rc = b->parena.reserve(PA.off + 256))) return rc;
-                char* pb = b->parena.as<char>();
-                // no word of a fresh (or re-laid-out) exchange region may look like a tagged datum of a coming launch
-                UH_HIP_CHECK(hipMemsetAsync(pb + o_part, 0, PA.off - o_part, st));
-                b->p_xoff = o_part; b->p_xbytes = PA.off - o_part;
-                auto pup = [&](size_t off, const void* src, size_t bytes) -> int {
-                    if (bytes) UH_HIP_CHECK(hipMemcpyAsync(pb + off, src, bytes, hipMemcpyHostToDevice, st));
-                    return UH_OK;
-                };
-                if ((rc = pup(o_fuv, h_uv.data(), h_uv.size() * 8))) return rc;
-                if ((rc = pup(o_fw, h_w.data(), h_w.size() * 8))) return rc;
-                if ((rc = pup(o_fid, h_id.data(), h_id.size() * 4))) return rc;
-                if ((rc = pup(o_xp, hx_ptr.data(), hx_ptr.size() * 4))) return rc;
-                if ((rc = pup(o_xuv, hx_uv.data(), hx_uv.size() * 8))) return rc;
-                if ((rc = pup(o_xw, hx_w.data(), hx_w.size() * 8))) return rc;
-                if ((rc = pup(o_xkf, hx_kf.data(), hx_kf.size() * 4))) return rc;
-                if ((rc = pup(o_xid, hx_id.data(), hx_id.size() * 4))) return rc;
-                if ((rc = pup(o_R0, h_R0.data(), h_R0.size() * 8))) return rc;
-                if ((rc = pup(o_fixkf, fix_kf.data(), fix_kf.size() * 4))) return rc;
-                UH_HIP_CHECK(hipStreamSynchronize(st));   // the staging vectors of this block die here
-                q.fe_uv = (const double2*)(pb + o_fuv); q.fe_w = (const double*)(pb + o_fw); q.fe_id = (const int*)(pb + o_fid);
-                q.fx_ptr = (const int*)(pb + o_xp); q.fx_uv = (const double2*)(pb + o_xuv); q.fx_w = (const double*)(pb + o_xw);
-                q.fx_kf = (const int*)(pb + o_xkf); q.fx_id = (const int*)(pb + o_xid);
-                q.poseR0 = (const double*)(pb + o_R0); q.fix_kf = (const int*)(pb + o_fixkf);
-                q.pose0 = (const double*)(base + o_pose0); q.pts0 = (const double*)(base + o_pts0);
-                q.part = (unsigned long long*)(pb + o_part); q.red = (unsigned long long*)(pb + o_red); q.partC = (unsigned long long*)(pb + o_pc);
-                q.flags = (unsigned long long*)(pb + o_fl);
-                b->p_lds = lay.total_bytes;
-                UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_persist_kernel<NF>), hipFuncAttributeMaxDynamicSharedMemorySize, lay.total_bytes));
-                b->persist = true;
-            }
-        }
-    }
     UH_HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors die here
     BAPtrs& p = b->ptrs;
     p.pt_ptr = (int*)(base + o_pt_ptr); p.pt_edges = (int*)(base + o_pt_edges); p.cam_ptr = (int*)(base + o_cam_ptr); p.cam_edges = (int*)(base + o_cam_edges);
@@ -2196,6 +2164,309 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     b->d_pts0 = (double*)(base + o_pts0);
     b->have_problem = true;
     return UH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ staged setParams (persistent form)
+static StageLayout stage_layout(int Kc, int Pc) {
+    StageLayout L;
+    Arena A;
+    L.pose0 = A.take<double>(7 * (size_t)Kc); L.poseR0 = A.take<double>(12 * (size_t)Kc); L.intr = A.take<double>(4 * (size_t)Kc);
+    L.slot = A.take<int>(Kc); L.free_kf = A.take<int>(Kc); L.fix_kf = A.take<int>(Kc);
+    L.poses_in = A.take<float>(16 * (size_t)Kc); L.fixed = A.take<unsigned char>(Kc); L.intr_f = A.take<float>(4 * (size_t)Kc);
+    L.points = A.take<float>(3 * (size_t)Pc);
+    L.obs = A.take<uh_ba_obs>(0);
+    return L;
+}
+static ResLayout res_layout(int Kc, int Pc, int Ec) {
+    ResLayout R;
+    Arena A;
+    R.poses = A.take<float>(16 * (size_t)Kc); R.state = A.take<double>(7 * (size_t)Kc); R.points = A.take<float>(3 * (size_t)Pc);
+    R.chi2 = A.take<double>(Ec); R.bad = A.take<unsigned char>(Ec);
+    R.bytes = A.off + 256;
+    return R;
+}
+
+// The staging and result blocks for (K, P, E), grown with headroom and kept across problems.  Waits for the H2D copy of the previous
+// problem first: the caller is about to overwrite the block.
+static int ensure_staging(uh_ba* b, int K, int P, int E) {
+    UH_HIP_CHECK(hipSetDevice(b->ctx->device));
+    if (b->stage_in_flight) { UH_HIP_CHECK(hipEventSynchronize(b->ev_stage)); b->stage_in_flight = false; }
+    if (b->h_stage && K <= b->cap_K && P <= b->cap_P && E <= b->cap_E) return UH_OK;
+    const int Kc = K <= b->cap_K ? b->cap_K : K + K / 4 + 4, Pc = P <= b->cap_P ? b->cap_P : P + P / 4 + 64, Ec = E <= b->cap_E ? b->cap_E : E + E / 4 + 1024;
+    const StageLayout L = stage_layout(Kc, Pc);
+    const ResLayout R = res_layout(Kc, Pc, Ec);
+    const size_t bytes = L.obs + (size_t)Ec * sizeof(uh_ba_obs) + 256;
+    unsigned char* ns = nullptr; unsigned char* nr = nullptr;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ns), bytes, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&nr), R.bytes, hipHostMallocMapped);
+    if (e != hipSuccess) {
+        if (ns) (void)hipHostFree(ns);
+        uh::set_error("uh_ba: hipHostMalloc of the staging / result blocks (%zu + %zu bytes) failed: %s", bytes, R.bytes, hipGetErrorString(e));
+        return UH_ENOMEM;
+    }
+    if (b->h_stage || b->h_res) UH_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));   // (a kernel may still be writing results into the old block)
+    if (b->h_stage) (void)hipHostFree(b->h_stage);
+    if (b->h_res) (void)hipHostFree(b->h_res);
+    std::memset(nr, 0, R.bytes);
+    b->h_stage = ns; b->h_stage_bytes = bytes; b->h_res = nr; b->h_res_bytes = R.bytes;
+    b->cap_K = Kc; b->cap_P = Pc; b->cap_E = Ec; b->slay = L; b->rlay = R;
+    b->have_problem = false; b->optimized = false;   // (results of an earlier problem lived in the old block)
+    if (!b->ev_stage) UH_HIP_CHECK(hipEventCreateWithFlags(&b->ev_stage, hipEventDisableTiming));
+    return UH_OK;
+}
+
+struct PersistPlan { bool ok; int NF, Lw, G, krows, nelem, SL, max_fix, kfix, lds, use_mfma; };
+
+template <int NF>
+static int persist_lds_bytes(const PersistPlan& pl, int n) { return persist_lds<NF>(pl.krows, n, pl.max_fix, pl.kfix).total_bytes; }
+
+// Which persistent instantiation runs a window of `nfree` free keyframes (0: none)
+static int persist_lanes(int nfree) { return nfree <= 8 ? 8 : 0; }
+
+template <int NF>
+static hipError_t persist_grant_lds(int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&ba_persist_kernel<NF>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+// Does the problem run as ONE persistent launch?  Limits come from the device, not from constants: every workgroup must be resident
+// at once (one per compute unit — their LDS blocks do not fit two to a CU), and its LDS block must fit what the device grants.
+static PersistPlan plan_persistent(uh_ba* b, int K, int P, int E, int nfree) {
+    PersistPlan pl{};
+    const char* form = getenv("UH_BA_FORM");
+    if (form && std::string(form) == "legacy") return pl;
+    if (getenv("UH_BA_WIDE") && atoi(getenv("UH_BA_WIDE")) != 0) return pl;
+    void* dflag = nullptr;
+    if (!b->h_stop || hipHostGetDevicePointer(&dflag, b->h_stop, 0) != hipSuccess) return pl;   // (the kernel reports through pinned memory)
+    if (nfree < 1 || P < 1 || E >= (1 << 20) - 1) return pl;
+    const int NF = persist_lanes(nfree);
+    if (!NF) return pl;
+    const int kLwMax = kPThreads / NF;   // one lane per (landmark, free-camera slot)
+    int Lw = std::max(std::min(8, kLwMax), std::min(kLwMax, uh_div_up(P, 64)));
+    if (const char* e = getenv("UH_BA_LW")) Lw = std::max(1, std::min(kLwMax, atoi(e)));
+    const int G = uh_div_up(P, Lw);
+    const int cus = b->ctx->num_cus > 0 ? b->ctx->num_cus : 256;
+    if (G > cus) return pl;
+    const int kfix = K - nfree;
+    if (kfix > 255) return pl;
+    pl.NF = NF; pl.Lw = Lw; pl.G = G; pl.kfix = kfix;
+    pl.max_fix = Lw * kfix;   // bound: every landmark of the tile seen by every fixed frame (nothing is counted on the host)
+    pl.krows = (3 * Lw + 15) & ~15;
+    const char* sch = getenv("UH_BA_SCHUR");
+    pl.use_mfma = (sch && std::string(sch) == "mfma") ? 1 : 0;   // default: register-blocked vector FMA
+    pl.nelem = (pl.use_mfma ? 6 * 256 : 78 * 16) + NF * 27 + 6 * NF + 4;
+    pl.SL = (uh_div_up(pl.nelem, G) + 1) & ~1;
+    pl.lds = persist_lds_bytes<8>(pl, 6 * nfree);
+    if (b->max_lds <= 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, b->ctx->device) != hipSuccess || v <= 0) v = 64 * 1024;
+        b->max_lds = v;
+    }
+    if (pl.lds > b->max_lds) return pl;
+    if (pl.lds > b->p_lds_set[0]) {   // once per size class, not per problem; a refusal selects the launch chain instead of failing setParams
+        if (persist_grant_lds<8>(pl.lds) != hipSuccess) { (void)hipGetLastError(); return pl; }
+        b->p_lds_set[0] = pl.lds;
+    }
+    pl.ok = true;
+    return pl;
+}
+
+// setParams of the persistent form on a filled staging block: header on the host (K-sized), ONE H2D copy, the ingest kernel.
+// No host-built table, no stream synchronisation; every device buffer is kept across problems.
+static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl) {
+    const StageLayout& L = b->slay;
+    unsigned char* hs = b->h_stage;
+    const float* poses = reinterpret_cast<const float*>(hs + L.poses_in);
+    const unsigned char* fixed = hs + L.fixed;
+    const float* intr_f = reinterpret_cast<const float*>(hs + L.intr_f);
+    double* pose0 = reinterpret_cast<double*>(hs + L.pose0); double* R0 = reinterpret_cast<double*>(hs + L.poseR0);
+    double* intr = reinterpret_cast<double*>(hs + L.intr);
+    int* slot = reinterpret_cast<int*>(hs + L.slot); int* free_kf = reinterpret_cast<int*>(hs + L.free_kf); int* fix_kf = reinterpret_cast<int*>(hs + L.fix_kf);
+    int nfree = 0, nfix = 0;
+    for (int k = 0; k < K; k++) {   // toSE3Quat (globaloptimizer_g2o.cpp:80-90): float 4x4 -> double R,t -> quaternion
+        if (!fixed[k]) { slot[k] = nfree; free_kf[nfree++] = k; } else { slot[k] = -1; fix_kf[nfix++] = k; }
+        const float* M = poses + 16 * k;
+        const double R[9] = {M[0], M[1], M[2], M[4], M[5], M[6], M[8], M[9], M[10]};
+        double* qq = pose0 + 7 * k;
+        quat_from_R_host(R, qq);
+        qq[4] = M[3]; qq[5] = M[7]; qq[6] = M[11];
+        for (int j = 0; j < 4; j++) intr[4 * k + j] = intr_f[4 * k + j];
+        double* Rk = R0 + 12 * k;   // R | t of the snapshot, from the normalised quaternion like the launch chain's init kernel
+        const double tx = 2 * qq[0], ty = 2 * qq[1], tz = 2 * qq[2];
+        const double twx = tx * qq[3], twy = ty * qq[3], twz = tz * qq[3];
+        const double txx = tx * qq[0], txy = ty * qq[0], txz = tz * qq[0];
+        const double tyy = ty * qq[1], tyz = tz * qq[1], tzz = tz * qq[2];
+        Rk[0] = 1 - (tyy + tzz); Rk[1] = txy - twz; Rk[2] = txz + twy;
+        Rk[3] = txy + twz; Rk[4] = 1 - (txx + tzz); Rk[5] = tyz - twx;
+        Rk[6] = txz - twy; Rk[7] = tyz + twx; Rk[8] = 1 - (txx + tyy);
+        Rk[9] = qq[4]; Rk[10] = qq[5]; Rk[11] = qq[6];
+    }
+    UH_HIP_CHECK(hipSetDevice(b->ctx->device));
+    hipStream_t st = b->ctx->stream;
+    int rc;
+    // ---- device buffers (all of them survive the problem)
+    if ((rc = b->dstage.reserve(b->h_stage_bytes))) return rc;
+    if ((rc = b->dT.reserve((size_t)b->cap_P * b->cap_K * sizeof(unsigned) + 256))) return rc;
+    if (b->dT_gen != b->dT.gen || (b->tseq & 0xFFFu) == 0xFFFu) {   // fresh memory, or the 12 bits wrap: no cell may look current
+        UH_HIP_CHECK(hipMemsetAsync(b->dT.p, 0, b->dT.cap, st));
+        b->dT_gen = b->dT.gen; b->tseq = 0;
+    }
+    ++b->tseq;
+    const unsigned tseq = (b->tseq & 0xFFFu) << 20;
+    if (!b->dscratch.p) {
+        if ((rc = b->dscratch.reserve(1024))) return rc;
+        UH_HIP_CHECK(hipMemsetAsync(b->dscratch.p, 0, b->dscratch.cap, st));
+        b->done_base = 0;
+    }
+    Arena PA;
+    PA.off = 256;   // [0, 64): the error word — never part of a tagged region
+    const size_t o_part = PA.take<unsigned long long>(2 * (size_t)pl.G * pl.G * pl.SL), o_red = PA.take<unsigned long long>(2 * (size_t)pl.G * pl.SL);
+    const size_t o_pc = PA.take<unsigned long long>(2 * 4 * (size_t)pl.G);
+    if ((rc = b->parena.reserve(PA.off + 256))) return rc;
+    if (b->parena_gen != b->parena.gen) {   // the exchange words validate themselves by tag: only fresh memory is cleared (and on the tag wrap)
+        UH_HIP_CHECK(hipMemsetAsync(b->parena.p, 0, b->parena.cap, st));
+        b->parena_gen = b->parena.gen;
+    }
+    // ---- ONE copy: header, frame arrays, points, observations
+    const size_t copy_bytes = L.obs + (size_t)E * sizeof(uh_ba_obs);
+    UH_HIP_CHECK(hipMemcpyAsync(b->dstage.p, hs, copy_bytes, hipMemcpyHostToDevice, st));
+    UH_HIP_CHECK(hipEventRecord(b->ev_stage, st));
+    b->stage_in_flight = true;
+    char* db = b->dstage.as<char>();
+    unsigned* h_err = reinterpret_cast<unsigned*>(b->h_stop + 200);   // pinned: [200] ingest error code, [204] observation
+    h_err[0] = 0; h_err[1] = 0;
+    void* d_pin = nullptr;
+    UH_HIP_CHECK(hipHostGetDevicePointer(&d_pin, b->h_stop, 0));
+    if (E > 0)
+        UH_LAUNCH(b->ctx, ba_ingest_kernel, dim3(uh_div_up(E, 256)), dim3(256), 0, reinterpret_cast<const uh_ba_obs*>(db + L.obs), E, P, K,
+                  b->dT.as<unsigned>(), tseq, reinterpret_cast<unsigned*>(static_cast<unsigned char*>(d_pin) + 200));
+    UH_HIP_CHECK(hipGetLastError());
+    // ---- kernel arguments
+    BADims& d = b->dims;
+    d.K = K; d.P = P; d.E = E; d.nfree = nfree; d.n = 6 * nfree;
+    d.nPointBlocks = std::max(uh_div_up(P, kPointsPerBlock), 1);
+    d.delta = b->params.huber_delta; d.dsqr = d.delta * d.delta; d.chi2_th = b->params.chi2_threshold;
+    BAPtrs& p = b->ptrs;
+    p = BAPtrs{};
+    p.slot = reinterpret_cast<const int*>(db + L.slot); p.free_kf = reinterpret_cast<const int*>(db + L.free_kf); p.intr = reinterpret_cast<const double*>(db + L.intr);
+    p.st = b->dscratch.as<BAState>();
+    p.clk = reinterpret_cast<long long*>(b->dscratch.as<char>() + 256);
+    p.stop = static_cast<const volatile unsigned char*>(d_pin);
+    BAPersist& q = b->pq;
+    q = BAPersist{};
+    q.G = pl.G; q.Lw = pl.Lw; q.krows = pl.krows; q.SL = pl.SL; q.nelem = pl.nelem; q.max_fix = pl.max_fix; q.kfix = pl.kfix; q.use_mfma = pl.use_mfma;
+    q.T = b->dT.as<unsigned>(); q.tseq = tseq;
+    q.obs = reinterpret_cast<const uh_ba_obs*>(db + L.obs); q.points = reinterpret_cast<const float*>(db + L.points);
+    q.poses_in = reinterpret_cast<const float*>(db + L.poses_in); q.fix_kf = reinterpret_cast<const int*>(db + L.fix_kf);
+    q.pose0 = reinterpret_cast<const double*>(db + L.pose0); q.poseR0 = reinterpret_cast<const double*>(db + L.poseR0);
+    char* pb = b->parena.as<char>();
+    q.errw = reinterpret_cast<unsigned long long*>(pb);
+    q.part = reinterpret_cast<unsigned long long*>(pb + o_part); q.red = reinterpret_cast<unsigned long long*>(pb + o_red); q.partC = reinterpret_cast<unsigned long long*>(pb + o_pc);
+    void* d_res = nullptr;
+    UH_HIP_CHECK(hipHostGetDevicePointer(&d_res, b->h_res, 0));
+    unsigned char* rb = static_cast<unsigned char*>(d_res);
+    const ResLayout& R = b->rlay;
+    q.r_poses = reinterpret_cast<float*>(rb + R.poses); q.r_state = reinterpret_cast<double*>(rb + R.state); q.r_points = reinterpret_cast<float*>(rb + R.points);
+    q.r_chi2 = reinterpret_cast<double*>(rb + R.chi2); q.r_bad = rb + R.bad;
+    q.done_ctr = reinterpret_cast<unsigned*>(b->dscratch.as<char>() + 768);
+    b->p_lds = pl.lds; b->p_nf = pl.NF;
+    b->persist = true; b->wide = false; b->fast = true;
+    b->have_problem = true;
+    return UH_OK;
+}
+
+static void set_problem_begin(uh_ba* b, const uh_ba_params* params) {
+    b->have_problem = false;
+    b->optimized = false;
+    if (params) b->params = *params;
+    if (b->params.huber_delta <= 0) b->params.huber_delta = std::sqrt(5.99);
+    if (b->params.chi2_threshold <= 0) b->params.chi2_threshold = 5.99;
+}
+
+extern "C" {
+
+// GlobalOptimizer::setParams: snapshot of everything the optimisation needs (the map may change afterwards)
+int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* params) {
+    UH_REQUIRE(b && pr, "uh_ba_set_problem: NULL argument");
+    set_problem_begin(b, params);
+    const int K = pr->n_frames, P = pr->n_points, E = pr->n_obs;
+    UH_REQUIRE(K >= 1 && P >= 0 && E >= 0, "uh_ba_set_problem: bad sizes K=%d P=%d E=%d", K, P, E);
+    UH_REQUIRE(pr->poses_f2g && pr->fixed && pr->intr, "uh_ba_set_problem: NULL frame arrays");
+    if (P > 0) UH_REQUIRE(pr->points, "uh_ba_set_problem: NULL points");
+    if (E > 0) UH_REQUIRE(pr->obs_point && pr->obs_frame && pr->obs_uv && pr->obs_inv_sigma, "uh_ba_set_problem: NULL observation arrays");
+    int nfree = 0;
+    for (int k = 0; k < K; k++) nfree += pr->fixed[k] ? 0 : 1;
+    const PersistPlan pl = plan_persistent(b, K, P, E, nfree);
+    if (!pl.ok) return set_problem_tables(b, pr);
+    int rc = ensure_staging(b, K, P, E);
+    if (rc) return rc;
+    const StageLayout& L = b->slay;
+    std::memcpy(b->h_stage + L.poses_in, pr->poses_f2g, 16 * (size_t)K * sizeof(float));
+    std::memcpy(b->h_stage + L.fixed, pr->fixed, K);
+    std::memcpy(b->h_stage + L.intr_f, pr->intr, 4 * (size_t)K * sizeof(float));
+    if (P) std::memcpy(b->h_stage + L.points, pr->points, 3 * (size_t)P * sizeof(float));
+    uh_ba_obs* ob = reinterpret_cast<uh_ba_obs*>(b->h_stage + L.obs);
+    unsigned oob = 0;
+    for (int e = 0; e < E; e++) {   // structure of arrays -> 24-byte records; indices checked on the way
+        const int pt = pr->obs_point[e], kf = pr->obs_frame[e];
+        oob |= (unsigned)((unsigned)pt >= (unsigned)P) | (unsigned)((unsigned)kf >= (unsigned)K);
+        ob[e].point = pt; ob[e].frame = kf; ob[e].u = pr->obs_uv[2 * e]; ob[e].v = pr->obs_uv[2 * e + 1]; ob[e].inv_sigma = pr->obs_inv_sigma[e];
+    }
+    if (oob)
+        for (int e = 0; e < E; e++)
+            UH_REQUIRE(pr->obs_point[e] >= 0 && pr->obs_point[e] < P && pr->obs_frame[e] >= 0 && pr->obs_frame[e] < K,
+                       "uh_ba_set_problem: observation %d references point %d / frame %d out of range", e, pr->obs_point[e], pr->obs_frame[e]);
+    return set_problem_fast(b, K, P, E, pl);
+}
+
+int uh_ba_map_staging(uh_ba* b, int n_frames, int n_points, int max_obs, uh_ba_staging* out) {
+    UH_REQUIRE(b && out, "uh_ba_map_staging: NULL argument");
+    UH_REQUIRE(n_frames >= 1 && n_points >= 0 && max_obs >= 0, "uh_ba_map_staging: bad sizes K=%d P=%d E=%d", n_frames, n_points, max_obs);
+    UH_REQUIRE(b->job.load() == 0, "uh_ba_map_staging: an optimisation is in flight (call uh_ba_wait)");
+    int rc = ensure_staging(b, n_frames, n_points, max_obs);
+    if (rc) return rc;
+    const StageLayout& L = b->slay;
+    out->poses_f2g = reinterpret_cast<float*>(b->h_stage + L.poses_in); out->fixed = b->h_stage + L.fixed; out->intr = reinterpret_cast<float*>(b->h_stage + L.intr_f);
+    out->points = reinterpret_cast<float*>(b->h_stage + L.points); out->obs = reinterpret_cast<uh_ba_obs*>(b->h_stage + L.obs);
+    out->cap_frames = b->cap_K; out->cap_points = b->cap_P; out->cap_obs = b->cap_E;
+    return UH_OK;
+}
+
+int uh_ba_set_problem_staged(uh_ba* b, int K, int P, int E, const uh_ba_params* params) {
+    UH_REQUIRE(b, "uh_ba_set_problem_staged: NULL argument");
+    UH_REQUIRE(b->h_stage, "uh_ba_set_problem_staged: no staging block (call uh_ba_map_staging first)");
+    UH_REQUIRE(K >= 1 && P >= 0 && E >= 0 && K <= b->cap_K && P <= b->cap_P && E <= b->cap_E,
+               "uh_ba_set_problem_staged: sizes K=%d P=%d E=%d exceed the mapped capacities %d / %d / %d", K, P, E, b->cap_K, b->cap_P, b->cap_E);
+    set_problem_begin(b, params);
+    const StageLayout& L = b->slay;
+    const uh_ba_obs* ob = reinterpret_cast<const uh_ba_obs*>(b->h_stage + L.obs);
+    const unsigned char* fixed = b->h_stage + L.fixed;
+    unsigned oob = 0;
+    for (int e = 0; e < E; e++) oob |= (unsigned)((unsigned)ob[e].point >= (unsigned)P) | (unsigned)((unsigned)ob[e].frame >= (unsigned)K);
+    if (oob)
+        for (int e = 0; e < E; e++)
+            UH_REQUIRE(ob[e].point >= 0 && ob[e].point < P && ob[e].frame >= 0 && ob[e].frame < K,
+                       "uh_ba_set_problem: observation %d references point %d / frame %d out of range", e, ob[e].point, ob[e].frame);
+    int nfree = 0;
+    for (int k = 0; k < K; k++) nfree += fixed[k] ? 0 : 1;
+    const PersistPlan pl = plan_persistent(b, K, P, E, nfree);
+    if (pl.ok) return set_problem_fast(b, K, P, E, pl);
+    // a window the persistent form does not take: hand the launch chain / wide form the arrays it wants
+    std::vector<int32_t> op(E), of(E);
+    std::vector<float> uv(2 * (size_t)E);
+    std::vector<double> w(E);
+    for (int e = 0; e < E; e++) { op[e] = ob[e].point; of[e] = ob[e].frame; uv[2 * e] = ob[e].u; uv[2 * e + 1] = ob[e].v; w[e] = ob[e].inv_sigma; }
+    uh_ba_problem pr{};
+    pr.n_frames = K; pr.n_points = P; pr.n_obs = E;
+    pr.poses_f2g = reinterpret_cast<const float*>(b->h_stage + L.poses_in); pr.fixed = fixed; pr.intr = reinterpret_cast<const float*>(b->h_stage + L.intr_f);
+    pr.points = reinterpret_cast<const float*>(b->h_stage + L.points);
+    pr.obs_point = op.data(); pr.obs_frame = of.data(); pr.obs_uv = uv.data(); pr.obs_inv_sigma = w.data();
+    return set_problem_tables(b, &pr);
+}
+
+int uh_ba_form(uh_ba* b, int* lanes_out) {
+    UH_REQUIRE(b && b->have_problem, "uh_ba_form: no problem set");
+    if (lanes_out) *lanes_out = b->persist ? b->p_nf : 0;
+    return b->wide ? 2 : (b->persist ? 1 : 0);
 }
 
 // GlobalOptimizer::optimize(bool* stopASAP).  The caller may flip *stop_asap asynchronously; it is sampled into a pinned,
@@ -2260,35 +2531,64 @@ int uh_ba_debug_clocks(uh_ba* b, int64_t* out64) {
 // Asynchronous form: the optimisation runs on a worker thread of the object (GlobalOptimizer::optimize is what the reference's
 // mapper thread spends its time in); uh_ba_wait returns its result.  The caller's thread is free to enqueue tracking work on
 // another stream in between.  One optimisation in flight per object.
+static void start_worker(uh_ba* b) {   // (called with b->mu held)
+    if (b->worker.joinable()) return;
+    b->worker = std::thread([b]() {
+        std::unique_lock<std::mutex> l(b->mu);
+        for (;;) {
+            // a mapper that is handed a keyframe every half millisecond: spin briefly for the next request before sleeping on the
+            // condition variable (a futex wake-up is ~10-20 us on the hand-over in each direction, 4 % of a 0.5 ms optimisation)
+            l.unlock();
+            spin_until([b]() { const int j = b->job.load(std::memory_order_acquire); return j == 1 || j == -1; }, 300);
+            l.lock();
+            b->cv.wait(l, [b]() { return b->job == 1 || b->job == -1; });
+            if (b->job == -1) return;
+            b->job = 2;
+            const volatile uint8_t* stop = b->job_stop;
+            const int kind = b->job_kind;
+            l.unlock();
+            int rc = UH_OK;
+            if (kind == 1) {   // setParams first (mapmanager.cpp:11388-11405: both calls run back to back on the mapper thread)
+                const uh_ba_params* ps = b->job_has_params ? &b->job_params : nullptr;
+                rc = b->job_problem ? uh_ba_set_problem(b, b->job_problem, ps)
+                                    : uh_ba_set_problem_staged(b, b->job_dims[0], b->job_dims[1], b->job_dims[2], ps);
+            }
+            if (rc == UH_OK) rc = uh_ba_optimize(b, stop);
+            const std::string err = rc ? std::string(uh_last_error()) : std::string();   // thread-local: carry it over
+            l.lock();
+            b->job_rc = rc;
+            b->job_err = err;
+            b->job = 3;
+            b->cv.notify_all();
+        }
+    });
+}
+
 int uh_ba_optimize_async(uh_ba* b, const volatile uint8_t* stop_asap) {
     UH_REQUIRE(b && b->have_problem, "uh_ba_optimize_async: no problem set (call uh_ba_set_problem first)");
     std::unique_lock<std::mutex> lk(b->mu);
     UH_REQUIRE(b->job == 0, "uh_ba_optimize_async: an optimisation is already in flight (call uh_ba_wait)");
-    if (!b->worker.joinable()) {
-        b->worker = std::thread([b]() {
-            std::unique_lock<std::mutex> l(b->mu);
-            for (;;) {
-                // a mapper that is handed a keyframe every half millisecond: spin briefly for the next request before sleeping on the
-                // condition variable (a futex wake-up is ~10-20 us on the hand-over in each direction, 4 % of a 0.5 ms optimisation)
-                l.unlock();
-                spin_until([b]() { const int j = b->job.load(std::memory_order_acquire); return j == 1 || j == -1; }, 300);
-                l.lock();
-                b->cv.wait(l, [b]() { return b->job == 1 || b->job == -1; });
-                if (b->job == -1) return;
-                b->job = 2;
-                const volatile uint8_t* stop = b->job_stop;
-                l.unlock();
-                const int rc = uh_ba_optimize(b, stop);
-                const std::string err = rc ? std::string(uh_last_error()) : std::string();   // thread-local: carry it over
-                l.lock();
-                b->job_rc = rc;
-                b->job_err = err;
-                b->job = 3;
-                b->cv.notify_all();
-            }
-        });
-    }
+    start_worker(b);
     b->job_stop = stop_asap;
+    b->job_kind = 0;
+    b->job = 1;
+    lk.unlock();
+    b->cv.notify_all();
+    return UH_OK;
+}
+
+int uh_ba_solve_async(uh_ba* b, const uh_ba_problem* problem, int n_frames, int n_points, int n_obs, const uh_ba_params* params,
+                      const volatile uint8_t* stop_asap) {
+    UH_REQUIRE(b, "uh_ba_solve_async: NULL argument");
+    std::unique_lock<std::mutex> lk(b->mu);
+    UH_REQUIRE(b->job == 0, "uh_ba_solve_async: an optimisation is already in flight (call uh_ba_wait)");
+    start_worker(b);
+    if (problem) { b->job_problem_copy = *problem; b->job_problem = &b->job_problem_copy; }   // (the struct is copied, the arrays are the caller's)
+    else { b->job_problem = nullptr; b->job_dims[0] = n_frames; b->job_dims[1] = n_points; b->job_dims[2] = n_obs; }
+    b->job_has_params = params != nullptr;
+    if (params) b->job_params = *params;
+    b->job_stop = stop_asap;
+    b->job_kind = 1;
     b->job = 1;
     lk.unlock();
     b->cv.notify_all();
@@ -2311,6 +2611,16 @@ uint8_t* uh_ba_stop_flag(uh_ba* b) { return b ? b->h_stop : nullptr; }
 
 int uh_ba_get_results(uh_ba* b, float* poses_out, float* points_out, double* chi2_out, uint8_t* bad_out, int32_t* iters_out) {
     UH_REQUIRE(b && b->have_problem && b->optimized, "uh_ba_get_results: optimize() has not run");
+    if (b->fast) {   // the optimisation kernel's tail has already written everything into the pinned result block
+        const BADims& d = b->dims;
+        const ResLayout& R = b->rlay;
+        if (poses_out) std::memcpy(poses_out, b->h_res + R.poses, 16 * (size_t)d.K * sizeof(float));
+        if (points_out && d.P) std::memcpy(points_out, b->h_res + R.points, 3 * (size_t)d.P * sizeof(float));
+        if (chi2_out && d.E) std::memcpy(chi2_out, b->h_res + R.chi2, (size_t)d.E * sizeof(double));
+        if (bad_out && d.E) std::memcpy(bad_out, b->h_res + R.bad, (size_t)d.E);
+        if (iters_out) { iters_out[0] = b->iters[0]; iters_out[1] = b->iters[1]; }
+        return UH_OK;
+    }
     UH_HIP_CHECK(hipSetDevice(b->ctx->device));
     hipStream_t st = b->ctx->stream;
     const BADims& d = b->dims;
@@ -2332,11 +2642,26 @@ int uh_ba_get_results(uh_ba* b, float* poses_out, float* points_out, double* chi
 // final pose state (qx qy qz qw tx ty tz per frame, fp64) — used by the parity tests to state the tolerance on se3
 int uh_ba_get_pose_state(uh_ba* b, double* pose7_out) {
     UH_REQUIRE(b && b->have_problem && b->optimized && pose7_out, "uh_ba_get_pose_state: not ready");
+    if (b->fast) { std::memcpy(pose7_out, b->h_res + b->rlay.state, 7 * (size_t)b->dims.K * sizeof(double)); return UH_OK; }
     BAState hs;
     UH_HIP_CHECK(hipMemcpyAsync(&hs, b->ptrs.st + (b->step & 1), sizeof(BAState), hipMemcpyDeviceToHost, b->ctx->stream));
     UH_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
     UH_HIP_CHECK(hipMemcpyAsync(pose7_out, b->ptrs.pose[hs.cur], 7 * (size_t)b->dims.K * 8, hipMemcpyDeviceToHost, b->ctx->stream));
     UH_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
+    return UH_OK;
+}
+
+// getResults in place
+int uh_ba_results_view_get(uh_ba* b, uh_ba_results_view* out) {
+    UH_REQUIRE(b && out, "uh_ba_results_view_get: NULL argument");
+    UH_REQUIRE(b->have_problem && b->optimized, "uh_ba_results_view_get: optimize() has not run");
+    UH_REQUIRE(b->fast, "uh_ba_results_view_get: the current problem runs in a form that keeps its results in HBM (use uh_ba_get_results)");
+    const ResLayout& R = b->rlay;
+    out->poses = reinterpret_cast<const float*>(b->h_res + R.poses); out->points = reinterpret_cast<const float*>(b->h_res + R.points);
+    out->chi2 = reinterpret_cast<const double*>(b->h_res + R.chi2); out->bad = b->h_res + R.bad;
+    out->pose_state = reinterpret_cast<const double*>(b->h_res + R.state);
+    out->iters[0] = b->iters[0]; out->iters[1] = b->iters[1];
+    out->n_frames = b->dims.K; out->n_points = b->dims.P; out->n_obs = b->dims.E;
     return UH_OK;
 }
 

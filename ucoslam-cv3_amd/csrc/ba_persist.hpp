@@ -37,20 +37,28 @@ struct BAPersist {
     unsigned tag_base;    // (launch sequence of this optimizer & 0xFFFFF) << 12: the upper bits of every exchanged word's tag.  The exchange
                           // buffers are zeroed whenever they are (re)allocated and whenever the sequence wraps, so a stale word never matches.
     float minChi2;
-    const double2* fe_uv; const double* fe_w; const int* fe_id;          // P x NF: the free cameras' observations, by (landmark, slot)
-    const int* fx_ptr; const double2* fx_uv; const double* fx_w; const int* fx_kf; const int* fx_id;   // CSR of fixed-camera observations (fx_kf: index into fix_kf)
-    const int* fix_kf;   // [kfix] frame index of every fixed frame that observes something
-    const double* pose0; const double* poseR0; const double* pts0;       // K x 7, K x 12, P x 3: the snapshot taken by setParams
+    // the problem as uh_ba_set_problem left it in HBM: ONE H2D copy of the staging block + ba_ingest_kernel (ba.hip) — no table is built
+    // on the host.  T[point * K + frame] = (problem sequence << 20) | (observation index + 1): a cell of an older problem never matches.
+    const unsigned* T; unsigned tseq;
+    const uh_ba_obs* obs;            // E x {point, frame, u, v, inv_sigma} (24 bytes, include/ucoslam_hip.h)
+    const float* points;             // P x 3 float (MapPoint::getCoordinates); widened to double here exactly as setParams does
+    const float* poses_in;           // K x 16 float: fixed frames are returned unchanged, and their rows test the depth of bad associations
+    const int* fix_kf;   // [kfix] frame index of EVERY fixed frame, ascending
+    const double* pose0; const double* poseR0;                           // K x 7, K x 12: the snapshot taken by setParams
+    // results (globaloptimizer_g2o.cpp:466-537), written by the kernel's tail — into pinned host memory where the device can reach it
+    // (getResults is then a host copy), else into a device block
+    float* r_poses; double* r_state; float* r_points; unsigned char* r_bad; double* r_chi2;
+    unsigned* done_ctr; unsigned done_target;   // workgroups that have delivered their results; the one that completes the count reports
     unsigned long long* part;        // [slice][workgroup][SL] tagged doubles (two words each)
     unsigned long long* red;         // [G * SL]
     unsigned long long* partC;       // [G][4]: chi2, scale, (workgroup 0: stop flag), -
     BAState* host_state;             // pinned, device-visible host memory: the final LM state ...
     unsigned long long* host_done;   // ... and (launch id << 32 | 1 = finished, 2 = a workgroup never arrived), written last: the host polls this word
-    unsigned long long* flags;   // [G] = error word (launch id << 32 | 1): some workgroup gave up waiting
+    unsigned long long* errw;    // error word (launch id << 32 | 1): some workgroup gave up waiting
 };
 
 struct PersistLds {      // offsets in doubles into the dynamic LDS block
-    int Yt, U, usz, out, x, bp, bs, bsp, wv, pose, poseR, red, sc, fxchi, fxobs, fxcam, fxact_bytes, fxk_bytes, pair_bytes, blk_bytes, flag_bytes, total_bytes;
+    int Yt, U, usz, out, x, bp, bs, bsp, wv, pose, poseR, red, sc, fxchi, fxobs, fxcam, fxact_bytes, fxk_bytes, fxid_bytes, fxptr_bytes, pair_bytes, blk_bytes, flag_bytes, total_bytes;
 };
 template <int NF>
 __host__ __device__ inline PersistLds persist_lds(int krows, int n, int max_fix, int kfix) {
@@ -76,6 +84,8 @@ __host__ __device__ inline PersistLds persist_lds(int krows, int n, int max_fix,
     o.fxact_bytes = a * 8;
     int b = o.fxact_bytes + ((max_fix + 15) & ~15);
     o.fxk_bytes = b; b += (max_fix + 15) & ~15;
+    o.fxid_bytes = b; b += 4 * ((max_fix + 3) & ~3);
+    o.fxptr_bytes = b; b += 4 * (kPThreads / NF + 4);
     o.pair_bytes = b; b += NF * (NF + 1) / 2 * 4;
     b = (b + 15) & ~15;
     o.blk_bytes = b; b += 80 * 2;
@@ -336,19 +346,26 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     const int ll = tid >> LG, s = tid & (NF - 1);
     const bool live = ll < nl;
     const int l = live ? l0 + ll : l0;
-    const int fb = q.fx_ptr[l0], fe = q.fx_ptr[l0 + nl];   // this workgroup's fixed-camera observations
+    int* const s_fxid = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + o.fxid_bytes);     // observation index of every staged fixed-camera observation
+    int* const s_fxptr = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + o.fxptr_bytes);   // [Lw + 1]: a landmark's range of them
+    const int KK = d.K;
+    // observation index of (point, frame), or -1: only a cell written by THIS problem's ingest carries its sequence number
+    auto cell = [&](int pt, int kf) -> int {
+        const unsigned t = q.T[(size_t)pt * KK + kf];
+        return (t & 0xFFF00000u) == q.tseq ? (int)(t & 0xFFFFFu) - 1 : -1;
+    };
 
     // ---- lane-resident constants and state
     int eid = -1;
-    if (live && s < nfree) eid = q.fe_id[(size_t)l * NF + s];
+    if (live && s < nfree) eid = cell(l, p.free_kf[s]);
     const bool has = eid >= 0;
     double ou = 0, ov = 0, ow = 0, fxk = 1, fyk = 1, cxk = 0, cyk = 0;
-    if (has) { const double2 t = q.fe_uv[(size_t)l * NF + s]; ou = t.x; ov = t.y; ow = q.fe_w[(size_t)l * NF + s]; }
+    if (has) { const uh_ba_obs ob = q.obs[eid]; ou = ob.u; ov = ob.v; ow = ob.inv_sigma; }
     if (s < nfree) { const int k = p.free_kf[s]; fxk = p.intr[4 * k]; fyk = p.intr[4 * k + 1]; cxk = p.intr[4 * k + 2]; cyk = p.intr[4 * k + 3]; }
     bool act = has;
     double chi_e = 0;
     double X[3] = {0, 0, 1}, Xt[3] = {0, 0, 1};
-    if (live) { X[0] = q.pts0[3 * (size_t)l]; X[1] = q.pts0[3 * (size_t)l + 1]; X[2] = q.pts0[3 * (size_t)l + 2]; }
+    if (live) { X[0] = q.points[3 * (size_t)l]; X[1] = q.points[3 * (size_t)l + 1]; X[2] = q.points[3 * (size_t)l + 2]; }
     double ci00 = 0, ci11 = 0, ci22 = 0, cl10 = 0, cl20 = 0, cl21 = 0, wl0 = 0, wl1 = 0, wl2 = 0, bl0 = 0, bl1 = 0, bl2 = 0;
     bool any_pt = false;
 
@@ -363,16 +380,33 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     for (int i = tid; i < 2 * NF * 12; i += kPThreads) s_poseR[i] = 0.0;
     if (tid < 8) s_sc[tid] = 0.0;
     __syncthreads();
-    for (int i = fb + tid; i < fe; i += kPThreads) {
-        s_fxact[i - fb] = 1; s_fxchi[i - fb] = 0.0; s_fxk[i - fb] = (unsigned char)q.fx_kf[i];
-        const double2 uv = q.fx_uv[i];
-        s_fxobs[3 * (i - fb)] = uv.x; s_fxobs[3 * (i - fb) + 1] = uv.y; s_fxobs[3 * (i - fb) + 2] = q.fx_w[i];
+    // observations by fixed cameras: staged in LDS per landmark, in ascending frame order (a fixed summation order); one thread per
+    // landmark walks the fixed frames' cells twice (count, then place) — kfix is 1-2 for a local BA window
+    if (tid < nl) {
+        int c = 0;
+        for (int j = 0; j < q.kfix; j++) c += cell(l0 + tid, q.fix_kf[j]) >= 0;
+        s_fxptr[tid + 1] = c;
+    }
+    if (tid == 0) s_fxptr[0] = 0;
+    __syncthreads();
+    if (tid == 0) for (int i = 0; i < nl; i++) s_fxptr[i + 1] += s_fxptr[i];
+    __syncthreads();
+    if (tid < nl) {
+        int at = s_fxptr[tid];
+        for (int j = 0; j < q.kfix; j++) {
+            const int e = cell(l0 + tid, q.fix_kf[j]);
+            if (e < 0) continue;
+            const uh_ba_obs ob = q.obs[e];
+            s_fxact[at] = 1; s_fxchi[at] = 0.0; s_fxk[at] = (unsigned char)j; s_fxid[at] = e;
+            s_fxobs[3 * at] = ob.u; s_fxobs[3 * at + 1] = ob.v; s_fxobs[3 * at + 2] = ob.inv_sigma;
+            ++at;
+        }
     }
     for (int i = tid; i < q.kfix * 16; i += kPThreads) {
         const int k = q.fix_kf[i >> 4], j = i & 15;
         s_fxcam[i] = j < 12 ? q.poseR0[12 * k + j] : p.intr[4 * k + (j - 12)];
     }
-    const int fxb = live ? q.fx_ptr[l] - fb : 0, fxe = live ? q.fx_ptr[l + 1] - fb : 0;   // this landmark's fixed-camera observations
+    const int fxb = live ? s_fxptr[ll] : 0, fxe = live ? s_fxptr[ll + 1] : 0;   // this landmark's fixed-camera observations
     if (tid < nfree) {
         const int k = p.free_kf[tid];
         for (int b = 0; b < 2; b++) {
@@ -401,9 +435,9 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     // at the next uniform check of s_flag[1]
     auto give_up = [&](long long& t0) -> bool {
         if (t0 == 0) t0 = wall_clock64();
-        if (__hip_atomic_load(q.flags + G, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == err_word || wall_clock64() - t0 > kPTimeoutTicks) {
+        if (__hip_atomic_load(q.errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == err_word || wall_clock64() - t0 > kPTimeoutTicks) {
             s_flag[1] = 1;
-            __hip_atomic_store(q.flags + G, err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(q.errw, err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (g == 0 && q.host_done) __hip_atomic_store(q.host_done, ((unsigned long long)q.launch_id << 32) | 2ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             return true;
         }
@@ -942,17 +976,56 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     }
 
     UH_BA_CLK(8);
-    // ================================================================================ results into the legacy buffers (slot 0)
-    if (live && s == 0) { double* o3 = p.pts[0] + 3 * (size_t)l; o3[0] = X[0]; o3[1] = X[1]; o3[2] = X[2]; }
-    if (has) p.e_chi2[eid] = chi_e;
-    for (int i = fb + tid; i < fe; i += kPThreads) p.e_chi2[q.fx_id[i]] = s_fxchi[i - fb];
+    // ================================================================================ results (GlobalOptimizerG2O::getResults, :466-537)
+    // Written by the workgroup that owns them, straight to where uh_ba_get_results reads them (pinned host memory when the device can
+    // reach it: system-scope stores travel as posted writes).  Float poses / points exactly as the reference converts them; a bad
+    // association = chi2 > 5.99 or negative depth of the FLOAT point under the FLOAT pose (fixed frames: their input pose).
+    auto sst = [](auto* dst, auto v) { __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    const float Xf0 = (float)X[0], Xf1 = (float)X[1], Xf2 = (float)X[2];
+    if (live && s == 0) { sst(q.r_points + 3 * (size_t)l, Xf0); sst(q.r_points + 3 * (size_t)l + 1, Xf1); sst(q.r_points + 3 * (size_t)l + 2, Xf2); }
+    if (has) {
+        bool bad = chi_e > d.chi2_th;
+        if (!bad) {
+            const double* Rt = s_poseR + (st.cur * NF + s) * 12;
+            const float z = (float)Rt[6] * Xf0 + (float)Rt[7] * Xf1 + (float)Rt[8] * Xf2 + (float)Rt[11];
+            if (z < 0) bad = true;
+        }
+        sst(q.r_chi2 + eid, chi_e);
+        sst(q.r_bad + eid, (unsigned char)bad);
+    }
+    for (int i = fxb + s; i < fxe; i += NF) {
+        const double chi = s_fxchi[i];
+        bool bad = chi > d.chi2_th;
+        if (!bad) {
+            const float* M = q.poses_in + 16 * (size_t)q.fix_kf[s_fxk[i]];
+            const float z = M[8] * Xf0 + M[9] * Xf1 + M[10] * Xf2 + M[11];
+            if (z < 0) bad = true;
+        }
+        sst(q.r_chi2 + s_fxid[i], chi);
+        sst(q.r_bad + s_fxid[i], (unsigned char)bad);
+    }
     if (g == 0) {
         for (int k = tid; k < d.K; k += kPThreads) {
             const int sl = p.slot[k];
-            for (int j = 0; j < 7; j++) p.pose[0][7 * k + j] = sl >= 0 ? s_pose[(st.cur * NF + sl) * 7 + j] : q.pose0[7 * k + j];
-            for (int j = 0; j < 12; j++) p.poseR[0][12 * k + j] = sl >= 0 ? s_poseR[(st.cur * NF + sl) * 12 + j] : q.poseR0[12 * k + j];
+            float* M = q.r_poses + 16 * (size_t)k;
+            if (sl < 0) {
+                for (int j = 0; j < 16; j++) sst(M + j, q.poses_in[16 * (size_t)k + j]);
+                for (int j = 0; j < 7; j++) sst(q.r_state + 7 * (size_t)k + j, q.pose0[7 * k + j]);
+            } else {
+                const double* Rt = s_poseR + (st.cur * NF + sl) * 12;
+                for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) sst(M + r * 4 + c, (float)Rt[r * 3 + c]); sst(M + r * 4 + 3, (float)Rt[9 + r]); }
+                sst(M + 12, 0.f); sst(M + 13, 0.f); sst(M + 14, 0.f); sst(M + 15, 1.f);
+                for (int j = 0; j < 7; j++) sst(q.r_state + 7 * (size_t)k + j, s_pose[(st.cur * NF + sl) * 7 + j]);
+            }
         }
-        if (tid == 0) {
+    }
+    // every workgroup's stores have been acknowledged before it is counted; the workgroup that completes the count publishes the final
+    // state and the completion word the host polls (posted writes of one device arrive in order)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned before = __hip_atomic_fetch_add(q.done_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (before + 1u == q.done_target) {
             BAState fin = st; fin.cur = 0; fin.pending = 0; p.st[0] = fin; p.st[1] = fin;
             if (q.host_state) {   // straight into pinned host memory: uh_ba_optimize polls host_done instead of synchronising the stream
                 *q.host_state = fin;

@@ -35,6 +35,7 @@ void set_error(const char* fmt, ...);
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    unsigned gen = 0;   // bumped by every (re)allocation: "same pointer" does not mean "same memory" (hipFree + hipMalloc may return the same base)
     int reserve(size_t bytes) {
         if (bytes <= cap) return UH_OK;
         if (p) (void)hipFree(p);
@@ -43,6 +44,7 @@ struct DevBuf {
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); p = nullptr; return UH_ENOMEM; }
         cap = want;
+        ++gen;
         return UH_OK;
     }
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }

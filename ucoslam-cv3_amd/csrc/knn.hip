@@ -1170,6 +1170,7 @@ struct uh_knn {
     unsigned stream_tag0 = 0;     // UH_KNN_TAG0: first tag of a fresh buffer (test hook for the wrap)
     uh::DevBuf redo_buf;
     const void* stream_buf = nullptr;   // the list buffer the tags refer to (a new allocation is cleared and starts over)
+    unsigned stream_gen = 0;            // ... and its allocation generation (hipFree + hipMalloc may hand back the same base address)
     uh::DevBuf list_buf;          // accept lists, counts and redo flags of the two-phase search
     uh::DevBuf q_buf, idx_buf, dist_buf;  // staging for the host-pointer API
     // hierarchical k-means form of the same index (uh_knn_build_kmeans)
@@ -1303,15 +1304,21 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
         if (nn >= idx->stream_min_nn && idx->accept_qpw == 2) {
             uint64_t* d_cand = idx->list_buf.as<uint64_t>();
             uint64_t* d_prog = d_cand + (size_t)nq * cap;          // (list_buf holds tagged words only: any layout of an earlier launch is harmless)
-            const void* had = idx->redo_buf.p;
+            const unsigned had = idx->redo_buf.gen;
             if ((rc = idx->redo_buf.reserve((size_t)(nq + 2) * 4))) return rc;
             int* d_nredo = idx->redo_buf.as<int>();                // two counters (launch parity), then the compacted list of the queries to redo
             int* d_redo = d_nredo + 2;
-            if (had != idx->redo_buf.p) UH_HIP_CHECK(hipMemsetAsync(d_nredo, 0, 8, idx->ctx->stream));
-            if (idx->stream_buf != idx->list_buf.p || idx->stream_tag == 0xFFFFFFFFu) {   // new memory, or the tag wraps: no stale word may match
+            if (had != idx->redo_buf.gen) UH_HIP_CHECK(hipMemsetAsync(d_nredo, 0, 8, idx->ctx->stream));
+            const bool same_mem = idx->stream_buf == idx->list_buf.p && idx->stream_gen == idx->list_buf.gen;
+            if (!same_mem || idx->stream_tag == 0xFFFFFFFFu) {   // new memory, or the tag wraps: no stale word may match
                 UH_HIP_CHECK(hipMemsetAsync(idx->list_buf.p, 0, idx->list_buf.cap, idx->ctx->stream));
-                idx->stream_tag = idx->stream_buf == idx->list_buf.p ? 0 : idx->stream_tag0;
+                idx->stream_tag = same_mem ? 0 : idx->stream_tag0;
                 idx->stream_buf = idx->list_buf.p;
+                idx->stream_gen = idx->list_buf.gen;
+                // the overflow counters are picked by tag parity and a launch clears only the NEXT launch's slot: after a tag reset the slot
+                // of the coming launch may still hold the count an earlier launch of the same parity left behind (stale query ids would
+                // be replayed by knn_redo_kernel) — clear both
+                UH_HIP_CHECK(hipMemsetAsync(d_nredo, 0, 8, idx->ctx->stream));
             }
             const unsigned tag = ++idx->stream_tag;
             const int nrep = uh_div_up(nq, kWave);

@@ -868,6 +868,9 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(const Plan plan, co
         __syncthreads();
         select_level(s_dyn, reinterpret_cast<int*>(s_dyn + total), ((lds_entries - total) / 2) * 2, total, L, lsel, lc);
     } else {
+        // levels too large for LDS are selected in HBM with plain loads: the other workgroups' write-through stores are in memory, but
+        // this CU's L1 / this XCD's L2 may still hold lines of cat_g from before they were written — invalidate them first
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         select_level(cat_g, static_cast<int*>(nullptr), 0, total, L, lsel, lc);
     }
 }

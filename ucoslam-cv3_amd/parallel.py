@@ -201,6 +201,8 @@ def unpack_frame_messages(all_buf, lay, world: int, max_features: int, cand_cap:
 
     hdr = torch.stack([all_buf[r, lay["header"][0]:lay["header"][0] + 16].view(torch.int32) for r in range(world)]).cpu().numpy()
     rows, nq = hdr[:, 0].tolist(), int(hdr[0, 1])
+    if max(rows) > max_features or min(rows) < 0 or not 0 <= nq <= max_features:   # a count above capacity would run into the next field
+        raise ValueError(f"frame message header out of range: level rows {rows}, queries {nq}, capacity {max_features}")
     ko, do = lay["kps"][0], lay["desc"][0]
     kps = torch.cat([all_buf[r, ko:ko + rows[r] * 28].view(torch.float32).reshape(-1, 7) for r in range(world)], 0)
     desc = torch.cat([all_buf[r, do:do + rows[r] * 32].reshape(-1, 32) for r in range(world)], 0)
