@@ -1717,6 +1717,7 @@ struct uh_ba {
     unsigned char* h_res = nullptr;       // pinned, device-visible result block: the kernel's tail writes getResults' outputs here
     size_t h_res_bytes = 0;
     ResLayout rlay{};
+    uh::DevBuf d_res;                     // the result block in HBM the kernel's tail fills first (same layout)
     bool fast = false;                    // the current problem was set through the staged path (persistent form)
     int p_nf = 0;                         // lanes per landmark of the persistent instantiation in use
     int p_lds_set[4] = {0, 0, 0, 0};      // dynamic LDS already granted to the instantiations (hipFuncSetAttribute once, not per problem)
@@ -1890,7 +1891,7 @@ int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, 
         UH_HIP_CHECK(hipMemsetAsync(b->parena.p, 0, b->parena.cap, st));
     }
     q.tag_base = (b->p_seq & 0xFFFFFu) << 12;
-    q.done_target = b->done_base + (unsigned)q.G;
+    q.done_base = b->done_base;
     BAState hs;
     void* d_pin = nullptr;
     UH_HIP_CHECK(hipHostGetDevicePointer(&d_pin, b->h_stop, 0));
@@ -1930,7 +1931,7 @@ int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, 
         uh::set_error("uh_ba_optimize: the persistent kernel's workgroups did not all become resident (%d workgroups, %d bytes of LDS each)", q.G, b->p_lds);
         return UH_ENODEVICE;
     }
-    b->done_base = q.done_target;
+    b->done_base += 2u * (unsigned)q.G;
     const unsigned* h_err = reinterpret_cast<const unsigned*>(b->h_stop + 200);
     if (h_err[0]) {   // left by ba_ingest_kernel (it ran in front of this launch on the same stream)
         const uh_ba_obs* ob = reinterpret_cast<const uh_ba_obs*>(b->h_stage + b->slay.obs);
@@ -2182,7 +2183,7 @@ static ResLayout res_layout(int Kc, int Pc, int Ec) {
     Arena A;
     R.poses = A.take<float>(16 * (size_t)Kc); R.state = A.take<double>(7 * (size_t)Kc); R.points = A.take<float>(3 * (size_t)Pc);
     R.chi2 = A.take<double>(Ec); R.bad = A.take<unsigned char>(Ec);
-    R.bytes = A.off + 256;
+    R.bytes = (A.off + 7) & ~(size_t)7;   // copied to the host as 8-byte words
     return R;
 }
 
@@ -2198,7 +2199,7 @@ static int ensure_staging(uh_ba* b, int K, int P, int E) {
     const size_t bytes = L.obs + (size_t)Ec * sizeof(uh_ba_obs) + 256;
     unsigned char* ns = nullptr; unsigned char* nr = nullptr;
     hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ns), bytes, hipHostMallocMapped);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&nr), R.bytes, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&nr), R.bytes + 256, hipHostMallocMapped);
     if (e != hipSuccess) {
         if (ns) (void)hipHostFree(ns);
         uh::set_error("uh_ba: hipHostMalloc of the staging / result blocks (%zu + %zu bytes) failed: %s", bytes, R.bytes, hipGetErrorString(e));
@@ -2207,8 +2208,8 @@ static int ensure_staging(uh_ba* b, int K, int P, int E) {
     if (b->h_stage || b->h_res) UH_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));   // (a kernel may still be writing results into the old block)
     if (b->h_stage) (void)hipHostFree(b->h_stage);
     if (b->h_res) (void)hipHostFree(b->h_res);
-    std::memset(nr, 0, R.bytes);
-    b->h_stage = ns; b->h_stage_bytes = bytes; b->h_res = nr; b->h_res_bytes = R.bytes;
+    std::memset(nr, 0, R.bytes + 256);
+    b->h_stage = ns; b->h_stage_bytes = bytes; b->h_res = nr; b->h_res_bytes = R.bytes + 256;
     b->cap_K = Kc; b->cap_P = Pc; b->cap_E = Ec; b->slay = L; b->rlay = R;
     b->have_problem = false; b->optimized = false;   // (results of an earlier problem lived in the old block)
     if (!b->ev_stage) UH_HIP_CHECK(hipEventCreateWithFlags(&b->ev_stage, hipEventDisableTiming));
@@ -2363,8 +2364,11 @@ static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl
     q.part = reinterpret_cast<unsigned long long*>(pb + o_part); q.red = reinterpret_cast<unsigned long long*>(pb + o_red); q.partC = reinterpret_cast<unsigned long long*>(pb + o_pc);
     void* d_res = nullptr;
     UH_HIP_CHECK(hipHostGetDevicePointer(&d_res, b->h_res, 0));
-    unsigned char* rb = static_cast<unsigned char*>(d_res);
+    b->rlay = res_layout(K, P, E);   // (exact sizes: the hand-over copies one contiguous range; the blocks are sized by the capacities)
     const ResLayout& R = b->rlay;
+    if ((rc = b->d_res.reserve(b->h_res_bytes))) return rc;
+    unsigned char* rb = b->d_res.as<unsigned char>();
+    q.r_dev = b->d_res.as<unsigned long long>(); q.r_host = static_cast<unsigned long long*>(d_res); q.r_words = R.bytes / 8;
     q.r_poses = reinterpret_cast<float*>(rb + R.poses); q.r_state = reinterpret_cast<double*>(rb + R.state); q.r_points = reinterpret_cast<float*>(rb + R.points);
     q.r_chi2 = reinterpret_cast<double*>(rb + R.chi2); q.r_bad = rb + R.bad;
     q.done_ctr = reinterpret_cast<unsigned*>(b->dscratch.as<char>() + 768);

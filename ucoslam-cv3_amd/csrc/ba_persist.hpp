@@ -45,10 +45,10 @@ struct BAPersist {
     const float* poses_in;           // K x 16 float: fixed frames are returned unchanged, and their rows test the depth of bad associations
     const int* fix_kf;   // [kfix] frame index of EVERY fixed frame, ascending
     const double* pose0; const double* poseR0;                           // K x 7, K x 12: the snapshot taken by setParams
-    // results (globaloptimizer_g2o.cpp:466-537), written by the kernel's tail — into pinned host memory where the device can reach it
-    // (getResults is then a host copy), else into a device block
+    // results (globaloptimizer_g2o.cpp:466-537), written by the kernel's tail into a block in HBM (these pointers), then copied to pinned host memory
     float* r_poses; double* r_state; float* r_points; unsigned char* r_bad; double* r_chi2;
-    unsigned* done_ctr; unsigned done_target;   // workgroups that have delivered their results; the one that completes the count reports
+    unsigned long long* r_dev; unsigned long long* r_host; size_t r_words;   // the result block in HBM, its pinned host twin, 8-byte words in use
+    unsigned* done_ctr; unsigned done_base;     // counts the workgroups through the two steps of the result hand-over (base: its value before this launch)
     unsigned long long* part;        // [slice][workgroup][SL] tagged doubles (two words each)
     unsigned long long* red;         // [G * SL]
     unsigned long long* partC;       // [G][4]: chi2, scale, (workgroup 0: stop flag), -
@@ -977,10 +977,12 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
 
     UH_BA_CLK(8);
     // ================================================================================ results (GlobalOptimizerG2O::getResults, :466-537)
-    // Written by the workgroup that owns them, straight to where uh_ba_get_results reads them (pinned host memory when the device can
-    // reach it: system-scope stores travel as posted writes).  Float poses / points exactly as the reference converts them; a bad
-    // association = chi2 > 5.99 or negative depth of the FLOAT point under the FLOAT pose (fixed frames: their input pose).
-    auto sst = [](auto* dst, auto v) { __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    // Float poses / points exactly as the reference converts them; a bad association = chi2 > 5.99 or negative depth of the FLOAT
+    // point under the FLOAT pose (fixed frames: their input pose).  Two steps, because tens of thousands of scattered system-scope
+    // stores serialise on the host link (measured: 1.3 ms for 26k observations): (1) every workgroup writes its part into a result
+    // block in HBM with write-through stores; (2) once all have, workgroup g copies slice g of that block to the pinned host block
+    // with consecutive lanes on consecutive words — 270 KB leave as ~500 wave-wide posted writes.  uh_ba_get_results is a host copy.
+    auto sst = [](auto* dst, auto v) { __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     const float Xf0 = (float)X[0], Xf1 = (float)X[1], Xf2 = (float)X[2];
     if (live && s == 0) { sst(q.r_points + 3 * (size_t)l, Xf0); sst(q.r_points + 3 * (size_t)l + 1, Xf1); sst(q.r_points + 3 * (size_t)l + 2, Xf2); }
     if (has) {
@@ -1019,13 +1021,33 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             }
         }
     }
-    // every workgroup's stores have been acknowledged before it is counted; the workgroup that completes the count publishes the final
-    // state and the completion word the host polls (posted writes of one device arrive in order)
+    // (1) -> (2): every workgroup's stores have been acknowledged before it is counted; everybody waits for the full count
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(q.done_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long t0 = 0;
+        while (__hip_atomic_load(q.done_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - q.done_base < (unsigned)G) if (give_up(t0)) break;
+    }
+    __syncthreads();
+    if (s_flag[1]) return;
+    {
+        const size_t per = (q.r_words + G - 1) / G, w0 = (size_t)g * per, w1 = w0 + per < q.r_words ? w0 + per : q.r_words;
+        for (size_t w = w0 + tid; w < w1; w += 4 * kPThreads) {   // four words in flight per lane
+            unsigned long long v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (w + u * kPThreads < w1) v[u] = __hip_atomic_load(q.r_dev + w + u * kPThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (w + u * kPThreads < w1) __hip_atomic_store(q.r_host + w + u * kPThreads, v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    // the workgroup that completes the second count publishes the final state and the completion word the host polls (posted writes
+    // of one device arrive in order)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         const unsigned before = __hip_atomic_fetch_add(q.done_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (before + 1u == q.done_target) {
+        if (before + 1u - q.done_base == 2u * (unsigned)G) {
             BAState fin = st; fin.cur = 0; fin.pending = 0; p.st[0] = fin; p.st[1] = fin;
             if (q.host_state) {   // straight into pinned host memory: uh_ba_optimize polls host_done instead of synchronising the stream
                 *q.host_state = fin;
