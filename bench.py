@@ -5,12 +5,17 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 laun
 rank per GPU.  Prints ONE JSON line on rank 0.
 
 Workload (BASELINE.json configs[1..3] combined = the metric's "ORB extract + match + local BA"):
-  one step = `frames_per_step` (4) synthetic 1241x376 frames already resident in HBM:
+  one step = `frames_per_step` (4) synthetic 1241x376 frames = one keyframe interval, THROUGH THE PLUGIN BOUNDARY (host in, host out):
+     the 4 frames enter from pinned host memory (one async H2D on the tracking stream),
      ORB extraction of the 4 frames in one batched launch set (8 levels, scale 1.2, 2000 features)
      4 x brute-force Hamming kNN, 2000 query descriptors (the frame's own ORB output) vs a 10 000-descriptor map,
          nn=10 unsorted — the FrameMatcher_Flann call shape (framematcher.cpp:213,239)
-     1 x local BA, 10 keyframes x 3000 landmarks (~26k observations), nIters=5 (+10), fp64 — one keyframe per 4 frames
-  value = frames / second over all ranks.  Multi-GPU: frame streams are independent, so every rank runs the same per-GPU
+     keypoints, descriptors, counts and the 4 x 2000 x 10 match rows return to pinned host memory (one async D2H),
+     1 x local BA, 10 keyframes x 3000 landmarks (~26k observations), nIters=5 (+10), fp64 — a FRESH problem every step, the three
+         phases of the plugin: setParams + optimize on the mapper thread (mapmanager.cpp:11388-11405), getResults on the tracker
+         thread (:1267-1305); the flattened arrays live in pageable host memory, the results return to host arrays
+  value = frames / second over all ranks (median of R repetitions of the K-step loop; min / max beside it).  The resident-loop figure
+  of rounds 1-2 (frames already in HBM, one problem re-optimised, nothing copied back) is stages.kernel_only_frames_per_s.  Multi-GPU: frame streams are independent, so every rank runs the same per-GPU
   workload on its own frames ("weak" scaling, no data-path collective); only the timing reduction crosses ranks.  With N > 1 the
   line also carries stages.sharded_*: ONE frame stream over all N GPUs (BASELINE config 5) — pyramid levels and train tiles
   sharded, every rank holding only its tile, one fused RCCL all-gather per frame (ucoslam_cv3_amd.parallel.ShardedFrameStream).
@@ -86,6 +91,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--knn-qpw", type=int, default=1, help="queries per wave of the exact matcher (1, 2, 4)")
     ap.add_argument("--quick", action="store_true", help="headline step only: skip the per-stage and side measurements")
+    ap.add_argument("--reps", type=int, default=15, help="repetitions of the timed K-step loop (median / min / max are reported)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,40 +118,76 @@ def main():
     dev = torch.device("cuda", local_rank)
     ctx = u.Context(local_rank, torch.cuda.current_stream().cuda_stream)
 
-    # ---- synthetic inputs, resident in HBM before the timed region
+    # ---- synthetic inputs: frames in pinned host memory (the camera's buffers), the map's descriptors resident in HBM (the map lives on
+    # the device between frames), N_PROB different local-BA problems as flattened arrays in pageable host memory
     frames_np = np.stack([synth.frame(W, H, seed=1000 * rank + f, shift=(2 * f, f)) for f in range(F)])
-    frames = torch.from_numpy(frames_np).to(dev)
+    frames_host = torch.from_numpy(frames_np).pin_memory()
+    frames = torch.empty((F, H, W), dtype=torch.uint8, device=dev)
+    frames.copy_(frames_host)
     map_desc_np, _ = synth.match_set(1, NT, seed=50 + rank)
     map_desc = torch.from_numpy(map_desc_np).to(dev)
-    ba_pr = synth.ba_problem(BA_K, BA_P, seed=rank)
+    N_PROB = 4
+    ba_problems = [synth.ba_problem(BA_K, BA_P, seed=rank * N_PROB + i) for i in range(N_PROB)]
+    ba_pr = ba_problems[0]
 
     ext = ORBextractor.create(ctx)
     fp = FeatParams(MAX_FEATURES, NLEVELS, SCALE)
-    orb_out = ext.extract_batch(frames, fp)
+    # ONE device block for everything a step hands back to the host: keypoints | descriptors | match rows | counts -> one D2H copy
+    o_kps, o_desc = 0, F * MAX_FEATURES * 28
+    o_idx = o_desc + F * MAX_FEATURES * 32
+    o_dist = o_idx + F * NQ * NN * 4
+    o_cnt = o_dist + F * NQ * NN * 4
+    out_bytes = o_cnt + 64
+    out_dev = torch.zeros(out_bytes, dtype=torch.uint8, device=dev)
+    out_host = torch.zeros(out_bytes, dtype=torch.uint8).pin_memory()
+    kps_v = out_dev[o_kps:o_desc].view(torch.float32).view(F, MAX_FEATURES, 7)
+    desc_v = out_dev[o_desc:o_idx].view(F, MAX_FEATURES, 32)
+    knn_idx = out_dev[o_idx:o_dist].view(torch.int32).view(F, NQ, NN)
+    knn_dist = out_dev[o_dist:o_cnt].view(torch.int32).view(F, NQ, NN)
+    cnt_v = out_dev[o_cnt:o_cnt + 4 * F].view(torch.int32)
+    orb_out = (kps_v, desc_v, cnt_v)
+    ext.extract_batch(frames, fp, orb_out)
     index = Index(ctx).build(map_desc)
     # queries per wave of the exact matcher: round 1 used 4 (a quarter of the L1/L2 streaming beside the latency-bound BA launch chain);
     # with the local BA as one persistent launch the step is bound by that launch alone and the plain one-query form is the fastest
     # (0.740 / 0.750 / 0.751 ms per step at 1 / 2 / 4)
     index.set_queries_per_wave(args.knn_qpw)
     # the reference runs local BA on its mapper thread, concurrently with tracking (mapmanager.cpp:1550);
-    # here BA gets its own HIP stream so that its latency-bound launch chain overlaps the tracking stream's kernels
+    # here BA gets its own HIP stream so that its kernel overlaps the tracking stream's
     ctx_ba = u.Context(local_rank, private=True)
     ba = GlobalOptimizer.create(ctx_ba)
-    ba.setParams(ba_pr, ParamSet(nIters=5))
-    knn_idx = torch.empty((F, NQ, NN), dtype=torch.int32, device=dev)
-    knn_dist = torch.empty((F, NQ, NN), dtype=torch.int32, device=dev)
+    ba_ps = ParamSet(nIters=5)
     L = u.lib()
-    from ucoslam_cv3_amd._lib import check, dev_ptr
+    from ucoslam_cv3_amd._lib import check, dev_ptr, np_ptr
+    ba_out = dict(poses=np.zeros((BA_K, 16), np.float32), points=np.zeros((BA_P, 3), np.float32), bad=np.zeros(max(p_["E"] for p_ in ba_problems), np.uint8),
+                  iters=np.zeros(2, np.int32))
+    step_no = [0]
+    ba_prepared = [ba.prepareProblem(p_) for p_ in ba_problems]   # (ctypes views of the flattened arrays, built once)
 
-    # mapper thread: uh_ba_optimize blocks its caller between the two LM passes, so it runs where the reference runs it — on a
-    # mapper thread beside the tracker (mapmanager.cpp:150 runThread) — here the worker thread of the BA object
-    # (uh_ba_optimize_async / uh_ba_wait), while this thread enqueues the tracking launches
+    # One keyframe interval through the plugin boundary.  Mapper thread (the BA object's worker, uh_ba_solve_async): setParams on a
+    # FRESH problem + optimize.  Tracker thread (this one): frames in, ORB, match, results out, then getResults of the mapper's BA.
     def step():
-        ba.optimize_async()
+        pr = ba_prepared[step_no[0] % N_PROB]
+        step_no[0] += 1
+        ba.solve_async(pr, ba_ps)
+        frames.copy_(frames_host, non_blocking=True)
         kps, desc, counts = ext.extract_batch(frames, fp, orb_out)
         # the F frames' descriptor blocks are contiguous [F, 2000, 32]: one launch matches all F x 2000 queries against the map
         check(L.uh_knn_search_dev(index._h, dev_ptr(desc), F * NQ, NN, dev_ptr(knn_idx), dev_ptr(knn_dist), 0, -1))
+        out_host.copy_(out_dev, non_blocking=True)
         ba.wait()
+        check(L.uh_ba_get_results(ba._h, np_ptr(ba_out["poses"]), np_ptr(ba_out["points"]), None, np_ptr(ba_out["bad"]), np_ptr(ba_out["iters"])))
+        torch.cuda.current_stream().synchronize()   # the tracker owns its host buffers again
+
+    # rounds 1-2's step, kept as stages.kernel_only_*: frames resident in HBM, ONE problem re-optimised, nothing returns to the host
+    ba_res = GlobalOptimizer.create(ctx_ba)
+    ba_res.setParams(ba_pr, ba_ps)
+
+    def step_resident():
+        ba_res.optimize_async()
+        ext.extract_batch(frames, fp, orb_out)
+        check(L.uh_knn_search_dev(index._h, dev_ptr(desc_v), F * NQ, NN, dev_ptr(knn_idx), dev_ptr(knn_dist), 0, -1))
+        ba_res.wait()
 
     def sync_all():
         torch.cuda.synchronize()
@@ -154,30 +196,32 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    t_local = time.perf_counter() - t0
+    reps_s = []
+    for _ in range(max(args.reps, 1)):   # R repetitions of EXACTLY K steps, each bracketed by barrier + synchronize
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        reps_s.append(time.perf_counter() - t0)
     if dist is not None:
         dist.barrier()
-        tt = torch.tensor([t_local], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_max = float(tt.item())
-    else:
-        t_max = t_local
-    counts = orb_out[2].cpu().numpy()
+        tt = torch.tensor(reps_s, dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)   # per repetition: the slowest rank
+        reps_s = [float(v) for v in tt.tolist()]
+    t_max = float(np.median(reps_s))
+    counts = out_host[o_cnt:o_cnt + 4 * F].view(torch.int32).numpy().copy()   # (as the host received them)
     full_frames = bool((counts == MAX_FEATURES).all())   # the synthetic scene yields the full 2000-keypoint budget
     total_frames = world * F * args.steps
     value = total_frames / t_max
     ms_per_step = 1e3 * t_max / args.steps
+    ms_min, ms_max = 1e3 * min(reps_s) / args.steps, 1e3 * max(reps_s) / args.steps
 
     # ---- per-stage split and roofline (rank 0; separate passes so event overhead never enters the headline number)
     roofline = None
     stage_ms = {}
     if rank == 0 and args.quick:
-        print(json.dumps({"value": round(value, 1), "ms_per_step": round(ms_per_step, 4), "knn_qpw": args.knn_qpw, "knn_form": os.environ.get("UH_KNN_FORM", "auto (accept-list forms from 3000 queries)")}), flush=True)
+        print(json.dumps({"value": round(value, 1), "ms_per_step": round(ms_per_step, 4), "ms_per_step_min": round(ms_min, 4), "ms_per_step_max": round(ms_max, 4), "reps": len(reps_s), "knn_qpw": args.knn_qpw, "knn_form": os.environ.get("UH_KNN_FORM", "auto (accept-list forms from 3000 queries)")}), flush=True)
         return
     if rank == 0:
         def timed(fn, reps):
@@ -193,17 +237,56 @@ def main():
             lambda: check(L.uh_knn_search_dev(index._h, dev_ptr(orb_out[1]), F * NQ, NN, dev_ptr(knn_idx), dev_ptr(knn_dist), 0, -1)), 50) / F
         stage_ms["match_ms_single_frame_launch"] = timed(
             lambda: check(L.uh_knn_search_dev(index._h, dev_ptr(orb_out[1][0]), NQ, NN, dev_ptr(knn_idx[0]), dev_ptr(knn_dist[0]), 0, -1)), 50)
-        stage_ms["ba_ms_per_keyframe"] = timed(lambda: ba.optimize(), 5)
+        # the local BA by phase of the plugin protocol (this thread, nothing else on the GPU): a FRESH problem per call as in the step
+        def ba_phases(reps):
+            ts, to, tg = [], [], []
+            for i in range(reps):
+                pr_i = ba_prepared[i % N_PROB]
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter(); ba.setParams(pr_i, ba_ps)
+                t1_ = time.perf_counter(); ba.optimize()
+                t2_ = time.perf_counter()
+                check(L.uh_ba_get_results(ba._h, np_ptr(ba_out["poses"]), np_ptr(ba_out["points"]), None, np_ptr(ba_out["bad"]), np_ptr(ba_out["iters"])))
+                t3_ = time.perf_counter()
+                ts.append(t1_ - t0_); to.append(t2_ - t1_); tg.append(t3_ - t2_)
+            return 1e3 * float(np.median(ts)), 1e3 * float(np.median(to)), 1e3 * float(np.median(tg))
+
+        ba_phases(3)
+        stage_ms["ba_set_problem_ms"], stage_ms["ba_optimize_after_set_ms"], stage_ms["ba_get_results_ms"] = ba_phases(24)
+        stage_ms["ba_protocol_ms_per_keyframe"] = stage_ms["ba_set_problem_ms"] + stage_ms["ba_optimize_after_set_ms"] + stage_ms["ba_get_results_ms"]
+        stage_ms["ba_ms_per_keyframe"] = timed(lambda: ba_res.optimize(), 5)   # optimize() alone on a resident problem (the kernel-side figure)
+
+        # the frames' way in and the results' way out (pinned host memory <-> HBM), alone on the stream: 4 frames H2D + one D2H of
+        # keypoints, descriptors, counts and match rows
+        def io_only():
+            frames.copy_(frames_host, non_blocking=True)
+            out_host.copy_(out_dev, non_blocking=True)
+
+        stage_ms["h2d_d2h_ms_per_frame"] = timed(io_only, 30) / F
+        stage_ms["h2d_bytes_per_frame"] = W * H
+        stage_ms["d2h_bytes_per_frame"] = out_bytes // F
+        for _ in range(3):
+            step_resident()
+        stage_ms["kernel_only_step_ms"] = timed(step_resident, 30)
+        stage_ms["kernel_only_frames_per_s"] = 1e3 * F / stage_ms["kernel_only_step_ms"]
         # the second frame size north_star asks for: the same step (4 frames, one kNN launch, one local BA) on 640x480 frames
         fr2 = torch.from_numpy(np.stack([synth.frame(640, 480, seed=77 + f, shift=(2 * f, f)) for f in range(F)])).to(dev)
         ext2 = ORBextractor.create(ctx)
         out2 = ext2.extract_batch(fr2, fp)
 
-        def step_640():
-            ba.optimize_async()
-            ext2.extract_batch(fr2, fp, out2)
-            check(L.uh_knn_search_dev(index._h, dev_ptr(out2[1]), F * NQ, NN, dev_ptr(knn_idx), dev_ptr(knn_dist), 0, -1))
+        fr2_host = fr2.cpu().pin_memory()
+
+        def step_640():   # the same through-the-boundary step on the other frame size
+            pr_i = ba_prepared[step_no[0] % N_PROB]
+            step_no[0] += 1
+            ba.solve_async(pr_i, ba_ps)
+            fr2.copy_(fr2_host, non_blocking=True)
+            ext2.extract_batch(fr2, fp, orb_out)
+            check(L.uh_knn_search_dev(index._h, dev_ptr(desc_v), F * NQ, NN, dev_ptr(knn_idx), dev_ptr(knn_dist), 0, -1))
+            out_host.copy_(out_dev, non_blocking=True)
             ba.wait()
+            check(L.uh_ba_get_results(ba._h, np_ptr(ba_out["poses"]), np_ptr(ba_out["points"]), None, np_ptr(ba_out["bad"]), np_ptr(ba_out["iters"])))
+            torch.cuda.current_stream().synchronize()
 
         for _ in range(3):
             step_640()
@@ -227,14 +310,14 @@ def main():
         out_b = ext_b.extract_batch(frames, fp)
         knn_idx_b, knn_dist_b = torch.empty_like(knn_idx), torch.empty_like(knn_dist)
 
-        def step_two_sessions():
-            ba.optimize_async()
+        def step_two_sessions():   # (resident form, like kernel_only_*)
+            ba_res.optimize_async()
             ba2.optimize_async()
             ext.extract_batch(frames, fp, orb_out)
             ext_b.extract_batch(frames, fp, out_b)
             check(L.uh_knn_search_dev(index._h, dev_ptr(orb_out[1]), F * NQ, NN, dev_ptr(knn_idx), dev_ptr(knn_dist), 0, -1))
             check(L.uh_knn_search_dev(idx_b._h, dev_ptr(out_b[1]), F * NQ, NN, dev_ptr(knn_idx_b), dev_ptr(knn_dist_b), 0, -1))
-            ba.wait()
+            ba_res.wait()
             ba2.wait()
 
         for _ in range(3):
@@ -266,14 +349,17 @@ def main():
         # ... and the tracker's search against the previous frame (system.cpp:5930-6460), called with (1.5 * maxDescDistance, projDistThr)
         stage_ms["projmatch_prev_ms_per_call_2000kp_3000pts"] = timed(lambda: pmatch.matchFrameToPrevFrame(
             ppose, pmp["ids"], pmp["pos3d"], pmp["octave"], pmp["desc"], 75.0, 15.0), 20)
-        ba_iters = [int(v) for v in ba.getResults()["iters"]]
+        ba_iters = [int(v) for v in ba_out["iters"]]   # (of the last step's problem)
         if not args.no_roofline:
             for c in (ctx, ctx_ba):
                 c.prof_enable(True)
                 c.prof_reset()
-            reps = 5
+            reps = 8
+            it_sum, e_sum = 0, 0
             for _ in range(reps):
+                e_sum += ba_problems[step_no[0] % N_PROB]["E"]
                 step()
+                it_sum += int(ba_out["iters"].sum())
             torch.cuda.synchronize()
             rep = dict(ctx.prof_report())
             rep.update(ctx_ba.prof_report())
@@ -287,8 +373,8 @@ def main():
                 c0, t0_ = short.get(n, (0, 0.0))
                 short[n] = (c0 + v[0], t0_ + v[1])
             # ---- algorithmic bytes per unit x units per launch / launch time / 8 TB/s
-            b8d = survey_8d_bytes(MAX_FEATURES, ba_pr["E"])
-            lm_iters = sum(ba_iters)                               # LM iterations one local BA executes (5 + 10 here)
+            b8d = survey_8d_bytes(MAX_FEATURES, e_sum // reps)     # (E = the profiled problems' average number of observations)
+            lm_iters = it_sum / reps                               # LM iterations one local BA executes (5 + 10 on these problems)
             unit_bytes = {"orb": F * b8d["orb_per_frame"], "match": F * b8d["match_per_frame"], "ba": lm_iters * b8d["ba_per_lm_iteration"]}
             unit_ms = {"orb": sum(v[1] for k, v in short.items() if k in ORB_KERNELS) / reps,
                        "match": sum(v[1] for k, v in short.items() if k in MATCH_KERNELS) / reps,
@@ -300,7 +386,7 @@ def main():
                 # the persistent kernel is ONE launch per local BA = lm_iters LM iterations; legacy BA kernels run once per trial
                 launches_per_ba = calls / reps
                 alg = unit_bytes["ba"] / launches_per_ba
-                units = f"{lm_iters} LM iterations per launch x {b8d['ba_per_lm_iteration']} B (E*32 + 2P*24 + 2K*56 + K^2*288)" if launches_per_ba <= 1.01 else \
+                units = f"{lm_iters:g} LM iterations per launch x {b8d['ba_per_lm_iteration']} B (E*32 + 2P*24 + 2K*56 + K^2*288)" if launches_per_ba <= 1.01 else \
                     f"{b8d['ba_per_lm_iteration']} B per LM iteration / {launches_per_ba / lm_iters:.2f} launches of this kernel per iteration"
             elif name in MATCH_KERNELS:
                 alg, units = unit_bytes["match"], f"{F} frames per launch x {b8d['match_per_frame']} B ((NQ+NT)*32 + NQ*k*8, k=10)"
@@ -309,11 +395,12 @@ def main():
                 units = f"{F} frames x {b8d['orb_per_frame']} B (whole extractor), this kernel's share by time"
             achieved = alg / (avg_ms * 1e-3) / 1e9
             traffic = impl = None
-            trials_est = lm_iters + 2
+            trials_est = int(round(lm_iters)) + 2
             if name == "ba_persist_kernel":
                 impl, g_wg = persistent_ba_exchange_bytes(ba_pr["P"], trials_est)
             try:   # HBM bytes per launch from the committed PMC passes (profiles/, scripts/collect_profiles.sh): FETCH_SIZE + WRITE_SIZE
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"].get(name)
+                pmc_file = next(f_ for f_ in (os.path.join(ROOT, "profiles", n_) for n_ in ("r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(f_))
+                pmc = json.load(open(pmc_file))["kernels"].get(name)
                 if pmc:
                     traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
             except Exception:
@@ -334,7 +421,7 @@ def main():
                 "kernels_us": {k: round(1e3 * v[1] / max(v[0], 1), 2) for k, v in sorted(short.items())},
             }
         # the metric's serial definition (1 / (t_ORB + t_match + t_BA amortised)) beside the overlapped headline
-        t_serial = stage_ms["orb_ms_per_frame"] + stage_ms["match_ms_per_frame"] + stage_ms["ba_ms_per_keyframe"] / F
+        t_serial = stage_ms["orb_ms_per_frame"] + stage_ms["match_ms_per_frame"] + stage_ms["h2d_d2h_ms_per_frame"] + stage_ms["ba_protocol_ms_per_keyframe"] / F
         stage_ms["serial_frames_per_s"] = 1e3 / t_serial
 
     # ---- sharded frame stream (N > 1): levels + train tiles sharded, each rank holding ONLY its tile, ONE fused all-gather per frame
@@ -457,10 +544,14 @@ def main():
         line = {
             "metric": "tracking frames/sec (ORB extract + match + local BA), 1241x376 mono",
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "ms_per_step_min": round(ms_min, 4), "ms_per_step_max": round(ms_max, 4), "reps": len(reps_s),
+            "timing": "median over reps of (K steps between barrier + synchronize) / K; value = frames / that",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (ORB, Hamming) + f64 (BA)", "data": "synthetic",
             "config": {"workload": "orb1241x376_2000f_8lv + hamming_knn_2000x10000_nn10 + local_ba_10kf_3000pt",
-                       "frames_per_step": F, "frames_per_keyframe": F, "parallelism": f"frame-streams x{world} (replicas, no data-path collective; value = overlapped tracking + local-BA streams per GPU, stages.serial_frames_per_s = the serial 8(d) definition"
+                       "frames_per_step": F, "frames_per_keyframe": F,
+                       "boundary": "host in / host out: frames from pinned host memory, keypoints + descriptors + match rows back to it; local BA = a fresh problem per keyframe through setParams / optimize / getResults on flattened host arrays",
+                       "parallelism": f"frame-streams x{world} (replicas, no data-path collective; value = overlapped tracking + local-BA streams per GPU, stages.serial_frames_per_s = the serial 8(d) definition"
                        + (f"; stages.sharded_* = ONE stream over {world} GPUs, levels + train tiles sharded, one RCCL all-gather per frame)" if world > 1 else ")")},
             "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in stage_ms.items()}, "keypoints_per_frame": int(counts.min()), "full_budget": full_frames,
             "ba_lm_iterations": ba_iters if rank == 0 else None,

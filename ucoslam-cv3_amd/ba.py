@@ -88,8 +88,8 @@ class GlobalOptimizer:
                       np_ptr(a["obs_kf"]), np_ptr(a["obs_uv"]), np_ptr(a["obs_w"]))
         return pr, a, (K, P, E)
 
-    def setParams(self, problem: dict, params: ParamSet | None = None):
-        pr, a, dims = self._problem_struct(problem)
+    def setParams(self, problem, params: ParamSet | None = None):
+        pr, a, dims = problem if isinstance(problem, tuple) else self._problem_struct(problem)
         check(lib().uh_ba_set_problem(self._h, C.byref(pr), C.byref(params) if params is not None else None))
         self._dims = dims
         self._obs = (a["obs_pt"], a["obs_kf"])
@@ -132,7 +132,7 @@ class GlobalOptimizer:
         self._stop_keep = stop_asap
         self._params_keep = params
         if problem is not None:
-            pr, a, dims = self._problem_struct(problem)
+            pr, a, dims = problem if isinstance(problem, tuple) else self._problem_struct(problem)   # (a tuple: prepareProblem()'s result)
             self._keep = (pr, a)
             self._obs = (a["obs_pt"], a["obs_kf"])
             check(lib().uh_ba_solve_async(self._h, C.byref(pr), 0, 0, 0, C.byref(params) if params is not None else None,
@@ -142,6 +142,10 @@ class GlobalOptimizer:
                                           np_ptr(stop_asap) if stop_asap is not None else None))
         self._dims = tuple(dims)
         self._bad = None
+
+    def prepareProblem(self, problem: dict):
+        """The ctypes view of a flattened problem, built once (solve_async / setParams accept it in place of the dict)."""
+        return self._problem_struct(problem)
 
     def form(self) -> str:
         """'persist<NF>' (one persistent launch, NF lanes per landmark), 'chain' (launch chain) or 'wide' (global BA)."""
