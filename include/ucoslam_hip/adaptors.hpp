@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../ucoslam_hip.h"
+#include "flatten_ba.hpp"
 
 namespace ucoslam_hip {
 
@@ -189,7 +190,7 @@ class Vocabulary {
 // ------------------------------------------------------------------------------------------------ bundle adjustment
 class GlobalOptimizer {
    public:
-    struct ParamSet { int nIters = 10; bool verbose = false; };   // the knobs of globaloptimizer.h:31-47 the mono path reads
+    using ParamSet = BAParamSet;   // globaloptimizer.h:31-47: used_frames, fixed_frames, fixFirstFrame, nIters, verbose
     explicit GlobalOptimizer(std::shared_ptr<Context> ctx) : ctx_(std::move(ctx)) { check(uh_ba_create(ctx_->get(), &b_)); }
     ~GlobalOptimizer() { uh_ba_destroy(b_); }
     // GlobalOptimizer::create(type): "" / "hip" select this implementation, anything else throws (globaloptimizer.cpp:27-33)
@@ -198,30 +199,63 @@ class GlobalOptimizer {
         return std::make_shared<GlobalOptimizer>(std::move(ctx));
     }
     std::string getName() const { return "hip"; }
-    // setParams(map, params): `problem` is the map already flattened by the caller (see INTEGRATION.md for the Map walker)
+    // setParams(map, params) (globaloptimizer_g2o.cpp:77-401): the selection rules of flatten_ba.hpp, written straight into the optimiser's
+    // pinned staging block; then ONE H2D copy + one kernel on the device.  Snapshots everything: the map may change afterwards.
+    template <class MapView>
+    void setParams(const MapView& map, const ParamSet& p) {
+        StagingSink sink(b_);
+        index_ = flatten_for_ba(map, p, sink);
+        uh_ba_params bp{p.nIters, 0.0, 0.0, 1.0f};
+        check(uh_ba_set_problem_staged(b_, (int)index_.frame_of.size(), (int)index_.point_of.size(), index_.n_obs, &bp));
+        staged_ = true;
+        obs_keep_.assign(sink.st.obs, sink.st.obs + index_.n_obs);   // (getResults names the bad associations by these)
+    }
+    // setParams on a map the caller has flattened already
     void setParams(const uh_ba_problem& problem, const ParamSet& p) {
         uh_ba_params bp{p.nIters, 0.0, 0.0, 1.0f};
         check(uh_ba_set_problem(b_, &problem, &bp));
-        obs_point_.assign(problem.obs_point, problem.obs_point + problem.n_obs);
-        obs_frame_.assign(problem.obs_frame, problem.obs_frame + problem.n_obs);
+        staged_ = false;
+        obs_keep_.resize(problem.n_obs);
+        for (int e = 0; e < problem.n_obs; e++) obs_keep_[e] = uh_ba_obs{problem.obs_point[e], problem.obs_frame[e], 0.f, 0.f, 0.0};
+        index_ = FlatBAIndex{};
+        index_.n_obs = problem.n_obs;
         K_ = problem.n_frames; P_ = problem.n_points;
     }
     void optimize(bool* stopASAP = nullptr) { check(uh_ba_optimize(b_, reinterpret_cast<const volatile uint8_t*>(stopASAP))); }
-    // getResults(map): poses K x 16 float, points P x 3 float
+    // getResults(map) (:466-537): poses of the free frames, point coordinates, updatePointNormalAndDistances; fills getBadAssociations()
+    template <class MapView>
+    void getResults(MapView& map) {
+        if (!staged_) throw std::runtime_error("GlobalOptimizer::getResults(map): setParams(map, ...) has not been called");
+        std::vector<float> poses(16 * index_.frame_of.size()), points(3 * index_.point_of.size() + 1);
+        std::vector<uint8_t> bad(index_.n_obs + 1);
+        check(uh_ba_get_results(b_, poses.data(), points.data(), nullptr, bad.data(), nullptr));
+        bad_ = apply_results(map, index_, poses.data(), points.data(), bad.data(), obs_keep_.data());
+    }
+    // getResults into plain arrays: poses K x 16 float, points P x 3 float (flattened indices)
     void getResults(std::vector<float>& poses_f2g, std::vector<float>& points) {
-        poses_f2g.resize((size_t)K_ * 16);
-        points.resize((size_t)P_ * 3);
-        std::vector<uint8_t> bad(obs_point_.size());
+        const size_t K = staged_ ? index_.frame_of.size() : (size_t)K_, P = staged_ ? index_.point_of.size() : (size_t)P_;
+        poses_f2g.resize(K * 16);
+        points.resize(P * 3);
+        std::vector<uint8_t> bad(obs_keep_.size() + 1);
         check(uh_ba_get_results(b_, poses_f2g.data(), points.data(), nullptr, bad.data(), nullptr));
         bad_.clear();
-        for (size_t e = 0; e < bad.size(); e++) if (bad[e]) bad_.push_back({(uint32_t)obs_point_[e], (uint32_t)obs_frame_[e]});
+        for (size_t e = 0; e < obs_keep_.size(); e++)
+            if (bad[e]) bad_.push_back(staged_ ? std::make_pair(index_.point_of[obs_keep_[e].point], index_.frame_of[obs_keep_[e].frame])
+                                               : std::make_pair((uint32_t)obs_keep_[e].point, (uint32_t)obs_keep_[e].frame));
     }
+    // one function to do everything (globaloptimizer_g2o.cpp:404-414)
+    template <class MapView>
+    void optimize(MapView& map, const ParamSet& p = ParamSet()) { setParams(map, p); optimize(); getResults(map); }
     std::vector<std::pair<uint32_t, uint32_t>> getBadAssociations() { return bad_; }
+    const FlatBAIndex& index() const { return index_; }
+    uh_ba* handle() const { return b_; }
    private:
     std::shared_ptr<Context> ctx_;
     uh_ba* b_ = nullptr;
     int K_ = 0, P_ = 0;
-    std::vector<int32_t> obs_point_, obs_frame_;
+    bool staged_ = false;
+    FlatBAIndex index_;
+    std::vector<uh_ba_obs> obs_keep_;
     std::vector<std::pair<uint32_t, uint32_t>> bad_;
 };
 

@@ -58,7 +58,102 @@ def test_cpp_adaptors_compile_and_fail_loudly_without_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_adaptors_run_on_gpu(tmp_path):
+def test_cpp_adaptors_run_on_gpu(tmp_path, oracle):
+    """Every C++ adaptor class (include/ucoslam_hip/adaptors.hpp — the product's stated host language) runs once on the GPU from a
+    plain g++ program, and each result is checked: ORBextractor vs the ORB oracle, Vocabulary / fBow vs the fbow oracle,
+    FrameMatcherBoW vs the independent Python restatement, GlobalOptimizer (through flatten_for_ba on a map) vs the vectors
+    recorded from the real g2o, Index / ProjectionMatcher by known answers."""
+    import struct
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    import py_oracle_matcher as pyo
+    import synth
+    from test_bow import _oracle_transform
+    from ucoslam_cv3_amd.bow import write_vocabulary_stream
+    from ucoslam_cv3_amd.orb import KEYPOINT_DTYPE
+
+    d = tmp_path / "io"
+    d.mkdir()
+    img = synth.frame(320, 240, seed=5)
+    (d / "frame.bin").write_bytes(struct.pack("<ii", 320, 240) + img.tobytes())
+    params, blob, meta = synth.vocabulary(k=10, depth=4, seed=3, aligment=8)
+    (d / "voc.bin").write_bytes(write_vocabulary_stream(params, blob))
+    pr = synth.ba_problem(8, 600, seed=21, nfixed=2)
+    K, P, E = pr["K"], pr["P"], pr["E"]
+    sf_chain = np.array([synth._scale_f32(o) for o in range(8)], np.float32)          # Frame::scaleFactors
+    inv = (1.0 / sf_chain.astype(np.float64)).astype(np.float32).astype(np.float64)  # (double)(float)(1. / f), what setParams stores
+    octave = np.array([int(np.argmin(np.abs(inv - w))) for w in pr["obs_w"]], np.int32)
+    assert np.array_equal(inv[octave], pr["obs_w"])
+    fixed = np.zeros((K + 3) & ~3, np.uint8)
+    fixed[:K] = pr["fixed"]
+    (d / "ba.bin").write_bytes(struct.pack("<iii", K, P, E) + pr["poses"].tobytes() + fixed.tobytes() + pr["intr"].tobytes()
+                                + pr["points"].tobytes() + pr["obs_pt"].tobytes() + pr["obs_kf"].tobytes() + pr["obs_uv"].tobytes() + octave.tobytes()
+                                + sf_chain.tobytes())
+    ba_ref = oracle_lib.ba_optimize(oracle, pr, 5)
     exe = _build_adaptor_probe(tmp_path)
-    out = subprocess.run([exe], capture_output=True, text=True)
-    assert out.returncode == 0 and "gpu path ok: first neighbour 0 dist 0" in out.stdout, out.stdout + out.stderr
+    out = subprocess.run([exe, str(d)], capture_output=True, text=True)
+    assert out.returncode == 0 and "gpu path ok: first neighbour 0 dist 0" in out.stdout and "all adaptors ran" in out.stdout, out.stdout + out.stderr
+
+    # ---- ORBextractor::detectAndCompute == the oracle, bit for bit
+    b = (d / "orb_out.bin").read_bytes()
+    n = struct.unpack_from("<i", b)[0]
+    kps = np.frombuffer(b, KEYPOINT_DTYPE, n, 4)
+    desc = np.frombuffer(b, np.uint8, n * 32, 4 + 28 * n).reshape(n, 32)
+    rk, rd = oracle_lib.orb_extract(oracle, img, 1000, 8, 1.2)
+    assert n == len(rk) and n > 300
+    assert kps.tobytes() == rk.tobytes() and np.array_equal(desc, rd)
+    # ---- Vocabulary::transform(level 3) maps == the oracle's per-descriptor triples assembled in feature order; score of a bag with itself
+    b = (d / "bow_out.bin").read_bytes()
+    off = 0
+    n1 = struct.unpack_from("<i", b, off)[0]; off += 4
+    bag = {}
+    for _ in range(n1):
+        i, w = struct.unpack_from("<If", b, off); off += 8
+        bag[i] = np.float32(w)
+    n2 = struct.unpack_from("<i", b, off)[0]; off += 4
+    nodes = {}
+    for _ in range(n2):
+        i, c = struct.unpack_from("<Ii", b, off); off += 8
+        nodes[i] = list(struct.unpack_from(f"<{c}I", b, off)); off += 4 * c
+    score = struct.unpack_from("<d", b, off)[0]
+    word, weight, node, valid = _oracle_transform(oracle, params, blob, np.ascontiguousarray(desc), 3)
+    rbag, rnodes = {}, {}
+    for i in range(n):
+        if word[i] != 0xFFFFFFFF:
+            rbag[int(word[i])] = np.float32(rbag.get(int(word[i]), np.float32(0)) + weight[i])
+        if valid[i]:
+            rnodes.setdefault(int(node[i]), []).append(i)
+    assert bag == rbag and nodes == rnodes
+    assert score > 0.999
+    # ---- FrameMatcherBoW (frame against itself) == the Python restatement on the same maps
+    b = (d / "bowmatch_out.bin").read_bytes()
+    nm = struct.unpack_from("<i", b)[0]
+    mm = np.frombuffer(b, np.dtype([("q", np.int32), ("t", np.int32), ("img", np.int32), ("d", np.float32)]), nm, 4)
+    f = dict(desc=desc, octave=kps["octave"].astype(np.int32), angle=kps["angle"].astype(np.float32), pt=np.stack([kps["x"], kps["y"]], 1),
+             bowvector_level=rnodes, scaleFactors=sf_chain)
+    used = np.ones(n, np.uint8)
+    ref = pyo.bow_match(f, f, used, used, 100.0, 0.8, True, 1)
+    assert [(int(m["q"]), int(m["t"]), float(m["d"])) for m in mm] == [(m["queryIdx"], m["trainIdx"], m["distance"]) for m in ref]
+    assert nm > 100 and all(int(m["q"]) == int(m["t"]) and m["d"] == 0 for m in mm)
+    # ---- GlobalOptimizer through flatten_for_ba on a map == the BA oracle (itself pinned by the real g2o) on the flattened problem
+    b = (d / "ba_out.bin").read_bytes()
+    kk, pp, ee = struct.unpack_from("<iii", b)
+    assert (kk, pp, ee) == (K, P, E)          # every frame used, every point has >= 2 observers, every observation an edge
+    poses = np.frombuffer(b, np.float32, 16 * K, 12).reshape(K, 16)
+    points = np.frombuffer(b, np.float32, 3 * P, 12 + 64 * K).reshape(P, 3)
+    off = 12 + 64 * K + 12 * P
+    nb = struct.unpack_from("<i", b, off)[0]
+    bad = np.frombuffer(b, np.uint32, 2 * nb, off + 4).reshape(nb, 2)
+    upd = struct.unpack_from("<i", b, off + 4 + 8 * nb)[0]
+    assert np.abs(poses - ba_ref["poses"]).max() < 1e-5 and np.abs(points - ba_ref["points"]).max() < 1e-4
+    np.testing.assert_array_equal(poses[pr["fixed"] == 1], pr["poses"][pr["fixed"] == 1])
+    # the map's edges are point-major (flatten_for_ba walks points, then their observers): compare the bad set, not its order;
+    # an association whose chi2 sits on the 5.99 boundary itself may fall either way
+    near = {(int(p_), int(k_)) for p_, k_, c_ in zip(pr["obs_pt"], pr["obs_kf"], ba_ref["chi2"]) if abs(c_ - 5.99) < 1e-6 * 5.99}
+    want = {(int(p_), int(k_)) for p_, k_, f_ in zip(pr["obs_pt"], pr["obs_kf"], ba_ref["bad"]) if f_}
+    got = {(int(a), int(c)) for a, c in bad}
+    assert (got ^ want) <= near and len(got) > 0 and upd == P
