@@ -733,6 +733,142 @@ __device__ __forceinline__ bool ldlt_rowlane_lds(double* M, int n, int ld, int n
     return failed;
 }
 
+// The same factorisation for 64 < n + 1 <= 128 rows: TWO rows per lane of wave 0 (rows lane and lane + 64), the panel buffer
+// s_y[2][6][128].  A pivot row lives in the low or the high register set of its lane — which one is uniform per column, so the
+// v_readlane source is chosen by a scalar select.  Used by the persistent kernel's 9-16 free keyframe instantiation (n <= 96).
+__device__ __forceinline__ double readlane2_f64(double lo, double hi, int row_uniform) {
+    const double a = readlane_f64(lo, row_uniform & 63), b = readlane_f64(hi, row_uniform & 63);
+    return row_uniform < 64 ? a : b;
+}
+__device__ __forceinline__ bool ldlt_rowlane2_lds(double* M, int n, int ld, int nfree, int npairs, const short (*s_pair)[2], double* s_y_raw) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nb = n / 6, nrow = n + 1;
+    double* const s_y = s_y_raw + ((reinterpret_cast<uintptr_t>(s_y_raw) >> 3) & 1);   // [2][6][128], 16-byte aligned
+    bool failed = false;
+    double lp0[6] = {0, 0, 0, 0, 0, 0}, lp1[6] = {0, 0, 0, 0, 0, 0};
+    auto wave0_step = [&](int kb) {
+        const int k0 = 6 * kb;
+        const int r0 = lane, r1 = lane + 64 < nrow ? lane + 64 : nrow - 1;   // (nrow > 64: every low row exists; idle high lanes shadow the last row)
+        double a0[6], a1[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { a0[j] = M[r0 * ld + k0 + j]; a1[j] = M[r1 * ld + k0 + j]; }
+        if (kb > 0) {
+            const double* yb = s_y + ((kb - 1) & 1) * 768 + k0;
+            double2 yv[6][3];
+#pragma unroll
+            for (int t = 0; t < 6; t++)
+#pragma unroll
+                for (int h = 0; h < 3; h++) yv[t][h] = *reinterpret_cast<const double2*>(yb + t * 128 + 2 * h);
+#pragma unroll
+            for (int t = 0; t < 6; t++)
+                asm volatile("" : "+v"(yv[t][0].x), "+v"(yv[t][0].y), "+v"(yv[t][1].x), "+v"(yv[t][1].y), "+v"(yv[t][2].x), "+v"(yv[t][2].y));
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+                a0[0] = fma(-lp0[t], yv[t][0].x, a0[0]); a0[1] = fma(-lp0[t], yv[t][0].y, a0[1]); a0[2] = fma(-lp0[t], yv[t][1].x, a0[2]);
+                a0[3] = fma(-lp0[t], yv[t][1].y, a0[3]); a0[4] = fma(-lp0[t], yv[t][2].x, a0[4]); a0[5] = fma(-lp0[t], yv[t][2].y, a0[5]);
+                a1[0] = fma(-lp1[t], yv[t][0].x, a1[0]); a1[1] = fma(-lp1[t], yv[t][0].y, a1[1]); a1[2] = fma(-lp1[t], yv[t][1].x, a1[2]);
+                a1[3] = fma(-lp1[t], yv[t][1].y, a1[3]); a1[4] = fma(-lp1[t], yv[t][2].x, a1[4]); a1[5] = fma(-lp1[t], yv[t][2].y, a1[5]);
+            }
+        }
+        asm volatile("" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(a0[4]), "+v"(a0[5]));
+        asm volatile("" : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]), "+v"(a1[4]), "+v"(a1[5]));
+        double dj[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            dj[j] = readlane2_f64(a0[j], a1[j], k0 + j);
+            failed = failed || dj[j] == 0.0 || !isfinite(dj[j]);
+            const double rr = __builtin_amdgcn_rcp(dj[j]);
+            const double e = fma(-dj[j], rr, 1.0);
+            const double ikj = fma(fma(e, e, e), rr, rr);
+            lp0[j] = a0[j] * ikj; lp1[j] = a1[j] * ikj;
+            if (j + 1 < 6) {
+                const double y = readlane2_f64(a0[j], a1[j], k0 + j + 1);
+                a0[j + 1] = fma(-(a0[j] * y), ikj, a0[j + 1]); a1[j + 1] = fma(-(a1[j] * y), ikj, a1[j + 1]);
+            }
+#pragma unroll
+            for (int c = j + 2; c < 6; c++) {
+                const double y = readlane2_f64(a0[j], a1[j], k0 + c);
+                a0[c] = fma(-lp0[j], y, a0[c]); a1[c] = fma(-lp1[j], y, a1[c]);
+            }
+        }
+        // every lane stores both rows (rows above the block land in the unused upper triangle; idle high lanes repeat the last row)
+        const int ri0 = r0 - k0, ri1 = r1 - k0;
+        double* yo = s_y + (kb & 1) * 768;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            M[r0 * ld + k0 + j] = ri0 == j ? dj[j] : lp0[j];
+            M[r1 * ld + k0 + j] = ri1 == j ? dj[j] : lp1[j];
+            yo[j * 128 + r0] = a0[j];
+            yo[j * 128 + r1] = a1[j];
+        }
+    };
+    auto trailing = [&](int kb) {   // waves 1..3: panel kb onto the tiles (s1 <= s2) with s1 >= kb + 2 and the right-hand-side row
+        const int k0 = 6 * kb, J0 = kb + 2;
+        if (J0 >= nb) return;
+        const int tile0 = J0 * nfree - J0 * (J0 - 1) / 2;
+        const int ntile = npairs - tile0;
+        const int nunits = 6 * ntile + (nb - J0);
+        const double* yb = s_y + (kb & 1) * 768;
+        for (int u = tid - 64; u < nunits; u += kSolveThreads - 64) {
+            int r, c0;
+            bool diag = false;
+            if (u < 6 * ntile) {
+                const int tile = u / 6, s1 = s_pair[tile0 + tile][0], s2 = s_pair[tile0 + tile][1];
+                r = 6 * s2 + (u - 6 * tile); c0 = 6 * s1; diag = s1 == s2;
+            } else { r = n; c0 = 6 * (J0 + (u - 6 * ntile)); }
+            double lr[6], acc[6];
+#pragma unroll
+            for (int t = 0; t < 6; t++) lr[t] = M[r * ld + k0 + t];
+#pragma unroll
+            for (int j = 0; j < 6; j++) acc[j] = M[r * ld + c0 + j];
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+                const double2 y01 = *reinterpret_cast<const double2*>(yb + t * 128 + c0), y23 = *reinterpret_cast<const double2*>(yb + t * 128 + c0 + 2),
+                              y45 = *reinterpret_cast<const double2*>(yb + t * 128 + c0 + 4);
+                acc[0] = fma(-lr[t], y01.x, acc[0]); acc[1] = fma(-lr[t], y01.y, acc[1]); acc[2] = fma(-lr[t], y23.x, acc[2]);
+                acc[3] = fma(-lr[t], y23.y, acc[3]); acc[4] = fma(-lr[t], y45.x, acc[4]); acc[5] = fma(-lr[t], y45.y, acc[5]);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++) if (!diag || c0 + j <= r) M[r * ld + c0 + j] = acc[j];
+        }
+    };
+    if (wv == 0 && nb > 0) wave0_step(0);
+    for (int kb = 0; kb < nb; kb++) {
+        __syncthreads();
+        if (kb == nb - 1) break;
+        if (wv == 0) wave0_step(kb + 1);
+        else if (tid < kSolveThreads) trailing(kb);
+    }
+    if (wv != 0) failed = false;
+    return failed;
+}
+
+// L^T x = z for 64 < n <= 128 (z = row n of M after the factorisation): wave 0, two unknowns per lane, one broadcast per column
+__device__ __forceinline__ void backsolve2_lds(const double* M, int n, int ld, double* s_x) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (wv != 0) return;
+    double x0 = M[(size_t)n * ld + lane], x1 = lane + 64 < n ? M[(size_t)n * ld + lane + 64] : 0.0;
+    const int r1 = lane + 64 < n ? lane + 64 : n - 1;
+    double l0[4], l1[4], n0[4], n1[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { const int jj = n - 1 - t >= 0 ? n - 1 - t : 0; l0[t] = M[(size_t)jj * ld + lane]; l1[t] = M[(size_t)jj * ld + r1]; }
+    for (int j0 = n - 1; j0 >= 0; j0 -= 4) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) { const int jj = j0 - 4 - t >= 0 ? j0 - 4 - t : 0; n0[t] = M[(size_t)jj * ld + lane]; n1[t] = M[(size_t)jj * ld + r1]; }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int j = j0 - t;   // column j: rows i < j take -L[j][i] x_j (steps past column 0 multiply by zero)
+            const double xj = readlane2_f64(x0, x1, j > 0 ? j : 0);
+            x0 = fma(-(lane < j ? l0[t] : 0.0), xj, x0);
+            x1 = fma(-(lane + 64 < j ? l1[t] : 0.0), xj, x1);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) { l0[t] = n0[t]; l1[t] = n1[t]; }
+    }
+    s_x[lane] = x0;
+    if (lane + 64 < n) s_x[lane + 64] = x1;
+}
+
 // Blocked look-ahead LDL^T of the bordered system [S b; b^T .] held as a lower triangle in LDS (row stride ld = n + 1, odd), shared by the
 // fused legacy solve and the persistent kernel.  Every thread of the workgroup calls it (it contains barriers); the first
 // kSolveThreads threads do the work.  Returns (in wave 0) whether a zero / non-finite pivot was met.
@@ -1900,6 +2036,7 @@ int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, 
     q.host_done = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(d_pin) + 192);
     switch (b->p_nf) {
         case 8: UH_LAUNCH(b->ctx, ba_persist_kernel<8>, dim3(q.G), dim3(kPThreads), (size_t)b->p_lds, b->ptrs, b->dims, q); break;
+        case 16: UH_LAUNCH(b->ctx, ba_persist_kernel<16>, dim3(q.G), dim3(kPThreads), (size_t)b->p_lds, b->ptrs, b->dims, q); break;
         default: uh::set_error("uh_ba_optimize: no persistent instantiation for %d lanes per landmark", b->p_nf); return UH_EINVAL;
     }
     UH_HIP_CHECK(hipGetLastError());
@@ -2216,13 +2353,19 @@ static int ensure_staging(uh_ba* b, int K, int P, int E) {
     return UH_OK;
 }
 
-struct PersistPlan { bool ok; int NF, Lw, G, krows, nelem, SL, max_fix, kfix, lds, use_mfma; };
+struct PersistPlan { bool ok; int NF, Lw, G, krows, nelem, SL, max_fix, kfix, lds, use_mfma, nb4, nblk, KS, off_cam; };
 
 template <int NF>
-static int persist_lds_bytes(const PersistPlan& pl, int n) { return persist_lds<NF>(pl.krows, n, pl.max_fix, pl.kfix).total_bytes; }
+static int persist_lds_bytes(const PersistPlan& pl, int n) { return persist_lds<NF>(pl.krows, n, pl.max_fix, pl.kfix, pl.off_cam, pl.KS, pl.SL).total_bytes; }
 
-// Which persistent instantiation runs a window of `nfree` free keyframes (0: none)
-static int persist_lanes(int nfree) { return nfree <= 8 ? 8 : 0; }
+// Which persistent instantiation runs a window of `nfree` free keyframes (0: none): one lane per (landmark, free-camera slot), so the
+// lanes per landmark are the number of free cameras rounded up to 8 or 16.  Beyond 16 the reduced system (6 nfree + 1)^2 doubles and
+// the landmark panel no longer share one workgroup's LDS, and 256 / 32 = 8 landmarks per workgroup would need more workgroups than the
+// chip has compute units: those windows run the launch chain.
+static int persist_lanes(int nfree) {
+    if (const char* e = getenv("UH_BA_NF")) { const int v = atoi(e); if ((v == 8 || v == 16) && nfree <= v) return v; }   // (A/B: force the wider instantiation)
+    return nfree <= 8 ? 8 : (nfree <= 16 ? 16 : 0);
+}
 
 template <int NF>
 static hipError_t persist_grant_lds(int bytes) {
@@ -2254,18 +2397,34 @@ static PersistPlan plan_persistent(uh_ba* b, int K, int P, int E, int nfree) {
     pl.krows = (3 * Lw + 15) & ~15;
     const char* sch = getenv("UH_BA_SCHUR");
     pl.use_mfma = (sch && std::string(sch) == "mfma") ? 1 : 0;   // default: register-blocked vector FMA
-    pl.nelem = (pl.use_mfma ? 6 * 256 : 78 * 16) + NF * 27 + 6 * NF + 4;
+    if (NF != 8) pl.use_mfma = 0;
+    const int n = 6 * nfree;
+    pl.nb4 = (n + 3) / 4; pl.nblk = pl.nb4 * (pl.nb4 + 1) / 2;
+    pl.off_cam = pl.use_mfma ? 6 * 256 : pl.nblk * 16;
+    pl.nelem = pl.off_cam + NF * 27 + 6 * NF + 4;
     pl.SL = (uh_div_up(pl.nelem, G) + 1) & ~1;
-    pl.lds = persist_lds_bytes<8>(pl, 6 * nfree);
+    // K-splits of the Schur product: work items = nblk * KS over 256 lanes, each krows / KS rows deep; the splits' partial blocks must
+    // fit the LDS region the reduced system occupies later ((n + 1)^2 doubles)
+    pl.KS = 1;
+    if (!pl.use_mfma) {
+        int best = 1 << 30;
+        for (int ks = 1; ks <= 6; ks++) {
+            if (ks > 1 && ks * pl.off_cam > (n + 1) * (n + 1) + 1452) break;
+            const int rounds = uh_div_up(pl.nblk * ks, kPThreads), depth = (uh_div_up(pl.krows, ks) + 3) & ~3;
+            if (rounds * depth < best) { best = rounds * depth; pl.KS = ks; }
+        }
+    }
+    pl.lds = NF == 8 ? persist_lds_bytes<8>(pl, n) : persist_lds_bytes<16>(pl, n);
     if (b->max_lds <= 0) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, b->ctx->device) != hipSuccess || v <= 0) v = 64 * 1024;
         b->max_lds = v;
     }
     if (pl.lds > b->max_lds) return pl;
-    if (pl.lds > b->p_lds_set[0]) {   // once per size class, not per problem; a refusal selects the launch chain instead of failing setParams
-        if (persist_grant_lds<8>(pl.lds) != hipSuccess) { (void)hipGetLastError(); return pl; }
-        b->p_lds_set[0] = pl.lds;
+    const int cls = NF == 8 ? 0 : 1;
+    if (pl.lds > b->p_lds_set[cls]) {   // once per size class, not per problem; a refusal selects the launch chain instead of failing setParams
+        if ((NF == 8 ? persist_grant_lds<8>(pl.lds) : persist_grant_lds<16>(pl.lds)) != hipSuccess) { (void)hipGetLastError(); return pl; }
+        b->p_lds_set[cls] = pl.lds;
     }
     pl.ok = true;
     return pl;
@@ -2355,6 +2514,7 @@ static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl
     BAPersist& q = b->pq;
     q = BAPersist{};
     q.G = pl.G; q.Lw = pl.Lw; q.krows = pl.krows; q.SL = pl.SL; q.nelem = pl.nelem; q.max_fix = pl.max_fix; q.kfix = pl.kfix; q.use_mfma = pl.use_mfma;
+    q.nb4 = pl.nb4; q.nblk = pl.nblk; q.KS = pl.KS;
     q.T = b->dT.as<unsigned>(); q.tseq = tseq;
     q.obs = reinterpret_cast<const uh_ba_obs*>(db + L.obs); q.points = reinterpret_cast<const float*>(db + L.points);
     q.poses_in = reinterpret_cast<const float*>(db + L.poses_in); q.fix_kf = reinterpret_cast<const int*>(db + L.fix_kf);

@@ -32,6 +32,7 @@ constexpr long long kPTimeoutTicks = 300000000ll;   // 3 s of the 100 MHz wall c
 
 struct BAPersist {
     int G, Lw, krows, SL, nelem, max_fix, kfix;
+    int nb4, nblk, KS;   // the product's 4x4 block grid: nb4 = ceil(n / 4) block columns, nblk upper blocks, KS splits of the K range
     int n1, n2, stop_at_begin, use_mfma;
     unsigned launch_id;   // tags the error / completion words of this launch
     unsigned tag_base;    // (launch sequence of this optimizer & 0xFFFFF) << 12: the upper bits of every exchanged word's tag.  The exchange
@@ -60,15 +61,17 @@ struct BAPersist {
 struct PersistLds {      // offsets in doubles into the dynamic LDS block
     int Yt, U, usz, out, x, bp, bs, bsp, wv, pose, poseR, red, sc, fxchi, fxobs, fxcam, fxact_bytes, fxk_bytes, fxid_bytes, fxptr_bytes, pair_bytes, blk_bytes, flag_bytes, total_bytes;
 };
+// off_cam = elements of the product part of a partial (nblk * 16, or the six MFMA tiles), KS = K-splits of the product, SL = slice length
 template <int NF>
-__host__ __device__ inline PersistLds persist_lds(int krows, int n, int max_fix, int kfix) {
-    constexpr int NP = 6 * NF, YS = NP + 2, NT = (NP / 16) * (NP / 16 + 1) / 2;
+__host__ __device__ inline PersistLds persist_lds(int krows, int n, int max_fix, int kfix, int off_cam, int KS, int SL) {
+    constexpr int NP = 6 * NF, YS = NP + 2;
     PersistLds o;
     int a = 0;
     o.Yt = a; a += krows * YS;
     o.U = a;
-    o.usz = (n + 1) * (n + 1) + 2 * 121 * 6;
-    if (o.usz < NT * 256 + 1856) o.usz = NT * 256 + 1856;   // the staged product (<= 1536) + the slice reduction's scratch (SL * min(G, 16) <= 1832)
+    o.usz = (n + 1) * (n + 1) + (n + 1 <= 64 ? 2 * 121 * 6 : 2 * 6 * 128 + 4);   // reduced system + the factorisation's panel buffer
+    if (o.usz < KS * off_cam) o.usz = KS * off_cam;                               // the product's K-split partials
+    { const int r = off_cam + (SL > 256 ? SL : 256) + 8; if (o.usz < r) o.usz = r; }   // the staged product + the slice reduction's scratch
     if (o.usz < kPWaves * NF * 33) o.usz = kPWaves * NF * 33;
     if (o.usz < 2048) o.usz = 2048;
     a += o.usz;
@@ -88,7 +91,7 @@ __host__ __device__ inline PersistLds persist_lds(int krows, int n, int max_fix,
     o.fxptr_bytes = b; b += 4 * (kPThreads / NF + 4);
     o.pair_bytes = b; b += NF * (NF + 1) / 2 * 4;
     b = (b + 15) & ~15;
-    o.blk_bytes = b; b += 80 * 2;
+    o.blk_bytes = b; b += ((NP / 4) * (NP / 4 + 1) / 2 * 2 + 15) & ~15;
     o.flag_bytes = b; b += 16;
     o.total_bytes = b;
     return o;
@@ -306,15 +309,17 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     // one wave per SIMD, every instruction on the critical path: when the tracking stream's waves share the SIMD, this wave issues first
     __builtin_amdgcn_s_setprio(3);
     uh_latency_critical();
-    static_assert(NF == 8, "lanes per landmark = padded number of free cameras");
-    constexpr int NP = 6 * NF, T = NP / 16, NT = T * (T + 1) / 2, YS = NP + 2;
+    static_assert(NF == 8 || NF == 16, "lanes per landmark = padded number of free cameras");
+    constexpr int NP = 6 * NF, YS = NP + 2;
+    constexpr int NT = 6;                       // (MFMA form, NF == 8 only: six upper 16x16 tiles of the 48 x 48 product)
     constexpr int LG = NF == 8 ? 3 : 4;
-    static_assert(T == 3, "tile bookkeeping below is written for three tile columns");
+    constexpr int NHP = NF == 8 ? 5 : 9;        // camera-side sums a lane owns after the butterfly transpose over 64 / NF landmarks
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = blockIdx.x;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);   // the wave index as a scalar: wave-uniform branches become s_cbranch
     const int n = d.n, ld = n + 1, nfree = d.nfree, npairs = nfree * (nfree + 1) / 2;
-    const PersistLds o = persist_lds<NF>(q.krows, n, q.max_fix, q.kfix);
+    const int OFF_CAM = (NF == 8 && q.use_mfma) ? NT * 256 : q.nblk * 16, OFF_BS = OFF_CAM + NF * 27, OFF_SC = OFF_BS + NP;
+    const PersistLds o = persist_lds<NF>(q.krows, n, q.max_fix, q.kfix, OFF_CAM, q.KS, q.SL);
     double* const Yt = lds + o.Yt;
     double* const U = lds + o.U;
     double* const Mm = U;
@@ -339,8 +344,8 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     int* const s_flag = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + o.flag_bytes);   // [0] solve ok, [1] error
 
     const int G = q.G, SL = q.SL;
-    // element offsets of a partial: the product (six 16x16 MFMA tiles, or the 78 upper 4x4 blocks of the vector-FMA form), camera sums, scalars
-    const int OFF_CAM = q.use_mfma ? NT * 256 : 78 * 16, OFF_BS = OFF_CAM + NF * 27, OFF_SC = OFF_BS + NP;
+    // (OFF_CAM / OFF_BS / OFF_SC: element offsets of a partial — the product (the nblk upper 4x4 blocks of the vector-FMA form, or six 16x16
+    // MFMA tiles), camera sums, b_schur, scalars)
     const int l0 = g * q.Lw;
     const int nl = min(q.Lw, d.P - l0);
     const int ll = tid >> LG, s = tid & (NF - 1);
@@ -419,10 +424,10 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         while (rem >= nfree - s1) { rem -= nfree - s1; ++s1; }
         s_pair[t][0] = (short)s1; s_pair[t][1] = (short)(s1 + rem);
     }
-    if (tid < 78) {
-        int bi = 0, rem = tid;
-        while (rem >= 12 - bi) { rem -= 12 - bi; ++bi; }
-        s_blk[tid][0] = (unsigned char)bi; s_blk[tid][1] = (unsigned char)(bi + rem);
+    for (int t = tid; t < q.nblk; t += kPThreads) {   // upper blocks of the nb4 x nb4 grid, row-major
+        int bi = 0, rem = t;
+        while (rem >= q.nb4 - bi) { rem -= q.nb4 - bi; ++bi; }
+        s_blk[t][0] = (unsigned char)bi; s_blk[t][1] = (unsigned char)(bi + rem);
     }
     if (tid == 0) { s_flag[0] = 1; s_flag[1] = 0; }
     __syncthreads();
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             int off = 0, real = 33;
             PartTranspose<33, 32, NF>::run(hp, lane, off, real);
 #pragma unroll
-            for (int i = 0; i < 5; i++) if (i < real) U[(wv * NF + s) * 33 + off + i] = hp[i];
+            for (int i = 0; i < NHP; i++) if (i < real) U[(wv * NF + s) * 33 + off + i] = hp[i];
         }
         if (!first) UH_BA_CLK(53);
         const double chi_part = (live && s == 0) ? acc[9] : 0.0;
@@ -588,57 +593,57 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         }
         if (tid == 0) { s_out[NF * 27 + NP] = cs; s_out[NF * 27 + NP + 1] = 0; s_out[NF * 27 + NP + 2] = mx; s_out[NF * 27 + NP + 3] = 0; }
         if (!first) UH_BA_CLK(54);
-        // S = Yt^T Yt.  Default: vector FMA, 4x4 register blocks — the 78 upper blocks of the 12x12 block grid x 3 thirds of the K range =
-        // 234 lanes, 16 accumulators each, four ds_read_b128 per 16 FMAs; the thirds are added in order through LDS.  Measured on MI355X
-        // (scripts/micro/mfma_f64_rate.hip): v_fma_f64 sustains 9.1 FMA/clk/SIMD, v_mfma_f64_16x16x4_f64 issues every ~160 cycles = 6.4, so the
-        // MFMA form below (UH_BA_SCHUR=mfma: six upper 16x16 tiles split over the waves, accumulators resident in AGPRs) loses on gfx950.
-        if (!first && !q.use_mfma) {
-            const int kt = tid / 78, bq = tid - 78 * kt;
-            const bool onj = tid < 234;
-            const int bi = s_blk[onj ? bq : 0][0], bj = s_blk[onj ? bq : 0][1];
-            const int kc = (q.krows + 2) / 3;
-            const int kbeg = kt * kc, kend = onj ? min(q.krows, kbeg + kc) : 0;
-            double acc4[16];
+        // S = Yt^T Yt.  Default: vector FMA, 4x4 register blocks — the nblk upper blocks of the nb4 x nb4 block grid x KS splits of the K
+        // range (78 x 3 = 234 items for eight free cameras: one per lane; more cameras: several per lane), 16 accumulators each, four
+        // ds_read_b128 per 16 FMAs; the splits are added in order through LDS.  Measured on MI355X (scripts/micro/mfma_f64_rate.hip):
+        // v_fma_f64 sustains 9.1 FMA/clk/SIMD, v_mfma_f64_16x16x4_f64 issues every ~160 cycles = 6.4, so the MFMA form below
+        // (UH_BA_SCHUR=mfma: six upper 16x16 tiles split over the waves, accumulators resident in AGPRs) loses on gfx950.
+        if (!first && !(NF == 8 && q.use_mfma)) {
+            __syncthreads();   // the camera sums in U have been read: U is free
+            const int nitems = q.nblk * q.KS;
+            const int kc = (q.krows + q.KS - 1) / q.KS;
+            for (int item = tid; item < nitems; item += kPThreads) {
+                const int kt = item / q.nblk, bq = item - kt * q.nblk;
+                const int bi = s_blk[bq][0], bj = s_blk[bq][1];
+                const int kbeg = kt * kc, kend = min(q.krows, kbeg + kc);
+                double acc4[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++) acc4[i] = 0;
-            const double* ra = Yt + 4 * bi, * rb = Yt + 4 * bj;
-            // four rows per iteration: their sixteen ds_read_b128 are issued together, so one LDS latency is paid per 64 FMAs
-            // (the compiler serialises load -> wait -> FMA inside an iteration and undoes hand-rotated prefetching)
-            for (int k = kbeg; k < kend; k += 4) {
-                double2 a01[4], a23[4], b01[4], b23[4];
+                for (int i = 0; i < 16; i++) acc4[i] = 0;
+                const double* ra = Yt + 4 * bi, * rb = Yt + 4 * bj;
+                // four rows per iteration: their sixteen ds_read_b128 are issued together, so one LDS latency is paid per 64 FMAs
+                // (the compiler serialises load -> wait -> FMA inside an iteration and undoes hand-rotated prefetching)
+                for (int k = kbeg; k < kend; k += 4) {
+                    double2 a01[4], a23[4], b01[4], b23[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int kk = k + u < kend ? k + u : kbeg;
-                    a01[u] = *reinterpret_cast<const double2*>(ra + kk * YS); a23[u] = *reinterpret_cast<const double2*>(ra + kk * YS + 2);
-                    b01[u] = *reinterpret_cast<const double2*>(rb + kk * YS); b23[u] = *reinterpret_cast<const double2*>(rb + kk * YS + 2);
+                    for (int u = 0; u < 4; u++) {
+                        const int kk = k + u < kend ? k + u : kbeg;
+                        a01[u] = *reinterpret_cast<const double2*>(ra + kk * YS); a23[u] = *reinterpret_cast<const double2*>(ra + kk * YS + 2);
+                        b01[u] = *reinterpret_cast<const double2*>(rb + kk * YS); b23[u] = *reinterpret_cast<const double2*>(rb + kk * YS + 2);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const double z = k + u < kend ? 1.0 : 0.0;   // rows past the end contribute nothing
+                        const double av[4] = {a01[u].x * z, a01[u].y * z, a23[u].x * z, a23[u].y * z}, bv[4] = {b01[u].x, b01[u].y, b23[u].x, b23[u].y};
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+#pragma unroll
+                            for (int c = 0; c < 4; c++) acc4[r * 4 + c] = fma(av[r], bv[c], acc4[r * 4 + c]);
+                    }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const double z = k + u < kend ? 1.0 : 0.0;   // rows past the end contribute nothing
-                    const double av[4] = {a01[u].x * z, a01[u].y * z, a23[u].x * z, a23[u].y * z}, bv[4] = {b01[u].x, b01[u].y, b23[u].x, b23[u].y};
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-#pragma unroll
-                        for (int c = 0; c < 4; c++) acc4[r * 4 + c] = fma(av[r], bv[c], acc4[r * 4 + c]);
-                }
-            }
-            __syncthreads();   // the camera sums in U have been read (before the product): U is free
-            if (onj && kt > 0) {
-#pragma unroll
-                for (int i = 0; i < 16; i++) U[(kt - 1) * 1248 + bq * 16 + i] = acc4[i];
+                for (int i = 0; i < 16; i++) U[kt * OFF_CAM + bq * 16 + i] = acc4[i];
             }
             __syncthreads();
-            if (onj && kt == 0) {
-                double u0[16], u1[16];   // all LDS reads first: interleaved with the write-through stores they serialise into 32 round trips
-#pragma unroll
-                for (int i = 0; i < 16; i++) { u0[i] = U[bq * 16 + i]; u1[i] = U[1248 + bq * 16 + i]; }
-#pragma unroll
-                for (int i = 0; i < 16; i++) U[bq * 16 + i] = (acc4[i] + u0[i]) + u1[i];   // staged: the stores below go out coalesced
-            }
+            if (q.KS > 1)   // the splits added in order; staged in U so that the stores below go out coalesced
+                for (int e = tid; e < OFF_CAM; e += kPThreads) {
+                    double r = U[e];
+                    for (int kt = 1; kt < q.KS; kt++) r += U[kt * OFF_CAM + e];
+                    U[e] = r;
+                }
         }
         // MFMA form: wave 0: (0,0) (0,1), wave 1: (0,2) (1,1), wave 2: (1,2) + half of b_schur, wave 3: (2,2) + the other half — every wave
         // runs the whole K range, so no reduction across waves is needed.
-        if (!first && q.use_mfma) {
+        if (NF == 8 && !first && q.use_mfma) {
             const int nks = q.krows >> 2;
             const int col = lane & 15, kr = lane >> 4;
             // column groups of the wave's tile(s): wave 0 (0,0)+(0,1), wave 1 (0,2)+(1,1), wave 2 (1,2), wave 3 (2,2)
@@ -698,7 +703,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         // HG groups of sources per element, chosen so that one pass of the workgroup covers the slice (SL * HG <= 256 threads) and a
         // thread's sources (~G / HG <= 8) go out as ONE batch of loads: every extra pass or batch is a memory round trip (~1.5 us)
         const int HG = max(1, min(G, kPThreads / SL));
-        double* const R = U + NT * 256;          // behind the staged product, which other waves may still be sending
+        double* const R = U + OFF_CAM;           // behind the staged product, which other waves may still be sending
         const size_t src = (size_t)g * G * SL;   // slice g of every workgroup's partial
         for (int idx = tid; idx < SL * HG; idx += kPThreads) {
             const int hg = idx / SL, e = idx - hg * SL;
@@ -738,15 +743,12 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     // Where the elements this thread fetches from the reduced vector go (the same every trial): an offset into `lds` (doubles), with bit 24
     // set for the entries that are copied (camera sums -> s_out, b_schur -> s_bs) and clear for the Schur product's entries, which
     // enter the lower triangle of S negated; -1: nothing to store.
-    int asm_dst[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const int idx = tid + u * kPThreads;
+    auto dst_of = [&](int idx) -> int {
         int t = -1;
         if (idx < q.nelem) {
             if (idx < OFF_CAM) {
                 int row, col;
-                if (q.use_mfma) {   // (tile, lane, register) of the MFMA C layout: row = (lane >> 4) + 4 * reg, col = lane & 15
+                if (NF == 8 && q.use_mfma) {   // (tile, lane, register) of the MFMA C layout: row = (lane >> 4) + 4 * reg, col = lane & 15
                     const int ti = idx >> 8, lq = (idx >> 2) & 63, vv = idx & 3;
                     const int tm = ti < 3 ? 0 : (ti < 5 ? 1 : 2), tn = ti < 3 ? ti : (ti < 5 ? ti - 2 : 2);
                     row = 16 * tm + (lq >> 4) + 4 * vv; col = 16 * tn + (lq & 15);
@@ -758,8 +760,11 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             } else if (idx < OFF_BS) t = (o.out + (idx - OFF_CAM)) | (1 << 24);
             else if (idx < OFF_SC) t = (o.bs + (idx - OFF_BS)) | (1 << 24);
         }
-        asm_dst[u] = t;
-    }
+        return t;
+    };
+    int asm_dst[8];   // the first batch of eight (all of it for up to eight free cameras) is worked out once; later batches on the fly
+#pragma unroll
+    for (int u = 0; u < 8; u++) asm_dst[u] = dst_of(tid + u * kPThreads);
     UH_BA_CLK(1);
     for (int pass = 0; pass < 2; pass++) {
         UH_BA_CLK(2 + 3 * pass);
@@ -794,19 +799,22 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         phase1(1.0, true, false);
         if (!reduce_slices()) return;
         lin_eval(st.cur, X, false);   // the first trial's linearisation (same estimate), inside the latency of the reduced vector's hand-off
-        {   // every wave for itself: one diagonal entry of Hpp per lane, max butterfly
-            // (n <= 48 < 64: one diagonal entry per lane; its three words go out as one batch, not three dependent round trips)
+        {   // every wave for itself: the diagonal entries of Hpp over the lanes (n <= 128: at most two per lane), max butterfly
+            // (all of a lane's words go out as one batch, not as dependent round trips)
             double m = 0.0;
             {
-                const int sc = lane / 6, a = lane - 6 * sc;
-                const size_t i_diag = lane < n ? (size_t)(OFF_CAM + sc * 27 + (a * 6 - a * (a - 1) / 2)) : (size_t)OFF_SC;   // diagonal of the 21-entry upper triangle
+                const int d0 = lane, d1 = lane + 64;
+                const int sc0 = d0 / 6, a0 = d0 - 6 * sc0, sc1 = d1 / 6, a1 = d1 - 6 * sc1;
+                const size_t i_d0 = d0 < n ? (size_t)(OFF_CAM + sc0 * 27 + (a0 * 6 - a0 * (a0 - 1) / 2)) : (size_t)OFF_SC;   // diagonal of the 21-entry upper triangle
+                const size_t i_d1 = d1 < n ? (size_t)(OFF_CAM + sc1 * 27 + (a1 * 6 - a1 * (a1 - 1) / 2)) : (size_t)OFF_SC;
                 long long t0 = 0;
                 for (;;) {
-                    const TWord wm = tld_raw(q.red, OFF_SC + 2), wd = tld_raw(q.red, i_diag), wc = tld_raw(q.red, OFF_SC);
+                    const TWord wm = tld_raw(q.red, OFF_SC + 2), wd0 = tld_raw(q.red, i_d0), wd1 = tld_raw(q.red, i_d1), wc = tld_raw(q.red, OFF_SC);
                     m = lane == 0 ? tval(wm) : 0.0;
-                    if (lane < n) m = fmax(m, fabs(tval(wd)));
+                    if (d0 < n) m = fmax(m, fabs(tval(wd0)));
+                    if (d1 < n) m = fmax(m, fabs(tval(wd1)));
                     chi_lin_pass = tval(wc);
-                    if ((tok(wm, tagB) && tok(wd, tagB) && tok(wc, tagB)) || give_up(t0)) break;
+                    if ((tok(wm, tagB) && tok(wd0, tagB) && tok(wd1, tagB) && tok(wc, tagB)) || give_up(t0)) break;
                 }
             }
 #pragma unroll
@@ -831,21 +839,21 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             if (!reduce_slices()) return;
             UH_BA_CLK(42);
             // ---- assemble S = Hpp + lambda I - Yt^T Yt (lower triangle, bordered with b = bp - b_schur), factorise, substitute
-            {   // (q.nelem <= 8 * kPThreads: one batch per thread; where each element goes was worked out once, before the passes)
+            for (int b0 = 0; b0 < q.nelem; b0 += 8 * kPThreads) {   // batches of eight elements per thread (one batch for up to eight free cameras)
                 double rv[8];
-                const int left = q.nelem - tid;
+                const int left = q.nelem - b0 - tid;
                 const int cnt = left <= 0 ? 0 : min(8, (left + kPThreads - 1) / kPThreads);
-                tload8(q.red, (size_t)tid, kPThreads, cnt, tagB, rv);
+                tload8(q.red, (size_t)(b0 + tid), kPThreads, cnt, tagB, rv);
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const int t = asm_dst[u];
+                    const int t = b0 == 0 ? asm_dst[u] : dst_of(b0 + tid + u * kPThreads);
                     if (t >= 0) lds[t & 0xFFFFFF] = (t >> 24) ? rv[u] : -rv[u];   // bit 24: camera sums / b_schur keep their sign, product entries enter S negated
                 }
             }
             __syncthreads();
             if (s_flag[1]) return;
-            if (tid < nfree * 21) {
-                const int sc = tid / 21, qq = tid - 21 * sc;
+            for (int t = tid; t < nfree * 21; t += kPThreads) {
+                const int sc = t / 21, qq = t - 21 * sc;
                 int a = 0, rem = qq;
                 while (rem >= 6 - a) { rem -= 6 - a; ++a; }
                 const int c = a + rem;
@@ -860,12 +868,13 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             if (tid == 0) s_flag[0] = 1;
             __syncthreads();
             UH_BA_CLK(43);
-            const bool failed = ldlt_bordered_lds(Mm, n, ld, nfree, npairs, s_pair, s_w);
+            const bool failed = (NF == 8 || n + 1 <= 64) ? ldlt_bordered_lds(Mm, n, ld, nfree, npairs, s_pair, s_w)
+                                                        : ldlt_rowlane2_lds(Mm, n, ld, nfree, npairs, s_pair, &s_w[0][0][0]);
             if (failed && tid == 0) s_flag[0] = 0;
             __syncthreads();
             UH_BA_CLK(44);
             const int ok = s_flag[0];
-            if (ok) backsolve_lds(Mm, n, ld, s_x);
+            if (ok) { if (NF == 8 || n <= 64) backsolve_lds(Mm, n, ld, s_x); else backsolve2_lds(Mm, n, ld, s_x); }
             else for (int i = tid; i < n; i += kPThreads) s_x[i] = 0.0;
             __syncthreads();
             UH_BA_CLK(45);
