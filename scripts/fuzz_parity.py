@@ -215,30 +215,30 @@ run("projmatch_prev", pmprev_case)
 from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
 from ucoslam_cv3_amd.pnp import PnPSolver
 
-def ba_case(seed):
-    r = np.random.default_rng(seed)
-    K, P, nfix = int(r.integers(3, 16)), int(r.integers(40, 1500)), int(r.integers(1, 3))
-    pr = synth.ba_problem(K, P, seed % 100000, nfixed=min(nfix, K - 1), outlier_frac=float(r.choice([0.0, 0.02, 0.1])), pose_noise=float(r.choice([0.005, 0.01, 0.03])))
-    opt = GlobalOptimizer.create(ctx)
-    opt.setParams(pr, ParamSet(nIters=int(r.choice([5, 10]))))
-    opt.optimize()
-    g = opt.getResults()
-    o = oracle_lib.ba_optimize(L, pr, opt._params.n_iters if hasattr(opt, "_params") else None) if False else None
-    return True, None
+_ba_stream = GlobalOptimizer.create(ctx)   # ONE object takes every other problem: a keyframe stream (staging blocks regrown, table cells reused)
 
 def ba_case2(seed):
     r = np.random.default_rng(seed)
-    K, P, nfix = int(r.integers(3, 16)), int(r.integers(40, 1500)), int(r.integers(1, 3))
+    K, P, nfix = int(r.integers(3, 22)), int(r.integers(40, 1500)), int(r.integers(1, 3))   # 1..20 free keyframes: both persistent instantiations and the launch chain
     nit = int(r.choice([5, 10]))
     pr = synth.ba_problem(K, P, seed % 100000, nfixed=min(nfix, K - 1), outlier_frac=float(r.choice([0.0, 0.02, 0.1])), pose_noise=float(r.choice([0.005, 0.01, 0.03])))
-    opt = GlobalOptimizer.create(ctx)
-    opt.setParams(pr, ParamSet(nIters=nit))
+    if r.random() < 0.25: os.environ["UH_BA_NF"] = "16"   # the 16-lane instantiation also on windows of up to 8 free keyframes
+    else: os.environ.pop("UH_BA_NF", None)
+    opt = _ba_stream if r.random() < 0.5 else GlobalOptimizer.create(ctx)
+    staged = r.random() < 0.3
+    if staged:
+        dims = opt.fillStaging(pr)
+        opt.setParamsStaged(*dims, ParamSet(nIters=nit))
+    else:
+        opt.setParams(pr, ParamSet(nIters=nit))
+    form = opt.form()
     opt.optimize()
     g = opt.getResults()
+    os.environ.pop("UH_BA_NF", None)
     o = oracle_lib.ba_optimize(L, pr, nit)
     err = float(np.abs(g["state"] - o["state"]).max())
     ok = g["iters"].tolist() == o["iters"].tolist() and err < 1e-6 and (g["bad"] == o["bad"]).mean() > 0.999
-    return ok, (K, P, nfix, nit, g["iters"].tolist(), o["iters"].tolist(), err)
+    return ok, (K, P, nfix, nit, form, staged, g["iters"].tolist(), o["iters"].tolist(), err)
 
 run("ba", ba_case2)
 

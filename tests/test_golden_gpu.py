@@ -55,7 +55,7 @@ def _ba_problem(g):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["persistent", "legacy", "wide"])
+@pytest.mark.parametrize("form", ["persistent", "persistent16", "legacy", "wide"])
 def test_hip_ba_equals_real_g2o(hip_ctx, form, monkeypatch):
     """Both passes of GlobalOptimizerG2O::optimize on the committed problem: se3 state within 1e-6 of the REAL g2o's, identical
     outer-iteration counts, identical bad-association flags (every one of the 4197), per-observation chi2 within 1e-6 relative."""
@@ -63,11 +63,14 @@ def test_hip_ba_equals_real_g2o(hip_ctx, form, monkeypatch):
 
     if form == "legacy":
         monkeypatch.setenv("UH_BA_FORM", "legacy")
+    if form == "persistent16":
+        monkeypatch.setenv("UH_BA_NF", "16")          # the 9-16 free keyframe instantiation on the golden's six free keyframes
     if form == "wide":
         monkeypatch.setenv("UH_BA_WIDE", "1")
     g = np.load(os.path.join(GOLD, "ba_golden.npz"))
     opt = GlobalOptimizer.create(hip_ctx)
     opt.setParams(_ba_problem(g), ParamSet(nIters=5))
+    assert opt.form() == {"persistent": "persist8", "persistent16": "persist16", "legacy": "chain", "wide": "wide"}[form]
     opt.optimize()
     got = opt.getResults()
     assert got["iters"].tolist() == g["ref_iters"].tolist()

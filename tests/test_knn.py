@@ -271,3 +271,57 @@ def test_hip_knn_error_behaviour(hip_ctx):
         index.search(q, 2)
     with pytest.raises(u.UcoslamHipError):        # only 32-byte descriptors
         index.build(np.zeros((4, 61), np.uint8))
+
+
+@pytest.mark.gpu
+def test_hip_knn_at_the_bench_launch_shape(hip_ctx, oracle):
+    """Exactly the launch bench.py times: 4 x 2000 = 8000 query rows against a 10 000-row map, nn = 10, unsorted heap rows, device
+    buffers in and out through uh_knn_search_dev (the one-launch streaming form at this size)."""
+    import torch
+
+    import ucoslam_cv3_amd as u
+    from ucoslam_cv3_amd._lib import check, dev_ptr
+    from ucoslam_cv3_amd.knn import Index
+
+    train, q0 = synth.match_set(2000, 10000, seed=50)
+    q = np.concatenate([q0, synth.match_set(2000, 10000, seed=51)[1], synth.match_set(2000, 10000, seed=52)[1], q0[::-1]])
+    assert q.shape == (8000, 32)
+    index = Index(hip_ctx).build(torch.from_numpy(train).cuda())
+    dq = torch.from_numpy(q).cuda()
+    idx = torch.empty((8000, 10), dtype=torch.int32, device="cuda")
+    dist = torch.empty_like(idx)
+    for _ in range(2):   # twice: the second launch runs on the first one's tagged lists
+        check(u.lib().uh_knn_search_dev(index._h, dev_ptr(dq), 8000, 10, dev_ptr(idx), dev_ptr(dist), 0, -1))
+        torch.cuda.synchronize()
+        ri, rd = oracle_lib.knn_search(oracle, train, q, 10, 0)
+        np.testing.assert_array_equal(idx.cpu().numpy(), ri)
+        np.testing.assert_array_equal(dist.cpu().numpy(), rd)
+
+
+@pytest.mark.gpu
+def test_hip_knn_stream_form_overflow_then_regrown_lists(hip_ctx, oracle, monkeypatch):
+    """the one-launch form picks its overflow counter by tag parity and clears only the NEXT launch's slot.  A launch with an
+    odd tag whose lists all overflow (distances descending with the row index -> knn_redo_kernel), followed by a larger query set (the
+    list buffer is reallocated, the tag starts over at 1 = odd again): the stale count must not be replayed."""
+    from ucoslam_cv3_amd.knn import Index
+
+    monkeypatch.setenv("UH_KNN_FORM", "stream")
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, 32, dtype=np.uint8)
+    n = 700
+    bits = np.unpackbits(np.repeat(base[None, :], n, 0), axis=1)
+    for i in range(n):
+        bits[i, : max(0, 250 - i // 3)] ^= 1
+    train = np.packbits(bits, axis=1)
+    index = Index(hip_ctx).build(train)
+    q_small = np.repeat(base[None, :], 90, 0)
+    for rep in range(3):   # tags 1, 2, 3: the last overflowing launch has an odd tag
+        idx, dist = index.search(q_small, 10, sorted=False)
+        ri, rd = oracle_lib.knn_search(oracle, train, q_small, 10, 0)
+        np.testing.assert_array_equal(idx, ri)
+        np.testing.assert_array_equal(dist, rd)
+    _, q_big = synth.match_set(4000, n, seed=7)   # 44x the queries: list_buf regrows, the tag is reset; random rows: nothing overflows
+    idx, dist = index.search(q_big, 10, sorted=False)
+    ri, rd = oracle_lib.knn_search(oracle, train, q_big, 10, 0)
+    np.testing.assert_array_equal(idx, ri)
+    np.testing.assert_array_equal(dist, rd)

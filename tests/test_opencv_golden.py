@@ -1,0 +1,92 @@
+"""ORB / fbow against vectors recorded from the REAL OpenCV / fbow — when such vectors exist.
+
+The build container has neither OpenCV nor a buildable fbow, so tests/golden/orb_golden.npz and fbow_golden.npz can only be produced
+elsewhere (tests/golden/make_orb_golden.py, make_fbow_golden.py — one run each on a machine with OpenCV).  Until a file is committed
+these tests SKIP with the reason below and tests/conftest.py prints "PARITY UNPINNED" in the session summary: the ORB and fbow
+stages are then bit-exact against this repository's own restatements only (oracle/orb_oracle.cpp, bow_oracle.cpp), which is stated
+in README.md and DESIGN.md.  With the files present, the oracle is compared in the CPU suite and the HIP kernels in the GPU suite."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ORB_GOLD = os.path.join(GOLD, "orb_golden.npz")
+FBOW_GOLD = os.path.join(GOLD, "fbow_golden.npz")
+WHY_ORB = ("PARITY UNPINNED: tests/golden/orb_golden.npz is absent — no OpenCV in the build container; run tests/golden/make_orb_golden.py "
+           "where cv2 is importable and commit the file")
+WHY_FBOW = ("PARITY UNPINNED: tests/golden/fbow_golden.npz is absent — fbow needs OpenCV headers to compile; run tests/golden/make_fbow_golden.py "
+            "where OpenCV's development files exist and commit the file")
+
+
+def _orb_gold():
+    if not os.path.exists(ORB_GOLD):
+        pytest.skip(WHY_ORB)
+    return np.load(ORB_GOLD)
+
+
+def _fast_rows(xys):
+    """(x, y, score) rows in raster order, as cv::FAST emits them."""
+    a = np.asarray(xys, np.float32).reshape(-1, 3)
+    return a[np.lexsort((a[:, 0], a[:, 1]))]
+
+
+def test_oracle_orb_stages_equal_opencv(oracle):
+    g = _orb_gold()
+    nl, sc = int(g["nlevels"]), float(g["scale"])
+    for ci, (w, h, seed) in enumerate(g["cases"]):
+        img = synth.frame(int(w), int(h), seed=int(seed))
+        for lvl in range(nl):
+            want = g[f"c{ci}_level{lvl}"]
+            got = oracle_lib.orb_pyramid_level(oracle, img, lvl, nl, sc)
+            assert got.shape == want.shape, f"OpenCV {g['cv_version']}: level {lvl} size"
+            np.testing.assert_array_equal(got, want, err_msg=f"OpenCV {g['cv_version']}: case {ci} pyramid level {lvl} (blur / cubic resize)")
+            for th in (20, 7):
+                key = f"c{ci}_fast{th}_level{lvl}"
+                if key in g.files:
+                    mine = oracle_lib.fast_detect(oracle, want, th).astype(np.float32)
+                    np.testing.assert_array_equal(_fast_rows(mine), _fast_rows(g[key]), err_msg=f"cv::FAST threshold {th}, case {ci} level {lvl}")
+    import ctypes as C
+
+    oracle.oracle_fast_atan2.restype = C.c_float
+    oracle.oracle_fast_atan2.argtypes = [C.c_float, C.c_float]
+    got = np.array([oracle.oracle_fast_atan2(float(y), float(x)) for y, x in g["atan_yx"]], np.float32)
+    np.testing.assert_array_equal(got, g["atan_deg"], err_msg="cv::fastAtan2")
+
+
+@pytest.mark.gpu
+def test_hip_orb_pyramid_equals_opencv(hip_ctx):
+    from ucoslam_cv3_amd.orb import FeatParams, ORBextractor
+
+    g = _orb_gold()
+    nl, sc = int(g["nlevels"]), float(g["scale"])
+    ext = ORBextractor.create(hip_ctx)
+    for ci, (w, h, seed) in enumerate(g["cases"]):
+        img = synth.frame(int(w), int(h), seed=int(seed))
+        ext.detectAndCompute(img, None, FeatParams(2000, nl, sc))
+        for lvl in range(nl):
+            np.testing.assert_array_equal(ext.debug_level(0, lvl, 0), g[f"c{ci}_level{lvl}"], err_msg=f"OpenCV {g['cv_version']}: case {ci} level {lvl}")
+
+
+def test_oracle_fbow_equals_real_fbow(oracle):
+    if not os.path.exists(FBOW_GOLD):
+        pytest.skip(WHY_FBOW)
+    from test_bow import _oracle_transform
+
+    g = np.load(FBOW_GOLD)
+    word, weight, node, valid = _oracle_transform(oracle, g["params"].tobytes(), g["blob"].tobytes(), np.ascontiguousarray(g["desc"]), int(g["level"]))
+    bag = {}
+    for i in range(len(word)):
+        if word[i] != 0xFFFFFFFF:
+            bag[int(word[i])] = np.float32(bag.get(int(word[i]), np.float32(0)) + weight[i])
+    assert sorted(bag) == g["bag_ids"].tolist()
+    np.testing.assert_array_equal(np.array([bag[k] for k in sorted(bag)], np.float32), g["bag_weights"])
+    nodes = {}
+    for i in range(len(word)):
+        if valid[i]:
+            nodes.setdefault(int(node[i]), []).append(i)
+    assert sorted(nodes) == g["node_ids"].tolist()
+    assert np.concatenate([np.array(nodes[k], np.uint32) for k in sorted(nodes)]).tolist() == g["node_feats"].tolist()

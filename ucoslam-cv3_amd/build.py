@@ -52,6 +52,28 @@ def _run(cmd, **kw):
     return r.stdout
 
 
+def source_digest() -> str:
+    """SHA-256 over every source the HIP library is built from (csrc/ + include/): stored beside the library by build_hip() so that a
+    test session can tell a stale .so from a current one without trusting file times (snapshots do not preserve them)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h"))]
+    inc = os.path.join(REPO, "include")
+    for root, _, names in sorted(os.walk(inc)):
+        files += [os.path.join(root, f) for f in sorted(names) if f.endswith((".h", ".hpp", ".inc"))]
+    for f in files:
+        h.update(os.path.relpath(f, REPO).encode())
+        h.update(open(f, "rb").read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
+def library_is_current() -> bool:
+    stamp = LIB_PATH + ".srchash"
+    return os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == source_digest()
+
+
 def build_hip(verbose: bool = False) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
@@ -72,6 +94,8 @@ def build_hip(verbose: bool = False) -> str:
                     print(out)
     if jobs or _newer(objs, LIB_PATH):
         _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH, *objs])
+    with open(LIB_PATH + ".srchash", "w") as f:
+        f.write(source_digest() + "\n")
     return LIB_PATH
 
 
