@@ -433,7 +433,11 @@ def main():
         map0_np, _ = synth.match_set(1, NT, seed=50)                       # the SAME map on every rank, each keeps its tile
         tile = Index(ctx).build(torch.from_numpy(map0_np[b[rank]:b[rank + 1]].copy()).to(dev)).set_row_offset(b[rank])
         ext_s = ORBextractor.create(ctx)
-        stream = parallel.ShardedFrameStream(ext_s, fp, tile, NN, MAX_FEATURES, cand_cap=64)
+        # the stream below Python (uh_fstream_*, csrc/fstream.hip): producers write into the message, ONE RCCL all-gather per frame through
+        # the library's own communicator on the tracking stream, the replay reads the gathered lists in place, no host synchronisation
+        stream = parallel.ShardedFrameStreamDev(ctx, ext_s, fp, tile, NN, MAX_FEATURES, cand_cap=64, rank=rank, world=world, device=dev)
+        if world > 1:
+            stream.init_comm()
         sframes = [torch.from_numpy(synth.frame(W, H, seed=9000 + f, shift=(2 * f, f))).to(dev) for f in range(4)]
         for i in range(6):
             stream.step(sframes[i % 4])
@@ -445,11 +449,11 @@ def main():
             r = stream.step(sframes[i % 4])
         torch.cuda.synchronize()
         ts = time.perf_counter() - t0
-        ovf = int(r["overflow"]) if r["overflow"] is not None else 0
+        ovf = int(r["overflow"])
         tt = torch.tensor([ts], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         sharded = {"sharded_frame_ms": round(1e3 * float(tt.item()) / n_s, 4), "sharded_frames_per_s": round(n_s / float(tt.item()), 2),
-                   "collectives_per_frame": 1, "message_bytes_per_rank": stream.lay["total"], "train_rows_per_rank": b[rank + 1] - b[rank],
+                   "collectives_per_frame": 1, "message_bytes_per_rank": stream.message_bytes, "train_rows_per_rank": b[rank + 1] - b[rank],
                    "levels_of_rank0": list(parallel.level_ranges(W, H, NLEVELS, SCALE, world)[0]), "overflow": ovf}
         if rank == 0:   # the same frame stream un-sharded on one GPU: one frame per launch sequence + full search (latency form)
             full = Index(ctx).build(torch.from_numpy(map0_np).to(dev))

@@ -138,6 +138,11 @@ int uh_knn_set_row_offset(uh_knn* idx, int offset);
 int uh_knn_replay_tiles_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int sorted, int max_dist,
                             const uint64_t* d_cand_all, const int32_t* d_counts_all, int nshards, int cap,
                             int32_t* d_indices, int32_t* d_distances, int32_t* d_overflow);
+/* ... on lists that still sit inside gathered messages: shard s's blocks begin cand_stride (uint64 elements) / count_stride (int32
+ * elements) behind shard s-1's — what uh_fstream_finish_dev uses, nothing is unpacked before the replay */
+int uh_knn_replay_tiles_strided_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int sorted, int max_dist,
+                                    const uint64_t* d_cand_all, size_t cand_stride, const int32_t* d_counts_all, size_t count_stride,
+                                    int nshards, int cap, int32_t* d_indices, int32_t* d_distances, int32_t* d_overflow);
 
 /* ------------------------------------------------------------------------
  * ORB extractor — replaces ucoslam::ORBextractor behind Feature2DSerializable:
@@ -409,6 +414,46 @@ typedef struct uh_bowmatch uh_bowmatch;
 int  uh_bowmatch_create(uh_ctx* ctx, uh_bowmatch** out);
 void uh_bowmatch_destroy(uh_bowmatch* bm);
 int  uh_bowmatch_match(uh_bowmatch* bm, const uh_bow_match_args* args, uh_dmatch* out, int cap);
+
+/* ------------------------------------------------------------------------
+ * One frame stream sharded over the GPUs of a node (BASELINE config 5): pyramid levels of frame t, the map's train tiles
+ * and the fbow descent of frame t-1 sharded over `world` ranks (one process per GPU), ONE all-gather of fixed-size messages per frame.
+ * The producers write straight into the send buffer and the exact replay reads the gathered lists where they lie (csrc/fstream.hip);
+ * counts stay on the device, a step never synchronises with the host.  Results trail the input by one frame (software pipeline).
+ *   ext   an extractor with its FeatParams set (uh_orb_set_params); its level range is set per call
+ *   tile  a uh_knn built over THIS rank's rows [nt*rank/world, nt*(rank+1)/world) with uh_knn_set_row_offset(first global row)
+ *   voc   optional vocabulary (NULL: no bag-of-words slices in the message)
+ * The collective is RCCL's all-gather on the context's stream: uh_fstream_comm_unique_id on rank 0 -> the 128 bytes reach every rank by
+ * any host channel -> uh_fstream_comm_init everywhere (librccl is loaded with dlopen); or uh_fstream_set_comm with the host's own
+ * ncclComm_t; world == 1 needs neither.  uh_fstream_put_message serves hosts with another transport.
+ * ------------------------------------------------------------------------ */
+typedef struct uh_fstream uh_fstream;
+typedef struct uh_fstream_params {
+    int32_t rank, world;
+    int32_t nn;                     /* neighbours per query (FrameMatcher: 10) */
+    int32_t max_features;           /* = FeatParams::maxFeatures: rows per frame, queries per search */
+    int32_t cand_cap;               /* accept-list capacity per (query, tile); an overflow is reported, see d_overflow */
+    int32_t sorted;                 /* KnnSearchParams::sorted */
+    int32_t bow_level;              /* Vocabulary::transform level (keyframedatabase.cpp:319: 3) */
+} uh_fstream_params;
+int    uh_fstream_create(uh_ctx* ctx, uh_orb* ext, uh_knn* tile, uh_bow* voc, const uh_fstream_params* params, uh_fstream** out);
+void   uh_fstream_destroy(uh_fstream* fs);
+size_t uh_fstream_message_bytes(const uh_fstream* fs);
+void*  uh_fstream_send_buffer(uh_fstream* fs);      /* device, message_bytes */
+void*  uh_fstream_recv_buffer(uh_fstream* fs);      /* device, world x message_bytes, rank order */
+int    uh_fstream_comm_unique_id(uint8_t id_out[128]);
+int    uh_fstream_comm_init(uh_fstream* fs, const uint8_t id[128]);
+int    uh_fstream_set_comm(uh_fstream* fs, void* nccl_comm);
+int    uh_fstream_put_message(uh_fstream* fs, int rank, const void* d_message);
+/* step t: this rank's levels [level_first, level_end) of the frame (device image), its tile's accept lists and its fbow slice for frame t-1 */
+int    uh_fstream_local_dev(uh_fstream* fs, const uint8_t* d_frame, int w, int h, size_t stride, int level_first, int level_end);
+int    uh_fstream_exchange(uh_fstream* fs);
+/* frame t complete (d_kps / d_desc: max_features rows, *d_count valid) and frame t-1's rows (d_prev_*: max_features x nn, the first
+ * *d_prev_count valid; 0 on the first step) + its fbow triples (max_features each, or NULL).  *d_overflow: bit 0 an accept list exceeded
+ * cand_cap (retry the frame with a larger capacity), bit 1 a message header was out of range.  All pointers are device pointers. */
+int    uh_fstream_finish_dev(uh_fstream* fs, uh_keypoint* d_kps, uint8_t* d_desc, int32_t* d_count, int32_t* d_prev_indices,
+                             int32_t* d_prev_distances, int32_t* d_prev_count, uint32_t* d_bow_word, float* d_bow_weight, uint32_t* d_bow_node,
+                             uint8_t* d_bow_valid, int32_t* d_overflow);
 
 /* ------------------------------------------------------------------------
  * Pose-only optimisation — replaces PnPSolver::solvePnp (monocular matches, no markers):

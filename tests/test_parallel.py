@@ -352,3 +352,68 @@ def test_sharded_frame_stream_equals_single_gpu(hip_ctx, world):
         else:
             assert all(r["prev_indices"] is None for r in res)
         prev_desc = desc[0, :n].clone()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(640, 480, 1000, 3001, 2), (640, 480, 1000, 3001, 3), (1241, 376, 2000, 10000, 8), (1241, 376, 2000, 10000, 1)],
+                         ids=lambda c: f"{c[0]}x{c[1]}_{c[2]}f_{c[3]}rows_world{c[4]}")
+def test_sharded_frame_stream_below_python_equals_single_gpu(hip_ctx, cfg):
+    """The C-level stream (uh_fstream_*, csrc/fstream.hip: producers write into the message, the replay reads the gathered lists in
+    place, counts never leave the device) with `world` ranks played one after the other on this GPU — each with ONLY its tile of the
+    map, its own extractor and its level range; the all-gather replaced by uh_fstream_put_message — at BASELINE config 5's size
+    (1241 x 376, 2000 features, 10 000 map rows, 8 ranks) and smaller: features of frame t, kNN rows and fbow triples of frame t-1
+    identical to the single-GPU extraction / search / descent on every rank."""
+    import synth
+    from ucoslam_cv3_amd import parallel
+    from ucoslam_cv3_amd.bow import Vocabulary, write_vocabulary_stream
+    from ucoslam_cv3_amd.knn import Index
+    from ucoslam_cv3_amd.orb import FeatParams, ORBextractor
+
+    W, H, nf, nt, world = cfg
+    nn = 10
+    fp = FeatParams(nf, 8, 1.2)
+    train, _ = synth.match_set(1, nt, seed=5)
+    d_train = torch.from_numpy(train).cuda()
+    full = Index(hip_ctx).build(d_train)
+    params, blob, _ = synth.vocabulary(k=10, depth=4, seed=2)
+    voc = Vocabulary(hip_ctx).fromStream(write_vocabulary_stream(params, blob))
+    ref_ext = ORBextractor.create(hip_ctx)
+    b = parallel.shard_bounds(len(train), world)
+    streams = []
+    for r in range(world):
+        tile = Index(hip_ctx).build(d_train[b[r]:b[r + 1]].clone()).set_row_offset(b[r])
+        streams.append(parallel.ShardedFrameStreamDev(hip_ctx, ORBextractor.create(hip_ctx), fp, tile, nn, nf, cand_cap=96, vocabulary=voc, bow_level=3,
+                                                      rank=r, world=world))
+    prev_desc = None
+    for t in range(4):
+        frame = torch.from_numpy(synth.frame(W, H, seed=40 + t, shift=(3 * t, t))).cuda()
+        for s in streams:
+            s.local(frame)
+        if world == 1:
+            streams[0].exchange()                      # (world 1: the library's own path)
+        else:
+            for dst in streams:
+                for r, src in enumerate(streams):
+                    dst.put_message(r, src)
+        res = [s.finish() for s in streams]
+        torch.cuda.synchronize()
+        kps, desc, counts = ref_ext.extract_batch(frame[None], fp)
+        n = int(counts[0])
+        for o in res:
+            assert int(o["count"]) == n and int(o["overflow"]) == 0
+            assert o["kps"][:n].cpu().numpy().tobytes() == kps[0, :n].cpu().numpy().tobytes()
+            assert (o["desc"][:n] == desc[0, :n]).all()
+        if prev_desc is not None:
+            m = prev_desc.shape[0]
+            ri, rd = full.search(prev_desc, nn, sorted=False)
+            trip = voc.transform_triplets(prev_desc, 3)
+            for o in res:
+                assert int(o["prev_count"]) == m
+                assert (o["prev_indices"][:m] == ri).all() and (o["prev_distances"][:m] == rd).all()
+                got = torch.stack([o["bow_word"][:m], o["bow_weight"][:m].view(torch.int32), o["bow_node"][:m], o["bow_valid"][:m].to(torch.int32)], 1)
+                v = trip[:, 3] != 0
+                assert (got[:, 0] == trip[:, 0]).all() and (got[:, 1] == trip[:, 1]).all() and (got[:, 3] == trip[:, 3]).all()
+                assert (got[v, 2] == trip[v, 2]).all()
+        else:
+            assert all(int(o["prev_count"]) == 0 for o in res)
+        prev_desc = desc[0, :n].clone()

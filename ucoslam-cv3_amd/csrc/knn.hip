@@ -860,7 +860,8 @@ template <int LV>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_replay_kernel(
     const uint8_t* __restrict__ train, ShardBounds sb, const uint8_t* __restrict__ queries, int nq, int k,
     int sorted, int maxd, const uint64_t* __restrict__ cand_all, const int32_t* __restrict__ counts_all, int cap,
-    int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ overflow) {
+    int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ overflow,
+    size_t cand_shard_stride, size_t count_shard_stride) {   // elements between two shards' blocks (nq * cap / nq when they are packed; a gathered message's length otherwise)
     const int lane = threadIdx.x & (kWave - 1);
     const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (qi >= nq) return;
@@ -869,7 +870,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_replay_kernel(
     WaveHeap h{0, -1, 0, lane};
     int dummy = 0;
     for (int s = 0; s < sb.n; ++s) {
-        int cnt = __builtin_amdgcn_readfirstlane(counts_all[(size_t)s * nq + qi]);
+        int cnt = __builtin_amdgcn_readfirstlane(counts_all[(size_t)s * count_shard_stride + qi]);
         if (cnt > cap && overflow) {   // tile-only ranks cannot rescan another rank's rows: report, the caller retries with a larger cap
             if (lane == 0) atomicOr(overflow, 1);
             continue;
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_replay_kernel(
             scan_range<false, LV>(h, train, sb.b[s], sb.b[s + 1], q, k, maxd, nullptr, dummy, 0);
             continue;
         }
-        const uint64_t* row = cand_all + ((size_t)s * nq + qi) * cap;
+        const uint64_t* row = cand_all + (size_t)s * cand_shard_stride + (size_t)qi * cap;
         for (int base = 0; base < cnt; base += kWave) {
             int j = base + lane;
             bool valid = j < cnt;
@@ -1182,10 +1183,13 @@ struct uh_knn {
 
 // ancestor-walk depth of the lane-distributed heap by nn (see WaveHeap::push_accepted)
 static void launch_replay(uh_knn* idx, dim3 grid, dim3 block, const ShardBounds& sb, const uint8_t* d_queries, int nq, int nn, int sorted, int max_dist,
-                          const uint64_t* d_cand, const int32_t* d_counts, int cap, int32_t* d_indices, int32_t* d_distances, int* d_overflow) {
-    if (nn <= 3) UH_LAUNCH(idx->ctx, knn_replay_kernel<1>, grid, block, 0, idx->d_train, sb, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_cand, d_counts, cap, d_indices, d_distances, d_overflow);
-    else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_replay_kernel<3>, grid, block, 0, idx->d_train, sb, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_cand, d_counts, cap, d_indices, d_distances, d_overflow);
-    else UH_LAUNCH(idx->ctx, knn_replay_kernel<6>, grid, block, 0, idx->d_train, sb, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_cand, d_counts, cap, d_indices, d_distances, d_overflow);
+                          const uint64_t* d_cand, const int32_t* d_counts, int cap, int32_t* d_indices, int32_t* d_distances, int* d_overflow,
+                          size_t cand_stride = 0, size_t count_stride = 0) {
+    if (!cand_stride) cand_stride = (size_t)nq * cap;
+    if (!count_stride) count_stride = (size_t)nq;
+    if (nn <= 3) UH_LAUNCH(idx->ctx, knn_replay_kernel<1>, grid, block, 0, idx->d_train, sb, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_cand, d_counts, cap, d_indices, d_distances, d_overflow, cand_stride, count_stride);
+    else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_replay_kernel<3>, grid, block, 0, idx->d_train, sb, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_cand, d_counts, cap, d_indices, d_distances, d_overflow, cand_stride, count_stride);
+    else UH_LAUNCH(idx->ctx, knn_replay_kernel<6>, grid, block, 0, idx->d_train, sb, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_cand, d_counts, cap, d_indices, d_distances, d_overflow, cand_stride, count_stride);
 }
 
 extern "C" {
@@ -1452,6 +1456,27 @@ int uh_knn_replay_tiles_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int n
     UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
     dim3 grid(uh_div_up(nq, kWavesPerBlock)), block(kWave * kWavesPerBlock);
     launch_replay(idx, grid, block, sb, d_queries, nq, nn, sorted, max_dist, d_cand_all, d_counts_all, cap, d_indices, d_distances, (int*)d_overflow);
+    UH_HIP_CHECK(hipGetLastError());
+    return UH_OK;
+}
+
+// the same replay on lists that still sit inside the gathered messages: shard s's block begins cand_stride / count_stride ELEMENTS behind shard
+// s-1's (the sharded frame stream, csrc/fstream.hip: nothing is unpacked before the replay)
+int uh_knn_replay_tiles_strided_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int sorted, int max_dist,
+                                    const uint64_t* d_cand_all, size_t cand_stride, const int32_t* d_counts_all, size_t count_stride, int nshards, int cap,
+                                    int32_t* d_indices, int32_t* d_distances, int32_t* d_overflow) {
+    int rc = check_search_args(idx, d_queries, nq, nn, d_indices, d_distances);
+    if (rc) return rc;
+    UH_REQUIRE(nshards >= 1 && nshards <= kMaxShards, "uh_knn_replay_tiles_strided_dev: nshards=%d outside [1,%d]", nshards, kMaxShards);
+    UH_REQUIRE(cap >= 1 && d_cand_all && d_counts_all && d_overflow, "uh_knn_replay_tiles_strided_dev: bad candidate buffers");
+    UH_REQUIRE(nshards == 1 || (cand_stride >= (size_t)nq * cap && count_stride >= (size_t)nq), "uh_knn_replay_tiles_strided_dev: strides shorter than a shard's block");
+    if (nq == 0) return UH_OK;
+    ShardBounds sb;
+    sb.n = nshards;
+    for (int s = 0; s <= nshards; ++s) sb.b[s] = 0;
+    UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
+    dim3 grid(uh_div_up(nq, kWavesPerBlock)), block(kWave * kWavesPerBlock);
+    launch_replay(idx, grid, block, sb, d_queries, nq, nn, sorted, max_dist, d_cand_all, d_counts_all, cap, d_indices, d_distances, (int*)d_overflow, cand_stride, count_stride);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
 }

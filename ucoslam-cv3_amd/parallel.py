@@ -289,3 +289,133 @@ class ShardedFrameStream:
 
     def step(self, frame):
         return self.finish(gather_messages(self.local(frame), self.group))
+
+
+# ------------------------------------------------------------------------------------------------ the same stream below Python
+class _FStreamParams(__import__("ctypes").Structure):
+    _fields_ = [(n, __import__("ctypes").c_int32) for n in ("rank", "world", "nn", "max_features", "cand_cap", "sorted", "bow_level")]
+
+
+def _declare_fstream(L, sig):
+    import ctypes as C
+
+    from ._lib import I, VP
+
+    sig("uh_fstream_create", I, VP, VP, VP, VP, C.POINTER(_FStreamParams), C.POINTER(VP))
+    sig("uh_fstream_destroy", None, VP)
+    sig("uh_fstream_message_bytes", C.c_size_t, VP)
+    sig("uh_fstream_send_buffer", VP, VP)
+    sig("uh_fstream_recv_buffer", VP, VP)
+    sig("uh_fstream_comm_unique_id", I, VP)
+    sig("uh_fstream_comm_init", I, VP, VP)
+    sig("uh_fstream_set_comm", I, VP, VP)
+    sig("uh_fstream_put_message", I, VP, I, VP)
+    sig("uh_fstream_local_dev", I, VP, VP, I, I, C.c_size_t, I, I)
+    sig("uh_fstream_exchange", I, VP)
+    sig("uh_fstream_finish_dev", I, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP)
+
+
+from . import _lib as _lib_mod  # noqa: E402
+
+_lib_mod._EXTRA_DECLS.append(_declare_fstream)
+
+
+class ShardedFrameStreamDev:
+    """ShardedFrameStream on the C ABI (uh_fstream_*, csrc/fstream.hip): the producers write straight into the message, the replay reads
+    the gathered lists in place, the collective is RCCL's all-gather on the context's stream through the library's own communicator
+    (init_comm), counts stay on the device — a step is a handful of launches and never synchronises with the host.
+    step(frame) returns device tensors: kps [F,7] / desc [F,32] / count [1] of `frame`, and prev_indices / prev_distances [F,nn] /
+    prev_count [1] (+ bow_word / bow_weight / bow_node / bow_valid [F]) of the PREVIOUS frame; rows beyond a count are undefined."""
+
+    def __init__(self, ctx, extractor, params, tile_index, nn: int, max_features: int, cand_cap: int = 64, sorted: bool = False,
+                 vocabulary=None, bow_level: int = 3, rank: int = 0, world: int = 1, device=None):
+        import ctypes as C
+
+        import torch
+
+        from ._lib import VP, check, lib
+
+        self.ctx, self.ext, self.params, self.index, self.voc = ctx, extractor, params, tile_index, vocabulary
+        self.rank, self.world, self.nn, self.F = rank, world, nn, max_features
+        check(lib().uh_orb_set_params(extractor._h, C.byref(params)))
+        p = _FStreamParams(rank, world, nn, max_features, cand_cap, int(sorted), bow_level)
+        self._h = VP()
+        check(lib().uh_fstream_create(ctx.handle, extractor._h, tile_index._h, vocabulary._h if vocabulary is not None else None, C.byref(p), C.byref(self._h)))
+        self.message_bytes = int(lib().uh_fstream_message_bytes(self._h))
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        F = max_features
+        self.out = dict(kps=torch.zeros((F, 7), dtype=torch.float32, device=dev), desc=torch.zeros((F, 32), dtype=torch.uint8, device=dev),
+                        count=torch.zeros(1, dtype=torch.int32, device=dev), prev_indices=torch.zeros((F, nn), dtype=torch.int32, device=dev),
+                        prev_distances=torch.zeros((F, nn), dtype=torch.int32, device=dev), prev_count=torch.zeros(1, dtype=torch.int32, device=dev),
+                        overflow=torch.zeros(1, dtype=torch.int32, device=dev))
+        if vocabulary is not None:
+            self.out.update(bow_word=torch.zeros(F, dtype=torch.int32, device=dev), bow_weight=torch.zeros(F, dtype=torch.float32, device=dev),
+                            bow_node=torch.zeros(F, dtype=torch.int32, device=dev), bow_valid=torch.zeros(F, dtype=torch.uint8, device=dev))
+        self._ranges = {}
+
+    def init_comm(self, group=None):
+        """The library's own RCCL communicator over the ranks of `group`: rank 0 draws the unique id, torch.distributed carries the
+        128 bytes (a host channel), every rank joins."""
+        import ctypes as C
+
+        import torch.distributed as dist
+
+        from ._lib import check, lib
+
+        ident = [None]
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            check(lib().uh_fstream_comm_unique_id(buf))
+            ident = [bytes(buf)]
+        dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        buf = (C.c_uint8 * 128).from_buffer_copy(ident[0])
+        check(lib().uh_fstream_comm_init(self._h, buf))
+        return self
+
+    def local(self, frame):
+        from ._lib import check, dev_ptr, lib
+
+        H, W = frame.shape
+        key = (W, H)
+        if key not in self._ranges:
+            self._ranges[key] = level_ranges(W, H, self.params.nOctaveLevels, self.params.scaleFactor, self.world)[self.rank]
+        first, end = self._ranges[key]
+        check(lib().uh_fstream_local_dev(self._h, dev_ptr(frame), W, H, frame.stride(0), first, end))
+
+    def exchange(self):
+        from ._lib import check, lib
+
+        check(lib().uh_fstream_exchange(self._h))
+
+    def put_message(self, rank: int, other: "ShardedFrameStreamDev"):
+        """(tests: several ranks played on one GPU) `other`'s message into this rank's receive buffer."""
+        from ._lib import check, lib
+
+        check(lib().uh_fstream_put_message(self._h, rank, lib().uh_fstream_send_buffer(other._h)))
+
+    def finish(self):
+        from ._lib import check, dev_ptr, lib
+
+        o = self.out
+        bow = [dev_ptr(o[k]) for k in ("bow_word", "bow_weight", "bow_node", "bow_valid")] if self.voc is not None else [None] * 4
+        check(lib().uh_fstream_finish_dev(self._h, dev_ptr(o["kps"]), dev_ptr(o["desc"]), dev_ptr(o["count"]), dev_ptr(o["prev_indices"]),
+                                          dev_ptr(o["prev_distances"]), dev_ptr(o["prev_count"]), *bow, dev_ptr(o["overflow"])))
+        return o
+
+    def step(self, frame):
+        self.local(frame)
+        self.exchange()
+        return self.finish()
+
+    def close(self):
+        from ._lib import VP, lib
+
+        if self._h:
+            lib().uh_fstream_destroy(self._h)
+            self._h = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
