@@ -183,6 +183,25 @@ int  uh_orb_get_params(const uh_orb* orb, uh_feat_params* params);
  * the grid-extractor type tags. */
 int  uh_orb_to_stream(const uh_orb* orb, const char* str_params, uint8_t* out, uint64_t cap, uint64_t* size);
 int  uh_orb_from_stream(uh_orb* orb, const uint8_t* data, uint64_t nbytes, char* str_params_out, uint64_t str_cap, uint64_t* consumed);
+/* FrameExtractor::toStream / fromStream (src/utils/frameextractor.cpp:651-884 / :886-1136, signature 1923123): the extractor block of a
+ * reference `.slm` checkpoint — the Feature2DSerializable stream above, the frame counter, three flags, marker size, the FeatParams in
+ * use, maxDescDistance, then the aruco::MarkerDetector stream (3rdparty/aruco/aruco/markerdetector.cpp:256-277, behind u64 13213) and the
+ * ucoslam::Params stream (src/ucoslamtypes.cpp:63-121).  The two trailing sub-streams belong to subsystems that stay with the host:
+ * fromStream walks them and reports where they lie (offsets / lengths into `data`), toStream writes the bytes it is given verbatim or,
+ * with NULL, what the reference's default-constructed objects write.  The HIP extractor detects no markers: detect_markers = 1 needs
+ * the host's own detector stream on writing and allow_markers on reading, and is refused otherwise. */
+typedef struct uh_frame_extractor_state {
+    uint32_t counter;               /* frames processed so far */
+    uint8_t  remove_from_markers, detect_markers, detect_keypoints;
+    float    marker_size;           /* Params::aruco_markerSize */
+    uh_feat_params feat_params;     /* the FeatParams the extractor is run with */
+    float    max_desc_distance;     /* Params::maxDescDistance */
+} uh_frame_extractor_state;
+int  uh_frame_extractor_to_stream(const uh_orb* orb, const char* str_params, const uh_frame_extractor_state* state, const uint8_t* aruco_stream,
+                                  uint64_t aruco_bytes, const uint8_t* params_stream, uint64_t params_bytes, uint8_t* out, uint64_t cap, uint64_t* size);
+int  uh_frame_extractor_from_stream(uh_orb* orb, const uint8_t* data, uint64_t nbytes, int allow_markers, uh_frame_extractor_state* state,
+                                    char* str_params_out, uint64_t str_cap, uint64_t* aruco_off, uint64_t* aruco_bytes, uint64_t* params_off,
+                                    uint64_t* params_bytes, uint64_t* consumed);
 int  uh_orb_set_blur(uh_orb* orb, int do_blur);            /* ORBextractor::doGaussianBlur() (ORBextractor.h:112) */
 int  uh_orb_set_sensitivity(uh_orb* orb, float v);         /* ORBextractor::setSensitivity (ORBextractor.cpp:457-466) */
 int  uh_orb_set_nonmaxima(uh_orb* orb, int on);            /* debug string "orb_nonmaxima" (ORBextractor.cpp:1146-1148,1176-1205): radius-3

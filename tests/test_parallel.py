@@ -417,3 +417,37 @@ def test_sharded_frame_stream_below_python_equals_single_gpu(hip_ctx, cfg):
         else:
             assert all(int(o["prev_count"]) == 0 for o in res)
         prev_desc = desc[0, :n].clone()
+
+
+@pytest.mark.gpu
+def test_fstream_exchange_through_rccl_with_one_rank(hip_ctx):
+    """The library's own RCCL path (librccl resolved with dlopen, ncclGetUniqueId -> ncclCommInitRank -> ncclAllGather on the context's
+    stream) with the one rank a 1-GPU box has: the results must equal the world-1 copy path's.  (More ranks need more GPUs: the
+    driver's multi-GPU bench is the first run of that.)"""
+    import ctypes as C
+
+    import synth
+    import ucoslam_cv3_amd as u
+    from ucoslam_cv3_amd import parallel
+    from ucoslam_cv3_amd.knn import Index
+    from ucoslam_cv3_amd.orb import FeatParams, ORBextractor
+
+    fp = FeatParams(1000, 8, 1.2)
+    train, _ = synth.match_set(1, 2000, seed=9)
+    d_train = torch.from_numpy(train).cuda()
+    outs = []
+    for use_rccl in (False, True):
+        s = parallel.ShardedFrameStreamDev(hip_ctx, ORBextractor.create(hip_ctx), fp, Index(hip_ctx).build(d_train), 10, 1000, cand_cap=96)
+        if use_rccl:
+            ident = (C.c_uint8 * 128)()
+            u._lib.check(u.lib().uh_fstream_comm_unique_id(ident))
+            u._lib.check(u.lib().uh_fstream_comm_init(s._h, ident))
+        res = []
+        for t in range(3):
+            o = s.step(torch.from_numpy(synth.frame(640, 480, seed=70 + t, shift=(2 * t, t))).cuda())
+            torch.cuda.synchronize()
+            n, m = int(o["count"]), int(o["prev_count"])
+            res.append((n, m, o["kps"][:n].cpu().numpy().tobytes(), o["desc"][:n].cpu().numpy().tobytes(), o["prev_indices"][:m].cpu().numpy().tobytes(),
+                        o["prev_distances"][:m].cpu().numpy().tobytes(), int(o["overflow"])))
+        outs.append(res)
+    assert outs[0] == outs[1] and outs[0][2][0] > 300 and outs[0][2][1] > 300

@@ -64,3 +64,84 @@ def test_kmeans_index_stream_equals_real_xflann_bytes(hip_ctx, case):
         Index(hip_ctx).fromStream(ref_stream[: len(ref_stream) // 2])
     with pytest.raises(u.UcoslamHipError):
         Index(hip_ctx).build(train).toStream()                               # Linear: no stream form (reference: "Not yet")
+
+
+# ------------------------------------------------------------------------------------------------ FrameExtractor (.slm extractor block)
+def _str(s: bytes) -> bytes:
+    return struct.pack("<I", len(s)) + s
+
+
+def _ref_aruco_stream(detect_mode=0, min_size=-1.0, dictionary=b"ALL_DICTS", corner=0) -> bytes:
+    """aruco::MarkerDetector::toStream, field by field as 3rdparty/aruco/aruco/markerdetector.cpp:256-277 writes it behind MarkerDetector_Impl's
+    u64 13213 (defaults: markerdetector.h:162-195; `ts` goes out with sizeof(pyrfactor) = 4 bytes)."""
+    return (struct.pack("<Q", 13213) + struct.pack("<iifi", detect_mode, 1, np.float32(0.015), 20) + struct.pack("<fi", np.float32(min_size), -1) + struct.pack("<B", 0)
+            + struct.pack("<iiiiiii", 0, 3, -1, 7, 0, 5, corner) + struct.pack("<B", 0) + struct.pack("<ffi", np.float32(0.25), 0.0, 0) + _str(dictionary))
+
+
+def _ref_params_stream(detect_markers=1, detect_kp=1, remove_kp_in_markers=1, max_desc=np.finfo(np.float32).max, marker_size=1.0, max_features=4000,
+                       n_levels=8, scale=1.2, run_sequential=0, extra=b"") -> bytes:
+    """ucoslam::Params::toStream, field by field as src/ucoslamtypes.cpp:63-121 writes it (defaults: Params::Params() :23-53 and ucoslamtypes.h:90-153)."""
+    f = np.float32
+    return (struct.pack("<Q", 9837138769928) + struct.pack("<BBffBi", detect_markers, detect_kp, f(-1), f(0.6), 0, 350)
+            + struct.pack("<BBfffiiii", 0, remove_kp_in_markers, f(max_desc), f(0.01), f(marker_size), 15, 2, 10, 3)
+            + struct.pack("<ffiifb", f(0.8), f(0.9), max_features, n_levels, f(scale), 1)
+            + struct.pack("<fiBfBfi", f(3), 3, 0, f(0.07), run_sequential, f(0.5), 5)
+            + _str(b"g2o") + _str(b"ARUCO_MIP_36h12") + _str(b"DM_NORMAL") + _str(b"CORNER_SUBPIX")
+            + struct.pack("<ffBBBB", f(0), f(1), 0, 1, 1, 0) + _str(extra) + struct.pack("<Q", 1837138769921))
+
+
+def _ref_frame_extractor_stream(feat_stream: bytes, counter, flags, marker_size, fp, max_desc, aruco: bytes, params: bytes) -> bytes:
+    """FrameExtractor::toStream (src/utils/frameextractor.cpp:651-884)."""
+    return (struct.pack("<Q", 1923123) + feat_stream + struct.pack("<I", counter) + struct.pack("<BBB", *flags) + struct.pack("<f", np.float32(marker_size))
+            + struct.pack("<iiiff", *fp) + struct.pack("<f", np.float32(max_desc)) + aruco + params)
+
+
+@pytest.mark.gpu
+def test_frame_extractor_stream_against_a_writer_that_follows_the_reference(hip_ctx):
+    """FrameExtractor::toStream / fromStream (sig 1923123): bytes equal to a field-by-field writer of the cited lines, for the marker-less
+    configuration (default ArUco / Params sub-streams) and for a stream carrying the host's own detector and parameter blocks; round trips;
+    the reference's error behaviour; the marker refusal."""
+    import ucoslam_cv3_amd as u
+    from ucoslam_cv3_amd.orb import FeatParams, FrameExtractorState, ORBextractor
+
+    ext = ORBextractor.create(hip_ctx)
+    fp = FeatParams(2000, 8, 1.2, nthreads=2)
+    u._lib.check(u.lib().uh_orb_set_params(ext._h, fp))
+    feat = ext.toStream("")
+    # ---- marker-less: the sub-streams are what default-constructed reference objects write (with the members the state fixes)
+    st = FrameExtractorState(17, 0, 0, 1, np.float32(1.0), fp, np.float32(50.0))
+    got = ext.frameExtractorToStream(st)
+    want = _ref_frame_extractor_stream(feat, 17, (0, 0, 1), 1.0, (2, 2000, 8, np.float32(1.2), np.float32(0)), 50.0, _ref_aruco_stream(),
+                                       _ref_params_stream(detect_markers=0, detect_kp=1, remove_kp_in_markers=0, max_desc=50.0, marker_size=1.0, max_features=2000))
+    assert got == want
+    ext2, st2, sp, aru, par, used = ORBextractor.frameExtractorFromStream(hip_ctx, got + b"the rest of the .slm stream")
+    assert used == len(got) and sp == "" and aru == _ref_aruco_stream() and par == want[len(want) - len(par):]
+    assert (st2.counter, st2.remove_from_markers, st2.detect_markers, st2.detect_keypoints) == (17, 0, 0, 1)
+    assert st2.marker_size == np.float32(1.0) and st2.max_desc_distance == np.float32(50.0) and st2.feat_params.maxFeatures == 2000
+    g = ext2.getParams()
+    assert (g.nthreads, g.maxFeatures, g.nOctaveLevels) == (2, 2000, 8) and g.scaleFactor == np.float32(1.2)
+    assert ext2.frameExtractorToStream(st2, sp, aru, par) == got
+    # ---- a checkpoint of a marker-using session: the host's detector / parameter blocks travel verbatim; reading needs allow_markers
+    aruco = _ref_aruco_stream(detect_mode=1, min_size=0.02, dictionary=b"ARUCO_MIP_36h12", corner=1)
+    params = _ref_params_stream(run_sequential=1, extra=b"some extra=1")
+    ref = _ref_frame_extractor_stream(feat, 5, (1, 1, 1), 0.12, (2, 2000, 8, np.float32(1.2), np.float32(0)), 50.0, aruco, params)
+    with pytest.raises(u.UcoslamHipError, match="marker detection"):
+        ORBextractor.frameExtractorFromStream(hip_ctx, ref)
+    ext3, st3, sp3, aru3, par3, used3 = ORBextractor.frameExtractorFromStream(hip_ctx, ref, allow_markers=True)
+    assert used3 == len(ref) and aru3 == aruco and par3 == params and st3.detect_markers == 1 and st3.marker_size == np.float32(0.12)
+    assert ext3.frameExtractorToStream(st3, sp3, aru3, par3) == ref
+    with pytest.raises(u.UcoslamHipError, match="no marker-detector stream"):
+        ext3.frameExtractorToStream(st3)
+    # ---- the reference's refusals
+    with pytest.raises(u.UcoslamHipError, match="invalid signature"):
+        ORBextractor.frameExtractorFromStream(hip_ctx, struct.pack("<Q", 1923124) + got[8:])
+    with pytest.raises(u.UcoslamHipError, match="signature error"):
+        ORBextractor.frameExtractorFromStream(hip_ctx, got[:8] + struct.pack("<Q", 7) + got[16:])
+    with pytest.raises(u.UcoslamHipError):
+        ORBextractor.frameExtractorFromStream(hip_ctx, got[: len(got) - 9])                     # the Params end signature is cut off
+    bad = bytearray(got)
+    bad[len(got) - len(par) - len(aru)] ^= 1                                                       # MarkerDetector_Impl's signature
+    with pytest.raises(u.UcoslamHipError, match="MarkerDetector_Impl"):
+        ORBextractor.frameExtractorFromStream(hip_ctx, bytes(bad))
+    with pytest.raises(u.UcoslamHipError, match="not a ucoslam::Params stream"):
+        ext.frameExtractorToStream(st, "", None, params[:-3])

@@ -28,7 +28,16 @@ class FeatParams(C.Structure):
         super().__init__(nthreads, maxFeatures, nOctaveLevels, scaleFactor, sensitivity)
 
 
+class FrameExtractorState(C.Structure):
+    """uh_frame_extractor_state: what FrameExtractor::toStream writes between the extractor's own stream and the two sub-streams."""
+    _fields_ = [("counter", C.c_uint32), ("remove_from_markers", C.c_uint8), ("detect_markers", C.c_uint8), ("detect_keypoints", C.c_uint8),
+                ("marker_size", C.c_float), ("feat_params", FeatParams), ("max_desc_distance", C.c_float)]
+
+
 def _declare(L, sig):
+    sig("uh_frame_extractor_to_stream", I, VP, C.c_char_p, C.POINTER(FrameExtractorState), VP, C.c_uint64, VP, C.c_uint64, VP, C.c_uint64, C.POINTER(C.c_uint64))
+    sig("uh_frame_extractor_from_stream", I, VP, VP, C.c_uint64, I, C.POINTER(FrameExtractorState), VP, C.c_uint64, C.POINTER(C.c_uint64),
+        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
     sig("uh_orb_to_stream", I, VP, C.c_char_p, VP, C.c_uint64, C.POINTER(C.c_uint64))
     sig("uh_orb_from_stream", I, VP, VP, C.c_uint64, VP, C.c_uint64, C.POINTER(C.c_uint64))
     sig("uh_orb_create", I, VP, C.POINTER(VP))
@@ -150,6 +159,29 @@ class ORBextractor:
         used = C.c_uint64()
         check(lib().uh_orb_from_stream(ext._h, np_ptr(buf), len(buf), sp, len(sp), C.byref(used)))
         return ext, sp.value.decode(), used.value
+
+    # FrameExtractor::toStream / fromStream (frameextractor.cpp:651-1136): the extractor block of a reference .slm checkpoint
+    def frameExtractorToStream(self, state: "FrameExtractorState", str_params: str = "", aruco: bytes | None = None, params: bytes | None = None) -> bytes:
+        size = C.c_uint64()
+        a = np.frombuffer(aruco, np.uint8) if aruco else None
+        p = np.frombuffer(params, np.uint8) if params else None
+        args = (self._h, str_params.encode(), C.byref(state), np_ptr(a) if a is not None else None, len(aruco or b""), np_ptr(p) if p is not None else None, len(params or b""))
+        check(lib().uh_frame_extractor_to_stream(*args, None, 0, C.byref(size)))
+        out = np.zeros(size.value, np.uint8)
+        check(lib().uh_frame_extractor_to_stream(*args, np_ptr(out), size.value, C.byref(size)))
+        return out.tobytes()
+
+    @staticmethod
+    def frameExtractorFromStream(ctx: _lib.Context, data: bytes, allow_markers: bool = False):
+        """-> (extractor, FrameExtractorState, str_params, aruco sub-stream bytes, Params sub-stream bytes, bytes consumed)."""
+        ext = ORBextractor(ctx)
+        buf = np.frombuffer(data, np.uint8)
+        st = FrameExtractorState()
+        sp = C.create_string_buffer(4096)
+        ao, ab, po, pb, used = (C.c_uint64() for _ in range(5))
+        check(lib().uh_frame_extractor_from_stream(ext._h, np_ptr(buf), len(buf), int(allow_markers), C.byref(st), sp, len(sp), C.byref(ao), C.byref(ab),
+                                                   C.byref(po), C.byref(pb), C.byref(used)))
+        return ext, st, sp.value.decode(), data[ao.value:ao.value + ab.value], data[po.value:po.value + pb.value], used.value
 
     def close(self):
         if self._h:
