@@ -166,18 +166,27 @@ def main():
 
     # One keyframe interval through the plugin boundary.  Mapper thread (the BA object's worker, uh_ba_solve_async): setParams on a
     # FRESH problem + optimize.  Tracker thread (this one): frames in, ORB, match, results out, then getResults of the mapper's BA.
+    # (the C entry points with their argument tuples built once: the harness is Python, the path it times is not)
+    import ctypes as C
+    solve_args = [(ba._h, C.byref(pr_[0]), 0, 0, 0, C.byref(ba_ps), None) for pr_ in ba_prepared]
+    get_args = (ba._h, np_ptr(ba_out["poses"]), np_ptr(ba_out["points"]), None, np_ptr(ba_out["bad"]), np_ptr(ba_out["iters"]))
+    knn_args = (index._h, dev_ptr(desc_v), F * NQ, NN, dev_ptr(knn_idx), dev_ptr(knn_dist), 0, -1)
+    cap_kp = max(L.uh_orb_max_keypoints(ext._h), 1)
+    orb_args = (ext._h, dev_ptr(frames), W, H, W, W * H, F, dev_ptr(kps_v), dev_ptr(desc_v), cap_kp, dev_ptr(cnt_v))
+    trk_stream = torch.cuda.current_stream()
+
     def step():
-        pr = ba_prepared[step_no[0] % N_PROB]
+        i = step_no[0] % N_PROB
         step_no[0] += 1
-        ba.solve_async(pr, ba_ps)
-        frames.copy_(frames_host, non_blocking=True)
-        kps, desc, counts = ext.extract_batch(frames, fp, orb_out)
+        check(L.uh_ba_solve_async(*solve_args[i]))                  # mapper thread: setParams (fresh problem) + optimize
+        frames.copy_(frames_host, non_blocking=True)                # tracker: 4 frames in
+        check(L.uh_orb_extract_dev(*orb_args))
         # the F frames' descriptor blocks are contiguous [F, 2000, 32]: one launch matches all F x 2000 queries against the map
-        check(L.uh_knn_search_dev(index._h, dev_ptr(desc), F * NQ, NN, dev_ptr(knn_idx), dev_ptr(knn_dist), 0, -1))
-        out_host.copy_(out_dev, non_blocking=True)
-        ba.wait()
-        check(L.uh_ba_get_results(ba._h, np_ptr(ba_out["poses"]), np_ptr(ba_out["points"]), None, np_ptr(ba_out["bad"]), np_ptr(ba_out["iters"])))
-        torch.cuda.current_stream().synchronize()   # the tracker owns its host buffers again
+        check(L.uh_knn_search_dev(*knn_args))
+        out_host.copy_(out_dev, non_blocking=True)                  # keypoints, descriptors, counts, match rows out
+        check(L.uh_ba_wait(ba._h))
+        check(L.uh_ba_get_results(*get_args))                       # tracker thread: getResults of the mapper's BA
+        trk_stream.synchronize()                                    # the tracker owns its host buffers again
 
     # rounds 1-2's step, kept as stages.kernel_only_*: frames resident in HBM, ONE problem re-optimised, nothing returns to the host
     ba_res = GlobalOptimizer.create(ctx_ba)
