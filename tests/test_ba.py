@@ -105,7 +105,9 @@ def test_oracle_edge_jacobian_central_differences(oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [(10, 3000, 0, 2), (6, 400, 1, 1), (4, 150, 2, 2), (12, 1500, 3, 3), (3, 60, 4, 3), (30, 1200, 5, 2), (22, 900, 6, 2), (14, 700, 7, 2),
                                  # the 16-lane persistent instantiation: 9 / 10 free keyframes (one row per lane in the solve), 11 / 13 / 16 (two rows per lane)
-                                 (11, 3000, 8, 2), (12, 800, 9, 2), (13, 600, 10, 2), (15, 2500, 11, 2), (18, 1000, 12, 2), (18, 3000, 13, 2), (17, 40, 14, 1)],
+                                 (11, 3000, 8, 2), (12, 800, 9, 2), (13, 600, 10, 2), (15, 2500, 11, 2), (18, 1000, 12, 2), (18, 3000, 13, 2), (17, 40, 14, 1),
+                                 # the launch chain's two-rows-per-lane solve at its limits: 17 and 21 free keyframes (127 rows)
+                                 (19, 900, 15, 2), (23, 1100, 16, 2)],
                          ids=lambda c: f"K{c[0]}_P{c[1]}_fix{c[3]}")
 def test_hip_ba_matches_oracle(hip_ctx, oracle, cfg):
     from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet

@@ -21,12 +21,12 @@
 //           or lambda *= nu, iteration/termination logic) to the state — same sums, same code, same result everywhere;
 //           workgroup 0 publishes it.  Then one workgroup per (camera i1 <= i2, landmark chunk): partial Hpl D^-1 Hpl^T
 //           blocks of the reduced system; plus the camera workgroups (Hpp, bp) on every trial but the first
-//   backsub prologue in EVERY workgroup (reduced system in LDS, n <= 120): S = Hpp + lambda I - sum of partials, blocked
+//   backsub prologue in EVERY workgroup (reduced system in LDS, n <= 126): S = Hpp + lambda I - sum of partials, blocked
 //           look-ahead LDL^T, substitution, pose update T <- exp(dx) T into the trial buffer — 94 identical solves in
 //           parallel instead of a one-workgroup launch.  Then 8 lanes per landmark: dx_l = D^-1 (b_l - Hpl^T dx_p), trial
 //           point, trial errors, partial chi2 / scale sums, and speculatively the linearisation AT THE TRIAL estimate into
 //           the trial half of the double-buffered Hll/bl/Hpl: accepting a trial flips estimate and linearisation together
-//   solve   stand-alone one-workgroup form of the solve for systems that need the HBM workspace (120 < n <= 384)
+//   solve   stand-alone one-workgroup form of the solve for systems that need the HBM workspace (126 < n <= 384)
 //   decide  stand-alone form of the decision, closes a round of enqueued steps (one wave)
 // (Folding solve and decide into the LAST-FINISHING workgroup of their producer launch — the threadfence-reduction pattern —
 // was measured and rejected: the agent-scope fences write back / invalidate the per-XCD L2s once per workgroup and cost
@@ -876,6 +876,8 @@ __device__ __forceinline__ void backsolve2_lds(const double* M, int n, int ld, d
 __device__ __forceinline__ bool ldlt_bordered_lds(double* M, int n, int ld, int nfree, int npairs, const short (*s_pair)[2],
                                                   double (*s_w)[121][6]) {
     if (n + 1 <= 64 && !UH_LDLT_LEGACY) return ldlt_rowlane_lds(M, n, ld, nfree, npairs, s_pair, &s_w[0][0][0]);   // (uniform)
+    // 65..128 rows (11-21 free cameras): two rows per lane; the caller's panel buffer must hold 2 x 6 x 128 + 2 doubles (s_w[2][129][6])
+    if (n + 1 <= 128 && !UH_LDLT_LEGACY) return ldlt_rowlane2_lds(M, n, ld, nfree, npairs, s_pair, &s_w[0][0][0]);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool active = tid < kSolveThreads;
     bool failed = false;
@@ -1038,7 +1040,7 @@ __device__ __forceinline__ void backsolve_lds(const double* M, int n, int ld, do
 
 // ------------------------------------------------------------------------------------------------ solve + pose update
 // One workgroup.  Assembles S = Hpp + lambda I - sum of the schur partials (chunk order), factorises it as L D L^T (no
-// pivoting; fails on a zero / non-finite pivot like Eigen's SimplicialLDLT) in LDS when it fits (n <= 120) else in HBM,
+// pivoting; fails on a zero / non-finite pivot like Eigen's SimplicialLDLT) in LDS when it fits (n <= 126) else in HBM,
 // substitutes, and writes T_trial = exp(dx) * T_cur for the free poses.  Row stride is n+1 doubles (odd) so that column
 // walks are LDS-bank-conflict free.
 struct SolveOut { bool done; int ok, cur; double lambda; };   // done: the pass had finished, nothing was computed
@@ -1153,7 +1155,8 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     // diagonal.
     bool failed = false;
     if constexpr (USE_LDS) {
-        __shared__ double s_w[2][121][6];
+        __shared__ double s_w_store[2][129][6];   // ([2][121][6] for the look-ahead form; the two-rows-per-lane form's panel buffer is [2][6][128] + alignment)
+        double (*s_w)[121][6] = reinterpret_cast<double (*)[121][6]>(&s_w_store[0][0][0]);
         failed = ldlt_bordered_lds(M, n, ld, d.nfree, npairs, s_pair, s_w);
     } else {
         __shared__ double s_w[6 * kMaxFree][6];
@@ -1277,6 +1280,11 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                 if (lane < n) { s_x[lane] = x; p.xp[lane] = x; }
             }
         } else {
+            if (USE_LDS && n <= 128) {   // two unknowns per lane of wave 0, one broadcast per column (the loop below: two barriers per column)
+                backsolve2_lds(M, n, ld, s_x);
+                __syncthreads();
+                for (int i = tid; i < n; i += kSolveThreads) p.xp[i] = s_x[i];
+            } else {
             if constexpr (USE_LDS) {   // z = D^-1 L^-1 b is row n of the bordered factorisation
                 for (int i = tid; i < n; i += kSolveThreads) s_x[i] = M[(size_t)n * ld + i];
             } else {
@@ -1296,6 +1304,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                 __syncthreads();
             }
             for (int i = tid; i < n; i += kSolveThreads) p.xp[i] = s_x[i];
+            }
         }
     } else {
         for (int i = tid; i < n; i += kSolveThreads) { p.xp[i] = 0.0; s_x[i] = 0.0; }
@@ -1309,7 +1318,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     out.done = false; out.ok = ok; out.cur = cur; out.lambda = lambda;
 }
 
-// stand-alone form: reduced systems too large for LDS (n > 120) factorise in the HBM workspace p.S, which only one
+// stand-alone form: reduced systems too large for LDS (n > 126) factorise in the HBM workspace p.S, which only one
 // workgroup may use
 template <bool USE_LDS>
 __global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADims d, int nsplit, int slot) {
@@ -1608,7 +1617,7 @@ __global__ __launch_bounds__(256) void ba_posew_kernel(BAPtrs p, BADims d, BAWid
 }
 
 // ------------------------------------------------------------------------------------------------ backsub + trial errors
-// FUSED (reduced system in LDS, n <= 120): every workgroup first solves the reduced system itself — the same assembly,
+// FUSED (reduced system in LDS, n <= 126): every workgroup first solves the reduced system itself — the same assembly,
 // factorisation and substitution in all of them, ~22 us that would otherwise be a one-workgroup launch of its own — keeps dx_p
 // in LDS and goes on with its landmarks.  All workgroups write identical trial poses / xp / solve_ok.  Saves one kernel
 // boundary and the dependent reloads behind it per LM trial.
@@ -1949,7 +1958,7 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
     hipStream_t st = b->ctx->stream;
     const BADims& d = b->dims;
     const int npairs = d.nfree * (d.nfree + 1) / 2;
-    const int use_lds = d.n <= 120 ? 1 : 0;
+    const int use_lds = d.n <= 126 ? 1 : 0;   // (21 free cameras: 127 rows = the two-rows-per-lane factorisation's limit; 129 KB of LDS)
     const size_t lds = use_lds ? (size_t)(d.n + 1) * (d.n + 1) * sizeof(double) : 0;   // n rows of S + the right-hand-side row
     for (int s = 0; s < nsteps; s++) {
         const int slot = b->step & 1;   // state left by the previous step (or by begin_pass / the closing decide kernel)
@@ -2254,6 +2263,9 @@ static int set_problem_tables(uh_ba* b, const uh_ba_problem* pr) {
     const size_t o_Hpp = A.take<double>(27 * (size_t)kCamChunks * std::max(nfree, 1)), o_bp = A.take<double>(std::max(d.n, 1));
     const int npairs_h = nfree * (nfree + 1) / 2;
     b->nsplit = std::max(1, std::min(kMaxSplit, uh_div_up(P, kThreads)));
+    // every workgroup of the back-substitution launch assembles ALL npairs x nsplit partials itself: with many camera pairs fewer, fatter
+    // landmark chunks win (measured, 3000 landmarks: 17 / 20 / 32 free cameras 2.20 / 2.90 / 9.9 ms with 12 chunks, 1.77 / 2.14 / 7.3 with 2)
+    if (npairs_h > 32) b->nsplit = std::max(1, std::min(b->nsplit, uh_div_up(384, npairs_h)));
     if (const char* e = getenv("UH_BA_NSPLIT")) b->nsplit = std::max(1, std::min(kMaxSplit, atoi(e)));   // tuning knob (measurement only)
     const size_t o_S = A.take<double>((size_t)(d.n + 1) * (d.n + 1)), o_Sp = A.take<double>(wide ? 42 : (size_t)b->nsplit * std::max(npairs_h, 1) * 42), o_xp = A.take<double>(std::max(d.n, 1));
     const size_t wn_pairs = w_pair_s1.size(), wn_items = w_item_pair.size(), wn_tri = w_tri_pt.size();

@@ -868,8 +868,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             if (tid == 0) s_flag[0] = 1;
             __syncthreads();
             UH_BA_CLK(43);
-            const bool failed = (NF == 8 || n + 1 <= 64) ? ldlt_bordered_lds(Mm, n, ld, nfree, npairs, s_pair, s_w)
-                                                        : ldlt_rowlane2_lds(Mm, n, ld, nfree, npairs, s_pair, &s_w[0][0][0]);
+            const bool failed = ldlt_bordered_lds(Mm, n, ld, nfree, npairs, s_pair, s_w);   // (row-per-lane up to 64 rows, two rows per lane up to 128)
             if (failed && tid == 0) s_flag[0] = 0;
             __syncthreads();
             UH_BA_CLK(44);
