@@ -278,6 +278,22 @@ def main():
             step_resident()
         stage_ms["kernel_only_step_ms"] = timed(step_resident, 30)
         stage_ms["kernel_only_frames_per_s"] = 1e3 * F / stage_ms["kernel_only_step_ms"]
+        # the same keyframe loop from a C++ host over the C ABI (examples/track_stream.cpp: its own synthetic inputs, host buffers in and
+        # out through uh_orb_extract_batch / uh_knn_search, no Python anywhere in the step) — compiled here with g++ if there is one
+        try:
+            import shutil, subprocess, tempfile
+            if shutil.which("g++"):
+                libdir = os.path.join(ROOT, "ucoslam-cv3_amd")
+                exe = os.path.join(tempfile.mkdtemp(prefix="uh_cpp_"), "track_stream")
+                subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(ROOT, "examples", "track_stream.cpp"), "-L", libdir, "-lucoslam_hip",
+                                       f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                torch.cuda.synchronize()
+                r_ = json.loads(subprocess.run([exe, str(args.steps), "9"], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
+                stage_ms["cpp_host_step_ms"] = r_["ms_per_step"]
+                stage_ms["cpp_host_frames_per_s"] = r_["frames_per_s"]
+        except Exception as e_:   # (a side measurement: never fails the bench)
+            stage_ms["cpp_host_step_ms"] = None
+            print("cpp host stage skipped:", repr(e_), file=sys.stderr)
         # the second frame size north_star asks for: the same step (4 frames, one kNN launch, one local BA) on 640x480 frames
         fr2 = torch.from_numpy(np.stack([synth.frame(640, 480, seed=77 + f, shift=(2 * f, f)) for f in range(F)])).to(dev)
         ext2 = ORBextractor.create(ctx)

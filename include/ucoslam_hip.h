@@ -44,6 +44,9 @@ int         uh_ctx_create_private(int device, uh_ctx** out);
 void        uh_ctx_destroy(uh_ctx* ctx);
 int         uh_ctx_synchronize(uh_ctx* ctx);
 void*       uh_ctx_stream(uh_ctx* ctx);
+/* pinned host memory for the buffers handed to the host-pointer entry points (asynchronous DMA instead of staged copies) */
+void*       uh_host_alloc(size_t bytes);
+void        uh_host_free(void* p);
 const char* uh_last_error(void);
 /* Per-kernel timing for measurement (bench.py roofline leg): when enabled every kernel launch of the stage objects
  * bound to this context is bracketed by HIP events on the context stream.  report: "<kernel> <calls> <total_ms>\n" lines. */
@@ -223,6 +226,10 @@ int uh_orb_extract(uh_orb* orb, const uint8_t* img, int w, int h, size_t stride,
  * d_kps + f*cap_per_frame, d_desc + f*cap_per_frame*32, d_counts[f].  Asynchronous on the context stream. */
 int uh_orb_extract_dev(uh_orb* orb, const uint8_t* d_imgs, int w, int h, size_t stride, size_t frame_stride,
                        int batch, uh_keypoint* d_kps, uint8_t* d_desc, int cap_per_frame, int32_t* d_counts);
+/* The same for `batch` frames in HOST memory, results to host memory (fixed-capacity blocks: frame f's rows at kps + f*cap, desc + f*cap*32,
+ * counts[f] of them valid; cap >= maxFeatures): one H2D copy, the batched launch set, three D2H copies, one synchronisation. */
+int uh_orb_extract_batch(uh_orb* orb, const uint8_t* imgs, int w, int h, size_t stride, size_t frame_stride, int batch,
+                         uh_keypoint* kps, uint8_t* desc, int cap, int32_t* counts);
 /* Verification tap: copy level `level` of frame `frame` (which: 0 pyramid, 1 FAST strength map) to `out`
  * (w*h bytes, may be NULL to query the size). */
 int uh_orb_debug_level(uh_orb* orb, int frame, int level, int which, uint8_t* out, int* w_out, int* h_out);

@@ -18,7 +18,9 @@ ctx_bg = u.Context(0, private=True)
 g = np.load(os.path.join(R, "tests", "golden", "ba_golden.npz"))
 pr = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
 big = synth.ba_problem(10, 3000, 0)
-stop = False
+wide16 = synth.ba_problem(14, 1500, 3)     # 12 free keyframes: the 16-lane instantiation (two rows per lane in the solve)
+keep = GlobalOptimizer.create(ctx_ba)      # every other optimisation goes through ONE long-lived object (a keyframe stream: staging blocks,
+stop = False                               # table cells and exchange buffers reused), the others through fresh ones
 
 
 def background():
@@ -45,8 +47,8 @@ t0 = time.time()
 n, bad = 0, 0
 first = {}
 while time.time() - t0 < budget:
-    for name, prob in (("golden", pr), ("bench", big)):
-        opt = GlobalOptimizer.create(ctx_ba)
+    for name, prob in (("golden", pr), ("bench", big), ("persist16", wide16)):
+        opt = keep if (n // 3) % 2 else GlobalOptimizer.create(ctx_ba)
         opt.setParams(prob, ParamSet(nIters=5))
         opt.optimize()
         got = opt.getResults()

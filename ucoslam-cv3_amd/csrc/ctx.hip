@@ -143,4 +143,13 @@ int uh_debug_background(uh_ctx* ctx, int mode, int blocks, int iters, const void
 
 void* uh_ctx_stream(uh_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
 
+// Pinned host memory for the buffers a host hands to the host-pointer entry points (frames in, keypoints / rows out): copies from / to it
+// are true asynchronous DMA; pageable memory works everywhere too, through the runtime's staging
+void* uh_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { uh::set_error("uh_host_alloc(%zu): hipHostMalloc failed", bytes); return nullptr; }
+    return p;
+}
+void uh_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 }  // extern "C"

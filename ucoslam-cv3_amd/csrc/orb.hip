@@ -1548,6 +1548,35 @@ int uh_orb_extract(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, u
     return UH_OK;
 }
 
+// detectAndCompute for a BATCH of frames, host memory in and out (the tracker's call shape when frames arrive in groups, and what a
+// C++ host without device buffers of its own uses): one H2D copy of the frames, the batched launch set, one D2H copy each of the
+// fixed-capacity keypoint / descriptor blocks and the counts, one synchronisation.  Frame f's rows are kps + f * cap, desc + f * cap * 32,
+// the first counts[f] of them valid.  Pinned buffers (uh_host_alloc) make the copies asynchronous DMA.
+int uh_orb_extract_batch(uh_orb* o, const uint8_t* imgs, int w, int h, size_t stride, size_t frame_stride, int batch, uh_keypoint* kps, uint8_t* desc,
+                         int cap, int32_t* counts) {
+    UH_REQUIRE(o && imgs && kps && desc && counts, "uh_orb_extract_batch: NULL argument");
+    UH_REQUIRE(w > 0 && h > 0 && batch >= 1 && stride >= (size_t)w && frame_stride >= stride * (size_t)(h - 1) + (size_t)w, "uh_orb_extract_batch: bad geometry");
+    const int maxk = std::max(o->fp.maxFeatures, 1);
+    UH_REQUIRE(cap >= maxk, "uh_orb_extract_batch: capacity %d below maxFeatures %d", cap, maxk);
+    int rc;
+    UH_HIP_CHECK(hipSetDevice(o->ctx->device));
+    hipStream_t st = o->ctx->stream;
+    if ((rc = o->d_in.reserve((size_t)w * h * batch))) return rc;
+    if ((rc = o->d_kps.reserve((size_t)cap * batch * sizeof(uh_keypoint)))) return rc;
+    if ((rc = o->d_desc.reserve((size_t)cap * batch * 32))) return rc;
+    if ((rc = o->d_counts.reserve((size_t)batch * 4 + 16))) return rc;
+    if (stride == (size_t)w && frame_stride == (size_t)w * h) UH_HIP_CHECK(hipMemcpyAsync(o->d_in.p, imgs, (size_t)w * h * batch, hipMemcpyHostToDevice, st));
+    else for (int f = 0; f < batch; f++)
+        UH_HIP_CHECK(hipMemcpy2DAsync(o->d_in.as<uint8_t>() + (size_t)f * w * h, w, imgs + (size_t)f * frame_stride, stride, w, h, hipMemcpyHostToDevice, st));
+    rc = run_frames(o, o->d_in.as<uint8_t>(), w, h, w, (size_t)w * h, batch, o->d_kps.as<KeyPointOut>(), o->d_desc.as<uint8_t>(), cap, o->d_counts.as<int>());
+    if (rc) return rc;
+    UH_HIP_CHECK(hipMemcpyAsync(kps, o->d_kps.p, (size_t)cap * batch * sizeof(uh_keypoint), hipMemcpyDeviceToHost, st));
+    UH_HIP_CHECK(hipMemcpyAsync(desc, o->d_desc.p, (size_t)cap * batch * 32, hipMemcpyDeviceToHost, st));
+    UH_HIP_CHECK(hipMemcpyAsync(counts, o->d_counts.p, (size_t)batch * 4, hipMemcpyDeviceToHost, st));
+    UH_HIP_CHECK(hipStreamSynchronize(st));
+    return UH_OK;
+}
+
 // Debug/verification taps (tests compare every stage with the oracle): copies one level of one frame's pyramid or
 // score map to the host.  which: 0 = pyramid, 1 = FAST strength map.
 int uh_orb_debug_level(uh_orb* o, int frame, int level, int which, uint8_t* out, int* w_out, int* h_out) {
