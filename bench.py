@@ -450,53 +450,55 @@ def main():
         stage_ms["serial_frames_per_s"] = 1e3 / t_serial
 
     # ---- sharded frame stream (N > 1): levels + train tiles sharded, each rank holding ONLY its tile, ONE fused all-gather per frame
-    sharded = None
-    if dist is not None and (world > 1 or os.environ.get("UH_BENCH_SHARDED")):   # (the env switch exercises the stage with one rank)
-        from ucoslam_cv3_amd import parallel
+    def run_sharded():
+        sharded = None
+        if dist is not None and (world > 1 or os.environ.get("UH_BENCH_SHARDED")):   # (the env switch exercises the stage with one rank)
+            from ucoslam_cv3_amd import parallel
 
-        b = parallel.shard_bounds(NT, world)
-        map0_np, _ = synth.match_set(1, NT, seed=50)                       # the SAME map on every rank, each keeps its tile
-        tile = Index(ctx).build(torch.from_numpy(map0_np[b[rank]:b[rank + 1]].copy()).to(dev)).set_row_offset(b[rank])
-        ext_s = ORBextractor.create(ctx)
-        # the stream below Python (uh_fstream_*, csrc/fstream.hip): producers write into the message, ONE RCCL all-gather per frame through
-        # the library's own communicator on the tracking stream, the replay reads the gathered lists in place, no host synchronisation
-        stream = parallel.ShardedFrameStreamDev(ctx, ext_s, fp, tile, NN, MAX_FEATURES, cand_cap=64, rank=rank, world=world, device=dev)
-        if world > 1:
-            stream.init_comm()
-        sframes = [torch.from_numpy(synth.frame(W, H, seed=9000 + f, shift=(2 * f, f))).to(dev) for f in range(4)]
-        for i in range(6):
-            stream.step(sframes[i % 4])
-        sync_all()
-        n_s = 40
-        t0 = time.perf_counter()
-        ovf = 0
-        for i in range(n_s):
-            r = stream.step(sframes[i % 4])
-        torch.cuda.synchronize()
-        ts = time.perf_counter() - t0
-        ovf = int(r["overflow"])
-        tt = torch.tensor([ts], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        sharded = {"sharded_frame_ms": round(1e3 * float(tt.item()) / n_s, 4), "sharded_frames_per_s": round(n_s / float(tt.item()), 2),
-                   "collectives_per_frame": 1, "message_bytes_per_rank": stream.message_bytes, "train_rows_per_rank": b[rank + 1] - b[rank],
-                   "levels_of_rank0": list(parallel.level_ranges(W, H, NLEVELS, SCALE, world)[0]), "overflow": ovf}
-        if rank == 0:   # the same frame stream un-sharded on one GPU: one frame per launch sequence + full search (latency form)
-            full = Index(ctx).build(torch.from_numpy(map0_np).to(dev))
-            one = sframes[0][None]
-            o1 = ext_s.extract_batch(one, fp)
-
-            def single():
-                k, d_, c = ext_s.extract_batch(one, fp, o1)
-                full.search(d_[0], NN)
-
-            for _ in range(3):
-                single()
-            torch.cuda.synchronize()
+            b = parallel.shard_bounds(NT, world)
+            map0_np, _ = synth.match_set(1, NT, seed=50)                       # the SAME map on every rank, each keeps its tile
+            tile = Index(ctx).build(torch.from_numpy(map0_np[b[rank]:b[rank + 1]].copy()).to(dev)).set_row_offset(b[rank])
+            ext_s = ORBextractor.create(ctx)
+            # the stream below Python (uh_fstream_*, csrc/fstream.hip): producers write into the message, ONE RCCL all-gather per frame through
+            # the library's own communicator on the tracking stream, the replay reads the gathered lists in place, no host synchronisation
+            stream = parallel.ShardedFrameStreamDev(ctx, ext_s, fp, tile, NN, MAX_FEATURES, cand_cap=64, rank=rank, world=world, device=dev)
+            if world > 1:
+                stream.init_comm()
+            sframes = [torch.from_numpy(synth.frame(W, H, seed=9000 + f, shift=(2 * f, f))).to(dev) for f in range(4)]
+            for i in range(6):
+                stream.step(sframes[i % 4])
+            sync_all()
+            n_s = 40
             t0 = time.perf_counter()
-            for _ in range(n_s):
-                single()
+            ovf = 0
+            for i in range(n_s):
+                r = stream.step(sframes[i % 4])
             torch.cuda.synchronize()
-            sharded["single_gpu_frame_ms"] = round(1e3 * (time.perf_counter() - t0) / n_s, 4)
+            ts = time.perf_counter() - t0
+            ovf = int(r["overflow"])
+            tt = torch.tensor([ts], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sharded = {"sharded_frame_ms": round(1e3 * float(tt.item()) / n_s, 4), "sharded_frames_per_s": round(n_s / float(tt.item()), 2),
+                       "collectives_per_frame": 1, "message_bytes_per_rank": stream.message_bytes, "train_rows_per_rank": b[rank + 1] - b[rank],
+                       "levels_of_rank0": list(parallel.level_ranges(W, H, NLEVELS, SCALE, world)[0]), "overflow": ovf}
+            if rank == 0:   # the same frame stream un-sharded on one GPU: one frame per launch sequence + full search (latency form)
+                full = Index(ctx).build(torch.from_numpy(map0_np).to(dev))
+                one = sframes[0][None]
+                o1 = ext_s.extract_batch(one, fp)
+
+                def single():
+                    k, d_, c = ext_s.extract_batch(one, fp, o1)
+                    full.search(d_[0], NN)
+
+                for _ in range(3):
+                    single()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n_s):
+                    single()
+                torch.cuda.synchronize()
+                sharded["single_gpu_frame_ms"] = round(1e3 * (time.perf_counter() - t0) / n_s, 4)
+        return sharded
 
     # ---- CPU baseline (rank 0, N=1 only): bounded sample of the same workload on the host cores, in the shapes SURVEY §8(d) asks for
     cpu = None
@@ -586,11 +588,39 @@ def main():
             "ba_lm_iterations": ba_iters if rank == 0 else None,
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        if sharded:
-            line["stages"].update({k: v for k, v in sharded.items()})
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 2)
             line["gpu_serial_over_cpu"] = round(stage_ms["serial_frames_per_s"] / cpu["value"], 2)
+
+    def emit_and_exit(code=0):
+        # RCCL writes its version banner through C stdio, which a pipe buffers until exit: drain it first so that the JSON
+        # line is the LAST line on stdout
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        os._exit(code)
+
+    # The sharded stage is a SIDE measurement whose collective has never run on more than one GPU anywhere: it runs last, under a
+    # watchdog, so that neither an exception nor a hang in it can cost the headline line (measured above, assembled already).
+    if dist is not None and (world > 1 or os.environ.get("UH_BENCH_SHARDED")):
+        import threading
+
+        dog = threading.Timer(120.0, lambda: (line["stages"].update({"sharded_error": "timed out after 120 s"}) if rank == 0 else None, emit_and_exit(0)))
+        dog.daemon = True
+        dog.start()
+        try:
+            sharded = run_sharded()
+            if rank == 0 and sharded:
+                line["stages"].update({k: v for k, v in sharded.items()})
+        except Exception as e_:
+            if rank == 0:
+                line["stages"]["sharded_error"] = repr(e_)[:300]
+            print("sharded stage failed:", repr(e_), file=sys.stderr)
+            dog.cancel()
+            emit_and_exit(0)   # (the other ranks may be inside a collective: no barrier, leave at once)
+        dog.cancel()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -601,6 +631,8 @@ def main():
 
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)
+    else:
+        line = None
 
 
 if __name__ == "__main__":
