@@ -106,7 +106,7 @@ struct TWord { pword lo, hi; };
 // written whole, and a reader still validates each half by its own tag) — half the store instructions and half the fabric writes of
 // two 8-byte stores (the exchange was 80 MB of 8-byte fabric writes per optimisation).
 __device__ __forceinline__ void tst(pword* base, size_t i, double v, unsigned tag) {
-    const pword b = (pword)__double_as_longlong(v), t = (pword)tag << 32;
+    const pword b = (pword)__double_as_longlong(v);
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 w = {(unsigned)b, tag, (unsigned)(b >> 32), tag};
     // (a buffer store through the builtin, not inline asm: the compiler must know this is a memory instruction that reads its data
@@ -329,7 +329,6 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     double* const s_bp = lds + o.bp;
     double* const s_bs = lds + o.bs;
     double* const s_bsp = lds + o.bsp;
-    double* const s_wv = lds + o.wv;
     double* const s_pose = lds + o.pose;
     double* const s_poseR = lds + o.poseR;
     double* const s_red = lds + o.red;
@@ -460,13 +459,6 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
 #pragma unroll
             for (int u = 0; u < 8; u++) { if (u < cnt) { ok = ok && tok(w[u], tag); v[u] = tval(w[u]); } else v[u] = 0.0; }
             if (ok || give_up(t0)) return;
-        }
-    };
-    auto tload1 = [&](const pword* base, size_t i, unsigned tag) -> double {
-        long long t0 = 0;
-        for (;;) {
-            const TWord w = tld_raw(base, i);
-            if (tok(w, tag) || give_up(t0)) return tval(w);
         }
     };
     auto part_at = [&](int i) -> size_t { const int sl = i / SL; return ((size_t)sl * G + g) * SL + (i - sl * SL); };   // element i of this workgroup's partial

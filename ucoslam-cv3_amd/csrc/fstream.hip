@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void fstream_unpack_kernel(const uint8_t* __re
                                                              uint8_t* __restrict__ bow_valid, int have_bow, int32_t* __restrict__ overflow,
                                                              const int32_t* __restrict__ prev_count_src, int32_t* __restrict__ prev_count_dst) {
     const int r = blockIdx.y;
-    __shared__ int s_off, s_cnt, s_total;
+    __shared__ int s_off, s_cnt;
     if (threadIdx.x == 0) {
         int off = 0, total = 0, mine = 0;
         bool clipped = false;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void fstream_unpack_kernel(const uint8_t* __re
             if (i == r) mine = c;
             total += c;
         }
-        s_off = off; s_cnt = mine; s_total = total;
+        s_off = off; s_cnt = mine;
         if (clipped && overflow) atomicOr(overflow, 2);
         if (r == 0 && blockIdx.x == 0) {
             if (prev_count_dst) *prev_count_dst = prev_count_src ? *prev_count_src : 0;   // (read before count_b is written: they may be the same row of the pair)

@@ -39,7 +39,7 @@ constexpr int kNmsTileBytes = 16384;     // cell_nms: LDS staging of one cell's 
 constexpr int kNmsPatchBytes = 20480;    // cell_nms (fused with the FAST strength): the cell's pixels + a 3-pixel frame
 constexpr int kSelThreads = 1024;       // selection workgroup: 16 waves share one level's cells
 constexpr int kSelWaves = kSelThreads / 64;
-constexpr int PATCH_SIZE = 31, HALF_PATCH = 15, EDGE = 19;
+constexpr int PATCH_SIZE = 31, EDGE = 19;
 
 struct LevelDesc {
     int w, h, pitch;
@@ -71,8 +71,7 @@ struct Plan {           // uploaded once per (size, params)
 };
 
 __device__ const signed char d_pattern[1024] = {UH_ORB_PATTERN_VALUES};
-__device__ const int d_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-// the 749 pixels of that disc as (v << 8 | u & 255), padded to 12 x 64 with the centre (u = v = 0 adds nothing to either moment):
+// the 749 pixels of the radius-15 disc (row half-widths umax = 15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3, ORBextractor.cpp:436-451) as (v << 8 | u & 255), padded to 12 x 64 with the centre (u = v = 0 adds nothing to either moment):
 // describe_kernel's lanes take twelve pixels each, all loads in flight together, instead of 31 lanes walking a row each
 struct DiscTable { short uv[768]; };
 constexpr DiscTable make_disc_table() {
