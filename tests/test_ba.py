@@ -429,3 +429,35 @@ def test_hip_ba_table_sequence_wrap(hip_ctx):
             opt.optimize()
     opt.setParams(big, ParamSet(nIters=5)); opt.optimize()
     assert _sig(opt.getResults()) == want
+
+
+@pytest.mark.gpu
+def test_hip_ba_compact_and_full_observation_records_agree(hip_ctx, monkeypatch):
+    """uh_ba_set_problem sends 16-byte records {point | frame << 24, u, v, (float)inv_sigma} when every information scalar is float-exact
+    (a third fewer bytes over the host link) and 24-byte records otherwise: same results bit for bit; a problem with ONE inexact scalar
+    takes the 24-byte form by itself."""
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    for cfg in ((10, 3000, 0, 2), (13, 901, 4, 2), (5, 77, 2, 1)):
+        pr = synth.ba_problem(*cfg[:3], nfixed=cfg[3])
+        sigs = []
+        for force24 in (False, True):
+            if force24:
+                monkeypatch.setenv("UH_BA_OBS24", "1")
+            else:
+                monkeypatch.delenv("UH_BA_OBS24", raising=False)
+            opt = GlobalOptimizer.create(hip_ctx)
+            opt.setParams(pr, ParamSet(nIters=5))
+            opt.optimize()
+            sigs.append(_sig(opt.getResults()))
+        assert sigs[0] == sigs[1]
+        monkeypatch.delenv("UH_BA_OBS24", raising=False)
+        odd = dict(pr)
+        odd["obs_w"] = pr["obs_w"].copy()
+        odd["obs_w"][len(odd["obs_w"]) // 2] = 1.0 / 3.0          # not a float: the whole problem goes out as 24-byte records
+        a, b = GlobalOptimizer.create(hip_ctx), GlobalOptimizer.create(hip_ctx)
+        a.setParams(odd, ParamSet(nIters=5)); a.optimize()
+        monkeypatch.setenv("UH_BA_OBS24", "1")
+        b.setParams(odd, ParamSet(nIters=5)); b.optimize()
+        monkeypatch.delenv("UH_BA_OBS24", raising=False)
+        assert _sig(a.getResults()) == _sig(b.getResults())

@@ -1800,10 +1800,12 @@ __global__ void ba_init_state_kernel(BAPtrs p, BADims d, const double* __restric
 // A (point, frame) pair that occurs twice (g2o would add two edges; this solver owns one lane per pair) and an index out of range
 // are reported through a pinned word the host reads after the optimisation: err[0] = 1 out of range / 2 duplicate, err[1] = observation.
 __global__ __launch_bounds__(256) void ba_ingest_kernel(const uh_ba_obs* __restrict__ obs, int E, int P, int K, unsigned* __restrict__ T, unsigned tseq,
-                                                        unsigned* err) {
+                                                        unsigned* err, int obs16) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= E) return;
-    const int pt = obs[e].point, kf = obs[e].frame;
+    int pt, kf;
+    if (obs16) { const unsigned w = reinterpret_cast<const unsigned*>(obs)[4 * (size_t)e]; pt = (int)(w & 0xFFFFFFu); kf = (int)(w >> 24); }
+    else { pt = obs[e].point; kf = obs[e].frame; }
     unsigned code = 0;
     if ((unsigned)pt >= (unsigned)P || (unsigned)kf >= (unsigned)K) code = 1;
     else {
@@ -1820,20 +1822,27 @@ __global__ __launch_bounds__(256) void ba_ingest_kernel(const uh_ba_obs* __restr
 // mirrors it into HBM (header + points as 16-byte words, observations as 24-byte records) and scatters the table cells from the
 // records it has in registers — one launch instead of a DMA + a launch.
 __global__ __launch_bounds__(256) void ba_ingest_direct_kernel(const unsigned char* __restrict__ host, unsigned char* __restrict__ dev, size_t head_bytes, size_t obs_off,
-                                                               int E, int P, int K, unsigned* __restrict__ T, unsigned tseq, unsigned* err, int head_blocks) {
+                                                               int E, int P, int K, unsigned* __restrict__ T, unsigned tseq, unsigned* err, int head_blocks, int obs16) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     if ((int)blockIdx.x < head_blocks) {   // header + frame arrays + points: [0, head_bytes), a multiple of 16
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
         const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
         if (i < head_bytes) *reinterpret_cast<u32x4*>(dev + i) = *reinterpret_cast<const u32x4*>(host + i);
         return;
     }
     const int e = ((int)blockIdx.x - head_blocks) * 256 + threadIdx.x;
     if (e >= E) return;
-    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(host + obs_off) + 3 * (size_t)e;
-    const unsigned long long w0 = src[0], w1 = src[1], w2 = src[2];
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(dev + obs_off) + 3 * (size_t)e;
-    dst[0] = w0; dst[1] = w1; dst[2] = w2;
-    const int pt = (int)(unsigned)w0, kf = (int)(unsigned)(w0 >> 32);
+    int pt, kf;
+    if (obs16) {   // 16-byte records: a third fewer bytes over the host link, which is what this kernel's time is made of
+        const u32x4 r = reinterpret_cast<const u32x4*>(host + obs_off)[e];
+        reinterpret_cast<u32x4*>(dev + obs_off)[e] = r;
+        pt = (int)(r.x & 0xFFFFFFu); kf = (int)(r.x >> 24);
+    } else {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(host + obs_off) + 3 * (size_t)e;
+        const unsigned long long w0 = src[0], w1 = src[1], w2 = src[2];
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(dev + obs_off) + 3 * (size_t)e;
+        dst[0] = w0; dst[1] = w1; dst[2] = w2;
+        pt = (int)(unsigned)w0; kf = (int)(unsigned)(w0 >> 32);
+    }
     unsigned code = 0;
     if ((unsigned)pt >= (unsigned)P || (unsigned)kf >= (unsigned)K) code = 1;
     else {
@@ -2115,10 +2124,12 @@ int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, 
     b->done_base += 2u * (unsigned)q.G;
     const unsigned* h_err = reinterpret_cast<const unsigned*>(b->h_stop + 200);
     if (h_err[0]) {   // left by ba_ingest_kernel (it ran in front of this launch on the same stream)
-        const uh_ba_obs* ob = reinterpret_cast<const uh_ba_obs*>(b->h_stage + b->slay.obs);
         const unsigned e = h_err[1] < (unsigned)b->dims.E ? h_err[1] : 0;
-        if (h_err[0] == 2) uh::set_error("uh_ba_set_problem: point %d observed twice by frame %d (observation %u)", ob[e].point, ob[e].frame, e);
-        else uh::set_error("uh_ba_set_problem: observation %u references point %d / frame %d out of range", e, ob[e].point, ob[e].frame);
+        int ept, ekf;
+        if (b->pq.obs16) { const unsigned w = reinterpret_cast<const unsigned*>(b->h_stage + b->slay.obs)[4 * (size_t)e]; ept = (int)(w & 0xFFFFFFu); ekf = (int)(w >> 24); }
+        else { const uh_ba_obs* ob = reinterpret_cast<const uh_ba_obs*>(b->h_stage + b->slay.obs); ept = ob[e].point; ekf = ob[e].frame; }
+        if (h_err[0] == 2) uh::set_error("uh_ba_set_problem: point %d observed twice by frame %d (observation %u)", ept, ekf, e);
+        else uh::set_error("uh_ba_set_problem: observation %u references point %d / frame %d out of range", e, ept, ekf);
         return UH_EINVAL;
     }
     b->iters[0] = hs.gate ? hs.iters_pass1 : hs.iters_done;
@@ -2492,7 +2503,7 @@ static PersistPlan plan_persistent(uh_ba* b, int K, int P, int E, int nfree) {
 
 // setParams of the persistent form on a filled staging block: header on the host (K-sized), ONE H2D copy, the ingest kernel.
 // No host-built table, no stream synchronisation; every device buffer is kept across problems.
-static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl) {
+static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl, bool obs16 = false) {
     const StageLayout& L = b->slay;
     unsigned char* hs = b->h_stage;
     const float* poses = reinterpret_cast<const float*>(hs + L.poses_in);
@@ -2559,14 +2570,14 @@ static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl
         UH_HIP_CHECK(hipHostGetDevicePointer(&d_hs, hs, 0));
         const int head_blocks = uh_div_up((int)(L.obs / 16), 256);
         UH_LAUNCH(b->ctx, ba_ingest_direct_kernel, dim3(head_blocks + uh_div_up(std::max(E, 1), 256)), dim3(256), 0, static_cast<const unsigned char*>(d_hs),
-                  reinterpret_cast<unsigned char*>(db), L.obs, L.obs, E, P, K, b->dT.as<unsigned>(), tseq, d_err, head_blocks);
+                  reinterpret_cast<unsigned char*>(db), L.obs, L.obs, E, P, K, b->dT.as<unsigned>(), tseq, d_err, head_blocks, obs16 ? 1 : 0);
     } else {
         // ---- ONE copy: header, frame arrays, points, observations
-        const size_t copy_bytes = L.obs + (size_t)E * sizeof(uh_ba_obs);
+        const size_t copy_bytes = L.obs + (size_t)E * (obs16 ? 16 : sizeof(uh_ba_obs));
         UH_HIP_CHECK(hipMemcpyAsync(b->dstage.p, hs, copy_bytes, hipMemcpyHostToDevice, st));
         if (E > 0)
             UH_LAUNCH(b->ctx, ba_ingest_kernel, dim3(uh_div_up(E, 256)), dim3(256), 0, reinterpret_cast<const uh_ba_obs*>(db + L.obs), E, P, K,
-                      b->dT.as<unsigned>(), tseq, d_err);
+                      b->dT.as<unsigned>(), tseq, d_err, obs16 ? 1 : 0);
     }
     UH_HIP_CHECK(hipEventRecord(b->ev_stage, st));   // behind the last reader of the staging block
     b->stage_in_flight = true;
@@ -2587,6 +2598,7 @@ static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl
     q.G = pl.G; q.Lw = pl.Lw; q.krows = pl.krows; q.SL = pl.SL; q.nelem = pl.nelem; q.max_fix = pl.max_fix; q.kfix = pl.kfix; q.use_mfma = pl.use_mfma;
     q.nb4 = pl.nb4; q.nblk = pl.nblk; q.KS = pl.KS;
     q.T = b->dT.as<unsigned>(); q.tseq = tseq;
+    q.obs16 = obs16 ? 1 : 0;
     q.obs = reinterpret_cast<const uh_ba_obs*>(db + L.obs); q.points = reinterpret_cast<const float*>(db + L.points);
     q.poses_in = reinterpret_cast<const float*>(db + L.poses_in); q.fix_kf = reinterpret_cast<const int*>(db + L.fix_kf);
     q.pose0 = reinterpret_cast<const double*>(db + L.pose0); q.poseR0 = reinterpret_cast<const double*>(db + L.poseR0);
@@ -2642,7 +2654,46 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     uh_ba_obs* ob = reinterpret_cast<uh_ba_obs*>(b->h_stage + L.obs);
     unsigned oob = 0;
     int e = 0;
-    {   // structure of arrays -> 24-byte records, two observations per step with 128-bit moves (this loop is most of setParams' host
+    // The ingest kernel's time is the bytes it fetches over the host link (~25 GB/s): when every information scalar is float-exact — the
+    // reference's always are, (double)(float)(1. / scaleFactor) — and the indices fit 24 + 8 bits, the records go out as 16 bytes
+    // {point | frame << 24, u, v, (float)inv_sigma} instead of 24.  Tried first; an inexact scalar falls through to the 24-byte form.
+    bool obs16 = K <= 256 && P < (1 << 24) && !(getenv("UH_BA_OBS24") && atoi(getenv("UH_BA_OBS24")));
+    if (obs16) {
+        __m128i bad = _mm_setzero_si128();
+        __m128d exact = _mm_castsi128_pd(_mm_set1_epi32(-1));
+        const __m128i pmax = _mm_set1_epi32(P - 1), kmax = _mm_set1_epi32(K - 1);
+        unsigned char* dst = reinterpret_cast<unsigned char*>(ob);
+        int i = 0;
+        for (; i + 2 <= E; i += 2, dst += 32) {
+            const __m128i pt = _mm_loadl_epi64(reinterpret_cast<const __m128i*>(pr->obs_point + i));
+            const __m128i kf = _mm_loadl_epi64(reinterpret_cast<const __m128i*>(pr->obs_frame + i));
+            const __m128 uv = _mm_loadu_ps(pr->obs_uv + 2 * i);
+            const __m128d w = _mm_loadu_pd(pr->obs_inv_sigma + i);
+            bad = _mm_or_si128(bad, _mm_or_si128(_mm_or_si128(pt, _mm_sub_epi32(pmax, pt)), _mm_or_si128(kf, _mm_sub_epi32(kmax, kf))));
+            const __m128 wf = _mm_cvtpd_ps(w);                                                  // w0f w1f 0 0
+            exact = _mm_and_pd(exact, _mm_cmpeq_pd(_mm_cvtps_pd(wf), w));
+            const __m128i pk = _mm_or_si128(pt, _mm_slli_epi32(kf, 24));                          // p0 p1 0 0
+            const __m128 a = _mm_castsi128_ps(_mm_unpacklo_epi32(pk, _mm_castps_si128(wf)));     // p0 w0 p1 w1
+            const __m128i r0 = _mm_shuffle_epi32(_mm_castps_si128(_mm_shuffle_ps(a, uv, _MM_SHUFFLE(1, 0, 1, 0))), _MM_SHUFFLE(1, 3, 2, 0));   // p0 u0 v0 w0
+            const __m128i r1 = _mm_shuffle_epi32(_mm_castps_si128(_mm_shuffle_ps(a, uv, _MM_SHUFFLE(3, 2, 3, 2))), _MM_SHUFFLE(1, 3, 2, 0));   // p1 u1 v1 w1
+            _mm_storeu_si128(reinterpret_cast<__m128i*>(dst), r0);
+            _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + 16), r1);
+        }
+        bool ok = _mm_movemask_pd(exact) == 3;
+        oob = (unsigned)_mm_movemask_ps(_mm_castsi128_ps(bad)) & 3u;
+        for (; i < E; i++, dst += 16) {
+            const int pt = pr->obs_point[i], kf = pr->obs_frame[i];
+            oob |= (unsigned)((unsigned)pt >= (unsigned)P) | (unsigned)((unsigned)kf >= (unsigned)K);
+            const float wf = (float)pr->obs_inv_sigma[i];
+            ok = ok && (double)wf == pr->obs_inv_sigma[i];
+            const unsigned pk = ((unsigned)pt & 0xFFFFFFu) | ((unsigned)kf << 24);
+            std::memcpy(dst, &pk, 4); std::memcpy(dst + 4, pr->obs_uv + 2 * i, 8); std::memcpy(dst + 12, &wf, 4);
+        }
+        obs16 = ok && !oob;   // (an index out of range may not survive the 24 + 8 bit packing: report it from the 24-byte pass below)
+        if (obs16) e = E;
+        else oob = 0;
+    }
+    if (!obs16) {   // structure of arrays -> 24-byte records, two observations per step with 128-bit moves (this loop is most of setParams' host
         // time: 26 000 observations, 31 us as scalar code, a third of that this way); indices checked on the way: an index is in range
         // iff neither i nor (n - 1 - i) is negative, the sign bits are OR-ed over the whole array
         __m128i bad = _mm_setzero_si128();
@@ -2671,7 +2722,7 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
         for (int e = 0; e < E; e++)
             UH_REQUIRE(pr->obs_point[e] >= 0 && pr->obs_point[e] < P && pr->obs_frame[e] >= 0 && pr->obs_frame[e] < K,
                        "uh_ba_set_problem: observation %d references point %d / frame %d out of range", e, pr->obs_point[e], pr->obs_frame[e]);
-    return set_problem_fast(b, K, P, E, pl);
+    return set_problem_fast(b, K, P, E, pl, obs16);
 }
 
 int uh_ba_map_staging(uh_ba* b, int n_frames, int n_points, int max_obs, uh_ba_staging* out) {

@@ -41,7 +41,8 @@ struct BAPersist {
     // the problem as uh_ba_set_problem left it in HBM: ONE H2D copy of the staging block + ba_ingest_kernel (ba.hip) — no table is built
     // on the host.  T[point * K + frame] = (problem sequence << 20) | (observation index + 1): a cell of an older problem never matches.
     const unsigned* T; unsigned tseq;
-    const uh_ba_obs* obs;            // E x {point, frame, u, v, inv_sigma} (24 bytes, include/ucoslam_hip.h)
+    const uh_ba_obs* obs;            // E x {point, frame, u, v, inv_sigma} (24 bytes, include/ucoslam_hip.h) — or, obs16 != 0, E x 16 bytes
+    int obs16;                       // {point | frame << 24, u, v, (float)inv_sigma}: what uh_ba_set_problem writes when every scalar is float-exact
     const float* points;             // P x 3 float (MapPoint::getCoordinates); widened to double here exactly as setParams does
     const float* poses_in;           // K x 16 float: fixed frames are returned unchanged, and their rows test the depth of bad associations
     const int* fix_kf;   // [kfix] frame index of EVERY fixed frame, ascending
@@ -364,7 +365,14 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     if (live && s < nfree) eid = cell(l, p.free_kf[s]);
     const bool has = eid >= 0;
     double ou = 0, ov = 0, ow = 0, fxk = 1, fyk = 1, cxk = 0, cyk = 0;
-    if (has) { const uh_ba_obs ob = q.obs[eid]; ou = ob.u; ov = ob.v; ow = ob.inv_sigma; }
+    // one observation's constants from either record format
+    auto load_obs = [&](int e, double& u_, double& v_, double& w_) {
+        if (q.obs16) {
+            const float4 r = reinterpret_cast<const float4*>(q.obs)[e];
+            u_ = r.y; v_ = r.z; w_ = r.w;
+        } else { const uh_ba_obs ob = q.obs[e]; u_ = ob.u; v_ = ob.v; w_ = ob.inv_sigma; }
+    };
+    if (has) load_obs(eid, ou, ov, ow);
     if (s < nfree) { const int k = p.free_kf[s]; fxk = p.intr[4 * k]; fyk = p.intr[4 * k + 1]; cxk = p.intr[4 * k + 2]; cyk = p.intr[4 * k + 3]; }
     bool act = has;
     double chi_e = 0;
@@ -400,9 +408,10 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         for (int j = 0; j < q.kfix; j++) {
             const int e = cell(l0 + tid, q.fix_kf[j]);
             if (e < 0) continue;
-            const uh_ba_obs ob = q.obs[e];
+            double fu, fv, fw;
+            load_obs(e, fu, fv, fw);
             s_fxact[at] = 1; s_fxchi[at] = 0.0; s_fxk[at] = (unsigned char)j; s_fxid[at] = e;
-            s_fxobs[3 * at] = ob.u; s_fxobs[3 * at + 1] = ob.v; s_fxobs[3 * at + 2] = ob.inv_sigma;
+            s_fxobs[3 * at] = fu; s_fxobs[3 * at + 1] = fv; s_fxobs[3 * at + 2] = fw;
             ++at;
         }
     }
