@@ -155,7 +155,7 @@ def main():
     # the reference runs local BA on its mapper thread, concurrently with tracking (mapmanager.cpp:1550);
     # here BA gets its own HIP stream so that its kernel overlaps the tracking stream's
     ctx_ba = u.Context(local_rank, private=True)
-    ba = GlobalOptimizer.create(ctx_ba)
+    ba = GlobalOptimizer.create(ctx_ba).wantChi2(False)   # (GlobalOptimizer::getResults returns poses, points and bad associations: no chi2)
     ba_ps = ParamSet(nIters=5)
     L = u.lib()
     from ucoslam_cv3_amd._lib import check, dev_ptr, np_ptr
@@ -189,7 +189,7 @@ def main():
         trk_stream.synchronize()                                    # the tracker owns its host buffers again
 
     # rounds 1-2's step, kept as stages.kernel_only_*: frames resident in HBM, ONE problem re-optimised, nothing returns to the host
-    ba_res = GlobalOptimizer.create(ctx_ba)
+    ba_res = GlobalOptimizer.create(ctx_ba).wantChi2(False)
     ba_res.setParams(ba_pr, ba_ps)
 
     def step_resident():
@@ -327,7 +327,7 @@ def main():
         # headroom figure, NOT the metric: two independent sessions (two frame streams, two maps, two local BAs) on this one GPU —
         # the latency-bound launch chains of the two BAs interleave, which one session cannot do with itself
         ctx_ba2 = u.Context(local_rank, private=True)
-        ba2 = GlobalOptimizer.create(ctx_ba2)
+        ba2 = GlobalOptimizer.create(ctx_ba2).wantChi2(False)
         ba2.setParams(synth.ba_problem(BA_K, BA_P, seed=rank + 100), ParamSet(nIters=5))
         ctx_t2 = u.Context(local_rank, private=True)
         ext_b = ORBextractor.create(ctx_t2)

@@ -148,6 +148,7 @@ int main(int argc, char** argv) {
     CHECK(uh_knn_create(trk, &index));
     CHECK(uh_knn_build(index, map_desc.data(), NT, 32, 32));
     CHECK(uh_ba_create(map, &ba));
+    CHECK(uh_ba_want_chi2(ba, 0));   // GlobalOptimizer::getResults returns poses, points and bad associations
     const uh_ba_params bp{5, 0.0, 0.0, 1.0f};
     // ---- outputs (pinned: the copies back are asynchronous DMA)
     uh_keypoint* kps = static_cast<uh_keypoint*>(uh_host_alloc((size_t)F * NFEAT * sizeof(uh_keypoint)));

@@ -340,6 +340,9 @@ int  uh_ba_solve_async(uh_ba* ba, const uh_ba_problem* problem, int n_frames, in
 /* which form the current problem runs in: 0 launch chain (9+ free keyframes that do not fit the persistent form), 1 persistent
  * one-launch kernel, 2 wide (global BA); *lanes_per_landmark_out (may be NULL) = the persistent form's padded number of free cameras */
 int  uh_ba_form(uh_ba* ba, int* lanes_per_landmark_out);
+/* the per-observation chi2 is an extra of this ABI (GlobalOptimizer::getResults does not return it) and three quarters of the bytes the
+ * optimisation kernel hands over: uh_ba_want_chi2(ba, 0) leaves it out from the next set_problem on (chi2_out must then be NULL) */
+int  uh_ba_want_chi2(uh_ba* ba, int on);
 
 /* ------------------------------------------------------------------------
  * Bag of words — replaces fbow::Vocabulary::transform / fBow::score:

@@ -461,3 +461,28 @@ def test_hip_ba_compact_and_full_observation_records_agree(hip_ctx, monkeypatch)
         b.setParams(odd, ParamSet(nIters=5)); b.optimize()
         monkeypatch.delenv("UH_BA_OBS24", raising=False)
         assert _sig(a.getResults()) == _sig(b.getResults())
+
+
+@pytest.mark.gpu
+def test_hip_ba_chi2_handover_can_be_switched_off(hip_ctx):
+    """uh_ba_want_chi2(0): the kernel's tail leaves the per-observation chi2 (an extra of this ABI) out of its result hand-over; everything
+    the reference's getResults returns is unchanged, asking for chi2 is an error, switching it back on works."""
+    import ucoslam_cv3_amd as u
+    from ucoslam_cv3_amd._lib import check, np_ptr
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    pr = synth.ba_problem(10, 1500, 3)
+    ref = GlobalOptimizer.create(hip_ctx)
+    ref.setParams(pr, ParamSet(nIters=5)); ref.optimize()
+    want = ref.getResults()
+    opt = GlobalOptimizer.create(hip_ctx).wantChi2(False)
+    opt.setParams(pr, ParamSet(nIters=5)); opt.optimize()
+    poses, points, bad, iters = np.zeros((pr["K"], 16), np.float32), np.zeros((pr["P"], 3), np.float32), np.zeros(pr["E"], np.uint8), np.zeros(2, np.int32)
+    check(u.lib().uh_ba_get_results(opt._h, np_ptr(poses), np_ptr(points), None, np_ptr(bad), np_ptr(iters)))
+    np.testing.assert_array_equal(poses, want["poses"]); np.testing.assert_array_equal(points, want["points"])
+    np.testing.assert_array_equal(bad, want["bad"]); assert iters.tolist() == want["iters"].tolist()
+    with pytest.raises(u.UcoslamHipError, match="chi2 was switched off"):
+        opt.getResults()
+    opt.wantChi2(True)
+    opt.setParams(pr, ParamSet(nIters=5)); opt.optimize()
+    assert _sig(opt.getResults()) == _sig(want)

@@ -56,6 +56,7 @@ def _declare(L, sig):
     sig("uh_ba_results_view_get", I, VP, C.POINTER(_ResultsView))
     sig("uh_ba_solve_async", I, VP, C.POINTER(_Problem), I, I, I, C.POINTER(ParamSet), VP)
     sig("uh_ba_form", I, VP, C.POINTER(C.c_int))
+    sig("uh_ba_want_chi2", I, VP, I)
 
 
 _lib._EXTRA_DECLS.append(_declare)
@@ -146,6 +147,11 @@ class GlobalOptimizer:
     def prepareProblem(self, problem: dict):
         """The ctypes view of a flattened problem, built once (solve_async / setParams accept it in place of the dict)."""
         return self._problem_struct(problem)
+
+    def wantChi2(self, on: bool):
+        """The per-observation chi2 is an extra of this ABI; switching it off (before setParams) shortens the kernel's result hand-over."""
+        check(lib().uh_ba_want_chi2(self._h, int(on)))
+        return self
 
     def form(self) -> str:
         """'persist<NF>' (one persistent launch, NF lanes per landmark), 'chain' (launch chain) or 'wide' (global BA)."""

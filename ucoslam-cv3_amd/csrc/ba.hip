@@ -1866,7 +1866,7 @@ struct StageLayout {
     size_t points, obs;                                  // P x 3 float, then E x uh_ba_obs: the copy ends behind the last observation
 };
 // Result block (pinned host memory the kernel's tail writes): byte offsets
-struct ResLayout { size_t poses, state, points, chi2, bad, bytes; };
+struct ResLayout { size_t poses, state, points, chi2, bad, bytes, bytes_no_chi2; };   // chi2 last: it is handed over only on request
 
 struct uh_ba {
     uh_ctx* ctx = nullptr;
@@ -1906,6 +1906,7 @@ struct uh_ba {
     size_t h_res_bytes = 0;
     ResLayout rlay{};
     uh::DevBuf d_res;                     // the result block in HBM the kernel's tail fills first (same layout)
+    bool want_chi2 = true;                // hand the per-observation chi2 (208 KB of the 270 KB of results at 26k observations) over to the host
     bool fast = false;                    // the current problem was set through the staged path (persistent form)
     int p_nf = 0;                         // lanes per landmark of the persistent instantiation in use
     int p_lds_set[4] = {0, 0, 0, 0};      // dynamic LDS already granted to the instantiations (hipFuncSetAttribute once, not per problem)
@@ -2390,7 +2391,9 @@ static ResLayout res_layout(int Kc, int Pc, int Ec) {
     ResLayout R;
     Arena A;
     R.poses = A.take<float>(16 * (size_t)Kc); R.state = A.take<double>(7 * (size_t)Kc); R.points = A.take<float>(3 * (size_t)Pc);
-    R.chi2 = A.take<double>(Ec); R.bad = A.take<unsigned char>(Ec);
+    R.bad = A.take<unsigned char>(Ec);
+    R.bytes_no_chi2 = (A.off + 7) & ~(size_t)7;
+    R.chi2 = A.take<double>(Ec);
     R.bytes = (A.off + 7) & ~(size_t)7;   // copied to the host as 8-byte words
     return R;
 }
@@ -2611,7 +2614,8 @@ static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl
     const ResLayout& R = b->rlay;
     if ((rc = b->d_res.reserve(b->h_res_bytes))) return rc;
     unsigned char* rb = b->d_res.as<unsigned char>();
-    q.r_dev = b->d_res.as<unsigned long long>(); q.r_host = static_cast<unsigned long long*>(d_res); q.r_words = R.bytes / 8;
+    q.r_dev = b->d_res.as<unsigned long long>(); q.r_host = static_cast<unsigned long long*>(d_res); q.r_words = (b->want_chi2 ? R.bytes : R.bytes_no_chi2) / 8;
+    q.want_chi2 = b->want_chi2 ? 1 : 0;
     q.r_poses = reinterpret_cast<float*>(rb + R.poses); q.r_state = reinterpret_cast<double*>(rb + R.state); q.r_points = reinterpret_cast<float*>(rb + R.points);
     q.r_chi2 = reinterpret_cast<double*>(rb + R.chi2); q.r_bad = rb + R.bad;
     q.done_ctr = reinterpret_cast<unsigned*>(b->dscratch.as<char>() + 768);
@@ -2770,6 +2774,14 @@ int uh_ba_set_problem_staged(uh_ba* b, int K, int P, int E, const uh_ba_params* 
     return set_problem_tables(b, &pr);
 }
 
+// the per-observation chi2 is an extra of this ABI (the reference's getResults does not return it): a host that never asks for it saves
+// the kernel three quarters of its result hand-over.  Takes effect with the next set_problem.
+int uh_ba_want_chi2(uh_ba* b, int on) {
+    UH_REQUIRE(b, "uh_ba_want_chi2: NULL");
+    b->want_chi2 = on != 0;
+    return UH_OK;
+}
+
 int uh_ba_form(uh_ba* b, int* lanes_out) {
     UH_REQUIRE(b && b->have_problem, "uh_ba_form: no problem set");
     if (lanes_out) *lanes_out = b->persist ? b->p_nf : 0;
@@ -2923,6 +2935,7 @@ int uh_ba_get_results(uh_ba* b, float* poses_out, float* points_out, double* chi
         const ResLayout& R = b->rlay;
         if (poses_out) std::memcpy(poses_out, b->h_res + R.poses, 16 * (size_t)d.K * sizeof(float));
         if (points_out && d.P) std::memcpy(points_out, b->h_res + R.points, 3 * (size_t)d.P * sizeof(float));
+        UH_REQUIRE(!(chi2_out && d.E) || b->pq.want_chi2, "uh_ba_get_results: chi2 was switched off for this problem (uh_ba_want_chi2)");
         if (chi2_out && d.E) std::memcpy(chi2_out, b->h_res + R.chi2, (size_t)d.E * sizeof(double));
         if (bad_out && d.E) std::memcpy(bad_out, b->h_res + R.bad, (size_t)d.E);
         if (iters_out) { iters_out[0] = b->iters[0]; iters_out[1] = b->iters[1]; }
@@ -2975,7 +2988,7 @@ int uh_ba_results_view_get(uh_ba* b, uh_ba_results_view* out) {
     UH_REQUIRE(b->fast, "uh_ba_results_view_get: the current problem runs in a form that keeps its results in HBM (use uh_ba_get_results)");
     const ResLayout& R = b->rlay;
     out->poses = reinterpret_cast<const float*>(b->h_res + R.poses); out->points = reinterpret_cast<const float*>(b->h_res + R.points);
-    out->chi2 = reinterpret_cast<const double*>(b->h_res + R.chi2); out->bad = b->h_res + R.bad;
+    out->chi2 = b->pq.want_chi2 ? reinterpret_cast<const double*>(b->h_res + R.chi2) : nullptr; out->bad = b->h_res + R.bad;
     out->pose_state = reinterpret_cast<const double*>(b->h_res + R.state);
     out->iters[0] = b->iters[0]; out->iters[1] = b->iters[1];
     out->n_frames = b->dims.K; out->n_points = b->dims.P; out->n_obs = b->dims.E;

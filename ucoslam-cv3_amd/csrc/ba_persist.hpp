@@ -49,6 +49,7 @@ struct BAPersist {
     const double* pose0; const double* poseR0;                           // K x 7, K x 12: the snapshot taken by setParams
     // results (globaloptimizer_g2o.cpp:466-537), written by the kernel's tail into a block in HBM (these pointers), then copied to pinned host memory
     float* r_poses; double* r_state; float* r_points; unsigned char* r_bad; double* r_chi2;
+    int want_chi2;                   // 0: the per-observation chi2 stays on the device (uh_ba_want_chi2)
     unsigned long long* r_dev; unsigned long long* r_host; size_t r_words;   // the result block in HBM, its pinned host twin, 8-byte words in use
     unsigned* done_ctr; unsigned done_base;     // counts the workgroups through the two steps of the result hand-over (base: its value before this launch)
     unsigned long long* part;        // [slice][workgroup][SL] tagged doubles (two words each)
@@ -1001,7 +1002,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             const float z = (float)Rt[6] * Xf0 + (float)Rt[7] * Xf1 + (float)Rt[8] * Xf2 + (float)Rt[11];
             if (z < 0) bad = true;
         }
-        sst(q.r_chi2 + eid, chi_e);
+        if (q.want_chi2) sst(q.r_chi2 + eid, chi_e);
         sst(q.r_bad + eid, (unsigned char)bad);
     }
     for (int i = fxb + s; i < fxe; i += NF) {
@@ -1012,7 +1013,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             const float z = M[8] * Xf0 + M[9] * Xf1 + M[10] * Xf2 + M[11];
             if (z < 0) bad = true;
         }
-        sst(q.r_chi2 + s_fxid[i], chi);
+        if (q.want_chi2) sst(q.r_chi2 + s_fxid[i], chi);
         sst(q.r_bad + s_fxid[i], (unsigned char)bad);
     }
     if (g == 0) {
