@@ -1043,9 +1043,78 @@ __device__ __forceinline__ void backsolve_lds(const double* M, int n, int ld, do
 // pivoting; fails on a zero / non-finite pivot like Eigen's SimplicialLDLT) in LDS when it fits (n <= 126) else in HBM,
 // substitutes, and writes T_trial = exp(dx) * T_cur for the free poses.  Row stride is n+1 doubles (odd) so that column
 // walks are LDS-bank-conflict free.
+// L y = b, y /= d, L^T x = y on the PACKED factor (row r at r (r + 1) / 2, unit lower L, d on the diagonal) for 64 < n <= 192: wave 0,
+// three unknowns per lane (rows lane, lane + 64, lane + 128), one v_readlane broadcast per column, the column's entries prefetched four
+// steps ahead.  (The loop form it replaces costs two workgroup barriers per column and direction: 4 n barriers.)
+__device__ __forceinline__ void trisolve_packed_lds(const double* M, int n, double* s_x) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (wv != 0) return;
+    const int r0 = lane, r1 = lane + 64, r2 = lane + 128;
+    auto tri = [](int r) -> size_t { return (size_t)r * (r + 1) / 2; };
+    double x0 = r0 < n ? s_x[r0] : 0.0, x1 = r1 < n ? s_x[r1] : 0.0, x2 = r2 < n ? s_x[r2] : 0.0;
+    const size_t t0 = tri(r0 < n ? r0 : n - 1), t1 = tri(r1 < n ? r1 : n - 1), t2 = tri(r2 < n ? r2 : n - 1);
+    // ---- forward: column j leaves the rows below it
+    auto fwd_load = [&](int j, double (&l)[3]) {   // L(r, j) for this lane's rows (0 where the row is not below column j)
+        const int jj = j < n ? j : n - 1;
+        l[0] = (r0 > jj && r0 < n) ? M[t0 + jj] : 0.0; l[1] = (r1 > jj && r1 < n) ? M[t1 + jj] : 0.0; l[2] = (r2 > jj && r2 < n) ? M[t2 + jj] : 0.0;
+    };
+    {
+        double l[4][3];
+#pragma unroll
+        for (int t = 0; t < 4; t++) fwd_load(t, l[t]);
+        for (int j0 = 0; j0 < n; j0 += 4) {
+            double nl[4][3];
+#pragma unroll
+            for (int t = 0; t < 4; t++) fwd_load(j0 + 4 + t, nl[t]);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int j = j0 + t;
+                if (j >= n) break;
+                const double a = readlane_f64(x0, j & 63), b = readlane_f64(x1, j & 63), c = readlane_f64(x2, j & 63);
+                const double xj = j < 64 ? a : (j < 128 ? b : c);
+                x0 = fma(-l[t][0], xj, x0); x1 = fma(-l[t][1], xj, x1); x2 = fma(-l[t][2], xj, x2);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) { l[t][0] = nl[t][0]; l[t][1] = nl[t][1]; l[t][2] = nl[t][2]; }
+        }
+    }
+    if (r0 < n) x0 /= M[t0 + r0];
+    if (r1 < n) x1 /= M[t1 + r1];
+    if (r2 < n) x2 /= M[t2 + r2];
+    // ---- backward: row j of L is column j of L^T: it leaves the rows above it
+    auto bwd_load = [&](int j, double (&l)[3]) {
+        const int jj = j >= 0 ? j : 0;
+        const size_t tj = tri(jj);
+        l[0] = r0 < jj ? M[tj + r0] : 0.0; l[1] = r1 < jj ? M[tj + r1] : 0.0; l[2] = r2 < jj ? M[tj + r2] : 0.0;
+    };
+    {
+        double l[4][3];
+#pragma unroll
+        for (int t = 0; t < 4; t++) bwd_load(n - 1 - t, l[t]);
+        for (int j0 = n - 1; j0 >= 0; j0 -= 4) {
+            double nl[4][3];
+#pragma unroll
+            for (int t = 0; t < 4; t++) bwd_load(j0 - 4 - t, nl[t]);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int j = j0 - t;
+                if (j < 0) break;
+                const double a = readlane_f64(x0, j & 63), b = readlane_f64(x1, j & 63), c = readlane_f64(x2, j & 63);
+                const double xj = j < 64 ? a : (j < 128 ? b : c);
+                x0 = fma(-l[t][0], xj, x0); x1 = fma(-l[t][1], xj, x1); x2 = fma(-l[t][2], xj, x2);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) { l[t][0] = nl[t][0]; l[t][1] = nl[t][1]; l[t][2] = nl[t][2]; }
+        }
+    }
+    if (r0 < n) s_x[r0] = x0;
+    if (r1 < n) s_x[r1] = x1;
+    if (r2 < n) s_x[r2] = x2;
+}
+
 struct SolveOut { bool done; int ok, cur; double lambda; };   // done: the pass had finished, nothing was computed
 
-template <bool USE_LDS>
+template <bool USE_LDS, bool PACKED = false>
 __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int nsplit, int slot, double* s_x /* LDS, 6*kMaxFree */, SolveOut& out) {
     extern __shared__ __attribute__((aligned(16))) double s_mat[];
     __shared__ int s_ok;
@@ -1053,7 +1122,11 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     const int n = d.n, ld = n + 1;
     const int npairs = d.nfree * (d.nfree + 1) / 2;
     // the address space must be known at compile time: a generic pointer would turn every access into a flat_load
-    auto M = [&]() { if constexpr (USE_LDS) return s_mat; else return p.S; }();
+    auto M = [&]() { if constexpr (USE_LDS || PACKED) return s_mat; else return p.S; }();
+    // PACKED (stand-alone solve, 127 < n + 1 <= 182): the lower triangle row by row in LDS, row r at r (r + 1) / 2 — a 30-camera system is
+    // 131 KB that way and never leaves the CU; only entries (r, c <= r) are ever written (reads of the few (r, c > r) the trailing update
+    // loads and discards land in the next row)
+    auto IX = [&](int r, int c) -> size_t { if constexpr (PACKED) return (size_t)r * (r + 1) / 2 + c; else return (size_t)r * ld + c; };
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long long clk_begin = wall_clock64();
     // assemble the lower triangle (+ diagonal) from the pair partials.  Four elements per thread and round, every partial
@@ -1133,8 +1206,8 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                 v = -v;
                 if (s1 == s2) v += h + (a == c ? lambda : 0.0);
                 const int r = 6 * s1 + a, cc = 6 * s2 + c;   // upper-block entry (r,cc); store it mirrored into the lower triangle
-                if (s1 == s2) { if (c <= a) M[(size_t)r * ld + cc] = v; }
-                else M[(size_t)cc * ld + r] = v;
+                if (s1 == s2) { if (c <= a) M[IX(r, cc)] = v; }
+                else M[IX(cc, r)] = v;
             }
         }
     }
@@ -1168,7 +1241,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     #pragma unroll
             for (int i = 0; i < 6; i++)
     #pragma unroll
-                for (int c = 0; c <= i; c++) a[i][c] = M[(k0 + i) * ld + k0 + c];
+                for (int c = 0; c <= i; c++) a[i][c] = M[IX((k0 + i), k0 + c)];
     #pragma unroll
             for (int j = 0; j < 6; j++) {
                 dk[j] = a[j][j];
@@ -1189,22 +1262,22 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     #pragma unroll
                 for (int i = 0; i < 6; i++) {
     #pragma unroll
-                    for (int c = 0; c < i; c++) M[(k0 + i) * ld + k0 + c] = a[i][c];
-                    M[(k0 + i) * ld + k0 + i] = dk[i];
+                    for (int c = 0; c < i; c++) M[IX((k0 + i), k0 + c)] = a[i][c];
+                    M[IX((k0 + i), k0 + i)] = dk[i];
                 }
             }
             // (b) panel: L_rk = A_rk * Lkk^-T * Dk^-1, one thread per row; y = L_rk * Dk goes to s_w
             for (int r = k0 + 6 + tid; r < n; r += kSolveThreads) {
                 double y[6];
     #pragma unroll
-                for (int j = 0; j < 6; j++) y[j] = M[r * ld + k0 + j];
+                for (int j = 0; j < 6; j++) y[j] = M[IX(r, k0 + j)];
     #pragma unroll
                 for (int j = 0; j < 6; j++) {
     #pragma unroll
                     for (int t = 0; t < j; t++) y[j] = fma(-y[t], a[j][t], y[j]);
                 }
     #pragma unroll
-                for (int j = 0; j < 6; j++) { M[r * ld + k0 + j] = y[j] * ik[j]; s_w[r][j] = y[j]; }
+                for (int j = 0; j < 6; j++) { M[IX(r, k0 + j)] = y[j] * ik[j]; s_w[r][j] = y[j]; }
             }
             __syncthreads();
             // (c) trailing update A_rc -= sum_t L_rt (d_t L_ct) for c <= r: the 6x6 tiles (s1 <= s2) behind block column kb are the
@@ -1224,14 +1297,14 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                         rr[u] = 6 * s2 + ti; cc[u] = 6 * s1 + tj;
                         on[u] = t_ < ntile && cc[u] <= rr[u];
     #pragma unroll
-                        for (int t = 0; t < 6; t++) { lr[u][t] = M[rr[u] * ld + k0 + t]; wc[u][t] = s_w[cc[u]][t]; }
-                        acc[u] = M[rr[u] * ld + cc[u]];
+                        for (int t = 0; t < 6; t++) { lr[u][t] = M[IX(rr[u], k0 + t)]; wc[u][t] = s_w[cc[u]][t]; }
+                        acc[u] = M[IX(rr[u], cc[u])];
                     }
     #pragma unroll
                     for (int u = 0; u < kTrailU; u++) {
     #pragma unroll
                         for (int t = 0; t < 6; t++) acc[u] = fma(-lr[u][t], wc[u][t], acc[u]);
-                        if (on[u]) M[rr[u] * ld + cc[u]] = acc[u];
+                        if (on[u]) M[IX(rr[u], cc[u])] = acc[u];
                     }
                 }
             }
@@ -1253,10 +1326,10 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                 const int lr = lane < n ? lane : n - 1;
                 double l[8], ln[8];
 #pragma unroll
-                for (int t = 0; t < 8; t++) { const int jj = t < n ? t : n - 1; l[t] = M[(size_t)lr * ld + jj]; }
+                for (int t = 0; t < 8; t++) { const int jj = t < n ? t : n - 1; l[t] = M[IX(lr, jj)]; }
                 for (int j0 = 0; !USE_LDS && j0 < n; j0 += 8) {          // L y = b, 8 columns of L prefetched one round ahead
 #pragma unroll
-                    for (int t = 0; t < 8; t++) { const int jj = j0 + 8 + t < n ? j0 + 8 + t : n - 1; ln[t] = M[(size_t)lr * ld + jj]; }
+                    for (int t = 0; t < 8; t++) { const int jj = j0 + 8 + t < n ? j0 + 8 + t : n - 1; ln[t] = M[IX(lr, jj)]; }
 #pragma unroll
                     for (int t = 0; t < 8; t++) { const int j = j0 + t; l[t] = (lane > j && lane < n) ? l[t] : 0.0; }
 #pragma unroll
@@ -1264,12 +1337,12 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
 #pragma unroll
                     for (int t = 0; t < 8; t++) l[t] = ln[t];
                 }
-                if (!USE_LDS && lane < n) x /= M[(size_t)lane * ld + lane];
+                if (!USE_LDS && lane < n) x /= M[IX(lane, lane)];
 #pragma unroll
-                for (int t = 0; t < 8; t++) { const int jj = n - 1 - t >= 0 ? n - 1 - t : 0; l[t] = M[(size_t)jj * ld + lr]; }
+                for (int t = 0; t < 8; t++) { const int jj = n - 1 - t >= 0 ? n - 1 - t : 0; l[t] = M[IX(jj, lr)]; }
                 for (int j0 = n - 1; j0 >= 0; j0 -= 8) {     // L^T x = y
 #pragma unroll
-                    for (int t = 0; t < 8; t++) { const int jj = j0 - 8 - t >= 0 ? j0 - 8 - t : 0; ln[t] = M[(size_t)jj * ld + lr]; }
+                    for (int t = 0; t < 8; t++) { const int jj = j0 - 8 - t >= 0 ? j0 - 8 - t : 0; ln[t] = M[IX(jj, lr)]; }
 #pragma unroll
                     for (int t = 0; t < 8; t++) { const int j = j0 - t; l[t] = lane < j ? l[t] : 0.0; }
 #pragma unroll
@@ -1280,7 +1353,12 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                 if (lane < n) { s_x[lane] = x; p.xp[lane] = x; }
             }
         } else {
-            if (USE_LDS && n <= 128) {   // two unknowns per lane of wave 0, one broadcast per column (the loop below: two barriers per column)
+            if (PACKED) {
+                __syncthreads();   // (s_x = b - b_schur, written by the assembly, is complete)
+                trisolve_packed_lds(M, n, s_x);
+                __syncthreads();
+                for (int i = tid; i < n; i += kSolveThreads) p.xp[i] = s_x[i];
+            } else if (USE_LDS && n <= 128) {   // two unknowns per lane of wave 0, one broadcast per column (the loop below: two barriers per column)
                 backsolve2_lds(M, n, ld, s_x);
                 __syncthreads();
                 for (int i = tid; i < n; i += kSolveThreads) p.xp[i] = s_x[i];
@@ -1291,16 +1369,16 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                 for (int j = 0; j < n; j++) {
                     const double xj = s_x[j];
                     __syncthreads();
-                    for (int i = j + 1 + tid; i < n; i += kSolveThreads) s_x[i] -= M[(size_t)i * ld + j] * xj;
+                    for (int i = j + 1 + tid; i < n; i += kSolveThreads) s_x[i] -= M[IX(i, j)] * xj;
                     __syncthreads();
                 }
-                for (int i = tid; i < n; i += kSolveThreads) s_x[i] /= M[(size_t)i * ld + i];
+                for (int i = tid; i < n; i += kSolveThreads) s_x[i] /= M[IX(i, i)];
             }
             __syncthreads();
             for (int j = n - 1; j >= 0; j--) {
                 const double xj = s_x[j];
                 __syncthreads();
-                for (int i = tid; i < j; i += kSolveThreads) s_x[i] -= M[(size_t)j * ld + i] * xj;
+                for (int i = tid; i < j; i += kSolveThreads) s_x[i] -= M[IX(j, i)] * xj;
                 __syncthreads();
             }
             for (int i = tid; i < n; i += kSolveThreads) p.xp[i] = s_x[i];
@@ -1320,12 +1398,12 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
 
 // stand-alone form: reduced systems too large for LDS (n > 126) factorise in the HBM workspace p.S, which only one
 // workgroup may use
-template <bool USE_LDS>
+template <bool USE_LDS, bool PACKED = false>
 __global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADims d, int nsplit, int slot) {
     uh_latency_critical();
     __shared__ double s_x[6 * kMaxFree];
     SolveOut o;
-    solve_body<USE_LDS>(p, d, nsplit, slot, s_x, o);
+    solve_body<USE_LDS, PACKED>(p, d, nsplit, slot, s_x, o);
 }
 
 // Stand-alone decision: closes a round of enqueued steps (the decision of a step is otherwise applied by the NEXT step's
@@ -2005,7 +2083,12 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
         if (use_lds) {
             UH_LAUNCH(b->ctx,ba_backsub_kernel<true>, dim3(d.nPointBlocks), dim3(kThreads), lds, b->ptrs, d, b->nsplit, slot ^ 1);
         } else {
-            UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kSolveThreads), 0, b->ptrs, d, b->nsplit, slot ^ 1);
+            // 22-30 free cameras: the stand-alone solve keeps the system as a packed triangle in its own LDS (<= 128 KB: 30 cameras); more: in HBM
+            const size_t packed = ((size_t)d.n * (d.n + 1) / 2 + 16) * sizeof(double);
+            if (packed <= 128 * 1024 && !(getenv("UH_BA_SOLVE") && std::string(getenv("UH_BA_SOLVE")) == "hbm"))
+                UH_LAUNCH(b->ctx, (ba_solve_kernel<false, true>), dim3(1), dim3(kSolveThreads), packed, b->ptrs, d, b->nsplit, slot ^ 1);
+            else
+                UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kSolveThreads), 0, b->ptrs, d, b->nsplit, slot ^ 1);
             UH_LAUNCH(b->ctx,ba_backsub_kernel<false>, dim3(d.nPointBlocks), dim3(kThreads), 0, b->ptrs, d, b->nsplit, slot ^ 1);
         }
         b->step++;
