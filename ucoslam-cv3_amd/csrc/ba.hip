@@ -1233,8 +1233,6 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
         failed = ldlt_bordered_lds(M, n, ld, d.nfree, npairs, s_pair, s_w);
     } else {
         __shared__ double s_w[6 * kMaxFree][6];
-        constexpr int kTilesPerRound = kSolveThreads / 36;
-        const int tq = tid / 36, te = tid - 36 * tq, ti = te / 6, tj = te - 6 * ti;   // trailing update: tile slot, row, column
         for (int k0 = 0; k0 < n; k0 += 6) {
             // (a) diagonal block -> Lkk (strict lower), dk, 1/dk
             double a[6][6], dk[6], ik[6];
@@ -1281,31 +1279,29 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
             }
             __syncthreads();
             // (c) trailing update A_rc -= sum_t L_rt (d_t L_ct) for c <= r: the 6x6 tiles (s1 <= s2) behind block column kb are the
-            //     tail of the s1-major pair list; each thread owns one (row, column) of a tile slot, kTrailU tiles in flight
+            //     tail of the s1-major pair list.  One thread per (tile, row): its six L entries and its six targets are read once and
+            //     meet the tile's 6 x 6 panel entries (s_w) in 36 FMAs — 48 operand reads per 36 FMAs; one thread per ELEMENT read 12 per 6,
+            //     and with the system in LDS the update was bound by exactly those reads.
             {
                 const int kb = k0 / 6;
                 const int tile0 = (kb + 1) * d.nfree - kb * (kb + 1) / 2;   // first pair with s1 > kb
                 const int ntile = npairs - tile0;
-                for (int tl = tq; tl < ntile && tq < kTilesPerRound; tl += kTrailU * kTilesPerRound) {
-                    int rr[kTrailU], cc[kTrailU]; bool on[kTrailU];
-                    double lr[kTrailU][6], wc[kTrailU][6], acc[kTrailU];
+                for (int u = tid; u < 6 * ntile; u += kSolveThreads) {
+                    const int tile = u / 6, i = u - 6 * tile;
+                    const int s1 = s_pair[tile0 + tile][0], s2 = s_pair[tile0 + tile][1];
+                    const int r = 6 * s2 + i, c0 = 6 * s1;
+                    const int ncol = s1 == s2 ? i + 1 : 6;   // (diagonal tiles: the lower triangle only — the packed form has no room for more)
+                    double lr[6], acc[6];
     #pragma unroll
-                    for (int u = 0; u < kTrailU; u++) {
-                        const int t_ = tl + u * kTilesPerRound;
-                        const int tc = t_ < ntile ? t_ : tl;
-                        const int s1 = s_pair[tile0 + tc][0], s2 = s_pair[tile0 + tc][1];
-                        rr[u] = 6 * s2 + ti; cc[u] = 6 * s1 + tj;
-                        on[u] = t_ < ntile && cc[u] <= rr[u];
+                    for (int t = 0; t < 6; t++) lr[t] = M[IX(r, k0 + t)];
     #pragma unroll
-                        for (int t = 0; t < 6; t++) { lr[u][t] = M[IX(rr[u], k0 + t)]; wc[u][t] = s_w[cc[u]][t]; }
-                        acc[u] = M[IX(rr[u], cc[u])];
-                    }
+                    for (int j = 0; j < 6; j++) acc[j] = j < ncol ? M[IX(r, c0 + j)] : 0.0;
     #pragma unroll
-                    for (int u = 0; u < kTrailU; u++) {
+                    for (int j = 0; j < 6; j++)
     #pragma unroll
-                        for (int t = 0; t < 6; t++) acc[u] = fma(-lr[u][t], wc[u][t], acc[u]);
-                        if (on[u]) M[IX(rr[u], cc[u])] = acc[u];
-                    }
+                        for (int t = 0; t < 6; t++) acc[j] = fma(-lr[t], s_w[c0 + j][t], acc[j]);
+    #pragma unroll
+                    for (int j = 0; j < 6; j++) if (j < ncol) M[IX(r, c0 + j)] = acc[j];
                 }
             }
             __syncthreads();
