@@ -290,3 +290,12 @@ def proj_problem(n_kpts=2000, n_pts=3000, seed=0, w=1241, h=376, n_levels=8, low
     fr = dict(und_kpts=kp, desc=np.ascontiguousarray(desc), scale_factors=sf, fx=fx, fy=fy, cx=cx, cy=cy, min_xy=(0, 0), max_xy=(w, h))
     pose = (_se3_exp(rng.normal(0, pose_noise, 6)) @ Tgt).astype(np.float32)
     return fr, mp, np.ascontiguousarray(pose.reshape(16))
+
+
+def ba_hard_problem(seed):
+    """A local BA that Levenberg-Marquardt does not sail through (rejected trials, lambda factors other than 1/3, passes that end on
+    ten rejections in a row): large pose / landmark / pixel noise and 30 % outliers on a small window."""
+    rng = np.random.default_rng(seed)
+    K = int(rng.integers(3, 12)); P = int(rng.integers(20, 300)); nf = int(rng.integers(1, 3))
+    pn = float(rng.choice([0.3, 0.6, 1.0])); ptn = float(rng.choice([2.0, 5.0, 10.0]))
+    return ba_problem(K, P, seed=seed, nfixed=nf, pose_noise=pn, point_noise=ptn, outlier_frac=0.3, pix_noise=3.0)

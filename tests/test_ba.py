@@ -488,3 +488,36 @@ def test_hip_ba_chi2_handover_can_be_switched_off(hip_ctx):
     opt.wantChi2(True)
     opt.setParams(pr, ParamSet(nIters=5)); opt.optimize()
     assert _sig(opt.getResults()) == _sig(want)
+
+
+@pytest.mark.gpu
+def test_hip_ba_hard_problems_rejected_trials_and_other_lambda_factors(hip_ctx, oracle):
+    """Local BAs that Levenberg-Marquardt does not sail through (synth.ba_hard_problem: rejected trials up to the ten in a row that end a
+    pass, accepted trials with lambda factors other than 1/3, passes cut short by the chi2 criterion).  The persistent kernel's
+    speculative trials (phase 1 of the next trial with lambda / 3 before the decision) must be DROPPED in exactly those cases: same
+    iteration counts and state as the oracle, and the debug counters show that both outcomes occurred over the set."""
+    import ctypes as C
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+    import ucoslam_cv3_amd as u
+
+    L = u.lib()
+    L.uh_ba_debug_clocks.argtypes = [C.c_void_p, C.c_void_p]; L.uh_ba_debug_clocks.restype = C.c_int
+    kept = dropped = early = 0
+    for seed in range(16):
+        pr = synth.ba_hard_problem(seed)
+        ref = oracle_lib.ba_optimize(oracle, pr, 5)
+        opt = GlobalOptimizer.create(hip_ctx)
+        opt.setParams(pr, ParamSet(nIters=5))
+        opt.optimize()
+        got = opt.getResults()
+        assert got["iters"].tolist() == ref["iters"].tolist(), seed
+        assert np.abs(got["state"] - ref["state"]).max() < POSE_TOL, (seed, np.abs(got["state"] - ref["state"]).max())
+        _assert_bad_flags_equal_up_to_the_boundary(got, ref)
+        early += ref["iters"].tolist() != [5, 10]
+        assert opt.form().startswith("persist")
+        clk = np.zeros(64, dtype=np.int64)
+        assert L.uh_ba_debug_clocks(opt._h, clk.ctypes.data) == 0
+        kept += int(clk[58]); dropped += int(clk[59])
+        opt.close()
+    assert early >= 4            # the set does contain passes that end before their iteration budget
+    assert kept > 0 and dropped > 0, (kept, dropped)

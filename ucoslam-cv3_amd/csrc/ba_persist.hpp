@@ -34,6 +34,7 @@ struct BAPersist {
     int G, Lw, krows, SL, nelem, max_fix, kfix;
     int nb4, nblk, KS;   // the product's 4x4 block grid: nb4 = ceil(n / 4) block columns, nblk upper blocks, KS splits of the K range
     int n1, n2, stop_at_begin, use_mfma;
+    int speculate;        // 1: speculative trials (see the trial loop); UH_BA_SPEC=0 keeps the three-hand-off form for A/B measurements
     unsigned launch_id;   // tags the error / completion words of this launch
     unsigned tag_base;    // (launch sequence of this optimizer & 0xFFFFF) << 12: the upper bits of every exchanged word's tag.  The exchange
                           // buffers are zeroed whenever they are (re)allocated and whenever the sequence wraps, so a stale word never matches.
@@ -290,6 +291,23 @@ struct PartTranspose {
     }
 };
 
+// chi2 sum, max and a second sum with the same pair of barriers (s_red holds 16 doubles)
+template <int NW>
+__device__ __forceinline__ void block_reduce3(double& a, double& b, double& c, double* s_red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ta = __shfl_xor(a, o), tb = __shfl_xor(b, o), tc = __shfl_xor(c, o);
+        a += ta; b = fmax(b, tb); c += tc;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = a; s_red[8 + (threadIdx.x >> 6)] = b; s_red[4 + (threadIdx.x >> 6)] = c; }
+    __syncthreads();
+    double ra = s_red[0], rb = s_red[8], rc = s_red[4];
+#pragma unroll
+    for (int w = 1; w < NW; w++) { ra += s_red[w]; rb = fmax(rb, s_red[8 + w]); rc += s_red[4 + w]; }
+    a = ra; b = rb; c = rc;
+}
+
 typedef double pmf4 __attribute__((ext_vector_type(4)));
 
 template <int NW>
@@ -473,6 +491,8 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     };
     auto part_at = [&](int i) -> size_t { const int sl = i / SL; return ((size_t)sl * G + g) * SL + (i - sl * SL); };   // element i of this workgroup's partial
 
+    bool clk_on = false;
+#define UH_BA_CLKT(i) do { if (clk_on) UH_BA_CLK(i); } while (0)
     BAState st;
     memset(&st, 0, sizeof(st));
     st.phase = 2; st.lambda = -1; st.ni = 2;
@@ -537,11 +557,10 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     };
     // ================================================================================ phase 1: linearise + Schur partial
     // first == true: the pass's opening evaluation at the current estimate (computeActiveErrors + computeLambdaInit): chi2 of
-    // every observation is recorded, the reduced-system product is skipped.  have_lin: acc / hp / H already hold this estimate's values.
-    auto phase1 = [&](double lambda, bool first, bool have_lin) {
+    // every observation is recorded, the reduced-system product is skipped.  acc / hp / H hold the linearisation (lin_eval, called just before).
+    auto phase1 = [&](double lambda, bool first, double scale_lane, double stop_val) {
         tagA = next_tag();
-        if (!have_lin) lin_eval(st.cur, X, first);
-        if (!first) UH_BA_CLK(52);
+        if (!first) UH_BA_CLKT(52);
 #pragma unroll
         for (int i = 0; i < 10; i++) {
 #pragma unroll
@@ -581,11 +600,11 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
 #pragma unroll
             for (int i = 0; i < NHP; i++) if (i < real) U[(wv * NF + s) * 33 + off + i] = hp[i];
         }
-        if (!first) UH_BA_CLK(53);
+        if (!first) UH_BA_CLKT(53);
         const double chi_part = (live && s == 0) ? acc[9] : 0.0;
         const double maxd = (live && s == 0 && any_pt) ? fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5]))) : 0.0;
-        double cs = chi_part, mx = maxd;
-        block_reduce2<kPWaves, true>(cs, mx, s_red);   // (its barriers also publish Yt / s_wv / the camera sums)
+        double cs = chi_part, mx = maxd, ss = scale_lane;
+        block_reduce3<kPWaves>(cs, mx, ss, s_red);   // (its barriers also publish Yt / s_wv / the camera sums)
         for (int t = tid; t < NF * 33; t += kPThreads) {   // 264 sums, wave order
             double r = U[t];
 #pragma unroll
@@ -593,8 +612,9 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             const int sc = t / 33, i = t - 33 * sc;
             s_out[i < 27 ? sc * 27 + i : NF * 27 + 6 * sc + (i - 27)] = r;
         }
-        if (tid == 0) { s_out[NF * 27 + NP] = cs; s_out[NF * 27 + NP + 1] = 0; s_out[NF * 27 + NP + 2] = mx; s_out[NF * 27 + NP + 3] = 0; }
-        if (!first) UH_BA_CLK(54);
+        // scalars of a partial: chi2 at the linearisation point, (speculative trial:) the previous trial's scale sum, max |Hll_jj|, stop flag
+        if (tid == 0) { s_out[NF * 27 + NP] = cs; s_out[NF * 27 + NP + 1] = ss; s_out[NF * 27 + NP + 2] = mx; s_out[NF * 27 + NP + 3] = g == 0 ? stop_val : 0.0; }
+        if (!first) UH_BA_CLKT(54);
         // S = Yt^T Yt.  Default: vector FMA, 4x4 register blocks — the nblk upper blocks of the nb4 x nb4 block grid x KS splits of the K
         // range (78 x 3 = 234 items for eight free cameras: one per lane; more cameras: several per lane), 16 accumulators each, four
         // ds_read_b128 per 16 FMAs; the splits are added in order through LDS.  Measured on MI355X (scripts/micro/mfma_f64_rate.hip):
@@ -689,9 +709,9 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 for (int v = 0; v < 4; v++) U[ti1 * 256 + lane * 4 + v] = t1[v];
             }
         }
-        if (!first) UH_BA_CLK(55);
+        if (!first) UH_BA_CLKT(55);
         __syncthreads();
-        if (!first) UH_BA_CLK(56);
+        if (!first) UH_BA_CLKT(56);
         __syncthreads();   // s_out complete
         // the partial goes out with consecutive lanes on consecutive words (one element per lane and instruction was 64 cache lines per store)
         for (int i = tid; i < NF * 27 + NP + 4; i += kPThreads) tst(q.part, part_at(OFF_CAM + i), s_out[i], tagA);
@@ -728,7 +748,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             }
             R[idx] = r;
         }
-        UH_BA_CLK(50);
+        UH_BA_CLKT(50);
         __syncthreads();
         if (s_flag[1]) return false;
         for (int e = tid; e < SL; e += kPThreads) {
@@ -737,7 +757,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             for (int hg = 1; hg < HG; hg++) { const double v = R[hg * SL + e]; r = is_max ? fmax(r, v) : r + v; }
             tst(q.red, (size_t)g * SL + e, r, tagB);
         }
-        UH_BA_CLK(51);
+        UH_BA_CLKT(51);
         __syncthreads();   // U is free again
         return true;
     };
@@ -761,6 +781,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 if (row <= col && col < n) t = o.U + col * ld + row;
             } else if (idx < OFF_BS) t = (o.out + (idx - OFF_CAM)) | (1 << 24);
             else if (idx < OFF_SC) t = (o.bs + (idx - OFF_BS)) | (1 << 24);
+            else t = (o.sc + 4 + (idx - OFF_SC)) | (1 << 24);   // the four scalars -> s_sc[4 .. 7] (the speculative trial's decision reads them)
         }
         return t;
     };
@@ -797,49 +818,69 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         if (pass == 0 && q.stop_at_begin) { st.phase = 2; st.stopped = 1; }
         if (st.phase == 2) continue;
 
-        // ---- opening evaluation: chi2 at the current estimate, lambda = tau * max |H_jj| (computeLambdaInit)
-        phase1(1.0, true, false);
-        if (!reduce_slices()) return;
-        lin_eval(st.cur, X, false);   // the first trial's linearisation (same estimate), inside the latency of the reduced vector's hand-off
-        {   // every wave for itself: the diagonal entries of Hpp over the lanes (n <= 128: at most two per lane), max butterfly
-            // (all of a lane's words go out as one batch, not as dependent round trips)
-            double m = 0.0;
-            {
-                const int d0 = lane, d1 = lane + 64;
-                const int sc0 = d0 / 6, a0 = d0 - 6 * sc0, sc1 = d1 / 6, a1 = d1 - 6 * sc1;
-                const size_t i_d0 = d0 < n ? (size_t)(OFF_CAM + sc0 * 27 + (a0 * 6 - a0 * (a0 - 1) / 2)) : (size_t)OFF_SC;   // diagonal of the 21-entry upper triangle
-                const size_t i_d1 = d1 < n ? (size_t)(OFF_CAM + sc1 * 27 + (a1 * 6 - a1 * (a1 - 1) / 2)) : (size_t)OFF_SC;
-                long long t0 = 0;
-                for (;;) {
-                    const TWord wm = tld_raw(q.red, OFF_SC + 2), wd0 = tld_raw(q.red, i_d0), wd1 = tld_raw(q.red, i_d1), wc = tld_raw(q.red, OFF_SC);
-                    m = lane == 0 ? tval(wm) : 0.0;
-                    if (d0 < n) m = fmax(m, fabs(tval(wd0)));
-                    if (d1 < n) m = fmax(m, fabs(tval(wd1)));
-                    chi_lin_pass = tval(wc);
-                    if ((tok(wm, tagB) && tok(wd0, tagB) && tok(wd1, tagB) && tok(wc, tagB)) || give_up(t0)) break;
-                }
-            }
-#pragma unroll
-            for (int oo = 32; oo > 0; oo >>= 1) m = fmax(m, __shfl_xor(m, oo));
-            st.lambda = 1e-5 * m; st.ni = 2;
-        }
-        __syncthreads();
-        if (s_flag[1]) return;
-
-        UH_BA_CLK(3 + 3 * pass);
-        bool spec_lin = true;   // acc / hp / H hold the linearisation at the current estimate (left by the opening, then by every trial's speculation)
-        while (st.phase != 2) {
-            const double lambda = st.lambda;
-            const int cur = st.cur, trial = cur ^ 1;
+        // ONE ITERATION of the loop below = [linearise] -> phase 1 -> hand-offs A, B -> [open decision] -> solve -> update -> (speculate | errors, C,
+        // decision).  The linearisation and phase 1 have exactly one call site (they are ~600 instructions and ~150 live registers:
+        // three inlined copies spilled 60 registers per lane and cost 2 us per trial); the pass's opening evaluation (chi2 at the current
+        // estimate, lambda = tau * max |H_jj|: computeLambdaInit) is the loop's first iteration, which leaves after hand-off A.
+        //
+        // SPECULATIVE TRIALS.  g2o accepts a step with gain ratio rho >= 0.94 by lambda <- lambda / 3 — every trial of a converging local BA.
+        // So a trial that cannot be the pass's last does not hand its chi2 around and wait for the verdict (hand-off C): it linearises at
+        // the TRIAL estimate at once (that evaluation IS the trial's error evaluation), runs phase 1 with lambda / 3 and sends the next
+        // trial's partial with the chi2 / scale sums of this one riding in its scalar slots.  Every workgroup takes the decision when the
+        // reduced vector arrives (B); accepted with exactly lambda / 3: the assembled system is the next trial's, two hand-offs per
+        // trial instead of three.  Anything else (rejected, another lambda, stop): the partial is dropped and phase 1 runs again from
+        // the decided state, identically in every workgroup.
+        bool opening = true;
+        bool pend = false;        // a speculative partial is out; the decision on the trial it follows is still open
+        double lambda_spec = 0, scale_lane = 0, stop_val = 0;   // what the speculative phase 1 runs with / carries
+        if (pass == 0 && g == 0 && tid == 0) { p.clk[58] = 0; p.clk[59] = 0; }   // (debug clocks: speculative trials kept / dropped, counted by workgroup 0)
+        int loop_no = 0;   // (the trial-phase clocks 40 .. 57 are those of the second pass's fourth loop iteration: a speculative trial in steady state)
+        while (opening || st.phase != 2) {
+            ++loop_no;
+            clk_on = pass == 1 && loop_no == 4;
+            double lambda = pend ? lambda_spec : st.lambda;
+            int cur = st.cur, trial = cur ^ 1;
             // the force-stop byte lives in pinned HOST memory: a PCIe round trip.  It is requested here, a whole trial before its value is
             // sent with the chi2 partials, instead of on the hand-off itself (1.5 - 3 us in front of every decision)
             unsigned char stop_byte = 0;
             if (g == 0 && tid == 0 && p.stop) stop_byte = *p.stop;
-            UH_BA_CLK(40);
-            phase1(lambda, false, spec_lin);
-            UH_BA_CLK(41);
+            UH_BA_CLKT(40);
+            {
+                const double Xe[3] = {pend ? Xt[0] : X[0], pend ? Xt[1] : X[1], pend ? Xt[2] : X[2]};
+                lin_eval(pend ? trial : cur, Xe, opening || pend);   // (chi2 recorded: computeActiveErrors at the pass's start / at the trial estimate)
+                phase1(opening ? 1.0 : lambda, opening, scale_lane, stop_val);
+            }
+            UH_BA_CLKT(41);
             if (!reduce_slices()) return;
-            UH_BA_CLK(42);
+            UH_BA_CLKT(42);
+            if (opening) {
+                opening = false;
+                // every wave for itself: the diagonal entries of Hpp over the lanes (n <= 128: at most two per lane), max butterfly
+                // (all of a lane's words go out as one batch, not as dependent round trips)
+                double m = 0.0;
+                {
+                    const int d0 = lane, d1 = lane + 64;
+                    const int sc0 = d0 / 6, a0 = d0 - 6 * sc0, sc1 = d1 / 6, a1 = d1 - 6 * sc1;
+                    const size_t i_d0 = d0 < n ? (size_t)(OFF_CAM + sc0 * 27 + (a0 * 6 - a0 * (a0 - 1) / 2)) : (size_t)OFF_SC;   // diagonal of the 21-entry upper triangle
+                    const size_t i_d1 = d1 < n ? (size_t)(OFF_CAM + sc1 * 27 + (a1 * 6 - a1 * (a1 - 1) / 2)) : (size_t)OFF_SC;
+                    long long t0 = 0;
+                    for (;;) {
+                        const TWord wm = tld_raw(q.red, OFF_SC + 2), wd0 = tld_raw(q.red, i_d0), wd1 = tld_raw(q.red, i_d1), wc = tld_raw(q.red, OFF_SC);
+                        m = lane == 0 ? tval(wm) : 0.0;
+                        if (d0 < n) m = fmax(m, fabs(tval(wd0)));
+                        if (d1 < n) m = fmax(m, fabs(tval(wd1)));
+                        chi_lin_pass = tval(wc);
+                        if ((tok(wm, tagB) && tok(wd0, tagB) && tok(wd1, tagB) && tok(wc, tagB)) || give_up(t0)) break;
+                    }
+                }
+#pragma unroll
+                for (int oo = 32; oo > 0; oo >>= 1) m = fmax(m, __shfl_xor(m, oo));
+                st.lambda = 1e-5 * m; st.ni = 2;
+                __syncthreads();
+                if (s_flag[1]) return;
+                UH_BA_CLK(3 + 3 * pass);
+                continue;
+            }
             // ---- assemble S = Hpp + lambda I - Yt^T Yt (lower triangle, bordered with b = bp - b_schur), factorise, substitute
             for (int b0 = 0; b0 < q.nelem; b0 += 8 * kPThreads) {   // batches of eight elements per thread (one batch for up to eight free cameras)
                 double rv[8];
@@ -854,6 +895,25 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             }
             __syncthreads();
             if (s_flag[1]) return;
+            if (pend) {   // the open decision (every thread, same inputs, same code)
+                pend = false;
+                scale_lane = 0; stop_val = 0;
+                DecideSums sm;
+                sm.lin = chi_lin_pass; sm.chi = s_sc[4]; sm.scale = s_sc[5]; sm.xs = s_sc[0];
+                const bool stopv = s_sc[7] != 0.0;
+                st.solve_ok = 1;
+                st.pending = 1;
+                st = apply_decision(st, sm, stopv);
+                const bool accepted = st.cur != cur;
+                if (accepted) { X[0] = Xt[0]; X[1] = Xt[1]; X[2] = Xt[2]; }
+                const bool kept = accepted && st.phase == 0 && st.lambda == lambda_spec;
+                if (g == 0 && tid == 0) p.clk[kept ? 58 : 59] += 1;
+                if (!kept) {   // not what was speculated on: again from the decided state
+                    __syncthreads();   // (the assembled entries in U are dropped; phase 1 writes there)
+                    continue;
+                }
+                cur = st.cur; trial = cur ^ 1;
+            }
             for (int t = tid; t < nfree * 21; t += kPThreads) {
                 const int sc = t / 21, qq = t - 21 * sc;
                 int a = 0, rem = qq;
@@ -869,16 +929,16 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             }
             if (tid == 0) s_flag[0] = 1;
             __syncthreads();
-            UH_BA_CLK(43);
+            UH_BA_CLKT(43);
             const bool failed = ldlt_bordered_lds(Mm, n, ld, nfree, npairs, s_pair, s_w);   // (row-per-lane up to 64 rows, two rows per lane up to 128)
             if (failed && tid == 0) s_flag[0] = 0;
             __syncthreads();
-            UH_BA_CLK(44);
+            UH_BA_CLKT(44);
             const int ok = s_flag[0];
             if (ok) { if (NF == 8 || n <= 64) backsolve_lds(Mm, n, ld, s_x); else backsolve2_lds(Mm, n, ld, s_x); }
             else for (int i = tid; i < n; i += kPThreads) s_x[i] = 0.0;
             __syncthreads();
-            UH_BA_CLK(45);
+            UH_BA_CLKT(45);
             if (wv == 0) {   // computeScale's pose part: sum x (lambda x + b)
                 double xs = 0;
                 for (int i = lane; i < n; i += 64) { const double x = s_x[i]; xs += x * (lambda * x + s_bp[i]); }
@@ -922,7 +982,14 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 Xt[0] += x0; Xt[1] += x1; Xt[2] += x2;
             }
             __syncthreads();   // trial poses complete
-            UH_BA_CLK(46);
+            UH_BA_CLKT(46);
+            if (q.speculate && ok && st.iteration + 1 < st.max_iters) {
+                lambda_spec = lambda * (1. / 3.);
+                scale_lane = scale_part; stop_val = stop_byte ? 1.0 : 0.0;
+                pend = true;
+                UH_BA_CLKT(49);
+                continue;
+            }
             // ---- trial errors (computeActiveErrors at the trial estimate)
             double chi_part = 0;
             if (has && act) {
@@ -946,8 +1013,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 tst(q.partC, 4 * (size_t)g, cs, tagC); tst(q.partC, 4 * (size_t)g + 1, ss, tagC);
                 if (g == 0) tst(q.partC, 2, stop_byte ? 1.0 : 0.0, tagC);
             }
-            UH_BA_CLK(47);
-            lin_eval(trial, Xt, false);   // speculation: the next trial's linearisation if this one is accepted (runs inside the hand-off's latency)
+            UH_BA_CLKT(47);
             // ---- decision (every wave of every workgroup, same inputs, same code)
             {
                 double c = 0, sc = 0;
@@ -970,18 +1036,17 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                         if (okw || give_up(t0)) break;
                     }
                 }
-                UH_BA_CLK(48);
+                UH_BA_CLKT(48);
                 DecideSums sm;
                 sm.lin = chi_lin_pass; sm.chi = wave_sum_fixed(c); sm.scale = wave_sum_fixed(sc); sm.xs = s_sc[0];
                 st.solve_ok = ok;
                 st.pending = 1;
                 st = apply_decision(st, sm, stopv);
-                spec_lin = st.cur != cur;   // accepted: the estimate IS the trial point the speculation was evaluated at
                 if (st.cur != cur) { X[0] = Xt[0]; X[1] = Xt[1]; X[2] = Xt[2]; }
             }
             __syncthreads();   // (a wave that gave up waiting has decided on garbage: everybody leaves together)
             if (s_flag[1]) return;
-            UH_BA_CLK(49);
+            UH_BA_CLKT(49);
         }
     }
 
