@@ -793,19 +793,29 @@ __device__ __forceinline__ bool ldlt_rowlane2_lds(double* M, int n, int ld, int 
             }
         }
         // every lane stores both rows (rows above the block land in the unused upper triangle; idle high lanes repeat the last row)
-        const int ri0 = r0 - k0, ri1 = r1 - k0;
         double* yo = s_y + (kb & 1) * 768;
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            M[r0 * ld + k0 + j] = ri0 == j ? dj[j] : lp0[j];
-            M[r1 * ld + k0 + j] = ri1 == j ? dj[j] : lp1[j];
+            M[r0 * ld + k0 + j] = lp0[j];
+            M[r1 * ld + k0 + j] = lp1[j];
             yo[j * 128 + r0] = a0[j];
             yo[j * 128 + r1] = a1[j];
         }
     };
+    // Block column kb of M from the diagonal upwards <- 0 (what wave 0's unmasked stores left there): the back substitution (backsolve2_lds)
+    // then needs no mask — a lane whose row is not below the column multiplies by zero.  Done by waves 1..3 behind their tiles; with two
+    // rows per lane on wave 0 they have the slack (one row per lane, n <= 63: they do not — there the factorisation got 0.9 us slower for
+    // 0.56 us less back substitution, and ldlt_rowlane_lds / backsolve_lds keep the masked form).  D is not kept: nobody needs it.
+    auto zero_upper = [&](int kb, int first, int step) {
+        const int k0 = 6 * kb;
+        for (int u = first; u < 6 * (k0 + 6); u += step) {
+            const int r = u / 6, j = u - 6 * r;
+            if (r <= k0 + j) M[r * ld + k0 + j] = 0.0;
+        }
+    };
     auto trailing = [&](int kb) {   // waves 1..3: panel kb onto the tiles (s1 <= s2) with s1 >= kb + 2 and the right-hand-side row
         const int k0 = 6 * kb, J0 = kb + 2;
-        if (J0 >= nb) return;
+        if (J0 >= nb) { zero_upper(kb, tid - 64, kSolveThreads - 64); return; }
         const int tile0 = J0 * nfree - J0 * (J0 - 1) / 2;
         const int ntile = npairs - tile0;
         const int nunits = 6 * ntile + (nb - J0);
@@ -832,6 +842,7 @@ __device__ __forceinline__ bool ldlt_rowlane2_lds(double* M, int n, int ld, int 
 #pragma unroll
             for (int j = 0; j < 6; j++) if (!diag || c0 + j <= r) M[r * ld + c0 + j] = acc[j];
         }
+        zero_upper(kb, tid - 64, kSolveThreads - 64);   // (after the tiles: they are what wave 0 waits for)
     };
     if (wv == 0 && nb > 0) wave0_step(0);
     for (int kb = 0; kb < nb; kb++) {
@@ -840,6 +851,7 @@ __device__ __forceinline__ bool ldlt_rowlane2_lds(double* M, int n, int ld, int 
         if (wv == 0) wave0_step(kb + 1);
         else if (tid < kSolveThreads) trailing(kb);
     }
+    if (nb > 0 && tid < kSolveThreads) zero_upper(nb - 1, tid, kSolveThreads);
     if (wv != 0) failed = false;
     return failed;
 }
@@ -848,23 +860,41 @@ __device__ __forceinline__ bool ldlt_rowlane2_lds(double* M, int n, int ld, int 
 __device__ __forceinline__ void backsolve2_lds(const double* M, int n, int ld, double* s_x) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (wv != 0) return;
+    // (unmasked: ldlt_rowlane2_lds leaves zeros on and above the diagonal.  Two sweeps, so that the register a column's value is read from is fixed per sweep: columns
+    // n-1 .. 64 in pairs (n is even), then 63 .. 0 in fours.)
     double x0 = M[(size_t)n * ld + lane], x1 = lane + 64 < n ? M[(size_t)n * ld + lane + 64] : 0.0;
     const int r1 = lane + 64 < n ? lane + 64 : n - 1;
-    double l0[4], l1[4], n0[4], n1[4];
+    {
+        double l0[2], l1[2], n0[2], n1[2];
 #pragma unroll
-    for (int t = 0; t < 4; t++) { const int jj = n - 1 - t >= 0 ? n - 1 - t : 0; l0[t] = M[(size_t)jj * ld + lane]; l1[t] = M[(size_t)jj * ld + r1]; }
-    for (int j0 = n - 1; j0 >= 0; j0 -= 4) {
+        for (int t = 0; t < 2; t++) { const int jj = n - 1 - t; l0[t] = M[(size_t)jj * ld + lane]; l1[t] = M[(size_t)jj * ld + r1]; }
+        for (int j0 = n - 1; j0 >= 64; j0 -= 2) {
 #pragma unroll
-        for (int t = 0; t < 4; t++) { const int jj = j0 - 4 - t >= 0 ? j0 - 4 - t : 0; n0[t] = M[(size_t)jj * ld + lane]; n1[t] = M[(size_t)jj * ld + r1]; }
+            for (int t = 0; t < 2; t++) { const int jj = j0 - 2 - t >= 64 ? j0 - 2 - t : 64; n0[t] = M[(size_t)jj * ld + lane]; n1[t] = M[(size_t)jj * ld + r1]; }
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int j = j0 - t;   // column j: rows i < j take -L[j][i] x_j (steps past column 0 multiply by zero)
-            const double xj = readlane2_f64(x0, x1, j > 0 ? j : 0);
-            x0 = fma(-(lane < j ? l0[t] : 0.0), xj, x0);
-            x1 = fma(-(lane + 64 < j ? l1[t] : 0.0), xj, x1);
+            for (int t = 0; t < 2; t++) {
+                const double xj = readlane_f64(x1, j0 - t - 64);   // (>= 0: n - 64 is even)
+                x0 = fma(-l0[t], xj, x0);
+                x1 = fma(-l1[t], xj, x1);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++) { l0[t] = n0[t]; l1[t] = n1[t]; }
         }
+    }
+    {
+        double l0[4], n0[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) { l0[t] = n0[t]; l1[t] = n1[t]; }
+        for (int t = 0; t < 4; t++) l0[t] = M[(size_t)(63 - t) * ld + lane];
+        for (int j0 = 63; j0 >= 0; j0 -= 4) {
+            if (j0 >= 4) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) n0[t] = M[(size_t)(j0 - 4 - t) * ld + lane];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) x0 = fma(-l0[t], readlane_f64(x0, j0 - t), x0);
+#pragma unroll
+            for (int t = 0; t < 4; t++) l0[t] = n0[t];
+        }
     }
     s_x[lane] = x0;
     if (lane + 64 < n) s_x[lane + 64] = x1;

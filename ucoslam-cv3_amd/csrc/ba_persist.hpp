@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     double* const s_out = lds + o.out;
     double* const s_x = lds + o.x;
     double* const s_bp = lds + o.bp;
-    double* const s_bs = lds + o.bs;
+    (void)o.bs;   // (the b_schur receive area of earlier forms: the reduced right-hand side now arrives in row n of Mm)
     double* const s_bsp = lds + o.bsp;
     double* const s_pose = lds + o.pose;
     double* const s_poseR = lds + o.poseR;
@@ -491,6 +491,44 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     };
     auto part_at = [&](int i) -> size_t { const int sl = i / SL; return ((size_t)sl * G + g) * SL + (i - sl * SL); };   // element i of this workgroup's partial
 
+    // element of the product partial that holds (row, col), row <= col (the inverse of dst_of's layouts)
+    auto prod_index = [&](int row, int col) -> int {
+        if (NF == 8 && q.use_mfma) {
+            const int tm = row >> 4, tn = col >> 4, ti = tm == 0 ? tn : (tm == 1 ? 2 + tn : 5), r16 = row & 15;
+            return ti * 256 + ((((r16 & 3) << 4) | (col & 15)) << 2) + (r16 >> 2);
+        }
+        const int bi = row >> 2, bj = col >> 2;
+        return (bi * q.nb4 - bi * (bi - 1) / 2 + (bj - bi)) * 16 + (row & 3) * 4 + (col & 3);
+    };
+    // is element idx of a partial a diagonal entry of S?  (the slice reduction puts lambda there)
+    auto is_diag_elem = [&](int idx) -> bool {
+        if (idx >= OFF_CAM) return false;
+        int row, col;
+        if (NF == 8 && q.use_mfma) {
+            const int ti = idx >> 8, lq = (idx >> 2) & 63, vv = idx & 3;
+            const int tm = ti < 3 ? 0 : (ti < 5 ? 1 : 2), tn = ti < 3 ? ti : (ti < 5 ? ti - 2 : 2);
+            row = 16 * tm + (lq >> 4) + 4 * vv; col = 16 * tn + (lq & 15);
+        } else {
+            const int bq = idx >> 4;
+            row = 4 * s_blk[bq][0] + ((idx >> 2) & 3); col = 4 * s_blk[bq][1] + (idx & 3);
+        }
+        return row == col && col < n;
+    };
+    // this thread's share of folding Hpp (21 upper entries per free camera) into the product: product element and camera-sum index
+    int fold_i[2], fold_s[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int t = tid + u * kPThreads;
+        fold_i[u] = -1; fold_s[u] = 0;
+        if (t < nfree * 21) {
+            const int sc = t / 21, qq = t - 21 * sc;
+            int a = 0, rem = qq;
+            while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+            fold_i[u] = prod_index(6 * sc + a, 6 * sc + a + rem);
+            fold_s[u] = sc * 27 + qq;
+        }
+    }
+    const bool red_diag0 = tid < SL && is_diag_elem(g * SL + tid);
     bool clk_on = false;
 #define UH_BA_CLKT(i) do { if (clk_on) UH_BA_CLK(i); } while (0)
     BAState st;
@@ -710,9 +748,17 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             }
         }
         if (!first) UH_BA_CLKT(55);
-        __syncthreads();
+        __syncthreads();   // the product (U) and the camera sums (s_out) are complete
         if (!first) UH_BA_CLKT(56);
-        __syncthreads();   // s_out complete
+        if (!first) {
+            // S = sum over workgroups of (Hpp_g - Y_g^T Y_g) + lambda I and b = sum of (bp_g - b_schur_g): each workgroup folds its camera
+            // sums into its product partial and its b_schur partial HERE, so that what arrives after hand-off B is the reduced system
+            // itself (the receiver used to add Hpp and form bp - b_schur in a second pass behind another barrier, on the critical path)
+#pragma unroll
+            for (int u = 0; u < 2; u++) if (fold_i[u] >= 0) U[fold_i[u]] -= s_out[fold_s[u]];
+            for (int j = tid; j < n; j += kPThreads) { const int sc = j / 6; s_out[NF * 27 + j] -= s_out[sc * 27 + 21 + (j - 6 * sc)]; }
+        }
+        __syncthreads();
         // the partial goes out with consecutive lanes on consecutive words (one element per lane and instruction was 64 cache lines per store)
         for (int i = tid; i < NF * 27 + NP + 4; i += kPThreads) tst(q.part, part_at(OFF_CAM + i), s_out[i], tagA);
         for (int i = tid; i < OFF_CAM; i += kPThreads) tst(q.part, part_at(i), first ? 0.0 : U[i], tagA);   // (opening evaluation: no product, but the round's tag)
@@ -720,7 +766,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
 
     // ================================================================================ exchange A -> B: slice-wise reduction
     unsigned tagB = 0;
-    auto reduce_slices = [&]() -> bool {
+    auto reduce_slices = [&](double lam) -> bool {   // lam: added to the diagonal of S here (0 for the opening evaluation)
         tagB = next_tag();
         // HG groups of sources per element, chosen so that one pass of the workgroup covers the slice (SL * HG <= 256 threads) and a
         // thread's sources (~G / HG <= 8) go out as ONE batch of loads: every extra pass or batch is a memory round trip (~1.5 us)
@@ -755,6 +801,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             const bool is_max = g * SL + e == OFF_SC + 2;
             double r = R[e];
             for (int hg = 1; hg < HG; hg++) { const double v = R[hg * SL + e]; r = is_max ? fmax(r, v) : r + v; }
+            if (e == tid ? red_diag0 : is_diag_elem(g * SL + e)) r -= lam;   // (the product arrives negated: - (Y^T Y - Hpp - lambda))
             tst(q.red, (size_t)g * SL + e, r, tagB);
         }
         UH_BA_CLKT(51);
@@ -763,8 +810,8 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     };
 
     // Where the elements this thread fetches from the reduced vector go (the same every trial): an offset into `lds` (doubles), with bit 24
-    // set for the entries that are copied (camera sums -> s_out, b_schur -> s_bs) and clear for the Schur product's entries, which
-    // enter the lower triangle of S negated; -1: nothing to store.
+    // set for the entries that are copied (bp -> s_bp, the scalars -> s_sc) and clear for the entries that arrive negated: the product
+    // (Y^T Y - Hpp - lambda on the diagonal) into the lower triangle of S, b_schur - bp into row n; -1: nothing to store.
     auto dst_of = [&](int idx) -> int {
         int t = -1;
         if (idx < q.nelem) {
@@ -779,8 +826,10 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                     row = 4 * s_blk[bq][0] + rr; col = 4 * s_blk[bq][1] + cq;
                 }
                 if (row <= col && col < n) t = o.U + col * ld + row;
-            } else if (idx < OFF_BS) t = (o.out + (idx - OFF_CAM)) | (1 << 24);
-            else if (idx < OFF_SC) t = (o.bs + (idx - OFF_BS)) | (1 << 24);
+            } else if (idx < OFF_BS) {   // camera sums: bp is kept (computeScale needs it); the Hpp entries have been folded into the product by the senders
+                const int i = idx - OFF_CAM, sc = i / 27, k = i - 27 * sc;
+                if (k >= 21) t = (o.bp + 6 * sc + (k - 21)) | (1 << 24);
+            } else if (idx < OFF_SC) t = o.U + n * ld + (idx - OFF_BS);   // b_schur - bp, negated on arrival: the bordered system's row n
             else t = (o.sc + 4 + (idx - OFF_SC)) | (1 << 24);   // the four scalars -> s_sc[4 .. 7] (the speculative trial's decision reads them)
         }
         return t;
@@ -851,7 +900,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 phase1(opening ? 1.0 : lambda, opening, scale_lane, stop_val);
             }
             UH_BA_CLKT(41);
-            if (!reduce_slices()) return;
+            if (!reduce_slices(opening ? 0.0 : lambda)) return;
             UH_BA_CLKT(42);
             if (opening) {
                 opening = false;
@@ -893,7 +942,8 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                     if (t >= 0) lds[t & 0xFFFFFF] = (t >> 24) ? rv[u] : -rv[u];   // bit 24: camera sums / b_schur keep their sign, product entries enter S negated
                 }
             }
-            __syncthreads();
+            if (tid == 0) s_flag[0] = 1;
+            __syncthreads();   // the reduced system [S b] (lower triangle + row n of Mm) and bp are complete
             if (s_flag[1]) return;
             if (pend) {   // the open decision (every thread, same inputs, same code)
                 pend = false;
@@ -914,21 +964,6 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 }
                 cur = st.cur; trial = cur ^ 1;
             }
-            for (int t = tid; t < nfree * 21; t += kPThreads) {
-                const int sc = t / 21, qq = t - 21 * sc;
-                int a = 0, rem = qq;
-                while (rem >= 6 - a) { rem -= 6 - a; ++a; }
-                const int c = a + rem;
-                Mm[(6 * sc + c) * ld + 6 * sc + a] += s_out[sc * 27 + qq] + (a == c ? lambda : 0.0);
-            }
-            if (tid < n) {
-                const int sc = tid / 6, a = tid - 6 * sc;
-                const double bpv = s_out[sc * 27 + 21 + a];
-                s_bp[tid] = bpv;
-                Mm[(size_t)n * ld + tid] = bpv - s_bs[tid];
-            }
-            if (tid == 0) s_flag[0] = 1;
-            __syncthreads();
             UH_BA_CLKT(43);
             const bool failed = ldlt_bordered_lds(Mm, n, ld, nfree, npairs, s_pair, s_w);   // (row-per-lane up to 64 rows, two rows per lane up to 128)
             if (failed && tid == 0) s_flag[0] = 0;
