@@ -26,6 +26,13 @@
 //     fixed: results are run-to-run deterministic and identical in every workgroup.
 #pragma once
 
+// The translation unit is compiled with -ffp-contract=off (the ORB stage reproduces the reference's un-contracted float arithmetic bit for
+// bit).  The BA's parity bar is a tolerance (1e-6 on the state, identical iteration counts), not bits: from here to the end of the unit
+// (this header is included last; only host code follows) a * b + c may fuse.  The edge evaluation and the 61 sums of a linearisation
+// were 738 v_mul_f64 + 576 v_add_f64 beside 426 v_fma_f64 on a kernel whose every instruction sits on a lone wave's critical path.
+// (apply_decision, the LDL^T and the back substitution are defined before this point and keep the unit's setting.)
+#pragma clang fp contract(fast)
+
 constexpr int kPThreads = 256;   // 4 waves, one per SIMD: each may use the whole 512-entry register file (256 VGPR + 256 AGPR)
 constexpr int kPWaves = kPThreads / 64;
 constexpr long long kPTimeoutTicks = 300000000ll;   // 3 s of the 100 MHz wall clock: a workgroup that never arrives
@@ -247,15 +254,69 @@ __device__ __forceinline__ void se3_left_update_p(double (&q)[4], double (&t)[3]
     for (int i = 0; i < 3; i++) t[i] = tn[i];
 }
 
+
+// ---- cross-lane sums without the LDS crossbar.  __shfl_xor is ds_bpermute_b32 (an address register, two LDS-pipe operations per double
+// and their ~100-cycle round trip); on a lone wave that latency is not hidden.  gfx950 can do every level of a butterfly in the VALU:
+//   partner 1, 2: DPP quad_perm;  4: row_half_mirror (i <-> 7-i);  8: row_mirror (i <-> 15-i) or row_ror:8 (i <-> i^8);
+//   16, 32: v_permlane16_swap / v_permlane32_swap (rows of 16 / 32 lanes of TWO registers exchanged: odd rows of the first with even rows
+//   of the second) — with both registers holding x, the two results are {own, partner} in one half of the wave and {partner, own} in
+//   the other: their sum is x + x_partner in every lane, no select.
+// The mirror levels pair lane i with another partner than i ^ 4 / i ^ 8, which is as good for an all-reduce: every level is a perfect
+// matching whose two lanes both form a + b, so all lanes end with the same bits (taken in ascending order of the levels).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// a (from this lane) and b (from this lane), rows of ROW lanes: returns {x0, x1} with x0 + x1 = (own a + partner's a) in even rows and
+// (partner's b + own b) in odd rows — the butterfly-transpose step; with a == b the plain pair sum
+template <int ROW>
+__device__ __forceinline__ void swap_rows(double& a, double& b) {
+    static_assert(ROW == 16 || ROW == 32, "v_permlane16_swap / v_permlane32_swap");
+    const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+    unsigned alo = (unsigned)ba, ahi = (unsigned)(ba >> 32), blo = (unsigned)bb, bhi = (unsigned)(bb >> 32);
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)   // (the device pass; through the builtin, not inline asm: the compiler inserts the wait states a VALU write -> permlane read needs)
+    if (ROW == 16) {
+        const auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false), h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        alo = l[0]; blo = l[1]; ahi = h[0]; bhi = h[1];
+    } else {
+        const auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false), h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        alo = l[0]; blo = l[1]; ahi = h[0]; bhi = h[1];
+    }
+#endif
+    a = __longlong_as_double(((long long)ahi << 32) | alo);
+    b = __longlong_as_double(((long long)bhi << 32) | blo);
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140, kDppRor8 = 0x128;
+// sum over the groups of W consecutive lanes (W = 8, 16, 64), the same bits in every lane of a group
+template <int W>
+__device__ __forceinline__ double group_sum(double v) {
+    v += dpp_f64<kDppXor1>(v);
+    v += dpp_f64<kDppXor2>(v);
+    v += dpp_f64<kDppHalfMirror>(v);
+    if (W >= 16) v += dpp_f64<kDppMirror>(v);
+    if (W >= 32) { double a = v, b = v; swap_rows<16>(a, b); v = a + b; }
+    if (W >= 64) { double a = v, b = v; swap_rows<32>(a, b); v = a + b; }
+    return v;
+}
+template <int W>
+__device__ __forceinline__ double group_max(double v) {
+    v = fmax(v, dpp_f64<kDppXor1>(v));
+    v = fmax(v, dpp_f64<kDppXor2>(v));
+    v = fmax(v, dpp_f64<kDppHalfMirror>(v));
+    if (W >= 16) v = fmax(v, dpp_f64<kDppMirror>(v));
+    if (W >= 32) { double a = v, b = v; swap_rows<16>(a, b); v = fmax(a, b); }
+    if (W >= 64) { double a = v, b = v; swap_rows<32>(a, b); v = fmax(a, b); }
+    return v;
+}
+
 // chi2 sum + max (or two sums) over the workgroup with ONE pair of barriers: the two butterflies interleave
 template <int NW, bool SECOND_IS_MAX>
 __device__ __forceinline__ void block_reduce2(double& a, double& b, double* s_red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ta = __shfl_xor(a, o), tb = __shfl_xor(b, o);
-        a += ta;
-        b = SECOND_IS_MAX ? fmax(b, tb) : b + tb;
-    }
+    a = group_sum<64>(a);
+    b = SECOND_IS_MAX ? group_max<64>(b) : group_sum<64>(b);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = a; s_red[8 + (threadIdx.x >> 6)] = b; }
     __syncthreads();
@@ -277,8 +338,17 @@ struct PartTranspose {
         for (int i = 0; i < H; i++) {
             const double lo = v[i];
             const double hi = (i + H < N) ? v[(i + H < N) ? i + H : 0] : 0.0;
-            const double keep = up ? hi : lo, send = up ? lo : hi;
-            nv[i] = keep + __shfl_xor(send, BIT);
+            if constexpr (BIT == 32 || BIT == 16) {   // rows exchanged between the two registers: (own lo + partner's lo) below, (partner's hi + own hi) above
+                double a = lo, b = hi;
+                swap_rows<BIT>(a, b);
+                nv[i] = a + b;
+            } else if constexpr (BIT == 8) {
+                const double keep = up ? hi : lo, send = up ? lo : hi;
+                nv[i] = keep + dpp_f64<kDppRor8>(send);
+            } else {
+                const double keep = up ? hi : lo, send = up ? lo : hi;
+                nv[i] = keep + __shfl_xor(send, BIT);
+            }
         }
         if (up) { off += H; real = real - H > 0 ? real - H : 0; }
         else real = real < H ? real : H;
@@ -294,11 +364,7 @@ struct PartTranspose {
 // chi2 sum, max and a second sum with the same pair of barriers (s_red holds 16 doubles)
 template <int NW>
 __device__ __forceinline__ void block_reduce3(double& a, double& b, double& c, double* s_red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ta = __shfl_xor(a, o), tb = __shfl_xor(b, o), tc = __shfl_xor(c, o);
-        a += ta; b = fmax(b, tb); c += tc;
-    }
+    a = group_sum<64>(a); b = group_max<64>(b); c = group_sum<64>(c);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = a; s_red[8 + (threadIdx.x >> 6)] = b; s_red[4 + (threadIdx.x >> 6)] = c; }
     __syncthreads();
@@ -600,10 +666,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         tagA = next_tag();
         if (!first) UH_BA_CLKT(52);
 #pragma unroll
-        for (int i = 0; i < 10; i++) {
-#pragma unroll
-            for (int oo = NF / 2; oo > 0; oo >>= 1) acc[i] += __shfl_xor(acc[i], oo);
-        }
+        for (int i = 0; i < 10; i++) acc[i] = group_sum<NF>(acc[i]);
         const unsigned long long anym = __ballot(any);
         any_pt = ((anym >> (lane & ~(NF - 1))) & ((1ull << NF) - 1)) != 0;
         bl0 = acc[6]; bl1 = acc[7]; bl2 = acc[8];
@@ -1004,8 +1067,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                     t2 = fma(Yt[(3 * ll + 2) * YS + 6 * s + a], xa, t2);
                 }
             }
-#pragma unroll
-            for (int oo = NF / 2; oo > 0; oo >>= 1) { t0 += __shfl_xor(t0, oo); t1 += __shfl_xor(t1, oo); t2 += __shfl_xor(t2, oo); }
+            t0 = group_sum<NF>(t0); t1 = group_sum<NF>(t1); t2 = group_sum<NF>(t2);
             double scale_part = 0;
             Xt[0] = X[0]; Xt[1] = X[1]; Xt[2] = X[2];
             if (live && any_pt && ok) {
