@@ -555,7 +555,11 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             if (ok || give_up(t0)) return;
         }
     };
-    auto part_at = [&](int i) -> size_t { const int sl = i / SL; return ((size_t)sl * G + g) * SL + (i - sl * SL); };   // element i of this workgroup's partial
+    // (i / SL and h-range / HG by multiplication: a 32-bit division is ~25 instructions, and the hand-offs did nine of them per thread and trial;
+    // m = floor(2^32 / d) + 1 gives floor(i / d) = mulhi(i, m) exactly for i * d < 2^32 — here i < 2^16)
+    const unsigned sl_inv = (unsigned)(0x100000000ull / (unsigned)SL) + 1u;
+    auto div_sl = [&](int i) -> int { return (int)__umulhi((unsigned)i, sl_inv); };
+    auto part_at = [&](int i) -> size_t { const int sl = div_sl(i); return ((size_t)sl * G + g) * SL + (i - sl * SL); };   // element i of this workgroup's partial
 
     // element of the product partial that holds (row, col), row <= col (the inverse of dst_of's layouts)
     auto prod_index = [&](int row, int col) -> int {
@@ -595,6 +599,8 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         }
     }
     const bool red_diag0 = tid < SL && is_diag_elem(g * SL + tid);
+    const int red_HG = max(1, min(G, kPThreads / SL));   // source groups per element in the slice reduction
+    const unsigned hg_inv = (unsigned)(0x100000000ull / (unsigned)red_HG) + 1u;
     bool clk_on = false;
 #define UH_BA_CLKT(i) do { if (clk_on) UH_BA_CLK(i); } while (0)
     BAState st;
@@ -833,11 +839,11 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         tagB = next_tag();
         // HG groups of sources per element, chosen so that one pass of the workgroup covers the slice (SL * HG <= 256 threads) and a
         // thread's sources (~G / HG <= 8) go out as ONE batch of loads: every extra pass or batch is a memory round trip (~1.5 us)
-        const int HG = max(1, min(G, kPThreads / SL));
+        const int HG = red_HG;
         double* const R = U + OFF_CAM;           // behind the staged product, which other waves may still be sending
         const size_t src = (size_t)g * G * SL;   // slice g of every workgroup's partial
         for (int idx = tid; idx < SL * HG; idx += kPThreads) {
-            const int hg = idx / SL, e = idx - hg * SL;
+            const int hg = div_sl(idx), e = idx - hg * SL;
             const bool is_max = g * SL + e == OFF_SC + 2;
             const bool used = g * SL + e < q.nelem;   // (the last slice is padded: nobody writes or needs those elements)
             // every source of this element in ONE batch of loads where possible (G <= 128: at most eight per thread): a separate load
@@ -846,7 +852,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             bool have = false;
             for (int h = hg; used && h < G; h += 8 * HG) {   // eight elements in flight, added in ascending order
                 double v[8];
-                const int cnt = min(8, (G - h + HG - 1) / HG);
+                const int cnt = min(8, HG == 1 ? G - h : (int)__umulhi((unsigned)(G - h + HG - 1), hg_inv));   // (the multiplier of a division by one does not fit 32 bits)
                 tload8(q.part, src + (size_t)h * SL + e, (size_t)HG * SL, cnt, tagA, v);
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
@@ -1028,8 +1034,12 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 cur = st.cur; trial = cur ^ 1;
             }
             UH_BA_CLKT(43);
-            const bool failed = ldlt_bordered_lds(Mm, n, ld, nfree, npairs, s_pair, s_w);   // (row-per-lane up to 64 rows, two rows per lane up to 128)
-            if (failed && tid == 0) s_flag[0] = 0;
+            // (one row per lane up to 63 rows; NF = 16: two waves with one row per lane each up to 118 rows — the eight-lane instantiation
+            // never has more than 48 and does not carry the wider forms' code and registers)
+            bool failed;
+            if constexpr (NF == 8) failed = ldlt_rowlane_lds(Mm, n, ld, nfree, npairs, s_pair, &s_w[0][0][0]);
+            else failed = ldlt_bordered_lds(Mm, n, ld, nfree, npairs, s_pair, s_w);
+            if (failed && lane == 0) s_flag[0] = 0;   // (the wave that saw the pivots: wave 0, or wave 1 of the two-wave factorisation)
             __syncthreads();
             UH_BA_CLKT(44);
             const int ok = s_flag[0];
