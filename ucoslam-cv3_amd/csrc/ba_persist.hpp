@@ -69,7 +69,7 @@ struct BAPersist {
 };
 
 struct PersistLds {      // offsets in doubles into the dynamic LDS block
-    int Yt, U, usz, out, x, bp, bs, bsp, wv, pose, poseR, red, sc, fxchi, fxobs, fxcam, fxact_bytes, fxk_bytes, fxid_bytes, fxptr_bytes, pair_bytes, blk_bytes, flag_bytes, total_bytes;
+    int Yt, U, usz, out, wsum, x, bp, bs, bsp, wv, pose, poseR, red, sc, fxchi, fxobs, fxcam, fxact_bytes, fxk_bytes, fxid_bytes, fxptr_bytes, pair_bytes, blk_bytes, flag_bytes, total_bytes;
 };
 // off_cam = elements of the product part of a partial (nblk * 16, or the six MFMA tiles), KS = K-splits of the product, SL = slice length
 template <int NF>
@@ -81,11 +81,12 @@ __host__ __device__ inline PersistLds persist_lds(int krows, int n, int max_fix,
     o.U = a;
     o.usz = (n + 1) * (n + 1) + (n + 1 <= 64 ? 2 * 121 * 6 : 2 * 6 * 128 + 4);   // reduced system + the factorisation's panel buffer
     if (o.usz < KS * off_cam) o.usz = KS * off_cam;                               // the product's K-split partials
-    { const int r = off_cam + (SL > 256 ? SL : 256) + 8; if (o.usz < r) o.usz = r; }   // the staged product + the slice reduction's scratch
+    { const int r = KS * off_cam + (SL > 256 ? SL : 256) + 8; if (o.usz < r) o.usz = r; }   // the product's K-split partials (added on the way out) + the slice reduction's scratch behind them
     if (o.usz < kPWaves * NF * 33) o.usz = kPWaves * NF * 33;
     if (o.usz < 2048) o.usz = 2048;
     a += o.usz;
     o.out = a; a += NF * 27 + NP + 4;
+    o.wsum = a; a += kPWaves * NF * 33;   // the waves' camera-side sums (outside U: the product may overwrite U while they are being added)
     o.x = a; a += NP; o.bp = a; a += NP; o.bs = a; a += NP;
     o.bsp = a; a += kPWaves * NP;
     o.wv = a; a += krows;
@@ -411,6 +412,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     double* const Mm = U;
     double (*const s_w)[121][6] = reinterpret_cast<double (*)[121][6]>(U + (size_t)ld * ld);
     double* const s_out = lds + o.out;
+    double* const s_wsum = lds + o.wsum;
     double* const s_x = lds + o.x;
     double* const s_bp = lds + o.bp;
     (void)o.bs;   // (the b_schur receive area of earlier forms: the reduced right-hand side now arrives in row n of Mm)
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             int off = 0, real = 33;
             PartTranspose<33, 32, NF>::run(hp, lane, off, real);
 #pragma unroll
-            for (int i = 0; i < NHP; i++) if (i < real) U[(wv * NF + s) * 33 + off + i] = hp[i];
+            for (int i = 0; i < NHP; i++) if (i < real) s_wsum[(wv * NF + s) * 33 + off + i] = hp[i];
         }
         if (!first) UH_BA_CLKT(53);
         const double chi_part = (live && s == 0) ? acc[9] : 0.0;
@@ -713,9 +715,9 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         double cs = chi_part, mx = maxd, ss = scale_lane;
         block_reduce3<kPWaves>(cs, mx, ss, s_red);   // (its barriers also publish Yt / s_wv / the camera sums)
         for (int t = tid; t < NF * 33; t += kPThreads) {   // 264 sums, wave order
-            double r = U[t];
+            double r = s_wsum[t];
 #pragma unroll
-            for (int w = 1; w < kPWaves; w++) r += U[w * NF * 33 + t];
+            for (int w = 1; w < kPWaves; w++) r += s_wsum[w * NF * 33 + t];
             const int sc = t / 33, i = t - 33 * sc;
             s_out[i < 27 ? sc * 27 + i : NF * 27 + 6 * sc + (i - 27)] = r;
         }
@@ -727,8 +729,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         // ds_read_b128 per 16 FMAs; the splits are added in order through LDS.  Measured on MI355X (scripts/micro/mfma_f64_rate.hip):
         // v_fma_f64 sustains 9.1 FMA/clk/SIMD, v_mfma_f64_16x16x4_f64 issues every ~160 cycles = 6.4, so the MFMA form below
         // (UH_BA_SCHUR=mfma: six upper 16x16 tiles split over the waves, accumulators resident in AGPRs) loses on gfx950.
-        if (!first && !(NF == 8 && q.use_mfma)) {
-            __syncthreads();   // the camera sums in U have been read: U is free
+        if (!first && !(NF == 8 && q.use_mfma)) {   // (U is free: its last users — the reduced system, the slice reduction's scratch — are behind barriers)
             const int nitems = q.nblk * q.KS;
             const int kc = (q.krows + q.KS - 1) / q.KS;
             for (int item = tid; item < nitems; item += kPThreads) {
@@ -762,13 +763,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
 #pragma unroll
                 for (int i = 0; i < 16; i++) U[kt * OFF_CAM + bq * 16 + i] = acc4[i];
             }
-            __syncthreads();
-            if (q.KS > 1)   // the splits added in order; staged in U so that the stores below go out coalesced
-                for (int e = tid; e < OFF_CAM; e += kPThreads) {
-                    double r = U[e];
-                    for (int kt = 1; kt < q.KS; kt++) r += U[kt * OFF_CAM + e];
-                    U[e] = r;
-                }
+            // (the K-splits' partials stay apart: the store loop at the end adds them, in order, on the way out)
         }
         // MFMA form: wave 0: (0,0) (0,1), wave 1: (0,2) (1,1), wave 2: (1,2) + half of b_schur, wave 3: (2,2) + the other half — every wave
         // runs the whole K range, so no reduction across waves is needed.
@@ -808,7 +803,6 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             }
             // element index of (tile t, lane, v) = (t*64 + lane)*4 + v; tile order (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
             const int ti0 = wvu == 0 ? 0 : (wvu == 1 ? 2 : (wvu == 2 ? 4 : 5)), ti1 = wvu == 0 ? 1 : 3;
-            __syncthreads();   // the camera sums in U have been read: U is free
 #pragma unroll
             for (int v = 0; v < 4; v++) U[ti0 * 256 + lane * 4 + v] = t0[v];
             if (wvu < 2) {
@@ -830,7 +824,12 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         __syncthreads();
         // the partial goes out with consecutive lanes on consecutive words (one element per lane and instruction was 64 cache lines per store)
         for (int i = tid; i < NF * 27 + NP + 4; i += kPThreads) tst(q.part, part_at(OFF_CAM + i), s_out[i], tagA);
-        for (int i = tid; i < OFF_CAM; i += kPThreads) tst(q.part, part_at(i), first ? 0.0 : U[i], tagA);   // (opening evaluation: no product, but the round's tag)
+        const int KSs = (NF == 8 && q.use_mfma) ? 1 : q.KS;
+        for (int i = tid; i < OFF_CAM; i += kPThreads) {   // (opening evaluation: no product, but the round's tag)
+            double r = 0.0;
+            if (!first) { r = U[i]; for (int kt = 1; kt < KSs; kt++) r += U[kt * OFF_CAM + i]; }
+            tst(q.part, part_at(i), r, tagA);
+        }
     };
 
     // ================================================================================ exchange A -> B: slice-wise reduction
@@ -840,7 +839,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         // HG groups of sources per element, chosen so that one pass of the workgroup covers the slice (SL * HG <= 256 threads) and a
         // thread's sources (~G / HG <= 8) go out as ONE batch of loads: every extra pass or batch is a memory round trip (~1.5 us)
         const int HG = red_HG;
-        double* const R = U + OFF_CAM;           // behind the staged product, which other waves may still be sending
+        double* const R = U + ((NF == 8 && q.use_mfma) ? 1 : q.KS) * OFF_CAM;   // behind the product's partials, which other waves may still be sending
         const size_t src = (size_t)g * G * SL;   // slice g of every workgroup's partial
         for (int idx = tid; idx < SL * HG; idx += kPThreads) {
             const int hg = div_sl(idx), e = idx - hg * SL;
