@@ -10,19 +10,22 @@
 //   * the linearisation is never materialised: a trial recomputes the 2x3 / 2x6 Jacobians (typesg2o.h:275-314, ~150 flop) from
 //     the 24-byte observation, forms Hll, its Cholesky factor L (3x3) and the whitened blocks Y_e = Hpl_e L^-T straight into an
 //     LDS panel Yt[3*landmark + k][6*camera + a];
-//   * Schur complement (g2o/core/block_solver.hpp:341-392): sum_l Hpl D^-1 Hpl^T = Yt^T Yt, a dense 48 x 48 x (3*Lw) fp64 GEMM
-//     per workgroup — v_mfma_f64_16x16x4_f64 on the six upper 16x16 tiles, K split over the four waves (UH_BA_SCHUR=valu selects the
-//     register-tiled vector-FMA form of the same product for the A/B in DESIGN.md);  b_schur = Yt^T (L^-1 b_l);
+//   * Schur complement (g2o/core/block_solver.hpp:341-392): sum_l Hpl D^-1 Hpl^T = Yt^T Yt, a dense 48 x 48 x (3*Lw) fp64 product
+//     per workgroup — vector FMA on 4x4 register blocks (UH_BA_SCHUR=mfma selects v_mfma_f64_16x16x4_f64 on the six upper 16x16
+//     tiles for the A/B in DESIGN.md: slower on gfx950);  b_schur = Yt^T (L^-1 b_l);
 //   * back-substitution (block_solver.hpp:419-442): dx_l = L^-T (L^-1 b_l - Y_l^T dx_p) from the same panel;
 //   * workgroups exchange only reduction partials, through write-through (sc1) stores of SELF-VALIDATING words: every double travels
 //     as two 64-bit words (32 payload bits | 32-bit tag = launch sequence and exchange round), so a reader polls the data itself —
 //     one memory round trip (~1.5 us on MI355X) per exchange instead of drain + flag + flag poll + data load:
-//       A: every workgroup's partial (tiles, Hpp/bp sums, b_schur, chi2, max diag)  -> slice-wise reduction by all workgroups
-//       B: the reduced 1804 doubles -> EVERY workgroup assembles and factorises the 48x48 system itself (no broadcast hop)
-//       C: trial chi2 / scale partials -> every workgroup takes the accept / reject decision itself (apply_decision)
-//     (each of them ONE batch of L2-bypassing loads per thread = one memory round trip; while C is in flight a workgroup already
-//     evaluates the next trial's linearisation at the trial estimate, used if the trial is accepted)
-//     so a trial costs three data hand-offs instead of two kernel boundaries + launch ramps, and all summation orders are
+//       A: every workgroup's partial (product with Hpp folded in, bp, b_schur - bp, chi2, max diag)  -> slice-wise reduction by all
+//          workgroups (lambda goes onto the diagonal there)
+//       B: the reduced vector -> EVERY workgroup scatters it into the bordered system and factorises it itself (no broadcast hop)
+//       C: trial chi2 / scale partials -> every workgroup takes the accept / reject decision itself (apply_decision) — only for a
+//          trial that may be its pass's last: any other trial is SPECULATIVE (see the trial loop): it linearises at the trial
+//          estimate at once, runs phase 1 with lambda / 3 and lets its chi2 ride in the next trial's partial; the decision is taken
+//          when B arrives
+//     (each of them ONE batch of L2-bypassing loads per thread = one memory round trip)
+//     so a trial costs two data hand-offs instead of two kernel boundaries + launch ramps, and all summation orders are
 //     fixed: results are run-to-run deterministic and identical in every workgroup.
 #pragma once
 
