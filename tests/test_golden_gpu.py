@@ -81,6 +81,36 @@ def test_hip_ba_equals_real_g2o(hip_ctx, form, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["persistent", "persistent16", "legacy"])
+def test_hip_ba_equals_real_g2o_where_trials_are_rejected(hip_ctx, form, monkeypatch):
+    """tests/golden/ba_hard_golden.npz: the REAL g2o on five problems whose LM trials are rejected, accepted with lambda factors other
+    than 1/3, or whose passes end early (make_ba_golden.py) — the branches the first fixture never takes, and the cases in which the
+    persistent kernel's speculative trials must be dropped.  A pass g2o did not run at all (no active vertex left: it reports -1)
+    counts as one empty iteration here."""
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    if form == "legacy":
+        monkeypatch.setenv("UH_BA_FORM", "legacy")
+    if form == "persistent16":
+        monkeypatch.setenv("UH_BA_NF", "16")
+    g = np.load(os.path.join(GOLD, "ba_hard_golden.npz"))
+    for seed in g["seeds"].tolist():
+        pr = {k: g[f"s{seed}_in_{k}"] for k in ("poses", "fixed", "intr", "points", "obs_pt", "obs_kf", "obs_uv", "obs_w")}
+        pr["K"], pr["P"], pr["E"] = len(pr["fixed"]), len(pr["points"]), len(pr["obs_pt"])
+        opt = GlobalOptimizer.create(hip_ctx)
+        opt.setParams(pr, ParamSet(nIters=5))
+        opt.optimize()
+        got = opt.getResults()
+        ref_iters = [1 if i < 0 else i for i in g[f"s{seed}_ref_iters"].tolist()]
+        assert got["iters"].tolist() == ref_iters, seed
+        assert np.abs(got["state"] - g[f"s{seed}_ref_state"]).max() < 1e-6, (seed, np.abs(got["state"] - g[f"s{seed}_ref_state"]).max())
+        ref_chi2 = g[f"s{seed}_ref_chi2"]
+        diff = np.nonzero(got["bad"] != g[f"s{seed}_ref_bad"])[0]
+        assert (np.abs(ref_chi2[diff] - 5.99) <= 1e-6 * 6.99).all(), seed          # flags may differ only on the chi2 = 5.99 boundary
+        opt.close()
+
+
+@pytest.mark.gpu
 def test_hip_pnp_equals_real_g2o(hip_ctx):
     from ucoslam_cv3_amd.pnp import PnPSolver
 
