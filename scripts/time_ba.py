@@ -21,7 +21,9 @@ dt = (time.perf_counter() - t) / N
 r = opt.getResults()
 print(f"ba optimize: {dt*1e3:.3f} ms per call (E={pr['E']}), iters={r['iters']}")
 
-# phase clocks of the last executed LM step (10 ns ticks), see UH_BA_CLK in csrc/ba.hip
+if opt.form().startswith("persist"):   # the persistent kernel's phase clocks are read by scripts/ba_ab.py (other indices)
+    sys.exit(0)
+# phase clocks of the last executed LM step of the LAUNCH CHAIN (10 ns ticks), see UH_BA_CLK in csrc/ba.hip (UH_BA_FORM=legacy)
 import ctypes as C
 L = u.lib()
 L.uh_ba_debug_clocks.argtypes = [C.c_void_p, C.c_void_p]

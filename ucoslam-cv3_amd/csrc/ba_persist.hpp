@@ -1215,6 +1215,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     }
     __syncthreads();
     if (s_flag[1]) return;
+    UH_BA_CLK(9);
     {
         const size_t per = (q.r_words + G - 1) / G, w0 = (size_t)g * per, w1 = w0 + per < q.r_words ? w0 + per : q.r_words;
         for (size_t w = w0 + tid; w < w1; w += 4 * kPThreads) {   // four words in flight per lane
@@ -1229,6 +1230,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     // of one device arrive in order)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    UH_BA_CLK(10);
     if (tid == 0) {
         const unsigned before = __hip_atomic_fetch_add(q.done_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (before + 1u - q.done_base == 2u * (unsigned)G) {
