@@ -604,6 +604,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         }
     }
     const bool red_diag0 = tid < SL && is_diag_elem(g * SL + tid);
+    const int open_beg = div_sl(OFF_CAM) * SL;   // first element of the slice that straddles the end of the product part
     const int red_HG = max(1, min(G, kPThreads / SL));   // source groups per element in the slice reduction
     const unsigned hg_inv = (unsigned)(0x100000000ull / (unsigned)red_HG) + 1u;
     bool clk_on = false;
@@ -681,7 +682,9 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         const unsigned long long anym = __ballot(any);
         any_pt = ((anym >> (lane & ~(NF - 1))) & ((1ull << NF) - 1)) != 0;
         bl0 = acc[6]; bl1 = acc[7]; bl2 = acc[8];
-        if (any_pt) {   // D = Hll + lambda I = L L^T
+        if (first) {
+            // (opening evaluation: chi2, max |H_jj| and the camera sums are all that is needed — no factor, no panel)
+        } else if (any_pt) {   // D = Hll + lambda I = L L^T
             const double d00 = acc[0] + lambda, d11 = acc[3] + lambda, d22 = acc[5] + lambda;
             ci00 = rsqrt_nr(d00);
             cl10 = acc[1] * ci00; cl20 = acc[2] * ci00;
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         } else {
             ci00 = ci11 = ci22 = cl10 = cl20 = cl21 = wl0 = wl1 = wl2 = 0;
         }
-        if (3 * ll + 2 < q.krows) {   // whitened blocks Y_e = Hpl_e L^-T, transposed into the panel (zeros where there is no observation)
+        if (!first && 3 * ll + 2 < q.krows) {   // whitened blocks Y_e = Hpl_e L^-T, transposed into the panel (zeros where there is no observation)
 #pragma unroll
             for (int a = 0; a < 6; a++) {
                 const double y0 = H[a * 3] * ci00;
@@ -828,7 +831,9 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         // the partial goes out with consecutive lanes on consecutive words (one element per lane and instruction was 64 cache lines per store)
         for (int i = tid; i < NF * 27 + NP + 4; i += kPThreads) tst(q.part, part_at(OFF_CAM + i), s_out[i], tagA);
         const int KSs = (NF == 8 && q.use_mfma) ? 1 : q.KS;
-        for (int i = tid; i < OFF_CAM; i += kPThreads) {   // (opening evaluation: no product, but the round's tag)
+        // (opening evaluation: there is no product; only the slice that straddles the end of the product part is sent, as zeros, so that
+        // its reducer finds the round's tag on every element — the slices below it are not reduced at all in that round)
+        for (int i = (first ? open_beg : 0) + tid; i < OFF_CAM; i += kPThreads) {
             double r = 0.0;
             if (!first) { r = U[i]; for (int kt = 1; kt < KSs; kt++) r += U[kt * OFF_CAM + i]; }
             tst(q.part, part_at(i), r, tagA);
@@ -837,7 +842,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
 
     // ================================================================================ exchange A -> B: slice-wise reduction
     unsigned tagB = 0;
-    auto reduce_slices = [&](double lam) -> bool {   // lam: added to the diagonal of S here (0 for the opening evaluation)
+    auto reduce_slices = [&](double lam, bool first) -> bool {   // lam: added to the diagonal of S here; first: the opening evaluation (camera sums and scalars only)
         tagB = next_tag();
         // HG groups of sources per element, chosen so that one pass of the workgroup covers the slice (SL * HG <= 256 threads) and a
         // thread's sources (~G / HG <= 8) go out as ONE batch of loads: every extra pass or batch is a memory round trip (~1.5 us)
@@ -847,7 +852,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         for (int idx = tid; idx < SL * HG; idx += kPThreads) {
             const int hg = div_sl(idx), e = idx - hg * SL;
             const bool is_max = g * SL + e == OFF_SC + 2;
-            const bool used = g * SL + e < q.nelem;   // (the last slice is padded: nobody writes or needs those elements)
+            const bool used = g * SL + e < q.nelem && !(first && (g + 1) * SL <= OFF_CAM);   // (the last slice is padded: nobody writes or needs those elements; opening: nor the product's slices)
             // every source of this element in ONE batch of loads where possible (G <= 128: at most eight per thread): a separate load
             // for the first source put a second memory round trip (~1.5 us) in front of every slice reduction
             double r = 0.0;
@@ -971,7 +976,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 phase1(opening ? 1.0 : lambda, opening, scale_lane, stop_val);
             }
             UH_BA_CLKT(41);
-            if (!reduce_slices(opening ? 0.0 : lambda)) return;
+            if (!reduce_slices(opening ? 0.0 : lambda, opening)) return;
             UH_BA_CLKT(42);
             if (opening) {
                 opening = false;
