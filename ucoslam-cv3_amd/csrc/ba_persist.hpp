@@ -536,8 +536,12 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     const pword err_word = ((pword)q.launch_id << 32) | 1ull;
     // a reader that has waited 3 s (a workgroup never became resident), or sees that somebody else gave up: flag it, everybody leaves
     // at the next uniform check of s_flag[1]
+    // t0 < 63: a count of misses — the first 63 polls repeat at once: a poll is one memory round trip and the error word costs a second,
+    // SERIAL one, which used to double the polling period of every hand-off —; from then on the wall-clock time the slow path began
+    // (wall-clock values are far above 64).
     auto give_up = [&](long long& t0) -> bool {
-        if (t0 == 0) t0 = wall_clock64();
+        if (t0 < 63) { ++t0; return false; }
+        if (t0 == 63) t0 = wall_clock64();
         if (__hip_atomic_load(q.errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == err_word || wall_clock64() - t0 > kPTimeoutTicks) {
             s_flag[1] = 1;
             __hip_atomic_store(q.errw, err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
