@@ -1172,75 +1172,99 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     // thread and round: with 8 free poses (36 pairs, 756 units) every partial of the reduced system is requested in ONE
     // round — the data was written by the previous launch on other XCDs, so a round costs a full HBM/MALL round trip.
     const int total = npairs * 21;
-    constexpr int kAsmU = 3;
     // the LM state (lambda, current buffer, "pass finished") is requested together with the first round of partials
     double lambda = 0;
     int cur = 0;
     bool have_state = false;
-    for (int t0 = tid; t0 < total; t0 += kSolveThreads * kAsmU) {
-        double2 xs[kAsmU][kMaxSplit];
-        double hs[kAsmU][2][kCamChunks];
-        int s1v[kAsmU], s2v[kAsmU], qv[kAsmU];
+    bool finished = false;
+    // One pass over the units of the camera pairs, AU units per thread and round with MS partial loads each in flight.  DIAG: the
+    // diagonal pairs, whose elements also take the camera-side sums (Hpp, bp: kCamChunks more loads per element); the other pairs'
+    // units carry no such loads or registers, so many more of them fit a round: with 17 free cameras (153 pairs x 3 chunks) the
+    // assembly was five rounds of 12 + 16 loads per unit (every unit issued kMaxSplit loads, the unused ones on chunk 0, and the
+    // camera loads' registers); now two rounds of 3 loads for the 136 off-diagonal pairs and one for the 17 diagonal ones.
+    auto pass = [&](auto au_c, auto ms_c, auto diag_c) {
+        constexpr int AU = decltype(au_c)::value, MS = decltype(ms_c)::value;
+        constexpr bool DIAG = decltype(diag_c)::value;
+        const int units = DIAG ? d.nfree * 21 : total;
+        for (int t0 = tid; t0 < units && !finished; t0 += kSolveThreads * AU) {
+            double2 xs[AU][MS];
+            double hs[DIAG ? AU : 1][2][kCamChunks];
+            int s1v[AU], s2v[AU], qv[AU];
 #pragma unroll
-        for (int u = 0; u < kAsmU; u++) {
-            const int t = t0 + u * kSolveThreads;
-            const int tc = t < total ? t : 0;
-            const int pair = tc / 21, q = 2 * (tc - pair * 21);
-            int s1 = 0, rem = pair;
-            while (rem >= d.nfree - s1) { rem -= d.nfree - s1; ++s1; }
-            const int s2 = s1 + rem;
-            s1v[u] = s1; s2v[u] = s2; qv[u] = t < total ? q : -1;
+            for (int u = 0; u < AU; u++) {
+                const int t = t0 + u * kSolveThreads;
+                const int tc = t < units ? t : 0;
+                int pair = tc / 21;
+                const int q = 2 * (tc - pair * 21);
+                int s1 = 0, s2 = 0;
+                if (DIAG) { s1 = s2 = pair; pair = s1 * d.nfree - s1 * (s1 - 1) / 2; }
+                else { int rem = pair; while (rem >= d.nfree - s1) { rem -= d.nfree - s1; ++s1; } s2 = s1 + rem; }
+                s1v[u] = s1; s2v[u] = s2; qv[u] = (t < units && (DIAG || s1 != s2)) ? q : -1;
 #pragma unroll
-            for (int k = 0; k < kMaxSplit; k++)
-                xs[u][k] = *reinterpret_cast<const double2*>(p.Spart + ((size_t)(k < nsplit ? k : 0) * npairs + pair) * 42 + q);
-            // camera-side entries that join these elements (diagonal pairs only): Hpp upper-triangle index or bp component
+                for (int k = 0; k < MS; k++)
+                    xs[u][k] = *reinterpret_cast<const double2*>(p.Spart + ((size_t)(k < nsplit ? k : 0) * npairs + pair) * 42 + q);
+                if constexpr (DIAG) {   // camera-side entries that join these elements: Hpp upper-triangle index or bp component
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int qq = q + j;
-                int hq = 0;
-                if (qq >= 36) hq = 21 + (qq - 36);
-                else { const int a = qq / 6, c = qq - a * 6, lo = a < c ? a : c, hi = a < c ? c : a; hq = lo * 6 - lo * (lo - 1) / 2 + (hi - lo); }
+                    for (int j = 0; j < 2; j++) {
+                        const int qq = q + j;
+                        int hq = 0;
+                        if (qq >= 36) hq = 21 + (qq - 36);
+                        else { const int a = qq / 6, c = qq - a * 6, lo = a < c ? a : c, hi = a < c ? c : a; hq = lo * 6 - lo * (lo - 1) / 2 + (hi - lo); }
 #pragma unroll
-                for (int cch = 0; cch < kCamChunks; cch++) hs[u][j][cch] = s1 == s2 ? p.HppPart[((size_t)s1 * kCamChunks + cch) * 27 + hq] : 0.0;
-            }
-        }
-        const long long clk_issued = wall_clock64();
-        if (!have_state) {
-            const BAState st = p.st[slot];
-            if (st.phase == 2) return;   // uniform: nothing has been written yet
-            lambda = st.lambda; cur = st.cur; have_state = true;
-            if (tid == 0 && blockIdx.x == 0) { p.clk[10] = clk_begin; p.clk[26] = clk_issued; p.clk[27] = wall_clock64(); }
-        }
-#pragma unroll
-        for (int u = 0; u < kAsmU; u++) {
-            const int s1 = s1v[u], s2 = s2v[u];
-            if (qv[u] < 0) continue;
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int q = qv[u] + j;
-                double v = 0;
-#pragma unroll
-                for (int k = 0; k < kMaxSplit; k++) if (k < nsplit) v += j ? xs[u][k].y : xs[u][k].x;
-                double h = 0;
-#pragma unroll
-                for (int cch = 0; cch < kCamChunks; cch++) h += hs[u][j][cch];
-                if (q >= 36) {   // b_schur = b_p - sum_l Hpl Dinv b_l (diagonal pairs carry it); b_p = sum of the camera chunks
-                    if (s1 == s2) {
-                        p.bp[6 * s1 + (q - 36)] = h;             // the decide stage needs b_p for computeScale
-                        s_x[6 * s1 + (q - 36)] = h - v;
-                        if constexpr (USE_LDS) M[(size_t)n * ld + 6 * s1 + (q - 36)] = h - v;   // row n of the bordered matrix
+                        for (int cch = 0; cch < kCamChunks; cch++) hs[u][j][cch] = p.HppPart[((size_t)s1 * kCamChunks + cch) * 27 + hq];
                     }
-                    continue;
                 }
-                const int a = q / 6, c = q - a * 6;
-                v = -v;
-                if (s1 == s2) v += h + (a == c ? lambda : 0.0);
-                const int r = 6 * s1 + a, cc = 6 * s2 + c;   // upper-block entry (r,cc); store it mirrored into the lower triangle
-                if (s1 == s2) { if (c <= a) M[IX(r, cc)] = v; }
-                else M[IX(cc, r)] = v;
+            }
+            const long long clk_issued = wall_clock64();
+            if (!have_state) {
+                const BAState st = p.st[slot];
+                if (st.phase == 2) { finished = true; break; }   // uniform: nothing has been written yet
+                lambda = st.lambda; cur = st.cur; have_state = true;
+                if (tid == 0 && blockIdx.x == 0) { p.clk[10] = clk_begin; p.clk[26] = clk_issued; p.clk[27] = wall_clock64(); }
+            }
+#pragma unroll
+            for (int u = 0; u < AU; u++) {
+                const int s1 = s1v[u], s2 = s2v[u];
+                if (qv[u] < 0) continue;
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int q = qv[u] + j;
+                    double v = 0;
+#pragma unroll
+                    for (int k = 0; k < MS; k++) if (k < nsplit) v += j ? xs[u][k].y : xs[u][k].x;
+                    double h = 0;
+                    if constexpr (DIAG) {
+#pragma unroll
+                        for (int cch = 0; cch < kCamChunks; cch++) h += hs[u][j][cch];
+                    }
+                    if (q >= 36) {   // b_schur = b_p - sum_l Hpl Dinv b_l (diagonal pairs carry it); b_p = sum of the camera chunks
+                        if (DIAG) {
+                            p.bp[6 * s1 + (q - 36)] = h;             // the decide stage needs b_p for computeScale
+                            s_x[6 * s1 + (q - 36)] = h - v;
+                            if constexpr (USE_LDS) M[(size_t)n * ld + 6 * s1 + (q - 36)] = h - v;   // row n of the bordered matrix
+                        }
+                        continue;
+                    }
+                    const int a = q / 6, c = q - a * 6;
+                    v = -v;
+                    if (DIAG) v += h + (a == c ? lambda : 0.0);
+                    const int r = 6 * s1 + a, cc = 6 * s2 + c;   // upper-block entry (r,cc); store it mirrored into the lower triangle
+                    if (DIAG) { if (c <= a) M[IX(r, cc)] = v; }
+                    else M[IX(cc, r)] = v;
+                }
             }
         }
+    };
+    using std::integral_constant;
+    using std::true_type; using std::false_type;
+    if (nsplit <= 3) {
+        pass(integral_constant<int, 2>{}, integral_constant<int, 3>{}, true_type{});     // (first: it requests the state; its lambda goes onto the diagonal)
+        if (!finished) pass(integral_constant<int, 8>{}, integral_constant<int, 3>{}, false_type{});
+    } else {
+        pass(integral_constant<int, 2>{}, integral_constant<int, kMaxSplit>{}, true_type{});
+        if (!finished) pass(integral_constant<int, 3>{}, integral_constant<int, kMaxSplit>{}, false_type{});
     }
+    if (finished) return;
     UH_BA_CLK(28);
     if (!have_state) {   // no free pose: nothing was assembled
         const BAState st = p.st[slot];
@@ -2390,7 +2414,8 @@ static int set_problem_tables(uh_ba* b, const uh_ba_problem* pr) {
     b->nsplit = std::max(1, std::min(kMaxSplit, uh_div_up(P, kThreads)));
     // every workgroup of the back-substitution launch assembles ALL npairs x nsplit partials itself: with many camera pairs fewer, fatter
     // landmark chunks win (measured, 3000 landmarks: 17 / 20 / 32 free cameras 2.20 / 2.90 / 9.9 ms with 12 chunks, 1.77 / 2.14 / 7.3 with 2)
-    if (npairs_h > 32) b->nsplit = std::max(1, std::min(b->nsplit, uh_div_up(384, npairs_h)));
+    if (npairs_h > 32) b->nsplit = std::max(1, std::min(b->nsplit, uh_div_up(300, npairs_h)));   // (17 free cameras: 2 chunks, measured best — scripts/ba_chain_kernels.py with UH_BA_NSPLIT)
+    if (const char* e = getenv("UH_BA_NSPLIT")) b->nsplit = std::max(1, std::min(kMaxSplit, atoi(e)));   // (measurement override: scripts/ba_chain_kernels.py)
     if (const char* e = getenv("UH_BA_NSPLIT")) b->nsplit = std::max(1, std::min(kMaxSplit, atoi(e)));   // tuning knob (measurement only)
     const size_t o_S = A.take<double>((size_t)(d.n + 1) * (d.n + 1)), o_Sp = A.take<double>(wide ? 42 : (size_t)b->nsplit * std::max(npairs_h, 1) * 42), o_xp = A.take<double>(std::max(d.n, 1));
     const size_t wn_pairs = w_pair_s1.size(), wn_items = w_item_pair.size(), wn_tri = w_tri_pt.size();
