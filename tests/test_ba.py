@@ -130,8 +130,8 @@ def test_oracle_edge_jacobian_central_differences(oracle):
                                  (11, 3000, 8, 2), (12, 800, 9, 2), (13, 600, 10, 2), (15, 2500, 11, 2), (18, 1000, 12, 2), (18, 3000, 13, 2), (17, 40, 14, 1),
                                  # the launch chain's two-rows-per-lane solve at its limits: 17 and 21 free keyframes (127 rows)
                                  (19, 900, 15, 2), (23, 1100, 16, 2),
-                                 # the stand-alone solve on a packed triangle in LDS: 22 and 30 free keyframes; 31: the HBM workspace
-                                 (24, 800, 17, 2), (32, 600, 18, 2), (33, 500, 19, 2)],
+                                 # the stand-alone solve on a packed triangle in LDS: 22, 30, 31 and 32 (its limit) free keyframes; 33: the HBM workspace
+                                 (24, 800, 17, 2), (32, 600, 18, 2), (33, 500, 19, 2), (34, 450, 20, 2), (35, 400, 21, 2)],
                          ids=lambda c: f"K{c[0]}_P{c[1]}_fix{c[3]}")
 def test_hip_ba_matches_oracle(hip_ctx, oracle, cfg):
     from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet

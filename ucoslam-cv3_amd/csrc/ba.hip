@@ -53,6 +53,7 @@ namespace {
 constexpr int kMaxFree = 64;          // free (non-fixed) poses in the reduced system
 constexpr int kThreads = 256;
 constexpr int kSolveThreads = 256;                      // solve: one workgroup of 4 waves (one per SIMD)
+constexpr int kPackedFree = 32;                          // stand-alone solve on a packed triangle in LDS: up to 32 free cameras (n = 192: 148 KB)
 constexpr int kMaxSplit = 12;                           // schur: landmark chunks per camera pair (partials the solve adds)
 constexpr int kTrailU = 4;                              // solve: trailing-update elements in flight per thread
 constexpr int kCamChunks = 8;                            // lin: workgroups per free camera
@@ -1161,7 +1162,9 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     const long long clk_begin = wall_clock64();
     // assemble the lower triangle (+ diagonal) from the pair partials.  Four elements per thread and round, every partial
     // load of the four issued before the first add: the kernel is one workgroup, so exposed L2 latency is its whole cost
-    __shared__ short s_pair[kMaxFree * (kMaxFree + 1) / 2][2];
+    // (PACKED serves at most kPackedFree cameras: its static LDS is sized for that, so that a 32-camera triangle — 148 KB — fits beside it)
+    constexpr int kFreeCap = PACKED ? kPackedFree : kMaxFree;
+    __shared__ short s_pair[kFreeCap * (kFreeCap + 1) / 2][2];
     for (int t = tid; t < npairs; t += kSolveThreads) {
         int s1 = 0, rem = t;
         while (rem >= d.nfree - s1) { rem -= d.nfree - s1; ++s1; }
@@ -1286,7 +1289,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
         double (*s_w)[121][6] = reinterpret_cast<double (*)[121][6]>(&s_w_store[0][0][0]);
         failed = ldlt_bordered_lds(M, n, ld, d.nfree, npairs, s_pair, s_w);
     } else {
-        __shared__ double s_w[6 * kMaxFree][6];
+        __shared__ double s_w[6 * kFreeCap][6];
         for (int k0 = 0; k0 < n; k0 += 6) {
             // (a) diagonal block -> Lkk (strict lower), dk, 1/dk
             double a[6][6], dk[6], ik[6];
@@ -1451,7 +1454,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
 template <bool USE_LDS, bool PACKED = false>
 __global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADims d, int nsplit, int slot) {
     uh_latency_critical();
-    __shared__ double s_x[6 * kMaxFree];
+    __shared__ double s_x[6 * (PACKED ? kPackedFree : kMaxFree)];
     SolveOut o;
     solve_body<USE_LDS, PACKED>(p, d, nsplit, slot, s_x, o);
 }
@@ -2133,9 +2136,12 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
         if (use_lds) {
             UH_LAUNCH(b->ctx,ba_backsub_kernel<true>, dim3(d.nPointBlocks), dim3(kThreads), lds, b->ptrs, d, b->nsplit, slot ^ 1);
         } else {
-            // 22-30 free cameras: the stand-alone solve keeps the system as a packed triangle in its own LDS (<= 128 KB: 30 cameras); more: in HBM
+            // 22-32 free cameras: the stand-alone solve keeps the system as a packed triangle in its own LDS (148 KB at 32 cameras, beside
+            // the kernel's static arrays, which are sized for that many: both are checked against the device's limit); more: in HBM
             const size_t packed = ((size_t)d.n * (d.n + 1) / 2 + 16) * sizeof(double);
-            if (packed <= 128 * 1024 && !(getenv("UH_BA_SOLVE") && std::string(getenv("UH_BA_SOLVE")) == "hbm"))
+            static const size_t packed_static = [] { hipFuncAttributes fa{}; return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&ba_solve_kernel<false, true>)) == hipSuccess ? fa.sharedSizeBytes : (size_t)1 << 30; }();
+            if (b->max_lds <= 0) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, b->ctx->device) == hipSuccess) b->max_lds = v; }
+            if (d.nfree <= kPackedFree && packed + packed_static <= (size_t)std::max(b->max_lds, 0) && !(getenv("UH_BA_SOLVE") && std::string(getenv("UH_BA_SOLVE")) == "hbm"))
                 UH_LAUNCH(b->ctx, (ba_solve_kernel<false, true>), dim3(1), dim3(kSolveThreads), packed, b->ptrs, d, b->nsplit, slot ^ 1);
             else
                 UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kSolveThreads), 0, b->ptrs, d, b->nsplit, slot ^ 1);
