@@ -543,3 +543,28 @@ def test_hip_ba_hard_problems_rejected_trials_and_other_lambda_factors(hip_ctx, 
         opt.close()
     assert early >= 4            # the set does contain passes that end before their iteration budget
     assert kept > 0 and dropped > 0, (kept, dropped)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(10, 3000, 0, 2), (18, 1000, 12, 2), (6, 400, 1, 1)], ids=lambda c: f"K{c[0]}_P{c[1]}")
+def test_hip_ba_speculative_and_plain_trials_agree(hip_ctx, oracle, cfg, monkeypatch):
+    """UH_BA_SPEC=0 keeps the three-hand-off trial (errors, chi2 hand-off, decision; the form every pass's LAST trial takes anyway) for the
+    whole optimisation: same iteration counts, states equal to round-off (the chi2 sums are added in another order), both within the
+    tolerance of the oracle."""
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    K, P, seed, nfix = cfg
+    pr = synth.ba_problem(K, P, seed, nfixed=nfix)
+    ref = oracle_lib.ba_optimize(oracle, pr, 5)
+    res = {}
+    for spec in ("1", "0"):
+        monkeypatch.setenv("UH_BA_SPEC", spec)
+        opt = GlobalOptimizer.create(hip_ctx)
+        opt.setParams(pr, ParamSet(nIters=5))
+        opt.optimize()
+        res[spec] = opt.getResults()
+        opt.close()
+        assert res[spec]["iters"].tolist() == ref["iters"].tolist()
+        assert np.abs(res[spec]["state"] - ref["state"]).max() < POSE_TOL
+    assert np.abs(res["1"]["state"] - res["0"]["state"]).max() < 1e-11
+    np.testing.assert_array_equal(res["1"]["bad"], res["0"]["bad"])

@@ -2739,7 +2739,7 @@ static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl
     BAPersist& q = b->pq;
     q = BAPersist{};
     q.G = pl.G; q.Lw = pl.Lw; q.krows = pl.krows; q.SL = pl.SL; q.nelem = pl.nelem; q.max_fix = pl.max_fix; q.kfix = pl.kfix; q.use_mfma = pl.use_mfma;
-    { static const int spec = [] { const char* e = getenv("UH_BA_SPEC"); return e && e[0] == '0' ? 0 : 1; }(); q.speculate = spec; }
+    { const char* e = getenv("UH_BA_SPEC"); q.speculate = e && e[0] == '0' ? 0 : 1; }   // (read per launch: the A/B scripts and a test switch it within one process)
     q.nb4 = pl.nb4; q.nblk = pl.nblk; q.KS = pl.KS;
     q.T = b->dT.as<unsigned>(); q.tseq = tseq;
     q.obs16 = obs16 ? 1 : 0;
