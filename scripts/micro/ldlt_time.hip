@@ -60,7 +60,14 @@ int run(int nfree) {
     for (int i = 0; i < n; i++) { double sx = 0; for (int j = 0; j < n; j++) sx += (j <= i ? A[i * ld + j] : A[j * ld + i]) * O[ld * ld + j]; errx = fmax(errx, fabs(sx - A[n * ld + i])); }
     printf("   backsolve %lld clocks (%.2f us), |S x - b| = %.3g\n", c[64], c[64] / 2390.0, errx);
     printf("nfree %d: best %lld shader clocks (%.2f us at 2.39 GHz), |LDL^T - A| = %.3g, |L D z - b| = %.3g\n", nfree, c[0], c[0] / 2390.0, err, errb);
-    if (false) for (int i = 0; i < 40; i++) if (c[1 + i]) printf("clk[%d] = +%lld\n", i, c[1 + i] - c[1]);
+#ifdef LDLT_PRINT_CLK
+    if (nfree == 8) {   // wave 0's stamps: 0 = start; per block column kb: 1+4kb after the panel application, 3+4kb after pivots + stores, 4+4kb behind the barrier
+        for (int kb = 0; kb < nfree; kb++) {
+            const long long b0 = kb == 0 ? c[1 + 0] : c[1 + 4 + 4 * (kb - 1)];
+            printf("   kb %d: loads + panel application %lld | pivots + stores %lld | barrier %lld clocks\n", kb, c[1 + 1 + 4 * kb] - b0, c[1 + 3 + 4 * kb] - c[1 + 1 + 4 * kb], c[1 + 4 + 4 * kb] - c[1 + 3 + 4 * kb]);
+        }
+    }
+#endif
     hipFree(dA); hipFree(dO); hipFree(dc);
     return !(err < 1e-9 && errb < 1e-9 && errx < 1e-9);
 }
