@@ -527,7 +527,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         while (rem >= q.nb4 - bi) { rem -= q.nb4 - bi; ++bi; }
         s_blk[t][0] = (unsigned char)bi; s_blk[t][1] = (unsigned char)(bi + rem);
     }
-    if (tid == 0) { s_flag[0] = 1; s_flag[1] = 0; }
+    if (tid == 0) { s_flag[0] = 1; s_flag[1] = 0; s_flag[2] = 0; }
     __syncthreads();
 
     // ---- exchange rounds: every workgroup runs the same sequence of rounds, so the round counter doubles as the tag
@@ -969,10 +969,6 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             clk_on = pass == 1 && loop_no == 4;
             double lambda = pend ? lambda_spec : st.lambda;
             int cur = st.cur, trial = cur ^ 1;
-            // the force-stop byte lives in pinned HOST memory: a PCIe round trip.  It is requested here, a whole trial before its value is
-            // sent with the chi2 partials, instead of on the hand-off itself (1.5 - 3 us in front of every decision)
-            unsigned char stop_byte = 0;
-            if (g == 0 && tid == 0 && p.stop) stop_byte = *p.stop;
             UH_BA_CLKT(40);
             {
                 const double Xe[3] = {pend ? Xt[0] : X[0], pend ? Xt[1] : X[1], pend ? Xt[2] : X[2]};
@@ -1054,9 +1050,15 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             __syncthreads();
             UH_BA_CLKT(44);
             const int ok = s_flag[0];
+            // The force-stop byte lives in pinned HOST memory: a PCIe round trip (1.5 - 2 us).  It is fetched HERE, by a lane of wave 1, which
+            // idles through wave 0's back substitution: requested at the top of the trial by thread 0 (as it used to be), the compiler
+            // waited for it on the spot — a one-byte value does not stay a pending load across a whole trial on a kernel out of registers
+            // — and workgroup 0, hence everybody, started every trial that much later.
+            if (g == 0 && tid == 64 && p.stop) s_flag[2] = *p.stop;
             if (ok) { if (NF == 8 || n <= 64) backsolve_lds(Mm, n, ld, s_x); else backsolve2_lds(Mm, n, ld, s_x); }
             else for (int i = tid; i < n; i += kPThreads) s_x[i] = 0.0;
             __syncthreads();
+            const unsigned char stop_byte = (unsigned char)s_flag[2];   // (workgroup 0; it travels with this trial's chi2)
             UH_BA_CLKT(45);
             if (wv == 0) {   // computeScale's pose part: sum x (lambda x + b)
                 double xs = 0;
