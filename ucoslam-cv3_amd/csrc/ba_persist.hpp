@@ -612,6 +612,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     const int red_HG = max(1, min(G, kPThreads / SL));   // source groups per element in the slice reduction
     const unsigned hg_inv = (unsigned)(0x100000000ull / (unsigned)red_HG) + 1u;
     bool clk_on = false;
+    int n_kept = 0, n_dropped = 0;   // speculative trials kept / dropped (debug clocks 58 / 59, written with the results)
 #define UH_BA_CLKT(i) do { if (clk_on) UH_BA_CLK(i); } while (0)
     BAState st;
     memset(&st, 0, sizeof(st));
@@ -962,7 +963,6 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         bool opening = true;
         bool pend = false;        // a speculative partial is out; the decision on the trial it follows is still open
         double lambda_spec = 0, scale_lane = 0, stop_val = 0;   // what the speculative phase 1 runs with / carries
-        if (pass == 0 && g == 0 && tid == 0) { p.clk[58] = 0; p.clk[59] = 0; }   // (debug clocks: speculative trials kept / dropped, counted by workgroup 0)
         int loop_no = 0;   // (the trial-phase clocks 40 .. 57 are those of the second pass's fourth loop iteration: a speculative trial in steady state)
         while (opening || st.phase != 2) {
             ++loop_no;
@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 const bool accepted = st.cur != cur;
                 if (accepted) { X[0] = Xt[0]; X[1] = Xt[1]; X[2] = Xt[2]; }
                 const bool kept = accepted && st.phase == 0 && st.lambda == lambda_spec;
-                if (g == 0 && tid == 0) p.clk[kept ? 58 : 59] += 1;
+                n_kept += kept ? 1 : 0; n_dropped += kept ? 0 : 1;   // (registers: a read-modify-write of the clock block here was a memory round trip on workgroup 0's path, every trial)
                 if (!kept) {   // not what was speculated on: again from the decided state
                     __syncthreads();   // (the assembled entries in U are dropped; phase 1 writes there)
                     continue;
@@ -1171,6 +1171,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     }
 
     UH_BA_CLK(8);
+    if (g == 0 && tid == 0) { p.clk[58] = n_kept; p.clk[59] = n_dropped; }
     // ================================================================================ results (GlobalOptimizerG2O::getResults, :466-537)
     // Float poses / points exactly as the reference converts them; a bad association = chi2 > 5.99 or negative depth of the FLOAT
     // point under the FLOAT pose (fixed frames: their input pose).  Two steps, because tens of thousands of scattered system-scope
