@@ -568,3 +568,42 @@ def test_hip_ba_speculative_and_plain_trials_agree(hip_ctx, oracle, cfg, monkeyp
         assert np.abs(res[spec]["state"] - ref["state"]).max() < POSE_TOL
     assert np.abs(res["1"]["state"] - res["0"]["state"]).max() < 1e-11
     np.testing.assert_array_equal(res["1"]["bad"], res["0"]["bad"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("staged", [False, True], ids=["arrays", "staged"])
+def test_hip_ba_falls_back_to_the_launch_chain_when_the_persistent_kernel_cannot_become_resident(hip_ctx, oracle, monkeypatch, staged):
+    """The persistent form needs all its workgroups resident at once; when another spinning kernel holds CUs (a second process on the
+    GPU), its launch gives up after a timeout.  optimize() must then not fail: the problem is still in the staging block (either record
+    format), so this optimisation and the object's next problems take the launch chain (UH_BA_FAIL_RESIDENCY=1 forces the failure)."""
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    pr = synth.ba_problem(10, 800, 3, nfixed=2)
+    ref = oracle_lib.ba_optimize(oracle, pr, 5)
+    opt = GlobalOptimizer.create(hip_ctx)
+    def set_():
+        if staged:
+            dims = opt.fillStaging(pr)
+            opt.setParamsStaged(*dims, ParamSet(nIters=5))
+        else:
+            opt.setParams(pr, ParamSet(nIters=5))
+    set_()
+    assert opt.form() == "persist8"
+    monkeypatch.setenv("UH_BA_FAIL_RESIDENCY", "1")
+    opt.optimize()                               # falls back instead of raising
+    monkeypatch.delenv("UH_BA_FAIL_RESIDENCY")
+    assert opt.form() == "chain"
+    got = opt.getResults()
+    assert got["iters"].tolist() == ref["iters"].tolist()
+    assert np.abs(got["state"] - ref["state"]).max() < POSE_TOL
+    _assert_bad_flags_equal_up_to_the_boundary(got, ref)
+    set_()                                       # the next problems of this object stay on the chain for a while ...
+    assert opt.form() == "chain"
+    opt.optimize()
+    assert np.abs(opt.getResults()["state"] - ref["state"]).max() < POSE_TOL
+    for _ in range(70):                          # ... and then the persistent form is tried again
+        set_()
+    assert opt.form() == "persist8"
+    opt.optimize()
+    assert np.abs(opt.getResults()["state"] - ref["state"]).max() < POSE_TOL
+    opt.close()

@@ -2018,6 +2018,7 @@ struct uh_ba {
     int nsplit = 1;
     bool wide = false;                    // more than kMaxFree free keyframes: sparse pair lists + blocked dense LDL^T in HBM
     bool persist = false;                 // 1..8 free keyframes: the whole optimisation is ONE persistent launch (ba_persist.hpp)
+    int persist_blocked = 0;              // > 0: the persistent form's workgroups did not all become resident lately (another spinning kernel shares the GPU): so many of the next problems take the launch chain
     BAPersist pq{};
     uh::DevBuf parena;                    // the persistent form's exchange buffers (tagged words only; [0, 64): the error word)
     unsigned parena_gen = ~0u;            // the allocation the exchange tags refer to (a new one is zeroed)
@@ -2205,6 +2206,14 @@ PersistAdmission g_persist_adm[16];   // per device (index & 15)
 // GlobalOptimizerG2O::optimize as ONE launch (ba_persist.hpp): both passes, relabelling, every trial
 int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, float mc) {
     hipStream_t st = b->ctx->stream;
+    if (const char* e = getenv("UH_BA_FAIL_RESIDENCY")) {   // test hook: behave as if the workgroups had not all become resident (nothing is launched)
+        if (e[0] == '1') {
+            (void)hipStreamSynchronize(st);   // (the ingest in front of the launch has run)
+            b->stage_in_flight = false;
+            uh::set_error("uh_ba_optimize: the persistent kernel's workgroups did not all become resident (forced by UH_BA_FAIL_RESIDENCY)");
+            return UH_ENODEVICE;
+        }
+    }
     BAPersist q = b->pq;
     q.n1 = n1; q.n2 = n2; q.minChi2 = mc;
     q.stop_at_begin = (b->h_stop && *b->h_stop) ? 1 : 0;
@@ -2596,6 +2605,7 @@ static PersistPlan plan_persistent(uh_ba* b, int K, int P, int E, int nfree) {
     void* dflag = nullptr;
     if (!b->h_stop || hipHostGetDevicePointer(&dflag, b->h_stop, 0) != hipSuccess) return pl;   // (the kernel reports through pinned memory)
     if (nfree < 1 || P < 1 || E >= (1 << 20) - 1) return pl;
+    if (b->persist_blocked > 0) { --b->persist_blocked; return pl; }
     const int NF = persist_lanes(nfree);
     if (!NF) return pl;
     const int kLwMax = kPThreads / NF;   // one lane per (landmark, free-camera slot)
@@ -2766,6 +2776,32 @@ static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl
     return UH_OK;
 }
 
+// The problem that sits in the staging block (either record format), handed to the launch chain / wide form as the arrays it wants.
+static int staged_problem_to_tables(uh_ba* b, int K, int P, int E, bool obs16) {
+    const StageLayout& L = b->slay;
+    std::vector<int32_t> op(E), of(E);
+    std::vector<float> uv(2 * (size_t)E);
+    std::vector<double> w(E);
+    if (obs16) {
+        const unsigned* r = reinterpret_cast<const unsigned*>(b->h_stage + L.obs);
+        for (int e = 0; e < E; e++) {
+            float f[3];
+            std::memcpy(f, r + 4 * (size_t)e + 1, sizeof(f));
+            op[e] = (int32_t)(r[4 * (size_t)e] & 0xFFFFFFu); of[e] = (int32_t)(r[4 * (size_t)e] >> 24);
+            uv[2 * e] = f[0]; uv[2 * e + 1] = f[1]; w[e] = f[2];
+        }
+    } else {
+        const uh_ba_obs* ob = reinterpret_cast<const uh_ba_obs*>(b->h_stage + L.obs);
+        for (int e = 0; e < E; e++) { op[e] = ob[e].point; of[e] = ob[e].frame; uv[2 * e] = ob[e].u; uv[2 * e + 1] = ob[e].v; w[e] = ob[e].inv_sigma; }
+    }
+    uh_ba_problem pr{};
+    pr.n_frames = K; pr.n_points = P; pr.n_obs = E;
+    pr.poses_f2g = reinterpret_cast<const float*>(b->h_stage + L.poses_in); pr.fixed = b->h_stage + L.fixed; pr.intr = reinterpret_cast<const float*>(b->h_stage + L.intr_f);
+    pr.points = reinterpret_cast<const float*>(b->h_stage + L.points);
+    pr.obs_point = op.data(); pr.obs_frame = of.data(); pr.obs_uv = uv.data(); pr.obs_inv_sigma = w.data();
+    return set_problem_tables(b, &pr);
+}
+
 static void set_problem_begin(uh_ba* b, const uh_ba_params* params) {
     b->have_problem = false;
     b->optimized = false;
@@ -2903,16 +2939,7 @@ int uh_ba_set_problem_staged(uh_ba* b, int K, int P, int E, const uh_ba_params* 
     const PersistPlan pl = plan_persistent(b, K, P, E, nfree);
     if (pl.ok) return set_problem_fast(b, K, P, E, pl);
     // a window the persistent form does not take: hand the launch chain / wide form the arrays it wants
-    std::vector<int32_t> op(E), of(E);
-    std::vector<float> uv(2 * (size_t)E);
-    std::vector<double> w(E);
-    for (int e = 0; e < E; e++) { op[e] = ob[e].point; of[e] = ob[e].frame; uv[2 * e] = ob[e].u; uv[2 * e + 1] = ob[e].v; w[e] = ob[e].inv_sigma; }
-    uh_ba_problem pr{};
-    pr.n_frames = K; pr.n_points = P; pr.n_obs = E;
-    pr.poses_f2g = reinterpret_cast<const float*>(b->h_stage + L.poses_in); pr.fixed = fixed; pr.intr = reinterpret_cast<const float*>(b->h_stage + L.intr_f);
-    pr.points = reinterpret_cast<const float*>(b->h_stage + L.points);
-    pr.obs_point = op.data(); pr.obs_frame = of.data(); pr.obs_uv = uv.data(); pr.obs_inv_sigma = w.data();
-    return set_problem_tables(b, &pr);
+    return staged_problem_to_tables(b, K, P, E, false);
 }
 
 // the per-observation chi2 is an extra of this ABI (the reference's getResults does not return it): a host that never asks for it saves
@@ -2941,7 +2968,18 @@ int uh_ba_optimize(uh_ba* b, const volatile uint8_t* stop_asap) {
     const float mc = b->params.min_chi2_between_iter;
     b->iters[0] = b->iters[1] = 0;
     b->step = 0;
-    if (b->persist) return run_persistent(b, stop_asap, n1, n2, mc);
+    if (b->persist) {
+        const int rcp = run_persistent(b, stop_asap, n1, n2, mc);
+        if (rcp != UH_ENODEVICE || !b->h_stage) return rcp;
+        // The persistent kernel's workgroups did not all become resident within its timeout (another process's or library's spinning
+        // kernel holds CUs: INTEGRATION.md section 8).  The problem is still in the staging block: this optimisation and the next 64
+        // problems of this object take the launch chain, which needs no co-residency; then the persistent form is tried again.
+        const std::string why = uh_last_error();
+        const int rc2 = staged_problem_to_tables(b, d.K, d.P, d.E, b->pq.obs16 != 0);   // (clears b->persist; the parameters stay)
+        b->persist_blocked = 64;
+        if (rc2 != UH_OK) { uh::set_error("%s; falling back to the launch chain failed too", why.c_str()); return UH_ENODEVICE; }
+        return uh_ba_optimize(b, stop_asap);
+    }
     UH_LAUNCH(b->ctx,ba_init_state_kernel, dim3(uh_div_up(nmax, 256)), dim3(256), 0, b->ptrs, d, b->d_pose0, b->d_pts0);
     // Both passes are enqueued in one go, one step per outer iteration: enough when no trial is rejected — a rejected trial is rare,
     // and a spare step whose pass is already finished would still cost its two launches (~10 us per pass); finish_pass() adds steps
