@@ -356,7 +356,7 @@ def main():
         pnp_pr = synth.pnp_problem(600, seed=3)
         pnp = PnPSolver(ctx)
         pd = {k: torch.from_numpy(np.ascontiguousarray(pnp_pr[k])).to(dev) for k in ("pose", "intr", "p3d", "kp", "invsig", "weight")}
-        pwork = torch.empty(600 * 11 + 64, dtype=torch.uint8, device=dev)
+        pwork = torch.empty(600 * 32, dtype=torch.uint8, device=dev)
         pout = (torch.empty(16, dtype=torch.float32, device=dev), torch.empty(600, dtype=torch.uint8, device=dev),
                 torch.empty(5, dtype=torch.int32, device=dev), torch.empty(7, dtype=torch.float64, device=dev))
         stage_ms["pnp_ms_per_solve_600_matches"] = timed(lambda: check(L.uh_pnp_solve_dev(

@@ -498,7 +498,8 @@ void uh_pnp_destroy(uh_pnp* pnp);
 int  uh_pnp_solve(uh_pnp* pnp, const float* pose_f2g, const float* intr4, int n, const float* p3d, const float* kp,
                   const float* inv_sigma, const float* weight, float* pose_out, uint8_t* bad_out, int32_t* iters_out4,
                   double* state_out7);
-/* device-resident form: d_work = n*11 bytes of scratch (8-byte aligned); d_result5 = {inliers, iters[4]}; one launch, async */
+/* device-resident form: d_work = n*32 bytes of scratch (16-byte aligned; only touched beyond 3000 matches); d_result5 = {inliers, iters[4]};
+ * one launch, asynchronous on the context stream */
 int  uh_pnp_solve_dev(uh_pnp* pnp, const float* d_pose_f2g, const float* d_intr4, int n, const float* d_p3d, const float* d_kp,
                       const float* d_inv_sigma, const float* d_weight, void* d_work, float* d_pose_out, uint8_t* d_bad_out,
                       int32_t* d_result5, double* d_state7);
@@ -578,6 +579,9 @@ int uh_ba_debug_clocks(uh_ba* ba, int64_t* out64);
  * stream, for scripts/time_interference.py: what about a neighbouring launch slows the latency-bound BA chain down */
 int uh_debug_background(uh_ctx* ctx, int mode, int blocks, int iters, const void* d_buf, size_t buf_bytes, void* d_sink);
 int uh_knn_debug_push_cycles(uh_knn* knn, int k, int n, long long* out3);
+/* shader-clock stamps of the pose-only solves that follow (on = 1) — out8[0] kernel entry, [1] matches staged, [2] rounds done, [3] results
+ * posted, [4] passes over the matches; out8 (may be NULL) receives the stamps of the last solve */
+int uh_pnp_debug_clocks(uh_pnp* pnp, int on, long long* out8);
 
 #ifdef __cplusplus
 }

@@ -259,41 +259,7 @@ __device__ __forceinline__ void se3_left_update_p(double (&q)[4], double (&t)[3]
 }
 
 
-// ---- cross-lane sums without the LDS crossbar.  __shfl_xor is ds_bpermute_b32 (an address register, two LDS-pipe operations per double
-// and their ~100-cycle round trip); on a lone wave that latency is not hidden.  gfx950 can do every level of a butterfly in the VALU:
-//   partner 1, 2: DPP quad_perm;  4: row_half_mirror (i <-> 7-i);  8: row_mirror (i <-> 15-i) or row_ror:8 (i <-> i^8);
-//   16, 32: v_permlane16_swap / v_permlane32_swap (rows of 16 / 32 lanes of TWO registers exchanged: odd rows of the first with even rows
-//   of the second) — with both registers holding x, the two results are {own, partner} in one half of the wave and {partner, own} in
-//   the other: their sum is x + x_partner in every lane, no select.
-// The mirror levels pair lane i with another partner than i ^ 4 / i ^ 8, which is as good for an all-reduce: every level is a perfect
-// matching whose two lanes both form a + b, so all lanes end with the same bits (taken in ascending order of the levels).
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-// a (from this lane) and b (from this lane), rows of ROW lanes: returns {x0, x1} with x0 + x1 = (own a + partner's a) in even rows and
-// (partner's b + own b) in odd rows — the butterfly-transpose step; with a == b the plain pair sum
-template <int ROW>
-__device__ __forceinline__ void swap_rows(double& a, double& b) {
-    static_assert(ROW == 16 || ROW == 32, "v_permlane16_swap / v_permlane32_swap");
-    const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
-    unsigned alo = (unsigned)ba, ahi = (unsigned)(ba >> 32), blo = (unsigned)bb, bhi = (unsigned)(bb >> 32);
-#if __has_builtin(__builtin_amdgcn_permlane32_swap)   // (the device pass; through the builtin, not inline asm: the compiler inserts the wait states a VALU write -> permlane read needs)
-    if (ROW == 16) {
-        const auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false), h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
-        alo = l[0]; blo = l[1]; ahi = h[0]; bhi = h[1];
-    } else {
-        const auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false), h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-        alo = l[0]; blo = l[1]; ahi = h[0]; bhi = h[1];
-    }
-#endif
-    a = __longlong_as_double(((long long)ahi << 32) | alo);
-    b = __longlong_as_double(((long long)bhi << 32) | blo);
-}
-constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140, kDppRor8 = 0x128;
+// (dpp_f64 / swap_rows / the kDpp* controls: reduce.hpp)
 // sum over the groups of W consecutive lanes (W = 8, 16, 64), the same bits in every lane of a group
 template <int W>
 __device__ __forceinline__ double group_sum(double v) {

@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdarg>
 #include <cstring>
+#include <atomic>
+#include <chrono>
 #include <string>
 #include <vector>
 #include "../../include/ucoslam_hip.h"
@@ -75,6 +77,58 @@ struct PinBuf {
     PinBuf(const PinBuf&) = delete;
     PinBuf& operator=(const PinBuf&) = delete;
 };
+
+
+// Pinned host memory that the device addresses directly (hipHostMallocMapped): the latency-bound per-frame entry points hand their
+// inputs to the kernel through such a block and receive the results in it — no copy engine, no stream synchronisation.
+struct MappedBuf {
+    void* h = nullptr;
+    void* d = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return UH_OK;
+        if (h) (void)hipHostFree(h);
+        h = d = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&h, want, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&d, h, 0);
+        if (e != hipSuccess) { set_error("hipHostMalloc(%zu, mapped) failed: %s", want, hipGetErrorString(e)); if (h) (void)hipHostFree(h); h = d = nullptr; return UH_ENOMEM; }
+        std::memset(h, 0, want);
+        cap = want;
+        return UH_OK;
+    }
+    template <typename T> T* host() const { return reinterpret_cast<T*>(h); }
+    template <typename T> T* dev() const { return reinterpret_cast<T*>(d); }
+    ~MappedBuf() { if (h) (void)hipHostFree(h); }
+    MappedBuf() = default;
+    MappedBuf(const MappedBuf&) = delete;
+    MappedBuf& operator=(const MappedBuf&) = delete;
+};
+
+// Wait for the completion word a kernel posts last (system-scope release store into pinned memory, behind its results): polling costs
+// a few hundred nanoseconds after the store lands, a stream synchronisation 10-20 us.  A launch that disappears without posting
+// (device fault) is noticed through hipStreamQuery; `what` names the caller in the error message.
+inline int wait_host_word(volatile unsigned long long* word, unsigned long long expect, hipStream_t st, const char* what, int timeout_s = 30) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        if (*word == expect) break;
+        __builtin_ia32_pause();
+        if ((spin & 4095) == 4095) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q != hipErrorNotReady && *word != expect) {
+                if (q == hipSuccess && *word == expect) break;
+                set_error("%s: the launch ended without posting its completion word (%s)", what, hipGetErrorString(q == hipSuccess ? hipGetLastError() : q));
+                return UH_ENODEVICE;
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s)) {
+                set_error("%s: no completion after %d s", what, timeout_s);
+                return UH_ENODEVICE;
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return UH_OK;
+}
 
 }  // namespace uh
 

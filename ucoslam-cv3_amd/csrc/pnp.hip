@@ -9,12 +9,23 @@
 //   src/optimization/typesg2o.h:82-105      WeightedHubberRobustKernel: the weight scales rho (the chi2 sums), not the Jacobian
 //   3rdparty/g2o                            Levenberg loop, lambda init/update, SE3 exp — as in ba.hip
 //
-// MI355X design: the problem is one 6x6 system over a few hundred to a few thousand matches, i.e. pure latency.  The
-// WHOLE solve — 4 rounds x <=10 iterations x <=10 trials, classification included — runs inside ONE persistent workgroup:
-// edges are strided over 256 threads, the 28 sums of a linearisation go through one deterministic butterfly-transpose
-// reduction, thread 0 does the 6x6 LDL^T / SE3 update / accept-reject between two barriers.  No kernel launches and no host
-// synchronisation inside the solve; one launch, one result.
+// MI355X design: one 6x6 system over a few hundred to a few thousand matches, ~20 dependent Levenberg trials — pure latency, so
+// the WHOLE solve runs inside ONE workgroup of one launch and every trial costs ONE pass over the matches and ONE barrier:
+//   * a pass evaluates a pose: per match the error, chi2, robust weight AND the Jacobian products, i.e. the trial's chi2 and the
+//     normal equations of the NEXT linearisation come out of the same pass (g2o re-linearises at the pose it has just accepted and
+//     gets exactly these numbers; after a rejection H and b of the old pose are still valid) — one pass per trial instead of two;
+//     the classification between two rounds is folded into the first pass of the next round;
+//   * the 29 sums (21 + 6 + chi2 + inlier count) go through one butterfly-transpose reduction per wave, one LDS exchange and one
+//     barrier (double-buffered by pass parity); every wave then adds the eight partials in wave order and holds the totals as
+//     wave-uniform values;
+//   * every wave solves the 6x6 system, applies the SE3 update and takes the accept / reject decision REDUNDANTLY from those
+//     identical totals: no wave waits for another one between two passes, no single-thread section, no second barrier;
+//   * the matches live in LDS for the whole solve (37 bytes each, n <= kPnpLdsMatches; larger n runs the same code on HBM arrays);
+//   * host form: the inputs are read straight from a pinned, device-visible staging block, the results go straight into pinned
+//     memory behind a completion word the host polls — one launch, no copy engine, no stream synchronisation.
+#include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 
 #include "common.hpp"
@@ -27,12 +38,14 @@ struct PnpArgs {
     const float* intr;       // fx fy cx cy
     int n;
     const float* p3d; const float* kp; const float* invsig; const float* weight;
-    double* e_chi2;          // n
-    unsigned char* flags;    // n x 3: active, robust, bad
+    void* work;              // n x 32 bytes of scratch (only used when the matches do not fit LDS)
     float* pose_out;         // 16
     unsigned char* bad_out;  // n
     int* result;             // [0] inliers, [1..4] outer iterations per round
-    double* state_out;       // 7
+    double* state_out;       // 7 or NULL
+    unsigned long long* host_done;   // NULL, or a word in pinned host memory that receives done_word after everything else
+    unsigned long long done_word;
+    long long* clk;          // NULL, or 8 timestamps (s_memtime) for scripts/time_pnp.py
 };
 
 struct PoseD { double q[4], t[3], Rt[12]; };
@@ -70,67 +83,46 @@ __device__ __forceinline__ void p_quat_norm(double* q) {
     const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
 }
-__device__ void p_set_Rt(PoseD& T) { p_quat_to_R(T.q, T.Rt); T.Rt[9] = T.t[0]; T.Rt[10] = T.t[1]; T.Rt[11] = T.t[2]; }
-__device__ void p_oplus(PoseD& T, const double* d) {   // T <- exp(d) * T
-    const double w0 = d[0], w1 = d[1], w2 = d[2];
-    const double theta = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
-    const double O[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
-    double O2[9];
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) O2[r * 3 + c] = O[r * 3] * O[c] + O[r * 3 + 1] * O[3 + c] + O[r * 3 + 2] * O[6 + c];
-    double a, b, c1, c2;
-    if (theta < 0.00001) { a = 1; b = 0.5; c1 = 0.5; c2 = 1.0 / 6.0; }
-    else {
-        double sn, cs;
-        sincos(theta, &sn, &cs);
-        a = sn / theta; b = (1 - cs) / (theta * theta); c1 = b; c2 = (theta - sn) / (theta * theta * theta);
-    }
-    double Rm[9], V[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) { const double I = (i % 4 == 0) ? 1.0 : 0.0; Rm[i] = I + a * O[i] + b * O2[i]; V[i] = I + c1 * O[i] + c2 * O2[i]; }
-    double qe[4], te[3], RE[9];
-    p_quat_from_R(Rm, qe);
-    p_quat_norm(qe);
-#pragma unroll
-    for (int r = 0; r < 3; r++) te[r] = V[r * 3] * d[3] + V[r * 3 + 1] * d[4] + V[r * 3 + 2] * d[5];
-    p_quat_to_R(qe, RE);
-    const double* q = T.q;
-    double qn[4] = {qe[3] * q[0] + qe[0] * q[3] + qe[1] * q[2] - qe[2] * q[1], qe[3] * q[1] + qe[1] * q[3] + qe[2] * q[0] - qe[0] * q[2],
-                    qe[3] * q[2] + qe[2] * q[3] + qe[0] * q[1] - qe[1] * q[0], qe[3] * q[3] - qe[0] * q[0] - qe[1] * q[1] - qe[2] * q[2]};
-    double tn[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) tn[r] = RE[r * 3] * T.t[0] + RE[r * 3 + 1] * T.t[1] + RE[r * 3 + 2] * T.t[2] + te[r];
-    p_quat_norm(qn);
-#pragma unroll
-    for (int i = 0; i < 4; i++) T.q[i] = qn[i];
-#pragma unroll
-    for (int i = 0; i < 3; i++) T.t[i] = tn[i];
-    p_set_Rt(T);
+__device__ __forceinline__ void p_set_Rt(PoseD& T) { p_quat_to_R(T.q, T.Rt); T.Rt[9] = T.t[0]; T.Rt[10] = T.t[1]; T.Rt[11] = T.t[2]; }
+// ---- fp64 primitives of the serial path: v_rcp_f64 / v_rsq_f64 + two Newton steps (<= 1 ulp) instead of the IEEE division /
+// square-root expansions (a dozen instructions each, on a path where every instruction is latency)
+__device__ __forceinline__ double rcp_nr(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
 }
-__device__ __forceinline__ bool p_solve6(const double* H, const double* b, double lam, double* x) {   // LDL^T, fails on a zero / non-finite pivot
-    // fully unrolled with compile-time indices: the 6x6 system stays in registers (runtime-indexed arrays live in scratch,
-    // one L2 round trip per access on the serial path of every LM trial)
-    double M[6][6], L[6][6], d[6], id[6], y[6];
+__device__ __forceinline__ double rsq_nr(double x) {   // x > 0
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    return y;
+}
+
+// Hu = the 21 upper-triangle entries row by row (H[a][c], a <= c, at index tri(a, c))
+__device__ __forceinline__ constexpr int tri(int a, int c) { return a * 6 - a * (a - 1) / 2 + (c - a); }
+__device__ __forceinline__ bool p_solve6(const double* Hu, const double* b, double lam, double* x) {   // LDL^T, fails on a zero / non-finite pivot
+    // fully unrolled with compile-time indices: the 6x6 system stays in registers.  x is left alone on failure.
+    double M[6][6], L[6][6], Ld[6][6], id[6], y[6];
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = 0; j < 6; j++) { M[i][j] = H[i * 6 + j] + (i == j ? lam : 0.0); L[i][j] = 0; }
+        for (int j = i; j < 6; j++) M[j][i] = Hu[tri(i, j)] + (i == j ? lam : 0.0);
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
         double dj = M[j][j];
 #pragma unroll
-        for (int k = 0; k < j; k++) dj -= L[j][k] * L[j][k] * d[k];
-        d[j] = dj;
+        for (int k = 0; k < j; k++) dj = fma(-L[j][k], Ld[j][k], dj);
         ok = ok && !(dj == 0.0 || !isfinite(dj));
-        id[j] = 1.0 / dj;   // one division per pivot; the column and the substitution multiply by it
+        id[j] = rcp_nr(dj);   // one reciprocal per pivot; the column and the substitution multiply by it
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
             double v = M[i][j];
 #pragma unroll
-            for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k] * d[k];
+            for (int k = 0; k < j; k++) v = fma(-L[i][k], Ld[j][k], v);
+            Ld[i][j] = v;             // L d
             L[i][j] = v * id[j];
         }
     }
@@ -139,7 +131,7 @@ __device__ __forceinline__ bool p_solve6(const double* H, const double* b, doubl
     for (int i = 0; i < 6; i++) {
         double v = b[i];
 #pragma unroll
-        for (int k = 0; k < i; k++) v -= L[i][k] * y[k];
+        for (int k = 0; k < i; k++) v = fma(-L[i][k], y[k], v);
         y[i] = v;
     }
 #pragma unroll
@@ -148,7 +140,7 @@ __device__ __forceinline__ bool p_solve6(const double* H, const double* b, doubl
     for (int i = 5; i >= 0; i--) {
         double v = y[i];
 #pragma unroll
-        for (int k = i + 1; k < 6; k++) v -= L[k][i] * y[k];
+        for (int k = i + 1; k < 6; k++) v = fma(-L[k][i], y[k], v);
         y[i] = v;
     }
 #pragma unroll
@@ -156,229 +148,387 @@ __device__ __forceinline__ bool p_solve6(const double* H, const double* b, doubl
     return true;
 }
 
-// CACHED: the per-match inputs (map point, keypoint, 1/sigma, weight), chi2 and the three flag bytes live in LDS for the
-// whole solve (44 bytes per match, n <= kPnpLdsMatches): the ~40 passes over the matches then cost LDS latency instead
-// of an L2 round trip each.  Larger n runs the same code on the HBM arrays.
+// T <- exp(d) * T on the 3x4 matrix (g2o: SE3Quat::exp(update) * estimate, se3quat.h:276-311 — the same Rodrigues / V matrices; g2o
+// goes through a unit quaternion after every product, which changes the result by rounding only).  For |w| < 0.5 the three
+// coefficients sin(t)/t, (1 - cos t)/t^2, (t - sin t)/t^3 come from their power series in t^2 (nine terms: truncation < 1e-19):
+// no square root, no division, no sincos on the path of every trial.
+__device__ __forceinline__ void p_oplus_rt(double (&Rt)[12], const double* d) {
+    const double w0 = d[0], w1 = d[1], w2 = d[2];
+    const double z = w0 * w0 + w1 * w1 + w2 * w2;   // theta^2
+    double a, b, c2;
+    if (z < 1e-10) { a = 1; b = 0.5; c2 = 1.0 / 6.0; }      // theta < 0.00001 (se3quat.h:290)
+    else if (z < 0.25) {
+        // 1/(2k+1)!, 1/(2k+2)!, 1/(2k+3)! with alternating signs, Horner in z
+        a = 1.0 / 355687428096000.0; b = 1.0 / 6402373705728000.0; c2 = 1.0 / 121645100408832000.0;
+        a = fma(a, z, -1.0 / 1307674368000.0); b = fma(b, z, -1.0 / 20922789888000.0); c2 = fma(c2, z, -1.0 / 355687428096000.0);
+        a = fma(a, z, 1.0 / 6227020800.0);     b = fma(b, z, 1.0 / 87178291200.0);     c2 = fma(c2, z, 1.0 / 1307674368000.0);
+        a = fma(a, z, -1.0 / 39916800.0);      b = fma(b, z, -1.0 / 479001600.0);      c2 = fma(c2, z, -1.0 / 6227020800.0);
+        a = fma(a, z, 1.0 / 362880.0);         b = fma(b, z, 1.0 / 3628800.0);         c2 = fma(c2, z, 1.0 / 39916800.0);
+        a = fma(a, z, -1.0 / 5040.0);          b = fma(b, z, -1.0 / 40320.0);          c2 = fma(c2, z, -1.0 / 362880.0);
+        a = fma(a, z, 1.0 / 120.0);            b = fma(b, z, 1.0 / 720.0);             c2 = fma(c2, z, 1.0 / 5040.0);
+        a = fma(a, z, -1.0 / 6.0);             b = fma(b, z, -1.0 / 24.0);             c2 = fma(c2, z, -1.0 / 120.0);
+        a = fma(a, z, 1.0);                    b = fma(b, z, 0.5);                     c2 = fma(c2, z, 1.0 / 6.0);
+    } else {
+        const double theta = sqrt(z);
+        double sn, cs;
+        sincos(theta, &sn, &cs);
+        a = sn / theta; b = (1 - cs) / z; c2 = (theta - sn) / (z * theta);
+    }
+    // O = [w]x, O2 = O*O = w w^T - z I;  Rm = I + a O + b O2,  V = I + b O + c2 O2
+    const double O[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+    const double O2[9] = {w0 * w0 - z, w0 * w1, w0 * w2, w0 * w1, w1 * w1 - z, w1 * w2, w0 * w2, w1 * w2, w2 * w2 - z};
+    double Rm[9], V[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        Rm[i] = fma(b, O2[i], fma(a, O[i], I));
+        V[i] = fma(c2, O2[i], fma(b, O[i], I));
+    }
+    double n[12];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) n[r * 3 + c] = fma(Rm[r * 3 + 2], Rt[6 + c], fma(Rm[r * 3 + 1], Rt[3 + c], Rm[r * 3] * Rt[c]));
+        const double rt = fma(Rm[r * 3 + 2], Rt[11], fma(Rm[r * 3 + 1], Rt[10], Rm[r * 3] * Rt[9]));
+        const double vu = fma(V[r * 3 + 2], d[5], fma(V[r * 3 + 1], d[4], V[r * 3] * d[3]));
+        n[9 + r] = rt + vu;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) Rt[i] = n[i];
+}
+
+// The matches live in LDS for the whole solve as 32-byte records {X, Y, Z, u, v, 1/sigma, weight, flags} (n <= kPnpLdsMatches:
+// 96 KB): a pass reads a match with two ds_read_b128.  Larger n runs the same code on records packed into the caller's scratch.
 constexpr int kPnpLdsMatches = 3000;
-// 8 waves = two per SIMD of the one CU this kernel lives on: the per-match fp64 chains (two divisions, a square root) of one wave
-// fill the latency gaps of the other; 600 matches are then one or two per thread
+// 8 waves = two per SIMD of the one CU this kernel lives on: the per-match fp64 chains of one wave fill the issue gaps of the other.
+// Wave 0 owns the Levenberg state and is alone on its SIMD during the serial steps (the other waves wait at the barrier).
 constexpr int kPnpThreads = 512, kPnpWaves = kPnpThreads / 64;
+constexpr int kNS = 29;               // sums per pass: H (21), b (6), robust chi2, inlier count
+constexpr unsigned kActive = 1, kRobust = 2, kBad = 4;
+enum : int { kModeEval = 0, kModeClassify = 1, kModeExit = 2 };
+
+struct __attribute__((aligned(16))) MatchRec { float X, Y, Z, u, v, invsig, weight; unsigned flags; };
+static_assert(sizeof(MatchRec) == 32, "match record");
 
 template <bool CACHED>
 __global__ __launch_bounds__(kPnpThreads) void pnp_solve_kernel(PnpArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_cache[];
-    __shared__ double s_part[kPnpWaves * 28], s_sum[28], s_red[kPnpWaves];
-    __shared__ PoseD s_T, s_T0, s_bak;
-    __shared__ double s_H[36], s_b[6], s_x[6];
-    __shared__ double s_lambda, s_ni, s_currentChi, s_lastChiRaw, s_rho;
-    __shared__ int s_ok2, s_again, s_ok, s_iter_cont, s_good;
-    __shared__ float s_prev, s_cur;
-    const int tid = threadIdx.x, n = A.n;
+    __shared__ __attribute__((aligned(16))) double s_part[kPnpWaves * 32];
+    __shared__ __attribute__((aligned(16))) double s_tot[32];
+    __shared__ __attribute__((aligned(16))) double s_pose[4][12];   // [0] pose to evaluate + accumulate, [1] pose of the excluded matches' fresh chi2 (end of the last
+                                                                    // round), [2] pose the kept chi2 belong to (the last one evaluated), [3] the input pose
+    __shared__ __attribute__((aligned(16))) double s_H[28];         // the normal equations of the current pose (21 + 6): wave 0's, parked here between solves
+    __shared__ int s_ctl[4];                                        // mode, classify, drop_robust
+    const int tid = threadIdx.x, lane = tid & 63, n = A.n;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave index as a scalar: the role split below is an s_cbranch
+    if (A.clk && tid == 0) A.clk[0] = __builtin_readcyclecounter();
     const double fx = A.intr[0], fy = A.intr[1], cx = A.intr[2], cy = A.intr[3];
     const double delta = (double)sqrtf(5.99f), dsqr = delta * delta;
-    // one set of names for both instantiations; in each the pointers have a single provenance (LDS or HBM), so the
-    // compiler emits ds_* or global_* accesses, never flat ones
-    double* e_chi2; const float* p3d; const float* kpt; const float* invsig; const float* weight;
-    unsigned char* active; unsigned char* robust; unsigned char* bad;
-    if constexpr (CACHED) {
-        e_chi2 = reinterpret_cast<double*>(s_cache);
-        float* c_p3d = reinterpret_cast<float*>(s_cache + 8 * (size_t)n);
-        float* c_kp = c_p3d + 3 * (size_t)n;
-        float* c_is = c_kp + 2 * (size_t)n;
-        float* c_w = c_is + n;
-        active = reinterpret_cast<unsigned char*>(c_w + n);
-        robust = active + n; bad = robust + n;
-        for (int i = tid; i < 3 * n; i += kPnpThreads) c_p3d[i] = A.p3d[i];
-        for (int i = tid; i < 2 * n; i += kPnpThreads) c_kp[i] = A.kp[i];
-        for (int i = tid; i < n; i += kPnpThreads) { c_is[i] = A.invsig[i]; c_w[i] = A.weight[i]; }
-        p3d = c_p3d; kpt = c_kp; invsig = c_is; weight = c_w;
-    } else {
-        e_chi2 = A.e_chi2; p3d = A.p3d; kpt = A.kp; invsig = A.invsig; weight = A.weight;
-        active = A.flags; robust = A.flags + n; bad = A.flags + 2 * (size_t)n;
+    // one name for both instantiations; in each the pointer has a single provenance (LDS or HBM): ds_* or global_* accesses, never flat
+    MatchRec* rec;
+    if constexpr (CACHED) rec = reinterpret_cast<MatchRec*>(s_cache);
+    else rec = reinterpret_cast<MatchRec*>(A.work);
+    for (int e = tid; e < n; e += kPnpThreads) {
+        MatchRec r;
+        r.X = A.p3d[3 * e]; r.Y = A.p3d[3 * e + 1]; r.Z = A.p3d[3 * e + 2]; r.u = A.kp[2 * e]; r.v = A.kp[2 * e + 1];
+        r.invsig = A.invsig[e]; r.weight = A.weight[e]; r.flags = kActive | kRobust;
+        rec[e] = r;
     }
-    for (int e = tid; e < n; e += kPnpThreads) { active[e] = 1; robust[e] = 1; bad[e] = 0; e_chi2[e] = 0; }
-    if (tid == 0) {
+    {
+        PoseD P;
         const float* M = A.pose_in;
         const double R0[9] = {M[0], M[1], M[2], M[4], M[5], M[6], M[8], M[9], M[10]};
-        p_quat_from_R(R0, s_T0.q);
-        p_quat_norm(s_T0.q);
-        s_T0.t[0] = M[3]; s_T0.t[1] = M[7]; s_T0.t[2] = M[11];
-        p_set_Rt(s_T0);
-        s_T = s_T0;
-        for (int i = 0; i < 5; i++) A.result[i] = 0;
+        p_quat_from_R(R0, P.q);       // g2o::SE3Quat(R, t): the rotation the optimisation starts from is the one of the NORMALISED quaternion
+        p_quat_norm(P.q);
+        P.t[0] = M[3]; P.t[1] = M[7]; P.t[2] = M[11];
+        p_set_Rt(P);
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) { s_pose[3][i] = P.Rt[i]; s_pose[1][i] = P.Rt[i]; s_pose[2][i] = P.Rt[i]; }
+        }
     }
     __syncthreads();
+    if (A.clk && tid == 0) A.clk[1] = __builtin_readcyclecounter();
 
-    auto edge_err = [&](int e, const double* Rt, double& ex, double& ey, double* pc) {
-        const double X0 = p3d[3 * e], X1 = p3d[3 * e + 1], X2 = p3d[3 * e + 2];
-        pc[0] = Rt[0] * X0 + Rt[1] * X1 + Rt[2] * X2 + Rt[9];
-        pc[1] = Rt[3] * X0 + Rt[4] * X1 + Rt[5] * X2 + Rt[10];
-        pc[2] = Rt[6] * X0 + Rt[7] * X1 + Rt[8] * X2 + Rt[11];
-        ex = (double)kpt[2 * e] - ((pc[0] / pc[2]) * fx + cx);
-        ey = (double)kpt[2 * e + 1] - ((pc[1] / pc[2]) * fy + cy);
-    };
-    auto robchi = [&](int e, double c) -> double {
-        if (!robust[e]) return c;
-        const double w = weight[e];
-        return (c <= dsqr) ? w * c : w * (2 * sqrt(c) * delta - dsqr);
+    // chi2 of a match at the pose Rt; xz, yz, invz for the Jacobian
+    auto project = [&](const MatchRec& m, const double* Rt, double& ex, double& ey, double& xz, double& yz, double& invz) -> double {
+        const double X0 = m.X, X1 = m.Y, X2 = m.Z;
+        const double p0 = fma(Rt[2], X2, fma(Rt[1], X1, fma(Rt[0], X0, Rt[9])));
+        const double p1 = fma(Rt[5], X2, fma(Rt[4], X1, fma(Rt[3], X0, Rt[10])));
+        const double p2 = fma(Rt[8], X2, fma(Rt[7], X1, fma(Rt[6], X0, Rt[11])));
+        invz = rcp_nr(p2);
+        xz = p0 * invz; yz = p1 * invz;
+        ex = (double)m.u - fma(xz, fx, cx);
+        ey = (double)m.v - fma(yz, fy, cy);
+        return (double)m.invsig * fma(ex, ex, ey * ey);
     };
 
-    for (int round = 0; round < 4 && n > 0; round++) {
-        if (tid == 0) { s_T = s_T0; s_prev = FLT_MAX; s_cur = FLT_MAX; s_ok = 1; s_iter_cont = 1; }
-        __syncthreads();
-        int done = 0;
-        for (int it = 0; it < 10; it++) {
-            if (!s_iter_cont) break;     // uniform (read after a barrier)
-            // ---- linearise at the current pose: errors, chi2, H, b
-            double acc[28];
+    // One pass over this thread's matches (every wave).  classify: first the reclassification that ends a round
+    // (pnpsolver.cpp:358-371): a match that was excluded gets a fresh chi2 at RtC, the others the chi2 of the LAST pose the optimiser
+    // evaluated them at (RtK: g2o keeps the edge errors of its last trial, accepted or not) — recomputed here instead of stored, same
+    // bits; chi2 > 5.99 -> outlier; drop_robust as the reference from its third round on.  Then (RtA != nullptr) every active match:
+    // error, chi2, robust weight and Jacobian at RtA, accumulated into the 29 sums; the wave's totals go to s_part.
+    auto pass = [&](bool accumulate, const double* RtA, bool classify, bool drop_robust) {
+        double acc[kNS];
 #pragma unroll
-            for (int i = 0; i < 28; i++) acc[i] = 0;
+        for (int i = 0; i < kNS; i++) acc[i] = 0;
+        for (int e = tid; e < n; e += kPnpThreads) {
+            const MatchRec m = rec[e];
+            unsigned f = m.flags;
+            double ex, ey, xz, yz, invz;
+            if (classify) {
+                double Rs[12];
+#pragma unroll
+                for (int i = 0; i < 12; i++) Rs[i] = s_pose[(f & kBad) ? 1 : 2][i];   // (read per match: four classifying passes per solve)
+                const double c = project(m, Rs, ex, ey, xz, yz, invz);
+                const bool b = c > (double)5.99f;
+                f = (b ? kBad : kActive) | (drop_robust ? 0u : (f & kRobust));
+                rec[e].flags = f;
+                acc[28] += b ? 0.0 : 1.0;
+            }
+            if (!(f & kActive) || !accumulate) continue;
+            const double c = project(m, RtA, ex, ey, xz, yz, invz);
+            const double w = m.invsig;
+            double rho1 = 1.0, rc = c;
+            if (f & kRobust) {
+                const double wt = m.weight;
+                if (c <= dsqr) rc = wt * c;
+                else { const double rs = rsq_nr(c); rc = wt * fma(2 * (c * rs), delta, -dsqr); rho1 = delta * rs; }
+            }
+            acc[27] += rc;
+            // 2x6 Jacobian rows (typesg2o.h:614-650): j = d ex / d xi, k = d ey / d xi; j[4] = k[3] = 0
+            const double zf = invz * fx, zg = invz * fy, xf = xz * fx, yg = yz * fy;
+            const double j0 = xf * yz, j1 = -fma(xf, xz, fx), j2 = yz * fx, j3 = -zf, j5 = xz * zf;
+            const double k0 = fma(yg, yz, fy), k1 = -(xz * yg), k2 = -(xz * fy), k4 = -zg, k5 = yz * zg;
+            const double s = rho1 * w;
+            const double J[6] = {j0, j1, j2, j3, 0.0, j5}, K[6] = {k0, k1, k2, 0.0, k4, k5};
+            const double sJ[6] = {s * j0, s * j1, s * j2, s * j3, 0.0, s * j5}, sK[6] = {s * k0, s * k1, s * k2, 0.0, s * k4, s * k5};
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int cc = a; cc < 6; cc++) {   // (the structural zeros are compile-time: their products are never formed)
+                    double v = acc[tri(a, cc)];
+                    if (a != 4 && cc != 4) v = fma(sJ[a], J[cc], v);
+                    if (a != 3 && cc != 3) v = fma(sK[a], K[cc], v);
+                    acc[tri(a, cc)] = v;
+                }
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                double v = acc[21 + a];
+                if (a != 4) v = fma(-sJ[a], ex, v);
+                if (a != 3) v = fma(-sK[a], ey, v);
+                acc[21 + a] = v;
+            }
+        }
+        int off = 0, real = kNS;
+        WaveTransposeValu<kNS, 32>::run(acc, lane, off, real);   // lane l ends with the wave total of one value index
+        if (real >= 1) s_part[wv * 32 + off] = acc[0];
+    };
+    // what a pass does is published by wave 0 through s_ctl / s_pose before barrier A
+    auto run_published_pass = [&]() -> int {
+        const int mode = s_ctl[0];
+        if (mode == kModeExit) return mode;
+        double RtA[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) RtA[i] = s_pose[0][i];
+        pass(mode != kModeClassify, RtA, s_ctl[1] != 0, s_ctl[2] != 0);
+        return mode;
+    };
+
+    if (wv != 0) {
+        // ---- the seven worker waves: evaluate what wave 0 publishes until it says stop
+        for (;;) {
+            __syncthreads();                    // A: the request is in LDS
+            const int mode = run_published_pass();
+            if (mode == kModeExit) break;
+            __syncthreads();                    // B: the partial sums are in LDS
+        }
+    } else {
+        // ---- wave 0: the Levenberg-Marquardt state machine (g2o's OptimizationAlgorithmLevenberg::solve + SparseOptimizer::optimize)
+        int n_pass = 0;
+        double chi_sum = 0, good_sum = 0;
+        // publish a request, take part in it, collect the 29 totals into s_tot (and the two this wave branches on into registers).
+        // s_pose[1] / s_pose[2] are maintained below; the pose just evaluated becomes "the pose the kept chi2 belong to".
+        auto evaluate = [&](int mode, const double* RtA, bool classify, bool drop_robust) {
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 12; i++) s_pose[0][i] = RtA[i];
+                s_ctl[0] = mode; s_ctl[1] = classify ? 1 : 0; s_ctl[2] = drop_robust ? 1 : 0;
+            }
+            __syncthreads();                    // A
+            pass(mode != kModeClassify, RtA, classify, drop_robust);
+            __syncthreads();                    // B
+            ++n_pass;
+            if (lane < kNS) {
+                double mine = s_part[lane];
+#pragma unroll
+                for (int w2 = 1; w2 < kPnpWaves; w2++) mine += s_part[w2 * 32 + lane];   // wave order
+                s_tot[lane] = mine;
+            }
+            if (lane == 0 && mode == kModeEval) {
+#pragma unroll
+                for (int i = 0; i < 12; i++) s_pose[2][i] = RtA[i];
+            }
+            // (the same wave wrote s_tot: LDS operations of one wave complete in order)
+            chi_sum = s_tot[27]; good_sum = s_tot[28];
+        };
+        auto adopt_linearisation = [&]() {      // the totals of the pass are the normal equations of the pose it evaluated
+            if (lane < 27) s_H[lane] = s_tot[lane];
+        };
+
+        double T[12];                       // current (last accepted) pose
+        double x[6] = {0, 0, 0, 0, 0, 0};   // the last solved step: a failed factorisation leaves it as it was (g2o's solution vector does the same)
+        int last_round = -1, good = n;
+        bool have_good = false;
+        for (int round = 0; round < 4 && n > 0; round++) {
+            // first pass of the round: (classification that ends the previous round) + linearisation at the input pose
+#pragma unroll
+            for (int i = 0; i < 12; i++) T[i] = s_pose[3][i];
+            evaluate(kModeEval, T, round > 0, round - 1 >= 2);
+            if (round > 0) {
+                good = (int)good_sum; have_good = true;
+                if (good < 10) break;
+            }
+            have_good = false;
+            adopt_linearisation();
+            double currentChi = chi_sum, lambda, ni = 2, lastChiRaw = chi_sum;
             {
-                double Rt[12];
+                double m = 0;
 #pragma unroll
-                for (int i = 0; i < 12; i++) Rt[i] = s_T.Rt[i];
-                for (int e = tid; e < n; e += kPnpThreads) {
-                    if (!active[e]) continue;
-                    double ex, ey, pc[3];
-                    edge_err(e, Rt, ex, ey, pc);
-                    const double w = invsig[e];
-                    const double c = w * (ex * ex + ey * ey);
-                    e_chi2[e] = c;
-                    acc[27] += robchi(e, c);
-                    const double X = pc[0], Y = pc[1], invz = 1.0 / pc[2], invz2 = invz * invz;
-                    const double J[12] = {X * Y * invz2 * fx, -(1 + (X * X * invz2)) * fx, Y * invz * fx, -invz * fx, 0, X * invz2 * fx,
-                                          (1 + Y * Y * invz2) * fy, -X * Y * invz2 * fy, -X * invz * fy, 0, -invz * fy, Y * invz2 * fy};
-                    double rho1 = 1.0;
-                    if (robust[e] && c > dsqr) rho1 = delta / sqrt(c);
-                    int q = 0;
-#pragma unroll
-                    for (int a = 0; a < 6; a++)
-#pragma unroll
-                        for (int cc = a; cc < 6; cc++) acc[q++] += (rho1 * w) * (J[a] * J[cc] + J[6 + a] * J[6 + cc]);
-#pragma unroll
-                    for (int a = 0; a < 6; a++) acc[21 + a] -= rho1 * (J[a] * w * ex + J[6 + a] * w * ey);
-                }
+                for (int j = 0; j < 6; j++) m = fmax(fabs(s_H[tri(j, j)]), m);
+                lambda = 1e-5 * m;
             }
-            block_sum_vec<28, kPnpWaves>(acc, s_part, s_sum);
-            if (tid == 0) {
-                int q = 0;
-                for (int a = 0; a < 6; a++) for (int cc = a; cc < 6; cc++) { s_H[a * 6 + cc] = s_sum[q]; s_H[cc * 6 + a] = s_sum[q]; q++; }
-                for (int a = 0; a < 6; a++) s_b[a] = s_sum[21 + a];
-                s_currentChi = s_sum[27];
-                if (it == 0) { double m = 0; for (int j = 0; j < 6; j++) m = fmax(fabs(s_H[j * 7]), m); s_lambda = 1e-5 * m; s_ni = 2; }
-                const float t = s_prev; s_prev = s_cur; s_cur = t;   // swap(prevChi2, curChi2) at loop entry
-            }
-            __syncthreads();
-            // ---- Levenberg trial loop
-            int qmax = 0;
-            double rho = 0;
-            for (;;) {
-                if (tid == 0) {
-                    s_bak = s_T;
-                    s_ok2 = p_solve6(s_H, s_b, s_lambda, s_x) ? 1 : 0;
-                    if (s_ok2) p_oplus(s_T, s_x);
-                }
-                __syncthreads();
-                double part = 0;
-                {
-                    double Rt[12];
+            float prevChi = FLT_MAX, curChi = FLT_MAX;
+            int done = 0;
+            for (int it = 0; it < 10; it++) {
+                { const float t = prevChi; prevChi = curChi; curChi = t; }   // swap(prevChi2, curChi2) at loop entry
+                int qmax = 0;
+                double rho = 0;
+                bool lam_finite = true;
+                for (;;) {
+                    double Tt[12], scale = 1e-3;
 #pragma unroll
-                    for (int i = 0; i < 12; i++) Rt[i] = s_T.Rt[i];
-                    for (int e = tid; e < n; e += kPnpThreads) {
-                        if (!active[e]) continue;
-                        double ex, ey, pc[3];
-                        edge_err(e, Rt, ex, ey, pc);
-                        const double c = (double)invsig[e] * (ex * ex + ey * ey);
-                        e_chi2[e] = c;
-                        part += robchi(e, c);
+                    for (int i = 0; i < 12; i++) Tt[i] = T[i];
+                    bool ok2;
+                    {
+                        double Hu[21], b[6];
+#pragma unroll
+                        for (int i = 0; i < 21; i++) Hu[i] = s_H[i];
+#pragma unroll
+                        for (int i = 0; i < 6; i++) b[i] = s_H[21 + i];
+                        ok2 = p_solve6(Hu, b, lambda, x);
+                        if (ok2) p_oplus_rt(Tt, x);
+                        double sc = 0;
+#pragma unroll
+                        for (int i = 0; i < 6; i++) sc += x[i] * (lambda * x[i] + b[i]);
+                        scale += sc;
                     }
-                }
-                const double tempRaw = block_sum<kPnpWaves>(part, s_red);   // valid in every thread
-                if (tid == 0) {
-                    s_lastChiRaw = tempRaw;
-                    double tempChi = s_ok2 ? tempRaw : DBL_MAX;
-                    double r = s_currentChi - tempChi, scale = 0;
-                    for (int i = 0; i < 6; i++) scale += s_x[i] * (s_lambda * s_x[i] + s_b[i]);
-                    scale += 1e-3;
-                    r /= scale;
-                    bool lam_finite = true;
+                    evaluate(kModeEval, Tt, false, false);
+                    lastChiRaw = chi_sum;
+                    const double tempChi = ok2 ? chi_sum : DBL_MAX;
+                    const double r = (currentChi - tempChi) / scale;
                     if (r > 0 && isfinite(tempChi)) {
                         const double t3 = 2 * r - 1;
                         double alpha = 1. - t3 * t3 * t3;
                         alpha = fmin(alpha, 2. / 3.);
-                        s_lambda *= fmax(1. / 3., alpha);
-                        s_ni = 2;
-                        s_currentChi = tempChi;
-                    } else {
-                        s_lambda *= s_ni; s_ni *= 2; s_T = s_bak;
-                        if (!isfinite(s_lambda)) lam_finite = false;
-                    }
-                    s_x[0] = s_x[0];
-                    s_rho = r;                       // publish rho
-                    s_again = lam_finite ? 1 : 0;    // 0 -> break before qmax++
-                }
-                __syncthreads();
-                rho = s_rho;
-                const int lam_ok = s_again;
-                __syncthreads();
-                if (!lam_ok) break;
-                qmax++;
-                if (!(rho < 0 && qmax < 10)) break;
-            }
-            done++;
-            if (tid == 0) {
-                const bool terminate = (qmax == 10 || rho == 0 || !isfinite(s_lambda));
-                s_cur = (float)s_lastChiRaw;
-                const float diff = s_prev - s_cur;
-                s_iter_cont = (!terminate && diff > 0.f) ? 1 : 0;
-            }
-            __syncthreads();
-        }
-        // ---- classification (:358-371)
-        int good = 0;
-        {
-            double Rt[12];
+                        lambda *= fmax(1. / 3., alpha);
+                        ni = 2;
+                        currentChi = tempChi;
 #pragma unroll
-            for (int i = 0; i < 12; i++) Rt[i] = s_T.Rt[i];
-            for (int e = tid; e < n; e += kPnpThreads) {
-                double c = e_chi2[e];
-                if (bad[e]) {
-                    double ex, ey, pc[3];
-                    edge_err(e, Rt, ex, ey, pc);
-                    c = (double)invsig[e] * (ex * ex + ey * ey);
-                    e_chi2[e] = c;
+                        for (int i = 0; i < 12; i++) T[i] = Tt[i];
+                        adopt_linearisation();                          // the pass has linearised at the accepted pose already
+                    } else {
+                        lambda *= ni; ni *= 2;                          // T and the normal equations stay those of the last accepted pose
+                        if (!isfinite(lambda)) lam_finite = false;
+                    }
+                    rho = r;
+                    if (!lam_finite) break;   // before qmax++
+                    qmax++;
+                    if (!(rho < 0 && qmax < 10)) break;
                 }
-                const bool b = c > (double)5.99f;
-                bad[e] = b; active[e] = !b;
-                if (round >= 2) robust[e] = 0;
-                good += !b;
+                done++;
+                const bool terminate = (qmax == 10 || rho == 0 || !isfinite(lambda));
+                curChi = (float)lastChiRaw;
+                const float diff = prevChi - curChi;
+                if (terminate || !(diff > 0.f)) break;
             }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 12; i++) s_pose[1][i] = T[i];
+                A.result[1 + round] = done;
+            }
+            last_round = round;
         }
-        const double gsum = block_sum<kPnpWaves>((double)good, s_red);
-        if (tid == 0) { A.result[1 + round] = done; s_good = (int)gsum; }
+        if (A.clk && lane == 0) A.clk[2] = __builtin_readcyclecounter();
+        if (n > 0 && !have_good) {   // the classification that ends the last round
+            double Te[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) Te[i] = s_pose[1][i];
+            evaluate(kModeClassify, Te, true, last_round >= 2);
+            good = (int)good_sum;
+        }
+        if (lane == 0) {
+            s_ctl[0] = kModeExit;
+            for (int r = last_round + 1; r < 4; r++) A.result[1 + r] = 0;
+            A.result[0] = n > 0 ? good : 0;
+            double Tend[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) Tend[i] = s_pose[1][i];
+            float* M = A.pose_out;
+            for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) M[r * 4 + c] = (float)Tend[r * 3 + c]; M[r * 4 + 3] = (float)Tend[9 + r]; }
+            M[12] = M[13] = M[14] = 0.f; M[15] = 1.f;
+            if (A.state_out) {
+                double q[4];
+                p_quat_from_R(Tend, q);
+                p_quat_norm(q);
+                for (int i = 0; i < 4; i++) A.state_out[i] = q[i];
+                for (int i = 0; i < 3; i++) A.state_out[4 + i] = Tend[9 + i];
+            }
+            if (A.clk) A.clk[4] = n_pass;
+        }
+        __syncthreads();                        // A of the exit request
+    }
+    for (int e = tid; e < n; e += kPnpThreads) A.bad_out[e] = (rec[e].flags & kBad) ? 1 : 0;
+    if (A.host_done) {   // results went to pinned host memory: make them visible, then post the completion word
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         __syncthreads();
-        if (s_good < 10) break;
+        if (tid == 0) __hip_atomic_store(A.host_done, A.done_word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __syncthreads();
-    int good = 0;
-    for (int e = tid; e < n; e += kPnpThreads) { A.bad_out[e] = bad[e]; good += !bad[e]; }
-    const double gsum = block_sum<kPnpWaves>((double)good, s_red);
-    if (tid == 0) {
-        A.result[0] = (int)gsum;
-        float* M = A.pose_out;
-        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) M[r * 4 + c] = (float)s_T.Rt[r * 3 + c]; M[r * 4 + 3] = (float)s_T.t[r]; }
-        M[12] = M[13] = M[14] = 0.f; M[15] = 1.f;
-        if (A.state_out) { for (int i = 0; i < 4; i++) A.state_out[i] = s_T.q[i]; for (int i = 0; i < 3; i++) A.state_out[4 + i] = s_T.t[i]; }
-    }
+    if (A.clk && tid == 0) A.clk[3] = __builtin_readcyclecounter();
 }
 
 }  // namespace
 
 struct uh_pnp {
     uh_ctx* ctx = nullptr;
-    uh::DevBuf d_in, d_work, d_out;
+    uh::DevBuf d_work;
+    uh::MappedBuf h_io;      // pinned, device-visible: [inputs | results | completion word]
+    unsigned long long seq = 0;
     bool attr_set = false;
+    long long* d_clk = nullptr;   // measurement hook (uh_pnp_debug_clocks)
+    ~uh_pnp() { if (d_clk) (void)hipFree(d_clk); }
 };
+
+namespace {
+
+int launch(uh_pnp* p, PnpArgs& A) {
+    const int n = A.n;
+    A.clk = p->d_clk;
+    if (n <= kPnpLdsMatches) {
+        const size_t lds = (size_t)std::max(n, 1) * 32;
+        if (!p->attr_set) {
+            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pnp_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kPnpLdsMatches * 32));
+            p->attr_set = true;
+        }
+        UH_LAUNCH(p->ctx, pnp_solve_kernel<true>, dim3(1), dim3(kPnpThreads), lds, A);
+    } else {
+        UH_LAUNCH(p->ctx, pnp_solve_kernel<false>, dim3(1), dim3(kPnpThreads), 0, A);
+    }
+    UH_HIP_CHECK(hipGetLastError());
+    return UH_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -391,7 +541,8 @@ int uh_pnp_create(uh_ctx* ctx, uh_pnp** out) {
 }
 void uh_pnp_destroy(uh_pnp* p) { delete p; }
 
-// Everything resident in HBM; asynchronous on the context stream.  d_work: n*8 + n*3 bytes of scratch (8-byte aligned).
+// Everything resident in HBM; asynchronous on the context stream.  d_work: n * 32 bytes of scratch (16-byte aligned), only used
+// beyond kPnpLdsMatches matches.
 int uh_pnp_solve_dev(uh_pnp* p, const float* d_pose_f2g, const float* d_intr4, int n, const float* d_p3d, const float* d_kp,
                      const float* d_inv_sigma, const float* d_weight, void* d_work, float* d_pose_out, uint8_t* d_bad_out,
                      int32_t* d_result5, double* d_state7) {
@@ -399,26 +550,17 @@ int uh_pnp_solve_dev(uh_pnp* p, const float* d_pose_f2g, const float* d_intr4, i
     UH_REQUIRE(n >= 0, "uh_pnp_solve_dev: negative match count");
     if (n > 0) UH_REQUIRE(d_p3d && d_kp && d_inv_sigma && d_weight && d_work && d_bad_out, "uh_pnp_solve_dev: NULL match arrays");
     UH_HIP_CHECK(hipSetDevice(p->ctx->device));
-    PnpArgs A;
+    PnpArgs A{};
     A.pose_in = d_pose_f2g; A.intr = d_intr4; A.n = n; A.p3d = d_p3d; A.kp = d_kp; A.invsig = d_inv_sigma; A.weight = d_weight;
-    A.e_chi2 = reinterpret_cast<double*>(d_work);
-    A.flags = reinterpret_cast<unsigned char*>(d_work) + (size_t)n * 8;
+    A.work = d_work;
     A.pose_out = d_pose_out; A.bad_out = d_bad_out; A.result = d_result5; A.state_out = d_state7;
-    if (n <= kPnpLdsMatches) {
-        const size_t lds = (size_t)n * 44 + 16;
-        if (!p->attr_set) {
-            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pnp_solve_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kPnpLdsMatches * 44 + 16));
-            p->attr_set = true;
-        }
-        UH_LAUNCH(p->ctx, pnp_solve_kernel<true>, dim3(1), dim3(kPnpThreads), lds, A);
-    } else {
-        UH_LAUNCH(p->ctx, pnp_solve_kernel<false>, dim3(1), dim3(kPnpThreads), 0, A);
-    }
-    UH_HIP_CHECK(hipGetLastError());
-    return UH_OK;
+    A.host_done = nullptr; A.done_word = 0;
+    return launch(p, A);
 }
 
 // Host-pointer form: PnPSolver::solvePnp(frame, map, matches, pose): returns the inlier count (>= 0) or a negative error.
+// The caller's arrays are packed into the object's pinned staging block (a few KB), the kernel reads them from there and writes
+// pose / flags / counters back into the same block; the host polls the completion word the kernel posts last.
 int uh_pnp_solve(uh_pnp* p, const float* pose_f2g, const float* intr4, int n, const float* p3d, const float* kp, const float* inv_sigma,
                  const float* weight, float* pose_out, uint8_t* bad_out, int32_t* iters_out4, double* state_out7) {
     UH_REQUIRE(p && pose_f2g && intr4 && pose_out, "uh_pnp_solve: NULL argument");
@@ -426,34 +568,49 @@ int uh_pnp_solve(uh_pnp* p, const float* pose_f2g, const float* intr4, int n, co
     if (n == 0) { memcpy(pose_out, pose_f2g, 64); if (iters_out4) memset(iters_out4, 0, 16); return 0; }   // pnpsolver.cpp:149-150
     UH_REQUIRE(p3d && kp && inv_sigma && weight && bad_out, "uh_pnp_solve: NULL match arrays");
     UH_HIP_CHECK(hipSetDevice(p->ctx->device));
-    hipStream_t st = p->ctx->stream;
     const size_t nf = (size_t)n;
-    const size_t o_pose = 0, o_intr = 64, o_p3d = 128, o_kp = o_p3d + nf * 12, o_is = o_kp + nf * 8, o_w = o_is + nf * 4, in_bytes = o_w + nf * 4;
+    auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    const size_t o_done = 0, o_pout = 64, o_res = 128, o_state = 192, o_pose = 256, o_intr = 320, o_p3d = 384, o_kp = al(o_p3d + nf * 12), o_is = al(o_kp + nf * 8),
+                 o_w = al(o_is + nf * 4), o_bad = al(o_w + nf * 4), total = al(o_bad + nf);
     int rc;
-    if ((rc = p->d_in.reserve(in_bytes))) return rc;
-    if ((rc = p->d_work.reserve(nf * 11 + 64))) return rc;
-    const size_t o_pout = 0, o_res = 64, o_state = 96, o_bad = 160, out_bytes = o_bad + nf;
-    if ((rc = p->d_out.reserve(out_bytes))) return rc;
-    char* din = p->d_in.as<char>();
-    UH_HIP_CHECK(hipMemcpyAsync(din + o_pose, pose_f2g, 64, hipMemcpyHostToDevice, st));
-    UH_HIP_CHECK(hipMemcpyAsync(din + o_intr, intr4, 16, hipMemcpyHostToDevice, st));
-    UH_HIP_CHECK(hipMemcpyAsync(din + o_p3d, p3d, nf * 12, hipMemcpyHostToDevice, st));
-    UH_HIP_CHECK(hipMemcpyAsync(din + o_kp, kp, nf * 8, hipMemcpyHostToDevice, st));
-    UH_HIP_CHECK(hipMemcpyAsync(din + o_is, inv_sigma, nf * 4, hipMemcpyHostToDevice, st));
-    UH_HIP_CHECK(hipMemcpyAsync(din + o_w, weight, nf * 4, hipMemcpyHostToDevice, st));
-    char* dout = p->d_out.as<char>();
-    rc = uh_pnp_solve_dev(p, (float*)(din + o_pose), (float*)(din + o_intr), n, (float*)(din + o_p3d), (float*)(din + o_kp), (float*)(din + o_is),
-                          (float*)(din + o_w), p->d_work.p, (float*)(dout + o_pout), (uint8_t*)(dout + o_bad), (int32_t*)(dout + o_res),
-                          (double*)(dout + o_state));
-    if (rc) return rc;
+    if ((rc = p->h_io.reserve(total))) return rc;
+    if (n > kPnpLdsMatches && (rc = p->d_work.reserve(nf * 32))) return rc;
+    char* h = p->h_io.host<char>();
+    char* d = p->h_io.dev<char>();
+    memcpy(h + o_pose, pose_f2g, 64);
+    memcpy(h + o_intr, intr4, 16);
+    memcpy(h + o_p3d, p3d, nf * 12);
+    memcpy(h + o_kp, kp, nf * 8);
+    memcpy(h + o_is, inv_sigma, nf * 4);
+    memcpy(h + o_w, weight, nf * 4);
+    PnpArgs A{};
+    A.pose_in = (const float*)(d + o_pose); A.intr = (const float*)(d + o_intr); A.n = n;
+    A.p3d = (const float*)(d + o_p3d); A.kp = (const float*)(d + o_kp); A.invsig = (const float*)(d + o_is); A.weight = (const float*)(d + o_w);
+    A.work = p->d_work.p;
+    A.pose_out = (float*)(d + o_pout); A.bad_out = (unsigned char*)(d + o_bad); A.result = (int*)(d + o_res); A.state_out = (double*)(d + o_state);
+    A.host_done = (unsigned long long*)(d + o_done);
+    A.done_word = ++p->seq;
+    std::atomic_thread_fence(std::memory_order_release);
+    if ((rc = launch(p, A))) return rc;
+    if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(h + o_done), A.done_word, p->ctx->stream, "uh_pnp_solve"))) return rc;
     int32_t res[5];
-    UH_HIP_CHECK(hipMemcpyAsync(pose_out, dout + o_pout, 64, hipMemcpyDeviceToHost, st));
-    UH_HIP_CHECK(hipMemcpyAsync(res, dout + o_res, 20, hipMemcpyDeviceToHost, st));
-    UH_HIP_CHECK(hipMemcpyAsync(bad_out, dout + o_bad, nf, hipMemcpyDeviceToHost, st));
-    if (state_out7) UH_HIP_CHECK(hipMemcpyAsync(state_out7, dout + o_state, 56, hipMemcpyDeviceToHost, st));
-    UH_HIP_CHECK(hipStreamSynchronize(st));
+    memcpy(res, h + o_res, 20);
+    memcpy(pose_out, h + o_pout, 64);
+    memcpy(bad_out, h + o_bad, nf);
+    if (state_out7) memcpy(state_out7, h + o_state, 56);
     if (iters_out4) memcpy(iters_out4, res + 1, 16);
     return res[0];
+}
+
+// measurement hook (scripts/time_pnp.py): shader-clock timestamps of the next solves — [0] kernel entry, [1] inputs staged,
+// [2] rounds done, [3] results posted (s_memtime ticks), [4] number of passes.  on = 0 switches it off again.
+int uh_pnp_debug_clocks(uh_pnp* p, int on, long long* out8) {
+    UH_REQUIRE(p, "uh_pnp_debug_clocks: NULL");
+    UH_HIP_CHECK(hipSetDevice(p->ctx->device));
+    if (on && !p->d_clk) { UH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p->d_clk), 64)); UH_HIP_CHECK(hipMemset(p->d_clk, 0, 64)); }
+    if (out8 && p->d_clk) { UH_HIP_CHECK(hipStreamSynchronize(p->ctx->stream)); UH_HIP_CHECK(hipMemcpy(out8, p->d_clk, 64, hipMemcpyDeviceToHost)); }
+    if (!on && p->d_clk) { (void)hipFree(p->d_clk); p->d_clk = nullptr; }
+    return UH_OK;
 }
 
 }  // extern "C"

@@ -20,6 +20,7 @@ def _declare(L, sig):
     sig("uh_pnp_destroy", None, VP)
     sig("uh_pnp_solve", I, VP, VP, VP, I, VP, VP, VP, VP, VP, VP, VP, VP)
     sig("uh_pnp_solve_dev", I, VP, VP, VP, I, VP, VP, VP, VP, VP, VP, VP, VP, VP)
+    sig("uh_pnp_debug_clocks", I, VP, I, VP)
 
 
 _lib._EXTRA_DECLS.append(_declare)
@@ -42,6 +43,12 @@ class PnPSolver:
             check(rc)
         out["ngood"] = rc
         out["bad"] = out["bad"][:n]
+        return out
+
+    def debug_clocks(self, on=True):
+        """Shader-clock stamps of the last solve (measurement hook): [entry, staged, rounds done, posted, passes, ...]."""
+        out = np.zeros(8, np.int64)
+        check(lib().uh_pnp_debug_clocks(self._h, int(on), np_ptr(out)))
         return out
 
     def close(self):
