@@ -22,6 +22,11 @@ for n in (100, 300, 600, 800, 1500, 3000, 4000):
     sol.debug_clocks(True)
     sol.solvePnp(*args)
     c = sol.debug_clocks(True)
+    if os.environ.get("PNP_TRACE"):
+        sol.debug_clocks(True); sol.solvePnp(*args); c = sol.debug_clocks(True)
+        tr = c[8:8 + int(c[4]) + 2]
+        print("   trials (round.it:qmax+/-):", " ".join(f"{(v >> 16) & 255}.{(v >> 8) & 255}:{v & 255}{'+' if v >> 24 else '-'}" for v in tr if v))
     sol.debug_clocks(False)
     tot = c[3] - c[0]
+    print("   wave 0 cycles: prepare(solve+update) %d  barrierA %d  matches+butterfly %d  barrierB %d  totals+decision %d  ladder passes %d" % tuple(c[16:22]))
     print(f"n={n:5d} wall {wall:7.1f} us  iters {r['iters'].tolist()} passes {c[4]}  clk: stage {c[1]-c[0]} rounds {c[2]-c[1]} post {c[3]-c[2]} total {tot}  per pass {(c[2]-c[1])/max(c[4],1):.0f}")

@@ -103,45 +103,39 @@ __device__ __forceinline__ double rsq_nr(double x) {   // x > 0
 // Hu = the 21 upper-triangle entries row by row (H[a][c], a <= c, at index tri(a, c))
 __device__ __forceinline__ constexpr int tri(int a, int c) { return a * 6 - a * (a - 1) / 2 + (c - a); }
 __device__ __forceinline__ bool p_solve6(const double* Hu, const double* b, double lam, double* x) {   // LDL^T, fails on a zero / non-finite pivot
-    // fully unrolled with compile-time indices: the 6x6 system stays in registers.  x is left alone on failure.
-    double M[6][6], L[6][6], Ld[6][6], id[6], y[6];
+    // Right-looking (every pivot's column updates the trailing block at once) with the right-hand side carried along, then a
+    // column-oriented back substitution: the dependent chain per pivot is reciprocal -> scale -> one fma instead of a dot product
+    // of growing length — this routine sits on the serial path of every trial.  Fully unrolled, compile-time indices: the system
+    // stays in registers.  x is left alone on failure.
+    double a[6][6], L[6][6], id[6], y[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < 6; i++) {
+        y[i] = b[i];
 #pragma unroll
-        for (int j = i; j < 6; j++) M[j][i] = Hu[tri(i, j)] + (i == j ? lam : 0.0);
+        for (int j = 0; j <= i; j++) a[i][j] = Hu[tri(j, i)] + (i == j ? lam : 0.0);
+    }
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-        double dj = M[j][j];
-#pragma unroll
-        for (int k = 0; k < j; k++) dj = fma(-L[j][k], Ld[j][k], dj);
+        const double dj = a[j][j];
         ok = ok && !(dj == 0.0 || !isfinite(dj));
-        id[j] = rcp_nr(dj);   // one reciprocal per pivot; the column and the substitution multiply by it
+        id[j] = rcp_nr(dj);
 #pragma unroll
-        for (int i = j + 1; i < 6; i++) {
-            double v = M[i][j];
+        for (int i = j + 1; i < 6; i++) L[i][j] = a[i][j] * id[j];
 #pragma unroll
-            for (int k = 0; k < j; k++) v = fma(-L[i][k], Ld[j][k], v);
-            Ld[i][j] = v;             // L d
-            L[i][j] = v * id[j];
-        }
+        for (int k = j + 1; k < 6; k++)
+#pragma unroll
+            for (int i = k; i < 6; i++) a[i][k] = fma(-L[i][j], a[k][j], a[i][k]);
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) y[i] = fma(-L[i][j], y[j], y[i]);
     }
     if (!ok) return false;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        double v = b[i];
-#pragma unroll
-        for (int k = 0; k < i; k++) v = fma(-L[i][k], y[k], v);
-        y[i] = v;
-    }
-#pragma unroll
     for (int i = 0; i < 6; i++) y[i] *= id[i];
 #pragma unroll
-    for (int i = 5; i >= 0; i--) {
-        double v = y[i];
+    for (int j = 5; j >= 0; j--) {
 #pragma unroll
-        for (int k = i + 1; k < 6; k++) v = fma(-L[k][i], y[k], v);
-        y[i] = v;
+        for (int i = 0; i < j; i++) y[i] = fma(-L[j][i], y[j], y[i]);
     }
 #pragma unroll
     for (int i = 0; i < 6; i++) x[i] = y[i];
@@ -205,7 +199,8 @@ constexpr int kPnpLdsMatches = 3000;
 constexpr int kPnpThreads = 512, kPnpWaves = kPnpThreads / 64;
 constexpr int kNS = 29;               // sums per pass: H (21), b (6), robust chi2, inlier count
 constexpr unsigned kActive = 1, kRobust = 2, kBad = 4;
-enum : int { kModeEval = 0, kModeClassify = 1, kModeExit = 2 };
+enum : int { kModeEval = 0, kModeClassify = 1, kModeExit = 2, kModeLadder = 3 };
+constexpr int kLadderMax = 8;         // candidates per ladder pass (one per wave; Levenberg's inner loop tries at most ten damping factors per iteration)
 
 struct __attribute__((aligned(16))) MatchRec { float X, Y, Z, u, v, invsig, weight; unsigned flags; };
 static_assert(sizeof(MatchRec) == 32, "match record");
@@ -218,7 +213,10 @@ __global__ __launch_bounds__(kPnpThreads) void pnp_solve_kernel(PnpArgs A) {
     __shared__ __attribute__((aligned(16))) double s_pose[4][12];   // [0] pose to evaluate + accumulate, [1] pose of the excluded matches' fresh chi2 (end of the last
                                                                     // round), [2] pose the kept chi2 belong to (the last one evaluated), [3] the input pose
     __shared__ __attribute__((aligned(16))) double s_H[28];         // the normal equations of the current pose (21 + 6): wave 0's, parked here between solves
-    __shared__ int s_ctl[4];                                        // mode, classify, drop_robust
+    __shared__ __attribute__((aligned(16))) double s_T[12], s_x[8]; // wave 0's: the current (last accepted) pose and the last solved step
+    __shared__ int s_ctl[4];                                        // mode, classify, drop_robust, ladder length
+    __shared__ __attribute__((aligned(16))) double s_lad[2];        // ladder request: lambda and ni of its first candidate
+    __shared__ __attribute__((aligned(16))) double s_cand[kLadderMax][20];   // per candidate: trial pose (12), step (6), factorisation ok (1)
     const int tid = threadIdx.x, lane = tid & 63, n = A.n;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave index as a scalar: the role split below is an s_cbranch
     if (A.clk && tid == 0) A.clk[0] = __builtin_readcyclecounter();
@@ -335,29 +333,235 @@ __global__ __launch_bounds__(kPnpThreads) void pnp_solve_kernel(PnpArgs A) {
         return mode;
     };
 
+    // ---- the damping ladder.  When a trial is rejected, Levenberg multiplies lambda by ni, doubles ni and tries again from the SAME
+    // pose and normal equations, up to ten times — at convergence (rho < 0 by rounding noise) it walks the whole ladder, which as
+    // dependent passes is most of a solve.  The candidates do not depend on each other's outcome, only the DECISION is sequential:
+    // wave w solves and applies candidates w, w + 8 (every wave the same bits as the sequential loop would produce), one pass
+    // evaluates the robust chi2 of all of them, wave 0 then walks the decisions in order and stops where the loop would have.
+    auto solve_candidates = [&]() {
+        const int K = s_ctl[3];
+        for (int k = wv; k < K; k += kPnpWaves) {
+            double lam = s_lad[0], nn = s_lad[1];
+            for (int j = 0; j < k; j++) { lam *= nn; nn *= 2; }
+            double Hu[21], b[6], Tt[12], xs[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 21; i++) Hu[i] = s_H[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) b[i] = s_H[21 + i];
+#pragma unroll
+            for (int i = 0; i < 12; i++) Tt[i] = s_pose[0][i];
+            const bool ok = p_solve6(Hu, b, lam, xs);
+            if (ok) p_oplus_rt(Tt, xs);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 12; i++) s_cand[k][i] = Tt[i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) s_cand[k][12 + i] = xs[i];
+                s_cand[k][18] = ok ? 1.0 : 0.0;
+            }
+        }
+    };
+    auto ladder_pass = [&]() {
+        const int K = s_ctl[3];
+        double chi[kLadderMax];
+#pragma unroll
+        for (int k = 0; k < kLadderMax; k++) {
+            chi[k] = 0;
+            if (k < K) {
+                double Rt[12];
+#pragma unroll
+                for (int i = 0; i < 12; i++) Rt[i] = s_cand[k][i];
+                for (int e = tid; e < n; e += kPnpThreads) {
+                    const MatchRec m = rec[e];
+                    if (!(m.flags & kActive)) continue;
+                    double ex, ey, xz, yz, invz;
+                    const double c = project(m, Rt, ex, ey, xz, yz, invz);
+                    double rc = c;
+                    if (m.flags & kRobust) {
+                        const double wt = m.weight;
+                        if (c <= dsqr) rc = wt * c;
+                        else rc = wt * fma(2 * (c * rsq_nr(c)), delta, -dsqr);
+                    }
+                    chi[k] += rc;
+                }
+            }
+        }
+        int off = 0, real = kLadderMax;
+        WaveTransposeValu<kLadderMax, 32>::run(chi, lane, off, real);
+        if (real >= 1) s_part[wv * 32 + off] = chi[0];
+    };
+
     if (wv != 0) {
         // ---- the seven worker waves: evaluate what wave 0 publishes until it says stop
         for (;;) {
             __syncthreads();                    // A: the request is in LDS
-            const int mode = run_published_pass();
-            if (mode == kModeExit) break;
+            if (s_ctl[0] == kModeLadder) {
+                solve_candidates();
+                __syncthreads();                // A2: the candidates' poses are in LDS
+                ladder_pass();
+            } else {
+                const int mode = run_published_pass();
+                if (mode == kModeExit) break;
+            }
             __syncthreads();                    // B: the partial sums are in LDS
         }
     } else {
-        // ---- wave 0: the Levenberg-Marquardt state machine (g2o's OptimizationAlgorithmLevenberg::solve + SparseOptimizer::optimize)
-        int n_pass = 0;
-        double chi_sum = 0, good_sum = 0;
-        // publish a request, take part in it, collect the 29 totals into s_tot (and the two this wave branches on into registers).
-        // s_pose[1] / s_pose[2] are maintained below; the pose just evaluated becomes "the pose the kept chi2 belong to".
-        auto evaluate = [&](int mode, const double* RtA, bool classify, bool drop_robust) {
-            if (lane == 0) {
-#pragma unroll
-                for (int i = 0; i < 12; i++) s_pose[0][i] = RtA[i];
-                s_ctl[0] = mode; s_ctl[1] = classify ? 1 : 0; s_ctl[2] = drop_robust ? 1 : 0;
+        // ---- wave 0: g2o's SparseOptimizer::optimize + OptimizationAlgorithmLevenberg::solve as a state machine whose every
+        // transition is ONE pass (or one damping-ladder pass) over the matches: a single call site for the pass keeps the code and
+        // the register allocation of this wave small.  The control flow is the reference's, statement for statement:
+        //   for round < 4 { T = T0; [classify previous round]; linearise;                         -> ST_INIT
+        //     for it < 10 { swap(prev, cur); qmax = 0;
+        //        do { solve; oplus; chi2 of the trial; accept / reject; } while (rho < 0 && ++qmax < 10)   -> ST_TRIAL, then ST_LADDER
+        //        (a pose accepted inside a ladder pass is linearised by ST_RELIN before the next solve)
+        //        stop on terminate or when the float chi2 no longer decreases }
+        //   } classify the last round                                                               -> ST_FINAL
+        enum : int { ST_INIT, ST_RELIN, ST_TRIAL, ST_LADDER, ST_FINAL, ST_DONE };
+        int st = n > 0 ? ST_INIT : ST_DONE;
+        // measurement (A.clk != NULL only): cycles of wave 0 by section of a plain pass — [16] request prepared (solve + update), [17] barrier A,
+        // [18] its share of the matches + butterfly, [19] barrier B, [20] totals + decision; [21] ladder passes as a whole
+        long long ph[6] = {0, 0, 0, 0, 0, 0}, tp = A.clk ? (long long)__builtin_readcyclecounter() : 0;
+        auto stamp = [&](int i) { if (A.clk) { const long long t = (long long)__builtin_readcyclecounter(); ph[i] += t - tp; tp = t; } };
+        int n_pass = 0, round = 0, it = 0, qmax = 0, done = 0, last_round = -1, good = n;
+        bool stale_H = false, lam_finite = true, ok2 = false;
+        double lambda = 0, ni = 2, currentChi = 0, lastChiRaw = 0, rho = 0, scale = 1;
+        float prevChi = FLT_MAX, curChi = FLT_MAX;
+        // (the pose and the last solved step live in LDS, s_T / s_x: nothing but scalars stays in registers across a pass.  A failed
+        // factorisation leaves the step as it was — g2o's solution vector does the same)
+        if (lane < 8) s_x[lane] = 0;
+
+        auto iter_begin = [&]() {
+            const float t = prevChi; prevChi = curChi; curChi = t;   // swap(prevChi2, curChi2) at loop entry
+            qmax = 0; rho = 0; lam_finite = true;
+            st = stale_H ? ST_RELIN : ST_TRIAL;
+        };
+        auto round_end = [&]() {
+            if (lane < 12) s_pose[1][lane] = s_T[lane];
+            if (lane == 0) A.result[1 + round] = done;
+            last_round = round;
+            ++round;
+            st = round < 4 ? ST_INIT : ST_FINAL;
+        };
+        auto after_trials = [&]() {          // the do-while of Levenberg's solve() has just evaluated a trial
+            if (lam_finite && rho < 0 && qmax < 10) { st = ST_LADDER; return; }
+            done++;
+            const bool terminate = (qmax == 10 || rho == 0 || !isfinite(lambda));
+            curChi = (float)lastChiRaw;
+            const float diff = prevChi - curChi;
+            if (terminate || !(diff > 0.f) || it + 1 >= 10) round_end();
+            else { ++it; iter_begin(); }
+        };
+        auto decide = [&](bool ok, double chi, const double* pose_lds) -> bool {   // one accept / reject decision (lambda, ni, currentChi, T)
+            lastChiRaw = chi;
+            const double tempChi = ok ? chi : DBL_MAX;
+            const double r = (currentChi - tempChi) / scale;
+            const bool acc = r > 0 && isfinite(tempChi);
+            if (acc) {
+                const double t3 = 2 * r - 1;
+                double alpha = 1. - t3 * t3 * t3;
+                alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha);
+                ni = 2;
+                currentChi = tempChi;
+                if (lane < 12) s_T[lane] = pose_lds[lane];
+            } else {
+                lambda *= ni; ni *= 2;                          // T and the normal equations stay those of the last accepted pose
+                if (!isfinite(lambda)) lam_finite = false;
             }
+            rho = r;
+            return acc;
+        };
+
+        while (st != ST_DONE) {
+            if (st == ST_LADDER) {
+                // ---- rejected: the rest of the damping ladder in one pass
+                const int K = 10 - qmax < kLadderMax ? 10 - qmax : kLadderMax;
+                if (lane < 12) s_pose[0][lane] = s_T[lane];
+                if (lane == 0) {
+                    s_ctl[0] = kModeLadder; s_ctl[3] = K;
+                    s_lad[0] = lambda; s_lad[1] = ni;
+                }
+                __syncthreads();                // A
+                solve_candidates();
+                __syncthreads();                // A2
+                ladder_pass();
+                __syncthreads();                // B
+                ++n_pass;
+                if (lane < kLadderMax) {
+                    double mine = s_part[lane];
+#pragma unroll
+                    for (int w2 = 1; w2 < kPnpWaves; w2++) mine += s_part[w2 * 32 + lane];   // wave order
+                    s_tot[lane] = mine;
+                }
+                double bb[6], x[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) { bb[i] = s_H[21 + i]; x[i] = s_x[i]; }
+                int k_last = 0;
+                for (int k = 0; k < K; k++) {   // the decisions, in the order the sequential loop takes them
+                    const bool okk = s_cand[k][18] != 0.0;
+                    if (okk) {
+#pragma unroll
+                        for (int i = 0; i < 6; i++) x[i] = s_cand[k][12 + i];
+                    }
+                    double sc = 0;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) sc += x[i] * (lambda * x[i] + bb[i]);
+                    scale = 1e-3 + sc;
+                    k_last = k;
+                    if (decide(okk, s_tot[k], s_cand[k])) stale_H = true;   // (a ladder pass does not linearise)
+                    if (!lam_finite) break;   // the reference leaves its loop before the increment when lambda overflows
+                    qmax++;
+                    if (!(rho < 0 && qmax < 10)) break;
+                }
+                if (lane < 12) s_pose[2][lane] = s_cand[k_last][lane];   // the edges keep the errors of the last trial the loop evaluated
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) s_x[i] = x[i];
+                }
+                after_trials();
+                stamp(5);
+                continue;
+            }
+            // ---- the request of this state
+            int mode = kModeEval;
+            bool classify = false, drop = false;
+            if (st == ST_INIT) {
+                if (lane < 12) { s_T[lane] = s_pose[3][lane]; s_pose[0][lane] = s_pose[3][lane]; }   // every round restarts from the input pose (:354)
+                classify = round > 0; drop = round - 1 >= 2;
+            } else if (st == ST_RELIN) {
+                if (lane < 12) s_pose[0][lane] = s_T[lane];
+            } else if (st == ST_TRIAL) {
+                double Tt[12], x[6], Hu[21], b[6];
+#pragma unroll
+                for (int i = 0; i < 12; i++) Tt[i] = s_T[i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) x[i] = s_x[i];
+#pragma unroll
+                for (int i = 0; i < 21; i++) Hu[i] = s_H[i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) b[i] = s_H[21 + i];
+                ok2 = p_solve6(Hu, b, lambda, x);
+                if (ok2) p_oplus_rt(Tt, x);
+                double sc = 0;
+#pragma unroll
+                for (int i = 0; i < 6; i++) sc += x[i] * (lambda * x[i] + b[i]);
+                scale = 1e-3 + sc;
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 12; i++) s_pose[0][i] = Tt[i];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) s_x[i] = x[i];
+                }
+            } else if (st == ST_FINAL) {
+                mode = kModeClassify; classify = true; drop = last_round >= 2;
+            }
+            if (lane == 0) { s_ctl[0] = mode; s_ctl[1] = classify ? 1 : 0; s_ctl[2] = drop ? 1 : 0; }
+            stamp(0);
             __syncthreads();                    // A
-            pass(mode != kModeClassify, RtA, classify, drop_robust);
+            stamp(1);
+            run_published_pass();
+            stamp(2);
             __syncthreads();                    // B
+            stamp(3);
             ++n_pass;
             if (lane < kNS) {
                 double mine = s_part[lane];
@@ -365,108 +569,40 @@ __global__ __launch_bounds__(kPnpThreads) void pnp_solve_kernel(PnpArgs A) {
                 for (int w2 = 1; w2 < kPnpWaves; w2++) mine += s_part[w2 * 32 + lane];   // wave order
                 s_tot[lane] = mine;
             }
-            if (lane == 0 && mode == kModeEval) {
-#pragma unroll
-                for (int i = 0; i < 12; i++) s_pose[2][i] = RtA[i];
-            }
+            if (mode == kModeEval && lane < 12) s_pose[2][lane] = s_pose[0][lane];   // the pose the edges' errors now belong to
             // (the same wave wrote s_tot: LDS operations of one wave complete in order)
-            chi_sum = s_tot[27]; good_sum = s_tot[28];
-        };
-        auto adopt_linearisation = [&]() {      // the totals of the pass are the normal equations of the pose it evaluated
-            if (lane < 27) s_H[lane] = s_tot[lane];
-        };
-
-        double T[12];                       // current (last accepted) pose
-        double x[6] = {0, 0, 0, 0, 0, 0};   // the last solved step: a failed factorisation leaves it as it was (g2o's solution vector does the same)
-        int last_round = -1, good = n;
-        bool have_good = false;
-        for (int round = 0; round < 4 && n > 0; round++) {
-            // first pass of the round: (classification that ends the previous round) + linearisation at the input pose
-#pragma unroll
-            for (int i = 0; i < 12; i++) T[i] = s_pose[3][i];
-            evaluate(kModeEval, T, round > 0, round - 1 >= 2);
-            if (round > 0) {
-                good = (int)good_sum; have_good = true;
-                if (good < 10) break;
-            }
-            have_good = false;
-            adopt_linearisation();
-            double currentChi = chi_sum, lambda, ni = 2, lastChiRaw = chi_sum;
-            {
-                double m = 0;
-#pragma unroll
-                for (int j = 0; j < 6; j++) m = fmax(fabs(s_H[tri(j, j)]), m);
-                lambda = 1e-5 * m;
-            }
-            float prevChi = FLT_MAX, curChi = FLT_MAX;
-            int done = 0;
-            for (int it = 0; it < 10; it++) {
-                { const float t = prevChi; prevChi = curChi; curChi = t; }   // swap(prevChi2, curChi2) at loop entry
-                int qmax = 0;
-                double rho = 0;
-                bool lam_finite = true;
-                for (;;) {
-                    double Tt[12], scale = 1e-3;
-#pragma unroll
-                    for (int i = 0; i < 12; i++) Tt[i] = T[i];
-                    bool ok2;
-                    {
-                        double Hu[21], b[6];
-#pragma unroll
-                        for (int i = 0; i < 21; i++) Hu[i] = s_H[i];
-#pragma unroll
-                        for (int i = 0; i < 6; i++) b[i] = s_H[21 + i];
-                        ok2 = p_solve6(Hu, b, lambda, x);
-                        if (ok2) p_oplus_rt(Tt, x);
-                        double sc = 0;
-#pragma unroll
-                        for (int i = 0; i < 6; i++) sc += x[i] * (lambda * x[i] + b[i]);
-                        scale += sc;
-                    }
-                    evaluate(kModeEval, Tt, false, false);
-                    lastChiRaw = chi_sum;
-                    const double tempChi = ok2 ? chi_sum : DBL_MAX;
-                    const double r = (currentChi - tempChi) / scale;
-                    if (r > 0 && isfinite(tempChi)) {
-                        const double t3 = 2 * r - 1;
-                        double alpha = 1. - t3 * t3 * t3;
-                        alpha = fmin(alpha, 2. / 3.);
-                        lambda *= fmax(1. / 3., alpha);
-                        ni = 2;
-                        currentChi = tempChi;
-#pragma unroll
-                        for (int i = 0; i < 12; i++) T[i] = Tt[i];
-                        adopt_linearisation();                          // the pass has linearised at the accepted pose already
-                    } else {
-                        lambda *= ni; ni *= 2;                          // T and the normal equations stay those of the last accepted pose
-                        if (!isfinite(lambda)) lam_finite = false;
-                    }
-                    rho = r;
-                    if (!lam_finite) break;   // before qmax++
-                    qmax++;
-                    if (!(rho < 0 && qmax < 10)) break;
+            const double chi_sum = s_tot[27], good_sum = s_tot[28];
+            if (st == ST_INIT) {
+                if (round > 0) {
+                    good = (int)good_sum;
+                    if (good < 10) { st = ST_DONE; continue; }
                 }
-                done++;
-                const bool terminate = (qmax == 10 || rho == 0 || !isfinite(lambda));
-                curChi = (float)lastChiRaw;
-                const float diff = prevChi - curChi;
-                if (terminate || !(diff > 0.f)) break;
-            }
-            if (lane == 0) {
+                if (lane < 27) s_H[lane] = s_tot[lane];          // the totals of the pass are the normal equations of the pose it evaluated
+                currentChi = chi_sum; lastChiRaw = chi_sum; ni = 2;
+                {
+                    double m = 0;
 #pragma unroll
-                for (int i = 0; i < 12; i++) s_pose[1][i] = T[i];
-                A.result[1 + round] = done;
+                    for (int j = 0; j < 6; j++) m = fmax(fabs(s_H[tri(j, j)]), m);
+                    lambda = 1e-5 * m;
+                }
+                prevChi = FLT_MAX; curChi = FLT_MAX; done = 0; stale_H = false; it = 0;
+                iter_begin();
+            } else if (st == ST_RELIN) {
+                if (lane < 27) s_H[lane] = s_tot[lane];
+                stale_H = false;
+                st = ST_TRIAL;
+            } else if (st == ST_TRIAL) {
+                if (decide(ok2, chi_sum, s_pose[0])) { if (lane < 27) s_H[lane] = s_tot[lane]; }   // the pass has linearised at the accepted pose already
+                if (lam_finite) qmax++;   // (the reference leaves its loop before the increment when lambda overflows)
+                after_trials();
+            } else {   // ST_FINAL: the classification that ends the last round
+                good = (int)good_sum;
+                st = ST_DONE;
             }
-            last_round = round;
+            stamp(4);
         }
+        if (A.clk && lane == 0) { for (int i = 0; i < 6; i++) A.clk[16 + i] = ph[i]; }
         if (A.clk && lane == 0) A.clk[2] = __builtin_readcyclecounter();
-        if (n > 0 && !have_good) {   // the classification that ends the last round
-            double Te[12];
-#pragma unroll
-            for (int i = 0; i < 12; i++) Te[i] = s_pose[1][i];
-            evaluate(kModeClassify, Te, true, last_round >= 2);
-            good = (int)good_sum;
-        }
         if (lane == 0) {
             s_ctl[0] = kModeExit;
             for (int r = last_round + 1; r < 4; r++) A.result[1 + r] = 0;
@@ -607,8 +743,8 @@ int uh_pnp_solve(uh_pnp* p, const float* pose_f2g, const float* intr4, int n, co
 int uh_pnp_debug_clocks(uh_pnp* p, int on, long long* out8) {
     UH_REQUIRE(p, "uh_pnp_debug_clocks: NULL");
     UH_HIP_CHECK(hipSetDevice(p->ctx->device));
-    if (on && !p->d_clk) { UH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p->d_clk), 64)); UH_HIP_CHECK(hipMemset(p->d_clk, 0, 64)); }
-    if (out8 && p->d_clk) { UH_HIP_CHECK(hipStreamSynchronize(p->ctx->stream)); UH_HIP_CHECK(hipMemcpy(out8, p->d_clk, 64, hipMemcpyDeviceToHost)); }
+    if (on && !p->d_clk) { UH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p->d_clk), 4096)); UH_HIP_CHECK(hipMemset(p->d_clk, 0, 4096)); }
+    if (out8 && p->d_clk) { UH_HIP_CHECK(hipStreamSynchronize(p->ctx->stream)); UH_HIP_CHECK(hipMemcpy(out8, p->d_clk, 4096, hipMemcpyDeviceToHost)); }
     if (!on && p->d_clk) { (void)hipFree(p->d_clk); p->d_clk = nullptr; }
     return UH_OK;
 }

@@ -47,7 +47,7 @@ class PnPSolver:
 
     def debug_clocks(self, on=True):
         """Shader-clock stamps of the last solve (measurement hook): [entry, staged, rounds done, posted, passes, ...]."""
-        out = np.zeros(8, np.int64)
+        out = np.zeros(512, np.int64)
         check(lib().uh_pnp_debug_clocks(self._h, int(on), np_ptr(out)))
         return out
 
