@@ -134,3 +134,40 @@ def test_hip_orb_large_frames_bit_exact(hip_ctx, oracle, cfg):
     rk, rd = oracle_lib.orb_extract(oracle, img, nf, nl, sf)
     _assert_same(kps, desc, rk, rd, str(cfg))
     assert len(kps) > 0.5 * nf
+
+
+@pytest.mark.gpu
+def test_hip_orb_pinned_buffers_take_the_copy_free_path(hip_ctx, oracle):
+    """uh_orb_extract with the frame and the output arrays in pinned host memory (the kernels read / write them where they lie, the
+    host polls a completion word) returns exactly what the pageable path returns; a capacity below the keypoint count is refused."""
+    import ctypes as C
+
+    import torch
+
+    from ucoslam_cv3_amd._lib import check, lib, np_ptr, UcoslamHipError
+    from ucoslam_cv3_amd.orb import KEYPOINT_DTYPE, FeatParams, ORBextractor
+
+    ext = ORBextractor.create(hip_ctx)
+    fp = FeatParams(2000, 8, 1.2)
+    for (w, h, pad) in ((1241, 376, 0), (640, 480, 32)):
+        img = synth.frame(w, h, seed=5)
+        rk, rd = ext.detectAndCompute(img, None, fp)                        # pageable in / out
+        pin_img = torch.zeros((h, w + pad), dtype=torch.uint8).pin_memory()  # (a row stride above the width, too)
+        pin_img[:, :w] = torch.from_numpy(img)
+        cap = 2000
+        pk = torch.zeros(cap * 28, dtype=torch.uint8).pin_memory()
+        pd = torch.zeros((cap, 32), dtype=torch.uint8).pin_memory()
+        n = C.c_int(0)
+        for _ in range(2):
+            check(lib().uh_orb_extract(ext._h, C.c_void_p(pin_img.data_ptr()), w, h, w + pad, C.c_void_p(pk.data_ptr()), C.c_void_p(pd.data_ptr()), cap, C.byref(n)))
+        kps = pk.numpy().view(KEYPOINT_DTYPE)[: n.value]
+        _assert_same(kps, pd.numpy()[: n.value], rk, rd, f"pinned {w}x{h}")
+        ref_k, ref_d = oracle_lib.orb_extract(oracle, img, 2000, 8, 1.2, True)
+        _assert_same(kps, pd.numpy()[: n.value], ref_k, ref_d, f"pinned {w}x{h} vs oracle")
+        # mixed: pinned frame, pageable outputs
+        k2 = np.zeros(cap, KEYPOINT_DTYPE); d2 = np.zeros((cap, 32), np.uint8)
+        check(lib().uh_orb_extract(ext._h, C.c_void_p(pin_img.data_ptr()), w, h, w + pad, np_ptr(k2), np_ptr(d2), cap, C.byref(n)))
+        _assert_same(k2[: n.value], d2[: n.value], rk, rd, "pinned frame, pageable outputs")
+        with pytest.raises(UcoslamHipError):
+            check(lib().uh_orb_extract(ext._h, C.c_void_p(pin_img.data_ptr()), w, h, w + pad, C.c_void_p(pk.data_ptr()), C.c_void_p(pd.data_ptr()), 100, C.byref(n)))
+        assert n.value == len(rk)

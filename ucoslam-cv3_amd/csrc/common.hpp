@@ -105,6 +105,15 @@ struct MappedBuf {
     MappedBuf& operator=(const MappedBuf&) = delete;
 };
 
+// The device address of a host pointer the runtime knows as pinned (hipHostMalloc / hipHostRegister), NULL for pageable memory.
+inline void* device_alias_of_host(const void* p) {
+    if (!p) return nullptr;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // (pageable: "invalid value", not an error here)
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+    return at.devicePointer;
+}
+
 // Wait for the completion word a kernel posts last (system-scope release store into pinned memory, behind its results): polling costs
 // a few hundred nanoseconds after the store lands, a stream synchronisation 10-20 us.  A launch that disappears without posting
 // (device fault) is noticed through hipStreamQuery; `what` names the caller in the error message.
@@ -175,6 +184,17 @@ struct ProfScope {
 }  // namespace uh
 
 // launch `kernel` on the context stream; when profiling is on, bracket it with HIP events on that same stream
+namespace uh {
+// enqueue a one-thread launch that stores `word` (system-scope release) into pinned host memory behind everything already on the
+// context stream: the host polls the word (wait_host_word) instead of synchronising the stream (ctx.hip)
+int post_host_word(uh_ctx* ctx, unsigned long long* d_word_in_pinned_memory, unsigned long long word);
+// 16-byte-wide copy launches on the context stream (sizes are rounded up to 16: the blocks involved are padded accordingly);
+// publish16 = one workgroup: copy into pinned memory, then post the completion word; a device status word (optional) is copied to
+// the 4 bytes at d_word + 8 and cleared
+int copy16(uh_ctx* ctx, void* dst, const void* src, size_t bytes);
+int publish16(uh_ctx* ctx, void* dst_pinned, const void* src, size_t bytes, unsigned* d_reset_word, unsigned long long* d_word_in_pinned_memory, unsigned long long word);
+}  // namespace uh
+
 #define UH_LAUNCH(ctx, kernel, grid, block, shmem, ...)                                        \
     do {                                                                                        \
         uh::ProfScope _ps((ctx), #kernel);                                                      \

@@ -12,6 +12,50 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace uh
 
+__global__ void uh_post_word_kernel(unsigned long long* host_done, unsigned long long word) {
+    __hip_atomic_store(host_done, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// 16-byte-wide copies between pinned host memory and HBM as plain launches on the context stream (no copy engine, no runtime staging):
+// every lane one 16-byte load + store; `publish` is the last launch of a host-pointer call — one workgroup copies the (small) result
+// block into pinned memory, clears the device-side status word for the next call and posts the completion word behind the data.
+__global__ __launch_bounds__(256) void uh_copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+__global__ __launch_bounds__(1024) void uh_publish_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, unsigned* reset_word,
+                                                          unsigned long long* host_done, unsigned long long word) {
+    for (size_t i = threadIdx.x; i < n16; i += 1024) dst[i] = src[i];
+    __syncthreads();   // (every wave's stores have completed: vmcnt(0) precedes the barrier)
+    if (threadIdx.x == 0) {
+        if (reset_word) {   // the call's device-side status word travels in the header (behind the completion word) and is cleared for the next call
+            reinterpret_cast<unsigned*>(host_done)[2] = *reset_word;
+            *reset_word = 0u;
+        }
+        __hip_atomic_store(host_done, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+namespace uh {
+int copy16(uh_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    const size_t n16 = (bytes + 15) / 16;
+    if (!n16) return UH_OK;
+    UH_LAUNCH(ctx, uh_copy16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, static_cast<const uint4*>(src), static_cast<uint4*>(dst), n16);
+    UH_HIP_CHECK(hipGetLastError());
+    return UH_OK;
+}
+int publish16(uh_ctx* ctx, void* dst_pinned, const void* src, size_t bytes, unsigned* d_reset_word, unsigned long long* d_word, unsigned long long word) {
+    UH_LAUNCH(ctx, uh_publish_kernel, dim3(1), dim3(1024), 0, static_cast<const uint4*>(src), static_cast<uint4*>(dst_pinned), (bytes + 15) / 16, d_reset_word, d_word, word);
+    UH_HIP_CHECK(hipGetLastError());
+    return UH_OK;
+}
+int post_host_word(uh_ctx* ctx, unsigned long long* d_word, unsigned long long word) {
+    UH_LAUNCH(ctx, uh_post_word_kernel, dim3(1), dim3(1), 0, d_word, word);
+    UH_HIP_CHECK(hipGetLastError());
+    return UH_OK;
+}
+}  // namespace uh
+
 extern "C" {
 
 const char* uh_last_error(void) { return uh::g_err; }

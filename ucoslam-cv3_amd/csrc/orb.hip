@@ -162,6 +162,31 @@ __global__ __launch_bounds__(256) void blur7_kernel(const uint8_t* __restrict__ 
     }
 }
 
+// A frame that lies in pinned host memory comes over with 16-byte loads (one PCIe read request per 64 bytes of a wave's row segment):
+// blur7_kernel reading it in place took 49 us per 1241 x 376 frame (byte loads, 1.5x halo re-reads over the link), this copy + the
+// blur from HBM take 15.  Rows of `w` bytes, source row stride `stride`, packed destination.
+__global__ __launch_bounds__(256) void ingest_kernel(const uint8_t* __restrict__ src, int w, int h, size_t stride, uint8_t* __restrict__ dst) {
+    if (stride == (size_t)w) {   // one contiguous array: 16-byte chunks from the (16-byte aligned) base
+        const size_t total = (size_t)w * h, i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+        if (i + 16 <= total) *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(src + i);
+        else for (size_t k = i; k < total; k++) dst[k] = src[k];
+        return;
+    }
+    const int chunks = (w + 15) / 16;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= chunks * h) return;
+    const int y = id / chunks, x = (id - y * chunks) * 16;
+    const uint8_t* sp = src + (size_t)y * stride + x;
+    uint8_t* dp = dst + (size_t)y * w + x;
+    if (x + 16 <= w) {
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const u32_unaligned*>(sp + 4 * k);
+#pragma unroll
+        for (int k = 0; k < 4; k++) *reinterpret_cast<u32_unaligned*>(dp + 4 * k) = v[k];
+    } else for (int k = 0; x + k < w; k++) dp[k] = sp[k];
+}
+
 // plain copy of the input into level 0 (doGaussianBlur == false)
 __global__ void copy_kernel(const uint8_t* __restrict__ src, int w, int h, size_t src_stride, size_t src_frame_stride,
                             uint8_t* __restrict__ dst, int dst_pitch, size_t dst_frame_stride) {
@@ -955,6 +980,10 @@ __global__ __launch_bounds__(64) void nonmax_kernel(const Plan plan, uint32_t* _
     if (lane == 0) *cnt = kept;
 }
 
+__device__ __forceinline__ void describe_slot(const Plan& plan, const uint8_t* __restrict__ pyr, size_t frame_stride, const uint32_t* __restrict__ sel,
+                                              size_t sel_frame_stride, const int* __restrict__ lc, KeyPointOut* s_kp,
+                                              unsigned long long* s_desc, int class_id, int frame, int lane, int slot);
+
 // One wave per output keypoint slot; 4 waves per block.
 __global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const uint8_t* __restrict__ pyr,
                                                        size_t frame_stride, const uint32_t* __restrict__ sel,
@@ -965,10 +994,36 @@ __global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const ui
     const int lane = threadIdx.x & 63;
     const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int* lc = level_counts + (size_t)frame * kMaxLevels;
-    int lvl = 0, base = 0, total = 0;
+    int total = 0;
     for (int l = 0; l < plan.nlevels; l++) total += lc[l];
     if (slot == 0 && lane == 0) frame_counts[frame] = total;
-    if (slot >= total || slot >= cap_per_frame) return;
+    // the workgroup's four keypoints are staged in LDS and leave as 16-byte stores: 8 + 7 store instructions per workgroup instead of
+    // 16 eight-byte and 8 struct pieces — what the write path to pinned host memory (one PCIe transaction per request) is bound by
+    __shared__ __attribute__((aligned(16))) unsigned long long s_desc[4][4];
+    __shared__ __attribute__((aligned(16))) KeyPointOut s_kp[4];
+    const int wv = threadIdx.x >> 6;
+    const int limit = total < cap_per_frame ? total : cap_per_frame;
+    if (slot < limit) describe_slot(plan, pyr, frame_stride, sel, sel_frame_stride, lc, &s_kp[wv], s_desc[wv], class_id, frame, lane, slot);
+    __syncthreads();
+    {
+        const int slot0 = blockIdx.x * 4, nvalid = min(max(limit - slot0, 0), 4);
+        const size_t o = (size_t)frame * cap_per_frame + slot0;
+        const int t = threadIdx.x;
+        if (t < 2 * nvalid) reinterpret_cast<uint4*>(desc + o * 32)[t] = reinterpret_cast<const uint4*>(&s_desc[0][0])[t];
+        else if (t >= 64 && t < 64 + 7 * nvalid) {   // (a second wave: the two groups of stores issue side by side)
+            const int i = t - 64;
+            uint32_t* dst = reinterpret_cast<uint32_t*>(kps + o);
+            if (nvalid == 4 && ((o * sizeof(KeyPointOut)) & 15) == 0 && (reinterpret_cast<uintptr_t>(kps) & 15) == 0) {
+                if (i < 7) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(&s_kp[0])[i];
+            } else dst[i] = reinterpret_cast<const uint32_t*>(&s_kp[0])[i];
+        }
+    }
+}
+
+__device__ __forceinline__ void describe_slot(const Plan& plan, const uint8_t* __restrict__ pyr, size_t frame_stride, const uint32_t* __restrict__ sel,
+                                              size_t sel_frame_stride, const int* __restrict__ lc, KeyPointOut* s_kp,
+                                              unsigned long long* s_desc, int class_id, int frame, int lane, int slot) {
+    int lvl = 0, base = 0;
     while (slot >= base + lc[lvl]) { base += lc[lvl]; ++lvl; }
     // the level is wave-uniform (slot is), but the compiler cannot see that: without the readfirstlane it copied the whole by-value Plan
     // to scratch to index it per lane — 120 bytes of scratch per lane, the "37x write amplification" of this kernel in the round-1 counters
@@ -1011,10 +1066,10 @@ __global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const ui
         const int t0 = center[(ptrdiff_t)r0 * L.pitch + c0], t1 = center[(ptrdiff_t)r1 * L.pitch + c1];
         word[j] = __ballot(t0 < t1);
     }
-    const size_t o = (size_t)frame * cap_per_frame + slot;
+    // into the workgroup's staging block: the four keypoints of a workgroup leave together as 16-byte stores (describe_kernel)
     if (lane < 4) {
         const unsigned long long w = lane == 0 ? word[0] : (lane == 1 ? word[1] : (lane == 2 ? word[2] : word[3]));
-        reinterpret_cast<unsigned long long*>(desc + o * 32)[lane] = w;
+        s_desc[lane] = w;
     }
     if (lane == 0) {
         KeyPointOut k;
@@ -1025,7 +1080,7 @@ __global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const ui
         k.response = (float)resp;
         k.octave = lvl;
         k.class_id = class_id;   // -1; 1 when the radius-3 suppression ran (it uses class_id as its flag and leaves it, :1179)
-        kps[o] = k;
+        *s_kp = k;
     }
 }
 
@@ -1084,6 +1139,8 @@ struct uh_orb {
     bool score_valid = false;      // d_score holds the last extraction's strength maps (uh_orb_debug_level computes them on demand)
     // staging for the host-pointer API
     uh::DevBuf d_in, d_kps, d_desc, d_counts;
+    uh::MappedBuf h_out;           // one-frame form: [completion word | count | keypoints | descriptors] when the caller's buffers are not pinned
+    unsigned long long seq = 0;
 };
 
 namespace {
@@ -1521,28 +1578,48 @@ int uh_orb_extract(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, u
     *n_out = 0;
     if (img == nullptr || w <= 0 || h <= 0) return UH_OK;   // ORBextractor.cpp:1254 — empty image: silent return
     UH_REQUIRE(stride >= (size_t)w, "uh_orb_extract: stride < width");
+    UH_REQUIRE(cap >= 0 && (cap == 0 || (kps && desc)), "uh_orb_extract: NULL output buffer");
     const int maxk = std::max(o->fp.maxFeatures, 1);
     int rc;
     UH_HIP_CHECK(hipSetDevice(o->ctx->device));
     hipStream_t st = o->ctx->stream;
-    if ((rc = o->d_in.reserve((size_t)w * h))) return rc;
-    if ((rc = o->d_kps.reserve((size_t)maxk * sizeof(uh_keypoint)))) return rc;
-    if ((rc = o->d_desc.reserve((size_t)maxk * 32))) return rc;
-    if ((rc = o->d_counts.reserve(16))) return rc;
-    UH_HIP_CHECK(hipMemcpy2DAsync(o->d_in.p, w, img, stride, w, h, hipMemcpyHostToDevice, st));
-    rc = run_frames(o, o->d_in.as<uint8_t>(), w, h, w, (size_t)w * h, 1, o->d_kps.as<KeyPointOut>(), o->d_desc.as<uint8_t>(), maxk,
-                    o->d_counts.as<int>());
+    // One frame is latency, not bandwidth: no copy engine and no stream synchronisation on the way.  A frame in pinned memory
+    // (uh_host_alloc / hipHostMalloc / hipHostRegister) is fetched by a kernel with 16-byte loads; keypoints, descriptors and the
+    // count are written by the last kernel into pinned memory — the caller's own buffers if they are pinned, this object's block
+    // otherwise — and a completion word follows them, which the host polls.
+    if ((rc = o->d_in.reserve((size_t)w * h + 16))) return rc;
+    if (const uint8_t* h_img = static_cast<const uint8_t*>(uh::device_alias_of_host(img))) {
+        const int chunks = stride == (size_t)w ? (int)(((size_t)w * h + 15) / 16) : ((w + 15) / 16) * h;
+        UH_LAUNCH(o->ctx, ingest_kernel, dim3(uh_div_up(chunks, 256)), dim3(256), 0, h_img, w, h, stride, o->d_in.as<uint8_t>());
+    } else if (stride == (size_t)w) {   // pageable frame: through the runtime's staging copy
+        UH_HIP_CHECK(hipMemcpyAsync(o->d_in.p, img, (size_t)w * h, hipMemcpyHostToDevice, st));
+    } else {
+        UH_HIP_CHECK(hipMemcpy2DAsync(o->d_in.p, w, img, stride, w, h, hipMemcpyHostToDevice, st));
+    }
+    const uint8_t* d_img = o->d_in.as<uint8_t>();
+    const size_t in_stride = (size_t)w;
+    const int slots = std::min(maxk, std::max(cap, 1));
+    const size_t o_cnt = 64, o_kps = 128, o_desc = o_kps + (((size_t)maxk * sizeof(uh_keypoint) + 63) & ~(size_t)63), total = o_desc + (size_t)maxk * 32;
+    if ((rc = o->h_out.reserve(total))) return rc;
+    char* hb = o->h_out.host<char>();
+    char* db = o->h_out.dev<char>();
+    KeyPointOut* d_kps = cap > 0 ? static_cast<KeyPointOut*>(uh::device_alias_of_host(kps)) : nullptr;
+    uint8_t* d_desc = cap > 0 ? static_cast<uint8_t*>(uh::device_alias_of_host(desc)) : nullptr;
+    const bool direct = d_kps && d_desc;
+    if (!direct) { d_kps = reinterpret_cast<KeyPointOut*>(db + o_kps); d_desc = reinterpret_cast<uint8_t*>(db + o_desc); }
+    rc = run_frames(o, d_img, w, h, in_stride, (size_t)in_stride * h, 1, d_kps, d_desc, direct ? slots : maxk, reinterpret_cast<int*>(db + o_cnt));
     if (rc) return rc;
-    int n = 0;
-    UH_HIP_CHECK(hipMemcpyAsync(&n, o->d_counts.p, 4, hipMemcpyDeviceToHost, st));
-    UH_HIP_CHECK(hipStreamSynchronize(st));
+    // the completion word as its own one-thread launch behind the last kernel (a ticket counter inside describe_kernel — one system-scope
+    // release and one same-address atomic per workgroup — cost 10 us more than this launch)
+    const unsigned long long word = ++o->seq;
+    if ((rc = uh::post_host_word(o->ctx, reinterpret_cast<unsigned long long*>(db), word))) return rc;
+    if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(hb), word, st, "uh_orb_extract"))) return rc;
+    const int n = *reinterpret_cast<const int*>(hb + o_cnt);
     *n_out = n;
     if (n > cap) { uh::set_error("uh_orb_extract: %d keypoints but capacity %d", n, cap); return UH_ECAPACITY; }
-    if (n > 0) {
-        UH_REQUIRE(kps && desc, "uh_orb_extract: NULL output buffer");
-        UH_HIP_CHECK(hipMemcpyAsync(kps, o->d_kps.p, (size_t)n * sizeof(uh_keypoint), hipMemcpyDeviceToHost, st));
-        UH_HIP_CHECK(hipMemcpyAsync(desc, o->d_desc.p, (size_t)n * 32, hipMemcpyDeviceToHost, st));
-        UH_HIP_CHECK(hipStreamSynchronize(st));
+    if (!direct && n > 0) {
+        std::memcpy(kps, hb + o_kps, (size_t)n * sizeof(uh_keypoint));
+        std::memcpy(desc, hb + o_desc, (size_t)n * 32);
     }
     return UH_OK;
 }

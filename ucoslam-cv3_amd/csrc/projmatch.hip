@@ -445,9 +445,17 @@ struct uh_projmatch {
     PmFrame fr{};
     uh::DevBuf d_frame;    // kp_xy | kp_octave | kp_desc | nodes | leaf_idx | scale
     uh::DevBuf d_points;   // pos3d | normal | min | max | desc | best_kp | best_dist | visible | overflow
-    uh::PinBuf h_in, h_out;
+    // pinned, device-visible staging: the frame block (set_frame), the points of a match call, its results + completion word.
+    // Everything moves as 16-byte-wide launches on the context stream (uh::copy16 / publish16); the host never synchronises the stream.
+    uh::MappedBuf h_frame, h_in, h_out;
+    unsigned long long seq = 0, frame_word = 0;   // completion words: of the last match call / of the last frame upload
+    std::vector<float> xy;
+    std::vector<int> oct;
+    std::vector<uh_dmatch> mm;
     KdBuilder kd;
     bool attr_set = false;
+    bool ovf_zeroed = false;
+    unsigned ovf_gen = 0;
 };
 
 extern "C" {
@@ -469,8 +477,10 @@ int uh_projmatch_set_frame(uh_projmatch* h, const uh_proj_frame* f) {
     UH_HIP_CHECK(hipSetDevice(h->ctx->device));
     hipStream_t st = h->ctx->stream;
     const int n = f->n_kpts;
-    std::vector<float> xy(2 * (size_t)std::max(n, 1));
-    std::vector<int> oct(std::max(n, 1));
+    std::vector<float>& xy = h->xy;
+    std::vector<int>& oct = h->oct;
+    xy.resize(2 * (size_t)std::max(n, 1));
+    oct.resize(std::max(n, 1));
     for (int i = 0; i < n; i++) {
         // the kernel packs a candidate's octave into 4 bits and an int8: anything outside [0,16) would silently corrupt bestLevel / bestLevel2
         UH_REQUIRE(f->und_kpts[i].octave >= 0 && f->und_kpts[i].octave < 16, "uh_projmatch_set_frame: octave %d of keypoint %d outside [0,16)", f->und_kpts[i].octave, i);
@@ -487,9 +497,15 @@ int uh_projmatch_set_frame(uh_projmatch* h, const uh_proj_frame* f) {
     int rc = h->d_frame.reserve(total + 256);
     if (rc) return rc;
     char* base = h->d_frame.as<char>();
-    {   // one pinned staging block, one H2D copy
-        if ((rc = h->h_in.reserve(total))) return rc;
-        char* hi = static_cast<char*>(h->h_in.p);
+    {   // one pinned staging block, one 16-byte-wide copy launch, no synchronisation: the block is only reused by the NEXT set_frame,
+        // which first makes sure this upload has landed (its completion word — long since posted unless two set_frame calls follow
+        // each other with nothing in between)
+        if (h->frame_word) {
+            if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(h->h_frame.host<char>()), h->frame_word, st, "uh_projmatch_set_frame"))) return rc;
+            h->frame_word = 0;
+        }
+        if ((rc = h->h_frame.reserve(total + 64))) return rc;
+        char* hi = h->h_frame.host<char>() + 64;   // (the first 64 bytes hold the completion word)
         if (n) {
             std::memcpy(hi + o_xy, xy.data(), 8 * (size_t)n);
             std::memcpy(hi + o_oct, oct.data(), 4 * (size_t)n);
@@ -498,8 +514,10 @@ int uh_projmatch_set_frame(uh_projmatch* h, const uh_proj_frame* f) {
             std::memcpy(hi + o_leaf, h->kd.leaf_idx.data(), 4 * (size_t)n);
         }
         std::memcpy(hi + o_scale, f->scale_factors, 4 * (size_t)f->n_levels);
-        UH_HIP_CHECK(hipMemcpyAsync(base, hi, total, hipMemcpyHostToDevice, st));
-        UH_HIP_CHECK(hipStreamSynchronize(st));   // the staging block is reused by match()
+        std::atomic_thread_fence(std::memory_order_release);
+        if ((rc = uh::copy16(h->ctx, base, h->h_frame.dev<char>() + 64, total))) return rc;
+        h->frame_word = ++h->seq;
+        if ((rc = uh::post_host_word(h->ctx, h->h_frame.dev<unsigned long long>(), h->frame_word))) return rc;
     }
     if (getenv("UH_PM_TIMING")) fprintf(stderr, "set_frame total: %.1f us (bytes %zu)\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), total);
     PmFrame& d = h->fr;
@@ -553,17 +571,21 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
     UH_HIP_CHECK(hipSetDevice(h->ctx->device));
     hipStream_t st = h->ctx->stream;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t o_pos = 0, o_nrm = al(o_pos + 12 * (size_t)n), o_min = al(o_nrm + 12 * (size_t)n), o_max = al(o_min + 4 * (size_t)n);
+    const size_t o_pos = 256 /* [0, 256): the walk-overflow status word, at a fixed place */, o_nrm = al(o_pos + 12 * (size_t)n), o_min = al(o_nrm + 12 * (size_t)n), o_max = al(o_min + 4 * (size_t)n);
     const size_t o_desc = al(o_max + 4 * (size_t)n), o_bk = al(o_desc + 32 * (size_t)n), o_bd = o_bk + 4 * (size_t)n, o_vis = o_bd + 4 * (size_t)n;
-    const size_t o_ovf = al(o_vis + (size_t)n), total = o_ovf + 256;
+    const size_t o_ovf = 0, o_end = al(o_vis + (size_t)n), total = o_end + 256;
     int rc = h->d_points.reserve(total);
     if (rc) return rc;
-    const size_t out_bytes = o_ovf + 64 - o_bk;
-    if ((rc = h->h_out.reserve(out_bytes))) return rc;
+    const size_t out_bytes = o_end - o_bk;
+    if ((rc = h->h_out.reserve(out_bytes + 64))) return rc;
     char* base = h->d_points.as<char>();
-    {   // one pinned staging block, one H2D copy (five pageable copies cost more than the kernel)
+    if (!h->ovf_zeroed || h->ovf_gen != h->d_points.gen) {   // the walk-overflow word: zero once per allocation, publish16 clears it after every call
+        UH_HIP_CHECK(hipMemsetAsync(base, 0, 256, st));
+        h->ovf_zeroed = true; h->ovf_gen = h->d_points.gen;
+    }
+    {   // one pinned staging block (the previous call's launches are complete: its results were awaited), one wide copy launch
         if ((rc = h->h_in.reserve(o_bk))) return rc;
-        char* hi = static_cast<char*>(h->h_in.p);
+        char* hi = h->h_in.host<char>();
         std::memcpy(hi + o_pos, mp->pos3d, 12 * (size_t)n);
         if (prev) std::memcpy(hi + o_min, octave, 4 * (size_t)n);   // the octaves travel in the min_dist slot
         else {
@@ -572,9 +594,9 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
             std::memcpy(hi + o_max, mp->max_dist, 4 * (size_t)n);
         }
         std::memcpy(hi + o_desc, mp->desc, 32 * (size_t)n);
-        UH_HIP_CHECK(hipMemcpyAsync(base, hi, o_desc + 32 * (size_t)n, hipMemcpyHostToDevice, st));
+        std::atomic_thread_fence(std::memory_order_release);
+        if ((rc = uh::copy16(h->ctx, base + o_pos, h->h_in.dev<char>() + o_pos, o_desc + 32 * (size_t)n - o_pos))) return rc;
     }
-    UH_HIP_CHECK(hipMemsetAsync(base + o_ovf, 0, 64, st));
     PmPoints P;
     P.n = n;
     P.pos3d = (const float*)(base + o_pos); P.normal = (const float*)(base + o_nrm); P.min_dist = (const float*)(base + o_min);
@@ -612,18 +634,21 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
         else UH_LAUNCH(h->ctx, (projmatch_kernel<false, true>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf);
     }
     UH_HIP_CHECK(hipGetLastError());
-    char* ho = static_cast<char*>(h->h_out.p);
-    UH_HIP_CHECK(hipMemcpyAsync(ho, base + o_bk, out_bytes, hipMemcpyDeviceToHost, st));
-    UH_HIP_CHECK(hipStreamSynchronize(st));
+    // results: one workgroup copies [best_kp | best_dist | visible | overflow] into pinned memory and posts the completion word
+    const unsigned long long word = ++h->seq;
+    if ((rc = uh::publish16(h->ctx, h->h_out.dev<char>() + 64, base + o_bk, out_bytes, reinterpret_cast<unsigned*>(base + o_ovf), h->h_out.dev<unsigned long long>(), word))) return rc;
+    if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(h->h_out.host<char>()), word, st, "uh_projmatch_match"))) return rc;
+    const char* ho = h->h_out.host<char>() + 64;
     const int* bk = (const int*)ho;
     const float* bd = (const float*)(ho + (o_bd - o_bk));
     const unsigned char* vis = (const unsigned char*)(ho + (o_vis - o_bk));
-    const int ovf = *(const int*)(ho + (o_ovf - o_bk));
+    const int ovf = *reinterpret_cast<const int*>(h->h_out.host<char>() + 8);
     UH_REQUIRE(!ovf, "uh_projmatch_match: kd-tree walk stack overflow");
     if (best_kp_out) std::memcpy(best_kp_out, bk, 4 * (size_t)n);
     if (best_dist_out) std::memcpy(best_dist_out, bd, 4 * (size_t)n);
     if (visible_out) std::memcpy(visible_out, vis, (size_t)n);
-    std::vector<uh_dmatch> mm;
+    std::vector<uh_dmatch>& mm = h->mm;
+    mm.clear();
     mm.reserve(n);
     for (int i = 0; i < n; i++)
         if (bk[i] >= 0) mm.push_back(uh_dmatch{bk[i], (int32_t)mp->ids[i], -1, bd[i]});
