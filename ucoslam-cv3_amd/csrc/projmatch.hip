@@ -72,7 +72,9 @@ public:
         leaf_idx.clear();
         leaf_idx.reserve(n);
         order_.resize(n);
-        for (int i = 0; i < n; i++) order_[i] = (uint32_t)i;
+        px_.resize(n); py_.resize(n);
+        tmp_l_.resize(n + 1); tmp_r_.resize(n + 1);
+        for (int i = 0; i < n; i++) { order_[i] = (uint32_t)i; px_[i] = xy[2 * (size_t)i]; py_[i] = xy[2 * (size_t)i + 1]; }
         max_depth = 0;
         if (n == 0) return;
         Box root;
@@ -86,17 +88,21 @@ public:
 private:
     struct Box { double lo[2], hi[2]; };
     const float* xy_ = nullptr;
+    // the index permutation the reference partitions in place, with the points' coordinates carried along in the same order: every
+    // scan below reads contiguous floats instead of gathering through the permutation
     std::vector<uint32_t> order_;
-    float coord(uint32_t i, int d) const { return xy_[2 * (size_t)i + d]; }
+    std::vector<float> px_, py_;
+    std::vector<int> tmp_l_, tmp_r_;
+    float* coords(int d) { return d == 0 ? px_.data() : py_.data(); }
 
     void bounds(int b, int e, Box& box) const {
-        for (int d = 0; d < 2; d++) box.lo[d] = box.hi[d] = coord(order_[b], d);
-        for (int k = b + 1; k < e; k++)
-            for (int d = 0; d < 2; d++) {
-                const float v = coord(order_[k], d);
-                if (v < box.lo[d]) box.lo[d] = v;
-                if (v > box.hi[d]) box.hi[d] = v;
-            }
+        float lx = px_[b], hx = px_[b], ly = py_[b], hy = py_[b];
+        for (int k = b + 1; k < e; k++) {
+            const float x = px_[k], y = py_[k];
+            lx = x < lx ? x : lx; hx = x > hx ? x : hx;
+            ly = y < ly ? y : ly; hy = y > hy ? y : hy;
+        }
+        box.lo[0] = lx; box.hi[0] = hx; box.lo[1] = ly; box.hi[1] = hy;
     }
 
     // picoflann.h:362-391: mean / variance over at most ~100 evenly spaced samples (float squares, double sums)
@@ -104,12 +110,11 @@ private:
         double s1[2] = {0, 0}, s2[2] = {0, 0};
         int step = 1, cnt = 0;
         if (e - b >= 200) step = (e - b) / 100;
-        for (int i = b; i < e; i += step, cnt++)
-            for (int d = 0; d < 2; d++) {
-                const float v = coord(order_[i], d);
-                s1[d] += v;
-                s2[d] += v * v;
-            }
+        for (int i = b; i < e; i += step, cnt++) {
+            const float x = px_[i], y = py_[i];
+            s1[0] += x; s2[0] += x * x;
+            s1[1] += y; s2[1] += y * y;
+        }
         const double inv = 1. / double(cnt);
         for (int d = 0; d < 2; d++) {
             mean[d] = s1[d] * inv;
@@ -117,24 +122,27 @@ private:
         }
     }
 
-    // picoflann.h:403-424: two Hoare passes -> [< cut | == cut | > cut]
-    void three_way(uint32_t* ind, int count, int dim, float cut, int& lim1, int& lim2) const {
-        int l = 0, r = count - 1;
-        for (;;) {
-            while (l <= r && coord(ind[l], dim) < cut) ++l;
-            while (l <= r && coord(ind[r], dim) >= cut) --r;
-            if (l > r) break;
-            std::swap(ind[l], ind[r]); ++l; --r;
-        }
-        lim1 = l;
-        r = count - 1;
-        for (;;) {
-            while (l <= r && coord(ind[l], dim) <= cut) ++l;
-            while (l <= r && coord(ind[r], dim) > cut) --r;
-            if (l > r) break;
-            std::swap(ind[l], ind[r]); ++l; --r;
-        }
-        lim2 = l;
+    void swap_items(int i, int j) {
+        std::swap(order_[i], order_[j]); std::swap(px_[i], px_[j]); std::swap(py_[i], py_[j]);
+    }
+
+    // One Hoare pass of picoflann.h:403-424 over [b, e) with the predicate "belongs left" = (v < cut) or (v <= cut): the reference
+    // walks l up to the first element that belongs right, r down to the last that belongs left, swaps them and repeats until the
+    // two meet.  That is: with m = the number of elements that belong left, the misplaced elements in front of b + m (ascending)
+    // are exchanged pairwise with the misplaced elements from b + m on (descending) — the same permutation, obtained here with a
+    // count and two branch-free compactions instead of two data-dependent scans (the scans mispredict on every other element).
+    template <bool INCLUSIVE>
+    int hoare_pass(int b, int e, const float* v, float cut) {
+        int m = 0;
+        for (int i = b; i < e; i++) m += INCLUSIVE ? (v[i] <= cut) : (v[i] < cut);
+        const int mid = b + m;
+        int* L = tmp_l_.data();
+        int* R = tmp_r_.data();
+        int nl = 0, nr = 0;
+        for (int i = b; i < mid; i++) { L[nl] = i; nl += INCLUSIVE ? !(v[i] <= cut) : !(v[i] < cut); }
+        for (int j = e - 1; j >= mid; j--) { R[nr] = j; nr += INCLUSIVE ? (v[j] <= cut) : (v[j] < cut); }
+        for (int k = 0; k < nl; k++) swap_items(L[k], R[k]);   // (nl == nr)
+        return mid;
     }
 
     // picoflann.h:238-345.  `box` is in/out: on return it is the tight box of the subtree.
@@ -155,16 +163,20 @@ private:
         sample_moments(b, e, mean, var);
         const int dim = var[1] > var[0] ? 1 : 0;
         double cut = mean[dim];
-        int lim1, lim2;
-        three_way(&order_[b], count, dim, (float)cut, lim1, lim2);
+        // picoflann.h:403-424: two Hoare passes -> [< cut | == cut | > cut]
+        const int lim1 = hoare_pass<false>(b, e, coords(dim), (float)cut) - b;
+        const int lim2 = hoare_pass<true>(b + lim1, e, coords(dim), (float)cut) - b;
         int at = count / 2;
         if (lim1 > count / 2) at = lim1;
         else if (lim2 < count / 2) at = lim2;
         if (lim1 == count || lim2 == 0) at = count / 2;
         if (at < kLeafMax || count - at < kLeafMax) {
-            std::sort(order_.begin() + b, order_.begin() + e, [&](const uint32_t& p, const uint32_t& q) { return coord(p, dim) < coord(q, dim); });
+            // std::sort exactly where the reference uses it (same libstdc++ => same permutation of equal keys)
+            const float* xy = xy_;
+            std::sort(order_.begin() + b, order_.begin() + e, [xy, dim](const uint32_t& p, const uint32_t& q) { return xy[2 * (size_t)p + dim] < xy[2 * (size_t)q + dim]; });
+            for (int i = b; i < e; i++) { px_[i] = xy[2 * (size_t)order_[i]]; py_[i] = xy[2 * (size_t)order_[i] + 1]; }
             at = count / 2;
-            cut = coord(order_[b + at], dim);
+            cut = coords(dim)[b + at];
         }
         Box lbox = box, rbox = box;
         lbox.hi[dim] = cut;
