@@ -294,6 +294,43 @@ def main():
         except Exception as e_:   # (a side measurement: never fails the bench)
             stage_ms["cpp_host_step_ms"] = None
             print("cpp host stage skipped:", repr(e_), file=sys.stderr)
+        # The reference tracker's real per-frame chain, ONE frame at a time, host buffers in and out of every call (examples/tracker_frame.cpp,
+        # a C++ host over the C ABI): uh_orb_extract -> uh_projmatch_set_frame -> uh_projmatch_match_prev -> uh_pnp_solve -> uh_projmatch_match
+        # -> uh_pnp_solve (frameextractor.cpp:430-520, frame.h:124, system.cpp:5930-6460 / :6559-6626, pnpsolver.cpp:116-409, map.cpp:651-770,
+        # system.cpp:6897-6954).  Not part of the metric (ORB + match + local BA); it is what a drop-in under process() pays per frame.
+        tracker = None
+        try:
+            if shutil.which("g++"):
+                exe = os.path.join(tempfile.mkdtemp(prefix="uh_trk_"), "tracker_frame")
+                subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(ROOT, "examples", "tracker_frame.cpp"), "-L", libdir, "-lucoslam_hip",
+                                       f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                torch.cuda.synchronize()
+                tracker = json.loads(subprocess.run([exe, "300", "30"], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
+                stage_ms["tracker_frame_ms"] = tracker["tracker_frame_ms"]
+                stage_ms["tracker_frames_per_s"] = tracker["tracker_frames_per_s"]
+        except Exception as e_:
+            print("tracker chain stage skipped:", repr(e_), file=sys.stderr)
+        # single-frame latency, host in / host out, batch 1 (what a sequential caller sees): ORB of one pinned frame into pinned arrays, the
+        # exact match of its 2000 descriptors against the 10 000-row map from / to host arrays, and the two in sequence
+        single = None
+        try:
+            one_img = frames_host[0].numpy()
+            s_k = torch.zeros(MAX_FEATURES * 28, dtype=torch.uint8).pin_memory()
+            s_d = torch.zeros((MAX_FEATURES, 32), dtype=torch.uint8).pin_memory()
+            s_i = torch.zeros((NQ, NN), dtype=torch.int32).pin_memory()
+            s_dd = torch.zeros((NQ, NN), dtype=torch.int32).pin_memory()
+            n_c = C.c_int(0)
+            ext1 = ORBextractor.create(ctx)
+            check(L.uh_orb_set_params(ext1._h, C.byref(fp)))
+            orb1 = lambda: check(L.uh_orb_extract(ext1._h, C.c_void_p(one_img.ctypes.data), W, H, W, C.c_void_p(s_k.data_ptr()), C.c_void_p(s_d.data_ptr()), MAX_FEATURES, C.byref(n_c)))
+            knn1 = lambda: check(L.uh_knn_search(index._h, C.c_void_p(s_d.data_ptr()), NQ, 32, NN, C.c_void_p(s_i.data_ptr()), C.c_void_p(s_dd.data_ptr()), 0, -1))
+            for _ in range(3):
+                orb1(); knn1()
+            single = {"orb_extract_ms": round(timed(orb1, 50), 4), "knn_search_ms": round(timed(knn1, 50), 4)}
+            single["orb_plus_match_ms"] = round(timed(lambda: (orb1(), knn1()), 50), 4)
+            single["note"] = "one 1241x376 frame / its 2000 x 10000 nn=10 search per call, pinned host buffers in and out, no batching"
+        except Exception as e_:
+            print("single-frame stage skipped:", repr(e_), file=sys.stderr)
         # the second frame size north_star asks for: the same step (4 frames, one kNN launch, one local BA) on 640x480 frames
         fr2 = torch.from_numpy(np.stack([synth.frame(640, 480, seed=77 + f, shift=(2 * f, f)) for f in range(F)])).to(dev)
         ext2 = ORBextractor.create(ctx)
@@ -423,17 +460,22 @@ def main():
             trials_est = int(round(lm_iters)) + 2
             if name == "ba_persist_kernel":
                 impl, g_wg = persistent_ba_exchange_bytes(ba_pr["P"], trials_est)
-            try:   # HBM bytes per launch from the committed PMC passes (profiles/, scripts/collect_profiles.sh): FETCH_SIZE + WRITE_SIZE
-                pmc_file = next(f_ for f_ in (os.path.join(ROOT, "profiles", n_) for n_ in ("r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(f_))
-                pmc = json.load(open(pmc_file))["kernels"].get(name)
+            # HBM bytes per launch from the committed PMC passes (profiles/, scripts/collect_profiles*.sh; separate FETCH_SIZE / WRITE_SIZE passes of
+            # `bench.py --quick`): NOT measured in this run.  Corrected as the guide prescribes for gfx950: FETCH_SIZE counts wide reads once -> x2.
+            pmc_all, pmc_src = {}, None
+            try:
+                pmc_file = next(f_ for f_ in (os.path.join(ROOT, "profiles", n_) for n_ in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(f_))
+                pmc_all = json.load(open(pmc_file))["kernels"]
+                pmc_src = "profiles/" + os.path.basename(pmc_file) + " (fetch_bytes_x2 + write_bytes per launch; separate rocprofv3 --pmc passes of `bench.py --quick`, not measured in this run)"
+                pmc = pmc_all.get(name)
                 if pmc:
-                    traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
+                    traffic = pmc.get("fetch_bytes_x2", 2 * pmc["fetch_bytes"]) + pmc["write_bytes"]
             except Exception:
                 traffic = None
             step_bytes = unit_bytes["orb"] + unit_bytes["match"] + unit_bytes["ba"]
             roofline = {
                 "bound": "hbm", "kernel": name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": pmc_src,
                 "traffic_ratio": round(traffic / alg, 2) if traffic else None,
                 "avg_launch_us": round(avg_ms * 1e3, 3), "algorithmic_bytes_per_launch": int(alg), "units_per_launch": units,
                 "impl_bytes_per_launch": impl,
@@ -445,6 +487,32 @@ def main():
                 "stage_gpu_ms_per_step": {k: round(v, 4) for k, v in unit_ms.items()},
                 "kernels_us": {k: round(1e3 * v[1] / max(v[0], 1), 2) for k, v in sorted(short.items())},
             }
+            # the other stages with THEIR bounds stated: the exact matcher is integer-ALU work (XOR + popcount + heap test per (query, train)
+            # pair), the extractor's kernels stream the pyramid
+            others = {}
+            knn_name = max((k for k in short if k in MATCH_KERNELS), key=lambda k: short[k][1], default=None)
+            if knn_name:
+                kc, kt = short[knn_name]
+                k_ms = kt / max(kc, 1)
+                pairs = F * NQ * NT
+                ops_per_pair = 16                                       # 4 x (v_xor + v_bcnt accumulate) on 64-bit halves + compare / ballot / index bookkeeping
+                valu_peak = 256 * 4 * 32 * 2.4e9                        # lane-ops/s: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md)
+                kp_ = pmc_all.get(knn_name)
+                others[knn_name] = {
+                    "avg_launch_us": round(k_ms * 1e3, 2),
+                    "valu": {"bound": "valu", "achieved": round(pairs * ops_per_pair / (k_ms * 1e-3) / 1e12, 3), "peak": round(valu_peak / 1e12, 2), "unit": "T lane-ops/s",
+                             "frac": round(pairs * ops_per_pair / (k_ms * 1e-3) / valu_peak, 4), "units_per_launch": f"{pairs} (query, train) pairs x ~{ops_per_pair} VALU lane-ops"},
+                    "hbm": {"bound": "hbm", "achieved": round(unit_bytes["match"] / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(unit_bytes["match"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": int(unit_bytes["match"]),
+                            "traffic": (kp_.get("fetch_bytes_x2", 2 * kp_["fetch_bytes"]) + kp_["write_bytes"]) if kp_ else None},
+                }
+            if unit_ms["orb"] > 0:
+                orb_traffic = sum((pmc_all[k].get("fetch_bytes_x2", 2 * pmc_all[k]["fetch_bytes"]) + pmc_all[k]["write_bytes"]) * (short[k][0] / reps) for k in short if k in ORB_KERNELS and k in pmc_all)
+                others["orb_kernels"] = {"bound": "hbm", "achieved": round(unit_bytes["orb"] / (unit_ms["orb"] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": round(unit_bytes["orb"] / (unit_ms["orb"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "gpu_ms_per_step": round(unit_ms["orb"], 4),
+                                         "algorithmic_bytes_per_step": int(unit_bytes["orb"]), "traffic_per_step": int(orb_traffic) if orb_traffic else None,
+                                         "note": f"{F} frames per step; launch-latency bound at this size (8-9 dependent launches of a few microseconds each)"}
+            roofline["others"] = others
         # the metric's serial definition (1 / (t_ORB + t_match + t_BA amortised)) beside the overlapped headline
         t_serial = stage_ms["orb_ms_per_frame"] + stage_ms["match_ms_per_frame"] + stage_ms["h2d_d2h_ms_per_frame"] + stage_ms["ba_protocol_ms_per_keyframe"] / F
         stage_ms["serial_frames_per_s"] = 1e3 / t_serial
@@ -545,6 +613,14 @@ def main():
         # independent single-threaded searches side by side
         m_1 = 1e3 / threaded_rate(1, 8, match_fn)
         m_all = 1e3 / threaded_rate(ncores, 3, match_fn)
+        # the matcher the reference's FrameMatcher_Flann actually runs (framematcher.cpp:213,239): a hierarchical k-means index built per
+        # train frame (k = 32, maxIters = 0) and searched with nn = 10, maxChecks = 16 — build + search, real xflann
+        hk_ms = None
+        if xf is not None:
+            t_ = time.perf_counter()
+            for _ in range(3):
+                oracle_lib.ref_hkmeans_search(xf, map_desc_np, q, NN, 32, 0, 16, 0)
+            hk_ms = 1e3 * (time.perf_counter() - t_) / 3
         g2o = oracle_lib.load_ref("g2o")
         n_ba = 4
         t = time.perf_counter()
@@ -563,6 +639,7 @@ def main():
             "value_all_cores": round(1e3 / t_all, 4), "value_one_core": round(1e3 / (1e3 / orb_1 + m_1 + ba_ms / F), 4),
             "orb_frames_per_s": {"1_thread": round(orb_1, 2), "2_threads": round(orb_2, 2), f"{ncores}_threads": round(orb_all, 2)},
             "match_ms_2000x10000_nn10": {"1_thread": round(m_1, 2), f"{ncores}_threads_throughput": round(m_all, 2)},
+            "match_hkmeans32_checks16_build_plus_search_ms_1_thread": round(hk_ms, 2) if hk_ms is not None else None,
             "ba_ms_per_keyframe_1_thread": round(ba_ms, 2),
             "sample": (f"ORB = this repo's oracle port (OpenCV absent: the reference extractor cannot be built), 8/12/{3 * ncores} frames at 1/2/{ncores} threads "
                        f"(whole frames per thread: an upper bound for the reference's level-parallel nthreads); matcher = "
@@ -570,6 +647,29 @@ def main():
                        f"BA = {'real g2o (oracle/_ref)' if g2o is not None else 'oracle port'}, {n_ba} local BAs, single-threaded like g2o; "
                        f"value = 1/(t_ORB(2 threads) + t_match(1 thread) + t_BA/{F}), the reference's default threading"),
         }
+
+    # CPU leg of the tracker's per-frame chain (rank 0, N=1): the same stages on the host cores, one thread — oracle ORB ("port"), this repo's
+    # restated projection matchers over the restated picoflann ("port"; both pinned to the real picoflann / real g2o where DESIGN.md says so),
+    # PnP through the REAL g2o (oracle/_ref, "reference")
+    if rank == 0 and cpu is not None:
+        try:
+            pfr_, pmp_, ppose_ = synth.proj_problem(2000, 3000, 0)
+            prev_ = {k_: v_[:800] for k_, v_ in pmp_.items()}
+            t_ = time.perf_counter(); oracle_lib.proj_match_prev(O, pfr_, prev_, ppose_, 75.0, 15.0); t_prev = 1e3 * (time.perf_counter() - t_)
+            t_ = time.perf_counter(); oracle_lib.proj_match(O, pfr_, pmp_, ppose_, 100.0, 15.0); t_map = 1e3 * (time.perf_counter() - t_)
+            pn1, pn2 = synth.pnp_problem(800, seed=3), synth.pnp_problem(1300, seed=4)
+            solver = (lambda pr_: oracle_lib.pnp_solve_ref(g2o, pr_)) if g2o is not None else (lambda pr_: oracle_lib.pnp_solve(O, pr_))
+            t_ = time.perf_counter(); solver(pn1); t_p1 = 1e3 * (time.perf_counter() - t_)
+            t_ = time.perf_counter(); solver(pn2); t_p2 = 1e3 * (time.perf_counter() - t_)
+            t_orb = 1e3 / orb_1
+            cpu["tracker_chain"] = {
+                "frame_ms": round(t_orb + t_prev + t_p1 + t_map + t_p2, 3), "frames_per_s": round(1e3 / (t_orb + t_prev + t_p1 + t_map + t_p2), 2), "cores": 1,
+                "orb_ms": round(t_orb, 3), "match_prev_800_ms_incl_kdtree": round(t_prev, 3), "pnp_800_ms": round(t_p1, 3), "match_map_3000_ms_incl_kdtree": round(t_map, 3),
+                "pnp_1300_ms": round(t_p2, 3),
+                "kind": {"orb": "port", "projection matchers": "port", "pnp": "reference" if g2o is not None else "port"},
+                "sample": "one call per stage on synthetic inputs of the tracker_frame example's sizes (2000 keypoints, 800 previous-frame items, 3000 map points, 800 / 1300 matches)"}
+        except Exception as e_:
+            print("cpu tracker leg skipped:", repr(e_), file=sys.stderr)
 
     if rank == 0:
         line = {
@@ -586,6 +686,7 @@ def main():
                        + (f"; stages.sharded_* = ONE stream over {world} GPUs, levels + train tiles sharded, one RCCL all-gather per frame)" if world > 1 else ")")},
             "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in stage_ms.items()}, "keypoints_per_frame": int(counts.min()), "full_budget": full_frames,
             "ba_lm_iterations": ba_iters if rank == 0 else None,
+            "tracker_chain": tracker, "single_frame_latency": single,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if cpu:

@@ -325,3 +325,32 @@ def test_hip_knn_stream_form_overflow_then_regrown_lists(hip_ctx, oracle, monkey
     ri, rd = oracle_lib.knn_search(oracle, train, q_big, 10, 0)
     np.testing.assert_array_equal(idx, ri)
     np.testing.assert_array_equal(dist, rd)
+
+
+@pytest.mark.gpu
+def test_hip_knn_host_api_with_pinned_buffers(hip_ctx, oracle):
+    """uh_knn_search with queries and result rows in pinned host memory (16-byte-wide copy launches + a polled completion word instead of
+    copy-engine transfers and a stream synchronisation) returns the oracle's rows, also when only one side is pinned."""
+    import ctypes as C
+
+    import torch
+
+    from ucoslam_cv3_amd._lib import check, lib, np_ptr
+    from ucoslam_cv3_amd.knn import Index
+
+    train, q = synth.match_set(2000, 10000, seed=21)
+    index = Index(hip_ctx).build(torch.from_numpy(train).cuda())
+    for nn, s in [(10, 0), (2, 1), (3, 0)]:     # (3: the row block is not a multiple of 16 bytes for odd query counts -> runtime copies)
+        nq = 2000 if nn != 3 else 1999
+        ref_i, ref_d = oracle_lib.knn_search(oracle, train, q[:nq], nn, s)
+        pq = torch.from_numpy(q[:nq].copy()).pin_memory()
+        pi = torch.zeros((nq, nn), dtype=torch.int32).pin_memory()
+        pd = torch.zeros((nq, nn), dtype=torch.int32).pin_memory()
+        for _ in range(2):
+            check(lib().uh_knn_search(index._h, C.c_void_p(pq.data_ptr()), nq, 32, nn, C.c_void_p(pi.data_ptr()), C.c_void_p(pd.data_ptr()), s, -1))
+        np.testing.assert_array_equal(pi.numpy(), ref_i)
+        np.testing.assert_array_equal(pd.numpy(), ref_d)
+        i2 = np.zeros((nq, nn), np.int32); d2 = np.zeros((nq, nn), np.int32)
+        check(lib().uh_knn_search(index._h, C.c_void_p(pq.data_ptr()), nq, 32, nn, np_ptr(i2), np_ptr(d2), s, -1))   # pinned in, pageable out
+        np.testing.assert_array_equal(i2, ref_i)
+        np.testing.assert_array_equal(d2, ref_d)

@@ -1174,6 +1174,8 @@ struct uh_knn {
     unsigned stream_gen = 0;            // ... and its allocation generation (hipFree + hipMalloc may hand back the same base address)
     uh::DevBuf list_buf;          // accept lists, counts and redo flags of the two-phase search
     uh::DevBuf q_buf, idx_buf, dist_buf;  // staging for the host-pointer API
+    uh::MappedBuf h_word;                 // completion word of a host-pointer search with pinned buffers
+    unsigned long long host_seq = 0;
     // hierarchical k-means form of the same index (uh_knn_build_kmeans)
     std::vector<uint8_t> km_blob;
     uh::DevBuf km_dev;
@@ -1396,12 +1398,30 @@ int uh_knn_search(uh_knn* idx, const uint8_t* queries, int nq, size_t q_stride, 
     if ((rc = idx->q_buf.reserve((size_t)nq * 32))) return rc;
     if ((rc = idx->idx_buf.reserve((size_t)nq * nn * 4))) return rc;
     if ((rc = idx->dist_buf.reserve((size_t)nq * nn * 4))) return rc;
-    UH_HIP_CHECK(hipMemcpy2DAsync(idx->q_buf.p, 32, queries, q_stride, 32, (size_t)nq, hipMemcpyHostToDevice, st));
+    // Pinned buffers (uh_host_alloc / hipHostMalloc / hipHostRegister) move as 16-byte-wide launches on the context stream and the host
+    // polls a completion word: one frame's search is latency, and a copy-engine transfer + stream synchronisation on each side costs
+    // more than the search.  Pageable buffers go through the runtime's copies (contiguous rows as ONE copy: a "2-D" copy of 2000 rows
+    // of 32 bytes is issued row by row).
+    const size_t out_bytes = (size_t)nq * nn * 4;
+    const uint8_t* pq = q_stride == 32 ? static_cast<const uint8_t*>(uh::device_alias_of_host(queries)) : nullptr;
+    if (pq && (reinterpret_cast<uintptr_t>(pq) & 15) == 0) { if ((rc = uh::copy16(idx->ctx, idx->q_buf.p, pq, (size_t)nq * 32))) return rc; }
+    else if (q_stride == 32) UH_HIP_CHECK(hipMemcpyAsync(idx->q_buf.p, queries, (size_t)nq * 32, hipMemcpyHostToDevice, st));
+    else UH_HIP_CHECK(hipMemcpy2DAsync(idx->q_buf.p, 32, queries, q_stride, 32, (size_t)nq, hipMemcpyHostToDevice, st));
     rc = uh_knn_search_dev(idx, idx->q_buf.as<uint8_t>(), nq, nn, idx->idx_buf.as<int32_t>(),
                            idx->dist_buf.as<int32_t>(), sorted, max_dist);
     if (rc) return rc;
-    UH_HIP_CHECK(hipMemcpyAsync(indices, idx->idx_buf.p, (size_t)nq * nn * 4, hipMemcpyDeviceToHost, st));
-    UH_HIP_CHECK(hipMemcpyAsync(distances, idx->dist_buf.p, (size_t)nq * nn * 4, hipMemcpyDeviceToHost, st));
+    int32_t* pi = static_cast<int32_t*>(uh::device_alias_of_host(indices));
+    int32_t* pd = pi ? static_cast<int32_t*>(uh::device_alias_of_host(distances)) : nullptr;
+    if (pi && pd && (out_bytes & 15) == 0 && ((reinterpret_cast<uintptr_t>(pi) | reinterpret_cast<uintptr_t>(pd)) & 15) == 0) {
+        if ((rc = idx->h_word.reserve(64))) return rc;
+        if ((rc = uh::copy16(idx->ctx, pi, idx->idx_buf.p, out_bytes))) return rc;
+        if ((rc = uh::copy16(idx->ctx, pd, idx->dist_buf.p, out_bytes))) return rc;
+        const unsigned long long word = ++idx->host_seq;
+        if ((rc = uh::post_host_word(idx->ctx, idx->h_word.dev<unsigned long long>(), word))) return rc;
+        return uh::wait_host_word(idx->h_word.host<volatile unsigned long long>(), word, st, "uh_knn_search");
+    }
+    UH_HIP_CHECK(hipMemcpyAsync(indices, idx->idx_buf.p, out_bytes, hipMemcpyDeviceToHost, st));
+    UH_HIP_CHECK(hipMemcpyAsync(distances, idx->dist_buf.p, out_bytes, hipMemcpyDeviceToHost, st));
     UH_HIP_CHECK(hipStreamSynchronize(st));
     return UH_OK;
 }
