@@ -205,6 +205,61 @@ int  uh_frame_extractor_to_stream(const uh_orb* orb, const char* str_params, con
 int  uh_frame_extractor_from_stream(uh_orb* orb, const uint8_t* data, uint64_t nbytes, int allow_markers, uh_frame_extractor_state* state,
                                     char* str_params_out, uint64_t str_cap, uint64_t* aruco_off, uint64_t* aruco_bytes, uint64_t* params_off,
                                     uint64_t* params_bytes, uint64_t* consumed);
+/* ucoslam::Params as a stream carries it (src/ucoslamtypes.cpp:63-121 toStream, :123-180 fromStream: u64 9837138769928 ... u64 1837138769921):
+ * the members the hot path and its host glue are driven by, parsed; the ArUco members are walked over.  Errors carry the reference's
+ * messages ("Invalid signature", "Reached EOF without finding end signature"). */
+typedef struct uh_params_view {
+    uint8_t detect_markers, detect_keypoints, kp_non_maxima_suppression, force_initialization_from_markers, remove_keypoints_into_markers,
+            run_sequential, auto_adjust_kp_sensitivity, relocalization_with_keypoints, relocalization_with_markers;
+    int8_t  kp_descriptor_type;             /* DescriptorTypes::Type (int8): 1 = DESC_ORB */
+    float   target_focus, kf_min_confidence, max_desc_distance, baseline_median_depth_ratio_min, aruco_marker_size, kf_culling, th_ref_ratio,
+            scale_factor, min_base_line, kpt_image_scale_factor;
+    int32_t max_new_points, proj_dist_thr, nthreads_feature_detector, max_visible_frames_per_marker, min_num_proj_points, max_features, n_octave_levels;
+    char    global_optimizer[32];           /* "g2o" */
+} uh_params_view;
+int uh_params_from_stream(const uint8_t* data, uint64_t nbytes, uh_params_view* out, uint64_t* consumed);
+
+/* System::saveToFile / readFromFile (src/utils/system.cpp:8099-8720), the `.slm` checkpoint:
+ *   u64 182312 | Map | Params | se3 pose (6 x f32) | i64 current keyframe | bool initialised | STATE i32 | MODES i32 | Frame current |
+ *   Frame previous | FrameExtractor | MapManager | cv::Mat (i32 rows, cols, type + data) | i64 | u64
+ * The hot path owns Params and the FrameExtractor block; Map / Frame / MapManager are the host's containers
+ * and carry no length — only their own readers know where they end.  Reading is therefore sectioned:
+ *   uh_system_stream_begin   checks the signature, says where the Map block starts (8)
+ *   [host: Map::fromStream]
+ *   uh_system_stream_state   on the bytes behind the Map: Params + the five state members; *consumed = where the current Frame starts
+ *   [host: Frame::fromStream x 2]
+ *   uh_frame_extractor_from_stream
+ *   [host: MapManager::fromStream]
+ *   uh_system_stream_tail    the cv::Mat header (its data stays in place: offset / length) and the two trailing integers
+ * and uh_system_to_stream composes a checkpoint from the host's blocks (opaque bytes; a missing one is refused by name), the extractor
+ * block of uh_frame_extractor_to_stream and the values below.  params == NULL writes the Params block the extractor block ends with. */
+typedef struct uh_system_state {
+    float   cur_pose_rt[6];                 /* se3: rx ry rz tx ty tz (NaN = invalid) */
+    int64_t current_keyframe;               /* -1 = none */
+    uint8_t is_initialized;
+    int32_t state;                          /* STATE_TRACKING = 0, STATE_LOST = 1 */
+    int32_t mode;                           /* MODE_SLAM = 0, MODE_LOCALIZATION = 1 */
+} uh_system_state;
+typedef struct uh_system_tail {
+    int32_t  mat_rows, mat_cols, mat_type;  /* cv::Mat header (io_utils.cpp:21-37); rows x cols == 0: no data */
+    uint64_t mat_data_offset, mat_data_bytes;   /* (reader) where the matrix data lies behind `data` */
+    int64_t  last_value_i64;                /* System's trailing int64 member (-1 by default) */
+    uint64_t last_value_u64;                /* System's trailing uint64 member (0 by default) */
+} uh_system_tail;
+typedef struct uh_system_parts {
+    const uint8_t* map;         uint64_t map_bytes;          /* host: Map::toStream */
+    const uint8_t* params;      uint64_t params_bytes;       /* Params::toStream bytes, or NULL */
+    uh_system_state state;
+    const uint8_t* cur_frame;   uint64_t cur_frame_bytes;    /* host: Frame::toStream */
+    const uint8_t* prev_frame;  uint64_t prev_frame_bytes;
+    const uint8_t* extractor;   uint64_t extractor_bytes;    /* uh_frame_extractor_to_stream */
+    const uint8_t* map_manager; uint64_t map_manager_bytes;  /* host: MapManager::toStream */
+    uh_system_tail tail;        const uint8_t* mat_data;
+} uh_system_parts;
+int uh_system_stream_begin(const uint8_t* data, uint64_t nbytes, uint64_t* map_offset);
+int uh_system_stream_state(const uint8_t* data, uint64_t nbytes, uh_params_view* params, uh_system_state* state, uint64_t* params_bytes, uint64_t* consumed);
+int uh_system_stream_tail(const uint8_t* data, uint64_t nbytes, uh_system_tail* tail, uint64_t* consumed);
+int uh_system_to_stream(const uh_system_parts* parts, uint8_t* out, uint64_t cap, uint64_t* size);
 int  uh_orb_set_blur(uh_orb* orb, int do_blur);            /* ORBextractor::doGaussianBlur() (ORBextractor.h:112) */
 int  uh_orb_set_sensitivity(uh_orb* orb, float v);         /* ORBextractor::setSensitivity (ORBextractor.cpp:457-466) */
 int  uh_orb_set_nonmaxima(uh_orb* orb, int on);            /* debug string "orb_nonmaxima" (ORBextractor.cpp:1146-1148,1176-1205): radius-3

@@ -145,3 +145,106 @@ def test_frame_extractor_stream_against_a_writer_that_follows_the_reference(hip_
         ORBextractor.frameExtractorFromStream(hip_ctx, bytes(bad))
     with pytest.raises(u.UcoslamHipError, match="not a ucoslam::Params stream"):
         ext.frameExtractorToStream(st, "", None, params[:-3])
+
+
+# ------------------------------------------------------------------------------------------------ System (.slm) sections owned by the path
+def _ref_system_stream(map_b, params_b, pose, cur_kf, init, state, mode, f_cur, f_prev, fe_b, mm_b, mat, last_i64, last_u64) -> bytes:
+    """System::saveToFile (src/utils/system.cpp:8099-8720, statement order) with the host's blocks as given bytes; cv::Mat as io_utils.cpp:21-37."""
+    if mat is None or mat.size == 0:
+        mat_b = struct.pack("<iii", 0, 0, 0)
+    else:
+        cv_type = {np.dtype(np.uint8): 0, np.dtype(np.float32): 5, np.dtype(np.float64): 6}[mat.dtype]
+        mat_b = struct.pack("<iii", mat.shape[0], mat.shape[1], cv_type) + np.ascontiguousarray(mat).tobytes()
+    return (struct.pack("<Q", 182312) + map_b + params_b + struct.pack("<6f", *pose) + struct.pack("<q", cur_kf) + struct.pack("<B", init) + struct.pack("<ii", state, mode)
+            + f_cur + f_prev + fe_b + mm_b + mat_b + struct.pack("<q", last_i64) + struct.pack("<Q", last_u64))
+
+
+def test_params_stream_and_system_sections_on_the_host():
+    """Params::fromStream and the sectioned reader of the System stream need no GPU: checked against field-by-field writers of the cited
+    reference lines, including the reference's error messages and its 'read until the end signature' loop."""
+    import ucoslam_cv3_amd as u
+    from ucoslam_cv3_amd import slm
+
+    par = _ref_params_stream(detect_markers=0, detect_kp=1, remove_kp_in_markers=0, max_desc=50.0, marker_size=0.25, max_features=2000, n_levels=8, scale=1.2,
+                             run_sequential=1, extra=b"k=v")
+    pv, used = slm.params_from_stream(par + b"tail")
+    assert used == len(par)
+    assert (pv.detect_markers, pv.detect_keypoints, pv.run_sequential, pv.kp_descriptor_type) == (0, 1, 1, 1)
+    assert pv.max_desc_distance == np.float32(50.0) and pv.proj_dist_thr == 15 and pv.nthreads_feature_detector == 2
+    assert (pv.max_features, pv.n_octave_levels) == (2000, 8) and pv.scale_factor == np.float32(1.2) and pv.aruco_marker_size == np.float32(0.25)
+    assert pv.global_optimizer == b"g2o" and pv.max_new_points == 350 and pv.kf_min_confidence == np.float32(0.6) and pv.kf_culling == np.float32(0.8)
+    # a newer writer may append fields before the end signature: the reader slides forward in 8-byte steps like the reference's loop
+    grown = par[:-8] + b"\x01" * 16 + par[-8:]
+    assert slm.params_from_stream(grown)[1] == len(grown)
+    with pytest.raises(u.UcoslamHipError, match="Invalid signature"):
+        slm.params_from_stream(b"\0" * 8 + par[8:])
+    with pytest.raises(u.UcoslamHipError, match="Reached EOF"):
+        slm.params_from_stream(par[:-8])
+    # ---- the System stream, sectioned
+    rng = np.random.default_rng(5)
+    blk = lambda n: rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    map_b, f_cur, f_prev, mm_b, fe_b = blk(1234), blk(333), blk(77), blk(901), struct.pack("<Q", 1923123) + blk(40)
+    pose = [0.1, -0.2, 0.3, 1.0, 2.0, 3.0]
+    mat = rng.random((4, 4)).astype(np.float32)
+    ref = _ref_system_stream(map_b, par, pose, 42, 1, 0, 1, f_cur, f_prev, fe_b, mm_b, mat, -1, 9)
+    off = slm.system_stream_begin(ref)
+    assert off == 8
+    after_map = ref[off + len(map_b):]                                   # (the host's Map::fromStream consumed its block)
+    pv2, st, pbytes, used = slm.system_stream_state(after_map)
+    assert pbytes == len(par) and used == len(par) + 24 + 8 + 1 + 8
+    assert list(st.cur_pose_rt) == [np.float32(v) for v in pose] and (st.current_keyframe, st.is_initialized, st.state, st.mode) == (42, 1, 0, 1)
+    assert pv2.max_features == 2000
+    after_mm = after_map[used + len(f_cur) + len(f_prev) + len(fe_b) + len(mm_b):]
+    tail, tused = slm.system_stream_tail(after_mm)
+    assert tused == len(after_mm) and (tail.mat_rows, tail.mat_cols, tail.mat_type) == (4, 4, 5) and tail.mat_data_bytes == 64
+    assert after_mm[tail.mat_data_offset: tail.mat_data_offset + 64] == mat.tobytes() and (tail.last_value_i64, tail.last_value_u64) == (-1, 9)
+    # ---- the writer composes the same bytes from the host's blocks; an empty matrix writes 0 0 0
+    t = slm.SystemTail(4, 4, 5, 0, 0, -1, 9)
+    got = slm.system_to_stream(map_b, st, f_cur, f_prev, fe_b, mm_b, t, mat.tobytes(), params=par)
+    assert got == ref
+    t0 = slm.SystemTail(0, 0, 0, 0, 0, 7, 0)
+    got0 = slm.system_to_stream(map_b, st, f_cur, f_prev, fe_b, mm_b, t0, params=par)
+    assert got0 == _ref_system_stream(map_b, par, pose, 42, 1, 0, 1, f_cur, f_prev, fe_b, mm_b, None, 7, 0)
+    # ---- refusals: foreign file, blocks that are the host's, misplaced sections
+    with pytest.raises(u.UcoslamHipError, match="invalid file type"):
+        slm.system_stream_begin(struct.pack("<Q", 182313) + ref[8:])
+    with pytest.raises(u.UcoslamHipError, match="Map block is missing"):
+        slm.system_to_stream(b"", st, f_cur, f_prev, fe_b, mm_b, t, mat.tobytes(), params=par)
+    with pytest.raises(u.UcoslamHipError, match="Frame block is missing"):
+        slm.system_to_stream(map_b, st, f_cur, b"", fe_b, mm_b, t, mat.tobytes(), params=par)
+    with pytest.raises(u.UcoslamHipError, match="MapManager block is missing"):
+        slm.system_to_stream(map_b, st, f_cur, f_prev, fe_b, b"", t, mat.tobytes(), params=par)
+    with pytest.raises(u.UcoslamHipError, match="not a FrameExtractor stream"):
+        slm.system_to_stream(map_b, st, f_cur, f_prev, blk(48), mm_b, t, mat.tobytes(), params=par)
+    with pytest.raises(u.UcoslamHipError, match="FOLLOW Map::fromStream"):
+        slm.system_stream_state(ref[off:])                                # the Map block has not been consumed
+    with pytest.raises(u.UcoslamHipError, match="not values of the reference's enums"):
+        slm.system_stream_state(par + struct.pack("<6f", *pose) + struct.pack("<q", 1) + b"\x01" + struct.pack("<ii", 5, 0))
+
+
+@pytest.mark.gpu
+def test_system_checkpoint_with_the_real_extractor_block(hip_ctx):
+    """A whole `.slm` stream around the HIP extractor's own FrameExtractor block: params = NULL writes the Params block the extractor block
+    ends with; reading the sections back restores the extractor and the state."""
+    from ucoslam_cv3_amd import slm
+    from ucoslam_cv3_amd.orb import FeatParams, FrameExtractorState, ORBextractor
+    import ucoslam_cv3_amd as u
+
+    ext = ORBextractor.create(hip_ctx)
+    fp = FeatParams(2000, 8, 1.2, nthreads=2)
+    u._lib.check(u.lib().uh_orb_set_params(ext._h, fp))
+    fe_b = ext.frameExtractorToStream(FrameExtractorState(3, 0, 0, 1, np.float32(1.0), fp, np.float32(50.0)))
+    rng = np.random.default_rng(9)
+    blk = lambda n: rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    map_b, f_cur, f_prev, mm_b = blk(500), blk(60), blk(61), blk(62)
+    st = slm.SystemState((C_float6 := (0.0, 0.0, 0.0, 0.5, 0.25, 0.125)), 7, 1, 0, 0)
+    got = slm.system_to_stream(map_b, st, f_cur, f_prev, fe_b, mm_b, slm.SystemTail(0, 0, 0, 0, 0, -1, 0))
+    par = _ref_params_stream(detect_markers=0, detect_kp=1, remove_kp_in_markers=0, max_desc=50.0, marker_size=1.0, max_features=2000)
+    assert got == _ref_system_stream(map_b, par, C_float6, 7, 1, 0, 0, f_cur, f_prev, fe_b, mm_b, None, -1, 0)
+    pv, st2, pbytes, used = slm.system_stream_state(got[8 + len(map_b):])
+    assert pv.max_features == 2000 and pv.max_desc_distance == np.float32(50.0) and st2.current_keyframe == 7
+    rest = got[8 + len(map_b) + used + len(f_cur) + len(f_prev):]
+    ext2, st_fe, sp, aru, parb, fe_used = ORBextractor.frameExtractorFromStream(hip_ctx, rest)
+    assert fe_used == len(fe_b) and st_fe.counter == 3 and ext2.getParams().maxFeatures == 2000
+    tail, tused = slm.system_stream_tail(rest[fe_used + len(mm_b):])
+    assert tused == 12 + 16 and tail.mat_data_bytes == 0 and tail.last_value_i64 == -1

@@ -4,4 +4,4 @@ The product is the HIP library `libucoslam_hip.so` behind the C ABI of include/u
 this package is the thin Python host side used by tests/, bench.py and __graft_entry__.py.
 """
 from ._lib import Context, UcoslamHipError, lib  # noqa: F401
-from . import ba, bow, knn, matcher, orb, parallel, pnp, projmatch  # noqa: F401,E402  (registers the ctypes prototypes)
+from . import ba, bow, knn, matcher, orb, parallel, pnp, projmatch, slm  # noqa: F401,E402  (registers the ctypes prototypes)

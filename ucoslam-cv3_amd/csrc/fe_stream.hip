@@ -155,3 +155,167 @@ int uh_frame_extractor_from_stream(uh_orb* orb, const uint8_t* data, uint64_t nb
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// System::saveToFile / readFromFile (src/utils/system.cpp:8099-8720; token-pasted source, statement starts) — the `.slm` checkpoint:
+//   u64 182312 | Map::toStream | Params::toStream | se3 current pose (6 x f32, raw) | i64 current keyframe | bool initialised |
+//   STATE (i32) | MODES (i32) | Frame current | Frame previous | FrameExtractor::toStream | MapManager::toStream |
+//   cv::Mat (io_utils.cpp:21-37: i32 rows, cols, type + rows x cols x elemSize bytes) | i64 | u64
+// The hot path owns two of these blocks: Params (the thresholds and extractor settings every stage of the path is driven by) and
+// the FrameExtractor block (uh_frame_extractor_*).  Map / Frame / MapManager are the host's own containers (SURVEY.md §2 row 18,
+// out of scope): they carry no length, so only the host's own fromStream knows where they end — the reader below is therefore
+// SECTIONED (the host reads its blocks, hands the remaining bytes back) and the writer takes those blocks as opaque bytes.  A
+// block that is missing is refused by name, never guessed.
+namespace {
+
+size_t cv_elem_size(int32_t type) {   // CV_ELEM_SIZE: depth = type & 7, channels = (type >> 3) + 1
+    static const int depth_bytes[8] = {1, 1, 2, 2, 4, 4, 8, 2};
+    return (size_t)depth_bytes[type & 7] * (size_t)(((type >> 3) & 511) + 1);
+}
+
+bool read_params(Reader& r, uh_params_view* v) {   // ucoslamtypes.cpp:123-180, field for field
+    if (r.get<uint64_t>() != 9837138769928ull) return false;
+    uh_params_view p{};
+    p.detect_markers = r.get<uint8_t>(); p.detect_keypoints = r.get<uint8_t>(); p.target_focus = r.get<float>(); p.kf_min_confidence = r.get<float>();
+    p.kp_non_maxima_suppression = r.get<uint8_t>(); p.max_new_points = r.get<int32_t>();
+    p.force_initialization_from_markers = r.get<uint8_t>(); p.remove_keypoints_into_markers = r.get<uint8_t>();
+    p.max_desc_distance = r.get<float>(); p.baseline_median_depth_ratio_min = r.get<float>(); p.aruco_marker_size = r.get<float>();
+    p.proj_dist_thr = r.get<int32_t>(); p.nthreads_feature_detector = r.get<int32_t>(); p.max_visible_frames_per_marker = r.get<int32_t>();
+    p.min_num_proj_points = r.get<int32_t>(); p.kf_culling = r.get<float>(); p.th_ref_ratio = r.get<float>();
+    p.max_features = r.get<int32_t>(); p.n_octave_levels = r.get<int32_t>(); p.scale_factor = r.get<float>(); p.kp_descriptor_type = r.get<int8_t>();
+    r.skip(4 + 4 + 1);                       // aruco_minerrratio_valid aruco_minNumFramesRequired aruco_allowOneFrameInitialization
+    p.min_base_line = r.get<float>(); p.run_sequential = r.get<uint8_t>();
+    r.skip(4 + 4);                           // markersOptWeight minMarkersForMaxWeight
+    {   // global_optimizer
+        const uint32_t n = r.get<uint32_t>();
+        if (!r.ok || r.at + n > r.n) return false;
+        const uint32_t k = n < sizeof(p.global_optimizer) - 1 ? n : (uint32_t)sizeof(p.global_optimizer) - 1;
+        std::memcpy(p.global_optimizer, r.p + r.at, k);
+        r.skip(n);
+    }
+    r.str(); r.str(); r.str();               // aruco_Dictionary aruco_DetectionMode aruco_CornerRefimentMethod
+    r.skip(4);                               // aruco_minMarkerSize
+    p.kpt_image_scale_factor = r.get<float>(); p.auto_adjust_kp_sensitivity = r.get<uint8_t>();
+    p.relocalization_with_keypoints = r.get<uint8_t>(); p.relocalization_with_markers = r.get<uint8_t>(); r.skip(1);   // inPlaneMarkers
+    r.str();                                 // extraParams
+    // "read until end signature" (:176-179): the reference slides an 8-byte window forward 8 bytes at a time
+    uint64_t sig = 0;
+    while (r.ok && sig != 1837138769921ull) sig = r.get<uint64_t>();
+    if (!r.ok) return false;
+    if (v) *v = p;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uh_params_from_stream(const uint8_t* data, uint64_t nbytes, uh_params_view* out, uint64_t* consumed) {
+    UH_REQUIRE(data && out, "uh_params_from_stream: NULL argument");
+    Reader r{data, nbytes};
+    const uint64_t sig = nbytes >= 8 ? r.get<uint64_t>() : 0;
+    UH_REQUIRE(sig == 9837138769928ull, "Invalid signature");   // ucoslamtypes.cpp:126
+    r.at = 0;
+    UH_REQUIRE(read_params(r, out), "Reached EOF without finding end signature");   // :179
+    if (consumed) *consumed = r.at;
+    return UH_OK;
+}
+
+int uh_system_stream_begin(const uint8_t* data, uint64_t nbytes, uint64_t* map_offset) {
+    UH_REQUIRE(data && map_offset, "uh_system_stream_begin: NULL argument");
+    uint64_t sig = 0;
+    if (nbytes >= 8) std::memcpy(&sig, data, 8);
+    UH_REQUIRE(sig == 182312ull, "void ucoslam::System::readFromFile(std::string)invalid file type:");   // system.cpp:8446
+    *map_offset = 8;   // Map::fromStream is the host's (it carries no length: only its reader knows where it ends)
+    return UH_OK;
+}
+
+int uh_system_stream_state(const uint8_t* data, uint64_t nbytes, uh_params_view* params, uh_system_state* state, uint64_t* params_bytes, uint64_t* consumed) {
+    UH_REQUIRE(data && params && state, "uh_system_stream_state: NULL argument (data = the bytes behind the host's Map block)");
+    Reader r{data, nbytes};
+    UH_REQUIRE(nbytes >= 8 && [&] { uint64_t s; std::memcpy(&s, data, 8); return s == 9837138769928ull; }(),
+               "uh_system_stream_state: no ucoslam::Params block here (Invalid signature) — pass the bytes that FOLLOW Map::fromStream");
+    UH_REQUIRE(read_params(r, params), "Reached EOF without finding end signature");
+    if (params_bytes) *params_bytes = r.at;
+    uh_system_state s{};
+    for (int i = 0; i < 6; i++) s.cur_pose_rt[i] = r.get<float>();
+    s.current_keyframe = r.get<int64_t>();
+    s.is_initialized = r.get<uint8_t>();
+    s.state = r.get<int32_t>();
+    s.mode = r.get<int32_t>();
+    UH_REQUIRE(r.ok, "uh_system_stream_state: truncated stream");
+    UH_REQUIRE((s.state == 0 || s.state == 1) && (s.mode == 0 || s.mode == 1), "uh_system_stream_state: STATE %d / MODES %d are not values of the reference's enums", s.state, s.mode);
+    *state = s;
+    if (consumed) *consumed = r.at;   // the current Frame's block starts here (host code)
+    return UH_OK;
+}
+
+int uh_system_stream_tail(const uint8_t* data, uint64_t nbytes, uh_system_tail* tail, uint64_t* consumed) {
+    UH_REQUIRE(data && tail, "uh_system_stream_tail: NULL argument (data = the bytes behind the host's MapManager block)");
+    Reader r{data, nbytes};
+    uh_system_tail t{};
+    t.mat_rows = r.get<int32_t>(); t.mat_cols = r.get<int32_t>(); t.mat_type = r.get<int32_t>();
+    UH_REQUIRE(r.ok && t.mat_rows >= 0 && t.mat_cols >= 0 && t.mat_rows <= 65536 && t.mat_cols <= 65536, "uh_system_stream_tail: no cv::Mat header here — pass the bytes that FOLLOW MapManager::fromStream");
+    t.mat_data_offset = r.at;
+    t.mat_data_bytes = (uint64_t)t.mat_rows * t.mat_cols > 0 ? (uint64_t)t.mat_rows * t.mat_cols * cv_elem_size(t.mat_type) : 0;   // io_utils.cpp:46: r*c > 0
+    r.skip(t.mat_data_bytes);
+    t.last_value_i64 = r.get<int64_t>();
+    t.last_value_u64 = r.get<uint64_t>();
+    UH_REQUIRE(r.ok, "uh_system_stream_tail: truncated stream");
+    *tail = t;
+    if (consumed) *consumed = r.at;
+    return UH_OK;
+}
+
+int uh_system_to_stream(const uh_system_parts* parts, uint8_t* out, uint64_t cap, uint64_t* size) {
+    UH_REQUIRE(parts && size, "uh_system_to_stream: NULL argument");
+    UH_REQUIRE(parts->map && parts->map_bytes, "uh_system_to_stream: the Map block is missing — Map::toStream is host code (SURVEY.md section 2 row 18), pass its bytes");
+    UH_REQUIRE(parts->cur_frame && parts->cur_frame_bytes && parts->prev_frame && parts->prev_frame_bytes,
+               "uh_system_to_stream: a Frame block is missing — Frame::toStream is host code, pass the bytes of the current and the previous frame");
+    UH_REQUIRE(parts->map_manager && parts->map_manager_bytes, "uh_system_to_stream: the MapManager block is missing — MapManager::toStream is host code, pass its bytes");
+    UH_REQUIRE(parts->extractor && parts->extractor_bytes >= 8, "uh_system_to_stream: the FrameExtractor block is missing (uh_frame_extractor_to_stream writes it)");
+    {
+        uint64_t sig; std::memcpy(&sig, parts->extractor, 8);
+        UH_REQUIRE(sig == 1923123ull, "uh_system_to_stream: the extractor bytes are not a FrameExtractor stream (signature 1923123)");
+    }
+    Writer w;
+    w.put<uint64_t>(182312ull);
+    w.raw(parts->map, parts->map_bytes);
+    if (parts->params) {
+        Reader r{parts->params, parts->params_bytes};
+        UH_REQUIRE(walk_params(r) && r.at == parts->params_bytes, "uh_system_to_stream: the parameter bytes are not a ucoslam::Params stream");
+        w.raw(parts->params, parts->params_bytes);
+    } else {   // the Params block the extractor block carries (FrameExtractor::toStream ends with one)
+        Reader r{parts->extractor, parts->extractor_bytes};
+        r.skip(8);
+        // Feature2DSerializable stream: u64 sig, u64 type, string, FeatParams
+        r.skip(16); r.str(); r.skip(sizeof(uh_feat_params));
+        r.skip(4 + 3 + 4 + sizeof(uh_feat_params) + 4);
+        UH_REQUIRE(r.ok && walk_aruco(r), "uh_system_to_stream: cannot walk the extractor block to its Params (pass parts->params)");
+        const uint64_t p0 = r.at;
+        UH_REQUIRE(walk_params(r), "uh_system_to_stream: cannot walk the extractor block's Params (pass parts->params)");
+        w.raw(parts->extractor + p0, r.at - p0);
+    }
+    for (int i = 0; i < 6; i++) w.put<float>(parts->state.cur_pose_rt[i]);
+    w.put<int64_t>(parts->state.current_keyframe);
+    w.put<uint8_t>(parts->state.is_initialized ? 1 : 0);
+    w.put<int32_t>(parts->state.state);
+    w.put<int32_t>(parts->state.mode);
+    w.raw(parts->cur_frame, parts->cur_frame_bytes);
+    w.raw(parts->prev_frame, parts->prev_frame_bytes);
+    w.raw(parts->extractor, parts->extractor_bytes);
+    w.raw(parts->map_manager, parts->map_manager_bytes);
+    const uint64_t mat_bytes = (uint64_t)parts->tail.mat_rows * parts->tail.mat_cols > 0 ? (uint64_t)parts->tail.mat_rows * parts->tail.mat_cols * cv_elem_size(parts->tail.mat_type) : 0;
+    UH_REQUIRE(mat_bytes == 0 || parts->mat_data, "uh_system_to_stream: the cv::Mat of the tail has %llu bytes of data but mat_data is NULL", (unsigned long long)mat_bytes);
+    w.put<int32_t>(mat_bytes ? parts->tail.mat_rows : 0); w.put<int32_t>(mat_bytes ? parts->tail.mat_cols : 0); w.put<int32_t>(mat_bytes ? parts->tail.mat_type : 0);   // io_utils.cpp:23-28: an empty Mat writes 0 0 0
+    if (mat_bytes) w.raw(parts->mat_data, mat_bytes);
+    w.put<int64_t>(parts->tail.last_value_i64);
+    w.put<uint64_t>(parts->tail.last_value_u64);
+    *size = w.b.size();
+    if (!out) return UH_OK;
+    if (cap < *size) { uh::set_error("uh_system_to_stream: %llu bytes needed, capacity %llu", (unsigned long long)*size, (unsigned long long)cap); return UH_ECAPACITY; }
+    std::memcpy(out, w.b.data(), w.b.size());
+    return UH_OK;
+}
+
+}  // extern "C"
