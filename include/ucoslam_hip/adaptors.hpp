@@ -8,8 +8,9 @@
 // Same method names, argument meaning and error behaviour (std::runtime_error where the reference throws, `false` where
 // xflann returns false).  This header needs no OpenCV: images/descriptors are plain pointers, keypoints are uh_keypoint
 // (layout of cv::KeyPoint), matches are uh_dmatch (layout of cv::DMatch).  The classes that literally derive from the
-// reference's bases (so that System/MapManager can hold them) are in the UCOSLAM_HIP_WITH_REFERENCE block at the end and in
-// INTEGRATION.md; they compile only inside the reference tree, where OpenCV exists.
+// reference's bases (so that System/MapManager can hold them) are NOT in this header: they need the reference's headers and
+// OpenCV, neither of which exists where this repository is built and tested, so they have never been compiled — INTEGRATION.md
+// sections 1 and 4 list them as the binding a maintainer adds inside the reference tree, on top of the classes below.
 #pragma once
 #include <cmath>
 #include <cstdint>

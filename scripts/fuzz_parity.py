@@ -250,12 +250,24 @@ def ba_case2(seed):
         spread = float(np.abs(ref["state"] - o["state"]).max())
         if spread > 1e-7 or ref["iters"].tolist() != o["iters"].tolist():
             _chaotic.append((seed, err, spread))
-            ok = err <= 1e3 * max(spread, 1e-9) or ref["iters"].tolist() != o["iters"].tolist()
+            # the GPU has to land on ONE of the two trajectories: the oracle's (within the amplified tolerance) or the real g2o's —
+            # iteration counts, state and bad flags; "the two references disagree" alone waives nothing
+            tol = 1e3 * max(spread, 1e-9)
+            near_o = g["iters"].tolist() == o["iters"].tolist() and err <= tol
+            err_r = float(np.abs(g["state"] - ref["state"]).max())
+            near_r = g["iters"].tolist() == ref["iters"].tolist() and err_r <= tol and (g["bad"] == ref["bad"]).mean() > 0.99
+            ok = near_o or near_r
+            if ok and not near_o:
+                _waived.append(seed)
     return ok, (K, P, nfix, nit, form, staged, "hard" if hard else "", g["iters"].tolist(), o["iters"].tolist(), err)
 
 _g2o = oracle_lib.load_ref("g2o")
 _chaotic = []
+_waived = []   # hard cases accepted because the GPU follows the real g2o's trajectory where the oracle's differs
 run("ba", ba_case2)
+if "ba" in report and len(_waived) > max(3, report["ba"][0] // 50):   # (a handful is round-off amplification; a fifth of the hard cases is a bug)
+    print(f"ba: FAIL — {len(_waived)} hard cases follow the real g2o but not the oracle (seeds {_waived[:10]}): more than round-off amplification explains", flush=True)
+    report["ba"][1].append(("waived", _waived[:20]))
 if _chaotic:
     print(f"ba: {len(_chaotic)} hard cases on which the oracle and the real g2o disagree beyond 1e-7 themselves (round-off amplification; worst GPU-oracle {max(c[1] for c in _chaotic):.1e}, worst g2o-oracle {max(c[2] for c in _chaotic):.1e})", flush=True)
 

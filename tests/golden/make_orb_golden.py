@@ -53,6 +53,40 @@ def main():
                     det = cv2.FastFeatureDetector_create(threshold=th, nonmaxSuppression=True, type=cv2.FAST_FEATURE_DETECTOR_TYPE_9_16)
                     kps = det.detect(cur, None)
                     out[f"c{ci}_fast{th}_level{lvl}"] = np.array([[k.pt[0], k.pt[1], k.response] for k in kps], np.float32).reshape(-1, 3)
+    # ---- diagnostics: whichever OpenCV this file comes from, a mismatch of a level is traced to ONE primitive in one run
+    # (a) the Gaussian taps: cv::getGaussianKernel's floats and what the 8-bit filter really applies — the response to an impulse of 255 in a
+    #     flat 0 image (row and column taps x 255, rounded by the fixed-point path: tells the legacy cvRound(k * 256) taps from the bit-exact ones)
+    out["diag_gauss_kernel_f64"] = cv2.getGaussianKernel(7, 2).reshape(-1)
+    out["diag_gauss_kernel_f32"] = cv2.getGaussianKernel(7, 2, cv2.CV_32F).reshape(-1)
+    imp = np.zeros((15, 15), np.uint8); imp[7, 7] = 255
+    out["diag_gauss_impulse"] = cv2.GaussianBlur(imp, (7, 7), 2, sigmaY=2, borderType=cv2.BORDER_REFLECT_101)
+    ramp = (np.add.outer(np.arange(23) * 11, np.arange(37) * 7) % 256).astype(np.uint8)
+    out["diag_gauss_ramp_in"] = ramp
+    out["diag_gauss_ramp"] = cv2.GaussianBlur(ramp, (7, 7), 2, sigmaY=2, borderType=cv2.BORDER_REFLECT_101)   # (the reflect-101 border included)
+    # (b) INTER_CUBIC 8U: a ramp and an impulse image resized by 1 / 1.2 (taps, their 11-bit rounding, the (v + 2^21) >> 22 descale, edge clamping)
+    out["diag_resize_ramp"] = cv2.resize(ramp, (int(np.rint(37 / 1.2)), int(np.rint(23 / 1.2))), interpolation=cv2.INTER_CUBIC)
+    imp2 = np.zeros((24, 36), np.uint8); imp2[::5, ::7] = 255
+    out["diag_resize_impulse_in"] = imp2
+    out["diag_resize_impulse"] = cv2.resize(imp2, (30, 20), interpolation=cv2.INTER_CUBIC)
+    # (c) cv::FAST on SUB-IMAGES, as ComputeKeyPoints_thread calls it per cell (:980,986): the rows / columns closer than 3 to the sub-image's
+    #     edge score 0 and the non-maximum test sees zeros beyond it — per-cell detection is not a crop of whole-image detection
+    base = out["c0_level0"]
+    rois = [(0, 0, 36, 36), (16, 16, 52, 52), (100, 60, 131, 92), (base.shape[1] - 40, base.shape[0] - 37, base.shape[1], base.shape[0]), (5, 120, 70, 150)]
+    out["diag_fast_rois"] = np.array(rois, np.int32)
+    for ri, (x0, y0, x1, y1) in enumerate(rois):
+        sub = np.ascontiguousarray(base[y0:y1, x0:x1])
+        for th in (20, 7):
+            det = cv2.FastFeatureDetector_create(threshold=th, nonmaxSuppression=True, type=cv2.FAST_FEATURE_DETECTOR_TYPE_9_16)
+            out[f"diag_fast_roi{ri}_th{th}"] = np.array([[k.pt[0], k.pt[1], k.response] for k in det.detect(sub, None)], np.float32).reshape(-1, 3)
+    # (d) KeyPointsFilter::retainBest has no Python binding in stock OpenCV; where a build exposes it, its order is recorded for level 0's strongest 700
+    try:
+        det = cv2.FastFeatureDetector_create(threshold=7, nonmaxSuppression=True, type=cv2.FAST_FEATURE_DETECTOR_TYPE_9_16)
+        kps = det.detect(base, None)
+        kept = cv2.KeyPointsFilter.retainBest(list(kps), 700)   # (AttributeError on stock builds)
+        out["diag_retain_best_in"] = np.array([[k.pt[0], k.pt[1], k.response] for k in kps], np.float32)
+        out["diag_retain_best_out"] = np.array([[k.pt[0], k.pt[1], k.response] for k in kept], np.float32)
+    except Exception as e:   # noqa: BLE001
+        out["diag_retain_best_unavailable"] = np.array(repr(e))
     # :105  fastAtan2((float)m_01, (float)m_10) on a grid of integer moments
     rng = np.random.default_rng(3)
     yx = np.concatenate([rng.integers(-40000, 40001, (4000, 2)), [[0, 0], [0, 5], [0, -5], [3, 0], [-3, 0], [1, 1], [-1, -1]]]).astype(np.float32)

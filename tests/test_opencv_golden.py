@@ -34,9 +34,39 @@ def _fast_rows(xys):
     return a[np.lexsort((a[:, 0], a[:, 1]))]
 
 
+def _diagnose(oracle, g):
+    """Which OpenCV primitive the oracle's restatement disagrees with (the diag_* arrays of make_orb_golden.py), as text for the assertion."""
+    notes = []
+    if "diag_gauss_impulse" not in g.files:
+        return "(fixture without diag_* arrays: regenerate it with the current make_orb_golden.py)"
+    def lvl0(img):   # the oracle's level 0 = GaussianBlur(7x7, sigma 2, reflect-101) of the image
+        return oracle_lib.orb_pyramid_level(oracle, np.ascontiguousarray(img), 0, 1, 1.2)
+    if not np.array_equal(lvl0(g["diag_gauss_ramp_in"]), g["diag_gauss_ramp"]):
+        imp = np.zeros((15, 15), np.uint8); imp[7, 7] = 255
+        notes.append(f"GaussianBlur differs; OpenCV's impulse row {g['diag_gauss_impulse'][7, 4:11].tolist()} vs oracle {lvl0(imp)[7, 4:11].tolist()} "
+                     f"(getGaussianKernel: {np.round(g['diag_gauss_kernel_f64'], 6).tolist()})")
+    lv1 = oracle_lib.orb_pyramid_level(oracle, np.ascontiguousarray(g["diag_gauss_ramp_in"]), 1, 2, 1.2, False)
+    if lv1.shape == g["diag_resize_ramp"].shape and not np.array_equal(lv1, g["diag_resize_ramp"]):
+        notes.append(f"resize(INTER_CUBIC) differs on the ramp at {int((lv1 != g['diag_resize_ramp']).sum())} pixels (max |d| {int(np.abs(lv1.astype(int) - g['diag_resize_ramp'].astype(int)).max())})")
+    base = g["c0_level0"]
+    for ri, (x0, y0, x1, y1) in enumerate(g["diag_fast_rois"]):
+        sub = np.ascontiguousarray(base[y0:y1, x0:x1])
+        for th in (20, 7):
+            if not np.array_equal(_fast_rows(oracle_lib.fast_detect(oracle, sub, th).astype(np.float32)), _fast_rows(g[f"diag_fast_roi{ri}_th{th}"])):
+                notes.append(f"cv::FAST(threshold {th}) differs on sub-image {ri} {(int(x0), int(y0), int(x1), int(y1))}")
+    return f"OpenCV {g['cv_version']}: " + ("; ".join(notes) if notes else "every diag_* primitive agrees (the mismatch is in how they are chained)")
+
+
 def test_oracle_orb_stages_equal_opencv(oracle):
     g = _orb_gold()
     nl, sc = int(g["nlevels"]), float(g["scale"])
+    try:
+        _check_orb_stages(oracle, g, nl, sc)
+    except AssertionError as e:
+        raise AssertionError(str(e) + "\nDIAGNOSIS: " + _diagnose(oracle, g)) from None
+
+
+def _check_orb_stages(oracle, g, nl, sc):
     for ci, (w, h, seed) in enumerate(g["cases"]):
         img = synth.frame(int(w), int(h), seed=int(seed))
         for lvl in range(nl):

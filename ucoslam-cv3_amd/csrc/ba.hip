@@ -2031,6 +2031,9 @@ struct uh_ba {
     hipEvent_t ev_stage = nullptr;        // recorded behind that copy: the staging block may be rewritten once it has completed
     bool stage_in_flight = false;
     uh::DevBuf dT;                        // (point x frame) -> problem sequence << 20 | observation index + 1
+    unsigned stage_gen = 0, problem_stage_gen = 0;   // uh_ba_map_staging bumps the first; set_problem_fast records it: the residency fallback
+                                          // re-reads the staging block and must not do so once the caller may have refilled it
+    bool persist_not_resident = false;    // the last persistent launch ended because a workgroup never became resident (as opposed to a launch that vanished)
     unsigned dT_gen = ~0u, tseq = 0;
     uh::DevBuf dscratch;                  // BAState[2], 64 phase clocks, completion counter
     unsigned done_base = 0;               // what the completion counter holds before the next launch
@@ -2243,6 +2246,7 @@ int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, 
     }
     UH_HIP_CHECK(hipGetLastError());
     bool err = false;
+    b->persist_not_resident = false;
     {
         // the kernel's last act is a system-scope release store of (launch id << 32 | 1) behind the results and the final state: polling
         // that word costs a few hundred nanoseconds of latency, a stream synchronisation + pageable D2H copies cost ~45 us per optimize()
@@ -2251,7 +2255,7 @@ int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, 
         for (unsigned spin = 0;; ++spin) {
             const unsigned long long w = *h_done;
             if (w == ok_word) break;
-            if (w == err_word) { err = true; break; }
+            if (w == err_word) { err = true; b->persist_not_resident = true; break; }
             if (stop_asap && *stop_asap) *b->h_stop = 1;
             __builtin_ia32_pause();
             if ((spin & 1023) == 1023) {
@@ -2267,7 +2271,12 @@ int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, 
         (void)hipStreamSynchronize(st);
         (void)hipMemsetAsync(b->dscratch.as<char>() + 768, 0, 4, st);   // the completion count of an aborted launch is meaningless
         b->done_base = 0;
-        uh::set_error("uh_ba_optimize: the persistent kernel's workgroups did not all become resident (%d workgroups, %d bytes of LDS each)", q.G, b->p_lds);
+        if (b->persist_not_resident) uh::set_error("uh_ba_optimize: the persistent kernel's workgroups did not all become resident (%d workgroups, %d bytes of LDS each)", q.G, b->p_lds);
+        else {
+            const hipError_t le = hipGetLastError();
+            uh::set_error("uh_ba_optimize: the persistent launch ended without reporting (%s): a device fault or a 30 s stall, not a residency problem — not retried",
+                          le == hipSuccess ? "no HIP error pending" : hipGetErrorString(le));
+        }
         return UH_ENODEVICE;
     }
     b->done_base += 2u * (unsigned)q.G;
@@ -2689,12 +2698,16 @@ static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl
     int rc;
     // ---- device buffers (all of them survive the problem)
     if ((rc = b->dstage.reserve(b->h_stage_bytes))) return rc;
-    if ((rc = b->dT.reserve((size_t)b->cap_P * b->cap_K * sizeof(unsigned) + 256))) return rc;
+    // the (point x frame) table is indexed pt * K + kf with THIS problem's K: P * K cells, not the product of the staging capacities
+    // (those only grow: one global BA staged through this object — 250 k points x 400 frames — would have made every later local
+    // BA reserve and clear 380 MB).  Only problems that fit the persistent form come here (P <= Lw x workgroups, K <= 271).
+    if ((rc = b->dT.reserve((size_t)P * K * sizeof(unsigned) + 256))) return rc;
     if (b->dT_gen != b->dT.gen || (b->tseq & 0xFFFu) == 0xFFFu) {   // fresh memory, or the 12 bits wrap: no cell may look current
         UH_HIP_CHECK(hipMemsetAsync(b->dT.p, 0, b->dT.cap, st));
         b->dT_gen = b->dT.gen; b->tseq = 0;
     }
     ++b->tseq;
+    b->problem_stage_gen = b->stage_gen;
     const unsigned tseq = (b->tseq & 0xFFFu) << 20;
     if (!b->dscratch.p) {
         if ((rc = b->dscratch.reserve(1024))) return rc;
@@ -2912,6 +2925,7 @@ int uh_ba_map_staging(uh_ba* b, int n_frames, int n_points, int max_obs, uh_ba_s
     UH_REQUIRE(b->job.load() == 0, "uh_ba_map_staging: an optimisation is in flight (call uh_ba_wait)");
     int rc = ensure_staging(b, n_frames, n_points, max_obs);
     if (rc) return rc;
+    ++b->stage_gen;   // the caller may overwrite the block from here on
     const StageLayout& L = b->slay;
     out->poses_f2g = reinterpret_cast<float*>(b->h_stage + L.poses_in); out->fixed = b->h_stage + L.fixed; out->intr = reinterpret_cast<float*>(b->h_stage + L.intr_f);
     out->points = reinterpret_cast<float*>(b->h_stage + L.points); out->obs = reinterpret_cast<uh_ba_obs*>(b->h_stage + L.obs);
@@ -2970,7 +2984,12 @@ int uh_ba_optimize(uh_ba* b, const volatile uint8_t* stop_asap) {
     b->step = 0;
     if (b->persist) {
         const int rcp = run_persistent(b, stop_asap, n1, n2, mc);
-        if (rcp != UH_ENODEVICE || !b->h_stage) return rcp;
+        if (rcp != UH_ENODEVICE || !b->h_stage || !b->persist_not_resident) return rcp;
+        if (b->problem_stage_gen != b->stage_gen) {   // uh_ba_map_staging was called since set_problem: the block may hold the NEXT keyframe's problem
+            const std::string why0 = uh_last_error();
+            uh::set_error("%s; the staging block has been remapped since set_problem, so the launch-chain fallback cannot rebuild this problem: set it again", why0.c_str());
+            return UH_ENODEVICE;
+        }
         // The persistent kernel's workgroups did not all become resident within its timeout (another process's or library's spinning
         // kernel holds CUs: INTEGRATION.md section 8).  The problem is still in the staging block: this optimisation and the next 64
         // problems of this object take the launch chain, which needs no co-residency; then the persistent form is tried again.

@@ -511,7 +511,8 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         if (__hip_atomic_load(q.errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == err_word || wall_clock64() - t0 > kPTimeoutTicks) {
             s_flag[1] = 1;
             __hip_atomic_store(q.errw, err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (g == 0 && q.host_done) __hip_atomic_store(q.host_done, ((unsigned long long)q.launch_id << 32) | 2ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // whichever workgroup gives up tells the host (the same word from all of them): the one that never became resident may be workgroup 0
+            if (q.host_done) __hip_atomic_store(q.host_done, ((unsigned long long)q.launch_id << 32) | 2ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             return true;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -1210,7 +1211,9 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     __syncthreads();
     UH_BA_CLK(10);
     if (tid == 0) {
-        const unsigned before = __hip_atomic_fetch_add(q.done_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // release (this workgroup's stores into pinned memory) / acquire (everybody else's, for the one that posts the completion word) at
+        // SYSTEM scope: the counter is the only thing that orders the other workgroups' result stores before the completion word
+        const unsigned before = __hip_atomic_fetch_add(q.done_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
         if (before + 1u - q.done_base == 2u * (unsigned)G) {
             BAState fin = st; fin.cur = 0; fin.pending = 0; p.st[0] = fin; p.st[1] = fin;
             if (q.host_state) {   // straight into pinned host memory: uh_ba_optimize polls host_done instead of synchronising the stream

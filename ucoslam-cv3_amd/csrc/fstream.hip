@@ -155,6 +155,11 @@ int uh_fstream_create(uh_ctx* ctx, uh_orb* ext, uh_knn* tile, uh_bow* voc, const
     UH_REQUIRE(p->world >= 1 && p->world <= 64 && p->rank >= 0 && p->rank < p->world, "uh_fstream_create: rank %d / world %d", p->rank, p->world);
     UH_REQUIRE(p->max_features >= 1 && p->cand_cap >= 1 && p->nn >= 1 && p->nn <= 64, "uh_fstream_create: bad sizes (max_features %d, cand_cap %d, nn %d)",
                p->max_features, p->cand_cap, p->nn);
+    {   // rows per frame = the extractor's feature budget: a mismatch would make the fixed-size message regions disagree with what the extractor writes
+        uh_feat_params efp;
+        if (uh_orb_get_params(ext, &efp) == UH_OK) UH_REQUIRE(efp.maxFeatures == p->max_features, "uh_fstream_create: max_features %d differs from the extractor's maxFeatures %d",
+                                                              p->max_features, efp.maxFeatures);
+    }
     uh_fstream* f = new uh_fstream();
     f->ctx = ctx; f->ext = ext; f->tile = tile; f->voc = voc; f->p = *p;
     f->L = layout(p->max_features, p->cand_cap, p->world, voc != nullptr);
