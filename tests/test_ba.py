@@ -606,4 +606,13 @@ def test_hip_ba_falls_back_to_the_launch_chain_when_the_persistent_kernel_cannot
     assert opt.form() == "persist8"
     opt.optimize()
     assert np.abs(opt.getResults()["state"] - ref["state"]).max() < POSE_TOL
+    if staged:   # a caller that has already remapped the staging block (for the next keyframe) cannot be served by the fallback: refused, not guessed
+        from ucoslam_cv3_amd._lib import UcoslamHipError
+
+        set_()
+        opt.fillStaging(pr)
+        monkeypatch.setenv("UH_BA_FAIL_RESIDENCY", "1")
+        with pytest.raises(UcoslamHipError, match="remapped"):
+            opt.optimize()
+        monkeypatch.delenv("UH_BA_FAIL_RESIDENCY")
     opt.close()

@@ -2213,6 +2213,7 @@ int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, 
         if (e[0] == '1') {
             (void)hipStreamSynchronize(st);   // (the ingest in front of the launch has run)
             b->stage_in_flight = false;
+            b->persist_not_resident = true;
             uh::set_error("uh_ba_optimize: the persistent kernel's workgroups did not all become resident (forced by UH_BA_FAIL_RESIDENCY)");
             return UH_ENODEVICE;
         }
