@@ -546,7 +546,8 @@ def main():
             ovf = int(r["overflow"])
             tt = torch.tensor([ts], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            sharded = {"sharded_frame_ms": round(1e3 * float(tt.item()) / n_s, 4), "sharded_frames_per_s": round(n_s / float(tt.item()), 2),
+            sharded = {"rccl_ranks": stream.comm_ranks(),   # ncclCommCount of the library's own communicator: what the collective really spans
+                       "sharded_frame_ms": round(1e3 * float(tt.item()) / n_s, 4), "sharded_frames_per_s": round(n_s / float(tt.item()), 2),
                        "collectives_per_frame": 1, "message_bytes_per_rank": stream.message_bytes, "train_rows_per_rank": b[rank + 1] - b[rank],
                        "levels_of_rank0": list(parallel.level_ranges(W, H, NLEVELS, SCALE, world)[0]), "overflow": ovf}
             if rank == 0:   # the same frame stream un-sharded on one GPU: one frame per launch sequence + full search (latency form)

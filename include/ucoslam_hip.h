@@ -528,6 +528,7 @@ void*  uh_fstream_recv_buffer(uh_fstream* fs);      /* device, world x message_b
 int    uh_fstream_comm_unique_id(uint8_t id_out[128]);
 int    uh_fstream_comm_init(uh_fstream* fs, const uint8_t id[128]);
 int    uh_fstream_set_comm(uh_fstream* fs, void* nccl_comm);
+int    uh_fstream_comm_ranks(uh_fstream* fs);       /* ncclCommCount of the communicator in use (1 without one); < 0 on error */
 int    uh_fstream_put_message(uh_fstream* fs, int rank, const void* d_message);
 /* step t: this rank's levels [level_first, level_end) of the frame (device image), its tile's accept lists and its fbow slice for frame t-1 */
 int    uh_fstream_local_dev(uh_fstream* fs, const uint8_t* d_frame, int w, int h, size_t stride, int level_first, int level_end);

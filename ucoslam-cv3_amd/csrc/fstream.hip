@@ -107,6 +107,7 @@ struct Rccl {
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
 };
 Rccl g_rccl;
 
@@ -121,6 +122,7 @@ int load_rccl() {
     g_rccl.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(h, "ncclAllGather"));
     g_rccl.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
     g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(h, "ncclGetErrorString"));
+    g_rccl.CommCount = reinterpret_cast<int (*)(void*, int*)>(dlsym(h, "ncclCommCount"));
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
         uh::set_error("uh_fstream: librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy");
         return UH_ENODEVICE;
@@ -205,6 +207,18 @@ int uh_fstream_comm_init(uh_fstream* f, const uint8_t id[128]) {
     if (e) { uh::set_error("ncclCommInitRank(rank %d of %d): %s", f->p.rank, f->p.world, g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); return UH_ENODEVICE; }
     f->comm = c; f->own_comm = true;
     return UH_OK;
+}
+
+// ranks of the communicator the stream gathers over, as RCCL reports it (ncclCommCount); 1 without a communicator (world 1 needs none)
+int uh_fstream_comm_ranks(uh_fstream* f) {
+    UH_REQUIRE(f, "uh_fstream_comm_ranks: NULL");
+    if (!f->comm) return 1;
+    UH_REQUIRE(g_rccl.CommCount || load_rccl() == UH_OK, "uh_fstream_comm_ranks: librccl not loaded");
+    UH_REQUIRE(g_rccl.CommCount, "uh_fstream_comm_ranks: librccl.so lacks ncclCommCount");
+    int n = 0;
+    const int e = g_rccl.CommCount(f->comm, &n);
+    if (e) { uh::set_error("ncclCommCount: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); return UH_ENODEVICE; }
+    return n;
 }
 
 int uh_fstream_set_comm(uh_fstream* f, void* nccl_comm) {

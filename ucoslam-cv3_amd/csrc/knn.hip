@@ -306,8 +306,12 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_search_kernel(
 //  Lists that overflow their capacity (distances descending with the row index) are collected and recomputed by knn_redo_kernel.
 // STREAM (knn_stream_kernel): the lists are consumed WHILE they grow, by replay waves of the same launch on other CUs.  An entry is then
 // launch tag << 32 | distance << 23 | row (a reader validates the tag: no flags, no ordering between words, nothing to clear between
-// launches), stored write-through; after every step that appended, and at the end with bit 31 set, the query's progress word
-// prog[q] = tag << 32 | entries so far follows.
+// launches) and entries travel in PAIRS: record r of query q = the 16 bytes at (r * nq + q) * 16, two tagged 8-byte halves written by ONE
+// 16-byte write-through store (the odd entry waits in a register for its partner; the last record of a list is flushed with an empty
+// second half).  No progress word accompanies the entries — a reader simply tries the next records and takes those whose two tags
+// match; prog[q] = tag << 32 | 1 << 31 | entries is written once, when the scan of the query ends.
+// (Round 3 stored every entry alone — an 8-byte fabric write each — and a progress word after every step that appended: 24.4 MB of
+// WRITE_SIZE for 5 MB of list payload per 8000 x 10 000 launch, and the replay's progress -> entries loads were a dependent pair.)
 template <int QPW, bool STREAM>
 __device__ __forceinline__ void accept_scan(
     const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k, int maxd,
@@ -315,11 +319,9 @@ __device__ __forceinline__ void accept_scan(
     const int lane = threadIdx.x & (kWave - 1);
     const int q0 = __builtin_amdgcn_readfirstlane(wave * QPW);
     if (q0 >= nq) return;
-    auto put = [&](size_t at, int d, int idx) {
-        if constexpr (STREAM) __hip_atomic_store(cand + at, ((uint64_t)tag << 32) | ((uint64_t)(uint32_t)d << 23) | (uint32_t)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else cand[at] = ((uint64_t)(uint32_t)d << 32) | (uint32_t)idx;
-    };
+    auto put = [&](size_t at, int d, int idx) { cand[at] = ((uint64_t)(uint32_t)d << 32) | (uint32_t)idx; };   // (two-launch form)
     uint32_t q[QPW][8];
+    unsigned pend[QPW];   // STREAM: the open record of each query (the first entry of a pair waits here), wave-uniform
     int sv[QPW];    // every 16-lane row: the smallest distances so far, ascending with the lane (INT_MAX where nothing has been seen yet)
     int thr[QPW];   // wave-uniform: the k-th smallest = lane k-1 of a row
     int nc[QPW];
@@ -327,8 +329,25 @@ __device__ __forceinline__ void accept_scan(
     for (int j = 0; j < QPW; ++j) {
         load_query(queries, q0 + j < nq ? q0 + j : nq - 1, q[j]);
         sv[j] = 0x7fffffff; thr[j] = 0x7fffffff;
-        nc[j] = 0;
+        nc[j] = 0; pend[j] = 0;
     }
+    // STREAM: the open record of each query (the first entry of a pair waits here), wave-uniform
+    typedef unsigned int st_u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs_rec = __builtin_amdgcn_make_buffer_rsrc(cand, 0, 0x7FFFFFFF, 0x00020000);
+    auto store_record = [&](int rec, int qj, unsigned w0, unsigned w1) {   // aux 16 = sc1: write-through, like ba_persist.hpp's tst()
+        if (lane == 0) {
+            const st_u32x4 w = {w0, tag, w1, tag};
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs_rec, (int)(((size_t)rec * nq + qj) * 16), 0, 16);
+        }
+    };
+    // one accepted entry (wave-uniform d, idx), in list order; nc[j] counts it whether it is stored or not (overflow is detected by the count)
+    auto append = [&](int j, int qj, int d, int idx) {
+        const int p = nc[j]++;
+        if (p >= cap) return;
+        const unsigned w = ((unsigned)d << 23) | (unsigned)idx;
+        if (!(p & 1)) pend[j] = w;
+        else store_record(p >> 1, qj, pend[j], w);
+    };
     const unsigned long long lt = (1ull << lane) - 1ull;
     // sorted insert of an accepted distance: every lane whose value exceeds d takes max(left neighbour, d) — its neighbour's value if that
     // also exceeds d, else d itself; the largest value falls off the end of the row.  Four vector instructions + one v_readlane.
@@ -352,19 +371,22 @@ __device__ __forceinline__ void accept_scan(
                 const int dl = rl(d, l);
                 if (dl >= thr[j]) continue;
                 const int il = rl(idx, l);
-                if (lane == 0 && nc[j] < cap) put((size_t)nc[j] * nq + qj, dl, il);
-                nc[j]++;
+                if constexpr (STREAM) append(j, qj, dl, il);
+                else { if (lane == 0 && nc[j] < cap) put((size_t)nc[j] * nq + qj, dl, il); nc[j]++; }
                 tighten(j, dl);
             }
             return;
         }
-        const int pos = nc[j] + __popcll(m & lt);
-        if (pass && pos < cap) put((size_t)pos * nq + qj, d, idx);
-        nc[j] += __popcll(m);
+        if constexpr (!STREAM) {
+            const int pos = nc[j] + __popcll(m & lt);
+            if (pass && pos < cap) put((size_t)pos * nq + qj, d, idx);
+            nc[j] += __popcll(m);
+        }
         while (m) {
             const int l = __builtin_ctzll(m);
             m &= m - 1;
             const int dl = rl(d, l);
+            if constexpr (STREAM) append(j, qj, dl, rl(idx, l));   // every row below the step's initial threshold is listed (in row order)
             if (dl >= thr[j]) continue;
             tighten(j, dl);
         }
@@ -396,12 +418,8 @@ __device__ __forceinline__ void accept_scan(
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) { d[u] = hamming256(a0[u], a1[u], q[j]); any = any || d[u] < tj; }
             if (__ballot(any) == 0) continue;
-            const int before = nc[j];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) feed(j, d[u], b + u * kWave + lane, q0 + j < nq, q0 + j < nq ? q0 + j : 0, u == 0 && b == t0);
-            if constexpr (STREAM)
-                if (nc[j] != before && lane == 0 && q0 + j < nq)
-                    __hip_atomic_store(prog + q0 + j, ((uint64_t)tag << 32) | (uint32_t)nc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
     {
@@ -429,9 +447,12 @@ __device__ __forceinline__ void accept_scan(
     }
 #pragma unroll
     for (int j = 0; j < QPW; ++j)
-        if (q0 + j < nq && lane == 0) {
-            if constexpr (STREAM) __hip_atomic_store(prog + q0 + j, ((uint64_t)tag << 32) | 0x80000000u | (uint32_t)nc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else counts[q0 + j] = nc[j];
+        if (q0 + j < nq) {
+            if constexpr (STREAM) {
+                const int stored = nc[j] < cap ? nc[j] : cap;
+                if (stored & 1) store_record(stored >> 1, q0 + j, pend[j], 0xFFFFFFFFu);   // the odd tail: second half = "no entry"
+                if (lane == 0) __hip_atomic_store(prog + q0 + j, ((uint64_t)tag << 32) | 0x80000000u | (uint32_t)nc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (lane == 0) counts[q0 + j] = nc[j];
         }
 }
 template <int QPW>
@@ -637,8 +658,9 @@ __device__ __forceinline__ void replay_staged(unsigned (&hw)[K], int& size, cons
 // The scanning waves wait for nobody, the replay workgroups are a small fixed part of the grid and come FIRST (resident before any
 // scan workgroup could crowd them out), so the launch always makes progress; a replay lane that sees no progress for two seconds hands
 // its query to knn_redo_kernel (as it does with an overflowed list), so even then the rows are right.
-// Protocol: accept_scan<., true>.  A replay wave polls its 64 progress words (one coalesced load), fetches the entries that are new
-// (at most kStreamStage per lane and round, all loads in flight together), keeps the prefix whose tags match, stages it in LDS and pushes it.
+// Protocol: accept_scan<., true>.  A replay wave fetches, per lane and round, the query's closing word and its next records (two, or
+// kStreamStage / 2 when the previous round filled the short fetch; all loads in flight together, none depends on another), keeps the prefix
+// of records whose two tags match, stages their entries in LDS and pushes them.
 constexpr int kStreamStage = 16;
 constexpr long long kStreamTimeout = 200000000ll;   // 2 s of the 100 MHz wall clock
 template <int K>
@@ -657,58 +679,61 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     unsigned* stage = s_stage + lane;
     const int qi = blockIdx.x * kWave + threadIdx.x;
     const bool haveq = qi < nq;
-    const uint64_t* col = cand + (haveq ? qi : 0);
     const uint64_t* pq = prog + (haveq ? qi : 0);
+    typedef unsigned int ld_u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs_rec = __builtin_amdgcn_make_buffer_rsrc(cand, 0, 0x7FFFFFFF, 0x00020000);
+    const int nrec_cap = (cap + 1) >> 1;                  // records per list
+    constexpr int kRec = kStreamStage / 2;                 // records fetched per lane and round (all loads in flight together)
     unsigned hw[K];
 #pragma unroll
     for (int i = 0; i < K; i++) hw[i] = 0;
-    int size = 0, e = 0;
+    int size = 0, r = 0;                                   // r: records consumed
     bool fin = !haveq, over = false;
+    int deep = 0;                                          // wave-uniform: the previous round filled its short fetch -> fetch the long one
     long long tlast = wall_clock64();
     while (__ballot(!fin) != 0) {
+        // the closing word (written once, when the query's scan ends) and the next records, all loads independent of each other
         const uint64_t pw = __hip_atomic_load(pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool ok = !fin && (unsigned)(pw >> 32) == tag;
-        const int nc = ok ? (int)((unsigned)pw & 0x7fffffffu) : 0;
-        const bool closed = ok && ((unsigned)pw & 0x80000000u) != 0;
+        ld_u32x4 v[kRec];
+        const int qv = haveq ? qi : 0;
+#pragma unroll
+        for (int u = 0; u < 2; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, (int)(((size_t)min(r + u, nrec_cap - 1) * nq + qv) * 16), 0, 16);   // aux 16 = sc1
+        if (deep) {
+#pragma unroll
+            for (int u = 2; u < kRec; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, (int)(((size_t)min(r + u, nrec_cap - 1) * nq + qv) * 16), 0, 16);
+        } else {
+#pragma unroll
+            for (int u = 2; u < kRec; u++) v[u] = ld_u32x4{0u, 0u, 0u, 0u};
+        }
+        const bool closed = !fin && (unsigned)(pw >> 32) == tag && ((unsigned)pw & 0x80000000u) != 0;
+        const int nc = closed ? (int)((unsigned)pw & 0x7fffffffu) : 0;
         if (closed && nc > cap) { over = true; fin = true; }
-        const int want = fin ? 0 : min(nc, cap) - e;
-        int most = want;
+        const int total = closed ? (min(nc, cap) + 1) >> 1 : nrec_cap;   // records this list will hold (once known)
+        int np = 0;
+        bool run = !fin;
+#pragma unroll
+        for (int u = 0; u < kRec; u++) {
+            run = run && r + u < total && v[u].y == tag && v[u].w == tag;   // both halves of the record carry this launch's tag
+            np += run ? 1 : 0;
+            stage[(2 * u) * kWave] = run ? v[u].x : kNoEntry;
+            stage[(2 * u + 1) * kWave] = run ? v[u].z : kNoEntry;
+        }
+        int most = np;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) most = max(most, __shfl_xor(most, o));
         most = __builtin_amdgcn_readfirstlane(most);
+        deep = most >= 2 ? 1 : 0;
         if (most == 0) {
-            fin = fin || closed;
+            if (closed && r >= total) fin = true;
             if (wall_clock64() - tlast > kStreamTimeout) { over = over || !fin; fin = true; }
-            __builtin_amdgcn_s_sleep(2);
+            if (__ballot(!fin) != 0) __builtin_amdgcn_s_sleep(2);
             continue;
         }
-        uint64_t v[kStreamStage];
-#pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = __hip_atomic_load(col + (size_t)min(e + u, cap - 1) * nq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (most > 4) {   // (a wave that keeps up with its scans sees a few new entries per round)
-#pragma unroll
-            for (int u = 4; u < kStreamStage; u++) v[u] = __hip_atomic_load(col + (size_t)min(e + u, cap - 1) * nq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-#pragma unroll
-            for (int u = 4; u < kStreamStage; u++) v[u] = 0;
-        }
-        int np = 0;
-        bool run = true;
-#pragma unroll
-        for (int u = 0; u < kStreamStage; u++) {
-            run = run && u < want && (unsigned)(v[u] >> 32) == tag;
-            np += run ? 1 : 0;
-            stage[u * kWave] = run ? (unsigned)v[u] : kNoEntry;
-        }
-        int steps = np;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) steps = max(steps, __shfl_xor(steps, o));
-        steps = __builtin_amdgcn_readfirstlane(steps);
-        if (steps) tlast = wall_clock64();
+        tlast = wall_clock64();
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): a lane reads back only what it staged itself
-        replay_staged<K>(hw, size, stage, steps, !fin);
-        e += np;
-        if (closed && e >= min(nc, cap)) fin = true;
+        replay_staged<K>(hw, size, stage, 2 * most, !fin);
+        r += np;
+        if (closed && r >= total) fin = true;
     }
     if (over) redo_list[atomicAdd(redo_count, 1)] = qi;
     heap_write_row<K>(hw, size, sorted, haveq && !over, qi, indices, distances);
@@ -1307,7 +1332,7 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
         const int cap = std::min(std::min(std::max(((int)(1.6 * expect) + 32 + 31) & ~31, 32), std::max((nrows + 31) & ~31, 32)), 256);
         int rc;
         if ((rc = idx->list_buf.reserve((size_t)nq * cap * 8 + (size_t)nq * 16 + 256))) return rc;
-        if (nn >= idx->stream_min_nn && idx->accept_qpw == 2) {
+        if (nn >= idx->stream_min_nn && idx->accept_qpw == 2 && (size_t)nq * cap * 8 < ((size_t)1 << 31)) {   // (record offsets are 32-bit buffer offsets)
             uint64_t* d_cand = idx->list_buf.as<uint64_t>();
             uint64_t* d_prog = d_cand + (size_t)nq * cap;          // (list_buf holds tagged words only: any layout of an earlier launch is harmless)
             const unsigned had = idx->redo_buf.gen;

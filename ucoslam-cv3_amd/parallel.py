@@ -309,6 +309,7 @@ def _declare_fstream(L, sig):
     sig("uh_fstream_comm_unique_id", I, VP)
     sig("uh_fstream_comm_init", I, VP, VP)
     sig("uh_fstream_set_comm", I, VP, VP)
+    sig("uh_fstream_comm_ranks", I, VP)
     sig("uh_fstream_put_message", I, VP, I, VP)
     sig("uh_fstream_local_dev", I, VP, VP, I, I, C.c_size_t, I, I)
     sig("uh_fstream_exchange", I, VP)
@@ -370,6 +371,13 @@ class ShardedFrameStreamDev:
         dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         buf = (C.c_uint8 * 128).from_buffer_copy(ident[0])
         check(lib().uh_fstream_comm_init(self._h, buf))
+
+    def comm_ranks(self) -> int:
+        """Ranks of the RCCL communicator in use (ncclCommCount); 1 when the stream runs without one."""
+        n = lib().uh_fstream_comm_ranks(self._h)
+        if n < 0:
+            check(n)
+        return n
         return self
 
     def local(self, frame):
