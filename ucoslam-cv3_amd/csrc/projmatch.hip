@@ -237,6 +237,9 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
                                                                int n_nodes, int levels, int* overflow) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x, g = lane / kGroup, gl = lane % kGroup, gw = (lane & 63) / kGroup;   // gw: group within its wave
+    // measurement (UH_PM_CLK): shader-clock stamps of workgroup 0, thread 0 in the status block behind the overflow word
+    long long* const clk = (overflow[1] == 0x434c4b && blockIdx.x == 0 && threadIdx.x == 0) ? reinterpret_cast<long long*>(overflow + 4) : nullptr;
+    if (clk) clk[0] = __builtin_readcyclecounter();
     const int n = f.n_kpts;
     size_t off = 0;
     KdNodeDev* s_nodes = reinterpret_cast<KdNodeDev*>(smem);
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
         }
         __syncthreads();
     }
+    if (clk) clk[1] = __builtin_readcyclecounter();
   for (int chunk = blockIdx.x; chunk * kGroupsPerWave < mp.n; chunk += gridDim.x) {
     const int m = chunk * kGroupsPerWave + g;
     const bool live = m < mp.n;
@@ -436,7 +440,9 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
             cur = go_left ? nd.left : nd.right;   // best child, same mindistsq
         }
     }
+    if (clk) { clk[2] = __builtin_readcyclecounter(); clk[5] = ncand; }
     if (!ovf) drain(ncand);
+    if (clk) clk[3] = __builtin_readcyclecounter();
     if (ovf) { if (gl == 0) *overflow = 1; best_kp = -1; }
     if constexpr (PREV) { if (best_kp != -1 && !(best_d < 0.7 * second_d)) best_kp = -1; }
     else if (best_kp != -1 && bestLevel2 == bestLevel && best_d > 0.8 * second_d) best_kp = -1;
@@ -445,6 +451,7 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
         mp.best_dist[m] = (PREV && best_kp < 0) ? 3.402823466e+38f : best_d;
         if (mp.visible) mp.visible[m] = vis ? 1 : 0;
     }
+    if (clk) clk[4] = __builtin_readcyclecounter();
   }
 }
 
@@ -595,6 +602,8 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
         UH_HIP_CHECK(hipMemsetAsync(base, 0, 256, st));
         h->ovf_zeroed = true; h->ovf_gen = h->d_points.gen;
     }
+    static const bool pm_clk = getenv("UH_PM_CLK") != nullptr;
+    if (pm_clk) { const unsigned magic[2] = {0u, 0x434c4bu}; UH_HIP_CHECK(hipMemcpyAsync(base, magic, 8, hipMemcpyHostToDevice, st)); }
     {   // one pinned staging block (the previous call's launches are complete: its results were awaited), one wide copy launch
         if ((rc = h->h_in.reserve(o_bk))) return rc;
         char* hi = h->h_in.host<char>();
@@ -650,6 +659,12 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
     const unsigned long long word = ++h->seq;
     if ((rc = uh::publish16(h->ctx, h->h_out.dev<char>() + 64, base + o_bk, out_bytes, reinterpret_cast<unsigned*>(base + o_ovf), h->h_out.dev<unsigned long long>(), word))) return rc;
     if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(h->h_out.host<char>()), word, st, "uh_projmatch_match"))) return rc;
+    if (pm_clk) {
+        long long c[6];
+        UH_HIP_CHECK(hipMemcpy(c, base + 16, sizeof(c), hipMemcpyDeviceToHost));
+        fprintf(stderr, "projmatch%s workgroup 0 cycles: stage %lld  visibility+walk %lld  final drain (%lld hits) %lld  tail %lld  total %lld\n", prev ? "_prev" : "", c[1] - c[0], c[2] - c[1],
+                c[5], c[3] - c[2], c[4] - c[3], c[4] - c[0]);
+    }
     const char* ho = h->h_out.host<char>() + 64;
     const int* bk = (const int*)ho;
     const float* bd = (const float*)(ho + (o_bd - o_bk));
