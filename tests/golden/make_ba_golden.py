@@ -13,17 +13,21 @@ import synth  # noqa: E402
 
 ref = oracle_lib.load_ref("g2o")
 assert ref is not None
-pr = synth.ba_problem(8, 600, seed=77, nfixed=2)
+# The first fixture's information scalars are full doubles 1 / 1.2^octave (synth.ba_problem(double_weights=True)): not float-exact, unlike
+# the reference's (double)(float) values — on purpose, it is the test of the 24-byte observation records.  The generator reproduces the
+# committed file bit for bit (checked below against the file it is about to replace).
+pr = synth.ba_problem(8, 600, seed=77, nfixed=2, double_weights=True)
 out = oracle_lib.ba_optimize_ref(ref, pr, 5)
 save = {f"in_{k}": pr[k] for k in ("poses", "fixed", "intr", "points", "obs_pt", "obs_kf", "obs_uv", "obs_w")}
 save.update(ref_state=out["state"], ref_poses=out["poses"], ref_points=out["points"], ref_bad=out["bad"], ref_iters=out["iters"],
             ref_chi2=out["chi2"])
-# The committed ba_golden.npz was generated when synth.ba_problem still produced full-double information weights (1 / 1.2^octave); the
-# generator has since moved to the reference's (double)(float) weights.  The old fixture is kept on purpose: its weights are not
-# float-exact, which makes it the test of the 24-byte observation records.  Pass --first to regenerate it with today's weights.
-if "--first" in sys.argv:
-    np.savez_compressed(os.path.join(HERE, "ba_golden.npz"), **save)
-    print("wrote ba_golden.npz", pr["K"], pr["P"], pr["E"])
+path = os.path.join(HERE, "ba_golden.npz")
+if os.path.exists(path):
+    old = np.load(path)
+    diff = [k for k in save if k not in old.files or not np.array_equal(old[k], save[k])]
+    print("ba_golden.npz:", "regenerated bit for bit" if not diff else f"DIFFERS from the committed file in {diff}")
+np.savez_compressed(path, **save)
+print("wrote ba_golden.npz", pr["K"], pr["P"], pr["E"])
 
 # Second fixture: problems Levenberg-Marquardt does NOT sail through (synth.ba_hard_problem: rejected trials, lambda factors other than
 # 1/3, passes ended early) — the real g2o's answers for the branches the first fixture never takes.  Seeds chosen among those on which

@@ -94,9 +94,11 @@ def _scale_f32(octave, scale_factor=1.2):
 
 
 def ba_problem(K=10, P=3000, seed=0, nfixed=2, outlier_frac=0.02, pose_noise=0.01, point_noise=0.05, pix_noise=0.5,
-               w=1241, h=376):
+               w=1241, h=376, double_weights=False):
     """Synthetic local BA: K keyframes on a line (baseline 0.3 m), KITTI intrinsics, P points in front,
-    observations where in-frame, octave uniform 0..7 -> information 1.2^-octave, first `nfixed` keyframes fixed."""
+    observations where in-frame, octave uniform 0..7 -> information 1.2^-octave, first `nfixed` keyframes fixed.
+    double_weights=True: the information scalars as full doubles 1 / 1.2^octave (not float-exact, unlike the reference's
+    (double)(float) values) — the form tests/golden/ba_golden.npz was recorded with; it exercises the 24-byte observation records."""
     rng = np.random.default_rng(seed)
     fx = fy = 718.856
     cx, cy = 607.19, 185.22
@@ -119,7 +121,7 @@ def ba_problem(K=10, P=3000, seed=0, nfixed=2, outlier_frac=0.02, pose_noise=0.0
                 noise = rng.normal(0, pix_noise, 2)
                 if rng.random() < outlier_frac:
                     noise += rng.normal(0, 25, 2)
-                obs_pt.append(p); obs_kf.append(k); obs_uv.append([u + noise[0], v + noise[1]]); obs_w.append(float(np.float32(1.0 / float(_scale_f32(octave)))))   # (double)(float)(1./f): the reference's vector<float> _InvScaleFactors
+                obs_pt.append(p); obs_kf.append(k); obs_uv.append([u + noise[0], v + noise[1]]); obs_w.append(1.0 / (1.2 ** octave) if double_weights else float(np.float32(1.0 / float(_scale_f32(octave)))))   # (double)(float)(1./f): the reference's vector<float> _InvScaleFactors
     poses = []
     fixed = np.zeros(K, np.uint8)
     fixed[:nfixed] = 1
