@@ -529,7 +529,12 @@ def main():
             ext_s = ORBextractor.create(ctx)
             # the stream below Python (uh_fstream_*, csrc/fstream.hip): producers write into the message, ONE RCCL all-gather per frame through
             # the library's own communicator on the tracking stream, the replay reads the gathered lists in place, no host synchronisation
-            stream = parallel.ShardedFrameStreamDev(ctx, ext_s, fp, tile, NN, MAX_FEATURES, cand_cap=64, rank=rank, world=world, device=dev)
+            # accept-list capacity per (query, tile): a tile scanned from an empty heap accepts k (1 + ln(rows / k)) rows on average (a record
+            # process, spread ~ its square root): mean + 4 sigma, rounded up to 16 — a list that overflows would invalidate the frame
+            rows_t = max(b[rank + 1] - b[rank], 1)
+            exp_acc = NN * (1.0 + np.log(max(rows_t / NN, 1.0)))
+            cand_cap = int(-(-(exp_acc + 4.0 * np.sqrt(exp_acc)) // 16) * 16)
+            stream = parallel.ShardedFrameStreamDev(ctx, ext_s, fp, tile, NN, MAX_FEATURES, cand_cap=cand_cap, rank=rank, world=world, device=dev)
             if world > 1:
                 stream.init_comm()
             sframes = [torch.from_numpy(synth.frame(W, H, seed=9000 + f, shift=(2 * f, f))).to(dev) for f in range(4)]
@@ -548,7 +553,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             sharded = {"rccl_ranks": stream.comm_ranks(),   # ncclCommCount of the library's own communicator: what the collective really spans
                        "sharded_frame_ms": round(1e3 * float(tt.item()) / n_s, 4), "sharded_frames_per_s": round(n_s / float(tt.item()), 2),
-                       "collectives_per_frame": 1, "message_bytes_per_rank": stream.message_bytes, "train_rows_per_rank": b[rank + 1] - b[rank],
+                       "collectives_per_frame": 1, "message_bytes_per_rank": stream.message_bytes, "cand_cap": cand_cap, "train_rows_per_rank": b[rank + 1] - b[rank],
                        "levels_of_rank0": list(parallel.level_ranges(W, H, NLEVELS, SCALE, world)[0]), "overflow": ovf}
             if rank == 0:   # the same frame stream un-sharded on one GPU: one frame per launch sequence + full search (latency form)
                 full = Index(ctx).build(torch.from_numpy(map0_np).to(dev))

@@ -312,10 +312,15 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_search_kernel(
 // match; prog[q] = tag << 32 | 1 << 31 | entries is written once, when the scan of the query ends.
 // (Round 3 stored every entry alone — an 8-byte fabric write each — and a progress word after every step that appended: 24.4 MB of
 // WRITE_SIZE for 5 MB of list payload per 8000 x 10 000 launch, and the replay's progress -> entries loads were a dependent pair.)
-template <int QPW, bool STREAM>
+// MODE 0: two-launch form (entry-major superset lists); 1: STREAM (tagged pair records, see above); 2: SHARD — the list of a tile scan
+// (uh_knn_scan_shard_dev): row-major [query][cap] words dist << 32 | global row, EXACTLY the rows the reference's heap would accept
+// on this tile (the serial walk over a step's passing lanes applies the tightened threshold before listing a row), in row order.
+enum : int { kScanTwoLaunch = 0, kScanStream = 1, kScanShard = 2 };
+template <int QPW, int MODE>
 __device__ __forceinline__ void accept_scan(
     const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k, int maxd,
     uint64_t* __restrict__ cand, int32_t* __restrict__ counts, int cap, int wave, uint64_t* __restrict__ prog, unsigned tag) {
+    constexpr bool STREAM = MODE == kScanStream, SHARD = MODE == kScanShard;
     const int lane = threadIdx.x & (kWave - 1);
     const int q0 = __builtin_amdgcn_readfirstlane(wave * QPW);
     if (q0 >= nq) return;
@@ -344,6 +349,7 @@ __device__ __forceinline__ void accept_scan(
     auto append = [&](int j, int qj, int d, int idx) {
         const int p = nc[j]++;
         if (p >= cap) return;
+        if constexpr (SHARD) { if (lane == 0) cand[(size_t)qj * cap + p] = ((uint64_t)(uint32_t)d << 32) | (uint32_t)idx; return; }
         const unsigned w = ((unsigned)d << 23) | (unsigned)idx;
         if (!(p & 1)) pend[j] = w;
         else store_record(p >> 1, qj, pend[j], w);
@@ -371,13 +377,13 @@ __device__ __forceinline__ void accept_scan(
                 const int dl = rl(d, l);
                 if (dl >= thr[j]) continue;
                 const int il = rl(idx, l);
-                if constexpr (STREAM) append(j, qj, dl, il);
+                if constexpr (STREAM || SHARD) append(j, qj, dl, il);
                 else { if (lane == 0 && nc[j] < cap) put((size_t)nc[j] * nq + qj, dl, il); nc[j]++; }
                 tighten(j, dl);
             }
             return;
         }
-        if constexpr (!STREAM) {
+        if constexpr (!STREAM && !SHARD) {
             const int pos = nc[j] + __popcll(m & lt);
             if (pass && pos < cap) put((size_t)pos * nq + qj, d, idx);
             nc[j] += __popcll(m);
@@ -388,6 +394,7 @@ __device__ __forceinline__ void accept_scan(
             const int dl = rl(d, l);
             if constexpr (STREAM) append(j, qj, dl, rl(idx, l));   // every row below the step's initial threshold is listed (in row order)
             if (dl >= thr[j]) continue;
+            if constexpr (SHARD) append(j, qj, dl, rl(idx, l));    // exactly the accepted rows
             tighten(j, dl);
         }
     };
@@ -452,7 +459,7 @@ __device__ __forceinline__ void accept_scan(
                 const int stored = nc[j] < cap ? nc[j] : cap;
                 if (stored & 1) store_record(stored >> 1, q0 + j, pend[j], 0xFFFFFFFFu);   // the odd tail: second half = "no entry"
                 if (lane == 0) __hip_atomic_store(prog + q0 + j, ((uint64_t)tag << 32) | 0x80000000u | (uint32_t)nc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (lane == 0) counts[q0 + j] = nc[j];
+            } else if (lane == 0) counts[q0 + j] = nc[j];   // (two-launch and shard forms)
         }
 }
 template <int QPW>
@@ -460,7 +467,13 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_accept_kernel(
     const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k, int maxd,
     uint64_t* __restrict__ cand, int32_t* __restrict__ counts, int cap, int* __restrict__ redo_count) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *redo_count = 0;   // (the replay launch behind this one counts the overflowed lists)
-    accept_scan<QPW, false>(train, t0, t1, queries, nq, k, maxd, cand, counts, cap, blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nullptr, 0u);
+    accept_scan<QPW, kScanTwoLaunch>(train, t0, t1, queries, nq, k, maxd, cand, counts, cap, blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nullptr, 0u);
+}
+// the tile scan of the sharded search for k <= 16: two queries per wave, threshold kept sorted along a DPP row (no heap pushes in the scan)
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_scan_shard2_kernel(
+    const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k, int maxd,
+    uint64_t* __restrict__ cand, int32_t* __restrict__ counts, int cap) {
+    accept_scan<2, kScanShard>(train, t0, t1, queries, nq, k, maxd, cand, counts, cap, blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nullptr, 0u);
 }
 
 constexpr int kRpK = 16;   // the two-phase form serves k <= 16
@@ -669,7 +682,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     uint64_t* __restrict__ cand, uint64_t* __restrict__ prog, int cap, unsigned tag, int nrep,
     int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ redo_list, int* __restrict__ redo_count, int* __restrict__ redo_next) {
     if ((int)blockIdx.x >= nrep) {
-        accept_scan<2, true>(train, t0, t1, queries, nq, K, maxd, cand, nullptr, cap, (int)blockIdx.x - nrep, prog, tag);
+        accept_scan<2, kScanStream>(train, t0, t1, queries, nq, K, maxd, cand, nullptr, cap, (int)blockIdx.x - nrep, prog, tag);
         return;
     }
     __shared__ unsigned s_stage[kStreamStage * kWave];
@@ -781,6 +794,58 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
         heap_push_wave<K>(hw, size, acc, cw);
     }
     heap_write_row<K>(hw, size, sorted, haveq && !over, qi, indices, distances);
+}
+
+// Replay of the gathered tile lists (uh_knn_replay_tiles*_dev) for k <= 16: ONE LANE PER QUERY, the heap in registers like
+// knn_replay_lane_kernel, shard after shard (= global row order).  A shard's lists are row-major [query][cap] words dist << 32 | row;
+// a lane's list is staged in LDS with all its loads in flight (one memory round trip per shard and wave).  A list that overflowed its
+// capacity sets *overflow (tile-only ranks cannot rescan another rank's rows).  The wave-per-query replay (knn_replay_kernel: ~1000
+// cycles of cross-lane traffic per accepted push) stays for k > 16 and for the form that rescans.
+template <int K>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) void knn_replay_shards_lane_kernel(
+    const uint64_t* __restrict__ cand_all, size_t cand_shard_stride, const int32_t* __restrict__ counts_all, size_t count_shard_stride, int nshards,
+    int nq, int sorted, int maxd, int cap, int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ overflow) {
+    extern __shared__ uint64_t s_list[];   // [cap][64]
+    const int qi = blockIdx.x * kWave + threadIdx.x;
+    const bool haveq = qi < nq;
+    const int qv = haveq ? qi : 0;
+    unsigned hw[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) hw[i] = 0;
+    int size = 0;
+    bool over = false;
+    for (int s = 0; s < nshards; ++s) {
+        const int cnt_raw = haveq ? counts_all[(size_t)s * count_shard_stride + qv] : 0;
+        if (cnt_raw > cap) over = true;
+        const int cnt = cnt_raw > cap ? 0 : cnt_raw;
+        int maxcnt = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, o));
+        maxcnt = __builtin_amdgcn_readfirstlane(maxcnt);
+        if (maxcnt == 0) continue;
+        const uint64_t* row = cand_all + (size_t)s * cand_shard_stride + (size_t)qv * cap;
+        for (int e0 = 0; e0 < maxcnt; e0 += 32) {
+            uint64_t v[32];
+#pragma unroll
+            for (int u = 0; u < 32; u++) v[u] = row[min(e0 + u, cap - 1)];
+#pragma unroll
+            for (int u = 0; u < 32; u++) if (e0 + u < maxcnt) s_list[(e0 + u) * kWave + threadIdx.x] = v[u];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the lane reads back only what it wrote itself
+        uint64_t nxt = s_list[threadIdx.x];
+        for (int e = 0; e < maxcnt; e++) {
+            const uint64_t cur = nxt;
+            nxt = s_list[min(e + 1, maxcnt - 1) * kWave + threadIdx.x];
+            const int d = (int)(cur >> 32);
+            const unsigned cw = ((unsigned)d << 23) | (unsigned)(uint32_t)cur;
+            const bool valid = e < cnt && !(maxd >= 0 && maxd < d);       // resultset.h:66
+            const bool acc = valid && (size < K || dist_less(cw, hw[0]));   // :67-69
+            if (!__ballot(acc)) continue;
+            heap_push_wave<K>(hw, size, acc, cw);
+        }
+    }
+    if (over && overflow) atomicOr(overflow, 1);
+    heap_write_row<K>(hw, size, sorted, haveq, qi, indices, distances);
 }
 
 // the (rare) queries whose accept list overflowed: the fused one-wave search, over a compacted list
@@ -1219,6 +1284,25 @@ static void launch_replay(uh_knn* idx, dim3 grid, dim3 block, const ShardBounds&
     else UH_LAUNCH(idx->ctx, knn_replay_kernel<6>, grid, block, 0, idx->d_train, sb, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_cand, d_counts, cap, d_indices, d_distances, d_overflow, cand_stride, count_stride);
 }
 
+// tile lists -> rows with one lane per query (k <= 16, rows below 2^23, no rescan); false: the caller uses the wave-per-query replay
+static bool launch_replay_lanes(uh_knn* idx, int nq, int nn, int sorted, int max_dist, const uint64_t* d_cand, size_t cand_stride, const int32_t* d_counts,
+                                size_t count_stride, int nshards, int cap, int32_t* d_indices, int32_t* d_distances, int* d_overflow) {
+    if (nn > kRpK || cap > 256 || getenv("UH_KNN_SHARD_FORM")) return false;   // (env: the A/B against the wave-per-query kernels)
+    if (!cand_stride) cand_stride = (size_t)nq * cap;
+    if (!count_stride) count_stride = (size_t)nq;
+    const dim3 grid(uh_div_up(nq, kWave)), block(kWave);
+    const size_t lds = (size_t)cap * kWave * 8;
+#define UH_KNN_RPS(K) case K: { static bool attr##K = false; if (!attr##K) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_replay_shards_lane_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * kWave * 8); attr##K = true; } \
+        UH_LAUNCH(idx->ctx, knn_replay_shards_lane_kernel<K>, grid, block, lds, d_cand, cand_stride, d_counts, count_stride, nshards, nq, sorted ? 1 : 0, max_dist, cap, d_indices, d_distances, d_overflow); } break
+    switch (nn) {
+        UH_KNN_RPS(1); UH_KNN_RPS(2); UH_KNN_RPS(3); UH_KNN_RPS(4); UH_KNN_RPS(5); UH_KNN_RPS(6); UH_KNN_RPS(7); UH_KNN_RPS(8);
+        UH_KNN_RPS(9); UH_KNN_RPS(10); UH_KNN_RPS(11); UH_KNN_RPS(12); UH_KNN_RPS(13); UH_KNN_RPS(14); UH_KNN_RPS(15); UH_KNN_RPS(16);
+        default: return false;
+    }
+#undef UH_KNN_RPS
+    return true;
+}
+
 extern "C" {
 
 int uh_knn_create(uh_ctx* ctx, uh_knn** out) {
@@ -1461,6 +1545,13 @@ int uh_knn_scan_shard_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn,
     dim3 grid(uh_div_up(nq, kWavesPerBlock)), block(kWave * kWavesPerBlock);
     // rows [shard_begin, shard_end) of this index carry the global indices row_offset + row: the kernel indexes a virtual base that
     // lies row_offset rows in front of the tile (only rows inside the tile are ever addressed)
+    if (nn <= kRpK && (long long)idx->row_offset + idx->shard_end <= (1 << 23) && !getenv("UH_KNN_SHARD_FORM")) {   // the threshold-only scan, two queries per wave
+        const dim3 g2(uh_div_up(uh_div_up(nq, 2), kWavesPerBlock));
+        UH_LAUNCH(idx->ctx, knn_scan_shard2_kernel, g2, block, 0, idx->d_train - (size_t)idx->row_offset * 32, idx->row_offset + idx->shard_begin,
+                  idx->row_offset + idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
+        UH_HIP_CHECK(hipGetLastError());
+        return UH_OK;
+    }
     UH_LAUNCH(idx->ctx,knn_scan_shard_kernel, grid, block, 0, idx->d_train - (size_t)idx->row_offset * 32, idx->row_offset + idx->shard_begin,
                        idx->row_offset + idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
     UH_HIP_CHECK(hipGetLastError());
@@ -1500,7 +1591,8 @@ int uh_knn_replay_tiles_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int n
     for (int s = 0; s <= nshards; ++s) sb.b[s] = 0;   // never used: there is no rescan in this form
     UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
     dim3 grid(uh_div_up(nq, kWavesPerBlock)), block(kWave * kWavesPerBlock);
-    launch_replay(idx, grid, block, sb, d_queries, nq, nn, sorted, max_dist, d_cand_all, d_counts_all, cap, d_indices, d_distances, (int*)d_overflow);
+    if (!launch_replay_lanes(idx, nq, nn, sorted, max_dist, d_cand_all, 0, d_counts_all, 0, nshards, cap, d_indices, d_distances, (int*)d_overflow))
+        launch_replay(idx, grid, block, sb, d_queries, nq, nn, sorted, max_dist, d_cand_all, d_counts_all, cap, d_indices, d_distances, (int*)d_overflow);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
 }
@@ -1521,7 +1613,8 @@ int uh_knn_replay_tiles_strided_dev(uh_knn* idx, const uint8_t* d_queries, int n
     for (int s = 0; s <= nshards; ++s) sb.b[s] = 0;
     UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
     dim3 grid(uh_div_up(nq, kWavesPerBlock)), block(kWave * kWavesPerBlock);
-    launch_replay(idx, grid, block, sb, d_queries, nq, nn, sorted, max_dist, d_cand_all, d_counts_all, cap, d_indices, d_distances, (int*)d_overflow, cand_stride, count_stride);
+    if (!launch_replay_lanes(idx, nq, nn, sorted, max_dist, d_cand_all, cand_stride, d_counts_all, count_stride, nshards, cap, d_indices, d_distances, (int*)d_overflow))
+        launch_replay(idx, grid, block, sb, d_queries, nq, nn, sorted, max_dist, d_cand_all, d_counts_all, cap, d_indices, d_distances, (int*)d_overflow, cand_stride, count_stride);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
 }

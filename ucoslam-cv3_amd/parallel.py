@@ -371,14 +371,16 @@ class ShardedFrameStreamDev:
         dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         buf = (C.c_uint8 * 128).from_buffer_copy(ident[0])
         check(lib().uh_fstream_comm_init(self._h, buf))
+        return self
 
     def comm_ranks(self) -> int:
         """Ranks of the RCCL communicator in use (ncclCommCount); 1 when the stream runs without one."""
+        from ._lib import check, lib
+
         n = lib().uh_fstream_comm_ranks(self._h)
         if n < 0:
             check(n)
         return n
-        return self
 
     def local(self, frame):
         from ._lib import check, dev_ptr, lib
