@@ -5,7 +5,7 @@
 //   Frame::create_kdtree             kd-tree over the undistorted keypoints                   uh_projmatch_set_frame   map_types/frame.h:124
 //   tracker: previous-frame search   project the previous frame's map points, match          uh_projmatch_match_prev  utils/system.cpp:5930-6460 (call :6559-6565)
 //   PnPSolver::solvePnp              pose from those matches (4 x 10 LM iterations)           uh_pnp_solve             optimization/pnpsolver.cpp:116-409 (call system.cpp:6626)
-//   Map::matchFrameToMapPoints       the local map projected with the refined pose            uh_projmatch_match       map.cpp:651-770 (call system.cpp:6897)
+//   Map::matchFrameToMapPoints       the local map projected with the refined pose, 4-px disc  uh_projmatch_match       map.cpp:651-770 (call system.cpp:6897; radius :6762-6881)
 //   PnPSolver::solvePnp              pose from the union of both match sets                   uh_pnp_solve             (call system.cpp:6954)
 //
 // The host glue between the calls is the reference's own (keypoint / map point look-ups per DMatch, pnpsolver.cpp:199-232; the second
@@ -246,12 +246,16 @@ int main(int argc, char** argv) {
         CHECK(in1);
         const double t5 = now_us();
         const uh_map_points mp{N_MAP, sc.map_ids.data(), sc.map_pos.data(), sc.map_nrm.data(), sc.map_min.data(), sc.map_max.data(), sc.map_desc.data()};
-        const int n2 = uh_projmatch_match(pm, pose1, &mp, MAX_DESC_DIST * 2.f, PROJ_DIST_THR, m_map.data(), (int)m_map.size(), nullptr, nullptr, nullptr);
+        // system.cpp:6762-6881: with at least 30 inliers the refined pose is kept and the local map is searched in a 4-pixel disc; otherwise
+        // the first matches are dropped, the predicted pose stays and the search radius is projDistThr again
+        const bool tracked = in1 >= 30;
+        const float* pose_for_map = tracked ? pose1 : sc.pose0;
+        const int n2 = uh_projmatch_match(pm, pose_for_map, &mp, MAX_DESC_DIST * 2.f, tracked ? 4.f : PROJ_DIST_THR, m_map.data(), (int)m_map.size(), nullptr, nullptr, nullptr);
         CHECK(n2);
         const double t6 = now_us();
         // system.cpp:6897-6954: inliers of the first set + the new matches, filter_ambiguous_query over the union, then the per-match look-ups
         m_all.clear();
-        for (int i = 0; i < n1; i++) if (!bad[i]) m_all.push_back(m_prev[i]);
+        if (tracked) for (int i = 0; i < n1; i++) if (!bad[i]) m_all.push_back(m_prev[i]);
         const int kept1 = (int)m_all.size();
         m_all.insert(m_all.end(), m_map.begin(), m_map.begin() + n2);
         const int na = m_all.empty() ? 0 : uh_filter_ambiguous(m_all.data(), (int)m_all.size(), 0);
@@ -271,7 +275,7 @@ int main(int argc, char** argv) {
         }
         const double t7 = now_us();
         float pose2[16];
-        const int in2 = uh_pnp_solve(pnp, pose1, intr, na, p3d.data(), kp2.data(), isg.data(), wgt.data(), pose2, bad.data(), iters, nullptr);
+        const int in2 = uh_pnp_solve(pnp, pose_for_map, intr, na, p3d.data(), kp2.data(), isg.data(), wgt.data(), pose2, bad.data(), iters, nullptr);
         CHECK(in2);
         const double t8 = now_us();
         if (it < 0) continue;

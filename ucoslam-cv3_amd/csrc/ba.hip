@@ -2233,6 +2233,10 @@ int run_persistent(uh_ba* b, const volatile uint8_t* stop_asap, int n1, int n2, 
         UH_HIP_CHECK(hipMemsetAsync(b->parena.p, 0, b->parena.cap, st));
     }
     q.tag_base = (b->p_seq & 0xFFFFFu) << 12;
+    {
+        static const long long ticks = [] { const char* e = getenv("UH_BA_RESIDENCY_TIMEOUT_MS"); const long long ms = e ? atoll(e) : 0; return ms > 0 ? ms * 100000ll : kPTimeoutTicksDefault; }();
+        q.timeout_ticks = ticks;
+    }
     q.done_base = b->done_base;
     BAState hs;
     void* d_pin = nullptr;

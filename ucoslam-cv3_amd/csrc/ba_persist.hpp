@@ -38,7 +38,10 @@
 
 constexpr int kPThreads = 256;   // 4 waves, one per SIMD: each may use the whole 512-entry register file (256 VGPR + 256 AGPR)
 constexpr int kPWaves = kPThreads / 64;
-constexpr long long kPTimeoutTicks = 300000000ll;   // 3 s of the 100 MHz wall clock: a workgroup that never arrives
+// How long a workgroup waits for one that never arrives (another tenant's kernels hold the CUs) before the launch gives up and
+// uh_ba_optimize takes the launch chain: 100 ms by default (UH_BA_RESIDENCY_TIMEOUT_MS) — a hand-off normally takes microseconds and the
+// whole launch half a millisecond; round 3 waited 3 s.
+constexpr long long kPTimeoutTicksDefault = 10000000ll;   // 100 ms of the 100 MHz wall clock
 
 struct BAPersist {
     int G, Lw, krows, SL, nelem, max_fix, kfix;
@@ -46,6 +49,7 @@ struct BAPersist {
     int n1, n2, stop_at_begin, use_mfma;
     int speculate;        // 1: speculative trials (see the trial loop); UH_BA_SPEC=0 keeps the three-hand-off form for A/B measurements
     unsigned launch_id;   // tags the error / completion words of this launch
+    long long timeout_ticks;   // see kPTimeoutTicksDefault
     unsigned tag_base;    // (launch sequence of this optimizer & 0xFFFFF) << 12: the upper bits of every exchanged word's tag.  The exchange
                           // buffers are zeroed whenever they are (re)allocated and whenever the sequence wraps, so a stale word never matches.
     float minChi2;
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     auto give_up = [&](long long& t0) -> bool {
         if (t0 < 63) { ++t0; return false; }
         if (t0 == 63) t0 = wall_clock64();
-        if (__hip_atomic_load(q.errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == err_word || wall_clock64() - t0 > kPTimeoutTicks) {
+        if (__hip_atomic_load(q.errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == err_word || wall_clock64() - t0 > q.timeout_ticks) {
             s_flag[1] = 1;
             __hip_atomic_store(q.errw, err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // whichever workgroup gives up tells the host (the same word from all of them): the one that never became resident may be workgroup 0

@@ -675,12 +675,15 @@ __device__ __forceinline__ void replay_staged(unsigned (&hw)[K], int& size, cons
 // kStreamStage / 2 when the previous round filled the short fetch; all loads in flight together, none depends on another), keeps the prefix
 // of records whose two tags match, stages their entries in LDS and pushes them.
 constexpr int kStreamStage = 16;
-constexpr long long kStreamTimeout = 200000000ll;   // 2 s of the 100 MHz wall clock
+// a replay lane that sees no new record for this long hands its query to knn_redo_kernel (the rows stay right; only time is lost):
+// 100 ms by default (UH_KNN_STREAM_TIMEOUT_MS; round 3: 2 s) — the scan of a whole launch takes ~0.1 ms
+constexpr long long kStreamTimeoutDefault = 10000000ll;   // 100 ms of the 100 MHz wall clock
 template <int K>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5, 5))) void knn_stream_kernel(
     const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int sorted, int maxd,
     uint64_t* __restrict__ cand, uint64_t* __restrict__ prog, int cap, unsigned tag, int nrep,
-    int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ redo_list, int* __restrict__ redo_count, int* __restrict__ redo_next) {
+    int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ redo_list, int* __restrict__ redo_count, int* __restrict__ redo_next,
+    long long timeout_ticks) {
     if ((int)blockIdx.x >= nrep) {
         accept_scan<2, kScanStream>(train, t0, t1, queries, nq, K, maxd, cand, nullptr, cap, (int)blockIdx.x - nrep, prog, tag);
         return;
@@ -738,7 +741,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5, 5))) v
         deep = most >= 2 ? 1 : 0;
         if (most == 0) {
             if (closed && r >= total) fin = true;
-            if (wall_clock64() - tlast > kStreamTimeout) { over = over || !fin; fin = true; }
+            if (wall_clock64() - tlast > timeout_ticks) { over = over || !fin; fin = true; }
             if (__ballot(!fin) != 0) __builtin_amdgcn_s_sleep(2);
             continue;
         }
@@ -1436,10 +1439,11 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
                 UH_HIP_CHECK(hipMemsetAsync(d_nredo, 0, 8, idx->ctx->stream));
             }
             const unsigned tag = ++idx->stream_tag;
+            static const long long stream_timeout = [] { const char* e = getenv("UH_KNN_STREAM_TIMEOUT_MS"); const long long ms = e ? atoll(e) : 0; return ms > 0 ? ms * 100000ll : kStreamTimeoutDefault; }();
             const int nrep = uh_div_up(nq, kWave);
             const dim3 gs(nrep + uh_div_up(nq, 2));
 #define UH_KNN_STREAM(K) case K: UH_LAUNCH(idx->ctx, knn_stream_kernel<K>, gs, dim3(kWave), 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, sorted ? 1 : 0, max_dist, \
-            d_cand, d_prog, cap, tag, nrep, d_indices, d_distances, d_redo, d_nredo + (tag & 1u), d_nredo + ((tag + 1u) & 1u)); break
+            d_cand, d_prog, cap, tag, nrep, d_indices, d_distances, d_redo, d_nredo + (tag & 1u), d_nredo + ((tag + 1u) & 1u), stream_timeout); break
             switch (nn) {
                 UH_KNN_STREAM(1); UH_KNN_STREAM(2); UH_KNN_STREAM(3); UH_KNN_STREAM(4); UH_KNN_STREAM(5); UH_KNN_STREAM(6); UH_KNN_STREAM(7); UH_KNN_STREAM(8);
                 UH_KNN_STREAM(9); UH_KNN_STREAM(10); UH_KNN_STREAM(11); UH_KNN_STREAM(12); UH_KNN_STREAM(13); UH_KNN_STREAM(14); UH_KNN_STREAM(15); UH_KNN_STREAM(16);

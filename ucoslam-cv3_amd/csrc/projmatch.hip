@@ -194,8 +194,10 @@ private:
 
 // ---------------------------------------------------------------------------------------------------------- device
 struct PmFrame {
-    const float2* kp_xy; const int* kp_octave; const uint64_t* kp_desc;   // n_kpts, n_kpts, n_kpts x 4
-    const KdNodeDev* nodes; const unsigned int* leaf_idx;
+    const uint64_t* kp_desc;        // n_kpts x 4
+    const KdNodeDev* nodes;
+    const float4* leaf_rec;         // n_kpts records in LEAF order: {x, y, bits(keypoint << 4 | octave), 0} — what a leaf visit needs, in one 16-byte read
+                                    // (round 3 chased leaf index -> coordinates -> octave through three dependent LDS reads per visit)
     double box[4];
     const float* scale; int n_levels; int n_kpts;
     float fx, fy, cx, cy, min_x, min_y, max_x, max_y;
@@ -225,7 +227,7 @@ __device__ __forceinline__ float logf_cr(float x) { return uh_sincosf::logf_glib
 // cuts the divergence (max over 4 instead of 64 walks per wave), parallelises the leaf and the L2 fetches, and fills 16x
 // more SIMDs.
 //
-// LDS layout of a workgroup: [nodes | kp_xy | leaf_idx | kp_octave(int8)] when the frame fits (IN_LDS), then per group the
+// LDS layout of a workgroup: [nodes | leaf records] when the frame fits (IN_LDS), then per group the
 // walk stack (double m, int rec per level) and the candidate list ((keypoint << 4) | octave, then the Hamming distance).
 // A frame of 2000 keypoints is ~40 KB, of 4000 ~80 KB: every node / leaf / coordinate access of the walk is an LDS access;
 // only descriptors of disc hits come from L2.
@@ -244,12 +246,8 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
     size_t off = 0;
     KdNodeDev* s_nodes = reinterpret_cast<KdNodeDev*>(smem);
     if (IN_LDS) off += ((size_t)n_nodes * sizeof(KdNodeDev) + 15) & ~(size_t)15;
-    float2* s_xy = reinterpret_cast<float2*>(smem + off);
-    if (IN_LDS) off += (size_t)n * 8;
-    unsigned int* s_leaf = reinterpret_cast<unsigned int*>(smem + off);
-    if (IN_LDS) off += (size_t)n * 4;
-    signed char* s_oct = reinterpret_cast<signed char*>(smem + off);
-    if (IN_LDS) off += ((size_t)n + 15) & ~(size_t)15;
+    float4* s_rec = reinterpret_cast<float4*>(smem + off);
+    if (IN_LDS) off += (size_t)n * 16;
     double* st_m = reinterpret_cast<double*>(smem + off) + (size_t)g * levels;
     off += (size_t)levels * kGroupsPerWave * 8;
     double* st_c = reinterpret_cast<double*>(smem + off) + (size_t)g * levels;
@@ -262,29 +260,25 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
     off += (size_t)kCandCap * kGroupsPerWave * 4;
     int* s_hd = reinterpret_cast<int*>(smem + off) + (size_t)g * kCandCap;
     if (IN_LDS) {
-        const unsigned int* gn = reinterpret_cast<const unsigned int*>(f.nodes);
-        unsigned int* sn = reinterpret_cast<unsigned int*>(s_nodes);
-        // eight independent loads in flight per lane and round (the plain loop is one L2 round trip per 64 words)
+        // 16-byte loads, eight in flight per lane and round (the node array is 24 n bytes in a 256-byte aligned block: the last chunk may
+        // run 8 bytes into its padding, which the LDS area's rounding covers)
+        const uint4* gn = reinterpret_cast<const uint4*>(f.nodes);
+        uint4* sn = reinterpret_cast<uint4*>(s_nodes);
         constexpr int U = 8;
-        for (int i0 = lane; i0 < n_nodes * 6; i0 += U * kPmThreads) {
-            unsigned int v[U];
+        const int n16 = (n_nodes * (int)sizeof(KdNodeDev) + 15) / 16;
+        for (int i0 = lane; i0 < n16; i0 += U * kPmThreads) {
+            uint4 v[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) { const int i = i0 + u * kPmThreads; v[u] = i < n_nodes * 6 ? gn[i] : 0u; }
+            for (int u = 0; u < U; u++) { const int i = i0 + u * kPmThreads; v[u] = gn[i < n16 ? i : 0]; }
 #pragma unroll
-            for (int u = 0; u < U; u++) { const int i = i0 + u * kPmThreads; if (i < n_nodes * 6) sn[i] = v[u]; }
+            for (int u = 0; u < U; u++) { const int i = i0 + u * kPmThreads; if (i < n16) sn[i] = v[u]; }
         }
         for (int i0 = lane; i0 < n; i0 += U * kPmThreads) {
-            float2 a[U]; unsigned int b[U]; int c[U];
+            float4 a[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int i = i0 + u * kPmThreads, ic = i < n ? i : 0;
-                a[u] = f.kp_xy[ic]; b[u] = f.leaf_idx[ic]; c[u] = f.kp_octave[ic];
-            }
+            for (int u = 0; u < U; u++) { const int i = i0 + u * kPmThreads; a[u] = f.leaf_rec[i < n ? i : 0]; }
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int i = i0 + u * kPmThreads;
-                if (i < n) { s_xy[i] = a[u]; s_leaf[i] = b[u]; s_oct[i] = (signed char)c[u]; }
-            }
+            for (int u = 0; u < U; u++) { const int i = i0 + u * kPmThreads; if (i < n) s_rec[i] = a[u]; }
         }
         __syncthreads();
     }
@@ -383,8 +377,10 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
         // is turned into "restore dists[col]" in place when the other child is entered.
         int sp = 0;
         int cur = 0;                 // node to visit (-1: take the top record)
+        int n_iter = 0, n_leaf = 0;
         double cur_m = (double)distsq;
         for (;;) {
+            ++n_iter;
             if (cur < 0) {
                 if (sp == 0) break;
                 const int rec = st_rec[sp - 1];
@@ -404,13 +400,14 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
             KdNodeDev nd;
             if (IN_LDS) nd = s_nodes[cur]; else nd = f.nodes[cur];
             if (nd.left < 0) {   // leaf: lane i of the group tests keypoint i; hits are appended in leaf order
+                ++n_leaf;
                 bool hit = false;
                 unsigned int id = 0;
                 int oc = 0;
                 if (gl < nd.leaf_count) {
-                    id = IN_LDS ? s_leaf[nd.leaf_begin + gl] : f.leaf_idx[nd.leaf_begin + gl];
-                    const float2 c = IN_LDS ? s_xy[id] : f.kp_xy[id];
-                    oc = IN_LDS ? (int)s_oct[id] : f.kp_octave[id];
+                    const float4 c = IN_LDS ? s_rec[nd.leaf_begin + gl] : f.leaf_rec[nd.leaf_begin + gl];
+                    const unsigned io = __float_as_uint(c.z);
+                    id = io >> 4; oc = (int)(io & 15u);
                     const double dx = px - c.x;
                     double sqd = dx * dx;
                     if (!(sqd > worst)) { const double dy = py - c.y; sqd += dy * dy; }
@@ -439,6 +436,7 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
             }
             cur = go_left ? nd.left : nd.right;   // best child, same mindistsq
         }
+        if (clk) { clk[6] = n_iter; clk[7] = n_leaf; }
     }
     if (clk) { clk[2] = __builtin_readcyclecounter(); clk[5] = ncand; }
     if (!ovf) drain(ncand);
@@ -462,7 +460,7 @@ struct uh_projmatch {
     bool have_frame = false;
     int n_kpts = 0, n_levels = 0;
     PmFrame fr{};
-    uh::DevBuf d_frame;    // kp_xy | kp_octave | kp_desc | nodes | leaf_idx | scale
+    uh::DevBuf d_frame;    // kp_desc | nodes | leaf records | scale
     uh::DevBuf d_points;   // pos3d | normal | min | max | desc | best_kp | best_dist | visible | overflow
     // pinned, device-visible staging: the frame block (set_frame), the points of a match call, its results + completion word.
     // Everything moves as 16-byte-wide launches on the context stream (uh::copy16 / publish16); the host never synchronises the stream.
@@ -511,8 +509,8 @@ int uh_projmatch_set_frame(uh_projmatch* h, const uh_proj_frame* f) {
     UH_REQUIRE(h->kd.max_depth <= kMaxDepth, "uh_projmatch_set_frame: kd-tree depth %d exceeds the walk stack (%d levels)", h->kd.max_depth, kMaxDepth);
     const size_t nn = h->kd.nodes.size();
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t o_xy = 0, o_oct = al(o_xy + 8 * (size_t)n), o_desc = al(o_oct + 4 * (size_t)n), o_nodes = al(o_desc + 32 * (size_t)n);
-    const size_t o_leaf = al(o_nodes + sizeof(KdNodeDev) * nn), o_scale = al(o_leaf + 4 * (size_t)n), total = al(o_scale + 4 * (size_t)f->n_levels);
+    const size_t o_desc = 0, o_nodes = al(o_desc + 32 * (size_t)n);
+    const size_t o_leaf = al(o_nodes + sizeof(KdNodeDev) * nn), o_scale = al(o_leaf + 16 * (size_t)n), total = al(o_scale + 4 * (size_t)f->n_levels);
     int rc = h->d_frame.reserve(total + 256);
     if (rc) return rc;
     char* base = h->d_frame.as<char>();
@@ -526,11 +524,14 @@ int uh_projmatch_set_frame(uh_projmatch* h, const uh_proj_frame* f) {
         if ((rc = h->h_frame.reserve(total + 64))) return rc;
         char* hi = h->h_frame.host<char>() + 64;   // (the first 64 bytes hold the completion word)
         if (n) {
-            std::memcpy(hi + o_xy, xy.data(), 8 * (size_t)n);
-            std::memcpy(hi + o_oct, oct.data(), 4 * (size_t)n);
             std::memcpy(hi + o_desc, f->desc, 32 * (size_t)n);
             std::memcpy(hi + o_nodes, h->kd.nodes.data(), sizeof(KdNodeDev) * nn);
-            std::memcpy(hi + o_leaf, h->kd.leaf_idx.data(), 4 * (size_t)n);
+            float* lr = reinterpret_cast<float*>(hi + o_leaf);   // the leaf records, in leaf order
+            for (int i = 0; i < n; i++) {
+                const uint32_t id = h->kd.leaf_idx[i], io = (id << 4) | (uint32_t)oct[id];
+                lr[4 * i] = xy[2 * (size_t)id]; lr[4 * i + 1] = xy[2 * (size_t)id + 1];
+                std::memcpy(lr + 4 * i + 2, &io, 4); lr[4 * i + 3] = 0.f;
+            }
         }
         std::memcpy(hi + o_scale, f->scale_factors, 4 * (size_t)f->n_levels);
         std::atomic_thread_fence(std::memory_order_release);
@@ -540,8 +541,8 @@ int uh_projmatch_set_frame(uh_projmatch* h, const uh_proj_frame* f) {
     }
     if (getenv("UH_PM_TIMING")) fprintf(stderr, "set_frame total: %.1f us (bytes %zu)\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), total);
     PmFrame& d = h->fr;
-    d.kp_xy = (const float2*)(base + o_xy); d.kp_octave = (const int*)(base + o_oct); d.kp_desc = (const uint64_t*)(base + o_desc);
-    d.nodes = (const KdNodeDev*)(base + o_nodes); d.leaf_idx = (const unsigned int*)(base + o_leaf); d.scale = (const float*)(base + o_scale);
+    d.kp_desc = (const uint64_t*)(base + o_desc);
+    d.nodes = (const KdNodeDev*)(base + o_nodes); d.leaf_rec = (const float4*)(base + o_leaf); d.scale = (const float*)(base + o_scale);
     for (int i = 0; i < 4; i++) d.box[i] = h->kd.root_box[i];
     d.n_levels = f->n_levels; d.n_kpts = n;
     d.fx = f->fx; d.fy = f->fy; d.cx = f->cx; d.cy = f->cy;
@@ -637,7 +638,7 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
     {
         const int n_nodes = (int)h->kd.nodes.size(), levels = h->kd.max_depth + 2;
         const size_t stack_bytes = (size_t)levels * kGroupsPerWave * 24 + (size_t)kCandCap * kGroupsPerWave * 8 + 64;
-        const size_t tree_bytes = (((size_t)n_nodes * sizeof(KdNodeDev) + 15) & ~(size_t)15) + 12 * (size_t)h->n_kpts + (((size_t)h->n_kpts + 15) & ~(size_t)15);
+        const size_t tree_bytes = (((size_t)n_nodes * sizeof(KdNodeDev) + 15) & ~(size_t)15) + 16 * (size_t)h->n_kpts;
         const bool in_lds = tree_bytes + stack_bytes <= kLdsBudget && !getenv("UH_PROJMATCH_NO_LDS");   // env: test knob for the big-frame path
         const size_t lds = stack_bytes + (in_lds ? tree_bytes : 0);
         if (!h->attr_set) {
@@ -660,10 +661,10 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
     if ((rc = uh::publish16(h->ctx, h->h_out.dev<char>() + 64, base + o_bk, out_bytes, reinterpret_cast<unsigned*>(base + o_ovf), h->h_out.dev<unsigned long long>(), word))) return rc;
     if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(h->h_out.host<char>()), word, st, "uh_projmatch_match"))) return rc;
     if (pm_clk) {
-        long long c[6];
+        long long c[8];
         UH_HIP_CHECK(hipMemcpy(c, base + 16, sizeof(c), hipMemcpyDeviceToHost));
-        fprintf(stderr, "projmatch%s workgroup 0 cycles: stage %lld  visibility+walk %lld  final drain (%lld hits) %lld  tail %lld  total %lld\n", prev ? "_prev" : "", c[1] - c[0], c[2] - c[1],
-                c[5], c[3] - c[2], c[4] - c[3], c[4] - c[0]);
+        fprintf(stderr, "projmatch%s workgroup 0 cycles: stage %lld  visibility+walk %lld (group 0: %lld loop iterations, %lld leaves)  final drain (%lld hits) %lld  tail %lld  total %lld\n",
+                prev ? "_prev" : "", c[1] - c[0], c[2] - c[1], c[6], c[7], c[5], c[3] - c[2], c[4] - c[3], c[4] - c[0]);
     }
     const char* ho = h->h_out.host<char>() + 64;
     const int* bk = (const int*)ho;
