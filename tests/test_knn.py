@@ -354,3 +354,24 @@ def test_hip_knn_host_api_with_pinned_buffers(hip_ctx, oracle):
         check(lib().uh_knn_search(index._h, C.c_void_p(pq.data_ptr()), nq, 32, nn, np_ptr(i2), np_ptr(d2), s, -1))   # pinned in, pageable out
         np.testing.assert_array_equal(i2, ref_i)
         np.testing.assert_array_equal(d2, ref_d)
+
+
+@pytest.mark.gpu
+def test_hip_knn_range_split_form_is_exact(hip_ctx, oracle, monkeypatch):
+    """UH_KNN_FORM=split: a frame's queries against S slices of the train range (the sharded search's scan kernel, one launch) + the
+    lane-per-query replay over the slices' exact accept lists — measured slower than the fused search and not the default, but it is the
+    single-GPU rehearsal of the sharded path's kernels: rows must equal the oracle's, overflowed lists included (redo)."""
+    import torch
+
+    from ucoslam_cv3_amd.knn import Index
+
+    monkeypatch.setenv("UH_KNN_FORM", "split")
+    for (train, q) in (synth.match_set(700, 6000, seed=61), synth.tie_stress_set(300, 4000, seed=62), synth.descending_set(6, 3000, seed=63)):
+        index = Index(hip_ctx).build(torch.from_numpy(train).cuda())
+        dq = torch.from_numpy(q).cuda()
+        for nn, s in [(10, 0), (2, 1), (16, 0)]:
+            idx, dist = index.search(dq, nn, sorted=bool(s))
+            torch.cuda.synchronize()
+            ri, rd = oracle_lib.knn_search(oracle, train, q, nn, s)
+            np.testing.assert_array_equal(idx.cpu().numpy(), ri)
+            np.testing.assert_array_equal(dist.cpu().numpy(), rd)

@@ -470,10 +470,17 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_accept_kernel(
     accept_scan<QPW, kScanTwoLaunch>(train, t0, t1, queries, nq, k, maxd, cand, counts, cap, blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nullptr, 0u);
 }
 // the tile scan of the sharded search for k <= 16: two queries per wave, threshold kept sorted along a DPP row (no heap pushes in the scan)
+// gridDim.y > 1: the range [t0, t1) is cut into gridDim.y consecutive slices, slice s = blockIdx.y with its lists at cand + s * nq * cap and
+// its counts at counts + s * nq — the latency form of the exact search for ONE frame's queries (uh_knn_search_dev below): a query's scan
+// is spread over several waves, the replay walks the slices' lists in row order.
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_scan_shard2_kernel(
     const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k, int maxd,
-    uint64_t* __restrict__ cand, int32_t* __restrict__ counts, int cap) {
-    accept_scan<2, kScanShard>(train, t0, t1, queries, nq, k, maxd, cand, counts, cap, blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nullptr, 0u);
+    uint64_t* __restrict__ cand, int32_t* __restrict__ counts, int cap, int* __restrict__ redo_count) {
+    if (redo_count && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *redo_count = 0;   // (the replay launch behind this one counts the overflowed lists)
+    const int S = gridDim.y, s = blockIdx.y;
+    const int b0 = t0 + (int)((long long)(t1 - t0) * s / S), b1 = t0 + (int)((long long)(t1 - t0) * (s + 1) / S);
+    accept_scan<2, kScanShard>(train, b0, b1, queries, nq, k, maxd, cand + (size_t)s * nq * cap, counts + (size_t)s * nq, cap,
+                               blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nullptr, 0u);
 }
 
 constexpr int kRpK = 16;   // the two-phase form serves k <= 16
@@ -807,7 +814,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
 template <int K>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) void knn_replay_shards_lane_kernel(
     const uint64_t* __restrict__ cand_all, size_t cand_shard_stride, const int32_t* __restrict__ counts_all, size_t count_shard_stride, int nshards,
-    int nq, int sorted, int maxd, int cap, int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ overflow) {
+    int nq, int sorted, int maxd, int cap, int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ overflow,
+    int* __restrict__ redo_list, int* __restrict__ redo_count) {
     extern __shared__ uint64_t s_list[];   // [cap][64]
     const int qi = blockIdx.x * kWave + threadIdx.x;
     const bool haveq = qi < nq;
@@ -847,8 +855,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
             heap_push_wave<K>(hw, size, acc, cw);
         }
     }
-    if (over && overflow) atomicOr(overflow, 1);
-    heap_write_row<K>(hw, size, sorted, haveq, qi, indices, distances);
+    if (over && redo_list) redo_list[atomicAdd(redo_count, 1)] = qi;   // (the search entry point: the fused kernel recomputes this query)
+    else if (over && overflow) atomicOr(overflow, 1);
+    heap_write_row<K>(hw, size, sorted, haveq && !(over && redo_list), qi, indices, distances);
 }
 
 // the (rare) queries whose accept list overflowed: the fused one-wave search, over a compacted list
@@ -1267,6 +1276,7 @@ struct uh_knn {
     unsigned stream_gen = 0;            // ... and its allocation generation (hipFree + hipMalloc may hand back the same base address)
     uh::DevBuf list_buf;          // accept lists, counts and redo flags of the two-phase search
     uh::DevBuf q_buf, idx_buf, dist_buf;  // staging for the host-pointer API
+    bool split_form = false;              // UH_KNN_FORM=split: the range-split form of small query sets (see uh_knn_search_dev)
     uh::MappedBuf h_word;                 // completion word of a host-pointer search with pinned buffers
     unsigned long long host_seq = 0;
     // hierarchical k-means form of the same index (uh_knn_build_kmeans)
@@ -1289,14 +1299,15 @@ static void launch_replay(uh_knn* idx, dim3 grid, dim3 block, const ShardBounds&
 
 // tile lists -> rows with one lane per query (k <= 16, rows below 2^23, no rescan); false: the caller uses the wave-per-query replay
 static bool launch_replay_lanes(uh_knn* idx, int nq, int nn, int sorted, int max_dist, const uint64_t* d_cand, size_t cand_stride, const int32_t* d_counts,
-                                size_t count_stride, int nshards, int cap, int32_t* d_indices, int32_t* d_distances, int* d_overflow) {
+                                size_t count_stride, int nshards, int cap, int32_t* d_indices, int32_t* d_distances, int* d_overflow,
+                                int* d_redo_list = nullptr, int* d_redo_count = nullptr) {
     if (nn > kRpK || cap > 256 || getenv("UH_KNN_SHARD_FORM")) return false;   // (env: the A/B against the wave-per-query kernels)
     if (!cand_stride) cand_stride = (size_t)nq * cap;
     if (!count_stride) count_stride = (size_t)nq;
     const dim3 grid(uh_div_up(nq, kWave)), block(kWave);
     const size_t lds = (size_t)cap * kWave * 8;
 #define UH_KNN_RPS(K) case K: { static bool attr##K = false; if (!attr##K) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn_replay_shards_lane_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * kWave * 8); attr##K = true; } \
-        UH_LAUNCH(idx->ctx, knn_replay_shards_lane_kernel<K>, grid, block, lds, d_cand, cand_stride, d_counts, count_stride, nshards, nq, sorted ? 1 : 0, max_dist, cap, d_indices, d_distances, d_overflow); } break
+        UH_LAUNCH(idx->ctx, knn_replay_shards_lane_kernel<K>, grid, block, lds, d_cand, cand_stride, d_counts, count_stride, nshards, nq, sorted ? 1 : 0, max_dist, cap, d_indices, d_distances, d_overflow, d_redo_list, d_redo_count); } break
     switch (nn) {
         UH_KNN_RPS(1); UH_KNN_RPS(2); UH_KNN_RPS(3); UH_KNN_RPS(4); UH_KNN_RPS(5); UH_KNN_RPS(6); UH_KNN_RPS(7); UH_KNN_RPS(8);
         UH_KNN_RPS(9); UH_KNN_RPS(10); UH_KNN_RPS(11); UH_KNN_RPS(12); UH_KNN_RPS(13); UH_KNN_RPS(14); UH_KNN_RPS(15); UH_KNN_RPS(16);
@@ -1314,6 +1325,7 @@ int uh_knn_create(uh_ctx* ctx, uh_knn** out) {
     k->ctx = ctx;
     if (const char* e = getenv("UH_KNN_FORM")) {
         const std::string f(e);
+        k->split_form = f == "split";
         if (f == "fused") k->two_phase_min_nq = 0x7fffffff;
         else if (f == "twophase") { k->two_phase_min_nq = 0; k->stream_min_nn = 0x7fffffff; }
         else if (f == "stream") { k->two_phase_min_nq = 0; k->stream_min_nn = 0; }
@@ -1486,6 +1498,38 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
         UH_HIP_CHECK(hipGetLastError());
         return UH_OK;
     }
+    // ---- UH_KNN_FORM=split (measured and NOT chosen): for ONE frame's queries the range is cut into S slices scanned by S times as many
+    // waves (the threshold-only scan of the sharded search, exact lists per slice) and a lane-per-query replay walks the slices' lists in
+    // row order.  The scan gets S times shorter, but every slice starts from an empty heap and lists 65 rows where the global heap accepts
+    // 79 in all: the replay wades through 260 entries per query in lockstep over 64 queries — 2000 x 10 000, nn 10: 144 us against 77
+    // fused / 73 as one stream-form launch.  Kept as the single-GPU rehearsal of the sharded search (same kernels).
+    {
+        const int nrows = idx->shard_end - idx->shard_begin;
+        const bool no_split = !idx->split_form;
+        int S = std::min(16, std::max(1, 8192 / std::max(nq, 1)));
+        S = std::min(S, nrows / 512);
+        if (!no_split && nn <= kRpK && S >= 2 && idx->shard_end <= (1 << 23) && qpw == 1) {
+            const double rows_s = (double)nrows / S, expect = nn * (1.0 + std::log(std::max(rows_s / nn, 1.0)));
+            const int cap = std::min(256, std::max(32, (((int)(expect + 4.0 * std::sqrt(expect)) + 15) & ~15)));
+            int rc;
+            if ((rc = idx->list_buf.reserve((size_t)S * nq * cap * 8 + (size_t)S * nq * 4 + (size_t)(nq + 2) * 4 + 256))) return rc;
+            idx->stream_buf = nullptr;   // (untagged words go into the buffer the stream form keeps its tagged ones in)
+            uint64_t* d_cand = idx->list_buf.as<uint64_t>();
+            int32_t* d_counts = reinterpret_cast<int32_t*>(d_cand + (size_t)S * nq * cap);
+            int* d_redo = d_counts + (size_t)S * nq;
+            int* d_nredo = d_redo + nq;
+            const dim3 gs(uh_div_up(uh_div_up(nq, 2), kWavesPerBlock), S);
+            UH_LAUNCH(idx->ctx, knn_scan_shard2_kernel, gs, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap, d_nredo);
+            if (launch_replay_lanes(idx, nq, nn, sorted, max_dist, d_cand, 0, d_counts, 0, S, cap, d_indices, d_distances, nullptr, d_redo, d_nredo)) {
+                const dim3 gd(64);
+                if (nn <= 3) UH_LAUNCH(idx->ctx, knn_redo_kernel<1>, gd, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo, (const int*)d_nredo);
+                else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_redo_kernel<3>, gd, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo, (const int*)d_nredo);
+                else UH_LAUNCH(idx->ctx, knn_redo_kernel<6>, gd, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo, (const int*)d_nredo);
+                UH_HIP_CHECK(hipGetLastError());
+                return UH_OK;
+            }
+        }
+    }
     if (qpw > 1) {
         const dim3 gq(uh_div_up(nq, kWavesPerBlock * qpw));
 #define UH_KNN_MQ(LV, Q) UH_LAUNCH(idx->ctx, (knn_search_mq_kernel<LV, Q>), gq, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances)
@@ -1552,7 +1596,7 @@ int uh_knn_scan_shard_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn,
     if (nn <= kRpK && (long long)idx->row_offset + idx->shard_end <= (1 << 23) && !getenv("UH_KNN_SHARD_FORM")) {   // the threshold-only scan, two queries per wave
         const dim3 g2(uh_div_up(uh_div_up(nq, 2), kWavesPerBlock));
         UH_LAUNCH(idx->ctx, knn_scan_shard2_kernel, g2, block, 0, idx->d_train - (size_t)idx->row_offset * 32, idx->row_offset + idx->shard_begin,
-                  idx->row_offset + idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
+                  idx->row_offset + idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap, static_cast<int*>(nullptr));
         UH_HIP_CHECK(hipGetLastError());
         return UH_OK;
     }
