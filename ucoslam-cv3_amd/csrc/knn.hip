@@ -806,8 +806,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 2))) v
     heap_write_row<K>(hw, size, sorted, haveq && !over, qi, indices, distances);
 }
 
-// Replay of the gathered tile lists (uh_knn_replay_tiles*_dev) for k <= 16: ONE LANE PER QUERY, the heap in registers like
-// knn_replay_lane_kernel, shard after shard (= global row order).  A shard's lists are row-major [query][cap] words dist << 32 | row;
+// Replay of tile lists for k <= 16 with ONE LANE PER QUERY, the heap in registers like knn_replay_lane_kernel, shard after shard (= global
+// row order); chosen for a single list only (see launch_replay_lanes).  A shard's lists are row-major [query][cap] words dist << 32 | row;
 // a lane's list is staged in LDS with all its loads in flight (one memory round trip per shard and wave).  A list that overflowed its
 // capacity sets *overflow (tile-only ranks cannot rescan another rank's rows).  The wave-per-query replay (knn_replay_kernel: ~1000
 // cycles of cross-lane traffic per accepted push) stays for k > 16 and for the form that rescans.
@@ -1301,7 +1301,12 @@ static void launch_replay(uh_knn* idx, dim3 grid, dim3 block, const ShardBounds&
 static bool launch_replay_lanes(uh_knn* idx, int nq, int nn, int sorted, int max_dist, const uint64_t* d_cand, size_t cand_stride, const int32_t* d_counts,
                                 size_t count_stride, int nshards, int cap, int32_t* d_indices, int32_t* d_distances, int* d_overflow,
                                 int* d_redo_list = nullptr, int* d_redo_count = nullptr) {
-    if (nn > kRpK || cap > 256 || getenv("UH_KNN_SHARD_FORM")) return false;   // (env: the A/B against the wave-per-query kernels)
+    // One lane per query steps through EVERY listed row in lockstep over 64 queries, the wave-per-query replay pays per ACCEPTED push: with
+    // one list (world 1: 70 rows listed, 79 accepted overall) the lane form wins (42 vs 51 us for 2000 queries), with the 8 lists of 8 tiles
+    // (425 rows listed per query) it loses (158 vs 52 us; scripts/time_shard_replay.py).  UH_KNN_SHARD_FORM=lanes / old force one for the A/B.
+    const char* form = getenv("UH_KNN_SHARD_FORM");
+    const bool force_lanes = form && std::string(form) == "lanes";
+    if (nn > kRpK || cap > 256 || (form && !force_lanes) || (nshards > 1 && !force_lanes && !d_redo_list)) return false;
     if (!cand_stride) cand_stride = (size_t)nq * cap;
     if (!count_stride) count_stride = (size_t)nq;
     const dim3 grid(uh_div_up(nq, kWave)), block(kWave);
