@@ -328,6 +328,13 @@ def main():
                 orb1(); knn1()
             single = {"orb_extract_ms": round(timed(orb1, 50), 4), "knn_search_ms": round(timed(knn1, 50), 4)}
             single["orb_plus_match_ms"] = round(timed(lambda: (orb1(), knn1()), 50), 4)
+            # the same extraction from / to PAGEABLE arrays (a cv::Mat the host never registered): the frame goes through the runtime's staging copy
+            pg_img = np.array(one_img, copy=True)
+            pg_k = np.zeros(MAX_FEATURES * 28, np.uint8); pg_d = np.zeros((MAX_FEATURES, 32), np.uint8)
+            orb_pg = lambda: check(L.uh_orb_extract(ext1._h, C.c_void_p(pg_img.ctypes.data), W, H, W, C.c_void_p(pg_k.ctypes.data), C.c_void_p(pg_d.ctypes.data), MAX_FEATURES, C.byref(n_c)))
+            for _ in range(3):
+                orb_pg()
+            single["orb_extract_pageable_ms"] = round(timed(orb_pg, 50), 4)
             single["note"] = "one 1241x376 frame / its 2000 x 10000 nn=10 search per call, pinned host buffers in and out, no batching"
         except Exception as e_:
             print("single-frame stage skipped:", repr(e_), file=sys.stderr)
