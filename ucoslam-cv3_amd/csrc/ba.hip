@@ -53,6 +53,7 @@ namespace {
 constexpr int kMaxFree = 64;          // free (non-fixed) poses in the reduced system
 constexpr int kThreads = 256;
 constexpr int kSolveThreads = 256;                      // solve: one workgroup of 4 waves (one per SIMD)
+constexpr int kPackedThreads = 512;                     // its workgroup: 8 waves, two per SIMD — the trailing update's tiles are latency-bound on one
 constexpr int kPackedFree = 32;                          // stand-alone solve on a packed triangle in LDS: up to 32 free cameras (n = 192: 148 KB)
 constexpr int kMaxSplit = 12;                           // schur: landmark chunks per camera pair (partials the solve adds)
 constexpr int kTrailU = 4;                              // solve: trailing-update elements in flight per thread
@@ -901,6 +902,8 @@ __device__ __forceinline__ void backsolve2_lds(const double* M, int n, int ld, d
     if (lane + 64 < n) s_x[lane + 64] = x1;
 }
 
+#include "ldlt_mfma.hpp"
+
 // Blocked look-ahead LDL^T of the bordered system [S b; b^T .] held as a lower triangle in LDS (row stride ld = n + 1, odd), shared by the
 // fused legacy solve and the persistent kernel.  Every thread of the workgroup calls it (it contains barriers); the first
 // kSolveThreads threads do the work.  Returns (in wave 0) whether a zero / non-finite pivot was met.
@@ -1150,6 +1153,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     extern __shared__ __attribute__((aligned(16))) double s_mat[];
     __shared__ int s_ok;
     out.done = true;
+    constexpr int NT = PACKED ? kPackedThreads : kSolveThreads;   // threads of the workgroup that runs this body
     const int n = d.n, ld = n + 1;
     const int npairs = d.nfree * (d.nfree + 1) / 2;
     // the address space must be known at compile time: a generic pointer would turn every access into a flat_load
@@ -1165,10 +1169,12 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     // (PACKED serves at most kPackedFree cameras: its static LDS is sized for that, so that a 32-camera triangle — 148 KB — fits beside it)
     constexpr int kFreeCap = PACKED ? kPackedFree : kMaxFree;
     __shared__ short s_pair[kFreeCap * (kFreeCap + 1) / 2][2];
-    for (int t = tid; t < npairs; t += kSolveThreads) {
-        int s1 = 0, rem = t;
-        while (rem >= d.nfree - s1) { rem -= d.nfree - s1; ++s1; }
-        s_pair[t][0] = (short)s1; s_pair[t][1] = (short)(s1 + rem);
+    if constexpr (!PACKED) {   // (the packed solve's factorisation does not walk camera pairs)
+        for (int t = tid; t < npairs; t += NT) {
+            int s1 = 0, rem = t;
+            while (rem >= d.nfree - s1) { rem -= d.nfree - s1; ++s1; }
+            s_pair[t][0] = (short)s1; s_pair[t][1] = (short)(s1 + rem);
+        }
     }
     // (no barrier: the assembly decodes its pairs arithmetically; s_pair is first read after the barrier that ends it)
     // Two consecutive elements per 16-byte load (42 is even, the partial blocks are 16-byte aligned), three such units per
@@ -1189,13 +1195,13 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
         constexpr int AU = decltype(au_c)::value, MS = decltype(ms_c)::value;
         constexpr bool DIAG = decltype(diag_c)::value;
         const int units = DIAG ? d.nfree * 21 : total;
-        for (int t0 = tid; t0 < units && !finished; t0 += kSolveThreads * AU) {
+        for (int t0 = tid; t0 < units && !finished; t0 += NT * AU) {
             double2 xs[AU][MS];
             double hs[DIAG ? AU : 1][2][kCamChunks];
             int s1v[AU], s2v[AU], qv[AU];
 #pragma unroll
             for (int u = 0; u < AU; u++) {
-                const int t = t0 + u * kSolveThreads;
+                const int t = t0 + u * NT;
                 const int tc = t < units ? t : 0;
                 int pair = tc / 21;
                 const int q = 2 * (tc - pair * 21);
@@ -1245,6 +1251,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                             p.bp[6 * s1 + (q - 36)] = h;             // the decide stage needs b_p for computeScale
                             s_x[6 * s1 + (q - 36)] = h - v;
                             if constexpr (USE_LDS) M[(size_t)n * ld + 6 * s1 + (q - 36)] = h - v;   // row n of the bordered matrix
+                            if constexpr (PACKED) M[IX(n, 6 * s1 + (q - 36))] = h - v;              // (the packed triangle carries that row too)
                         }
                         continue;
                     }
@@ -1284,7 +1291,11 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     // in the update) and a loop-invariant thread -> (row, column) mapping.  After it M holds L (unit lower) and d on the
     // diagonal.
     bool failed = false;
-    if constexpr (USE_LDS) {
+    if constexpr (PACKED) {
+        // 22-32 free keyframes: panels by every thread, MFMA trailing update, block back substitution (ldlt_mfma.hpp); x lands in s_x
+        double* const s_aux = s_mat + ((((size_t)(n + 1) * (n + 2) / 2) + 1) & ~(size_t)1);
+        failed = ldlt_solve_mfma_lds<true>(M, n, ld, s_aux, s_x);
+    } else if constexpr (USE_LDS) {
         __shared__ double s_w_store[2][129][6];   // ([2][121][6] for the look-ahead form; the two-rows-per-lane form's panel buffer is [2][6][128] + alignment)
         double (*s_w)[121][6] = reinterpret_cast<double (*)[121][6]>(&s_w_store[0][0][0]);
         failed = ldlt_bordered_lds(M, n, ld, d.nfree, npairs, s_pair, s_w);
@@ -1322,7 +1333,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                 }
             }
             // (b) panel: L_rk = A_rk * Lkk^-T * Dk^-1, one thread per row; y = L_rk * Dk goes to s_w
-            for (int r = k0 + 6 + tid; r < n; r += kSolveThreads) {
+            for (int r = k0 + 6 + tid; r < n; r += NT) {
                 double y[6];
     #pragma unroll
                 for (int j = 0; j < 6; j++) y[j] = M[IX(r, k0 + j)];
@@ -1343,7 +1354,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                 const int kb = k0 / 6;
                 const int tile0 = (kb + 1) * d.nfree - kb * (kb + 1) / 2;   // first pair with s1 > kb
                 const int ntile = npairs - tile0;
-                for (int u = tid; u < 6 * ntile; u += kSolveThreads) {
+                for (int u = tid; u < 6 * ntile; u += NT) {
                     const int tile = u / 6, i = u - 6 * tile;
                     const int s1 = s_pair[tile0 + tile][0], s2 = s_pair[tile0 + tile][1];
                     const int r = 6 * s2 + i, c0 = 6 * s1;
@@ -1406,39 +1417,36 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                 if (lane < n) { s_x[lane] = x; p.xp[lane] = x; }
             }
         } else {
-            if (PACKED) {
-                __syncthreads();   // (s_x = b - b_schur, written by the assembly, is complete)
-                trisolve_packed_lds(M, n, s_x);
-                __syncthreads();
-                for (int i = tid; i < n; i += kSolveThreads) p.xp[i] = s_x[i];
+            if constexpr (PACKED) {
+                for (int i = tid; i < n; i += NT) p.xp[i] = s_x[i];   // (the solve above substituted already)
             } else if (USE_LDS && n <= 128) {   // two unknowns per lane of wave 0, one broadcast per column (the loop below: two barriers per column)
                 backsolve2_lds(M, n, ld, s_x);
                 __syncthreads();
-                for (int i = tid; i < n; i += kSolveThreads) p.xp[i] = s_x[i];
+                for (int i = tid; i < n; i += NT) p.xp[i] = s_x[i];
             } else {
             if constexpr (USE_LDS) {   // z = D^-1 L^-1 b is row n of the bordered factorisation
-                for (int i = tid; i < n; i += kSolveThreads) s_x[i] = M[(size_t)n * ld + i];
+                for (int i = tid; i < n; i += NT) s_x[i] = M[(size_t)n * ld + i];
             } else {
                 for (int j = 0; j < n; j++) {
                     const double xj = s_x[j];
                     __syncthreads();
-                    for (int i = j + 1 + tid; i < n; i += kSolveThreads) s_x[i] -= M[IX(i, j)] * xj;
+                    for (int i = j + 1 + tid; i < n; i += NT) s_x[i] -= M[IX(i, j)] * xj;
                     __syncthreads();
                 }
-                for (int i = tid; i < n; i += kSolveThreads) s_x[i] /= M[IX(i, i)];
+                for (int i = tid; i < n; i += NT) s_x[i] /= M[IX(i, i)];
             }
             __syncthreads();
             for (int j = n - 1; j >= 0; j--) {
                 const double xj = s_x[j];
                 __syncthreads();
-                for (int i = tid; i < j; i += kSolveThreads) s_x[i] -= M[IX(j, i)] * xj;
+                for (int i = tid; i < j; i += NT) s_x[i] -= M[IX(j, i)] * xj;
                 __syncthreads();
             }
-            for (int i = tid; i < n; i += kSolveThreads) p.xp[i] = s_x[i];
+            for (int i = tid; i < n; i += NT) p.xp[i] = s_x[i];
             }
         }
     } else {
-        for (int i = tid; i < n; i += kSolveThreads) { p.xp[i] = 0.0; s_x[i] = 0.0; }
+        for (int i = tid; i < n; i += NT) { p.xp[i] = 0.0; s_x[i] = 0.0; }
     }
     __syncthreads();
     UH_BA_CLKL(13);
@@ -1452,7 +1460,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
 // stand-alone form: reduced systems too large for LDS (n > 126) factorise in the HBM workspace p.S, which only one
 // workgroup may use
 template <bool USE_LDS, bool PACKED = false>
-__global__ __launch_bounds__(kSolveThreads) void ba_solve_kernel(BAPtrs p, BADims d, int nsplit, int slot) {
+__global__ __launch_bounds__(PACKED ? kPackedThreads : kSolveThreads) void ba_solve_kernel(BAPtrs p, BADims d, int nsplit, int slot) {
     uh_latency_critical();
     __shared__ double s_x[6 * (PACKED ? kPackedFree : kMaxFree)];
     SolveOut o;
@@ -2142,11 +2150,11 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
         } else {
             // 22-32 free cameras: the stand-alone solve keeps the system as a packed triangle in its own LDS (148 KB at 32 cameras, beside
             // the kernel's static arrays, which are sized for that many: both are checked against the device's limit); more: in HBM
-            const size_t packed = ((size_t)d.n * (d.n + 1) / 2 + 16) * sizeof(double);
+            const size_t packed = ((size_t)(d.n + 1) * (d.n + 2) / 2 + 2 + kLdltAux) * sizeof(double);   // rows 0 .. n (row n = right-hand side) + the solve's scratch
             static const size_t packed_static = [] { hipFuncAttributes fa{}; return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&ba_solve_kernel<false, true>)) == hipSuccess ? fa.sharedSizeBytes : (size_t)1 << 30; }();
             if (b->max_lds <= 0) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, b->ctx->device) == hipSuccess) b->max_lds = v; }
             if (d.nfree <= kPackedFree && packed + packed_static <= (size_t)std::max(b->max_lds, 0) && !(getenv("UH_BA_SOLVE") && std::string(getenv("UH_BA_SOLVE")) == "hbm"))
-                UH_LAUNCH(b->ctx, (ba_solve_kernel<false, true>), dim3(1), dim3(kSolveThreads), packed, b->ptrs, d, b->nsplit, slot ^ 1);
+                UH_LAUNCH(b->ctx, (ba_solve_kernel<false, true>), dim3(1), dim3(kPackedThreads), packed, b->ptrs, d, b->nsplit, slot ^ 1);
             else
                 UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kSolveThreads), 0, b->ptrs, d, b->nsplit, slot ^ 1);
             UH_LAUNCH(b->ctx,ba_backsub_kernel<false>, dim3(d.nPointBlocks), dim3(kThreads), 0, b->ptrs, d, b->nsplit, slot ^ 1);
