@@ -124,6 +124,11 @@ int uh_knn_search_kmeans_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int 
  * counts: nshards blocks of [nq]. */
 int uh_knn_scan_shard_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int max_dist,
                           uint64_t* d_cand, int32_t* d_counts, int cap);
+/* Query rows [*d_valid_rows, nq) of every following uh_knn_scan_shard_dev are not scanned and emit EMPTY lists (NULL: all rows count).
+ * For a caller whose query buffer is a fixed-capacity frame block of which only the first `count` rows — a number that lives on the
+ * device — are this frame's descriptors (FrameExtractor's output, frameextractor.cpp:270-340, fed to the sharded matcher): rows left
+ * over from an earlier frame must not be able to overflow a list. */
+int uh_knn_set_valid_rows_dev(uh_knn* idx, const int32_t* d_valid_rows);
 int uh_knn_replay_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int sorted, int max_dist,
                       const uint64_t* d_cand_all, const int32_t* d_counts_all, int nshards, int cap,
                       int32_t* d_indices, int32_t* d_distances);

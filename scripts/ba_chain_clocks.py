@@ -6,7 +6,7 @@ from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
 torch.cuda.set_device(0)
 ctx=u.Context(0, private=True)
 L=u.lib(); L.uh_ba_debug_clocks.argtypes=[C.c_void_p,C.c_void_p]; L.uh_ba_debug_clocks.restype=C.c_int
-for nfree in (17,21):
+for nfree in ([int(a) for a in sys.argv[1:]] or [17, 21]):
     pr=synth.ba_problem(nfree+2,3000,nfree); opt=GlobalOptimizer.create(ctx); opt.setParams(pr, ParamSet(nIters=5))
     for _ in range(3): opt.optimize()
     clk=np.zeros(64,dtype=np.int64); L.uh_ba_debug_clocks(opt._h, clk.ctypes.data)

@@ -257,6 +257,37 @@ def test_hip_knn_sharded_replay_equals_single(hip_ctx, oracle, nshards, cap):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nn", [10, 20])
+def test_hip_knn_shard_scan_ignores_rows_behind_the_device_count(hip_ctx, oracle, nn):
+    """A frame block of fixed capacity whose first `count` rows (a device-side number) are this frame's descriptors: the rows behind
+    them emit EMPTY lists — stale descriptors cannot overflow a list (fstream.hip) — and the valid rows' results are those
+    of the reference search."""
+    import torch
+
+    from ucoslam_cv3_amd.knn import Index
+
+    train, q = synth.match_set(600, 1500, seed=77)
+    valid = 250
+    dt, dq = torch.from_numpy(train).cuda(), torch.from_numpy(q).cuda()
+    index = Index(hip_ctx).build(dt)
+    cnt = torch.tensor([valid], dtype=torch.int32, device="cuda")
+    cap = 1024
+    index.set_valid_rows(cnt)
+    cand, counts = index.scan_shard(dq, nn, cap)
+    torch.cuda.synchronize()
+    c = counts.cpu().numpy()
+    assert (c[valid:] == 0).all() and (c[:valid] > 0).all()
+    idx, dist = index.replay(dq, nn, cand[None], counts[None])
+    torch.cuda.synchronize()
+    ri, rd = oracle_lib.knn_search(oracle, train, q[:valid], nn, 0)
+    np.testing.assert_array_equal(idx.cpu().numpy()[:valid], ri)
+    np.testing.assert_array_equal(dist.cpu().numpy()[:valid], rd)
+    index.set_valid_rows(None)
+    _, counts2 = index.scan_shard(dq, nn, cap)
+    assert (counts2.cpu().numpy() > 0).all()
+
+
+@pytest.mark.gpu
 def test_hip_knn_error_behaviour(hip_ctx):
     import ucoslam_cv3_amd as u
     from ucoslam_cv3_amd.knn import Index

@@ -82,6 +82,7 @@ def _declare(L: C.CDLL):
     sig("uh_knn_scan_shard_dev", I, VP, VP, I, I, I, VP, VP, I)
     sig("uh_knn_replay_dev", I, VP, VP, I, I, I, I, VP, VP, I, I, VP, VP)
     sig("uh_knn_set_row_offset", I, VP, I)
+    sig("uh_knn_set_valid_rows_dev", I, VP, VP)
     sig("uh_knn_to_stream", I, VP, VP, C.c_uint64, C.POINTER(C.c_uint64))
     sig("uh_knn_from_stream", I, VP, VP, C.c_uint64)
     sig("uh_knn_replay_tiles_dev", I, VP, VP, I, I, I, I, VP, VP, I, I, VP, VP, VP)

@@ -244,6 +244,9 @@ int uh_fstream_local_dev(uh_fstream* f, const uint8_t* d_frame, int w, int h, si
     f->sent_prev = f->have_prev;
     if (f->have_prev) {
         const uint8_t* q = f->desc_of(f->cur);
+        // only the first cnt[cur] rows of the block are frame t-1's descriptors (finish rewrites that many): the rows behind them are
+        // older frames' and must not be able to overflow a list
+        if ((rc = uh_knn_set_valid_rows_dev(f->tile, f->cnt.as<int32_t>() + f->cur))) return rc;
         if ((rc = uh_knn_scan_shard_dev(f->tile, q, F, f->p.nn, -1, reinterpret_cast<uint64_t*>(m + f->L.cand), reinterpret_cast<int32_t*>(m + f->L.counts), f->p.cand_cap)))
             return rc;
         if (f->voc) {

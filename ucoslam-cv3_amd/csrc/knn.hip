@@ -475,12 +475,17 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_accept_kernel(
 // is spread over several waves, the replay walks the slices' lists in row order.
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_scan_shard2_kernel(
     const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k, int maxd,
-    uint64_t* __restrict__ cand, int32_t* __restrict__ counts, int cap, int* __restrict__ redo_count) {
+    uint64_t* __restrict__ cand, int32_t* __restrict__ counts, int cap, int* __restrict__ redo_count, const int32_t* __restrict__ valid_rows) {
     if (redo_count && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *redo_count = 0;   // (the replay launch behind this one counts the overflowed lists)
     const int S = gridDim.y, s = blockIdx.y;
     const int b0 = t0 + (int)((long long)(t1 - t0) * s / S), b1 = t0 + (int)((long long)(t1 - t0) * (s + 1) / S);
-    accept_scan<2, kScanShard>(train, b0, b1, queries, nq, k, maxd, cand + (size_t)s * nq * cap, counts + (size_t)s * nq, cap,
-                               blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nullptr, 0u);
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    int nqv = nq;
+    if (valid_rows) {   // uh_knn_set_valid_rows_dev: query rows from *valid_rows on are not scanned and get an EMPTY list (no overflow can come from them)
+        nqv = min(nq, max(*valid_rows, 0));
+        if ((threadIdx.x & (kWave - 1)) < 2) { const int q = 2 * wave + (threadIdx.x & 1); if (q >= nqv && q < nq) counts[(size_t)s * nq + q] = 0; }
+    }
+    accept_scan<2, kScanShard>(train, b0, b1, queries, nqv, k, maxd, cand + (size_t)s * nq * cap, counts + (size_t)s * nq, cap, wave, nullptr, 0u);
 }
 
 constexpr int kRpK = 16;   // the two-phase form serves k <= 16
@@ -944,10 +949,11 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_search_mq_kernel(
 // Shard scan: emits the locally accepted candidates in index order.
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_scan_shard_kernel(
     const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k,
-    int maxd, uint64_t* __restrict__ cand, int32_t* __restrict__ counts, int cap) {
+    int maxd, uint64_t* __restrict__ cand, int32_t* __restrict__ counts, int cap, const int32_t* __restrict__ valid_rows) {
     const int lane = threadIdx.x & (kWave - 1);
     const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (qi >= nq) return;
+    if (valid_rows && qi >= *valid_rows) { if (lane == 0) counts[qi] = 0; return; }   // (uh_knn_set_valid_rows_dev)
     uint32_t q[8];
     load_query(queries, qi, q);
     WaveHeap h{0, -1, 0, lane};
@@ -1259,6 +1265,7 @@ struct uh_knn {
     const uint8_t* d_train = nullptr;
     int nt = 0;
     int shard_begin = 0, shard_end = 0;
+    const int32_t* d_valid_rows = nullptr;   // uh_knn_set_valid_rows_dev: the shard scan's query rows from *d_valid_rows on get empty lists
     int row_offset = 0;           // global index of row 0 (uh_knn_set_row_offset): an index that holds only one tile of a sharded train set
     int qpw = 1;                  // queries per wave of the exact search (uh_knn_set_queries_per_wave)
     // Exact search, nn <= 16, which kernels run (MI355X, 10 000 train rows; scripts/knn_forms.py): below 3000 queries the fused one-wave-per-query
@@ -1524,7 +1531,7 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
             int* d_redo = d_counts + (size_t)S * nq;
             int* d_nredo = d_redo + nq;
             const dim3 gs(uh_div_up(uh_div_up(nq, 2), kWavesPerBlock), S);
-            UH_LAUNCH(idx->ctx, knn_scan_shard2_kernel, gs, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap, d_nredo);
+            UH_LAUNCH(idx->ctx, knn_scan_shard2_kernel, gs, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap, d_nredo, static_cast<const int32_t*>(nullptr));
             if (launch_replay_lanes(idx, nq, nn, sorted, max_dist, d_cand, 0, d_counts, 0, S, cap, d_indices, d_distances, nullptr, d_redo, d_nredo)) {
                 const dim3 gd(64);
                 if (nn <= 3) UH_LAUNCH(idx->ctx, knn_redo_kernel<1>, gd, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo, (const int*)d_nredo);
@@ -1601,13 +1608,23 @@ int uh_knn_scan_shard_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn,
     if (nn <= kRpK && (long long)idx->row_offset + idx->shard_end <= (1 << 23) && !getenv("UH_KNN_SHARD_FORM")) {   // the threshold-only scan, two queries per wave
         const dim3 g2(uh_div_up(uh_div_up(nq, 2), kWavesPerBlock));
         UH_LAUNCH(idx->ctx, knn_scan_shard2_kernel, g2, block, 0, idx->d_train - (size_t)idx->row_offset * 32, idx->row_offset + idx->shard_begin,
-                  idx->row_offset + idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap, static_cast<int*>(nullptr));
+                  idx->row_offset + idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap, static_cast<int*>(nullptr), idx->d_valid_rows);
         UH_HIP_CHECK(hipGetLastError());
         return UH_OK;
     }
     UH_LAUNCH(idx->ctx,knn_scan_shard_kernel, grid, block, 0, idx->d_train - (size_t)idx->row_offset * 32, idx->row_offset + idx->shard_begin,
-                       idx->row_offset + idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap);
+                       idx->row_offset + idx->shard_end, d_queries, nq, nn, max_dist, d_cand, d_counts, cap, idx->d_valid_rows);
     UH_HIP_CHECK(hipGetLastError());
+    return UH_OK;
+}
+
+// Query rows [*d_valid_rows, nq) of every following uh_knn_scan_shard_dev are not scanned and emit empty lists (NULL: every row counts).
+// For callers whose query buffer is a fixed-capacity frame block of which only the first `count` rows — a number that exists on the
+// device only — are this frame's descriptors (the stream of fstream.hip): stale rows could otherwise overflow a list and raise the
+// replay's overflow flag for a frame whose valid rows all fit.
+int uh_knn_set_valid_rows_dev(uh_knn* idx, const int32_t* d_valid_rows) {
+    UH_REQUIRE(idx, "uh_knn_set_valid_rows_dev: NULL index");
+    idx->d_valid_rows = d_valid_rows;
     return UH_OK;
 }
 

@@ -154,6 +154,13 @@ class Index:
                                       dev_ptr(counts_all), nshards, cap, dev_ptr(idx), dev_ptr(dist)))
         return idx, dist
 
+    def set_valid_rows(self, d_count=None):
+        """Query rows [*d_count, nq) of the following scan_shard calls are not scanned and get empty lists (None: every row counts).
+        d_count: a one-element int32 device tensor the caller keeps alive."""
+        self._valid_rows = d_count
+        check(lib().uh_knn_set_valid_rows_dev(self._h, dev_ptr(d_count) if d_count is not None else None))
+        return self
+
     def set_row_offset(self, offset: int):
         """This index holds ONE tile of a sharded train set: row 0 has the global index `offset` (used by scan_shard)."""
         check(lib().uh_knn_set_row_offset(self._h, offset))
