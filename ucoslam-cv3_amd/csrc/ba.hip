@@ -115,6 +115,7 @@ struct BAPtrs {
     double* HppPart; double* bp;   // nfree x kCamChunks x 27 partial (21 upper Hpp entries + 6 of bp); summed bp nfree x 6
     double* S;                // (n x (n+1)) HBM workspace of the factorisation when it does not fit in LDS
     double* Spart;            // nsplit x npairs x 42: schur partials (6x6 block + 6-vector)
+    double* dpart; double* dbpart;   // dense Schur form (ba_schur_dense_kernel): [G][tiles][256] product partials in MFMA C layout, [G][16 ntt] b_schur partials
     double* xp;               // n
     double* part_lin_chi;     // nPointBlocks
     double* part_maxdiag;     // nPointBlocks + nfree
@@ -547,6 +548,268 @@ __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, 
     block_sum_vec<42>(acc, s_part, s_out);
     if (have_pair && threadIdx.x < 42) p.Spart[((size_t)chunk * npairs + pair) * 42 + threadIdx.x] = s_out[threadIdx.x];
     UH_BA_CLK(5);
+}
+
+// ------------------------------------------------------------------------------------------------ schur, dense form (17-32 free cameras)
+// The pair form above recomputes a landmark's D^-1 for every camera pair and re-reads both Hpl blocks per pair: 528 pairs x 3000
+// landmarks x 360 B = 570 MB of L2 traffic per launch at 32 free cameras (106 us); local-BA windows are dense (a landmark is seen by
+// most of the window), so the product is a dense SYRK.  Here workgroup g owns the landmarks [g * lpw, (g + 1) * lpw), 16 at a time:
+//   * panel: one thread per (landmark, camera): Hll + lambda I = L L^T (3 x 3), Y = Hpl L^-T (6 x 3) into the LDS panel
+//     Yt[3 l + k][6 c + a] (zeros where the camera does not see the landmark), z = L^-1 b_l; every Hpl block is read ONCE;
+//   * product: S_g += Yt^T Yt as v_mfma_f64_16x16x4_f64 on the lower 16 x 16 tiles (K = 48 rows per chunk = 12 MFMAs per tile), the
+//     tiles dealt to the four waves, accumulators resident for the whole launch; b_schur_g += Yt^T z by the first n threads;
+//   * the G partials are written in MFMA C layout (2 KB per tile, fully coalesced) and summed IN WORKGROUP ORDER by
+//     ba_schur_reduce_kernel into the pair layout the solve's assembly reads (as ONE chunk): run-to-run deterministic.
+// The prologue (the previous trial's decision, lambda at iteration 0, the published state) and the camera workgroups are those of
+// ba_schur_kernel.  Reference: g2o/core/block_solver.hpp:341-392 (Hschur -= Hpl D^-1 Hpl^T, b -= Hpl D^-1 b_l).
+struct SchurDense { int G, cpw, ntt, ys, T; };   // workgroups, 16-landmark chunks per workgroup, tiles per dimension, LDS row stride, lower tiles
+constexpr int kSchurDenseMaxT = 20;              // lower tiles per wave: 78 tiles (12 per dimension, 32 free cameras) over four waves
+
+__device__ __forceinline__ double schur_rsqrt(double x) {   // v_rsq_f64 + two Newton steps; x <= 0 / NaN gives NaN / inf (the solve then reports failure)
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x, r * r, 1.5);
+    r = r * fma(-0.5 * x, r * r, 1.5);
+    return r;
+}
+
+// tile t = ti (ti + 1) / 2 + tj of the lower triangle, as compile-time functions: a wave's tile list is STATIC (wave w owns the tiles
+// w, w + 4, ...), so an MFMA's operands are picked from a register array of the 12 column groups by constant indices — one LDS read
+// per column group and k-step (12) instead of two per tile (40)
+__host__ __device__ constexpr int schur_tile_row(int t) { int ti = 0, t0 = 0; while (t0 + ti + 1 <= t) { t0 += ti + 1; ++ti; } return ti; }
+__host__ __device__ constexpr int schur_tile_col(int t) { int ti = 0, t0 = 0; while (t0 + ti + 1 <= t) { t0 += ti + 1; ++ti; } return t - t0; }
+
+template <int WV, int NTT>
+__device__ __forceinline__ void schur_dense_wave(const BAPtrs& p, const BADims& d, const SchurDense& sd, const BAState& st, double lambda, double* Yt, double* s_z) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g = blockIdx.x - d.nfree * kCamChunks, n = d.n, YS = sd.ys, i16 = lane & 15, kq = lane >> 4;   // (the camera workgroups come first)
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    constexpr int TT = NTT * (NTT + 1) / 2, NOWN = (TT - WV + 3) / 4;   // this wave's tiles: WV, WV + 4, ... < TT — everything below is unrolled over them
+    f64x4 acc[NOWN];
+#pragma unroll
+    for (int u = 0; u < NOWN; u++) acc[u] = f64x4{0, 0, 0, 0};
+    double bacc = 0;
+    const double* Hll = p.Hll[st.cur];
+    const double* Hpl = p.Hpl[st.cur];
+    const double* bl = p.bl[st.cur];
+    const int nslot = 16 * d.nfree;
+    for (int c = 0; c < sd.cpw; c++) {
+        const int l0 = (g * sd.cpw + c) * 16;
+        if (l0 >= d.P) break;   // (uniform)
+        if (c > 0) __syncthreads();   // the previous chunk's product has read the panel
+        // panel, two (landmark, camera) slots per thread with their loads issued together (the rounds are three dependent memory
+        // round trips each: edge id -> activity flag -> the blocks)
+        constexpr int RND = 2;
+        int e[RND], l[RND], sc[RND], pt[RND]; bool act[RND], live[RND];
+#pragma unroll
+        for (int r = 0; r < RND; r++) {
+            const int sl = tid + r * kThreads;
+            live[r] = sl < nslot;
+            l[r] = live[r] ? sl / d.nfree : 0; sc[r] = live[r] ? sl - l[r] * d.nfree : 0; pt[r] = l0 + l[r];
+            live[r] = live[r] && pt[r] < d.P;
+            e[r] = live[r] ? p.edge_of[(size_t)pt[r] * d.nfree + sc[r]] : -1;
+        }
+#pragma unroll
+        for (int r = 0; r < RND; r++) act[r] = e[r] >= 0 && p.e_active[e[r] >= 0 ? e[r] : 0] != 0;
+        double D[RND][6], bb[RND][18], bi[RND][3];
+#pragma unroll
+        for (int r = 0; r < RND; r++) {
+            const double* Dp = Hll + 9 * (size_t)(live[r] ? pt[r] : 0);
+            D[r][0] = Dp[0]; D[r][1] = Dp[3]; D[r][2] = Dp[6]; D[r][3] = Dp[4]; D[r][4] = Dp[7]; D[r][5] = Dp[8];
+            const double* Bp = Hpl + 18 * (size_t)(act[r] ? e[r] : 0);
+#pragma unroll
+            for (int i = 0; i < 18; i++) bb[r][i] = Bp[i];
+            const double* bp = bl + 3 * (size_t)(live[r] ? pt[r] : 0);
+            bi[r][0] = bp[0]; bi[r][1] = bp[1]; bi[r][2] = bp[2];
+        }
+#pragma unroll
+        for (int r = 0; r < RND; r++) {
+            if (tid + r * kThreads >= nslot) continue;
+            const double d00 = D[r][0] + lambda, d10 = D[r][1], d20 = D[r][2], d11 = D[r][3] + lambda, d21 = D[r][4], d22 = D[r][5] + lambda;
+            const double r0 = schur_rsqrt(d00), l10 = d10 * r0, l20 = d20 * r0;
+            const double r1 = schur_rsqrt(fma(-l10, l10, d11)), l21 = fma(-l20, l10, d21) * r1;
+            const double r2 = schur_rsqrt(fma(-l21, l21, fma(-l20, l20, d22)));
+            double* yo = Yt + 3 * l[r] * YS + 6 * sc[r];
+#pragma unroll
+            for (int a = 0; a < 6; a++) {   // Y_a L^T = B_a (zeros where the camera does not see the landmark)
+                const double y0 = bb[r][3 * a] * r0, y1 = fma(-y0, l10, bb[r][3 * a + 1]) * r1, y2 = fma(-y1, l21, fma(-y0, l20, bb[r][3 * a + 2])) * r2;
+                yo[a] = act[r] ? y0 : 0.0; yo[YS + a] = act[r] ? y1 : 0.0; yo[2 * YS + a] = act[r] ? y2 : 0.0;
+            }
+            if (sc[r] == 0) {   // z = L^-1 b_l
+                const double z0 = bi[r][0] * r0, z1 = fma(-l10, z0, bi[r][1]) * r1, z2 = fma(-l21, z1, fma(-l20, z0, bi[r][2])) * r2;
+                s_z[3 * l[r]] = live[r] ? z0 : 0.0; s_z[3 * l[r] + 1] = live[r] ? z1 : 0.0; s_z[3 * l[r] + 2] = live[r] ? z2 : 0.0;
+            }
+        }
+        __syncthreads();
+        if (c == 0 && g == 0 && tid == 0) p.clk[6] = wall_clock64();
+        if (tid < n) {
+#pragma unroll 8
+            for (int k = 0; k < 48; k++) bacc = fma(Yt[k * YS + tid], s_z[k], bacc);
+        }
+        // product: the 12 column groups of a k-step in registers (the next step's are fetched behind this step's MFMAs)
+        double cur[NTT], nxt[NTT];
+        const double* row0 = Yt + kq * YS + i16;
+#pragma unroll
+        for (int cg = 0; cg < NTT; cg++) cur[cg] = row0[16 * cg];
+        for (int k4 = 0; k4 < 12; k4++) {
+            const double* rown = Yt + (4 * (k4 + 1 < 12 ? k4 + 1 : k4) + kq) * YS + i16;
+#pragma unroll
+            for (int cg = 0; cg < NTT; cg++) nxt[cg] = rown[16 * cg];
+#pragma unroll
+            for (int u = 0; u < NOWN; u++)
+                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[schur_tile_row(WV + 4 * u)], cur[schur_tile_col(WV + 4 * u)], acc[u], 0, 0, 0);
+#pragma unroll
+            for (int cg = 0; cg < NTT; cg++) cur[cg] = nxt[cg];
+        }
+    }
+    if (g == 0 && tid == 0) p.clk[7] = wall_clock64();
+    double* out = p.dpart + (size_t)g * TT * 256;
+#pragma unroll
+    for (int u = 0; u < NOWN; u++) {
+        double* o = out + (size_t)(WV + 4 * u) * 256 + lane * 4;
+        *reinterpret_cast<double2*>(o) = double2{acc[u][0], acc[u][1]};
+        *reinterpret_cast<double2*>(o + 2) = double2{acc[u][2], acc[u][3]};
+    }
+    if (tid < n) p.dbpart[(size_t)g * 16 * sd.ntt + tid] = bacc;
+}
+
+__global__ __launch_bounds__(kThreads) void ba_schur_dense_kernel(BAPtrs p, BADims d, SchurDense sd, int slot) {
+    uh_latency_critical();
+    extern __shared__ __attribute__((aligned(16))) double s_dense[];   // Yt[48][ys], z[48]
+    __shared__ BAState s_state;
+    const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ncam = d.nfree * kCamChunks;
+    const bool cam_role = (int)blockIdx.x < ncam;   // (the camera workgroups go first: they are the shorter ones and were the launch's tail behind the product workgroups)
+#ifdef UH_BA_DENSE_CLK   // whole-launch stamps (scripts/ba_chain_clocks.py): entry of workgroup 0, the last product / camera workgroup's end
+    if ((int)blockIdx.x == ncam && tid == 0) { p.clk[15] = wall_clock64(); p.clk[16] = 0; p.clk[17] = 0; }
+#define UH_DENSE_END(i) do { if (tid == 0) atomicMax((unsigned long long*)&p.clk[i], (unsigned long long)wall_clock64()); } while (0)
+#else
+#define UH_DENSE_END(i)
+#endif
+    if (tid < 64) {
+        const BAState st0 = p.st[slot];
+        const DecideSums sm = decide_sums(p, d, tid, st0.lambda);
+        if (tid == 0) s_state = (st0.phase != 2 && st0.pending) ? apply_decision(st0, sm, st0.stop_seen != 0) : st0;
+    }
+    double* const Yt = s_dense;
+    double* const s_z = s_dense + 48 * sd.ys;
+    if (!cam_role) for (int i = tid; i < 48 * sd.ys; i += kThreads) Yt[i] = 0.0;   // (the padding columns stay zero for the whole launch)
+    __syncthreads();
+    BAState st = s_state;
+    if (st.phase == 2) {
+        if (blockIdx.x == 0 && tid == 0) { st.pending = 0; p.st[slot ^ 1] = st; }
+        return;
+    }
+    if ((int)blockIdx.x == ncam && tid == 0) p.clk[4] = wall_clock64();
+    double lambda = st.lambda;
+    if (st.iteration == 0 && st.qmax == 0) {   // tau * max |H_jj| over poses and landmarks (as in ba_schur_kernel)
+        double m = 0;
+        for (int i = 0; i < d.nPointBlocks; i++) m = fmax(m, p.part_maxdiag[i]);
+        for (int s = 0; s < d.nfree; s++) {
+            int q = 0;
+            for (int a = 0; a < 6; a++) {
+                double v = 0;
+                for (int c = 0; c < kCamChunks; c++) v += p.HppPart[((size_t)s * kCamChunks + c) * 27 + q];
+                m = fmax(m, fabs(v));
+                q += 6 - a;
+            }
+        }
+        lambda = 1e-5 * m;
+        st.lambda = lambda; st.ni = 2;
+    }
+    if (blockIdx.x == 0 && tid == 0) { BAState pub = st; pub.pending = 1; pub.stop_seen = 0; p.st[slot ^ 1] = pub; }
+    if (cam_role) {
+        if (!st.first_trial) camera_block(p, d, blockIdx.x, p.poseR[st.cur], p.pts[st.cur]);
+        UH_DENSE_END(17);
+        return;
+    }
+    // each wave runs its own instantiation (the same barriers, a static tile list), one set per number of tile rows
+#define UH_SCHUR_DENSE_NTT(N) case N: switch (wv) { \
+        case 0: schur_dense_wave<0, N>(p, d, sd, st, lambda, Yt, s_z); break; case 1: schur_dense_wave<1, N>(p, d, sd, st, lambda, Yt, s_z); break; \
+        case 2: schur_dense_wave<2, N>(p, d, sd, st, lambda, Yt, s_z); break; default: schur_dense_wave<3, N>(p, d, sd, st, lambda, Yt, s_z); break; } break;
+    switch (sd.ntt) {
+        UH_SCHUR_DENSE_NTT(7) UH_SCHUR_DENSE_NTT(8) UH_SCHUR_DENSE_NTT(9) UH_SCHUR_DENSE_NTT(10) UH_SCHUR_DENSE_NTT(11) UH_SCHUR_DENSE_NTT(12)
+        default: break;   // (the host launches this kernel for 7..12 tile rows only: 17..32 free cameras)
+    }
+#undef UH_SCHUR_DENSE_NTT
+    if ((int)blockIdx.x == ncam && tid == 0) p.clk[5] = wall_clock64();
+    UH_DENSE_END(16);
+}
+
+// Sum of the G dense partials, in workgroup order, into the pair layout the solve's assembly reads (Spart as ONE chunk).  Workgroup t
+// sums tile t: thread e reads word e of the tile in every partial (consecutive threads, consecutive words), finds its element (i, j)
+// from the MFMA C layout (row = (lane >> 4) + 4 reg, col = lane & 15) and writes entry (a, c) of pair (j / 6, i / 6) — both orders
+// inside a diagonal camera block.  Workgroup T sums b_schur.
+constexpr int kReduceGroups = 4;   // the partials are cut into four consecutive ranges, summed by four thread groups and added in range order
+// mode 0: into Spart (the pair layout, for a solve that assembles itself); mode 1 / 2: the FINISHED system into p.S — camera sums and
+// lambda added on the diagonal blocks exactly as the assembly does ((-sum) + (h + lambda)), row n = b_p - b_schur, b_p stored for the
+// decision — with row stride n + 1 (1: the fused solve) or as a packed lower triangle (2: the stand-alone solve): the solve copies it.
+__global__ __launch_bounds__(kThreads* kReduceGroups) void ba_schur_reduce_kernel(BAPtrs p, BADims d, SchurDense sd, int slot, int mode) {
+    uh_latency_critical();
+    __shared__ double s_sum[kReduceGroups][kThreads];
+    const BAState stp = p.st[slot];
+    if (stp.phase == 2) return;   // (the pass had finished: the schur launch wrote nothing)
+    const int tid = threadIdx.x & (kThreads - 1), grp = threadIdx.x / kThreads, t = blockIdx.x;
+    const double* src; size_t stride;
+    const bool bvec = t == sd.T;
+    if (bvec) { src = p.dbpart + (tid < d.n ? tid : 0); stride = (size_t)16 * sd.ntt; }
+    else { src = p.dpart + (size_t)t * 256 + tid; stride = (size_t)sd.T * 256; }
+    const int g0 = (int)((long long)sd.G * grp / kReduceGroups), g1 = (int)((long long)sd.G * (grp + 1) / kReduceGroups);
+    double v = 0;
+    int gidx = g0;
+    for (; gidx + 16 <= g1; gidx += 16) {   // (a partial was written by another XCD a moment ago: every batch is a memory round trip)
+        double w[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) w[u] = src[(size_t)(gidx + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v += w[u];
+    }
+    {
+        double w[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) w[u] = gidx + u < g1 ? src[(size_t)(gidx + u) * stride] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; u++) v += w[u];
+    }
+    s_sum[grp][tid] = v;
+    __syncthreads();
+    if (grp != 0) return;
+#pragma unroll
+    for (int k = 1; k < kReduceGroups; k++) v += s_sum[k][tid];
+    auto pair_of = [&](int s1, int s2) { return s1 * d.nfree - s1 * (s1 - 1) / 2 + (s2 - s1); };
+    const int n = d.n, ld = n + 1;
+    auto SX = [&](int r, int c) -> size_t { return mode == 2 ? (size_t)r * (r + 1) / 2 + c : (size_t)r * ld + c; };
+    if (bvec) {
+        if (tid >= n) return;
+        const int sc = tid / 6, a = tid - 6 * sc;
+        if (mode == 0) { p.Spart[(size_t)pair_of(sc, sc) * 42 + 36 + a] = v; return; }
+        double h = 0;
+#pragma unroll
+        for (int cch = 0; cch < kCamChunks; cch++) h += p.HppPart[((size_t)sc * kCamChunks + cch) * 27 + 21 + a];
+        p.bp[tid] = h;
+        p.S[SX(n, tid)] = h - v;
+        return;
+    }
+    const int ti = schur_tile_row(t), tj = schur_tile_col(t);
+    const int lane = tid >> 2, reg = tid & 3;
+    const int i = 16 * ti + (lane >> 4) + 4 * reg, j = 16 * tj + (lane & 15);
+    if (i >= n || j > i) return;
+    const int si = i / 6, ai = i - 6 * si, sj = j / 6, aj = j - 6 * sj;
+    if (mode == 0) {
+        double* o = p.Spart + (size_t)pair_of(sj, si) * 42;
+        o[aj * 6 + ai] = v;
+        if (si == sj && i != j) o[ai * 6 + aj] = v;
+        return;
+    }
+    v = -v;
+    if (si == sj) {
+        const int lo = aj, hi = ai;   // (j <= i inside the block: aj <= ai)
+        const int hq = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);
+        double h = 0;
+#pragma unroll
+        for (int cch = 0; cch < kCamChunks; cch++) h += p.HppPart[((size_t)si * kCamChunks + cch) * 27 + hq];
+        v += h + (i == j ? stp.lambda : 0.0);
+    }
+    p.S[SX(i, j)] = v;
 }
 
 // Pose update of free pose `s` into the trial buffer: T_trial = exp(dx) * T_cur (SE3Quat::exp, VertexSE3Expmap::oplusImpl);
@@ -1267,7 +1530,27 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     };
     using std::integral_constant;
     using std::true_type; using std::false_type;
-    if (nsplit <= 3) {
+    if (nsplit == 0) {
+        // The dense Schur form's reduce launch (ba_schur_reduce_kernel) left the finished system in p.S — partials summed, camera sums
+        // and lambda folded in, right-hand side as row n, in THIS body's layout (packed, or row stride n + 1): a straight copy.
+        if constexpr (USE_LDS || PACKED) {
+            const size_t total = PACKED ? (size_t)(n + 1) * (n + 2) / 2 : (size_t)(n + 1) * ld;
+            constexpr int CU = 6;   // 16-byte units per thread in flight
+            for (size_t i0 = 2 * (size_t)tid; i0 < total; i0 += 2 * (size_t)NT * CU) {
+                double2 w[CU];
+#pragma unroll
+                for (int u = 0; u < CU; u++) { const size_t i = i0 + 2 * (size_t)NT * u; w[u] = i + 1 < total ? *reinterpret_cast<const double2*>(p.S + i) : double2{i < total ? p.S[i] : 0.0, 0.0}; }
+                if (!have_state) {
+                    const BAState st = p.st[slot];
+                    if (st.phase == 2) { finished = true; break; }   // uniform: nothing has been written yet
+                    lambda = st.lambda; cur = st.cur; have_state = true;
+                    if (tid == 0 && blockIdx.x == 0) { p.clk[10] = clk_begin; p.clk[26] = clk_begin; p.clk[27] = wall_clock64(); }
+                }
+#pragma unroll
+                for (int u = 0; u < CU; u++) { const size_t i = i0 + 2 * (size_t)NT * u; if (i + 1 < total) *reinterpret_cast<double2*>(M + i) = w[u]; else if (i < total) M[i] = w[u].x; }
+            }
+        }
+    } else if (nsplit <= 3) {
         pass(integral_constant<int, 2>{}, integral_constant<int, 3>{}, true_type{});     // (first: it requests the state; its lambda goes onto the diagonal)
         if (!finished) pass(integral_constant<int, 8>{}, integral_constant<int, 3>{}, false_type{});
     } else {
@@ -2024,6 +2307,7 @@ struct uh_ba {
     unsigned char* h_stop = nullptr;      // pinned, device-visible force-stop flag
     int iters[2] = {0, 0};
     int nsplit = 1;
+    bool dense = false; SchurDense sd{};   // 17-32 free keyframes of the launch chain: ba_schur_dense_kernel + ba_schur_reduce_kernel (Spart then holds ONE chunk)
     bool wide = false;                    // more than kMaxFree free keyframes: sparse pair lists + blocked dense LDL^T in HBM
     bool persist = false;                 // 1..8 free keyframes: the whole optimisation is ONE persistent launch (ba_persist.hpp)
     int persist_blocked = 0;              // > 0: the persistent form's workgroups did not all become resident lately (another spinning kernel shares the GPU): so many of the next problems take the launch chain
@@ -2144,20 +2428,33 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
             b->step++;
             continue;
         }
-        UH_LAUNCH(b->ctx,ba_schur_kernel, dim3(std::max(npairs, 1) * b->nsplit + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d, b->nsplit, slot);
-        if (use_lds) {
-            UH_LAUNCH(b->ctx,ba_backsub_kernel<true>, dim3(d.nPointBlocks), dim3(kThreads), lds, b->ptrs, d, b->nsplit, slot ^ 1);
-        } else {
-            // 22-32 free cameras: the stand-alone solve keeps the system as a packed triangle in its own LDS (148 KB at 32 cameras, beside
-            // the kernel's static arrays, which are sized for that many: both are checked against the device's limit); more: in HBM
-            const size_t packed = ((size_t)(d.n + 1) * (d.n + 2) / 2 + 2 + kLdltAux) * sizeof(double);   // rows 0 .. n (row n = right-hand side) + the solve's scratch
+        // which solve follows: fused into the back-substitution launch (system in LDS, n <= 126), stand-alone on a packed triangle in LDS
+        // (22-32 free cameras: 148 KB at 32, beside the kernel's static arrays — both checked against the device's limit), else in HBM
+        const size_t packed = ((size_t)(d.n + 1) * (d.n + 2) / 2 + 2 + kLdltAux) * sizeof(double);   // rows 0 .. n (row n = right-hand side) + the solve's scratch
+        bool use_packed = false;
+        if (!use_lds) {
             static const size_t packed_static = [] { hipFuncAttributes fa{}; return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&ba_solve_kernel<false, true>)) == hipSuccess ? fa.sharedSizeBytes : (size_t)1 << 30; }();
             if (b->max_lds <= 0) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, b->ctx->device) == hipSuccess) b->max_lds = v; }
-            if (d.nfree <= kPackedFree && packed + packed_static <= (size_t)std::max(b->max_lds, 0) && !(getenv("UH_BA_SOLVE") && std::string(getenv("UH_BA_SOLVE")) == "hbm"))
-                UH_LAUNCH(b->ctx, (ba_solve_kernel<false, true>), dim3(1), dim3(kPackedThreads), packed, b->ptrs, d, b->nsplit, slot ^ 1);
+            use_packed = d.nfree <= kPackedFree && packed + packed_static <= (size_t)std::max(b->max_lds, 0) && !(getenv("UH_BA_SOLVE") && std::string(getenv("UH_BA_SOLVE")) == "hbm");
+        }
+        // dense Schur form: the reduce launch leaves the FINISHED system in p.S in the following solve's layout (1: row stride n + 1,
+        // 2: packed) and the solve copies it (nsplit 0); the HBM solve keeps its own assembly from Spart (0)
+        static const bool pre_off = getenv("UH_BA_PREBUILT") && atoi(getenv("UH_BA_PREBUILT")) == 0;   // (A/B knob)
+        const int pre_mode = (b->dense && !pre_off) ? (use_lds ? 1 : (use_packed ? 2 : 0)) : 0;
+        const int ns = pre_mode ? 0 : b->nsplit;
+        if (b->dense) {
+            UH_LAUNCH(b->ctx, ba_schur_dense_kernel, dim3(d.nfree * kCamChunks + b->sd.G), dim3(kThreads), (size_t)(48 * b->sd.ys + 48) * sizeof(double), b->ptrs, d, b->sd, slot);
+            UH_LAUNCH(b->ctx, ba_schur_reduce_kernel, dim3(b->sd.T + 1), dim3(kThreads * kReduceGroups), 0, b->ptrs, d, b->sd, slot ^ 1, pre_mode);
+        } else
+        UH_LAUNCH(b->ctx,ba_schur_kernel, dim3(std::max(npairs, 1) * b->nsplit + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d, b->nsplit, slot);
+        if (use_lds) {
+            UH_LAUNCH(b->ctx,ba_backsub_kernel<true>, dim3(d.nPointBlocks), dim3(kThreads), lds, b->ptrs, d, ns, slot ^ 1);
+        } else {
+            if (use_packed)
+                UH_LAUNCH(b->ctx, (ba_solve_kernel<false, true>), dim3(1), dim3(kPackedThreads), packed, b->ptrs, d, ns, slot ^ 1);
             else
-                UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kSolveThreads), 0, b->ptrs, d, b->nsplit, slot ^ 1);
-            UH_LAUNCH(b->ctx,ba_backsub_kernel<false>, dim3(d.nPointBlocks), dim3(kThreads), 0, b->ptrs, d, b->nsplit, slot ^ 1);
+                UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kSolveThreads), 0, b->ptrs, d, ns, slot ^ 1);
+            UH_LAUNCH(b->ctx,ba_backsub_kernel<false>, dim3(d.nPointBlocks), dim3(kThreads), 0, b->ptrs, d, ns, slot ^ 1);
         }
         b->step++;
     }
@@ -2454,6 +2751,21 @@ static int set_problem_tables(uh_ba* b, const uh_ba_problem* pr) {
     if (npairs_h > 32) b->nsplit = std::max(1, std::min(b->nsplit, uh_div_up(300, npairs_h)));   // (17 free cameras: 2 chunks, measured best — scripts/ba_chain_kernels.py with UH_BA_NSPLIT)
     if (const char* e = getenv("UH_BA_NSPLIT")) b->nsplit = std::max(1, std::min(kMaxSplit, atoi(e)));   // (measurement override: scripts/ba_chain_kernels.py)
     if (const char* e = getenv("UH_BA_NSPLIT")) b->nsplit = std::max(1, std::min(kMaxSplit, atoi(e)));   // tuning knob (measurement only)
+    // dense Schur form: windows of 17-32 free keyframes (UH_BA_SCHUR_DENSE=0 keeps the pair form)
+    {
+        const char* e = getenv("UH_BA_SCHUR_DENSE");
+        b->dense = !wide && nfree >= 17 && nfree <= 32 && !(e && atoi(e) == 0);   // (7..12 tile rows: the kernel's instantiations)
+        if (b->dense) {
+            SchurDense& sd = b->sd;
+            sd.ntt = uh_div_up(d.n, 16); sd.T = sd.ntt * (sd.ntt + 1) / 2;
+            sd.ys = 16 * sd.ntt + ((sd.ntt & 1) ? 0 : 16);   // row stride = 16 (mod 32) doubles: the four k-rows of an MFMA operand read fall on disjoint banks
+            const int chunks = std::max(uh_div_up(P, 16), 1);
+            const int gmax = getenv("UH_BA_DENSE_G") ? std::max(1, atoi(getenv("UH_BA_DENSE_G"))) : 224;   // (tuning knob: scripts/ba_chain_kernels.py)
+            sd.cpw = uh_div_up(chunks, gmax); sd.G = uh_div_up(chunks, sd.cpw);
+            b->nsplit = 1;
+        }
+    }
+    const size_t o_dpart = A.take<double>(b->dense ? (size_t)b->sd.G * b->sd.T * 256 : 1), o_dbpart = A.take<double>(b->dense ? (size_t)b->sd.G * 16 * b->sd.ntt : 1);
     const size_t o_S = A.take<double>((size_t)(d.n + 1) * (d.n + 1)), o_Sp = A.take<double>(wide ? 42 : (size_t)b->nsplit * std::max(npairs_h, 1) * 42), o_xp = A.take<double>(std::max(d.n, 1));
     const size_t wn_pairs = w_pair_s1.size(), wn_items = w_item_pair.size(), wn_tri = w_tri_pt.size();
     const size_t o_wps1 = A.take<int>(wn_pairs + 1), o_wps2 = A.take<int>(wn_pairs + 1), o_wpip = A.take<int>(wn_pairs + 2);
@@ -2525,6 +2837,7 @@ static int set_problem_tables(uh_ba* b, const uh_ba_problem* pr) {
     for (int i = 0; i < 2; i++) { p.Hll[i] = (double*)(base + o_Hll[i]); p.bl[i] = (double*)(base + o_bl[i]); p.Hpl[i] = (double*)(base + o_Hpl[i]); }
     p.HppPart = (double*)(base + o_Hpp); p.bp = (double*)(base + o_bp);
     p.S = (double*)(base + o_S); p.Spart = (double*)(base + o_Sp); p.xp = (double*)(base + o_xp);
+    p.dpart = (double*)(base + o_dpart); p.dbpart = (double*)(base + o_dbpart);
     {
         BAWide& W = b->wd;
         W.n_pairs = (int)wn_pairs; W.n_items = (int)wn_items; W.ld = d.n + 1;
