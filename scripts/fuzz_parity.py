@@ -20,8 +20,9 @@ def run(name, fn):
     if only and name not in only:
         return
     t0, n, bad = time.time(), 0, []
-    while time.time() - t0 < budget:
-        seed = int(rng.integers(0, 2 ** 31))
+    replay = [int(x) for x in os.environ.get("UH_FUZZ_SEEDS", "").split(",") if x]   # re-run given seeds of the selected stage (A/B of one path)
+    while (n < len(replay)) if replay else (time.time() - t0 < budget):
+        seed = replay[n] if replay else int(rng.integers(0, 2 ** 31))
         try:
             ok, info = fn(seed)
         except Exception as e:   # a crash is a failure too
@@ -219,7 +220,7 @@ _ba_stream = GlobalOptimizer.create(ctx)   # ONE object takes every other proble
 
 def ba_case2(seed):
     r = np.random.default_rng(seed)
-    K, P, nfix = int(r.integers(3, 22)), int(r.integers(40, 1500)), int(r.integers(1, 3))   # 1..20 free keyframes: both persistent instantiations and the launch chain
+    K, P, nfix = int(r.integers(3, 37)), int(r.integers(40, 1500)), int(r.integers(1, 3))   # 1..35 free keyframes: both persistent instantiations, the launch chain with the fused, the packed (dense Schur form: 17-32) and the HBM solve
     nit = int(r.choice([5, 10]))
     hard = r.random() < 0.35   # a third of the cases: rejected trials, lambda factors other than 1/3, passes that end early (the speculative trial's drop path)
     if hard:
