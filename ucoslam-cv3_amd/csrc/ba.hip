@@ -1078,40 +1078,69 @@ __device__ __forceinline__ bool ldlt_rowlane2_lds(double* M, int n, int ld, int 
             if (r <= k0 + j) M[r * ld + k0 + j] = 0.0;
         }
     };
-    auto trailing = [&](int kb) {   // waves 1..3: panel kb onto the tiles (s1 <= s2) with s1 >= kb + 2 and the right-hand-side row
-        const int k0 = 6 * kb, J0 = kb + 2;
-        if (J0 >= nb) { zero_upper(kb, tid - 64, kSolveThreads - 64); return; }
-        const int tile0 = J0 * nfree - J0 * (J0 - 1) / 2;
-        const int ntile = npairs - tile0;
-        const int nunits = 6 * ntile + (nb - J0);
+    // Waves 1..3: the rank-6 update of panel kb on everything behind block column kb + 1 (rows c0 .. n, the right-hand-side row
+    // included), as v_mfma_f64_16x16x4_f64 on 32 x 16 macro tiles with K padded from 6 to 8 (the lanes of k = 6, 7 feed zeros).  The
+    // element-per-thread form it replaces (one (row, 6-column tile) per thread: 48 LDS operand reads per 36 FMAs) kept wave 0 waiting
+    // at the barrier for half of a 17-camera factorisation (scripts/micro/ldlt_time.hip: 35 k of 70 k clocks).  The row-stride layout
+    // has room above the diagonal (block column kb' is zeroed from the diagonal upwards by zero_upper(kb') AFTER every update that
+    // reaches it), so a tile that straddles the diagonal simply updates those words too: only a tile past the last row or the last
+    // column redirects its missing elements to a dump word (the unused word (0, n)).
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    auto trailing = [&](int kb) {
+        const int k0 = 6 * kb, c0 = 6 * (kb + 2);
+        if (c0 >= nrow) { zero_upper(kb, tid - 64, kSolveThreads - 64); return; }
         const double* yb = s_y + (kb & 1) * 768;
-        for (int u = tid - 64; u < nunits; u += kSolveThreads - 64) {
-            int r, c0;
-            bool diag = false;
-            if (u < 6 * ntile) {
-                const int tile = u / 6, s1 = s_pair[tile0 + tile][0], s2 = s_pair[tile0 + tile][1];
-                r = 6 * s2 + (u - 6 * tile); c0 = 6 * s1; diag = s1 == s2;
-            } else { r = n; c0 = 6 * (J0 + (u - 6 * ntile)); }
-            double lr[6], acc[6];
+        const int w = __builtin_amdgcn_readfirstlane(wv) - 1, i16 = lane & 15, kq = lane >> 4;
+        const int TC = (n - c0 + 15) >> 4;   // tile columns (the border row has no column of its own)
+        const bool k2 = kq < 2;   // this lane's second k-step exists (k = 4 + kq < 6)
+        // a tile column's macro tiles are anchored at the LAST row (the top one may start above the diagonal — those words are the
+        // free upper triangle — so none is ragged at the bottom: a ragged tile costs three times an interior one)
+        int tj = 0, m0 = 0;
+        for (int m = w;; m += 3) {
+            while (tj < TC && m0 + ((nrow - c0 - 16 * tj + 31) >> 5) <= m) { m0 += (nrow - c0 - 16 * tj + 31) >> 5; ++tj; }
+            if (tj >= TC) break;
+            const int cb = c0 + 16 * tj, rb = nrow - 32 * (m - m0 + 1), cc = cb + i16, rw0 = rb + kq;
+            const double b0 = yb[kq * 128 + (cc < 128 ? cc : 127)], b1r = yb[(k2 ? 4 + kq : 0) * 128 + (cc < 128 ? cc : 127)];
+            const double b1 = k2 ? b1r : 0.0;
+            f64x4 acc0, acc1;
+            if (rb >= 0 && cb + 16 <= ld) {   // (uniform) no ragged edge
+                const int ab0 = (rb + i16) * ld + k0 + kq, ab1 = ab0 + 16 * ld;
+                const double a00 = M[ab0], a01r = M[ab0 + (k2 ? 4 : 0)], a10 = M[ab1], a11r = M[ab1 + (k2 ? 4 : 0)];
+                const int i0 = rw0 * ld + cc;
 #pragma unroll
-            for (int t = 0; t < 6; t++) lr[t] = M[r * ld + k0 + t];
+                for (int v = 0; v < 4; v++) { acc0[v] = M[i0 + 4 * v * ld]; acc1[v] = M[i0 + (16 + 4 * v) * ld]; }
+                const double a01 = k2 ? -a01r : 0.0, a11 = k2 ? -a11r : 0.0;
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a00, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a10, b0, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, b1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, b1, acc1, 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 6; j++) acc[j] = M[r * ld + c0 + j];
+                for (int v = 0; v < 4; v++) { M[i0 + 4 * v * ld] = acc0[v]; M[i0 + (16 + 4 * v) * ld] = acc1[v]; }
+            } else {
+                const int ar0 = rb + i16 > 0 ? rb + i16 : 0, ar1 = rb + 16 + i16 > 0 ? rb + 16 + i16 : 0;   // (a tile that starts before row 0 or ends past column n)
+                const int ab0 = ar0 * ld + k0 + kq, ab1 = ar1 * ld + k0 + kq;
+                const double a00 = M[ab0], a01r = M[ab0 + (k2 ? 4 : 0)], a10 = M[ab1], a11r = M[ab1 + (k2 ? 4 : 0)];
+                int iv[8];
 #pragma unroll
-            for (int t = 0; t < 6; t++) {
-                const double2 y01 = *reinterpret_cast<const double2*>(yb + t * 128 + c0), y23 = *reinterpret_cast<const double2*>(yb + t * 128 + c0 + 2),
-                              y45 = *reinterpret_cast<const double2*>(yb + t * 128 + c0 + 4);
-                acc[0] = fma(-lr[t], y01.x, acc[0]); acc[1] = fma(-lr[t], y01.y, acc[1]); acc[2] = fma(-lr[t], y23.x, acc[2]);
-                acc[3] = fma(-lr[t], y23.y, acc[3]); acc[4] = fma(-lr[t], y45.x, acc[4]); acc[5] = fma(-lr[t], y45.y, acc[5]);
+                for (int v = 0; v < 8; v++) iv[v] = (rw0 + 4 * v >= 0 && cc < ld) ? (rw0 + 4 * v) * ld + cc : n;   // (word (0, n): the dump)
+#pragma unroll
+                for (int v = 0; v < 4; v++) { acc0[v] = M[iv[v]]; acc1[v] = M[iv[4 + v]]; }
+                const double a01 = k2 ? -a01r : 0.0, a11 = k2 ? -a11r : 0.0;
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a00, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a10, b0, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, b1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, b1, acc1, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; v++) { M[iv[v]] = acc0[v]; M[iv[4 + v]] = acc1[v]; }
             }
-#pragma unroll
-            for (int j = 0; j < 6; j++) if (!diag || c0 + j <= r) M[r * ld + c0 + j] = acc[j];
         }
         zero_upper(kb, tid - 64, kSolveThreads - 64);   // (after the tiles: they are what wave 0 waits for)
     };
     if (wv == 0 && nb > 0) wave0_step(0);
     for (int kb = 0; kb < nb; kb++) {
+        UH_LDLT_CLK(100);   // (scripts/micro/ldlt_time.hip: wave 0's and wave 1's waits at the barrier tell which side the factorisation is bound by)
         __syncthreads();
+        UH_LDLT_CLK(101);
         if (kb == nb - 1) break;
         if (wv == 0) wave0_step(kb + 1);
         else if (tid < kSolveThreads) trailing(kb);
