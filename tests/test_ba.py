@@ -131,7 +131,9 @@ def test_oracle_edge_jacobian_central_differences(oracle):
                                  # the launch chain's two-rows-per-lane solve at its limits: 17 and 21 free keyframes (127 rows)
                                  (19, 900, 15, 2), (23, 1100, 16, 2),
                                  # the stand-alone solve on a packed triangle in LDS: 22, 30, 31 and 32 (its limit) free keyframes; 33: the HBM workspace
-                                 (24, 800, 17, 2), (32, 600, 18, 2), (33, 500, 19, 2), (34, 450, 20, 2), (35, 400, 21, 2)],
+                                 (24, 800, 17, 2), (32, 600, 18, 2), (33, 500, 19, 2), (34, 450, 20, 2), (35, 400, 21, 2),
+                                 # the dense Schur form's remaining tile-row counts (10 at 25 free keyframes; 7-9, 11, 12 are above)
+                                 (27, 700, 22, 2)],
                          ids=lambda c: f"K{c[0]}_P{c[1]}_fix{c[3]}")
 def test_hip_ba_matches_oracle(hip_ctx, oracle, cfg):
     from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
@@ -157,6 +159,33 @@ def test_hip_ba_matches_oracle(hip_ctx, oracle, cfg):
     again = opt.getResults()
     np.testing.assert_array_equal(again["state"], got["state"])
     assert len(opt.getBadAssociations()) == int(got["bad"].sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,P", [(19, 900), (26, 1100), (34, 450)])
+def test_hip_ba_chain_schur_forms_agree(hip_ctx, oracle, monkeypatch, K, P):
+    """17-32 free keyframes: the dense Schur form (MFMA product + reduce launch that leaves the finished system for the solve), the
+    same with the solve assembling from the pair layout (UH_BA_PREBUILT=0) and the pair form (UH_BA_SCHUR_DENSE=0) all reproduce
+    the oracle: same iteration counts, state within the tolerance."""
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    pr = synth.ba_problem(K, P, 31 + K, nfixed=2)
+    ref = oracle_lib.ba_optimize(oracle, pr, 5)
+    states = []
+    for env in ({}, {"UH_BA_PREBUILT": "0"}, {"UH_BA_SCHUR_DENSE": "0"}):
+        for k in ("UH_BA_PREBUILT", "UH_BA_SCHUR_DENSE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        opt = GlobalOptimizer.create(hip_ctx)
+        opt.setParams(pr, ParamSet(nIters=5))
+        opt.optimize()
+        got = opt.getResults()
+        assert opt.form() == "chain"
+        assert got["iters"].tolist() == ref["iters"].tolist(), env
+        assert np.abs(got["state"] - ref["state"]).max() < POSE_TOL, env
+        states.append(got["state"])
+    assert np.abs(states[0] - states[1]).max() < 1e-9 and np.abs(states[0] - states[2]).max() < 1e-9
 
 
 @pytest.mark.gpu

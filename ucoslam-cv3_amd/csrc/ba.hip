@@ -2468,7 +2468,7 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
         }
         // dense Schur form: the reduce launch leaves the FINISHED system in p.S in the following solve's layout (1: row stride n + 1,
         // 2: packed) and the solve copies it (nsplit 0); the HBM solve keeps its own assembly from Spart (0)
-        static const bool pre_off = getenv("UH_BA_PREBUILT") && atoi(getenv("UH_BA_PREBUILT")) == 0;   // (A/B knob)
+        const bool pre_off = getenv("UH_BA_PREBUILT") && atoi(getenv("UH_BA_PREBUILT")) == 0;   // (A/B knob, read per call: tests toggle it)
         const int pre_mode = (b->dense && !pre_off) ? (use_lds ? 1 : (use_packed ? 2 : 0)) : 0;
         const int ns = pre_mode ? 0 : b->nsplit;
         if (b->dense) {
