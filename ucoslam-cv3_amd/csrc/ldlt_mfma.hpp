@@ -61,7 +61,7 @@ __device__ __forceinline__ bool factor_diag6(const double* M, IXF IX, int k0, Di
 
 // Every thread of the workgroup calls it (it contains barriers; blockDim.x >= n + 1, a multiple of 64).  M: rows 0 .. n, row n = b.
 // On return s_x[0 .. n) = x (valid after the caller's next barrier) and M holds L (strictly below the diagonal), D on the diagonal,
-// z in row n.  Returns (every thread) whether a pivot was zero / non-finite — the caller publishes it.
+// z in row n.  Returns (in the waves that hold rows, thread 0 among them) whether a pivot was zero / non-finite — the caller publishes it.
 template <bool PACKED>
 __device__ __forceinline__ bool ldlt_solve_mfma_lds(double* M, int n, int ld, double* s_aux, double* s_x) {
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
@@ -84,7 +84,7 @@ __device__ __forceinline__ bool ldlt_solve_mfma_lds(double* M, int n, int ld, do
     const int i16 = lane & 15, kq = lane >> 4;
     const int dumpix = (int)(s_aux + 60 - M);
     auto macro_tile = [&](int k0, int rb, int cb, const double (&dq)[3]) {
-        const bool interior = rb >= cb + 16 && rb + 32 <= nrow;   // (uniform)
+        const bool interior = rb >= cb + 16 && cb + 16 <= n;   // (uniform; the tiles are anchored at the last row: rb + 32 <= nrow always)
         const int cc = cb + i16, rw0 = rb + kq;
         const int i0 = IX(rw0, cc);
         int iv[8];
@@ -114,7 +114,7 @@ __device__ __forceinline__ bool ldlt_solve_mfma_lds(double* M, int n, int ld, do
             // REDIRECTED to a dump word in the scratch block — its lane loads, accumulates and stores like every other, nobody reads
             // the word — so the tile needs eight index selects and no select on data, no exec mask, no branch.
             // exists(v)  <=>  cc <= rw < nrow and cc < n  <=>  (unsigned)(rw - cc) < (cc < n ? nrow - cc : 0),  rw - cc = d0 + 4 v
-            const int ar0 = rb + i16 < nrow ? rb + i16 : nrow - 1, ar1 = rb + 16 + i16 < nrow ? rb + 16 + i16 : nrow - 1, br = cc < n ? cc : n - 1;
+            const int ar0 = rb + i16 > 0 ? rb + i16 : 0, ar1 = rb + 16 + i16 > 0 ? rb + 16 + i16 : 0, br = cc < n ? cc : n - 1;   // (rows above the diagonal only feed redirected elements)
             const int ab0 = IX(ar0, k0 + kq), ab1 = IX(ar1, k0 + kq), bb = IX(br, k0 + kq);
 #pragma unroll
             for (int s = 0; s < 3; s++) { a0[s] = M[ab0 + 4 * s]; a1[s] = M[ab1 + 4 * s]; b[s] = M[bb + 4 * s]; }
@@ -138,17 +138,17 @@ __device__ __forceinline__ bool ldlt_solve_mfma_lds(double* M, int n, int ld, do
     auto trailing = [&](int k0) {
         const int c0 = k0 + 12;
         if (c0 >= nrow) return;
-        const int T = (nrow - c0 + 15) >> 4;          // 16-row / 16-column tiles of the remaining triangle
         const int TC = (n - c0 + 15) >> 4;            // tile columns that hold a column of S (the border row has none of its own)
         double dq[3];
 #pragma unroll
         for (int s = 0; s < 3; s++) dq[s] = s_d[4 * s + kq];
-        // macro tiles: tile column tj holds ceil((T - tj) / 2) of them, from the diagonal downwards
+        // macro tiles: tile column tj (columns cb ..) holds ceil((nrow - cb) / 32) of them, anchored at the LAST row, so that only the top
+        // one of a column — the one that meets the diagonal, and may start above it — takes the path with redirected elements
         int tj = 0, m0 = 0;
         for (int m = wv;; m += nw) {
-            while (tj < TC && m0 + ((T - tj + 1) >> 1) <= m) { m0 += (T - tj + 1) >> 1; ++tj; }
+            while (tj < TC && m0 + ((nrow - c0 - 16 * tj + 31) >> 5) <= m) { m0 += (nrow - c0 - 16 * tj + 31) >> 5; ++tj; }
             if (tj >= TC) break;
-            macro_tile(k0, c0 + 16 * tj + 32 * (m - m0), c0 + 16 * tj, dq);
+            macro_tile(k0, nrow - 32 * (m - m0 + 1), c0 + 16 * tj, dq);
         }
     };
 
@@ -179,35 +179,39 @@ __device__ __forceinline__ bool ldlt_solve_mfma_lds(double* M, int n, int ld, do
         }
     };
 
+    // waves that hold no row (a 512-thread workgroup on a 193-row system has four of them: they are there for the trailing update)
+    // skip the panels' arithmetic — it would be redundant work on the SIMDs the row-holding waves run on — and only keep the barriers
+    const bool pw = wv * 64 < nrow;
     for (int kb0 = 0; kb0 < nb; kb0 += 2) {
         const int k0 = 6 * kb0;
         const bool two = kb0 + 1 < nb;
         UH_LDLTM_CLK(0);
         // ---- first panel of the pair
         DiagBlock D;
-        failed = factor_diag6(M, IX, k0, D) || failed;
-        double y1[6], l1[6];
+        double y1[6], l1[6], y2[6], l2[6];
         const bool below1 = r >= k0 + 6;
+        if (pw) {
+            failed = factor_diag6(M, IX, k0, D) || failed;
 #pragma unroll
-        for (int j = 0; j < 6; j++) y1[j] = r >= k0 ? M[rbase + k0 + j] : 0.0;   // (a row IN the block: the entries right of its diagonal are never used)
-        row_solve(D, y1, l1);
-        if (below1 && own) {
+            for (int j = 0; j < 6; j++) y1[j] = r >= k0 ? M[rbase + k0 + j] : 0.0;   // (a row IN the block: the entries right of its diagonal are never used)
+            row_solve(D, y1, l1);
+            if (below1 && own) {
 #pragma unroll
-            for (int j = 0; j < 6; j++) M[rbase + k0 + j] = l1[j];
-            const int q = r - (k0 + 6);
-            if (q < 6 && two) {
+                for (int j = 0; j < 6; j++) M[rbase + k0 + j] = l1[j];
+                const int q = r - (k0 + 6);
+                if (q < 6 && two) {
 #pragma unroll
-                for (int t = 0; t < 6; t++) s_ys[t * 6 + q] = y1[t];
+                    for (int t = 0; t < 6; t++) s_ys[t * 6 + q] = y1[t];
+                }
             }
+            store_pivots(D, 0);
         }
-        store_pivots(D, 0);
         UH_LDLTM_CLK(1);
         __syncthreads();   // A: s_ys, the first panel's L
-        store_own_diag(y1, l1, k0);
+        if (pw) store_own_diag(y1, l1, k0);
         if (!two) break;   // (an odd last block column: nothing lies behind it)
         // ---- the first panel's rank-6 contribution to the second block column, own row
-        double y2[6];
-        {
+        if (pw) {
             double yv[6][6];
 #pragma unroll
             for (int t = 0; t < 6; t++)
@@ -228,20 +232,19 @@ __device__ __forceinline__ bool ldlt_solve_mfma_lds(double* M, int n, int ld, do
         }
         UH_LDLTM_CLK(2);
         __syncthreads();   // B: the second diagonal block
-        failed = factor_diag6(M, IX, k0 + 6, D) || failed;
-        double l2[6];
-        {
+        if (pw) {
+            failed = factor_diag6(M, IX, k0 + 6, D) || failed;
             const bool below2 = r >= k0 + 12;
             row_solve(D, y2, l2);
             if (below2 && own) {
 #pragma unroll
                 for (int j = 0; j < 6; j++) M[rbase + k0 + 6 + j] = l2[j];
             }
+            store_pivots(D, 1);
         }
-        store_pivots(D, 1);
         UH_LDLTM_CLK(3);
         __syncthreads();   // C: both panels and their pivots
-        store_own_diag(y2, l2, k0 + 6);   // (nothing of the trailing update reads these rows' block)
+        if (pw) store_own_diag(y2, l2, k0 + 6);   // (nothing of the trailing update reads these rows' block)
         // ---- trailing update behind the pair
         trailing(k0);
         UH_LDLTM_CLK(4);
@@ -263,7 +266,9 @@ __device__ __forceinline__ bool ldlt_solve_mfma_lds(double* M, int n, int ld, do
     };
     __syncthreads();
     fetch(nb - 1);
+    const bool sw = wv * 64 < n;   // (a wave without an unknown: barriers only)
     for (int kb = nb - 1; kb >= 0; kb--) {
+        if (!sw) { __syncthreads(); continue; }
         const int k0 = 6 * kb;
         double x[6];
 #pragma unroll
