@@ -78,7 +78,7 @@ int run(int nfree) {
 }
 int main() {
     int bad = 0;
-    for (int nf : {1, 2, 3, 5, 7, 8, 12, 16, 17, 20}) bad += run(nf);
+    for (int nf : {1, 2, 3, 5, 7, 8, 9, 10, 12, 16, 17, 20}) bad += run(nf);
     printf(bad ? "FAILED\n" : "ok\n");
     return bad;
 }

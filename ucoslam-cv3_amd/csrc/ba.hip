@@ -989,7 +989,9 @@ __device__ __forceinline__ bool ldlt_rowlane_lds(double* M, int n, int ld, int n
     UH_LDLT_CLK(0);
     if (wv == 0 && nb > 0) wave0_step(0);
     for (int kb = 0; kb < nb; kb++) {
+        UH_LDLT_CLK(100);
         __syncthreads();   // panel kb is in M / s_y[kb & 1]; the trailing update of panel kb-1 is complete
+        UH_LDLT_CLK(101);
         UH_LDLT_CLK(4 + 4 * kb);
         if (kb == nb - 1) break;
         if (wv == 0) wave0_step(kb + 1);
