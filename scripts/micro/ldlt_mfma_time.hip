@@ -1,14 +1,10 @@
-// Times ldlt_mfma_lds (ldlt_mfma.hpp) alone on one workgroup: packed triangle (stand-alone solve, 22-32 free keyframes) and the
-// bordered row-stride form (fused solve, 17-21), checks L D L^T = A and S x = b through the substitutions that follow it in ba.hip.
+// Times ldlt_solve_mfma_lds (ldlt_mfma.hpp) alone on one workgroup of 256 / 512 threads: packed triangle (the stand-alone solve of 22-32
+// free keyframes) and the row-stride form; checks L D L^T = A and S x = b.  Thread 0's phase stamps cost ~250 clocks each.
 // scripts/micro/run_ldlt_mfma_time.sh
 #include <hip/hip_runtime.h>
 __device__ long long g_acc[8];
 __device__ long long g_last;
 #define UH_LDLTM_CLK(i) do { if (threadIdx.x == 0) { const long long t_ = clock64(); if (i > 0) g_acc[i] += t_ - g_last; g_last = t_; } } while (0)
-__device__ long long g_t[4], g_tl;
-#ifdef LDLTM_TSTAMP
-#define UH_LDLTM_T(i) do { if (threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = clock64(); if (i > 0) g_t[i] += t_ - g_tl; g_tl = t_; } } while (0)
-#endif
 #include "ba.hip"
 #include <cstdio>
 #include <vector>
@@ -36,7 +32,7 @@ __global__ __launch_bounds__(NT) void k(const double* A, const double* b, double
         for (int i = threadIdx.x; i < n; i += NT) xout[i] = s_x[i];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { clk[0] = best; clk[1] = bestb; for (int i = 0; i < 8; i++) { clk[2 + i] = g_acc[i] / reps; g_acc[i] = 0; } for (int i = 0; i < 4; i++) { clk[10 + i] = g_t[i] / reps; g_t[i] = 0; } }
+    if (threadIdx.x == 0) { clk[0] = best; clk[1] = bestb; for (int i = 0; i < 8; i++) { clk[2 + i] = g_acc[i] / reps; g_acc[i] = 0; } }
 }
 template <bool PACKED, int NT>
 int run(int nfree) {
@@ -70,7 +66,6 @@ int run(int nfree) {
     printf("%s %d threads nfree %2d (n %3d): solve %6lld clocks (%6.2f us), |LDL^T - A| / max|A| = %.3g, |S x - b| = %.3g\n", PACKED ? "packed" : "stride", NT, nfree, n,
            c[0], c[0] / 2390.0, err / scale, errx);
     printf("      thread 0: first panels %lld, second panel application %lld, second panels %lld, trailing %lld, its barrier %lld, substitution %lld clocks\n", c[3], c[4], c[5], c[6], c[2] + c[7], c[8]);
-    printf("      thread 0's tiles: operands in %lld, MFMAs %lld, write-back %lld clocks\n", c[11], c[12], c[13]);
     hipFree(dA); hipFree(dO); hipFree(db); hipFree(dx); hipFree(dc);
     return !(err / scale < 1e-12 && errx < 1e-9);
 }

@@ -50,18 +50,22 @@ int run(int nfree) {
     for (int i = 0; i < n; i++) for (int j = i + 1; j < ld; j++) A[i * ld + j] = std::nan("");   // the upper triangle is never to be used
     for (int j = 0; j < n; j++) A[n * ld + j] = N(rng);
     double *dA, *dO; long long* dc;
-    hipMalloc(&dA, A.size() * 8); hipMalloc(&dO, (A.size() + 64) * 8); hipMalloc(&dc, 69 * 8);
+    hipMalloc(&dA, A.size() * 8); hipMalloc(&dO, (A.size() + 256) * 8); hipMalloc(&dc, 69 * 8);
     hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
     const size_t lds = (ld * ld + 2 + 2 * 129 * 6) * 8;
     hipLaunchKernelGGL(k, dim3(1), dim3(256), lds, 0, dA, dO, n, nfree, dc, 20);
     hipDeviceSynchronize();
     long long c[69]; hipMemcpy(c, dc, sizeof(c), hipMemcpyDeviceToHost);
-    std::vector<double> O(A.size() + 64); hipMemcpy(O.data(), dO, O.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> O(A.size() + 256); hipMemcpy(O.data(), dO, O.size() * 8, hipMemcpyDeviceToHost);
+    auto worse = [](double a, double b) { return (b > a || b != b) ? b : a; };   // (a NaN is an error, not a smaller number)
+    // from 64 rows on the two-rows-per-lane form runs: it keeps no D (zeros on and above the diagonal) — recover d_k = S_kk - sum_t L_kt^2 d_t
+    std::vector<double> D(n);
+    for (int k = 0; k < n; k++) { if (n + 1 <= 64) D[k] = O[k * ld + k]; else { double s = A[k * ld + k]; for (int t = 0; t < k; t++) s -= O[k * ld + t] * O[k * ld + t] * D[t]; D[k] = s; } }
     double err = 0, errb = 0;
-    for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) { double s = 0; for (int k = 0; k <= j; k++) { const double li = k == i ? 1.0 : O[i * ld + k], lj = k == j ? 1.0 : O[j * ld + k]; s += li * O[k * ld + k] * lj; } err = fmax(err, fabs(s - A[i * ld + j])); }
-    for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k <= i; k++) s += (k == i ? 1.0 : O[i * ld + k]) * O[k * ld + k] * O[n * ld + k]; errb = fmax(errb, fabs(s - A[n * ld + i])); }   // L D z = b
+    for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) { double s = 0; for (int k = 0; k <= j; k++) { const double li = k == i ? 1.0 : O[i * ld + k], lj = k == j ? 1.0 : O[j * ld + k]; s += li * D[k] * lj; } err = worse(err, fabs(s - A[i * ld + j])); }
+    for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k <= i; k++) s += (k == i ? 1.0 : O[i * ld + k]) * D[k] * O[n * ld + k]; errb = worse(errb, fabs(s - A[n * ld + i])); }   // L D z = b
     double errx = 0;   // S x = b with the original matrix
-    for (int i = 0; i < n; i++) { double sx = 0; for (int j = 0; j < n; j++) sx += (j <= i ? A[i * ld + j] : A[j * ld + i]) * O[ld * ld + j]; errx = fmax(errx, fabs(sx - A[n * ld + i])); }
+    for (int i = 0; i < n; i++) { double sx = 0; for (int j = 0; j < n; j++) sx += (j <= i ? A[i * ld + j] : A[j * ld + i]) * O[ld * ld + j]; errx = worse(errx, fabs(sx - A[n * ld + i])); }
     printf("   backsolve %lld clocks (%.2f us), |S x - b| = %.3g\n", c[64], c[64] / 2390.0, errx);
     printf("   barrier waits per factorisation: wave 0 (panels) %lld, wave 1 (trailing update) %lld clocks\n", c[65], c[66]);
     printf("nfree %d: best %lld shader clocks (%.2f us at 2.39 GHz), |LDL^T - A| = %.3g, |L D z - b| = %.3g\n", nfree, c[0], c[0] / 2390.0, err, errb);

@@ -563,7 +563,6 @@ __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, 
 // The prologue (the previous trial's decision, lambda at iteration 0, the published state) and the camera workgroups are those of
 // ba_schur_kernel.  Reference: g2o/core/block_solver.hpp:341-392 (Hschur -= Hpl D^-1 Hpl^T, b -= Hpl D^-1 b_l).
 struct SchurDense { int G, cpw, ntt, ys, T; };   // workgroups, 16-landmark chunks per workgroup, tiles per dimension, LDS row stride, lower tiles
-constexpr int kSchurDenseMaxT = 20;              // lower tiles per wave: 78 tiles (12 per dimension, 32 free cameras) over four waves
 
 __device__ __forceinline__ double schur_rsqrt(double x) {   // v_rsq_f64 + two Newton steps; x <= 0 / NaN gives NaN / inf (the solve then reports failure)
     double r = __builtin_amdgcn_rsq(x);
@@ -1371,75 +1370,6 @@ __device__ __forceinline__ void backsolve_lds(const double* M, int n, int ld, do
 // pivoting; fails on a zero / non-finite pivot like Eigen's SimplicialLDLT) in LDS when it fits (n <= 126) else in HBM,
 // substitutes, and writes T_trial = exp(dx) * T_cur for the free poses.  Row stride is n+1 doubles (odd) so that column
 // walks are LDS-bank-conflict free.
-// L y = b, y /= d, L^T x = y on the PACKED factor (row r at r (r + 1) / 2, unit lower L, d on the diagonal) for 64 < n <= 192: wave 0,
-// three unknowns per lane (rows lane, lane + 64, lane + 128), one v_readlane broadcast per column, the column's entries prefetched four
-// steps ahead.  (The loop form it replaces costs two workgroup barriers per column and direction: 4 n barriers.)
-__device__ __forceinline__ void trisolve_packed_lds(const double* M, int n, double* s_x) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (wv != 0) return;
-    const int r0 = lane, r1 = lane + 64, r2 = lane + 128;
-    auto tri = [](int r) -> size_t { return (size_t)r * (r + 1) / 2; };
-    double x0 = r0 < n ? s_x[r0] : 0.0, x1 = r1 < n ? s_x[r1] : 0.0, x2 = r2 < n ? s_x[r2] : 0.0;
-    const size_t t0 = tri(r0 < n ? r0 : n - 1), t1 = tri(r1 < n ? r1 : n - 1), t2 = tri(r2 < n ? r2 : n - 1);
-    // ---- forward: column j leaves the rows below it
-    auto fwd_load = [&](int j, double (&l)[3]) {   // L(r, j) for this lane's rows (0 where the row is not below column j)
-        const int jj = j < n ? j : n - 1;
-        l[0] = (r0 > jj && r0 < n) ? M[t0 + jj] : 0.0; l[1] = (r1 > jj && r1 < n) ? M[t1 + jj] : 0.0; l[2] = (r2 > jj && r2 < n) ? M[t2 + jj] : 0.0;
-    };
-    {
-        double l[4][3];
-#pragma unroll
-        for (int t = 0; t < 4; t++) fwd_load(t, l[t]);
-        for (int j0 = 0; j0 < n; j0 += 4) {
-            double nl[4][3];
-#pragma unroll
-            for (int t = 0; t < 4; t++) fwd_load(j0 + 4 + t, nl[t]);
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int j = j0 + t;
-                if (j >= n) break;
-                const double a = readlane_f64(x0, j & 63), b = readlane_f64(x1, j & 63), c = readlane_f64(x2, j & 63);
-                const double xj = j < 64 ? a : (j < 128 ? b : c);
-                x0 = fma(-l[t][0], xj, x0); x1 = fma(-l[t][1], xj, x1); x2 = fma(-l[t][2], xj, x2);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; t++) { l[t][0] = nl[t][0]; l[t][1] = nl[t][1]; l[t][2] = nl[t][2]; }
-        }
-    }
-    if (r0 < n) x0 /= M[t0 + r0];
-    if (r1 < n) x1 /= M[t1 + r1];
-    if (r2 < n) x2 /= M[t2 + r2];
-    // ---- backward: row j of L is column j of L^T: it leaves the rows above it
-    auto bwd_load = [&](int j, double (&l)[3]) {
-        const int jj = j >= 0 ? j : 0;
-        const size_t tj = tri(jj);
-        l[0] = r0 < jj ? M[tj + r0] : 0.0; l[1] = r1 < jj ? M[tj + r1] : 0.0; l[2] = r2 < jj ? M[tj + r2] : 0.0;
-    };
-    {
-        double l[4][3];
-#pragma unroll
-        for (int t = 0; t < 4; t++) bwd_load(n - 1 - t, l[t]);
-        for (int j0 = n - 1; j0 >= 0; j0 -= 4) {
-            double nl[4][3];
-#pragma unroll
-            for (int t = 0; t < 4; t++) bwd_load(j0 - 4 - t, nl[t]);
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int j = j0 - t;
-                if (j < 0) break;
-                const double a = readlane_f64(x0, j & 63), b = readlane_f64(x1, j & 63), c = readlane_f64(x2, j & 63);
-                const double xj = j < 64 ? a : (j < 128 ? b : c);
-                x0 = fma(-l[t][0], xj, x0); x1 = fma(-l[t][1], xj, x1); x2 = fma(-l[t][2], xj, x2);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; t++) { l[t][0] = nl[t][0]; l[t][1] = nl[t][1]; l[t][2] = nl[t][2]; }
-        }
-    }
-    if (r0 < n) s_x[r0] = x0;
-    if (r1 < n) s_x[r1] = x1;
-    if (r2 < n) s_x[r2] = x2;
-}
-
 struct SolveOut { bool done; int ok, cur; double lambda; };   // done: the pass had finished, nothing was computed
 
 template <bool USE_LDS, bool PACKED = false>

@@ -1,4 +1,4 @@
-// Solve of the reduced camera system for 17-32 free keyframes (102 <= n <= 192): one workgroup of 256 threads, the system in LDS
+// Solve of the reduced camera system for 22-32 free keyframes (132 <= n <= 192; any n + 1 <= blockDim.x works): one workgroup, the system in LDS
 // (included by ba.hip inside its anonymous namespace, behind fast_rcp).
 //
 // What it replaces: g2o hands Hschur to Eigen::SimplicialLDLT (g2o/solvers/eigen/linear_solver_eigen.h:92-120; natural ordering of a
@@ -25,12 +25,6 @@ typedef double ldlt_f64x4 __attribute__((ext_vector_type(4)));
 #define UH_LDLTM_CLK(i)   // scripts/micro/ldlt_mfma_time.hip stamps thread 0's phases through this hook
 #endif
 
-#ifndef UH_LDLTM_T
-#define UH_LDLTM_T(i)
-#endif
-#ifndef LDLTM_NMFMA
-#define LDLTM_NMFMA 3
-#endif
 constexpr int kLdltAux = 64;   // doubles of LDS scratch the solve needs beside the matrix
 
 // 6 x 6 diagonal block at (k0, k0), read from M by every thread (broadcast) and factorised in registers: unit lower L (strict part),
