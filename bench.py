@@ -116,6 +116,13 @@ def main():
 
     F = args.frames_per_step
     dev = torch.device("cuda", local_rank)
+    # UH_BENCH_CU_SPLIT=<n>: the mapper's stream on mask bits [0, n) and the tracker's on [n, all) of the compute units (n / 8 CUs of every
+    # XCD for the local BA, the rest for the tracker: uh_ctx_create_private_cus) — the two never share a CU
+    cu_split = int(os.environ.get("UH_BENCH_CU_SPLIT", "0"))
+    n_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+    if cu_split:
+        _trk_ctx = u.Context(local_rank, cus=(cu_split, n_cus - cu_split))
+        torch.cuda.set_stream(torch.cuda.ExternalStream(u.lib().uh_ctx_stream(_trk_ctx._h), device=dev))
     ctx = u.Context(local_rank, torch.cuda.current_stream().cuda_stream)
 
     # ---- synthetic inputs: frames in pinned host memory (the camera's buffers), the map's descriptors resident in HBM (the map lives on
@@ -154,7 +161,7 @@ def main():
     index.set_queries_per_wave(args.knn_qpw)
     # the reference runs local BA on its mapper thread, concurrently with tracking (mapmanager.cpp:1550);
     # here BA gets its own HIP stream so that its kernel overlaps the tracking stream's
-    ctx_ba = u.Context(local_rank, private=True)
+    ctx_ba = u.Context(local_rank, cus=(0, cu_split)) if cu_split else u.Context(local_rank, private=True)
     ba = GlobalOptimizer.create(ctx_ba).wantChi2(False)   # (GlobalOptimizer::getResults returns poses, points and bad associations: no chi2)
     ba_ps = ParamSet(nIters=5)
     L = u.lib()

@@ -41,6 +41,11 @@ typedef struct uh_ctx uh_ctx;
  * uh_ctx_create_private() creates and owns a non-blocking stream instead. */
 int         uh_ctx_create(int device, void* hip_stream, uh_ctx** out);
 int         uh_ctx_create_private(int device, uh_ctx** out);
+/* A private stream confined to a share of the GPU's compute units: mask bits [first_bit, first_bit + n_bits) of
+ * hipExtStreamCreateWithCUMask — on MI355X bit p is CU p / 8 of XCD p % 8, so a contiguous range takes the same number of CUs from every
+ * XCD.  For hosts that run the mapper's local BA (latency-bound, <= 94 workgroups) beside the tracker's wide launches, as the reference
+ * runs them on two threads (system.cpp / mapmanager.cpp:150): disjoint ranges keep the two from sharing a CU. */
+int         uh_ctx_create_private_cus(int device, int first_bit, int n_bits, uh_ctx** out);
 void        uh_ctx_destroy(uh_ctx* ctx);
 int         uh_ctx_synchronize(uh_ctx* ctx);
 void*       uh_ctx_stream(uh_ctx* ctx);

@@ -241,6 +241,39 @@ def test_hip_ba_stop_flag_and_errors(hip_ctx, oracle):
 
 
 @pytest.mark.gpu
+def test_hip_ba_and_search_on_disjoint_compute_unit_shares(oracle):
+    """uh_ctx_create_private_cus: the mapper's local BA on mask bits [0, 96) (12 CUs of every XCD on MI355X: the persistent form sizes its
+    co-resident grid from the context's CU count), the tracker's search on the rest — same results as on the whole chip; a share that
+    would leave an XCD empty, or reaches past the device, is refused."""
+    import torch
+    import ucoslam_cv3_amd as u
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+    from ucoslam_cv3_amd.knn import Index
+
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    if ncu < 128:
+        pytest.skip("needs a device with at least 128 compute units")
+    ctx_ba, ctx_trk = u.Context(0, cus=(0, 96)), u.Context(0, cus=(96, ncu - 96))
+    pr = synth.ba_problem(10, 3000, 0, nfixed=2)
+    opt = GlobalOptimizer.create(ctx_ba)
+    opt.setParams(pr, ParamSet(nIters=5))
+    opt.optimize()
+    got = opt.getResults()
+    assert opt.form().startswith("persist")
+    ref = oracle_lib.ba_optimize(oracle, pr, 5)
+    assert got["iters"].tolist() == ref["iters"].tolist()
+    assert np.abs(got["state"] - ref["state"]).max() < POSE_TOL
+    train, q = synth.match_set(500, 3000, seed=5)
+    idx, dist = Index(ctx_trk).build(torch.from_numpy(train).cuda()).search(torch.from_numpy(q).cuda(), 10)
+    ctx_trk.synchronize()
+    ri, rd = oracle_lib.knn_search(oracle, train, q, 10, 0)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ri)
+    for bad in ((0, 4), (ncu - 8, 16), (-8, 16)):
+        with pytest.raises(Exception):
+            u.Context(0, cus=bad)
+
+
+@pytest.mark.gpu
 def test_hip_ba_async_equals_sync(hip_ctx):
     """uh_ba_optimize_async / uh_ba_wait (optimisation on the object's worker thread, like the reference's mapper thread)."""
     import ucoslam_cv3_amd as u

@@ -58,6 +58,7 @@ def _declare(L: C.CDLL):
     sig("uh_version", I)
     sig("uh_ctx_create", I, I, VP, C.POINTER(VP))
     sig("uh_ctx_create_private", I, I, C.POINTER(VP))
+    sig("uh_ctx_create_private_cus", I, I, I, I, C.POINTER(VP))
     sig("uh_ctx_destroy", None, VP)
     sig("uh_ctx_synchronize", I, VP)
     sig("uh_ctx_stream", VP, VP)
@@ -97,9 +98,11 @@ class Context:
     """uh_ctx: one GPU + one HIP stream. `stream` is a torch stream's `.cuda_stream` integer (0/None = the
     default stream); private=True makes the context create and own a non-blocking stream."""
 
-    def __init__(self, device: int = 0, stream: int | None = None, private: bool = False):
+    def __init__(self, device: int = 0, stream: int | None = None, private: bool = False, cus: tuple | None = None):
         self._h = VP()
-        if private:
+        if cus is not None:   # (first mask bit, number of bits): a private stream on that share of the compute units
+            check(lib().uh_ctx_create_private_cus(device, int(cus[0]), int(cus[1]), C.byref(self._h)))
+        elif private:
             check(lib().uh_ctx_create_private(device, C.byref(self._h)))
         else:
             check(lib().uh_ctx_create(device, VP(stream) if stream else None, C.byref(self._h)))

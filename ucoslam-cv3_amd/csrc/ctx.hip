@@ -1,5 +1,6 @@
 // Context + error plumbing of the C ABI (include/ucoslam_hip.h).
 #include <algorithm>
+#include <vector>
 #include "common.hpp"
 
 namespace uh {
@@ -97,6 +98,29 @@ static int ctx_create(int device, void* hip_stream, bool private_stream, uh_ctx*
 
 int uh_ctx_create(int device, void* hip_stream, uh_ctx** out) { return ctx_create(device, hip_stream, false, out); }
 int uh_ctx_create_private(int device, uh_ctx** out) { return ctx_create(device, nullptr, true, out); }
+
+// A private stream confined to a share of the compute units (hipExtStreamCreateWithCUMask).  On MI355X bit p of the mask is CU p / 8 of
+// XCD p % 8 (scripts/micro/cu_mask_probe.hip), so a contiguous bit range [first_bit, first_bit + n_bits) is the same number of CUs on
+// every XCD; a mask that leaves an XCD empty is ignored by the runtime, so a range shorter than the XCD count is refused.  The
+// context reports n_bits as its CU count (the persistent local BA sizes its co-resident grid from it).
+int uh_ctx_create_private_cus(int device, int first_bit, int n_bits, uh_ctx** out) {
+    UH_REQUIRE(out != nullptr, "uh_ctx_create_private_cus: out is NULL");
+    int rc = ctx_create(device, nullptr, false, out);   // (device checks; the stream is made below)
+    if (rc) return rc;
+    uh_ctx* c = *out;
+    const int total = c->num_cus;
+    if (!(first_bit >= 0 && n_bits >= 8 && first_bit + n_bits <= total)) {
+        uh::set_error("uh_ctx_create_private_cus: bits [%d, %d) outside the device's %d compute units (or fewer than 8)", first_bit, first_bit + n_bits, total);
+        delete c; *out = nullptr; return UH_EINVAL;
+    }
+    std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
+    for (int p = first_bit; p < first_bit + n_bits; p++) mask[p >> 5] |= 1u << (p & 31);
+    const hipError_t e = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data());
+    if (e != hipSuccess) { uh::set_error("hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e)); delete c; *out = nullptr; return UH_ENODEVICE; }
+    c->owns_stream = true;
+    c->num_cus = n_bits;
+    return UH_OK;
+}
 
 void uh_ctx_destroy(uh_ctx* ctx) {
     if (!ctx) return;
