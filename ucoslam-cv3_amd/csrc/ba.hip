@@ -53,6 +53,7 @@ namespace {
 constexpr int kMaxFree = 64;          // free (non-fixed) poses in the reduced system
 constexpr int kThreads = 256;
 constexpr int kSolveThreads = 256;                      // solve: one workgroup of 4 waves (one per SIMD)
+constexpr int kFusedThreads = 512;                      // the chain's fused solve (17-21 free cameras): wave 0 the panels, seven waves the trailing update (wave 0 waited half the factorisation for three)
 constexpr int kPackedThreads = 512;                     // its workgroup: 8 waves, two per SIMD — the trailing update's tiles are latency-bound on one
 constexpr int kPackedFree = 32;                          // stand-alone solve on a packed triangle in LDS: up to 32 free cameras (n = 192: 148 KB)
 constexpr int kMaxSplit = 12;                           // schur: landmark chunks per camera pair (partials the solve adds)
@@ -962,7 +963,7 @@ __device__ __forceinline__ bool ldlt_rowlane_lds(double* M, int n, int ld, int n
         const int ntile = npairs - tile0;
         const int nunits = 6 * ntile + (nb - J0);
         const double* yb = s_y + (kb & 1) * 384;
-        for (int u = tid - 64; u < nunits; u += kSolveThreads - 64) {
+        for (int u = tid - 64; u < nunits; u += (int)blockDim.x - 64) {
             int r, c0;
             bool diag = false;
             if (u < 6 * ntile) {
@@ -994,7 +995,7 @@ __device__ __forceinline__ bool ldlt_rowlane_lds(double* M, int n, int ld, int n
         UH_LDLT_CLK(4 + 4 * kb);
         if (kb == nb - 1) break;
         if (wv == 0) wave0_step(kb + 1);
-        else if (tid < kSolveThreads) trailing(kb);
+        else trailing(kb);   // (every other wave of the workgroup: three in the persistent kernel, seven in the chain's fused solve)
     }
     if (wv != 0) failed = false;   // only wave 0 sees the pivots
     return failed;
@@ -1089,15 +1090,15 @@ __device__ __forceinline__ bool ldlt_rowlane2_lds(double* M, int n, int ld, int 
     typedef double f64x4 __attribute__((ext_vector_type(4)));
     auto trailing = [&](int kb) {
         const int k0 = 6 * kb, c0 = 6 * (kb + 2);
-        if (c0 >= nrow) { zero_upper(kb, tid - 64, kSolveThreads - 64); return; }
+        if (c0 >= nrow) { zero_upper(kb, tid - 64, (int)blockDim.x - 64); return; }
         const double* yb = s_y + (kb & 1) * 768;
-        const int w = __builtin_amdgcn_readfirstlane(wv) - 1, i16 = lane & 15, kq = lane >> 4;
+        const int w = __builtin_amdgcn_readfirstlane(wv) - 1, nwt = ((int)blockDim.x >> 6) - 1, i16 = lane & 15, kq = lane >> 4;
         const int TC = (n - c0 + 15) >> 4;   // tile columns (the border row has no column of its own)
         const bool k2 = kq < 2;   // this lane's second k-step exists (k = 4 + kq < 6)
         // a tile column's macro tiles are anchored at the LAST row (the top one may start above the diagonal — those words are the
         // free upper triangle — so none is ragged at the bottom: a ragged tile costs three times an interior one)
         int tj = 0, m0 = 0;
-        for (int m = w;; m += 3) {
+        for (int m = w;; m += nwt) {
             while (tj < TC && m0 + ((nrow - c0 - 16 * tj + 31) >> 5) <= m) { m0 += (nrow - c0 - 16 * tj + 31) >> 5; ++tj; }
             if (tj >= TC) break;
             const int cb = c0 + 16 * tj, rb = nrow - 32 * (m - m0 + 1), cc = cb + i16, rw0 = rb + kq;
@@ -1135,7 +1136,7 @@ __device__ __forceinline__ bool ldlt_rowlane2_lds(double* M, int n, int ld, int 
                 for (int v = 0; v < 4; v++) { M[iv[v]] = acc0[v]; M[iv[4 + v]] = acc1[v]; }
             }
         }
-        zero_upper(kb, tid - 64, kSolveThreads - 64);   // (after the tiles: they are what wave 0 waits for)
+        zero_upper(kb, tid - 64, (int)blockDim.x - 64);   // (after the tiles: they are what wave 0 waits for)
     };
     if (wv == 0 && nb > 0) wave0_step(0);
     for (int kb = 0; kb < nb; kb++) {
@@ -1144,9 +1145,9 @@ __device__ __forceinline__ bool ldlt_rowlane2_lds(double* M, int n, int ld, int 
         UH_LDLT_CLK(101);
         if (kb == nb - 1) break;
         if (wv == 0) wave0_step(kb + 1);
-        else if (tid < kSolveThreads) trailing(kb);
+        else trailing(kb);
     }
-    if (nb > 0 && tid < kSolveThreads) zero_upper(nb - 1, tid, kSolveThreads);
+    if (nb > 0) zero_upper(nb - 1, tid, (int)blockDim.x);
     if (wv != 0) failed = false;
     return failed;
 }
@@ -1377,7 +1378,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     extern __shared__ __attribute__((aligned(16))) double s_mat[];
     __shared__ int s_ok;
     out.done = true;
-    constexpr int NT = PACKED ? kPackedThreads : kSolveThreads;   // threads of the workgroup that runs this body
+    constexpr int NT = PACKED ? kPackedThreads : (USE_LDS ? kFusedThreads : kSolveThreads);   // threads of the workgroup that runs this body
     const int n = d.n, ld = n + 1;
     const int npairs = d.nfree * (d.nfree + 1) / 2;
     // the address space must be known at compile time: a generic pointer would turn every access into a flat_load
@@ -2005,7 +2006,7 @@ __global__ __launch_bounds__(256) void ba_posew_kernel(BAPtrs p, BADims d, BAWid
 // in LDS and goes on with its landmarks.  All workgroups write identical trial poses / xp / solve_ok.  Saves one kernel
 // boundary and the dependent reloads behind it per LM trial.
 template <bool FUSED>
-__global__ __launch_bounds__(kThreads) void ba_backsub_kernel(BAPtrs p, BADims d, int nsplit, int slot) {
+__global__ __launch_bounds__(FUSED ? kFusedThreads : kThreads) void ba_backsub_kernel(BAPtrs p, BADims d, int nsplit, int slot) {
     uh_latency_critical();
     __shared__ double s_red[kThreads];
     __shared__ double s_xp[6 * kMaxFree];
@@ -2020,6 +2021,7 @@ __global__ __launch_bounds__(kThreads) void ba_backsub_kernel(BAPtrs p, BADims d
         solve_body<true>(p, d, nsplit, slot, s_xp, so);
         if (so.done) return;
         __syncthreads();   // trial poses (written to HBM by this workgroup) and s_xp are complete
+        if (threadIdx.x >= kThreads) return;   // (the waves that were here for the solve: the landmark phase below is laid out for kThreads)
         cur = so.cur; ok = so.ok; lambda = so.lambda;
     } else {
         const BAState st = p.st[slot];
@@ -2409,7 +2411,7 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
         } else
         UH_LAUNCH(b->ctx,ba_schur_kernel, dim3(std::max(npairs, 1) * b->nsplit + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d, b->nsplit, slot);
         if (use_lds) {
-            UH_LAUNCH(b->ctx,ba_backsub_kernel<true>, dim3(d.nPointBlocks), dim3(kThreads), lds, b->ptrs, d, ns, slot ^ 1);
+            UH_LAUNCH(b->ctx,ba_backsub_kernel<true>, dim3(d.nPointBlocks), dim3(kFusedThreads), lds, b->ptrs, d, ns, slot ^ 1);
         } else {
             if (use_packed)
                 UH_LAUNCH(b->ctx, (ba_solve_kernel<false, true>), dim3(1), dim3(kPackedThreads), packed, b->ptrs, d, ns, slot ^ 1);
