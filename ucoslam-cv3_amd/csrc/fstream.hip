@@ -247,8 +247,9 @@ int uh_fstream_local_dev(uh_fstream* f, const uint8_t* d_frame, int w, int h, si
         // only the first cnt[cur] rows of the block are frame t-1's descriptors (finish rewrites that many): the rows behind them are
         // older frames' and must not be able to overflow a list
         if ((rc = uh_knn_set_valid_rows_dev(f->tile, f->cnt.as<int32_t>() + f->cur))) return rc;
-        if ((rc = uh_knn_scan_shard_dev(f->tile, q, F, f->p.nn, -1, reinterpret_cast<uint64_t*>(m + f->L.cand), reinterpret_cast<int32_t*>(m + f->L.counts), f->p.cand_cap)))
-            return rc;
+        rc = uh_knn_scan_shard_dev(f->tile, q, F, f->p.nn, -1, reinterpret_cast<uint64_t*>(m + f->L.cand), reinterpret_cast<int32_t*>(m + f->L.counts), f->p.cand_cap);
+        (void)uh_knn_set_valid_rows_dev(f->tile, nullptr);   // (the launch has taken the pointer: the caller's index does not keep one into this stream's memory)
+        if (rc) return rc;
         if (f->voc) {
             const int b0 = (int)((long long)F * f->p.rank / f->p.world), b1 = (int)((long long)F * (f->p.rank + 1) / f->p.world);
             if (b1 > b0 && (rc = uh_bow_transform_dev(f->voc, q + (size_t)b0 * 32, b1 - b0, f->p.bow_level, reinterpret_cast<uint32_t*>(m + f->L.bow_word),
