@@ -133,7 +133,9 @@ def test_oracle_edge_jacobian_central_differences(oracle):
                                  # the stand-alone solve on a packed triangle in LDS: 22, 30, 31 and 32 (its limit) free keyframes; 33: the HBM workspace
                                  (24, 800, 17, 2), (32, 600, 18, 2), (33, 500, 19, 2), (34, 450, 20, 2), (35, 400, 21, 2),
                                  # the dense Schur form's remaining tile-row counts (10 at 25 free keyframes; 7-9, 11, 12 are above)
-                                 (27, 700, 22, 2)],
+                                 (27, 700, 22, 2),
+                                 # 33-64 free keyframes: the system in HBM, factorised by the same panels + MFMA update on global memory
+                                 (42, 500, 23, 2), (50, 450, 24, 2), (66, 400, 25, 2)],
                          ids=lambda c: f"K{c[0]}_P{c[1]}_fix{c[3]}")
 def test_hip_ba_matches_oracle(hip_ctx, oracle, cfg):
     from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
@@ -159,6 +161,25 @@ def test_hip_ba_matches_oracle(hip_ctx, oracle, cfg):
     again = opt.getResults()
     np.testing.assert_array_equal(again["state"], got["state"])
     assert len(opt.getBadAssociations()) == int(got["bad"].sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,P", [(6, 300), (14, 600), (24, 800), (30, 500)])
+def test_hip_ba_chain_solve_in_hbm_at_small_sizes(hip_ctx, oracle, monkeypatch, K, P):
+    """UH_BA_SOLVE=hbm + the launch chain forced (UH_BA_FORM=legacy): the HBM solve (33+ free keyframes in production) on systems of every
+    small shape — an odd number of block columns, fewer rows than a wave, more than a tile row."""
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    monkeypatch.setenv("UH_BA_SOLVE", "hbm")
+    monkeypatch.setenv("UH_BA_FORM", "legacy")
+    pr = synth.ba_problem(K, P, 40 + K, nfixed=1)
+    ref = oracle_lib.ba_optimize(oracle, pr, 5)
+    opt = GlobalOptimizer.create(hip_ctx)
+    opt.setParams(pr, ParamSet(nIters=5))
+    opt.optimize()
+    got = opt.getResults()
+    assert got["iters"].tolist() == ref["iters"].tolist()
+    assert np.abs(got["state"] - ref["state"]).max() < POSE_TOL
 
 
 @pytest.mark.gpu

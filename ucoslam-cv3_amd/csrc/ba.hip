@@ -53,6 +53,7 @@ namespace {
 constexpr int kMaxFree = 64;          // free (non-fixed) poses in the reduced system
 constexpr int kThreads = 256;
 constexpr int kSolveThreads = 256;                      // solve: one workgroup of 4 waves (one per SIMD)
+constexpr int kHbmThreads = 512;                        // the stand-alone solve in HBM (33-64 free cameras): a thread per row of up to 385
 constexpr int kFusedThreads = 512;                      // the chain's fused solve (17-21 free cameras): wave 0 the panels, seven waves the trailing update (wave 0 waited half the factorisation for three)
 constexpr int kPackedThreads = 512;                     // its workgroup: 8 waves, two per SIMD — the trailing update's tiles are latency-bound on one
 constexpr int kPackedFree = 32;                          // stand-alone solve on a packed triangle in LDS: up to 32 free cameras (n = 192: 148 KB)
@@ -1378,7 +1379,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     extern __shared__ __attribute__((aligned(16))) double s_mat[];
     __shared__ int s_ok;
     out.done = true;
-    constexpr int NT = PACKED ? kPackedThreads : (USE_LDS ? kFusedThreads : kSolveThreads);   // threads of the workgroup that runs this body
+    constexpr int NT = PACKED ? kPackedThreads : (USE_LDS ? kFusedThreads : kHbmThreads);   // threads of the workgroup that runs this body
     const int n = d.n, ld = n + 1;
     const int npairs = d.nfree * (d.nfree + 1) / 2;
     // the address space must be known at compile time: a generic pointer would turn every access into a flat_load
@@ -1477,6 +1478,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                             s_x[6 * s1 + (q - 36)] = h - v;
                             if constexpr (USE_LDS) M[(size_t)n * ld + 6 * s1 + (q - 36)] = h - v;   // row n of the bordered matrix
                             if constexpr (PACKED) M[IX(n, 6 * s1 + (q - 36))] = h - v;              // (the packed triangle carries that row too)
+                            if constexpr (!PACKED && !USE_LDS) M[(size_t)n * ld + 6 * s1 + (q - 36)] = h - v;   // (and so does the system in HBM: p.S has n + 1 rows)
                         }
                         continue;
                     }
@@ -1536,10 +1538,18 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     // in the update) and a loop-invariant thread -> (row, column) mapping.  After it M holds L (unit lower) and d on the
     // diagonal.
     bool failed = false;
+    bool solved = false;   // the factorisation below substituted too: x is in s_x
     if constexpr (PACKED) {
+        solved = true;
         // 22-32 free keyframes: panels by every thread, MFMA trailing update, block back substitution (ldlt_mfma.hpp); x lands in s_x
         double* const s_aux = s_mat + ((((size_t)(n + 1) * (n + 2) / 2) + 1) & ~(size_t)1);
         failed = ldlt_solve_mfma_lds<true>(M, n, ld, s_aux, s_x);
+    } else if (!USE_LDS && n + 1 <= NT && true) {
+        // 33-64 free keyframes, the system in HBM (row stride n + 1): the same factorisation on global memory — a pair of block columns
+        // is six dependent memory steps instead of the twenty of the 6-column form below
+        __shared__ __attribute__((aligned(16))) double s_aux_hbm[kLdltAux];
+        failed = ldlt_solve_mfma_lds<false>(M, n, ld, s_aux_hbm, s_x);
+        solved = true;
     } else if constexpr (USE_LDS) {
         __shared__ double s_w_store[2][129][6];   // ([2][121][6] for the look-ahead form; the two-rows-per-lane form's panel buffer is [2][6][128] + alignment)
         double (*s_w)[121][6] = reinterpret_cast<double (*)[121][6]>(&s_w_store[0][0][0]);
@@ -1625,7 +1635,9 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
 
     const int ok = s_ok;
     UH_BA_CLKL(12);
-    if (ok) {
+    if (ok && solved) {
+        for (int i = tid; i < n; i += NT) p.xp[i] = s_x[i];   // (s_x is complete: the barrier above)
+    } else if (ok) {
         if (n <= 64) {
             // one wave, x_i lives in lane i; column j of L is read conflict-free thanks to the odd row stride.  x_j is
             // broadcast with v_readlane (j is wave-uniform) and the 2n dependent steps are branch-free: a column outside the
@@ -1662,9 +1674,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
                 if (lane < n) { s_x[lane] = x; p.xp[lane] = x; }
             }
         } else {
-            if constexpr (PACKED) {
-                for (int i = tid; i < n; i += NT) p.xp[i] = s_x[i];   // (the solve above substituted already)
-            } else if (USE_LDS && n <= 128) {   // two unknowns per lane of wave 0, one broadcast per column (the loop below: two barriers per column)
+            if (USE_LDS && n <= 128) {   // two unknowns per lane of wave 0, one broadcast per column (the loop below: two barriers per column)
                 backsolve2_lds(M, n, ld, s_x);
                 __syncthreads();
                 for (int i = tid; i < n; i += NT) p.xp[i] = s_x[i];
@@ -1705,7 +1715,7 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
 // stand-alone form: reduced systems too large for LDS (n > 126) factorise in the HBM workspace p.S, which only one
 // workgroup may use
 template <bool USE_LDS, bool PACKED = false>
-__global__ __launch_bounds__(PACKED ? kPackedThreads : kSolveThreads) void ba_solve_kernel(BAPtrs p, BADims d, int nsplit, int slot) {
+__global__ __launch_bounds__(PACKED ? kPackedThreads : kHbmThreads) void ba_solve_kernel(BAPtrs p, BADims d, int nsplit, int slot) {
     uh_latency_critical();
     __shared__ double s_x[6 * (PACKED ? kPackedFree : kMaxFree)];
     SolveOut o;
@@ -2362,7 +2372,8 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
     hipStream_t st = b->ctx->stream;
     const BADims& d = b->dims;
     const int npairs = d.nfree * (d.nfree + 1) / 2;
-    const int use_lds = d.n <= 126 ? 1 : 0;   // (21 free cameras: 127 rows = the two-rows-per-lane factorisation's limit; 129 KB of LDS)
+    const bool hbm_forced = getenv("UH_BA_SOLVE") && std::string(getenv("UH_BA_SOLVE")) == "hbm";   // (tests: the HBM solve on systems of any size)
+    const int use_lds = (d.n <= 126 && !hbm_forced) ? 1 : 0;   // (21 free cameras: 127 rows = the two-rows-per-lane factorisation's limit; 129 KB of LDS)
     const size_t lds = use_lds ? (size_t)(d.n + 1) * (d.n + 1) * sizeof(double) : 0;   // n rows of S + the right-hand-side row
     for (int s = 0; s < nsteps; s++) {
         const int slot = b->step & 1;   // state left by the previous step (or by begin_pass / the closing decide kernel)
@@ -2398,7 +2409,7 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
         if (!use_lds) {
             static const size_t packed_static = [] { hipFuncAttributes fa{}; return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&ba_solve_kernel<false, true>)) == hipSuccess ? fa.sharedSizeBytes : (size_t)1 << 30; }();
             if (b->max_lds <= 0) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, b->ctx->device) == hipSuccess) b->max_lds = v; }
-            use_packed = d.nfree <= kPackedFree && packed + packed_static <= (size_t)std::max(b->max_lds, 0) && !(getenv("UH_BA_SOLVE") && std::string(getenv("UH_BA_SOLVE")) == "hbm");
+            use_packed = d.nfree <= kPackedFree && packed + packed_static <= (size_t)std::max(b->max_lds, 0) && !hbm_forced;
         }
         // dense Schur form: the reduce launch leaves the FINISHED system in p.S in the following solve's layout (1: row stride n + 1,
         // 2: packed) and the solve copies it (nsplit 0); the HBM solve keeps its own assembly from Spart (0)
@@ -2416,7 +2427,7 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
             if (use_packed)
                 UH_LAUNCH(b->ctx, (ba_solve_kernel<false, true>), dim3(1), dim3(kPackedThreads), packed, b->ptrs, d, ns, slot ^ 1);
             else
-                UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kSolveThreads), 0, b->ptrs, d, ns, slot ^ 1);
+                UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kHbmThreads), 0, b->ptrs, d, ns, slot ^ 1);
             UH_LAUNCH(b->ctx,ba_backsub_kernel<false>, dim3(d.nPointBlocks), dim3(kThreads), 0, b->ptrs, d, ns, slot ^ 1);
         }
         b->step++;

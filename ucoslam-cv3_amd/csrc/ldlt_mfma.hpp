@@ -76,7 +76,9 @@ __device__ __forceinline__ bool ldlt_solve_mfma_lds(double* M, int n, int ld, do
     // it with vector work (scripts/micro/mfma_f64_burst.hip), so with one wave per SIMD the update is bound by the instructions
     // around the MFMAs: 80 per 16 x 16 tile in the first form of this loop.
     const int i16 = lane & 15, kq = lane >> 4;
-    const int dumpix = (int)(s_aux + 60 - M);
+    // the word that absent elements are redirected to: in the solve's LDS scratch when the packed triangle lives there; the row-stride
+    // form (which may live in HBM) has a free word of its own, (0, n) — column n of a row above the border row
+    const int dumpix = PACKED ? (int)(s_aux + 60 - M) : n;
     auto macro_tile = [&](int k0, int rb, int cb, const double (&dq)[3]) {
         const bool interior = rb >= cb + 16 && cb + 16 <= n;   // (uniform; the tiles are anchored at the last row: rb + 32 <= nrow always)
         const int cc = cb + i16, rw0 = rb + kq;
