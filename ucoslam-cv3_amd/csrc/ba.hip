@@ -1544,91 +1544,17 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
         // 22-32 free keyframes: panels by every thread, MFMA trailing update, block back substitution (ldlt_mfma.hpp); x lands in s_x
         double* const s_aux = s_mat + ((((size_t)(n + 1) * (n + 2) / 2) + 1) & ~(size_t)1);
         failed = ldlt_solve_mfma_lds<true>(M, n, ld, s_aux, s_x);
-    } else if (!USE_LDS && n + 1 <= NT && true) {
-        // 33-64 free keyframes, the system in HBM (row stride n + 1): the same factorisation on global memory — a pair of block columns
-        // is six dependent memory steps instead of the twenty of the 6-column form below
-        __shared__ __attribute__((aligned(16))) double s_aux_hbm[kLdltAux];
-        failed = ldlt_solve_mfma_lds<false>(M, n, ld, s_aux_hbm, s_x);
-        solved = true;
     } else if constexpr (USE_LDS) {
         __shared__ double s_w_store[2][129][6];   // ([2][121][6] for the look-ahead form; the two-rows-per-lane form's panel buffer is [2][6][128] + alignment)
         double (*s_w)[121][6] = reinterpret_cast<double (*)[121][6]>(&s_w_store[0][0][0]);
         failed = ldlt_bordered_lds(M, n, ld, d.nfree, npairs, s_pair, s_w);
     } else {
-        __shared__ double s_w[6 * kFreeCap][6];
-        for (int k0 = 0; k0 < n; k0 += 6) {
-            // (a) diagonal block -> Lkk (strict lower), dk, 1/dk
-            double a[6][6], dk[6], ik[6];
-    #pragma unroll
-            for (int i = 0; i < 6; i++)
-    #pragma unroll
-                for (int c = 0; c <= i; c++) a[i][c] = M[IX((k0 + i), k0 + c)];
-    #pragma unroll
-            for (int j = 0; j < 6; j++) {
-                dk[j] = a[j][j];
-                failed = failed || dk[j] == 0.0 || !isfinite(dk[j]);
-                ik[j] = fast_rcp(dk[j]);
-                double lcol[6];
-    #pragma unroll
-                for (int i = j + 1; i < 6; i++) lcol[i] = a[i][j] * ik[j];      // L(i,j); a[.][j] keeps L*d_j during the update
-    #pragma unroll
-                for (int i = j + 1; i < 6; i++)
-    #pragma unroll
-                    for (int c = j + 1; c <= i; c++) a[i][c] = fma(-lcol[i], a[c][j], a[i][c]);
-    #pragma unroll
-                for (int i = j + 1; i < 6; i++) a[i][j] = lcol[i];
-            }
-            __syncthreads();   // every thread has read the block before it is overwritten
-            if (tid == 0) {
-    #pragma unroll
-                for (int i = 0; i < 6; i++) {
-    #pragma unroll
-                    for (int c = 0; c < i; c++) M[IX((k0 + i), k0 + c)] = a[i][c];
-                    M[IX((k0 + i), k0 + i)] = dk[i];
-                }
-            }
-            // (b) panel: L_rk = A_rk * Lkk^-T * Dk^-1, one thread per row; y = L_rk * Dk goes to s_w
-            for (int r = k0 + 6 + tid; r < n; r += NT) {
-                double y[6];
-    #pragma unroll
-                for (int j = 0; j < 6; j++) y[j] = M[IX(r, k0 + j)];
-    #pragma unroll
-                for (int j = 0; j < 6; j++) {
-    #pragma unroll
-                    for (int t = 0; t < j; t++) y[j] = fma(-y[t], a[j][t], y[j]);
-                }
-    #pragma unroll
-                for (int j = 0; j < 6; j++) { M[IX(r, k0 + j)] = y[j] * ik[j]; s_w[r][j] = y[j]; }
-            }
-            __syncthreads();
-            // (c) trailing update A_rc -= sum_t L_rt (d_t L_ct) for c <= r: the 6x6 tiles (s1 <= s2) behind block column kb are the
-            //     tail of the s1-major pair list.  One thread per (tile, row): its six L entries and its six targets are read once and
-            //     meet the tile's 6 x 6 panel entries (s_w) in 36 FMAs — 48 operand reads per 36 FMAs; one thread per ELEMENT read 12 per 6,
-            //     and with the system in LDS the update was bound by exactly those reads.
-            {
-                const int kb = k0 / 6;
-                const int tile0 = (kb + 1) * d.nfree - kb * (kb + 1) / 2;   // first pair with s1 > kb
-                const int ntile = npairs - tile0;
-                for (int u = tid; u < 6 * ntile; u += NT) {
-                    const int tile = u / 6, i = u - 6 * tile;
-                    const int s1 = s_pair[tile0 + tile][0], s2 = s_pair[tile0 + tile][1];
-                    const int r = 6 * s2 + i, c0 = 6 * s1;
-                    const int ncol = s1 == s2 ? i + 1 : 6;   // (diagonal tiles: the lower triangle only — the packed form has no room for more)
-                    double lr[6], acc[6];
-    #pragma unroll
-                    for (int t = 0; t < 6; t++) lr[t] = M[IX(r, k0 + t)];
-    #pragma unroll
-                    for (int j = 0; j < 6; j++) acc[j] = j < ncol ? M[IX(r, c0 + j)] : 0.0;
-    #pragma unroll
-                    for (int j = 0; j < 6; j++)
-    #pragma unroll
-                        for (int t = 0; t < 6; t++) acc[j] = fma(-lr[t], s_w[c0 + j][t], acc[j]);
-    #pragma unroll
-                    for (int j = 0; j < 6; j++) if (j < ncol) M[IX(r, c0 + j)] = acc[j];
-                }
-            }
-            __syncthreads();
-        }
+        // 33-64 free keyframes, the system in HBM (row stride n + 1, n + 1 <= 385 rows: a thread per row): the same factorisation on
+        // global memory — a pair of block columns is six dependent memory steps; the 6-column form it replaces (diagonal block in,
+        // factor, out; panel in, out; update; three barriers that wait for stores: 25 us per block column) took twenty
+        __shared__ __attribute__((aligned(16))) double s_aux_hbm[kLdltAux];
+        failed = ldlt_solve_mfma_lds<false>(M, n, ld, s_aux_hbm, s_x);
+        solved = true;
     }
     if (failed && tid == 0) s_ok = 0;   // zero / non-finite pivot (Eigen SimplicialLDLT would report failure)
     __syncthreads();
@@ -1638,66 +1564,44 @@ __device__ __forceinline__ void solve_body(const BAPtrs& p, const BADims& d, int
     if (ok && solved) {
         for (int i = tid; i < n; i += NT) p.xp[i] = s_x[i];   // (s_x is complete: the barrier above)
     } else if (ok) {
-        if (n <= 64) {
-            // one wave, x_i lives in lane i; column j of L is read conflict-free thanks to the odd row stride.  x_j is
-            // broadcast with v_readlane (j is wave-uniform) and the 2n dependent steps are branch-free: a column outside the
-            // matrix, or a lane the step does not touch, multiplies by 0
-            if (wv == 0) {
-                double x = lane < n ? (USE_LDS ? M[(size_t)n * ld + lane] : s_x[lane]) : 0.0;   // LDS path: z = D^-1 L^-1 b is row n
-                const int lr = lane < n ? lane : n - 1;
-                double l[8], ln[8];
+        // the fused solve (system in LDS, bordered: z = D^-1 L^-1 b is row n): L^T x = z
+        if constexpr (USE_LDS) {
+            if (n <= 64) {
+                // one wave, x_i lives in lane i; row j of L (column j of L^T) is read conflict-free thanks to the odd row stride.  x_j is
+                // broadcast with v_readlane (j is wave-uniform) and the n dependent steps are branch-free: a lane the step does not touch
+                // multiplies by 0
+                if (wv == 0) {
+                    double x = lane < n ? M[(size_t)n * ld + lane] : 0.0;
+                    const int lr = lane < n ? lane : n - 1;
+                    double l[8], ln[8];
 #pragma unroll
-                for (int t = 0; t < 8; t++) { const int jj = t < n ? t : n - 1; l[t] = M[IX(lr, jj)]; }
-                for (int j0 = 0; !USE_LDS && j0 < n; j0 += 8) {          // L y = b, 8 columns of L prefetched one round ahead
+                    for (int t = 0; t < 8; t++) { const int jj = n - 1 - t >= 0 ? n - 1 - t : 0; l[t] = M[IX(jj, lr)]; }
+                    for (int j0 = n - 1; j0 >= 0; j0 -= 8) {
 #pragma unroll
-                    for (int t = 0; t < 8; t++) { const int jj = j0 + 8 + t < n ? j0 + 8 + t : n - 1; ln[t] = M[IX(lr, jj)]; }
+                        for (int t = 0; t < 8; t++) { const int jj = j0 - 8 - t >= 0 ? j0 - 8 - t : 0; ln[t] = M[IX(jj, lr)]; }
 #pragma unroll
-                    for (int t = 0; t < 8; t++) { const int j = j0 + t; l[t] = (lane > j && lane < n) ? l[t] : 0.0; }
+                        for (int t = 0; t < 8; t++) { const int j = j0 - t; l[t] = lane < j ? l[t] : 0.0; }
 #pragma unroll
-                    for (int t = 0; t < 8; t++) x = fma(-l[t], readlane_f64(x, j0 + t < 63 ? j0 + t : 63), x);
+                        for (int t = 0; t < 8; t++) x = fma(-l[t], readlane_f64(x, j0 - t > 0 ? j0 - t : 0), x);
 #pragma unroll
-                    for (int t = 0; t < 8; t++) l[t] = ln[t];
+                        for (int t = 0; t < 8; t++) l[t] = ln[t];
+                    }
+                    if (lane < n) { s_x[lane] = x; p.xp[lane] = x; }
                 }
-                if (!USE_LDS && lane < n) x /= M[IX(lane, lane)];
-#pragma unroll
-                for (int t = 0; t < 8; t++) { const int jj = n - 1 - t >= 0 ? n - 1 - t : 0; l[t] = M[IX(jj, lr)]; }
-                for (int j0 = n - 1; j0 >= 0; j0 -= 8) {     // L^T x = y
-#pragma unroll
-                    for (int t = 0; t < 8; t++) { const int jj = j0 - 8 - t >= 0 ? j0 - 8 - t : 0; ln[t] = M[IX(jj, lr)]; }
-#pragma unroll
-                    for (int t = 0; t < 8; t++) { const int j = j0 - t; l[t] = lane < j ? l[t] : 0.0; }
-#pragma unroll
-                    for (int t = 0; t < 8; t++) x = fma(-l[t], readlane_f64(x, j0 - t > 0 ? j0 - t : 0), x);
-#pragma unroll
-                    for (int t = 0; t < 8; t++) l[t] = ln[t];
-                }
-                if (lane < n) { s_x[lane] = x; p.xp[lane] = x; }
-            }
-        } else {
-            if (USE_LDS && n <= 128) {   // two unknowns per lane of wave 0, one broadcast per column (the loop below: two barriers per column)
+            } else if (n <= 128) {   // two unknowns per lane of wave 0, one broadcast per column
                 backsolve2_lds(M, n, ld, s_x);
                 __syncthreads();
                 for (int i = tid; i < n; i += NT) p.xp[i] = s_x[i];
-            } else {
-            if constexpr (USE_LDS) {   // z = D^-1 L^-1 b is row n of the bordered factorisation
+            } else {                 // (not reached by the launch chain: the fused solve serves n <= 126) column sweeps, two barriers per column
                 for (int i = tid; i < n; i += NT) s_x[i] = M[(size_t)n * ld + i];
-            } else {
-                for (int j = 0; j < n; j++) {
+                __syncthreads();
+                for (int j = n - 1; j >= 0; j--) {
                     const double xj = s_x[j];
                     __syncthreads();
-                    for (int i = j + 1 + tid; i < n; i += NT) s_x[i] -= M[IX(i, j)] * xj;
+                    for (int i = tid; i < j; i += NT) s_x[i] -= M[IX(j, i)] * xj;
                     __syncthreads();
                 }
-                for (int i = tid; i < n; i += NT) s_x[i] /= M[IX(i, i)];
-            }
-            __syncthreads();
-            for (int j = n - 1; j >= 0; j--) {
-                const double xj = s_x[j];
-                __syncthreads();
-                for (int i = tid; i < j; i += NT) s_x[i] -= M[IX(j, i)] * xj;
-                __syncthreads();
-            }
-            for (int i = tid; i < n; i += NT) p.xp[i] = s_x[i];
+                for (int i = tid; i < n; i += NT) p.xp[i] = s_x[i];
             }
         }
     } else {
