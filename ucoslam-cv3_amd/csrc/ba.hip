@@ -813,6 +813,51 @@ __global__ __launch_bounds__(kThreads* kReduceGroups) void ba_schur_reduce_kerne
     p.S[SX(i, j)] = v;
 }
 
+// The reduced system of the pair form, finished, into p.S (row stride n + 1, lower triangle, row n = b_p - b_schur; b_p stored for the
+// decision) — for the solve in HBM (33-64 free cameras), which then needs no assembly of its own: one workgroup summing 2080 pairs x 42
+// words was 185 us of a 64-camera trial.  Thread per (pair, q); the arithmetic and its order are those of the solve's assembly:
+// sum of the chunks, negated, + (camera sums + lambda) on the diagonal blocks.
+__global__ __launch_bounds__(kThreads) void ba_assemble_pairs_kernel(BAPtrs p, BADims d, int nsplit, int slot) {
+    uh_latency_critical();
+    const BAState st = p.st[slot];
+    if (st.phase == 2) return;
+    const int npairs = d.nfree * (d.nfree + 1) / 2;
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= npairs * 42) return;
+    const int pair = idx / 42, q = idx - 42 * pair;
+    int s1 = 0, rem = pair;
+    while (rem >= d.nfree - s1) { rem -= d.nfree - s1; ++s1; }
+    const int s2 = s1 + rem;
+    const bool diag = s1 == s2;
+    if (q >= 36 && !diag) return;
+    double v = 0;
+    for (int k = 0; k < nsplit; k++) v += p.Spart[((size_t)k * npairs + pair) * 42 + q];
+    const int n = d.n, ld = n + 1;
+    if (q >= 36) {
+        const int a = q - 36;
+        double h = 0;
+#pragma unroll
+        for (int cch = 0; cch < kCamChunks; cch++) h += p.HppPart[((size_t)s1 * kCamChunks + cch) * 27 + 21 + a];
+        p.bp[6 * s1 + a] = h;
+        p.S[(size_t)n * ld + 6 * s1 + a] = h - v;
+        return;
+    }
+    const int a = q / 6, c = q - 6 * a;
+    v = -v;
+    if (diag) {
+        if (c > a) return;   // (the lower triangle of a diagonal block)
+        const int lo = c, hi = a;
+        const int hq = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);
+        double h = 0;
+#pragma unroll
+        for (int cch = 0; cch < kCamChunks; cch++) h += p.HppPart[((size_t)s1 * kCamChunks + cch) * 27 + hq];
+        v += h + (a == c ? st.lambda : 0.0);
+        p.S[(size_t)(6 * s1 + a) * ld + 6 * s1 + c] = v;
+    } else {
+        p.S[(size_t)(6 * s2 + c) * ld + 6 * s1 + a] = v;   // upper-block entry (6 s1 + a, 6 s2 + c), stored mirrored
+    }
+}
+
 // Pose update of free pose `s` into the trial buffer: T_trial = exp(dx) * T_cur (SE3Quat::exp, VertexSE3Expmap::oplusImpl);
 // with ok == 0 (the solve failed) the trial pose is the current one.  x: the solved increment (LDS or HBM).
 // T <- exp(dx) * T on (unit quaternion q, translation t): SE3Quat::exp (se3quat.h:276) and VertexSE3Expmap::oplusImpl
@@ -2325,13 +2370,16 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
             UH_LAUNCH(b->ctx, ba_schur_reduce_kernel, dim3(b->sd.T + 1), dim3(kThreads * kReduceGroups), 0, b->ptrs, d, b->sd, slot ^ 1, pre_mode);
         } else
         UH_LAUNCH(b->ctx,ba_schur_kernel, dim3(std::max(npairs, 1) * b->nsplit + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d, b->nsplit, slot);
+        // the solve in HBM takes the finished system from a launch of its own (every pair's words in parallel) instead of assembling alone
+        const bool pre_hbm = !b->dense && !use_lds && !use_packed && npairs > 0 && !pre_off;
+        if (pre_hbm) UH_LAUNCH(b->ctx, ba_assemble_pairs_kernel, dim3(uh_div_up(npairs * 42, kThreads)), dim3(kThreads), 0, b->ptrs, d, b->nsplit, slot ^ 1);
         if (use_lds) {
             UH_LAUNCH(b->ctx,ba_backsub_kernel<true>, dim3(d.nPointBlocks), dim3(kFusedThreads), lds, b->ptrs, d, ns, slot ^ 1);
         } else {
             if (use_packed)
                 UH_LAUNCH(b->ctx, (ba_solve_kernel<false, true>), dim3(1), dim3(kPackedThreads), packed, b->ptrs, d, ns, slot ^ 1);
             else
-                UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kHbmThreads), 0, b->ptrs, d, ns, slot ^ 1);
+                UH_LAUNCH(b->ctx,ba_solve_kernel<false>, dim3(1), dim3(kHbmThreads), 0, b->ptrs, d, pre_hbm ? 0 : ns, slot ^ 1);
             UH_LAUNCH(b->ctx,ba_backsub_kernel<false>, dim3(d.nPointBlocks), dim3(kThreads), 0, b->ptrs, d, ns, slot ^ 1);
         }
         b->step++;
