@@ -564,7 +564,7 @@ __global__ __launch_bounds__(kThreads) void ba_schur_kernel(BAPtrs p, BADims d, 
 //     ba_schur_reduce_kernel into the pair layout the solve's assembly reads (as ONE chunk): run-to-run deterministic.
 // The prologue (the previous trial's decision, lambda at iteration 0, the published state) and the camera workgroups are those of
 // ba_schur_kernel.  Reference: g2o/core/block_solver.hpp:341-392 (Hschur -= Hpl D^-1 Hpl^T, b -= Hpl D^-1 b_l).
-struct SchurDense { int G, cpw, ntt, ys, T; };   // workgroups, 16-landmark chunks per workgroup, tiles per dimension, LDS row stride, lower tiles
+struct SchurDense { int G, cpw, ntt, ys, T, SP, nown; };   // landmark groups (= partials), chunks per group, tiles per dimension, LDS row stride, lower tiles; wide form: workgroups per group, tiles per wave
 
 __device__ __forceinline__ double schur_rsqrt(double x) {   // v_rsq_f64 + two Newton steps; x <= 0 / NaN gives NaN / inf (the solve then reports failure)
     double r = __builtin_amdgcn_rsq(x);
@@ -736,6 +736,156 @@ __global__ __launch_bounds__(kThreads) void ba_schur_dense_kernel(BAPtrs p, BADi
     UH_DENSE_END(16);
 }
 
+// The dense form for 33-64 free cameras (13-24 tile rows, up to 300 lower tiles: their accumulators do not fit one workgroup).  SP
+// workgroups share a landmark group; each builds the group's panels itself (8 landmarks = 24 rows at a time: the panel of 24 tile
+// columns is 77 KB) and owns a contiguous range of the tile list, NOWN tiles per wave.  A wave's tile list is computed at run time
+// (the operands' column offsets are wave-uniform scalars), every k-step reads its 2 NOWN operands from LDS and issues NOWN MFMAs —
+// no predicate: a slot past the end of the list works on tile 0 and is not stored.
+template <int NOWN>
+__global__ __launch_bounds__(kThreads) void ba_schur_dense_wide_kernel(BAPtrs p, BADims d, SchurDense sd, int slot) {
+    uh_latency_critical();
+    extern __shared__ __attribute__((aligned(16))) double s_dense[];   // Yt[24][ys], z[24]
+    __shared__ BAState s_state;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ncam = d.nfree * kCamChunks;
+    const bool cam_role = (int)blockIdx.x < ncam;
+    if (tid < 64) {
+        const BAState st0 = p.st[slot];
+        const DecideSums sm = decide_sums(p, d, tid, st0.lambda);
+        if (tid == 0) s_state = (st0.phase != 2 && st0.pending) ? apply_decision(st0, sm, st0.stop_seen != 0) : st0;
+    }
+    constexpr int ROWS = 24;
+    double* const Yt = s_dense;
+    double* const s_z = s_dense + ROWS * sd.ys;
+    if (!cam_role) for (int i = tid; i < ROWS * sd.ys; i += kThreads) Yt[i] = 0.0;
+    __syncthreads();
+    BAState st = s_state;
+    if (st.phase == 2) {
+        if (blockIdx.x == 0 && tid == 0) { st.pending = 0; p.st[slot ^ 1] = st; }
+        return;
+    }
+    if ((int)blockIdx.x == ncam && tid == 0) p.clk[4] = wall_clock64();
+    double lambda = st.lambda;
+    if (st.iteration == 0 && st.qmax == 0) {   // tau * max |H_jj| over poses and landmarks (as in ba_schur_kernel)
+        double m = 0;
+        for (int i = 0; i < d.nPointBlocks; i++) m = fmax(m, p.part_maxdiag[i]);
+        for (int s = 0; s < d.nfree; s++) {
+            int q = 0;
+            for (int a = 0; a < 6; a++) {
+                double v = 0;
+                for (int c = 0; c < kCamChunks; c++) v += p.HppPart[((size_t)s * kCamChunks + c) * 27 + q];
+                m = fmax(m, fabs(v));
+                q += 6 - a;
+            }
+        }
+        lambda = 1e-5 * m;
+        st.lambda = lambda; st.ni = 2;
+    }
+    if (blockIdx.x == 0 && tid == 0) { BAState pub = st; pub.pending = 1; pub.stop_seen = 0; p.st[slot ^ 1] = pub; }
+    if (cam_role) {
+        if (!st.first_trial) camera_block(p, d, blockIdx.x, p.poseR[st.cur], p.pts[st.cur]);
+        return;
+    }
+    const int wg = blockIdx.x - ncam, g = wg / sd.SP, sp = wg - g * sd.SP;
+    const int n = d.n, YS = sd.ys, i16 = lane & 15, kq = lane >> 4;
+    const int tps = (sd.T + sd.SP - 1) / sd.SP, tbeg = sp * tps, tend = min(sd.T, tbeg + tps);   // this workgroup's tiles
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+    f64x4 acc[NOWN];
+    int offA[NOWN], offB[NOWN], tix[NOWN];
+#pragma unroll
+    for (int u = 0; u < NOWN; u++) {
+        acc[u] = f64x4{0, 0, 0, 0};
+        const int t = tbeg + wv + 4 * u;
+        tix[u] = t < tend ? t : -1;
+        const int tc = t < tend ? t : 0;
+        offA[u] = 16 * schur_tile_row(tc); offB[u] = 16 * schur_tile_col(tc);
+    }
+    double bacc[2] = {0, 0};
+    const double* Hll = p.Hll[st.cur];
+    const double* Hpl = p.Hpl[st.cur];
+    const double* bl = p.bl[st.cur];
+    const int nslot = 8 * d.nfree;   // (<= 512: two slots per thread)
+    for (int c = 0; c < sd.cpw; c++) {
+        const int l0 = (g * sd.cpw + c) * 8;
+        if (l0 >= d.P) break;   // (uniform)
+        if (c > 0) __syncthreads();
+        constexpr int RND = 2;
+        int e[RND], l[RND], sc[RND], pt[RND]; bool act[RND], live[RND];
+#pragma unroll
+        for (int r = 0; r < RND; r++) {
+            const int sl = tid + r * kThreads;
+            live[r] = sl < nslot;
+            l[r] = live[r] ? sl / d.nfree : 0; sc[r] = live[r] ? sl - l[r] * d.nfree : 0; pt[r] = l0 + l[r];
+            live[r] = live[r] && pt[r] < d.P;
+            e[r] = live[r] ? p.edge_of[(size_t)pt[r] * d.nfree + sc[r]] : -1;
+        }
+#pragma unroll
+        for (int r = 0; r < RND; r++) act[r] = e[r] >= 0 && p.e_active[e[r] >= 0 ? e[r] : 0] != 0;
+        double D[RND][6], bb[RND][18], bi[RND][3];
+#pragma unroll
+        for (int r = 0; r < RND; r++) {
+            const double* Dp = Hll + 9 * (size_t)(live[r] ? pt[r] : 0);
+            D[r][0] = Dp[0]; D[r][1] = Dp[3]; D[r][2] = Dp[6]; D[r][3] = Dp[4]; D[r][4] = Dp[7]; D[r][5] = Dp[8];
+            const double* Bp = Hpl + 18 * (size_t)(act[r] ? e[r] : 0);
+#pragma unroll
+            for (int i = 0; i < 18; i++) bb[r][i] = Bp[i];
+            const double* bp = bl + 3 * (size_t)(live[r] ? pt[r] : 0);
+            bi[r][0] = bp[0]; bi[r][1] = bp[1]; bi[r][2] = bp[2];
+        }
+#pragma unroll
+        for (int r = 0; r < RND; r++) {
+            if (tid + r * kThreads >= nslot) continue;
+            const double d00 = D[r][0] + lambda, d10 = D[r][1], d20 = D[r][2], d11 = D[r][3] + lambda, d21 = D[r][4], d22 = D[r][5] + lambda;
+            const double r0 = schur_rsqrt(d00), l10 = d10 * r0, l20 = d20 * r0;
+            const double r1 = schur_rsqrt(fma(-l10, l10, d11)), l21 = fma(-l20, l10, d21) * r1;
+            const double r2 = schur_rsqrt(fma(-l21, l21, fma(-l20, l20, d22)));
+            double* yo = Yt + 3 * l[r] * YS + 6 * sc[r];
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                const double y0 = bb[r][3 * a] * r0, y1 = fma(-y0, l10, bb[r][3 * a + 1]) * r1, y2 = fma(-y1, l21, fma(-y0, l20, bb[r][3 * a + 2])) * r2;
+                yo[a] = act[r] ? y0 : 0.0; yo[YS + a] = act[r] ? y1 : 0.0; yo[2 * YS + a] = act[r] ? y2 : 0.0;
+            }
+            if (sc[r] == 0) {
+                const double z0 = bi[r][0] * r0, z1 = fma(-l10, z0, bi[r][1]) * r1, z2 = fma(-l21, z1, fma(-l20, z0, bi[r][2])) * r2;
+                s_z[3 * l[r]] = live[r] ? z0 : 0.0; s_z[3 * l[r] + 1] = live[r] ? z1 : 0.0; s_z[3 * l[r] + 2] = live[r] ? z2 : 0.0;
+            }
+        }
+        __syncthreads();
+        if (sp == 0) {   // (b_schur once per landmark group)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int col = tid + h * kThreads;
+                if (col < n) {
+#pragma unroll 8
+                    for (int k = 0; k < ROWS; k++) bacc[h] = fma(Yt[k * YS + col], s_z[k], bacc[h]);
+                }
+            }
+        }
+        for (int k4 = 0; k4 < ROWS / 4; k4++) {
+            const double* row = Yt + (4 * k4 + kq) * YS + i16;
+            double a[NOWN], b[NOWN];
+#pragma unroll
+            for (int u = 0; u < NOWN; u++) { a[u] = row[offA[u]]; b[u] = row[offB[u]]; }
+#pragma unroll
+            for (int u = 0; u < NOWN; u++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc[u], 0, 0, 0);
+        }
+    }
+    double* out = p.dpart + (size_t)g * sd.T * 256;
+#pragma unroll
+    for (int u = 0; u < NOWN; u++) {
+        if (tix[u] >= 0) {
+            double* o = out + (size_t)tix[u] * 256 + lane * 4;
+            *reinterpret_cast<double2*>(o) = double2{acc[u][0], acc[u][1]};
+            *reinterpret_cast<double2*>(o + 2) = double2{acc[u][2], acc[u][3]};
+        }
+    }
+    if (sp == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) { const int col = tid + h * kThreads; if (col < n) p.dbpart[(size_t)g * 16 * sd.ntt + col] = bacc[h]; }
+    }
+    if ((int)blockIdx.x == ncam && tid == 0) p.clk[5] = wall_clock64();
+}
+
 // Sum of the G dense partials, in workgroup order, into the pair layout the solve's assembly reads (Spart as ONE chunk).  Workgroup t
 // sums tile t: thread e reads word e of the tile in every partial (consecutive threads, consecutive words), finds its element (i, j)
 // from the MFMA C layout (row = (lane >> 4) + 4 reg, col = lane & 15) and writes entry (a, c) of pair (j / 6, i / 6) — both orders
@@ -751,8 +901,9 @@ __global__ __launch_bounds__(kThreads* kReduceGroups) void ba_schur_reduce_kerne
     if (stp.phase == 2) return;   // (the pass had finished: the schur launch wrote nothing)
     const int tid = threadIdx.x & (kThreads - 1), grp = threadIdx.x / kThreads, t = blockIdx.x;
     const double* src; size_t stride;
-    const bool bvec = t == sd.T;
-    if (bvec) { src = p.dbpart + (tid < d.n ? tid : 0); stride = (size_t)16 * sd.ntt; }
+    const bool bvec = t >= sd.T;                    // workgroups T, T + 1: b_schur, 256 columns each
+    const int bcol = (t - sd.T) * kThreads + tid;
+    if (bvec) { src = p.dbpart + (bcol < d.n ? bcol : 0); stride = (size_t)16 * sd.ntt; }
     else { src = p.dpart + (size_t)t * 256 + tid; stride = (size_t)sd.T * 256; }
     const int g0 = (int)((long long)sd.G * grp / kReduceGroups), g1 = (int)((long long)sd.G * (grp + 1) / kReduceGroups);
     double v = 0;
@@ -780,14 +931,14 @@ __global__ __launch_bounds__(kThreads* kReduceGroups) void ba_schur_reduce_kerne
     const int n = d.n, ld = n + 1;
     auto SX = [&](int r, int c) -> size_t { return mode == 2 ? (size_t)r * (r + 1) / 2 + c : (size_t)r * ld + c; };
     if (bvec) {
-        if (tid >= n) return;
-        const int sc = tid / 6, a = tid - 6 * sc;
+        if (bcol >= n) return;
+        const int sc = bcol / 6, a = bcol - 6 * sc;
         if (mode == 0) { p.Spart[(size_t)pair_of(sc, sc) * 42 + 36 + a] = v; return; }
         double h = 0;
 #pragma unroll
         for (int cch = 0; cch < kCamChunks; cch++) h += p.HppPart[((size_t)sc * kCamChunks + cch) * 27 + 21 + a];
-        p.bp[tid] = h;
-        p.S[SX(n, tid)] = h - v;
+        p.bp[bcol] = h;
+        p.S[SX(n, bcol)] = h - v;
         return;
     }
     const int ti = schur_tile_row(t), tj = schur_tile_col(t);
@@ -2363,11 +2514,20 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
         // dense Schur form: the reduce launch leaves the FINISHED system in p.S in the following solve's layout (1: row stride n + 1,
         // 2: packed) and the solve copies it (nsplit 0); the HBM solve keeps its own assembly from Spart (0)
         const bool pre_off = getenv("UH_BA_PREBUILT") && atoi(getenv("UH_BA_PREBUILT")) == 0;   // (A/B knob, read per call: tests toggle it)
-        const int pre_mode = (b->dense && !pre_off) ? (use_lds ? 1 : (use_packed ? 2 : 0)) : 0;
+        // (the solve in HBM, 33-64 free cameras, factorises p.S in place: row stride n + 1 = mode 1, and nothing to copy)
+        const int pre_mode = (b->dense && !pre_off) ? ((use_lds || !use_packed) ? 1 : 2) : 0;
         const int ns = pre_mode ? 0 : b->nsplit;
         if (b->dense) {
-            UH_LAUNCH(b->ctx, ba_schur_dense_kernel, dim3(d.nfree * kCamChunks + b->sd.G), dim3(kThreads), (size_t)(48 * b->sd.ys + 48) * sizeof(double), b->ptrs, d, b->sd, slot);
-            UH_LAUNCH(b->ctx, ba_schur_reduce_kernel, dim3(b->sd.T + 1), dim3(kThreads * kReduceGroups), 0, b->ptrs, d, b->sd, slot ^ 1, pre_mode);
+            const SchurDense& sd = b->sd;
+            if (sd.SP > 0) {
+                const dim3 gridw(d.nfree * kCamChunks + sd.G * sd.SP);
+                const size_t ldsw = (size_t)(24 * sd.ys + 24) * sizeof(double);
+                if (sd.nown == 12) UH_LAUNCH(b->ctx, ba_schur_dense_wide_kernel<12>, gridw, dim3(kThreads), ldsw, b->ptrs, d, sd, slot);
+                else if (sd.nown == 16) UH_LAUNCH(b->ctx, ba_schur_dense_wide_kernel<16>, gridw, dim3(kThreads), ldsw, b->ptrs, d, sd, slot);
+                else UH_LAUNCH(b->ctx, ba_schur_dense_wide_kernel<20>, gridw, dim3(kThreads), ldsw, b->ptrs, d, sd, slot);
+            } else
+                UH_LAUNCH(b->ctx, ba_schur_dense_kernel, dim3(d.nfree * kCamChunks + sd.G), dim3(kThreads), (size_t)(48 * sd.ys + 48) * sizeof(double), b->ptrs, d, sd, slot);
+            UH_LAUNCH(b->ctx, ba_schur_reduce_kernel, dim3(sd.T + uh_div_up(d.n, kThreads)), dim3(kThreads * kReduceGroups), 0, b->ptrs, d, sd, slot ^ 1, pre_mode);
         } else
         UH_LAUNCH(b->ctx,ba_schur_kernel, dim3(std::max(npairs, 1) * b->nsplit + d.nfree * kCamChunks), dim3(kThreads), 0, b->ptrs, d, b->nsplit, slot);
         // the solve in HBM takes the finished system from a launch of its own (every pair's words in parallel) instead of assembling alone
@@ -2680,14 +2840,21 @@ static int set_problem_tables(uh_ba* b, const uh_ba_problem* pr) {
     // dense Schur form: windows of 17-32 free keyframes (UH_BA_SCHUR_DENSE=0 keeps the pair form)
     {
         const char* e = getenv("UH_BA_SCHUR_DENSE");
-        b->dense = !wide && nfree >= 17 && nfree <= 32 && !(e && atoi(e) == 0);   // (7..12 tile rows: the kernel's instantiations)
+        b->dense = !wide && nfree >= 17 && nfree <= kMaxFree && !(e && atoi(e) == 0);   // (17-32: 7..12 tile rows, one workgroup per landmark group; 33-64: the wide kernel)
         if (b->dense) {
             SchurDense& sd = b->sd;
             sd.ntt = uh_div_up(d.n, 16); sd.T = sd.ntt * (sd.ntt + 1) / 2;
             sd.ys = 16 * sd.ntt + ((sd.ntt & 1) ? 0 : 16);   // row stride = 16 (mod 32) doubles: the four k-rows of an MFMA operand read fall on disjoint banks
-            const int chunks = std::max(uh_div_up(P, 16), 1);
-            const int gmax = getenv("UH_BA_DENSE_G") ? std::max(1, atoi(getenv("UH_BA_DENSE_G"))) : 224;   // (tuning knob: scripts/ba_chain_kernels.py)
+            const bool widek = nfree > 32;
+            const int chunks = std::max(uh_div_up(P, widek ? 8 : 16), 1);
+            const int gmax = getenv("UH_BA_DENSE_G") ? std::max(1, atoi(getenv("UH_BA_DENSE_G"))) : (widek ? 96 : 224);   // (tuning knob: scripts/ba_chain_kernels.py)
             sd.cpw = uh_div_up(chunks, gmax); sd.G = uh_div_up(chunks, sd.cpw);
+            sd.SP = 0; sd.nown = 0;
+            if (widek) {   // tile list cut over SP workgroups of at most 80 tiles, 4 waves x nown tiles each (kernel instantiations: 12, 16, 20)
+                sd.SP = uh_div_up(sd.T, 80);
+                const int need = uh_div_up(uh_div_up(sd.T, sd.SP), 4);
+                sd.nown = need <= 12 ? 12 : (need <= 16 ? 16 : 20);
+            }
             b->nsplit = 1;
         }
     }
