@@ -183,9 +183,9 @@ def test_hip_ba_chain_solve_in_hbm_at_small_sizes(hip_ctx, oracle, monkeypatch, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K,P", [(19, 900), (26, 1100), (34, 450)])
+@pytest.mark.parametrize("K,P", [(19, 900), (26, 1100), (34, 450), (42, 400), (66, 300)])
 def test_hip_ba_chain_schur_forms_agree(hip_ctx, oracle, monkeypatch, K, P):
-    """17-32 free keyframes: the dense Schur form (MFMA product + reduce launch that leaves the finished system for the solve), the
+    """17-64 free keyframes (fused, packed and HBM solve; the narrow and the wide dense kernel): the dense Schur form (MFMA product + reduce launch that leaves the finished system for the solve), the
     same with the solve assembling from the pair layout (UH_BA_PREBUILT=0) and the pair form (UH_BA_SCHUR_DENSE=0) all reproduce
     the oracle: same iteration counts, state within the tolerance."""
     from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
