@@ -374,6 +374,15 @@ def main():
         gba.setParams(synth.ba_problem(100, 5000, seed=1, nfixed=2), ParamSet(nIters=10))
         gba.optimize()
         stage_ms["global_ba_ms_100kf_5000pt_330kobs"] = timed(lambda: gba.optimize(), 2)
+        # local BA over larger windows (the reference's window is the covisibility neighbourhood, not a constant 10: mapmanager.cpp:11085-11413):
+        # optimize() of nfree + 2 keyframes x 3000 landmarks — persistent form to 16 free keyframes, launch chain (dense Schur form; fused,
+        # packed-in-LDS and HBM solve) beyond
+        for nfree_w in (16, 17, 24, 32, 48, 64):
+            wba = GlobalOptimizer.create(ctx_ba).wantChi2(False)
+            wba.setParams(synth.ba_problem(nfree_w + 2, 3000, seed=nfree_w, nfixed=2), ParamSet(nIters=5))
+            wba.optimize()
+            stage_ms[f"ba_optimize_ms_{nfree_w}_free_kf_3000pt"] = timed(lambda: wba.optimize(), 5)
+            del wba
         del gba
         # headroom figure, NOT the metric: two independent sessions (two frame streams, two maps, two local BAs) on this one GPU —
         # the latency-bound launch chains of the two BAs interleave, which one session cannot do with itself
