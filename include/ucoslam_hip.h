@@ -645,9 +645,10 @@ int uh_ba_debug_clocks(uh_ba* ba, int64_t* out64);
  * stream, for scripts/time_interference.py: what about a neighbouring launch slows the latency-bound BA chain down */
 int uh_debug_background(uh_ctx* ctx, int mode, int blocks, int iters, const void* d_buf, size_t buf_bytes, void* d_sink);
 int uh_knn_debug_push_cycles(uh_knn* knn, int k, int n, long long* out3);
-/* shader-clock stamps of the pose-only solves that follow (on = 1) — out8[0] kernel entry, [1] matches staged, [2] rounds done, [3] results
- * posted, [4] passes over the matches; out8 (may be NULL) receives the stamps of the last solve */
-int uh_pnp_debug_clocks(uh_pnp* pnp, int on, long long* out8);
+/* shader-clock stamps of the pose-only solves that follow (on = 1) — out512[0] kernel entry, [1] matches staged, [2] rounds done,
+ * [3] results posted, [4] passes over the matches, [5 ..] per-pass stamps; out512 (may be NULL) receives the stamps of the last solve and
+ * MUST hold 512 entries (4096 bytes: the whole stamp block is copied) */
+int uh_pnp_debug_clocks(uh_pnp* pnp, int on, long long* out512);
 
 #ifdef __cplusplus
 }

@@ -2412,6 +2412,7 @@ struct uh_ba {
     int p_lds_set[4] = {0, 0, 0, 0};      // dynamic LDS already granted to the instantiations (hipFuncSetAttribute once, not per problem)
     int max_lds = 0;                      // hipDeviceAttributeMaxSharedMemoryPerBlock of the device
     int job_kind = 0;                     // worker: 0 optimize, 1 setParams + optimize (uh_ba_solve_async)
+    bool knob_hbm_solve = false, knob_prebuilt_off = false;   // UH_BA_SOLVE=hbm / UH_BA_PREBUILT=0 as uh_ba_set_problem found them
     const uh_ba_problem* job_problem = nullptr; uh_ba_problem job_problem_copy{};
     int job_dims[3] = {0, 0, 0};
     uh_ba_params job_params{}; bool job_has_params = false;
@@ -2472,7 +2473,7 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
     hipStream_t st = b->ctx->stream;
     const BADims& d = b->dims;
     const int npairs = d.nfree * (d.nfree + 1) / 2;
-    const bool hbm_forced = getenv("UH_BA_SOLVE") && std::string(getenv("UH_BA_SOLVE")) == "hbm";   // (tests: the HBM solve on systems of any size)
+    const bool hbm_forced = b->knob_hbm_solve;   // (tests: the HBM solve on systems of any size; read by uh_ba_set_problem on the caller's thread)
     const int use_lds = (d.n <= 126 && !hbm_forced) ? 1 : 0;   // (21 free cameras: 127 rows = the two-rows-per-lane factorisation's limit; 129 KB of LDS)
     const size_t lds = use_lds ? (size_t)(d.n + 1) * (d.n + 1) * sizeof(double) : 0;   // n rows of S + the right-hand-side row
     for (int s = 0; s < nsteps; s++) {
@@ -2513,7 +2514,7 @@ int enqueue_steps(uh_ba* b, int nsteps, bool pass_start) {
         }
         // dense Schur form: the reduce launch leaves the FINISHED system in p.S in the following solve's layout (1: row stride n + 1,
         // 2: packed) and the solve copies it (nsplit 0); the HBM solve keeps its own assembly from Spart (0)
-        const bool pre_off = getenv("UH_BA_PREBUILT") && atoi(getenv("UH_BA_PREBUILT")) == 0;   // (A/B knob, read per call: tests toggle it)
+        const bool pre_off = b->knob_prebuilt_off;   // (A/B knob, read by uh_ba_set_problem on the caller's thread: getenv here would race a setenv elsewhere)
         // (the solve in HBM, 33-64 free cameras, factorises p.S in place: row stride n + 1 = mode 1, and nothing to copy)
         const int pre_mode = (b->dense && !pre_off) ? ((use_lds || !use_packed) ? 1 : 2) : 0;
         const int ns = pre_mode ? 0 : b->nsplit;
@@ -2836,7 +2837,9 @@ static int set_problem_tables(uh_ba* b, const uh_ba_problem* pr) {
     // landmark chunks win (measured, 3000 landmarks: 17 / 20 / 32 free cameras 2.20 / 2.90 / 9.9 ms with 12 chunks, 1.77 / 2.14 / 7.3 with 2)
     if (npairs_h > 32) b->nsplit = std::max(1, std::min(b->nsplit, uh_div_up(300, npairs_h)));   // (17 free cameras: 2 chunks, measured best — scripts/ba_chain_kernels.py with UH_BA_NSPLIT)
     if (const char* e = getenv("UH_BA_NSPLIT")) b->nsplit = std::max(1, std::min(kMaxSplit, atoi(e)));   // (measurement override: scripts/ba_chain_kernels.py)
-    if (const char* e = getenv("UH_BA_NSPLIT")) b->nsplit = std::max(1, std::min(kMaxSplit, atoi(e)));   // tuning knob (measurement only)
+    // knobs the launch chain consults per step, possibly on the optimiser's worker thread: read ONCE here, on the caller's thread
+    { const char* e = getenv("UH_BA_SOLVE"); b->knob_hbm_solve = e && std::string(e) == "hbm"; }
+    { const char* e = getenv("UH_BA_PREBUILT"); b->knob_prebuilt_off = e && atoi(e) == 0; }
     // dense Schur form: windows of 17-32 free keyframes (UH_BA_SCHUR_DENSE=0 keeps the pair form)
     {
         const char* e = getenv("UH_BA_SCHUR_DENSE");

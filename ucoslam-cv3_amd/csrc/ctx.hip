@@ -1,5 +1,6 @@
 // Context + error plumbing of the C ABI (include/ucoslam_hip.h).
 #include <algorithm>
+#include <string>
 #include <vector>
 #include "common.hpp"
 
@@ -27,7 +28,10 @@ __global__ __launch_bounds__(256) void uh_copy16_kernel(const uint4* __restrict_
 __global__ __launch_bounds__(1024) void uh_publish_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, unsigned* reset_word,
                                                           unsigned long long* host_done, unsigned long long word) {
     for (size_t i = threadIdx.x; i < n16; i += 1024) dst[i] = src[i];
-    __syncthreads();   // (every wave's stores have completed: vmcnt(0) precedes the barrier)
+    // Every thread releases its own stores at system scope BEFORE the barrier (as pnp_solve_kernel does): a workgroup barrier alone does
+    // not make the other waves drain their outstanding stores to pinned memory, and thread 0's release below only covers its own wave.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
     if (threadIdx.x == 0) {
         if (reset_word) {   // the call's device-side status word travels in the header (behind the completion word) and is cleared for the next call
             reinterpret_cast<unsigned*>(host_done)[2] = *reset_word;
@@ -103,12 +107,22 @@ int uh_ctx_create_private(int device, uh_ctx** out) { return ctx_create(device, 
 // XCD p % 8 (scripts/micro/cu_mask_probe.hip), so a contiguous bit range [first_bit, first_bit + n_bits) is the same number of CUs on
 // every XCD; a mask that leaves an XCD empty is ignored by the runtime, so a range shorter than the XCD count is refused.  The
 // context reports n_bits as its CU count (the persistent local BA sizes its co-resident grid from it).
+// UNLIKE uh_ctx_create_private this stream has DEFAULT priority and is BLOCKING (hipExtStreamCreateWithCUMask offers neither flag): it
+// synchronises implicitly with the NULL stream and shares the default hardware-queue pool, so keep NULL-stream work away from it.
+// The bit layout (one bit per CU, XCD = bit % 8) was probed on gfx950 only: other devices are refused.
 int uh_ctx_create_private_cus(int device, int first_bit, int n_bits, uh_ctx** out) {
     UH_REQUIRE(out != nullptr, "uh_ctx_create_private_cus: out is NULL");
     int rc = ctx_create(device, nullptr, false, out);   // (device checks; the stream is made below)
     if (rc) return rc;
     uh_ctx* c = *out;
     const int total = c->num_cus;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+            uh::set_error("uh_ctx_create_private_cus: the CU-mask bit layout is only validated on gfx950 (device reports %s)", prop.gcnArchName);
+            delete c; *out = nullptr; return UH_EINVAL;
+        }
+    }
     if (!(first_bit >= 0 && n_bits >= 8 && first_bit + n_bits <= total)) {
         uh::set_error("uh_ctx_create_private_cus: bits [%d, %d) outside the device's %d compute units (or fewer than 8)", first_bit, first_bit + n_bits, total);
         delete c; *out = nullptr; return UH_EINVAL;

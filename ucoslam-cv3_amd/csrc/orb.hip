@@ -1588,7 +1588,11 @@ int uh_orb_extract(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, u
     // count are written by the last kernel into pinned memory — the caller's own buffers if they are pinned, this object's block
     // otherwise — and a completion word follows them, which the host polls.
     if ((rc = o->d_in.reserve((size_t)w * h + 16))) return rc;
-    if (const uint8_t* h_img = static_cast<const uint8_t*>(uh::device_alias_of_host(img))) {
+    // (the 16-byte loads / stores of the pinned paths need 16-byte aligned bases: an interior pointer — an ROI, a numpy view inside a pinned
+    // block — that is not aligned takes the staging paths below instead of relying on the hardware's unaligned-access mode)
+    const uint8_t* h_img = static_cast<const uint8_t*>(uh::device_alias_of_host(img));
+    if (h_img && stride == (size_t)w && (reinterpret_cast<uintptr_t>(h_img) & 15) != 0) h_img = nullptr;   // (the strided path copies 4-byte pieces of any alignment)
+    if (h_img) {
         const int chunks = stride == (size_t)w ? (int)(((size_t)w * h + 15) / 16) : ((w + 15) / 16) * h;
         UH_LAUNCH(o->ctx, ingest_kernel, dim3(uh_div_up(chunks, 256)), dim3(256), 0, h_img, w, h, stride, o->d_in.as<uint8_t>());
     } else if (stride == (size_t)w) {   // pageable frame: through the runtime's staging copy
@@ -1605,7 +1609,7 @@ int uh_orb_extract(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, u
     char* db = o->h_out.dev<char>();
     KeyPointOut* d_kps = cap > 0 ? static_cast<KeyPointOut*>(uh::device_alias_of_host(kps)) : nullptr;
     uint8_t* d_desc = cap > 0 ? static_cast<uint8_t*>(uh::device_alias_of_host(desc)) : nullptr;
-    const bool direct = d_kps && d_desc;
+    const bool direct = d_kps && d_desc && (reinterpret_cast<uintptr_t>(d_desc) & 15) == 0;   // (describe_kernel stores descriptors 16 bytes wide)
     if (!direct) { d_kps = reinterpret_cast<KeyPointOut*>(db + o_kps); d_desc = reinterpret_cast<uint8_t*>(db + o_desc); }
     rc = run_frames(o, d_img, w, h, in_stride, (size_t)in_stride * h, 1, d_kps, d_desc, direct ? slots : maxk, reinterpret_cast<int*>(db + o_cnt));
     if (rc) return rc;

@@ -739,12 +739,13 @@ int uh_pnp_solve(uh_pnp* p, const float* pose_f2g, const float* intr4, int n, co
 }
 
 // measurement hook (scripts/time_pnp.py): shader-clock timestamps of the next solves — [0] kernel entry, [1] inputs staged,
-// [2] rounds done, [3] results posted (s_memtime ticks), [4] number of passes.  on = 0 switches it off again.
-int uh_pnp_debug_clocks(uh_pnp* p, int on, long long* out8) {
+// [2] rounds done, [3] results posted (s_memtime ticks), [4] number of passes.  on = 0 switches it off again.  out512: 512 entries
+// (the whole 4096-byte stamp block is copied).
+int uh_pnp_debug_clocks(uh_pnp* p, int on, long long* out512) {
     UH_REQUIRE(p, "uh_pnp_debug_clocks: NULL");
     UH_HIP_CHECK(hipSetDevice(p->ctx->device));
     if (on && !p->d_clk) { UH_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p->d_clk), 4096)); UH_HIP_CHECK(hipMemset(p->d_clk, 0, 4096)); }
-    if (out8 && p->d_clk) { UH_HIP_CHECK(hipStreamSynchronize(p->ctx->stream)); UH_HIP_CHECK(hipMemcpy(out8, p->d_clk, 4096, hipMemcpyDeviceToHost)); }
+    if (out512 && p->d_clk) { UH_HIP_CHECK(hipStreamSynchronize(p->ctx->stream)); UH_HIP_CHECK(hipMemcpy(out512, p->d_clk, 4096, hipMemcpyDeviceToHost)); }
     if (!on && p->d_clk) { (void)hipFree(p->d_clk); p->d_clk = nullptr; }
     return UH_OK;
 }
