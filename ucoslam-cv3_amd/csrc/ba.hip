@@ -1393,6 +1393,7 @@ __device__ __forceinline__ void backsolve2_lds(const double* M, int n, int ld, d
     if (lane + 64 < n) s_x[lane + 64] = x1;
 }
 
+#include "ldlt_rowlane_v2.hpp"
 #include "ldlt_mfma.hpp"
 
 // Blocked look-ahead LDL^T of the bordered system [S b; b^T .] held as a lower triangle in LDS (row stride ld = n + 1, odd), shared by the
@@ -1400,7 +1401,7 @@ __device__ __forceinline__ void backsolve2_lds(const double* M, int n, int ld, d
 // kSolveThreads threads do the work.  Returns (in wave 0) whether a zero / non-finite pivot was met.
 __device__ __forceinline__ bool ldlt_bordered_lds(double* M, int n, int ld, int nfree, int npairs, const short (*s_pair)[2],
                                                   double (*s_w)[121][6]) {
-    if (n + 1 <= 64 && !UH_LDLT_LEGACY) return ldlt_rowlane_lds(M, n, ld, nfree, npairs, s_pair, &s_w[0][0][0]);   // (uniform)
+    if (n + 1 <= 64 && !UH_LDLT_LEGACY) return ldlt_rowlane_v2<true>(M, n, ld, nfree, npairs, s_pair, &s_w[0][0][0]);   // (uniform)
     // 65..128 rows (11-21 free cameras): two rows per lane; the caller's panel buffer must hold 2 x 6 x 128 + 2 doubles (s_w[2][129][6])
     if (n + 1 <= 128 && !UH_LDLT_LEGACY) return ldlt_rowlane2_lds(M, n, ld, nfree, npairs, s_pair, &s_w[0][0][0]);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;

@@ -941,6 +941,15 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             double lambda = pend ? lambda_spec : st.lambda;
             int cur = st.cur, trial = cur ^ 1;
             UH_BA_CLKT(40);
+            // The force-stop byte lives in pinned HOST memory: a PCIe round trip (1.5 - 2 us).  It is requested HERE, at the top of the
+            // trial, as a load whose destination is LDS (global_load_lds_dword: no register, no wait in the issuing wave) and is read
+            // behind the back substitution; the first barrier on the way (phase 1's block reduction, ~3 us later) is the first
+            // instruction that waits for it.  Rounds 2-4 fetched it through a register in wave 1 DURING the back substitution: the
+            // barrier behind the substitution then waited for the PCIe round trip — 2.3 us of every trial of workgroup 0, hence of
+            // everybody, for 0.9 us of substitution.
+            if (g == 0 && tid == 64 && p.stop)
+                __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)const_cast<const unsigned char*>(p.stop),
+                                                 (__attribute__((address_space(3))) void*)(s_flag + 2), 4, 0, 0);
             {
                 const double Xe[3] = {pend ? Xt[0] : X[0], pend ? Xt[1] : X[1], pend ? Xt[2] : X[2]};
                 lin_eval(pend ? trial : cur, Xe, opening || pend);   // (chi2 recorded: computeActiveErrors at the pass's start / at the trial estimate)
@@ -1012,24 +1021,32 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 cur = st.cur; trial = cur ^ 1;
             }
             UH_BA_CLKT(43);
-            // (one row per lane up to 63 rows; NF = 16: two waves with one row per lane each up to 118 rows — the eight-lane instantiation
-            // never has more than 48 and does not carry the wider forms' code and registers)
-            bool failed;
-            if constexpr (NF == 8) failed = ldlt_rowlane_lds(Mm, n, ld, nfree, npairs, s_pair, &s_w[0][0][0]);
-            else failed = ldlt_bordered_lds(Mm, n, ld, nfree, npairs, s_pair, s_w);
-            if (failed && lane == 0) s_flag[0] = 0;   // (the wave that saw the pivots: wave 0, or wave 1 of the two-wave factorisation)
-            __syncthreads();
-            UH_BA_CLKT(44);
-            const int ok = s_flag[0];
-            // The force-stop byte lives in pinned HOST memory: a PCIe round trip (1.5 - 2 us).  It is fetched HERE, by a lane of wave 1, which
-            // idles through wave 0's back substitution: requested at the top of the trial by thread 0 (as it used to be), the compiler
-            // waited for it on the spot — a one-byte value does not stay a pending load across a whole trial on a kernel out of registers
-            // — and workgroup 0, hence everybody, started every trial that much later.
-            if (g == 0 && tid == 64 && p.stop) s_flag[2] = *p.stop;
-            if (ok) { if (NF == 8 || n <= 64) backsolve_lds(Mm, n, ld, s_x); else backsolve2_lds(Mm, n, ld, s_x); }
-            else for (int i = tid; i < n; i += kPThreads) s_x[i] = 0.0;
-            __syncthreads();
-            const unsigned char stop_byte = (unsigned char)s_flag[2];   // (workgroup 0; it travels with this trial's chi2)
+            // (the eight-lane instantiation never has more than 48 rows and does not carry the wider forms' code and registers)
+            // Factorisation and back substitution.  Up to 10 free keyframes (n + 1 <= 64 rows): row per lane, wave 0 owns the pivots and
+            // substitutes straight behind its last block column (its own data: no barrier, no flag round trip in between); ONE barrier
+            // then publishes x and the verdict.  11-16 free keyframes: two rows per lane (ldlt_bordered_lds, backsolve2_lds).
+            int ok;
+            if (NF == 8 || n + 1 <= 64) {
+                const bool failed = ldlt_rowlane_v2<false>(Mm, n, ld, nfree, npairs, s_pair, &s_w[0][0][0]);
+                UH_BA_CLKT(44);
+                if (wvu == 0) {
+                    if (!failed) backsolve_v2(Mm, n, ld, s_x, s_sc + 3);   // (s_sc[3]: cleared at the kernel's start and never written again)
+                    else if (lane < n) s_x[lane] = 0.0;
+                    if (lane == 0) s_flag[0] = failed ? 0 : 1;
+                }
+                __syncthreads();
+                ok = s_flag[0];
+            } else {
+                const bool failed = ldlt_bordered_lds(Mm, n, ld, nfree, npairs, s_pair, s_w);
+                if (failed && lane == 0) s_flag[0] = 0;   // (the wave that saw the pivots)
+                __syncthreads();
+                UH_BA_CLKT(44);
+                ok = s_flag[0];
+                if (ok) backsolve2_lds(Mm, n, ld, s_x);
+                else for (int i = tid; i < n; i += kPThreads) s_x[i] = 0.0;
+                __syncthreads();
+            }
+            const unsigned char stop_byte = (unsigned char)(s_flag[2] & 0xFF);   // (workgroup 0; it travels with this trial's chi2)
             UH_BA_CLKT(45);
             if (wv == 0) {   // computeScale's pose part: sum x (lambda x + b)
                 double xs = 0;
