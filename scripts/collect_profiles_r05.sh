@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round 5, runs on the GPU box (via gpurun).  Outputs under gpurun_out/prof_r05/, condensed by scripts/parse_profiles_r05.py into profiles/.
+#   quick/      rocprofv3 --kernel-trace --stats of `bench.py --quick`: the headline loop ONLY (the dominant kernel's average over the same
+#               launches as ms_per_step)
+#   pmc_*/      HBM traffic counters of the headline loop, one pass each (--pmc with --kernel-trace only)
+#   chain/      kernel stats of the local-BA launch chain at 17 / 24 / 32 / 48 / 64 free keyframes (scripts/ba_window_sweep.py): every MFMA
+#               kernel of the path by name
+#   chain_mfma/ SQ_VALU_MFMA_BUSY_CYCLES + SQ_BUSY_CYCLES of the same command (its own pass), chain_fetch/, chain_write/: its traffic
+#   tracker/    kernel stats of the tracker's per-frame chain (examples/tracker_frame.cpp, the C++ host)
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof_r05
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+Q="python $R/bench.py --quick --steps 20 --warmup 5 --reps 15"
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/quick -o bench -- $Q > $OUT/quick.log 2>&1
+Q3="python $R/bench.py --quick --steps 6 --warmup 2 --reps 1"
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/pmc_fetch -o bench -- $Q3 > $OUT/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $OUT/pmc_write -o bench -- $Q3 > $OUT/pmc_write.log 2>&1
+export UH_SWEEP_NO_ORACLE=1
+W="python $R/scripts/ba_window_sweep.py 3000 17 24 32 48 64"
+timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $OUT/chain -o chain -- $W > $OUT/chain.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace -f csv -d $OUT/chain_mfma -o chain -- $W > $OUT/chain_mfma.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES --kernel-trace -f csv -d $OUT/chain_mops -o chain -- $W > $OUT/chain_mops.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/chain_fetch -o chain -- $W > $OUT/chain_fetch.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $OUT/chain_write -o chain -- $W > $OUT/chain_write.log 2>&1
+EXE=/tmp/tracker_frame_prof
+g++ -std=c++17 -O2 -o $EXE $R/examples/tracker_frame.cpp -L$R/ucoslam-cv3_amd -lucoslam_hip -Wl,-rpath,$R/ucoslam-cv3_amd -Wl,-rpath,/opt/rocm/lib -lpthread
+timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/tracker -o trk -- $EXE 200 20 > $OUT/tracker.log 2>&1
+$EXE 300 30 > $OUT/tracker_plain.json 2>&1
+find $OUT -name "*.csv" | head -30
+tail -2 $OUT/quick.log

@@ -100,6 +100,8 @@ __device__ __forceinline__ bool ldlt_rowlane_v2(double* M, int n, int ld, int nf
             for (int j = 0; j < 6; j++) {
                 const double dj = readlane_f64(a[j], k0 + j);
                 failed = failed || dj == 0.0 || !isfinite(dj);
+                // 1/d: v_rcp_f64 (2^-23 relative) and ONE cubic step r0 (1 + e + e^2), e = 1 - d r0: error e^3 = 2^-69.  (Tried: the next pivot's
+                // column as (a - p r0) - (p r0)(e + e^2), one dependent operation less on the chain — two instructions more, 7 % slower.)
                 const double r0 = __builtin_amdgcn_rcp(dj);
                 const double e = fma(-dj, r0, 1.0);
                 const double ikj = fma(fma(e, e, e), r0, r0);
