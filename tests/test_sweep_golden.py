@@ -113,8 +113,8 @@ def test_oracle_pnp_equals_real_g2o_at_tracker_sizes(oracle, gold, case):
 # ------------------------------------------------------------------------------------------------ GPU: the HIP forms against the fixture
 _FORMS = {  # window -> (expected form, environment variants that must all reproduce the real g2o)
     10: ("persist8", [{}, {"UH_BA_FORM": "legacy"}, {"UH_BA_NF": "16"}]),
-    18: ("chain", [{}, {"UH_BA_SCHUR_DENSE": "0"}]),            # fused row-per-lane solve, dense / pair Schur form
-    19: ("chain", [{}, {"UH_BA_PREBUILT": "0"}]),
+    18: ("persist16", [{}, {"UH_BA_FORM": "legacy"}]),          # 16 free keyframes: the widest persistent window (two rows per lane); the launch chain
+    19: ("chain", [{}, {"UH_BA_PREBUILT": "0"}, {"UH_BA_SCHUR_DENSE": "0"}]),   # 17 free: fused row-per-lane solve, dense / pair Schur form
     26: ("chain", [{}, {"UH_BA_SCHUR_DENSE": "0"}]),            # packed MFMA solve
     34: ("chain", [{}, {"UH_BA_SOLVE": "hbm"}]),                # 32 free keyframes: packed solve; forced HBM solve
     50: ("chain", [{}, {"UH_BA_SCHUR_DENSE": "0"}]),            # 48 free: wide dense kernel + HBM solve

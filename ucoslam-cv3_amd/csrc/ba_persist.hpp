@@ -75,6 +75,7 @@ struct BAPersist {
     unsigned long long* errw;    // error word (launch id << 32 | 1): some workgroup gave up waiting
 };
 
+constexpr int kFxCam = 20;   // doubles per fixed frame in LDS: R | t (12), fx fy cx cy (4), row 2 of the INPUT float pose widened to double (4: the depth test of getResults)
 struct PersistLds {      // offsets in doubles into the dynamic LDS block
     int Yt, U, usz, out, wsum, x, bp, bs, bsp, wv, pose, poseR, red, sc, fxchi, fxobs, fxcam, fxact_bytes, fxk_bytes, fxid_bytes, fxptr_bytes, pair_bytes, blk_bytes, flag_bytes, total_bytes;
 };
@@ -101,7 +102,7 @@ __host__ __device__ inline PersistLds persist_lds(int krows, int n, int max_fix,
     o.red = a; a += 16; o.sc = a; a += 8;
     o.fxchi = a; a += max_fix;
     o.fxobs = a; a += 3 * max_fix;
-    o.fxcam = a; a += 16 * kfix;
+    o.fxcam = a; a += kFxCam * kfix;
     o.fxact_bytes = a * 8;
     int b = o.fxact_bytes + ((max_fix + 15) & ~15);
     o.fxk_bytes = b; b += (max_fix + 15) & ~15;
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     double* const s_sc = lds + o.sc;
     double* const s_fxchi = lds + o.fxchi;
     double* const s_fxobs = lds + o.fxobs;     // [max_fix][3]: u, v, information scalar
-    double* const s_fxcam = lds + o.fxcam;     // [kfix][16]: R | t (12) and fx fy cx cy of the fixed frames
+    double* const s_fxcam = lds + o.fxcam;     // [kfix][kFxCam]: R | t (12), fx fy cx cy, row 2 of the input float pose
     unsigned char* const s_fxact = reinterpret_cast<unsigned char*>(lds) + o.fxact_bytes;
     unsigned char* const s_fxk = reinterpret_cast<unsigned char*>(lds) + o.fxk_bytes;
     short (*const s_pair)[2] = reinterpret_cast<short (*)[2]>(reinterpret_cast<unsigned char*>(lds) + o.pair_bytes);
@@ -475,9 +476,9 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             ++at;
         }
     }
-    for (int i = tid; i < q.kfix * 16; i += kPThreads) {
-        const int k = q.fix_kf[i >> 4], j = i & 15;
-        s_fxcam[i] = j < 12 ? q.poseR0[12 * k + j] : p.intr[4 * k + (j - 12)];
+    for (int i = tid; i < q.kfix * kFxCam; i += kPThreads) {
+        const int f = i / kFxCam, j = i - f * kFxCam, k = q.fix_kf[f];
+        s_fxcam[i] = j < 12 ? q.poseR0[12 * k + j] : (j < 16 ? p.intr[4 * k + (j - 12)] : (double)q.poses_in[16 * (size_t)k + 8 + (j - 16)]);
     }
     const int fxb = live ? s_fxptr[ll] : 0, fxe = live ? s_fxptr[ll + 1] : 0;   // this landmark's fixed-camera observations
     if (tid < nfree) {
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             for (int i = fxb + s; i < fxe; i += NF) {
                 if (!s_fxact[i]) continue;
                 any = true;
-                const double* C = s_fxcam + 16 * s_fxk[i];
+                const double* C = s_fxcam + kFxCam * s_fxk[i];
                 EdgeLin L;
                 edge_eval_p<1>(s_fxobs[3 * i], s_fxobs[3 * i + 1], s_fxobs[3 * i + 2], C[12], C[13], C[14], C[15], d.delta, d.dsqr, C, Xp, robust, L);
                 if (first) s_fxchi[i] = L.chi2;
@@ -904,7 +905,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 if (chi_e > d.chi2_th || !(z > 0.0)) act = false;
             }
             for (int i = fxb + s; i < fxe; i += NF) {
-                const double* Rt = s_fxcam + 16 * s_fxk[i];
+                const double* Rt = s_fxcam + kFxCam * s_fxk[i];
                 const double z = Rt[6] * X[0] + Rt[7] * X[1] + Rt[8] * X[2] + Rt[11];
                 if (s_fxchi[i] > d.chi2_th || !(z > 0.0)) s_fxact[i] = 0;
             }
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             }
             for (int i = fxb + s; i < fxe; i += NF) {
                 if (!s_fxact[i]) continue;
-                const double* C = s_fxcam + 16 * s_fxk[i];
+                const double* C = s_fxcam + kFxCam * s_fxk[i];
                 EdgeLin L;
                 edge_eval_p<0>(s_fxobs[3 * i], s_fxobs[3 * i + 1], s_fxobs[3 * i + 2], C[12], C[13], C[14], C[15], d.delta, d.dsqr, C, Xt, robust, L);
                 s_fxchi[i] = L.chi2;
@@ -1183,31 +1184,39 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         const double chi = s_fxchi[i];
         bool bad = chi > d.chi2_th;
         if (!bad) {
-            const float* M = q.poses_in + 16 * (size_t)q.fix_kf[s_fxk[i]];
-            const float z = M[8] * Xf0 + M[9] * Xf1 + M[10] * Xf2 + M[11];
+            // (row 2 of the fixed frame's input float pose, staged in LDS at the kernel's start: read from HBM here it was two dependent
+            // memory round trips per observation in front of every workgroup's result stores)
+            const double* M = s_fxcam + kFxCam * s_fxk[i] + 16;
+            const float z = (float)M[0] * Xf0 + (float)M[1] * Xf1 + (float)M[2] * Xf2 + (float)M[3];
             if (z < 0) bad = true;
         }
         if (q.want_chi2) sst(q.r_chi2 + s_fxid[i], chi);
         sst(q.r_bad + s_fxid[i], (unsigned char)bad);
     }
-    if (g == 0) {
-        for (int k = tid; k < d.K; k += kPThreads) {
+    if (g == 0) {   // poses: one element per thread (16 floats of the 4 x 4 matrix + 7 doubles of the se3 state per frame; a thread per frame was 23 stores behind dependent loads)
+        for (int t = tid; t < d.K * 23; t += kPThreads) {
+            const int k = t / 23, j = t - 23 * k;
             const int sl = p.slot[k];
-            float* M = q.r_poses + 16 * (size_t)k;
-            if (sl < 0) {
-                for (int j = 0; j < 16; j++) sst(M + j, q.poses_in[16 * (size_t)k + j]);
-                for (int j = 0; j < 7; j++) sst(q.r_state + 7 * (size_t)k + j, q.pose0[7 * k + j]);
+            if (j < 16) {
+                float v;
+                if (sl < 0) v = q.poses_in[16 * (size_t)k + j];
+                else {
+                    const double* Rt = s_poseR + (st.cur * NF + sl) * 12;
+                    const int r = j >> 2, c = j & 3;
+                    v = r == 3 ? (c == 3 ? 1.f : 0.f) : (float)(c < 3 ? Rt[r * 3 + c] : Rt[9 + r]);
+                }
+                sst(q.r_poses + 16 * (size_t)k + j, v);
             } else {
-                const double* Rt = s_poseR + (st.cur * NF + sl) * 12;
-                for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) sst(M + r * 4 + c, (float)Rt[r * 3 + c]); sst(M + r * 4 + 3, (float)Rt[9 + r]); }
-                sst(M + 12, 0.f); sst(M + 13, 0.f); sst(M + 14, 0.f); sst(M + 15, 1.f);
-                for (int j = 0; j < 7; j++) sst(q.r_state + 7 * (size_t)k + j, s_pose[(st.cur * NF + sl) * 7 + j]);
+                const int i7 = j - 16;
+                sst(q.r_state + 7 * (size_t)k + i7, sl < 0 ? q.pose0[7 * k + i7] : s_pose[(st.cur * NF + sl) * 7 + i7]);
             }
         }
     }
     // (1) -> (2): every workgroup's stores have been acknowledged before it is counted; everybody waits for the full count
+    UH_BA_CLK(11);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    UH_BA_CLK(12);
     if (tid == 0) {
         __hip_atomic_fetch_add(q.done_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         long long t0 = 0;
