@@ -42,23 +42,24 @@ BA_K, BA_P = 10, 3000
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
 
 
-def level_sizes():
-    inv, s = [], 1.0
+def level_sizes(w=None, h=None):
+    w, h = w or W, h or H
     sc = np.float32(1.0)
     out = []
     for l in range(NLEVELS):
-        out.append((int(np.rint(np.float32(W) * (np.float32(1.0) / sc))), int(np.rint(np.float32(H) * (np.float32(1.0) / sc)))))
+        out.append((int(np.rint(np.float32(w) * (np.float32(1.0) / sc))), int(np.rint(np.float32(h) * (np.float32(1.0) / sc)))))
         sc = np.float32(sc * np.float32(SCALE))
     return out
 
 
-def survey_8d_bytes(n_kpts, ba_E, ba_P=BA_P, ba_K=BA_K):
+def survey_8d_bytes(n_kpts, ba_E, ba_P=BA_P, ba_K=BA_K, w=None, h=None):
     """SURVEY.md §8(d), verbatim: algorithmic bytes per unit of each stage of the path.
        B_orb   = W*H + 2*sum_l (w_l+38)(h_l+38) + N*(28+32)                    per frame
        B_match = (NQ+NT)*32 + NQ*k*8                                            per frame (k = 10: the FrameMatcher_Flann call shape)
        B_ba    = E*32 + 2*P*24 + 2*K*56 + K^2*288                               per LM iteration"""
-    lv = level_sizes()
-    b_orb = W * H + 2 * sum((w + 38) * (h + 38) for w, h in lv) + n_kpts * 60
+    w, h = w or W, h or H
+    lv = level_sizes(w, h)
+    b_orb = w * h + 2 * sum((wl + 38) * (hl + 38) for wl, hl in lv) + n_kpts * 60
     b_match = (NQ + NT) * 32 + NQ * NN * 8
     b_ba = ba_E * 32 + 2 * ba_P * 24 + 2 * ba_K * 56 + ba_K * ba_K * 288
     return {"orb_per_frame": b_orb, "match_per_frame": b_match, "ba_per_lm_iteration": b_ba}
@@ -271,6 +272,40 @@ def main():
         stage_ms["ba_set_problem_ms"], stage_ms["ba_optimize_after_set_ms"], stage_ms["ba_get_results_ms"] = ba_phases(24)
         stage_ms["ba_protocol_ms_per_keyframe"] = stage_ms["ba_set_problem_ms"] + stage_ms["ba_optimize_after_set_ms"] + stage_ms["ba_get_results_ms"]
         stage_ms["ba_ms_per_keyframe"] = timed(lambda: ba_res.optimize(), 5)   # optimize() alone on a resident problem (the kernel-side figure)
+        stage_ms["ba_keyframes_per_s"] = 1e3 / stage_ms["ba_protocol_ms_per_keyframe"]   # local BAs per second through the plugin protocol (nothing else on the GPU)
+
+        # The metric's two halves on their own, so that a reader can compose another frames-per-keyframe ratio than this bench's 4:
+        # tracking only = the step WITHOUT the local BA (frames in from pinned memory, ORB, match, results out), host in / host out
+        def step_tracking(fk=F):
+            frames[:fk].copy_(frames_host[:fk], non_blocking=True)
+            check(L.uh_orb_extract_dev(ext._h, dev_ptr(frames), W, H, W, W * H, fk, dev_ptr(kps_v), dev_ptr(desc_v), cap_kp, dev_ptr(cnt_v)))
+            check(L.uh_knn_search_dev(index._h, dev_ptr(desc_v), fk * NQ, NN, dev_ptr(knn_idx), dev_ptr(knn_dist), 0, -1))
+            out_host.copy_(out_dev, non_blocking=True)
+            trk_stream.synchronize()
+
+        for _ in range(3):
+            step_tracking()
+        stage_ms["tracking_only_step_ms"] = timed(step_tracking, 30)
+        stage_ms["tracking_only_frames_per_s"] = 1e3 * F / stage_ms["tracking_only_step_ms"]
+
+        # value at other frames-per-keyframe ratios: one local BA (fresh problem, mapper thread) beside fk frames of tracking per keyframe
+        # interval — fk = 1, 2: a batch of fk frames; fk = 8: two batches of 4.  (fk = 4 is the headline step itself.)
+        def step_fpk(fk):
+            i = step_no[0] % N_PROB
+            step_no[0] += 1
+            check(L.uh_ba_solve_async(*solve_args[i]))
+            for b0 in range(0, fk, F):
+                step_tracking(min(F, fk - b0))
+            check(L.uh_ba_wait(ba._h))
+            check(L.uh_ba_get_results(*get_args))
+
+        fpk = {}
+        for fk in (1, 2, 4, 8):
+            for _ in range(3):
+                step_fpk(fk)
+            ms_ = timed(lambda: step_fpk(fk), 20)
+            fpk[str(fk)] = {"step_ms": round(ms_, 4), "frames_per_s": round(1e3 * fk / ms_, 1)}
+        stage_ms["value_by_frames_per_keyframe"] = fpk
 
         # the frames' way in and the results' way out (pinned host memory <-> HBM), alone on the stream: 4 frames H2D + one D2H of
         # keypoints, descriptors, counts and match rows
@@ -409,6 +444,37 @@ def main():
             step_two_sessions()
         stage_ms["two_sessions_step_ms"] = timed(step_two_sessions, 15)
         stage_ms["two_sessions_frames_per_s"] = 1e3 * 2 * F / stage_ms["two_sessions_step_ms"]
+        # ... and three: 3 x 94 spinning workgroups do not fit the 7/8-of-the-CUs admission budget of the persistent launches (ba.hip,
+        # PersistAdmission): the third session's local BA WAITS for one of the other two to leave (it does not change form) — the figure shows
+        # what that costs.  forms = uh_ba_form of each session's optimiser.
+        ctx_ba3 = u.Context(local_rank, private=True)
+        ba3 = GlobalOptimizer.create(ctx_ba3).wantChi2(False)
+        ba3.setParams(synth.ba_problem(BA_K, BA_P, seed=rank + 200), ParamSet(nIters=5))
+        ctx_t3 = u.Context(local_rank, private=True)
+        ext_c = ORBextractor.create(ctx_t3)
+        idx_c = Index(ctx_t3).build(map_desc)
+        out_c = ext_c.extract_batch(frames, fp)
+        knn_idx_c, knn_dist_c = torch.empty_like(knn_idx), torch.empty_like(knn_dist)
+
+        def step_three_sessions():
+            ba_res.optimize_async(); ba2.optimize_async(); ba3.optimize_async()
+            ext.extract_batch(frames, fp, orb_out)
+            ext_b.extract_batch(frames, fp, out_b)
+            ext_c.extract_batch(frames, fp, out_c)
+            check(L.uh_knn_search_dev(index._h, dev_ptr(orb_out[1]), F * NQ, NN, dev_ptr(knn_idx), dev_ptr(knn_dist), 0, -1))
+            check(L.uh_knn_search_dev(idx_b._h, dev_ptr(out_b[1]), F * NQ, NN, dev_ptr(knn_idx_b), dev_ptr(knn_dist_b), 0, -1))
+            check(L.uh_knn_search_dev(idx_c._h, dev_ptr(out_c[1]), F * NQ, NN, dev_ptr(knn_idx_c), dev_ptr(knn_dist_c), 0, -1))
+            ba_res.wait(); ba2.wait(); ba3.wait()
+
+        for _ in range(3):
+            step_three_sessions()
+        three_ms = timed(step_three_sessions, 15)
+        stage_ms["sessions_on_one_gpu"] = {
+            "frames_per_s": {"1": round(stage_ms["kernel_only_frames_per_s"], 1), "2": round(stage_ms["two_sessions_frames_per_s"], 1), "3": round(1e3 * 3 * F / three_ms, 1)},
+            "step_ms": {"1": round(stage_ms["kernel_only_step_ms"], 4), "2": round(stage_ms["two_sessions_step_ms"], 4), "3": round(three_ms, 4)},
+            "ba_forms": [ba_res.form(), ba2.form(), ba3.form()],
+            "note": "resident form (frames in HBM, one problem per session re-optimised); persistent local-BA launches are admitted up to 7/8 of the CUs: two run side by side, a third waits its turn"}
+        del ba3, ext_c, idx_c
         stage_ms["orb_ms_per_frame_640x480"] = timed(lambda: ext2.extract_batch(fr2, fp, out2), 20) / F
         # not part of the metric's step (ORB + match + local BA): the per-frame pose-only solve (PnPSolver::solvePnp, 600 matches)
         from ucoslam_cv3_amd.pnp import PnPSolver
@@ -487,7 +553,7 @@ def main():
             # `bench.py --quick`): NOT measured in this run.  Corrected as the guide prescribes for gfx950: FETCH_SIZE counts wide reads once -> x2.
             pmc_all, pmc_src = {}, None
             try:
-                pmc_file = next(f_ for f_ in (os.path.join(ROOT, "profiles", n_) for n_ in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(f_))
+                pmc_file = next(f_ for f_ in (os.path.join(ROOT, "profiles", n_) for n_ in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(f_))
                 pmc_all = json.load(open(pmc_file))["kernels"]
                 pmc_src = "profiles/" + os.path.basename(pmc_file) + " (fetch_bytes_x2 + write_bytes per launch; separate rocprofv3 --pmc passes of `bench.py --quick`, not measured in this run)"
                 pmc = pmc_all.get(name)
@@ -535,6 +601,19 @@ def main():
                                          "frac": round(unit_bytes["orb"] / (unit_ms["orb"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "gpu_ms_per_step": round(unit_ms["orb"], 4),
                                          "algorithmic_bytes_per_step": int(unit_bytes["orb"]), "traffic_per_step": int(orb_traffic) if orb_traffic else None,
                                          "note": f"{F} frames per step; launch-latency bound at this size (8-9 dependent launches of a few microseconds each)"}
+            # the second frame size north_star names: the same step on 640 x 480 frames (SURVEY 8(d) bytes of that size over the measured times)
+            n640 = int(out2[2].min().item()) if hasattr(out2[2], "min") else MAX_FEATURES
+            b640 = survey_8d_bytes(n640, e_sum // reps, w=640, h=480)
+            step640_bytes = F * b640["orb_per_frame"] + F * b640["match_per_frame"] + unit_bytes["ba"]
+            others["frame_640x480"] = {
+                "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "keypoints_per_frame": n640,
+                "orb_algorithmic_bytes_per_frame": int(b640["orb_per_frame"]), "orb_ms_per_frame": round(stage_ms["orb_ms_per_frame_640x480"], 4),
+                "orb_achieved": round(b640["orb_per_frame"] / (stage_ms["orb_ms_per_frame_640x480"] * 1e-3) / 1e9, 2),
+                "orb_frac": round(b640["orb_per_frame"] / (stage_ms["orb_ms_per_frame_640x480"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                "step_ms": round(stage_ms["step_ms_640x480"], 4), "frames_per_s": round(stage_ms["frames_per_s_640x480"], 1),
+                "step_bytes": int(step640_bytes), "step_achieved": round(step640_bytes / (stage_ms["step_ms_640x480"] * 1e-3) / 1e9, 2),
+                "step_frac": round(step640_bytes / (stage_ms["step_ms_640x480"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                "note": "the step is the local-BA protocol at this size too (the BA does not depend on the frame size); the extractor alone is launch-latency bound"}
             roofline["others"] = others
         # the metric's serial definition (1 / (t_ORB + t_match + t_BA amortised)) beside the overlapped headline
         t_serial = stage_ms["orb_ms_per_frame"] + stage_ms["match_ms_per_frame"] + stage_ms["h2d_d2h_ms_per_frame"] + stage_ms["ba_protocol_ms_per_keyframe"] / F
@@ -659,6 +738,14 @@ def main():
             else:
                 oracle_lib.ba_optimize(O, ba_pr, 5)
         ba_ms = 1e3 * (time.perf_counter() - t) / n_ba
+        # real-g2o legs for the larger local-BA windows the bench times on the GPU (stages.ba_optimize_ms_<n>_free_kf_3000pt): one optimisation each
+        ba_windows_cpu = {}
+        if g2o is not None:
+            for nfree_w in (16, 32, 64):
+                pr_w = synth.ba_problem(nfree_w + 2, 3000, seed=nfree_w, nfixed=2)
+                t_ = time.perf_counter()
+                oracle_lib.ba_optimize_ref(g2o, pr_w, 5)
+                ba_windows_cpu[str(nfree_w)] = round(1e3 * (time.perf_counter() - t_), 1)
         # the reference's own arrangement: extractor with nthreads = 2 (ucoslamtypes.cpp:40), matcher 1 thread, g2o 1 thread (config.h:7)
         t_ref = 1e3 / orb_2 + m_1 + ba_ms / F
         t_all = 1e3 / orb_all + m_all + ba_ms / F
@@ -670,6 +757,7 @@ def main():
             "match_ms_2000x10000_nn10": {"1_thread": round(m_1, 2), f"{ncores}_threads_throughput": round(m_all, 2)},
             "match_hkmeans32_checks16_build_plus_search_ms_1_thread": round(hk_ms, 2) if hk_ms is not None else None,
             "ba_ms_per_keyframe_1_thread": round(ba_ms, 2),
+            "ba_ms_by_free_keyframes_3000pt_real_g2o_1_thread": ba_windows_cpu,
             "sample": (f"ORB = this repo's oracle port (OpenCV absent: the reference extractor cannot be built), 8/12/{3 * ncores} frames at 1/2/{ncores} threads "
                        f"(whole frames per thread: an upper bound for the reference's level-parallel nthreads); matcher = "
                        f"{'real xflann Linear (oracle/_ref)' if xf is not None else 'oracle port'}, 8 searches on 1 thread and {3 * ncores} on {ncores} threads (independent searches: the reference's threads > 1 path crashes), 2000x10000 nn=10; "
@@ -742,8 +830,14 @@ def main():
         dog.start()
         try:
             sharded = run_sharded()
+            if sharded and world > 1:
+                assert sharded["rccl_ranks"] == world, f"the sharded stream's communicator spans {sharded['rccl_ranks']} ranks, not {world}"
             if rank == 0 and sharded:
                 line["stages"].update({k: v for k, v in sharded.items()})
+                # the two multi-GPU lines side by side: replicas (the metric: N independent streams) and ONE stream sharded over the N GPUs
+                line["multi_gpu"] = {"replica_frames_per_s": line["value"], "sharded_one_stream_frames_per_s": sharded["sharded_frames_per_s"],
+                                     "rccl_ranks": sharded["rccl_ranks"], "n_gpus": world,
+                                     "note": "value = replicas (weak scaling, no data-path collective); the sharded line is ONE frame stream with levels + train tiles + fbow slices over the ranks and one RCCL all-gather per frame — by this repository's own accounting it cannot beat a single GPU at this frame size (DESIGN.md section 6)"}
         except Exception as e_:
             if rank == 0:
                 line["stages"]["sharded_error"] = repr(e_)[:300]

@@ -287,6 +287,19 @@ int  uh_orb_max_keypoints(const uh_orb* orb);              /* = maxFeatures: upp
  * An empty image (NULL / w<=0 / h<=0) returns 0 keypoints silently (ORBextractor.cpp:1254). */
 int uh_orb_extract(uh_orb* orb, const uint8_t* img, int w, int h, size_t stride,
                    uh_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+/* The frame as the camera delivers it and the keypoints as Frame stores them — the two per-frame steps FrameExtractor performs around the
+ * extractor (src/utils/frameextractor.cpp:2960,3046 cv::cvtColor(COLOR_BGR2GRAY) for three-channel input; :3985 undistortPoints(kpts,
+ * ImageParams) = src/basictypes/misc.cpp:269-293: cv::undistortPoints, then x*fx + cx in float) done on the device inside the same launches:
+ *   channels  1 (CV_8UC1), 3 (BGR) or 4 (BGRA) interleaved bytes per pixel, row stride in bytes
+ *   und_xy    NULL, or cap x 2 floats receiving Frame::und_kpts[i].pt for every returned keypoint (needs uh_orb_set_camera)
+ * uh_orb_set_camera: ImageParams' CameraMatrix (CV_32F) and Distorsion (k1 k2 p1 p2 [k3 [k4 k5 k6]], n_dist of them; 0 = none: the result is
+ * still the float round trip (x - cx)/fx*fx + cx of the reference, not the input).  NULL switches the camera off.
+ * uh_undistort_points_host: the same arithmetic on the host (no GPU) for n points. */
+typedef struct uh_camera { float fx, fy, cx, cy; float dist[8]; int32_t n_dist; } uh_camera;
+int uh_orb_set_camera(uh_orb* orb, const uh_camera* cam);
+int uh_orb_extract_frame(uh_orb* orb, const uint8_t* img, int w, int h, size_t stride, int channels,
+                         uh_keypoint* kps, uint8_t* desc, float* und_xy, int cap, int* n_out);
+int uh_undistort_points_host(const uh_camera* cam, const float* xy, int n, float* out_xy);
 /* `batch` frames resident in HBM (frame f at d_imgs + f*frame_stride); outputs per frame at
  * d_kps + f*cap_per_frame, d_desc + f*cap_per_frame*32, d_counts[f].  Asynchronous on the context stream. */
 int uh_orb_extract_dev(uh_orb* orb, const uint8_t* d_imgs, int w, int h, size_t stride, size_t frame_stride,

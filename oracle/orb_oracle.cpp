@@ -651,4 +651,44 @@ void oracle_nth_element_perm(const int* keys, int n, int nth, int* perm_out) {
     for (int i = 0; i < n; i++) perm_out[i] = v[i].second;
 }
 
+// ---- FrameExtractor's two steps around the extractor (TEST INFRASTRUCTURE like the rest of this file; parity UNPINNED: both call into
+// OpenCV, which this image does not have).
+// cv::cvtColor(in, gray, COLOR_BGR2GRAY) for 8-bit input (src/utils/frameextractor.cpp:2960,3046): OpenCV's RGB2Gray<uchar>, 15-bit
+// fixed point — coefficients B 3735, G 19235, R 9798, rounding constant 2^14, shift 15.  cn = 3 (BGR) or 4 (BGRA, alpha ignored).
+void oracle_bgr2gray(const uint8_t* src, int w, int h, size_t stride, int cn, uint8_t* dst) {
+    for (int y = 0; y < h; y++) {
+        const uint8_t* row = src + (size_t)y * stride;
+        for (int x = 0; x < w; x++) {
+            const int b = row[x * cn], g = row[x * cn + 1], r = row[x * cn + 2];
+            dst[(size_t)y * w + x] = (uint8_t)((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15);
+        }
+    }
+}
+// undistortPoints(points, ImageParams) of src/basictypes/misc.cpp:269-293: cv::undistortPoints(points, out, CameraMatrix, Distorsion)
+// — per point, in double: x = (u - cx) * (1 / fx); five iterations (TermCriteria(MAX_ITER, 5, 0.01)) of
+//     r2 = x^2 + y^2;  icdist = (1 + ((k7 r2 + k6) r2 + k5) r2) / (1 + ((k4 r2 + k1) r2 + k0) r2);   [icdist < 0: keep the start, stop]
+//     dx = 2 k2 x y + k3 (r2 + 2 x^2);  dy = k2 (r2 + 2 y^2) + 2 k3 x y;   x = (x0 - dx) icdist;  y = (y0 - dy) icdist
+// the result narrowed to float — then x * fx + cx in float (misc.cpp:283-291).  cam4 = fx fy cx cy (CV_32F), dist = k1 k2 p1 p2 k3 k4 k5 k6.
+void oracle_undistort_points(const float* cam4, const float* dist, int n_dist, const float* xy, int n, float* out) {
+    double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n_dist && i < 8; i++) k[i] = dist[i];
+    const double fx = cam4[0], fy = cam4[1], cx = cam4[2], cy = cam4[3], ifx = 1.0 / fx, ify = 1.0 / fy;
+    for (int i = 0; i < n; i++) {
+        double x = ((double)xy[2 * i] - cx) * ifx, y = ((double)xy[2 * i + 1] - cy) * ify;
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            if (icdist < 0) { x = x0; y = y0; break; }
+            const double dx = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x), dy = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+            x = (x0 - dx) * icdist;
+            y = (y0 - dy) * icdist;
+        }
+        const float xf = (float)x, yf = (float)y;
+        volatile float px = xf * cam4[0]; volatile float py = yf * cam4[1];   // (float product, then float sum: no contraction)
+        out[2 * i] = px + cam4[2];
+        out[2 * i + 1] = py + cam4[3];
+    }
+}
+
 }  // extern "C"

@@ -22,9 +22,8 @@ for K, P, seed, nfix in cfgs:
     pr = synth.ba_problem(K, P, seed, nfixed=nfix)
     ref = oracle_lib.ba_optimize(O, pr, 5)
     out = {}
-    for form in ("persist", "persist-mfma", "legacy"):
+    for form in ("persist", "legacy"):
         os.environ["UH_BA_FORM"] = "legacy" if form == "legacy" else "persist"
-        os.environ["UH_BA_SCHUR"] = "mfma" if form == "persist-mfma" else "valu"
         opt = GlobalOptimizer.create(ctx)
         opt.setParams(pr, ParamSet(nIters=5))
         try:

@@ -72,7 +72,7 @@ if ks:
         e = dur.setdefault(k, [0, 0.0])
         e[0] += int(r["Calls"]); e[1] += float(r["TotalDurationNs"])
 chain = {"command": "rocprofv3 --pmc <counters> --kernel-trace -- python scripts/ba_window_sweep.py 3000 17 24 32 48 64   (UH_SWEEP_NO_ORACLE=1; one pass per counter set)",
-         "note": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES summed over the kernel's launches (all windows): the share of the cycles in which the kernel has a wave resident on an SE that its MFMA pipe is busy.  v_mfma_f64_16x16x4_f64 sustains 6.4 FMA / clock / SIMD on gfx950 (profiles/r03_mfma_f64.json) against 11.4 for v_fma_f64 (scripts/micro/chain_latency.hip): these kernels are bound by the instructions around the MFMAs and by launch / memory latency, not by the matrix pipe.",
+         "note": "mfma_util_of_chip = SQ_VALU_MFMA_BUSY_CYCLES per launch / (average launch duration x 2.4 GHz x 256 CUs x 4 SIMDs): the MfmaUtil formula of gfx94x with the kernel's duration as GRBM_GUI_ACTIVE — the share of the chip's matrix-pipe cycles the kernel keeps busy (all windows 17-64 free keyframes pooled).  v_mfma_f64_16x16x4_f64 sustains 6.4 FMA / clock / SIMD on gfx950 (profiles/r03_mfma_f64.json) against 11.4 for v_fma_f64 (scripts/micro/chain_latency.hip): these kernels are bound by the instructions around the MFMAs and by launch / memory latency, not by the matrix pipe.",
          "kernels": {}}
 for k in sorted(set(mf) | set(mo) | set(cf) | set(cw)):
     if not k.startswith(("ba_", "uh_")):
@@ -83,7 +83,10 @@ for k in sorted(set(mf) | set(mo) | set(cf) | set(cw)):
     if k in mf:
         b, s_ = mf[k]["SQ_VALU_MFMA_BUSY_CYCLES"][1], mf[k]["SQ_BUSY_CYCLES"][1]
         e["mfma_busy_cycles_per_launch"] = round(b / max(mf[k]["SQ_VALU_MFMA_BUSY_CYCLES"][0], 1)); e["sq_busy_cycles_per_launch"] = round(s_ / max(mf[k]["SQ_BUSY_CYCLES"][0], 1))
-        e["mfma_busy_frac"] = round(b / s_, 5) if s_ else None
+        e["mfma_busy_over_sq_busy"] = round(b / s_, 5) if s_ else None   # (raw ratio of the two counters: SQ_BUSY is per shader engine, MFMA_BUSY per SIMD — not a fraction)
+        if k in dur and dur[k][0]:
+            # gfx94x MfmaUtil formula with the kernel's own duration for GRBM_GUI_ACTIVE: busy SIMD-cycles / (duration x 2.4 GHz x 256 CUs x 4 SIMDs)
+            e["mfma_util_of_chip"] = round((b / max(mf[k]["SQ_VALU_MFMA_BUSY_CYCLES"][0], 1)) / (dur[k][1] / dur[k][0] * 2.4 * 256 * 4), 5)
     if k in mo:
         e["mfma_mops_f64_per_launch"] = round(mo[k]["SQ_INSTS_VALU_MFMA_MOPS_F64"][1] / max(mo[k]["SQ_INSTS_VALU_MFMA_MOPS_F64"][0], 1))
     if k in cf:

@@ -171,3 +171,22 @@ def test_hip_orb_pinned_buffers_take_the_copy_free_path(hip_ctx, oracle):
         with pytest.raises(UcoslamHipError):
             check(lib().uh_orb_extract(ext._h, C.c_void_p(pin_img.data_ptr()), w, h, w + pad, C.c_void_p(pk.data_ptr()), C.c_void_p(pd.data_ptr()), 100, C.byref(n)))
         assert n.value == len(rk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"UH_ORB_FAST": "map"}, {"UH_ORB_PYRAMID": "chain"}, {"UH_ORB_FAST": "map", "UH_ORB_PYRAMID": "chain"}],
+                         ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
+def test_hip_orb_fallback_forms_bit_exact(hip_ctx, oracle, monkeypatch, env):
+    """The two forms the plan falls back to when a cell / a level pair does not fit the fused kernels' staging buffers — the strength map +
+    separate NMS launch (UH_ORB_FAST=map) and one resize launch per level (UH_ORB_PYRAMID=chain) — forced at the bench's frame size, where
+    the fused forms normally run: the same bits as the oracle (keypoints, descriptors, order)."""
+    from ucoslam_cv3_amd.orb import FeatParams, ORBextractor
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ext = ORBextractor.create(hip_ctx)
+    for (w, h, nf) in ((1241, 376, 2000), (640, 480, 1500)):
+        img = synth.frame(w, h, seed=3)
+        kps, desc = ext.detectAndCompute(img, None, FeatParams(nf, 8, 1.2))
+        rk, rd = oracle_lib.orb_extract(oracle, img, nf, 8, 1.2, True)
+        _assert_same(kps, desc, rk, rd, f"{env} {w}x{h}")

@@ -1074,130 +1074,8 @@ __device__ __forceinline__ void pose_update_one(const BAPtrs& p, int s, int cur,
 #ifndef UH_LDLT_CLK
 #define UH_LDLT_CLK(i)   // scripts/micro/ldlt_time.hip stamps the phases of the factorisation through this hook
 #endif
-// LDL^T of the bordered system [S b; b^T .] (lower triangle in LDS, row stride ld = n + 1) for n + 1 <= 64 rows: ROW PER LANE.
-// Wave 0 owns the serial chain; lane r keeps row r's six entries of the current block column in registers:
-//   C  apply the previous panel to block column kb: a_j -= sum_t l_prev[t] * y[k0 + j][t]   (own l from registers, y broadcast from LDS)
-//   DP right-looking elimination over the block's six columns, all rows at once: pivots and the block's own rows come from lanes
-//      k0 .. k0+5 with v_readlane; l = y D^-1 goes into M, y into the panel buffer s_y[kb & 1][t][row]
-// and meets the other waves at ONE barrier per block column; they apply panel kb to everything behind block column kb+1 (one thread per
-// row x six columns: 6 + 6 + 18 LDS reads for 36 FMAs) while wave 0 is already on block column kb+1.  Measured with
-// scripts/micro/ldlt_time.hip on MI355X for n = 48: 21.8 k shader clocks for the element-per-thread form below (two barriers per block
-// column, 13 LDS reads per 6 FMAs, 8-way bank conflicts on the panel writes), see DESIGN.md for this form.
-// The right-hand side rides along as row n; M ends up holding L (unit lower), D on the diagonal and D^-1 L^-1 b in row n.
-__device__ __forceinline__ bool ldlt_rowlane_lds(double* M, int n, int ld, int nfree, int npairs, const short (*s_pair)[2], double* s_y_raw) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nb = n / 6, nrow = n + 1;
-    // [2][6][64], 16-byte aligned.  (Pointer arithmetic, not an integer round trip: the latter loses the LDS address space and every access
-    // to the panel buffer becomes a flat_load / flat_store.)
-    double* const s_y = s_y_raw + ((reinterpret_cast<uintptr_t>(s_y_raw) >> 3) & 1);
-    bool failed = false;
-    double lprev[6] = {0, 0, 0, 0, 0, 0};
-    auto wave0_step = [&](int kb) {
-        const int k0 = 6 * kb;
-        const int r = lane < nrow ? lane : nrow - 1;   // idle lanes shadow the last row
-        double a[6];
-#pragma unroll
-        for (int j = 0; j < 6; j++) a[j] = M[r * ld + k0 + j];
-        if (kb > 0) {
-            const double* yb = s_y + ((kb - 1) & 1) * 384 + k0;
-            double2 yv[6][3];
-#pragma unroll
-            for (int t = 0; t < 6; t++)
-#pragma unroll
-                for (int h = 0; h < 3; h++) yv[t][h] = *reinterpret_cast<const double2*>(yb + t * 64 + 2 * h);
-            // all eighteen broadcast reads are in flight before the first FMA (the register allocator otherwise recycles three registers
-            // and the step pays six LDS round trips instead of one)
-#pragma unroll
-            for (int t = 0; t < 6; t++)
-                asm volatile("" : "+v"(yv[t][0].x), "+v"(yv[t][0].y), "+v"(yv[t][1].x), "+v"(yv[t][1].y), "+v"(yv[t][2].x), "+v"(yv[t][2].y));
-#pragma unroll
-            for (int t = 0; t < 6; t++) {
-                a[0] = fma(-lprev[t], yv[t][0].x, a[0]); a[1] = fma(-lprev[t], yv[t][0].y, a[1]); a[2] = fma(-lprev[t], yv[t][1].x, a[2]);
-                a[3] = fma(-lprev[t], yv[t][1].y, a[3]); a[4] = fma(-lprev[t], yv[t][2].x, a[4]); a[5] = fma(-lprev[t], yv[t][2].y, a[5]);
-            }
-        }
-        // the 36 FMAs above are six independent chains: forced to be complete here they issue back to back; left alone, the compiler sinks
-        // each chain in front of its first use, onto the serial pivot chain below
-        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]));
-        UH_LDLT_CLK(1 + 4 * kb);
-        // D + P fused: right-looking elimination over the block's six columns for ALL rows at once.  Column j: the pivot d_j sits in lane
-        // k0+j (v_readlane), every lane forms its own l_j = a_j / d_j, and a_c -= l_j * y_cj with y_cj = a_j of lane k0+c.  The cost of a
-        // wave instruction does not depend on how many lanes need it: factorising the 6x6 block redundantly in every lane (35 FMAs + 15
-        // multiplies) and then substituting (15 FMAs) issued twice the fp64 instructions of this form.
-        double dj[6];
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            dj[j] = readlane_f64(a[j], k0 + j);
-            failed = failed || dj[j] == 0.0 || !isfinite(dj[j]);
-            // 1/d: v_rcp_f64 (2^29 ulp = 2^-23 relative) and ONE cubic step r0 (1 + e + e^2), e = 1 - d r0: error e^3 = 2^-69, three
-            // dependent operations on the pivot chain instead of the four of two Newton steps
-            const double r0 = __builtin_amdgcn_rcp(dj[j]);
-            const double e = fma(-dj[j], r0, 1.0);
-            const double ikj = fma(fma(e, e, e), r0, r0);
-            lprev[j] = a[j] * ikj;
-            // the next pivot's column is updated as a - (a_j y) / d: the product does not wait for the reciprocal, so the chain from pivot
-            // to pivot is rcp, 3 x fma, fma instead of rcp, 3 x fma, mul, fma
-            if (j + 1 < 6) a[j + 1] = fma(-(a[j] * readlane_f64(a[j], k0 + j + 1)), ikj, a[j + 1]);
-#pragma unroll
-            for (int c = j + 2; c < 6; c++) a[c] = fma(-lprev[j], readlane_f64(a[j], k0 + c), a[c]);
-        }
-        // Every lane stores, no lane is masked: rows above the block (and entries right of the diagonal inside it) land in M's upper
-        // triangle, which nobody reads; idle lanes repeat the last row's values; panel rows k0 .. k0+5 of s_y are never read.  Without
-        // the twelve conditional stores the whole step is one basic block for the scheduler.
-        const int ri = lane - k0;
-        double* yo = s_y + (kb & 1) * 384 + lane;
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            M[r * ld + k0 + j] = ri == j ? dj[j] : lprev[j];
-            yo[j * 64] = a[j];
-        }
-        UH_LDLT_CLK(3 + 4 * kb);
-    };
-    auto trailing = [&](int kb) {   // waves 1..3: panel kb onto the tiles (s1 <= s2) with s1 >= kb + 2 and the right-hand-side row
-        const int k0 = 6 * kb, J0 = kb + 2;
-        if (J0 >= nb) return;
-        const int tile0 = J0 * nfree - J0 * (J0 - 1) / 2;   // first pair with s1 >= J0 in the s1-major pair list
-        const int ntile = npairs - tile0;
-        const int nunits = 6 * ntile + (nb - J0);
-        const double* yb = s_y + (kb & 1) * 384;
-        for (int u = tid - 64; u < nunits; u += (int)blockDim.x - 64) {
-            int r, c0;
-            bool diag = false;
-            if (u < 6 * ntile) {
-                const int tile = u / 6, s1 = s_pair[tile0 + tile][0], s2 = s_pair[tile0 + tile][1];
-                r = 6 * s2 + (u - 6 * tile); c0 = 6 * s1; diag = s1 == s2;
-            } else { r = n; c0 = 6 * (J0 + (u - 6 * ntile)); }
-            double lr[6], acc[6];
-#pragma unroll
-            for (int t = 0; t < 6; t++) lr[t] = M[r * ld + k0 + t];
-#pragma unroll
-            for (int j = 0; j < 6; j++) acc[j] = M[r * ld + c0 + j];
-#pragma unroll
-            for (int t = 0; t < 6; t++) {
-                const double2 y01 = *reinterpret_cast<const double2*>(yb + t * 64 + c0), y23 = *reinterpret_cast<const double2*>(yb + t * 64 + c0 + 2),
-                              y45 = *reinterpret_cast<const double2*>(yb + t * 64 + c0 + 4);
-                acc[0] = fma(-lr[t], y01.x, acc[0]); acc[1] = fma(-lr[t], y01.y, acc[1]); acc[2] = fma(-lr[t], y23.x, acc[2]);
-                acc[3] = fma(-lr[t], y23.y, acc[3]); acc[4] = fma(-lr[t], y45.x, acc[4]); acc[5] = fma(-lr[t], y45.y, acc[5]);
-            }
-#pragma unroll
-            for (int j = 0; j < 6; j++) if (!diag || c0 + j <= r) M[r * ld + c0 + j] = acc[j];
-        }
-    };
-    UH_LDLT_CLK(0);
-    if (wv == 0 && nb > 0) wave0_step(0);
-    for (int kb = 0; kb < nb; kb++) {
-        UH_LDLT_CLK(100);
-        __syncthreads();   // panel kb is in M / s_y[kb & 1]; the trailing update of panel kb-1 is complete
-        UH_LDLT_CLK(101);
-        UH_LDLT_CLK(4 + 4 * kb);
-        if (kb == nb - 1) break;
-        if (wv == 0) wave0_step(kb + 1);
-        else trailing(kb);   // (every other wave of the workgroup: three in the persistent kernel, seven in the chain's fused solve)
-    }
-    if (wv != 0) failed = false;   // only wave 0 sees the pivots
-    return failed;
-}
-
+// (The row-per-lane factorisation for n + 1 <= 64 rows and its back substitution live in ldlt_rowlane_v2.hpp since round 5; rounds 3-4's
+// ldlt_rowlane_lds — 6.4 us for eight free keyframes against 4.9 — is in the history.)
 // The same factorisation for 64 < n + 1 <= 128 rows: TWO rows per lane of wave 0 (rows lane and lane + 64), the panel buffer
 // s_y[2][6][128].  A pivot row lives in the low or the high register set of its lane — which one is uniform per column, so the
 // v_readlane source is chosen by a scalar select.  Used by the persistent kernel's 9-16 free keyframe instantiation (n <= 96).
@@ -1527,41 +1405,6 @@ __device__ __forceinline__ bool ldlt_bordered_lds(double* M, int n, int ld, int 
         if (wv != 0) failed = false;   // only wave 0 sees the pivots
     }
     return failed;
-}
-
-// L^T x = z for the bordered factorisation above (z = D^-1 L^-1 b is row n of M); x goes to s_x.  n <= 64: one wave, x_i in lane i,
-// x_j broadcast with v_readlane; larger n: column sweeps with barriers.  Every thread of the workgroup calls it.
-__device__ __forceinline__ void backsolve_lds(const double* M, int n, int ld, double* s_x) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (n <= 64) {
-        if (wv == 0) {
-            double x = lane < n ? M[(size_t)n * ld + lane] : 0.0;
-            const int lr = lane < n ? lane : n - 1;
-            double l[8], ln[8];
-#pragma unroll
-            for (int t = 0; t < 8; t++) { const int jj = n - 1 - t >= 0 ? n - 1 - t : 0; l[t] = M[(size_t)jj * ld + lr]; }
-            for (int j0 = n - 1; j0 >= 0; j0 -= 8) {
-#pragma unroll
-                for (int t = 0; t < 8; t++) { const int jj = j0 - 8 - t >= 0 ? j0 - 8 - t : 0; ln[t] = M[(size_t)jj * ld + lr]; }
-#pragma unroll
-                for (int t = 0; t < 8; t++) { const int j = j0 - t; l[t] = lane < j ? l[t] : 0.0; }
-#pragma unroll
-                for (int t = 0; t < 8; t++) x = fma(-l[t], readlane_f64(x, j0 - t > 0 ? j0 - t : 0), x);
-#pragma unroll
-                for (int t = 0; t < 8; t++) l[t] = ln[t];
-            }
-            if (lane < n) s_x[lane] = x;
-        }
-    } else {
-        for (int i = tid; i < n; i += blockDim.x) s_x[i] = M[(size_t)n * ld + i];
-        __syncthreads();
-        for (int j = n - 1; j >= 0; j--) {
-            const double xj = s_x[j];
-            __syncthreads();
-            for (int i = tid; i < j; i += blockDim.x) s_x[i] -= M[(size_t)j * ld + i] * xj;
-            __syncthreads();
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------ solve + pose update
@@ -3008,7 +2851,7 @@ static int ensure_staging(uh_ba* b, int K, int P, int E) {
     return UH_OK;
 }
 
-struct PersistPlan { bool ok; int NF, Lw, G, krows, nelem, SL, max_fix, kfix, lds, use_mfma, nb4, nblk, KS, off_cam; };
+struct PersistPlan { bool ok; int NF, Lw, G, krows, nelem, SL, max_fix, kfix, lds, nb4, nblk, KS, off_cam; };
 
 template <int NF>
 static int persist_lds_bytes(const PersistPlan& pl, int n) { return persist_lds<NF>(pl.krows, n, pl.max_fix, pl.kfix, pl.off_cam, pl.KS, pl.SL).total_bytes; }
@@ -3051,18 +2894,15 @@ static PersistPlan plan_persistent(uh_ba* b, int K, int P, int E, int nfree) {
     pl.NF = NF; pl.Lw = Lw; pl.G = G; pl.kfix = kfix;
     pl.max_fix = Lw * kfix;   // bound: every landmark of the tile seen by every fixed frame (nothing is counted on the host)
     pl.krows = (3 * Lw + 15) & ~15;
-    const char* sch = getenv("UH_BA_SCHUR");
-    pl.use_mfma = (sch && std::string(sch) == "mfma") ? 1 : 0;   // default: register-blocked vector FMA
-    if (NF != 8) pl.use_mfma = 0;
     const int n = 6 * nfree;
     pl.nb4 = (n + 3) / 4; pl.nblk = pl.nb4 * (pl.nb4 + 1) / 2;
-    pl.off_cam = pl.use_mfma ? 6 * 256 : pl.nblk * 16;
+    pl.off_cam = pl.nblk * 16;   // the product part of a partial: the upper 4 x 4 blocks (vector FMA; the v_mfma_f64 form of rounds 2-4 was slower on gfx950 and is gone: docs/DESIGN_history_r1_r3.md, profiles/r03_mfma_f64.json)
     pl.nelem = pl.off_cam + NF * 27 + 6 * NF + 4;
     pl.SL = (uh_div_up(pl.nelem, G) + 1) & ~1;
     // K-splits of the Schur product: work items = nblk * KS over 256 lanes, each krows / KS rows deep; the splits' partial blocks must
     // fit the LDS region the reduced system occupies later ((n + 1)^2 doubles)
     pl.KS = 1;
-    if (!pl.use_mfma) {
+    {
         int best = 1 << 30;
         for (int ks = 1; ks <= 6; ks++) {
             if (ks > 1 && ks * pl.off_cam > (n + 1) * (n + 1) + 1452) break;
@@ -3184,7 +3024,7 @@ static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl
     p.stop = static_cast<const volatile unsigned char*>(d_pin);
     BAPersist& q = b->pq;
     q = BAPersist{};
-    q.G = pl.G; q.Lw = pl.Lw; q.krows = pl.krows; q.SL = pl.SL; q.nelem = pl.nelem; q.max_fix = pl.max_fix; q.kfix = pl.kfix; q.use_mfma = pl.use_mfma;
+    q.G = pl.G; q.Lw = pl.Lw; q.krows = pl.krows; q.SL = pl.SL; q.nelem = pl.nelem; q.max_fix = pl.max_fix; q.kfix = pl.kfix;
     { const char* e = getenv("UH_BA_SPEC"); q.speculate = e && e[0] == '0' ? 0 : 1; }   // (read per launch: the A/B scripts and a test switch it within one process)
     q.nb4 = pl.nb4; q.nblk = pl.nblk; q.KS = pl.KS;
     q.T = b->dT.as<unsigned>(); q.tseq = tseq;

@@ -11,8 +11,8 @@
 //     the 24-byte observation, forms Hll, its Cholesky factor L (3x3) and the whitened blocks Y_e = Hpl_e L^-T straight into an
 //     LDS panel Yt[3*landmark + k][6*camera + a];
 //   * Schur complement (g2o/core/block_solver.hpp:341-392): sum_l Hpl D^-1 Hpl^T = Yt^T Yt, a dense 48 x 48 x (3*Lw) fp64 product
-//     per workgroup — vector FMA on 4x4 register blocks (UH_BA_SCHUR=mfma selects v_mfma_f64_16x16x4_f64 on the six upper 16x16
-//     tiles for the A/B in DESIGN.md: slower on gfx950);  b_schur = Yt^T (L^-1 b_l);
+//     per workgroup — vector FMA on 4x4 register blocks (v_mfma_f64_16x16x4_f64 on the six upper 16x16 tiles was measured in rounds
+//     2-4 and removed in round 5: 6.4 FMA / clock / SIMD against 11.4 for v_fma_f64 on gfx950);  b_schur = Yt^T (L^-1 b_l);
 //   * back-substitution (block_solver.hpp:419-442): dx_l = L^-T (L^-1 b_l - Y_l^T dx_p) from the same panel;
 //   * workgroups exchange only reduction partials, through write-through (sc1) stores of SELF-VALIDATING words: every double travels
 //     as two 64-bit words (32 payload bits | 32-bit tag = launch sequence and exchange round), so a reader polls the data itself —
@@ -46,7 +46,7 @@ constexpr long long kPTimeoutTicksDefault = 10000000ll;   // 100 ms of the 100 M
 struct BAPersist {
     int G, Lw, krows, SL, nelem, max_fix, kfix;
     int nb4, nblk, KS;   // the product's 4x4 block grid: nb4 = ceil(n / 4) block columns, nblk upper blocks, KS splits of the K range
-    int n1, n2, stop_at_begin, use_mfma;
+    int n1, n2, stop_at_begin;
     int speculate;        // 1: speculative trials (see the trial loop); UH_BA_SPEC=0 keeps the three-hand-off form for A/B measurements
     unsigned launch_id;   // tags the error / completion words of this launch
     long long timeout_ticks;   // see kPTimeoutTicksDefault
@@ -349,7 +349,6 @@ __device__ __forceinline__ void block_reduce3(double& a, double& b, double& c, d
     a = ra; b = rb; c = rc;
 }
 
-typedef double pmf4 __attribute__((ext_vector_type(4)));
 
 template <int NW>
 __device__ __forceinline__ double block_max_n(double v, double* s_red) {
@@ -372,14 +371,13 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     uh_latency_critical();
     static_assert(NF == 8 || NF == 16, "lanes per landmark = padded number of free cameras");
     constexpr int NP = 6 * NF, YS = NP + 2;
-    constexpr int NT = 6;                       // (MFMA form, NF == 8 only: six upper 16x16 tiles of the 48 x 48 product)
     constexpr int LG = NF == 8 ? 3 : 4;
     constexpr int NHP = NF == 8 ? 5 : 9;        // camera-side sums a lane owns after the butterfly transpose over 64 / NF landmarks
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = blockIdx.x;
     const int wvu = __builtin_amdgcn_readfirstlane(wv);   // the wave index as a scalar: wave-uniform branches become s_cbranch
     const int n = d.n, ld = n + 1, nfree = d.nfree, npairs = nfree * (nfree + 1) / 2;
-    const int OFF_CAM = (NF == 8 && q.use_mfma) ? NT * 256 : q.nblk * 16, OFF_BS = OFF_CAM + NF * 27, OFF_SC = OFF_BS + NP;
+    const int OFF_CAM = q.nblk * 16, OFF_BS = OFF_CAM + NF * 27, OFF_SC = OFF_BS + NP;
     const PersistLds o = persist_lds<NF>(q.krows, n, q.max_fix, q.kfix, OFF_CAM, q.KS, q.SL);
     double* const Yt = lds + o.Yt;
     double* const U = lds + o.U;
@@ -544,10 +542,6 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
 
     // element of the product partial that holds (row, col), row <= col (the inverse of dst_of's layouts)
     auto prod_index = [&](int row, int col) -> int {
-        if (NF == 8 && q.use_mfma) {
-            const int tm = row >> 4, tn = col >> 4, ti = tm == 0 ? tn : (tm == 1 ? 2 + tn : 5), r16 = row & 15;
-            return ti * 256 + ((((r16 & 3) << 4) | (col & 15)) << 2) + (r16 >> 2);
-        }
         const int bi = row >> 2, bj = col >> 2;
         return (bi * q.nb4 - bi * (bi - 1) / 2 + (bj - bi)) * 16 + (row & 3) * 4 + (col & 3);
     };
@@ -555,14 +549,8 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
     auto is_diag_elem = [&](int idx) -> bool {
         if (idx >= OFF_CAM) return false;
         int row, col;
-        if (NF == 8 && q.use_mfma) {
-            const int ti = idx >> 8, lq = (idx >> 2) & 63, vv = idx & 3;
-            const int tm = ti < 3 ? 0 : (ti < 5 ? 1 : 2), tn = ti < 3 ? ti : (ti < 5 ? ti - 2 : 2);
-            row = 16 * tm + (lq >> 4) + 4 * vv; col = 16 * tn + (lq & 15);
-        } else {
-            const int bq = idx >> 4;
-            row = 4 * s_blk[bq][0] + ((idx >> 2) & 3); col = 4 * s_blk[bq][1] + (idx & 3);
-        }
+        const int bq = idx >> 4;
+        row = 4 * s_blk[bq][0] + ((idx >> 2) & 3); col = 4 * s_blk[bq][1] + (idx & 3);
         return row == col && col < n;
     };
     // this thread's share of folding Hpp (21 upper entries per free camera) into the product: product element and camera-sum index
@@ -707,12 +695,13 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         // scalars of a partial: chi2 at the linearisation point, (speculative trial:) the previous trial's scale sum, max |Hll_jj|, stop flag
         if (tid == 0) { s_out[NF * 27 + NP] = cs; s_out[NF * 27 + NP + 1] = ss; s_out[NF * 27 + NP + 2] = mx; s_out[NF * 27 + NP + 3] = g == 0 ? stop_val : 0.0; }
         if (!first) UH_BA_CLKT(54);
-        // S = Yt^T Yt.  Default: vector FMA, 4x4 register blocks — the nblk upper blocks of the nb4 x nb4 block grid x KS splits of the K
+        // S = Yt^T Yt: vector FMA, 4x4 register blocks — the nblk upper blocks of the nb4 x nb4 block grid x KS splits of the K
         // range (78 x 3 = 234 items for eight free cameras: one per lane; more cameras: several per lane), 16 accumulators each, four
         // ds_read_b128 per 16 FMAs; the splits are added in order through LDS.  Measured on MI355X (scripts/micro/mfma_f64_rate.hip):
-        // v_fma_f64 sustains 9.1 FMA/clk/SIMD, v_mfma_f64_16x16x4_f64 issues every ~160 cycles = 6.4, so the MFMA form below
-        // (UH_BA_SCHUR=mfma: six upper 16x16 tiles split over the waves, accumulators resident in AGPRs) loses on gfx950.
-        if (!first && !(NF == 8 && q.use_mfma)) {   // (U is free: its last users — the reduced system, the slice reduction's scratch — are behind barriers)
+        // v_fma_f64 sustains 9.1-11.4 FMA/clk/SIMD, v_mfma_f64_16x16x4_f64 issues every ~160 cycles = 6.4: the MFMA form of this product
+        // (six upper 16x16 tiles split over the waves, accumulators resident in AGPRs; rounds 2-4 behind UH_BA_SCHUR=mfma) lost on
+        // gfx950 — kernel 0.454 against 0.430 ms — and was removed in round 5.
+        if (!first) {   // (U is free: its last users — the reduced system, the slice reduction's scratch — are behind barriers)
             const int nitems = q.nblk * q.KS;
             const int kc = (q.krows + q.KS - 1) / q.KS;
             for (int item = tid; item < nitems; item += kPThreads) {
@@ -748,51 +737,6 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             }
             // (the K-splits' partials stay apart: the store loop at the end adds them, in order, on the way out)
         }
-        // MFMA form: wave 0: (0,0) (0,1), wave 1: (0,2) (1,1), wave 2: (1,2) + half of b_schur, wave 3: (2,2) + the other half — every wave
-        // runs the whole K range, so no reduction across waves is needed.
-        if (NF == 8 && !first && q.use_mfma) {
-            const int nks = q.krows >> 2;
-            const int col = lane & 15, kr = lane >> 4;
-            // column groups of the wave's tile(s): wave 0 (0,0)+(0,1), wave 1 (0,2)+(1,1), wave 2 (1,2), wave 3 (2,2)
-            const int ga = wvu == 0 ? 0 : (wvu == 1 ? 0 : (wvu == 2 ? 16 : 32)), gb = wvu == 0 ? 0 : 32;
-            const int gc = wvu == 0 ? 0 : 16, gd = 16;
-            pmf4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
-            {
-                // v_mfma_f64_16x16x4_f64 through inline asm with "+a": the accumulators stay in AGPRs for the whole loop (the builtin form
-                // made the compiler copy all eight registers VGPR <-> AGPR around every instruction).  Consecutive MFMAs never depend on
-                // each other: two tiles alternate (waves 0/1), or even / odd k-steps go to two accumulators (waves 2/3).
-                const double* row = Yt + kr * YS + col;
-                if (wvu < 2) {
-                    double ya = row[ga], yb = row[gb], yc = row[gc], yd = row[gd];
-                    for (int ks = 0; ks < nks; ks++) {
-                        const double* nrow = Yt + (4 * (ks + 1 < nks ? ks + 1 : ks) + kr) * YS + col;   // next k-step's operands while the MFMAs run
-                        const double na = nrow[ga], nb = nrow[gb], nc = nrow[gc], nd = nrow[gd];
-                        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(t0) : "v"(ya), "v"(yb));
-                        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(t1) : "v"(yc), "v"(yd));
-                        ya = na; yb = nb; yc = nc; yd = nd;
-                    }
-                    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-                } else {
-                    for (int ks = 0; ks < nks; ks += 2) {
-                        const double* r0 = Yt + (4 * ks + kr) * YS + col;
-                        const double ya = r0[ga], yb = r0[gb], yc = r0[4 * YS + ga], yd = r0[4 * YS + gb];
-                        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(t0) : "v"(ya), "v"(yb));
-                        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(t1) : "v"(yc), "v"(yd));
-                    }
-                    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-                    for (int v = 0; v < 4; v++) t0[v] += t1[v];
-                }
-            }
-            // element index of (tile t, lane, v) = (t*64 + lane)*4 + v; tile order (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
-            const int ti0 = wvu == 0 ? 0 : (wvu == 1 ? 2 : (wvu == 2 ? 4 : 5)), ti1 = wvu == 0 ? 1 : 3;
-#pragma unroll
-            for (int v = 0; v < 4; v++) U[ti0 * 256 + lane * 4 + v] = t0[v];
-            if (wvu < 2) {
-#pragma unroll
-                for (int v = 0; v < 4; v++) U[ti1 * 256 + lane * 4 + v] = t1[v];
-            }
-        }
         if (!first) UH_BA_CLKT(55);
         __syncthreads();   // the product (U) and the camera sums (s_out) are complete
         if (!first) UH_BA_CLKT(56);
@@ -807,7 +751,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         __syncthreads();
         // the partial goes out with consecutive lanes on consecutive words (one element per lane and instruction was 64 cache lines per store)
         for (int i = tid; i < NF * 27 + NP + 4; i += kPThreads) tst(q.part, part_at(OFF_CAM + i), s_out[i], tagA);
-        const int KSs = (NF == 8 && q.use_mfma) ? 1 : q.KS;
+        const int KSs = q.KS;
         // (opening evaluation: there is no product; only the slice that straddles the end of the product part is sent, as zeros, so that
         // its reducer finds the round's tag on every element — the slices below it are not reduced at all in that round)
         for (int i = (first ? open_beg : 0) + tid; i < OFF_CAM; i += kPThreads) {
@@ -824,7 +768,7 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         // HG groups of sources per element, chosen so that one pass of the workgroup covers the slice (SL * HG <= 256 threads) and a
         // thread's sources (~G / HG <= 8) go out as ONE batch of loads: every extra pass or batch is a memory round trip (~1.5 us)
         const int HG = red_HG;
-        double* const R = U + ((NF == 8 && q.use_mfma) ? 1 : q.KS) * OFF_CAM;   // behind the product's partials, which other waves may still be sending
+        double* const R = U + q.KS * OFF_CAM;   // behind the product's partials, which other waves may still be sending
         const size_t src = (size_t)g * G * SL;   // slice g of every workgroup's partial
         for (int idx = tid; idx < SL * HG; idx += kPThreads) {
             const int hg = div_sl(idx), e = idx - hg * SL;
@@ -870,14 +814,9 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         if (idx < q.nelem) {
             if (idx < OFF_CAM) {
                 int row, col;
-                if (NF == 8 && q.use_mfma) {   // (tile, lane, register) of the MFMA C layout: row = (lane >> 4) + 4 * reg, col = lane & 15
-                    const int ti = idx >> 8, lq = (idx >> 2) & 63, vv = idx & 3;
-                    const int tm = ti < 3 ? 0 : (ti < 5 ? 1 : 2), tn = ti < 3 ? ti : (ti < 5 ? ti - 2 : 2);
-                    row = 16 * tm + (lq >> 4) + 4 * vv; col = 16 * tn + (lq & 15);
-                } else {            // (4x4 block of the upper block triangle, r, c)
-                    const int bq = idx >> 4, rr = (idx >> 2) & 3, cq = idx & 3;
-                    row = 4 * s_blk[bq][0] + rr; col = 4 * s_blk[bq][1] + cq;
-                }
+                // (4x4 block of the upper block triangle, r, c)
+                const int bq = idx >> 4, rr = (idx >> 2) & 3, cq = idx & 3;
+                row = 4 * s_blk[bq][0] + rr; col = 4 * s_blk[bq][1] + cq;
                 if (row <= col && col < n) t = o.U + col * ld + row;
             } else if (idx < OFF_BS) {   // camera sums: bp is kept (computeScale needs it); the Hpp entries have been folded into the product by the senders
                 const int i = idx - OFF_CAM, sc = i / 27, k = i - 27 * sc;

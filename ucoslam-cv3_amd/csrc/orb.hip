@@ -187,6 +187,33 @@ __global__ __launch_bounds__(256) void ingest_kernel(const uint8_t* __restrict__
     } else for (int k = 0; x + k < w; k++) dp[k] = sp[k];
 }
 
+// An interleaved BGR (3 bytes) or BGRA (4 bytes) frame to gray on its way in: cv::cvtColor(in, gray, COLOR_BGR2GRAY) as FrameExtractor does
+// for three-channel input (src/utils/frameextractor.cpp:2960,3046) — OpenCV's 8-bit form: (B * 3735 + G * 19235 + R * 9798 + 2^14) >> 15
+// (RGB2Gray<uchar>, 15-bit coefficients; OpenCV >= 4 — unpinned like the rest of the extractor, oracle_bgr2gray restates it).  A thread
+// converts four pixels (12 or 16 source bytes, dword loads: the source may be pinned host memory) into one dword of the packed gray frame.
+__global__ __launch_bounds__(256) void ingest_bgr_kernel(const uint8_t* __restrict__ src, int w, int h, size_t stride, int cn, uint8_t* __restrict__ dst) {
+    const int quads = (w + 3) / 4;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= quads * h) return;
+    const int y = id / quads, x = (id - y * quads) * 4;
+    const uint8_t* sp = src + (size_t)y * stride + (size_t)x * cn;
+    uint8_t px[16];
+    const int npx = min(4, w - x), nbytes = npx * cn;
+    if (npx == 4 && ((reinterpret_cast<uintptr_t>(sp) & 3) == 0)) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (k * 4 < nbytes) *reinterpret_cast<uint32_t*>(px + 4 * k) = *reinterpret_cast<const uint32_t*>(sp + 4 * k);
+    } else {
+        for (int k = 0; k < nbytes; k++) px[k] = sp[k];
+    }
+    uint8_t g[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (k < npx) g[k] = (uint8_t)(((int)px[k * cn] * 3735 + (int)px[k * cn + 1] * 19235 + (int)px[k * cn + 2] * 9798 + (1 << 14)) >> 15);
+    uint8_t* dp = dst + (size_t)y * w + x;
+    if (npx == 4 && (reinterpret_cast<uintptr_t>(dp) & 3) == 0) *reinterpret_cast<uint32_t*>(dp) = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16) | ((uint32_t)g[3] << 24);
+    else for (int k = 0; k < npx; k++) dp[k] = g[k];
+}
+
 // plain copy of the input into level 0 (doGaussianBlur == false)
 __global__ void copy_kernel(const uint8_t* __restrict__ src, int w, int h, size_t src_stride, size_t src_frame_stride,
                             uint8_t* __restrict__ dst, int dst_pitch, size_t dst_frame_stride) {
@@ -984,12 +1011,36 @@ __device__ __forceinline__ void describe_slot(const Plan& plan, const uint8_t* _
                                               size_t sel_frame_stride, const int* __restrict__ lc, KeyPointOut* s_kp,
                                               unsigned long long* s_desc, int class_id, int frame, int lane, int slot);
 
+// Camera model of the frames (ImageParams: CameraMatrix CV_32F fx fy cx cy, Distorsion k1 k2 p1 p2 [k3 [k4 k5 k6]]) for the undistorted
+// keypoints: undistortPoints(points, ImageParams) of src/basictypes/misc.cpp:269-293 = cv::undistortPoints(points, out, K, D) — normalise
+// with 1/fx, 1/fy in double, FIVE fixed-point iterations of the distortion model (the overload's TermCriteria(MAX_ITER, 5, 0.01): a count,
+// no early exit), a float result — followed by x * fx + cx in FLOAT arithmetic (misc.cpp:283-291; this unit is compiled without
+// contraction).  Called for every frame's keypoints at src/utils/frameextractor.cpp:3985; parity UNPINNED like the rest of the extractor
+// (OpenCV absent): KATs + oracle/orb_oracle.cpp::oracle_undistort_points.
+struct CamModel { double fx, fy, cx, cy, ifx, ify, k[8]; float ffx, ffy, fcx, fcy; int on; };
+__host__ __device__ inline void undistort_point(const CamModel& c, float u, float v, float& ox, float& oy) {
+    double x = ((double)u - c.cx) * c.ifx, y = ((double)v - c.cy) * c.ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((c.k[7] * r2 + c.k[6]) * r2 + c.k[5]) * r2) / (1 + ((c.k[4] * r2 + c.k[1]) * r2 + c.k[0]) * r2);
+        if (icdist < 0) { x = x0; y = y0; break; }   // (OpenCV: the point is left at its normalised position)
+        const double dX = 2 * c.k[2] * x * y + c.k[3] * (r2 + 2 * x * x);
+        const double dY = c.k[2] * (r2 + 2 * y * y) + 2 * c.k[3] * x * y;
+        x = (x0 - dX) * icdist;
+        y = (y0 - dY) * icdist;
+    }
+    ox = (float)x * c.ffx + c.fcx;
+    oy = (float)y * c.ffy + c.fcy;
+}
+
 // One wave per output keypoint slot; 4 waves per block.
 __global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const uint8_t* __restrict__ pyr,
                                                        size_t frame_stride, const uint32_t* __restrict__ sel,
                                                        size_t sel_frame_stride, const int* __restrict__ level_counts,
                                                        KeyPointOut* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                       int cap_per_frame, int* __restrict__ frame_counts, int class_id) {
+                                                       int cap_per_frame, int* __restrict__ frame_counts, int class_id,
+                                                       const CamModel cam, float* __restrict__ und) {
     const int frame = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -1010,7 +1061,12 @@ __global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const ui
         const size_t o = (size_t)frame * cap_per_frame + slot0;
         const int t = threadIdx.x;
         if (t < 2 * nvalid) reinterpret_cast<uint4*>(desc + o * 32)[t] = reinterpret_cast<const uint4*>(&s_desc[0][0])[t];
-        else if (t >= 64 && t < 64 + 7 * nvalid) {   // (a second wave: the two groups of stores issue side by side)
+        else if (und && t >= 128 && t < 128 + nvalid) {   // (a third wave) the undistorted position of each of the four keypoints, Frame::und_kpts
+            float ux, uy;
+            undistort_point(cam, s_kp[t - 128].x, s_kp[t - 128].y, ux, uy);
+            reinterpret_cast<float2*>(und)[o + (t - 128)] = make_float2(ux, uy);
+        }
+        if (t >= 64 && t < 64 + 7 * nvalid) {   // (a second wave: the two groups of stores issue side by side)
             const int i = t - 64;
             uint32_t* dst = reinterpret_cast<uint32_t*>(kps + o);
             if (nvalid == 4 && ((o * sizeof(KeyPointOut)) & 15) == 0 && (reinterpret_cast<uintptr_t>(kps) & 15) == 0) {
@@ -1141,6 +1197,8 @@ struct uh_orb {
     uh::DevBuf d_in, d_kps, d_desc, d_counts;
     uh::MappedBuf h_out;           // one-frame form: [completion word | count | keypoints | descriptors] when the caller's buffers are not pinned
     unsigned long long seq = 0;
+    CamModel cam{};                // uh_orb_set_camera: on = 1 -> the one-frame entry can return the undistorted keypoints
+    uh::DevBuf d_raw;              // an interleaved BGR / BGRA frame on its way to gray (uh_orb_extract_frame)
 };
 
 namespace {
@@ -1370,7 +1428,7 @@ int make_plan(uh_orb* o, int w, int h, int batch) {
 }
 
 int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, size_t img_frame_stride, int batch,
-               KeyPointOut* d_kps, uint8_t* d_desc, int cap_per_frame, int* d_counts) {
+               KeyPointOut* d_kps, uint8_t* d_desc, int cap_per_frame, int* d_counts, float* d_und = nullptr) {
     int rc;
     if (!o->planned || o->w != w || o->h != h || o->batch < batch) {
         if ((rc = make_plan(o, w, h, std::max(batch, o->planned && o->w == w && o->h == h ? o->batch : 0)))) return rc;
@@ -1444,7 +1502,7 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
     const int slots = std::min(std::max(P.maxFeatures, 1), std::max(cap_per_frame, 1));
     UH_LAUNCH(o->ctx,describe_kernel, dim3(uh_div_up(slots, 4), batch), dim3(256), 0, P, pyr, o->frame_stride,
                        o->d_sel.as<uint32_t>(), o->sel_stride, o->d_level_counts.as<int>(), d_kps, d_desc, cap_per_frame,
-                       d_counts, o->nonmaxima ? 1 : -1);
+                       d_counts, o->nonmaxima ? 1 : -1, o->cam, o->cam.on ? d_und : nullptr);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
 }
@@ -1572,13 +1630,15 @@ int uh_orb_extract_dev(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t st
                       cap_per_frame, d_counts);
 }
 
-int uh_orb_extract(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, uh_keypoint* kps, uint8_t* desc, int cap,
-                   int* n_out) {
+static int extract_one(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, int cn, uh_keypoint* kps, uint8_t* desc, float* und_xy, int cap,
+                       int* n_out) {
     UH_REQUIRE(o && n_out, "uh_orb_extract: NULL argument");
     *n_out = 0;
     if (img == nullptr || w <= 0 || h <= 0) return UH_OK;   // ORBextractor.cpp:1254 — empty image: silent return
-    UH_REQUIRE(stride >= (size_t)w, "uh_orb_extract: stride < width");
+    UH_REQUIRE(cn == 1 || cn == 3 || cn == 4, "uh_orb_extract_frame: %d channels (1 = gray, 3 = BGR, 4 = BGRA)", cn);
+    UH_REQUIRE(stride >= (size_t)w * cn, "uh_orb_extract: stride < row bytes");
     UH_REQUIRE(cap >= 0 && (cap == 0 || (kps && desc)), "uh_orb_extract: NULL output buffer");
+    UH_REQUIRE(!und_xy || o->cam.on, "uh_orb_extract_frame: undistorted keypoints asked for but no camera set (uh_orb_set_camera)");
     const int maxk = std::max(o->fp.maxFeatures, 1);
     int rc;
     UH_HIP_CHECK(hipSetDevice(o->ctx->device));
@@ -1591,6 +1651,16 @@ int uh_orb_extract(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, u
     // (the 16-byte loads / stores of the pinned paths need 16-byte aligned bases: an interior pointer — an ROI, a numpy view inside a pinned
     // block — that is not aligned takes the staging paths below instead of relying on the hardware's unaligned-access mode)
     const uint8_t* h_img = static_cast<const uint8_t*>(uh::device_alias_of_host(img));
+    if (cn != 1) {   // colour frame: to gray on the way in (cv::cvtColor COLOR_BGR2GRAY, frameextractor.cpp:2960) — from pinned memory in place, else through a staged copy
+        const uint8_t* src = h_img;
+        size_t sstride = stride;
+        if (!src) {
+            if ((rc = o->d_raw.reserve((size_t)w * cn * h + 16))) return rc;
+            UH_HIP_CHECK(hipMemcpy2DAsync(o->d_raw.p, (size_t)w * cn, img, stride, (size_t)w * cn, h, hipMemcpyHostToDevice, st));
+            src = o->d_raw.as<uint8_t>(); sstride = (size_t)w * cn;
+        }
+        UH_LAUNCH(o->ctx, ingest_bgr_kernel, dim3(uh_div_up(((w + 3) / 4) * h, 256)), dim3(256), 0, src, w, h, sstride, cn, o->d_in.as<uint8_t>());
+    } else {
     if (h_img && stride == (size_t)w && (reinterpret_cast<uintptr_t>(h_img) & 15) != 0) h_img = nullptr;   // (the strided path copies 4-byte pieces of any alignment)
     if (h_img) {
         const int chunks = stride == (size_t)w ? (int)(((size_t)w * h + 15) / 16) : ((w + 15) / 16) * h;
@@ -1600,10 +1670,12 @@ int uh_orb_extract(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, u
     } else {
         UH_HIP_CHECK(hipMemcpy2DAsync(o->d_in.p, w, img, stride, w, h, hipMemcpyHostToDevice, st));
     }
+    }
     const uint8_t* d_img = o->d_in.as<uint8_t>();
     const size_t in_stride = (size_t)w;
     const int slots = std::min(maxk, std::max(cap, 1));
-    const size_t o_cnt = 64, o_kps = 128, o_desc = o_kps + (((size_t)maxk * sizeof(uh_keypoint) + 63) & ~(size_t)63), total = o_desc + (size_t)maxk * 32;
+    const size_t o_cnt = 64, o_kps = 128, o_desc = o_kps + (((size_t)maxk * sizeof(uh_keypoint) + 63) & ~(size_t)63), o_und = o_desc + (size_t)maxk * 32,
+                 total = o_und + (und_xy ? (size_t)maxk * 8 : 0);
     if ((rc = o->h_out.reserve(total))) return rc;
     char* hb = o->h_out.host<char>();
     char* db = o->h_out.dev<char>();
@@ -1611,7 +1683,11 @@ int uh_orb_extract(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, u
     uint8_t* d_desc = cap > 0 ? static_cast<uint8_t*>(uh::device_alias_of_host(desc)) : nullptr;
     const bool direct = d_kps && d_desc && (reinterpret_cast<uintptr_t>(d_desc) & 15) == 0;   // (describe_kernel stores descriptors 16 bytes wide)
     if (!direct) { d_kps = reinterpret_cast<KeyPointOut*>(db + o_kps); d_desc = reinterpret_cast<uint8_t*>(db + o_desc); }
-    rc = run_frames(o, d_img, w, h, in_stride, (size_t)in_stride * h, 1, d_kps, d_desc, direct ? slots : maxk, reinterpret_cast<int*>(db + o_cnt));
+    // (the undistorted positions: into the caller's array if it is pinned and 8-byte aligned, else into this object's block)
+    float* d_und = und_xy ? static_cast<float*>(uh::device_alias_of_host(und_xy)) : nullptr;
+    const bool und_direct = d_und && (reinterpret_cast<uintptr_t>(d_und) & 7) == 0;
+    if (und_xy && !und_direct) d_und = reinterpret_cast<float*>(db + o_und);
+    rc = run_frames(o, d_img, w, h, in_stride, (size_t)in_stride * h, 1, d_kps, d_desc, direct ? slots : maxk, reinterpret_cast<int*>(db + o_cnt), d_und);
     if (rc) return rc;
     // the completion word as its own one-thread launch behind the last kernel (a ticket counter inside describe_kernel — one system-scope
     // release and one same-address atomic per workgroup — cost 10 us more than this launch)
@@ -1625,6 +1701,38 @@ int uh_orb_extract(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, u
         std::memcpy(kps, hb + o_kps, (size_t)n * sizeof(uh_keypoint));
         std::memcpy(desc, hb + o_desc, (size_t)n * 32);
     }
+    if (und_xy && !und_direct && n > 0) std::memcpy(und_xy, hb + o_und, (size_t)n * 8);
+    return UH_OK;
+}
+
+int uh_orb_extract(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, uh_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
+    return extract_one(o, img, w, h, stride, 1, kps, desc, nullptr, cap, n_out);
+}
+int uh_orb_extract_frame(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, int channels, uh_keypoint* kps, uint8_t* desc, float* und_xy,
+                         int cap, int* n_out) {
+    return extract_one(o, img, w, h, stride, channels, kps, desc, und_xy, cap, n_out);
+}
+int uh_orb_set_camera(uh_orb* o, const uh_camera* cam) {
+    UH_REQUIRE(o, "uh_orb_set_camera: NULL extractor");
+    CamModel c{};
+    if (cam) {
+        UH_REQUIRE(cam->n_dist >= 0 && cam->n_dist <= 8 && cam->fx != 0.f && cam->fy != 0.f, "uh_orb_set_camera: %d distortion coefficients / zero focal length", cam->n_dist);
+        c.fx = cam->fx; c.fy = cam->fy; c.cx = cam->cx; c.cy = cam->cy; c.ifx = 1.0 / c.fx; c.ify = 1.0 / c.fy;
+        for (int i = 0; i < cam->n_dist; i++) c.k[i] = cam->dist[i];
+        c.ffx = cam->fx; c.ffy = cam->fy; c.fcx = cam->cx; c.fcy = cam->cy;
+        c.on = 1;
+    }
+    o->cam = c;
+    return UH_OK;
+}
+// host-only form of the same arithmetic (a caller that has keypoints from elsewhere; tests): n points in, n out
+int uh_undistort_points_host(const uh_camera* cam, const float* xy, int n, float* out_xy) {
+    UH_REQUIRE(cam && (n == 0 || (xy && out_xy)) && cam->n_dist >= 0 && cam->n_dist <= 8, "uh_undistort_points_host: bad argument");
+    CamModel c{};
+    c.fx = cam->fx; c.fy = cam->fy; c.cx = cam->cx; c.cy = cam->cy; c.ifx = 1.0 / c.fx; c.ify = 1.0 / c.fy;
+    for (int i = 0; i < cam->n_dist; i++) c.k[i] = cam->dist[i];
+    c.ffx = cam->fx; c.ffy = cam->fy; c.fcx = cam->cx; c.fcy = cam->cy;
+    for (int i = 0; i < n; i++) undistort_point(c, xy[2 * i], xy[2 * i + 1], out_xy[2 * i], out_xy[2 * i + 1]);
     return UH_OK;
 }
 

@@ -28,6 +28,23 @@ class FeatParams(C.Structure):
         super().__init__(nthreads, maxFeatures, nOctaveLevels, scaleFactor, sensitivity)
 
 
+class Camera(C.Structure):
+    """uh_camera: ImageParams' CameraMatrix (CV_32F) and Distorsion (k1 k2 p1 p2 [k3 [k4 k5 k6]])."""
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("dist", C.c_float * 8), ("n_dist", C.c_int32)]
+
+    def __init__(self, fx, fy, cx, cy, dist=()):
+        d = (C.c_float * 8)(*[float(v) for v in dist])
+        super().__init__(fx, fy, cx, cy, d, len(dist))
+
+
+def undistort_points_host(cam: Camera, xy):
+    """undistortPoints(points, ImageParams) (misc.cpp:269-293) on the host: n x 2 float32 in, n x 2 out."""
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.empty_like(xy)
+    check(lib().uh_undistort_points_host(C.byref(cam), np_ptr(xy) if len(xy) else None, len(xy), np_ptr(out) if len(xy) else None))
+    return out
+
+
 class FrameExtractorState(C.Structure):
     """uh_frame_extractor_state: what FrameExtractor::toStream writes between the extractor's own stream and the two sub-streams."""
     _fields_ = [("counter", C.c_uint32), ("remove_from_markers", C.c_uint8), ("detect_markers", C.c_uint8), ("detect_keypoints", C.c_uint8),
@@ -52,6 +69,9 @@ def _declare(L, sig):
     sig("uh_orb_extract", I, VP, VP, I, I, SZ, VP, VP, I, C.POINTER(I))
     sig("uh_orb_extract_dev", I, VP, VP, I, I, SZ, SZ, I, VP, VP, I, VP)
     sig("uh_orb_debug_level", I, VP, I, I, I, VP, C.POINTER(I), C.POINTER(I))
+    sig("uh_orb_set_camera", I, VP, C.POINTER(Camera))
+    sig("uh_orb_extract_frame", I, VP, VP, I, I, SZ, I, VP, VP, VP, I, C.POINTER(I))
+    sig("uh_undistort_points_host", I, C.POINTER(Camera), VP, I, VP)
 
 
 _lib._EXTRA_DECLS.append(_declare)
@@ -114,6 +134,30 @@ class ORBextractor:
         check(lib().uh_orb_extract(self._h, np_ptr(img), img.shape[1], img.shape[0], img.strides[0], np_ptr(kps), np_ptr(desc),
                                    cap, C.byref(n)))
         return kps[: n.value].copy(), desc[: n.value].copy()
+
+    def setCamera(self, cam: Camera | None):
+        check(lib().uh_orb_set_camera(self._h, C.byref(cam) if cam is not None else None))
+        return self
+
+    def extractFrame(self, image, params: FeatParams | None = None, undistorted=True):
+        """The frame as the camera delivers it (H x W gray, H x W x 3 BGR or H x W x 4 BGRA, uint8) -> (keypoints, descriptors, und_xy):
+        FrameExtractor's cvtColor + detectAndCompute + undistortPoints (frameextractor.cpp:2960, :3985) in one call."""
+        if params is not None:
+            check(lib().uh_orb_set_params(self._h, C.byref(params)))
+        img = np.asarray(image)
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        if img.dtype != np.uint8 or img.ndim not in (2, 3) or cn not in (1, 3, 4):
+            raise _lib.UcoslamHipError(_lib.UH_EINVAL, "image must be uint8, H x W [x 3 | x 4]")
+        if img.strides[-1] != 1 or (img.ndim == 3 and img.strides[1] != cn):
+            img = np.ascontiguousarray(img)
+        cap = max(lib().uh_orb_max_keypoints(self._h), 1)
+        kps = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        und = np.zeros((cap, 2), np.float32) if undistorted else None
+        n = C.c_int(0)
+        check(lib().uh_orb_extract_frame(self._h, np_ptr(img), img.shape[1], img.shape[0], img.strides[0], cn, np_ptr(kps), np_ptr(desc),
+                                         np_ptr(und) if undistorted else None, cap, C.byref(n)))
+        return kps[: n.value].copy(), desc[: n.value].copy(), (und[: n.value].copy() if undistorted else None)
 
     def extract_batch(self, frames, params: FeatParams | None = None, out=None):
         """frames: torch uint8 CUDA tensor [B,H,W] (resident in HBM). Returns (kps [B,cap,7] f32 view, desc [B,cap,32], counts [B])."""
