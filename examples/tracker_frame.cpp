@@ -1,7 +1,7 @@
 // The reference tracker's per-frame chain over the C ABI, ONE frame at a time, host buffers in and out of every call — what a drop-in
 // under UcoSlam::process() executes between two camera frames (reference file:line, statement starts of the token-pasted source):
 //
-//   FrameExtractor::process          ORB detectAndCompute of the frame                        uh_orb_extract           frameextractor.cpp:430-520
+//   FrameExtractor::process          ORB detectAndCompute + undistortPoints of the frame        uh_orb_extract_frame     frameextractor.cpp:430-520, :3985
 //   Frame::create_kdtree             kd-tree over the undistorted keypoints                   uh_projmatch_set_frame   map_types/frame.h:124
 //   tracker: previous-frame search   project the previous frame's map points, match          uh_projmatch_match_prev  utils/system.cpp:5930-6460 (call :6559-6565)
 //   PnPSolver::solvePnp              pose from those matches (4 x 10 LM iterations)           uh_pnp_solve             optimization/pnpsolver.cpp:116-409 (call system.cpp:6626)
@@ -119,6 +119,9 @@ int main(int argc, char** argv) {
 
     uh_keypoint* kps = static_cast<uh_keypoint*>(uh_host_alloc((size_t)NFEAT * sizeof(uh_keypoint)));
     uint8_t* desc = static_cast<uint8_t*>(uh_host_alloc((size_t)NFEAT * 32));
+    float* und_xy = static_cast<float*>(uh_host_alloc((size_t)NFEAT * 2 * sizeof(float)));
+    const uh_camera cam{FX, FY, CX, CY, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 5};   // a rectified (KITTI-like) camera: zero coefficients, the arithmetic still runs
+    CHECK(uh_orb_set_camera(ext, &cam));
 
     // ---- scenes: one ORB extraction each, the map is made from its output
     std::vector<Scene> scenes(NSCENES);
@@ -220,7 +223,10 @@ int main(int argc, char** argv) {
         Scene& sc = scenes[(it + warmup) % NSCENES];
         const double t0 = now_us();
         int n = 0;
-        CHECK(uh_orb_extract(ext, sc.image, W, H, W, kps, desc, NFEAT, &n));
+        // FrameExtractor::process: detectAndCompute + undistortPoints(kpts, ImageParams) in one call (frameextractor.cpp:430-520, :3985;
+        // misc.cpp:269-293) — Frame::und_kpts = the keypoints with the undistorted positions
+        CHECK(uh_orb_extract_frame(ext, sc.image, W, H, W, 1, kps, desc, und_xy, NFEAT, &n));
+        for (int i = 0; i < n; i++) { kps[i].x = und_xy[2 * i]; kps[i].y = und_xy[2 * i + 1]; }
         const double t1 = now_us();
         const uh_proj_frame fr{kps, n, desc, sf, NLEV, FX, FY, CX, CY, 0, 0, W, H};
         CHECK(uh_projmatch_set_frame(pm, &fr));

@@ -51,6 +51,6 @@ for K, P, seed, nfix in cfgs:
             print(f"    kernel: setup {us(0,1):.2f} | pass 1: begin+opening {us(2,3):.2f}, trials {us(3,5):.2f} | pass 2: relabel+opening {us(5,6):.2f}, trials {us(6,8):.2f} | total to results {us(0,8):.2f} us")
             print(f"    results: stores issued {us(8,11):.2f} | acknowledged + barrier {us(11,12):.2f} | count of all workgroups {us(12,9):.2f}")
             print(f"    results hand-over (workgroup 0): result block + count {us(8,9):.2f} | copy of its slice to the pinned host block {us(9,10):.2f} us")
-            print(f"    phase1: edges {us(40,52):.2f} | butterfly+chol+Y {us(52,53):.2f} | block sums+camsum {us(53,54):.2f} | product+stores {us(54,55):.2f} | tail {us(55,41):.2f}")
+            print(f"    phase1: edges {us(40,52):.2f} | butterfly+chol+Y {us(52,53):.2f} | block sums+camsum {us(53,54):.2f} | product+stores {us(54,55):.2f} | tail {us(55,41):.2f} (wait for the other waves' product {us(55,56):.2f}, fold + barrier {us(56,60):.2f}, camera-sum stores {us(60,61):.2f}, product stores {us(61,41):.2f})")
     if "persist" in out and "legacy" in out:
         print(f"    persist vs legacy |state| {np.abs(out['persist']['state']-out['legacy']['state']).max():.2e}")

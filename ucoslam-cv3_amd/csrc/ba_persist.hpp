@@ -522,15 +522,16 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         return false;
     };
     // up to eight tagged elements (first, first + stride, ...), all loads in flight together; spins until every tag matches
-    auto tload8 = [&](const pword* base, size_t first, size_t stride, int cnt, unsigned tag, double (&v)[8]) {
+    // (need: bit u clear = element u is not wanted — nobody sent it this round — and is neither fetched nor waited for)
+    auto tload8 = [&](const pword* base, size_t first, size_t stride, int cnt, unsigned tag, double (&v)[8], unsigned need = 0xFFu) {
         long long t0 = 0;
         for (;;) {
             TWord w[8];
             bool ok = true;
 #pragma unroll
-            for (int u = 0; u < 8; u++) if (u < cnt) w[u] = tld_raw(base, first + u * stride);
+            for (int u = 0; u < 8; u++) if (u < cnt && ((need >> u) & 1u)) w[u] = tld_raw(base, first + u * stride);
 #pragma unroll
-            for (int u = 0; u < 8; u++) { if (u < cnt) { ok = ok && tok(w[u], tag); v[u] = tval(w[u]); } else v[u] = 0.0; }
+            for (int u = 0; u < 8; u++) { if (u < cnt && ((need >> u) & 1u)) { ok = ok && tok(w[u], tag); v[u] = tval(w[u]); } else v[u] = 0.0; }
             if (ok || give_up(t0)) return;
         }
     };
@@ -749,11 +750,20 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             for (int j = tid; j < n; j += kPThreads) { const int sc = j / 6; s_out[NF * 27 + j] -= s_out[sc * 27 + 21 + (j - 6 * sc)]; }
         }
         __syncthreads();
+        if (!first) UH_BA_CLKT(60);
         // the partial goes out with consecutive lanes on consecutive words (one element per lane and instruction was 64 cache lines per store)
-        for (int i = tid; i < NF * 27 + NP + 4; i += kPThreads) tst(q.part, part_at(OFF_CAM + i), s_out[i], tagA);
+        // (a trial does not send the 21 Hpp entries of a camera's 27 sums: they have been folded into the product above, nobody reads them —
+        // only the opening evaluation needs them, for max |H_jj|; 168 of 1516 elements less on the wire)
+        for (int i = tid; i < NF * 27 + NP + 4; i += kPThreads) {
+            if (!first && i < NF * 27 && i - 27 * (i / 27) < 21) continue;
+            tst(q.part, part_at(OFF_CAM + i), s_out[i], tagA);
+        }
+        if (!first) UH_BA_CLKT(61);
         const int KSs = q.KS;
         // (opening evaluation: there is no product; only the slice that straddles the end of the product part is sent, as zeros, so that
         // its reducer finds the round's tag on every element — the slices below it are not reduced at all in that round)
+        // (Round 5 stamps: camera-sum stores 0.36 us, these five stores per thread 1.04 us — the write-through stores themselves, ~250 ns per
+        // wave instruction; fetching all K-split partials of four elements before the first addition made it 1.36: not the LDS reads.)
         for (int i = (first ? open_beg : 0) + tid; i < OFF_CAM; i += kPThreads) {
             double r = 0.0;
             if (!first) { r = U[i]; for (int kt = 1; kt < KSs; kt++) r += U[kt * OFF_CAM + i]; }
@@ -773,7 +783,9 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
         for (int idx = tid; idx < SL * HG; idx += kPThreads) {
             const int hg = div_sl(idx), e = idx - hg * SL;
             const bool is_max = g * SL + e == OFF_SC + 2;
-            const bool used = g * SL + e < q.nelem && !(first && (g + 1) * SL <= OFF_CAM);   // (the last slice is padded: nobody writes or needs those elements; opening: nor the product's slices)
+            const int ge = g * SL + e;
+            const bool hpp = ge >= OFF_CAM && ge < OFF_BS && (ge - OFF_CAM) - 27 * ((ge - OFF_CAM) / 27) < 21;   // (an Hpp entry: sent in the opening evaluation only)
+            const bool used = ge < q.nelem && !(first && (g + 1) * SL <= OFF_CAM) && !(hpp && !first);   // (the last slice is padded: nobody writes or needs those elements; opening: nor the product's slices)
             // every source of this element in ONE batch of loads where possible (G <= 128: at most eight per thread): a separate load
             // for the first source put a second memory round trip (~1.5 us) in front of every slice reduction
             double r = 0.0;
@@ -799,6 +811,10 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
             double r = R[e];
             for (int hg = 1; hg < HG; hg++) { const double v = R[hg * SL + e]; r = is_max ? fmax(r, v) : r + v; }
             if (e == tid ? red_diag0 : is_diag_elem(g * SL + e)) r -= lam;   // (the product arrives negated: - (Y^T Y - Hpp - lambda))
+            {
+                const int ge = g * SL + e;
+                if (!first && ge >= OFF_CAM && ge < OFF_BS && (ge - OFF_CAM) - 27 * ((ge - OFF_CAM) / 27) < 21) continue;   // (nobody fetches an Hpp entry in a trial)
+            }
             tst(q.red, (size_t)g * SL + e, r, tagB);
         }
         UH_BA_CLKT(51);
@@ -931,7 +947,10 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                 double rv[8];
                 const int left = q.nelem - b0 - tid;
                 const int cnt = left <= 0 ? 0 : min(8, (left + kPThreads - 1) / kPThreads);
-                tload8(q.red, (size_t)(b0 + tid), kPThreads, cnt, tagB, rv);
+                unsigned need = 0;
+#pragma unroll
+                for (int u = 0; u < 8; u++) need |= ((b0 == 0 ? asm_dst[u] : dst_of(b0 + tid + u * kPThreads)) >= 0 ? 1u : 0u) << u;
+                tload8(q.red, (size_t)(b0 + tid), kPThreads, cnt, tagB, rv, need);
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const int t = b0 == 0 ? asm_dst[u] : dst_of(b0 + tid + u * kPThreads);
