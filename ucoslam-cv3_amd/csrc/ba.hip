@@ -2138,26 +2138,7 @@ __global__ void ba_init_state_kernel(BAPtrs p, BADims d, const double* __restric
 // numbers and read as empty, so the table is never cleared between problems (only when it is reallocated or the 12 bits wrap).
 // A (point, frame) pair that occurs twice (g2o would add two edges; this solver owns one lane per pair) and an index out of range
 // are reported through a pinned word the host reads after the optimisation: err[0] = 1 out of range / 2 duplicate, err[1] = observation.
-__global__ __launch_bounds__(256) void ba_ingest_kernel(const uh_ba_obs* __restrict__ obs, int E, int P, int K, unsigned* __restrict__ T, unsigned tseq,
-                                                        unsigned* err, int obs16) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= E) return;
-    int pt, kf;
-    if (obs16) { const unsigned w = reinterpret_cast<const unsigned*>(obs)[4 * (size_t)e]; pt = (int)(w & 0xFFFFFFu); kf = (int)(w >> 24); }
-    else { pt = obs[e].point; kf = obs[e].frame; }
-    unsigned code = 0;
-    if ((unsigned)pt >= (unsigned)P || (unsigned)kf >= (unsigned)K) code = 1;
-    else {
-        const unsigned old = atomicExch(T + (size_t)pt * K + kf, tseq | (unsigned)(e + 1));
-        if ((old & 0xFFF00000u) == tseq) code = 2;
-    }
-    if (code) {
-        __hip_atomic_store(err + 1, (unsigned)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-// The same with the H2D copy folded in (the default; UH_BA_INGEST=copy selects the DMA + ba_ingest_kernel pair for the A/B): the kernel reads the pinned staging block over the host link itself,
+// ba_ingest_direct_kernel does that with the H2D copy folded in: the kernel reads the pinned staging block over the host link itself,
 // mirrors it into HBM (header + points as 16-byte words, observations as 24-byte records) and scatters the table cells from the
 // records it has in registers — one launch instead of a DMA + a launch.
 __global__ __launch_bounds__(256) void ba_ingest_direct_kernel(const unsigned char* __restrict__ host, unsigned char* __restrict__ dev, size_t head_bytes, size_t obs_off,
@@ -2992,21 +2973,13 @@ static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl
     void* d_pin = nullptr;
     UH_HIP_CHECK(hipHostGetDevicePointer(&d_pin, b->h_stop, 0));
     unsigned* d_err = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(d_pin) + 200);
-    // measured on MI355X (bench.py --quick, same box): 0.588 ms per step with the DMA + kernel pair, 0.574-0.581 with the one kernel
-    static const bool direct = [] { const char* e = getenv("UH_BA_INGEST"); return !(e && std::string(e) == "copy"); }();
-    if (direct) {   // the kernel fetches the staging block over the host link itself: one launch, no DMA
+    {   // the kernel fetches the staging block over the host link itself: one launch, no DMA (the DMA + ingest-launch pair it replaced —
+        // 0.588 against 0.574-0.581 ms per step — was kept behind UH_BA_INGEST=copy until round 5)
         void* d_hs = nullptr;
         UH_HIP_CHECK(hipHostGetDevicePointer(&d_hs, hs, 0));
         const int head_blocks = uh_div_up((int)(L.obs / 16), 256);
         UH_LAUNCH(b->ctx, ba_ingest_direct_kernel, dim3(head_blocks + uh_div_up(std::max(E, 1), 256)), dim3(256), 0, static_cast<const unsigned char*>(d_hs),
                   reinterpret_cast<unsigned char*>(db), L.obs, L.obs, E, P, K, b->dT.as<unsigned>(), tseq, d_err, head_blocks, obs16 ? 1 : 0);
-    } else {
-        // ---- ONE copy: header, frame arrays, points, observations
-        const size_t copy_bytes = L.obs + (size_t)E * (obs16 ? 16 : sizeof(uh_ba_obs));
-        UH_HIP_CHECK(hipMemcpyAsync(b->dstage.p, hs, copy_bytes, hipMemcpyHostToDevice, st));
-        if (E > 0)
-            UH_LAUNCH(b->ctx, ba_ingest_kernel, dim3(uh_div_up(E, 256)), dim3(256), 0, reinterpret_cast<const uh_ba_obs*>(db + L.obs), E, P, K,
-                      b->dT.as<unsigned>(), tseq, d_err, obs16 ? 1 : 0);
     }
     UH_HIP_CHECK(hipEventRecord(b->ev_stage, st));   // behind the last reader of the staging block
     b->stage_in_flight = true;
