@@ -212,6 +212,16 @@ struct PmPoints {
 };
 
 struct PmPose { float T[12]; float cc[3]; };
+// The call's hand-over, done by the kernel itself (round 5; rounds 3-4: a copy launch in front and a publish launch behind, ~6 us of kernel
+// and a launch gap each): the candidates' arrays are read from the pinned staging block in place, the per-point results go to HBM with
+// write-through (agent-scope) stores, every workgroup takes a ticket behind its acknowledged stores, and the workgroup that draws the last
+// one copies the result block into pinned memory 8 bytes a lane, clears the ticket and the walk-overflow word for the next call and posts
+// the completion word (one system-scope release).
+struct PmPublish {
+    unsigned* ticket;                          // HBM, 0 between calls
+    const unsigned long long* dev_out; unsigned long long* host_out; unsigned n8;   // the result block in HBM, its pinned twin, 8-byte words
+    unsigned long long* host_done; unsigned long long word;                        // pinned: completion word; word [1] low half receives the overflow flag
+};
 
 __device__ __forceinline__ float logf_cr(float x) { return uh_sincosf::logf_glibc(x); }   // libm's logf, bit for bit
 
@@ -236,7 +246,7 @@ __device__ __forceinline__ float logf_cr(float x) { return uh_sincosf::logf_glib
 // maxRepjDist * scaleFactors[octave], best/second without demotion from (float)(minDescDist + 0.01), accept best < 0.7 * second.
 template <bool IN_LDS, bool PREV>
 __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoints mp, PmPose ps, float minDescDist, float maxRepjDist,
-                                                               int n_nodes, int levels, int* overflow) {
+                                                               int n_nodes, int levels, int* overflow, PmPublish pub) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x, g = lane / kGroup, gl = lane % kGroup, gw = (lane & 63) / kGroup;   // gw: group within its wave
     // measurement (UH_PM_CLK): shader-clock stamps of workgroup 0, thread 0 in the status block behind the overflow word
@@ -441,16 +451,40 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
     if (clk) { clk[2] = __builtin_readcyclecounter(); clk[5] = ncand; }
     if (!ovf) drain(ncand);
     if (clk) clk[3] = __builtin_readcyclecounter();
-    if (ovf) { if (gl == 0) *overflow = 1; best_kp = -1; }
+    if (ovf) { if (gl == 0) __hip_atomic_store(overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); best_kp = -1; }
     if constexpr (PREV) { if (best_kp != -1 && !(best_d < 0.7 * second_d)) best_kp = -1; }
     else if (best_kp != -1 && bestLevel2 == bestLevel && best_d > 0.8 * second_d) best_kp = -1;
-    if (live && gl == 0) {
-        mp.best_kp[m] = best_kp;
-        mp.best_dist[m] = (PREV && best_kp < 0) ? 3.402823466e+38f : best_d;
-        if (mp.visible) mp.visible[m] = vis ? 1 : 0;
+    if (live && gl == 0) {   // (write-through: the publishing workgroup may sit on another XCD)
+        __hip_atomic_store(mp.best_kp + m, best_kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mp.best_dist + m, (PREV && best_kp < 0) ? 3.402823466e+38f : best_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mp.visible) __hip_atomic_store(mp.visible + m, (unsigned char)(vis ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (clk) clk[4] = __builtin_readcyclecounter();
   }
+    if (!pub.ticket) return;
+    // ---- hand-over: ticket behind this workgroup's acknowledged stores; the last workgroup publishes
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(pub.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    for (unsigned i = threadIdx.x; i < pub.n8; i += 4 * kPmThreads) {   // four words in flight per lane
+        unsigned long long v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (i + u * kPmThreads < pub.n8) v[u] = __hip_atomic_load(pub.dev_out + i + u * kPmThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (i + u * kPmThreads < pub.n8) __hip_atomic_store(pub.host_out + i + u * kPmThreads, v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (threadIdx.x == 0) {
+        const int ov = __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        reinterpret_cast<unsigned*>(pub.host_done)[2] = (unsigned)ov;      // the status word travels in the header, behind the completion word
+        __hip_atomic_store(overflow, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pub.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // every thread: its stores into pinned memory before the word
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(pub.host_done, pub.word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace
@@ -617,13 +651,15 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
         }
         std::memcpy(hi + o_desc, mp->desc, 32 * (size_t)n);
         std::atomic_thread_fence(std::memory_order_release);
-        if ((rc = uh::copy16(h->ctx, base + o_pos, h->h_in.dev<char>() + o_pos, o_desc + 32 * (size_t)n - o_pos))) return rc;
     }
     PmPoints P;
     P.n = n;
-    P.pos3d = (const float*)(base + o_pos); P.normal = (const float*)(base + o_nrm); P.min_dist = (const float*)(base + o_min);
-    P.max_dist = (const float*)(base + o_max); P.desc = (const uint64_t*)(base + o_desc);
-    P.octave = (const int*)(base + o_min);
+    {   // (read by the kernel where they lie, in the pinned block: every group fetches its own candidate once)
+        const char* in = h->h_in.dev<char>();
+        P.pos3d = (const float*)(in + o_pos); P.normal = (const float*)(in + o_nrm); P.min_dist = (const float*)(in + o_min);
+        P.max_dist = (const float*)(in + o_max); P.desc = (const uint64_t*)(in + o_desc);
+        P.octave = (const int*)(in + o_min);
+    }
     P.best_kp = (int*)(base + o_bk); P.best_dist = (float*)(base + o_bd); P.visible = (unsigned char*)(base + o_vis);
     PmPose ps;
     const float* T = pose_f2g;
@@ -650,15 +686,17 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
         }
         const dim3 grid(std::min(uh_div_up(n, kGroupsPerWave), kPmMaxBlocks));
         int* d_ovf = (int*)(base + o_ovf);
-        if (in_lds && !prev) UH_LAUNCH(h->ctx, (projmatch_kernel<true, false>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf);
-        else if (!prev) UH_LAUNCH(h->ctx, (projmatch_kernel<false, false>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf);
-        else if (in_lds) UH_LAUNCH(h->ctx, (projmatch_kernel<true, true>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf);
-        else UH_LAUNCH(h->ctx, (projmatch_kernel<false, true>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf);
+        const unsigned long long word = ++h->seq;
+        const PmPublish pub{reinterpret_cast<unsigned*>(base + 128), reinterpret_cast<const unsigned long long*>(base + o_bk), reinterpret_cast<unsigned long long*>(h->h_out.dev<char>() + 64),
+                            (unsigned)(out_bytes / 8), h->h_out.dev<unsigned long long>(), word};
+        if (in_lds && !prev) UH_LAUNCH(h->ctx, (projmatch_kernel<true, false>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf, pub);
+        else if (!prev) UH_LAUNCH(h->ctx, (projmatch_kernel<false, false>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf, pub);
+        else if (in_lds) UH_LAUNCH(h->ctx, (projmatch_kernel<true, true>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf, pub);
+        else UH_LAUNCH(h->ctx, (projmatch_kernel<false, true>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf, pub);
     }
     UH_HIP_CHECK(hipGetLastError());
-    // results: one workgroup copies [best_kp | best_dist | visible | overflow] into pinned memory and posts the completion word
-    const unsigned long long word = ++h->seq;
-    if ((rc = uh::publish16(h->ctx, h->h_out.dev<char>() + 64, base + o_bk, out_bytes, reinterpret_cast<unsigned*>(base + o_ovf), h->h_out.dev<unsigned long long>(), word))) return rc;
+    // results: the kernel's last workgroup copies [best_kp | best_dist | visible] and the overflow flag into pinned memory and posts the completion word
+    const unsigned long long word = h->seq;
     if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(h->h_out.host<char>()), word, st, "uh_projmatch_match"))) return rc;
     if (pm_clk) {
         long long c[8];
