@@ -34,6 +34,7 @@
 // All reductions run in a fixed order, so results are run-to-run deterministic.  MFMA is not used: the only dense algebra is
 // 6x3·3x3·3x6 products per landmark pair (fp64) — far below any matrix-core tile; see DESIGN.md.
 #include <cfloat>
+#include <functional>
 #include <cstdio>
 #include <emmintrin.h>
 #include <condition_variable>
@@ -2141,15 +2142,16 @@ __global__ void ba_init_state_kernel(BAPtrs p, BADims d, const double* __restric
 // ba_ingest_direct_kernel does that with the H2D copy folded in: the kernel reads the pinned staging block over the host link itself,
 // mirrors it into HBM (header + points as 16-byte words, observations as 24-byte records) and scatters the table cells from the
 // records it has in registers — one launch instead of a DMA + a launch.
+// (e_begin: the launch serves observations [e_begin, E) — uh_ba_set_problem sends the records in two halves, the first while it still packs the second)
 __global__ __launch_bounds__(256) void ba_ingest_direct_kernel(const unsigned char* __restrict__ host, unsigned char* __restrict__ dev, size_t head_bytes, size_t obs_off,
-                                                               int E, int P, int K, unsigned* __restrict__ T, unsigned tseq, unsigned* err, int head_blocks, int obs16) {
+                                                               int E, int P, int K, unsigned* __restrict__ T, unsigned tseq, unsigned* err, int head_blocks, int obs16, int e_begin) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     if ((int)blockIdx.x < head_blocks) {   // header + frame arrays + points: [0, head_bytes), a multiple of 16
         const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
         if (i < head_bytes) *reinterpret_cast<u32x4*>(dev + i) = *reinterpret_cast<const u32x4*>(host + i);
         return;
     }
-    const int e = ((int)blockIdx.x - head_blocks) * 256 + threadIdx.x;
+    const int e = e_begin + ((int)blockIdx.x - head_blocks) * 256 + threadIdx.x;
     if (e >= E) return;
     int pt, kf;
     if (obs16) {   // 16-byte records: a third fewer bytes over the host link, which is what this kernel's time is made of
@@ -2909,7 +2911,11 @@ static PersistPlan plan_persistent(uh_ba* b, int K, int P, int E, int nfree) {
 
 // setParams of the persistent form on a filled staging block: header on the host (K-sized), ONE H2D copy, the ingest kernel.
 // No host-built table, no stream synchronisation; every device buffer is kept across problems.
-static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl, bool obs16 = false) {
+// pack(e0, e1, as16, exact, oob): writes observation records [e0, e1) (e0 even) into the staging block in the 16- or 24-byte form; clears `exact`
+// when a scalar does not survive the 16-byte form, sets `oob` on an index out of range.  NULL: the records are in the block already (24-byte form
+// unless obs16).  With a packer the records leave in TWO ingest launches, the first running over the host link while the second half is packed.
+using ObsPacker = std::function<void(int, int, bool, bool&, unsigned&)>;
+static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl, bool obs16 = false, const ObsPacker* pack = nullptr, unsigned* oob_out = nullptr) {
     const StageLayout& L = b->slay;
     unsigned char* hs = b->h_stage;
     const float* poses = reinterpret_cast<const float*>(hs + L.poses_in);
@@ -2952,7 +2958,7 @@ static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl
     }
     ++b->tseq;
     b->problem_stage_gen = b->stage_gen;
-    const unsigned tseq = (b->tseq & 0xFFFu) << 20;
+    unsigned tseq = (b->tseq & 0xFFFu) << 20;
     if (!b->dscratch.p) {
         if ((rc = b->dscratch.reserve(1024))) return rc;
         UH_HIP_CHECK(hipMemsetAsync(b->dscratch.p, 0, b->dscratch.cap, st));
@@ -2973,13 +2979,41 @@ static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl
     void* d_pin = nullptr;
     UH_HIP_CHECK(hipHostGetDevicePointer(&d_pin, b->h_stop, 0));
     unsigned* d_err = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(d_pin) + 200);
-    {   // the kernel fetches the staging block over the host link itself: one launch, no DMA (the DMA + ingest-launch pair it replaced —
+    {   // the kernel fetches the staging block over the host link itself: no DMA (the DMA + ingest-launch pair it replaced —
         // 0.588 against 0.574-0.581 ms per step — was kept behind UH_BA_INGEST=copy until round 5)
         void* d_hs = nullptr;
         UH_HIP_CHECK(hipHostGetDevicePointer(&d_hs, hs, 0));
         const int head_blocks = uh_div_up((int)(L.obs / 16), 256);
-        UH_LAUNCH(b->ctx, ba_ingest_direct_kernel, dim3(head_blocks + uh_div_up(std::max(E, 1), 256)), dim3(256), 0, static_cast<const unsigned char*>(d_hs),
-                  reinterpret_cast<unsigned char*>(db), L.obs, L.obs, E, P, K, b->dT.as<unsigned>(), tseq, d_err, head_blocks, obs16 ? 1 : 0);
+        auto ingest = [&](bool head, int e0, int e1, bool as16, unsigned seq) {
+            UH_LAUNCH(b->ctx, ba_ingest_direct_kernel, dim3((head ? head_blocks : 0) + uh_div_up(std::max(e1 - e0, 1), 256)), dim3(256), 0, static_cast<const unsigned char*>(d_hs),
+                      reinterpret_cast<unsigned char*>(db), L.obs, L.obs, e1, P, K, b->dT.as<unsigned>(), seq, d_err, head ? head_blocks : 0, as16 ? 1 : 0, e0);
+        };
+        if (!pack) ingest(true, 0, E, obs16, tseq);
+        else {
+            // two halves: the first half's records cross the host link (~25 GB/s: 10 us) while the host packs the second (round 5; one launch
+            // behind the whole packing loop put its 21 us in front of the optimisation)
+            const int mid = E >= 4096 ? (E / 2) & ~1 : E;
+            bool exact = true;
+            unsigned oob = 0;
+            (*pack)(0, mid, obs16, exact, oob);
+            if (obs16 && !exact) { obs16 = false; exact = true; (*pack)(0, mid, false, exact, oob); }
+            if (!oob) ingest(true, 0, mid, obs16, tseq);
+            if (mid < E && !oob) {
+                (*pack)(mid, E, obs16, exact, oob);
+                if (obs16 && !exact) {   // the second half does not fit the 16-byte form: everything again as 24-byte records, under a new table sequence
+                    obs16 = false; exact = true;
+                    UH_HIP_CHECK(hipStreamSynchronize(st));   // (the first half's launch still reads the 16-byte records this pass overwrites; rare path)
+                    h_err[0] = 0; h_err[1] = 0;
+                    (*pack)(0, E, false, exact, oob);
+                    if ((b->tseq & 0xFFFu) == 0xFFFu) { UH_HIP_CHECK(hipMemsetAsync(b->dT.p, 0, b->dT.cap, st)); b->tseq = 0; }
+                    ++b->tseq;
+                    tseq = (b->tseq & 0xFFFu) << 20;
+                    if (!oob) ingest(true, 0, E, false, tseq);
+                } else if (!oob) ingest(false, mid, E, obs16, tseq);
+            }
+            if (oob_out) *oob_out = oob;
+            if (oob) { (void)hipStreamSynchronize(st); h_err[0] = 0; h_err[1] = 0; return UH_EINVAL; }   // (a launch of the first half may be in flight: nothing of this problem survives)
+        }
     }
     UH_HIP_CHECK(hipEventRecord(b->ev_stage, st));   // behind the last reader of the staging block
     b->stage_in_flight = true;
@@ -3082,58 +3116,54 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
     std::memcpy(b->h_stage + L.intr_f, pr->intr, 4 * (size_t)K * sizeof(float));
     if (P) std::memcpy(b->h_stage + L.points, pr->points, 3 * (size_t)P * sizeof(float));
     uh_ba_obs* ob = reinterpret_cast<uh_ba_obs*>(b->h_stage + L.obs);
-    unsigned oob = 0;
-    int e = 0;
     // The ingest kernel's time is the bytes it fetches over the host link (~25 GB/s): when every information scalar is float-exact — the
     // reference's always are, (double)(float)(1. / scaleFactor) — and the indices fit 24 + 8 bits, the records go out as 16 bytes
     // {point | frame << 24, u, v, (float)inv_sigma} instead of 24.  Tried first; an inexact scalar falls through to the 24-byte form.
-    bool obs16 = K <= 256 && P < (1 << 24) && !(getenv("UH_BA_OBS24") && atoi(getenv("UH_BA_OBS24")));
-    if (obs16) {
-        __m128i bad = _mm_setzero_si128();
-        __m128d exact = _mm_castsi128_pd(_mm_set1_epi32(-1));
+    const bool try16 = K <= 256 && P < (1 << 24) && !(getenv("UH_BA_OBS24") && atoi(getenv("UH_BA_OBS24")));
+    // structure of arrays -> records [e0, e1) (e0 even), two observations per step with 128-bit moves (this loop is most of setParams' host
+    // time: 26 000 observations, 31 us as scalar code, a third of that this way); indices checked on the way: an index is in range
+    // iff neither i nor (n - 1 - i) is negative, the sign bits are OR-ed over the range
+    const ObsPacker pack = [&](int e0, int e1, bool as16, bool& exact_out, unsigned& oob) {
         const __m128i pmax = _mm_set1_epi32(P - 1), kmax = _mm_set1_epi32(K - 1);
-        unsigned char* dst = reinterpret_cast<unsigned char*>(ob);
-        int i = 0;
-        for (; i + 2 <= E; i += 2, dst += 32) {
+        __m128i bad = _mm_setzero_si128();
+        int i = e0;
+        if (as16) {
+            __m128d exact = _mm_castsi128_pd(_mm_set1_epi32(-1));
+            unsigned char* dst = reinterpret_cast<unsigned char*>(ob) + 16 * (size_t)e0;
+            for (; i + 2 <= e1; i += 2, dst += 32) {
+                const __m128i pt = _mm_loadl_epi64(reinterpret_cast<const __m128i*>(pr->obs_point + i));
+                const __m128i kf = _mm_loadl_epi64(reinterpret_cast<const __m128i*>(pr->obs_frame + i));
+                const __m128 uv = _mm_loadu_ps(pr->obs_uv + 2 * i);
+                const __m128d w = _mm_loadu_pd(pr->obs_inv_sigma + i);
+                bad = _mm_or_si128(bad, _mm_or_si128(_mm_or_si128(pt, _mm_sub_epi32(pmax, pt)), _mm_or_si128(kf, _mm_sub_epi32(kmax, kf))));
+                const __m128 wf = _mm_cvtpd_ps(w);                                                  // w0f w1f 0 0
+                exact = _mm_and_pd(exact, _mm_cmpeq_pd(_mm_cvtps_pd(wf), w));
+                const __m128i pk = _mm_or_si128(pt, _mm_slli_epi32(kf, 24));                          // p0 p1 0 0
+                const __m128 a = _mm_castsi128_ps(_mm_unpacklo_epi32(pk, _mm_castps_si128(wf)));     // p0 w0 p1 w1
+                const __m128i r0 = _mm_shuffle_epi32(_mm_castps_si128(_mm_shuffle_ps(a, uv, _MM_SHUFFLE(1, 0, 1, 0))), _MM_SHUFFLE(1, 3, 2, 0));   // p0 u0 v0 w0
+                const __m128i r1 = _mm_shuffle_epi32(_mm_castps_si128(_mm_shuffle_ps(a, uv, _MM_SHUFFLE(3, 2, 3, 2))), _MM_SHUFFLE(1, 3, 2, 0));   // p1 u1 v1 w1
+                _mm_storeu_si128(reinterpret_cast<__m128i*>(dst), r0);
+                _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + 16), r1);
+            }
+            bool ok = _mm_movemask_pd(exact) == 3;
+            oob |= (unsigned)_mm_movemask_ps(_mm_castsi128_ps(bad)) & 3u;
+            for (; i < e1; i++, dst += 16) {
+                const int pt = pr->obs_point[i], kf = pr->obs_frame[i];
+                oob |= (unsigned)((unsigned)pt >= (unsigned)P) | (unsigned)((unsigned)kf >= (unsigned)K);
+                const float wf = (float)pr->obs_inv_sigma[i];
+                ok = ok && (double)wf == pr->obs_inv_sigma[i];
+                const unsigned pk = ((unsigned)pt & 0xFFFFFFu) | ((unsigned)kf << 24);
+                std::memcpy(dst, &pk, 4); std::memcpy(dst + 4, pr->obs_uv + 2 * i, 8); std::memcpy(dst + 12, &wf, 4);
+            }
+            if (!ok) exact_out = false;
+            return;
+        }
+        unsigned char* dst = reinterpret_cast<unsigned char*>(ob) + 24 * (size_t)e0;
+        for (; i + 2 <= e1; i += 2, dst += 48) {
             const __m128i pt = _mm_loadl_epi64(reinterpret_cast<const __m128i*>(pr->obs_point + i));
             const __m128i kf = _mm_loadl_epi64(reinterpret_cast<const __m128i*>(pr->obs_frame + i));
-            const __m128 uv = _mm_loadu_ps(pr->obs_uv + 2 * i);
-            const __m128d w = _mm_loadu_pd(pr->obs_inv_sigma + i);
-            bad = _mm_or_si128(bad, _mm_or_si128(_mm_or_si128(pt, _mm_sub_epi32(pmax, pt)), _mm_or_si128(kf, _mm_sub_epi32(kmax, kf))));
-            const __m128 wf = _mm_cvtpd_ps(w);                                                  // w0f w1f 0 0
-            exact = _mm_and_pd(exact, _mm_cmpeq_pd(_mm_cvtps_pd(wf), w));
-            const __m128i pk = _mm_or_si128(pt, _mm_slli_epi32(kf, 24));                          // p0 p1 0 0
-            const __m128 a = _mm_castsi128_ps(_mm_unpacklo_epi32(pk, _mm_castps_si128(wf)));     // p0 w0 p1 w1
-            const __m128i r0 = _mm_shuffle_epi32(_mm_castps_si128(_mm_shuffle_ps(a, uv, _MM_SHUFFLE(1, 0, 1, 0))), _MM_SHUFFLE(1, 3, 2, 0));   // p0 u0 v0 w0
-            const __m128i r1 = _mm_shuffle_epi32(_mm_castps_si128(_mm_shuffle_ps(a, uv, _MM_SHUFFLE(3, 2, 3, 2))), _MM_SHUFFLE(1, 3, 2, 0));   // p1 u1 v1 w1
-            _mm_storeu_si128(reinterpret_cast<__m128i*>(dst), r0);
-            _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + 16), r1);
-        }
-        bool ok = _mm_movemask_pd(exact) == 3;
-        oob = (unsigned)_mm_movemask_ps(_mm_castsi128_ps(bad)) & 3u;
-        for (; i < E; i++, dst += 16) {
-            const int pt = pr->obs_point[i], kf = pr->obs_frame[i];
-            oob |= (unsigned)((unsigned)pt >= (unsigned)P) | (unsigned)((unsigned)kf >= (unsigned)K);
-            const float wf = (float)pr->obs_inv_sigma[i];
-            ok = ok && (double)wf == pr->obs_inv_sigma[i];
-            const unsigned pk = ((unsigned)pt & 0xFFFFFFu) | ((unsigned)kf << 24);
-            std::memcpy(dst, &pk, 4); std::memcpy(dst + 4, pr->obs_uv + 2 * i, 8); std::memcpy(dst + 12, &wf, 4);
-        }
-        obs16 = ok && !oob;   // (an index out of range may not survive the 24 + 8 bit packing: report it from the 24-byte pass below)
-        if (obs16) e = E;
-        else oob = 0;
-    }
-    if (!obs16) {   // structure of arrays -> 24-byte records, two observations per step with 128-bit moves (this loop is most of setParams' host
-        // time: 26 000 observations, 31 us as scalar code, a third of that this way); indices checked on the way: an index is in range
-        // iff neither i nor (n - 1 - i) is negative, the sign bits are OR-ed over the whole array
-        __m128i bad = _mm_setzero_si128();
-        const __m128i pmax = _mm_set1_epi32(P - 1), kmax = _mm_set1_epi32(K - 1);
-        unsigned char* dst = reinterpret_cast<unsigned char*>(ob);
-        for (; e + 2 <= E; e += 2, dst += 48) {
-            const __m128i pt = _mm_loadl_epi64(reinterpret_cast<const __m128i*>(pr->obs_point + e));
-            const __m128i kf = _mm_loadl_epi64(reinterpret_cast<const __m128i*>(pr->obs_frame + e));
-            const __m128i uv = _mm_loadu_si128(reinterpret_cast<const __m128i*>(pr->obs_uv + 2 * e));
-            const __m128i w = _mm_loadu_si128(reinterpret_cast<const __m128i*>(pr->obs_inv_sigma + e));
+            const __m128i uv = _mm_loadu_si128(reinterpret_cast<const __m128i*>(pr->obs_uv + 2 * i));
+            const __m128i w = _mm_loadu_si128(reinterpret_cast<const __m128i*>(pr->obs_inv_sigma + i));
             bad = _mm_or_si128(bad, _mm_or_si128(_mm_or_si128(pt, _mm_sub_epi32(pmax, pt)), _mm_or_si128(kf, _mm_sub_epi32(kmax, kf))));
             const __m128i pk = _mm_unpacklo_epi32(pt, kf);                                            // pt0 kf0 pt1 kf1
             _mm_storeu_si128(reinterpret_cast<__m128i*>(dst), _mm_unpacklo_epi64(pk, uv));           // pt0 kf0 u0 v0
@@ -3141,18 +3171,20 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
             _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + 24), _mm_unpackhi_epi64(pk, uv));      // pt1 kf1 u1 v1
             _mm_storel_epi64(reinterpret_cast<__m128i*>(dst + 40), _mm_unpackhi_epi64(w, w));        // w1
         }
-        oob = (unsigned)_mm_movemask_ps(_mm_castsi128_ps(bad)) & 3u;   // (lanes 0, 1 hold the two observations; 2, 3 were zero-filled loads)
-    }
-    for (; e < E; e++) {
-        const int pt = pr->obs_point[e], kf = pr->obs_frame[e];
-        oob |= (unsigned)((unsigned)pt >= (unsigned)P) | (unsigned)((unsigned)kf >= (unsigned)K);
-        ob[e].point = pt; ob[e].frame = kf; ob[e].u = pr->obs_uv[2 * e]; ob[e].v = pr->obs_uv[2 * e + 1]; ob[e].inv_sigma = pr->obs_inv_sigma[e];
-    }
-    if (oob)
+        oob |= (unsigned)_mm_movemask_ps(_mm_castsi128_ps(bad)) & 3u;   // (lanes 0, 1 hold the two observations; 2, 3 were zero-filled loads)
+        for (; i < e1; i++) {
+            const int pt = pr->obs_point[i], kf = pr->obs_frame[i];
+            oob |= (unsigned)((unsigned)pt >= (unsigned)P) | (unsigned)((unsigned)kf >= (unsigned)K);
+            ob[i].point = pt; ob[i].frame = kf; ob[i].u = pr->obs_uv[2 * i]; ob[i].v = pr->obs_uv[2 * i + 1]; ob[i].inv_sigma = pr->obs_inv_sigma[i];
+        }
+    };
+    unsigned oob = 0;
+    rc = set_problem_fast(b, K, P, E, pl, try16, &pack, &oob);
+    if (oob)   // (an index out of range may not survive the 24 + 8 bit packing: found by the packer, named here)
         for (int e = 0; e < E; e++)
             UH_REQUIRE(pr->obs_point[e] >= 0 && pr->obs_point[e] < P && pr->obs_frame[e] >= 0 && pr->obs_frame[e] < K,
                        "uh_ba_set_problem: observation %d references point %d / frame %d out of range", e, pr->obs_point[e], pr->obs_frame[e]);
-    return set_problem_fast(b, K, P, E, pl, obs16);
+    return rc;
 }
 
 int uh_ba_map_staging(uh_ba* b, int n_frames, int n_points, int max_obs, uh_ba_staging* out) {
