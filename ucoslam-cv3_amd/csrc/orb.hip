@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void cell_nms_kernel(const Plan plan, const Ce
                                                        int* __restrict__ cell_counts /* [frame][cell][2] */, int tile_bytes) {
     __shared__ int s_wave[4];
     __shared__ int s_base, s_n20;
-    const int cell = blockIdx.x, frame = blockIdx.y;
+    const int cell = blockIdx.y, frame = blockIdx.x;   // frame fastest: with a batch of 8 one frame's cells (and their halos) share one XCD's L2 (describe_kernel)
     int lvl = 0;
     while (lvl + 1 < plan.nlevels && cell >= plan.lv[lvl + 1].cell_begin) ++lvl;
     const LevelDesc& L = plan.lv[lvl];
@@ -1040,10 +1040,13 @@ __global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const ui
                                                        size_t sel_frame_stride, const int* __restrict__ level_counts,
                                                        KeyPointOut* __restrict__ kps, uint8_t* __restrict__ desc,
                                                        int cap_per_frame, int* __restrict__ frame_counts, int class_id,
-                                                       const CamModel cam, float* __restrict__ und) {
-    const int frame = blockIdx.y;
+                                                       const CamModel cam, float* __restrict__ und, int batch) {
+    // 1-D grid, frame fastest: consecutive workgroups go to consecutive XCDs, so with a batch of 8 (or any multiple / divisor of 8) one
+    // frame's pyramid is pulled into ONE XCD's L2 instead of all eight (2-D grid, round 1-4: FETCH_SIZE x2 22.7 MB per 8-frame launch
+    // against 7.6 MB of blurred pyramid; profiles/r05_fetch_size_calibration.json for the counter's meaning on byte gathers)
+    const int frame = blockIdx.x % batch, bx = blockIdx.x / batch;
     const int lane = threadIdx.x & 63;
-    const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int slot = __builtin_amdgcn_readfirstlane(bx * 4 + (threadIdx.x >> 6));
     const int* lc = level_counts + (size_t)frame * kMaxLevels;
     int total = 0;
     for (int l = 0; l < plan.nlevels; l++) total += lc[l];
@@ -1057,7 +1060,7 @@ __global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const ui
     if (slot < limit) describe_slot(plan, pyr, frame_stride, sel, sel_frame_stride, lc, &s_kp[wv], s_desc[wv], class_id, frame, lane, slot);
     __syncthreads();
     {
-        const int slot0 = blockIdx.x * 4, nvalid = min(max(limit - slot0, 0), 4);
+        const int slot0 = bx * 4, nvalid = min(max(limit - slot0, 0), 4);
         const size_t o = (size_t)frame * cap_per_frame + slot0;
         const int t = threadIdx.x;
         if (t < 2 * nvalid) reinterpret_cast<uint4*>(desc + o * 32)[t] = reinterpret_cast<const uint4*>(&s_desc[0][0])[t];
@@ -1477,11 +1480,11 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
     }
     if (P.total_cells > 0) {
         if (o->fuse_fast) {
-            UH_LAUNCH(o->ctx,cell_nms_kernel<true>, dim3(P.total_cells, batch), dim3(256), (size_t)o->nms_lds_bytes, P, o->d_cells.as<CellDesc>(),
+            UH_LAUNCH(o->ctx,cell_nms_kernel<true>, dim3(batch, P.total_cells), dim3(256), (size_t)o->nms_lds_bytes, P, o->d_cells.as<CellDesc>(),
                                (const uint8_t*)pyr, o->frame_stride, o->d_cand.as<uint32_t>(), o->cand_stride, o->d_cell_counts.as<int>(),
                                o->nms_tile_bytes);
         } else {
-            UH_LAUNCH(o->ctx,cell_nms_kernel<false>, dim3(P.total_cells, batch), dim3(256), 0, P, o->d_cells.as<CellDesc>(),
+            UH_LAUNCH(o->ctx,cell_nms_kernel<false>, dim3(batch, P.total_cells), dim3(256), 0, P, o->d_cells.as<CellDesc>(),
                                (const uint8_t*)o->d_score.as<uint8_t>(), o->frame_stride, o->d_cand.as<uint32_t>(), o->cand_stride,
                                o->d_cell_counts.as<int>(), 0);
         }
@@ -1500,9 +1503,9 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
         UH_LAUNCH(o->ctx,nonmax_kernel, dim3(P.nlevels, batch), dim3(64), lds, P, o->d_sel.as<uint32_t>(), o->sel_stride, o->d_level_counts.as<int>());
     }
     const int slots = std::min(std::max(P.maxFeatures, 1), std::max(cap_per_frame, 1));
-    UH_LAUNCH(o->ctx,describe_kernel, dim3(uh_div_up(slots, 4), batch), dim3(256), 0, P, pyr, o->frame_stride,
+    UH_LAUNCH(o->ctx,describe_kernel, dim3(uh_div_up(slots, 4) * batch), dim3(256), 0, P, pyr, o->frame_stride,
                        o->d_sel.as<uint32_t>(), o->sel_stride, o->d_level_counts.as<int>(), d_kps, d_desc, cap_per_frame,
-                       d_counts, o->nonmaxima ? 1 : -1, o->cam, o->cam.on ? d_und : nullptr);
+                       d_counts, o->nonmaxima ? 1 : -1, o->cam, o->cam.on ? d_und : nullptr, batch);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
 }
