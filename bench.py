@@ -238,7 +238,7 @@ def main():
     roofline = None
     stage_ms = {}
     if rank == 0 and args.quick:
-        print(json.dumps({"value": round(value, 1), "ms_per_step": round(ms_per_step, 4), "ms_per_step_min": round(ms_min, 4), "ms_per_step_max": round(ms_max, 4), "reps": len(reps_s), "knn_qpw": args.knn_qpw, "knn_form": os.environ.get("UH_KNN_FORM", "auto (accept-list forms from 3000 queries)")}), flush=True)
+        print(json.dumps({"value": round(value, 1), "ms_per_step": round(ms_per_step, 4), "ms_per_step_min": round(ms_min, 4), "ms_per_step_max": round(ms_max, 4), "reps": len(reps_s), "knn_qpw": args.knn_qpw, "knn_form": os.environ.get("UH_KNN_FORM", "auto (nn >= 6: scan + replay in one launch)")}), flush=True)
         return
     if rank == 0:
         def timed(fn, reps):

@@ -43,6 +43,11 @@ constexpr int kMaxShards = 64;
 struct ShardBounds { int n; int b[kMaxShards + 1]; };
 
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// compile-time loop: every index inside f is a constant (register arrays stay in registers)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
 
 // Lane-distributed ResultSet: lane j holds heap slot j.  A push is BRANCH-FREE VECTOR CODE with a short dependent chain
 // of cross-lane operations (the latency of those, not ALU work, is what a push costs):
@@ -316,7 +321,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void knn_search_kernel(
 // (uh_knn_scan_shard_dev): row-major [query][cap] words dist << 32 | global row, EXACTLY the rows the reference's heap would accept
 // on this tile (the serial walk over a step's passing lanes applies the tightened threshold before listing a row), in row order.
 enum : int { kScanTwoLaunch = 0, kScanStream = 1, kScanShard = 2 };
-template <int QPW, int MODE>
+constexpr int kVecStepMin = 4;   // passing rows of a 64-row step from which the step is decided for all rows at once (accept_scan::feed_vec)
+template <int QPW, int MODE, int DEPTH = 2>
 __device__ __forceinline__ void accept_scan(
     const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int k, int maxd,
     uint64_t* __restrict__ cand, int32_t* __restrict__ counts, int cap, int wave, uint64_t* __restrict__ prog, unsigned tag) {
@@ -366,10 +372,88 @@ __device__ __forceinline__ void accept_scan(
     // The first step of a scan is taken row by row, exactly as the reference accepts (its 64 rows all lie below the initial threshold:
     // emitting them wholesale made every list 64 - k (1 + ln(64 / k)) entries longer); afterwards all rows below the threshold at the
     // start of the step are appended at once, then the threshold is tightened with them.
+    // A step with MANY rows below the threshold — the first steps of a scan: 64, ~17, ~12, ~9 ... of the step's 64 rows pass, half of all
+    // the pushes of a query fall into its first 256 rows — is decided for all its rows at once instead of one serial walk iteration (~40
+    // dependent instructions) per passing row.  Row i is accepted (resultset.h:66-69, dist < worst) iff fewer than k of ALL earlier rows are
+    // <= d_i; of those only the k smallest so far (sv) and the step's own earlier passing rows can be that small, so with
+    // e_i = #{passing l < i : d_l <= d_i} the test is sv[k - 1 - e_i] > d_i (sv ascending): one short loop over the passing lanes that
+    // counts e (a readlane, two compares, an add), one ds_bpermute.  The list gets EXACTLY the accepted rows, in row order (the serial walk
+    // of the stream form lists every passing row: entries the replay only rejects); the threshold is tightened with the accepted
+    // distances.  Stream form: the accepted words are compacted along the lanes (one ds_permute: accepted lanes to their list slots, the
+    // others behind them — a permutation, no two lanes push to one slot) and leave as whole records, one 16-byte store per LANE.
+    // FIRST mode — the first step of a scan (empty list, no threshold yet; 64 serial walk iterations of ~200 clocks each were 10 us of a
+    // 48 us scan wave, two queries per wave): e and the full rank of every row come from 63 + 63 wave shifts (v_mov_dpp wave_shr:1 /
+    // wave_shl:1, a compare and an add-with-carry each — no scalar instruction in the chain), the 64 distances are SORTED by one
+    // ds_permute (rank -> lane) and the k smallest replicated into the four rows of sv.
+    auto feed_vec = [&](int j, int d, int idx, bool pass, uint64_t m, int qj, bool first) -> bool {
+        int e = 0;
+        if (first) {
+            const int key = pass ? d : 0x7ffffffe;   // (one below the shifts' fill value: a vacated lane never counts, rows that do not pass tie among themselves)
+            int sh = key, rk = 0;
+#pragma nounroll   // (unrolled — even partly: the compiler finishes the job — the scheduler hoists the 63 shifts and the kernel needs 179 registers)
+            for (int t = 1; t < kWave; ++t) {
+                sh = __builtin_amdgcn_update_dpp(0x7fffffff, sh, 0x138, 0xF, 0xF, false);   // wave_shr:1: lane i <- lane i - 1 (lane 0 keeps "nothing")
+                e += sh <= key ? 1 : 0;
+            }
+            sh = key;
+#pragma nounroll
+            for (int t = 1; t < kWave; ++t) {
+                sh = __builtin_amdgcn_update_dpp(0x7fffffff, sh, 0x130, 0xF, 0xF, false);   // wave_shl:1: lane i <- lane i + 1
+                rk += sh < key ? 1 : 0;
+            }
+            rk += e;   // rows before i that are <= d_i + rows behind i that are < d_i: a permutation of 0 .. 63 (rows that do not pass sort last, in row order)
+            const int sorted = __builtin_amdgcn_ds_permute(rk << 2, key);
+            const int s16 = __builtin_amdgcn_ds_bpermute((lane & 15) << 2, sorted);
+            sv[j] = s16 >= 0x7ffffffe ? 0x7fffffff : s16;
+        } else {
+            for (uint64_t mm = m; mm;) {
+                const int l = __builtin_ctzll(mm);
+                mm &= mm - 1;
+                const int dl = rl(d, l);
+                e += (dl <= d && l < lane) ? 1 : 0;
+            }
+        }
+        const int kth = first ? 0x7fffffff : __builtin_amdgcn_ds_bpermute(max(k - 1 - e, 0) << 2, sv[j]);   // (lane r of every 16-lane row of sv = the r-th smallest)
+        const bool acc = pass && e < k && d < kth;
+        const uint64_t ma = __ballot(acc);
+        const int na = __popcll(ma), base = nc[j];
+        const int posl = __popcll(ma & lt);
+        if constexpr (STREAM) {
+            const int odd = base & 1, tot = na + odd;
+            if (tot > kWave || base + na > cap) return false;   // (left to the serial walk: a list about to overflow; 64 accepted rows behind a pending entry)
+            const unsigned w = ((unsigned)d << 23) | (unsigned)idx;
+            const int slot = acc ? posl + odd : tot + __popcll(~ma & lt);   // (with a pending entry the last of the others wraps to slot 0, which is the pending entry's)
+            unsigned c = (unsigned)__builtin_amdgcn_ds_permute((slot & (kWave - 1)) << 2, (int)w);
+            if (odd && lane == 0) c = pend[j];
+            const unsigned w0 = (unsigned)__builtin_amdgcn_ds_bpermute((2 * lane) << 2, (int)c);
+            const unsigned w1 = (unsigned)__builtin_amdgcn_ds_bpermute((2 * lane + 1) << 2, (int)c);
+            if (lane < (tot >> 1)) {
+                const st_u32x4 rec = {w0, tag, w1, tag};
+                __builtin_amdgcn_raw_buffer_store_b128(rec, rs_rec, (int)(((size_t)((base >> 1) + lane) * nq + qj) * 16), 0, 16);
+            }
+            if (tot & 1) pend[j] = (unsigned)rl((int)c, tot - 1);
+        } else if constexpr (SHARD) {
+            if (acc && base + posl < cap) cand[(size_t)qj * cap + base + posl] = ((uint64_t)(uint32_t)d << 32) | (uint32_t)idx;
+        } else {
+            if (acc && base + posl < cap) put((size_t)(base + posl) * nq + qj, d, idx);
+        }
+        nc[j] = base + na;
+        if (!first)
+            for (uint64_t mm = ma; mm;) {
+                const int l = __builtin_ctzll(mm);
+                mm &= mm - 1;
+                const int dl = rl(d, l);
+                const int left = __builtin_amdgcn_update_dpp(0, sv[j], 0x111, 0xF, 0xF, false);
+                sv[j] = sv[j] > dl ? max(left, dl) : sv[j];
+            }
+        thr[j] = rl(sv[j], k - 1);
+        return true;
+    };
     auto feed = [&](int j, int d, int idx, bool valid, int qj, bool exact) {
         const bool pass = valid && (maxd < 0 || d <= maxd) && d < thr[j];
         uint64_t m = __ballot(pass);
         if (!m) return;
+        if (__popcll(m) >= kVecStepMin && feed_vec(j, d, idx, pass, m, qj, exact && nc[j] == 0)) return;
         if (exact) {
             while (m) {
                 const int l = __builtin_ctzll(m);
@@ -429,16 +513,23 @@ __device__ __forceinline__ void accept_scan(
             for (int u = 0; u < UNROLL; ++u) feed(j, d[u], b + u * kWave + lane, q0 + j < nq, q0 + j < nq ? q0 + j : 0, u == 0 && b == t0);
         }
     };
-    {
-        uint4 a0[UNROLL], a1[UNROLL], b0[UNROLL], b1[UNROLL];
-        if (base + G <= t1) fetch(base, a0, a1);
-        for (; base + 2 * G <= t1; base += 2 * G) {
-            fetch(base + G, b0, b1);
-            score(base, a0, a1);
-            fetch(min(base + 2 * G, t1 - G), a0, a1);   // (clamped: the wave-uniform part of the address is not bounds-checked)
-            score(base + G, b0, b1);
+    // DEPTH groups of 256 rows rotate: while one is scored the loads of the next DEPTH - 1 are in flight.  Two buffers (rounds 2-4) hide an
+    // L2 round trip only behind ANOTHER wave's work: with one scan wave per SIMD (one frame's 2000 queries) a group took ~2900 clocks for
+    // ~800 of arithmetic — the wide-register form of the stream kernel rotates four (128 registers of loads).
+    if (const int ng = (t1 - base) / G; ng > 0) {
+        uint4 x0[DEPTH][UNROLL], x1[DEPTH][UNROLL];
+        auto gaddr = [&](int g) { return t0 + min(g, ng - 1) * G; };   // (clamped: the wave-uniform part of the address is not bounds-checked)
+        static_for<0, DEPTH - 1>([&](auto sc) { constexpr int i = decltype(sc)::value; fetch(gaddr(i), x0[i], x1[i]); });
+        int g = 0;
+        for (; g + DEPTH <= ng; g += DEPTH) {
+            static_for<0, DEPTH>([&](auto sc) {
+                constexpr int i = decltype(sc)::value, nb = (i + DEPTH - 1) % DEPTH;
+                fetch(gaddr(g + i + DEPTH - 1), x0[nb], x1[nb]);
+                score(t0 + (g + i) * G, x0[i], x1[i]);
+            });
         }
-        if (base + G <= t1) { score(base, a0, a1); base += G; }
+        static_for<0, DEPTH - 1>([&](auto sc) { constexpr int i = decltype(sc)::value; if (g + i < ng) score(t0 + (g + i) * G, x0[i], x1[i]); });
+        base = t0 + ng * G;
     }
     for (; base < t1; base += kWave) {
         const int t = base + lane;
@@ -493,10 +584,6 @@ constexpr int kRpK = 16;   // the two-phase form serves k <= 16
 // ---- ResultSet in the registers of one lane (K = the search's k): resultset.h:64-135, the sequential swaps of the reference.
 // Every index below is a compile-time constant (static_for / template recursion, not unrolled loops with early exits): one index the
 // optimiser cannot fold sends the whole heap to scratch memory.
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
 // An entry is ONE 32-bit word, distance << 23 | row index (distance <= 256, fewer than 2^23 rows — the host checks): every move of the
 // sifts is one select instead of two.  The heap orders by distance alone (ties never move an entry): d(a) < d(b) <=> a < (b & kDistMask).
 constexpr unsigned kDistMask = 0xFF800000u;
@@ -654,8 +741,21 @@ __device__ __forceinline__ void replay_staged(unsigned (&hw)[K], int& size, cons
             const unsigned cw = nxt;
             ++u;
             nxt = stage[min(u, steps - 1) * kWave];
-            const bool acc = cw != kNoEntry && (size < K || dist_less(cw, hw[0]));
-            if (__ballot(acc)) heap_push_wave<K>(hw, size, acc, cw);
+            // the first K entries of the lists, all live lanes in step (the first round of a replay wave: every list opens with the ~28 rows
+            // its scan accepts among the first 64): the append slot is the same constant in every lane — a 3-step climb instead of the
+            // select chains of the general form (~165 instructions per entry, 4 us per wave for K = 10)
+            const unsigned long long lv = __ballot(live);
+            const int s0 = lv ? rl(size, __builtin_ctzll(lv)) : K;   // (the size of the first live lane)
+            if (s0 < K && __ballot(live && (size != s0 || cw == kNoEntry)) == 0) {
+                static_for<0, K>([&](auto pc) {
+                    constexpr int P = decltype(pc)::value;
+                    if (s0 == P) heap_append_step<K, P>(hw, live, cw, live ? cw & kDistMask : 0u);
+                });
+                size = live ? size + 1 : size;
+            } else {
+                const bool acc = cw != kNoEntry && (size < K || dist_less(cw, hw[0]));
+                if (__ballot(acc)) heap_push_wave<K>(hw, size, acc, cw);
+            }
             if (__ballot(live && size != K) == 0) break;
         }
     }
@@ -687,21 +787,32 @@ __device__ __forceinline__ void replay_staged(unsigned (&hw)[K], int& size, cons
 // kStreamStage / 2 when the previous round filled the short fetch; all loads in flight together, none depends on another), keeps the prefix
 // of records whose two tags match, stages their entries in LDS and pushes them.
 constexpr int kStreamStage = 16;
+constexpr int kMinRec = 2;   // (0 / 1 / 2 / 3 at 2000 queries: 56.0 / 47.0 / 46.7 / 48.1 us per search)
 // a replay lane that sees no new record for this long hands its query to knn_redo_kernel (the rows stay right; only time is lost):
 // 100 ms by default (UH_KNN_STREAM_TIMEOUT_MS; round 3: 2 s) — the scan of a whole launch takes ~0.1 ms
 constexpr long long kStreamTimeoutDefault = 10000000ll;   // 100 ms of the 100 MHz wall clock
-template <int K>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5, 5))) void knn_stream_kernel(
+// W = waves per SIMD the launch is compiled for: 5 (102 registers) when the scan workgroups outnumber the chip's SIMDs several times
+// (8000 queries: 4125 workgroups, two queries per scan wave, two row groups in rotation), 2 for one frame's queries (2000 + 32
+// workgroups on 1024 SIMDs): ONE query per scan wave — twice the waves for the same arithmetic, every SIMD holds two, the serial
+// head of a scan (the first 256 rows) overlaps with the other wave's — and four row groups in rotation (128 registers of loads).
+// 2000 x 10 000, nn 10 (MI355X, HIP events, round 5): 72.3 us -> 46.7 with the first-step / lockstep / static-fill changes above and
+// this form; scan waves end at 24-38 us (were 41-57), the replay waves 7 us behind the last one (were 15).
+// The overflowed (or timed-out) queries are redone by the replay workgroups THEMSELVES once all of them have finished (a ticket per
+// workgroup; they are co-resident from the first cycle of the launch): no dependent knn_redo_kernel launch behind every search
+// (4.5 us + the launch gap, always paid, almost never needed).
+template <int K, int W>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(W, W))) void knn_stream_kernel(
     const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int sorted, int maxd,
     uint64_t* __restrict__ cand, uint64_t* __restrict__ prog, int cap, unsigned tag, int nrep,
     int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ redo_list, int* __restrict__ redo_count, int* __restrict__ redo_next,
     long long timeout_ticks) {
+    // redo_count[0] = overflowed queries of this launch, [2] = replay workgroups that have finished; redo_next likewise for the next launch
     if ((int)blockIdx.x >= nrep) {
-        accept_scan<2, kScanStream>(train, t0, t1, queries, nq, K, maxd, cand, nullptr, cap, (int)blockIdx.x - nrep, prog, tag);
+        accept_scan<(W < 5 ? 1 : 2), kScanStream, (W < 5 ? 4 : 2)>(train, t0, t1, queries, nq, K, maxd, cand, nullptr, cap, (int)blockIdx.x - nrep, prog, tag);
         return;
     }
     __shared__ unsigned s_stage[kStreamStage * kWave];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *redo_next = 0;   // the NEXT launch's overflow counter (this launch's was cleared by the previous one)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { redo_next[0] = 0; redo_next[2] = 0; }   // the NEXT launch's counters (this launch's were cleared by the previous one)
     __builtin_amdgcn_s_setprio(3);                              // a dependent chain beside throughput-bound scan waves: issue first
     const int lane = threadIdx.x & (kWave - 1);
     unsigned* stage = s_stage + lane;
@@ -719,20 +830,26 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5, 5))) v
     bool fin = !haveq, over = false;
     int deep = 0;                                          // wave-uniform: the previous round filled its short fetch -> fetch the long one
     long long tlast = wall_clock64();
-    while (__ballot(!fin) != 0) {
-        // the closing word (written once, when the query's scan ends) and the next records, all loads independent of each other
-        const uint64_t pw = __hip_atomic_load(pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ld_u32x4 v[kRec];
-        const int qv = haveq ? qi : 0;
+    // One round: the closing word (written once, when the query's scan ends) and the next records, all loads independent of each other.
+    // (Round 5 tried issuing the NEXT round's loads before pushing this round's entries: the records it sees are one round old, the rounds
+    // get smaller and more numerous — 2000 queries: 75 -> 87 us.)
+    uint64_t pw;
+    ld_u32x4 v[kRec];
+    const int qv = haveq ? qi : 0;
+    auto fetch = [&](int rr, int dp) {
+        pw = __hip_atomic_load(pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int u = 0; u < 2; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, (int)(((size_t)min(r + u, nrec_cap - 1) * nq + qv) * 16), 0, 16);   // aux 16 = sc1
-        if (deep) {
+        for (int u = 0; u < 2; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, (int)(((size_t)min(rr + u, nrec_cap - 1) * nq + qv) * 16), 0, 16);   // aux 16 = sc1
+        if (dp) {
 #pragma unroll
-            for (int u = 2; u < kRec; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, (int)(((size_t)min(r + u, nrec_cap - 1) * nq + qv) * 16), 0, 16);
+            for (int u = 2; u < kRec; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_rec, (int)(((size_t)min(rr + u, nrec_cap - 1) * nq + qv) * 16), 0, 16);
         } else {
 #pragma unroll
             for (int u = 2; u < kRec; u++) v[u] = ld_u32x4{0u, 0u, 0u, 0u};
         }
+    };
+    while (__ballot(!fin) != 0) {
+        fetch(r, deep);
         const bool closed = !fin && (unsigned)(pw >> 32) == tag && ((unsigned)pw & 0x80000000u) != 0;
         const int nc = closed ? (int)((unsigned)pw & 0x7fffffffu) : 0;
         if (closed && nc > cap) { over = true; fin = true; }
@@ -746,25 +863,50 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(5, 5))) v
             stage[(2 * u) * kWave] = run ? v[u].x : kNoEntry;
             stage[(2 * u + 1) * kWave] = run ? v[u].z : kNoEntry;
         }
-        int most = np;
+        int most = 0;   // max over the lanes of np (0 .. kRec): eight independent ballots instead of a six-deep shuffle chain
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) most = max(most, __shfl_xor(most, o));
-        most = __builtin_amdgcn_readfirstlane(most);
+        for (int c = 1; c <= kRec; c++) most = __ballot(np >= c) != 0 ? c : most;
         deep = most >= 2 ? 1 : 0;
-        if (most == 0) {
+        // The 64 queries of the wave push in LOCKSTEP: a round costs max-over-lanes steps, so rounds in which a few lanes have one or two
+        // entries each (the trickle behind the first 256 rows of a scan: ~0.4 entries per query and microsecond) made the wave take 2-3
+        // steps per entry it consumed.  A round now starts only when EVERY unfinished lane has kMinRec records waiting or all it
+        // will ever get (its scan has closed the list): the lanes then hold about the same number of entries.
+        const bool ready = fin || np >= kMinRec || (closed && r + np >= total);
+        const bool wait_more = __ballot(!ready) != 0 && most != 0;
+        if (wait_more) deep = 1;
+        if (most == 0 || wait_more) {
             if (closed && r >= total) fin = true;
             if (wall_clock64() - tlast > timeout_ticks) { over = over || !fin; fin = true; }
             if (__ballot(!fin) != 0) __builtin_amdgcn_s_sleep(2);
             continue;
         }
         tlast = wall_clock64();
+        const int rn = r + np;
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): a lane reads back only what it staged itself
         replay_staged<K>(hw, size, stage, 2 * most, !fin);
-        r += np;
+        r = rn;
         if (closed && r >= total) fin = true;
     }
     if (over) redo_list[atomicAdd(redo_count, 1)] = qi;
     heap_write_row<K>(hw, size, sorted, haveq && !over, qi, indices, distances);
+    // ---- the queries to redo (overflowed lists, time-outs), shared among the replay workgroups once ALL of them are through
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_fetch_add(redo_count + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(redo_count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nrep) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int nredo = __builtin_amdgcn_readfirstlane(__hip_atomic_load(redo_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (nredo == 0) return;
+    __builtin_amdgcn_s_setprio(0);
+    constexpr int LV = K <= 3 ? 1 : K <= 15 ? 3 : 6;   // (knn_search_kernel's heap levels for this k)
+    for (int j = blockIdx.x; j < nredo; j += nrep) {
+        const int rq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(redo_list + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        uint32_t q[8];
+        load_query(queries, rq, q);
+        WaveHeap h{0, -1, 0, lane};
+        int ncand = 0;
+        scan_range<false, LV>(h, train, t0, t1, q, K, maxd, nullptr, ncand, 0);
+        finish_row(h, K, sorted, indices, distances, rq);
+    }
 }
 
 template <int K>
@@ -1274,6 +1416,7 @@ struct uh_knn {
     // plain scan faster than the streaming one: 8000 x nn 2: 73 against 81 us).  UH_KNN_FORM=fused | twophase | stream forces one form.
     int two_phase_min_nq = 3000;
     int stream_min_nn = 6;
+    int stream_min_nq = 1;        // round 5: nn >= stream_min_nn takes the stream form at every size (2000 queries: 43 us against 74 fused, 64 queries: 33 against 61)
     unsigned replay_attr = 0;     // bit k: knn_replay_lane_kernel<k>'s dynamic-LDS attribute has been set on this index's device
     int accept_qpw = 2;           // queries per wave of the accept scan (UH_KNN_ACCEPT_QPW=1 for the A/B)
     unsigned stream_tag = 0;      // launch tag of the streamed lists (0 = the value freshly cleared memory holds, never used)
@@ -1338,7 +1481,7 @@ int uh_knn_create(uh_ctx* ctx, uh_knn** out) {
     if (const char* e = getenv("UH_KNN_FORM")) {
         const std::string f(e);
         k->split_form = f == "split";
-        if (f == "fused") k->two_phase_min_nq = 0x7fffffff;
+        if (f == "fused") k->two_phase_min_nq = k->stream_min_nq = 0x7fffffff;
         else if (f == "twophase") { k->two_phase_min_nq = 0; k->stream_min_nn = 0x7fffffff; }
         else if (f == "stream") { k->two_phase_min_nq = 0; k->stream_min_nn = 0; }
     }
@@ -1435,7 +1578,7 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
     // slower (the pushes of a wave's queries serialise), its L1/L2 traffic and its resident waves drop to 1/2 or 1/4, which is what a
     // latency-bound neighbour on another stream (the local BA) needs
     const int qpw = nn <= 15 ? idx->qpw : 1;
-    if (nn <= kRpK && nq >= idx->two_phase_min_nq && idx->shard_end <= (1 << 23)) {   // (the replay packs distance and row index into 32 bits)
+    if (nn <= kRpK && (nq >= idx->two_phase_min_nq || (nn >= idx->stream_min_nn && nq >= idx->stream_min_nq)) && idx->shard_end <= (1 << 23)) {   // (the replay packs distance and row index into 32 bits)
         // accept-list capacity: the expected number of accepted pushes is k (1 + ln(N / k)) (a record process), its spread ~ sqrt of
         // that; lists that still overflow (distances descending with the row index) are redone by knn_redo_kernel
         const int nrows = std::max(idx->shard_end - idx->shard_begin, 1);
@@ -1447,10 +1590,10 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
             uint64_t* d_cand = idx->list_buf.as<uint64_t>();
             uint64_t* d_prog = d_cand + (size_t)nq * cap;          // (list_buf holds tagged words only: any layout of an earlier launch is harmless)
             const unsigned had = idx->redo_buf.gen;
-            if ((rc = idx->redo_buf.reserve((size_t)(nq + 2) * 4))) return rc;
-            int* d_nredo = idx->redo_buf.as<int>();                // two counters (launch parity), then the compacted list of the queries to redo
-            int* d_redo = d_nredo + 2;
-            if (had != idx->redo_buf.gen) UH_HIP_CHECK(hipMemsetAsync(d_nredo, 0, 8, idx->ctx->stream));
+            if ((rc = idx->redo_buf.reserve((size_t)(nq + 4) * 4))) return rc;
+            int* d_nredo = idx->redo_buf.as<int>();                // [parity]: queries to redo, [2 + parity]: replay workgroups through; then the compacted list of the queries to redo
+            int* d_redo = d_nredo + 4;
+            if (had != idx->redo_buf.gen) UH_HIP_CHECK(hipMemsetAsync(d_nredo, 0, 16, idx->ctx->stream));
             const bool same_mem = idx->stream_buf == idx->list_buf.p && idx->stream_gen == idx->list_buf.gen;
             if (!same_mem || idx->stream_tag == 0xFFFFFFFFu) {   // new memory, or the tag wraps: no stale word may match
                 UH_HIP_CHECK(hipMemsetAsync(idx->list_buf.p, 0, idx->list_buf.cap, idx->ctx->stream));
@@ -1460,25 +1603,23 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
                 // the overflow counters are picked by tag parity and a launch clears only the NEXT launch's slot: after a tag reset the slot
                 // of the coming launch may still hold the count an earlier launch of the same parity left behind (stale query ids would
                 // be replayed by knn_redo_kernel) — clear both
-                UH_HIP_CHECK(hipMemsetAsync(d_nredo, 0, 8, idx->ctx->stream));
+                UH_HIP_CHECK(hipMemsetAsync(d_nredo, 0, 16, idx->ctx->stream));
             }
             const unsigned tag = ++idx->stream_tag;
             static const long long stream_timeout = [] { const char* e = getenv("UH_KNN_STREAM_TIMEOUT_MS"); const long long ms = e ? atoll(e) : 0; return ms > 0 ? ms * 100000ll : kStreamTimeoutDefault; }();
             const int nrep = uh_div_up(nq, kWave);
-            const dim3 gs(nrep + uh_div_up(nq, 2));
-#define UH_KNN_STREAM(K) case K: UH_LAUNCH(idx->ctx, knn_stream_kernel<K>, gs, dim3(kWave), 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, sorted ? 1 : 0, max_dist, \
-            d_cand, d_prog, cap, tag, nrep, d_indices, d_distances, d_redo, d_nredo + (tag & 1u), d_nredo + ((tag + 1u) & 1u), stream_timeout); break
+            const bool few = nrep + nq <= 2 * 4 * std::max(idx->ctx->num_cus, 64);   // at most two one-wave workgroups per SIMD with ONE query per scan wave: the wide-register form (knn_stream_kernel)
+            const dim3 gs(nrep + (few ? nq : uh_div_up(nq, 2)));
+#define UH_KNN_STREAM_W(K, W) UH_LAUNCH(idx->ctx, (knn_stream_kernel<K, W>), gs, dim3(kWave), 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, sorted ? 1 : 0, max_dist, \
+            d_cand, d_prog, cap, tag, nrep, d_indices, d_distances, d_redo, d_nredo + (tag & 1u), d_nredo + ((tag + 1u) & 1u), stream_timeout)
+#define UH_KNN_STREAM(K) case K: if (few) UH_KNN_STREAM_W(K, 2); else UH_KNN_STREAM_W(K, 5); break
             switch (nn) {
                 UH_KNN_STREAM(1); UH_KNN_STREAM(2); UH_KNN_STREAM(3); UH_KNN_STREAM(4); UH_KNN_STREAM(5); UH_KNN_STREAM(6); UH_KNN_STREAM(7); UH_KNN_STREAM(8);
                 UH_KNN_STREAM(9); UH_KNN_STREAM(10); UH_KNN_STREAM(11); UH_KNN_STREAM(12); UH_KNN_STREAM(13); UH_KNN_STREAM(14); UH_KNN_STREAM(15); UH_KNN_STREAM(16);
                 default: break;
             }
 #undef UH_KNN_STREAM
-            const dim3 gd(64);
-            const int* nr = d_nredo + (tag & 1u);
-            if (nn <= 3) UH_LAUNCH(idx->ctx, knn_redo_kernel<1>, gd, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo, nr);
-            else if (nn <= 15) UH_LAUNCH(idx->ctx, knn_redo_kernel<3>, gd, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo, nr);
-            else UH_LAUNCH(idx->ctx, knn_redo_kernel<6>, gd, block, 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nn, sorted ? 1 : 0, max_dist, d_indices, d_distances, (const int*)d_redo, nr);
+#undef UH_KNN_STREAM_W
             UH_HIP_CHECK(hipGetLastError());
             return UH_OK;
         }

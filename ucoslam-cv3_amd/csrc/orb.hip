@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void cell_nms_kernel(const Plan plan, const Ce
                                                        int* __restrict__ cell_counts /* [frame][cell][2] */, int tile_bytes) {
     __shared__ int s_wave[4];
     __shared__ int s_base, s_n20;
-    const int cell = blockIdx.y, frame = blockIdx.x;   // frame fastest: with a batch of 8 one frame's cells (and their halos) share one XCD's L2 (describe_kernel)
+    const int cell = blockIdx.y, frame = blockIdx.x;   // frame fastest: with a batch of 4 one frame's cells (and their halos) share two XCDs' L2s, with 8 one (describe_kernel)
     int lvl = 0;
     while (lvl + 1 < plan.nlevels && cell >= plan.lv[lvl + 1].cell_begin) ++lvl;
     const LevelDesc& L = plan.lv[lvl];
@@ -1041,8 +1041,8 @@ __global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const ui
                                                        KeyPointOut* __restrict__ kps, uint8_t* __restrict__ desc,
                                                        int cap_per_frame, int* __restrict__ frame_counts, int class_id,
                                                        const CamModel cam, float* __restrict__ und, int batch) {
-    // 1-D grid, frame fastest: consecutive workgroups go to consecutive XCDs, so with a batch of 8 (or any multiple / divisor of 8) one
-    // frame's pyramid is pulled into ONE XCD's L2 instead of all eight (2-D grid, round 1-4: FETCH_SIZE x2 22.7 MB per 8-frame launch
+    // 1-D grid, frame fastest: consecutive workgroups go to consecutive XCDs, so with a batch of 8 one frame's pyramid is pulled into ONE
+    // XCD's L2 (batch 4, the bench step: two) instead of all eight (2-D grid, round 1-4: FETCH_SIZE x2 22.7 MB per 4-frame launch
     // against 7.6 MB of blurred pyramid; profiles/r05_fetch_size_calibration.json for the counter's meaning on byte gathers)
     const int frame = blockIdx.x % batch, bx = blockIdx.x / batch;
     const int lane = threadIdx.x & 63;
