@@ -14,6 +14,8 @@ python scripts/fuzz_parity.py 300 ba 2>&1 | grep -v "^/opt" > $O/fuzz_ba.txt
 python scripts/ba_stress.py 60 2>&1 | grep -v "^/opt" | tail -5 > $O/ba_stress.txt
 python scripts/ba_window_sweep.py 2>&1 | grep -v "^/opt" > $O/ba_window_sweep.txt
 python scripts/time_pnp.py 2>&1 | grep -v "^/opt" > $O/time_pnp.txt
+(UH_KNN_FORM=fused python scripts/knn_nq_sweep.py; python scripts/knn_nq_sweep.py) 2>&1 | grep -E "^fused|^default" > $O/knn_nq_sweep.txt
+bash scripts/knn_pmc_r05.sh 2>&1 | grep -E "^8000|^2000" > $O/knn_pmc.txt
 python bench.py > $O/bench.json 2> $O/bench.err
 bash scripts/collect_profiles_r05.sh > $O/collect.log 2>&1
 find $R/gpurun_out/prof_r05 -name "*kernel_trace.csv" -delete
