@@ -800,19 +800,27 @@ constexpr long long kStreamTimeoutDefault = 10000000ll;   // 100 ms of the 100 M
 // The overflowed (or timed-out) queries are redone by the replay workgroups THEMSELVES once all of them have finished (a ticket per
 // workgroup; they are co-resident from the first cycle of the launch): no dependent knn_redo_kernel launch behind every search
 // (4.5 us + the launch gap, always paid, almost never needed).
+// Host form (uh_knn_search with pinned result arrays): the replay workgroups copy the finished rows to the host arrays themselves — 16 bytes
+// per lane and store: a row written where it is produced would be ten 4-byte PCIe writes — and the last of them posts the completion word
+// (projmatch.hip's PmPublish): one launch instead of search + two copies + word.
+struct KnnHostOut {
+    int32_t* host_idx; int32_t* host_dist; unsigned n16;          // pinned twins of `indices` / `distances`, 16-byte units per array
+    unsigned long long* host_done; unsigned long long word;      // pinned completion word (NULL: device form)
+};
 template <int K, int W>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(W, W))) void knn_stream_kernel(
     const uint8_t* __restrict__ train, int t0, int t1, const uint8_t* __restrict__ queries, int nq, int sorted, int maxd,
     uint64_t* __restrict__ cand, uint64_t* __restrict__ prog, int cap, unsigned tag, int nrep,
     int32_t* __restrict__ indices, int32_t* __restrict__ distances, int* __restrict__ redo_list, int* __restrict__ redo_count, int* __restrict__ redo_next,
-    long long timeout_ticks) {
-    // redo_count[0] = overflowed queries of this launch, [2] = replay workgroups that have finished; redo_next likewise for the next launch
+    long long timeout_ticks, KnnHostOut ho) {
+    // redo_count[0] = overflowed queries of this launch, [2] = replay workgroups that have finished their lists, [4] = ... their redo share,
+    // [6] = ... their part of the copy to the host; redo_next likewise for the next launch
     if ((int)blockIdx.x >= nrep) {
         accept_scan<(W < 5 ? 1 : 2), kScanStream, (W < 5 ? 4 : 2)>(train, t0, t1, queries, nq, K, maxd, cand, nullptr, cap, (int)blockIdx.x - nrep, prog, tag);
         return;
     }
     __shared__ unsigned s_stage[kStreamStage * kWave];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { redo_next[0] = 0; redo_next[2] = 0; }   // the NEXT launch's counters (this launch's were cleared by the previous one)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { redo_next[0] = 0; redo_next[2] = 0; redo_next[4] = 0; redo_next[6] = 0; }   // the NEXT launch's counters (this launch's were cleared by the previous one)
     __builtin_amdgcn_s_setprio(3);                              // a dependent chain beside throughput-bound scan waves: issue first
     const int lane = threadIdx.x & (kWave - 1);
     unsigned* stage = s_stage + lane;
@@ -895,17 +903,39 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(W, W))) v
     while (__hip_atomic_load(redo_count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nrep) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const int nredo = __builtin_amdgcn_readfirstlane(__hip_atomic_load(redo_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (nredo == 0) return;
-    __builtin_amdgcn_s_setprio(0);
-    constexpr int LV = K <= 3 ? 1 : K <= 15 ? 3 : 6;   // (knn_search_kernel's heap levels for this k)
-    for (int j = blockIdx.x; j < nredo; j += nrep) {
-        const int rq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(redo_list + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        uint32_t q[8];
-        load_query(queries, rq, q);
-        WaveHeap h{0, -1, 0, lane};
-        int ncand = 0;
-        scan_range<false, LV>(h, train, t0, t1, q, K, maxd, nullptr, ncand, 0);
-        finish_row(h, K, sorted, indices, distances, rq);
+    if (nredo != 0) {
+        __builtin_amdgcn_s_setprio(0);
+        constexpr int LV = K <= 3 ? 1 : K <= 15 ? 3 : 6;   // (knn_search_kernel's heap levels for this k)
+        for (int j = blockIdx.x; j < nredo; j += nrep) {
+            const int rq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(redo_list + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            uint32_t q[8];
+            load_query(queries, rq, q);
+            WaveHeap h{0, -1, 0, lane};
+            int ncand = 0;
+            scan_range<false, LV>(h, train, t0, t1, q, K, maxd, nullptr, ncand, 0);
+            finish_row(h, K, sorted, indices, distances, rq);
+        }
+        if (ho.host_done) {   // the redone rows of every workgroup before anybody copies
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) __hip_atomic_fetch_add(redo_count + 4, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(redo_count + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nrep) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    if (!ho.host_done) return;
+    {
+        const uint4* si = reinterpret_cast<const uint4*>(indices);
+        const uint4* sd = reinterpret_cast<const uint4*>(distances);
+        uint4* di = reinterpret_cast<uint4*>(ho.host_idx);
+        uint4* dd = reinterpret_cast<uint4*>(ho.host_dist);
+        for (unsigned i = blockIdx.x * kWave + lane; i < ho.n16; i += (unsigned)nrep * kWave) { di[i] = si[i]; dd[i] = sd[i]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // every lane: its stores into pinned memory before the ticket, and so before the word
+        int last = 0;
+        if (lane == 0) last = __hip_atomic_fetch_add(redo_count + 6, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nrep - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(ho.host_done, ho.word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1567,8 +1597,9 @@ static int check_search_args(const uh_knn* idx, const void* q, int nq, int nn, c
     return UH_OK;
 }
 
-int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int32_t* d_indices,
-                      int32_t* d_distances, int sorted, int max_dist) {
+// ho (host form): where the stream form hands the rows to the host itself; *handed is set when it did (the other forms leave that to the caller)
+static int knn_search_dev_impl(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int32_t* d_indices,
+                               int32_t* d_distances, int sorted, int max_dist, KnnHostOut ho, bool* handed) {
     int rc = check_search_args(idx, d_queries, nq, nn, d_indices, d_distances);
     if (rc) return rc;
     if (nq == 0) return UH_OK;
@@ -1590,10 +1621,10 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
             uint64_t* d_cand = idx->list_buf.as<uint64_t>();
             uint64_t* d_prog = d_cand + (size_t)nq * cap;          // (list_buf holds tagged words only: any layout of an earlier launch is harmless)
             const unsigned had = idx->redo_buf.gen;
-            if ((rc = idx->redo_buf.reserve((size_t)(nq + 4) * 4))) return rc;
-            int* d_nredo = idx->redo_buf.as<int>();                // [parity]: queries to redo, [2 + parity]: replay workgroups through; then the compacted list of the queries to redo
-            int* d_redo = d_nredo + 4;
-            if (had != idx->redo_buf.gen) UH_HIP_CHECK(hipMemsetAsync(d_nredo, 0, 16, idx->ctx->stream));
+            if ((rc = idx->redo_buf.reserve((size_t)(nq + 8) * 4))) return rc;
+            int* d_nredo = idx->redo_buf.as<int>();                // [parity]: queries to redo, [2 / 4 / 6 + parity]: replay workgroups through their lists / redo share / host copy; then the compacted list of the queries to redo
+            int* d_redo = d_nredo + 8;
+            if (had != idx->redo_buf.gen) UH_HIP_CHECK(hipMemsetAsync(d_nredo, 0, 32, idx->ctx->stream));
             const bool same_mem = idx->stream_buf == idx->list_buf.p && idx->stream_gen == idx->list_buf.gen;
             if (!same_mem || idx->stream_tag == 0xFFFFFFFFu) {   // new memory, or the tag wraps: no stale word may match
                 UH_HIP_CHECK(hipMemsetAsync(idx->list_buf.p, 0, idx->list_buf.cap, idx->ctx->stream));
@@ -1603,7 +1634,7 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
                 // the overflow counters are picked by tag parity and a launch clears only the NEXT launch's slot: after a tag reset the slot
                 // of the coming launch may still hold the count an earlier launch of the same parity left behind (stale query ids would
                 // be replayed by knn_redo_kernel) — clear both
-                UH_HIP_CHECK(hipMemsetAsync(d_nredo, 0, 16, idx->ctx->stream));
+                UH_HIP_CHECK(hipMemsetAsync(d_nredo, 0, 32, idx->ctx->stream));
             }
             const unsigned tag = ++idx->stream_tag;
             static const long long stream_timeout = [] { const char* e = getenv("UH_KNN_STREAM_TIMEOUT_MS"); const long long ms = e ? atoll(e) : 0; return ms > 0 ? ms * 100000ll : kStreamTimeoutDefault; }();
@@ -1611,7 +1642,7 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
             const bool few = nrep + nq <= 2 * 4 * std::max(idx->ctx->num_cus, 64);   // at most two one-wave workgroups per SIMD with ONE query per scan wave: the wide-register form (knn_stream_kernel)
             const dim3 gs(nrep + (few ? nq : uh_div_up(nq, 2)));
 #define UH_KNN_STREAM_W(K, W) UH_LAUNCH(idx->ctx, (knn_stream_kernel<K, W>), gs, dim3(kWave), 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, sorted ? 1 : 0, max_dist, \
-            d_cand, d_prog, cap, tag, nrep, d_indices, d_distances, d_redo, d_nredo + (tag & 1u), d_nredo + ((tag + 1u) & 1u), stream_timeout)
+            d_cand, d_prog, cap, tag, nrep, d_indices, d_distances, d_redo, d_nredo + (tag & 1u), d_nredo + ((tag + 1u) & 1u), stream_timeout, ho)
 #define UH_KNN_STREAM(K) case K: if (few) UH_KNN_STREAM_W(K, 2); else UH_KNN_STREAM_W(K, 5); break
             switch (nn) {
                 UH_KNN_STREAM(1); UH_KNN_STREAM(2); UH_KNN_STREAM(3); UH_KNN_STREAM(4); UH_KNN_STREAM(5); UH_KNN_STREAM(6); UH_KNN_STREAM(7); UH_KNN_STREAM(8);
@@ -1621,6 +1652,7 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
 #undef UH_KNN_STREAM
 #undef UH_KNN_STREAM_W
             UH_HIP_CHECK(hipGetLastError());
+            if (handed) *handed = ho.host_done != nullptr;
             return UH_OK;
         }
         idx->stream_buf = nullptr;   // (the two-launch form writes untagged words into the same buffer)
@@ -1697,6 +1729,11 @@ int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int
     return UH_OK;
 }
 
+int uh_knn_search_dev(uh_knn* idx, const uint8_t* d_queries, int nq, int nn, int32_t* d_indices,
+                      int32_t* d_distances, int sorted, int max_dist) {
+    return knn_search_dev_impl(idx, d_queries, nq, nn, d_indices, d_distances, sorted, max_dist, KnnHostOut{nullptr, nullptr, 0u, nullptr, 0ull}, nullptr);
+}
+
 int uh_knn_search(uh_knn* idx, const uint8_t* queries, int nq, size_t q_stride, int nn, int32_t* indices,
                   int32_t* distances, int sorted, int max_dist) {
     int rc = check_search_args(idx, queries, nq, nn, indices, distances);
@@ -1717,13 +1754,22 @@ int uh_knn_search(uh_knn* idx, const uint8_t* queries, int nq, size_t q_stride, 
     if (pq && (reinterpret_cast<uintptr_t>(pq) & 15) == 0) { if ((rc = uh::copy16(idx->ctx, idx->q_buf.p, pq, (size_t)nq * 32))) return rc; }
     else if (q_stride == 32) UH_HIP_CHECK(hipMemcpyAsync(idx->q_buf.p, queries, (size_t)nq * 32, hipMemcpyHostToDevice, st));
     else UH_HIP_CHECK(hipMemcpy2DAsync(idx->q_buf.p, 32, queries, q_stride, 32, (size_t)nq, hipMemcpyHostToDevice, st));
-    rc = uh_knn_search_dev(idx, idx->q_buf.as<uint8_t>(), nq, nn, idx->idx_buf.as<int32_t>(),
-                           idx->dist_buf.as<int32_t>(), sorted, max_dist);
-    if (rc) return rc;
     int32_t* pi = static_cast<int32_t*>(uh::device_alias_of_host(indices));
     int32_t* pd = pi ? static_cast<int32_t*>(uh::device_alias_of_host(distances)) : nullptr;
-    if (pi && pd && (out_bytes & 15) == 0 && ((reinterpret_cast<uintptr_t>(pi) | reinterpret_cast<uintptr_t>(pd)) & 15) == 0) {
+    const bool pinned_out = pi && pd && (out_bytes & 15) == 0 && ((reinterpret_cast<uintptr_t>(pi) | reinterpret_cast<uintptr_t>(pd)) & 15) == 0;
+    KnnHostOut ho{nullptr, nullptr, 0u, nullptr, 0ull};
+    if (pinned_out) {
         if ((rc = idx->h_word.reserve(64))) return rc;
+        ho = KnnHostOut{pi, pd, (unsigned)(out_bytes / 16), idx->h_word.dev<unsigned long long>(), idx->host_seq + 1};
+    }
+    bool handed = false;
+    rc = knn_search_dev_impl(idx, idx->q_buf.as<uint8_t>(), nq, nn, idx->idx_buf.as<int32_t>(), idx->dist_buf.as<int32_t>(), sorted, max_dist, ho, &handed);
+    if (rc) return rc;
+    if (handed) {   // the stream form copied the rows and posts the word itself
+        const unsigned long long word = ++idx->host_seq;
+        return uh::wait_host_word(idx->h_word.host<volatile unsigned long long>(), word, st, "uh_knn_search");
+    }
+    if (pinned_out) {
         if ((rc = uh::copy16(idx->ctx, pi, idx->idx_buf.p, out_bytes))) return rc;
         if ((rc = uh::copy16(idx->ctx, pd, idx->dist_buf.p, out_bytes))) return rc;
         const unsigned long long word = ++idx->host_seq;
