@@ -10,13 +10,20 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_r05
-rm -rf $OUT; mkdir -p $OUT
+PARTS=${UH_COLLECT_PARTS:-headline chain tracker}   # e.g. UH_COLLECT_PARTS="headline tracker" refreshes those and leaves chain/ as it is
+mkdir -p $OUT
+has() { [[ " $PARTS " == *" $1 "* ]]; }
 cd /tmp && export TMPDIR=/tmp
+if has headline; then
+rm -rf $OUT/quick $OUT/pmc_fetch $OUT/pmc_write
 Q="python $R/bench.py --quick --steps 20 --warmup 5 --reps 15"
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/quick -o bench -- $Q > $OUT/quick.log 2>&1
 Q3="python $R/bench.py --quick --steps 6 --warmup 2 --reps 1"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/pmc_fetch -o bench -- $Q3 > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $OUT/pmc_write -o bench -- $Q3 > $OUT/pmc_write.log 2>&1
+fi
+if has chain; then
+rm -rf $OUT/chain $OUT/chain_mfma $OUT/chain_mops $OUT/chain_fetch $OUT/chain_write
 export UH_SWEEP_NO_ORACLE=1
 W="python $R/scripts/ba_window_sweep.py 3000 17 24 32 48 64"
 timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $OUT/chain -o chain -- $W > $OUT/chain.log 2>&1
@@ -24,9 +31,13 @@ timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-tra
 timeout 400 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVE_CYCLES --kernel-trace -f csv -d $OUT/chain_mops -o chain -- $W > $OUT/chain_mops.log 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/chain_fetch -o chain -- $W > $OUT/chain_fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $OUT/chain_write -o chain -- $W > $OUT/chain_write.log 2>&1
+fi
+if has tracker; then
+rm -rf $OUT/tracker
 EXE=/tmp/tracker_frame_prof
 g++ -std=c++17 -O2 -o $EXE $R/examples/tracker_frame.cpp -L$R/ucoslam-cv3_amd -lucoslam_hip -Wl,-rpath,$R/ucoslam-cv3_amd -Wl,-rpath,/opt/rocm/lib -lpthread
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/tracker -o trk -- $EXE 200 20 > $OUT/tracker.log 2>&1
 $EXE 300 30 > $OUT/tracker_plain.json 2>&1
+fi
 find $OUT -name "*.csv" | head -30
 tail -2 $OUT/quick.log

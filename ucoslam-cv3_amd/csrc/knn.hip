@@ -360,7 +360,9 @@ __device__ __forceinline__ void accept_scan(
         if (!(p & 1)) pend[j] = w;
         else store_record(p >> 1, qj, pend[j], w);
     };
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    // set bits of a wave mask below this lane: v_mbcnt_lo / _hi (a precomputed (1 << lane) - 1 was two registers live through the whole scan —
+    // spilled to scratch at 96 registers: 2 MB of scratch writes per 8000-query launch)
+    auto below = [](unsigned long long mask) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u)); };
     // sorted insert of an accepted distance: every lane whose value exceeds d takes max(left neighbour, d) — its neighbour's value if that
     // also exceeds d, else d itself; the largest value falls off the end of the row.  Four vector instructions + one v_readlane.
     auto tighten = [&](int j, int dl) {
@@ -403,7 +405,9 @@ __device__ __forceinline__ void accept_scan(
             }
             rk += e;   // rows before i that are <= d_i + rows behind i that are < d_i: a permutation of 0 .. 63 (rows that do not pass sort last, in row order)
             const int sorted = __builtin_amdgcn_ds_permute(rk << 2, key);
-            const int s16 = __builtin_amdgcn_ds_bpermute((lane & 15) << 2, sorted);
+            int lsel = lane;   // (through an opaque move: hoisted out of the scan loop, (lane & 15) << 2 is one more register live for the whole kernel — spilled at 96)
+            asm volatile("" : "+v"(lsel));
+            const int s16 = __builtin_amdgcn_ds_bpermute((lsel & 15) << 2, sorted);
             sv[j] = s16 >= 0x7ffffffe ? 0x7fffffff : s16;
         } else {
             for (uint64_t mm = m; mm;) {
@@ -417,12 +421,12 @@ __device__ __forceinline__ void accept_scan(
         const bool acc = pass && e < k && d < kth;
         const uint64_t ma = __ballot(acc);
         const int na = __popcll(ma), base = nc[j];
-        const int posl = __popcll(ma & lt);
+        const int posl = below(ma);
         if constexpr (STREAM) {
             const int odd = base & 1, tot = na + odd;
             if (tot > kWave || base + na > cap) return false;   // (left to the serial walk: a list about to overflow; 64 accepted rows behind a pending entry)
             const unsigned w = ((unsigned)d << 23) | (unsigned)idx;
-            const int slot = acc ? posl + odd : tot + __popcll(~ma & lt);   // (with a pending entry the last of the others wraps to slot 0, which is the pending entry's)
+            const int slot = acc ? posl + odd : tot + below(~ma);   // (with a pending entry the last of the others wraps to slot 0, which is the pending entry's)
             unsigned c = (unsigned)__builtin_amdgcn_ds_permute((slot & (kWave - 1)) << 2, (int)w);
             if (odd && lane == 0) c = pend[j];
             const unsigned w0 = (unsigned)__builtin_amdgcn_ds_bpermute((2 * lane) << 2, (int)c);
@@ -468,7 +472,7 @@ __device__ __forceinline__ void accept_scan(
             return;
         }
         if constexpr (!STREAM && !SHARD) {
-            const int pos = nc[j] + __popcll(m & lt);
+            const int pos = nc[j] + below(m);
             if (pass && pos < cap) put((size_t)pos * nq + qj, d, idx);
             nc[j] += __popcll(m);
         }
@@ -881,11 +885,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(W, W))) v
         // will ever get (its scan has closed the list): the lanes then hold about the same number of entries.
         const bool ready = fin || np >= kMinRec || (closed && r + np >= total);
         const bool wait_more = __ballot(!ready) != 0 && most != 0;
-        if (wait_more) deep = 1;
         if (most == 0 || wait_more) {
             if (closed && r >= total) fin = true;
             if (wall_clock64() - tlast > timeout_ticks) { over = over || !fin; fin = true; }
-            if (__ballot(!fin) != 0) __builtin_amdgcn_s_sleep(2);
+            if (__ballot(!fin) != 0) __builtin_amdgcn_s_sleep(24);   // ~0.6 us between polls (every poll is a fabric read of each lane's next records)
             continue;
         }
         tlast = wall_clock64();
