@@ -476,11 +476,26 @@ __device__ __forceinline__ void accept_scan(
             if (pass && pos < cap) put((size_t)pos * nq + qj, d, idx);
             nc[j] += __popcll(m);
         }
+        if constexpr (STREAM) {
+            // round 5: the stream form lists exactly the accepted rows too (it listed every row below the step's initial threshold and left the
+            // rejection to the replay), and the walk reads ONE packed word per row — the distance is its top nine bits
+            const unsigned wv = ((unsigned)d << 23) | (unsigned)idx;
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const unsigned wl = (unsigned)rl((int)wv, l);
+                const int dl = (int)(wl >> 23);
+                if (dl >= thr[j]) continue;
+                const int p = nc[j]++;
+                if (p < cap) { if (!(p & 1)) pend[j] = wl; else store_record(p >> 1, qj, pend[j], wl); }
+                tighten(j, dl);
+            }
+            return;
+        }
         while (m) {
             const int l = __builtin_ctzll(m);
             m &= m - 1;
             const int dl = rl(d, l);
-            if constexpr (STREAM) append(j, qj, dl, rl(idx, l));   // every row below the step's initial threshold is listed (in row order)
             if (dl >= thr[j]) continue;
             if constexpr (SHARD) append(j, qj, dl, rl(idx, l));    // exactly the accepted rows
             tighten(j, dl);
