@@ -1465,6 +1465,8 @@ struct uh_knn {
     int two_phase_min_nq = 3000;
     int stream_min_nn = 6;
     int stream_min_nq = 1;        // round 5: nn >= stream_min_nn takes the stream form at every size (2000 queries: 43 us against 74 fused, 64 queries: 33 against 61)
+    bool stream_when_few = true;  // ... and EVERY nn <= 16 while the one-query-per-wave form applies (queries + replay workgroups <= 2 per SIMD, ~2000 queries):
+                                  // nn 2: 20-34 us against 29-36 fused, nn 5: 24-37 against 42-52 (scripts/knn_nq_sweep.py, profiles/r05_knn_nq_sweep.txt)
     unsigned replay_attr = 0;     // bit k: knn_replay_lane_kernel<k>'s dynamic-LDS attribute has been set on this index's device
     int accept_qpw = 2;           // queries per wave of the accept scan (UH_KNN_ACCEPT_QPW=1 for the A/B)
     unsigned stream_tag = 0;      // launch tag of the streamed lists (0 = the value freshly cleared memory holds, never used)
@@ -1529,8 +1531,8 @@ int uh_knn_create(uh_ctx* ctx, uh_knn** out) {
     if (const char* e = getenv("UH_KNN_FORM")) {
         const std::string f(e);
         k->split_form = f == "split";
-        if (f == "fused") k->two_phase_min_nq = k->stream_min_nq = 0x7fffffff;
-        else if (f == "twophase") { k->two_phase_min_nq = 0; k->stream_min_nn = 0x7fffffff; }
+        if (f == "fused") { k->two_phase_min_nq = k->stream_min_nq = 0x7fffffff; k->stream_when_few = false; }
+        else if (f == "twophase") { k->two_phase_min_nq = 0; k->stream_min_nn = 0x7fffffff; k->stream_when_few = false; }
         else if (f == "stream") { k->two_phase_min_nq = 0; k->stream_min_nn = 0; }
     }
     if (const char* f = getenv("UH_KNN_ACCEPT_QPW")) k->accept_qpw = atoi(f) == 1 ? 1 : 2;
@@ -1627,7 +1629,8 @@ static int knn_search_dev_impl(uh_knn* idx, const uint8_t* d_queries, int nq, in
     // slower (the pushes of a wave's queries serialise), its L1/L2 traffic and its resident waves drop to 1/2 or 1/4, which is what a
     // latency-bound neighbour on another stream (the local BA) needs
     const int qpw = nn <= 15 ? idx->qpw : 1;
-    if (nn <= kRpK && (nq >= idx->two_phase_min_nq || (nn >= idx->stream_min_nn && nq >= idx->stream_min_nq)) && idx->shard_end <= (1 << 23)) {   // (the replay packs distance and row index into 32 bits)
+    const bool few_form = uh_div_up(nq, kWave) + nq <= 2 * 4 * std::max(idx->ctx->num_cus, 64);   // at most two one-wave workgroups per SIMD with ONE query per scan wave (knn_stream_kernel<K, 2>)
+    if (nn <= kRpK && (nq >= idx->two_phase_min_nq || (nn >= idx->stream_min_nn && nq >= idx->stream_min_nq) || (few_form && idx->stream_when_few)) && idx->shard_end <= (1 << 23)) {   // (the replay packs distance and row index into 32 bits)
         // accept-list capacity: the expected number of accepted pushes is k (1 + ln(N / k)) (a record process), its spread ~ sqrt of
         // that; lists that still overflow (distances descending with the row index) are redone by knn_redo_kernel
         const int nrows = std::max(idx->shard_end - idx->shard_begin, 1);
@@ -1635,7 +1638,7 @@ static int knn_search_dev_impl(uh_knn* idx, const uint8_t* d_queries, int nq, in
         const int cap = std::min(std::min(std::max(((int)(1.6 * expect) + 32 + 31) & ~31, 32), std::max((nrows + 31) & ~31, 32)), 256);
         int rc;
         if ((rc = idx->list_buf.reserve((size_t)nq * cap * 8 + (size_t)nq * 16 + 256))) return rc;
-        if (nn >= idx->stream_min_nn && idx->accept_qpw == 2 && (size_t)nq * cap * 8 < ((size_t)1 << 31)) {   // (record offsets are 32-bit buffer offsets)
+        if ((nn >= idx->stream_min_nn || (few_form && idx->stream_when_few)) && idx->accept_qpw == 2 && (size_t)nq * cap * 8 < ((size_t)1 << 31)) {   // (record offsets are 32-bit buffer offsets)
             uint64_t* d_cand = idx->list_buf.as<uint64_t>();
             uint64_t* d_prog = d_cand + (size_t)nq * cap;          // (list_buf holds tagged words only: any layout of an earlier launch is harmless)
             const unsigned had = idx->redo_buf.gen;
@@ -1657,7 +1660,7 @@ static int knn_search_dev_impl(uh_knn* idx, const uint8_t* d_queries, int nq, in
             const unsigned tag = ++idx->stream_tag;
             static const long long stream_timeout = [] { const char* e = getenv("UH_KNN_STREAM_TIMEOUT_MS"); const long long ms = e ? atoll(e) : 0; return ms > 0 ? ms * 100000ll : kStreamTimeoutDefault; }();
             const int nrep = uh_div_up(nq, kWave);
-            const bool few = nrep + nq <= 2 * 4 * std::max(idx->ctx->num_cus, 64);   // at most two one-wave workgroups per SIMD with ONE query per scan wave: the wide-register form (knn_stream_kernel)
+            const bool few = few_form;
             const dim3 gs(nrep + (few ? nq : uh_div_up(nq, 2)));
 #define UH_KNN_STREAM_W(K, W) UH_LAUNCH(idx->ctx, (knn_stream_kernel<K, W>), gs, dim3(kWave), 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, sorted ? 1 : 0, max_dist, \
             d_cand, d_prog, cap, tag, nrep, d_indices, d_distances, d_redo, d_nredo + (tag & 1u), d_nredo + ((tag + 1u) & 1u), stream_timeout, ho)
