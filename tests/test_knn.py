@@ -406,3 +406,34 @@ def test_hip_knn_range_split_form_is_exact(hip_ctx, oracle, monkeypatch):
             ri, rd = oracle_lib.knn_search(oracle, train, q, nn, s)
             np.testing.assert_array_equal(idx.cpu().numpy(), ri)
             np.testing.assert_array_equal(dist.cpu().numpy(), rd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,nn", [(90, 10), (2000, 10), (2000, 2), (5000, 10)])
+def test_hip_knn_host_form_with_pinned_arrays_hands_the_rows_over_in_the_launch(hip_ctx, oracle, nq, nn):
+    """uh_knn_search with PINNED result arrays (what bench.py's single_frame_latency and a tracker's host call use): the stream form's replay
+    workgroups copy the rows to the host arrays and post the completion word themselves (round 5, knn_stream_kernel's KnnHostOut) — the
+    one-query-per-wave form (<= ~2000 queries), the two-queries-per-wave form (5000) and a set whose every list OVERFLOWS (distances
+    descending with the row index: the redone rows must be in the arrays before any workgroup copies).  Three calls each: the word sequence
+    advances, the arrays are overwritten."""
+    import ctypes as C
+    import torch
+    import ucoslam_cv3_amd as u
+    from ucoslam_cv3_amd.knn import Index
+
+    L = u.lib()
+    sets = [synth.match_set(nq, 3000, seed=11), synth.tie_stress_set(nq, 2000, seed=12)]
+    if nq <= 128:
+        sets.append(synth.descending_set(nq, 700, seed=13))
+    for train, q in sets:
+        index = Index(hip_ctx).build(train)
+        hq = torch.from_numpy(np.ascontiguousarray(q)).pin_memory()
+        hi = torch.full((nq, nn), -7, dtype=torch.int32).pin_memory()
+        hd = torch.full((nq, nn), -7, dtype=torch.int32).pin_memory()
+        ri, rd = oracle_lib.knn_search(oracle, train, q, nn, 0)
+        for rep in range(3):
+            hi.fill_(-7); hd.fill_(-7)
+            from ucoslam_cv3_amd._lib import check as _check
+            _check(L.uh_knn_search(index._h, C.c_void_p(hq.data_ptr()), nq, 32, nn, C.c_void_p(hi.data_ptr()), C.c_void_p(hd.data_ptr()), 0, -1))
+            np.testing.assert_array_equal(hi.numpy(), ri)
+            np.testing.assert_array_equal(hd.numpy(), rd)
