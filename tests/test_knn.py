@@ -437,3 +437,18 @@ def test_hip_knn_host_form_with_pinned_arrays_hands_the_rows_over_in_the_launch(
             _check(L.uh_knn_search(index._h, C.c_void_p(hq.data_ptr()), nq, 32, nn, C.c_void_p(hi.data_ptr()), C.c_void_p(hd.data_ptr()), 0, -1))
             np.testing.assert_array_equal(hi.numpy(), ri)
             np.testing.assert_array_equal(hd.numpy(), rd)
+
+
+@pytest.mark.gpu
+def test_hip_knn_very_large_batches_leave_the_one_launch_form(hip_ctx, oracle):
+    """The stream form's replay workgroups wait for each other (shared redo, host hand-over), so the form is used only while all of them fit
+    the device at once (<= 2 per compute unit: 32 768 queries on MI355X); 40 000 queries take the two launches — same rows."""
+    from ucoslam_cv3_amd.knn import Index
+
+    train, _ = synth.match_set(16, 400, seed=21)
+    q = np.concatenate([synth.match_set(2000, 400, seed=100 + s)[1] for s in range(20)])
+    index = Index(hip_ctx).build(train)
+    idx, dist = index.search(q, 10, sorted=False)
+    ri, rd = oracle_lib.knn_search(oracle, train, q, 10, 0)
+    np.testing.assert_array_equal(idx, ri)
+    np.testing.assert_array_equal(dist, rd)

@@ -1638,7 +1638,11 @@ static int knn_search_dev_impl(uh_knn* idx, const uint8_t* d_queries, int nq, in
         const int cap = std::min(std::min(std::max(((int)(1.6 * expect) + 32 + 31) & ~31, 32), std::max((nrows + 31) & ~31, 32)), 256);
         int rc;
         if ((rc = idx->list_buf.reserve((size_t)nq * cap * 8 + (size_t)nq * 16 + 256))) return rc;
-        if ((nn >= idx->stream_min_nn || (few_form && idx->stream_when_few)) && idx->accept_qpw == 2 && (size_t)nq * cap * 8 < ((size_t)1 << 31)) {   // (record offsets are 32-bit buffer offsets)
+        // the replay workgroups of the stream form wait for each other at the end (the shared redo, the hand-over to the host): ALL of them must be
+        // resident at once — they are the first workgroups of the grid, and they are kept to at most two per compute unit (32 768 queries on
+        // MI355X; a 20th of the one-wave slots); larger batches take the two launches
+        const bool stream_fits = uh_div_up(nq, kWave) <= 2 * std::max(idx->ctx->num_cus, 64);
+        if (stream_fits && (nn >= idx->stream_min_nn || (few_form && idx->stream_when_few)) && idx->accept_qpw == 2 && (size_t)nq * cap * 8 < ((size_t)1 << 31)) {   // (record offsets are 32-bit buffer offsets)
             uint64_t* d_cand = idx->list_buf.as<uint64_t>();
             uint64_t* d_prog = d_cand + (size_t)nq * cap;          // (list_buf holds tagged words only: any layout of an earlier launch is harmless)
             const unsigned had = idx->redo_buf.gen;
