@@ -1,5 +1,6 @@
 """Soak of the tracking stream beside the local BA: ORB (4 frames) + exact kNN (8000 x 10000, nn 10 -> the one-launch search, and nn 2 -> the
-two-launch form) repeated while `optimize_async` runs on its own stream; every result is compared with the unloaded one.
+two-launch form; round 5: also ONE frame's 2000 queries at nn 10 and nn 2 -> the one-query-per-wave form of the one-launch search, whose replay
+workgroups wait for each other at the end) repeated while `optimize_async` runs on its own stream; every result is compared with the unloaded one.
 usage: python scripts/soak_tracking.py [seconds]"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,8 +27,10 @@ def once():
     q = desc.reshape(-1, 32)
     i10, d10 = index.search(q, 10, sorted=False)
     i2, d2 = index.search(q, 2, sorted=True)
+    j10, e10 = index.search(q[:2000], 10, sorted=False)
+    j2, e2 = index.search(q[2000:4000], 2, sorted=False)
     torch.cuda.synchronize()
-    return [t.clone() for t in (kps.view(torch.uint8), desc, counts, i10, d10, i2, d2)]
+    return [t.clone() for t in (kps.view(torch.uint8), desc, counts, i10, d10, i2, d2, j10, e10, j2, e2)]
 
 ref = once()
 t0 = time.time(); n = bad = 0
