@@ -42,9 +42,9 @@ namespace {
 constexpr int kLeafMax = 10;          // picoflann _maxLeafSize
 constexpr int kMaxDepth = 90;         // deeper trees (pathological inputs) are refused: the walk stacks live in LDS
 constexpr size_t kLdsBudget = 150 * 1024;   // of the CU's 160 KB
-constexpr int kPmThreads = 256;       // four waves share the LDS copy of the frame
-constexpr int kGroup = 16;            // lanes per map point (a leaf holds <= 10 keypoints)
-constexpr int kGroupsPerWave = kPmThreads / kGroup;   // groups (map points in flight) per workgroup
+constexpr int kPmThreads = 1024;      // at most sixteen waves share the LDS copy of the frame (the launch picks 4 .. 16: see uh_projmatch_match)
+constexpr int kGroup = 64;            // lanes per map point: ONE point per wave (round 5; a leaf holds <= 10 keypoints, the drain uses all 64)
+constexpr int kGroupsMax = kPmThreads / kGroup;   // groups (map points in flight) per workgroup, at most
 constexpr int kPmMaxBlocks = 768;     // workgroups loop over chunks of 16 map points: the frame is staged once per workgroup
 constexpr int kCandCap = 128;         // per-point list of disc hits between two drains (a leaf adds at most 10)
 
@@ -206,8 +206,11 @@ struct PmFrame {
 
 struct PmPoints {
     int n;
-    const float* pos3d; const float* normal; const float* min_dist; const float* max_dist; const uint64_t* desc;
-    const int* octave;      // PREV mode: octave of the previous frame's keypoint
+    // one 64-byte record per candidate, in the pinned staging block (read by the kernel in place): position (3 floats), then normal (3),
+    // min / max distance — or, PREV mode, the previous frame's keypoint octave in word 3 —, then the 32-byte descriptor.  Five separate
+    // arrays (rounds 3-5a) were five small reads over the host link per candidate — 15 000 requests for 3000 map points, ~6 us before a walk
+    // could start; one record is one 64-byte request.
+    const uint4* rec;
     int* best_kp; float* best_dist; unsigned char* visible;
 };
 
@@ -224,6 +227,12 @@ struct PmPublish {
 };
 
 __device__ __forceinline__ float logf_cr(float x) { return uh_sincosf::logf_glibc(x); }   // libm's logf, bit for bit
+__device__ __forceinline__ double readlane_f64(double v, int lane_uniform) {   // lane index must be wave-uniform
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane_uniform);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane_uniform);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 
 // Walk records (one per tree level at most): (other child << 2) | (col << 1) | state, with the other child's mindistsq, the
 // cut distance and the float dists[col] to restore; state 0 = other child still to be searched, 1 = being searched (restore
@@ -244,11 +253,15 @@ __device__ __forceinline__ float logf_cr(float x) { return uh_sincosf::logf_glib
 // PREV = false: Map::matchFrameToMapPoints (map.cpp:689-759).  PREV = true: the tracker's search against the previous frame's
 // keypoints (system.cpp:5930-6460): Frame::project visibility, the keypoint's own octave as the only admissible level, radius
 // maxRepjDist * scaleFactors[octave], best/second without demotion from (float)(minDescDist + 0.01), accept best < 0.7 * second.
-template <bool IN_LDS, bool PREV>
+// LANE_STACK (levels <= 64, i.e. always but for pathological trees): the walk records live across the LANES of the point's wave — record i in
+// lane i, pushed by a predicated move, popped by v_readlane with the (wave-uniform) stack pointer — instead of in LDS: a pop was three to four
+// dependent LDS round trips of an iteration that has five.
+template <bool IN_LDS, bool PREV, bool LANE_STACK>
 __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoints mp, PmPose ps, float minDescDist, float maxRepjDist,
                                                                int n_nodes, int levels, int* overflow, PmPublish pub) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x, g = lane / kGroup, gl = lane % kGroup, gw = (lane & 63) / kGroup;   // gw: group within its wave
+    const int nthr = (int)blockDim.x, gpw = nthr / kGroup;   // threads and groups of THIS launch's workgroups
     // measurement (UH_PM_CLK): shader-clock stamps of workgroup 0, thread 0 in the status block behind the overflow word
     long long* const clk = (overflow[1] == 0x434c4b && blockIdx.x == 0 && threadIdx.x == 0) ? reinterpret_cast<long long*>(overflow + 4) : nullptr;
     if (clk) clk[0] = __builtin_readcyclecounter();
@@ -259,16 +272,31 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
     float4* s_rec = reinterpret_cast<float4*>(smem + off);
     if (IN_LDS) off += (size_t)n * 16;
     double* st_m = reinterpret_cast<double*>(smem + off) + (size_t)g * levels;
-    off += (size_t)levels * kGroupsPerWave * 8;
+    off += (size_t)levels * gpw * 8;
     double* st_c = reinterpret_cast<double*>(smem + off) + (size_t)g * levels;
-    off += (size_t)levels * kGroupsPerWave * 8;
+    off += (size_t)levels * gpw * 8;
     int* st_rec = reinterpret_cast<int*>(smem + off) + (size_t)g * levels;
-    off += (size_t)levels * kGroupsPerWave * 4;
+    off += (size_t)levels * gpw * 4;
     float* st_d = reinterpret_cast<float*>(smem + off) + (size_t)g * levels;
-    off += (size_t)levels * kGroupsPerWave * 4;
+    off += (size_t)levels * gpw * 4;
     unsigned int* s_cand = reinterpret_cast<unsigned int*>(smem + off) + (size_t)g * kCandCap;
-    off += (size_t)kCandCap * kGroupsPerWave * 4;
+    off += (size_t)kCandCap * gpw * 4;
     int* s_hd = reinterpret_cast<int*>(smem + off) + (size_t)g * kCandCap;
+    // The candidate of this wave's FIRST chunk is requested before the frame is staged: it lies in pinned host memory (uh_projmatch_match
+    // hands the points over in place), a host-link round trip that used to start only behind the staging's barrier.
+    struct Cand { float P0, P1, P2, n0, n1, n2, mind, maxd; int oct; uint64_t q0, q1, q2, q3; };
+    auto load_cand = [&](int mc) {
+        const uint4* r = mp.rec + 4 * (size_t)mc;
+        const uint4 a = r[0], b = r[1], d0 = r[2], d1 = r[3];
+        Cand c;
+        c.P0 = __uint_as_float(a.x); c.P1 = __uint_as_float(a.y); c.P2 = __uint_as_float(a.z);
+        c.oct = (int)a.w; c.n0 = __uint_as_float(a.w); c.n1 = __uint_as_float(b.x); c.n2 = __uint_as_float(b.y);
+        c.mind = __uint_as_float(b.z); c.maxd = __uint_as_float(b.w);
+        c.q0 = ((uint64_t)d0.y << 32) | d0.x; c.q1 = ((uint64_t)d0.w << 32) | d0.z; c.q2 = ((uint64_t)d1.y << 32) | d1.x; c.q3 = ((uint64_t)d1.w << 32) | d1.z;
+        return c;
+    };
+    const int m_first = (int)blockIdx.x * gpw + g;
+    const Cand c_first = load_cand(m_first < mp.n ? m_first : 0);
     if (IN_LDS) {
         // 16-byte loads, eight in flight per lane and round (the node array is 24 n bytes in a 256-byte aligned block: the last chunk may
         // run 8 bytes into its padding, which the LDS area's rounding covers)
@@ -276,34 +304,35 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
         uint4* sn = reinterpret_cast<uint4*>(s_nodes);
         constexpr int U = 8;
         const int n16 = (n_nodes * (int)sizeof(KdNodeDev) + 15) / 16;
-        for (int i0 = lane; i0 < n16; i0 += U * kPmThreads) {
+        for (int i0 = lane; i0 < n16; i0 += U * nthr) {
             uint4 v[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) { const int i = i0 + u * kPmThreads; v[u] = gn[i < n16 ? i : 0]; }
+            for (int u = 0; u < U; u++) { const int i = i0 + u * nthr; v[u] = gn[i < n16 ? i : 0]; }
 #pragma unroll
-            for (int u = 0; u < U; u++) { const int i = i0 + u * kPmThreads; if (i < n16) sn[i] = v[u]; }
+            for (int u = 0; u < U; u++) { const int i = i0 + u * nthr; if (i < n16) sn[i] = v[u]; }
         }
-        for (int i0 = lane; i0 < n; i0 += U * kPmThreads) {
+        for (int i0 = lane; i0 < n; i0 += U * nthr) {
             float4 a[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) { const int i = i0 + u * kPmThreads; a[u] = f.leaf_rec[i < n ? i : 0]; }
+            for (int u = 0; u < U; u++) { const int i = i0 + u * nthr; a[u] = f.leaf_rec[i < n ? i : 0]; }
 #pragma unroll
-            for (int u = 0; u < U; u++) { const int i = i0 + u * kPmThreads; if (i < n) s_rec[i] = a[u]; }
+            for (int u = 0; u < U; u++) { const int i = i0 + u * nthr; if (i < n) s_rec[i] = a[u]; }
         }
         __syncthreads();
     }
     if (clk) clk[1] = __builtin_readcyclecounter();
-  for (int chunk = blockIdx.x; chunk * kGroupsPerWave < mp.n; chunk += gridDim.x) {
-    const int m = chunk * kGroupsPerWave + g;
+  for (int chunk = blockIdx.x; chunk * gpw < mp.n; chunk += gridDim.x) {
+    const int m = chunk * gpw + g;
     const bool live = m < mp.n;
     const int mc = live ? m : 0;
-    // ---- visibility tests and search parameters (identical in the 16 lanes of the group)
+    const Cand cd = chunk == (int)blockIdx.x ? c_first : load_cand(mc);
+    // ---- visibility tests and search parameters (identical in the lanes of the group)
     bool vis = false;
     float px = 0, py = 0;
     int predicted = 0;
     double worst = 0;
     if constexpr (PREV) {
-        const float P0 = mp.pos3d[3 * mc], P1 = mp.pos3d[3 * mc + 1], P2 = mp.pos3d[3 * mc + 2];
+        const float P0 = cd.P0, P1 = cd.P1, P2 = cd.P2;
         const float* T = ps.T;
         const float z = P0 * T[8] + P1 * T[9] + P2 * T[10] + T[11];       // Frame::project (frame.h:140-161)
         const float x = P0 * T[0] + P1 * T[1] + P2 * T[2] + T[3];
@@ -311,26 +340,26 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
         const float iz = (float)(1. / z);
         px = ((f.fx * x) * iz) + f.cx; py = ((f.fy * y) * iz) + f.cy;
         vis = live && !(z < 0) && (px >= f.min_x && py >= f.min_y && px < f.max_x && py < f.max_y);
-        predicted = mp.octave[mc];
+        predicted = cd.oct;
         if (vis) {
             const double radius = (double)(maxRepjDist * f.scale[predicted]);
             worst = radius * radius;
         }
     } else {
-        const float P0 = mp.pos3d[3 * mc], P1 = mp.pos3d[3 * mc + 1], P2 = mp.pos3d[3 * mc + 2];
+        const float P0 = cd.P0, P1 = cd.P1, P2 = cd.P2;
         float v0 = ps.cc[0] - P0, v1 = ps.cc[1] - P1, v2 = ps.cc[2] - P2;   // getViewCos
         const double s = 1. / sqrt((double)v0 * v0 + (double)v1 * v1 + (double)v2 * v2);
         v0 = (float)(v0 * s); v1 = (float)(v1 * s); v2 = (float)(v2 * s);
-        const float viewCos = v0 * mp.normal[3 * mc] + v1 * mp.normal[3 * mc + 1] + v2 * mp.normal[3 * mc + 2];
+        const float viewCos = v0 * cd.n0 + v1 * cd.n1 + v2 * cd.n2;
         const float* T = ps.T;
         const float x = T[0] * P0 + T[1] * P1 + T[2] * P2 + T[3];
         const float y = T[4] * P0 + T[5] * P1 + T[6] * P2 + T[7];
         const float z = T[8] * P0 + T[9] * P1 + T[10] * P2 + T[11];
         const float dist = (float)sqrt((double)x * x + (double)y * y + (double)z * z);
-        const float maxd = mp.max_dist[mc];
+        const float maxd = cd.maxd;
         const float iz = (float)(1. / z);
         px = x * f.fx * iz + f.cx; py = y * f.fy * iz + f.cy;
-        vis = live && !(viewCos < 0.5) && !(z < 0) && (0.8f * mp.min_dist[mc] < dist && dist < 1.2f * maxd) &&
+        vis = live && !(viewCos < 0.5) && !(z < 0) && (0.8f * cd.mind < dist && dist < 1.2f * maxd) &&
               (px > f.min_x && py > f.min_y && px < f.max_x && py < f.max_y);
         if (vis) {
             const int ns = (int)ceilf(logf_cr(maxd / dist) / f.log_scale);
@@ -346,8 +375,7 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
     const int oct_lo = PREV ? predicted : predicted - 1;
     int bestLevel = 0, bestLevel2 = -1;
     bool ovf = false;
-    const uint64_t* qd = mp.desc + 4 * (size_t)mc;
-    const uint64_t q0 = qd[0], q1 = qd[1], q2 = qd[2], q3 = qd[3];
+    const uint64_t q0 = cd.q0, q1 = cd.q1, q2 = cd.q2, q3 = cd.q3;
     int ncand = 0;
     // drain: Hamming distances of the listed hits (16 lanes, one hit each per round), then the in-order best / second rule
     auto drain = [&](int cnt) {
@@ -386,6 +414,7 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
         // will be searched at all.  Only nodes whose other child WILL be searched leave a record (most do not); the record
         // is turned into "restore dists[col]" in place when the other child is entered.
         int sp = 0;
+        int l_rec = 0; double l_m = 0, l_c = 0; float l_d = 0;   // LANE_STACK: this lane's walk record (lane = stack slot)
         int cur = 0;                 // node to visit (-1: take the top record)
         int n_iter = 0, n_leaf = 0;
         double cur_m = (double)distsq;
@@ -393,22 +422,34 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
             ++n_iter;
             if (cur < 0) {
                 if (sp == 0) break;
-                const int rec = st_rec[sp - 1];
+                const int top = __builtin_amdgcn_readfirstlane(sp) - 1;   // (one point per wave: the stack pointer is wave-uniform)
+                const int rec = LANE_STACK ? __builtin_amdgcn_readlane(l_rec, top) : st_rec[sp - 1];
                 const int col = (rec >> 1) & 1;
                 if (rec & 1) {       // the other child's subtree is done: dists[col] = dst
-                    const double dstd = (double)st_d[sp - 1];
+                    const double dstd = (double)(LANE_STACK ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(l_d), top)) : st_d[sp - 1]);
                     if (col == 0) dd0 = dstd; else dd1 = dstd;
                     --sp;
                     continue;
                 }
-                const double cutv = st_c[sp - 1];   // enter the other child: dists[col] = cut
+                const double cutv = LANE_STACK ? readlane_f64(l_c, top) : st_c[sp - 1];   // enter the other child: dists[col] = cut
                 if (col == 0) dd0 = cutv; else dd1 = cutv;
                 cur = rec >> 2;
-                cur_m = st_m[sp - 1];
-                if (gl == 0) st_rec[sp - 1] = rec | 1;
+                cur_m = LANE_STACK ? readlane_f64(l_m, top) : st_m[sp - 1];
+                if constexpr (LANE_STACK) { if (gl == top) l_rec = rec | 1; }
+                else if (gl == 0) st_rec[sp - 1] = rec | 1;
             }
+            // the whole 24-byte node in ONE round trip: three 8-byte reads issued together (left as `nd = s_nodes[cur]` the compiler fetched the
+            // fields where they are used — left / right, then the planes, then the column, then the leaf range: four to five dependent LDS
+            // round trips per tree step, ~500 of its ~650 clocks)
             KdNodeDev nd;
-            if (IN_LDS) nd = s_nodes[cur]; else nd = f.nodes[cur];
+            {
+                const uint2* np = reinterpret_cast<const uint2*>(IN_LDS ? s_nodes + cur : f.nodes + cur);
+                uint2 w0 = np[0], w1 = np[1], w2 = np[2];
+                asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w1.x), "+v"(w1.y), "+v"(w2.x), "+v"(w2.y));   // (all six words are needed HERE)
+                nd.divlow = __uint_as_float(w0.x); nd.divhigh = __uint_as_float(w0.y);
+                nd.left = (int)w1.x; nd.right = (int)w1.y; nd.leaf_begin = (int)w2.x;
+                nd.leaf_count = (short)(w2.y & 0xFFFFu); nd.col = (short)(w2.y >> 16);
+            }
             if (nd.left < 0) {   // leaf: lane i of the group tests keypoint i; hits are appended in leaf order
                 ++n_leaf;
                 bool hit = false;
@@ -423,8 +464,9 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
                     if (!(sqd > worst)) { const double dy = py - c.y; sqd += dy * dy; }
                     hit = sqd < worst && oc >= oct_lo && oc <= predicted;
                 }
-                const unsigned int gm = (unsigned int)((__ballot(hit) >> (gw * kGroup)) & ((1ull << kGroup) - 1ull));
-                if (hit) s_cand[ncand + __popc(gm & ((1u << gl) - 1u))] = (id << 4) | (unsigned int)oc;
+                // (only lanes gl < leaf_count <= 10 can hit: the group's hit mask fits 32 bits whatever kGroup is)
+                const unsigned int gm = (unsigned int)((__ballot(hit) >> (gw * (kGroup & 63))) & (kGroup >= 32 ? 0xFFFFFFFFull : ((1ull << (kGroup & 31)) - 1ull)));
+                if (hit) s_cand[ncand + __popc(gm & ((1u << (gl & 31)) - 1u))] = (id << 4) | (unsigned int)oc;
                 ncand += __popc(gm);
                 if (ncand > kCandCap - kLeafMax) { drain(ncand); ncand = 0; }
                 cur = -1;
@@ -438,10 +480,9 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
             const double m2 = cur_m + cut - dst;
             if (m2 * 1.0 <= worst) {
                 if (sp + 1 > levels) { ovf = true; break; }
-                if (gl == 0) {
-                    st_rec[sp] = ((go_left ? nd.right : nd.left) << 2) | ((int)nd.col << 1);
-                    st_m[sp] = m2; st_c[sp] = cut; st_d[sp] = dst;
-                }
+                const int nrec = ((go_left ? nd.right : nd.left) << 2) | ((int)nd.col << 1);
+                if constexpr (LANE_STACK) { if (gl == sp) { l_rec = nrec; l_m = m2; l_c = cut; l_d = dst; } }
+                else if (gl == 0) { st_rec[sp] = nrec; st_m[sp] = m2; st_c[sp] = cut; st_d[sp] = dst; }
                 sp++;
             }
             cur = go_left ? nd.left : nd.right;   // best child, same mindistsq
@@ -469,12 +510,12 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
     if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(pub.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
     __syncthreads();
     if (!s_last) return;
-    for (unsigned i = threadIdx.x; i < pub.n8; i += 4 * kPmThreads) {   // four words in flight per lane
+    for (unsigned i = threadIdx.x; i < pub.n8; i += 4 * (unsigned)nthr) {   // four words in flight per lane
         unsigned long long v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) if (i + u * kPmThreads < pub.n8) v[u] = __hip_atomic_load(pub.dev_out + i + u * kPmThreads, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int u = 0; u < 4; u++) if (i + u * nthr < pub.n8) v[u] = __hip_atomic_load(pub.dev_out + i + u * nthr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int u = 0; u < 4; u++) if (i + u * kPmThreads < pub.n8) __hip_atomic_store(pub.host_out + i + u * kPmThreads, v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int u = 0; u < 4; u++) if (i + u * nthr < pub.n8) __hip_atomic_store(pub.host_out + i + u * nthr, v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (threadIdx.x == 0) {
         const int ov = __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -639,27 +680,21 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
     }
     static const bool pm_clk = getenv("UH_PM_CLK") != nullptr;
     if (pm_clk) { const unsigned magic[2] = {0u, 0x434c4bu}; UH_HIP_CHECK(hipMemcpyAsync(base, magic, 8, hipMemcpyHostToDevice, st)); }
-    {   // one pinned staging block (the previous call's launches are complete: its results were awaited), one wide copy launch
-        if ((rc = h->h_in.reserve(o_bk))) return rc;
+    {   // one pinned staging block (the previous call's launches are complete: its results were awaited): the candidates as 64-byte records
+        if ((rc = h->h_in.reserve(o_pos + 64 * (size_t)n + 64))) return rc;
         char* hi = h->h_in.host<char>();
-        std::memcpy(hi + o_pos, mp->pos3d, 12 * (size_t)n);
-        if (prev) std::memcpy(hi + o_min, octave, 4 * (size_t)n);   // the octaves travel in the min_dist slot
-        else {
-            std::memcpy(hi + o_nrm, mp->normal, 12 * (size_t)n);
-            std::memcpy(hi + o_min, mp->min_dist, 4 * (size_t)n);
-            std::memcpy(hi + o_max, mp->max_dist, 4 * (size_t)n);
+        float* rec = reinterpret_cast<float*>(hi + o_pos);
+        for (int i = 0; i < n; i++, rec += 16) {
+            rec[0] = mp->pos3d[3 * i]; rec[1] = mp->pos3d[3 * i + 1]; rec[2] = mp->pos3d[3 * i + 2];
+            if (prev) { std::memcpy(rec + 3, octave + i, 4); rec[4] = rec[5] = rec[6] = rec[7] = 0.f; }
+            else { rec[3] = mp->normal[3 * i]; rec[4] = mp->normal[3 * i + 1]; rec[5] = mp->normal[3 * i + 2]; rec[6] = mp->min_dist[i]; rec[7] = mp->max_dist[i]; }
+            std::memcpy(rec + 8, mp->desc + 32 * (size_t)i, 32);
         }
-        std::memcpy(hi + o_desc, mp->desc, 32 * (size_t)n);
         std::atomic_thread_fence(std::memory_order_release);
     }
     PmPoints P;
     P.n = n;
-    {   // (read by the kernel where they lie, in the pinned block: every group fetches its own candidate once)
-        const char* in = h->h_in.dev<char>();
-        P.pos3d = (const float*)(in + o_pos); P.normal = (const float*)(in + o_nrm); P.min_dist = (const float*)(in + o_min);
-        P.max_dist = (const float*)(in + o_max); P.desc = (const uint64_t*)(in + o_desc);
-        P.octave = (const int*)(in + o_min);
-    }
+    P.rec = reinterpret_cast<const uint4*>(h->h_in.dev<char>() + o_pos);   // (read by the kernel where they lie: every wave fetches its own candidate once)
     P.best_kp = (int*)(base + o_bk); P.best_dist = (float*)(base + o_bd); P.visible = (unsigned char*)(base + o_vis);
     PmPose ps;
     const float* T = pose_f2g;
@@ -673,26 +708,37 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
     }
     {
         const int n_nodes = (int)h->kd.nodes.size(), levels = h->kd.max_depth + 2;
-        const size_t stack_bytes = (size_t)levels * kGroupsPerWave * 24 + (size_t)kCandCap * kGroupsPerWave * 8 + 64;
+        // Points per workgroup (= waves: one point per wave).  The walk is issue-bound — ~70 instructions per tree step and point, whatever shares
+        // the SIMD — so the points are spread over as many compute units as there are: 800 previous-frame items ran on 50 CUs at 16 per
+        // workgroup (match_prev 58 us); every workgroup stages the frame itself (~80 KB from L2: 2-3 us), so not below 4.
+        const int ncu = std::max(h->ctx->num_cus, 64);
+        const int gpw = std::min(kGroupsMax, std::max(4, uh_div_up(n, ncu)));
+        const size_t stack_bytes = (size_t)levels * gpw * 24 + (size_t)kCandCap * gpw * 8 + 64;
         const size_t tree_bytes = (((size_t)n_nodes * sizeof(KdNodeDev) + 15) & ~(size_t)15) + 16 * (size_t)h->n_kpts;
         const bool in_lds = tree_bytes + stack_bytes <= kLdsBudget && !getenv("UH_PROJMATCH_NO_LDS");   // env: test knob for the big-frame path
         const size_t lds = stack_bytes + (in_lds ? tree_bytes : 0);
         if (!h->attr_set) {
-            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(projmatch_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(projmatch_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(projmatch_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(projmatch_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+#define UH_PM_ATTR(A, B, C) UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(projmatch_kernel<A, B, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget))
+            UH_PM_ATTR(true, false, true); UH_PM_ATTR(false, false, true); UH_PM_ATTR(true, true, true); UH_PM_ATTR(false, true, true);
+            UH_PM_ATTR(true, false, false); UH_PM_ATTR(false, false, false); UH_PM_ATTR(true, true, false); UH_PM_ATTR(false, true, false);
+#undef UH_PM_ATTR
             h->attr_set = true;
         }
-        const dim3 grid(std::min(uh_div_up(n, kGroupsPerWave), kPmMaxBlocks));
+        const dim3 grid(std::min(uh_div_up(n, gpw), kPmMaxBlocks));
         int* d_ovf = (int*)(base + o_ovf);
         const unsigned long long word = ++h->seq;
         const PmPublish pub{reinterpret_cast<unsigned*>(base + 128), reinterpret_cast<const unsigned long long*>(base + o_bk), reinterpret_cast<unsigned long long*>(h->h_out.dev<char>() + 64),
                             (unsigned)(out_bytes / 8), h->h_out.dev<unsigned long long>(), word};
-        if (in_lds && !prev) UH_LAUNCH(h->ctx, (projmatch_kernel<true, false>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf, pub);
-        else if (!prev) UH_LAUNCH(h->ctx, (projmatch_kernel<false, false>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf, pub);
-        else if (in_lds) UH_LAUNCH(h->ctx, (projmatch_kernel<true, true>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf, pub);
-        else UH_LAUNCH(h->ctx, (projmatch_kernel<false, true>), grid, dim3(kPmThreads), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf, pub);
+        const bool lane_stack = levels <= kGroup;
+#define UH_PM_LAUNCH(A, B, C) UH_LAUNCH(h->ctx, (projmatch_kernel<A, B, C>), grid, dim3(gpw * kGroup), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf, pub)
+        if (lane_stack) {
+            if (in_lds && !prev) UH_PM_LAUNCH(true, false, true); else if (!prev) UH_PM_LAUNCH(false, false, true);
+            else if (in_lds) UH_PM_LAUNCH(true, true, true); else UH_PM_LAUNCH(false, true, true);
+        } else {
+            if (in_lds && !prev) UH_PM_LAUNCH(true, false, false); else if (!prev) UH_PM_LAUNCH(false, false, false);
+            else if (in_lds) UH_PM_LAUNCH(true, true, false); else UH_PM_LAUNCH(false, true, false);
+        }
+#undef UH_PM_LAUNCH
     }
     UH_HIP_CHECK(hipGetLastError());
     // results: the kernel's last workgroup copies [best_kp | best_dist | visible] and the overflow flag into pinned memory and posts the completion word
