@@ -42,7 +42,7 @@ namespace {
 constexpr int kLeafMax = 10;          // picoflann _maxLeafSize
 constexpr int kMaxDepth = 90;         // deeper trees (pathological inputs) are refused: the walk stacks live in LDS
 constexpr size_t kLdsBudget = 150 * 1024;   // of the CU's 160 KB
-constexpr int kPmThreads = 1024;      // at most sixteen waves share the LDS copy of the frame (the launch picks 4 .. 16: see uh_projmatch_match)
+constexpr int kPmThreads = 768;       // at most twelve waves share the LDS copy of the frame (the launch picks 4 .. 12: see uh_projmatch_match; 170 registers per lane)
 constexpr int kGroup = 64;            // lanes per map point: ONE point per wave (round 5; a leaf holds <= 10 keypoints, the drain uses all 64)
 constexpr int kGroupsMax = kPmThreads / kGroup;   // groups (map points in flight) per workgroup, at most
 constexpr int kPmMaxBlocks = 768;     // workgroups loop over chunks of 16 map points: the frame is staged once per workgroup
@@ -413,12 +413,114 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
         // to float, which the (float) cast hides), hence mindistsq' = mindistsq + cut - dst and whether the other child
         // will be searched at all.  Only nodes whose other child WILL be searched leave a record (most do not); the record
         // is turned into "restore dists[col]" in place when the other child is entered.
+        int n_iter = 0, n_leaf = 0;
+        // ---- Round 5: the walk of ONE point spread over the lanes of its wave.  This is a RADIUS search (`worst` never changes), and what a
+        // node sees — mindistsq and the two dists[] entries — depends on the path from the root only (entering an "other" child sets
+        // dists[col] = cut, a best child inherits everything; what a finished subtree leaves behind is the old value rounded to float, which
+        // every later use casts to float anyway), so the subtrees can be expanded side by side: lane 0 starts at the root, every lane follows
+        // its best-child chain down to a leaf, and whenever the other child must be searched too it is handed to a free lane (all of a level's
+        // hand-overs at once: ballot, prefix count, ds_bpermute of the child's state).  A lane's path is its KEY — bit (63 - depth) set
+        // where it was the "other" child — and the leaves' depth-first order, which the candidate list must keep (best / second without
+        // demotion is order-dependent), is the order of the keys.  ~tree-depth steps of ~60 instructions instead of one ~90-instruction
+        // step per visited node; the launch ended with its heaviest point (radius 15 px x scale x 1.6: 60+ visited nodes).
+        // More than 64 leaves (or levels): the serial walk below.
+        bool walked = false;
+        if constexpr (LANE_STACK) {
+            int node = gl == 0 ? 0 : -1;      // >= 0: node to expand; -1: free lane; -2: this lane has reached its leaf
+            double pm = (double)distsq, pd0 = dd0, pd1 = dd1;
+            unsigned long long key = 0;
+            int lbeg = 0, lcnt = 0;
+            int nl = 1;                       // lanes in use (wave-uniform)
+            bool fits = true;
+            for (int depth = 0;; ++depth) {
+                const bool act = node >= 0;
+                if (__ballot(act) == 0) break;
+                if (depth >= 64) { fits = false; break; }
+                const int nsafe = act ? node : 0;
+                const uint2* np = reinterpret_cast<const uint2*>(IN_LDS ? s_nodes + nsafe : f.nodes + nsafe);
+                uint2 w0 = np[0], w1 = np[1], w2 = np[2];
+                asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w1.x), "+v"(w1.y), "+v"(w2.x), "+v"(w2.y));
+                const float divlow = __uint_as_float(w0.x), divhigh = __uint_as_float(w0.y);
+                const int left = (int)w1.x, right = (int)w1.y;
+                const int col = (int)(w2.y >> 16);
+                const bool isleaf = left < 0;
+                if (act && isleaf) { lbeg = (int)w2.x; lcnt = (int)(w2.y & 0xFFFFu); node = -2; }
+                const bool inner = act && !isleaf;
+                const double val = col == 0 ? px : py;
+                const double diff1 = val - divlow, diff2 = val - divhigh;
+                const bool go_left = diff1 + diff2 < 0;
+                const double cut = go_left ? diff2 * diff2 : diff1 * diff1;
+                const float dst = (float)(col == 0 ? pd0 : pd1);
+                const double m2 = pm + cut - dst;
+                const bool wantB = inner && (m2 * 1.0 <= worst);
+                const unsigned long long mb = __ballot(wantB);
+                const int cntB = __popcll(mb);
+                if (nl + cntB > kGroup) { fits = false; break; }
+                if (cntB) {
+                    int src = gl, k = 0;      // receiving lane nl + k pulls from the k-th lane that hands a child over
+                    for (unsigned long long t = mb; t; t &= t - 1, ++k) { const int b = __builtin_ctzll(t); src = gl == nl + k ? b : src; }
+                    const int bnode = go_left ? right : left;
+                    const double bd0 = col == 0 ? cut : pd0, bd1 = col == 0 ? pd1 : cut;
+                    const unsigned long long bkey = key | (1ull << (63 - depth));
+                    const int sa = src << 2;
+                    auto pull64 = [&](unsigned long long v) {
+                        const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(sa, (int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_ds_bpermute(sa, (int)(unsigned)(v >> 32));
+                        return ((unsigned long long)hi << 32) | lo;
+                    };
+                    const int r_node = __builtin_amdgcn_ds_bpermute(sa, bnode);
+                    const double r_m = __longlong_as_double((long long)pull64((unsigned long long)__double_as_longlong(m2)));
+                    const double r_d0 = __longlong_as_double((long long)pull64((unsigned long long)__double_as_longlong(bd0)));
+                    const double r_d1 = __longlong_as_double((long long)pull64((unsigned long long)__double_as_longlong(bd1)));
+                    const unsigned long long r_key = pull64(bkey);
+                    if (gl >= nl && gl < nl + cntB) { node = r_node; pm = r_m; pd0 = r_d0; pd1 = r_d1; key = r_key; }
+                    nl += cntB;
+                }
+                if (inner) node = go_left ? left : right;   // the best child: same mindistsq, same dists, same key
+                ++n_iter;
+            }
+            if (fits) {
+                walked = true;
+                n_leaf = nl;
+                // every used lane holds one leaf.  Its slots' place in the depth-first order: the leaf counts of all leaves with a smaller key
+                int off = 0, total = 0;
+                for (int j = 0; j < nl; j++) {
+                    const unsigned long long kj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, j);
+                    const int cj = __builtin_amdgcn_readlane(lcnt, j);
+                    off += kj < key ? cj : 0;
+                    total += cj;
+                }
+                for (int s0 = 0; s0 < total; s0 += kGroup) {
+                    const int sidx = s0 + gl;
+                    int kp = -1;
+                    for (int j = 0; j < nl; j++) {
+                        const int oj = __builtin_amdgcn_readlane(off, j), cj = __builtin_amdgcn_readlane(lcnt, j), bj = __builtin_amdgcn_readlane(lbeg, j);
+                        kp = (sidx >= oj && sidx < oj + cj) ? bj + (sidx - oj) : kp;
+                    }
+                    bool hit = false;
+                    unsigned int id = 0;
+                    int oc = 0;
+                    if (kp >= 0) {
+                        const float4 c = IN_LDS ? s_rec[kp] : f.leaf_rec[kp];
+                        const unsigned io = __float_as_uint(c.z);
+                        id = io >> 4; oc = (int)(io & 15u);
+                        const double dx = px - c.x;
+                        double sqd = dx * dx;
+                        if (!(sqd > worst)) { const double dy = py - c.y; sqd += dy * dy; }
+                        hit = sqd < worst && oc >= oct_lo && oc <= predicted;
+                    }
+                    const unsigned long long hm = __ballot(hit);
+                    if (hit) s_cand[ncand + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u))] = (id << 4) | (unsigned int)oc;
+                    ncand += __popcll(hm);
+                    if (ncand > kCandCap - kGroup) { drain(ncand); ncand = 0; }
+                }
+            }
+        }
         int sp = 0;
         int l_rec = 0; double l_m = 0, l_c = 0; float l_d = 0;   // LANE_STACK: this lane's walk record (lane = stack slot)
-        int cur = 0;                 // node to visit (-1: take the top record)
-        int n_iter = 0, n_leaf = 0;
+        int cur = walked ? -1 : 0;   // node to visit (-1: take the top record; walked: nothing left to do)
         double cur_m = (double)distsq;
         for (;;) {
+            if (walked) break;
             ++n_iter;
             if (cur < 0) {
                 if (sp == 0) break;
