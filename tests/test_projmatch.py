@@ -242,3 +242,25 @@ def test_hip_projmatch_prev_frame_edge_inputs(hip_ctx, oracle, monkeypatch):
     ref = oracle_lib.proj_match_prev(oracle, fr2, mp, pose, 8.0, 15.0)
     assert got["matches"].tobytes() == ref["matches"].tobytes() and len(ref["matches"]) > 10
     np.testing.assert_array_equal(got["best_kp"], ref["best_kp"])
+
+
+@pytest.mark.gpu
+def test_hip_projmatch_discs_wider_than_64_leaves_take_the_serial_walk(hip_ctx, oracle):
+    """Round 5 spreads the walk of one point over the 64 lanes of its wave, one leaf per lane; a disc that covers more than 64 leaves (here:
+    120 px x scale x 1.6 on 4000 keypoints — hundreds of keypoints per disc) falls back to the serial walk.  Both matchers, same order-
+    dependent results as picoflann's recursion."""
+    from ucoslam_cv3_amd.projmatch import ProjectionMatcher
+
+    fr, mp, pose = synth.proj_problem(4000, 1500, 12, low_entropy=True)
+    pm = ProjectionMatcher(hip_ctx)
+    pm.setFrame(fr["und_kpts"], fr["desc"], fr["scale_factors"], fr["fx"], fr["fy"], fr["cx"], fr["cy"], fr["min_xy"], fr["max_xy"])
+    got = pm.matchFrameToMapPoints(pose, mp["ids"], mp["pos3d"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], 3.0, 120.0)
+    ref = oracle_lib.proj_match(oracle, fr, mp, pose, 3.0, 120.0)
+    np.testing.assert_array_equal(got["best_kp"], ref["best_kp"])
+    np.testing.assert_array_equal(got["best_dist"][ref["best_kp"] >= 0], ref["best_dist"][ref["best_kp"] >= 0])
+    assert got["matches"].tobytes() == ref["matches"].tobytes()
+    got = pm.matchFrameToPrevFrame(pose, mp["ids"], mp["pos3d"], mp["octave"], mp["desc"], 100.0, 120.0)
+    ref = oracle_lib.proj_match_prev(oracle, fr, mp, pose, 100.0, 120.0)
+    np.testing.assert_array_equal(got["best_kp"], ref["best_kp"])
+    np.testing.assert_array_equal(got["best_dist"], ref["best_dist"])
+    assert got["matches"].tobytes() == ref["matches"].tobytes()
