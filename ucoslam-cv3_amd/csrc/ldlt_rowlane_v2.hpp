@@ -79,6 +79,11 @@ __device__ __forceinline__ bool ldlt_rowlane_v2(double* M, int n, int ld, int nf
         const int r = lane < nrow ? lane : nrow - 1;   // idle lanes shadow the last row
         double* const Mr = M + r * ld;
         double lprev[6] = {0, 0, 0, 0, 0, 0};
+        // A zero or non-finite pivot is detected ONCE, behind the last one: d = 0 gives r0 = inf and e = NaN, d = inf gives r0 = 0 and e = NaN,
+        // a NaN stays one — and the refined reciprocal carries it into the next pivot's column (lane k0 + j + 1 takes a[j] * l * ikj), so the
+        // LAST reciprocal is non-finite exactly when some pivot was bad.  (Rounds 3-5a tested every pivot: a class test, a compare and two
+        // scalar ORs on wave 0's issue-bound step, 48 times.)
+        double ikl = 1.0;
         for (int kb = 0; kb < nb; kb++) {
             const int k0 = 6 * kb;
             double a[6];
@@ -99,12 +104,12 @@ __device__ __forceinline__ bool ldlt_rowlane_v2(double* M, int n, int ld, int nf
 #pragma unroll
             for (int j = 0; j < 6; j++) {
                 const double dj = readlane_f64(a[j], k0 + j);
-                failed = failed || dj == 0.0 || !isfinite(dj);
                 // 1/d: v_rcp_f64 (2^-23 relative) and ONE cubic step r0 (1 + e + e^2), e = 1 - d r0: error e^3 = 2^-69.  (Tried: the next pivot's
                 // column as (a - p r0) - (p r0)(e + e^2), one dependent operation less on the chain — two instructions more, 7 % slower.)
                 const double r0 = __builtin_amdgcn_rcp(dj);
                 const double e = fma(-dj, r0, 1.0);
                 const double ikj = fma(fma(e, e, e), r0, r0);
+                ikl = ikj;
                 lprev[j] = a[j] * ikj;
                 if (j + 1 < 6) a[j + 1] = fma(-(a[j] * readlane_f64(a[j], k0 + j + 1)), ikj, a[j + 1]);
 #pragma unroll
@@ -115,6 +120,7 @@ __device__ __forceinline__ bool ldlt_rowlane_v2(double* M, int n, int ld, int nf
             for (int j = 0; j < 6; j++) { yo[j * 64] = a[j]; Mr[k0 + j] = lprev[j]; }
             if (FINAL_BARRIER || kb + 1 < nb) __syncthreads();   // panel kb is in M / s_y[kb & 1]; the trailing update of panel kb - 1 is complete
         }
+        failed = !isfinite(ikl);
     } else {
         const int nthr = (int)blockDim.x - 64;
         for (int kb = 0; kb < (FINAL_BARRIER ? nb : nb - 1); kb++) {
