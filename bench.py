@@ -488,6 +488,20 @@ def main():
         stage_ms["pnp_ms_per_solve_600_matches"] = timed(lambda: check(L.uh_pnp_solve_dev(
             pnp._h, dev_ptr(pd["pose"]), dev_ptr(pd["intr"]), 600, dev_ptr(pd["p3d"]), dev_ptr(pd["kp"]), dev_ptr(pd["invsig"]), dev_ptr(pd["weight"]),
             dev_ptr(pwork), dev_ptr(pout[0]), dev_ptr(pout[1]), dev_ptr(pout[2]), dev_ptr(pout[3]))), 20)
+        # also outside the metric's step: what FrameMatcher_Flann really runs per frame pair — xflann's hierarchical k-means index (k = 32) built on
+        # the 10 000 train descriptors (host, as in the reference: the build is xflann's own byte layout) and searched with 16 checks for the
+        # frame's 2000 queries (GPU); the CPU leg beside it is cpu_baseline.match_hkmeans32_checks16_build_plus_search_ms_1_thread
+        try:
+            km_train, _ = synth.match_set(1, NT, seed=7)
+            t_b = time.perf_counter()
+            km_index = Index(ctx).build_kmeans(km_train, 32, 0)
+            torch.cuda.synchronize()
+            stage_ms["hkmeans32_build_ms_10000_rows_host"] = 1e3 * (time.perf_counter() - t_b)
+            km_q = orb_out[1][0]
+            km_index.search_kmeans(km_q, NN, 16, sorted=False)
+            stage_ms["hkmeans32_search_ms_2000q_checks16"] = timed(lambda: km_index.search_kmeans(km_q, NN, 16, sorted=False), 30)
+        except Exception as e_:
+            print("hkmeans stage skipped:", repr(e_), file=sys.stderr)
         # also outside the metric's step: the projection matcher (Map::matchFrameToMapPoints), 2000 keypoints x 3000 candidate
         # map points, host buffers in and out as the reference's call site has them (includes one H2D and one D2H)
         from ucoslam_cv3_amd.projmatch import ProjectionMatcher
