@@ -835,7 +835,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(W, W))) v
     // redo_count[0] = overflowed queries of this launch, [2] = replay workgroups that have finished their lists, [4] = ... their redo share,
     // [6] = ... their part of the copy to the host; redo_next likewise for the next launch
     if ((int)blockIdx.x >= nrep) {
-        accept_scan<(W < 5 ? 1 : 2), kScanStream, (W < 5 ? 4 : 2)>(train, t0, t1, queries, nq, K, maxd, cand, nullptr, cap, (int)blockIdx.x - nrep, prog, tag);
+        accept_scan<(W < 5 ? 1 : 2), kScanStream, (W < 4 ? 4 : 2)>(train, t0, t1, queries, nq, K, maxd, cand, nullptr, cap, (int)blockIdx.x - nrep, prog, tag);
         return;
     }
     __shared__ unsigned s_stage[kStreamStage * kWave];
@@ -1665,10 +1665,12 @@ static int knn_search_dev_impl(uh_knn* idx, const uint8_t* d_queries, int nq, in
             static const long long stream_timeout = [] { const char* e = getenv("UH_KNN_STREAM_TIMEOUT_MS"); const long long ms = e ? atoll(e) : 0; return ms > 0 ? ms * 100000ll : kStreamTimeoutDefault; }();
             const int nrep = uh_div_up(nq, kWave);
             const bool few = few_form;
-            const dim3 gs(nrep + (few ? nq : uh_div_up(nq, 2)));
+            const bool few3 = !few && nn >= idx->stream_min_nn && nrep + nq <= 3 * 4 * std::max(idx->ctx->num_cus, 64);   // one query per scan wave at three waves per SIMD (2000 < queries <= ~3000; 170 registers)
+            const bool few4 = !few && !few3 && nn >= idx->stream_min_nn && nrep + nq <= 4 * 4 * std::max(idx->ctx->num_cus, 64);   // ... at four (two row groups in rotation: 128 registers)
+            const dim3 gs(nrep + (few || few3 || few4 ? nq : uh_div_up(nq, 2)));
 #define UH_KNN_STREAM_W(K, W) UH_LAUNCH(idx->ctx, (knn_stream_kernel<K, W>), gs, dim3(kWave), 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, sorted ? 1 : 0, max_dist, \
             d_cand, d_prog, cap, tag, nrep, d_indices, d_distances, d_redo, d_nredo + (tag & 1u), d_nredo + ((tag + 1u) & 1u), stream_timeout, ho)
-#define UH_KNN_STREAM(K) case K: if (few) UH_KNN_STREAM_W(K, 2); else UH_KNN_STREAM_W(K, 5); break
+#define UH_KNN_STREAM(K) case K: if (few) UH_KNN_STREAM_W(K, 2); else if (few3) UH_KNN_STREAM_W(K, 3); else if (few4) UH_KNN_STREAM_W(K, 4); else UH_KNN_STREAM_W(K, 5); break
             switch (nn) {
                 UH_KNN_STREAM(1); UH_KNN_STREAM(2); UH_KNN_STREAM(3); UH_KNN_STREAM(4); UH_KNN_STREAM(5); UH_KNN_STREAM(6); UH_KNN_STREAM(7); UH_KNN_STREAM(8);
                 UH_KNN_STREAM(9); UH_KNN_STREAM(10); UH_KNN_STREAM(11); UH_KNN_STREAM(12); UH_KNN_STREAM(13); UH_KNN_STREAM(14); UH_KNN_STREAM(15); UH_KNN_STREAM(16);
