@@ -782,6 +782,7 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
     }
     static const bool pm_clk = getenv("UH_PM_CLK") != nullptr;
     if (pm_clk) { const unsigned magic[2] = {0u, 0x434c4bu}; UH_HIP_CHECK(hipMemcpyAsync(base, magic, 8, hipMemcpyHostToDevice, st)); }
+    const auto t_pack0 = std::chrono::steady_clock::now();
     {   // one pinned staging block (the previous call's launches are complete: its results were awaited): the candidates as 64-byte records
         if ((rc = h->h_in.reserve(o_pos + 64 * (size_t)n + 64))) return rc;
         char* hi = h->h_in.host<char>();
@@ -794,6 +795,7 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
         }
         std::atomic_thread_fence(std::memory_order_release);
     }
+    if (getenv("UH_PM_TIMING")) fprintf(stderr, "projmatch%s: packing %d records %.1f us\n", prev ? "_prev" : "", n, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_pack0).count());
     PmPoints P;
     P.n = n;
     P.rec = reinterpret_cast<const uint4*>(h->h_in.dev<char>() + o_pos);   // (read by the kernel where they lie: every wave fetches its own candidate once)
