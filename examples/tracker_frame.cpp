@@ -1,8 +1,10 @@
 // The reference tracker's per-frame chain over the C ABI, ONE frame at a time, host buffers in and out of every call — what a drop-in
 // under UcoSlam::process() executes between two camera frames (reference file:line, statement starts of the token-pasted source):
 //
-//   FrameExtractor::process          ORB detectAndCompute + undistortPoints of the frame        uh_orb_extract_frame     frameextractor.cpp:430-520, :3985
-//   Frame::create_kdtree             kd-tree over the undistorted keypoints                   uh_projmatch_set_frame   map_types/frame.h:124
+//   FrameExtractor::process          ORB detectAndCompute + undistortPoints of the frame        uh_orb_extract_frame_dev frameextractor.cpp:430-520, :3985
+//   Frame::create_kdtree             kd-tree over the undistorted keypoints — built ON THE    (inside the call above)  frameextractor.cpp:4258, map_types/frame.h:124
+//                                    DEVICE behind the extractor's completion; the matcher     uh_projmatch_set_frame_dev
+//                                    adopts the device-resident frame (no D2H -> build -> H2D)
 //   tracker: previous-frame search   project the previous frame's map points, match          uh_projmatch_match_prev  utils/system.cpp:5930-6460 (call :6559-6565)
 //   PnPSolver::solvePnp              pose from those matches (4 x 10 LM iterations)           uh_pnp_solve             optimization/pnpsolver.cpp:116-409 (call system.cpp:6626)
 //   Map::matchFrameToMapPoints       the local map projected with the refined pose, 4-px disc  uh_projmatch_match       map.cpp:651-770 (call system.cpp:6897; radius :6762-6881)
@@ -15,7 +17,7 @@
 // so every stage works on data the previous one produced.  Prints one JSON line with the median per-stage and per-frame latencies.
 //
 //   g++ -std=c++17 -O2 -o tracker_frame examples/tracker_frame.cpp -Lucoslam-cv3_amd -lucoslam_hip -Wl,-rpath,$PWD/ucoslam-cv3_amd -Wl,-rpath,/opt/rocm/lib -lpthread
-//   ./tracker_frame [frames=200] [warmup=20]
+//   ./tracker_frame [frames=200] [warmup=20] [route=dev|host]     (host: uh_orb_extract_frame + uh_projmatch_set_frame, the kd-tree built on the CPU)
 #include <algorithm>
 #include <array>
 #include <chrono>
@@ -105,6 +107,7 @@ struct Stat {
 
 int main(int argc, char** argv) {
     const int frames = argc > 1 ? std::atoi(argv[1]) : 200, warmup = argc > 2 ? std::atoi(argv[2]) : 20;
+    const bool dev_route = !(argc > 3 && std::strcmp(argv[3], "host") == 0);
     uh_ctx* ctx = nullptr;
     if (uh_ctx_create_private(0, &ctx) < 0) { std::printf("no device: %s (there is no CPU path)\n", uh_last_error()); return 0; }
     uh_orb* ext = nullptr; uh_projmatch* pm = nullptr; uh_pnp* pnp = nullptr;
@@ -113,6 +116,8 @@ int main(int argc, char** argv) {
     CHECK(uh_orb_set_params(ext, &fp));
     CHECK(uh_projmatch_create(ctx, &pm));
     CHECK(uh_pnp_create(ctx, &pnp));
+    uh_dev_frame* dfr = nullptr;
+    CHECK(uh_dev_frame_create(ctx, &dfr));
     float sf[NLEV]; sf[0] = 1.f; for (int i = 1; i < NLEV; i++) sf[i] = sf[i - 1] * 1.2f;   // the extractor's float chain (ORBextractor.cpp:468-515)
     float inv_sf[NLEV]; for (int i = 0; i < NLEV; i++) inv_sf[i] = (float)(1. / sf[i]);         // pnpsolver.cpp:191-192
     const float intr[4] = {FX, FY, CX, CY};
@@ -225,11 +230,13 @@ int main(int argc, char** argv) {
         int n = 0;
         // FrameExtractor::process: detectAndCompute + undistortPoints(kpts, ImageParams) in one call (frameextractor.cpp:430-520, :3985;
         // misc.cpp:269-293) — Frame::und_kpts = the keypoints with the undistorted positions
-        CHECK(uh_orb_extract_frame(ext, sc.image, W, H, W, 1, kps, desc, und_xy, NFEAT, &n));
+        if (dev_route) CHECK(uh_orb_extract_frame_dev(ext, sc.image, W, H, W, 1, kps, desc, und_xy, NFEAT, &n, dfr));
+        else CHECK(uh_orb_extract_frame(ext, sc.image, W, H, W, 1, kps, desc, und_xy, NFEAT, &n));
         for (int i = 0; i < n; i++) { kps[i].x = und_xy[2 * i]; kps[i].y = und_xy[2 * i + 1]; }
         const double t1 = now_us();
         const uh_proj_frame fr{kps, n, desc, sf, NLEV, FX, FY, CX, CY, 0, 0, W, H};
-        CHECK(uh_projmatch_set_frame(pm, &fr));
+        if (dev_route) CHECK(uh_projmatch_set_frame_dev(pm, dfr, &fr));
+        else CHECK(uh_projmatch_set_frame(pm, &fr));
         const double t2 = now_us();
         const uh_prev_points pp{(int32_t)sc.prev_ids.size(), sc.prev_ids.data(), sc.prev_pos.data(), sc.prev_oct.data(), sc.prev_desc.data()};
         const int n1 = uh_projmatch_match_prev(pm, sc.pose0, &pp, MAX_DESC_DIST * 1.5f, PROJ_DIST_THR, m_prev.data(), (int)m_prev.size(), nullptr, nullptr);
@@ -294,14 +301,14 @@ int main(int argc, char** argv) {
         pose_err = std::max(pose_err, e);
     }
     const double f = frames > 0 ? 1.0 / frames : 0;
-    std::printf("{\"host\": \"c++ over the C ABI, one frame at a time, host in / host out\", \"frames\": %d, \"tracker_frame_ms\": %.4f, \"tracker_frame_ms_min\": %.4f, "
+    std::printf("{\"host\": \"c++ over the C ABI, one frame at a time, host in / host out\", \"frame_route\": \"%s\", \"frames\": %d, \"tracker_frame_ms\": %.4f, \"tracker_frame_ms_min\": %.4f, "
                 "\"tracker_frame_ms_p90\": %.4f, \"tracker_frames_per_s\": %.1f, "
                 "\"orb_extract_ms\": %.4f, \"set_frame_ms\": %.4f, \"match_prev_ms\": %.4f, \"pnp1_ms\": %.4f, \"match_map_ms\": %.4f, \"pnp2_ms\": %.4f, \"host_glue_ms\": %.4f, "
                 "\"keypoints\": %.1f, \"prev_items\": %d, \"map_points\": %d, \"matches_prev\": %.1f, \"matches_map\": %.1f, \"inliers1\": %.1f, \"inliers2\": %.1f, "
                 "\"max_pose_err_vs_truth\": %.5f}\n",
-                frames, t_frame.med() / 1e3, t_frame.lo() / 1e3, t_frame.p90() / 1e3, 1e6 / std::max(t_frame.med(), 1e-9), t_orb.med() / 1e3, t_set.med() / 1e3, t_prev.med() / 1e3,
+                dev_route ? "device-resident frame, kd-tree built on the device" : "keypoints to the host, kd-tree built on the host", frames, t_frame.med() / 1e3, t_frame.lo() / 1e3, t_frame.p90() / 1e3, 1e6 / std::max(t_frame.med(), 1e-9), t_orb.med() / 1e3, t_set.med() / 1e3, t_prev.med() / 1e3,
                 t_pnp1.med() / 1e3, t_map.med() / 1e3, t_pnp2.med() / 1e3, t_glue.med() / 1e3, sum_kp * f, N_PREV, N_MAP, sum_prev * f, sum_map * f, sum_in1 * f, sum_in2 * f, pose_err);
-    uh_pnp_destroy(pnp); uh_projmatch_destroy(pm); uh_orb_destroy(ext);
+    uh_pnp_destroy(pnp); uh_projmatch_destroy(pm); uh_orb_destroy(ext); uh_dev_frame_destroy(dfr);
     for (auto& s : scenes) uh_host_free(s.image);
     uh_host_free(kps); uh_host_free(desc);
     uh_ctx_destroy(ctx);

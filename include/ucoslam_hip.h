@@ -300,6 +300,21 @@ int uh_orb_set_camera(uh_orb* orb, const uh_camera* cam);
 int uh_orb_extract_frame(uh_orb* orb, const uint8_t* img, int w, int h, size_t stride, int channels,
                          uh_keypoint* kps, uint8_t* desc, float* und_xy, int cap, int* n_out);
 int uh_undistort_points_host(const uh_camera* cam, const float* xy, int n, float* out_xy);
+/* The Frame that FrameExtractor::process produces, kept ON THE DEVICE for the tracker (src/utils/frameextractor.cpp:430-520 detectAndCompute,
+ * :3985 undistortPoints, :4258 Frame::create_kdtree -> src/basictypes/picoflann.h:150-163,238-345): uh_orb_extract_frame_dev is
+ * uh_orb_extract_frame (same host outputs, same completion) that also leaves the descriptors and the undistorted keypoints in `frame`
+ * (HBM) and enqueues ONE more launch behind its completion word which builds picoflann's kd-tree there, node for node what the reference
+ * builds on the CPU (up to 4096 keypoints; needs uh_orb_set_camera).  uh_projmatch_set_frame_dev adopts such a frame: nothing goes
+ * device -> host -> device, no tree is built on the host.  A frame object is overwritten by the next extraction into it: keep two to
+ * hold the previous frame.  uh_dev_frame_tree (inspection / tests) waits for the build and copies the tree out: nodes24_out as in
+ * uh_projmatch_debug_tree with room for 2n/5 + 2 nodes, leaf_idx_out / leaf_octave_out n entries, leaf_xy_out 2n floats (any may be NULL). */
+typedef struct uh_dev_frame uh_dev_frame;
+int  uh_dev_frame_create(uh_ctx* ctx, uh_dev_frame** out);
+void uh_dev_frame_destroy(uh_dev_frame* frame);
+int  uh_orb_extract_frame_dev(uh_orb* orb, const uint8_t* img, int w, int h, size_t stride, int channels,
+                              uh_keypoint* kps, uint8_t* desc, float* und_xy, int cap, int* n_out, uh_dev_frame* frame);
+int  uh_dev_frame_tree(uh_dev_frame* frame, int32_t* n_kpts, int32_t* n_nodes, void* nodes24_out, uint32_t* leaf_idx_out, float* leaf_xy_out,
+                       int32_t* leaf_octave_out, double* root_box4, int32_t* max_depth);
 /* `batch` frames resident in HBM (frame f at d_imgs + f*frame_stride); outputs per frame at
  * d_kps + f*cap_per_frame, d_desc + f*cap_per_frame*32, d_counts[f].  Asynchronous on the context stream. */
 int uh_orb_extract_dev(uh_orb* orb, const uint8_t* d_imgs, int w, int h, size_t stride, size_t frame_stride,
@@ -618,6 +633,9 @@ typedef struct uh_projmatch uh_projmatch;
 int  uh_projmatch_create(uh_ctx* ctx, uh_projmatch** out);
 void uh_projmatch_destroy(uh_projmatch* pm);
 int  uh_projmatch_set_frame(uh_projmatch* pm, const uh_proj_frame* frame);
+/* the frame uh_orb_extract_frame_dev left on the device; `params` gives scale factors, camera and image bounds (its und_kpts / n_kpts / desc
+ * are ignored).  `frame` must stay alive and un-overwritten while the matcher uses it. */
+int  uh_projmatch_set_frame_dev(uh_projmatch* pm, uh_dev_frame* frame, const uh_proj_frame* params);
 int  uh_projmatch_match(uh_projmatch* pm, const float* pose_f2g /* row-major 4x4 */, const uh_map_points* points,
                         float min_desc_dist, float max_repj_dist, uh_dmatch* matches_out, int32_t cap,
                         int32_t* best_kp_out /* n or NULL */, float* best_dist_out /* n or NULL */, uint8_t* visible_out /* n or NULL */);
@@ -646,6 +664,11 @@ int  uh_projmatch_debug_tree(uh_projmatch* pm, int32_t* n_nodes, const void** no
 /* the same build as a host-only function (no GPU needed): nodes24_out has room for 2n+2 nodes, leaf_idx_out for n entries */
 int  uh_kdtree_build_host(const float* xy, int32_t n, int32_t* n_nodes, void* nodes24_out, uint32_t* leaf_idx_out,
                           double* root_box4, int32_t* max_depth);
+/* test hooks of the device builder (csrc/kdbuild.hpp): the same outputs from the build kernel (n <= 4096; threads 0 = default, 256, 512 or
+ * 1024), and — host only — the permutation its restatement of libstdc++'s std::sort gives n float keys (compared with std::sort itself) */
+int  uh_kdtree_build_dev(uh_ctx* ctx, const float* xy, int32_t n, int32_t threads, int32_t* n_nodes, void* nodes24_out, uint32_t* leaf_idx_out,
+                         double* root_box4, int32_t* max_depth);
+int  uh_kdtree_sort_restated_host(const float* keys, int32_t n, uint32_t* perm_out);
 
 /* ------------------------------------------------------------------------
  * Measurement hooks (used by scripts/time_ba.py and scripts/knn_push_bench.py; not part of the drop-in surface).

@@ -426,4 +426,13 @@ int oracle_proj_match_prev(const oracle_keypoint* und_kpts, int n_kpts, const ui
     return (int)matches.size();
 }
 
+// libstdc++'s own std::sort on an index array ordered by the keys — the algorithm picoflann's fallback calls (picoflann.h:438-441).
+// tests/test_kdbuild.py holds the product's restatement of its data movement (csrc/kdbuild.hpp) against this.
+void oracle_std_sort_perm(const float* keys, int n, uint32_t* perm) {
+    std::vector<uint32_t> p(n);
+    for (int i = 0; i < n; i++) p[i] = (uint32_t)i;
+    std::sort(p.begin(), p.end(), [keys](const uint32_t& a, const uint32_t& b) { return keys[a] < keys[b]; });
+    for (int i = 0; i < n; i++) perm[i] = p[i];
+}
+
 }  // extern "C"

@@ -1,0 +1,539 @@
+// picoflann's KdTreeIndex<2>::build on the device: ONE workgroup builds the tree of a frame's undistorted keypoints in LDS,
+// node for node and leaf for leaf what src/basictypes/picoflann.h:150-163,238-345 builds on the CPU (Frame::create_kdtree,
+// src/utils/frameextractor.cpp:4258 / map_types/frame.h:124) and what the host restatement KdBuilder (projmatch.hip) builds.
+//
+// The recursion becomes a level-synchronous sweep (every node of a depth at once):
+//   moments      mean / variance of both coordinates over <= ~100 evenly spaced samples, double sums IN SAMPLE ORDER (a rounding per
+//                addition: the order is part of the result) — four lanes per node, one serial chain each
+//   Hoare passes [< cut | == cut | > cut] exactly as picoflann's two scans permute the points (picoflann.h:403-424).  One pass = "with
+//                m points belonging left, the misplaced points in front of b + m (ascending) are exchanged pairwise with the misplaced
+//                points behind (descending)"; the ranks come from ONE prefix sum of the predicate over all points of the level
+//                (segments are contiguous), the pairs meet through two index lists
+//   std::sort    where picoflann falls back to it (a side of the mean split would hold < 10 points — always for 11..19 points): libstdc++'s
+//                introsort = a partitioning phase (median of three, unguarded Hoare partition, heapsort at the depth limit; serial, one lane
+//                per node, nothing to do up to 16 points) followed by an insertion sort, which is a STABLE sort of what the first phase
+//                left — computed here as a rank (smaller keys + equal keys in front) by every point in parallel
+// The first levels are swept by the whole workgroup; once a level holds one node per wave every wave takes a subtree and runs the same
+// sweep alone (no workgroup barrier below that point).  Boxes: picoflann's per-node box is only observable through divhigh (= the tight
+// lower bound of the right subtree) and the root box; lower bounds and the counts of inner nodes climb from the leaves (the second child
+// to arrive at a parent goes on), the root's upper bounds are the maximum over the leaves / cuts that no ancestor's `lbox.hi[dim] = cut`
+// overrides.  Node numbers are picoflann's (children of the r-th split in depth-first order are 2r + 1, 2r + 2).
+#pragma once
+#include <cstdint>
+
+#include "introselect.hpp"   // UH_HD, uh_sel::floor_log2, wave_mem_sync
+
+namespace uh_kd {
+
+constexpr int kLeafMax = 10;        // picoflann _maxLeafSize
+constexpr int kDevMaxPoints = 4096; // one workgroup's LDS holds the points and the nodes up to here (a wave's lanes own <= 64 points each)
+
+struct Elem { float x, y; uint32_t id; };
+
+// ---------------------------------------------------------------------------------------------- libstdc++ std::sort, first phase
+// GCC 11 <bits/stl_algo.h>: std::sort = __introsort_loop(first, last, 2 * lg(n)) + __final_insertion_sort.  The accessor A moves whole
+// points: key(i), get(i), set(i, e), swap(i, j); comp(a, b) = key(a) < key(b).
+template <class A> UH_HD void median_to_first(A& a, int result, int x, int y, int z) {
+    if (a.key(x) < a.key(y)) {
+        if (a.key(y) < a.key(z)) a.swap(result, y);
+        else if (a.key(x) < a.key(z)) a.swap(result, z);
+        else a.swap(result, x);
+    } else if (a.key(x) < a.key(z)) a.swap(result, x);
+    else if (a.key(y) < a.key(z)) a.swap(result, z);
+    else a.swap(result, y);
+}
+
+template <class A> UH_HD int unguarded_partition(A& a, int first, int last, int pivot) {
+    const float pv = a.key(pivot);   // (the pivot slot lies outside [first, last))
+    for (;;) {
+        while (a.key(first) < pv) ++first;
+        --last;
+        while (pv < a.key(last)) --last;
+        if (!(first < last)) return first;
+        a.swap(first, last);
+        ++first;
+    }
+}
+
+// std::__adjust_heap + std::__push_heap
+template <class A> UH_HD void adjust_heap(A& a, int first, int hole, int len, const Elem& value) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (a.key(first + child) < a.key(first + child - 1)) child--;
+        a.set(first + hole, a.get(first + child));
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        a.set(first + hole, a.get(first + child - 1));
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && a.key(first + parent) < a.ekey(value)) {
+        a.set(first + hole, a.get(first + parent));
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a.set(first + hole, value);
+}
+
+// std::__partial_sort(first, last, last): __heap_select (= __make_heap, nothing behind middle) + __sort_heap
+template <class A> UH_HD void heap_sort(A& a, int first, int last) {
+    const int len = last - first;
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        for (;;) {
+            const Elem value = a.get(first + parent);
+            adjust_heap(a, first, parent, len, value);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    while (last - first > 1) {   // __pop_heap(first, last, last)
+        --last;
+        const Elem value = a.get(last);
+        a.set(last, a.get(first));
+        adjust_heap(a, first, 0, last - first, value);
+    }
+}
+
+// __introsort_loop: the recursion on the right part becomes a stack (disjoint ranges: the order in which they are processed does not
+// change the data movement inside either).  What is left for the insertion sort that follows is "a stable sort of this".
+template <class A> UH_HD void sort_phase(A& a, int first, int last) {
+    if (last - first <= 16) return;
+    struct Fr { int first, last, depth; };
+    Fr st[40];   // depth limits strictly decrease from the bottom of the stack to its top: <= 2 lg(n) + 1 entries
+    int sp = 0;
+    st[sp++] = Fr{first, last, 2 * uh_sel::floor_log2(last - first)};
+    while (sp) {
+        const Fr f = st[--sp];
+        int fi = f.first, la = f.last, dl = f.depth;
+        while (la - fi > 16) {
+            if (dl == 0) { heap_sort(a, fi, la); break; }
+            --dl;
+            const int mid = fi + (la - fi) / 2;
+            median_to_first(a, fi, fi + 1, mid, la - 1);
+            const int cut = unguarded_partition(a, fi + 1, la, fi);
+            st[sp++] = Fr{cut, la, dl};
+            la = cut;
+        }
+    }
+}
+
+// LDS need of kd_build_workgroup for up to n_cap points and nwaves waves (host and device agree on the layout through this)
+UH_HD int node_cap(int n_cap, int nwaves) { return 2 * n_cap / 5 + 4 * nwaves + 8; }
+UH_HD size_t lds_bytes(int n_cap, int nwaves) {
+    const size_t n = (size_t)n_cap + 2, m = (size_t)node_cap(n_cap, nwaves);
+    size_t b = m * 8;                 // ncut
+    b += n * 4 * 3;                   // px, py, S (u32: doubles as the float scratch of the fallback permutation)
+    b += m * 4 * 4;                   // nlo[2], ndivhigh, nlim
+    b += n * 2 * 3;                   // ord, eseg, scr
+    b += m * 2 * 5;                   // nb, ne, nchild, npar, ncnt
+    b += m;                           // nflag
+    return (b + 64 + 15) & ~(size_t)15;
+}
+
+}  // namespace uh_kd
+
+#if defined(__HIPCC__)
+namespace uh_kd {
+
+struct Lds {
+    double* ncut;
+    float* px; float* py; unsigned* S;
+    float* nlo; float* ndivhigh; unsigned* nlim;
+    unsigned short* ord; unsigned short* eseg; unsigned short* scr;
+    unsigned short* nb; unsigned short* ne; unsigned short* nchild; unsigned short* npar; unsigned short* ncnt;
+    unsigned char* nflag;   // bit 0 split dimension, bit 1 std::sort fallback taken, bits 2-3 "an ancestor's cut overrides my upper bound in x / y"
+    int m_cap;
+};
+
+__device__ __forceinline__ Lds carve(unsigned char* base, int n_cap, int nwaves) {
+    const size_t n = (size_t)n_cap + 2, m = (size_t)node_cap(n_cap, nwaves);
+    Lds V;
+    unsigned char* p = base;
+    V.ncut = reinterpret_cast<double*>(p); p += m * 8;
+    V.px = reinterpret_cast<float*>(p); p += n * 4;
+    V.py = reinterpret_cast<float*>(p); p += n * 4;
+    V.S = reinterpret_cast<unsigned*>(p); p += n * 4;
+    V.nlo = reinterpret_cast<float*>(p); p += m * 8;
+    V.ndivhigh = reinterpret_cast<float*>(p); p += m * 4;
+    V.nlim = reinterpret_cast<unsigned*>(p); p += m * 4;
+    V.ord = reinterpret_cast<unsigned short*>(p); p += n * 2;
+    V.eseg = reinterpret_cast<unsigned short*>(p); p += n * 2;
+    V.scr = reinterpret_cast<unsigned short*>(p); p += n * 2;
+    V.nb = reinterpret_cast<unsigned short*>(p); p += m * 2;
+    V.ne = reinterpret_cast<unsigned short*>(p); p += m * 2;
+    V.nchild = reinterpret_cast<unsigned short*>(p); p += m * 2;
+    V.npar = reinterpret_cast<unsigned short*>(p); p += m * 2;
+    V.ncnt = reinterpret_cast<unsigned short*>(p); p += m * 2;
+    V.nflag = p;
+    V.m_cap = (int)m;
+    return V;
+}
+
+struct LdsAcc {   // the points of one node as std::sort sees them, keyed by coordinate `dim`
+    const Lds& V; int dim;
+    __device__ __forceinline__ float key(int i) const { return dim ? V.py[i] : V.px[i]; }
+    __device__ __forceinline__ float ekey(const Elem& e) const { return dim ? e.y : e.x; }
+    __device__ __forceinline__ Elem get(int i) const { return Elem{V.px[i], V.py[i], V.ord[i]}; }
+    __device__ __forceinline__ void set(int i, const Elem& e) const { V.px[i] = e.x; V.py[i] = e.y; V.ord[i] = (unsigned short)e.id; }
+    __device__ __forceinline__ void swap(int i, int j) const { const Elem a = get(i), b = get(j); set(i, b); set(j, a); }
+};
+
+constexpr unsigned short kNoNode = 0xFFFF, kRootPar = 0xFFFE;
+
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl((int)(b & 0xffffffffll), src), hi = __shfl((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+template <bool WG> __device__ __forceinline__ void team_sync() {
+    if (WG) __syncthreads(); else uh_sel::wave_mem_sync();
+}
+
+// exclusive prefix of v over the team's threads and the team total (WG: through s_w, one word per wave; the callers' next team_sync
+// separates two uses of s_w)
+template <bool WG> __device__ __forceinline__ int team_excl_scan(int v, int& total, unsigned* s_w) {
+    const int lane = threadIdx.x & 63;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    if (!WG) { total = __shfl(inc, 63); return inc - v; }
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 63) s_w[wave] = (unsigned)inc;
+    __syncthreads();
+    int pre = 0, tot = 0;
+    for (int w = 0; w < nw; w++) { const int x = (int)s_w[w]; pre += w < wave ? x : 0; tot += x; }
+    total = tot;
+    return pre + inc - v;
+}
+
+// Sweeps levels of the tree below the nodes [lvl_b, lvl_e) (depth `depth`) whose points are [eb, ee), with the team's threads tid of nthr
+// (the whole workgroup or one wave); runs at most max_levels levels and leaves the next level's node range and depth behind.  cursor: the
+// team's node allocator; status[0]: "a node of this level took the std::sort fallback", status[1]: children that will split again.
+template <bool WG>
+__device__ void sweep_levels(const Lds& V, const int tid, const int nthr, const int eb, const int ee, int& lvl_b, int& lvl_e, unsigned* cursor,
+                             unsigned* status, unsigned* s_w, int& depth, const int max_levels, unsigned* s_maxdepth) {
+    const int ept = (ee - eb + nthr - 1) / nthr;   // <= 64: the predicate of a thread's points is one 64-bit mask
+    const int i0 = eb + tid * ept;
+    const int lane = threadIdx.x & 63;
+    bool more = lvl_e > lvl_b;
+    for (int lv = 0; lv < max_levels && more; ++lv) {
+        const int nL = lvl_e - lvl_b;
+        const unsigned c0 = *cursor;
+        // ---- mean / variance over the samples, split dimension, cut (picoflann.h:362-401): lanes 4j .. 4j+3 own the four sums of node j
+        for (int q0 = 0; q0 < nL * 4; q0 += nthr) {
+            const int q = q0 + tid, nd = q >> 2, ch = q & 3;
+            const int g = lvl_b + nd;
+            int b = 0, e = 0;
+            bool act = nd < nL;
+            if (act) { b = V.nb[g]; e = V.ne[g]; act = e - b > kLeafMax; }
+            double s = 0;
+            int cnt = 0;
+            if (act) {
+                const int c = e - b;
+                const int step = c >= 200 ? c / 100 : 1;
+                const float* v = (ch & 2) ? V.py : V.px;
+                if (ch & 1) for (int i = b; i < e; i += step, cnt++) { const float x = v[i]; s += (double)(x * x); }
+                else for (int i = b; i < e; i += step, cnt++) s += (double)v[i];
+            }
+            const int l0 = lane & ~3;
+            const double s1x = shfl_f64(s, l0), s2x = shfl_f64(s, l0 + 1), s1y = shfl_f64(s, l0 + 2), s2y = shfl_f64(s, l0 + 3);
+            if (act && ch == 0) {
+                const double inv = 1. / double(cnt);
+                const double m0 = s1x * inv, m1 = s1y * inv;
+                const double v0 = s2x * inv - m0 * m0, v1 = s2y * inv - m1 * m1;
+                const int dim = v1 > v0 ? 1 : 0;
+                V.ncut[g] = dim ? m1 : m0;
+                V.nflag[g] = (unsigned char)((V.nflag[g] & ~3u) | (unsigned)dim);
+            }
+        }
+        // ---- the two Hoare passes: "v < cut" over the node, then "v <= cut" (over the whole node = over its part behind the first limit:
+        // everything in front of it satisfies the predicate and stays where it is)
+        for (int pass = 0; pass < 2; ++pass) {
+            team_sync<WG>();
+            if (pass == 0 && tid == 0) { status[0] = 0; status[1] = 0; }   // (the previous level's readers are a barrier behind)
+            unsigned long long fm = 0, am = 0;
+            for (int k = 0; k < ept; k++) {
+                const int i = i0 + k;
+                if (i >= ee) break;
+                const unsigned g = V.eseg[i];
+                if (g == kNoNode) continue;
+                am |= 1ull << k;
+                const float cutf = (float)V.ncut[g];
+                const float v = (V.nflag[g] & 1) ? V.py[i] : V.px[i];
+                if (pass ? v <= cutf : v < cutf) fm |= 1ull << k;
+            }
+            int total;
+            const int ex = team_excl_scan<WG>(__popcll(fm), total, s_w);
+            for (int k = 0; k < ept; k++) {
+                const int i = i0 + k;
+                if (i >= ee) break;
+                V.S[i] = (unsigned)(ex + __popcll(fm & ((1ull << k) - 1ull)));
+            }
+            team_sync<WG>();
+            for (int k = 0; k < ept; k++) {
+                const int i = i0 + k;
+                if (i >= ee) break;
+                if (!((am >> k) & 1)) continue;
+                const unsigned g = V.eseg[i];
+                const int b = V.nb[g], e = V.ne[g];
+                const int Sb = (int)V.S[b], Se = e == ee ? total : (int)V.S[e], Si = (int)V.S[i];
+                const int m = Se - Sb, mid = b + m;
+                const bool f = (fm >> k) & 1;
+                if (i == b) V.nlim[g] = pass ? (V.nlim[g] | ((unsigned)m << 16)) : (unsigned)m;
+                if (i < mid && !f) V.scr[b + (i - b) - (Si - Sb)] = (unsigned short)i;     // k-th misplaced point of the front part
+                else if (i >= mid && f) V.scr[e - 1 - (Se - Si - 1)] = (unsigned short)i;   // k-th misplaced point counted from the end
+            }
+            team_sync<WG>();
+            for (int k = 0; k < ept; k++) {
+                const int j = i0 + k;
+                if (j >= ee) break;
+                if (!((am >> k) & 1)) continue;
+                const unsigned g = V.eseg[j];
+                const int b = V.nb[g], e = V.ne[g];
+                const int Sb = (int)V.S[b], Se = e == ee ? total : (int)V.S[e];
+                const int mid = b + (Se - Sb);
+                const int Sm = mid == e ? Se : (int)V.S[mid];
+                const int nl = (mid - b) - (Sm - Sb);
+                if (j - b < nl) {
+                    const int iL = V.scr[j], iR = V.scr[e - 1 - (j - b)];
+                    const float ax = V.px[iL], ay = V.py[iL], bx = V.px[iR], by = V.py[iR];
+                    const unsigned short ao = V.ord[iL], bo = V.ord[iR];
+                    V.px[iL] = bx; V.py[iL] = by; V.ord[iL] = bo;
+                    V.px[iR] = ax; V.py[iR] = ay; V.ord[iR] = ao;
+                }
+            }
+        }
+        team_sync<WG>();
+        // ---- where to split (picoflann.h:426-437), the std::sort fallback's serial phase, the two children
+        for (int q0 = 0; q0 < nL; q0 += nthr) {
+            const int nd = q0 + tid;
+            if (nd >= nL) continue;
+            const int g = lvl_b + nd;
+            const int b = V.nb[g], e = V.ne[g], c = e - b;
+            if (c <= kLeafMax) continue;
+            const unsigned lim = V.nlim[g];
+            const int lim1 = (int)(lim & 0xffffu), lim2 = (int)(lim >> 16);
+            int at = c / 2;
+            if (lim1 > c / 2) at = lim1;
+            else if (lim2 < c / 2) at = lim2;
+            if (lim1 == c || lim2 == 0) at = c / 2;
+            unsigned flag = V.nflag[g];
+            if (at < kLeafMax || c - at < kLeafMax) {
+                LdsAcc acc{V, (int)(flag & 1)};
+                sort_phase(acc, b, e);
+                at = c / 2;
+                flag |= 2;
+                atomicOr(&status[0], 1u);
+            }
+            V.nflag[g] = (unsigned char)flag;
+            const unsigned chd = atomicAdd(cursor, 2u);
+            V.nchild[g] = (unsigned short)chd;
+            const unsigned dimbit = 4u << (flag & 1);
+            V.nb[chd] = (unsigned short)b; V.ne[chd] = (unsigned short)(b + at); V.nchild[chd] = 0; V.npar[chd] = (unsigned short)g;
+            V.nflag[chd] = (unsigned char)((flag & 0xCu) | dimbit);          // lbox.hi[dim] = cut hides the left subtree's upper bound in dim
+            V.nb[chd + 1] = (unsigned short)(b + at); V.ne[chd + 1] = (unsigned short)e; V.nchild[chd + 1] = 0; V.npar[chd + 1] = (unsigned short)g;
+            V.nflag[chd + 1] = (unsigned char)(flag & 0xCu);
+            const unsigned nsplit = (at > kLeafMax ? 1u : 0u) + (c - at > kLeafMax ? 1u : 0u);
+            if (nsplit) atomicAdd(&status[1], nsplit);
+            atomicMax(s_maxdepth, (unsigned)(depth + 1));
+        }
+        team_sync<WG>();
+        const bool anyfb = status[0] != 0;
+        more = status[1] != 0;
+        lvl_b = (int)c0;
+        lvl_e = (int)*cursor;
+        ++depth;
+        // ---- the fallback's insertion sort = a stable sort of what the serial phase left: rank by (key, position), permute through S
+        if (anyfb) {
+            unsigned long long pm = 0;
+            for (int k = 0; k < ept; k++) {
+                const int i = i0 + k;
+                if (i >= ee) break;
+                const unsigned g = V.eseg[i];
+                if (g == kNoNode || !(V.nflag[g] & 2)) continue;
+                pm |= 1ull << k;
+                const int b = V.nb[g], e = V.ne[g];
+                const float* v = (V.nflag[g] & 1) ? V.py : V.px;
+                const float ki = v[i];
+                int r = 0;
+                for (int j = b; j < e; j++) { const float kj = v[j]; r += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
+                V.scr[i] = (unsigned short)(b + r);
+            }
+            float* tf = reinterpret_cast<float*>(V.S);
+            team_sync<WG>();
+            for (int k = 0; k < ept; k++) if ((pm >> k) & 1) tf[V.scr[i0 + k]] = V.px[i0 + k];
+            team_sync<WG>();
+            for (int k = 0; k < ept; k++) if ((pm >> k) & 1) V.px[i0 + k] = tf[i0 + k];
+            team_sync<WG>();
+            for (int k = 0; k < ept; k++) if ((pm >> k) & 1) tf[V.scr[i0 + k]] = V.py[i0 + k];
+            team_sync<WG>();
+            for (int k = 0; k < ept; k++) if ((pm >> k) & 1) V.py[i0 + k] = tf[i0 + k];
+            team_sync<WG>();
+            for (int k = 0; k < ept; k++) if ((pm >> k) & 1) V.S[V.scr[i0 + k]] = V.ord[i0 + k];
+            team_sync<WG>();
+            for (int k = 0; k < ept; k++) if ((pm >> k) & 1) V.ord[i0 + k] = (unsigned short)V.S[i0 + k];
+            team_sync<WG>();
+        }
+        // ---- every point learns its child; a fallback node's cut is the first point of its right half (picoflann.h:441-446)
+        for (int k = 0; k < ept; k++) {
+            const int i = i0 + k;
+            if (i >= ee) break;
+            const unsigned g = V.eseg[i];
+            if (g == kNoNode) continue;
+            const unsigned chd = V.nchild[g];
+            const int mid = V.ne[chd];
+            const unsigned flag = V.nflag[g];
+            if ((flag & 2) && i == mid) V.ncut[g] = (double)((flag & 1) ? V.py[i] : V.px[i]);
+            const unsigned child = i < mid ? chd : chd + 1;
+            const int cs = (int)V.ne[child] - (int)V.nb[child];
+            V.eseg[i] = cs > kLeafMax ? (unsigned short)child : kNoNode;
+        }
+    }
+}
+
+struct Node24 { float divlow, divhigh; int left, right; int leaf_begin; short leaf_count, col; };
+static_assert(sizeof(Node24) == 24, "node layout");
+struct Meta { unsigned long long word; int n, n_nodes, max_depth, m_used; double box[4]; };   // 56 bytes, in pinned host memory
+
+// The whole build by one workgroup (blockDim.x = 64 * 2^j threads, 256 .. 1024).  in[i] = {x, y, bits(octave), -} of keypoint i;
+// nodes_out: room for 2 * (n / 5) + 1 nodes (uh_kd::node_cap covers it), leaf_out[i] = {x, y, bits(keypoint << 4 | octave), 0} in leaf order.
+// Thread 0 leaves {n, n_nodes, depth, root box} in *meta and, last, stores `word` into meta->word with system-scope release.
+__device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const float4* __restrict__ in, const int n, Node24* __restrict__ nodes_out,
+                                float4* __restrict__ leaf_out, Meta* meta, const unsigned long long word) {
+    __shared__ unsigned s_w[16], s_cursor[17], s_status[17][2], s_maxdepth;
+    __shared__ double s_rhi[16][2];
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+    const Lds V = carve(lds_base, n_cap, nwaves);
+    for (int g = tid; g < V.m_cap; g += nthr) V.npar[g] = kNoNode;
+    for (int i = tid; i < n; i += nthr) {
+        const float4 r = in[i];
+        V.px[i] = r.x; V.py[i] = r.y; V.ord[i] = (unsigned short)i;
+        V.eseg[i] = n > kLeafMax ? (unsigned short)0 : kNoNode;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        V.nb[0] = 0; V.ne[0] = (unsigned short)n; V.nchild[0] = 0; V.npar[0] = kRootPar; V.nflag[0] = 0;
+        s_cursor[16] = 1; s_status[16][0] = 0; s_status[16][1] = 0;
+        s_maxdepth = n > 0 ? 1 : 0;
+    }
+    __syncthreads();
+    int m_used = n > 0 ? 1 : 0;
+    if (n > kLeafMax) {
+        int lvl_b = 0, lvl_e = 1, depth = 1;
+        const int k_wg = uh_sel::floor_log2(nwaves);
+        sweep_levels<true>(V, tid, nthr, 0, n, lvl_b, lvl_e, &s_cursor[16], s_status[16], s_w, depth, k_wg, &s_maxdepth);
+        __syncthreads();
+        // hand-over: node lvl_b + w goes to wave w with a node region of its own (a subtree of c points holds at most 2c/5 nodes)
+        const int nL = lvl_e - lvl_b;
+        unsigned base = s_cursor[16], mine = 0;
+        int mb = 0, me = 0;
+        for (int j = 0; j < nL; j++) {
+            const int b = V.nb[lvl_b + j], e = V.ne[lvl_b + j];
+            if (j == wave) { mine = base; mb = b; me = e; }
+            base += (unsigned)(2 * (e - b) / 5 + 2);
+        }
+        m_used = (int)base;
+        if (wave < nL && me - mb > kLeafMax && V.nchild[lvl_b + wave] == 0) {
+            if (lane == 0) { s_cursor[wave] = mine; s_status[wave][0] = 0; s_status[wave][1] = 0; }
+            uh_sel::wave_mem_sync();
+            int lb = lvl_b + wave, le = lb + 1, d = depth;
+            sweep_levels<false>(V, lane, 64, mb, me, lb, le, &s_cursor[wave], s_status[wave], nullptr, d, 1 << 20, &s_maxdepth);
+        }
+        __syncthreads();
+    }
+    // ---- from the leaves up: tight lower bounds (divhigh of a parent = its right child's in the split dimension), counts of inner nodes;
+    // the root's upper bounds from the leaves / cuts no ancestor overrides.  The second child to arrive at a parent goes on.
+    for (int g = tid; g < m_used; g += nthr) V.nlim[g] = 0;
+    __syncthreads();
+    double rhi0 = -__builtin_huge_val(), rhi1 = -__builtin_huge_val();
+    for (int g = tid; g < m_used; g += nthr) {
+        if (V.npar[g] == kNoNode || V.nchild[g] != 0) continue;
+        const int b = V.nb[g], e = V.ne[g];
+        float lx = V.px[b], hx = lx, ly = V.py[b], hy = ly;
+        for (int i = b + 1; i < e; i++) {
+            const float x = V.px[i], y = V.py[i];
+            lx = x < lx ? x : lx; hx = x > hx ? x : hx;
+            ly = y < ly ? y : ly; hy = y > hy ? y : hy;
+        }
+        V.nlo[2 * g] = lx; V.nlo[2 * g + 1] = ly; V.ncnt[g] = 0;
+        const unsigned fl = V.nflag[g];
+        if (!(fl & 4) && (double)hx > rhi0) rhi0 = (double)hx;
+        if (!(fl & 8) && (double)hy > rhi1) rhi1 = (double)hy;
+        int X = g;
+        for (;;) {
+            const unsigned p = V.npar[X];
+            if (p == kRootPar) break;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            const unsigned old = atomicAdd(&V.nlim[p], 1u);
+            if (old == 0) break;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            const unsigned l = V.nchild[p], r = l + 1;
+            const unsigned pf = V.nflag[p];
+            const int dim = (int)(pf & 1);
+            const float l0 = V.nlo[2 * l], l1 = V.nlo[2 * l + 1], r0 = V.nlo[2 * r], r1 = V.nlo[2 * r + 1];
+            V.ndivhigh[p] = dim ? r1 : r0;
+            V.nlo[2 * p] = l0 < r0 ? l0 : r0;
+            V.nlo[2 * p + 1] = l1 < r1 ? l1 : r1;
+            V.ncnt[p] = (unsigned short)(1 + V.ncnt[l] + V.ncnt[r]);
+            const double cut = V.ncut[p];
+            if (!(pf & (4u << dim))) { if (dim) { if (cut > rhi1) rhi1 = cut; } else if (cut > rhi0) rhi0 = cut; }
+            X = (int)p;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double a = shfl_f64(rhi0, lane ^ o), b = shfl_f64(rhi1, lane ^ o);
+        rhi0 = a > rhi0 ? a : rhi0; rhi1 = b > rhi1 ? b : rhi1;
+    }
+    if (lane == 0) { s_rhi[wave][0] = rhi0; s_rhi[wave][1] = rhi1; }
+    __syncthreads();
+    // ---- picoflann's node numbers (children of the r-th split in depth-first order: 2r + 1, 2r + 2) and the flattened records
+    const int n_nodes = n > 0 ? 1 + 2 * (V.nchild[0] != 0 ? (int)V.ncnt[0] : 0) : 0;
+    for (int g = tid; g < m_used; g += nthr) {
+        if (V.npar[g] == kNoNode) continue;
+        int acc = 0, stepg = 0, right = 0;
+        for (int X = g;;) {
+            const unsigned p = V.npar[X];
+            if (p == kRootPar) break;
+            const unsigned l = V.nchild[p];
+            const int isr = l + 1 == (unsigned)X;
+            const int s = 1 + (isr ? (int)V.ncnt[l] : 0);
+            if (X == g) { stepg = s; right = isr; } else acc += s;
+            X = (int)p;
+        }
+        const bool root = V.npar[g] == kRootPar;
+        const int id = root ? 0 : 2 * acc + 1 + right;
+        const int pre = root ? 0 : acc + stepg;
+        Node24 nd;
+        if (V.nchild[g] != 0) {
+            nd.divlow = (float)V.ncut[g]; nd.divhigh = V.ndivhigh[g];
+            nd.left = 2 * pre + 1; nd.right = 2 * pre + 2; nd.leaf_begin = 0; nd.leaf_count = 0; nd.col = (short)(V.nflag[g] & 1);
+        } else {
+            nd.divlow = 0.f; nd.divhigh = 0.f; nd.left = -1; nd.right = -1;
+            nd.leaf_begin = V.nb[g]; nd.leaf_count = (short)(V.ne[g] - V.nb[g]); nd.col = 0;
+        }
+        nodes_out[id] = nd;
+    }
+    for (int i = tid; i < n; i += nthr) {
+        const unsigned id = V.ord[i];
+        const unsigned oct = __float_as_uint(in[id].z);
+        leaf_out[i] = make_float4(V.px[i], V.py[i], __uint_as_float((id << 4) | (oct & 15u)), 0.f);
+    }
+    if (tid == 0) {
+        double h0 = s_rhi[0][0], h1 = s_rhi[0][1];
+        for (int w = 1; w < nwaves; w++) { h0 = s_rhi[w][0] > h0 ? s_rhi[w][0] : h0; h1 = s_rhi[w][1] > h1 ? s_rhi[w][1] : h1; }
+        meta->n = n; meta->n_nodes = n_nodes; meta->max_depth = (int)s_maxdepth; meta->m_used = m_used;
+        if (n > 0) { meta->box[0] = (double)V.nlo[0]; meta->box[1] = h0; meta->box[2] = (double)V.nlo[1]; meta->box[3] = h1; }
+        else { meta->box[0] = meta->box[1] = meta->box[2] = meta->box[3] = 0.0; }
+        __hip_atomic_store(&meta->word, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+}  // namespace uh_kd
+#endif

@@ -26,6 +26,7 @@
 #include <string>
 
 #include "common.hpp"
+#include "devframe.hpp"
 #include "glibc_sincosf.hpp"
 #include "introselect.hpp"
 #include "../../include/ucoslam_hip_orb_pattern.inc"
@@ -1040,7 +1041,8 @@ __global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const ui
                                                        size_t sel_frame_stride, const int* __restrict__ level_counts,
                                                        KeyPointOut* __restrict__ kps, uint8_t* __restrict__ desc,
                                                        int cap_per_frame, int* __restrict__ frame_counts, int class_id,
-                                                       const CamModel cam, float* __restrict__ und, int batch) {
+                                                       const CamModel cam, float* __restrict__ und, int batch,
+                                                       uint8_t* __restrict__ desc_dev, float4* __restrict__ kd_in) {
     // 1-D grid, frame fastest: consecutive workgroups go to consecutive XCDs, so with a batch of 8 one frame's pyramid is pulled into ONE
     // XCD's L2 (batch 4, the bench step: two) instead of all eight (2-D grid, round 1-4: FETCH_SIZE x2 22.7 MB per 4-frame launch
     // against 7.6 MB of blurred pyramid; profiles/r05_fetch_size_calibration.json for the counter's meaning on byte gathers)
@@ -1063,11 +1065,15 @@ __global__ __launch_bounds__(256) void describe_kernel(const Plan plan, const ui
         const int slot0 = bx * 4, nvalid = min(max(limit - slot0, 0), 4);
         const size_t o = (size_t)frame * cap_per_frame + slot0;
         const int t = threadIdx.x;
-        if (t < 2 * nvalid) reinterpret_cast<uint4*>(desc + o * 32)[t] = reinterpret_cast<const uint4*>(&s_desc[0][0])[t];
-        else if (und && t >= 128 && t < 128 + nvalid) {   // (a third wave) the undistorted position of each of the four keypoints, Frame::und_kpts
+        if (t < 2 * nvalid) {
+            const uint4 w = reinterpret_cast<const uint4*>(&s_desc[0][0])[t];
+            reinterpret_cast<uint4*>(desc + o * 32)[t] = w;
+            if (desc_dev) reinterpret_cast<uint4*>(desc_dev + o * 32)[t] = w;   // the frame stays on the device too (uh_dev_frame: the projection matcher's copy)
+        } else if (und && t >= 128 && t < 128 + nvalid) {   // (a third wave) the undistorted position of each of the four keypoints, Frame::und_kpts
             float ux, uy;
             undistort_point(cam, s_kp[t - 128].x, s_kp[t - 128].y, ux, uy);
             reinterpret_cast<float2*>(und)[o + (t - 128)] = make_float2(ux, uy);
+            if (kd_in) kd_in[o + (t - 128)] = make_float4(ux, uy, __int_as_float(s_kp[t - 128].octave), 0.f);   // input of the kd-tree build launch (kdbuild.hip)
         }
         if (t >= 64 && t < 64 + 7 * nvalid) {   // (a second wave: the two groups of stores issue side by side)
             const int i = t - 64;
@@ -1431,7 +1437,7 @@ int make_plan(uh_orb* o, int w, int h, int batch) {
 }
 
 int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, size_t img_frame_stride, int batch,
-               KeyPointOut* d_kps, uint8_t* d_desc, int cap_per_frame, int* d_counts, float* d_und = nullptr) {
+               KeyPointOut* d_kps, uint8_t* d_desc, int cap_per_frame, int* d_counts, float* d_und = nullptr, uh_dev_frame* fr = nullptr) {
     int rc;
     if (!o->planned || o->w != w || o->h != h || o->batch < batch) {
         if ((rc = make_plan(o, w, h, std::max(batch, o->planned && o->w == w && o->h == h ? o->batch : 0)))) return rc;
@@ -1505,7 +1511,8 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
     const int slots = std::min(std::max(P.maxFeatures, 1), std::max(cap_per_frame, 1));
     UH_LAUNCH(o->ctx,describe_kernel, dim3(uh_div_up(slots, 4) * batch), dim3(256), 0, P, pyr, o->frame_stride,
                        o->d_sel.as<uint32_t>(), o->sel_stride, o->d_level_counts.as<int>(), d_kps, d_desc, cap_per_frame,
-                       d_counts, o->nonmaxima ? 1 : -1, o->cam, o->cam.on ? d_und : nullptr, batch);
+                       d_counts, o->nonmaxima ? 1 : -1, o->cam, o->cam.on ? d_und : nullptr, batch, fr ? fr->desc() : (uint8_t*)nullptr,
+                       fr ? fr->kd_in() : (float4*)nullptr);
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
 }
@@ -1634,16 +1641,25 @@ int uh_orb_extract_dev(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t st
 }
 
 static int extract_one(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, int cn, uh_keypoint* kps, uint8_t* desc, float* und_xy, int cap,
-                       int* n_out) {
+                       int* n_out, uh_dev_frame* fr = nullptr) {
     UH_REQUIRE(o && n_out, "uh_orb_extract: NULL argument");
     *n_out = 0;
-    if (img == nullptr || w <= 0 || h <= 0) return UH_OK;   // ORBextractor.cpp:1254 — empty image: silent return
+    if (img == nullptr || w <= 0 || h <= 0) {   // ORBextractor.cpp:1254 — empty image: silent return (a device frame becomes the empty frame)
+        if (fr) { int rc0 = uh::dev_frame_reserve(fr, 1); if (rc0 || (rc0 = uh::kd_build_launch(fr, nullptr, 0, 0, 0))) return rc0; }
+        return UH_OK;
+    }
     UH_REQUIRE(cn == 1 || cn == 3 || cn == 4, "uh_orb_extract_frame: %d channels (1 = gray, 3 = BGR, 4 = BGRA)", cn);
     UH_REQUIRE(stride >= (size_t)w * cn, "uh_orb_extract: stride < row bytes");
     UH_REQUIRE(cap >= 0 && (cap == 0 || (kps && desc)), "uh_orb_extract: NULL output buffer");
     UH_REQUIRE(!und_xy || o->cam.on, "uh_orb_extract_frame: undistorted keypoints asked for but no camera set (uh_orb_set_camera)");
     const int maxk = std::max(o->fp.maxFeatures, 1);
     int rc;
+    if (fr) {   // the frame also stays on the device (descriptors, undistorted keypoints, kd-tree): uh_orb_extract_frame_dev
+        UH_REQUIRE(fr->ctx == o->ctx, "uh_orb_extract_frame_dev: the device frame belongs to another context");
+        UH_REQUIRE(o->cam.on, "uh_orb_extract_frame_dev: no camera set (uh_orb_set_camera): Frame::und_kpts need one");
+        UH_REQUIRE(o->lvl_first == 0 && o->lvl_end < 0, "uh_orb_extract_frame_dev: a pyramid-level shard is not a frame");
+        if ((rc = uh::dev_frame_reserve(fr, maxk))) return rc;
+    }
     UH_HIP_CHECK(hipSetDevice(o->ctx->device));
     hipStream_t st = o->ctx->stream;
     // One frame is latency, not bandwidth: no copy engine and no stream synchronisation on the way.  A frame in pinned memory
@@ -1678,7 +1694,7 @@ static int extract_one(uh_orb* o, const uint8_t* img, int w, int h, size_t strid
     const size_t in_stride = (size_t)w;
     const int slots = std::min(maxk, std::max(cap, 1));
     const size_t o_cnt = 64, o_kps = 128, o_desc = o_kps + (((size_t)maxk * sizeof(uh_keypoint) + 63) & ~(size_t)63), o_und = o_desc + (size_t)maxk * 32,
-                 total = o_und + (und_xy ? (size_t)maxk * 8 : 0);
+                 total = o_und + ((und_xy || fr) ? (size_t)maxk * 8 : 0);
     if ((rc = o->h_out.reserve(total))) return rc;
     char* hb = o->h_out.host<char>();
     char* db = o->h_out.dev<char>();
@@ -1688,14 +1704,20 @@ static int extract_one(uh_orb* o, const uint8_t* img, int w, int h, size_t strid
     if (!direct) { d_kps = reinterpret_cast<KeyPointOut*>(db + o_kps); d_desc = reinterpret_cast<uint8_t*>(db + o_desc); }
     // (the undistorted positions: into the caller's array if it is pinned and 8-byte aligned, else into this object's block)
     float* d_und = und_xy ? static_cast<float*>(uh::device_alias_of_host(und_xy)) : nullptr;
-    const bool und_direct = d_und && (reinterpret_cast<uintptr_t>(d_und) & 7) == 0;
-    if (und_xy && !und_direct) d_und = reinterpret_cast<float*>(db + o_und);
-    rc = run_frames(o, d_img, w, h, in_stride, (size_t)in_stride * h, 1, d_kps, d_desc, direct ? slots : maxk, reinterpret_cast<int*>(db + o_cnt), d_und);
+    // (with staged keypoints the launch runs at cap_per_frame = maxk, so describe_kernel stores up to maxk positions — the caller's
+    // array holds only `cap` of them: write into it only when the launch itself is bounded by `cap`, or `cap` covers every slot)
+    const bool und_direct = d_und && (reinterpret_cast<uintptr_t>(d_und) & 7) == 0 && (direct || cap >= maxk);
+    if ((und_xy || fr) && !und_direct) d_und = reinterpret_cast<float*>(db + o_und);
+    const int cap_launch = direct ? slots : maxk;
+    rc = run_frames(o, d_img, w, h, in_stride, (size_t)in_stride * h, 1, d_kps, d_desc, cap_launch, reinterpret_cast<int*>(db + o_cnt), d_und, fr);
     if (rc) return rc;
     // the completion word as its own one-thread launch behind the last kernel (a ticket counter inside describe_kernel — one system-scope
     // release and one same-address atomic per workgroup — cost 10 us more than this launch)
     const unsigned long long word = ++o->seq;
     if ((rc = uh::post_host_word(o->ctx, reinterpret_cast<unsigned long long*>(db), word))) return rc;
+    // Frame::create_kdtree (frameextractor.cpp:4258) as one more launch BEHIND the completion word: the host gets its keypoints and goes on
+    // while the tree is built; the projection matcher adopts it with uh_projmatch_set_frame_dev (no D2H -> host build -> H2D)
+    if (fr && (rc = uh::kd_build_launch(fr, o->d_level_counts.as<int>(), o->plan.nlevels, cap_launch, 0))) return rc;
     if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(hb), word, st, "uh_orb_extract"))) return rc;
     const int n = *reinterpret_cast<const int*>(hb + o_cnt);
     *n_out = n;
@@ -1714,6 +1736,11 @@ int uh_orb_extract(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, u
 int uh_orb_extract_frame(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, int channels, uh_keypoint* kps, uint8_t* desc, float* und_xy,
                          int cap, int* n_out) {
     return extract_one(o, img, w, h, stride, channels, kps, desc, und_xy, cap, n_out);
+}
+int uh_orb_extract_frame_dev(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, int channels, uh_keypoint* kps, uint8_t* desc, float* und_xy,
+                             int cap, int* n_out, uh_dev_frame* frame) {
+    UH_REQUIRE(frame, "uh_orb_extract_frame_dev: NULL device frame");
+    return extract_one(o, img, w, h, stride, channels, kps, desc, und_xy, cap, n_out, frame);
 }
 int uh_orb_set_camera(uh_orb* o, const uh_camera* cam) {
     UH_REQUIRE(o, "uh_orb_set_camera: NULL extractor");

@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "devframe.hpp"
 #include "glibc_sincosf.hpp"
 
 extern "C" int uh_filter_ambiguous(uh_dmatch* matches, int n, int by_train);
@@ -647,6 +648,10 @@ struct uh_projmatch {
     std::vector<int> oct;
     std::vector<uh_dmatch> mm;
     KdBuilder kd;
+    int n_nodes = 0, max_depth = 0;     // of the current frame's tree (built on the host by set_frame, on the device for set_frame_dev)
+    uh_dev_frame* dev = nullptr;        // the current frame is this device-resident one (uh_projmatch_set_frame_dev)
+    uh::DevBuf d_scale;                 // set_frame_dev: the scale factors (uploaded when they change)
+    std::vector<float> scale_host;
     bool attr_set = false;
     bool ovf_zeroed = false;
     unsigned ovf_gen = 0;
@@ -726,6 +731,38 @@ int uh_projmatch_set_frame(uh_projmatch* h, const uh_proj_frame* f) {
     d.min_x = (float)f->min_x; d.min_y = (float)f->min_y; d.max_x = (float)f->max_x; d.max_y = (float)f->max_y;
     d.log_scale = f->n_levels > 1 ? std::log(f->scale_factors[1]) : 1.f;   // float overload = libm logf, as Frame::predictScale
     h->n_kpts = n; h->n_levels = f->n_levels;
+    h->n_nodes = (int)nn; h->max_depth = h->kd.max_depth; h->dev = nullptr;
+    h->have_frame = true;
+    return UH_OK;
+}
+
+// The frame the extractor left on the device (uh_orb_extract_frame_dev: descriptors, undistorted keypoints in leaf order, kd-tree built by
+// kdbuild.hip) becomes the matcher's frame: no keypoints or descriptors cross the host link, no tree is built on the host.  `f` carries the
+// camera / scale / image-bounds fields only (und_kpts, n_kpts, desc are ignored).
+int uh_projmatch_set_frame_dev(uh_projmatch* h, uh_dev_frame* fr, const uh_proj_frame* f) {
+    UH_REQUIRE(h && fr && f, "uh_projmatch_set_frame_dev: NULL argument");
+    UH_REQUIRE(fr->ctx == h->ctx, "uh_projmatch_set_frame_dev: the device frame belongs to another context");
+    UH_REQUIRE(f->n_levels >= 1 && f->n_levels <= 16 && f->scale_factors, "uh_projmatch_set_frame_dev: scale factors missing");
+    UH_HIP_CHECK(hipSetDevice(h->ctx->device));
+    int rc;
+    if (h->scale_host.size() != (size_t)f->n_levels || std::memcmp(h->scale_host.data(), f->scale_factors, 4 * (size_t)f->n_levels) != 0) {
+        h->scale_host.assign(f->scale_factors, f->scale_factors + f->n_levels);
+        if ((rc = h->d_scale.reserve(64))) return rc;
+        UH_HIP_CHECK(hipMemcpyAsync(h->d_scale.p, h->scale_host.data(), 4 * (size_t)f->n_levels, hipMemcpyHostToDevice, h->ctx->stream));
+    }
+    const uh_kd::Meta* m = nullptr;
+    if ((rc = uh::dev_frame_wait(fr, &m, "uh_projmatch_set_frame_dev"))) return rc;   // (the build runs behind the extractor's completion word: normally done)
+    UH_REQUIRE(m->max_depth <= kMaxDepth, "uh_projmatch_set_frame_dev: kd-tree depth %d exceeds the walk stack (%d levels)", m->max_depth, kMaxDepth);
+    PmFrame& d = h->fr;
+    d.kp_desc = reinterpret_cast<const uint64_t*>(fr->desc());
+    d.nodes = reinterpret_cast<const KdNodeDev*>(fr->nodes()); d.leaf_rec = fr->leaf(); d.scale = h->d_scale.as<float>();
+    for (int i = 0; i < 4; i++) d.box[i] = m->box[i];
+    d.n_levels = f->n_levels; d.n_kpts = m->n;
+    d.fx = f->fx; d.fy = f->fy; d.cx = f->cx; d.cy = f->cy;
+    d.min_x = (float)f->min_x; d.min_y = (float)f->min_y; d.max_x = (float)f->max_x; d.max_y = (float)f->max_y;
+    d.log_scale = f->n_levels > 1 ? std::log(f->scale_factors[1]) : 1.f;
+    h->n_kpts = m->n; h->n_levels = f->n_levels;
+    h->n_nodes = m->n_nodes; h->max_depth = m->max_depth; h->dev = fr;
     h->have_frame = true;
     return UH_OK;
 }
@@ -746,6 +783,7 @@ int uh_kdtree_build_host(const float* xy, int32_t n, int32_t* n_nodes, void* nod
 // flattened tree of the current frame (for tests: compared with the oracle's / the real picoflann's build)
 int uh_projmatch_debug_tree(uh_projmatch* h, int32_t* n_nodes, const void** nodes24, const uint32_t** leaf_idx, double* root_box4, int32_t* max_depth) {
     UH_REQUIRE(h && h->have_frame, "uh_projmatch_debug_tree: no frame set");
+    UH_REQUIRE(!h->dev, "uh_projmatch_debug_tree: the current frame is device-resident (use uh_dev_frame_tree)");
     if (n_nodes) *n_nodes = (int32_t)h->kd.nodes.size();
     if (nodes24) *nodes24 = h->kd.nodes.data();
     if (leaf_idx) *leaf_idx = h->kd.leaf_idx.data();
@@ -811,7 +849,7 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
         ps.cc[2] = m8 * 0.f + m9 * 0.f + m10 * 0.f + m11;
     }
     {
-        const int n_nodes = (int)h->kd.nodes.size(), levels = h->kd.max_depth + 2;
+        const int n_nodes = h->n_nodes, levels = h->max_depth + 2;
         // Points per workgroup (= waves: one point per wave).  The walk is issue-bound — ~70 instructions per tree step and point, whatever shares
         // the SIMD — so the points are spread over as many compute units as there are: 800 previous-frame items ran on 50 CUs at 16 per
         // workgroup (match_prev 58 us); every workgroup stages the frame itself (~80 KB from L2: 2-3 us), so not below 4.

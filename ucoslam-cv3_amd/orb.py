@@ -72,9 +72,47 @@ def _declare(L, sig):
     sig("uh_orb_set_camera", I, VP, C.POINTER(Camera))
     sig("uh_orb_extract_frame", I, VP, VP, I, I, SZ, I, VP, VP, VP, I, C.POINTER(I))
     sig("uh_undistort_points_host", I, C.POINTER(Camera), VP, I, VP)
+    sig("uh_dev_frame_create", I, VP, C.POINTER(VP))
+    sig("uh_dev_frame_destroy", None, VP)
+    sig("uh_orb_extract_frame_dev", I, VP, VP, I, I, SZ, I, VP, VP, VP, I, C.POINTER(I), VP)
+    sig("uh_dev_frame_tree", I, VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), VP, VP, VP, VP, VP, C.POINTER(C.c_int32))
 
 
 _lib._EXTRA_DECLS.append(_declare)
+
+
+class DeviceFrame:
+    """uh_dev_frame: the Frame FrameExtractor::process produces (descriptors, undistorted keypoints, kd-tree), resident in HBM."""
+
+    def __init__(self, ctx: _lib.Context):
+        self.ctx = ctx
+        self._h = VP()
+        check(lib().uh_dev_frame_create(ctx.handle, C.byref(self._h)))
+
+    def tree(self):
+        """The kd-tree of the latest extraction, copied out (waits for the build launch): dict(nodes, leaf_idx, leaf_xy, leaf_octave, root_box, depth)."""
+        from .projmatch import KDNODE_DTYPE
+
+        n, nn, depth = C.c_int32(), C.c_int32(), C.c_int32()
+        box = np.zeros(4, np.float64)
+        check(lib().uh_dev_frame_tree(self._h, C.byref(n), C.byref(nn), None, None, None, None, np_ptr(box), C.byref(depth)))
+        nodes = np.zeros(max(nn.value, 1), KDNODE_DTYPE)
+        leaf = np.zeros(max(n.value, 1), np.uint32)
+        xy = np.zeros((max(n.value, 1), 2), np.float32)
+        oc = np.zeros(max(n.value, 1), np.int32)
+        check(lib().uh_dev_frame_tree(self._h, C.byref(n), C.byref(nn), np_ptr(nodes), np_ptr(leaf), np_ptr(xy), np_ptr(oc), np_ptr(box), C.byref(depth)))
+        return dict(nodes=nodes[: nn.value], leaf_idx=leaf[: n.value], leaf_xy=xy[: n.value], leaf_octave=oc[: n.value], root_box=box, depth=depth.value)
+
+    def close(self):
+        if self._h:
+            lib().uh_dev_frame_destroy(self._h)
+            self._h = VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ORBextractor:
@@ -139,7 +177,12 @@ class ORBextractor:
         check(lib().uh_orb_set_camera(self._h, C.byref(cam) if cam is not None else None))
         return self
 
-    def extractFrame(self, image, params: FeatParams | None = None, undistorted=True):
+    def extractFrameDev(self, image, frame: "DeviceFrame", params: FeatParams | None = None):
+        """extractFrame that also leaves the frame (descriptors, undistorted keypoints, kd-tree) in `frame` on the device
+        (uh_orb_extract_frame_dev); same host outputs."""
+        return self.extractFrame(image, params, True, frame)
+
+    def extractFrame(self, image, params: FeatParams | None = None, undistorted=True, _frame=None):
         """The frame as the camera delivers it (H x W gray, H x W x 3 BGR or H x W x 4 BGRA, uint8) -> (keypoints, descriptors, und_xy):
         FrameExtractor's cvtColor + detectAndCompute + undistortPoints (frameextractor.cpp:2960, :3985) in one call."""
         if params is not None:
@@ -155,8 +198,12 @@ class ORBextractor:
         desc = np.zeros((cap, 32), np.uint8)
         und = np.zeros((cap, 2), np.float32) if undistorted else None
         n = C.c_int(0)
-        check(lib().uh_orb_extract_frame(self._h, np_ptr(img), img.shape[1], img.shape[0], img.strides[0], cn, np_ptr(kps), np_ptr(desc),
-                                         np_ptr(und) if undistorted else None, cap, C.byref(n)))
+        if _frame is not None:
+            check(lib().uh_orb_extract_frame_dev(self._h, np_ptr(img), img.shape[1], img.shape[0], img.strides[0], cn, np_ptr(kps), np_ptr(desc),
+                                                 np_ptr(und) if undistorted else None, cap, C.byref(n), _frame._h))
+        else:
+            check(lib().uh_orb_extract_frame(self._h, np_ptr(img), img.shape[1], img.shape[0], img.strides[0], cn, np_ptr(kps), np_ptr(desc),
+                                             np_ptr(und) if undistorted else None, cap, C.byref(n)))
         return kps[: n.value].copy(), desc[: n.value].copy(), (und[: n.value].copy() if undistorted else None)
 
     def extract_batch(self, frames, params: FeatParams | None = None, out=None):

@@ -40,6 +40,9 @@ def _declare(L, sig):
     sig("uh_projmatch_match_prev", I, VP, VP, C.POINTER(_PrevPoints), C.c_float, C.c_float, VP, C.c_int32, VP, VP)
     sig("uh_projmatch_debug_tree", I, VP, C.POINTER(C.c_int32), C.POINTER(VP), C.POINTER(VP), VP, C.POINTER(C.c_int32))
     sig("uh_kdtree_build_host", I, VP, C.c_int32, C.POINTER(C.c_int32), VP, VP, VP, C.POINTER(C.c_int32))
+    sig("uh_kdtree_build_dev", I, VP, VP, C.c_int32, C.c_int32, C.POINTER(C.c_int32), VP, VP, VP, C.POINTER(C.c_int32))
+    sig("uh_kdtree_sort_restated_host", I, VP, C.c_int32, VP)
+    sig("uh_projmatch_set_frame_dev", I, VP, VP, C.POINTER(_ProjFrame))
 
 
 _lib._EXTRA_DECLS.append(_declare)
@@ -61,6 +64,26 @@ def kdtree_build_host(xy):
     return dict(nodes=nodes[:nn.value], leaf_idx=leaf[:n], root_box=box, depth=depth.value)
 
 
+def kdtree_build_dev(ctx, xy, threads=0):
+    """The same tree from the device builder (csrc/kdbuild.hpp), n <= 4096 — test hook."""
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    n = len(xy)
+    nodes = np.zeros(2 * n + 2, KDNODE_DTYPE)
+    leaf = np.zeros(max(n, 1), np.uint32)
+    box = np.zeros(4, np.float64)
+    nn, depth = C.c_int32(), C.c_int32()
+    check(lib().uh_kdtree_build_dev(ctx.handle, np_ptr(xy) if n else None, n, threads, C.byref(nn), np_ptr(nodes), np_ptr(leaf), np_ptr(box), C.byref(depth)))
+    return dict(nodes=nodes[:nn.value], leaf_idx=leaf[:n], root_box=box, depth=depth.value)
+
+
+def kdtree_sort_restated_host(keys):
+    """The permutation the device builder's restatement of libstdc++'s std::sort gives these float keys (host code, no GPU)."""
+    keys = np.ascontiguousarray(keys, np.float32)
+    perm = np.zeros(max(len(keys), 1), np.uint32)
+    check(lib().uh_kdtree_sort_restated_host(np_ptr(keys) if len(keys) else None, len(keys), np_ptr(perm)))
+    return perm[: len(keys)]
+
+
 class ProjectionMatcher:
     def __init__(self, ctx: _lib.Context):
         self.ctx = ctx
@@ -77,6 +100,13 @@ class ProjectionMatcher:
                        int(min_xy[0]), int(min_xy[1]), int(max_xy[0]), int(max_xy[1]))
         check(lib().uh_projmatch_set_frame(self._h, C.byref(f)))
         self.n_kpts = len(k)
+
+    def setFrameDev(self, frame, scale_factors, fx, fy, cx, cy, min_xy=(0, 0), max_xy=(INT_MAX, INT_MAX)):
+        """Adopt the frame ORBextractor.extractFrameDev left on the device (no keypoints / descriptors cross the host link)."""
+        s = np.ascontiguousarray(scale_factors, np.float32)
+        f = _ProjFrame(None, 0, None, np_ptr(s), len(s), fx, fy, cx, cy, int(min_xy[0]), int(min_xy[1]), int(max_xy[0]), int(max_xy[1]))
+        check(lib().uh_projmatch_set_frame_dev(self._h, frame._h, C.byref(f)))
+        self._keep = frame
 
     def matchFrameToMapPoints(self, pose_f2g, ids, pos3d, normal, min_dist, max_dist, mp_desc, minDescDist, maxRepjDist):
         """Returns dict(matches DMATCH_DTYPE[k], best_kp int32[n], best_dist float32[n], visible uint8[n])."""
