@@ -1,0 +1,20 @@
+"""Phase stamps of the device kd-tree build (UH_KD_CLK=1 prints them) and HIP-event timing of the launch for a few point counts."""
+import os
+import sys
+
+os.environ.setdefault("UH_KD_CLK", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import ucoslam_cv3_amd as u
+from ucoslam_cv3_amd.projmatch import kdtree_build_dev, kdtree_build_host
+
+ctx = u.Context(0, torch.cuda.current_stream().cuda_stream)
+rng = np.random.default_rng(0)
+for n in (2000, 4000, 500):
+    xy = (rng.random((n, 2)) * [1241, 376]).astype(np.float32)
+    for threads in (1024, 512, 256):
+        for rep in range(3):
+            t = kdtree_build_dev(ctx, xy, threads)
+        assert t["nodes"].tobytes() == kdtree_build_host(xy)["nodes"].tobytes()

@@ -15,6 +15,7 @@ struct uh_dev_frame {
     size_t o_desc = 0, o_in = 0, o_nodes = 0, o_leaf = 0;
     unsigned long long seq = 0;   // word of the latest build launch (0: none yet)
     bool attr_set = false;
+    uh::DevBuf d_clk;        // UH_KD_CLK=1: phase stamps of the build launch (measurement only)
 
     uint8_t* desc() const { return buf.as<uint8_t>() + o_desc; }
     float4* kd_in() const { return reinterpret_cast<float4*>(buf.as<uint8_t>() + o_in); }

@@ -2,6 +2,7 @@
 // (src/utils/frameextractor.cpp:4258, src/basictypes/picoflann.h:150-163,238-345) and the device-resident frame object around it.
 // The algorithm is in kdbuild.hpp; this unit owns the kernel, the uh_dev_frame object and the test hooks.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -12,7 +13,7 @@ namespace {
 
 __global__ __launch_bounds__(1024) void kd_build_kernel(const float4* __restrict__ in, int n_direct, const int* __restrict__ level_counts, int nlevels,
                                                         int cap, int n_cap, uh_kd::Node24* __restrict__ nodes, float4* __restrict__ leaf, uh_kd::Meta* meta,
-                                                        unsigned long long word) {
+                                                        unsigned long long word, long long* clk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_kd[];
     int n = n_direct;
     if (level_counts) {   // the extractor's per-level counts (select_kernel), clipped exactly as describe_kernel clips its slots
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(1024) void kd_build_kernel(const float4* __restrict
         }
         return;
     }
-    uh_kd::build_workgroup(s_kd, n_cap, in, n, nodes, leaf, meta, word);
+    uh_kd::build_workgroup(s_kd, n_cap, in, n, nodes, leaf, meta, word, clk);
 }
 
 __global__ void kd_pack_xy_kernel(const float2* __restrict__ xy, int n, float4* __restrict__ out) {
@@ -66,9 +67,12 @@ int kd_build_launch(uh_dev_frame* f, const int* d_level_counts, int nlevels, int
         UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kd_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
         f->attr_set = true;
     }
+    static const bool want_clk = getenv("UH_KD_CLK") != nullptr;
+    if (want_clk && !f->d_clk.p) { int rc = f->d_clk.reserve(192 * 8); if (rc) return rc; }
+    if (f->d_clk.p) UH_HIP_CHECK(hipMemsetAsync(f->d_clk.p, 0, 192 * 8, f->ctx->stream));
     const unsigned long long word = ++f->seq;
     UH_LAUNCH(f->ctx, kd_build_kernel, dim3(1), dim3(f->threads), lds, (const float4*)f->kd_in(), n_direct, d_level_counts, nlevels, cap, f->n_cap, f->nodes(),
-              f->leaf(), f->meta.dev<uh_kd::Meta>(), word);
+              f->leaf(), f->meta.dev<uh_kd::Meta>(), word, f->d_clk.as<long long>());
     UH_HIP_CHECK(hipGetLastError());
     return UH_OK;
 }
@@ -144,6 +148,19 @@ int uh_kdtree_build_dev(uh_ctx* ctx, const float* xy, int32_t n, int32_t threads
     if ((rc = uh::kd_build_launch(&f, nullptr, 0, 0, n))) return rc;
     rc = uh_dev_frame_tree(&f, nullptr, n_nodes, nodes24_out, leaf_idx_out, nullptr, nullptr, root_box4, max_depth);
     UH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (f.d_clk.p) {   // UH_KD_CLK=1: wall-clock stamps (10 ns units) of workgroup thread 0
+        long long c[192];
+        UH_HIP_CHECK(hipMemcpy(c, f.d_clk.p, sizeof(c), hipMemcpyDeviceToHost));
+        fprintf(stderr, "kd build n=%d threads=%d [us]: load %.2f  wg-levels %.2f  wave-levels(w0) %.2f  join %.2f  zero %.2f  climb %.2f  nodes %.2f  leaves %.2f  total %.2f\n", n, f.threads,
+                (c[1] - c[0]) * 0.01, (c[2] - c[1]) * 0.01, (c[3] - c[2]) * 0.01, (c[4] - c[3]) * 0.01, (c[5] - c[4]) * 0.01, (c[6] - c[5]) * 0.01, (c[7] - c[6]) * 0.01, (c[8] - c[7]) * 0.01, (c[8] - c[0]) * 0.01);
+        for (int part = 0; part < 2; part++)
+            for (int lv = 0; lv < 6; lv++) {
+                const long long* q = c + (part ? 64 : 16) + lv * 8;
+                if (!q[0] || !q[6]) continue;
+                fprintf(stderr, "  %s level %d: moments %.2f  pass0 %.2f  pass1 %.2f  split %.2f  fallback %.2f  children %.2f\n", part ? "wave0" : "wg", lv, (q[1] - q[0]) * 0.01, ((q[2] ? q[2] : q[3]) - q[1]) * 0.01,
+                        (q[2] ? (q[3] - q[2]) * 0.01 : 0.0), (q[4] - q[3]) * 0.01, (q[5] - q[4]) * 0.01, (q[6] - q[5]) * 0.01);
+            }
+    }
     return rc;
 }
 

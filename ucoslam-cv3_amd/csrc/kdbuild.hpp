@@ -7,8 +7,9 @@
 //                addition: the order is part of the result) — four lanes per node, one serial chain each
 //   Hoare passes [< cut | == cut | > cut] exactly as picoflann's two scans permute the points (picoflann.h:403-424).  One pass = "with
 //                m points belonging left, the misplaced points in front of b + m (ascending) are exchanged pairwise with the misplaced
-//                points behind (descending)"; the ranks come from ONE prefix sum of the predicate over all points of the level
-//                (segments are contiguous), the pairs meet through two index lists
+//                points behind (descending)"; the ranks come from the wave ballots of the predicate over rows of 64 consecutive points and
+//                one prefix sum over the rows (segments are contiguous: a node's count is a difference of two prefix values), the pairs
+//                meet through two index lists.  The second pass moves nothing unless a point EQUALS its node's cut: it is skipped then
 //   std::sort    where picoflann falls back to it (a side of the mean split would hold < 10 points — always for 11..19 points): libstdc++'s
 //                introsort = a partitioning phase (median of three, unguarded Hoare partition, heapsort at the depth limit; serial, one lane
 //                per node, nothing to do up to 16 points) followed by an insertion sort, which is a STABLE sort of what the first phase
@@ -124,13 +125,14 @@ template <class A> UH_HD void sort_phase(A& a, int first, int last) {
 
 // LDS need of kd_build_workgroup for up to n_cap points and nwaves waves (host and device agree on the layout through this)
 UH_HD int node_cap(int n_cap, int nwaves) { return 2 * n_cap / 5 + 4 * nwaves + 8; }
+UH_HD int row_cap(int n_cap, int nwaves) { return n_cap / 64 + 2 * nwaves + 4; }
 UH_HD size_t lds_bytes(int n_cap, int nwaves) {
     const size_t n = (size_t)n_cap + 2, m = (size_t)node_cap(n_cap, nwaves);
-    size_t b = m * 8;                 // ncut
-    b += n * 4 * 3;                   // px, py, S (u32: doubles as the float scratch of the fallback permutation)
-    b += m * 4 * 4;                   // nlo[2], ndivhigh, nlim
+    size_t b = m * 8 + (size_t)row_cap(n_cap, nwaves) * 8;   // ncut, bal
+    b += n * 4 * 3;                   // px, py, tmp (the scratch of the fallback permutation)
+    b += m * 4 * 6;                   // nlo[2], ndivhigh, nlim, nbe, ncutf
     b += n * 2 * 3;                   // ord, eseg, scr
-    b += m * 2 * 5;                   // nb, ne, nchild, npar, ncnt
+    b += m * 2 * 4;                   // nchild, npar, ncnt, nmid
     b += m;                           // nflag
     return (b + 64 + 15) & ~(size_t)15;
 }
@@ -141,11 +143,11 @@ UH_HD size_t lds_bytes(int n_cap, int nwaves) {
 namespace uh_kd {
 
 struct Lds {
-    double* ncut;
-    float* px; float* py; unsigned* S;
-    float* nlo; float* ndivhigh; unsigned* nlim;
+    double* ncut; unsigned long long* bal;
+    float* px; float* py; unsigned* tmp;
+    float* nlo; float* ndivhigh; unsigned* nlim; unsigned* nbe; float* ncutf;
     unsigned short* ord; unsigned short* eseg; unsigned short* scr;
-    unsigned short* nb; unsigned short* ne; unsigned short* nchild; unsigned short* npar; unsigned short* ncnt;
+    unsigned short* nchild; unsigned short* npar; unsigned short* ncnt; unsigned short* nmid;
     unsigned char* nflag;   // bit 0 split dimension, bit 1 std::sort fallback taken, bits 2-3 "an ancestor's cut overrides my upper bound in x / y"
     int m_cap;
 };
@@ -155,20 +157,22 @@ __device__ __forceinline__ Lds carve(unsigned char* base, int n_cap, int nwaves)
     Lds V;
     unsigned char* p = base;
     V.ncut = reinterpret_cast<double*>(p); p += m * 8;
+    V.bal = reinterpret_cast<unsigned long long*>(p); p += (size_t)row_cap(n_cap, nwaves) * 8;
     V.px = reinterpret_cast<float*>(p); p += n * 4;
     V.py = reinterpret_cast<float*>(p); p += n * 4;
-    V.S = reinterpret_cast<unsigned*>(p); p += n * 4;
+    V.tmp = reinterpret_cast<unsigned*>(p); p += n * 4;
     V.nlo = reinterpret_cast<float*>(p); p += m * 8;
     V.ndivhigh = reinterpret_cast<float*>(p); p += m * 4;
     V.nlim = reinterpret_cast<unsigned*>(p); p += m * 4;
+    V.nbe = reinterpret_cast<unsigned*>(p); p += m * 4;
+    V.ncutf = reinterpret_cast<float*>(p); p += m * 4;
     V.ord = reinterpret_cast<unsigned short*>(p); p += n * 2;
     V.eseg = reinterpret_cast<unsigned short*>(p); p += n * 2;
     V.scr = reinterpret_cast<unsigned short*>(p); p += n * 2;
-    V.nb = reinterpret_cast<unsigned short*>(p); p += m * 2;
-    V.ne = reinterpret_cast<unsigned short*>(p); p += m * 2;
     V.nchild = reinterpret_cast<unsigned short*>(p); p += m * 2;
     V.npar = reinterpret_cast<unsigned short*>(p); p += m * 2;
     V.ncnt = reinterpret_cast<unsigned short*>(p); p += m * 2;
+    V.nmid = reinterpret_cast<unsigned short*>(p); p += m * 2;
     V.nflag = p;
     V.m_cap = (int)m;
     return V;
@@ -195,112 +199,149 @@ template <bool WG> __device__ __forceinline__ void team_sync() {
     if (WG) __syncthreads(); else uh_sel::wave_mem_sync();
 }
 
-// exclusive prefix of v over the team's threads and the team total (WG: through s_w, one word per wave; the callers' next team_sync
-// separates two uses of s_w)
-template <bool WG> __device__ __forceinline__ int team_excl_scan(int v, int& total, unsigned* s_w) {
-    const int lane = threadIdx.x & 63;
-    int inc = v;
+// One coordinate's sums over the samples b, b + step, .. < e in sample order: s1 += x, s2 += x * x (float square, double sums —
+// picoflann.h:362-391).  The loads run eight samples ahead of the two dependent addition chains.
+__device__ __forceinline__ void sample_sums(const float* __restrict__ v, int b, int e, int step, double& s1, double& s2, int& cnt) {
+    float cur[8], nxt[8];
+    s1 = 0; s2 = 0; cnt = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
-    if (!WG) { total = __shfl(inc, 63); return inc - v; }
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if (lane == 63) s_w[wave] = (unsigned)inc;
-    __syncthreads();
-    int pre = 0, tot = 0;
-    for (int w = 0; w < nw; w++) { const int x = (int)s_w[w]; pre += w < wave ? x : 0; tot += x; }
-    total = tot;
-    return pre + inc - v;
+    for (int u = 0; u < 8; u++) { const int j = b + u * step; cur[u] = j < e ? v[j] : 0.f; }
+    for (int i = b; i < e; i += 8 * step) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int j = i + (8 + u) * step; nxt[u] = j < e ? v[j] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (i + u * step < e) { const float x = cur[u]; s1 += (double)x; s2 += (double)(x * x); cnt++; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) cur[u] = nxt[u];
+    }
 }
 
 // Sweeps levels of the tree below the nodes [lvl_b, lvl_e) (depth `depth`) whose points are [eb, ee), with the team's threads tid of nthr
 // (the whole workgroup or one wave); runs at most max_levels levels and leaves the next level's node range and depth behind.  cursor: the
-// team's node allocator; status[0]: "a node of this level took the std::sort fallback", status[1]: children that will split again.
+// team's node allocator; status[0]: "a node of this level took the std::sort fallback", status[1]: children that will split again,
+// status[2]: "a point equals its node's cut" (all zero on entry).  bal: the team's row ballots (>= ceil((ee - eb) / 64) words).
+// Point i = eb + 64 r + lane belongs to row r; the team's wave tw owns rows tw, tw + nw, ..
 template <bool WG>
 __device__ void sweep_levels(const Lds& V, const int tid, const int nthr, const int eb, const int ee, int& lvl_b, int& lvl_e, unsigned* cursor,
-                             unsigned* status, unsigned* s_w, int& depth, const int max_levels, unsigned* s_maxdepth) {
-    const int ept = (ee - eb + nthr - 1) / nthr;   // <= 64: the predicate of a thread's points is one 64-bit mask
-    const int i0 = eb + tid * ept;
+                             unsigned* status, unsigned long long* bal, int& depth, const int max_levels, unsigned* s_maxdepth, long long* clk) {
+#define UH_KD_STAMP(j) do { if (clk && tid == 0 && lv < 6) clk[lv * 8 + (j)] = wall_clock64(); } while (0)
     const int lane = threadIdx.x & 63;
+    const int tw = WG ? (int)(threadIdx.x >> 6) : 0, nw = WG ? (int)(blockDim.x >> 6) : 1;
+    const int nrows = (ee - eb + 63) >> 6;          // <= 64
+    const int ept = (nrows + nw - 1) / nw;          // rows per wave
+    const unsigned long long ltmask = (1ull << lane) - 1ull;
     bool more = lvl_e > lvl_b;
     for (int lv = 0; lv < max_levels && more; ++lv) {
         const int nL = lvl_e - lvl_b;
         const unsigned c0 = *cursor;
-        // ---- mean / variance over the samples, split dimension, cut (picoflann.h:362-401): lanes 4j .. 4j+3 own the four sums of node j
-        for (int q0 = 0; q0 < nL * 4; q0 += nthr) {
-            const int q = q0 + tid, nd = q >> 2, ch = q & 3;
+        UH_KD_STAMP(0);
+        // ---- mean / variance over the samples, split dimension, cut (picoflann.h:362-401): lanes 2j, 2j + 1 own node j's x and y sums
+        for (int q0 = 0; q0 < nL * 2; q0 += nthr) {
+            const int q = q0 + tid, nd = q >> 1, ch = q & 1;
             const int g = lvl_b + nd;
             int b = 0, e = 0;
             bool act = nd < nL;
-            if (act) { b = V.nb[g]; e = V.ne[g]; act = e - b > kLeafMax; }
-            double s = 0;
+            if (act) { const unsigned be = V.nbe[g]; b = (int)(be & 0xffffu); e = (int)(be >> 16); act = e - b > kLeafMax; }
+            double s1 = 0, s2 = 0;
             int cnt = 0;
             if (act) {
                 const int c = e - b;
-                const int step = c >= 200 ? c / 100 : 1;
-                const float* v = (ch & 2) ? V.py : V.px;
-                if (ch & 1) for (int i = b; i < e; i += step, cnt++) { const float x = v[i]; s += (double)(x * x); }
-                else for (int i = b; i < e; i += step, cnt++) s += (double)v[i];
+                sample_sums(ch ? V.py : V.px, b, e, c >= 200 ? c / 100 : 1, s1, s2, cnt);
             }
-            const int l0 = lane & ~3;
-            const double s1x = shfl_f64(s, l0), s2x = shfl_f64(s, l0 + 1), s1y = shfl_f64(s, l0 + 2), s2y = shfl_f64(s, l0 + 3);
+            const double o1 = shfl_f64(s1, lane ^ 1), o2 = shfl_f64(s2, lane ^ 1);
             if (act && ch == 0) {
                 const double inv = 1. / double(cnt);
-                const double m0 = s1x * inv, m1 = s1y * inv;
-                const double v0 = s2x * inv - m0 * m0, v1 = s2y * inv - m1 * m1;
+                const double m0 = s1 * inv, m1 = o1 * inv;
+                const double v0 = s2 * inv - m0 * m0, v1 = o2 * inv - m1 * m1;
                 const int dim = v1 > v0 ? 1 : 0;
-                V.ncut[g] = dim ? m1 : m0;
+                const double cut = dim ? m1 : m0;
+                V.ncut[g] = cut;
+                V.ncutf[g] = (float)cut;
                 V.nflag[g] = (unsigned char)((V.nflag[g] & ~3u) | (unsigned)dim);
             }
         }
         // ---- the two Hoare passes: "v < cut" over the node, then "v <= cut" (over the whole node = over its part behind the first limit:
-        // everything in front of it satisfies the predicate and stays where it is)
+        // everything in front of it satisfies the predicate and stays where it is; without a point equal to a cut it moves nothing)
         for (int pass = 0; pass < 2; ++pass) {
             team_sync<WG>();
+            UH_KD_STAMP(1 + pass);
             if (pass == 0 && tid == 0) { status[0] = 0; status[1] = 0; }   // (the previous level's readers are a barrier behind)
-            unsigned long long fm = 0, am = 0;
+            bool eqany = false;
             for (int k = 0; k < ept; k++) {
-                const int i = i0 + k;
-                if (i >= ee) break;
-                const unsigned g = V.eseg[i];
-                if (g == kNoNode) continue;
-                am |= 1ull << k;
-                const float cutf = (float)V.ncut[g];
-                const float v = (V.nflag[g] & 1) ? V.py[i] : V.px[i];
-                if (pass ? v <= cutf : v < cutf) fm |= 1ull << k;
+                const int r = tw + k * nw;
+                if (r >= nrows) break;
+                const int i = eb + r * 64 + lane;
+                const bool valid = i < ee;
+                const unsigned g = valid ? V.eseg[i] : 0u;
+                const float x = valid ? V.px[i] : 0.f, y = valid ? V.py[i] : 0.f;
+                const unsigned be = V.nbe[g];
+                const float cf = V.ncutf[g];
+                const unsigned fl = V.nflag[g];
+                const bool active = valid && (int)(be >> 16) - (int)(be & 0xffffu) > kLeafMax;
+                const float v = (fl & 1) ? y : x;
+                const bool f = active && (pass ? v <= cf : v < cf);
+                const unsigned long long bm = __ballot(f);
+                if (lane == 0) bal[r] = bm;
+                if (pass == 0) eqany = eqany || __ballot(active && v == cf) != 0ull;
             }
-            int total;
-            const int ex = team_excl_scan<WG>(__popcll(fm), total, s_w);
+            if (pass == 0 && eqany && lane == 0) atomicOr(&status[2], 1u);
+            team_sync<WG>();
+            // row prefix: lane r of every wave holds the number of set predicates in front of row r
+            const unsigned long long rowbits = lane < nrows ? bal[lane] : 0ull;
+            int rb = __popcll(rowbits);
+            {
+                int inc = rb;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+                rb = inc - rb;
+            }
+            const int total = __shfl(rb, 63) + __popc((unsigned)__shfl((int)(rowbits >> 32), 63)) + __popc((unsigned)__shfl((int)(rowbits & 0xffffffffull), 63));
+            const bool need2 = status[2] != 0;
+            // S(x): predicates set in [eb, x)
+#define UH_KD_S(x, out) do { const int o_ = (x) - eb, r_ = o_ >> 6; const int base_ = __shfl(rb, r_ & 63); \
+                             const unsigned long long bv_ = bal[r_ < nrows ? r_ : 0]; \
+                             (out) = r_ < nrows ? base_ + __popcll(bv_ & ((1ull << (o_ & 63)) - 1ull)) : total; } while (0)
             for (int k = 0; k < ept; k++) {
-                const int i = i0 + k;
-                if (i >= ee) break;
-                V.S[i] = (unsigned)(ex + __popcll(fm & ((1ull << k) - 1ull)));
+                const int r = tw + k * nw;
+                if (r >= nrows) break;
+                const int i = eb + r * 64 + lane;
+                const bool valid = i < ee;
+                const unsigned g = valid ? V.eseg[i] : 0u;
+                const unsigned be = V.nbe[g];
+                const int b = valid ? (int)(be & 0xffffu) : eb, e = valid ? (int)(be >> 16) : eb;
+                const bool active = valid && e - b > kLeafMax;
+                const unsigned long long own = bal[r];
+                const bool f = (own >> lane) & 1ull;
+                const int Si = __shfl(rb, r) + __popcll(own & ltmask);
+                int Sb, Se;
+                UH_KD_S(b, Sb);
+                UH_KD_S(e, Se);
+                if (active) {
+                    const int m = Se - Sb, mid = b + m;
+                    if (i == b) V.nlim[g] = pass ? ((V.nlim[g] & 0xffffu) | ((unsigned)m << 16)) : ((unsigned)m | ((unsigned)m << 16));
+                    if (i < mid && !f) V.scr[b + (i - b) - (Si - Sb)] = (unsigned short)i;     // k-th misplaced point of the front part
+                    else if (i >= mid && f) V.scr[e - 1 - (Se - Si - 1)] = (unsigned short)i;   // k-th misplaced point counted from the end
+                }
             }
             team_sync<WG>();
             for (int k = 0; k < ept; k++) {
-                const int i = i0 + k;
-                if (i >= ee) break;
-                if (!((am >> k) & 1)) continue;
-                const unsigned g = V.eseg[i];
-                const int b = V.nb[g], e = V.ne[g];
-                const int Sb = (int)V.S[b], Se = e == ee ? total : (int)V.S[e], Si = (int)V.S[i];
-                const int m = Se - Sb, mid = b + m;
-                const bool f = (fm >> k) & 1;
-                if (i == b) V.nlim[g] = pass ? (V.nlim[g] | ((unsigned)m << 16)) : (unsigned)m;
-                if (i < mid && !f) V.scr[b + (i - b) - (Si - Sb)] = (unsigned short)i;     // k-th misplaced point of the front part
-                else if (i >= mid && f) V.scr[e - 1 - (Se - Si - 1)] = (unsigned short)i;   // k-th misplaced point counted from the end
-            }
-            team_sync<WG>();
-            for (int k = 0; k < ept; k++) {
-                const int j = i0 + k;
-                if (j >= ee) break;
-                if (!((am >> k) & 1)) continue;
-                const unsigned g = V.eseg[j];
-                const int b = V.nb[g], e = V.ne[g];
-                const int Sb = (int)V.S[b], Se = e == ee ? total : (int)V.S[e];
+                const int r = tw + k * nw;
+                if (r >= nrows) break;
+                const int j = eb + r * 64 + lane;
+                const bool valid = j < ee;
+                const unsigned g = valid ? V.eseg[j] : 0u;
+                const unsigned be = V.nbe[g];
+                const int b = valid ? (int)(be & 0xffffu) : eb, e = valid ? (int)(be >> 16) : eb;
+                const bool active = valid && e - b > kLeafMax;
+                int Sb, Se, Sm;
+                UH_KD_S(b, Sb);
+                UH_KD_S(e, Se);
                 const int mid = b + (Se - Sb);
-                const int Sm = mid == e ? Se : (int)V.S[mid];
+                UH_KD_S(mid, Sm);
                 const int nl = (mid - b) - (Sm - Sb);
-                if (j - b < nl) {
+                if (active && j - b < nl) {
                     const int iL = V.scr[j], iR = V.scr[e - 1 - (j - b)];
                     const float ax = V.px[iL], ay = V.py[iL], bx = V.px[iR], by = V.py[iR];
                     const unsigned short ao = V.ord[iL], bo = V.ord[iR];
@@ -308,14 +349,19 @@ __device__ void sweep_levels(const Lds& V, const int tid, const int nthr, const 
                     V.px[iR] = ax; V.py[iR] = ay; V.ord[iR] = ao;
                 }
             }
+#undef UH_KD_S
+            if (!need2) break;
         }
         team_sync<WG>();
+        UH_KD_STAMP(3);
+        if (tid == 0) status[2] = 0;   // (read two barriers ago, set again two barriers ahead)
         // ---- where to split (picoflann.h:426-437), the std::sort fallback's serial phase, the two children
         for (int q0 = 0; q0 < nL; q0 += nthr) {
             const int nd = q0 + tid;
             if (nd >= nL) continue;
             const int g = lvl_b + nd;
-            const int b = V.nb[g], e = V.ne[g], c = e - b;
+            const unsigned be = V.nbe[g];
+            const int b = (int)(be & 0xffffu), e = (int)(be >> 16), c = e - b;
             if (c <= kLeafMax) continue;
             const unsigned lim = V.nlim[g];
             const int lim1 = (int)(lim & 0xffffu), lim2 = (int)(lim >> 16);
@@ -334,67 +380,78 @@ __device__ void sweep_levels(const Lds& V, const int tid, const int nthr, const 
             V.nflag[g] = (unsigned char)flag;
             const unsigned chd = atomicAdd(cursor, 2u);
             V.nchild[g] = (unsigned short)chd;
+            V.nmid[g] = (unsigned short)(b + at);
             const unsigned dimbit = 4u << (flag & 1);
-            V.nb[chd] = (unsigned short)b; V.ne[chd] = (unsigned short)(b + at); V.nchild[chd] = 0; V.npar[chd] = (unsigned short)g;
+            V.nbe[chd] = (unsigned)b | ((unsigned)(b + at) << 16); V.nchild[chd] = 0; V.npar[chd] = (unsigned short)g;
             V.nflag[chd] = (unsigned char)((flag & 0xCu) | dimbit);          // lbox.hi[dim] = cut hides the left subtree's upper bound in dim
-            V.nb[chd + 1] = (unsigned short)(b + at); V.ne[chd + 1] = (unsigned short)e; V.nchild[chd + 1] = 0; V.npar[chd + 1] = (unsigned short)g;
+            V.nbe[chd + 1] = (unsigned)(b + at) | ((unsigned)e << 16); V.nchild[chd + 1] = 0; V.npar[chd + 1] = (unsigned short)g;
             V.nflag[chd + 1] = (unsigned char)(flag & 0xCu);
             const unsigned nsplit = (at > kLeafMax ? 1u : 0u) + (c - at > kLeafMax ? 1u : 0u);
             if (nsplit) atomicAdd(&status[1], nsplit);
             atomicMax(s_maxdepth, (unsigned)(depth + 1));
         }
         team_sync<WG>();
+        UH_KD_STAMP(4);
         const bool anyfb = status[0] != 0;
         more = status[1] != 0;
         lvl_b = (int)c0;
         lvl_e = (int)*cursor;
         ++depth;
-        // ---- the fallback's insertion sort = a stable sort of what the serial phase left: rank by (key, position), permute through S
+        // ---- the fallback's insertion sort = a stable sort of what the serial phase left: rank by (key, position), permute through tmp
         if (anyfb) {
             unsigned long long pm = 0;
             for (int k = 0; k < ept; k++) {
-                const int i = i0 + k;
-                if (i >= ee) break;
+                const int r = tw + k * nw;
+                if (r >= nrows) break;
+                const int i = eb + r * 64 + lane;
+                if (i >= ee) continue;
                 const unsigned g = V.eseg[i];
-                if (g == kNoNode || !(V.nflag[g] & 2)) continue;
+                const unsigned fl = V.nflag[g];
+                if (!(fl & 2) || V.nchild[g] == 0) continue;
                 pm |= 1ull << k;
-                const int b = V.nb[g], e = V.ne[g];
-                const float* v = (V.nflag[g] & 1) ? V.py : V.px;
+                const unsigned be = V.nbe[g];
+                const int b = (int)(be & 0xffffu), e = (int)(be >> 16);
+                const float* v = (fl & 1) ? V.py : V.px;
                 const float ki = v[i];
-                int r = 0;
-                for (int j = b; j < e; j++) { const float kj = v[j]; r += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
-                V.scr[i] = (unsigned short)(b + r);
+                int rk = 0;
+                for (int j = b; j < e; j++) { const float kj = v[j]; rk += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
+                V.scr[i] = (unsigned short)(b + rk);
             }
-            float* tf = reinterpret_cast<float*>(V.S);
+            float* tf = reinterpret_cast<float*>(V.tmp);
+#define UH_KD_EACH(body) for (int k = 0; k < ept; k++) if ((pm >> k) & 1ull) { const int i = eb + (tw + k * nw) * 64 + lane; body; }
             team_sync<WG>();
-            for (int k = 0; k < ept; k++) if ((pm >> k) & 1) tf[V.scr[i0 + k]] = V.px[i0 + k];
+            UH_KD_EACH(tf[V.scr[i]] = V.px[i]);
             team_sync<WG>();
-            for (int k = 0; k < ept; k++) if ((pm >> k) & 1) V.px[i0 + k] = tf[i0 + k];
+            UH_KD_EACH(V.px[i] = tf[i]);
             team_sync<WG>();
-            for (int k = 0; k < ept; k++) if ((pm >> k) & 1) tf[V.scr[i0 + k]] = V.py[i0 + k];
+            UH_KD_EACH(tf[V.scr[i]] = V.py[i]);
             team_sync<WG>();
-            for (int k = 0; k < ept; k++) if ((pm >> k) & 1) V.py[i0 + k] = tf[i0 + k];
+            UH_KD_EACH(V.py[i] = tf[i]);
             team_sync<WG>();
-            for (int k = 0; k < ept; k++) if ((pm >> k) & 1) V.S[V.scr[i0 + k]] = V.ord[i0 + k];
+            UH_KD_EACH(V.tmp[V.scr[i]] = V.ord[i]);
             team_sync<WG>();
-            for (int k = 0; k < ept; k++) if ((pm >> k) & 1) V.ord[i0 + k] = (unsigned short)V.S[i0 + k];
+            UH_KD_EACH(V.ord[i] = (unsigned short)V.tmp[i]);
             team_sync<WG>();
+#undef UH_KD_EACH
         }
+        UH_KD_STAMP(5);
         // ---- every point learns its child; a fallback node's cut is the first point of its right half (picoflann.h:441-446)
         for (int k = 0; k < ept; k++) {
-            const int i = i0 + k;
-            if (i >= ee) break;
+            const int r = tw + k * nw;
+            if (r >= nrows) break;
+            const int i = eb + r * 64 + lane;
+            if (i >= ee) continue;
             const unsigned g = V.eseg[i];
-            if (g == kNoNode) continue;
             const unsigned chd = V.nchild[g];
-            const int mid = V.ne[chd];
+            if (chd == 0) continue;    // a leaf's points keep the leaf
+            const int mid = V.nmid[g];
             const unsigned flag = V.nflag[g];
-            if ((flag & 2) && i == mid) V.ncut[g] = (double)((flag & 1) ? V.py[i] : V.px[i]);
-            const unsigned child = i < mid ? chd : chd + 1;
-            const int cs = (int)V.ne[child] - (int)V.nb[child];
-            V.eseg[i] = cs > kLeafMax ? (unsigned short)child : kNoNode;
+            if ((flag & 2) && i == mid) { const double cut = (double)((flag & 1) ? V.py[i] : V.px[i]); V.ncut[g] = cut; V.ncutf[g] = (float)cut; }
+            V.eseg[i] = (unsigned short)(i < mid ? chd : chd + 1);
         }
+        UH_KD_STAMP(6);
     }
+#undef UH_KD_STAMP
 }
 
 struct Node24 { float divlow, divhigh; int left, right; int leaf_begin; short leaf_count, col; };
@@ -405,8 +462,10 @@ struct Meta { unsigned long long word; int n, n_nodes, max_depth, m_used; double
 // nodes_out: room for 2 * (n / 5) + 1 nodes (uh_kd::node_cap covers it), leaf_out[i] = {x, y, bits(keypoint << 4 | octave), 0} in leaf order.
 // Thread 0 leaves {n, n_nodes, depth, root box} in *meta and, last, stores `word` into meta->word with system-scope release.
 __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const float4* __restrict__ in, const int n, Node24* __restrict__ nodes_out,
-                                float4* __restrict__ leaf_out, Meta* meta, const unsigned long long word) {
-    __shared__ unsigned s_w[16], s_cursor[17], s_status[17][2], s_maxdepth;
+                                float4* __restrict__ leaf_out, Meta* meta, const unsigned long long word, long long* clk = nullptr) {
+#define UH_KD_TOP(j) do { if (clk && threadIdx.x == 0) clk[j] = wall_clock64(); } while (0)
+    UH_KD_TOP(0);
+    __shared__ unsigned s_cursor[17], s_status[17][4], s_maxdepth;
     __shared__ double s_rhi[16][2];
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
     const Lds V = carve(lds_base, n_cap, nwaves);
@@ -414,47 +473,61 @@ __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const 
     for (int i = tid; i < n; i += nthr) {
         const float4 r = in[i];
         V.px[i] = r.x; V.py[i] = r.y; V.ord[i] = (unsigned short)i;
-        V.eseg[i] = n > kLeafMax ? (unsigned short)0 : kNoNode;
+        V.eseg[i] = 0;
     }
+    if (tid < 17) { s_status[tid][0] = 0; s_status[tid][1] = 0; s_status[tid][2] = 0; }
     __syncthreads();
     if (tid == 0) {
-        V.nb[0] = 0; V.ne[0] = (unsigned short)n; V.nchild[0] = 0; V.npar[0] = kRootPar; V.nflag[0] = 0;
-        s_cursor[16] = 1; s_status[16][0] = 0; s_status[16][1] = 0;
+        V.nbe[0] = (unsigned)n << 16; V.nchild[0] = 0; V.npar[0] = kRootPar; V.nflag[0] = 0;
+        s_cursor[16] = 1;
         s_maxdepth = n > 0 ? 1 : 0;
     }
     __syncthreads();
+    UH_KD_TOP(1);
     int m_used = n > 0 ? 1 : 0;
     if (n > kLeafMax) {
         int lvl_b = 0, lvl_e = 1, depth = 1;
         const int k_wg = uh_sel::floor_log2(nwaves);
-        sweep_levels<true>(V, tid, nthr, 0, n, lvl_b, lvl_e, &s_cursor[16], s_status[16], s_w, depth, k_wg, &s_maxdepth);
+        sweep_levels<true>(V, tid, nthr, 0, n, lvl_b, lvl_e, &s_cursor[16], s_status[16], V.bal, depth, k_wg, &s_maxdepth, clk ? clk + 16 : nullptr);
         __syncthreads();
+        UH_KD_TOP(2);
         // hand-over: node lvl_b + w goes to wave w with a node region of its own (a subtree of c points holds at most 2c/5 nodes)
         const int nL = lvl_e - lvl_b;
         unsigned base = s_cursor[16], mine = 0;
-        int mb = 0, me = 0;
+        int mb = 0, me = 0, before = 0;   // before: subtrees in front of mine (the level's nodes are in allocation order, not in point order)
+        {
+            const unsigned bw = V.nbe[lvl_b + (wave < nL ? wave : 0)];
+            mb = (int)(bw & 0xffffu); me = (int)(bw >> 16);
+        }
         for (int j = 0; j < nL; j++) {
-            const int b = V.nb[lvl_b + j], e = V.ne[lvl_b + j];
-            if (j == wave) { mine = base; mb = b; me = e; }
+            const unsigned be = V.nbe[lvl_b + j];
+            const int b = (int)(be & 0xffffu), e = (int)(be >> 16);
+            if (j == wave) mine = base;
+            before += b < mb ? 1 : 0;
             base += (unsigned)(2 * (e - b) / 5 + 2);
         }
         m_used = (int)base;
-        if (wave < nL && me - mb > kLeafMax && V.nchild[lvl_b + wave] == 0) {
-            if (lane == 0) { s_cursor[wave] = mine; s_status[wave][0] = 0; s_status[wave][1] = 0; }
+        if (wave < nL && me - mb > kLeafMax) {
+            if (lane == 0) s_cursor[wave] = mine;
             uh_sel::wave_mem_sync();
             int lb = lvl_b + wave, le = lb + 1, d = depth;
-            sweep_levels<false>(V, lane, 64, mb, me, lb, le, &s_cursor[wave], s_status[wave], nullptr, d, 1 << 20, &s_maxdepth);
+            sweep_levels<false>(V, lane, 64, mb, me, lb, le, &s_cursor[wave], s_status[wave], V.bal + (mb >> 6) + before, d, 1 << 20, &s_maxdepth,
+                                clk && wave == 0 ? clk + 64 : nullptr);
         }
+        UH_KD_TOP(3);
         __syncthreads();
+        UH_KD_TOP(4);
     }
     // ---- from the leaves up: tight lower bounds (divhigh of a parent = its right child's in the split dimension), counts of inner nodes;
     // the root's upper bounds from the leaves / cuts no ancestor overrides.  The second child to arrive at a parent goes on.
     for (int g = tid; g < m_used; g += nthr) V.nlim[g] = 0;
     __syncthreads();
+    UH_KD_TOP(5);
     double rhi0 = -__builtin_huge_val(), rhi1 = -__builtin_huge_val();
     for (int g = tid; g < m_used; g += nthr) {
         if (V.npar[g] == kNoNode || V.nchild[g] != 0) continue;
-        const int b = V.nb[g], e = V.ne[g];
+        const unsigned be = V.nbe[g];
+        const int b = (int)(be & 0xffffu), e = (int)(be >> 16);
         float lx = V.px[b], hx = lx, ly = V.py[b], hy = ly;
         for (int i = b + 1; i < e; i++) {
             const float x = V.px[i], y = V.py[i];
@@ -493,6 +566,7 @@ __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const 
     }
     if (lane == 0) { s_rhi[wave][0] = rhi0; s_rhi[wave][1] = rhi1; }
     __syncthreads();
+    UH_KD_TOP(6);
     // ---- picoflann's node numbers (children of the r-th split in depth-first order: 2r + 1, 2r + 2) and the flattened records
     const int n_nodes = n > 0 ? 1 + 2 * (V.nchild[0] != 0 ? (int)V.ncnt[0] : 0) : 0;
     for (int g = tid; g < m_used; g += nthr) {
@@ -510,16 +584,18 @@ __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const 
         const bool root = V.npar[g] == kRootPar;
         const int id = root ? 0 : 2 * acc + 1 + right;
         const int pre = root ? 0 : acc + stepg;
+        const unsigned be = V.nbe[g];
         Node24 nd;
         if (V.nchild[g] != 0) {
             nd.divlow = (float)V.ncut[g]; nd.divhigh = V.ndivhigh[g];
             nd.left = 2 * pre + 1; nd.right = 2 * pre + 2; nd.leaf_begin = 0; nd.leaf_count = 0; nd.col = (short)(V.nflag[g] & 1);
         } else {
             nd.divlow = 0.f; nd.divhigh = 0.f; nd.left = -1; nd.right = -1;
-            nd.leaf_begin = V.nb[g]; nd.leaf_count = (short)(V.ne[g] - V.nb[g]); nd.col = 0;
+            nd.leaf_begin = (int)(be & 0xffffu); nd.leaf_count = (short)((be >> 16) - (be & 0xffffu)); nd.col = 0;
         }
         nodes_out[id] = nd;
     }
+    UH_KD_TOP(7);
     for (int i = tid; i < n; i += nthr) {
         const unsigned id = V.ord[i];
         const unsigned oct = __float_as_uint(in[id].z);
@@ -531,8 +607,10 @@ __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const 
         meta->n = n; meta->n_nodes = n_nodes; meta->max_depth = (int)s_maxdepth; meta->m_used = m_used;
         if (n > 0) { meta->box[0] = (double)V.nlo[0]; meta->box[1] = h0; meta->box[2] = (double)V.nlo[1]; meta->box[3] = h1; }
         else { meta->box[0] = meta->box[1] = meta->box[2] = meta->box[3] = 0.0; }
+        UH_KD_TOP(8);
         __hip_atomic_store(&meta->word, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+#undef UH_KD_TOP
 }
 
 }  // namespace uh_kd
