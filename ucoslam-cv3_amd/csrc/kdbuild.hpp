@@ -199,23 +199,42 @@ template <bool WG> __device__ __forceinline__ void team_sync() {
     if (WG) __syncthreads(); else uh_sel::wave_mem_sync();
 }
 
-// One coordinate's sums over the samples b, b + step, .. < e in sample order: s1 += x, s2 += x * x (float square, double sums —
-// picoflann.h:362-391).  The loads run eight samples ahead of the two dependent addition chains.
-__device__ __forceinline__ void sample_sums(const float* __restrict__ v, int b, int e, int step, double& s1, double& s2, int& cnt) {
+// One sum over the cnt samples v[b], v[b + step], .. in sample order: sq ? s += x * x (float square) : s += x, double accumulator
+// (picoflann.h:362-391).  Full groups of eight run without predicates, the loads one group ahead of the dependent addition chain.
+__device__ __forceinline__ double sample_sum(const float* __restrict__ v, int b, int step, int cnt, bool sq) {
+    double s = 0;
+    const float* p = v + b;
+    const int full = cnt >> 3;
     float cur[8], nxt[8];
-    s1 = 0; s2 = 0; cnt = 0;
+    if (full) {
 #pragma unroll
-    for (int u = 0; u < 8; u++) { const int j = b + u * step; cur[u] = j < e ? v[j] : 0.f; }
-    for (int i = b; i < e; i += 8 * step) {
+        for (int u = 0; u < 8; u++) cur[u] = p[u * step];
+        for (int g = 1; g < full; g++) {
+            p += 8 * step;
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int j = i + (8 + u) * step; nxt[u] = j < e ? v[j] : 0.f; }
+            for (int u = 0; u < 8; u++) nxt[u] = p[u * step];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            if (i + u * step < e) { const float x = cur[u]; s1 += (double)x; s2 += (double)(x * x); cnt++; }
+            for (int u = 0; u < 8; u++) { const float x = cur[u]; s += (double)(sq ? x * x : x); }
+#pragma unroll
+            for (int u = 0; u < 8; u++) cur[u] = nxt[u];
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) cur[u] = nxt[u];
+        for (int u = 0; u < 8; u++) { const float x = cur[u]; s += (double)(sq ? x * x : x); }
+        p += 8 * step;
     }
+    for (int u = 0; u < (cnt & 7); u++) { const float x = p[u * step]; s += (double)(sq ? x * x : x); }
+    return s;
+}
+
+// inclusive prefix sum over the 64 lanes in the VALU (DPP row shifts + row broadcasts; __shfl_up is ds_bpermute: an LDS round trip a step)
+__device__ __forceinline__ int wave_incl_scan(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return x;
 }
 
 // Sweeps levels of the tree below the nodes [lvl_b, lvl_e) (depth `depth`) whose points are [eb, ee), with the team's threads tid of nthr
@@ -237,24 +256,26 @@ __device__ void sweep_levels(const Lds& V, const int tid, const int nthr, const 
         const int nL = lvl_e - lvl_b;
         const unsigned c0 = *cursor;
         UH_KD_STAMP(0);
-        // ---- mean / variance over the samples, split dimension, cut (picoflann.h:362-401): lanes 2j, 2j + 1 own node j's x and y sums
-        for (int q0 = 0; q0 < nL * 2; q0 += nthr) {
-            const int q = q0 + tid, nd = q >> 1, ch = q & 1;
+        // ---- mean / variance over the samples, split dimension, cut (picoflann.h:362-401): lanes 4j .. 4j + 3 own node j's four sums
+        for (int q0 = 0; q0 < nL * 4; q0 += nthr) {
+            const int q = q0 + tid, nd = q >> 2, ch = q & 3;
             const int g = lvl_b + nd;
             int b = 0, e = 0;
             bool act = nd < nL;
             if (act) { const unsigned be = V.nbe[g]; b = (int)(be & 0xffffu); e = (int)(be >> 16); act = e - b > kLeafMax; }
-            double s1 = 0, s2 = 0;
+            double s = 0;
             int cnt = 0;
             if (act) {
-                const int c = e - b;
-                sample_sums(ch ? V.py : V.px, b, e, c >= 200 ? c / 100 : 1, s1, s2, cnt);
+                const int c = e - b, step = c >= 200 ? c / 100 : 1;
+                cnt = (c + step - 1) / step;
+                s = sample_sum((ch & 2) ? V.py : V.px, b, step, cnt, (ch & 1) != 0);
             }
-            const double o1 = shfl_f64(s1, lane ^ 1), o2 = shfl_f64(s2, lane ^ 1);
+            const int l0 = lane & ~3;
+            const double s1x = shfl_f64(s, l0), s2x = shfl_f64(s, l0 + 1), s1y = shfl_f64(s, l0 + 2), s2y = shfl_f64(s, l0 + 3);
             if (act && ch == 0) {
                 const double inv = 1. / double(cnt);
-                const double m0 = s1 * inv, m1 = o1 * inv;
-                const double v0 = s2 * inv - m0 * m0, v1 = o2 * inv - m1 * m1;
+                const double m0 = s1x * inv, m1 = s1y * inv;
+                const double v0 = s2x * inv - m0 * m0, v1 = s2y * inv - m1 * m1;
                 const int dim = v1 > v0 ? 1 : 0;
                 const double cut = dim ? m1 : m0;
                 V.ncut[g] = cut;
@@ -291,13 +312,9 @@ __device__ void sweep_levels(const Lds& V, const int tid, const int nthr, const 
             // row prefix: lane r of every wave holds the number of set predicates in front of row r
             const unsigned long long rowbits = lane < nrows ? bal[lane] : 0ull;
             int rb = __popcll(rowbits);
-            {
-                int inc = rb;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
-                rb = inc - rb;
-            }
-            const int total = __shfl(rb, 63) + __popc((unsigned)__shfl((int)(rowbits >> 32), 63)) + __popc((unsigned)__shfl((int)(rowbits & 0xffffffffull), 63));
+            rb = wave_incl_scan(rb) - rb;
+            const int total = __builtin_amdgcn_readlane(rb, 63) + __popc((unsigned)__builtin_amdgcn_readlane((int)(rowbits >> 32), 63)) +
+                              __popc((unsigned)__builtin_amdgcn_readlane((int)(rowbits & 0xffffffffull), 63));
             const bool need2 = status[2] != 0;
             // S(x): predicates set in [eb, x)
 #define UH_KD_S(x, out) do { const int o_ = (x) - eb, r_ = o_ >> 6; const int base_ = __shfl(rb, r_ & 63); \
@@ -314,7 +331,7 @@ __device__ void sweep_levels(const Lds& V, const int tid, const int nthr, const 
                 const bool active = valid && e - b > kLeafMax;
                 const unsigned long long own = bal[r];
                 const bool f = (own >> lane) & 1ull;
-                const int Si = __shfl(rb, r) + __popcll(own & ltmask);
+                const int Si = __builtin_amdgcn_readlane(rb, r) + __popcll(own & ltmask);
                 int Sb, Se;
                 UH_KD_S(b, Sb);
                 UH_KD_S(e, Se);
@@ -352,10 +369,10 @@ __device__ void sweep_levels(const Lds& V, const int tid, const int nthr, const 
 #undef UH_KD_S
             if (!need2) break;
         }
-        team_sync<WG>();
         UH_KD_STAMP(3);
-        if (tid == 0) status[2] = 0;   // (read two barriers ago, set again two barriers ahead)
-        // ---- where to split (picoflann.h:426-437), the std::sort fallback's serial phase, the two children
+        if (tid == 0) status[2] = 0;   // (read a barrier ago, set again two barriers ahead)
+        // ---- where to split (picoflann.h:426-437) and the two children — straight behind the swaps: the limits were counted a barrier ago,
+        // and only the std::sort fallback (below, behind the barrier) needs the points in their final places
         for (int q0 = 0; q0 < nL; q0 += nthr) {
             const int nd = q0 + tid;
             if (nd >= nL) continue;
@@ -371,8 +388,6 @@ __device__ void sweep_levels(const Lds& V, const int tid, const int nthr, const 
             if (lim1 == c || lim2 == 0) at = c / 2;
             unsigned flag = V.nflag[g];
             if (at < kLeafMax || c - at < kLeafMax) {
-                LdsAcc acc{V, (int)(flag & 1)};
-                sort_phase(acc, b, e);
                 at = c / 2;
                 flag |= 2;
                 atomicOr(&status[0], 1u);
@@ -394,11 +409,24 @@ __device__ void sweep_levels(const Lds& V, const int tid, const int nthr, const 
         UH_KD_STAMP(4);
         const bool anyfb = status[0] != 0;
         more = status[1] != 0;
+        const int cur_b = lvl_b;   // (this level's nodes: the fallback below still works on them)
         lvl_b = (int)c0;
         lvl_e = (int)*cursor;
         ++depth;
-        // ---- the fallback's insertion sort = a stable sort of what the serial phase left: rank by (key, position), permute through tmp
+        // ---- picoflann's std::sort fallback: libstdc++'s partitioning phase by one lane per node, then the insertion sort = a stable sort
+        // of what that left: rank by (key, position), permute through tmp
         if (anyfb) {
+            for (int q0 = 0; q0 < nL; q0 += nthr) {
+                const int nd = q0 + tid;
+                if (nd >= nL) continue;
+                const int g = cur_b + nd;
+                const unsigned fl = V.nflag[g];
+                if (!(fl & 2)) continue;
+                const unsigned be = V.nbe[g];
+                LdsAcc acc{V, (int)(fl & 1)};
+                sort_phase(acc, (int)(be & 0xffffu), (int)(be >> 16));
+            }
+            team_sync<WG>();
             unsigned long long pm = 0;
             for (int k = 0; k < ept; k++) {
                 const int r = tw + k * nw;
