@@ -664,8 +664,8 @@ int  uh_projmatch_debug_tree(uh_projmatch* pm, int32_t* n_nodes, const void** no
 /* the same build as a host-only function (no GPU needed): nodes24_out has room for 2n+2 nodes, leaf_idx_out for n entries */
 int  uh_kdtree_build_host(const float* xy, int32_t n, int32_t* n_nodes, void* nodes24_out, uint32_t* leaf_idx_out,
                           double* root_box4, int32_t* max_depth);
-/* test hooks of the device builder (csrc/kdbuild.hpp): the same outputs from the build kernel (n <= 4096; threads 0 = default, 256, 512 or
- * 1024), and — host only — the permutation its restatement of libstdc++'s std::sort gives n float keys (compared with std::sort itself) */
+/* test hooks of the device builder (csrc/kdbuild.hpp): the same outputs from the build kernel (n <= 4096; threads 0 = default, 256 or
+ * 512), and — host only — the permutation its restatement of libstdc++'s std::sort gives n float keys (compared with std::sort itself) */
 int  uh_kdtree_build_dev(uh_ctx* ctx, const float* xy, int32_t n, int32_t threads, int32_t* n_nodes, void* nodes24_out, uint32_t* leaf_idx_out,
                          double* root_box4, int32_t* max_depth);
 int  uh_kdtree_sort_restated_host(const float* keys, int32_t n, uint32_t* perm_out);

@@ -8,7 +8,7 @@ rng = np.random.default_rng(21)
 sizes = [int(a) for a in sys.argv[1:]] or [5, 11, 12, 20, 40, 64, 128, 500, 1024, 2000, 4096]
 for n in sizes:
     xy = (rng.random((n, 2)) * [1241, 376]).astype(np.float32)
-    for th in (256, 1024):
+    for th in (256, 512):
         print("run", n, th, flush=True)
         a = kdtree_build_dev(ctx, xy, th); b = kdtree_build_host(xy)
         ok = a["nodes"].tobytes() == b["nodes"].tobytes() and a["leaf_idx"].tobytes() == b["leaf_idx"].tobytes()

@@ -11,7 +11,7 @@ struct uh_dev_frame {
     uh::DevBuf buf;          // [descriptors n_cap x 32 | build input n_cap x 16 {und x, und y, bits(octave), -} | nodes | leaf records n_cap x 16]
     uh::MappedBuf meta;      // uh_kd::Meta, written by the build launch; its word is the completion word the host polls
     int n_cap = 0;
-    int threads = 1024;      // of the build workgroup (UH_KD_THREADS: 256 / 512 / 1024)
+    int threads = 512;       // of the build workgroup (UH_KD_THREADS: 256 / 512; 512 lanes leave each 256 registers: the cached row state of kdbuild.hpp)
     size_t o_desc = 0, o_in = 0, o_nodes = 0, o_leaf = 0;
     unsigned long long seq = 0;   // word of the latest build launch (0: none yet)
     bool attr_set = false;

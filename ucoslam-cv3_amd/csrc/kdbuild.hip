@@ -11,7 +11,7 @@
 
 namespace {
 
-__global__ __launch_bounds__(1024) void kd_build_kernel(const float4* __restrict__ in, int n_direct, const int* __restrict__ level_counts, int nlevels,
+__global__ __launch_bounds__(512) void kd_build_kernel(const float4* __restrict__ in, int n_direct, const int* __restrict__ level_counts, int nlevels,
                                                         int cap, int n_cap, uh_kd::Node24* __restrict__ nodes, float4* __restrict__ leaf, uh_kd::Meta* meta,
                                                         unsigned long long word, long long* clk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_kd[];
@@ -43,7 +43,7 @@ namespace uh {
 int dev_frame_reserve(uh_dev_frame* f, int n_cap) {
     UH_REQUIRE(n_cap >= 1 && n_cap <= uh_kd::kDevMaxPoints, "device frame: %d keypoints exceed the device kd-tree builder's %d (use uh_projmatch_set_frame)", n_cap, uh_kd::kDevMaxPoints);
     if (n_cap <= f->n_cap) return UH_OK;
-    static const int env_threads = [] { const char* e = getenv("UH_KD_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 0; }();
+    static const int env_threads = [] { const char* e = getenv("UH_KD_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512) ? v : 0; }();
     if (env_threads) f->threads = env_threads;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t m = (size_t)uh_kd::node_cap(n_cap, 16);
@@ -128,11 +128,11 @@ int uh_dev_frame_tree(uh_dev_frame* f, int32_t* n_kpts, int32_t* n_nodes, void* 
     return UH_OK;
 }
 
-// test hook: the device build of n host points (octave 0), same outputs as uh_kdtree_build_host; threads = 0 (default) / 256 / 512 / 1024
+// test hook: the device build of n host points (octave 0), same outputs as uh_kdtree_build_host; threads = 0 (default) / 256 / 512
 int uh_kdtree_build_dev(uh_ctx* ctx, const float* xy, int32_t n, int32_t threads, int32_t* n_nodes, void* nodes24_out, uint32_t* leaf_idx_out,
                         double* root_box4, int32_t* max_depth) {
     UH_REQUIRE(ctx && n >= 0 && (n == 0 || xy) && n_nodes && nodes24_out && leaf_idx_out && root_box4, "uh_kdtree_build_dev: bad arguments");
-    UH_REQUIRE(threads == 0 || threads == 256 || threads == 512 || threads == 1024, "uh_kdtree_build_dev: %d threads (256 / 512 / 1024)", threads);
+    UH_REQUIRE(threads == 0 || threads == 256 || threads == 512, "uh_kdtree_build_dev: %d threads (256 / 512)", threads);
     uh_dev_frame f;
     f.ctx = ctx;
     int rc = uh::dev_frame_reserve(&f, std::max(n, 1));
@@ -153,6 +153,9 @@ int uh_kdtree_build_dev(uh_ctx* ctx, const float* xy, int32_t n, int32_t threads
         UH_HIP_CHECK(hipMemcpy(c, f.d_clk.p, sizeof(c), hipMemcpyDeviceToHost));
         fprintf(stderr, "kd build n=%d threads=%d [us]: load %.2f  wg-levels %.2f  wave-levels(w0) %.2f  join %.2f  zero %.2f  climb %.2f  nodes %.2f  leaves %.2f  total %.2f\n", n, f.threads,
                 (c[1] - c[0]) * 0.01, (c[2] - c[1]) * 0.01, (c[3] - c[2]) * 0.01, (c[4] - c[3]) * 0.01, (c[5] - c[4]) * 0.01, (c[6] - c[5]) * 0.01, (c[7] - c[6]) * 0.01, (c[8] - c[7]) * 0.01, (c[8] - c[0]) * 0.01);
+        fprintf(stderr, "  waves done after the hand-over [us] (points):");
+        for (int w = 0; w < f.threads / 64; w++) fprintf(stderr, " %.1f (%lld)", (c[128 + w] - c[2]) * 0.01, c[144 + w]);
+        fprintf(stderr, "\n");
         for (int part = 0; part < 2; part++)
             for (int lv = 0; lv < 6; lv++) {
                 const long long* q = c + (part ? 64 : 16) + lv * 8;

@@ -178,12 +178,13 @@ __device__ __forceinline__ Lds carve(unsigned char* base, int n_cap, int nwaves)
     return V;
 }
 
-struct LdsAcc {   // the points of one node as std::sort sees them, keyed by coordinate `dim`
-    const Lds& V; int dim;
-    __device__ __forceinline__ float key(int i) const { return dim ? V.py[i] : V.px[i]; }
+struct LdsAcc {   // the points of one node as std::sort sees them, keyed by coordinate `dim` (pointers by value: a reference to the Lds
+                  // block would pin all of its seventeen pointers in scratch memory, reloaded behind every barrier)
+    float* px; float* py; unsigned short* ord; int dim;
+    __device__ __forceinline__ float key(int i) const { return dim ? py[i] : px[i]; }
     __device__ __forceinline__ float ekey(const Elem& e) const { return dim ? e.y : e.x; }
-    __device__ __forceinline__ Elem get(int i) const { return Elem{V.px[i], V.py[i], V.ord[i]}; }
-    __device__ __forceinline__ void set(int i, const Elem& e) const { V.px[i] = e.x; V.py[i] = e.y; V.ord[i] = (unsigned short)e.id; }
+    __device__ __forceinline__ Elem get(int i) const { return Elem{px[i], py[i], ord[i]}; }
+    __device__ __forceinline__ void set(int i, const Elem& e) const { px[i] = e.x; py[i] = e.y; ord[i] = (unsigned short)e.id; }
     __device__ __forceinline__ void swap(int i, int j) const { const Elem a = get(i), b = get(j); set(i, b); set(j, a); }
 };
 
@@ -242,8 +243,12 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
 // team's node allocator; status[0]: "a node of this level took the std::sort fallback", status[1]: children that will split again,
 // status[2]: "a point equals its node's cut" (all zero on entry).  bal: the team's row ballots (>= ceil((ee - eb) / 64) words).
 // Point i = eb + 64 r + lane belongs to row r; the team's wave tw owns rows tw, tw + nw, ..
-template <bool WG>
-__device__ void sweep_levels(const Lds& V, const int tid, const int nthr, const int eb, const int ee, int& lvl_b, int& lvl_e, unsigned* cursor,
+// FAST (the caller guarantees <= kKC rows per wave — always so for the first levels of <= 4096 points on 1024 threads and for subtrees of
+// <= 256 points): what a lane knows about its points (node, range) stays in registers from level to level and the rows of a phase are
+// loaded side by side; otherwise every phase re-reads it row by row.
+constexpr int kKC = 4;
+template <bool WG, bool FAST>
+__device__ __forceinline__ void sweep_levels(const Lds V, const int tid, const int nthr, const int eb, const int ee, int& lvl_b, int& lvl_e, unsigned* cursor,
                              unsigned* status, unsigned long long* bal, int& depth, const int max_levels, unsigned* s_maxdepth, long long* clk) {
 #define UH_KD_STAMP(j) do { if (clk && tid == 0 && lv < 6) clk[lv * 8 + (j)] = wall_clock64(); } while (0)
     const int lane = threadIdx.x & 63;
@@ -252,6 +257,25 @@ __device__ void sweep_levels(const Lds& V, const int tid, const int nthr, const 
     const int ept = (nrows + nw - 1) / nw;          // rows per wave
     const unsigned long long ltmask = (1ull << lane) - 1ull;
     bool more = lvl_e > lvl_b;
+    // FAST: per row u of this wave — the lane's point, its node and the node's range
+    int fi[kKC], fb[kKC], fe[kKC];
+    unsigned fg[kKC];
+    bool fvalid[kKC];
+    if constexpr (FAST) {
+#pragma unroll
+        for (int u = 0; u < kKC; u++) {
+            const int r = tw + u * nw;
+            fi[u] = eb + r * 64 + lane;
+            fvalid[u] = r < nrows && fi[u] < ee;
+            fg[u] = fvalid[u] ? V.eseg[fi[u]] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kKC; u++) {
+            const unsigned be = V.nbe[fg[u]];
+            fb[u] = fvalid[u] ? (int)(be & 0xffffu) : eb;
+            fe[u] = fvalid[u] ? (int)(be >> 16) : eb;
+        }
+    }
     for (int lv = 0; lv < max_levels && more; ++lv) {
         const int nL = lvl_e - lvl_b;
         const unsigned c0 = *cursor;
@@ -289,6 +313,89 @@ __device__ void sweep_levels(const Lds& V, const int tid, const int nthr, const 
             team_sync<WG>();
             UH_KD_STAMP(1 + pass);
             if (pass == 0 && tid == 0) { status[0] = 0; status[1] = 0; }   // (the previous level's readers are a barrier behind)
+            if constexpr (FAST) {
+                // ---- A: predicates, one ballot per row
+                float fx[kKC], fy[kKC], fcf[kKC];
+                unsigned ffl[kKC];
+#pragma unroll
+                for (int u = 0; u < kKC; u++) {
+                    fx[u] = fvalid[u] ? V.px[fi[u]] : 0.f; fy[u] = fvalid[u] ? V.py[fi[u]] : 0.f;
+                    fcf[u] = V.ncutf[fg[u]]; ffl[u] = V.nflag[fg[u]];
+                }
+                unsigned long long bm[kKC];
+                bool eqany = false;
+#pragma unroll
+                for (int u = 0; u < kKC; u++) {
+                    const bool active = fvalid[u] && fe[u] - fb[u] > kLeafMax;
+                    const float v = (ffl[u] & 1) ? fy[u] : fx[u];
+                    bm[u] = __ballot(active && (pass ? v <= fcf[u] : v < fcf[u]));
+                    if (pass == 0) eqany = eqany || __ballot(active && v == fcf[u]) != 0ull;
+                    const int r = tw + u * nw;
+                    if (lane == 0 && r < nrows) bal[r] = bm[u];
+                }
+                if (pass == 0 && eqany && lane == 0) atomicOr(&status[2], 1u);
+                team_sync<WG>();
+                // ---- B: row prefix, node counts, the two index lists
+                const unsigned long long rowbits = lane < nrows ? bal[lane] : 0ull;
+                int rb = __popcll(rowbits);
+                rb = wave_incl_scan(rb) - rb;
+                const int total = __builtin_amdgcn_readlane(rb, 63) + __popc((unsigned)__builtin_amdgcn_readlane((int)(rowbits >> 32), 63)) +
+                                  __popc((unsigned)__builtin_amdgcn_readlane((int)(rowbits & 0xffffffffull), 63));
+                const bool need2f = status[2] != 0;
+#define UH_KD_SF(x, out) do { const int o_ = (x) - eb, r_ = o_ >> 6; const int base_ = __shfl(rb, r_ & 63); \
+                              const unsigned long long bv_ = bal[r_ < nrows ? r_ : 0]; \
+                              (out) = r_ < nrows ? base_ + __popcll(bv_ & ((1ull << (o_ & 63)) - 1ull)) : total; } while (0)
+                int Sb[kKC], Se[kKC];
+#pragma unroll
+                for (int u = 0; u < kKC; u++) { UH_KD_SF(fb[u], Sb[u]); UH_KD_SF(fe[u], Se[u]); }
+#pragma unroll
+                for (int u = 0; u < kKC; u++) {
+                    const int r = tw + u * nw;
+                    const bool active = fvalid[u] && fe[u] - fb[u] > kLeafMax;
+                    const int Si = __builtin_amdgcn_readlane(rb, r & 63) + __popcll(bm[u] & ltmask);
+                    const bool f = (bm[u] >> lane) & 1ull;
+                    if (active) {
+                        const int i = fi[u], b = fb[u], e = fe[u];
+                        const int m = Se[u] - Sb[u], mid = b + m;
+                        if (i == b) V.nlim[fg[u]] = pass ? ((V.nlim[fg[u]] & 0xffffu) | ((unsigned)m << 16)) : ((unsigned)m | ((unsigned)m << 16));
+                        if (i < mid && !f) V.scr[b + (i - b) - (Si - Sb[u])] = (unsigned short)i;
+                        else if (i >= mid && f) V.scr[e - 1 - (Se[u] - Si - 1)] = (unsigned short)i;
+                    }
+                }
+                team_sync<WG>();
+                // ---- C: the pairs change places
+                int Sm[kKC];
+#pragma unroll
+                for (int u = 0; u < kKC; u++) { const int mid = fb[u] + (Se[u] - Sb[u]); UH_KD_SF(mid, Sm[u]); }
+#undef UH_KD_SF
+                int iL[kKC], iR[kKC];
+                bool sw[kKC];
+#pragma unroll
+                for (int u = 0; u < kKC; u++) {
+                    const int b = fb[u], e = fe[u], j = fi[u];
+                    const int mid = b + (Se[u] - Sb[u]);
+                    const int nl = (mid - b) - (Sm[u] - Sb[u]);
+                    sw[u] = fvalid[u] && e - b > kLeafMax && j - b < nl;
+                    iL[u] = sw[u] ? (int)V.scr[j] : 0;
+                    iR[u] = sw[u] ? (int)V.scr[e - 1 - (j - b)] : 0;
+                }
+                float ax[kKC], ay[kKC], bx[kKC], by[kKC];
+                unsigned short ao[kKC], bo[kKC];
+#pragma unroll
+                for (int u = 0; u < kKC; u++) {
+                    ax[u] = V.px[iL[u]]; ay[u] = V.py[iL[u]]; ao[u] = V.ord[iL[u]];
+                    bx[u] = V.px[iR[u]]; by[u] = V.py[iR[u]]; bo[u] = V.ord[iR[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < kKC; u++) {
+                    if (sw[u]) {
+                        V.px[iL[u]] = bx[u]; V.py[iL[u]] = by[u]; V.ord[iL[u]] = bo[u];
+                        V.px[iR[u]] = ax[u]; V.py[iR[u]] = ay[u]; V.ord[iR[u]] = ao[u];
+                    }
+                }
+                if (!need2f) break;
+                continue;
+            }
             bool eqany = false;
             for (int k = 0; k < ept; k++) {
                 const int r = tw + k * nw;
@@ -423,7 +530,7 @@ __device__ void sweep_levels(const Lds& V, const int tid, const int nthr, const 
                 const unsigned fl = V.nflag[g];
                 if (!(fl & 2)) continue;
                 const unsigned be = V.nbe[g];
-                LdsAcc acc{V, (int)(fl & 1)};
+                LdsAcc acc{V.px, V.py, V.ord, (int)(fl & 1)};
                 sort_phase(acc, (int)(be & 0xffffu), (int)(be >> 16));
             }
             team_sync<WG>();
@@ -464,6 +571,20 @@ __device__ void sweep_levels(const Lds& V, const int tid, const int nthr, const 
         }
         UH_KD_STAMP(5);
         // ---- every point learns its child; a fallback node's cut is the first point of its right half (picoflann.h:441-446)
+        if constexpr (FAST) {
+            unsigned chd[kKC], flg[kKC];
+            int mid[kKC];
+#pragma unroll
+            for (int u = 0; u < kKC; u++) { chd[u] = V.nchild[fg[u]]; mid[u] = V.nmid[fg[u]]; flg[u] = V.nflag[fg[u]]; }
+#pragma unroll
+            for (int u = 0; u < kKC; u++) {
+                if (!fvalid[u] || chd[u] == 0) continue;    // a leaf's points keep the leaf
+                const int i = fi[u];
+                if ((flg[u] & 2) && i == mid[u]) { const double cut = (double)((flg[u] & 1) ? V.py[i] : V.px[i]); V.ncut[fg[u]] = cut; V.ncutf[fg[u]] = (float)cut; }
+                if (i < mid[u]) { fg[u] = chd[u]; fe[u] = mid[u]; } else { fg[u] = chd[u] + 1; fb[u] = mid[u]; }
+                V.eseg[i] = (unsigned short)fg[u];
+            }
+        } else
         for (int k = 0; k < ept; k++) {
             const int r = tw + k * nw;
             if (r >= nrows) break;
@@ -486,7 +607,7 @@ struct Node24 { float divlow, divhigh; int left, right; int leaf_begin; short le
 static_assert(sizeof(Node24) == 24, "node layout");
 struct Meta { unsigned long long word; int n, n_nodes, max_depth, m_used; double box[4]; };   // 56 bytes, in pinned host memory
 
-// The whole build by one workgroup (blockDim.x = 64 * 2^j threads, 256 .. 1024).  in[i] = {x, y, bits(octave), -} of keypoint i;
+// The whole build by one workgroup (blockDim.x = 256 or 512 threads).  in[i] = {x, y, bits(octave), -} of keypoint i;
 // nodes_out: room for 2 * (n / 5) + 1 nodes (uh_kd::node_cap covers it), leaf_out[i] = {x, y, bits(keypoint << 4 | octave), 0} in leaf order.
 // Thread 0 leaves {n, n_nodes, depth, root box} in *meta and, last, stores `word` into meta->word with system-scope release.
 __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const float4* __restrict__ in, const int n, Node24* __restrict__ nodes_out,
@@ -516,7 +637,8 @@ __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const 
     if (n > kLeafMax) {
         int lvl_b = 0, lvl_e = 1, depth = 1;
         const int k_wg = uh_sel::floor_log2(nwaves);
-        sweep_levels<true>(V, tid, nthr, 0, n, lvl_b, lvl_e, &s_cursor[16], s_status[16], V.bal, depth, k_wg, &s_maxdepth, clk ? clk + 16 : nullptr);
+        if ((n + 63) / 64 <= kKC * nwaves) sweep_levels<true, true>(V, tid, nthr, 0, n, lvl_b, lvl_e, &s_cursor[16], s_status[16], V.bal, depth, k_wg, &s_maxdepth, clk ? clk + 16 : nullptr);
+        else sweep_levels<true, false>(V, tid, nthr, 0, n, lvl_b, lvl_e, &s_cursor[16], s_status[16], V.bal, depth, k_wg, &s_maxdepth, clk ? clk + 16 : nullptr);
         __syncthreads();
         UH_KD_TOP(2);
         // hand-over: node lvl_b + w goes to wave w with a node region of its own (a subtree of c points holds at most 2c/5 nodes)
@@ -539,10 +661,13 @@ __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const 
             if (lane == 0) s_cursor[wave] = mine;
             uh_sel::wave_mem_sync();
             int lb = lvl_b + wave, le = lb + 1, d = depth;
-            sweep_levels<false>(V, lane, 64, mb, me, lb, le, &s_cursor[wave], s_status[wave], V.bal + (mb >> 6) + before, d, 1 << 20, &s_maxdepth,
-                                clk && wave == 0 ? clk + 64 : nullptr);
+            if (me - mb <= 64 * kKC) sweep_levels<false, true>(V, lane, 64, mb, me, lb, le, &s_cursor[wave], s_status[wave], V.bal + (mb >> 6) + before, d, 1 << 20, &s_maxdepth,
+                                                               clk && wave == 0 ? clk + 64 : nullptr);
+            else sweep_levels<false, false>(V, lane, 64, mb, me, lb, le, &s_cursor[wave], s_status[wave], V.bal + (mb >> 6) + before, d, 1 << 20, &s_maxdepth,
+                                            clk && wave == 0 ? clk + 64 : nullptr);
         }
         UH_KD_TOP(3);
+        if (clk && lane == 0) { clk[128 + wave] = wall_clock64(); clk[144 + wave] = me - mb; }
         __syncthreads();
         UH_KD_TOP(4);
     }
