@@ -350,6 +350,10 @@ def main():
                 tracker = json.loads(subprocess.run([exe, "300", "30"], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
                 stage_ms["tracker_frame_ms"] = tracker["tracker_frame_ms"]
                 stage_ms["tracker_frames_per_s"] = tracker["tracker_frames_per_s"]
+                # the same chain with the frame kept on the device and Frame::create_kdtree built there (uh_orb_extract_frame_dev /
+                # uh_projmatch_set_frame_dev, csrc/kdbuild.hpp): identical results, no host CPU time for the tree, slower today
+                trk_dev = json.loads(subprocess.run([exe, "300", "30", "dev"], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
+                tracker["device_frame_route"] = {k: trk_dev[k] for k in ("tracker_frame_ms", "orb_extract_ms", "set_frame_ms", "match_prev_ms", "match_map_ms")}
         except Exception as e_:
             print("tracker chain stage skipped:", repr(e_), file=sys.stderr)
         # single-frame latency, host in / host out, batch 1 (what a sequential caller sees): ORB of one pinned frame into pinned arrays, the

@@ -1,10 +1,12 @@
 // The reference tracker's per-frame chain over the C ABI, ONE frame at a time, host buffers in and out of every call — what a drop-in
 // under UcoSlam::process() executes between two camera frames (reference file:line, statement starts of the token-pasted source):
 //
-//   FrameExtractor::process          ORB detectAndCompute + undistortPoints of the frame        uh_orb_extract_frame_dev frameextractor.cpp:430-520, :3985
-//   Frame::create_kdtree             kd-tree over the undistorted keypoints — built ON THE    (inside the call above)  frameextractor.cpp:4258, map_types/frame.h:124
-//                                    DEVICE behind the extractor's completion; the matcher     uh_projmatch_set_frame_dev
-//                                    adopts the device-resident frame (no D2H -> build -> H2D)
+//   FrameExtractor::process          ORB detectAndCompute + undistortPoints of the frame        uh_orb_extract_frame     frameextractor.cpp:430-520, :3985
+//   Frame::create_kdtree             kd-tree over the undistorted keypoints                   uh_projmatch_set_frame   frameextractor.cpp:4258, map_types/frame.h:124
+//                                    route "dev": the frame stays on the device, the tree is   uh_orb_extract_frame_dev + uh_projmatch_set_frame_dev
+//                                    built there by one workgroup (csrc/kdbuild.hpp) — the same
+//                                    tree, no host CPU time, but ~105 us on one compute unit
+//                                    against ~50 us on a host core: not the default
 //   tracker: previous-frame search   project the previous frame's map points, match          uh_projmatch_match_prev  utils/system.cpp:5930-6460 (call :6559-6565)
 //   PnPSolver::solvePnp              pose from those matches (4 x 10 LM iterations)           uh_pnp_solve             optimization/pnpsolver.cpp:116-409 (call system.cpp:6626)
 //   Map::matchFrameToMapPoints       the local map projected with the refined pose, 4-px disc  uh_projmatch_match       map.cpp:651-770 (call system.cpp:6897; radius :6762-6881)
@@ -17,7 +19,7 @@
 // so every stage works on data the previous one produced.  Prints one JSON line with the median per-stage and per-frame latencies.
 //
 //   g++ -std=c++17 -O2 -o tracker_frame examples/tracker_frame.cpp -Lucoslam-cv3_amd -lucoslam_hip -Wl,-rpath,$PWD/ucoslam-cv3_amd -Wl,-rpath,/opt/rocm/lib -lpthread
-//   ./tracker_frame [frames=200] [warmup=20] [route=dev|host]     (host: uh_orb_extract_frame + uh_projmatch_set_frame, the kd-tree built on the CPU)
+//   ./tracker_frame [frames=200] [warmup=20] [route=host|dev]     (dev: uh_orb_extract_frame_dev + uh_projmatch_set_frame_dev, the kd-tree built on the device)
 #include <algorithm>
 #include <array>
 #include <chrono>
@@ -107,7 +109,7 @@ struct Stat {
 
 int main(int argc, char** argv) {
     const int frames = argc > 1 ? std::atoi(argv[1]) : 200, warmup = argc > 2 ? std::atoi(argv[2]) : 20;
-    const bool dev_route = !(argc > 3 && std::strcmp(argv[3], "host") == 0);
+    const bool dev_route = argc > 3 && std::strcmp(argv[3], "dev") == 0;
     uh_ctx* ctx = nullptr;
     if (uh_ctx_create_private(0, &ctx) < 0) { std::printf("no device: %s (there is no CPU path)\n", uh_last_error()); return 0; }
     uh_orb* ext = nullptr; uh_projmatch* pm = nullptr; uh_pnp* pnp = nullptr;

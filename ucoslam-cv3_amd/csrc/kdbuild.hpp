@@ -243,10 +243,10 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
 // team's node allocator; status[0]: "a node of this level took the std::sort fallback", status[1]: children that will split again,
 // status[2]: "a point equals its node's cut" (all zero on entry).  bal: the team's row ballots (>= ceil((ee - eb) / 64) words).
 // Point i = eb + 64 r + lane belongs to row r; the team's wave tw owns rows tw, tw + nw, ..
-// FAST (the caller guarantees <= kKC rows per wave — always so for the first levels of <= 4096 points on 1024 threads and for subtrees of
-// <= 256 points): what a lane knows about its points (node, range) stays in registers from level to level and the rows of a phase are
+// FAST (the caller guarantees <= kKC rows per wave — always so for the first levels of <= 4096 points on 512 threads and for subtrees of
+// <= 512 points): what a lane knows about its points (node, range) stays in registers from level to level and the rows of a phase are
 // loaded side by side; otherwise every phase re-reads it row by row.
-constexpr int kKC = 4;
+constexpr int kKC = 8;
 template <bool WG, bool FAST>
 __device__ __forceinline__ void sweep_levels(const Lds V, const int tid, const int nthr, const int eb, const int ee, int& lvl_b, int& lvl_e, unsigned* cursor,
                              unsigned* status, unsigned long long* bal, int& depth, const int max_levels, unsigned* s_maxdepth, long long* clk) {
@@ -261,6 +261,7 @@ __device__ __forceinline__ void sweep_levels(const Lds V, const int tid, const i
     int fi[kKC], fb[kKC], fe[kKC];
     unsigned fg[kKC];
     bool fvalid[kKC];
+    const int nrw = tw < nrows ? (nrows - tw + nw - 1) / nw : 0;   // rows this wave owns (FAST: <= kKC)
     if constexpr (FAST) {
 #pragma unroll
         for (int u = 0; u < kKC; u++) {
@@ -314,83 +315,93 @@ __device__ __forceinline__ void sweep_levels(const Lds V, const int tid, const i
             UH_KD_STAMP(1 + pass);
             if (pass == 0 && tid == 0) { status[0] = 0; status[1] = 0; }   // (the previous level's readers are a barrier behind)
             if constexpr (FAST) {
+                unsigned* const nrec = reinterpret_cast<unsigned*>(V.ndivhigh);   // (free until the climb) per node: predicates set in front of it | its middle << 16
                 // ---- A: predicates, one ballot per row
-                float fx[kKC], fy[kKC], fcf[kKC];
-                unsigned ffl[kKC];
-#pragma unroll
-                for (int u = 0; u < kKC; u++) {
-                    fx[u] = fvalid[u] ? V.px[fi[u]] : 0.f; fy[u] = fvalid[u] ? V.py[fi[u]] : 0.f;
-                    fcf[u] = V.ncutf[fg[u]]; ffl[u] = V.nflag[fg[u]];
-                }
                 unsigned long long bm[kKC];
-                bool eqany = false;
+                {
+                    float fx[kKC], fy[kKC], fcf[kKC];
+                    unsigned ffl[kKC];
 #pragma unroll
-                for (int u = 0; u < kKC; u++) {
-                    const bool active = fvalid[u] && fe[u] - fb[u] > kLeafMax;
-                    const float v = (ffl[u] & 1) ? fy[u] : fx[u];
-                    bm[u] = __ballot(active && (pass ? v <= fcf[u] : v < fcf[u]));
-                    if (pass == 0) eqany = eqany || __ballot(active && v == fcf[u]) != 0ull;
-                    const int r = tw + u * nw;
-                    if (lane == 0 && r < nrows) bal[r] = bm[u];
+                    for (int u = 0; u < kKC; u++) {
+                        if (u >= nrw) break;
+                        fx[u] = fvalid[u] ? V.px[fi[u]] : 0.f; fy[u] = fvalid[u] ? V.py[fi[u]] : 0.f;
+                        fcf[u] = V.ncutf[fg[u]]; ffl[u] = V.nflag[fg[u]];
+                    }
+                    bool eqany = false;
+#pragma unroll
+                    for (int u = 0; u < kKC; u++) {
+                        if (u >= nrw) break;
+                        const bool active = fvalid[u] && fe[u] - fb[u] > kLeafMax;
+                        const float v = (ffl[u] & 1) ? fy[u] : fx[u];
+                        bm[u] = __ballot(active && (pass ? v <= fcf[u] : v < fcf[u]));
+                        if (pass == 0) eqany = eqany || __ballot(active && v == fcf[u]) != 0ull;
+                        if (lane == 0) bal[tw + u * nw] = bm[u];
+                    }
+                    if (pass == 0 && eqany && lane == 0) atomicOr(&status[2], 1u);
                 }
-                if (pass == 0 && eqany && lane == 0) atomicOr(&status[2], 1u);
                 team_sync<WG>();
-                // ---- B: row prefix, node counts, the two index lists
+                // ---- B1: row prefix; one lane per node: predicates in front of the node and inside it
                 const unsigned long long rowbits = lane < nrows ? bal[lane] : 0ull;
                 int rb = __popcll(rowbits);
                 rb = wave_incl_scan(rb) - rb;
                 const int total = __builtin_amdgcn_readlane(rb, 63) + __popc((unsigned)__builtin_amdgcn_readlane((int)(rowbits >> 32), 63)) +
                                   __popc((unsigned)__builtin_amdgcn_readlane((int)(rowbits & 0xffffffffull), 63));
                 const bool need2f = status[2] != 0;
-#define UH_KD_SF(x, out) do { const int o_ = (x) - eb, r_ = o_ >> 6; const int base_ = __shfl(rb, r_ & 63); \
-                              const unsigned long long bv_ = bal[r_ < nrows ? r_ : 0]; \
-                              (out) = r_ < nrows ? base_ + __popcll(bv_ & ((1ull << (o_ & 63)) - 1ull)) : total; } while (0)
-                int Sb[kKC], Se[kKC];
-#pragma unroll
-                for (int u = 0; u < kKC; u++) { UH_KD_SF(fb[u], Sb[u]); UH_KD_SF(fe[u], Se[u]); }
-#pragma unroll
-                for (int u = 0; u < kKC; u++) {
-                    const int r = tw + u * nw;
-                    const bool active = fvalid[u] && fe[u] - fb[u] > kLeafMax;
-                    const int Si = __builtin_amdgcn_readlane(rb, r & 63) + __popcll(bm[u] & ltmask);
-                    const bool f = (bm[u] >> lane) & 1ull;
-                    if (active) {
-                        const int i = fi[u], b = fb[u], e = fe[u];
-                        const int m = Se[u] - Sb[u], mid = b + m;
-                        if (i == b) V.nlim[fg[u]] = pass ? ((V.nlim[fg[u]] & 0xffffu) | ((unsigned)m << 16)) : ((unsigned)m | ((unsigned)m << 16));
-                        if (i < mid && !f) V.scr[b + (i - b) - (Si - Sb[u])] = (unsigned short)i;
-                        else if (i >= mid && f) V.scr[e - 1 - (Se[u] - Si - 1)] = (unsigned short)i;
+                for (int q0 = 0; q0 < nL; q0 += nthr) {   // (uniform trip count: the shuffles below need every lane)
+                    const int nd = q0 + tid;
+                    const int g = lvl_b + (nd < nL ? nd : 0);
+                    const unsigned be = V.nbe[g];
+                    const int b = (int)(be & 0xffffu), e = (int)(be >> 16);
+                    int Sb, Se;
+                    { const int o_ = b - eb, r_ = o_ >> 6; const int base_ = __shfl(rb, r_ & 63); const unsigned long long bv_ = bal[r_ < nrows ? r_ : 0];
+                      Sb = r_ < nrows ? base_ + __popcll(bv_ & ((1ull << (o_ & 63)) - 1ull)) : total; }
+                    { const int o_ = e - eb, r_ = o_ >> 6; const int base_ = __shfl(rb, r_ & 63); const unsigned long long bv_ = bal[r_ < nrows ? r_ : 0];
+                      Se = r_ < nrows ? base_ + __popcll(bv_ & ((1ull << (o_ & 63)) - 1ull)) : total; }
+                    if (nd < nL && e - b > kLeafMax) {
+                        const int m = Se - Sb;
+                        nrec[g] = (unsigned)Sb | ((unsigned)(b + m) << 16);
+                        V.nlim[g] = pass ? ((V.nlim[g] & 0xffffu) | ((unsigned)m << 16)) : ((unsigned)m | ((unsigned)m << 16));
                     }
                 }
                 team_sync<WG>();
-                // ---- C: the pairs change places
-                int Sm[kKC];
-#pragma unroll
-                for (int u = 0; u < kKC; u++) { const int mid = fb[u] + (Se[u] - Sb[u]); UH_KD_SF(mid, Sm[u]); }
-#undef UH_KD_SF
-                int iL[kKC], iR[kKC];
-                bool sw[kKC];
+                // ---- B2: a misplaced point of the back part lists itself (k-th from the end), one of the front part remembers its k
+                int kf[kKC];
 #pragma unroll
                 for (int u = 0; u < kKC; u++) {
-                    const int b = fb[u], e = fe[u], j = fi[u];
-                    const int mid = b + (Se[u] - Sb[u]);
-                    const int nl = (mid - b) - (Sm[u] - Sb[u]);
-                    sw[u] = fvalid[u] && e - b > kLeafMax && j - b < nl;
-                    iL[u] = sw[u] ? (int)V.scr[j] : 0;
-                    iR[u] = sw[u] ? (int)V.scr[e - 1 - (j - b)] : 0;
+                    kf[u] = -1;
+                    if (u >= nrw) break;
+                    const unsigned rec = nrec[fg[u]];
+                    const int Sb = (int)(rec & 0xffffu), mid = (int)(rec >> 16);
+                    const int i = fi[u], b = fb[u], e = fe[u];
+                    const int Si = __builtin_amdgcn_readlane(rb, (tw + u * nw) & 63) + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm[u], 0u));
+                    const bool f = (bm[u] >> lane) & 1ull;
+                    if (fvalid[u] && e - b > kLeafMax) {
+                        if (i < mid && !f) kf[u] = (i - b) - (Si - Sb);
+                        else if (i >= mid && f) V.scr[e - 1 - (Sb + (mid - b) - Si - 1)] = (unsigned short)i;
+                    }
                 }
-                float ax[kKC], ay[kKC], bx[kKC], by[kKC];
-                unsigned short ao[kKC], bo[kKC];
+                team_sync<WG>();
+                // ---- C: every misplaced point of the front part changes places with its partner
+                {
+                    int ip[kKC];
 #pragma unroll
-                for (int u = 0; u < kKC; u++) {
-                    ax[u] = V.px[iL[u]]; ay[u] = V.py[iL[u]]; ao[u] = V.ord[iL[u]];
-                    bx[u] = V.px[iR[u]]; by[u] = V.py[iR[u]]; bo[u] = V.ord[iR[u]];
-                }
+                    for (int u = 0; u < kKC; u++) { if (u >= nrw) break; ip[u] = kf[u] >= 0 ? (int)V.scr[fe[u] - 1 - kf[u]] : fi[u]; }
+                    float ax[kKC], ay[kKC], bx[kKC], by[kKC];
+                    unsigned short ao[kKC], bo[kKC];
 #pragma unroll
-                for (int u = 0; u < kKC; u++) {
-                    if (sw[u]) {
-                        V.px[iL[u]] = bx[u]; V.py[iL[u]] = by[u]; V.ord[iL[u]] = bo[u];
-                        V.px[iR[u]] = ax[u]; V.py[iR[u]] = ay[u]; V.ord[iR[u]] = ao[u];
+                    for (int u = 0; u < kKC; u++) {
+                        if (u >= nrw) break;
+                        const int i = fvalid[u] ? fi[u] : eb, j = fvalid[u] ? ip[u] : eb;
+                        ax[u] = V.px[i]; ay[u] = V.py[i]; ao[u] = V.ord[i];
+                        bx[u] = V.px[j]; by[u] = V.py[j]; bo[u] = V.ord[j];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kKC; u++) {
+                        if (u >= nrw) break;
+                        if (kf[u] >= 0) {
+                            V.px[fi[u]] = bx[u]; V.py[fi[u]] = by[u]; V.ord[fi[u]] = bo[u];
+                            V.px[ip[u]] = ax[u]; V.py[ip[u]] = ay[u]; V.ord[ip[u]] = ao[u];
+                        }
                     }
                 }
                 if (!need2f) break;
