@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <cstring>
 #include <random>
@@ -1334,88 +1335,220 @@ inline int host_hamming32(const uint8_t* a, const uint8_t* b) {
     return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) + __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
 }
 
+// ---- std::shuffle(first, last, std::mt19937()) as a position permutation.  The reference default-constructs the generator for every
+// node it splits (kmeansindexcreator.cpp:44-), so the permutation depends on the node's SIZE only, and libstdc++'s loop walks the
+// positions front to back (one draw per pair of positions below 65536 elements, an extra first draw for even sizes): the swaps of a size
+// are a prefix of the swaps of every larger size of the same parity.  They are RECORDED from the library call itself (a value type whose
+// ADL swap logs its operands) once per parity and replayed per node — no generator construction (624-word seeding + twist) per node.
+struct KmSwapRec { uint32_t id; };
+thread_local std::vector<uint32_t>* g_km_swaplog = nullptr;
+thread_local const KmSwapRec* g_km_swapbase = nullptr;
+inline void swap(KmSwapRec& a, KmSwapRec& b) noexcept {
+    g_km_swaplog->push_back((uint32_t)(&a - g_km_swapbase));
+    g_km_swaplog->push_back((uint32_t)(&b - g_km_swapbase));
+    const uint32_t t = a.id; a.id = b.id; b.id = t;
+}
+constexpr int kKmPairLimit = 65535;   // libstdc++: two positions per draw while n * n <= the generator's range (2^32 - 1)
+struct KmShuffleTables {
+    std::mutex mu;
+    std::vector<uint32_t> tgt[2];   // by parity of the size: tgt[i] = the position element i is swapped with (step i, i >= 1)
+    void ensure(int m) {            // caller holds mu
+        std::vector<uint32_t>& t = tgt[m & 1];
+        if ((int)t.size() >= m) return;
+        int want = std::max(m, 4096);
+        want = std::min(want + want / 2, kKmPairLimit);
+        if ((want & 1) != (m & 1)) want -= 1;
+        if (want < m) want = m;
+        std::vector<KmSwapRec> v(want);
+        for (int i = 0; i < want; i++) v[i].id = (uint32_t)i;
+        std::vector<uint32_t> log;
+        log.reserve(2 * (size_t)want);
+        g_km_swaplog = &log; g_km_swapbase = v.data();
+        std::mt19937 gen;
+        std::shuffle(v.begin(), v.end(), gen);
+        g_km_swaplog = nullptr; g_km_swapbase = nullptr;
+        t.assign(want, 0);
+        for (size_t q = 0; q + 1 < log.size(); q += 2) t[log[q]] = log[q + 1];   // (iter_swap(i, first + pos): the first operand is step i)
+    }
+};
+KmShuffleTables& km_tables() { static KmShuffleTables t; return t; }
+
+// rowsv <- std::shuffle(rowsv.begin(), rowsv.end(), std::mt19937()) (scratch: m entries)
+void km_shuffle(std::vector<uint32_t>& rowsv, std::vector<uint32_t>& scratch) {
+    const int m = (int)rowsv.size();
+    if (m < 2) return;
+    if (m > kKmPairLimit) { std::mt19937 gen; std::shuffle(rowsv.begin(), rowsv.end(), gen); return; }
+    KmShuffleTables& T = km_tables();
+    scratch.resize(m);
+    {
+        std::lock_guard<std::mutex> lk(T.mu);
+        T.ensure(m);
+        const uint32_t* t = T.tgt[m & 1].data();
+        uint32_t* p = scratch.data();
+        for (int i = 0; i < m; i++) p[i] = (uint32_t)i;
+        for (int i = 1; i < m; i++) { const uint32_t j = t[i]; const uint32_t a = p[i]; p[i] = p[j]; p[j] = a; }
+    }
+    std::vector<uint32_t> out(m);
+    for (int i = 0; i < m; i++) out[i] = rowsv[scratch[i]];
+    rowsv.swap(out);
+}
+
+// One node being split: its rows in shuffled order, the clusters forming under it.
+struct KmSplit {
+    int node = 0;
+    std::vector<uint32_t> rowsv, centres;
+    std::vector<KmBuildNode> kids;
+    std::vector<uint8_t> assign;     // cluster of rowsv[p], filled by the assignment step
+    size_t prev_hash = 0, cur_hash = 1, niters = 0;
+    bool active = true;
+};
+// nearest centre (first minimum — "an exact hit ends the scan" picks the same one) for every row of every split in `work`
+using KmAssignFn = std::function<int(const uint8_t* rows, int k, std::vector<KmSplit*>& work)>;
+
+int km_assign_host(const uint8_t* rows, int /*k*/, std::vector<KmSplit*>& work) {
+    for (KmSplit* sp : work) {
+        const int nc = (int)sp->kids.size();
+        sp->assign.resize(sp->rowsv.size());
+        for (size_t p = 0; p < sp->rowsv.size(); p++) {
+            int best = 0, bestd = 0x7fffffff;
+            for (int c = 0; c < nc; c++) {
+                const int d = host_hamming32(sp->kids[c].centre, rows + 32 * (size_t)sp->rowsv[p]);
+                if (d < bestd) { bestd = d; best = c; }
+                if (bestd == 0) break;
+            }
+            sp->assign[p] = (uint8_t)best;
+        }
+    }
+    return UH_OK;
+}
+
+// The assignment step of the build on the device: one thread per row of a node being split (positions of all the level's nodes
+// concatenated) — Hamming distance to each of its node's <= k centres, first minimum.  Inputs are read where the host packed them
+// (pinned, device-visible: 6 bytes per row + the centres), the cluster numbers go back the same way; the train rows are in HBM.
+__global__ __launch_bounds__(256) void kmeans_assign_kernel(const uint8_t* __restrict__ rows, const uint32_t* __restrict__ pos_row, const uint16_t* __restrict__ pos_slot,
+                                                            const uint8_t* __restrict__ centres, const uint8_t* __restrict__ slot_nc, int k, int npos,
+                                                            uint8_t* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npos) return;
+    const uint32_t r = pos_row[p];
+    const unsigned slot = pos_slot[p];
+    const int nc = slot_nc[slot];
+    const uint4* rp = reinterpret_cast<const uint4*>(rows + 32 * (size_t)r);
+    const uint4 a = rp[0], b = rp[1];
+    const uint4* cp = reinterpret_cast<const uint4*>(centres + (size_t)slot * k * 32);
+    int best = 0, bestd = 0x7fffffff;
+    for (int c = 0; c < nc; c++) {
+        const uint4 x = cp[2 * c], y = cp[2 * c + 1];
+        const int d = __popc(a.x ^ x.x) + __popc(a.y ^ x.y) + __popc(a.z ^ x.z) + __popc(a.w ^ x.w) + __popc(b.x ^ y.x) + __popc(b.y ^ y.y) + __popc(b.z ^ y.z) +
+                      __popc(b.w ^ y.w);
+        if (d < bestd) { bestd = d; best = c; }
+    }
+    out[p] = (uint8_t)best;
+}
+
 // returns UH_OK, or UH_EINVAL with the error text set.  depth_out: levels of internal blocks above the deepest leaf block.
-int kmeans_build_blob(const uint8_t* rows, int n, int k, int max_iters, std::vector<uint8_t>& blob, int& depth_out) {
+// Level by level (the reference recurses; its convert() lays the blocks out breadth first, which is the order nodes are appended in
+// here): every node of a level is shuffled and given its centres on the host, then ONE assignment step serves all of them (the device
+// kernel behind uh_knn_build_kmeans, km_assign_host behind the host-only hook) — the distances are where the build's time goes.
+int kmeans_build_blob(const uint8_t* rows, int n, int k, int max_iters, std::vector<uint8_t>& blob, int& depth_out, const KmAssignFn& assign_fn) {
     std::vector<KmBuildNode> nodes(1);
     std::vector<int> depth(1, 0);
     nodes[0].rows.resize(n);
     for (int i = 0; i < n; i++) nodes[0].rows[i] = (uint32_t)i;
     depth_out = 0;
-    // nodes are appended child by child while the vector is walked front to back: index order == the breadth-first order of
-    // KMeansIndexCreator::convert, whatever order the reference's recursion created them in
-    for (size_t cur = 0; cur < nodes.size(); cur++) {
-        if (cur != 0 && (int)nodes[cur].rows.size() <= k) continue;   // leaf (the root is always split)
-        if (depth[cur] > 64) {
-            uh::set_error("uh_knn_build_kmeans: the tree does not stop splitting (a cluster keeps collapsing into one child); the reference does not terminate on this input");
-            return UH_EINVAL;
-        }
-        std::vector<uint32_t> rowsv;
-        rowsv.swap(nodes[cur].rows);
-        std::mt19937 gen;
-        std::shuffle(rowsv.begin(), rowsv.end(), gen);
-        std::vector<uint32_t> centres;   // first k mutually distinct rows
-        for (size_t next = 0; next < rowsv.size() && (int)centres.size() < k; next++) {
-            bool dup = false;
-            for (uint32_t c : centres) if (host_hamming32(rows + 32 * (size_t)rowsv[next], rows + 32 * (size_t)c) == 0) { dup = true; break; }
-            if (!dup) centres.push_back(rowsv[next]);
-        }
-        const int nc = (int)centres.size();
-        std::vector<KmBuildNode> kids(nc);
-        for (int c = 0; c < nc; c++) std::memcpy(kids[c].centre, rows + 32 * (size_t)centres[c], 32);
-        auto assign = [&]() {   // nearest centre, first minimum; an exact hit ends the scan
-            for (auto& kd : kids) kd.rows.clear();
-            for (uint32_t r : rowsv) {
-                int best = 0, bestd = 0x7fffffff;
-                for (int c = 0; c < nc; c++) {
-                    const int d = host_hamming32(kids[c].centre, rows + 32 * (size_t)r);
-                    if (d < bestd) { bestd = d; best = c; }
-                    if (bestd == 0) break;
-                }
-                kids[best].rows.push_back(r);
-            }
-        };
-        assign();
-        // k-means rounds (HKMeansParams maxIters; -1 = until the assignment hash repeats): centres move to the bitwise majority of
-        // their clusters (kmeansindexcreator.h:245-262, 390-422)
-        size_t prev_hash = 0, cur_hash = 1, niters = 0;
-        while (cur_hash != prev_hash && (max_iters == -1 || niters++ < (size_t)max_iters)) {
-            std::swap(prev_hash, cur_hash);
-            for (int c = 0; c < nc; c++) {
-                if (kids[c].rows.empty()) kids[c].rows.push_back(centres[c]);
-                int sum[256] = {0};
-                for (uint32_t r : kids[c].rows) {
-                    const uint8_t* pr = rows + 32 * (size_t)r;
-                    for (int j = 0; j < 32; j++)
-                        for (int bit = 0; bit < 8; bit++) if (pr[j] & (128 >> bit)) ++sum[j * 8 + bit];
-                }
-                const int half = (int)kids[c].rows.size() / 2 + (int)(kids[c].rows.size() % 2);
-                std::memset(kids[c].centre, 0, 32);
-                for (int i = 0; i < 256; i++) if (sum[i] >= half) kids[c].centre[i / 8] |= (uint8_t)(1 << (7 - (i % 8)));
-            }
-            assign();
-            size_t seed = 0;
-            for (auto& kd : kids) for (uint32_t id : kd.rows) seed ^= id + 0x9e3779b9 + (seed << 6) + (seed >> 2);
-            cur_hash = seed;
-        }
-        int nkept = 0;
-        for (auto& kd : kids) nkept += !kd.rows.empty();
-        if (nkept == 1 && (int)rowsv.size() > k) {
-            bool same = true;
-            for (uint32_t r : rowsv) if (host_hamming32(rows + 32 * (size_t)r, rows + 32 * (size_t)rowsv[0]) != 0) { same = false; break; }
-            if (same) {
-                uh::set_error("uh_knn_build_kmeans: more than k=%d identical descriptors: the reference's tree construction does not terminate on this input", k);
+    std::vector<uint32_t> scratch;
+    size_t lvl_b = 0, lvl_e = 1;
+    while (lvl_b < lvl_e) {
+        std::vector<KmSplit> splits;
+        for (size_t cur = lvl_b; cur < lvl_e; cur++) {
+            if (cur != 0 && (int)nodes[cur].rows.size() <= k) continue;   // leaf (the root is always split)
+            if (depth[cur] > 64) {
+                uh::set_error("uh_knn_build_kmeans: the tree does not stop splitting (a cluster keeps collapsing into one child); the reference does not terminate on this input");
                 return UH_EINVAL;
             }
+            splits.emplace_back();
+            KmSplit& sp = splits.back();
+            sp.node = (int)cur;
+            sp.rowsv.swap(nodes[cur].rows);
+            km_shuffle(sp.rowsv, scratch);
+            for (size_t next = 0; next < sp.rowsv.size() && (int)sp.centres.size() < k; next++) {   // first k mutually distinct rows
+                bool dup = false;
+                for (uint32_t c : sp.centres) if (host_hamming32(rows + 32 * (size_t)sp.rowsv[next], rows + 32 * (size_t)c) == 0) { dup = true; break; }
+                if (!dup) sp.centres.push_back(sp.rowsv[next]);
+            }
+            sp.kids.resize(sp.centres.size());
+            for (size_t c = 0; c < sp.centres.size(); c++) std::memcpy(sp.kids[c].centre, rows + 32 * (size_t)sp.centres[c], 32);
         }
-        const int first = (int)nodes.size();
-        for (auto& kd : kids) {   // empty clusters are dropped (:268-271)
-            if (kd.rows.empty()) continue;
-            nodes.push_back(std::move(kd));
-            depth.push_back(depth[cur] + 1);
+        auto distribute = [&](std::vector<KmSplit*>& work) -> int {
+            const int rc = assign_fn(rows, k, work);
+            if (rc) return rc;
+            for (KmSplit* sp : work) {
+                for (auto& kd : sp->kids) kd.rows.clear();
+                for (size_t p = 0; p < sp->rowsv.size(); p++) sp->kids[sp->assign[p]].rows.push_back(sp->rowsv[p]);
+            }
+            return UH_OK;
+        };
+        std::vector<KmSplit*> work;
+        for (KmSplit& sp : splits) work.push_back(&sp);
+        int rc = work.empty() ? UH_OK : distribute(work);
+        if (rc) return rc;
+        // k-means rounds (HKMeansParams maxIters; -1 = until the assignment hash repeats): centres move to the bitwise majority of
+        // their clusters (kmeansindexcreator.h:245-262, 390-422); every node runs its own number of rounds
+        for (;;) {
+            work.clear();
+            for (KmSplit& sp : splits) {
+                if (!sp.active) continue;
+                if (!(sp.cur_hash != sp.prev_hash && (max_iters == -1 || sp.niters++ < (size_t)max_iters))) { sp.active = false; continue; }
+                std::swap(sp.prev_hash, sp.cur_hash);
+                const int nc = (int)sp.kids.size();
+                for (int c = 0; c < nc; c++) {
+                    KmBuildNode& kd = sp.kids[c];
+                    if (kd.rows.empty()) kd.rows.push_back(sp.centres[c]);
+                    int sum[256] = {0};
+                    for (uint32_t r : kd.rows) {
+                        const uint8_t* pr = rows + 32 * (size_t)r;
+                        for (int j = 0; j < 32; j++)
+                            for (int bit = 0; bit < 8; bit++) if (pr[j] & (128 >> bit)) ++sum[j * 8 + bit];
+                    }
+                    const int half = (int)kd.rows.size() / 2 + (int)(kd.rows.size() % 2);
+                    std::memset(kd.centre, 0, 32);
+                    for (int i = 0; i < 256; i++) if (sum[i] >= half) kd.centre[i / 8] |= (uint8_t)(1 << (7 - (i % 8)));
+                }
+                work.push_back(&sp);
+            }
+            if (work.empty()) break;
+            if ((rc = distribute(work))) return rc;
+            for (KmSplit* sp : work) {
+                size_t seed = 0;
+                for (auto& kd : sp->kids) for (uint32_t id : kd.rows) seed ^= id + 0x9e3779b9 + (seed << 6) + (seed >> 2);
+                sp->cur_hash = seed;
+            }
         }
-        nodes[cur].first_child = first;
-        nodes[cur].n_children = nkept;
-        depth_out = std::max(depth_out, depth[cur] + 1);
+        const size_t next_b = nodes.size();
+        for (KmSplit& sp : splits) {
+            const int cur = sp.node;
+            int nkept = 0;
+            for (auto& kd : sp.kids) nkept += !kd.rows.empty();
+            if (nkept == 1 && (int)sp.rowsv.size() > k) {
+                bool same = true;
+                for (uint32_t r : sp.rowsv) if (host_hamming32(rows + 32 * (size_t)r, rows + 32 * (size_t)sp.rowsv[0]) != 0) { same = false; break; }
+                if (same) {
+                    uh::set_error("uh_knn_build_kmeans: more than k=%d identical descriptors: the reference's tree construction does not terminate on this input", k);
+                    return UH_EINVAL;
+                }
+            }
+            const int first = (int)nodes.size();
+            for (auto& kd : sp.kids) {   // empty clusters are dropped (:268-271)
+                if (kd.rows.empty()) continue;
+                nodes.push_back(std::move(kd));
+                depth.push_back(depth[cur] + 1);
+            }
+            nodes[cur].first_child = first;
+            nodes[cur].n_children = nkept;
+            depth_out = std::max(depth_out, depth[cur] + 1);
+        }
+        lvl_b = next_b;
+        lvl_e = nodes.size();
     }
     auto pad8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
     std::vector<uint64_t> off(nodes.size());
@@ -1482,6 +1615,10 @@ struct uh_knn {
     // hierarchical k-means form of the same index (uh_knn_build_kmeans)
     std::vector<uint8_t> km_blob;
     uh::DevBuf km_dev;
+    uh::DevBuf km_rows;                   // the train rows of the build in HBM (the assignment kernel's operand)
+    uh::MappedBuf km_stage;               // [completion word | clusters out | row per position | slot per position | centres per slot | centres of a slot]
+    unsigned long long km_seq = 0;
+    double km_assign_us = 0; int km_assign_calls = 0;   // UH_KM_TIMING
     int km_k = 0, km_n = 0, km_depth = 0;
     bool km_attr = false;
 };
@@ -1920,12 +2057,66 @@ int uh_knn_build_kmeans(uh_knn* idx, const uint8_t* features, int n, int k, int 
     UH_REQUIRE(features != nullptr, "uh_knn_build_kmeans: NULL features");
     UH_REQUIRE(k >= 2 && k <= kWave, "uh_knn_build_kmeans: k=%d outside [2,%d] (one lane per child)", k, kWave);
     UH_REQUIRE(max_iters >= -1, "uh_knn_build_kmeans: maxIters=%d (use -1 for 'until convergence')", max_iters);
-    int rc = kmeans_build_blob(features, n, k, max_iters, idx->km_blob, idx->km_depth);
-    if (rc) { idx->km_blob.clear(); return rc; }
     UH_HIP_CHECK(hipSetDevice(idx->ctx->device));
+    hipStream_t st = idx->ctx->stream;
+    int rc;
+    if ((rc = idx->km_rows.reserve(32 * (size_t)n))) return rc;
+    UH_HIP_CHECK(hipMemcpyAsync(idx->km_rows.p, features, 32 * (size_t)n, hipMemcpyHostToDevice, st));   // (crosses while the host shuffles the root)
+    // the distances — where the reference's build time goes (kmeansindexcreator.cpp:44-) — on the device, one launch per level and k-means round
+    const KmAssignFn assign_dev = [idx, st](const uint8_t*, int kk, std::vector<KmSplit*>& work) -> int {
+        size_t npos = 0;
+        for (KmSplit* sp : work) npos += sp->rowsv.size();
+        const size_t nslots = work.size();
+        if (npos == 0) return UH_OK;
+        const auto ta = std::chrono::steady_clock::now();
+        UH_REQUIRE(nslots <= 65535, "uh_knn_build_kmeans: %zu nodes split on one level", nslots);
+        auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+        const size_t o_out = 64, o_row = al(o_out + npos), o_slot = al(o_row + 4 * npos), o_nc = al(o_slot + 2 * npos), o_cen = al(o_nc + nslots),
+                     total = al(o_cen + nslots * (size_t)kk * 32);
+        int rc2 = idx->km_stage.reserve(total);
+        if (rc2) return rc2;
+        char* hb = idx->km_stage.host<char>();
+        char* db = idx->km_stage.dev<char>();
+        uint32_t* h_row = reinterpret_cast<uint32_t*>(hb + o_row);
+        uint16_t* h_slot = reinterpret_cast<uint16_t*>(hb + o_slot);
+        size_t p = 0;
+        for (size_t s2 = 0; s2 < nslots; s2++) {
+            KmSplit* sp = work[s2];
+            std::memcpy(h_row + p, sp->rowsv.data(), 4 * sp->rowsv.size());
+            for (size_t q = 0; q < sp->rowsv.size(); q++) h_slot[p + q] = (uint16_t)s2;
+            p += sp->rowsv.size();
+            hb[o_nc + s2] = (char)(uint8_t)sp->kids.size();
+            for (size_t c = 0; c < sp->kids.size(); c++) std::memcpy(hb + o_cen + (s2 * (size_t)kk + c) * 32, sp->kids[c].centre, 32);
+        }
+        std::atomic_thread_fence(std::memory_order_release);
+        UH_LAUNCH(idx->ctx, kmeans_assign_kernel, dim3(uh_div_up((int)npos, 256)), dim3(256), 0, (const uint8_t*)idx->km_rows.as<uint8_t>(),
+                  (const uint32_t*)(db + o_row), (const uint16_t*)(db + o_slot), (const uint8_t*)(db + o_cen), (const uint8_t*)(db + o_nc), kk, (int)npos,
+                  reinterpret_cast<uint8_t*>(db + o_out));
+        UH_HIP_CHECK(hipGetLastError());
+        const unsigned long long word = ++idx->km_seq;
+        if ((rc2 = uh::post_host_word(idx->ctx, reinterpret_cast<unsigned long long*>(db), word))) return rc2;
+        if ((rc2 = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(hb), word, st, "uh_knn_build_kmeans"))) return rc2;
+        p = 0;
+        for (KmSplit* sp : work) {
+            sp->assign.assign(reinterpret_cast<const uint8_t*>(hb + o_out) + p, reinterpret_cast<const uint8_t*>(hb + o_out) + p + sp->rowsv.size());
+            p += sp->rowsv.size();
+        }
+        idx->km_assign_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta).count();
+        idx->km_assign_calls++;
+        return UH_OK;
+    };
+    idx->km_assign_us = 0; idx->km_assign_calls = 0;
+    static const bool km_timing = getenv("UH_KM_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = kmeans_build_blob(features, n, k, max_iters, idx->km_blob, idx->km_depth, assign_dev);
+    if (rc) { idx->km_blob.clear(); return rc; }
+    const auto t1 = std::chrono::steady_clock::now();
     if ((rc = idx->km_dev.reserve(idx->km_blob.size() + 64))) return rc;
     UH_HIP_CHECK(hipMemcpyAsync(idx->km_dev.p, idx->km_blob.data(), idx->km_blob.size(), hipMemcpyHostToDevice, idx->ctx->stream));
     UH_HIP_CHECK(hipStreamSynchronize(idx->ctx->stream));
+    if (km_timing) fprintf(stderr, "kmeans build n=%d: tree %.1f us (assign steps %.1f us in %d launches), blob upload %.1f us\n", n,
+                           std::chrono::duration<double, std::micro>(t1 - t0).count(), idx->km_assign_us, idx->km_assign_calls,
+                           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count());
     idx->km_k = k;
     idx->km_n = n;
     return UH_OK;
@@ -1936,7 +2127,7 @@ int uh_knn_kmeans_build_host(const uint8_t* features, int n, int k, int max_iter
     UH_REQUIRE(features && n > 0 && k >= 2 && k <= kWave && max_iters >= -1 && size, "uh_knn_kmeans_build_host: bad arguments");
     std::vector<uint8_t> blob;
     int depth = 0;
-    const int rc = kmeans_build_blob(features, n, k, max_iters, blob, depth);
+    const int rc = kmeans_build_blob(features, n, k, max_iters, blob, depth, km_assign_host);
     if (rc) return rc;
     *size = blob.size();
     if (out && cap) std::memcpy(out, blob.data(), (size_t)std::min<uint64_t>(cap, blob.size()));
