@@ -493,14 +493,31 @@ def main():
             pnp._h, dev_ptr(pd["pose"]), dev_ptr(pd["intr"]), 600, dev_ptr(pd["p3d"]), dev_ptr(pd["kp"]), dev_ptr(pd["invsig"]), dev_ptr(pd["weight"]),
             dev_ptr(pwork), dev_ptr(pout[0]), dev_ptr(pout[1]), dev_ptr(pout[2]), dev_ptr(pout[3]))), 20)
         # also outside the metric's step: what FrameMatcher_Flann really runs per frame pair — xflann's hierarchical k-means index (k = 32) built on
-        # the 10 000 train descriptors (host, as in the reference: the build is xflann's own byte layout) and searched with 16 checks for the
-        # frame's 2000 queries (GPU); the CPU leg beside it is cpu_baseline.match_hkmeans32_checks16_build_plus_search_ms_1_thread
+        # the train descriptors and searched with 16 checks for the frame's 2000 queries; the CPU leg beside it is
+        # cpu_baseline.match_hkmeans32_checks16_build_plus_search_ms_1_thread.  Round 6: the build runs level by level — shuffles (replayed from
+        # libstdc++'s recorded swaps), centres and the byte layout on the host, the distances of a whole level in one device launch.
         try:
             km_train, _ = synth.match_set(1, NT, seed=7)
-            t_b = time.perf_counter()
-            km_index = Index(ctx).build_kmeans(km_train, 32, 0)
+            km_index = Index(ctx)
+            for _ in range(3):
+                km_index.build_kmeans(km_train, 32, 0)
             torch.cuda.synchronize()
-            stage_ms["hkmeans32_build_ms_10000_rows_host"] = 1e3 * (time.perf_counter() - t_b)
+            t_b = time.perf_counter()
+            for _ in range(10):
+                km_index.build_kmeans(km_train, 32, 0)
+            torch.cuda.synchronize()
+            stage_ms["hkmeans32_build_ms_10000_rows"] = 1e3 * (time.perf_counter() - t_b) / 10
+            km_pair = Index(ctx)   # one frame pair of the matcher: the train FRAME's 2000 descriptors, build + search
+            km_tr2 = np.ascontiguousarray(km_train[:MAX_FEATURES])
+            km_q0 = orb_out[1][0]
+            for _ in range(3):
+                km_pair.build_kmeans(km_tr2, 32, 0); km_pair.search_kmeans(km_q0, NN, 16, sorted=False)
+            torch.cuda.synchronize()
+            t_b = time.perf_counter()
+            for _ in range(10):
+                km_pair.build_kmeans(km_tr2, 32, 0); km_pair.search_kmeans(km_q0, NN, 16, sorted=False)
+            torch.cuda.synchronize()
+            stage_ms["hkmeans32_frame_pair_build_plus_search_ms_2000x2000"] = 1e3 * (time.perf_counter() - t_b) / 10
             km_q = orb_out[1][0]
             km_index.search_kmeans(km_q, NN, 16, sorted=False)
             stage_ms["hkmeans32_search_ms_2000q_checks16"] = timed(lambda: km_index.search_kmeans(km_q, NN, 16, sorted=False), 30)

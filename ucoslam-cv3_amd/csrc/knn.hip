@@ -1322,10 +1322,11 @@ __global__ void knn_push_bench_kernel(int k, int n, long long* out) {
 // centres, so the libstdc++ call itself is the specification — and searched on the GPU.
 namespace {
 
-struct KmBuildNode {
-    std::vector<uint32_t> rows;      // rows assigned to this node (leaf: kept; internal: moved to the children)
-    uint8_t centre[32] = {0};        // feature shown in the parent's block: a train row, or the cluster's bitwise majority
+struct KmNode {   // breadth-first order == the block order of KMeansIndexCreator::convert
+    uint32_t begin = 0, count = 0;   // its rows: lvl_rows[level][begin, begin + count)
+    int level = 0;
     int first_child = -1, n_children = 0;
+    uint32_t centre = 0;             // the feature shown in the parent's block: a train row, or (>= n) extra centre number centre - n (a bitwise majority)
 };
 
 inline int host_hamming32(const uint8_t* a, const uint8_t* b) {
@@ -1352,6 +1353,7 @@ constexpr int kKmPairLimit = 65535;   // libstdc++: two positions per draw while
 struct KmShuffleTables {
     std::mutex mu;
     std::vector<uint32_t> tgt[2];   // by parity of the size: tgt[i] = the position element i is swapped with (step i, i >= 1)
+    std::vector<uint32_t> root_perm; int root_n = -1;   // the last root's permutation
     void ensure(int m) {            // caller holds mu
         std::vector<uint32_t>& t = tgt[m & 1];
         if ((int)t.size() >= m) return;
@@ -1373,54 +1375,46 @@ struct KmShuffleTables {
 };
 KmShuffleTables& km_tables() { static KmShuffleTables t; return t; }
 
-// rowsv <- std::shuffle(rowsv.begin(), rowsv.end(), std::mt19937()) (scratch: m entries)
-void km_shuffle(std::vector<uint32_t>& rowsv, std::vector<uint32_t>& scratch) {
-    const int m = (int)rowsv.size();
-    if (m < 2) return;
-    if (m > kKmPairLimit) { std::mt19937 gen; std::shuffle(rowsv.begin(), rowsv.end(), gen); return; }
-    KmShuffleTables& T = km_tables();
-    scratch.resize(m);
-    {
-        std::lock_guard<std::mutex> lk(T.mu);
-        T.ensure(m);
-        const uint32_t* t = T.tgt[m & 1].data();
-        uint32_t* p = scratch.data();
-        for (int i = 0; i < m; i++) p[i] = (uint32_t)i;
-        for (int i = 1; i < m; i++) { const uint32_t j = t[i]; const uint32_t a = p[i]; p[i] = p[j]; p[j] = a; }
-    }
-    std::vector<uint32_t> out(m);
-    for (int i = 0; i < m; i++) out[i] = rowsv[scratch[i]];
-    rowsv.swap(out);
-}
-
-// One node being split: its rows in shuffled order, the clusters forming under it.
-struct KmSplit {
-    int node = 0;
-    std::vector<uint32_t> rowsv, centres;
-    std::vector<KmBuildNode> kids;
-    std::vector<uint8_t> assign;     // cluster of rowsv[p], filled by the assignment step
-    size_t prev_hash = 0, cur_hash = 1, niters = 0;
-    bool active = true;
+// The assignment step's operands, packed by the builder where the step reads them (host memory; pinned and device-visible behind
+// uh_knn_build_kmeans): for every row of every node being split on this level its row number and the node's slot, per slot the number of
+// centres and their 32-byte features.  The step fills `cluster`.
+struct KmAssignIO {
+    size_t npos = 0, nslots = 0;
+    uint32_t* pos_row = nullptr; uint16_t* pos_slot = nullptr; uint8_t* slot_nc = nullptr; uint8_t* centres = nullptr;   // centres: slot * k * 32
+    const uint8_t* cluster = nullptr;
 };
-// nearest centre (first minimum — "an exact hit ends the scan" picks the same one) for every row of every split in `work`
-using KmAssignFn = std::function<int(const uint8_t* rows, int k, std::vector<KmSplit*>& work)>;
-
-int km_assign_host(const uint8_t* rows, int /*k*/, std::vector<KmSplit*>& work) {
-    for (KmSplit* sp : work) {
-        const int nc = (int)sp->kids.size();
-        sp->assign.resize(sp->rowsv.size());
-        for (size_t p = 0; p < sp->rowsv.size(); p++) {
+struct KmAssigner {
+    virtual ~KmAssigner() {}
+    virtual int reserve(size_t npos, size_t nslots, int k, KmAssignIO& io) = 0;   // buffers for a level (contents need not survive the next reserve)
+    virtual int run(const uint8_t* rows, int k, KmAssignIO& io) = 0;             // nearest centre, first minimum ("an exact hit ends the scan" picks the same one)
+};
+struct KmAssignerHost : KmAssigner {
+    std::vector<uint8_t> buf, out;
+    int reserve(size_t npos, size_t nslots, int k, KmAssignIO& io) override {
+        auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+        const size_t o_row = 0, o_slot = al(4 * npos), o_nc = al(o_slot + 2 * npos), o_cen = al(o_nc + nslots), total = o_cen + nslots * (size_t)k * 32;
+        buf.resize(total); out.resize(npos);
+        io.npos = npos; io.nslots = nslots;
+        io.pos_row = reinterpret_cast<uint32_t*>(buf.data() + o_row); io.pos_slot = reinterpret_cast<uint16_t*>(buf.data() + o_slot);
+        io.slot_nc = buf.data() + o_nc; io.centres = buf.data() + o_cen; io.cluster = out.data();
+        return UH_OK;
+    }
+    int run(const uint8_t* rows, int k, KmAssignIO& io) override {
+        for (size_t p = 0; p < io.npos; p++) {
+            const unsigned slot = io.pos_slot[p];
+            const int nc = io.slot_nc[slot];
+            const uint8_t* cen = io.centres + (size_t)slot * k * 32;
             int best = 0, bestd = 0x7fffffff;
             for (int c = 0; c < nc; c++) {
-                const int d = host_hamming32(sp->kids[c].centre, rows + 32 * (size_t)sp->rowsv[p]);
+                const int d = host_hamming32(cen + 32 * (size_t)c, rows + 32 * (size_t)io.pos_row[p]);
                 if (d < bestd) { bestd = d; best = c; }
                 if (bestd == 0) break;
             }
-            sp->assign[p] = (uint8_t)best;
+            out[p] = (uint8_t)best;
         }
+        return UH_OK;
     }
-    return UH_OK;
-}
+};
 
 // The assignment step of the build on the device: one thread per row of a node being split (positions of all the level's nodes
 // concatenated) — Hamming distance to each of its node's <= k centres, first minimum.  Inputs are read where the host packed them
@@ -1449,103 +1443,165 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(const uint8_t* __res
 // returns UH_OK, or UH_EINVAL with the error text set.  depth_out: levels of internal blocks above the deepest leaf block.
 // Level by level (the reference recurses; its convert() lays the blocks out breadth first, which is the order nodes are appended in
 // here): every node of a level is shuffled and given its centres on the host, then ONE assignment step serves all of them (the device
-// kernel behind uh_knn_build_kmeans, km_assign_host behind the host-only hook) — the distances are where the build's time goes.
-int kmeans_build_blob(const uint8_t* rows, int n, int k, int max_iters, std::vector<uint8_t>& blob, int& depth_out, const KmAssignFn& assign_fn) {
-    std::vector<KmBuildNode> nodes(1);
-    std::vector<int> depth(1, 0);
-    nodes[0].rows.resize(n);
-    for (int i = 0; i < n; i++) nodes[0].rows[i] = (uint32_t)i;
+// kernel behind uh_knn_build_kmeans, KmAssignerHost behind the host-only hook) — the distances are where the build's time goes.  The
+// rows of a level live in one flat array grouped by node; a node's clusters are a stable counting sort of its shuffled rows.
+// blob_alloc(total) returns where the block data goes (total bytes, written completely).
+int kmeans_build_blob(const uint8_t* rows, int n, int k, int max_iters, const std::function<uint8_t*(size_t)>& blob_alloc, int& depth_out, KmAssigner& asg) {
+    std::vector<KmNode> nodes(1);
+    std::vector<std::vector<uint32_t>> lvl_rows(1);
+    std::vector<uint8_t> extra;   // majority centres (k-means rounds), 32 bytes each
+    lvl_rows[0].resize(n);
+    for (int i = 0; i < n; i++) lvl_rows[0][i] = (uint32_t)i;
+    nodes[0].count = (uint32_t)n;
     depth_out = 0;
-    std::vector<uint32_t> scratch;
+    std::vector<uint32_t> perm, centres;
+    struct Split { int node; size_t pos0; uint32_t count; int nc; size_t cen0; bool active; size_t prev_hash, cur_hash, niters; };
     size_t lvl_b = 0, lvl_e = 1;
-    while (lvl_b < lvl_e) {
-        std::vector<KmSplit> splits;
+    for (int level = 0; lvl_b < lvl_e; level++) {
+        std::vector<Split> splits;
+        size_t npos = 0;
         for (size_t cur = lvl_b; cur < lvl_e; cur++) {
-            if (cur != 0 && (int)nodes[cur].rows.size() <= k) continue;   // leaf (the root is always split)
-            if (depth[cur] > 64) {
+            if (cur != 0 && (int)nodes[cur].count <= k) continue;   // leaf (the root is always split)
+            if (level > 64) {
                 uh::set_error("uh_knn_build_kmeans: the tree does not stop splitting (a cluster keeps collapsing into one child); the reference does not terminate on this input");
                 return UH_EINVAL;
             }
-            splits.emplace_back();
-            KmSplit& sp = splits.back();
-            sp.node = (int)cur;
-            sp.rowsv.swap(nodes[cur].rows);
-            km_shuffle(sp.rowsv, scratch);
-            for (size_t next = 0; next < sp.rowsv.size() && (int)sp.centres.size() < k; next++) {   // first k mutually distinct rows
-                bool dup = false;
-                for (uint32_t c : sp.centres) if (host_hamming32(rows + 32 * (size_t)sp.rowsv[next], rows + 32 * (size_t)c) == 0) { dup = true; break; }
-                if (!dup) sp.centres.push_back(sp.rowsv[next]);
-            }
-            sp.kids.resize(sp.centres.size());
-            for (size_t c = 0; c < sp.centres.size(); c++) std::memcpy(sp.kids[c].centre, rows + 32 * (size_t)sp.centres[c], 32);
+            splits.push_back(Split{(int)cur, npos, nodes[cur].count, 0, 0, true, 0, 1, 0});
+            npos += nodes[cur].count;
         }
-        auto distribute = [&](std::vector<KmSplit*>& work) -> int {
-            const int rc = assign_fn(rows, k, work);
-            if (rc) return rc;
-            for (KmSplit* sp : work) {
-                for (auto& kd : sp->kids) kd.rows.clear();
-                for (size_t p = 0; p < sp->rowsv.size(); p++) sp->kids[sp->assign[p]].rows.push_back(sp->rowsv[p]);
-            }
-            return UH_OK;
-        };
-        std::vector<KmSplit*> work;
-        for (KmSplit& sp : splits) work.push_back(&sp);
-        int rc = work.empty() ? UH_OK : distribute(work);
+        if (splits.empty()) break;
+        KmAssignIO io;
+        int rc = asg.reserve(npos, splits.size(), k, io);
         if (rc) return rc;
+        UH_REQUIRE(splits.size() <= 65535, "uh_knn_build_kmeans: %zu nodes split on one level", splits.size());
+        const std::vector<uint32_t>& cur_rows = lvl_rows[level];
+        centres.clear();
+        for (size_t si = 0; si < splits.size(); si++) {
+            Split& sp = splits[si];
+            const KmNode& nd = nodes[sp.node];
+            uint32_t* dst = io.pos_row + sp.pos0;
+            const uint32_t* src = cur_rows.data() + nd.begin;
+            const int m = (int)nd.count;
+            // std::shuffle(rows, std::mt19937()) through the recorded swaps
+            if (m > kKmPairLimit) { std::memcpy(dst, src, 4 * (size_t)m); std::mt19937 gen; std::shuffle(dst, dst + m, gen); }
+            else if (m < 2) { if (m) dst[0] = src[0]; }
+            else {
+                KmShuffleTables& T = km_tables();
+                std::lock_guard<std::mutex> lk(T.mu);
+                if (sp.node == 0 && T.root_n == m) std::memcpy(dst, T.root_perm.data(), 4 * (size_t)m);   // (the root's rows are 0 .. n-1: its shuffle IS the permutation; train sets repeat their size)
+                else {
+                    T.ensure(m);
+                    perm.resize(m);
+                    const uint32_t* t = T.tgt[m & 1].data();
+                    uint32_t* p = perm.data();
+                    for (int i = 0; i < m; i++) p[i] = (uint32_t)i;
+                    for (int i = 1; i < m; i++) { const uint32_t j = t[i]; const uint32_t a = p[i]; p[i] = p[j]; p[j] = a; }
+                    for (int i = 0; i < m; i++) dst[i] = src[p[i]];
+                    if (sp.node == 0) { T.root_perm.assign(dst, dst + m); T.root_n = m; }
+                }
+            }
+            for (int i = 0; i < m; i++) io.pos_slot[sp.pos0 + i] = (uint16_t)si;
+            sp.cen0 = centres.size();
+            for (int next = 0; next < m && sp.nc < k; next++) {   // first k mutually distinct rows
+                bool dup = false;
+                for (int c = 0; c < sp.nc; c++) if (host_hamming32(rows + 32 * (size_t)dst[next], rows + 32 * (size_t)centres[sp.cen0 + c]) == 0) { dup = true; break; }
+                if (!dup) { centres.push_back(dst[next]); sp.nc++; }
+            }
+            io.slot_nc[si] = (uint8_t)sp.nc;
+            for (int c = 0; c < sp.nc; c++) std::memcpy(io.centres + (si * (size_t)k + c) * 32, rows + 32 * (size_t)centres[sp.cen0 + c], 32);
+        }
+        if ((rc = asg.run(rows, k, io))) return rc;
+        // clusters -> the next level's flat array: per node a stable counting sort of its shuffled rows (the order push_back gives the reference)
+        lvl_rows.emplace_back(npos);
+        std::vector<uint32_t>& next_rows = lvl_rows.back();
+        std::vector<uint32_t> cnt((size_t)k * splits.size());
+        auto sort_clusters = [&](const Split& sp, size_t si) {
+            uint32_t* c = cnt.data() + si * (size_t)k;
+            std::fill(c, c + k, 0u);
+            const uint8_t* cl = io.cluster + sp.pos0;
+            for (uint32_t i = 0; i < sp.count; i++) c[cl[i]]++;
+            uint32_t off[64];
+            uint32_t o = (uint32_t)sp.pos0;
+            for (int q = 0; q < sp.nc; q++) { off[q] = o; o += c[q]; }
+            const uint32_t* src = io.pos_row + sp.pos0;
+            for (uint32_t i = 0; i < sp.count; i++) next_rows[off[cl[i]]++] = src[i];
+        };
+        for (size_t si = 0; si < splits.size(); si++) sort_clusters(splits[si], si);
         // k-means rounds (HKMeansParams maxIters; -1 = until the assignment hash repeats): centres move to the bitwise majority of
         // their clusters (kmeansindexcreator.h:245-262, 390-422); every node runs its own number of rounds
+        std::vector<uint8_t> majority;   // per split: k x 32 bytes, valid once a round has run for it
+        if (max_iters != 0) majority.assign(splits.size() * (size_t)k * 32, 0);
+        std::vector<char> has_majority(splits.size(), 0);
         for (;;) {
-            work.clear();
-            for (KmSplit& sp : splits) {
+            bool any = false;
+            for (size_t si = 0; si < splits.size(); si++) {
+                Split& sp = splits[si];
                 if (!sp.active) continue;
                 if (!(sp.cur_hash != sp.prev_hash && (max_iters == -1 || sp.niters++ < (size_t)max_iters))) { sp.active = false; continue; }
                 std::swap(sp.prev_hash, sp.cur_hash);
-                const int nc = (int)sp.kids.size();
-                for (int c = 0; c < nc; c++) {
-                    KmBuildNode& kd = sp.kids[c];
-                    if (kd.rows.empty()) kd.rows.push_back(sp.centres[c]);
+                const uint32_t* c = cnt.data() + si * (size_t)k;
+                uint32_t o = (uint32_t)sp.pos0;
+                for (int q = 0; q < sp.nc; q++) {
                     int sum[256] = {0};
-                    for (uint32_t r : kd.rows) {
-                        const uint8_t* pr = rows + 32 * (size_t)r;
+                    const uint32_t cn = c[q] ? c[q] : 1u;   // an empty cluster is given its centre row back (:390-)
+                    for (uint32_t i = 0; i < cn; i++) {
+                        const uint8_t* pr = rows + 32 * (size_t)(c[q] ? next_rows[o + i] : centres[sp.cen0 + q]);
                         for (int j = 0; j < 32; j++)
                             for (int bit = 0; bit < 8; bit++) if (pr[j] & (128 >> bit)) ++sum[j * 8 + bit];
                     }
-                    const int half = (int)kd.rows.size() / 2 + (int)(kd.rows.size() % 2);
-                    std::memset(kd.centre, 0, 32);
-                    for (int i = 0; i < 256; i++) if (sum[i] >= half) kd.centre[i / 8] |= (uint8_t)(1 << (7 - (i % 8)));
+                    o += c[q];
+                    const int half = (int)cn / 2 + (int)(cn % 2);
+                    uint8_t* ce = majority.data() + (si * (size_t)k + q) * 32;
+                    std::memset(ce, 0, 32);
+                    for (int i = 0; i < 256; i++) if (sum[i] >= half) ce[i / 8] |= (uint8_t)(1 << (7 - (i % 8)));
+                    std::memcpy(io.centres + (si * (size_t)k + q) * 32, ce, 32);
                 }
-                work.push_back(&sp);
+                has_majority[si] = 1;
+                any = true;
             }
-            if (work.empty()) break;
-            if ((rc = distribute(work))) return rc;
-            for (KmSplit* sp : work) {
+            if (!any) break;
+            // (one step over the whole level: a node that is no longer active gets the assignment it already has — its centres did not move)
+            if ((rc = asg.run(rows, k, io))) return rc;
+            for (size_t si = 0; si < splits.size(); si++) {
+                Split& sp = splits[si];
+                if (!sp.active) continue;
+                sort_clusters(sp, si);
                 size_t seed = 0;
-                for (auto& kd : sp->kids) for (uint32_t id : kd.rows) seed ^= id + 0x9e3779b9 + (seed << 6) + (seed >> 2);
-                sp->cur_hash = seed;
+                for (uint32_t i = 0; i < sp.count; i++) { const uint32_t id = next_rows[sp.pos0 + i]; seed ^= id + 0x9e3779b9 + (seed << 6) + (seed >> 2); }
+                sp.cur_hash = seed;
             }
         }
         const size_t next_b = nodes.size();
-        for (KmSplit& sp : splits) {
-            const int cur = sp.node;
+        for (size_t si = 0; si < splits.size(); si++) {
+            const Split& sp = splits[si];
+            const uint32_t* c = cnt.data() + si * (size_t)k;
             int nkept = 0;
-            for (auto& kd : sp.kids) nkept += !kd.rows.empty();
-            if (nkept == 1 && (int)sp.rowsv.size() > k) {
+            for (int q = 0; q < sp.nc; q++) nkept += c[q] != 0;
+            if (nkept == 1 && (int)sp.count > k) {
                 bool same = true;
-                for (uint32_t r : sp.rowsv) if (host_hamming32(rows + 32 * (size_t)r, rows + 32 * (size_t)sp.rowsv[0]) != 0) { same = false; break; }
+                const uint32_t* pr = io.pos_row + sp.pos0;
+                for (uint32_t i = 0; i < sp.count; i++) if (host_hamming32(rows + 32 * (size_t)pr[i], rows + 32 * (size_t)pr[0]) != 0) { same = false; break; }
                 if (same) {
                     uh::set_error("uh_knn_build_kmeans: more than k=%d identical descriptors: the reference's tree construction does not terminate on this input", k);
                     return UH_EINVAL;
                 }
             }
             const int first = (int)nodes.size();
-            for (auto& kd : sp.kids) {   // empty clusters are dropped (:268-271)
-                if (kd.rows.empty()) continue;
-                nodes.push_back(std::move(kd));
-                depth.push_back(depth[cur] + 1);
+            uint32_t o = (uint32_t)sp.pos0;
+            for (int q = 0; q < sp.nc; q++) {   // empty clusters are dropped (:268-271)
+                if (c[q] == 0) continue;
+                KmNode kd;
+                kd.begin = o; kd.count = c[q]; kd.level = level + 1;
+                if (has_majority[si]) {
+                    kd.centre = (uint32_t)n + (uint32_t)(extra.size() / 32);
+                    extra.insert(extra.end(), majority.data() + (si * (size_t)k + q) * 32, majority.data() + (si * (size_t)k + q + 1) * 32);
+                } else kd.centre = centres[sp.cen0 + q];
+                nodes.push_back(kd);
+                o += c[q];
             }
-            nodes[cur].first_child = first;
-            nodes[cur].n_children = nkept;
-            depth_out = std::max(depth_out, depth[cur] + 1);
+            nodes[sp.node].first_child = first;
+            nodes[sp.node].n_children = nkept;
+            depth_out = std::max(depth_out, level + 1);
         }
         lvl_b = next_b;
         lvl_e = nodes.size();
@@ -1554,25 +1610,29 @@ int kmeans_build_blob(const uint8_t* rows, int n, int k, int max_iters, std::vec
     std::vector<uint64_t> off(nodes.size());
     uint64_t total = 0;
     for (size_t i = 0; i < nodes.size(); i++) {
-        const size_t cnt = nodes[i].n_children ? (size_t)nodes[i].n_children : nodes[i].rows.size();
+        const size_t cnt = nodes[i].n_children ? (size_t)nodes[i].n_children : nodes[i].count;
         off[i] = total;
         total += pad8(8 + 8 * cnt) + 32 * cnt;
     }
     if (total >= (1ull << 31)) { uh::set_error("uh_knn_build_kmeans: index of %llu bytes exceeds the 31-bit block offsets of the reference's search", (unsigned long long)total); return UH_EINVAL; }
-    blob.assign(total, 0);
+    uint8_t* const blob = blob_alloc((size_t)total);
+    if (!blob) return UH_ENOMEM;
     for (size_t i = 0; i < nodes.size(); i++) {
-        const KmBuildNode& nd = nodes[i];
+        const KmNode& nd = nodes[i];
         const bool leaf = nd.n_children == 0;
-        const uint32_t cnt = leaf ? (uint32_t)nd.rows.size() : (uint32_t)nd.n_children;
-        uint8_t* blk = blob.data() + off[i];
-        const uint16_t n16 = (uint16_t)cnt;
+        const uint32_t cnt = leaf ? nd.count : (uint32_t)nd.n_children;
+        uint8_t* blk = blob + off[i];
         const uint32_t hs = (uint32_t)pad8(8 + 8 * (size_t)cnt);
+        std::memset(blk, 0, hs);
+        const uint16_t n16 = (uint16_t)cnt;
         std::memcpy(blk, &n16, 2);
         blk[2] = leaf ? 1 : 0;
         std::memcpy(blk + 4, &hs, 4);
+        const uint32_t* lr = leaf ? lvl_rows[nd.level].data() + nd.begin : nullptr;
         for (uint32_t j = 0; j < cnt; j++) {
-            const uint64_t info = leaf ? ((uint64_t)nd.rows[j] | 0x8000000000000000ull) : off[nd.first_child + j];
-            const uint8_t* feat = leaf ? rows + 32 * (size_t)nd.rows[j] : nodes[nd.first_child + j].centre;   // row, or centre
+            const uint64_t info = leaf ? ((uint64_t)lr[j] | 0x8000000000000000ull) : off[nd.first_child + j];
+            const uint32_t src = leaf ? lr[j] : nodes[nd.first_child + j].centre;
+            const uint8_t* feat = src < (uint32_t)n ? rows + 32 * (size_t)src : extra.data() + 32 * (size_t)(src - (uint32_t)n);   // row, or majority centre
             std::memcpy(blk + 8 + 8 * (size_t)j, &info, 8);
             std::memcpy(blk + hs + 32 * (size_t)j, feat, 32);
         }
@@ -1613,7 +1673,11 @@ struct uh_knn {
     uh::MappedBuf h_word;                 // completion word of a host-pointer search with pinned buffers
     unsigned long long host_seq = 0;
     // hierarchical k-means form of the same index (uh_knn_build_kmeans)
-    std::vector<uint8_t> km_blob;
+    std::vector<uint8_t> km_blob;         // host copy of the block data (streams, uh_knn_kmeans_blob): filled from km_pin on demand after a device build
+    uh::MappedBuf km_pin;                 // the build writes the block data here (pinned): [completion word | blocks]; a 16-byte-wide launch moves it to km_dev
+    size_t km_size = 0;                   // bytes of block data
+    bool km_blob_stale = false;           // km_blob has not been copied out of km_pin yet
+    unsigned long long km_pin_word = 0;   // completion word of the launch that last read km_pin
     uh::DevBuf km_dev;
     uh::DevBuf km_rows;                   // the train rows of the build in HBM (the assignment kernel's operand)
     uh::MappedBuf km_stage;               // [completion word | clusters out | row per position | slot per position | centres per slot | centres of a slot]
@@ -2052,6 +2116,7 @@ int uh_knn_set_row_offset(uh_knn* idx, int offset) {
 int uh_knn_build_kmeans(uh_knn* idx, const uint8_t* features, int n, int k, int max_iters) {
     UH_REQUIRE(idx, "uh_knn_build_kmeans: NULL index");
     idx->km_blob.clear();
+    idx->km_blob_stale = false;
     idx->km_n = 0;
     if (n <= 0) return UH_OK;   // index.cpp:49 — empty features leave the index unbuilt
     UH_REQUIRE(features != nullptr, "uh_knn_build_kmeans: NULL features");
@@ -2063,58 +2128,66 @@ int uh_knn_build_kmeans(uh_knn* idx, const uint8_t* features, int n, int k, int 
     if ((rc = idx->km_rows.reserve(32 * (size_t)n))) return rc;
     UH_HIP_CHECK(hipMemcpyAsync(idx->km_rows.p, features, 32 * (size_t)n, hipMemcpyHostToDevice, st));   // (crosses while the host shuffles the root)
     // the distances — where the reference's build time goes (kmeansindexcreator.cpp:44-) — on the device, one launch per level and k-means round
-    const KmAssignFn assign_dev = [idx, st](const uint8_t*, int kk, std::vector<KmSplit*>& work) -> int {
-        size_t npos = 0;
-        for (KmSplit* sp : work) npos += sp->rowsv.size();
-        const size_t nslots = work.size();
-        if (npos == 0) return UH_OK;
-        const auto ta = std::chrono::steady_clock::now();
-        UH_REQUIRE(nslots <= 65535, "uh_knn_build_kmeans: %zu nodes split on one level", nslots);
-        auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
-        const size_t o_out = 64, o_row = al(o_out + npos), o_slot = al(o_row + 4 * npos), o_nc = al(o_slot + 2 * npos), o_cen = al(o_nc + nslots),
-                     total = al(o_cen + nslots * (size_t)kk * 32);
-        int rc2 = idx->km_stage.reserve(total);
-        if (rc2) return rc2;
-        char* hb = idx->km_stage.host<char>();
-        char* db = idx->km_stage.dev<char>();
-        uint32_t* h_row = reinterpret_cast<uint32_t*>(hb + o_row);
-        uint16_t* h_slot = reinterpret_cast<uint16_t*>(hb + o_slot);
-        size_t p = 0;
-        for (size_t s2 = 0; s2 < nslots; s2++) {
-            KmSplit* sp = work[s2];
-            std::memcpy(h_row + p, sp->rowsv.data(), 4 * sp->rowsv.size());
-            for (size_t q = 0; q < sp->rowsv.size(); q++) h_slot[p + q] = (uint16_t)s2;
-            p += sp->rowsv.size();
-            hb[o_nc + s2] = (char)(uint8_t)sp->kids.size();
-            for (size_t c = 0; c < sp->kids.size(); c++) std::memcpy(hb + o_cen + (s2 * (size_t)kk + c) * 32, sp->kids[c].centre, 32);
+    struct DevAssigner : KmAssigner {
+        uh_knn* idx; hipStream_t st; size_t o_out = 0;
+        int reserve(size_t npos, size_t nslots, int kk, KmAssignIO& io) override {
+            auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+            o_out = 64;
+            const size_t o_row = al(o_out + npos), o_slot = al(o_row + 4 * npos), o_nc = al(o_slot + 2 * npos), o_cen = al(o_nc + nslots),
+                         total = al(o_cen + nslots * (size_t)kk * 32);
+            const int rc2 = idx->km_stage.reserve(total);   // (the previous level's launch has been awaited: the block is free)
+            if (rc2) return rc2;
+            char* hb = idx->km_stage.host<char>();
+            io.npos = npos; io.nslots = nslots;
+            io.pos_row = reinterpret_cast<uint32_t*>(hb + o_row); io.pos_slot = reinterpret_cast<uint16_t*>(hb + o_slot);
+            io.slot_nc = reinterpret_cast<uint8_t*>(hb + o_nc); io.centres = reinterpret_cast<uint8_t*>(hb + o_cen);
+            io.cluster = reinterpret_cast<const uint8_t*>(hb + o_out);
+            return UH_OK;
         }
-        std::atomic_thread_fence(std::memory_order_release);
-        UH_LAUNCH(idx->ctx, kmeans_assign_kernel, dim3(uh_div_up((int)npos, 256)), dim3(256), 0, (const uint8_t*)idx->km_rows.as<uint8_t>(),
-                  (const uint32_t*)(db + o_row), (const uint16_t*)(db + o_slot), (const uint8_t*)(db + o_cen), (const uint8_t*)(db + o_nc), kk, (int)npos,
-                  reinterpret_cast<uint8_t*>(db + o_out));
-        UH_HIP_CHECK(hipGetLastError());
-        const unsigned long long word = ++idx->km_seq;
-        if ((rc2 = uh::post_host_word(idx->ctx, reinterpret_cast<unsigned long long*>(db), word))) return rc2;
-        if ((rc2 = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(hb), word, st, "uh_knn_build_kmeans"))) return rc2;
-        p = 0;
-        for (KmSplit* sp : work) {
-            sp->assign.assign(reinterpret_cast<const uint8_t*>(hb + o_out) + p, reinterpret_cast<const uint8_t*>(hb + o_out) + p + sp->rowsv.size());
-            p += sp->rowsv.size();
+        int run(const uint8_t*, int kk, KmAssignIO& io) override {
+            const auto ta = std::chrono::steady_clock::now();
+            char* hb = idx->km_stage.host<char>();
+            char* db = idx->km_stage.dev<char>();
+            auto dev = [&](const void* h) { return db + (reinterpret_cast<const char*>(h) - hb); };
+            std::atomic_thread_fence(std::memory_order_release);
+            UH_LAUNCH(idx->ctx, kmeans_assign_kernel, dim3(uh_div_up((int)io.npos, 256)), dim3(256), 0, (const uint8_t*)idx->km_rows.as<uint8_t>(),
+                      (const uint32_t*)dev(io.pos_row), (const uint16_t*)dev(io.pos_slot), (const uint8_t*)dev(io.centres), (const uint8_t*)dev(io.slot_nc), kk,
+                      (int)io.npos, reinterpret_cast<uint8_t*>(db + o_out));
+            UH_HIP_CHECK(hipGetLastError());
+            const unsigned long long word = ++idx->km_seq;
+            int rc2;
+            if ((rc2 = uh::post_host_word(idx->ctx, reinterpret_cast<unsigned long long*>(db), word))) return rc2;
+            if ((rc2 = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(hb), word, st, "uh_knn_build_kmeans"))) return rc2;
+            idx->km_assign_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta).count();
+            idx->km_assign_calls++;
+            return UH_OK;
         }
-        idx->km_assign_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta).count();
-        idx->km_assign_calls++;
-        return UH_OK;
-    };
+    } assign_dev;
+    assign_dev.idx = idx; assign_dev.st = st;
     idx->km_assign_us = 0; idx->km_assign_calls = 0;
     static const bool km_timing = getenv("UH_KM_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    rc = kmeans_build_blob(features, n, k, max_iters, idx->km_blob, idx->km_depth, assign_dev);
-    if (rc) { idx->km_blob.clear(); return rc; }
+    if (idx->km_pin_word) {   // the previous build's upload has read the pinned block (long since, unless two builds follow each other directly)
+        if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(idx->km_pin.host<char>()), idx->km_pin_word, st, "uh_knn_build_kmeans"))) return rc;
+        idx->km_pin_word = 0;
+    }
+    int rc_alloc = UH_OK;
+    const std::function<uint8_t*(size_t)> blob_alloc = [idx, &rc_alloc](size_t total) -> uint8_t* {
+        rc_alloc = idx->km_pin.reserve(total + 64 + 16);
+        if (rc_alloc) return nullptr;
+        idx->km_size = total;
+        return idx->km_pin.host<uint8_t>() + 64;
+    };
+    rc = kmeans_build_blob(features, n, k, max_iters, blob_alloc, idx->km_depth, assign_dev);
+    if (rc) { idx->km_size = 0; return rc_alloc ? rc_alloc : rc; }
     const auto t1 = std::chrono::steady_clock::now();
-    if ((rc = idx->km_dev.reserve(idx->km_blob.size() + 64))) return rc;
-    UH_HIP_CHECK(hipMemcpyAsync(idx->km_dev.p, idx->km_blob.data(), idx->km_blob.size(), hipMemcpyHostToDevice, idx->ctx->stream));
-    UH_HIP_CHECK(hipStreamSynchronize(idx->ctx->stream));
-    if (km_timing) fprintf(stderr, "kmeans build n=%d: tree %.1f us (assign steps %.1f us in %d launches), blob upload %.1f us\n", n,
+    if ((rc = idx->km_dev.reserve(idx->km_size + 64))) return rc;
+    std::atomic_thread_fence(std::memory_order_release);
+    if ((rc = uh::copy16(idx->ctx, idx->km_dev.p, idx->km_pin.dev<char>() + 64, idx->km_size))) return rc;   // no synchronisation: searches follow on the same stream
+    idx->km_pin_word = ++idx->km_seq;
+    if ((rc = uh::post_host_word(idx->ctx, idx->km_pin.dev<unsigned long long>(), idx->km_pin_word))) return rc;
+    idx->km_blob_stale = true;
+    if (km_timing) fprintf(stderr, "kmeans build n=%d: tree %.1f us (assign steps %.1f us in %d launches), blob upload enqueued in %.1f us\n", n,
                            std::chrono::duration<double, std::micro>(t1 - t0).count(), idx->km_assign_us, idx->km_assign_calls,
                            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count());
     idx->km_k = k;
@@ -2127,7 +2200,8 @@ int uh_knn_kmeans_build_host(const uint8_t* features, int n, int k, int max_iter
     UH_REQUIRE(features && n > 0 && k >= 2 && k <= kWave && max_iters >= -1 && size, "uh_knn_kmeans_build_host: bad arguments");
     std::vector<uint8_t> blob;
     int depth = 0;
-    const int rc = kmeans_build_blob(features, n, k, max_iters, blob, depth, km_assign_host);
+    KmAssignerHost host_asg;
+    const int rc = kmeans_build_blob(features, n, k, max_iters, [&blob](size_t total) { blob.resize(total); return blob.data(); }, depth, host_asg);
     if (rc) return rc;
     *size = blob.size();
     if (out && cap) std::memcpy(out, blob.data(), (size_t)std::min<uint64_t>(cap, blob.size()));
@@ -2172,8 +2246,16 @@ bool km_blob_shape(const std::vector<uint8_t>& blob, int& depth, int& max_n) {
 }
 }  // namespace
 
+// the host copy of a device-built index's block data, made on first use (the build leaves it in pinned memory only)
+static void km_sync_host_blob(uh_knn* idx) {
+    if (!idx->km_blob_stale) return;
+    idx->km_blob.assign(idx->km_pin.host<uint8_t>() + 64, idx->km_pin.host<uint8_t>() + 64 + idx->km_size);
+    idx->km_blob_stale = false;
+}
+
 int uh_knn_to_stream(uh_knn* idx, uint8_t* out, uint64_t cap, uint64_t* size) {
     UH_REQUIRE(idx && size, "uh_knn_to_stream: NULL argument");
+    km_sync_host_blob(idx);
     if (idx->km_n == 0 || idx->km_blob.empty()) {
         // Index::toStream throws for an index that does not own its features; Linear::toStream is "Not yet" in the reference (linear.cpp:78-80)
         uh::set_error("uh_knn_to_stream: only the hierarchical k-means index has a stream form (xflann: Linear::toStream is not implemented)");
@@ -2218,6 +2300,7 @@ int uh_knn_from_stream(uh_knn* idx, const uint8_t* data, uint64_t nbytes) {
     UH_HIP_CHECK(hipMemcpyAsync(idx->km_dev.p, blob.data(), blob.size(), hipMemcpyHostToDevice, idx->ctx->stream));
     UH_HIP_CHECK(hipStreamSynchronize(idx->ctx->stream));
     idx->km_blob.swap(blob);
+    idx->km_blob_stale = false;
     idx->km_depth = depth;
     idx->km_k = std::max(max_n, 2);
     idx->km_n = (int)P.npoints;
@@ -2226,6 +2309,7 @@ int uh_knn_from_stream(uh_knn* idx, const uint8_t* data, uint64_t nbytes) {
 
 int uh_knn_kmeans_blob(uh_knn* idx, const uint8_t** data, uint64_t* size) {
     UH_REQUIRE(idx && data && size, "uh_knn_kmeans_blob: NULL argument");
+    km_sync_host_blob(idx);
     *data = idx->km_blob.empty() ? nullptr : idx->km_blob.data();
     *size = idx->km_blob.size();
     return UH_OK;
