@@ -83,7 +83,7 @@ for k in sorted(set(mf) | set(mo) | set(cf) | set(cw)):
     if k in mf:
         b, s_ = mf[k]["SQ_VALU_MFMA_BUSY_CYCLES"][1], mf[k]["SQ_BUSY_CYCLES"][1]
         e["mfma_busy_cycles_per_launch"] = round(b / max(mf[k]["SQ_VALU_MFMA_BUSY_CYCLES"][0], 1)); e["sq_busy_cycles_per_launch"] = round(s_ / max(mf[k]["SQ_BUSY_CYCLES"][0], 1))
-        e["mfma_busy_over_sq_busy"] = round(b / s_, 5) if s_ else None   # (raw ratio of the two counters: SQ_BUSY is per shader engine, MFMA_BUSY per SIMD — not a fraction)
+        # (no busy-over-busy ratio: SQ_BUSY_CYCLES is per shader engine, SQ_VALU_MFMA_BUSY_CYCLES per SIMD — their quotient exceeded 1 and is not a utilisation)
         if k in dur and dur[k][0]:
             # gfx94x MfmaUtil formula with the kernel's own duration for GRBM_GUI_ACTIVE: busy SIMD-cycles / (duration x 2.4 GHz x 256 CUs x 4 SIMDs)
             e["mfma_util_of_chip"] = round((b / max(mf[k]["SQ_VALU_MFMA_BUSY_CYCLES"][0], 1)) / (dur[k][1] / dur[k][0] * 2.4 * 256 * 4), 5)
