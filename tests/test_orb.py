@@ -174,7 +174,7 @@ def test_hip_orb_pinned_buffers_take_the_copy_free_path(hip_ctx, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"UH_ORB_FAST": "map"}, {"UH_ORB_PYRAMID": "chain"}, {"UH_ORB_FAST": "map", "UH_ORB_PYRAMID": "chain"}],
+@pytest.mark.parametrize("env", [{"UH_ORB_FAST": "map"}, {"UH_ORB_PYRAMID": "chain"}, {"UH_ORB_PYRAMID": "pair"}, {"UH_ORB_FAST": "map", "UH_ORB_PYRAMID": "chain"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_hip_orb_fallback_forms_bit_exact(hip_ctx, oracle, monkeypatch, env):
     """The two forms the plan falls back to when a cell / a level pair does not fit the fused kernels' staging buffers — the strength map +

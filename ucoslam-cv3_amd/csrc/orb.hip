@@ -421,6 +421,144 @@ __global__ __launch_bounds__(256) void resize_pair_kernel(const uint8_t* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the whole pyramid in ONE launch
+// Blur + every resize of ComputePyramid (ORBextractor.cpp:1261-1263, 1355-1393) by spatial tiles: level l depends on level l - 1 only
+// through a 4-tap footprint, so a workgroup that owns the same share R_l of EVERY level (tile (i, j) of an NTX x NTY partition) builds
+// them all out of LDS — at level l the rectangle C_l = R_l + what its C_{l+1} reads (the host works the rectangles out top down from the
+// tap tables: the halo accumulates to ~26 pixels at level 0), computed from the C_{l-1} it holds, only R_l going to HBM.  Four or five
+// dependent launches of 5-10 us become one; halo pixels are computed by two or more workgroups (the same integers).  Arithmetic: the
+// blur and resize paths above, restated on LDS rectangles (horizontal int32 sums per source row and destination column, vertical pass
+// over bands of 32 destination rows).
+constexpr int kPyrThreads = 1024, kPyrBand = 96;   // destination rows per vertical-pass band
+struct PyrTile { short r[kMaxLevels][4], c[kMaxLevels][4]; };   // x0 y0 x1 y1 (exclusive): what the tile writes / computes of each level
+struct PyrPlan { int ntiles, nlevels; int szA, szB, szRaw, szH16, szH32; };   // LDS areas in bytes
+struct PyrTaps { const int* xofs; const short* xcoef; const int* yofs; const short* ycoef; };
+
+__global__ __launch_bounds__(kPyrThreads) void pyramid_fused_kernel(const uint8_t* __restrict__ src, int w, int h, size_t src_stride, size_t src_frame_stride,
+                                                                   uint8_t* __restrict__ pyr, size_t frame_stride, const Plan plan, const PyrPlan pp,
+                                                                   const PyrTile* __restrict__ tiles, const PyrTaps taps, int blur) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_pyr[];
+    __shared__ short s_yrow[kPyrBand][4], s_ycf[kPyrBand][4];
+    const PyrTile& T = tiles[blockIdx.x];
+    const uint8_t* in = src + (size_t)blockIdx.z * src_frame_stride;
+    uint8_t* F = pyr + (size_t)blockIdx.z * frame_stride;
+    uint8_t* bufA = s_pyr;                       // levels 0, 2, 4, ..
+    uint8_t* bufB = s_pyr + pp.szA;              // levels 1, 3, 5, .. (level 0's raw tile and 16-bit sums live here first)
+    int* h32 = reinterpret_cast<int*>(s_pyr + pp.szA + (pp.szB > pp.szRaw + pp.szH16 ? pp.szB : pp.szRaw + pp.szH16));
+    const int tid = threadIdx.x;
+    // ---- level 0: the blurred (or copied) rectangle C_0
+    {
+        const int cx0 = T.c[0][0], cy0 = T.c[0][1], cw = T.c[0][2] - cx0, ch = T.c[0][3] - cy0;
+        const int rx0 = T.r[0][0], ry0 = T.r[0][1], rx1 = T.r[0][2], ry1 = T.r[0][3];
+        const LevelDesc& L0 = plan.lv[0];
+        if (cw > 0 && ch > 0) {
+            const int pa = (cw + 3) & ~3;
+            if (blur) {
+                uint8_t* raw = bufB;
+                uint16_t* h16 = reinterpret_cast<uint16_t*>(bufB + pp.szRaw);
+                const int rw = cw + 6, rh = ch + 6, rp = (rw + 3) & ~3;
+                {   // a thread keeps its column: the reflected source column is worked out once
+                    const int rstep = max(kPyrThreads / rw, 1), lx = tid % rw, r0 = tid / rw;
+                    if (r0 < rstep) {
+                        const int gx = reflect101(cx0 + lx - 3, w);
+                        for (int ly = r0; ly < rh; ly += 8 * rstep) {   // eight loads in flight (a dependent global load a row would be ~1 us each)
+                            uint8_t v[8];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) { const int y = ly + u * rstep; v[u] = y < rh ? in[(size_t)reflect101(cy0 + y - 3, h) * src_stride + gx] : (uint8_t)0; }
+#pragma unroll
+                            for (int u = 0; u < 8; u++) { const int y = ly + u * rstep; if (y < rh) raw[y * rp + lx] = v[u]; }
+                        }
+                    }
+                }
+                __syncthreads();
+                const int rstep = max(kPyrThreads / cw, 1), lx = tid % cw, r0 = tid / cw;
+                if (r0 < rstep)
+                    for (int ly = r0; ly < rh; ly += rstep) {   // horizontal 8.8 sums
+                        const uint8_t* q = raw + ly * rp + lx;
+                        h16[ly * pa + lx] = (uint16_t)(18u * (q[0] + q[6]) + 34u * (q[1] + q[5]) + 48u * (q[2] + q[4]) + 56u * q[3]);
+                    }
+                __syncthreads();
+                if (r0 < rstep) {
+                    const int gx = cx0 + lx;
+                    const bool xin = gx >= rx0 && gx < rx1;
+                    for (int ly = r0; ly < ch; ly += rstep) {   // vertical 16.16 sums
+                        const uint16_t* q = h16 + ly * pa + lx;
+                        const uint32_t sv = 18u * ((uint32_t)q[0] + q[6 * pa]) + 34u * ((uint32_t)q[pa] + q[5 * pa]) + 48u * ((uint32_t)q[2 * pa] + q[4 * pa]) + 56u * q[3 * pa];
+                        const uint8_t o = (uint8_t)((sv + 32768u) >> 16);
+                        bufA[ly * pa + lx] = o;
+                        const int gy = cy0 + ly;
+                        if (xin && gy >= ry0 && gy < ry1) F[L0.img_off + (size_t)gy * L0.pitch + gx] = o;
+                    }
+                }
+            } else {
+                const unsigned m_cw = div_magic(cw);
+                for (int i = tid; i < cw * ch; i += kPyrThreads) {
+                    const int ly = div_by(i, cw, m_cw), lx = i - ly * cw;
+                    const int gx = cx0 + lx, gy = cy0 + ly;
+                    const uint8_t o = in[(size_t)gy * src_stride + gx];
+                    bufA[ly * pa + lx] = o;
+                    if (gx >= rx0 && gx < rx1 && gy >= ry0 && gy < ry1) F[L0.img_off + (size_t)gy * L0.pitch + gx] = o;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- levels 1 ..: C_l from C_{l-1}
+    for (int l = 1; l < pp.nlevels; l++) {
+        const LevelDesc& S = plan.lv[l - 1];
+        const LevelDesc& D = plan.lv[l];
+        const uint8_t* P = (l & 1) ? bufA : bufB;
+        uint8_t* Q = (l & 1) ? bufB : bufA;
+        const int px0 = T.c[l - 1][0], py0 = T.c[l - 1][1], pw = T.c[l - 1][2] - px0;
+        const int ppitch = (pw + 3) & ~3;
+        const int cx0 = T.c[l][0], cy0 = T.c[l][1], cw = T.c[l][2] - cx0, ch = T.c[l][3] - cy0;
+        const int rx0 = T.r[l][0], ry0 = T.r[l][1], rx1 = T.r[l][2], ry1 = T.r[l][3];
+        if (cw <= 0 || ch <= 0) continue;     // (uniform; the tiles above this level are empty too)
+        const int qp = (cw + 3) & ~3;
+        const int* xofs = taps.xofs + D.xtap_off; const short* xcoef = taps.xcoef + (size_t)D.xtap_off * 4;
+        const int* yofs = taps.yofs + D.ytap_off; const short* ycoef = taps.ycoef + (size_t)D.ytap_off * 4;
+        // a thread keeps its destination column through both passes: its four source columns and horizontal taps are worked out once
+        const int rstep = max(kPyrThreads / cw, 1), c = tid % cw, r0 = tid / cw, gx = cx0 + c;
+        const bool mine = r0 < rstep;
+        int sx[4], cxk[4];
+        {
+            const int xo = xofs[gx];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { sx[k] = min(max(xo - 1 + k, 0), S.w - 1) - px0; cxk[k] = xcoef[gx * 4 + k]; }
+        }
+        const bool xin = gx >= rx0 && gx < rx1;
+        for (int by = 0; by < ch; by += kPyrBand) {
+            const int bh = min(kPyrBand, ch - by);
+            const int gy_first = cy0 + by, gy_last = gy_first + bh - 1;
+            const int sy0 = min(max(yofs[gy_first] - 1, 0), S.h - 1), sy1 = min(max(yofs[gy_last] + 2, 0), S.h - 1);
+            const int srows = sy1 - sy0 + 1;
+            if (tid < bh) {   // the band's vertical taps, once (a global load per row inside the pass below would be a dependent ~1 us each)
+                const int gy = gy_first + tid, yo = yofs[gy];
+                const short* yc = ycoef + gy * 4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { s_yrow[tid][k] = (short)(min(max(yo - 1 + k, 0), S.h - 1) - sy0); s_ycf[tid][k] = yc[k]; }
+            }
+            if (mine)
+                for (int r = r0; r < srows; r += rstep) {   // horizontal pass: every source row of the band
+                    const uint8_t* row = P + (sy0 + r - py0) * ppitch;
+                    h32[r * qp + c] = row[sx[0]] * cxk[0] + row[sx[1]] * cxk[1] + row[sx[2]] * cxk[2] + row[sx[3]] * cxk[3];
+                }
+            __syncthreads();
+            if (mine)
+                for (int r = r0; r < bh; r += rstep) {      // vertical pass
+                    const int gy = gy_first + r;
+                    int acc = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc += h32[s_yrow[r][k] * qp + c] * s_ycf[r][k];
+                    const uint8_t o = (uint8_t)min(max((acc + (1 << 21)) >> 22, 0), 255);
+                    Q[(by + r) * qp + c] = o;
+                    if (xin && gy >= ry0 && gy < ry1) F[D.img_off + (size_t)gy * D.pitch + gx] = o;
+                }
+            __syncthreads();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ FAST strength map
 // score(p) = max over the 16 arcs of 9 contiguous circle pixels of min(|I_k - I_p| signed the same way) - 1, clamped to >= 0:
 // the value cv::cornerScore<16> returns for any threshold <= score.  Pixels closer than 3 to the level edge score 0.
@@ -1199,6 +1337,10 @@ struct uh_orb {
     bool pair_ok[kMaxLevels] = {};  // levels l and l+1 can be built by one resize_pair_kernel launch (the footprints fit its staging area)
     bool pair_fusion = true;       // UH_ORB_PYRAMID=chain: one launch per level
     int pair_from = 4;             // three to six frames: levels >= pair_from are built two per launch (UH_ORB_PAIR_FROM for the A/B)
+    bool pyr_fused = false;        // the whole pyramid in one launch (pyramid_fused_kernel): the plan's rectangles fit LDS (UH_ORB_PYRAMID=pair | chain for the launch-per-level forms)
+    PyrPlan pyr_plan{};
+    uh::DevBuf d_pyr_tiles;
+    bool pyr_attr = false;
     bool fuse_fast = false;        // every cell fits cell_nms_kernel<true>'s staging buffers: no strength map, no fast_score launch
     int nms_tile_bytes = 0, nms_lds_bytes = 0;   // cell_nms_kernel<true>'s dynamic LDS: strength tile | patch / candidate lists
     bool score_valid = false;      // d_score holds the last extraction's strength maps (uh_orb_debug_level computes them on demand)
@@ -1354,6 +1496,77 @@ int make_plan(uh_orb* o, int w, int h, int batch) {
             o->pair_ok[l] = fits;
         }
     }
+    {   // pyramid_fused_kernel: every level's share of a spatial tile (R) and what the tile must compute of it for the level above (C), top down
+        const char* e = getenv("UH_ORB_PYRAMID");
+        const bool want = !(e && (std::string(e) == "chain" || std::string(e) == "pair"));
+        o->pyr_fused = false;
+        const int nlv = P.lvl_end;
+        auto clampi = [](int v, int lo, int hi) { return std::min(std::max(v, lo), hi); };
+        // ~256 square tiles (one workgroup per compute unit for ONE frame: the halo makes a tile compute ~5x its share, which costs nothing
+        // while the chip is otherwise idle; batches of three frames or more keep the launch-per-level forms, measured faster there)
+        for (int attempt = 0; want && nlv >= 1 && attempt < 8 && !o->pyr_fused; attempt++) {
+            const int ncu = o->ctx->num_cus > 0 ? o->ctx->num_cus : 256;
+            const double side = std::sqrt((double)w * h / (double)ncu) / std::pow(1.4142, attempt);
+            int ntx = std::max(1, (int)std::lround(w / std::max(side, 8.0))), nty = std::max(1, (int)std::lround(h / std::max(side, 8.0)));
+            // (sixteen waves of <= 128 registers: ONE workgroup per compute unit — a 257th tile would be a second round of the whole launch)
+            while (attempt == 0 && ntx * nty > ncu && ntx > 1) --ntx;
+            if ((long long)ntx * nty > 8192) break;
+            std::vector<PyrTile> tiles((size_t)ntx * nty);
+            PyrPlan pl{};
+            pl.ntiles = ntx * nty; pl.nlevels = nlv;
+            long long szA = 16, szB = 16, szRaw = 16, szH16 = 16, szH32 = 16;
+            bool ok = true;
+            for (int ty = 0; ty < nty && ok; ty++)
+                for (int tx = 0; tx < ntx && ok; tx++) {
+                    PyrTile& T = tiles[(size_t)ty * ntx + tx];
+                    int cx0 = 0, cy0 = 0, cx1 = 0, cy1 = 0;   // C of the level above (empty)
+                    for (int l = nlv - 1; l >= 0; l--) {
+                        const LevelDesc& L = P.lv[l];
+                        const int rx0 = (int)((long long)tx * L.w / ntx), rx1 = (int)((long long)(tx + 1) * L.w / ntx);
+                        const int ry0 = (int)((long long)ty * L.h / nty), ry1 = (int)((long long)(ty + 1) * L.h / nty);
+                        int x0 = rx0, x1 = rx1, y0 = ry0, y1 = ry1;
+                        const bool r_empty = rx1 <= rx0 || ry1 <= ry0;
+                        if (r_empty) { x0 = y0 = 0; x1 = y1 = 0; }
+                        if (l + 1 < nlv && cx1 > cx0 && cy1 > cy0) {   // what C_{l+1} reads of this level
+                            const LevelDesc& U = P.lv[l + 1];
+                            const int* ux = xofs.data() + U.xtap_off; const int* uy = yofs.data() + U.ytap_off;
+                            const int fx0 = clampi(ux[cx0] - 1, 0, L.w - 1), fx1 = clampi(ux[cx1 - 1] + 2, 0, L.w - 1) + 1;
+                            const int fy0 = clampi(uy[cy0] - 1, 0, L.h - 1), fy1 = clampi(uy[cy1 - 1] + 2, 0, L.h - 1) + 1;
+                            if (x1 <= x0 || y1 <= y0) { x0 = fx0; x1 = fx1; y0 = fy0; y1 = fy1; }
+                            else { x0 = std::min(x0, fx0); x1 = std::max(x1, fx1); y0 = std::min(y0, fy0); y1 = std::max(y1, fy1); }
+                        }
+                        T.r[l][0] = (short)(r_empty ? 0 : rx0); T.r[l][1] = (short)(r_empty ? 0 : ry0); T.r[l][2] = (short)(r_empty ? 0 : rx1); T.r[l][3] = (short)(r_empty ? 0 : ry1);
+                        T.c[l][0] = (short)x0; T.c[l][1] = (short)y0; T.c[l][2] = (short)x1; T.c[l][3] = (short)y1;
+                        cx0 = x0; cy0 = y0; cx1 = x1; cy1 = y1;
+                        const long long cw = x1 - x0, ch = y1 - y0, pitch = (cw + 3) & ~3ll;
+                        if (cw <= 0 || ch <= 0) continue;
+                        if (cw + 6 > kPyrThreads) ok = false;   // (a thread per column)
+                        if (l & 1) szB = std::max(szB, pitch * ch); else szA = std::max(szA, pitch * ch);
+                        if (l == 0) { szRaw = std::max(szRaw, ((cw + 6 + 3) & ~3ll) * (ch + 6)); szH16 = std::max(szH16, (ch + 6) * pitch * 2); }
+                        else {
+                            const LevelDesc& Sv = P.lv[l - 1];
+                            const int* ly = yofs.data() + L.ytap_off;
+                            for (int by = 0; by < ch; by += kPyrBand) {
+                                const int g0 = y0 + by, g1 = y0 + std::min<long long>(by + kPyrBand, ch) - 1;
+                                const int s0 = clampi(ly[g0] - 1, 0, Sv.h - 1), s1 = clampi(ly[g1] + 2, 0, Sv.h - 1);
+                                szH32 = std::max(szH32, (long long)(s1 - s0 + 1) * pitch * 4);
+                            }
+                        }
+                    }
+                }
+            auto al16 = [](long long v) { return (int)((v + 15) & ~15ll); };
+            pl.szA = al16(szA); pl.szB = al16(szB); pl.szRaw = al16(szRaw); pl.szH16 = al16(szH16); pl.szH32 = al16(szH32);
+            const long long lds = (long long)pl.szA + std::max(pl.szB, pl.szRaw + pl.szH16) + pl.szH32;
+            if (!ok || lds > 150 * 1024) continue;
+            o->pyr_plan = pl;
+            int rcp = o->d_pyr_tiles.reserve(tiles.size() * sizeof(PyrTile));
+            if (rcp) return rcp;
+            UH_HIP_CHECK(hipSetDevice(o->ctx->device));
+            UH_HIP_CHECK(hipMemcpyAsync(o->d_pyr_tiles.p, tiles.data(), tiles.size() * sizeof(PyrTile), hipMemcpyHostToDevice, o->ctx->stream));
+            UH_HIP_CHECK(hipStreamSynchronize(o->ctx->stream));
+            o->pyr_fused = true;
+        }
+    }
     {   // the FAST strength is computed inside cell_nms_kernel when every cell fits its staging buffers (UH_ORB_FAST=map: the two-launch form)
         bool fits = true;
         for (const CellDesc& C : o->cells) {
@@ -1451,14 +1664,25 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
         UH_HIP_CHECK(hipMemsetAsync(d_counts, 0, sizeof(int) * batch, st));
         return UH_OK;
     }
-    if (o->blur_first) {
+    const bool fused = o->pyr_fused && batch == 1;
+    if (fused) {   // blur + every resize in one launch
+        const PyrPlan& pl = o->pyr_plan;
+        const size_t lds = (size_t)pl.szA + (size_t)std::max(pl.szB, pl.szRaw + pl.szH16) + (size_t)pl.szH32;
+        if (!o->pyr_attr) {
+            UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pyramid_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            o->pyr_attr = true;
+        }
+        const PyrTaps tp{o->d_xofs.as<int>(), o->d_xcoef.as<short>(), o->d_yofs.as<int>(), o->d_ycoef.as<short>()};
+        UH_LAUNCH(o->ctx, pyramid_fused_kernel, dim3(pl.ntiles, 1, batch), dim3(kPyrThreads), lds, d_imgs, w, h, stride, img_frame_stride, pyr, o->frame_stride, P, pl,
+                  (const PyrTile*)o->d_pyr_tiles.as<PyrTile>(), tp, o->blur_first ? 1 : 0);
+    } else if (o->blur_first) {
         UH_LAUNCH(o->ctx,blur7_kernel, dim3(uh_div_up(w, 64), uh_div_up(h, 16), batch), dim3(256), 0, d_imgs, w, h, stride,
                            img_frame_stride, pyr + L0.img_off, L0.pitch, o->frame_stride);
     } else {
         UH_LAUNCH(o->ctx,copy_kernel, dim3(uh_div_up(w, 256), h, batch), dim3(256), 0, d_imgs, w, h, stride,
                            img_frame_stride, pyr + L0.img_off, L0.pitch, o->frame_stride);
     }
-    for (int l = 1; l < P.lvl_end; l++) {
+    for (int l = 1; l < P.lvl_end && !fused; l++) {
         const LevelDesc& S = P.lv[l - 1];
         const LevelDesc& D = P.lv[l];
         // two levels per launch: for one or two frames everywhere (pure launch latency); up to 16 frames six only above level 3, where the
