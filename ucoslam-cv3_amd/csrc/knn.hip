@@ -1723,6 +1723,10 @@ static bool launch_replay_lanes(uh_knn* idx, int nq, int nn, int sorted, int max
     return true;
 }
 
+// compute units the context's stream can really use (a CU-masked context reports its share, ADVICE r5: the replay workgroups of the stream
+// form barrier on each other inside the launch and must all be resident — the capacity tests must not assume more CUs than the mask gives)
+static inline int km_cus(const uh_ctx* c) { return c->num_cus > 0 ? c->num_cus : 64; }
+
 extern "C" {
 
 int uh_knn_create(uh_ctx* ctx, uh_knn** out) {
@@ -1830,9 +1834,9 @@ static int knn_search_dev_impl(uh_knn* idx, const uint8_t* d_queries, int nq, in
     // slower (the pushes of a wave's queries serialise), its L1/L2 traffic and its resident waves drop to 1/2 or 1/4, which is what a
     // latency-bound neighbour on another stream (the local BA) needs
     const int qpw = nn <= 15 ? idx->qpw : 1;
-    const bool few_form = uh_div_up(nq, kWave) + nq <= 2 * 4 * std::max(idx->ctx->num_cus, 64);
+    const bool few_form = uh_div_up(nq, kWave) + nq <= 2 * 4 * km_cus(idx->ctx);
     // one query per scan wave at up to four waves per SIMD (~4000 queries); nn <= 5: up to three (at 4000 queries the two launches win: nn 2 51 us against 58)
-    const bool few_any = uh_div_up(nq, kWave) + nq <= (nn >= idx->stream_min_nn ? 4 : 3) * 4 * std::max(idx->ctx->num_cus, 64);   // at most two one-wave workgroups per SIMD with ONE query per scan wave (knn_stream_kernel<K, 2>)
+    const bool few_any = uh_div_up(nq, kWave) + nq <= (nn >= idx->stream_min_nn ? 4 : 3) * 4 * km_cus(idx->ctx);   // at most two one-wave workgroups per SIMD with ONE query per scan wave (knn_stream_kernel<K, 2>)
     if (nn <= kRpK && (nq >= idx->two_phase_min_nq || (nn >= idx->stream_min_nn && nq >= idx->stream_min_nq) || (few_any && idx->stream_when_few)) && idx->shard_end <= (1 << 23)) {   // (the replay packs distance and row index into 32 bits)
         // accept-list capacity: the expected number of accepted pushes is k (1 + ln(N / k)) (a record process), its spread ~ sqrt of
         // that; lists that still overflow (distances descending with the row index) are redone by knn_redo_kernel
@@ -1844,8 +1848,8 @@ static int knn_search_dev_impl(uh_knn* idx, const uint8_t* d_queries, int nq, in
         // the replay workgroups of the stream form wait for each other at the end (the shared redo, the hand-over to the host): ALL of them must be
         // resident at once — they are the first workgroups of the grid, and they are kept to at most two per compute unit (32 768 queries on
         // MI355X; a 20th of the one-wave slots); larger batches take the two launches
-        const bool stream_fits = uh_div_up(nq, kWave) <= 2 * std::max(idx->ctx->num_cus, 64);
-        if (stream_fits && (nn >= idx->stream_min_nn || (few_any && idx->stream_when_few)) && idx->accept_qpw == 2 && (size_t)nq * cap * 8 < ((size_t)1 << 31)) {   // (record offsets are 32-bit buffer offsets)
+        const bool stream_fits = uh_div_up(nq, kWave) <= 2 * km_cus(idx->ctx);
+        if (stream_fits && cap >= kWave /* (the vector first step writes a whole step before the list-full test: ADVICE r5) */ && (nn >= idx->stream_min_nn || (few_any && idx->stream_when_few)) && idx->accept_qpw == 2 && (size_t)nq * cap * 8 < ((size_t)1 << 31)) {   // (record offsets are 32-bit buffer offsets)
             uint64_t* d_cand = idx->list_buf.as<uint64_t>();
             uint64_t* d_prog = d_cand + (size_t)nq * cap;          // (list_buf holds tagged words only: any layout of an earlier launch is harmless)
             const unsigned had = idx->redo_buf.gen;
@@ -1868,8 +1872,8 @@ static int knn_search_dev_impl(uh_knn* idx, const uint8_t* d_queries, int nq, in
             static const long long stream_timeout = [] { const char* e = getenv("UH_KNN_STREAM_TIMEOUT_MS"); const long long ms = e ? atoll(e) : 0; return ms > 0 ? ms * 100000ll : kStreamTimeoutDefault; }();
             const int nrep = uh_div_up(nq, kWave);
             const bool few = few_form;
-            const bool few3 = !few && nrep + nq <= 3 * 4 * std::max(idx->ctx->num_cus, 64);   // one query per scan wave at three waves per SIMD (2000 < queries <= ~3000; 170 registers)
-            const bool few4 = !few && !few3 && nrep + nq <= 4 * 4 * std::max(idx->ctx->num_cus, 64);   // ... at four (two row groups in rotation: 128 registers)
+            const bool few3 = !few && nrep + nq <= 3 * 4 * km_cus(idx->ctx);   // one query per scan wave at three waves per SIMD (2000 < queries <= ~3000; 170 registers)
+            const bool few4 = !few && !few3 && nrep + nq <= 4 * 4 * km_cus(idx->ctx);   // ... at four (two row groups in rotation: 128 registers)
             const dim3 gs(nrep + (few || few3 || few4 ? nq : uh_div_up(nq, 2)));
 #define UH_KNN_STREAM_W(K, W) UH_LAUNCH(idx->ctx, (knn_stream_kernel<K, W>), gs, dim3(kWave), 0, idx->d_train, idx->shard_begin, idx->shard_end, d_queries, nq, sorted ? 1 : 0, max_dist, \
             d_cand, d_prog, cap, tag, nrep, d_indices, d_distances, d_redo, d_nredo + (tag & 1u), d_nredo + ((tag + 1u) & 1u), stream_timeout, ho)

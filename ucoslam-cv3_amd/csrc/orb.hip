@@ -190,7 +190,9 @@ __global__ __launch_bounds__(256) void ingest_kernel(const uint8_t* __restrict__
 
 // An interleaved BGR (3 bytes) or BGRA (4 bytes) frame to gray on its way in: cv::cvtColor(in, gray, COLOR_BGR2GRAY) as FrameExtractor does
 // for three-channel input (src/utils/frameextractor.cpp:2960,3046) — OpenCV's 8-bit form: (B * 3735 + G * 19235 + R * 9798 + 2^14) >> 15
-// (RGB2Gray<uchar>, 15-bit coefficients; OpenCV >= 4 — unpinned like the rest of the extractor, oracle_bgr2gray restates it).  A thread
+// (RGB2Gray<uchar>, 15-bit coefficients: OpenCV >= 3.4.2 / 4.x — the same line as the >= 4.3 GaussianBlur / resize semantics this extractor
+// restates; OpenCV 3.0 - 3.4.1 used 14-bit coefficients 1868 / 9617 / 4899, which differ by one grey level on many pixels: a host built
+// against those must convert on its side and hand over gray frames.  Unpinned like the rest of the extractor, oracle_bgr2gray restates it).  A thread
 // converts four pixels (12 or 16 source bytes, dword loads: the source may be pinned host memory) into one dword of the packed gray frame.
 __global__ __launch_bounds__(256) void ingest_bgr_kernel(const uint8_t* __restrict__ src, int w, int h, size_t stride, int cn, uint8_t* __restrict__ dst) {
     const int quads = (w + 3) / 4;

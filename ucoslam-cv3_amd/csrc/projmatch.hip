@@ -885,7 +885,10 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
     UH_HIP_CHECK(hipGetLastError());
     // results: the kernel's last workgroup copies [best_kp | best_dist | visible] and the overflow flag into pinned memory and posts the completion word
     const unsigned long long word = h->seq;
-    if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(h->h_out.host<char>()), word, st, "uh_projmatch_match"))) return rc;
+    if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(h->h_out.host<char>()), word, st, "uh_projmatch_match"))) {
+        h->ovf_zeroed = false;   //  a launch that died may have left its ticket / overflow word behind: the next call clears the block again
+        return rc;
+    }
     if (pm_clk) {
         long long c[8];
         UH_HIP_CHECK(hipMemcpy(c, base + 16, sizeof(c), hipMemcpyDeviceToHost));
