@@ -46,7 +46,7 @@ for K, P, seed, nfix in cfgs:
             us = lambda a, b: (clk[b] - clk[a]) / 100.0
             spec = os.environ.get("UH_BA_SPEC", "1") != "0"   # (a speculative trial has no errors / C / decision phases of its own: clocks 47, 48 are stale)
             tailp = f"| speculative trials kept / dropped {clk[58]} / {clk[59]} " if spec else f"| errors {us(46,47):.2f} | C {us(47,48):.2f} | decide {us(48,49):.2f} "
-            print(f"    pass 2, 4th loop iteration: lin + phase1 {us(40,41):.2f} | A+slices+B {us(41,42):.2f} (wait A {us(41,50):.2f}, slice {us(50,51):.2f}, wait B {us(51,42):.2f}) | assemble (+ decision) {us(42,43):.2f} | factor {us(43,44):.2f} "
+            print(f"    pass 2, 4th loop iteration: lin + phase1 {us(40,41):.2f} | A+slices+B {us(41,42):.2f} (wait A {us(41,50):.2f}, slice {us(50,51):.2f}, wait B {us(51,42):.2f}) | assemble (+ decision) {us(42,43):.2f} (reduced vector fetched + scattered {us(42,57):.2f}, barrier {us(57,62):.2f}, decision {us(62,43):.2f}) | factor {us(43,44):.2f} "
                   f"| backsolve {us(44,45):.2f} | pose+backsub {us(45,46):.2f} {tailp}| total {us(40,49):.2f} us")
             print(f"    kernel: setup {us(0,1):.2f} | pass 1: begin+opening {us(2,3):.2f}, trials {us(3,5):.2f} | pass 2: relabel+opening {us(5,6):.2f}, trials {us(6,8):.2f} | total to results {us(0,8):.2f} us")
             print(f"    results: stores issued {us(8,11):.2f} | acknowledged + barrier {us(11,12):.2f} | count of all workgroups {us(12,9):.2f}")

@@ -957,8 +957,10 @@ __global__ __launch_bounds__(kPThreads) void ba_persist_kernel(BAPtrs p, BADims 
                     if (t >= 0) lds[t & 0xFFFFFF] = (t >> 24) ? rv[u] : -rv[u];   // bit 24: camera sums / b_schur keep their sign, product entries enter S negated
                 }
             }
+            UH_BA_CLKT(57);   // (round 6: the reduced vector has arrived and is scattered into the factorisation's layout)
             if (tid == 0) s_flag[0] = 1;
             __syncthreads();   // the reduced system [S b] (lower triangle + row n of Mm) and bp are complete
+            UH_BA_CLKT(62);
             if (s_flag[1]) return;
             if (pend) {   // the open decision (every thread, same inputs, same code)
                 pend = false;

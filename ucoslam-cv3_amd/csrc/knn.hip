@@ -1680,6 +1680,7 @@ struct uh_knn {
     unsigned long long km_pin_word = 0;   // completion word of the launch that last read km_pin
     uh::DevBuf km_dev;
     uh::DevBuf km_rows;                   // the train rows of the build in HBM (the assignment kernel's operand)
+    uh::MappedBuf km_rows_pin;            // ... on their way there when the caller's array is pageable
     uh::MappedBuf km_stage;               // [completion word | clusters out | row per position | slot per position | centres per slot | centres of a slot]
     unsigned long long km_seq = 0;
     double km_assign_us = 0; int km_assign_calls = 0;   // UH_KM_TIMING
@@ -2130,7 +2131,17 @@ int uh_knn_build_kmeans(uh_knn* idx, const uint8_t* features, int n, int k, int 
     hipStream_t st = idx->ctx->stream;
     int rc;
     if ((rc = idx->km_rows.reserve(32 * (size_t)n))) return rc;
-    UH_HIP_CHECK(hipMemcpyAsync(idx->km_rows.p, features, 32 * (size_t)n, hipMemcpyHostToDevice, st));   // (crosses while the host shuffles the root)
+    {   // the rows to HBM by a 16-byte-wide launch, from where they lie if the caller's array is pinned, else through this object's pinned block
+        // (hipMemcpyAsync from pageable memory holds the calling thread for the whole staged copy: ~30 us per 320 KB); crosses while the host shuffles the root
+        const void* src = ((reinterpret_cast<uintptr_t>(features) & 15) == 0) ? uh::device_alias_of_host(features) : nullptr;
+        if (!src) {
+            if ((rc = idx->km_rows_pin.reserve(32 * (size_t)n + 16))) return rc;
+            std::memcpy(idx->km_rows_pin.host<uint8_t>(), features, 32 * (size_t)n);
+            std::atomic_thread_fence(std::memory_order_release);
+            src = idx->km_rows_pin.dev<uint8_t>();
+        }
+        if ((rc = uh::copy16(idx->ctx, idx->km_rows.p, src, 32 * (size_t)n))) return rc;
+    }
     // the distances — where the reference's build time goes (kmeansindexcreator.cpp:44-) — on the device, one launch per level and k-means round
     struct DevAssigner : KmAssigner {
         uh_knn* idx; hipStream_t st; size_t o_out = 0;

@@ -137,6 +137,7 @@ private:
         int m = 0;
         for (int i = b; i < e; i++) m += INCLUSIVE ? (v[i] <= cut) : (v[i] < cut);
         const int mid = b + m;
+        if (m == 0 || mid == e) return mid;   // one side is empty: nothing is misplaced (the usual outcome of the second pass: no point EQUALS the cut)
         int* L = tmp_l_.data();
         int* R = tmp_r_.data();
         int nl = 0, nr = 0;
