@@ -588,7 +588,7 @@ def main():
             # `bench.py --quick`): NOT measured in this run.  Corrected as the guide prescribes for gfx950: FETCH_SIZE counts wide reads once -> x2.
             pmc_all, pmc_src = {}, None
             try:
-                pmc_file = next(f_ for f_ in (os.path.join(ROOT, "profiles", n_) for n_ in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(f_))
+                pmc_file = next(f_ for f_ in (os.path.join(ROOT, "profiles", n_) for n_ in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")) if os.path.exists(f_))
                 pmc_all = json.load(open(pmc_file))["kernels"]
                 pmc_src = "profiles/" + os.path.basename(pmc_file) + " (fetch_bytes_x2 + write_bytes per launch; separate rocprofv3 --pmc passes of `bench.py --quick`, not measured in this run)"
                 pmc = pmc_all.get(name)

@@ -212,6 +212,31 @@ def pmprev_case(seed):   # the tracker's search against the previous frame (uh_p
 
 run("projmatch_prev", pmprev_case)
 
+# ---- Frame::create_kdtree on the device (csrc/kdbuild.hpp) against the host builder (pinned to the real picoflann by the goldens)
+from ucoslam_cv3_amd.projmatch import kdtree_build_dev, kdtree_build_host
+
+def kd_case(seed):
+    r = np.random.default_rng(seed)
+    n = int(r.integers(0, 4097)) if r.random() < 0.7 else int(r.integers(0, 200))
+    mode = int(r.integers(0, 6))
+    if mode == 0:
+        xy = (r.random((n, 2)) * [1241, 376]).astype(np.float32)
+    elif mode == 1:
+        xy = r.integers(0, max(2, int(r.integers(2, 200))), (n, 2)).astype(np.float32)
+    elif mode == 2:   # extractor-like: pixel centres of a level scaled back to level 0
+        xy = (r.integers(0, 400, (n, 2)).astype(np.float32) + np.float32(0.5)) * np.float32(1.2) ** r.integers(0, 8, (n, 1)).astype(np.float32)
+    elif mode == 3:
+        xy = r.normal([600, 180], [r.random() * 80 + 0.01, r.random() * 8 + 0.01], (n, 2)).astype(np.float32)
+    elif mode == 4:
+        xy = np.stack([r.random(n).astype(np.float32) * 1e-3, r.integers(0, 3, n).astype(np.float32)], 1)
+    else:
+        xy = (r.normal(0, 1, (n, 2)) * [3e4, 1e-2]).astype(np.float32)
+    a, b = kdtree_build_dev(ctx, xy, int(r.choice([0, 256, 512]))), kdtree_build_host(xy)
+    ok = a["nodes"].tobytes() == b["nodes"].tobytes() and a["leaf_idx"].tobytes() == b["leaf_idx"].tobytes() and a["root_box"].tobytes() == b["root_box"].tobytes() and a["depth"] == b["depth"]
+    return ok, None if ok else (n, mode)
+
+run("kdtree_device", kd_case)
+
 # ---- BA and PnP (tolerance 1e-6 on the se3 state, identical iteration counts / flags)
 from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
 from ucoslam_cv3_amd.pnp import PnPSolver

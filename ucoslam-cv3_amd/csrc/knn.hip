@@ -857,6 +857,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(W, W))) v
     int size = 0, r = 0;                                   // r: records consumed
     bool fin = !haveq, over = false;
     int deep = 0;                                          // wave-uniform: the previous round filled its short fetch -> fetch the long one
+    int idle = 0;                                          // consecutive polls that found nothing new for any lane
+    constexpr int kIdleBackoff = 2;
     long long tlast = wall_clock64();
     // One round: the closing word (written once, when the query's scan ends) and the next records, all loads independent of each other.
     // (Round 5 tried issuing the NEXT round's loads before pushing this round's entries: the records it sees are one round old, the rounds
@@ -904,9 +906,17 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(W, W))) v
         if (most == 0 || wait_more) {
             if (closed && r >= total) fin = true;
             if (wall_clock64() - tlast > timeout_ticks) { over = over || !fin; fin = true; }
-            if (__ballot(!fin) != 0) __builtin_amdgcn_s_sleep(24);   // ~0.6 us between polls (every poll is a fabric read of each lane's next records)
+            // ~0.6 us between polls (every poll is a fabric read of each lane's closing word and next records); round 6: a wave that found
+            // NOTHING new twice in a row backs off to ~1.3 and then ~1.9 us — the scan delivers ~0.4 entries per query and microsecond
+            // behind its first rows, so the short polls mostly re-read what they had seen (FETCH_SIZE 15.0 -> 18.6 MB in round 5)
+            if (__ballot(!fin) != 0) {
+                if (most == 0 && idle >= kIdleBackoff) { if (idle >= 2 * kIdleBackoff) __builtin_amdgcn_s_sleep(72); else __builtin_amdgcn_s_sleep(48); }
+                else __builtin_amdgcn_s_sleep(24);
+            }
+            idle = most == 0 ? idle + 1 : 0;
             continue;
         }
+        idle = 0;
         tlast = wall_clock64();
         const int rn = r + np;
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): a lane reads back only what it staged itself
