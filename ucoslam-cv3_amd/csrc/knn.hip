@@ -857,8 +857,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(W, W))) v
     int size = 0, r = 0;                                   // r: records consumed
     bool fin = !haveq, over = false;
     int deep = 0;                                          // wave-uniform: the previous round filled its short fetch -> fetch the long one
-    int idle = 0;                                          // consecutive polls that found nothing new for any lane
-    constexpr int kIdleBackoff = 2;
     long long tlast = wall_clock64();
     // One round: the closing word (written once, when the query's scan ends) and the next records, all loads independent of each other.
     // (Round 5 tried issuing the NEXT round's loads before pushing this round's entries: the records it sees are one round old, the rounds
@@ -906,17 +904,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(W, W))) v
         if (most == 0 || wait_more) {
             if (closed && r >= total) fin = true;
             if (wall_clock64() - tlast > timeout_ticks) { over = over || !fin; fin = true; }
-            // ~0.6 us between polls (every poll is a fabric read of each lane's closing word and next records); round 6: a wave that found
-            // NOTHING new twice in a row backs off to ~1.3 and then ~1.9 us — the scan delivers ~0.4 entries per query and microsecond
-            // behind its first rows, so the short polls mostly re-read what they had seen (FETCH_SIZE 15.0 -> 18.6 MB in round 5)
-            if (__ballot(!fin) != 0) {
-                if (most == 0 && idle >= kIdleBackoff) { if (idle >= 2 * kIdleBackoff) __builtin_amdgcn_s_sleep(72); else __builtin_amdgcn_s_sleep(48); }
-                else __builtin_amdgcn_s_sleep(24);
-            }
-            idle = most == 0 ? idle + 1 : 0;
+            // ~0.6 us between polls (every poll is a fabric read of each lane's next records).  Round 6 tried a back-off for waves that find nothing
+            // new (1.3, then 1.9 us): kernel 136.5 us and FETCH_SIZE x 2 18.5 MB inside the headline loop, both unchanged — the polls are not where
+            // the 3.6 MB of round 5 went; removed again.
+            if (__ballot(!fin) != 0) __builtin_amdgcn_s_sleep(24);
             continue;
         }
-        idle = 0;
         tlast = wall_clock64();
         const int rn = r + np;
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): a lane reads back only what it staged itself
@@ -1432,17 +1425,31 @@ struct KmAssignerHost : KmAssigner {
 __global__ __launch_bounds__(256) void kmeans_assign_kernel(const uint8_t* __restrict__ rows, const uint32_t* __restrict__ pos_row, const uint16_t* __restrict__ pos_slot,
                                                             const uint8_t* __restrict__ centres, const uint8_t* __restrict__ slot_nc, int k, int npos,
                                                             uint8_t* __restrict__ out) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    // The centres live in pinned HOST memory (un-cached on the device side): read once per workgroup into LDS — a workgroup's 256 consecutive
+    // positions belong to a few consecutive slots — instead of k x 32 bytes over the host link per THREAD (round 6, first form: 24 us per launch,
+    // ~10 MB of link reads for 10 000 rows).  More than kSlotsLds slots in one workgroup (a level of tiny nodes): those threads read in place.
+    constexpr int kSlotsLds = 16;
+    __shared__ __attribute__((aligned(16))) uint4 s_cen[kSlotsLds * 64 * 2];   // k <= 64 centres of 32 bytes per slot
+    const int p0 = blockIdx.x * blockDim.x, p = p0 + threadIdx.x;
+    const unsigned sl0 = pos_slot[p0], sl1 = pos_slot[min(p0 + (int)blockDim.x, npos) - 1];
+    const int nsl = min((int)(sl1 - sl0) + 1, kSlotsLds);
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(centres + (size_t)sl0 * k * 32);
+        for (int i = threadIdx.x; i < nsl * k * 2; i += blockDim.x) s_cen[i] = src[i];
+    }
+    __syncthreads();
     if (p >= npos) return;
     const uint32_t r = pos_row[p];
     const unsigned slot = pos_slot[p];
     const int nc = slot_nc[slot];
     const uint4* rp = reinterpret_cast<const uint4*>(rows + 32 * (size_t)r);
     const uint4 a = rp[0], b = rp[1];
-    const uint4* cp = reinterpret_cast<const uint4*>(centres + (size_t)slot * k * 32);
+    const bool in_lds = slot - sl0 < (unsigned)nsl;
+    const uint4* cl = s_cen + (size_t)(in_lds ? slot - sl0 : 0u) * k * 2;
+    const uint4* cg = reinterpret_cast<const uint4*>(centres + (size_t)slot * k * 32);
     int best = 0, bestd = 0x7fffffff;
     for (int c = 0; c < nc; c++) {
-        const uint4 x = cp[2 * c], y = cp[2 * c + 1];
+        const uint4 x = in_lds ? cl[2 * c] : cg[2 * c], y = in_lds ? cl[2 * c + 1] : cg[2 * c + 1];
         const int d = __popc(a.x ^ x.x) + __popc(a.y ^ x.y) + __popc(a.z ^ x.z) + __popc(a.w ^ x.w) + __popc(b.x ^ y.x) + __popc(b.y ^ y.y) + __popc(b.z ^ y.z) +
                       __popc(b.w ^ y.w);
         if (d < bestd) { bestd = d; best = c; }
