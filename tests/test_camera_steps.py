@@ -114,3 +114,31 @@ def test_hip_extract_frame_colour_in_undistorted_out(hip_ctx, oracle, cn, pinned
     # and the plain entry point is untouched by the camera
     k2, d2 = ext.detectAndCompute(gray, None, FeatParams(nf, 8, 1.2))
     np.testing.assert_array_equal(d2, rd)
+
+
+@pytest.mark.gpu
+def test_hip_extract_frame_small_capacity_does_not_write_past_a_pinned_und_array(hip_ctx):
+    """a pinned und_xy of `cap` entries beside pageable keypoint / descriptor arrays — the launch runs at maxFeatures slots, so the
+    positions must go through the extractor's own block: UH_ECAPACITY comes back and the bytes behind the caller's array are untouched."""
+    import ctypes as C
+
+    import torch
+    from ucoslam_cv3_amd import _lib
+    from ucoslam_cv3_amd.orb import KEYPOINT_DTYPE, Camera, FeatParams, ORBextractor
+
+    L = _lib.lib()
+    w, h, cap = 1241, 376, 100
+    img = synth.frame(w, h, seed=12)
+    ext = ORBextractor.create(hip_ctx).setCamera(Camera(*KITTI, DIST5))
+    fp = FeatParams(2000, 8, 1.2)
+    _lib.check(L.uh_orb_set_params(ext._h, C.byref(fp)))
+    kps = np.zeros(cap, KEYPOINT_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    und_t = torch.full((cap * 2 + 4096,), 7.0, dtype=torch.float32).pin_memory()   # guard floats behind the cap entries
+    und = und_t.numpy()
+    n = C.c_int(0)
+    rc = L.uh_orb_extract_frame(ext._h, img.ctypes.data_as(C.c_void_p), w, h, w, 1, kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p),
+                                und.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+    hip_ctx.synchronize()
+    assert rc == _lib.UH_ECAPACITY and n.value > cap
+    assert (und[2 * cap:] == 7.0).all()

@@ -1209,15 +1209,24 @@ struct BranchHeapLds {
     int size;
     int cap;                   // the LDS region really holds `cap` entries: a push beyond it is dropped (== the reference whenever cap == kBranchMax,
                                // and never an overrun into the neighbouring wave's heap should the host's worst-case bound ever be too small)
-    __device__ __forceinline__ void push(int dist, unsigned int off) {   // heap.h push + "down"
+    // heap.h push + "down" (the new entry climbs while it is smaller than its parent).  Round 6: the whole climb in ONE LDS round trip — lane j
+    // reads the j-th ancestor of the insertion slot (slot_j = ((size + 1) >> j) - 1), a ballot finds how far the entry climbs, the lanes of
+    // the passed ancestors write them one level down and the entry takes the slot where it stopped: the same swaps as the sequential loop
+    // (the order of equal-distance branches is observable), 2 reads + 2 writes per lane instead of log2(size) dependent round trips per push —
+    // ~31 pushes per internal block were most of a query's time.
+    __device__ __forceinline__ void push(int dist, unsigned int off, int lane) {
         if (size >= cap) return;
-        int i = size;
-        while (i != 0) {
-            const int p = (i - 1) >> 1;
-            const int dp = d[p];
-            if (dist < dp) { d[i] = dp; o[i] = o[p]; i = p; } else break;
-        }
-        d[i] = dist; o[i] = off;
+        const int s1 = size + 1;
+        const int levels = 31 - __builtin_clz(s1);                 // ancestors of the insertion slot: j = 1 .. levels (slot_levels = 0, the root)
+        const int slot = (s1 >> min(lane, 31)) - 1;                // lane 0: the insertion slot itself
+        const bool anc = lane >= 1 && lane <= levels;
+        const int dj = anc ? d[slot] : 0;
+        const unsigned int oj = anc ? o[slot] : 0u;
+        // climbs past ancestor j iff dist < d_j for every ancestor up to j: the first ancestor that holds stops it
+        const unsigned long long stops = __ballot(anc && !(dist < dj)) | (1ull << (levels + 1));
+        const int m = __builtin_ctzll(stops) - 1;                  // ancestors passed: 1 .. m
+        if (anc && lane <= m) { const int below = (s1 >> (lane - 1)) - 1; d[below] = dj; o[below] = oj; }
+        if (lane == 0) { const int at = (s1 >> m) - 1; d[at] = dist; o[at] = off; }
         size++;
     }
     __device__ __forceinline__ unsigned int pop() {                      // heap.h pop + "up"
@@ -1252,7 +1261,7 @@ __global__ __launch_bounds__(kWave* kKmWaves) void knn_kmeans_search_kernel(
     load_query(queries, qi, q);
     WaveHeap h{0, -1, 0, lane};
     BranchHeapLds bh{s_heap + (size_t)wv * 2 * cap, reinterpret_cast<unsigned int*>(s_heap + (size_t)wv * 2 * cap + cap), 0, cap};
-    bh.push(0, 0u);
+    bh.push(0, 0u, lane);
     int nchecks = 0, ncand = 0;
     while (nchecks < max_checks && bh.size != 0) {
         unsigned int off = bh.pop();
@@ -1283,9 +1292,9 @@ __global__ __launch_bounds__(kWave* kKmWaves) void knn_kmeans_search_kernel(
                 const int dc = rl(dl, c);
                 const int oc = rl((int)info, c);
                 if (dc < bestd) {
-                    if (besto != -1) bh.push(bestd, (unsigned int)besto);
+                    if (besto != -1) bh.push(bestd, (unsigned int)besto, lane);
                     bestd = dc; besto = oc;
-                } else bh.push(dc, (unsigned int)oc);
+                } else bh.push(dc, (unsigned int)oc, lane);
             }
             off = (unsigned int)besto;
         }
