@@ -24,10 +24,13 @@ def _same_tree(mine, ref):
     np.testing.assert_array_equal(mine["root_box"], ref["root_bbox"])
 
 
+@pytest.mark.parametrize("scalar", [False, True], ids=["default", "no-avx512"])
 @pytest.mark.parametrize("name", list(_clouds().keys()))
-def test_host_kdtree_build_equals_oracle(oracle, name):
+def test_host_kdtree_build_equals_oracle(oracle, name, scalar, monkeypatch):
     from ucoslam_cv3_amd.projmatch import kdtree_build_host
 
+    if scalar:   # the builder's AVX-512 Hoare pass is taken where the host has it: the scalar form must stay covered too
+        monkeypatch.setenv("UH_KD_NO_AVX512", "1")
     xy = _clouds()[name]
     mine = kdtree_build_host(xy)
     if len(xy) == 0:

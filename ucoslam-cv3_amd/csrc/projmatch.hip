@@ -24,6 +24,8 @@
 //   host   orders the per-point results into the DMatch list and runs filter_ambiguous_query (matcher.hip).
 // Floating-point conventions are those of oracle/proj_oracle.cpp (float ops in source order, no contraction; cv::norm in
 // double); predictScale's logf is libm's, reproduced on the device by glibc_sincosf.hpp.
+#include <immintrin.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -78,6 +80,19 @@ public:
         for (int i = 0; i < n; i++) { order_[i] = (uint32_t)i; px_[i] = xy[2 * (size_t)i]; py_[i] = xy[2 * (size_t)i + 1]; }
         max_depth = 0;
         if (n == 0) return;
+        {   // exponent spread of the non-zero coordinates (see sample_moments); non-finite values keep the ordered chains
+            int emin = 1 << 30, emax = -(1 << 30);
+            bool fin = true;
+            for (int i = 0; i < 2 * n; i++) {
+                uint32_t bits;
+                std::memcpy(&bits, &xy[i], 4);
+                const int ex = (int)((bits >> 23) & 0xffu);
+                if (ex == 0xff) fin = false;
+                if ((bits & 0x7fffffffu) == 0) continue;
+                emin = std::min(emin, ex); emax = std::max(emax, ex);
+            }
+            exact_sums_ = fin && emin >= 1 /* no denormals */ && emax - emin <= 10;
+        }
         Box root;
         bounds(0, n, root);
         nodes.reserve(2 * (size_t)n + 2);
@@ -106,15 +121,37 @@ private:
         box.lo[0] = lx; box.hi[0] = hx; box.lo[1] = ly; box.hi[1] = hy;
     }
 
-    // picoflann.h:362-391: mean / variance over at most ~100 evenly spaced samples (float squares, double sums)
+    // picoflann.h:362-391: mean / variance over at most ~100 evenly spaced samples (float squares, double sums IN SAMPLE ORDER: four
+    // dependent addition chains, ~a third of the build).  Round 6: when every coordinate of the cloud lies within a factor 2^10 of every
+    // other (exponent spread <= 10: any extractor output — pixels 19 .. 4095 — does), no partial sum of <= 256 samples is ever rounded
+    // (x: multiples of 2^(e_min-23) below 2^(e_max+9); fl(x*x): multiples of 2^(2 e_min-23) below 2^(2 e_max+10) — both fit 53 bits), so
+    // the sums are the exact real sums in ANY order and four partial accumulators per sum give the same bits; otherwise the chains stay.
+    bool exact_sums_ = false;
     void sample_moments(int b, int e, double mean[2], double var[2]) const {
         double s1[2] = {0, 0}, s2[2] = {0, 0};
         int step = 1, cnt = 0;
         if (e - b >= 200) step = (e - b) / 100;
-        for (int i = b; i < e; i += step, cnt++) {
-            const float x = px_[i], y = py_[i];
-            s1[0] += x; s2[0] += x * x;
-            s1[1] += y; s2[1] += y * y;
+        if (exact_sums_) {
+            double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
+            cnt = (e - b + step - 1) / step;
+            const float* qx = px_.data() + b; const float* qy = py_.data() + b;
+            int k = 0;
+            for (; k + 4 <= cnt; k += 4) {
+#pragma GCC unroll 4
+                for (int u = 0; u < 4; u++) {
+                    const float x = qx[(size_t)(k + u) * step], y = qy[(size_t)(k + u) * step];
+                    a1[u] += x; a2[u] += x * x; c1[u] += y; c2[u] += y * y;
+                }
+            }
+            for (; k < cnt; k++) { const float x = qx[(size_t)k * step], y = qy[(size_t)k * step]; a1[0] += x; a2[0] += x * x; c1[0] += y; c2[0] += y * y; }
+            s1[0] = (a1[0] + a1[1]) + (a1[2] + a1[3]); s2[0] = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+            s1[1] = (c1[0] + c1[1]) + (c1[2] + c1[3]); s2[1] = (c2[0] + c2[1]) + (c2[2] + c2[3]);
+        } else {
+            for (int i = b; i < e; i += step, cnt++) {
+                const float x = px_[i], y = py_[i];
+                s1[0] += x; s2[0] += x * x;
+                s1[1] += y; s2[1] += y * y;
+            }
         }
         const double inv = 1. / double(cnt);
         for (int d = 0; d < 2; d++) {
@@ -134,6 +171,7 @@ private:
     // count and two branch-free compactions instead of two data-dependent scans (the scans mispredict on every other element).
     template <bool INCLUSIVE>
     int hoare_pass(int b, int e, const float* v, float cut) {
+        if (avx512_) return hoare_pass_avx512<INCLUSIVE>(b, e, v, cut);
         int m = 0;
         for (int i = b; i < e; i++) m += INCLUSIVE ? (v[i] <= cut) : (v[i] < cut);
         const int mid = b + m;
@@ -144,6 +182,38 @@ private:
         for (int i = b; i < mid; i++) { L[nl] = i; nl += INCLUSIVE ? !(v[i] <= cut) : !(v[i] < cut); }
         for (int j = e - 1; j >= mid; j--) { R[nr] = j; nr += INCLUSIVE ? (v[j] <= cut) : (v[j] < cut); }
         for (int k = 0; k < nl; k++) swap_items(L[k], R[k]);   // (nl == nr)
+        return mid;
+    }
+    // The same pass with AVX-512 where the host has it (round 6; the count and the two index lists are ~half of a build): sixteen
+    // predicates per compare, the misplaced positions leave through vpcompressd.  Same permutation: the k-th misplaced position of the front
+    // part (ascending) meets the k-th of the back part counted from the end.
+    bool avx512_ = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && !getenv("UH_KD_NO_AVX512");
+    template <bool INCLUSIVE>
+    __attribute__((target("avx512f,avx512vl,popcnt"))) int hoare_pass_avx512(int b, int e, const float* v, float cut) {
+        const __m512 vc = _mm512_set1_ps(cut);
+#define left_mask(i_, n_) _mm512_mask_cmp_ps_mask((__mmask16)((1u << (n_)) - 1u), _mm512_maskz_loadu_ps((__mmask16)((1u << (n_)) - 1u), v + (i_)), vc, INCLUSIVE ? _CMP_LE_OQ : _CMP_LT_OQ)   /* "belongs left" of v[i .. i + n), n <= 16 */
+        int m = 0;
+        for (int i = b; i < e; i += 16) m += __builtin_popcount(left_mask(i, std::min(16, e - i)));
+        const int mid = b + m;
+        if (m == 0 || mid == e) return mid;
+        int* L = tmp_l_.data();
+        int* R = tmp_r_.data();
+        int nl = 0, nr = 0;
+        const __m512i lane = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        for (int i = b; i < mid; i += 16) {
+            const int n = std::min(16, mid - i);
+            const __mmask16 mis = (__mmask16)(~left_mask(i, n) & ((1u << n) - 1u));
+            _mm512_mask_compressstoreu_epi32(L + nl, mis, _mm512_add_epi32(lane, _mm512_set1_epi32(i)));
+            nl += __builtin_popcount(mis);
+        }
+        for (int i = mid; i < e; i += 16) {   // ascending here; paired from the end below
+            const int n = std::min(16, e - i);
+            const __mmask16 mis = left_mask(i, n);
+            _mm512_mask_compressstoreu_epi32(R + nr, mis, _mm512_add_epi32(lane, _mm512_set1_epi32(i)));
+            nr += __builtin_popcount(mis);
+        }
+        for (int k = 0; k < nl; k++) swap_items(L[k], R[nr - 1 - k]);   // (nl == nr)
+#undef left_mask
         return mid;
     }
 
