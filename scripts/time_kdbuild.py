@@ -14,7 +14,7 @@ ctx = u.Context(0, torch.cuda.current_stream().cuda_stream)
 rng = np.random.default_rng(0)
 for n in (2000, 4000, 500):
     xy = (rng.random((n, 2)) * [1241, 376]).astype(np.float32)
-    for threads in (512, 256):
+    for threads in (0, 512, 256):   # 0: the build over three launches
         for rep in range(3):
             t = kdtree_build_dev(ctx, xy, threads)
         assert t["nodes"].tobytes() == kdtree_build_host(xy)["nodes"].tobytes()

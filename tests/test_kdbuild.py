@@ -100,7 +100,7 @@ def _more_clouds():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("threads", [0, 256])
+@pytest.mark.parametrize("threads", [0, 256, 512])
 @pytest.mark.parametrize("name", list(_more_clouds().keys()))
 def test_device_kdtree_equals_host_builder(hip_ctx, name, threads):
     from ucoslam_cv3_amd.projmatch import kdtree_build_dev, kdtree_build_host

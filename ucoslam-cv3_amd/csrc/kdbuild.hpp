@@ -618,42 +618,86 @@ struct Node24 { float divlow, divhigh; int left, right; int leaf_begin; short le
 static_assert(sizeof(Node24) == 24, "node layout");
 struct Meta { unsigned long long word; int n, n_nodes, max_depth, m_used; double box[4]; };   // 56 bytes, in pinned host memory
 
-// The whole build by one workgroup (blockDim.x = 256 or 512 threads).  in[i] = {x, y, bits(octave), -} of keypoint i;
-// nodes_out: room for 2 * (n / 5) + 1 nodes (uh_kd::node_cap covers it), leaf_out[i] = {x, y, bits(keypoint << 4 | octave), 0} in leaf order.
-// Thread 0 leaves {n, n_nodes, depth, root box} in *meta and, last, stores `word` into meta->word with system-scope release.
+// ---- the build over THREE launches (round 6, second form): the top levels by one workgroup (kd_top), one workgroup per subtree below them
+// on its own compute unit (kd_sub: one wave per SIMD instead of two sharing one, a quarter of the rows per wave), a small join launch that
+// numbers the nodes across subtrees.  What travels between them (HBM scratch of the frame object):
+struct TopNode { unsigned nbe; unsigned short nchild, npar; unsigned flag; double cut; };
+struct TopDump { int nsub, n, depth, ntop, lvl_b, lvl_e, pad0, pad1; TopNode node[64]; };   // nsub = 0: kd_top built the whole tree itself (small / shallow clouds)
+struct SubSum { int cnt_int, n_nodes, maxdepth, pad; float lo[2]; double rhi[2]; };       // a subtree as its parent sees it
+constexpr int kSplitMin = 1200;   // below this one workgroup finishes sooner than three launches do (measured: 500 points 55 vs 64 us, 2000 points 102 vs 95 us)
+constexpr int kSubMax = 8;      // subtrees = nodes of the level below log2(waves of kd_top) sweeps
+
+enum : int { kFull = 0, kTop = 1, kSub = 2 };
+struct SubArgs {            // kSub: the subtree this workgroup builds
+    const float4* pts;      // the points as kd_top left them: {x, y, bits(keypoint), -} in position order
+    int pos0;               // position of the subtree's first point
+    unsigned root_flags;    // the "upper bound overridden" bits its root inherits
+    int depth0;             // depth of its root
+    SubSum* sum;
+};
+
+// One workgroup (blockDim.x = 256 or 512 threads).  kFull: the whole build.  in[i] = {x, y, bits(octave), -} of keypoint i; nodes_out: room
+// for 2 * (n / 5) + 1 nodes (uh_kd::node_cap covers it), leaf_out[i] = {x, y, bits(keypoint << 4 | octave), 0} in leaf order; thread 0 leaves
+// {n, n_nodes, depth, root box} in *meta and, last, stores `word` into meta->word with system-scope release.  kTop: the same, unless the
+// tree is deep enough to be shared out after the workgroup-wide levels — then the points, the top nodes and the subtree roots go to
+// `dump` / `pts_out` and nothing else is written.  kSub: the subtree of SubArgs with picoflann's numbering LOCAL to it (root 0), leaf
+// records at their final places, a SubSum for the join.
+template <int MODE>
 __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const float4* __restrict__ in, const int n, Node24* __restrict__ nodes_out,
-                                float4* __restrict__ leaf_out, Meta* meta, const unsigned long long word, long long* clk = nullptr) {
+                                float4* __restrict__ leaf_out, Meta* meta, const unsigned long long word, long long* clk, TopDump* dump, float4* pts_out,
+                                const SubArgs sub) {
 #define UH_KD_TOP(j) do { if (clk && threadIdx.x == 0) clk[j] = wall_clock64(); } while (0)
     UH_KD_TOP(0);
     __shared__ unsigned s_cursor[17], s_status[17][4], s_maxdepth;
     __shared__ double s_rhi[16][2];
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
     const Lds V = carve(lds_base, n_cap, nwaves);
+    const int pos0 = MODE == kSub ? sub.pos0 : 0;
     for (int g = tid; g < V.m_cap; g += nthr) V.npar[g] = kNoNode;
     for (int i = tid; i < n; i += nthr) {
-        const float4 r = in[i];
-        V.px[i] = r.x; V.py[i] = r.y; V.ord[i] = (unsigned short)i;
+        if constexpr (MODE == kSub) {
+            const float4 r = sub.pts[pos0 + i];
+            V.px[i] = r.x; V.py[i] = r.y; V.ord[i] = (unsigned short)__float_as_uint(r.z);
+        } else {
+            const float4 r = in[i];
+            V.px[i] = r.x; V.py[i] = r.y; V.ord[i] = (unsigned short)i;
+        }
         V.eseg[i] = 0;
     }
     if (tid < 17) { s_status[tid][0] = 0; s_status[tid][1] = 0; s_status[tid][2] = 0; }
     __syncthreads();
+    const int depth_root = MODE == kSub ? sub.depth0 : 1;
     if (tid == 0) {
-        V.nbe[0] = (unsigned)n << 16; V.nchild[0] = 0; V.npar[0] = kRootPar; V.nflag[0] = 0;
+        V.nbe[0] = (unsigned)n << 16; V.nchild[0] = 0; V.npar[0] = kRootPar; V.nflag[0] = MODE == kSub ? (unsigned char)(sub.root_flags & 0xCu) : (unsigned char)0;
         s_cursor[16] = 1;
-        s_maxdepth = n > 0 ? 1 : 0;
+        s_maxdepth = n > 0 ? (unsigned)depth_root : 0u;
     }
     __syncthreads();
     UH_KD_TOP(1);
     int m_used = n > 0 ? 1 : 0;
     if (n > kLeafMax) {
-        int lvl_b = 0, lvl_e = 1, depth = 1;
+        int lvl_b = 0, lvl_e = 1, depth = depth_root;
         const int k_wg = uh_sel::floor_log2(nwaves);
         if ((n + 63) / 64 <= kKC * nwaves) sweep_levels<true, true>(V, tid, nthr, 0, n, lvl_b, lvl_e, &s_cursor[16], s_status[16], V.bal, depth, k_wg, &s_maxdepth, clk ? clk + 16 : nullptr);
         else sweep_levels<true, false>(V, tid, nthr, 0, n, lvl_b, lvl_e, &s_cursor[16], s_status[16], V.bal, depth, k_wg, &s_maxdepth, clk ? clk + 16 : nullptr);
         __syncthreads();
         UH_KD_TOP(2);
-        // hand-over: node lvl_b + w goes to wave w with a node region of its own (a subtree of c points holds at most 2c/5 nodes)
         const int nL = lvl_e - lvl_b;
+        if constexpr (MODE == kTop) {
+            // deep enough to share out?  (every node of the level exists and at least one will split again; a shallow tree is finished here)
+            if (n >= kSplitMin && nL == nwaves && nL <= kSubMax && s_status[16][1] != 0) {
+                for (int i = tid; i < n; i += nthr) pts_out[i] = make_float4(V.px[i], V.py[i], __uint_as_float((unsigned)V.ord[i]), 0.f);
+                const int ntop = (int)s_cursor[16];
+                for (int g = tid; g < ntop && g < 64; g += nthr) {
+                    TopNode t;
+                    t.nbe = V.nbe[g]; t.nchild = V.nchild[g]; t.npar = V.npar[g]; t.flag = V.nflag[g]; t.cut = V.ncut[g];
+                    dump->node[g] = t;
+                }
+                if (tid == 0) { dump->nsub = nL; dump->n = n; dump->depth = depth; dump->ntop = ntop; dump->lvl_b = lvl_b; dump->lvl_e = lvl_e; }
+                return;
+            }
+        }
+        // hand-over: node lvl_b + w goes to wave w with a node region of its own (a subtree of c points holds at most 2c/5 nodes)
         unsigned base = s_cursor[16], mine = 0;
         int mb = 0, me = 0, before = 0;   // before: subtrees in front of mine (the level's nodes are in allocation order, not in point order)
         {
@@ -682,6 +726,7 @@ __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const 
         __syncthreads();
         UH_KD_TOP(4);
     }
+    if constexpr (MODE == kTop) { if (tid == 0) dump->nsub = 0; }
     // ---- from the leaves up: tight lower bounds (divhigh of a parent = its right child's in the split dimension), counts of inner nodes;
     // the root's upper bounds from the leaves / cuts no ancestor overrides.  The second child to arrive at a parent goes on.
     for (int g = tid; g < m_used; g += nthr) V.nlim[g] = 0;
@@ -732,7 +777,8 @@ __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const 
     __syncthreads();
     UH_KD_TOP(6);
     // ---- picoflann's node numbers (children of the r-th split in depth-first order: 2r + 1, 2r + 2) and the flattened records
-    const int n_nodes = n > 0 ? 1 + 2 * (V.nchild[0] != 0 ? (int)V.ncnt[0] : 0) : 0;
+    const int n_int = n > 0 && V.nchild[0] != 0 ? (int)V.ncnt[0] : 0;
+    const int n_nodes = n > 0 ? 1 + 2 * n_int : 0;
     for (int g = tid; g < m_used; g += nthr) {
         if (V.npar[g] == kNoNode) continue;
         int acc = 0, stepg = 0, right = 0;
@@ -755,7 +801,7 @@ __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const 
             nd.left = 2 * pre + 1; nd.right = 2 * pre + 2; nd.leaf_begin = 0; nd.leaf_count = 0; nd.col = (short)(V.nflag[g] & 1);
         } else {
             nd.divlow = 0.f; nd.divhigh = 0.f; nd.left = -1; nd.right = -1;
-            nd.leaf_begin = (int)(be & 0xffffu); nd.leaf_count = (short)((be >> 16) - (be & 0xffffu)); nd.col = 0;
+            nd.leaf_begin = pos0 + (int)(be & 0xffffu); nd.leaf_count = (short)((be >> 16) - (be & 0xffffu)); nd.col = 0;
         }
         nodes_out[id] = nd;
     }
@@ -763,18 +809,93 @@ __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const 
     for (int i = tid; i < n; i += nthr) {
         const unsigned id = V.ord[i];
         const unsigned oct = __float_as_uint(in[id].z);
-        leaf_out[i] = make_float4(V.px[i], V.py[i], __uint_as_float((id << 4) | (oct & 15u)), 0.f);
+        leaf_out[pos0 + i] = make_float4(V.px[i], V.py[i], __uint_as_float((id << 4) | (oct & 15u)), 0.f);
     }
     if (tid == 0) {
         double h0 = s_rhi[0][0], h1 = s_rhi[0][1];
         for (int w = 1; w < nwaves; w++) { h0 = s_rhi[w][0] > h0 ? s_rhi[w][0] : h0; h1 = s_rhi[w][1] > h1 ? s_rhi[w][1] : h1; }
-        meta->n = n; meta->n_nodes = n_nodes; meta->max_depth = (int)s_maxdepth; meta->m_used = m_used;
-        if (n > 0) { meta->box[0] = (double)V.nlo[0]; meta->box[1] = h0; meta->box[2] = (double)V.nlo[1]; meta->box[3] = h1; }
-        else { meta->box[0] = meta->box[1] = meta->box[2] = meta->box[3] = 0.0; }
-        UH_KD_TOP(8);
-        __hip_atomic_store(&meta->word, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if constexpr (MODE == kSub) {
+            SubSum sm;
+            sm.cnt_int = n_int; sm.n_nodes = n_nodes; sm.maxdepth = (int)s_maxdepth; sm.pad = 0;
+            sm.lo[0] = n > 0 ? V.nlo[0] : 0.f; sm.lo[1] = n > 0 ? V.nlo[1] : 0.f; sm.rhi[0] = h0; sm.rhi[1] = h1;
+            *sub.sum = sm;
+            UH_KD_TOP(8);
+        } else {
+            meta->n = n; meta->n_nodes = n_nodes; meta->max_depth = (int)s_maxdepth; meta->m_used = m_used;
+            if (n > 0) { meta->box[0] = (double)V.nlo[0]; meta->box[1] = h0; meta->box[2] = (double)V.nlo[1]; meta->box[3] = h1; }
+            else { meta->box[0] = meta->box[1] = meta->box[2] = meta->box[3] = 0.0; }
+            UH_KD_TOP(8);
+            __hip_atomic_store(&meta->word, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 #undef UH_KD_TOP
+}
+
+// The join launch (one workgroup): the top nodes' counts, lower bounds and numbers from the subtrees' summaries (thread 0: <= 15 nodes), then every
+// subtree's records to their final numbers (a local number L > 0 becomes L + 2 * the subtree root's depth-first rank, the local root takes the
+// number its parent gives it), meta and the completion word.
+__device__ void join_workgroup(const TopDump* __restrict__ dump, const SubSum* __restrict__ sums, const Node24* __restrict__ sub_nodes, const int node_stride,
+                               Node24* __restrict__ nodes_out, Meta* meta, const unsigned long long word) {
+    __shared__ int s_cnt[64], s_pre[64], s_id[64], s_base[kSubMax], s_rootid[kSubMax], s_nn[kSubMax];
+    __shared__ float s_lo[64][2];
+    __shared__ TopNode s_top[2 * kSubMax];
+    __shared__ SubSum s_sum[kSubMax];
+    const int nsub = dump->nsub;
+    if (nsub == 0) return;   // kd_top finished the tree (and posted the word) itself
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int ntop = dump->ntop, lvl_b = dump->lvl_b, lvl_e = dump->lvl_e;
+    // (one parallel read of what thread 0 walks through below: a dependent global load per node costs it a microsecond each)
+    if (tid < ntop) s_top[tid] = dump->node[tid];
+    if (tid >= 64 && tid < 64 + nsub) s_sum[tid - 64] = sums[tid - 64];
+    __syncthreads();
+    if (tid == 0) {
+        double rhi0 = -__builtin_huge_val(), rhi1 = -__builtin_huge_val();
+        int maxd = dump->depth;
+        for (int g = ntop - 1; g >= 0; g--) {   // children carry larger numbers than their parents
+            const TopNode t = s_top[g];
+            if (g >= lvl_b && g < lvl_e) {
+                const SubSum sm = s_sum[g - lvl_b];
+                s_cnt[g] = sm.cnt_int; s_lo[g][0] = sm.lo[0]; s_lo[g][1] = sm.lo[1];
+                rhi0 = sm.rhi[0] > rhi0 ? sm.rhi[0] : rhi0; rhi1 = sm.rhi[1] > rhi1 ? sm.rhi[1] : rhi1;
+                maxd = sm.maxdepth > maxd ? sm.maxdepth : maxd;
+            } else {
+                const int l = t.nchild, r = l + 1, dim = (int)(t.flag & 1);
+                s_cnt[g] = 1 + s_cnt[l] + s_cnt[r];
+                s_lo[g][0] = s_lo[l][0] < s_lo[r][0] ? s_lo[l][0] : s_lo[r][0];
+                s_lo[g][1] = s_lo[l][1] < s_lo[r][1] ? s_lo[l][1] : s_lo[r][1];
+                if (!(t.flag & (4u << dim))) { if (dim) { if (t.cut > rhi1) rhi1 = t.cut; } else if (t.cut > rhi0) rhi0 = t.cut; }
+            }
+        }
+        s_pre[0] = 0; s_id[0] = 0;
+        for (int g = 0; g < ntop; g++) {
+            if (g >= lvl_b && g < lvl_e) continue;
+            const TopNode t = s_top[g];
+            const int l = t.nchild, r = l + 1, dim = (int)(t.flag & 1);
+            s_pre[l] = s_pre[g] + 1; s_pre[r] = s_pre[g] + 1 + s_cnt[l];
+            s_id[l] = 2 * s_pre[g] + 1; s_id[r] = 2 * s_pre[g] + 2;
+            Node24 nd;
+            nd.divlow = (float)t.cut; nd.divhigh = s_lo[r][dim]; nd.left = s_id[l]; nd.right = s_id[r]; nd.leaf_begin = 0; nd.leaf_count = 0; nd.col = (short)dim;
+            nodes_out[s_id[g]] = nd;
+        }
+        for (int j = 0; j < nsub; j++) {
+            const int g = lvl_b + j;
+            s_base[j] = s_pre[g]; s_rootid[j] = s_id[g]; s_nn[j] = s_sum[j].n_nodes;
+        }
+        meta->n = dump->n; meta->n_nodes = 1 + 2 * s_cnt[0]; meta->max_depth = maxd; meta->m_used = ntop;
+        meta->box[0] = (double)s_lo[0][0]; meta->box[1] = rhi0; meta->box[2] = (double)s_lo[0][1]; meta->box[3] = rhi1;
+    }
+    __syncthreads();
+    for (int j = 0; j < nsub; j++) {
+        const int add = 2 * s_base[j], nn = s_nn[j];
+        const Node24* src = sub_nodes + (size_t)j * node_stride;
+        for (int L = tid; L < nn; L += nthr) {
+            Node24 nd = src[L];
+            if (nd.left >= 0) { nd.left += add; nd.right += add; }
+            nodes_out[L == 0 ? s_rootid[j] : L + add] = nd;
+        }
+    }
+    __syncthreads();   // (the records are for later launches of this stream; the word announces meta, which thread 0 wrote itself)
+    if (tid == 0) __hip_atomic_store(&meta->word, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace uh_kd
