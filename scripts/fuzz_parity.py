@@ -218,9 +218,13 @@ from ucoslam_cv3_amd.projmatch import kdtree_build_dev, kdtree_build_host
 def kd_case(seed):
     r = np.random.default_rng(seed)
     n = int(r.integers(0, 4097)) if r.random() < 0.7 else int(r.integers(0, 200))
-    mode = int(r.integers(0, 6))
+    mode = int(r.integers(0, 8))
     if mode == 0:
         xy = (r.random((n, 2)) * [1241, 376]).astype(np.float32)
+    elif mode == 6:   # inside an extractor's 19 px border: the builders' exact-sum route
+        xy = (r.random((n, 2)) * [1203, 338] + 19).astype(np.float32)
+    elif mode == 7:   # the same on integer pixels (ties in both coordinates)
+        xy = np.stack([r.integers(19, 1222, n), r.integers(19, 357, n)], 1).astype(np.float32)
     elif mode == 1:
         xy = r.integers(0, max(2, int(r.integers(2, 200))), (n, 2)).astype(np.float32)
     elif mode == 2:   # extractor-like: pixel centres of a level scaled back to level 0

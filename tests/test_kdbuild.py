@@ -87,6 +87,9 @@ def _more_clouds():
     out = dict(_clouds())
     for n in (12, 16, 17, 19, 20, 23, 33, 64, 65, 199, 200, 201, 399, 400, 1023, 1024, 1025, 3000, 4096):
         out[f"rand{n}"] = (rng.random((n, 2)) * [1241, 376]).astype(np.float32)
+    # what an extractor leaves (19 px border): non-zero coordinates within 11 binades — the builders' exact-sum route (kdbuild.hpp sweep_levels)
+    for n in (11, 21, 40, 150, 199, 200, 201, 398, 777, 1200, 1999, 2000, 2500, 4000):
+        out[f"inrange{n}"] = (rng.random((n, 2)) * [1203, 338] + 19).astype(np.float32)
     # integer pixel positions of level 0 (zero-distortion camera): columns and rows repeat
     out["pixels2000"] = np.stack([rng.integers(19, 1222, 2000), rng.integers(19, 357, 2000)], 1).astype(np.float32)
     out["pixels_scaled"] = (np.stack([rng.integers(0, 200, 3000), rng.integers(0, 60, 3000)], 1).astype(np.float32) + np.float32(0.5)) * \

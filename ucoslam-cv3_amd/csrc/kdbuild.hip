@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void kd_sub_kernel(const float4* __restrict__ 
     if (j >= dump->nsub) return;
     const uh_kd::TopNode t = dump->node[dump->lvl_b + j];
     uh_kd::SubArgs a;
-    a.pts = pts; a.pos0 = (int)(t.nbe & 0xffffu); a.root_flags = t.flag; a.depth0 = dump->depth; a.sum = sums + j;
+    a.pts = pts; a.pos0 = (int)(t.nbe & 0xffffu); a.root_flags = t.flag; a.depth0 = dump->depth; a.exact = dump->exact; a.sum = sums + j;
     const int c = (int)(t.nbe >> 16) - a.pos0;
     uh_kd::build_workgroup<uh_kd::kSub>(s_kd, n_cap, in, c, sub_nodes + (size_t)j * node_stride, leaf, nullptr, 0ull, j == 0 ? clk : nullptr, nullptr, nullptr, a);
 }

@@ -238,6 +238,29 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
     return x;
 }
 
+// x + (the value `ctrl` rows away within the lane's row of 16, 0 from outside the row): one step of a row-wide prefix sum of doubles in the VALU
+template <int CTRL>
+__device__ __forceinline__ double row_shr_add_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return v + __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// lane 15 of every row of 16 lanes ends up with the row's sum
+__device__ __forceinline__ double row16_total_f64(double v) {
+    v = row_shr_add_f64<0x111>(v); v = row_shr_add_f64<0x112>(v); v = row_shr_add_f64<0x114>(v); v = row_shr_add_f64<0x118>(v);
+    return v;
+}
+
+// exponent range of a float's magnitude for the exact-sum test below (zeros do not count, a non-finite value poisons it)
+__device__ __forceinline__ void exp_range(float v, int& emin, int& emax) {
+    const unsigned bits = __float_as_uint(v);
+    const int ex = (int)((bits >> 23) & 0xffu);
+    if (ex == 0xff) { emin = -1000; return; }
+    if ((bits & 0x7fffffffu) == 0) return;
+    emin = ex < emin ? ex : emin; emax = ex > emax ? ex : emax;
+}
+
 // Sweeps levels of the tree below the nodes [lvl_b, lvl_e) (depth `depth`) whose points are [eb, ee), with the team's threads tid of nthr
 // (the whole workgroup or one wave); runs at most max_levels levels and leaves the next level's node range and depth behind.  cursor: the
 // team's node allocator; status[0]: "a node of this level took the std::sort fallback", status[1]: children that will split again,
@@ -249,7 +272,7 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
 constexpr int kKC = 8;
 template <bool WG, bool FAST>
 __device__ __forceinline__ void sweep_levels(const Lds V, const int tid, const int nthr, const int eb, const int ee, int& lvl_b, int& lvl_e, unsigned* cursor,
-                             unsigned* status, unsigned long long* bal, int& depth, const int max_levels, unsigned* s_maxdepth, long long* clk) {
+                             unsigned* status, unsigned long long* bal, int& depth, const int max_levels, unsigned* s_maxdepth, long long* clk, const bool exact) {
 #define UH_KD_STAMP(j) do { if (clk && tid == 0 && lv < 6) clk[lv * 8 + (j)] = wall_clock64(); } while (0)
     const int lane = threadIdx.x & 63;
     const int tw = WG ? (int)(threadIdx.x >> 6) : 0, nw = WG ? (int)(blockDim.x >> 6) : 1;
@@ -281,7 +304,39 @@ __device__ __forceinline__ void sweep_levels(const Lds V, const int tid, const i
         const int nL = lvl_e - lvl_b;
         const unsigned c0 = *cursor;
         UH_KD_STAMP(0);
-        // ---- mean / variance over the samples, split dimension, cut (picoflann.h:362-401): lanes 4j .. 4j + 3 own node j's four sums
+        // ---- mean / variance over the samples, split dimension, cut (picoflann.h:362-401).
+        // exact (all non-zero coordinates finite, normal, within 11 binades — any extractor output is): no partial sum of the <= 199 samples
+        // (multiples of 2^(e_min-23) below 2^(e_max+9); float squares: multiples of 2^(2 e_min-23) below 2^(2 e_max+10)) is ever rounded, so the
+        // sums are the exact real sums in ANY order: a row of 16 lanes shares a node's samples and adds up through DPP (2.6 -> 1.2 us a level;
+        // a whole wave per node with every load in flight at once measured no faster: the phase is the chain index -> loads -> sums -> division).
+        // Otherwise lanes 4j .. 4j + 3 own node j's four sums and walk the samples in picoflann's order.
+        if (exact) {
+            const int sub = lane & 15, grp = tid >> 4, ngrp = nthr >> 4;
+            for (int n0 = 0; n0 < nL; n0 += ngrp) {
+                const int nd = n0 + grp, g = lvl_b + nd;
+                int b = 0, e = 0;
+                bool act = nd < nL;
+                if (act) { const unsigned be = V.nbe[g]; b = (int)(be & 0xffffu); e = (int)(be >> 16); act = e - b > kLeafMax; }
+                const int c = e - b, step = c >= 200 ? c / 100 : 1;
+                const int cnt = act ? (c + step - 1) / step : 0;
+                double a1 = 0, a2 = 0, c1 = 0, c2 = 0;
+                for (int k = sub; k < cnt; k += 16) {
+                    const float x = V.px[b + k * step], y = V.py[b + k * step];
+                    a1 += (double)x; a2 += (double)(x * x); c1 += (double)y; c2 += (double)(y * y);
+                }
+                a1 = row16_total_f64(a1); a2 = row16_total_f64(a2); c1 = row16_total_f64(c1); c2 = row16_total_f64(c2);
+                if (act && sub == 15) {
+                    const double inv = 1. / double(cnt);
+                    const double m0 = a1 * inv, m1 = c1 * inv;
+                    const double v0 = a2 * inv - m0 * m0, v1 = c2 * inv - m1 * m1;
+                    const int dim = v1 > v0 ? 1 : 0;
+                    const double cut = dim ? m1 : m0;
+                    V.ncut[g] = cut;
+                    V.ncutf[g] = (float)cut;
+                    V.nflag[g] = (unsigned char)((V.nflag[g] & ~3u) | (unsigned)dim);
+                }
+            }
+        } else
         for (int q0 = 0; q0 < nL * 4; q0 += nthr) {
             const int q = q0 + tid, nd = q >> 2, ch = q & 3;
             const int g = lvl_b + nd;
@@ -622,7 +677,7 @@ struct Meta { unsigned long long word; int n, n_nodes, max_depth, m_used; double
 // on its own compute unit (kd_sub: one wave per SIMD instead of two sharing one, a quarter of the rows per wave), a small join launch that
 // numbers the nodes across subtrees.  What travels between them (HBM scratch of the frame object):
 struct TopNode { unsigned nbe; unsigned short nchild, npar; unsigned flag; double cut; };
-struct TopDump { int nsub, n, depth, ntop, lvl_b, lvl_e, pad0, pad1; TopNode node[64]; };   // nsub = 0: kd_top built the whole tree itself (small / shallow clouds)
+struct TopDump { int nsub, n, depth, ntop, lvl_b, lvl_e, exact, pad1; TopNode node[64]; };   // nsub = 0: kd_top built the whole tree itself (small / shallow clouds)
 struct SubSum { int cnt_int, n_nodes, maxdepth, pad; float lo[2]; double rhi[2]; };       // a subtree as its parent sees it
 constexpr int kSplitMin = 1200;   // below this one workgroup finishes sooner than three launches do (measured: 500 points 55 vs 64 us, 2000 points 102 vs 95 us)
 constexpr int kSubMax = 8;      // subtrees = nodes of the level below log2(waves of kd_top) sweeps
@@ -633,6 +688,7 @@ struct SubArgs {            // kSub: the subtree this workgroup builds
     int pos0;               // position of the subtree's first point
     unsigned root_flags;    // the "upper bound overridden" bits its root inherits
     int depth0;             // depth of its root
+    int exact;              // the cloud passed the exact-sum test (sweep_levels)
     SubSum* sum;
 };
 
@@ -650,10 +706,14 @@ __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const 
     UH_KD_TOP(0);
     __shared__ unsigned s_cursor[17], s_status[17][4], s_maxdepth;
     __shared__ double s_rhi[16][2];
+    __shared__ int s_emin, s_emax;
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
     const Lds V = carve(lds_base, n_cap, nwaves);
     const int pos0 = MODE == kSub ? sub.pos0 : 0;
+    if (MODE != kSub && tid == 0) { s_emin = 1 << 20; s_emax = 0; }
     for (int g = tid; g < V.m_cap; g += nthr) V.npar[g] = kNoNode;
+    int emin = 1 << 20, emax = 0;
+    if (MODE != kSub) __syncthreads();
     for (int i = tid; i < n; i += nthr) {
         if constexpr (MODE == kSub) {
             const float4 r = sub.pts[pos0 + i];
@@ -661,8 +721,17 @@ __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const 
         } else {
             const float4 r = in[i];
             V.px[i] = r.x; V.py[i] = r.y; V.ord[i] = (unsigned short)i;
+            exp_range(r.x, emin, emax); exp_range(r.y, emin, emax);
         }
         V.eseg[i] = 0;
+    }
+    if constexpr (MODE != kSub) {   // the exponent range of the cloud, for sweep_levels' exact sums
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int a = __shfl_xor(emin, o), b = __shfl_xor(emax, o);
+            emin = a < emin ? a : emin; emax = b > emax ? b : emax;
+        }
+        if (lane == 0) { atomicMin(&s_emin, emin); atomicMax(&s_emax, emax); }
     }
     if (tid < 17) { s_status[tid][0] = 0; s_status[tid][1] = 0; s_status[tid][2] = 0; }
     __syncthreads();
@@ -674,12 +743,13 @@ __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const 
     }
     __syncthreads();
     UH_KD_TOP(1);
+    const bool exact = MODE == kSub ? sub.exact != 0 : (s_emin >= 1 && s_emax - s_emin <= 10);   // (emin < 1: a denormal or a non-finite coordinate)
     int m_used = n > 0 ? 1 : 0;
     if (n > kLeafMax) {
         int lvl_b = 0, lvl_e = 1, depth = depth_root;
         const int k_wg = uh_sel::floor_log2(nwaves);
-        if ((n + 63) / 64 <= kKC * nwaves) sweep_levels<true, true>(V, tid, nthr, 0, n, lvl_b, lvl_e, &s_cursor[16], s_status[16], V.bal, depth, k_wg, &s_maxdepth, clk ? clk + 16 : nullptr);
-        else sweep_levels<true, false>(V, tid, nthr, 0, n, lvl_b, lvl_e, &s_cursor[16], s_status[16], V.bal, depth, k_wg, &s_maxdepth, clk ? clk + 16 : nullptr);
+        if ((n + 63) / 64 <= kKC * nwaves) sweep_levels<true, true>(V, tid, nthr, 0, n, lvl_b, lvl_e, &s_cursor[16], s_status[16], V.bal, depth, k_wg, &s_maxdepth, clk ? clk + 16 : nullptr, exact);
+        else sweep_levels<true, false>(V, tid, nthr, 0, n, lvl_b, lvl_e, &s_cursor[16], s_status[16], V.bal, depth, k_wg, &s_maxdepth, clk ? clk + 16 : nullptr, exact);
         __syncthreads();
         UH_KD_TOP(2);
         const int nL = lvl_e - lvl_b;
@@ -693,7 +763,7 @@ __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const 
                     t.nbe = V.nbe[g]; t.nchild = V.nchild[g]; t.npar = V.npar[g]; t.flag = V.nflag[g]; t.cut = V.ncut[g];
                     dump->node[g] = t;
                 }
-                if (tid == 0) { dump->nsub = nL; dump->n = n; dump->depth = depth; dump->ntop = ntop; dump->lvl_b = lvl_b; dump->lvl_e = lvl_e; }
+                if (tid == 0) { dump->exact = exact ? 1 : 0; dump->nsub = nL; dump->n = n; dump->depth = depth; dump->ntop = ntop; dump->lvl_b = lvl_b; dump->lvl_e = lvl_e; }
                 return;
             }
         }
@@ -717,9 +787,9 @@ __device__ void build_workgroup(unsigned char* lds_base, const int n_cap, const 
             uh_sel::wave_mem_sync();
             int lb = lvl_b + wave, le = lb + 1, d = depth;
             if (me - mb <= 64 * kKC) sweep_levels<false, true>(V, lane, 64, mb, me, lb, le, &s_cursor[wave], s_status[wave], V.bal + (mb >> 6) + before, d, 1 << 20, &s_maxdepth,
-                                                               clk && wave == 0 ? clk + 64 : nullptr);
+                                                               clk && wave == 0 ? clk + 64 : nullptr, exact);
             else sweep_levels<false, false>(V, lane, 64, mb, me, lb, le, &s_cursor[wave], s_status[wave], V.bal + (mb >> 6) + before, d, 1 << 20, &s_maxdepth,
-                                            clk && wave == 0 ? clk + 64 : nullptr);
+                                            clk && wave == 0 ? clk + 64 : nullptr, exact);
         }
         UH_KD_TOP(3);
         if (clk && lane == 0) { clk[128 + wave] = wall_clock64(); clk[144 + wave] = me - mb; }
