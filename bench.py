@@ -425,60 +425,44 @@ def main():
         del gba
         # headroom figure, NOT the metric: two independent sessions (two frame streams, two maps, two local BAs) on this one GPU —
         # the latency-bound launch chains of the two BAs interleave, which one session cannot do with itself
-        ctx_ba2 = u.Context(local_rank, private=True)
-        ba2 = GlobalOptimizer.create(ctx_ba2).wantChi2(False)
-        ba2.setParams(synth.ba_problem(BA_K, BA_P, seed=rank + 100), ParamSet(nIters=5))
-        ctx_t2 = u.Context(local_rank, private=True)
-        ext_b = ORBextractor.create(ctx_t2)
-        idx_b = Index(ctx_t2).build(map_desc)
-        out_b = ext_b.extract_batch(frames, fp)
-        knn_idx_b, knn_dist_b = torch.empty_like(knn_idx), torch.empty_like(knn_dist)
+        # ... three and four: 94 spinning workgroups per local BA — a third does not fit the 7/8-of-the-CUs admission budget of the persistent
+        # launches (ba.hip, PersistAdmission) and WAITS for one of the others to leave (it does not change form: the launch-chain form beside two
+        # persistent launches is slower still, scripts/sessions_probe.py) — the figures show what that costs.  forms = uh_ba_form of each session's optimiser.
+        class _Session:
+            def __init__(self, k):
+                self.ctx_ba, self.ctx_t = u.Context(local_rank, private=True), u.Context(local_rank, private=True)
+                self.ba = GlobalOptimizer.create(self.ctx_ba).wantChi2(False)
+                self.ba.setParams(synth.ba_problem(BA_K, BA_P, seed=rank + 100 * k), ParamSet(nIters=5))
+                self.ext = ORBextractor.create(self.ctx_t)
+                self.idx = Index(self.ctx_t).build(map_desc)
+                self.out = self.ext.extract_batch(frames, fp)
+                self.knn_idx, self.knn_dist = torch.empty_like(knn_idx), torch.empty_like(knn_dist)
 
-        def step_two_sessions():   # (resident form, like kernel_only_*)
-            ba_res.optimize_async()
-            ba2.optimize_async()
-            ext.extract_batch(frames, fp, orb_out)
-            ext_b.extract_batch(frames, fp, out_b)
-            check(L.uh_knn_search_dev(index._h, dev_ptr(orb_out[1]), F * NQ, NN, dev_ptr(knn_idx), dev_ptr(knn_dist), 0, -1))
-            check(L.uh_knn_search_dev(idx_b._h, dev_ptr(out_b[1]), F * NQ, NN, dev_ptr(knn_idx_b), dev_ptr(knn_dist_b), 0, -1))
-            ba_res.wait()
-            ba2.wait()
+        import types
 
-        for _ in range(3):
-            step_two_sessions()
-        stage_ms["two_sessions_step_ms"] = timed(step_two_sessions, 15)
-        stage_ms["two_sessions_frames_per_s"] = 1e3 * 2 * F / stage_ms["two_sessions_step_ms"]
-        # ... and three: 3 x 94 spinning workgroups do not fit the 7/8-of-the-CUs admission budget of the persistent launches (ba.hip,
-        # PersistAdmission): the third session's local BA WAITS for one of the other two to leave (it does not change form) — the figure shows
-        # what that costs.  forms = uh_ba_form of each session's optimiser.
-        ctx_ba3 = u.Context(local_rank, private=True)
-        ba3 = GlobalOptimizer.create(ctx_ba3).wantChi2(False)
-        ba3.setParams(synth.ba_problem(BA_K, BA_P, seed=rank + 200), ParamSet(nIters=5))
-        ctx_t3 = u.Context(local_rank, private=True)
-        ext_c = ORBextractor.create(ctx_t3)
-        idx_c = Index(ctx_t3).build(map_desc)
-        out_c = ext_c.extract_batch(frames, fp)
-        knn_idx_c, knn_dist_c = torch.empty_like(knn_idx), torch.empty_like(knn_dist)
+        sess = [types.SimpleNamespace(ba=ba_res, ext=ext, idx=index, out=orb_out, knn_idx=knn_idx, knn_dist=knn_dist)]   # the bench's own objects as the first session
+        sess += [_Session(k) for k in (1, 2, 3)]
 
-        def step_three_sessions():
-            ba_res.optimize_async(); ba2.optimize_async(); ba3.optimize_async()
-            ext.extract_batch(frames, fp, orb_out)
-            ext_b.extract_batch(frames, fp, out_b)
-            ext_c.extract_batch(frames, fp, out_c)
-            check(L.uh_knn_search_dev(index._h, dev_ptr(orb_out[1]), F * NQ, NN, dev_ptr(knn_idx), dev_ptr(knn_dist), 0, -1))
-            check(L.uh_knn_search_dev(idx_b._h, dev_ptr(out_b[1]), F * NQ, NN, dev_ptr(knn_idx_b), dev_ptr(knn_dist_b), 0, -1))
-            check(L.uh_knn_search_dev(idx_c._h, dev_ptr(out_c[1]), F * NQ, NN, dev_ptr(knn_idx_c), dev_ptr(knn_dist_c), 0, -1))
-            ba_res.wait(); ba2.wait(); ba3.wait()
+        def step_sessions(n):   # (resident form, like kernel_only_*)
+            for s_ in sess[:n]: s_.ba.optimize_async()
+            for s_ in sess[:n]: s_.ext.extract_batch(frames, fp, s_.out)
+            for s_ in sess[:n]: check(L.uh_knn_search_dev(s_.idx._h, dev_ptr(s_.out[1]), F * NQ, NN, dev_ptr(s_.knn_idx), dev_ptr(s_.knn_dist), 0, -1))
+            for s_ in sess[:n]: s_.ba.wait()
 
-        for _ in range(3):
-            step_three_sessions()
-        three_ms = timed(step_three_sessions, 15)
+        sess_ms = {1: stage_ms["kernel_only_step_ms"]}
+        for n_s in (2, 3, 4):
+            for _ in range(3):
+                step_sessions(n_s)
+            sess_ms[n_s] = timed(lambda: step_sessions(n_s), 15)
+        stage_ms["two_sessions_step_ms"] = sess_ms[2]
+        stage_ms["two_sessions_frames_per_s"] = 1e3 * 2 * F / sess_ms[2]
         stage_ms["sessions_on_one_gpu"] = {
-            "frames_per_s": {"1": round(stage_ms["kernel_only_frames_per_s"], 1), "2": round(stage_ms["two_sessions_frames_per_s"], 1), "3": round(1e3 * 3 * F / three_ms, 1)},
-            "step_ms": {"1": round(stage_ms["kernel_only_step_ms"], 4), "2": round(stage_ms["two_sessions_step_ms"], 4), "3": round(three_ms, 4)},
-            "ba_forms": [ba_res.form(), ba2.form(), ba3.form()],
-            "note": "resident form (frames in HBM, one problem per session re-optimised); persistent local-BA launches are admitted up to 7/8 of the CUs: two run side by side, a third waits its turn"}
-        del ba3, ext_c, idx_c
+            "frames_per_s": {str(n_s): round(1e3 * n_s * F / sess_ms[n_s], 1) for n_s in (1, 2, 3, 4)},
+            "step_ms": {str(n_s): round(sess_ms[n_s], 4) for n_s in (1, 2, 3, 4)},
+            "ba_forms": [s_.ba.form() for s_ in sess],
+            "note": "resident form (frames in HBM, one problem per session re-optimised); persistent local-BA launches are admitted up to 7/8 of the CUs: two run side by side, "
+                    "a third and a fourth wait their turn (412 registers per lane leave no room for a second landmark group per workgroup: DESIGN.md section 4.3)"}
+        del sess
         stage_ms["orb_ms_per_frame_640x480"] = timed(lambda: ext2.extract_batch(fr2, fp, out2), 20) / F
         # not part of the metric's step (ORB + match + local BA): the per-frame pose-only solve (PnPSolver::solvePnp, 600 matches)
         from ucoslam_cv3_amd.pnp import PnPSolver

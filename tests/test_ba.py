@@ -414,6 +414,37 @@ def test_hip_ba_persistent_is_exact_under_uneven_background_load(hip_ctx):
         th.join()
 
 
+@pytest.mark.gpu
+def test_hip_ba_four_sessions_share_the_gpu_and_keep_their_results(hip_ctx):
+    """Four independent sessions (an optimiser on a private context each) start their local BAs at the same moment: 4 x 94 spinning
+    workgroups do not fit the persistent launches' admission budget (7/8 of the compute units, ba.hip PersistAdmission), so two run side
+    by side and the others are admitted as those leave — none changes form, none times out, and every session's result equals the one
+    it computes alone, bit for bit, round after round."""
+    import ucoslam_cv3_amd as u
+    from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
+
+    def sig(opt):
+        r = opt.getResults()
+        return r["state"].tobytes() + r["iters"].tobytes() + r["bad"].tobytes()
+
+    sessions = []
+    for i in range(4):
+        ctx = u.Context(0, private=True)
+        opt = GlobalOptimizer.create(ctx)
+        opt.setParams(synth.ba_problem(10, 3000, seed=300 + i), ParamSet(nIters=5))
+        opt.optimize()
+        sessions.append((ctx, opt, sig(opt)))
+    assert all(opt.form().startswith("persist") for _, opt, _ in sessions)
+    for rnd in range(25):
+        for _, opt, _ in sessions:
+            opt.optimize_async()
+        for _, opt, _ in sessions:
+            opt.wait()
+        for i, (_, opt, alone) in enumerate(sessions):
+            assert sig(opt) == alone, f"session {i}, round {rnd}: result beside three other sessions differs from the one computed alone"
+        assert all(opt.form().startswith("persist") for _, opt, _ in sessions)
+
+
 # ------------------------------------------------------------------------------------------------ the plugin protocol per keyframe
 def _sig(r):
     return r["state"].tobytes() + r["iters"].tobytes() + r["bad"].tobytes() + r["chi2"].tobytes() + r["poses"].tobytes() + r["points"].tobytes()
