@@ -10,7 +10,7 @@ from ucoslam_cv3_amd.pnp import PnPSolver
 
 ctx = u.Context(0, private=True)
 sol = PnPSolver(ctx)
-for n in (100, 300, 600, 800, 1500, 3000, 4000):
+for n in (100, 300, 600, 800, 1300, 1500, 3000, 4000):
     pr = synth.pnp_problem(n, seed=3)
     args = (pr["pose"], pr["intr"], pr["p3d"], pr["kp"], pr["invsig"], pr["weight"])
     for _ in range(5):
