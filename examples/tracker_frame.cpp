@@ -19,7 +19,7 @@
 // so every stage works on data the previous one produced.  Prints one JSON line with the median per-stage and per-frame latencies.
 //
 //   g++ -std=c++17 -O2 -o tracker_frame examples/tracker_frame.cpp -Lucoslam-cv3_amd -lucoslam_hip -Wl,-rpath,$PWD/ucoslam-cv3_amd -Wl,-rpath,/opt/rocm/lib -lpthread
-//   ./tracker_frame [frames=200] [warmup=20] [route=host|dev]     (dev: uh_orb_extract_frame_dev + uh_projmatch_set_frame_dev, the kd-tree built on the device)
+//   ./tracker_frame [frames=200] [warmup=20] [route=host|dev|devhost]     (dev: uh_orb_extract_frame_dev + uh_projmatch_set_frame_dev, the kd-tree built on the device; devhost: the same frame object, tree by the host core)
 #include <algorithm>
 #include <array>
 #include <chrono>
@@ -109,7 +109,8 @@ struct Stat {
 
 int main(int argc, char** argv) {
     const int frames = argc > 1 ? std::atoi(argv[1]) : 200, warmup = argc > 2 ? std::atoi(argv[2]) : 20;
-    const bool dev_route = argc > 3 && std::strcmp(argv[3], "dev") == 0;
+    const bool hybrid_route = argc > 3 && std::strcmp(argv[3], "devhost") == 0;   // frame resident on the device, its tree built by this core
+    const bool dev_route = hybrid_route || (argc > 3 && std::strcmp(argv[3], "dev") == 0);
     uh_ctx* ctx = nullptr;
     if (uh_ctx_create_private(0, &ctx) < 0) { std::printf("no device: %s (there is no CPU path)\n", uh_last_error()); return 0; }
     uh_orb* ext = nullptr; uh_projmatch* pm = nullptr; uh_pnp* pnp = nullptr;
@@ -120,6 +121,7 @@ int main(int argc, char** argv) {
     CHECK(uh_pnp_create(ctx, &pnp));
     uh_dev_frame* dfr = nullptr;
     CHECK(uh_dev_frame_create(ctx, &dfr));
+    if (hybrid_route) CHECK(uh_dev_frame_set_tree_builder(dfr, 1));
     float sf[NLEV]; sf[0] = 1.f; for (int i = 1; i < NLEV; i++) sf[i] = sf[i - 1] * 1.2f;   // the extractor's float chain (ORBextractor.cpp:468-515)
     float inv_sf[NLEV]; for (int i = 0; i < NLEV; i++) inv_sf[i] = (float)(1. / sf[i]);         // pnpsolver.cpp:191-192
     const float intr[4] = {FX, FY, CX, CY};
@@ -308,7 +310,7 @@ int main(int argc, char** argv) {
                 "\"orb_extract_ms\": %.4f, \"set_frame_ms\": %.4f, \"match_prev_ms\": %.4f, \"pnp1_ms\": %.4f, \"match_map_ms\": %.4f, \"pnp2_ms\": %.4f, \"host_glue_ms\": %.4f, "
                 "\"keypoints\": %.1f, \"prev_items\": %d, \"map_points\": %d, \"matches_prev\": %.1f, \"matches_map\": %.1f, \"inliers1\": %.1f, \"inliers2\": %.1f, "
                 "\"max_pose_err_vs_truth\": %.5f}\n",
-                dev_route ? "device-resident frame, kd-tree built on the device" : "keypoints to the host, kd-tree built on the host", frames, t_frame.med() / 1e3, t_frame.lo() / 1e3, t_frame.p90() / 1e3, 1e6 / std::max(t_frame.med(), 1e-9), t_orb.med() / 1e3, t_set.med() / 1e3, t_prev.med() / 1e3,
+                hybrid_route ? "device-resident frame, kd-tree built by the host core and uploaded" : dev_route ? "device-resident frame, kd-tree built on the device" : "keypoints to the host, kd-tree built on the host", frames, t_frame.med() / 1e3, t_frame.lo() / 1e3, t_frame.p90() / 1e3, 1e6 / std::max(t_frame.med(), 1e-9), t_orb.med() / 1e3, t_set.med() / 1e3, t_prev.med() / 1e3,
                 t_pnp1.med() / 1e3, t_map.med() / 1e3, t_pnp2.med() / 1e3, t_glue.med() / 1e3, sum_kp * f, N_PREV, N_MAP, sum_prev * f, sum_map * f, sum_in1 * f, sum_in2 * f, pose_err);
     uh_pnp_destroy(pnp); uh_projmatch_destroy(pm); uh_orb_destroy(ext); uh_dev_frame_destroy(dfr);
     for (auto& s : scenes) uh_host_free(s.image);

@@ -311,6 +311,12 @@ int uh_undistort_points_host(const uh_camera* cam, const float* xy, int n, float
 typedef struct uh_dev_frame uh_dev_frame;
 int  uh_dev_frame_create(uh_ctx* ctx, uh_dev_frame** out);
 void uh_dev_frame_destroy(uh_dev_frame* frame);
+/* Who builds the kd-tree of a device frame.  on_host = 0 (default): the build launches behind the extraction (the host does nothing but wait).
+ * on_host = 1: no build launch; uh_projmatch_set_frame_dev builds the tree on the calling core from the host copy of the undistorted keypoints
+ * (frame->und_kpts / n_kpts of its uh_proj_frame argument, exactly the arrays uh_orb_extract_frame_dev returned) and uploads nodes and leaf records
+ * into the frame object — the descriptors still never cross the host link a second time.  Same tree, byte for byte; the faster route while a
+ * core is free (Frame::create_kdtree, frameextractor.cpp:4258). */
+int  uh_dev_frame_set_tree_builder(uh_dev_frame* frame, int32_t on_host);
 int  uh_orb_extract_frame_dev(uh_orb* orb, const uint8_t* img, int w, int h, size_t stride, int channels,
                               uh_keypoint* kps, uint8_t* desc, float* und_xy, int cap, int* n_out, uh_dev_frame* frame);
 int  uh_dev_frame_tree(uh_dev_frame* frame, int32_t* n_kpts, int32_t* n_nodes, void* nodes24_out, uint32_t* leaf_idx_out, float* leaf_xy_out,

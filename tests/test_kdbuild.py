@@ -226,6 +226,24 @@ def test_frame_stays_on_the_device_between_extractor_and_projection_matcher(hip_
     b = dev.matchFrameToPrevFrame(pose, mp["ids"], mp["pos3d"], mp["octave"], mp["desc"], 75.0, 15.0)
     for k in ("matches", "best_kp", "best_dist"):
         np.testing.assert_array_equal(a[k], b[k])
+    # third route: the frame resident, its tree built by the host core and uploaded into the frame object (no build launch)
+    fr_h = DeviceFrame(hip_ctx).setTreeBuilder(True)
+    kps_h, desc_h, und_h = ext.extractFrameDev(img, fr_h, fp)
+    np.testing.assert_array_equal(kps_h, kps0)
+    np.testing.assert_array_equal(und_h, und0)
+    hyb = ProjectionMatcher(hip_ctx)
+    hyb.setFrameDev(fr_h, sf, cam.fx, cam.fy, cam.cx, cam.cy, (0, 0), (1241, 376), und_kpts=ukp)
+    a = host.matchFrameToMapPoints(pose, mp["ids"], mp["pos3d"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], 100.0, 15.0)
+    b = hyb.matchFrameToMapPoints(pose, mp["ids"], mp["pos3d"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], 100.0, 15.0)
+    for k in ("matches", "best_kp", "best_dist", "visible"):
+        np.testing.assert_array_equal(a[k], b[k])
+    a = host.matchFrameToPrevFrame(pose, mp["ids"], mp["pos3d"], mp["octave"], mp["desc"], 75.0, 15.0)
+    b = hyb.matchFrameToPrevFrame(pose, mp["ids"], mp["pos3d"], mp["octave"], mp["desc"], 75.0, 15.0)
+    for k in ("matches", "best_kp", "best_dist"):
+        np.testing.assert_array_equal(a[k], b[k])
+    hyb.setFrameDev(fr_h, sf, cam.fx, cam.fy, cam.cx, cam.cy, (0, 0), (1241, 376), und_kpts=ukp)   # again: the staging block is reused behind its completion word
+    b = hyb.matchFrameToPrevFrame(pose, mp["ids"], mp["pos3d"], mp["octave"], mp["desc"], 75.0, 15.0)
+    np.testing.assert_array_equal(a["matches"], b["matches"])
     # a second extraction into the same frame object replaces it (and an empty image yields the empty frame)
     img2 = synth.frame(1241, 376, seed=6, shift=(3, 1))
     kps2, desc2, und2 = ext.extractFrameDev(img2, fr, fp)

@@ -12,6 +12,8 @@ struct uh_dev_frame {
     uh::MappedBuf meta;      // uh_kd::Meta, written by the build launch; its word is the completion word the host polls
     int n_cap = 0;
     int threads = 512;       // of the build workgroup (UH_KD_THREADS: 256 / 512; 512 lanes leave each 256 registers: the cached row state of kdbuild.hpp)
+    bool host_tree = false;  // uh_dev_frame_set_tree_builder(f, 1): no build launch — uh_projmatch_set_frame_dev builds the tree on the calling core from the host copy of the
+                             // undistorted keypoints and uploads nodes + leaf records into this object; the descriptors still never leave the device
     bool split = true;       // the build over three launches (kdbuild.hpp); false: one launch of `threads` (UH_KD_SPLIT=0, UH_KD_THREADS, the test hook's explicit sizes)
     size_t o_desc = 0, o_in = 0, o_nodes = 0, o_leaf = 0;
     size_t o_pts = 0, o_dump = 0, o_sums = 0, o_sub = 0;   // scratch of the split build: points after the top levels, top nodes, subtree summaries and records

@@ -1871,7 +1871,7 @@ static int extract_one(uh_orb* o, const uint8_t* img, int w, int h, size_t strid
     UH_REQUIRE(o && n_out, "uh_orb_extract: NULL argument");
     *n_out = 0;
     if (img == nullptr || w <= 0 || h <= 0) {   // ORBextractor.cpp:1254 — empty image: silent return (a device frame becomes the empty frame)
-        if (fr) { int rc0 = uh::dev_frame_reserve(fr, 1); if (rc0 || (rc0 = uh::kd_build_launch(fr, nullptr, 0, 0, 0))) return rc0; }
+        if (fr) { int rc0 = uh::dev_frame_reserve(fr, 1); if (rc0 || (!fr->host_tree && (rc0 = uh::kd_build_launch(fr, nullptr, 0, 0, 0)))) return rc0; }
         return UH_OK;
     }
     UH_REQUIRE(cn == 1 || cn == 3 || cn == 4, "uh_orb_extract_frame: %d channels (1 = gray, 3 = BGR, 4 = BGRA)", cn);
@@ -1943,7 +1943,7 @@ static int extract_one(uh_orb* o, const uint8_t* img, int w, int h, size_t strid
     if ((rc = uh::post_host_word(o->ctx, reinterpret_cast<unsigned long long*>(db), word))) return rc;
     // Frame::create_kdtree (frameextractor.cpp:4258) as one more launch BEHIND the completion word: the host gets its keypoints and goes on
     // while the tree is built; the projection matcher adopts it with uh_projmatch_set_frame_dev (no D2H -> host build -> H2D)
-    if (fr && (rc = uh::kd_build_launch(fr, o->d_level_counts.as<int>(), o->plan.nlevels, cap_launch, 0))) return rc;
+    if (fr && !fr->host_tree && (rc = uh::kd_build_launch(fr, o->d_level_counts.as<int>(), o->plan.nlevels, cap_launch, 0))) return rc;
     if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(hb), word, st, "uh_orb_extract"))) return rc;
     const int n = *reinterpret_cast<const int*>(hb + o_cnt);
     *n_out = n;

@@ -821,6 +821,59 @@ int uh_projmatch_set_frame_dev(uh_projmatch* h, uh_dev_frame* fr, const uh_proj_
         if ((rc = h->d_scale.reserve(64))) return rc;
         UH_HIP_CHECK(hipMemcpyAsync(h->d_scale.p, h->scale_host.data(), 4 * (size_t)f->n_levels, hipMemcpyHostToDevice, h->ctx->stream));
     }
+    if (fr->host_tree) {
+        // the tree by this core (KdBuilder, as uh_projmatch_set_frame), nodes and leaf records uploaded into the frame object; the descriptors
+        // and everything else stay where the extractor left them
+        const int n = f->n_kpts;
+        UH_REQUIRE(n >= 0 && n <= fr->n_cap && (n == 0 || f->und_kpts), "uh_projmatch_set_frame_dev: %d keypoints for a device frame of capacity %d (host-built tree)", n, fr->n_cap);
+        std::vector<float>& xy = h->xy;
+        std::vector<int>& oct = h->oct;
+        xy.resize(2 * (size_t)std::max(n, 1));
+        oct.resize(std::max(n, 1));
+        for (int i = 0; i < n; i++) {
+            UH_REQUIRE(f->und_kpts[i].octave >= 0 && f->und_kpts[i].octave < 16, "uh_projmatch_set_frame_dev: octave %d of keypoint %d outside [0,16)", f->und_kpts[i].octave, i);
+            xy[2 * i] = f->und_kpts[i].x; xy[2 * i + 1] = f->und_kpts[i].y; oct[i] = f->und_kpts[i].octave;
+        }
+        h->kd.build(xy.data(), n);
+        UH_REQUIRE(h->kd.max_depth <= kMaxDepth, "uh_projmatch_set_frame_dev: kd-tree depth %d exceeds the walk stack (%d levels)", h->kd.max_depth, kMaxDepth);
+        const size_t nn = h->kd.nodes.size(), gap = fr->o_leaf - fr->o_nodes, span = gap + 16 * (size_t)n;
+        UH_REQUIRE(sizeof(KdNodeDev) * nn <= gap, "uh_projmatch_set_frame_dev: %zu nodes exceed the device frame's node block", nn);
+        hipStream_t st = h->ctx->stream;
+        if (h->frame_word) {
+            if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(h->h_frame.host<char>()), h->frame_word, st, "uh_projmatch_set_frame_dev"))) return rc;
+            h->frame_word = 0;
+        }
+        if ((rc = h->h_frame.reserve(span + 64))) return rc;
+        char* hi = h->h_frame.host<char>() + 64;   // (the first 64 bytes hold the completion word)
+        if (n) {
+            std::memcpy(hi, h->kd.nodes.data(), sizeof(KdNodeDev) * nn);
+            float* lr = reinterpret_cast<float*>(hi + gap);   // the leaf records, in leaf order
+            for (int i = 0; i < n; i++) {
+                const uint32_t id = h->kd.leaf_idx[i], io = (id << 4) | (uint32_t)oct[id];
+                lr[4 * i] = xy[2 * (size_t)id]; lr[4 * i + 1] = xy[2 * (size_t)id + 1];
+                std::memcpy(lr + 4 * i + 2, &io, 4); lr[4 * i + 3] = 0.f;
+            }
+            std::atomic_thread_fence(std::memory_order_release);
+            // (only what the tree occupies of the node block travels: two copies when the gap between them is larger than the nodes)
+            const size_t nbytes = (sizeof(KdNodeDev) * nn + 15) & ~(size_t)15;
+            if ((rc = uh::copy16(h->ctx, reinterpret_cast<char*>(fr->nodes()), h->h_frame.dev<char>() + 64, nbytes))) return rc;
+            if ((rc = uh::copy16(h->ctx, reinterpret_cast<char*>(fr->leaf()), h->h_frame.dev<char>() + 64 + gap, 16 * (size_t)n))) return rc;
+            h->frame_word = ++h->seq;
+            if ((rc = uh::post_host_word(h->ctx, h->h_frame.dev<unsigned long long>(), h->frame_word))) return rc;
+        }
+        PmFrame& d = h->fr;
+        d.kp_desc = reinterpret_cast<const uint64_t*>(fr->desc());
+        d.nodes = reinterpret_cast<const KdNodeDev*>(fr->nodes()); d.leaf_rec = fr->leaf(); d.scale = h->d_scale.as<float>();
+        for (int i = 0; i < 4; i++) d.box[i] = h->kd.root_box[i];
+        d.n_levels = f->n_levels; d.n_kpts = n;
+        d.fx = f->fx; d.fy = f->fy; d.cx = f->cx; d.cy = f->cy;
+        d.min_x = (float)f->min_x; d.min_y = (float)f->min_y; d.max_x = (float)f->max_x; d.max_y = (float)f->max_y;
+        d.log_scale = f->n_levels > 1 ? std::log(f->scale_factors[1]) : 1.f;
+        h->n_kpts = n; h->n_levels = f->n_levels;
+        h->n_nodes = (int)nn; h->max_depth = h->kd.max_depth; h->dev = fr;
+        h->have_frame = true;
+        return UH_OK;
+    }
     const uh_kd::Meta* m = nullptr;
     if ((rc = uh::dev_frame_wait(fr, &m, "uh_projmatch_set_frame_dev"))) return rc;   // (the build runs behind the extractor's completion word: normally done)
     UH_REQUIRE(m->max_depth <= kMaxDepth, "uh_projmatch_set_frame_dev: kd-tree depth %d exceeds the walk stack (%d levels)", m->max_depth, kMaxDepth);

@@ -74,6 +74,7 @@ def _declare(L, sig):
     sig("uh_undistort_points_host", I, C.POINTER(Camera), VP, I, VP)
     sig("uh_dev_frame_create", I, VP, C.POINTER(VP))
     sig("uh_dev_frame_destroy", None, VP)
+    sig("uh_dev_frame_set_tree_builder", I, VP, C.c_int32)
     sig("uh_orb_extract_frame_dev", I, VP, VP, I, I, SZ, I, VP, VP, VP, I, C.POINTER(I), VP)
     sig("uh_dev_frame_tree", I, VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), VP, VP, VP, VP, VP, C.POINTER(C.c_int32))
 
@@ -88,6 +89,12 @@ class DeviceFrame:
         self.ctx = ctx
         self._h = VP()
         check(lib().uh_dev_frame_create(ctx.handle, C.byref(self._h)))
+
+    def setTreeBuilder(self, on_host: bool):
+        """Who builds the kd-tree: the build launches behind the extraction (False, default) or the host core inside
+        ProjectionMatcher.setFrameDev(..., und_kpts=...) (True: no build launch; the descriptors stay on the device either way)."""
+        check(lib().uh_dev_frame_set_tree_builder(self._h, 1 if on_host else 0))
+        return self
 
     def tree(self):
         """The kd-tree of the latest extraction, copied out (waits for the build launch): dict(nodes, leaf_idx, leaf_xy, leaf_octave, root_box, depth)."""

@@ -101,10 +101,14 @@ class ProjectionMatcher:
         check(lib().uh_projmatch_set_frame(self._h, C.byref(f)))
         self.n_kpts = len(k)
 
-    def setFrameDev(self, frame, scale_factors, fx, fy, cx, cy, min_xy=(0, 0), max_xy=(INT_MAX, INT_MAX)):
-        """Adopt the frame ORBextractor.extractFrameDev left on the device (no keypoints / descriptors cross the host link)."""
+    def setFrameDev(self, frame, scale_factors, fx, fy, cx, cy, min_xy=(0, 0), max_xy=(INT_MAX, INT_MAX), und_kpts=None):
+        """Adopt the frame ORBextractor.extractFrameDev left on the device (no keypoints / descriptors cross the host link).
+        und_kpts: the undistorted keypoints (KEYPOINT_DTYPE) — needed when the frame's tree is built by the host core
+        (DeviceFrame.setTreeBuilder(True)), ignored otherwise."""
         s = np.ascontiguousarray(scale_factors, np.float32)
-        f = _ProjFrame(None, 0, None, np_ptr(s), len(s), fx, fy, cx, cy, int(min_xy[0]), int(min_xy[1]), int(max_xy[0]), int(max_xy[1]))
+        k = np.ascontiguousarray(und_kpts) if und_kpts is not None else None
+        f = _ProjFrame(np_ptr(k) if k is not None and len(k) else None, len(k) if k is not None else 0, None, np_ptr(s), len(s), fx, fy, cx, cy,
+                       int(min_xy[0]), int(min_xy[1]), int(max_xy[0]), int(max_xy[1]))
         check(lib().uh_projmatch_set_frame_dev(self._h, frame._h, C.byref(f)))
         self._keep = frame
 
