@@ -77,22 +77,23 @@ public:
         order_.resize(n);
         px_.resize(n); py_.resize(n);
         tmp_l_.resize(n + 1); tmp_r_.resize(n + 1);
-        for (int i = 0; i < n; i++) { order_[i] = (uint32_t)i; px_[i] = xy[2 * (size_t)i]; py_[i] = xy[2 * (size_t)i + 1]; }
+        // (the same loop finds the exponent spread of the non-zero coordinates — see sample_moments; branch-free: a zero counts as neither
+        // bound, a non-finite value shows as exponent 255, a denormal as exponent 0)
+        uint32_t emin = 255, emax = 0;
+        for (int i = 0; i < n; i++) {
+            order_[i] = (uint32_t)i;
+            const float x = xy[2 * (size_t)i], y = xy[2 * (size_t)i + 1];
+            px_[i] = x; py_[i] = y;
+            uint32_t bx, by;
+            std::memcpy(&bx, &x, 4); std::memcpy(&by, &y, 4);
+            const uint32_t ex = (bx >> 23) & 0xffu, ey = (by >> 23) & 0xffu;
+            const bool zx = (bx & 0x7fffffffu) == 0, zy = (by & 0x7fffffffu) == 0;
+            emin = std::min(emin, std::min(zx ? 255u : ex, zy ? 255u : ey));
+            emax = std::max(emax, std::max(zx ? 0u : ex, zy ? 0u : ey));
+        }
         max_depth = 0;
         if (n == 0) return;
-        {   // exponent spread of the non-zero coordinates (see sample_moments); non-finite values keep the ordered chains
-            int emin = 1 << 30, emax = -(1 << 30);
-            bool fin = true;
-            for (int i = 0; i < 2 * n; i++) {
-                uint32_t bits;
-                std::memcpy(&bits, &xy[i], 4);
-                const int ex = (int)((bits >> 23) & 0xffu);
-                if (ex == 0xff) fin = false;
-                if ((bits & 0x7fffffffu) == 0) continue;
-                emin = std::min(emin, ex); emax = std::max(emax, ex);
-            }
-            exact_sums_ = fin && emin >= 1 /* no denormals */ && emax - emin <= 10;
-        }
+        exact_sums_ = emax != 255 /* finite */ && emin >= 1 /* no denormals */ && emax - emin <= 10;   // (a cloud of zeros only: the unsigned difference wraps and the ordered chains stay — equally right)
         Box root;
         bounds(0, n, root);
         nodes.reserve(2 * (size_t)n + 2);
@@ -131,7 +132,10 @@ private:
         double s1[2] = {0, 0}, s2[2] = {0, 0};
         int step = 1, cnt = 0;
         if (e - b >= 200) step = (e - b) / 100;
-        if (exact_sums_) {
+        if (exact_sums_ && avx512_ && step == 1) {
+            cnt = e - b;
+            moments_avx512(px_.data() + b, py_.data() + b, cnt, s1, s2);
+        } else if (exact_sums_) {
             double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
             cnt = (e - b + step - 1) / step;
             const float* qx = px_.data() + b; const float* qy = py_.data() + b;
@@ -158,6 +162,25 @@ private:
             mean[d] = s1[d] * inv;
             var[d] = s2[d] * inv - mean[d] * mean[d];
         }
+    }
+
+    // exact sums (see above) of cnt contiguous samples, eight doubles per accumulator: fl(x), fl(x * x) in float as picoflann squares it
+    __attribute__((target("avx512f,avx512vl"))) static void moments_avx512(const float* qx, const float* qy, int cnt, double s1[2], double s2[2]) {
+        __m512d a1 = _mm512_setzero_pd(), a2 = a1, c1 = a1, c2 = a1;
+        int k = 0;
+        for (; k + 8 <= cnt; k += 8) {
+            const __m256 x = _mm256_loadu_ps(qx + k), y = _mm256_loadu_ps(qy + k);
+            a1 = _mm512_add_pd(a1, _mm512_cvtps_pd(x)); a2 = _mm512_add_pd(a2, _mm512_cvtps_pd(_mm256_mul_ps(x, x)));
+            c1 = _mm512_add_pd(c1, _mm512_cvtps_pd(y)); c2 = _mm512_add_pd(c2, _mm512_cvtps_pd(_mm256_mul_ps(y, y)));
+        }
+        if (k < cnt) {
+            const __mmask8 m = (__mmask8)((1u << (cnt - k)) - 1u);
+            const __m256 x = _mm256_maskz_loadu_ps(m, qx + k), y = _mm256_maskz_loadu_ps(m, qy + k);   // (zeros add nothing)
+            a1 = _mm512_add_pd(a1, _mm512_cvtps_pd(x)); a2 = _mm512_add_pd(a2, _mm512_cvtps_pd(_mm256_mul_ps(x, x)));
+            c1 = _mm512_add_pd(c1, _mm512_cvtps_pd(y)); c2 = _mm512_add_pd(c2, _mm512_cvtps_pd(_mm256_mul_ps(y, y)));
+        }
+        s1[0] = _mm512_reduce_add_pd(a1); s2[0] = _mm512_reduce_add_pd(a2);
+        s1[1] = _mm512_reduce_add_pd(c1); s2[1] = _mm512_reduce_add_pd(c2);
     }
 
     void swap_items(int i, int j) {
@@ -243,10 +266,28 @@ private:
         else if (lim2 < count / 2) at = lim2;
         if (lim1 == count || lim2 == 0) at = count / 2;
         if (at < kLeafMax || count - at < kLeafMax) {
-            // std::sort exactly where the reference uses it (same libstdc++ => same permutation of equal keys)
-            const float* xy = xy_;
-            std::sort(order_.begin() + b, order_.begin() + e, [xy, dim](const uint32_t& p, const uint32_t& q) { return xy[2 * (size_t)p + dim] < xy[2 * (size_t)q + dim]; });
-            for (int i = b; i < e; i++) { px_[i] = xy[2 * (size_t)order_[i]]; py_[i] = xy[2 * (size_t)order_[i] + 1]; }
+            // std::sort exactly where the reference uses it (same libstdc++ => same permutation of equal keys).  Up to 16 elements — most of
+            // the nodes that come here hold 11..19 points — libstdc++'s std::sort IS its insertion sort (introsort's loop does nothing below
+            // _S_threshold = 16, __final_insertion_sort is one guarded __insertion_sort): done here on the carried coordinates, no gathers
+            // through the permutation in the comparisons and none behind them.
+            if (count <= 16) {
+                float* key = coords(dim); float* oth = coords(dim ^ 1);
+                for (int i = b + 1; i < e; i++) {
+                    const float k = key[i], o = oth[i];
+                    const uint32_t id = order_[i];
+                    int j = i;
+                    if (k < key[b]) {   // (libstdc++ moves the whole prefix when the element is smaller than the first one: same result)
+                        for (; j > b; j--) { key[j] = key[j - 1]; oth[j] = oth[j - 1]; order_[j] = order_[j - 1]; }
+                    } else {
+                        for (; k < key[j - 1]; j--) { key[j] = key[j - 1]; oth[j] = oth[j - 1]; order_[j] = order_[j - 1]; }
+                    }
+                    key[j] = k; oth[j] = o; order_[j] = id;
+                }
+            } else {
+                const float* xy = xy_;
+                std::sort(order_.begin() + b, order_.begin() + e, [xy, dim](const uint32_t& p, const uint32_t& q) { return xy[2 * (size_t)p + dim] < xy[2 * (size_t)q + dim]; });
+                for (int i = b; i < e; i++) { px_[i] = xy[2 * (size_t)order_[i]]; py_[i] = xy[2 * (size_t)order_[i] + 1]; }
+            }
             at = count / 2;
             cut = coords(dim)[b + at];
         }
