@@ -755,7 +755,12 @@ struct uh_projmatch {
     // pinned, device-visible staging: the frame block (set_frame), the points of a match call, its results + completion word.
     // Everything moves as 16-byte-wide launches on the context stream (uh::copy16 / publish16); the host never synchronises the stream.
     uh::MappedBuf h_frame, h_in, h_out;
-    unsigned long long seq = 0, frame_word = 0;   // completion words: of the last match call / of the last frame upload
+    unsigned long long seq = 0, frame_word = 0;   // completion words: of the last match call / of the last frame upload (posted only on demand, see upload_pending)
+    // The frame upload (a copy launch reading the pinned staging block) needs no completion word of its own: every match call that follows
+    // runs behind it on the same stream and the host waits for THAT call's word — which also proves the upload has been read.  Only two
+    // set_frame calls with no match in between post and wait for a word (round 6: the word launch sat between the upload and the first
+    // match of every frame, 4 us of dispatch on the tracker's critical path).
+    bool upload_pending = false;
     std::vector<float> xy;
     std::vector<int> oct;
     std::vector<uh_dmatch> mm;
@@ -780,6 +785,17 @@ int uh_projmatch_create(uh_ctx* ctx, uh_projmatch** out) {
 }
 
 void uh_projmatch_destroy(uh_projmatch* h) { delete h; }
+
+// before the pinned staging block of the frame upload is written again: make sure the previous upload has been read (see upload_pending)
+static int pm_staging_free(uh_projmatch* h, const char* what) {
+    if (!h->upload_pending) return UH_OK;
+    int rc;
+    h->frame_word = ++h->seq;
+    if ((rc = uh::post_host_word(h->ctx, h->h_frame.dev<unsigned long long>(), h->frame_word))) return rc;
+    if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(h->h_frame.host<char>()), h->frame_word, h->ctx->stream, what))) return rc;
+    h->upload_pending = false;
+    return UH_OK;
+}
 
 int uh_projmatch_set_frame(uh_projmatch* h, const uh_proj_frame* f) {
     UH_REQUIRE(h && f, "uh_projmatch_set_frame: NULL argument");
@@ -811,10 +827,7 @@ int uh_projmatch_set_frame(uh_projmatch* h, const uh_proj_frame* f) {
     {   // one pinned staging block, one 16-byte-wide copy launch, no synchronisation: the block is only reused by the NEXT set_frame,
         // which first makes sure this upload has landed (its completion word — long since posted unless two set_frame calls follow
         // each other with nothing in between)
-        if (h->frame_word) {
-            if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(h->h_frame.host<char>()), h->frame_word, st, "uh_projmatch_set_frame"))) return rc;
-            h->frame_word = 0;
-        }
+        if ((rc = pm_staging_free(h, "uh_projmatch_set_frame"))) return rc;
         if ((rc = h->h_frame.reserve(total + 64))) return rc;
         char* hi = h->h_frame.host<char>() + 64;   // (the first 64 bytes hold the completion word)
         if (n) {
@@ -830,8 +843,7 @@ int uh_projmatch_set_frame(uh_projmatch* h, const uh_proj_frame* f) {
         std::memcpy(hi + o_scale, f->scale_factors, 4 * (size_t)f->n_levels);
         std::atomic_thread_fence(std::memory_order_release);
         if ((rc = uh::copy16(h->ctx, base, h->h_frame.dev<char>() + 64, total))) return rc;
-        h->frame_word = ++h->seq;
-        if ((rc = uh::post_host_word(h->ctx, h->h_frame.dev<unsigned long long>(), h->frame_word))) return rc;
+        h->upload_pending = true;
     }
     if (getenv("UH_PM_TIMING")) fprintf(stderr, "set_frame total: %.1f us (bytes %zu)\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), total);
     PmFrame& d = h->fr;
@@ -880,10 +892,7 @@ int uh_projmatch_set_frame_dev(uh_projmatch* h, uh_dev_frame* fr, const uh_proj_
         const size_t nn = h->kd.nodes.size(), gap = fr->o_leaf - fr->o_nodes, span = gap + 16 * (size_t)n;
         UH_REQUIRE(sizeof(KdNodeDev) * nn <= gap, "uh_projmatch_set_frame_dev: %zu nodes exceed the device frame's node block", nn);
         hipStream_t st = h->ctx->stream;
-        if (h->frame_word) {
-            if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(h->h_frame.host<char>()), h->frame_word, st, "uh_projmatch_set_frame_dev"))) return rc;
-            h->frame_word = 0;
-        }
+        if ((rc = pm_staging_free(h, "uh_projmatch_set_frame_dev"))) return rc;
         if ((rc = h->h_frame.reserve(span + 64))) return rc;
         char* hi = h->h_frame.host<char>() + 64;   // (the first 64 bytes hold the completion word)
         if (n) {
@@ -899,8 +908,7 @@ int uh_projmatch_set_frame_dev(uh_projmatch* h, uh_dev_frame* fr, const uh_proj_
             const size_t nbytes = (sizeof(KdNodeDev) * nn + 15) & ~(size_t)15;
             if ((rc = uh::copy16(h->ctx, reinterpret_cast<char*>(fr->nodes()), h->h_frame.dev<char>() + 64, nbytes))) return rc;
             if ((rc = uh::copy16(h->ctx, reinterpret_cast<char*>(fr->leaf()), h->h_frame.dev<char>() + 64 + gap, 16 * (size_t)n))) return rc;
-            h->frame_word = ++h->seq;
-            if ((rc = uh::post_host_word(h->ctx, h->h_frame.dev<unsigned long long>(), h->frame_word))) return rc;
+            h->upload_pending = true;
         }
         PmFrame& d = h->fr;
         d.kp_desc = reinterpret_cast<const uint64_t*>(fr->desc());
@@ -1054,6 +1062,7 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
         h->ovf_zeroed = false;   //  a launch that died may have left its ticket / overflow word behind: the next call clears the block again
         return rc;
     }
+    h->upload_pending = false;   // (this call ran behind the frame upload on the same stream)
     if (pm_clk) {
         long long c[8];
         UH_HIP_CHECK(hipMemcpy(c, base + 16, sizeof(c), hipMemcpyDeviceToHost));
