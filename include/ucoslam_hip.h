@@ -663,6 +663,38 @@ typedef struct uh_prev_points {
 int  uh_projmatch_match_prev(uh_projmatch* pm, const float* pose_f2g /* row-major 4x4 */, const uh_prev_points* points,
                              float min_desc_dist, float max_repj_dist, uh_dmatch* matches_out, int32_t cap,
                              int32_t* best_kp_out /* n or NULL */, float* best_dist_out /* n or NULL */);
+/* The tracker's pose estimation for one frame as ONE call: the search against the previous frame, PnPSolver::solvePnp, the decision
+ * (>= min_inliers inliers: refined pose + small disc, else predicted pose + wide radius), Map::matchFrameToMapPoints, the union of the first
+ * solve's inliers with the new matches under filter_ambiguous_query, the per-match look-ups and the second solvePnp (src/utils/system.cpp
+ * :5930-6460, :6559-6566, :6762-6881, :6897-6954 after preprocessing; pnpsolver.cpp:116-409) — exactly what
+ *     uh_projmatch_match_prev -> look-ups -> uh_pnp_solve -> uh_projmatch_match -> union, uh_filter_ambiguous, look-ups -> uh_pnp_solve
+ * return, bit for bit, with the look-ups and list handling done on the device between the launches and ONE wait at the end (seven launches on
+ * the context stream; csrc/track.hpp).  The look-ups: first solve — the candidate's own position, weight 1; second solve — the position and
+ * weight of row prev_map_row[i] of `map` when that is >= 0 (a previous-frame item that is also in the local map), else the candidate's own;
+ * keypoint = the frame's undistorted keypoint, inv_sigma = inv_sigma_levels[its octave].  Needs a device-resident frame
+ * (uh_orb_extract_frame_dev + uh_projmatch_set_frame_dev, either tree builder) of <= 4096 keypoints; pm and pnp on the same context. */
+typedef struct uh_track_args {
+    const float* pose0;                 /* predicted pose f2g, row-major 4x4 */
+    const float* intr4;                 /* fx fy cx cy */
+    const float* inv_sigma_levels;      /* n_levels: 1 / scaleFactor per octave (the solver's per-match inv_sigma) */
+    int32_t n_levels;
+    const uh_prev_points* prev;         /* candidates of the previous-frame search */
+    const int32_t* prev_map_row;        /* prev->n: row of the same map point in `map`, or -1; NULL = all -1 */
+    const uh_map_points* map;           /* candidates of the local-map search */
+    const float* map_weight;            /* map->n: the solver weight of each map point (0.5 for unstable ones); NULL = all 1 */
+    float prev_min_desc_dist, prev_max_repj_dist;   /* system.cpp:6559-6565: maxDescDistance * 1.5, projDistThr */
+    float map_min_desc_dist, map_radius_tracked, map_radius_lost;   /* :6762-6881: maxDescDistance * 2, 4 px, projDistThr */
+    int32_t min_inliers;                /* 30 */
+} uh_track_args;
+typedef struct uh_track_result {
+    uh_dmatch* matches_prev; uint8_t* bad_prev; int32_t cap_prev;    /* in: buffers (>= prev->n); out: the first search's matches and the first solve's outlier flags */
+    uh_dmatch* matches_map; int32_t cap_map;                          /* >= map->n: the second search's own matches */
+    uh_dmatch* matches_all; uint8_t* bad_all; int32_t cap_all;        /* >= prev->n + map->n: the union the second solve ran on, its outlier flags */
+    int32_t n_prev, n_map, n_all, tracked, inliers1, inliers2;
+    int32_t iters1[4], iters2[4];
+    float pose1[16], pose2[16];
+} uh_track_result;
+int  uh_track_pose(uh_projmatch* pm, uh_pnp* pnp, const uh_track_args* args, uh_track_result* result);
 /* test hook: the flattened kd-tree of the current frame (24-byte nodes {float divlow, divhigh; int32 left, right, leaf_begin;
  * int16 leaf_count, col}), the leaf index list, the root box {x.min, x.max, y.min, y.max} and the tree depth */
 int  uh_projmatch_debug_tree(uh_projmatch* pm, int32_t* n_nodes, const void** nodes24, const uint32_t** leaf_idx,

@@ -37,6 +37,7 @@ struct PnpArgs {
     const float* pose_in;    // 16
     const float* intr;       // fx fy cx cy
     int n;
+    const int* n_dev;        // NULL, or the match count in device memory (written by an earlier launch of the stream; n is then its upper bound)
     const float* p3d; const float* kp; const float* invsig; const float* weight;
     void* work;              // n x 32 bytes of scratch (only used when the matches do not fit LDS)
     float* pose_out;         // 16
@@ -217,7 +218,17 @@ __global__ __launch_bounds__(kPnpThreads) void pnp_solve_kernel(PnpArgs A) {
     __shared__ int s_ctl[4];                                        // mode, classify, drop_robust, ladder length
     __shared__ __attribute__((aligned(16))) double s_lad[2];        // ladder request: lambda and ni of its first candidate
     __shared__ __attribute__((aligned(16))) double s_cand[kLadderMax][20];   // per candidate: trial pose (12), step (6), factorisation ok (1)
-    const int tid = threadIdx.x, lane = tid & 63, n = A.n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    int n = A.n;
+    if (A.n_dev) {   // (uh_track_pose: the matches were chosen on the device)
+        const int nd = __builtin_amdgcn_readfirstlane(*A.n_dev);
+        n = nd < n ? nd : n;
+        if (n <= 0) {   // pnpsolver.cpp:149-150: without matches the pose comes back as it went in
+            if (tid < 16) A.pose_out[tid] = A.pose_in[tid];
+            if (tid < 5) A.result[tid] = 0;
+            return;
+        }
+    }
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave index as a scalar: the role split below is an s_cbranch
     if (A.clk && tid == 0) A.clk[0] = __builtin_readcyclecounter();
     const double fx = A.intr[0], fy = A.intr[1], cx = A.intr[2], cy = A.intr[3];
@@ -665,6 +676,23 @@ int launch(uh_pnp* p, PnpArgs& A) {
 }
 
 }  // namespace
+
+namespace uh {
+uh_ctx* pnp_ctx(uh_pnp* p) { return p->ctx; }
+// the solve behind uh_track_pose: everything resident, the match count decided by an earlier launch of the same stream
+int pnp_enqueue_dev(uh_pnp* p, const float* d_pose, const float* d_intr4, int n_cap, const int* d_n, const float* d_p3d, const float* d_kp, const float* d_inv_sigma,
+                    const float* d_weight, float* d_pose_out, unsigned char* d_bad_out, int* d_result5) {
+    UH_HIP_CHECK(hipSetDevice(p->ctx->device));
+    int rc;
+    if (n_cap > kPnpLdsMatches && (rc = p->d_work.reserve((size_t)n_cap * 32))) return rc;
+    PnpArgs A{};
+    A.pose_in = d_pose; A.intr = d_intr4; A.n = n_cap; A.n_dev = d_n; A.p3d = d_p3d; A.kp = d_kp; A.invsig = d_inv_sigma; A.weight = d_weight;
+    A.work = p->d_work.p;
+    A.pose_out = d_pose_out; A.bad_out = d_bad_out; A.result = d_result5; A.state_out = nullptr;
+    A.host_done = nullptr; A.done_word = 0;
+    return launch(p, A);
+}
+}  // namespace uh
 
 extern "C" {
 

@@ -328,6 +328,7 @@ struct PmPoints {
 };
 
 struct PmPose { float T[12]; float cc[3]; };
+struct PmDyn { PmPose ps; float radius; int skip; };   // a search whose pose / radius an earlier launch of the same stream decides (uh_track_pose); skip: nothing to do
 // The call's hand-over, done by the kernel itself (round 5; rounds 3-4: a copy launch in front and a publish launch behind, ~6 us of kernel
 // and a launch gap each): the candidates' arrays are read from the pinned staging block in place, the per-point results go to HBM with
 // write-through (agent-scope) stores, every workgroup takes a ticket behind its acknowledged stores, and the workgroup that draws the last
@@ -371,8 +372,9 @@ __device__ __forceinline__ double readlane_f64(double v, int lane_uniform) {   /
 // dependent LDS round trips of an iteration that has five.
 template <bool IN_LDS, bool PREV, bool LANE_STACK>
 __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoints mp, PmPose ps, float minDescDist, float maxRepjDist,
-                                                               int n_nodes, int levels, int* overflow, PmPublish pub) {
+                                                               int n_nodes, int levels, int* overflow, PmPublish pub, const PmDyn* __restrict__ dyn) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (dyn) { ps = dyn->ps; maxRepjDist = dyn->radius; }   // (uniform: scalar loads)
     const int lane = threadIdx.x, g = lane / kGroup, gl = lane % kGroup, gw = (lane & 63) / kGroup;   // gw: group within its wave
     const int nthr = (int)blockDim.x, gpw = nthr / kGroup;   // threads and groups of THIS launch's workgroups
     // measurement (UH_PM_CLK): shader-clock stamps of workgroup 0, thread 0 in the status block behind the overflow word
@@ -751,10 +753,17 @@ struct uh_projmatch {
     int n_kpts = 0, n_levels = 0;
     PmFrame fr{};
     uh::DevBuf d_frame;    // kp_desc | nodes | leaf records | scale
-    uh::DevBuf d_points;   // pos3d | normal | min | max | desc | best_kp | best_dist | visible | overflow
     // pinned, device-visible staging: the frame block (set_frame), the points of a match call, its results + completion word.
     // Everything moves as 16-byte-wide launches on the context stream (uh::copy16 / publish16); the host never synchronises the stream.
-    uh::MappedBuf h_frame, h_in, h_out;
+    uh::MappedBuf h_frame;
+    // the buffers of a match call: slot 0 serves uh_projmatch_match / _match_prev; uh_track_pose (track.hpp) enqueues its two searches
+    // back to back without waiting in between and gives the second one slot 1
+    struct Slot {
+        uh::DevBuf d_points;          // status block | best_kp | best_dist | visible
+        uh::MappedBuf h_in, h_out;    // the candidates' records (read by the kernel in place); results + completion word
+        bool ovf_zeroed = false;
+        unsigned ovf_gen = 0;
+    } slot[2];
     unsigned long long seq = 0, frame_word = 0;   // completion words: of the last match call / of the last frame upload (posted only on demand, see upload_pending)
     // The frame upload (a copy launch reading the pinned staging block) needs no completion word of its own: every match call that follows
     // runs behind it on the same stream and the host waits for THAT call's word — which also proves the upload has been read.  Only two
@@ -770,8 +779,8 @@ struct uh_projmatch {
     uh::DevBuf d_scale;                 // set_frame_dev: the scale factors (uploaded when they change)
     std::vector<float> scale_host;
     bool attr_set = false;
-    bool ovf_zeroed = false;
-    unsigned ovf_gen = 0;
+    struct uh_track_state* track = nullptr;   // uh_track_pose's buffers (track.hpp), created on first use
+    ~uh_projmatch();
 };
 
 extern "C" {
@@ -969,52 +978,63 @@ int uh_projmatch_debug_tree(uh_projmatch* h, int32_t* n_nodes, const void** node
 
 namespace {
 
-// one implementation behind uh_projmatch_match (octave == nullptr) and uh_projmatch_match_prev (normal/min/max == nullptr)
-int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* ids, const float* pos3d, const float* normal,
-                 const float* mn_dist, const float* mx_dist, const uint8_t* desc, const int32_t* octave, float min_desc_dist,
-                 float max_repj_dist, uh_dmatch* matches_out, int32_t cap, int32_t* best_kp_out, float* best_dist_out, uint8_t* visible_out) {
+// What a search leaves behind until its results are collected: where they lie (HBM, pinned twin) and the call's completion word.
+struct PmPending {
+    int n = 0, slot = 0;
+    bool prev = false;
+    unsigned long long word = 0;
+    const int* d_best_kp = nullptr; const float* d_best_dist = nullptr;   // HBM (for launches behind this one on the same stream)
+    const float* d_rec = nullptr;                                        // the candidates' 64-byte records (pinned, device address)
+    size_t o_bk = 0, o_bd = 0, o_vis = 0;
+};
+
+// Stage the candidates and enqueue the search (no waiting).  octave == nullptr: Map::matchFrameToMapPoints; normal / min / max == nullptr: the
+// previous-frame search.  dyn != nullptr: pose and radius are read from device memory at launch time (written by an earlier launch of this stream).
+int match_enqueue(uh_projmatch* h, int slot, const float* pose_f2g, const PmDyn* dyn, int n, const float* pos3d, const float* normal,
+                  const float* mn_dist, const float* mx_dist, const uint8_t* desc, const int32_t* octave, float min_desc_dist, float max_repj_dist, PmPending* pend) {
     const bool prev = octave != nullptr;
-    struct { int32_t n; const uint32_t* ids; const float* pos3d; const float* normal; const float* min_dist; const float* max_dist; const uint8_t* desc; }
-        mpv{n, ids, pos3d, normal, mn_dist, mx_dist, desc}, *mp = &mpv;
+    uh_projmatch::Slot& S = h->slot[slot];
     UH_HIP_CHECK(hipSetDevice(h->ctx->device));
     hipStream_t st = h->ctx->stream;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t o_pos = 256 /* [0, 256): the walk-overflow status word, at a fixed place */, o_nrm = al(o_pos + 12 * (size_t)n), o_min = al(o_nrm + 12 * (size_t)n), o_max = al(o_min + 4 * (size_t)n);
-    const size_t o_desc = al(o_max + 4 * (size_t)n), o_bk = al(o_desc + 32 * (size_t)n), o_bd = o_bk + 4 * (size_t)n, o_vis = o_bd + 4 * (size_t)n;
+    const size_t o_pos = 256 /* [0, 256): the walk-overflow status word, at a fixed place */;
+    const size_t o_bk = 256, o_bd = o_bk + 4 * (size_t)n, o_vis = o_bd + 4 * (size_t)n;
     const size_t o_ovf = 0, o_end = al(o_vis + (size_t)n), total = o_end + 256;
-    int rc = h->d_points.reserve(total);
+    int rc = S.d_points.reserve(total);
     if (rc) return rc;
     const size_t out_bytes = o_end - o_bk;
-    if ((rc = h->h_out.reserve(out_bytes + 64))) return rc;
-    char* base = h->d_points.as<char>();
-    if (!h->ovf_zeroed || h->ovf_gen != h->d_points.gen) {   // the walk-overflow word: zero once per allocation, publish16 clears it after every call
+    if ((rc = S.h_out.reserve(out_bytes + 64))) return rc;
+    char* base = S.d_points.as<char>();
+    if (!S.ovf_zeroed || S.ovf_gen != S.d_points.gen) {   // the walk-overflow word: zero once per allocation, the kernel's last workgroup clears it after every call
         UH_HIP_CHECK(hipMemsetAsync(base, 0, 256, st));
-        h->ovf_zeroed = true; h->ovf_gen = h->d_points.gen;
+        S.ovf_zeroed = true; S.ovf_gen = S.d_points.gen;
     }
     static const bool pm_clk = getenv("UH_PM_CLK") != nullptr;
     if (pm_clk) { const unsigned magic[2] = {0u, 0x434c4bu}; UH_HIP_CHECK(hipMemcpyAsync(base, magic, 8, hipMemcpyHostToDevice, st)); }
+    static const bool pm_timing = getenv("UH_PM_TIMING") != nullptr;
     const auto t_pack0 = std::chrono::steady_clock::now();
     {   // one pinned staging block (the previous call's launches are complete: its results were awaited): the candidates as 64-byte records
-        if ((rc = h->h_in.reserve(o_pos + 64 * (size_t)n + 64))) return rc;
-        char* hi = h->h_in.host<char>();
+        if ((rc = S.h_in.reserve(o_pos + 64 * (size_t)n + 64))) return rc;
+        char* hi = S.h_in.host<char>();
         float* rec = reinterpret_cast<float*>(hi + o_pos);
         for (int i = 0; i < n; i++, rec += 16) {
-            rec[0] = mp->pos3d[3 * i]; rec[1] = mp->pos3d[3 * i + 1]; rec[2] = mp->pos3d[3 * i + 2];
+            rec[0] = pos3d[3 * i]; rec[1] = pos3d[3 * i + 1]; rec[2] = pos3d[3 * i + 2];
             if (prev) { std::memcpy(rec + 3, octave + i, 4); rec[4] = rec[5] = rec[6] = rec[7] = 0.f; }
-            else { rec[3] = mp->normal[3 * i]; rec[4] = mp->normal[3 * i + 1]; rec[5] = mp->normal[3 * i + 2]; rec[6] = mp->min_dist[i]; rec[7] = mp->max_dist[i]; }
-            std::memcpy(rec + 8, mp->desc + 32 * (size_t)i, 32);
+            else { rec[3] = normal[3 * i]; rec[4] = normal[3 * i + 1]; rec[5] = normal[3 * i + 2]; rec[6] = mn_dist[i]; rec[7] = mx_dist[i]; }
+            std::memcpy(rec + 8, desc + 32 * (size_t)i, 32);
         }
         std::atomic_thread_fence(std::memory_order_release);
     }
-    if (getenv("UH_PM_TIMING")) fprintf(stderr, "projmatch%s: packing %d records %.1f us\n", prev ? "_prev" : "", n, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_pack0).count());
+    if (pm_timing) fprintf(stderr, "projmatch%s: packing %d records %.1f us\n", prev ? "_prev" : "", n, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_pack0).count());
     PmPoints P;
     P.n = n;
-    P.rec = reinterpret_cast<const uint4*>(h->h_in.dev<char>() + o_pos);   // (read by the kernel where they lie: every wave fetches its own candidate once)
+    P.rec = reinterpret_cast<const uint4*>(S.h_in.dev<char>() + o_pos);   // (read by the kernel where they lie: every wave fetches its own candidate once)
     P.best_kp = (int*)(base + o_bk); P.best_dist = (float*)(base + o_bd); P.visible = (unsigned char*)(base + o_vis);
-    PmPose ps;
-    const float* T = pose_f2g;
-    for (int i = 0; i < 12; i++) ps.T[i] = T[i];
-    {   // camCenter = pose_f2g.inv() * (0,0,0), se3transform.h:89-113
+    PmPose ps{};
+    if (pose_f2g) {
+        const float* T = pose_f2g;
+        for (int i = 0; i < 12; i++) ps.T[i] = T[i];
+        // camCenter = pose_f2g.inv() * (0,0,0), se3transform.h:89-113
         const float m0 = T[0], m1 = T[4], m2 = T[8], m4 = T[1], m5 = T[5], m6 = T[9], m8 = T[2], m9 = T[6], m10 = T[10];
         const float m3 = -(T[3] * m0 + T[7] * m1 + T[11] * m2), m7 = -(T[3] * m4 + T[7] * m5 + T[11] * m6), m11 = -(T[3] * m8 + T[7] * m9 + T[11] * m10);
         ps.cc[0] = m0 * 0.f + m1 * 0.f + m2 * 0.f + m3;
@@ -1030,7 +1050,8 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
         const int gpw = std::min(kGroupsMax, std::max(4, uh_div_up(n, ncu)));
         const size_t stack_bytes = (size_t)levels * gpw * 24 + (size_t)kCandCap * gpw * 8 + 64;
         const size_t tree_bytes = (((size_t)n_nodes * sizeof(KdNodeDev) + 15) & ~(size_t)15) + 16 * (size_t)h->n_kpts;
-        const bool in_lds = tree_bytes + stack_bytes <= kLdsBudget && !getenv("UH_PROJMATCH_NO_LDS");   // env: test knob for the big-frame path
+        static const bool no_lds = getenv("UH_PROJMATCH_NO_LDS") != nullptr;   // env: test knob for the big-frame path
+        const bool in_lds = tree_bytes + stack_bytes <= kLdsBudget && !no_lds;
         const size_t lds = stack_bytes + (in_lds ? tree_bytes : 0);
         if (!h->attr_set) {
 #define UH_PM_ATTR(A, B, C) UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(projmatch_kernel<A, B, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget))
@@ -1042,10 +1063,10 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
         const dim3 grid(std::min(uh_div_up(n, gpw), kPmMaxBlocks));
         int* d_ovf = (int*)(base + o_ovf);
         const unsigned long long word = ++h->seq;
-        const PmPublish pub{reinterpret_cast<unsigned*>(base + 128), reinterpret_cast<const unsigned long long*>(base + o_bk), reinterpret_cast<unsigned long long*>(h->h_out.dev<char>() + 64),
-                            (unsigned)(out_bytes / 8), h->h_out.dev<unsigned long long>(), word};
+        const PmPublish pub{reinterpret_cast<unsigned*>(base + 128), reinterpret_cast<const unsigned long long*>(base + o_bk), reinterpret_cast<unsigned long long*>(S.h_out.dev<char>() + 64),
+                            (unsigned)(out_bytes / 8), S.h_out.dev<unsigned long long>(), word};
         const bool lane_stack = levels <= kGroup;
-#define UH_PM_LAUNCH(A, B, C) UH_LAUNCH(h->ctx, (projmatch_kernel<A, B, C>), grid, dim3(gpw * kGroup), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf, pub)
+#define UH_PM_LAUNCH(A, B, C) UH_LAUNCH(h->ctx, (projmatch_kernel<A, B, C>), grid, dim3(gpw * kGroup), lds, h->fr, P, ps, min_desc_dist, max_repj_dist, n_nodes, levels, d_ovf, pub, dyn)
         if (lane_stack) {
             if (in_lds && !prev) UH_PM_LAUNCH(true, false, true); else if (!prev) UH_PM_LAUNCH(false, false, true);
             else if (in_lds) UH_PM_LAUNCH(true, true, true); else UH_PM_LAUNCH(false, true, true);
@@ -1054,35 +1075,61 @@ int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* 
             else if (in_lds) UH_PM_LAUNCH(true, true, false); else UH_PM_LAUNCH(false, true, false);
         }
 #undef UH_PM_LAUNCH
+        pend->word = word;
     }
     UH_HIP_CHECK(hipGetLastError());
+    pend->n = n; pend->slot = slot; pend->prev = prev;
+    pend->d_best_kp = P.best_kp; pend->d_best_dist = P.best_dist; pend->d_rec = reinterpret_cast<const float*>(P.rec);
+    pend->o_bk = o_bk; pend->o_bd = o_bd; pend->o_vis = o_vis;
+    return UH_OK;
+}
+
+// Wait for a search and collect its per-candidate results (pinned block -> the caller's arrays, any may be NULL).
+int match_collect(uh_projmatch* h, const PmPending& pd, const char* what, const int** bk_out, const float** bd_out, int32_t* best_kp_out, float* best_dist_out, uint8_t* visible_out) {
+    uh_projmatch::Slot& S = h->slot[pd.slot];
+    int rc;
     // results: the kernel's last workgroup copies [best_kp | best_dist | visible] and the overflow flag into pinned memory and posts the completion word
-    const unsigned long long word = h->seq;
-    if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(h->h_out.host<char>()), word, st, "uh_projmatch_match"))) {
-        h->ovf_zeroed = false;   //  a launch that died may have left its ticket / overflow word behind: the next call clears the block again
+    if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(S.h_out.host<char>()), pd.word, h->ctx->stream, what))) {
+        S.ovf_zeroed = false;   //  a launch that died may have left its ticket / overflow word behind: the next call clears the block again
         return rc;
     }
     h->upload_pending = false;   // (this call ran behind the frame upload on the same stream)
+    static const bool pm_clk = getenv("UH_PM_CLK") != nullptr;
     if (pm_clk) {
         long long c[8];
-        UH_HIP_CHECK(hipMemcpy(c, base + 16, sizeof(c), hipMemcpyDeviceToHost));
+        UH_HIP_CHECK(hipMemcpy(c, S.d_points.as<char>() + 16, sizeof(c), hipMemcpyDeviceToHost));
         fprintf(stderr, "projmatch%s workgroup 0 cycles: stage %lld  visibility+walk %lld (group 0: %lld loop iterations, %lld leaves)  final drain (%lld hits) %lld  tail %lld  total %lld\n",
-                prev ? "_prev" : "", c[1] - c[0], c[2] - c[1], c[6], c[7], c[5], c[3] - c[2], c[4] - c[3], c[4] - c[0]);
+                pd.prev ? "_prev" : "", c[1] - c[0], c[2] - c[1], c[6], c[7], c[5], c[3] - c[2], c[4] - c[3], c[4] - c[0]);
     }
-    const char* ho = h->h_out.host<char>() + 64;
+    const char* ho = S.h_out.host<char>() + 64;
+    const int n = pd.n;
     const int* bk = (const int*)ho;
-    const float* bd = (const float*)(ho + (o_bd - o_bk));
-    const unsigned char* vis = (const unsigned char*)(ho + (o_vis - o_bk));
-    const int ovf = *reinterpret_cast<const int*>(h->h_out.host<char>() + 8);
-    UH_REQUIRE(!ovf, "uh_projmatch_match: kd-tree walk stack overflow");
+    const float* bd = (const float*)(ho + (pd.o_bd - pd.o_bk));
+    const unsigned char* vis = (const unsigned char*)(ho + (pd.o_vis - pd.o_bk));
+    const int ovf = *reinterpret_cast<const int*>(S.h_out.host<char>() + 8);
+    UH_REQUIRE(!ovf, "%s: kd-tree walk stack overflow", what);
     if (best_kp_out) std::memcpy(best_kp_out, bk, 4 * (size_t)n);
     if (best_dist_out) std::memcpy(best_dist_out, bd, 4 * (size_t)n);
     if (visible_out) std::memcpy(visible_out, vis, (size_t)n);
+    if (bk_out) *bk_out = bk;
+    if (bd_out) *bd_out = bd;
+    return UH_OK;
+}
+
+// one implementation behind uh_projmatch_match (octave == nullptr) and uh_projmatch_match_prev (normal/min/max == nullptr)
+int match_common(uh_projmatch* h, const float* pose_f2g, int n, const uint32_t* ids, const float* pos3d, const float* normal,
+                 const float* mn_dist, const float* mx_dist, const uint8_t* desc, const int32_t* octave, float min_desc_dist,
+                 float max_repj_dist, uh_dmatch* matches_out, int32_t cap, int32_t* best_kp_out, float* best_dist_out, uint8_t* visible_out) {
+    PmPending pd;
+    int rc = match_enqueue(h, 0, pose_f2g, nullptr, n, pos3d, normal, mn_dist, mx_dist, desc, octave, min_desc_dist, max_repj_dist, &pd);
+    if (rc) return rc;
+    const int* bk = nullptr; const float* bd = nullptr;
+    if ((rc = match_collect(h, pd, "uh_projmatch_match", &bk, &bd, best_kp_out, best_dist_out, visible_out))) return rc;
     std::vector<uh_dmatch>& mm = h->mm;
     mm.clear();
     mm.reserve(n);
     for (int i = 0; i < n; i++)
-        if (bk[i] >= 0) mm.push_back(uh_dmatch{bk[i], (int32_t)mp->ids[i], -1, bd[i]});
+        if (bk[i] >= 0) mm.push_back(uh_dmatch{bk[i], (int32_t)ids[i], -1, bd[i]});
     int k = mm.empty() ? 0 : uh_filter_ambiguous(mm.data(), (int)mm.size(), 0);
     if (k < 0) return k;
     UH_REQUIRE(k <= cap, "uh_projmatch_match: %d matches do not fit the output buffer (cap %d)", k, (int)cap);
@@ -1121,3 +1168,5 @@ int uh_projmatch_match_prev(uh_projmatch* h, const float* pose_f2g, const uh_pre
 }
 
 }  // extern "C"
+
+#include "track.hpp"

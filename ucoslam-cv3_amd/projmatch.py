@@ -32,7 +32,21 @@ class _PrevPoints(C.Structure):
     _fields_ = [("n", C.c_int32), ("ids", VP), ("pos3d", VP), ("octave", VP), ("desc", VP)]
 
 
+class _TrackArgs(C.Structure):
+    _fields_ = [("pose0", VP), ("intr4", VP), ("inv_sigma_levels", VP), ("n_levels", C.c_int32), ("prev", C.POINTER(_PrevPoints)), ("prev_map_row", VP),
+                ("map", C.POINTER(_MapPoints)), ("map_weight", VP), ("prev_min_desc_dist", C.c_float), ("prev_max_repj_dist", C.c_float),
+                ("map_min_desc_dist", C.c_float), ("map_radius_tracked", C.c_float), ("map_radius_lost", C.c_float), ("min_inliers", C.c_int32)]
+
+
+class _TrackResult(C.Structure):
+    _fields_ = [("matches_prev", VP), ("bad_prev", VP), ("cap_prev", C.c_int32), ("matches_map", VP), ("cap_map", C.c_int32),
+                ("matches_all", VP), ("bad_all", VP), ("cap_all", C.c_int32),
+                ("n_prev", C.c_int32), ("n_map", C.c_int32), ("n_all", C.c_int32), ("tracked", C.c_int32), ("inliers1", C.c_int32), ("inliers2", C.c_int32),
+                ("iters1", C.c_int32 * 4), ("iters2", C.c_int32 * 4), ("pose1", C.c_float * 16), ("pose2", C.c_float * 16)]
+
+
 def _declare(L, sig):
+    sig("uh_track_pose", I, VP, VP, C.POINTER(_TrackArgs), C.POINTER(_TrackResult))
     sig("uh_projmatch_create", I, VP, C.POINTER(VP))
     sig("uh_projmatch_destroy", None, VP)
     sig("uh_projmatch_set_frame", I, VP, C.POINTER(_ProjFrame))
@@ -150,6 +164,38 @@ class ProjectionMatcher:
         if rc < 0:
             check(rc)
         return dict(matches=out[:rc].copy(), best_kp=best_kp[:n], best_dist=best_d[:n])
+
+    def trackPose(self, pnp, pose0, intr4, inv_sigma_levels, prev, mp, prev_map_row=None, map_weight=None, prev_min_desc_dist=75.0, prev_max_repj_dist=15.0,
+                  map_min_desc_dist=100.0, map_radius_tracked=4.0, map_radius_lost=15.0, min_inliers=30):
+        """uh_track_pose: the previous-frame search, solvePnp, the decision, the local-map search, the union and the second solvePnp of one
+        frame as ONE call (system.cpp:5930-6954).  prev: dict(ids, pos3d, octave, desc); mp: dict(ids, pos3d, normal, min_dist, max_dist, desc);
+        the frame is the device-resident one given to setFrameDev.  Returns dict(matches_prev, bad_prev, matches_map, matches_all, bad_all,
+        tracked, inliers1, inliers2, iters1, iters2, pose1, pose2)."""
+        pose = np.ascontiguousarray(pose0, np.float32).reshape(16)
+        intr = np.ascontiguousarray(intr4, np.float32).reshape(4)
+        isl = np.ascontiguousarray(inv_sigma_levels, np.float32)
+        pid = np.ascontiguousarray(prev["ids"], np.uint32)
+        n_p = len(pid)
+        pa = [np.ascontiguousarray(prev["pos3d"], np.float32).reshape(n_p, 3), np.ascontiguousarray(prev["octave"], np.int32), np.ascontiguousarray(prev["desc"], np.uint8).reshape(n_p, 32)]
+        pp = _PrevPoints(n_p, np_ptr(pid) if n_p else None, *[np_ptr(x) if n_p else None for x in pa])
+        mid = np.ascontiguousarray(mp["ids"], np.uint32)
+        n_m = len(mid)
+        ma = [np.ascontiguousarray(mp["pos3d"], np.float32).reshape(n_m, 3), np.ascontiguousarray(mp["normal"], np.float32).reshape(n_m, 3),
+              np.ascontiguousarray(mp["min_dist"], np.float32), np.ascontiguousarray(mp["max_dist"], np.float32), np.ascontiguousarray(mp["desc"], np.uint8).reshape(n_m, 32)]
+        mpp = _MapPoints(n_m, np_ptr(mid) if n_m else None, *[np_ptr(x) if n_m else None for x in ma])
+        row = np.ascontiguousarray(prev_map_row, np.int32) if prev_map_row is not None else None
+        wgt = np.ascontiguousarray(map_weight, np.float32) if map_weight is not None else None
+        args = _TrackArgs(np_ptr(pose), np_ptr(intr), np_ptr(isl), len(isl), C.pointer(pp), np_ptr(row) if row is not None and n_p else None, C.pointer(mpp),
+                          np_ptr(wgt) if wgt is not None and n_m else None, float(prev_min_desc_dist), float(prev_max_repj_dist), float(map_min_desc_dist),
+                          float(map_radius_tracked), float(map_radius_lost), int(min_inliers))
+        m1 = np.zeros(max(n_p, 1), DMATCH_DTYPE); b1 = np.zeros(max(n_p, 1), np.uint8)
+        m2 = np.zeros(max(n_m, 1), DMATCH_DTYPE)
+        mA = np.zeros(max(n_p + n_m, 1), DMATCH_DTYPE); bA = np.zeros(max(n_p + n_m, 1), np.uint8)
+        res = _TrackResult(np_ptr(m1), np_ptr(b1), len(m1), np_ptr(m2), len(m2), np_ptr(mA), np_ptr(bA), len(mA))
+        check(lib().uh_track_pose(self._h, pnp._h, C.byref(args), C.byref(res)))
+        return dict(matches_prev=m1[: res.n_prev].copy(), bad_prev=b1[: res.n_prev].copy(), matches_map=m2[: res.n_map].copy(), matches_all=mA[: res.n_all].copy(),
+                    bad_all=bA[: res.n_all].copy(), tracked=bool(res.tracked), inliers1=res.inliers1, inliers2=res.inliers2, iters1=np.array(res.iters1[:], np.int32),
+                    iters2=np.array(res.iters2[:], np.int32), pose1=np.array(res.pose1[:], np.float32), pose2=np.array(res.pose2[:], np.float32))
 
     def debug_tree(self):
         nn, nodes, leaf, depth = C.c_int32(), VP(), VP(), C.c_int32()
