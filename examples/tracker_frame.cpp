@@ -19,7 +19,7 @@
 // so every stage works on data the previous one produced.  Prints one JSON line with the median per-stage and per-frame latencies.
 //
 //   g++ -std=c++17 -O2 -o tracker_frame examples/tracker_frame.cpp -Lucoslam-cv3_amd -lucoslam_hip -Wl,-rpath,$PWD/ucoslam-cv3_amd -Wl,-rpath,/opt/rocm/lib -lpthread
-//   ./tracker_frame [frames=200] [warmup=20] [route=host|dev|devhost]     (dev: uh_orb_extract_frame_dev + uh_projmatch_set_frame_dev, the kd-tree built on the device; devhost: the same frame object, tree by the host core)
+//   ./tracker_frame [frames=200] [warmup=20] [route=host|dev|devhost|fused]     (dev: uh_orb_extract_frame_dev + uh_projmatch_set_frame_dev, the kd-tree built on the device; devhost: the same frame object, tree by the host core)
 #include <algorithm>
 #include <array>
 #include <chrono>
@@ -109,7 +109,8 @@ struct Stat {
 
 int main(int argc, char** argv) {
     const int frames = argc > 1 ? std::atoi(argv[1]) : 200, warmup = argc > 2 ? std::atoi(argv[2]) : 20;
-    const bool hybrid_route = argc > 3 && std::strcmp(argv[3], "devhost") == 0;   // frame resident on the device, its tree built by this core
+    const bool fused_route = argc > 3 && std::strcmp(argv[3], "fused") == 0;     // devhost + the four tracker calls as ONE (uh_track_pose)
+    const bool hybrid_route = fused_route || (argc > 3 && std::strcmp(argv[3], "devhost") == 0);   // frame resident on the device, its tree built by this core
     const bool dev_route = hybrid_route || (argc > 3 && std::strcmp(argv[3], "dev") == 0);
     uh_ctx* ctx = nullptr;
     if (uh_ctx_create_private(0, &ctx) < 0) { std::printf("no device: %s (there is no CPU path)\n", uh_last_error()); return 0; }
@@ -225,6 +226,16 @@ int main(int argc, char** argv) {
     std::vector<uh_dmatch> m_prev(N_PREV), m_map(N_MAP), m_all;
     std::vector<float> p3d, kp2, isg, wgt;
     std::vector<uint8_t> bad;
+    // uh_track_pose's view of the map bookkeeping: per previous-frame item its row in the local map (TheMap->map_points[id]), per map point its solver weight
+    std::vector<std::vector<int32_t>> prev_row(scenes.size());
+    std::vector<std::vector<float>> map_w(scenes.size());
+    for (size_t si = 0; si < scenes.size(); si++) {
+        Scene& sc = scenes[si];
+        for (uint32_t id : sc.prev_ids) prev_row[si].push_back((size_t)id < sc.id_to_map.size() ? sc.id_to_map[id] : -1);
+        for (int i = 0; i < N_MAP; i++) map_w[si].push_back(sc.map_unstable[i] ? 0.5f : 1.f);
+    }
+    std::vector<uh_dmatch> f_prev(N_PREV + 1), f_map(N_MAP + 1), f_all(N_PREV + N_MAP + 1);
+    std::vector<uint8_t> f_bad1(N_PREV + 1), f_bad2(N_PREV + N_MAP + 1);
     Stat t_orb, t_set, t_prev, t_pnp1, t_map, t_pnp2, t_glue, t_frame;
     long sum_prev = 0, sum_map = 0, sum_in1 = 0, sum_in2 = 0, sum_kp = 0;
     double pose_err = 0;
@@ -243,6 +254,24 @@ int main(int argc, char** argv) {
         else CHECK(uh_projmatch_set_frame(pm, &fr));
         const double t2 = now_us();
         const uh_prev_points pp{(int32_t)sc.prev_ids.size(), sc.prev_ids.data(), sc.prev_pos.data(), sc.prev_oct.data(), sc.prev_desc.data()};
+        if (fused_route) {
+            const size_t si = (size_t)((it + warmup) % NSCENES);
+            const uh_map_points mpf{N_MAP, sc.map_ids.data(), sc.map_pos.data(), sc.map_nrm.data(), sc.map_min.data(), sc.map_max.data(), sc.map_desc.data()};
+            const uh_track_args ta{sc.pose0, intr, inv_sf, NLEV, &pp, prev_row[si].data(), &mpf, map_w[si].data(), MAX_DESC_DIST * 1.5f, PROJ_DIST_THR, MAX_DESC_DIST * 2.f, 4.f, PROJ_DIST_THR, 30};
+            uh_track_result tr{};
+            tr.matches_prev = f_prev.data(); tr.bad_prev = f_bad1.data(); tr.cap_prev = (int32_t)f_prev.size();
+            tr.matches_map = f_map.data(); tr.cap_map = (int32_t)f_map.size();
+            tr.matches_all = f_all.data(); tr.bad_all = f_bad2.data(); tr.cap_all = (int32_t)f_all.size();
+            CHECK(uh_track_pose(pm, pnp, &ta, &tr));
+            const double t8f = now_us();
+            if (it < 0) continue;
+            t_orb.add(t1 - t0); t_set.add(t2 - t1); t_prev.add(t8f - t2); t_frame.add(t8f - t0);
+            sum_prev += tr.n_prev; sum_map += tr.n_map; sum_in1 += tr.inliers1; sum_in2 += tr.inliers2; sum_kp += n;
+            float Mgf[16]; to_f16(sc.Tgt, Mgf);
+            double ef = 0; for (int i = 0; i < 12; i++) ef = std::max(ef, (double)std::fabs(Mgf[i] - tr.pose2[i]));
+            pose_err = std::max(pose_err, ef);
+            continue;
+        }
         const int n1 = uh_projmatch_match_prev(pm, sc.pose0, &pp, MAX_DESC_DIST * 1.5f, PROJ_DIST_THR, m_prev.data(), (int)m_prev.size(), nullptr, nullptr);
         CHECK(n1);
         const double t3 = now_us();
@@ -310,7 +339,7 @@ int main(int argc, char** argv) {
                 "\"orb_extract_ms\": %.4f, \"set_frame_ms\": %.4f, \"match_prev_ms\": %.4f, \"pnp1_ms\": %.4f, \"match_map_ms\": %.4f, \"pnp2_ms\": %.4f, \"host_glue_ms\": %.4f, "
                 "\"keypoints\": %.1f, \"prev_items\": %d, \"map_points\": %d, \"matches_prev\": %.1f, \"matches_map\": %.1f, \"inliers1\": %.1f, \"inliers2\": %.1f, "
                 "\"max_pose_err_vs_truth\": %.5f}\n",
-                hybrid_route ? "device-resident frame, kd-tree built by the host core and uploaded" : dev_route ? "device-resident frame, kd-tree built on the device" : "keypoints to the host, kd-tree built on the host", frames, t_frame.med() / 1e3, t_frame.lo() / 1e3, t_frame.p90() / 1e3, 1e6 / std::max(t_frame.med(), 1e-9), t_orb.med() / 1e3, t_set.med() / 1e3, t_prev.med() / 1e3,
+                fused_route ? "device-resident frame, kd-tree built by the host core, searches + solves as one call (uh_track_pose; its time is reported as match_prev_ms)" : hybrid_route ? "device-resident frame, kd-tree built by the host core and uploaded" : dev_route ? "device-resident frame, kd-tree built on the device" : "keypoints to the host, kd-tree built on the host", frames, t_frame.med() / 1e3, t_frame.lo() / 1e3, t_frame.p90() / 1e3, 1e6 / std::max(t_frame.med(), 1e-9), t_orb.med() / 1e3, t_set.med() / 1e3, t_prev.med() / 1e3,
                 t_pnp1.med() / 1e3, t_map.med() / 1e3, t_pnp2.med() / 1e3, t_glue.med() / 1e3, sum_kp * f, N_PREV, N_MAP, sum_prev * f, sum_map * f, sum_in1 * f, sum_in2 * f, pose_err);
     uh_pnp_destroy(pnp); uh_projmatch_destroy(pm); uh_orb_destroy(ext); uh_dev_frame_destroy(dfr);
     for (auto& s : scenes) uh_host_free(s.image);

@@ -77,10 +77,12 @@ def test_tracker_chain_host_runs_the_per_frame_sequence(tmp_path):
     assert "device" in h["frame_route"]
     for k in ("keypoints", "matches_prev", "matches_map", "inliers1", "inliers2", "max_pose_err_vs_truth"):
         assert h[k] == r[k], (k, h[k], r[k])
-    # ... and so does the resident frame whose tree the host core builds (uh_dev_frame_set_tree_builder(frame, 1))
-    out = subprocess.run([exe, "40", "5", "devhost"], capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout + out.stderr
-    h = json.loads(out.stdout.strip().splitlines()[-1])
-    assert "host core" in h["frame_route"]
-    for k in ("keypoints", "matches_prev", "matches_map", "inliers1", "inliers2", "max_pose_err_vs_truth"):
-        assert h[k] == r[k], (k, h[k], r[k])
+    # ... and so does the resident frame whose tree the host core builds (uh_dev_frame_set_tree_builder(frame, 1)), with the four tracker
+    # calls one after the other and as ONE call (uh_track_pose: list handling and look-ups on the device)
+    for route, tag in (("devhost", "host core"), ("fused", "uh_track_pose")):
+        out = subprocess.run([exe, "40", "5", route], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        h = json.loads(out.stdout.strip().splitlines()[-1])
+        assert tag in h["frame_route"]
+        for k in ("keypoints", "matches_prev", "matches_map", "inliers1", "inliers2", "max_pose_err_vs_truth"):
+            assert h[k] == r[k], (route, k, h[k], r[k])

@@ -122,7 +122,7 @@ def test_track_pose_equals_the_four_operators(hip_ctx, host_tree):
     from ucoslam_cv3_amd.pnp import PnPSolver
 
     pnp = PnPSolver(hip_ctx)
-    for seed, kw in ((5, {}), (6, {}), (7, dict(n_prev=300, n_map=1200)), (8, dict(pose_noise=0.8))):
+    for seed, kw in ((5, {}), (6, {}), (7, dict(n_prev=300, n_map=1200)), (8, dict(pose_noise=0.8)), (11, dict(n_prev=1500, n_map=6500))):   # (the last: working lists too long for LDS)
         sc = _scene(hip_ctx, seed, host_tree, **kw)
         s = _sequence(sc, pnp)
         f = sc["pm"].trackPose(pnp, sc["pose0"], sc["intr"], sc["inv_sf"], sc["prev"], sc["mp"], prev_map_row=sc["prev_row"], map_weight=sc["weight"])

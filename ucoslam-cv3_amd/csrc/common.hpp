@@ -195,6 +195,13 @@ int copy16(uh_ctx* ctx, void* dst, const void* src, size_t bytes);
 int publish16(uh_ctx* ctx, void* dst_pinned, const void* src, size_t bytes, unsigned* d_reset_word, unsigned long long* d_word_in_pinned_memory, unsigned long long word);
 }  // namespace uh
 
+namespace uh {
+// uh_track_pose (track.hpp): the first solve's launch also takes the tracker's decision behind its last write — "enough inliers: the refined pose
+// and the small disc, else the predicted pose and the wide radius" (system.cpp:6762-6881) — and leaves the local-map search its pose (rows +
+// camera centre, 15 floats), radius (float 15) and a zero word (16) at dyn17, the chosen pose at pose_map (16 floats), the flag at tracked
+struct PnpDecide { int min_inliers; float r_tracked, r_lost; float* dyn17; float* pose_map; int* tracked; };
+}  // namespace uh
+
 #define UH_LAUNCH(ctx, kernel, grid, block, shmem, ...)                                        \
     do {                                                                                        \
         uh::ProfScope _ps((ctx), #kernel);                                                      \

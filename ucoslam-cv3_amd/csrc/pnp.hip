@@ -47,7 +47,26 @@ struct PnpArgs {
     unsigned long long* host_done;   // NULL, or a word in pinned host memory that receives done_word after everything else
     unsigned long long done_word;
     long long* clk;          // NULL, or 8 timestamps (s_memtime) for scripts/time_pnp.py
+    uh::PnpDecide dec;       // dyn17 != NULL: the tracker's decision rides on this solve (common.hpp)
 };
+
+// one thread: the decision of system.cpp:6762-6881 from this solve's inlier count; M = the pose it returns (16 floats)
+__device__ void pnp_decide(const PnpArgs& A, int inliers, const float* M) {
+    const int tracked = inliers >= A.dec.min_inliers ? 1 : 0;
+    const float* T = tracked ? M : A.pose_in;
+    float* d = A.dec.dyn17;
+    for (int i = 0; i < 12; i++) d[i] = T[i];
+    // camCenter = pose_f2g.inv() * (0,0,0), se3transform.h:89-113 — the float expressions of projmatch.hip's match_enqueue
+    const float m0 = T[0], m1 = T[4], m2 = T[8], m4 = T[1], m5 = T[5], m6 = T[9], m8 = T[2], m9 = T[6], m10 = T[10];
+    const float m3 = -(T[3] * m0 + T[7] * m1 + T[11] * m2), m7 = -(T[3] * m4 + T[7] * m5 + T[11] * m6), m11 = -(T[3] * m8 + T[7] * m9 + T[11] * m10);
+    d[12] = m0 * 0.f + m1 * 0.f + m2 * 0.f + m3;
+    d[13] = m4 * 0.f + m5 * 0.f + m6 * 0.f + m7;
+    d[14] = m8 * 0.f + m9 * 0.f + m10 * 0.f + m11;
+    d[15] = tracked ? A.dec.r_tracked : A.dec.r_lost;
+    d[16] = 0.f;
+    for (int i = 0; i < 16; i++) A.dec.pose_map[i] = T[i];
+    *A.dec.tracked = tracked;
+}
 
 struct PoseD { double q[4], t[3], Rt[12]; };
 
@@ -226,6 +245,7 @@ __global__ __launch_bounds__(kPnpThreads) void pnp_solve_kernel(PnpArgs A) {
         if (n <= 0) {   // pnpsolver.cpp:149-150: without matches the pose comes back as it went in
             if (tid < 16) A.pose_out[tid] = A.pose_in[tid];
             if (tid < 5) A.result[tid] = 0;
+            if (A.dec.dyn17 && tid == 0) pnp_decide(A, 0, A.pose_in);
             return;
         }
     }
@@ -624,6 +644,12 @@ __global__ __launch_bounds__(kPnpThreads) void pnp_solve_kernel(PnpArgs A) {
             float* M = A.pose_out;
             for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) M[r * 4 + c] = (float)Tend[r * 3 + c]; M[r * 4 + 3] = (float)Tend[9 + r]; }
             M[12] = M[13] = M[14] = 0.f; M[15] = 1.f;
+            if (A.dec.dyn17) {
+                float Mv[16];
+                for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Mv[r * 4 + c] = (float)Tend[r * 3 + c]; Mv[r * 4 + 3] = (float)Tend[9 + r]; }
+                Mv[12] = Mv[13] = Mv[14] = 0.f; Mv[15] = 1.f;
+                pnp_decide(A, n > 0 ? good : 0, Mv);
+            }
             if (A.state_out) {
                 double q[4];
                 p_quat_from_R(Tend, q);
@@ -681,7 +707,7 @@ namespace uh {
 uh_ctx* pnp_ctx(uh_pnp* p) { return p->ctx; }
 // the solve behind uh_track_pose: everything resident, the match count decided by an earlier launch of the same stream
 int pnp_enqueue_dev(uh_pnp* p, const float* d_pose, const float* d_intr4, int n_cap, const int* d_n, const float* d_p3d, const float* d_kp, const float* d_inv_sigma,
-                    const float* d_weight, float* d_pose_out, unsigned char* d_bad_out, int* d_result5) {
+                    const float* d_weight, float* d_pose_out, unsigned char* d_bad_out, int* d_result5, const PnpDecide* dec) {
     UH_HIP_CHECK(hipSetDevice(p->ctx->device));
     int rc;
     if (n_cap > kPnpLdsMatches && (rc = p->d_work.reserve((size_t)n_cap * 32))) return rc;
@@ -690,6 +716,7 @@ int pnp_enqueue_dev(uh_pnp* p, const float* d_pose, const float* d_intr4, int n_
     A.work = p->d_work.p;
     A.pose_out = d_pose_out; A.bad_out = d_bad_out; A.result = d_result5; A.state_out = nullptr;
     A.host_done = nullptr; A.done_word = 0;
+    if (dec) A.dec = *dec;
     return launch(p, A);
 }
 }  // namespace uh

@@ -325,6 +325,8 @@ struct PmPoints {
     // could start; one record is one 64-byte request.
     const uint4* rec;
     int* best_kp; float* best_dist; unsigned char* visible;
+    float4* pos_out;   // NULL, or HBM: every candidate's position again (uh_track_pose's look-ups gather from it instead of from pinned memory)
+    const uint4* aux_in; uint4* aux_out;   // with pos_out: a 16-byte record per candidate the caller staged in pinned memory ({id, map row, weight, -}), moved to HBM likewise
 };
 
 struct PmPose { float T[12]; float cc[3]; };
@@ -716,6 +718,7 @@ __global__ __launch_bounds__(kPmThreads) void projmatch_kernel(PmFrame f, PmPoin
         __hip_atomic_store(mp.best_kp + m, best_kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(mp.best_dist + m, (PREV && best_kp < 0) ? 3.402823466e+38f : best_d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (mp.visible) __hip_atomic_store(mp.visible + m, (unsigned char)(vis ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mp.pos_out) { mp.pos_out[m] = make_float4(cd.P0, cd.P1, cd.P2, 0.f); mp.aux_out[m] = mp.aux_in[m]; }
     }
     if (clk) clk[4] = __builtin_readcyclecounter();
   }
@@ -913,10 +916,8 @@ int uh_projmatch_set_frame_dev(uh_projmatch* h, uh_dev_frame* fr, const uh_proj_
                 std::memcpy(lr + 4 * i + 2, &io, 4); lr[4 * i + 3] = 0.f;
             }
             std::atomic_thread_fence(std::memory_order_release);
-            // (only what the tree occupies of the node block travels: two copies when the gap between them is larger than the nodes)
-            const size_t nbytes = (sizeof(KdNodeDev) * nn + 15) & ~(size_t)15;
-            if ((rc = uh::copy16(h->ctx, reinterpret_cast<char*>(fr->nodes()), h->h_frame.dev<char>() + 64, nbytes))) return rc;
-            if ((rc = uh::copy16(h->ctx, reinterpret_cast<char*>(fr->leaf()), h->h_frame.dev<char>() + 64 + gap, 16 * (size_t)n))) return rc;
+            // (one launch over the node block and the leaf records: the unused tail of the node block travels with them — a few KB against a second launch)
+            if ((rc = uh::copy16(h->ctx, reinterpret_cast<char*>(fr->nodes()), h->h_frame.dev<char>() + 64, span))) return rc;
             h->upload_pending = true;
         }
         PmFrame& d = h->fr;
@@ -991,7 +992,9 @@ struct PmPending {
 // Stage the candidates and enqueue the search (no waiting).  octave == nullptr: Map::matchFrameToMapPoints; normal / min / max == nullptr: the
 // previous-frame search.  dyn != nullptr: pose and radius are read from device memory at launch time (written by an earlier launch of this stream).
 int match_enqueue(uh_projmatch* h, int slot, const float* pose_f2g, const PmDyn* dyn, int n, const float* pos3d, const float* normal,
-                  const float* mn_dist, const float* mx_dist, const uint8_t* desc, const int32_t* octave, float min_desc_dist, float max_repj_dist, PmPending* pend) {
+                  const float* mn_dist, const float* mx_dist, const uint8_t* desc, const int32_t* octave, float min_desc_dist, float max_repj_dist, PmPending* pend,
+                  float4* pos_out = nullptr, const uint32_t* ids = nullptr, const int32_t* rows = nullptr, const float* weights = nullptr, const float* weights_by_row = nullptr,
+                  uint4* aux_out = nullptr) {
     const bool prev = octave != nullptr;
     uh_projmatch::Slot& S = h->slot[slot];
     UH_HIP_CHECK(hipSetDevice(h->ctx->device));
@@ -1014,8 +1017,16 @@ int match_enqueue(uh_projmatch* h, int slot, const float* pose_f2g, const PmDyn*
     static const bool pm_timing = getenv("UH_PM_TIMING") != nullptr;
     const auto t_pack0 = std::chrono::steady_clock::now();
     {   // one pinned staging block (the previous call's launches are complete: its results were awaited): the candidates as 64-byte records
-        if ((rc = S.h_in.reserve(o_pos + 64 * (size_t)n + 64))) return rc;
+        if ((rc = S.h_in.reserve(o_pos + 80 * (size_t)n + 64))) return rc;   // (64-byte records, then uh_track_pose's 16-byte ones)
         char* hi = S.h_in.host<char>();
+        if (pos_out) {   // uh_track_pose: {id, row of the same point in the local map (a map candidate: its own), the solver weight of that row}
+            uint32_t* ax = reinterpret_cast<uint32_t*>(hi + o_pos + 64 * (size_t)n);
+            for (int i = 0; i < n; i++, ax += 4) {
+                const int row = prev ? (rows ? rows[i] : -1) : i;
+                const float w = prev ? (row >= 0 && weights_by_row ? weights_by_row[row] : 1.f) : (weights ? weights[i] : 1.f);
+                ax[0] = ids[i]; std::memcpy(ax + 1, &row, 4); std::memcpy(ax + 2, &w, 4); ax[3] = 0;
+            }
+        }
         float* rec = reinterpret_cast<float*>(hi + o_pos);
         for (int i = 0; i < n; i++, rec += 16) {
             rec[0] = pos3d[3 * i]; rec[1] = pos3d[3 * i + 1]; rec[2] = pos3d[3 * i + 2];
@@ -1030,6 +1041,8 @@ int match_enqueue(uh_projmatch* h, int slot, const float* pose_f2g, const PmDyn*
     P.n = n;
     P.rec = reinterpret_cast<const uint4*>(S.h_in.dev<char>() + o_pos);   // (read by the kernel where they lie: every wave fetches its own candidate once)
     P.best_kp = (int*)(base + o_bk); P.best_dist = (float*)(base + o_bd); P.visible = (unsigned char*)(base + o_vis);
+    P.pos_out = pos_out;
+    P.aux_in = reinterpret_cast<const uint4*>(S.h_in.dev<char>() + o_pos + 64 * (size_t)n); P.aux_out = aux_out;
     PmPose ps{};
     if (pose_f2g) {
         const float* T = pose_f2g;

@@ -8,11 +8,14 @@
 //                             PnPSolver::solvePnp                                      (uh_pnp_solve)
 // Called one after the other through the C ABI the four operators cost four host round trips (launch latency + completion word + unpacking +
 // the host's look-ups in between: ~55 of the frame's ~430 us were no kernel's).  Here the host stages both candidate sets, enqueues
-// SEVEN launches on the context stream and waits once; what the host did between the calls runs on the device:
+// SIX launches on the context stream and waits once; what the host did between the calls runs on the device:
 //   projmatch_kernel<prev>  ->  track_select_kernel (matches in item order, filter_ambiguous_query, look-ups for the solve)
-//   -> pnp_solve_kernel (match count from device memory)  ->  track_decide_kernel (pose / radius of the map search)
+//   -> pnp_solve_kernel (match count from device memory; its last thread also takes the decision: pose / radius of the map search)
 //   -> projmatch_kernel<map> (pose and radius read from device memory)  ->  track_select_kernel (its own filter, the union with the
 //   first solve's inliers, filter, look-ups)  ->  pnp_solve_kernel  ->  track_publish_kernel (everything the sequence of calls returns).
+// The look-ups gather from HBM only: the searches leave every candidate's position and its {id, map row, weight} record there again
+// (PmPoints::pos_out / aux_out: one more 16-byte read per candidate inside launches that wait on such reads anyway; gathering from pinned
+// memory in the select launches was one host-link request per match — 31 us for the second one — and staging the tables there 5 us).
 // Same results as the four calls, bit for bit (tests/test_track.py, tests/test_cpp_host.py): the same kernels do the searching and
 // the solving; the list logic is integer work (stable minimum per keypoint = uh_filter_ambiguous, matcher.hip keep_best_per_key).
 // This file is included at the end of projmatch.hip (it uses that unit's internals).
@@ -20,7 +23,7 @@
 
 namespace uh {
 int pnp_enqueue_dev(uh_pnp* p, const float* d_pose, const float* d_intr4, int n_cap, const int* d_n, const float* d_p3d, const float* d_kp, const float* d_inv_sigma,
-                    const float* d_weight, float* d_pose_out, unsigned char* d_bad_out, int* d_result5);
+                    const float* d_weight, float* d_pose_out, unsigned char* d_bad_out, int* d_result5, const PnpDecide* dec);
 uh_ctx* pnp_ctx(uh_pnp* p);
 }
 
@@ -34,7 +37,7 @@ enum : int { kTrkN1 = 0, kTrkN2 = 1, kTrkNA = 2, kTrkTracked = 3, kTrkRes1 = 4 /
 
 struct TrkSelect {
     // the search whose results become a list (candidate order)
-    int nB; const int* bk; const float* bd; const unsigned* ids; int map_kind;
+    int nB; const int* bk; const float* bd; const uint4* aux; int map_kind;   // aux: {id, map row, weight} per candidate (HBM, left by the search)
     // second form only: the list carried over from the first solve (its inliers enter the union when the frame counts as tracked)
     const uh_dmatch* carry; const int* carry_src; const unsigned char* carry_bad; int carry_cap;
     int* hdr;                       // counts in / out (see the enum)
@@ -43,30 +46,34 @@ struct TrkSelect {
     uh_dmatch* final_out;                   // second form: the union after its filter (NULL in the first form)
     int* final_src;                         // scratch: source of each element of the final list
     // look-ups for the solve over the final list
-    const float* rec_prev; const float* rec_map;   // 64-byte candidate records (position = floats 0..2)
-    const int* prev_map_row; const float* map_weight; int prefer_map_row;
+    const float4* pos_prev; const float4* pos_map;   // HBM: the candidates' positions as the searches left them
+    const uint4* aux_prev; const uint4* aux_map; int prefer_map_row;
     const float4* kp_xyo; const float* inv_sigma_lv; int n_levels;
     float* p3d; float* kp; float* isg; float* wgt;
     int n_kpts;
     TrkElem* scratch_a; TrkElem* scratch_b;
+    long long* clk;   // UH_TRK_CLK: 8 wall-clock stamps (10 ns) of thread 0
 };
 
-// exclusive prefix over the workgroup's flags of one chunk (one flag per thread); returns the thread's rank and the chunk's total
-__device__ __forceinline__ int trk_block_rank(int flag, int* s_wave, int& total) {
+// Exclusive prefix over the workgroup's per-thread counts; returns the thread's offset and (total) the sum.  Two barriers.
+__device__ __forceinline__ int trk_block_offset(int count, int* s_wave, int& total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int inc = uh_kd::wave_incl_scan(flag);
+    const int inc = uh_kd::wave_incl_scan(count);
     if (lane == 63) s_wave[wave] = inc;
     __syncthreads();
     int base = 0, tot = 0;
+#pragma unroll
     for (int w = 0; w < kTrkThreads / 64; w++) { const int v = s_wave[w]; base += w < wave ? v : 0; tot += v; }
     __syncthreads();
     total = tot;
-    return base + inc - flag;
+    return base + inc - count;
 }
+
+constexpr int kTrkItems = 4;   // consecutive list positions per thread and pass: lists of up to 4096 elements take ONE scan (two barriers of sixteen waves) per step
 
 // uh_filter_ambiguous(list, n, by query) on the device: the first strict minimum of the distance per keypoint stays, in list order
 // (matcher.hip keep_best_per_key).  in / out may not alias.  Returns the new length (every thread).
-__device__ int trk_filter(const TrkElem* __restrict__ in, int n, TrkElem* __restrict__ out, unsigned long long* s_best, int n_kpts, int* s_wave) {
+__device__ int trk_filter(const TrkElem* in, int n, TrkElem* out, unsigned long long* s_best, int n_kpts, int* s_wave) {
     for (int k = threadIdx.x; k < n_kpts; k += kTrkThreads) s_best[k] = ~0ull;
     __syncthreads();
     for (int pos = threadIdx.x; pos < n; pos += kTrkThreads) {
@@ -75,106 +82,115 @@ __device__ int trk_filter(const TrkElem* __restrict__ in, int n, TrkElem* __rest
     }
     __syncthreads();
     int kept = 0;
-    for (int p0 = 0; p0 < n; p0 += kTrkThreads) {
-        const int pos = p0 + threadIdx.x;
-        TrkElem e{};
-        int keep = 0;
-        if (pos < n) { e = in[pos]; keep = (unsigned)(s_best[e.query] & 0xffffffffull) == (unsigned)pos ? 1 : 0; }
+    for (int p0 = 0; p0 < n; p0 += kTrkThreads * kTrkItems) {
+        TrkElem e[kTrkItems];
+        int keep[kTrkItems], cnt = 0;
+#pragma unroll
+        for (int u = 0; u < kTrkItems; u++) {
+            const int pos = p0 + (int)threadIdx.x * kTrkItems + u;
+            keep[u] = 0;
+            if (pos < n) { e[u] = in[pos]; keep[u] = (unsigned)(s_best[e[u].query] & 0xffffffffull) == (unsigned)pos ? 1 : 0; }
+            cnt += keep[u];
+        }
         int tot;
-        const int r = trk_block_rank(keep, s_wave, tot);
-        if (keep) out[kept + r] = e;
+        int o = kept + trk_block_offset(cnt, s_wave, tot);
+#pragma unroll
+        for (int u = 0; u < kTrkItems; u++) if (keep[u]) out[o++] = e[u];
         kept += tot;
     }
     __syncthreads();
     return kept;
 }
 
-__global__ __launch_bounds__(kTrkThreads) void track_select_kernel(TrkSelect a) {
+// LDS_LISTS: the two working lists live in dynamic LDS (cap elements each) instead of the HBM scratch (round trips through L2 between the steps)
+template <bool LDS_LISTS>
+__global__ __launch_bounds__(kTrkThreads) void track_select_kernel(TrkSelect a, int cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     __shared__ unsigned long long s_best[4096];
     __shared__ int s_wave[kTrkThreads / 64];
+    __shared__ float s_isl[16];
+    if (threadIdx.x < 16) s_isl[threadIdx.x] = (int)threadIdx.x < a.n_levels ? a.inv_sigma_lv[threadIdx.x] : 0.f;   // (pinned memory: read once, not once per match)
+    TrkElem* const LA = LDS_LISTS ? reinterpret_cast<TrkElem*>(s_dyn) : a.scratch_a;
+    TrkElem* const LB = LDS_LISTS ? reinterpret_cast<TrkElem*>(s_dyn) + cap : a.scratch_b;
     const int tid = threadIdx.x;
+#define UH_TRK_STAMP(j) do { if (a.clk && tid == 0) a.clk[j] = wall_clock64(); } while (0)
+    UH_TRK_STAMP(0);
+    UH_TRK_STAMP(1);
     // ---- the search's hits in candidate order
     int nF = 0;
-    for (int p0 = 0; p0 < a.nB; p0 += kTrkThreads) {
-        const int i = p0 + tid;
-        int kpi = -1;
-        if (i < a.nB) kpi = a.bk[i];
-        const int flag = kpi >= 0 ? 1 : 0;
+    for (int p0 = 0; p0 < a.nB; p0 += kTrkThreads * kTrkItems) {
+        int kpi[kTrkItems], cnt = 0;
+        unsigned id[kTrkItems];
+        float dist[kTrkItems];
+#pragma unroll
+        for (int u = 0; u < kTrkItems; u++) {
+            const int i = p0 + tid * kTrkItems + u;
+            kpi[u] = -1; id[u] = 0; dist[u] = 0.f;
+            if (i < a.nB) { kpi[u] = a.bk[i]; id[u] = a.aux[i].x; dist[u] = a.bd[i]; }
+            cnt += kpi[u] >= 0 ? 1 : 0;
+        }
         int tot;
-        const int r = trk_block_rank(flag, s_wave, tot);
-        if (flag) a.scratch_a[nF + r] = TrkElem{kpi, a.ids[i], a.bd[i], (a.map_kind << 30) | i};
+        int o = nF + trk_block_offset(cnt, s_wave, tot);
+#pragma unroll
+        for (int u = 0; u < kTrkItems; u++) if (kpi[u] >= 0) LA[o++] = TrkElem{kpi[u], id[u], dist[u], (a.map_kind << 30) | (p0 + tid * kTrkItems + u)};
         nF += tot;
     }
     __syncthreads();
+    UH_TRK_STAMP(2);
     // ---- filter_ambiguous_query of the search's own list (uh_projmatch_match / _match_prev end with it)
-    const int n_fresh = trk_filter(a.scratch_a, nF, a.scratch_b, s_best, a.n_kpts, s_wave);
+    const int n_fresh = trk_filter(LA, nF, LB, s_best, a.n_kpts, s_wave);
+    UH_TRK_STAMP(3);
     for (int p = tid; p < n_fresh; p += kTrkThreads) {
-        const TrkElem e = a.scratch_b[p];
+        const TrkElem e = LB[p];
         a.fresh_out[p] = uh_dmatch{e.query, (int)e.id, -1, e.dist};
         a.fresh_src[p] = e.src;
     }
-    const TrkElem* fin = a.scratch_b;
+    const TrkElem* fin = LB;
     int n_fin = n_fresh;
+    UH_TRK_STAMP(4);
     if (a.carry) {
         // ---- the union: inliers of the first solve (when the frame counts as tracked), then the new matches; filter again
         const int tracked = a.hdr[kTrkTracked];
         const int nc = tracked ? min(a.hdr[kTrkN1], a.carry_cap) : 0;
         int nU = 0;
-        for (int p0 = 0; p0 < nc; p0 += kTrkThreads) {
-            const int p = p0 + tid;
-            const int flag = p < nc && !a.carry_bad[p] ? 1 : 0;
+        for (int p0 = 0; p0 < nc; p0 += kTrkThreads * kTrkItems) {
+            int flag[kTrkItems], cnt = 0;
+#pragma unroll
+            for (int u = 0; u < kTrkItems; u++) { const int p = p0 + tid * kTrkItems + u; flag[u] = p < nc && !a.carry_bad[p] ? 1 : 0; cnt += flag[u]; }
             int tot;
-            const int r = trk_block_rank(flag, s_wave, tot);
-            if (flag) { const uh_dmatch m = a.carry[p]; a.scratch_a[nU + r] = TrkElem{m.queryIdx, (unsigned)m.trainIdx, m.distance, a.carry_src[p]}; }
+            int o = nU + trk_block_offset(cnt, s_wave, tot);
+#pragma unroll
+            for (int u = 0; u < kTrkItems; u++)
+                if (flag[u]) { const int p = p0 + tid * kTrkItems + u; const uh_dmatch m = a.carry[p]; LA[o++] = TrkElem{m.queryIdx, (unsigned)m.trainIdx, m.distance, a.carry_src[p]}; }
             nU += tot;
         }
         __syncthreads();
-        for (int p = tid; p < n_fresh; p += kTrkThreads) a.scratch_a[nU + p] = a.scratch_b[p];
+        for (int p = tid; p < n_fresh; p += kTrkThreads) LA[nU + p] = LB[p];
         __syncthreads();
         nU += n_fresh;
-        // (scratch_b is free again: its content lives in scratch_a now)
-        n_fin = trk_filter(a.scratch_a, nU, a.scratch_b, s_best, a.n_kpts, s_wave);
-        fin = a.scratch_b;
-        for (int p = tid; p < n_fin; p += kTrkThreads) { const TrkElem e = fin[p]; a.final_out[p] = uh_dmatch{e.query, (int)e.id, -1, e.dist}; }
+        // (LB is free again: its content lives in LA now)
+        n_fin = trk_filter(LA, nU, LB, s_best, a.n_kpts, s_wave);
+        for (int p = tid; p < n_fin; p += kTrkThreads) { const TrkElem e = LB[p]; a.final_out[p] = uh_dmatch{e.query, (int)e.id, -1, e.dist}; }
     }
+    UH_TRK_STAMP(5);
     // ---- the solver's per-match look-ups (pnpsolver.cpp:199-232): the point's coordinates and weight, the keypoint, 1 / scaleFactor of its octave
     for (int p = tid; p < n_fin; p += kTrkThreads) {
         const TrkElem e = fin[p];
         const int is_map = (e.src >> 30) & 1, idx = e.src & 0x3fffffff;
-        int row = is_map ? idx : -1;
-        if (!is_map && a.prefer_map_row && a.prev_map_row) row = a.prev_map_row[idx];
-        const float* rec = row >= 0 ? a.rec_map + 16 * (size_t)row : a.rec_prev + 16 * (size_t)idx;
-        a.p3d[3 * p] = rec[0]; a.p3d[3 * p + 1] = rec[1]; a.p3d[3 * p + 2] = rec[2];
-        a.wgt[p] = row >= 0 && a.prefer_map_row && a.map_weight ? a.map_weight[row] : 1.f;
+        const uint4 ax = is_map ? a.aux_map[idx] : a.aux_prev[idx];
+        const int row = a.prefer_map_row ? (int)ax.y : -1;   // (first solve: the candidate's own position, weight 1)
+        const float4 pos = row >= 0 ? a.pos_map[row] : a.pos_prev[idx];
+        a.p3d[3 * p] = pos.x; a.p3d[3 * p + 1] = pos.y; a.p3d[3 * p + 2] = pos.z;
+        a.wgt[p] = row >= 0 ? __uint_as_float(ax.z) : 1.f;
         const float4 k = a.kp_xyo[e.query];
         a.kp[2 * p] = k.x; a.kp[2 * p + 1] = k.y;
         const int oct = (int)(__float_as_uint(k.z) & 15u);
-        a.isg[p] = a.inv_sigma_lv[oct < a.n_levels ? oct : 0];
+        a.isg[p] = s_isl[oct < a.n_levels ? oct : 0];
         if (a.final_src) a.final_src[p] = e.src;
     }
     if (tid == 0) { a.hdr[a.fresh_n_slot] = n_fresh; a.hdr[a.final_n_slot] = n_fin; }
-}
-
-// system.cpp:6762-6881: with at least min_inliers inliers the refined pose is kept and the local map is searched in a small disc; otherwise
-// the first matches are dropped, the predicted pose stays and the radius is the wide one.  Leaves the pose for the search (as the kernel
-// wants it: rows + camera centre, se3transform.h:89-113 — the host's float expressions), for the second solve, and the flag.
-__global__ void track_decide_kernel(const float* __restrict__ pose0, const float* __restrict__ pose1, int* hdr, int min_inliers, float r_tracked, float r_lost,
-                                    PmDyn* dyn, float* pose_map) {
-    if (threadIdx.x != 0) return;
-    const int tracked = hdr[kTrkRes1] >= min_inliers ? 1 : 0;
-    const float* T = tracked ? pose1 : pose0;
-    PmDyn d;
-    for (int i = 0; i < 12; i++) d.ps.T[i] = T[i];
-    const float m0 = T[0], m1 = T[4], m2 = T[8], m4 = T[1], m5 = T[5], m6 = T[9], m8 = T[2], m9 = T[6], m10 = T[10];
-    const float m3 = -(T[3] * m0 + T[7] * m1 + T[11] * m2), m7 = -(T[3] * m4 + T[7] * m5 + T[11] * m6), m11 = -(T[3] * m8 + T[7] * m9 + T[11] * m10);
-    d.ps.cc[0] = m0 * 0.f + m1 * 0.f + m2 * 0.f + m3;
-    d.ps.cc[1] = m4 * 0.f + m5 * 0.f + m6 * 0.f + m7;
-    d.ps.cc[2] = m8 * 0.f + m9 * 0.f + m10 * 0.f + m11;
-    d.radius = tracked ? r_tracked : r_lost;
-    d.skip = 0;
-    *dyn = d;
-    for (int i = 0; i < 16; i++) pose_map[i] = T[i];
-    hdr[kTrkTracked] = tracked;
+    UH_TRK_STAMP(6);
+#undef UH_TRK_STAMP
 }
 
 struct TrkPublish {
@@ -212,6 +228,8 @@ struct uh_track_state {
     uh::MappedBuf h_par;   // pinned: [completion word | pose0 | intr | inv sigma per level | candidate ids | prev_map_row | map weights]
     uh::MappedBuf h_out;   // pinned: the results
     unsigned long long seq = 0;
+    bool attr_set = false;
+    uh::DevBuf d_clk;      // UH_TRK_CLK (measurement)
 };
 
 uh_projmatch::~uh_projmatch() { delete track; }
@@ -250,23 +268,19 @@ int uh_track_pose(uh_projmatch* h, uh_pnp* pnp, const uh_track_args* a, uh_track
     const size_t o_p3d = o; o = al(o + 12 * (size_t)capa); const size_t o_kp = o; o = al(o + 8 * (size_t)capa); const size_t o_isg = o; o = al(o + 4 * (size_t)capa);
     const size_t o_wgt = o; o = al(o + 4 * (size_t)capa);
     const size_t o_sa = o; o = al(o + sizeof(TrkElem) * (size_t)capa); const size_t o_sb = o; o = al(o + sizeof(TrkElem) * (size_t)capa);
+    const size_t o_posp = o; o = al(o + 16 * (size_t)cap1); const size_t o_posm = o; o = al(o + 16 * (size_t)cap2);
+    const size_t o_auxp = o; o = al(o + 16 * (size_t)cap1); const size_t o_auxm = o; o = al(o + 16 * (size_t)cap2);
     if ((rc = T.d.reserve(o))) return rc;
     char* D = T.d.as<char>();
     // ---- pinned parameter block (read by the launches in place)
     size_t q = 64;
     const size_t q_pose0 = q; q += 64; const size_t q_intr = q; q += 64; const size_t q_isl = q; q += 64;
-    const size_t q_idp = q; q = al(q + 4 * (size_t)cap1); const size_t q_idm = q; q = al(q + 4 * (size_t)cap2);
-    const size_t q_row = q; q = al(q + 4 * (size_t)cap1); const size_t q_w = q; q = al(q + 4 * (size_t)cap2);
     if ((rc = T.h_par.reserve(q))) return rc;   // (the previous call's launches are complete: its results were awaited)
     char* hp = T.h_par.host<char>();
     char* dp = T.h_par.dev<char>();
     std::memcpy(hp + q_pose0, a->pose0, 64);
     std::memcpy(hp + q_intr, a->intr4, 16);
     std::memcpy(hp + q_isl, a->inv_sigma_levels, 4 * (size_t)a->n_levels);
-    if (np) std::memcpy(hp + q_idp, a->prev->ids, 4 * (size_t)np);
-    if (nm) std::memcpy(hp + q_idm, a->map->ids, 4 * (size_t)nm);
-    if (a->prev_map_row && np) std::memcpy(hp + q_row, a->prev_map_row, 4 * (size_t)np);
-    if (a->map_weight && nm) std::memcpy(hp + q_w, a->map_weight, 4 * (size_t)nm);
     // ---- pinned result block
     size_t w = 0;
     const size_t w_hdr = w; w = al(w + 4 * kTrkHdrInts); const size_t w_pose1 = w; w += 64; const size_t w_pose2 = w; w = al(w + 64);
@@ -282,37 +296,53 @@ int uh_track_pose(uh_projmatch* h, uh_pnp* pnp, const uh_track_args* a, uh_track
     // ---- 1: the search against the previous frame (slot 0), its list and look-ups, the first solve
     PmPending pd1, pd2;
     if (np) {
-        if ((rc = match_enqueue(h, 0, a->pose0, nullptr, np, a->prev->pos3d, nullptr, nullptr, nullptr, a->prev->desc, a->prev->octave, a->prev_min_desc_dist, a->prev_max_repj_dist, &pd1))) return rc;
+        if ((rc = match_enqueue(h, 0, a->pose0, nullptr, np, a->prev->pos3d, nullptr, nullptr, nullptr, a->prev->desc, a->prev->octave, a->prev_min_desc_dist, a->prev_max_repj_dist, &pd1,
+                                reinterpret_cast<float4*>(D + o_posp), a->prev->ids, a->prev_map_row, nullptr, a->map_weight, reinterpret_cast<uint4*>(D + o_auxp)))) return rc;
     }
     // (the map candidates are staged now, while the device works on the first search: slot 1 has its own pinned block)
     TrkSelect s1{};
-    s1.nB = np; s1.bk = pd1.d_best_kp; s1.bd = pd1.d_best_dist; s1.ids = reinterpret_cast<const unsigned*>(dp + q_idp); s1.map_kind = 0;
+    s1.nB = np; s1.bk = pd1.d_best_kp; s1.bd = pd1.d_best_dist; s1.aux = reinterpret_cast<const uint4*>(D + o_auxp); s1.map_kind = 0;
     s1.carry = nullptr; s1.hdr = hdr; s1.fresh_n_slot = kTrkN1; s1.final_n_slot = kTrkN1;
     s1.fresh_out = reinterpret_cast<uh_dmatch*>(D + o_m1); s1.fresh_src = reinterpret_cast<int*>(D + o_src1); s1.final_out = nullptr; s1.final_src = nullptr;
-    s1.rec_prev = pd1.d_rec; s1.rec_map = nullptr; s1.prev_map_row = nullptr; s1.map_weight = nullptr; s1.prefer_map_row = 0;
+    s1.pos_prev = reinterpret_cast<const float4*>(D + o_posp); s1.pos_map = reinterpret_cast<const float4*>(D + o_posm);
+    s1.aux_prev = reinterpret_cast<const uint4*>(D + o_auxp); s1.aux_map = reinterpret_cast<const uint4*>(D + o_auxm); s1.prefer_map_row = 0;
     s1.kp_xyo = kp_xyo; s1.inv_sigma_lv = reinterpret_cast<const float*>(dp + q_isl); s1.n_levels = a->n_levels;
     s1.p3d = reinterpret_cast<float*>(D + o_p3d); s1.kp = reinterpret_cast<float*>(D + o_kp); s1.isg = reinterpret_cast<float*>(D + o_isg); s1.wgt = reinterpret_cast<float*>(D + o_wgt);
     s1.n_kpts = nk; s1.scratch_a = reinterpret_cast<TrkElem*>(D + o_sa); s1.scratch_b = reinterpret_cast<TrkElem*>(D + o_sb);
-    UH_LAUNCH(h->ctx, track_select_kernel, dim3(1), dim3(kTrkThreads), 0, s1);
-    if ((rc = uh::pnp_enqueue_dev(pnp, reinterpret_cast<const float*>(dp + q_pose0), reinterpret_cast<const float*>(dp + q_intr), std::min(cap1, capn), hdr + kTrkN1, s1.p3d, s1.kp, s1.isg, s1.wgt,
-                                  reinterpret_cast<float*>(D + o_pose1), reinterpret_cast<unsigned char*>(D + o_bad1), hdr + kTrkRes1))) return rc;
-    // ---- 2: the decision, the search of the local map at the decided pose / radius (slot 1), the union, the second solve
+    static const bool trk_clk = getenv("UH_TRK_CLK") != nullptr;
+    if (trk_clk && !T.d_clk.p) { if ((rc = T.d_clk.reserve(16 * 8))) return rc; }
+    s1.clk = trk_clk ? T.d_clk.as<long long>() : nullptr;
+    // the select launches' working lists: in LDS while two lists of capa elements fit beside the per-keypoint table
+    const size_t sel_lds = 2 * sizeof(TrkElem) * (size_t)capa;
+    const bool sel_in_lds = sel_lds <= 120 * 1024;
+    if (sel_in_lds && !T.attr_set) {
+        UH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(track_select_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+        T.attr_set = true;
+    }
+    if (sel_in_lds) UH_LAUNCH(h->ctx, track_select_kernel<true>, dim3(1), dim3(kTrkThreads), sel_lds, s1, capa);
+    else UH_LAUNCH(h->ctx, track_select_kernel<false>, dim3(1), dim3(kTrkThreads), 0, s1, capa);
+    // (the decision — refined pose + small disc or predicted pose + wide radius — rides on the solve's last thread)
+    static_assert(sizeof(PmDyn) == 17 * 4, "PmDyn is what pnp_decide writes");
     PmDyn* dyn = reinterpret_cast<PmDyn*>(D + o_dyn);
-    UH_LAUNCH(h->ctx, track_decide_kernel, dim3(1), dim3(64), 0, reinterpret_cast<const float*>(dp + q_pose0), reinterpret_cast<const float*>(D + o_pose1), hdr, a->min_inliers, a->map_radius_tracked,
-              a->map_radius_lost, dyn, reinterpret_cast<float*>(D + o_posem));
+    const uh::PnpDecide dec{a->min_inliers, a->map_radius_tracked, a->map_radius_lost, reinterpret_cast<float*>(dyn), reinterpret_cast<float*>(D + o_posem), hdr + kTrkTracked};
+    if ((rc = uh::pnp_enqueue_dev(pnp, reinterpret_cast<const float*>(dp + q_pose0), reinterpret_cast<const float*>(dp + q_intr), std::min(cap1, capn), hdr + kTrkN1, s1.p3d, s1.kp, s1.isg, s1.wgt,
+                                  reinterpret_cast<float*>(D + o_pose1), reinterpret_cast<unsigned char*>(D + o_bad1), hdr + kTrkRes1, &dec))) return rc;
+    // ---- 2: the search of the local map at the decided pose / radius (slot 1), the union, the second solve
     if (nm) {
-        if ((rc = match_enqueue(h, 1, nullptr, dyn, nm, a->map->pos3d, a->map->normal, a->map->min_dist, a->map->max_dist, a->map->desc, nullptr, a->map_min_desc_dist, a->map_radius_tracked, &pd2))) return rc;
+        if ((rc = match_enqueue(h, 1, nullptr, dyn, nm, a->map->pos3d, a->map->normal, a->map->min_dist, a->map->max_dist, a->map->desc, nullptr, a->map_min_desc_dist, a->map_radius_tracked, &pd2,
+                                reinterpret_cast<float4*>(D + o_posm), a->map->ids, nullptr, a->map_weight, nullptr, reinterpret_cast<uint4*>(D + o_auxm)))) return rc;
     }
     TrkSelect s2 = s1;
-    s2.nB = nm; s2.bk = pd2.d_best_kp; s2.bd = pd2.d_best_dist; s2.ids = reinterpret_cast<const unsigned*>(dp + q_idm); s2.map_kind = 1;
+    s2.nB = nm; s2.bk = pd2.d_best_kp; s2.bd = pd2.d_best_dist; s2.aux = reinterpret_cast<const uint4*>(D + o_auxm); s2.map_kind = 1;
     s2.carry = reinterpret_cast<const uh_dmatch*>(D + o_m1); s2.carry_src = reinterpret_cast<const int*>(D + o_src1); s2.carry_bad = reinterpret_cast<const unsigned char*>(D + o_bad1); s2.carry_cap = cap1;
     s2.fresh_n_slot = kTrkN2; s2.final_n_slot = kTrkNA;
+    if (trk_clk) s2.clk = T.d_clk.as<long long>() + 8;
     s2.fresh_out = reinterpret_cast<uh_dmatch*>(D + o_m2); s2.fresh_src = reinterpret_cast<int*>(D + o_src2); s2.final_out = reinterpret_cast<uh_dmatch*>(D + o_ma); s2.final_src = reinterpret_cast<int*>(D + o_srca);
-    s2.rec_prev = pd1.d_rec; s2.rec_map = pd2.d_rec;
-    s2.prev_map_row = a->prev_map_row ? reinterpret_cast<const int*>(dp + q_row) : nullptr; s2.map_weight = a->map_weight ? reinterpret_cast<const float*>(dp + q_w) : nullptr; s2.prefer_map_row = 1;
-    UH_LAUNCH(h->ctx, track_select_kernel, dim3(1), dim3(kTrkThreads), 0, s2);
+    s2.prefer_map_row = 1;
+    if (sel_in_lds) UH_LAUNCH(h->ctx, track_select_kernel<true>, dim3(1), dim3(kTrkThreads), sel_lds, s2, capa);
+    else UH_LAUNCH(h->ctx, track_select_kernel<false>, dim3(1), dim3(kTrkThreads), 0, s2, capa);
     if ((rc = uh::pnp_enqueue_dev(pnp, reinterpret_cast<const float*>(D + o_posem), reinterpret_cast<const float*>(dp + q_intr), capn, hdr + kTrkNA, s2.p3d, s2.kp, s2.isg, s2.wgt,
-                                  reinterpret_cast<float*>(D + o_pose2), reinterpret_cast<unsigned char*>(D + o_bada), hdr + kTrkRes2))) return rc;
+                                  reinterpret_cast<float*>(D + o_pose2), reinterpret_cast<unsigned char*>(D + o_bada), hdr + kTrkRes2, nullptr))) return rc;
     // ---- 3: everything back in one block
     char* ho = T.h_out.host<char>();
     char* dout = T.h_out.dev<char>();
@@ -331,6 +361,15 @@ int uh_track_pose(uh_projmatch* h, uh_pnp* pnp, const uh_track_args* a, uh_track
         return rc;
     }
     h->upload_pending = false;
+    if (trk_clk) {
+        long long c[16];
+        UH_HIP_CHECK(hipMemcpy(c, T.d_clk.p, sizeof(c), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 2; k++) {
+            const long long* q = c + 8 * k;
+            fprintf(stderr, "track_select %d [us]: stage %.2f  candidates %.2f  filter %.2f  outputs %.2f  union+filter %.2f  look-ups %.2f  total %.2f\n", k + 1, (q[1] - q[0]) * 0.01, (q[2] - q[1]) * 0.01,
+                    (q[3] - q[2]) * 0.01, (q[4] - q[3]) * 0.01, (q[5] - q[4]) * 0.01, (q[6] - q[5]) * 0.01, (q[6] - q[0]) * 0.01);
+        }
+    }
     // (both searches posted their own words and walk-overflow flags on the way: the stream is in order, they are long since visible)
     for (int sl = 0; sl < 2; sl++) {
         if ((sl == 0 && !np) || (sl == 1 && !nm)) continue;
