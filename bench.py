@@ -354,6 +354,14 @@ def main():
                 # uh_projmatch_set_frame_dev, csrc/kdbuild.hpp): identical results, no host CPU time for the tree, slower today
                 trk_dev = json.loads(subprocess.run([exe, "300", "30", "dev"], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
                 tracker["device_frame_route"] = {k: trk_dev[k] for k in ("tracker_frame_ms", "orb_extract_ms", "set_frame_ms", "match_prev_ms", "match_map_ms")}
+                # ... and with the four tracker calls (previous-frame search, solvePnp, local-map search, solvePnp) as ONE call on a resident frame whose tree the
+                # host core builds (uh_track_pose, csrc/track.hpp: list handling and look-ups on the device, six launches, one wait): identical results
+                trk_f = json.loads(subprocess.run([exe, "300", "30", "fused"], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
+                tracker["fused_route"] = {"tracker_frame_ms": trk_f["tracker_frame_ms"], "tracker_frames_per_s": trk_f["tracker_frames_per_s"], "orb_extract_ms": trk_f["orb_extract_ms"],
+                                          "set_frame_ms": trk_f["set_frame_ms"], "track_pose_ms": trk_f["match_prev_ms"],
+                                          "same_results": all(trk_f[k] == tracker[k] for k in ("keypoints", "matches_prev", "matches_map", "inliers1", "inliers2", "max_pose_err_vs_truth"))}
+                stage_ms["tracker_frame_ms_fused"] = trk_f["tracker_frame_ms"]
+                stage_ms["tracker_frames_per_s_fused"] = trk_f["tracker_frames_per_s"]
         except Exception as e_:
             print("tracker chain stage skipped:", repr(e_), file=sys.stderr)
         # single-frame latency, host in / host out, batch 1 (what a sequential caller sees): ORB of one pinned frame into pinned arrays, the
