@@ -317,6 +317,9 @@ void uh_dev_frame_destroy(uh_dev_frame* frame);
  * into the frame object — the descriptors still never cross the host link a second time.  Same tree, byte for byte; the faster route while a
  * core is free (Frame::create_kdtree, frameextractor.cpp:4258). */
 int  uh_dev_frame_set_tree_builder(uh_dev_frame* frame, int32_t on_host);
+/* a frame that was not extracted here (read from a file, made by another extractor) into a device frame object: n undistorted keypoints (x, y, octave
+ * are used) and their n x 32 descriptor bytes; the tree is built as for an extracted frame.  Synchronous — a utility, not the per-frame path. */
+int  uh_dev_frame_upload(uh_dev_frame* frame, const uh_keypoint* und_kpts, int32_t n, const uint8_t* desc);
 int  uh_orb_extract_frame_dev(uh_orb* orb, const uint8_t* img, int w, int h, size_t stride, int channels,
                               uh_keypoint* kps, uint8_t* desc, float* und_xy, int cap, int* n_out, uh_dev_frame* frame);
 int  uh_dev_frame_tree(uh_dev_frame* frame, int32_t* n_kpts, int32_t* n_nodes, void* nodes24_out, uint32_t* leaf_idx_out, float* leaf_xy_out,

@@ -241,6 +241,69 @@ def kd_case(seed):
 
 run("kdtree_device", kd_case)
 
+# ---- uh_track_pose (csrc/track.hpp): the tracker's pose estimation as one call against the four operators in sequence (bit for bit)
+from ucoslam_cv3_amd.orb import DeviceFrame
+from ucoslam_cv3_amd.pnp import PnPSolver as _TrkPnP
+from ucoslam_cv3_amd.projmatch import DMATCH_DTYPE as _DM
+_trk_pnp = _TrkPnP(ctx)
+_trk_frames = [DeviceFrame(ctx), DeviceFrame(ctx).setTreeBuilder(True)]
+
+def track_case(seed):
+    from ucoslam_cv3_amd._lib import lib, np_ptr
+    r = np.random.default_rng(seed)
+    nk, npt = int(r.integers(12, 4000)), int(r.integers(40, 5000))
+    le = bool(r.random() < 0.2)
+    fr, mp, pose = synth.proj_problem(nk, npt, seed % 100000, low_entropy=le, n_levels=int(r.integers(2, 9)), pose_noise=float(r.choice([0.0, 0.002, 0.02, 0.5])))
+    dfr = _trk_frames[int(r.integers(0, 2))]
+    dfr.upload(fr["und_kpts"], fr["desc"])
+    pm.setFrameDev(dfr, fr["scale_factors"], fr["fx"], fr["fy"], fr["cx"], fr["cy"], fr["min_xy"], fr["max_xy"], und_kpts=fr["und_kpts"])
+    # previous-frame items: a subset of the map points (some with ids outside the local map and a slightly different position)
+    n_prev = int(r.integers(0, min(npt, 1500)))
+    rows = np.sort(r.choice(npt, n_prev, replace=False)) if n_prev else np.zeros(0, np.int64)
+    in_map = r.random(n_prev) < 0.7
+    prev = dict(ids=np.where(in_map, mp["ids"][rows], 10 ** 6 + np.arange(n_prev)).astype(np.uint32), pos3d=(mp["pos3d"][rows] + r.normal(0, 0.002, (n_prev, 3))).astype(np.float32),
+                octave=mp["octave"][rows].astype(np.int32), desc=np.ascontiguousarray(mp["desc"][rows]))
+    prev_row = np.where(in_map, rows, -1).astype(np.int32)
+    weight = np.where(r.random(npt) < 0.2, np.float32(0.5), np.float32(1.0)).astype(np.float32)
+    intr = np.array([fr["fx"], fr["fy"], fr["cx"], fr["cy"]], np.float32)
+    inv_sf = (np.float32(1) / fr["scale_factors"]).astype(np.float32)
+    d1, r1 = (float(r.choice([3.0, 8.0])) if le else float(r.choice([100.0, 75.0]))), float(r.choice([7.5, 15.0, 40.0]))
+    d2, rt, rl = (8.0 if le else float(r.choice([100.0, 50.0]))), float(r.choice([4.0, 2.5])), float(r.choice([15.0, 40.0]))
+    mi = int(r.choice([30, 30, 5, 100000]))
+    ukp = fr["und_kpts"]
+    # the four operators
+    a = pm.matchFrameToPrevFrame(pose, prev["ids"], prev["pos3d"], prev["octave"], prev["desc"], d1, r1)
+    m1 = a["matches"]
+    pid = {int(v): i for i, v in enumerate(prev["ids"])}
+    it1 = np.array([pid[int(t)] for t in m1["trainIdx"]], np.int64)
+    q1 = m1["queryIdx"]
+    s1 = _trk_pnp.solvePnp(pose, intr, prev["pos3d"][it1].reshape(-1, 3), np.stack([ukp["x"][q1], ukp["y"][q1]], 1).reshape(-1, 2), inv_sf[ukp["octave"][q1]], np.ones(len(m1), np.float32))
+    tracked = s1["ngood"] >= mi
+    pose_map = s1["pose"] if tracked else pose
+    b = pm.matchFrameToMapPoints(pose_map, mp["ids"], mp["pos3d"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], d2, rt if tracked else rl)
+    m2 = b["matches"]
+    un = np.ascontiguousarray(np.concatenate([m1[s1["bad"][: len(m1)] == 0] if tracked else m1[:0], m2]).astype(_DM))
+    if len(un):
+        un = un[: lib().uh_filter_ambiguous(np_ptr(un), len(un), 0)]
+    mrow = {int(v): i for i, v in enumerate(mp["ids"])}
+    p3d = np.zeros((len(un), 3), np.float32); w = np.ones(len(un), np.float32)
+    for i, tr in enumerate(un["trainIdx"]):
+        row = mrow.get(int(tr), -1)
+        if row >= 0: p3d[i] = mp["pos3d"][row]; w[i] = weight[row]
+        else: p3d[i] = prev["pos3d"][pid[int(tr)]]
+    qa = un["queryIdx"]
+    s2 = _trk_pnp.solvePnp(pose_map, intr, p3d, np.stack([ukp["x"][qa], ukp["y"][qa]], 1).reshape(-1, 2), inv_sf[ukp["octave"][qa]], w)
+    # the one call
+    f = pm.trackPose(_trk_pnp, pose, intr, inv_sf, prev, mp, prev_map_row=prev_row, map_weight=weight, prev_min_desc_dist=d1, prev_max_repj_dist=r1, map_min_desc_dist=d2,
+                     map_radius_tracked=rt, map_radius_lost=rl, min_inliers=mi)
+    ok = (f["matches_prev"].tobytes() == m1.tobytes() and f["matches_map"].tobytes() == m2.tobytes() and f["matches_all"].tobytes() == un.tobytes()
+          and (f["bad_prev"] == s1["bad"][: len(m1)]).all() and (f["bad_all"] == s2["bad"][: len(un)]).all() and f["tracked"] == bool(tracked)
+          and f["inliers1"] == s1["ngood"] and f["inliers2"] == s2["ngood"] and (f["iters1"] == s1["iters"]).all() and (f["iters2"] == s2["iters"]).all()
+          and (len(m1) == 0 or f["pose1"].tobytes() == np.asarray(s1["pose"], np.float32).tobytes()) and f["pose2"].tobytes() == np.asarray(s2["pose"], np.float32).tobytes())
+    return ok, None if ok else (nk, npt, n_prev, le, mi, len(m1), len(m2), len(un))
+
+run("track_pose", track_case)
+
 # ---- BA and PnP (tolerance 1e-6 on the se3 state, identical iteration counts / flags)
 from ucoslam_cv3_amd.ba import GlobalOptimizer, ParamSet
 from ucoslam_cv3_amd.pnp import PnPSolver

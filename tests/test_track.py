@@ -157,6 +157,28 @@ def test_track_pose_when_the_first_solve_fails_and_with_empty_sets(hip_ctx):
 
 
 @pytest.mark.gpu
+def test_track_pose_on_a_frame_without_keypoints(hip_ctx):
+    """A blank image: no keypoints, hence no matches — both poses come back as the predicted one, as through the four operators."""
+    from ucoslam_cv3_amd.orb import Camera, DeviceFrame, FeatParams, ORBextractor
+    from ucoslam_cv3_amd.pnp import PnPSolver
+    from ucoslam_cv3_amd.projmatch import ProjectionMatcher
+
+    donor = _scene(hip_ctx, 5, True, n_prev=200, n_map=500)
+    ext = ORBextractor(hip_ctx)
+    ext.setCamera(Camera(718.856, 718.856, 607.19, 185.22, ()))
+    fr = DeviceFrame(hip_ctx).setTreeBuilder(True)
+    kps, desc, und = ext.extractFrameDev(np.full((376, 1241), 90, np.uint8), fr, FeatParams(maxFeatures=2000, nOctaveLevels=8, scaleFactor=1.2))
+    assert len(kps) == 0
+    pm = ProjectionMatcher(hip_ctx)
+    sf = (np.float32(1) / donor["inv_sf"]).astype(np.float32)
+    pm.setFrameDev(fr, sf, 718.856, 718.856, 607.19, 185.22, (0, 0), (1241, 376), und_kpts=kps)
+    pnp = PnPSolver(hip_ctx)
+    f = pm.trackPose(pnp, donor["pose0"], donor["intr"], donor["inv_sf"], donor["prev"], donor["mp"], prev_map_row=donor["prev_row"], map_weight=donor["weight"])
+    assert len(f["matches_prev"]) == 0 and len(f["matches_map"]) == 0 and len(f["matches_all"]) == 0 and not f["tracked"] and f["inliers1"] == 0 and f["inliers2"] == 0
+    assert f["pose1"].tobytes() == donor["pose0"].tobytes() and f["pose2"].tobytes() == donor["pose0"].tobytes()
+
+
+@pytest.mark.gpu
 def test_track_pose_needs_a_device_frame(hip_ctx):
     from ucoslam_cv3_amd._lib import UcoslamHipError
     from ucoslam_cv3_amd.pnp import PnPSolver

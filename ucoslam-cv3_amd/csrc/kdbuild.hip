@@ -155,6 +155,30 @@ int uh_dev_frame_set_tree_builder(uh_dev_frame* f, int32_t on_host) {
     return UH_OK;
 }
 
+// A frame that was not extracted here (read from a file, produced by another extractor) becomes a device frame: descriptors and undistorted
+// keypoints are uploaded, the tree is built as for an extracted one (the build launches, or later the host core: uh_dev_frame_set_tree_builder).
+// Synchronous (a utility, not the per-frame path).
+int uh_dev_frame_upload(uh_dev_frame* f, const uh_keypoint* und_kpts, int32_t n, const uint8_t* desc) {
+    UH_REQUIRE(f && n >= 0 && (n == 0 || (und_kpts && desc)), "uh_dev_frame_upload: bad arguments");
+    int rc = uh::dev_frame_reserve(f, std::max(n, 1));
+    if (rc) return rc;
+    UH_HIP_CHECK(hipSetDevice(f->ctx->device));
+    std::vector<float> in(4 * (size_t)std::max(n, 1));
+    for (int i = 0; i < n; i++) {
+        UH_REQUIRE(und_kpts[i].octave >= 0 && und_kpts[i].octave < 16, "uh_dev_frame_upload: octave %d of keypoint %d outside [0,16)", und_kpts[i].octave, i);
+        in[4 * (size_t)i] = und_kpts[i].x; in[4 * (size_t)i + 1] = und_kpts[i].y;
+        const int32_t o = und_kpts[i].octave;
+        std::memcpy(&in[4 * (size_t)i + 2], &o, 4); in[4 * (size_t)i + 3] = 0.f;
+    }
+    if (n) {
+        UH_HIP_CHECK(hipMemcpyAsync(f->kd_in(), in.data(), 16 * (size_t)n, hipMemcpyHostToDevice, f->ctx->stream));
+        UH_HIP_CHECK(hipMemcpyAsync(f->desc(), desc, 32 * (size_t)n, hipMemcpyHostToDevice, f->ctx->stream));
+    }
+    if (!f->host_tree && (rc = uh::kd_build_launch(f, nullptr, 0, 0, n))) return rc;
+    UH_HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
+    return UH_OK;
+}
+
 // test hook / inspection: the tree of the frame's latest extraction, copied to the host (waits for the build)
 int uh_dev_frame_tree(uh_dev_frame* f, int32_t* n_kpts, int32_t* n_nodes, void* nodes24_out, uint32_t* leaf_idx_out, float* leaf_xy_out,
                       int32_t* leaf_octave_out, double* root_box4, int32_t* max_depth) {

@@ -75,6 +75,7 @@ def _declare(L, sig):
     sig("uh_dev_frame_create", I, VP, C.POINTER(VP))
     sig("uh_dev_frame_destroy", None, VP)
     sig("uh_dev_frame_set_tree_builder", I, VP, C.c_int32)
+    sig("uh_dev_frame_upload", I, VP, VP, C.c_int32, VP)
     sig("uh_orb_extract_frame_dev", I, VP, VP, I, I, SZ, I, VP, VP, VP, I, C.POINTER(I), VP)
     sig("uh_dev_frame_tree", I, VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), VP, VP, VP, VP, VP, C.POINTER(C.c_int32))
 
@@ -94,6 +95,13 @@ class DeviceFrame:
         """Who builds the kd-tree: the build launches behind the extraction (False, default) or the host core inside
         ProjectionMatcher.setFrameDev(..., und_kpts=...) (True: no build launch; the descriptors stay on the device either way)."""
         check(lib().uh_dev_frame_set_tree_builder(self._h, 1 if on_host else 0))
+        return self
+
+    def upload(self, und_kpts, desc):
+        """uh_dev_frame_upload: a frame from elsewhere (KEYPOINT_DTYPE array with undistorted x / y, n x 32 descriptors) into this object."""
+        k = np.ascontiguousarray(und_kpts, KEYPOINT_DTYPE)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(len(k), 32)
+        check(lib().uh_dev_frame_upload(self._h, np_ptr(k) if len(k) else None, len(k), np_ptr(d) if len(k) else None))
         return self
 
     def tree(self):
