@@ -10,7 +10,7 @@ timeout 120 python scripts/ba_ab.py 10 3000 0 2 2>&1 | grep -v "^/opt" > $O/ba_a
 UH_KD_CLK=1 timeout 120 python scripts/time_kdbuild.py 2>&1 | grep -v "^/opt" > $O/time_kdbuild.txt
 UH_KM_TIMING=1 timeout 120 python scripts/time_hkmeans.py 2>&1 | grep -v "^/opt" | tail -12 > $O/time_hkmeans.txt
 timeout 120 python scripts/time_orb.py 2>&1 | grep -v "^/opt" > $O/time_orb.txt
-timeout 1500 python scripts/fuzz_parity.py 60 2>&1 | grep -v "^/opt" > $O/fuzz_all.txt
+timeout 1800 python scripts/fuzz_parity.py 60 2>&1 | grep -v "^/opt" > $O/fuzz_all.txt
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 1500 bash scripts/collect_profiles_r06.sh > $O/collect.log 2>&1
 find $R/gpurun_out/prof_r06 -name "*kernel_trace.csv" -delete

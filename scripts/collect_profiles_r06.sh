@@ -39,7 +39,11 @@ g++ -std=c++17 -O2 -o $EXE $R/examples/tracker_frame.cpp -L$R/ucoslam-cv3_amd -l
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/tracker -o trk -- $EXE 200 20 > $OUT/tracker.log 2>&1
 $EXE 300 30 > $OUT/tracker_plain.json 2>&1
 $EXE 300 30 dev > $OUT/tracker_dev_plain.json 2>&1
-rm -rf $OUT/tracker_dev $OUT/hkmeans
+$EXE 300 30 fused > $OUT/tracker_fused_plain.json 2>&1
+rm -rf $OUT/tracker_dev $OUT/hkmeans $OUT/tracker_fused
+timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/tracker_fused -o trk -- $EXE 200 20 fused > $OUT/tracker_fused.log 2>&1
+python $R/scripts/trace_gaps.py $OUT/tracker_fused ingest > $OUT/tracker_fused_timeline.txt 2>&1
+find $OUT/tracker_fused -name "*kernel_trace.csv" -delete
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/tracker_dev -o trk -- $EXE 200 20 dev > $OUT/tracker_dev.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $OUT/hkmeans -o hk -- python $R/scripts/time_hkmeans.py > $OUT/hkmeans.log 2>&1
 fi

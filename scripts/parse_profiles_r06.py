@@ -19,11 +19,20 @@ def first(pattern):
     return g[0] if g else None
 
 
-for sub, name in (("quick", "r06_quick_kernel_stats.csv"), ("tracker", "r06_tracker_kernel_stats.csv"), ("tracker_dev", "r06_tracker_dev_frame_kernel_stats.csv"), ("hkmeans", "r06_hkmeans_kernel_stats.csv"), ("chain", "r06_chain_kernel_stats.csv")):
+for sub, name in (("quick", "r06_quick_kernel_stats.csv"), ("tracker", "r06_tracker_kernel_stats.csv"), ("tracker_dev", "r06_tracker_dev_frame_kernel_stats.csv"), ("tracker_fused", "r06_tracker_fused_kernel_stats.csv"), ("hkmeans", "r06_hkmeans_kernel_stats.csv"), ("chain", "r06_chain_kernel_stats.csv")):
     f = first(os.path.join(src, sub, "**", "*kernel_stats.csv"))
     if f:
         shutil.copy(f, os.path.join("profiles", name))
         print("copied", f, "->", name)
+for nm, dst in (("tracker_fused_plain.json", "r06_tracker_frame_fused.json"),):
+    tpf = os.path.join(src, nm)
+    if os.path.exists(tpf):
+        line = [l for l in open(tpf).read().splitlines() if l.startswith("{")]
+        if line:
+            json.dump(json.loads(line[-1]), open(os.path.join("profiles", dst), "w"), indent=1)
+tl = os.path.join(src, "tracker_fused_timeline.txt")
+if os.path.exists(tl):
+    shutil.copy(tl, os.path.join("profiles", "r06_tracker_fused_timeline.txt"))
 tp = os.path.join(src, "tracker_plain.json")
 if os.path.exists(tp):
     line = [l for l in open(tp).read().splitlines() if l.startswith("{")]
