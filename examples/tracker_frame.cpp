@@ -245,14 +245,27 @@ int main(int argc, char** argv) {
         int n = 0;
         // FrameExtractor::process: detectAndCompute + undistortPoints(kpts, ImageParams) in one call (frameextractor.cpp:430-520, :3985;
         // misc.cpp:269-293) — Frame::und_kpts = the keypoints with the undistorted positions
+        double t1, t2;
+        if (fused_route) {
+            // the extraction in two halves: the undistorted keypoints (position + octave) come back as soon as the selection is done, the tree is
+            // built from them while the descriptors are still being computed
+            const uh_keypoint* early = nullptr;
+            CHECK(uh_orb_extract_frame_dev_begin(ext, sc.image, W, H, W, 1, kps, desc, und_xy, NFEAT, &n, dfr, &early));
+            t1 = now_us();
+            const uh_proj_frame fre{early, n, desc, sf, NLEV, FX, FY, CX, CY, 0, 0, W, H};
+            CHECK(uh_projmatch_set_frame_dev(pm, dfr, &fre));
+            CHECK(uh_orb_extract_frame_dev_end(ext, &n));
+            t2 = now_us();
+        } else {
         if (dev_route) CHECK(uh_orb_extract_frame_dev(ext, sc.image, W, H, W, 1, kps, desc, und_xy, NFEAT, &n, dfr));
         else CHECK(uh_orb_extract_frame(ext, sc.image, W, H, W, 1, kps, desc, und_xy, NFEAT, &n));
         for (int i = 0; i < n; i++) { kps[i].x = und_xy[2 * i]; kps[i].y = und_xy[2 * i + 1]; }
-        const double t1 = now_us();
+        t1 = now_us();
         const uh_proj_frame fr{kps, n, desc, sf, NLEV, FX, FY, CX, CY, 0, 0, W, H};
         if (dev_route) CHECK(uh_projmatch_set_frame_dev(pm, dfr, &fr));
         else CHECK(uh_projmatch_set_frame(pm, &fr));
-        const double t2 = now_us();
+        t2 = now_us();
+        }
         const uh_prev_points pp{(int32_t)sc.prev_ids.size(), sc.prev_ids.data(), sc.prev_pos.data(), sc.prev_oct.data(), sc.prev_desc.data()};
         if (fused_route) {
             const size_t si = (size_t)((it + warmup) % NSCENES);

@@ -322,6 +322,13 @@ int  uh_dev_frame_set_tree_builder(uh_dev_frame* frame, int32_t on_host);
 int  uh_dev_frame_upload(uh_dev_frame* frame, const uh_keypoint* und_kpts, int32_t n, const uint8_t* desc);
 int  uh_orb_extract_frame_dev(uh_orb* orb, const uint8_t* img, int w, int h, size_t stride, int channels,
                               uh_keypoint* kps, uint8_t* desc, float* und_xy, int cap, int* n_out, uh_dev_frame* frame);
+/* the same call in two halves: _begin returns as soon as the undistorted keypoints — x, y, octave; the other fields come with _end — are on the host
+ * (*und_kpts_early: this object's array, valid until the next extraction), so that the caller builds the kd-tree (uh_projmatch_set_frame_dev with
+ * uh_dev_frame_set_tree_builder(frame, 1)) while the descriptors are still being computed; _end completes kps / desc / und_xy.  No other
+ * extraction on this object in between. */
+int  uh_orb_extract_frame_dev_begin(uh_orb* orb, const uint8_t* img, int w, int h, size_t stride, int channels,
+                                    uh_keypoint* kps, uint8_t* desc, float* und_xy, int cap, int* n_out, uh_dev_frame* frame, const uh_keypoint** und_kpts_early);
+int  uh_orb_extract_frame_dev_end(uh_orb* orb, int* n_out);
 int  uh_dev_frame_tree(uh_dev_frame* frame, int32_t* n_kpts, int32_t* n_nodes, void* nodes24_out, uint32_t* leaf_idx_out, float* leaf_xy_out,
                        int32_t* leaf_octave_out, double* root_box4, int32_t* max_depth);
 /* `batch` frames resident in HBM (frame f at d_imgs + f*frame_stride); outputs per frame at

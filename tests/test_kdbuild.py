@@ -244,6 +244,15 @@ def test_frame_stays_on_the_device_between_extractor_and_projection_matcher(hip_
     hyb.setFrameDev(fr_h, sf, cam.fx, cam.fy, cam.cx, cam.cy, (0, 0), (1241, 376), und_kpts=ukp)   # again: the staging block is reused behind its completion word
     b = hyb.matchFrameToPrevFrame(pose, mp["ids"], mp["pos3d"], mp["octave"], mp["desc"], 75.0, 15.0)
     np.testing.assert_array_equal(a["matches"], b["matches"])
+    # the extraction in two halves: the undistorted keypoints (position + octave) arrive ahead of the descriptors, the tree is built from them
+    early = ext.extractFrameDevBegin(img, fr_h, fp)
+    hyb.setFrameDev(fr_h, sf, cam.fx, cam.fy, cam.cx, cam.cy, (0, 0), (1241, 376), und_kpts=early)
+    kps_e, desc_e, und_e = ext.extractFrameDevEnd()
+    np.testing.assert_array_equal(kps_e, kps0); np.testing.assert_array_equal(desc_e, desc0); np.testing.assert_array_equal(und_e, und0)
+    np.testing.assert_array_equal(np.stack([early["x"], early["y"]], 1), und0)
+    np.testing.assert_array_equal(early["octave"], kps0["octave"])
+    b = hyb.matchFrameToPrevFrame(pose, mp["ids"], mp["pos3d"], mp["octave"], mp["desc"], 75.0, 15.0)
+    np.testing.assert_array_equal(a["matches"], b["matches"])
     # a second extraction into the same frame object replaces it (and an empty image yields the empty frame)
     img2 = synth.frame(1241, 376, seed=6, shift=(3, 1))
     kps2, desc2, und2 = ext.extractFrameDev(img2, fr, fp)

@@ -1289,6 +1289,42 @@ __device__ __forceinline__ void describe_slot(const Plan& plan, const uint8_t* _
     }
 }
 
+// uh_orb_extract_frame_dev_begin: the frame's undistorted keypoints (position + octave: what Frame::create_kdtree needs) leave for the host
+// as soon as the selection is done — one workgroup, behind select_kernel and in front of describe_kernel — with a completion word of their
+// own, so that the host builds the kd-tree while the descriptors are still being computed.  Same float expressions as describe_slot /
+// describe_kernel's third wave (the final values are written again there, identically).
+struct EarlyUnd { KeyPointOut* kpts; int* count; unsigned long long* word_ptr; unsigned long long word; int cap; };
+__global__ __launch_bounds__(1024) void und_early_kernel(const Plan plan, const uint32_t* __restrict__ sel, const int* __restrict__ lc, const CamModel cam, const EarlyUnd ea) {
+    __shared__ int s_base[kMaxLevels + 1], s_off[kMaxLevels];
+    __shared__ float s_scale[kMaxLevels];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int b = 0;
+        for (int l = 0; l < plan.nlevels; l++) { s_base[l] = b; b += lc[l]; }
+        for (int l = plan.nlevels; l <= kMaxLevels; l++) s_base[l] = b;
+    }
+    if (tid < plan.nlevels) { s_off[tid] = plan.lv[tid].sel_off; s_scale[tid] = plan.lv[tid].scale; }
+    __syncthreads();
+    const int total = s_base[plan.nlevels], limit = total < ea.cap ? total : ea.cap;
+    for (int slot = tid; slot < limit; slot += 1024) {
+        int lvl = 0;
+        while (slot >= s_base[lvl + 1]) ++lvl;
+        const uint32_t e = sel[s_off[lvl] + (slot - s_base[lvl])];
+        const int cx = e & 0xFFF, cy = (e >> 12) & 0xFFF;
+        float kx = (float)cx, ky = (float)cy;
+        if (lvl != 0) { kx = (kx + 0.5f) * s_scale[lvl]; ky = (ky + 0.5f) * s_scale[lvl]; }
+        float ux, uy;
+        undistort_point(cam, kx, ky, ux, uy);
+        KeyPointOut k;
+        k.x = ux; k.y = uy; k.size = 0.f; k.angle = 0.f; k.response = 0.f; k.octave = lvl; k.class_id = -1;
+        ea.kpts[slot] = k;
+    }
+    if (tid == 0) *ea.count = total;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // every thread: its stores into pinned memory before the word
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(ea.word_ptr, ea.word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 inline int cvRoundf(float v) { return (int)lrintf(v); }
 inline int cvFloord(double v) { int i = (int)v; return i - (i > v); }
@@ -1348,6 +1384,15 @@ struct uh_orb {
     bool score_valid = false;      // d_score holds the last extraction's strength maps (uh_orb_debug_level computes them on demand)
     // staging for the host-pointer API
     uh::DevBuf d_in, d_kps, d_desc, d_counts;
+    uh::MappedBuf h_early;         // uh_orb_extract_frame_dev_begin: [completion word | count | undistorted keypoints (position + octave)]
+    unsigned long long early_seq = 0;
+    struct Pending {               // between uh_orb_extract_frame_dev_begin and _end
+        bool active = false, direct = false, und_direct = false;
+        unsigned long long word = 0;
+        uh_keypoint* kps = nullptr; uint8_t* desc = nullptr; float* und_xy = nullptr;
+        int cap = 0;
+        size_t o_cnt = 0, o_kps = 0, o_desc = 0, o_und = 0;
+    } pending;
     uh::MappedBuf h_out;           // one-frame form: [completion word | count | keypoints | descriptors] when the caller's buffers are not pinned
     unsigned long long seq = 0;
     CamModel cam{};                // uh_orb_set_camera: on = 1 -> the one-frame entry can return the undistorted keypoints
@@ -1652,7 +1697,7 @@ int make_plan(uh_orb* o, int w, int h, int batch) {
 }
 
 int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, size_t img_frame_stride, int batch,
-               KeyPointOut* d_kps, uint8_t* d_desc, int cap_per_frame, int* d_counts, float* d_und = nullptr, uh_dev_frame* fr = nullptr) {
+               KeyPointOut* d_kps, uint8_t* d_desc, int cap_per_frame, int* d_counts, float* d_und = nullptr, uh_dev_frame* fr = nullptr, const EarlyUnd* early = nullptr) {
     int rc;
     if (!o->planned || o->w != w || o->h != h || o->batch < batch) {
         if ((rc = make_plan(o, w, h, std::max(batch, o->planned && o->w == w && o->h == h ? o->batch : 0)))) return rc;
@@ -1734,6 +1779,8 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
         }
         UH_LAUNCH(o->ctx,nonmax_kernel, dim3(P.nlevels, batch), dim3(64), lds, P, o->d_sel.as<uint32_t>(), o->sel_stride, o->d_level_counts.as<int>());
     }
+    if (early)   // (one frame: the undistorted keypoints to the host ahead of the descriptors)
+        UH_LAUNCH(o->ctx, und_early_kernel, dim3(1), dim3(1024), 0, P, (const uint32_t*)o->d_sel.as<uint32_t>(), (const int*)o->d_level_counts.as<int>(), o->cam, *early);
     const int slots = std::min(std::max(P.maxFeatures, 1), std::max(cap_per_frame, 1));
     UH_LAUNCH(o->ctx,describe_kernel, dim3(uh_div_up(slots, 4) * batch), dim3(256), 0, P, pyr, o->frame_stride,
                        o->d_sel.as<uint32_t>(), o->sel_stride, o->d_level_counts.as<int>(), d_kps, d_desc, cap_per_frame,
@@ -1866,10 +1913,15 @@ int uh_orb_extract_dev(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t st
                       cap_per_frame, d_counts);
 }
 
+static int extract_finish(uh_orb* o, int* n_out);
+
+// early != NULL: return as soon as the undistorted keypoints are on the host (*early = this object's array of them); uh_orb_extract_frame_dev_end completes the call
 static int extract_one(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, int cn, uh_keypoint* kps, uint8_t* desc, float* und_xy, int cap,
-                       int* n_out, uh_dev_frame* fr = nullptr) {
+                       int* n_out, uh_dev_frame* fr = nullptr, const uh_keypoint** early = nullptr) {
     UH_REQUIRE(o && n_out, "uh_orb_extract: NULL argument");
+    UH_REQUIRE(!o->pending.active, "uh_orb_extract: uh_orb_extract_frame_dev_begin without its _end");
     *n_out = 0;
+    if (early) *early = nullptr;
     if (img == nullptr || w <= 0 || h <= 0) {   // ORBextractor.cpp:1254 — empty image: silent return (a device frame becomes the empty frame)
         if (fr) { int rc0 = uh::dev_frame_reserve(fr, 1); if (rc0 || (!fr->host_tree && (rc0 = uh::kd_build_launch(fr, nullptr, 0, 0, 0)))) return rc0; }
         return UH_OK;
@@ -1935,7 +1987,14 @@ static int extract_one(uh_orb* o, const uint8_t* img, int w, int h, size_t strid
     const bool und_direct = d_und && (reinterpret_cast<uintptr_t>(d_und) & 7) == 0 && (direct || cap >= maxk);
     if ((und_xy || fr) && !und_direct) d_und = reinterpret_cast<float*>(db + o_und);
     const int cap_launch = direct ? slots : maxk;
-    rc = run_frames(o, d_img, w, h, in_stride, (size_t)in_stride * h, 1, d_kps, d_desc, cap_launch, reinterpret_cast<int*>(db + o_cnt), d_und, fr);
+    EarlyUnd ea{};
+    if (early) {
+        if ((rc = o->h_early.reserve(128 + (size_t)maxk * sizeof(uh_keypoint)))) return rc;
+        char* de = o->h_early.dev<char>();
+        ea.kpts = reinterpret_cast<KeyPointOut*>(de + 128); ea.count = reinterpret_cast<int*>(de + 64); ea.word_ptr = reinterpret_cast<unsigned long long*>(de);
+        ea.word = ++o->early_seq; ea.cap = cap_launch;
+    }
+    rc = run_frames(o, d_img, w, h, in_stride, (size_t)in_stride * h, 1, d_kps, d_desc, cap_launch, reinterpret_cast<int*>(db + o_cnt), d_und, fr, early ? &ea : nullptr);
     if (rc) return rc;
     // the completion word as its own one-thread launch behind the last kernel (a ticket counter inside describe_kernel — one system-scope
     // release and one same-address atomic per workgroup — cost 10 us more than this launch)
@@ -1944,15 +2003,36 @@ static int extract_one(uh_orb* o, const uint8_t* img, int w, int h, size_t strid
     // Frame::create_kdtree (frameextractor.cpp:4258) as one more launch BEHIND the completion word: the host gets its keypoints and goes on
     // while the tree is built; the projection matcher adopts it with uh_projmatch_set_frame_dev (no D2H -> host build -> H2D)
     if (fr && !fr->host_tree && (rc = uh::kd_build_launch(fr, o->d_level_counts.as<int>(), o->plan.nlevels, cap_launch, 0))) return rc;
-    if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(hb), word, st, "uh_orb_extract"))) return rc;
-    const int n = *reinterpret_cast<const int*>(hb + o_cnt);
-    *n_out = n;
-    if (n > cap) { uh::set_error("uh_orb_extract: %d keypoints but capacity %d", n, cap); return UH_ECAPACITY; }
-    if (!direct && n > 0) {
-        std::memcpy(kps, hb + o_kps, (size_t)n * sizeof(uh_keypoint));
-        std::memcpy(desc, hb + o_desc, (size_t)n * 32);
+    uh_orb::Pending& pd = o->pending;
+    pd.active = true; pd.direct = direct; pd.und_direct = und_direct; pd.word = word; pd.kps = kps; pd.desc = desc; pd.und_xy = und_xy; pd.cap = cap;
+    pd.o_cnt = o_cnt; pd.o_kps = o_kps; pd.o_desc = o_desc; pd.o_und = o_und;
+    if (early) {   // the keypoints' undistorted positions and octaves are enough for the caller to go on with (the kd-tree): the rest is collected by _end
+        char* he = o->h_early.host<char>();
+        if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(he), ea.word, st, "uh_orb_extract_frame_dev_begin"))) { pd.active = false; return rc; }
+        const int n = *reinterpret_cast<const int*>(he + 64);
+        *n_out = n;
+        *early = reinterpret_cast<const uh_keypoint*>(he + 128);
+        if (n > cap) { pd.active = false; (void)hipStreamSynchronize(st); uh::set_error("uh_orb_extract: %d keypoints but capacity %d", n, cap); return UH_ECAPACITY; }
+        return UH_OK;
     }
-    if (und_xy && !und_direct && n > 0) std::memcpy(und_xy, hb + o_und, (size_t)n * 8);
+    return extract_finish(o, n_out);
+}
+
+static int extract_finish(uh_orb* o, int* n_out) {
+    uh_orb::Pending& pd = o->pending;
+    UH_REQUIRE(pd.active, "uh_orb_extract_frame_dev_end: no extraction in flight");
+    pd.active = false;
+    char* hb = o->h_out.host<char>();
+    int rc;
+    if ((rc = uh::wait_host_word(reinterpret_cast<volatile unsigned long long*>(hb), pd.word, o->ctx->stream, "uh_orb_extract"))) return rc;
+    const int n = *reinterpret_cast<const int*>(hb + pd.o_cnt);
+    if (n_out) *n_out = n;
+    if (n > pd.cap) { uh::set_error("uh_orb_extract: %d keypoints but capacity %d", n, pd.cap); return UH_ECAPACITY; }
+    if (!pd.direct && n > 0) {
+        std::memcpy(pd.kps, hb + pd.o_kps, (size_t)n * sizeof(uh_keypoint));
+        std::memcpy(pd.desc, hb + pd.o_desc, (size_t)n * 32);
+    }
+    if (pd.und_xy && !pd.und_direct && n > 0) std::memcpy(pd.und_xy, hb + pd.o_und, (size_t)n * 8);
     return UH_OK;
 }
 
@@ -1967,6 +2047,20 @@ int uh_orb_extract_frame_dev(uh_orb* o, const uint8_t* img, int w, int h, size_t
                              int cap, int* n_out, uh_dev_frame* frame) {
     UH_REQUIRE(frame, "uh_orb_extract_frame_dev: NULL device frame");
     return extract_one(o, img, w, h, stride, channels, kps, desc, und_xy, cap, n_out, frame);
+}
+// uh_orb_extract_frame_dev in two halves: _begin returns as soon as the undistorted keypoints (position + octave; the other fields are not
+// filled in yet) are on the host — *und_kpts_early points at this object's array of them, valid until the next extraction — so that the
+// caller builds the kd-tree (uh_projmatch_set_frame_dev with a host-built tree) while describe_kernel still runs; _end waits for the
+// descriptors / keypoints / und_xy the _begin call was given buffers for.  Nothing else may be extracted in between.
+int uh_orb_extract_frame_dev_begin(uh_orb* o, const uint8_t* img, int w, int h, size_t stride, int channels, uh_keypoint* kps, uint8_t* desc, float* und_xy,
+                                   int cap, int* n_out, uh_dev_frame* frame, const uh_keypoint** und_kpts_early) {
+    UH_REQUIRE(frame && und_kpts_early, "uh_orb_extract_frame_dev_begin: NULL argument");
+    return extract_one(o, img, w, h, stride, channels, kps, desc, und_xy, cap, n_out, frame, und_kpts_early);
+}
+int uh_orb_extract_frame_dev_end(uh_orb* o, int* n_out) {
+    UH_REQUIRE(o, "uh_orb_extract_frame_dev_end: NULL extractor");
+    if (!o->pending.active) return UH_OK;   // (an empty image: _begin had nothing to launch)
+    return extract_finish(o, n_out);
 }
 int uh_orb_set_camera(uh_orb* o, const uh_camera* cam) {
     UH_REQUIRE(o, "uh_orb_set_camera: NULL extractor");

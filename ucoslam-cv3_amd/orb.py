@@ -77,6 +77,8 @@ def _declare(L, sig):
     sig("uh_dev_frame_set_tree_builder", I, VP, C.c_int32)
     sig("uh_dev_frame_upload", I, VP, VP, C.c_int32, VP)
     sig("uh_orb_extract_frame_dev", I, VP, VP, I, I, SZ, I, VP, VP, VP, I, C.POINTER(I), VP)
+    sig("uh_orb_extract_frame_dev_begin", I, VP, VP, I, I, SZ, I, VP, VP, VP, I, C.POINTER(I), VP, C.POINTER(VP))
+    sig("uh_orb_extract_frame_dev_end", I, VP, C.POINTER(I))
     sig("uh_dev_frame_tree", I, VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), VP, VP, VP, VP, VP, C.POINTER(C.c_int32))
 
 
@@ -196,6 +198,30 @@ class ORBextractor:
         """extractFrame that also leaves the frame (descriptors, undistorted keypoints, kd-tree) in `frame` on the device
         (uh_orb_extract_frame_dev); same host outputs."""
         return self.extractFrame(image, params, True, frame)
+
+    def extractFrameDevBegin(self, image, frame: "DeviceFrame", params: FeatParams | None = None):
+        """First half of extractFrameDev (uh_orb_extract_frame_dev_begin): returns the undistorted keypoints — x, y, octave only — as soon as the
+        selection is done; build the tree with them (ProjectionMatcher.setFrameDev(..., und_kpts=...)), then call extractFrameDevEnd()."""
+        if params is not None:
+            check(lib().uh_orb_set_params(self._h, C.byref(params)))
+        img = np.ascontiguousarray(image)
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        cap = max(lib().uh_orb_max_keypoints(self._h), 1)
+        self._pend = (np.zeros(cap, KEYPOINT_DTYPE), np.zeros((cap, 32), np.uint8), np.zeros((cap, 2), np.float32), img)
+        n, early = C.c_int(0), VP()
+        check(lib().uh_orb_extract_frame_dev_begin(self._h, np_ptr(img), img.shape[1], img.shape[0], img.strides[0], cn, np_ptr(self._pend[0]), np_ptr(self._pend[1]),
+                                                   np_ptr(self._pend[2]), cap, C.byref(n), frame._h, C.byref(early)))
+        if not n.value:
+            return np.zeros(0, KEYPOINT_DTYPE)
+        return np.frombuffer((C.c_char * (n.value * KEYPOINT_DTYPE.itemsize)).from_address(early.value), KEYPOINT_DTYPE).copy()
+
+    def extractFrameDevEnd(self):
+        """Second half: (keypoints, descriptors, und_xy) of the extraction extractFrameDevBegin started."""
+        n = C.c_int(0)
+        check(lib().uh_orb_extract_frame_dev_end(self._h, C.byref(n)))
+        kps, desc, und, _ = self._pend
+        self._pend = None
+        return kps[: n.value].copy(), desc[: n.value].copy(), und[: n.value].copy()
 
     def extractFrame(self, image, params: FeatParams | None = None, undistorted=True, _frame=None):
         """The frame as the camera delivers it (H x W gray, H x W x 3 BGR or H x W x 4 BGRA, uint8) -> (keypoints, descriptors, und_xy):
