@@ -1293,10 +1293,15 @@ __device__ __forceinline__ void describe_slot(const Plan& plan, const uint8_t* _
 // as soon as the selection is done — one workgroup, behind select_kernel and in front of describe_kernel — with a completion word of their
 // own, so that the host builds the kd-tree while the descriptors are still being computed.  Same float expressions as describe_slot /
 // describe_kernel's third wave (the final values are written again there, identically).
-struct EarlyUnd { KeyPointOut* kpts; int* count; unsigned long long* word_ptr; unsigned long long word; int cap; };
-__global__ __launch_bounds__(1024) void und_early_kernel(const Plan plan, const uint32_t* __restrict__ sel, const int* __restrict__ lc, const CamModel cam, const EarlyUnd ea) {
+struct EarlyUnd { KeyPointOut* kpts; int* count; unsigned long long* word_ptr; unsigned long long word; int cap; unsigned* ticket; };
+constexpr int kEarlyThreads = 256, kEarlyGroups = 8;   // (cv::undistortPoints' five double-precision iterations for 2000 points on ONE compute unit were 7 us)
+__global__ __launch_bounds__(kEarlyThreads) void und_early_kernel(const Plan plan, const uint32_t* __restrict__ sel, const int* __restrict__ lc, const CamModel cam, const EarlyUnd ea) {
     __shared__ int s_base[kMaxLevels + 1], s_off[kMaxLevels];
     __shared__ float s_scale[kMaxLevels];
+    __shared__ unsigned s_last;
+    // 256 records at a time through LDS: they leave as 16-byte stores of consecutive lanes (28-byte records written field by field are one small
+    // host-link write each)
+    __shared__ __attribute__((aligned(16))) KeyPointOut s_rec[kEarlyThreads];
     const int tid = threadIdx.x;
     if (tid == 0) {
         int b = 0;
@@ -1306,23 +1311,39 @@ __global__ __launch_bounds__(1024) void und_early_kernel(const Plan plan, const 
     if (tid < plan.nlevels) { s_off[tid] = plan.lv[tid].sel_off; s_scale[tid] = plan.lv[tid].scale; }
     __syncthreads();
     const int total = s_base[plan.nlevels], limit = total < ea.cap ? total : ea.cap;
-    for (int slot = tid; slot < limit; slot += 1024) {
-        int lvl = 0;
-        while (slot >= s_base[lvl + 1]) ++lvl;
-        const uint32_t e = sel[s_off[lvl] + (slot - s_base[lvl])];
-        const int cx = e & 0xFFF, cy = (e >> 12) & 0xFFF;
-        float kx = (float)cx, ky = (float)cy;
-        if (lvl != 0) { kx = (kx + 0.5f) * s_scale[lvl]; ky = (ky + 0.5f) * s_scale[lvl]; }
-        float ux, uy;
-        undistort_point(cam, kx, ky, ux, uy);
-        KeyPointOut k;
-        k.x = ux; k.y = uy; k.size = 0.f; k.angle = 0.f; k.response = 0.f; k.octave = lvl; k.class_id = -1;
-        ea.kpts[slot] = k;
+    for (int s0 = (int)blockIdx.x * kEarlyThreads; s0 < limit; s0 += (int)gridDim.x * kEarlyThreads) {
+        const int slot = s0 + tid;
+        if (slot < limit) {
+            int lvl = 0;
+            while (slot >= s_base[lvl + 1]) ++lvl;
+            const uint32_t e = sel[s_off[lvl] + (slot - s_base[lvl])];
+            const int cx = e & 0xFFF, cy = (e >> 12) & 0xFFF;
+            float kx = (float)cx, ky = (float)cy;
+            if (lvl != 0) { kx = (kx + 0.5f) * s_scale[lvl]; ky = (ky + 0.5f) * s_scale[lvl]; }
+            float ux, uy;
+            undistort_point(cam, kx, ky, ux, uy);
+            KeyPointOut k;
+            k.x = ux; k.y = uy; k.size = 0.f; k.angle = 0.f; k.response = 0.f; k.octave = lvl; k.class_id = -1;
+            s_rec[tid] = k;
+        }
+        __syncthreads();
+        const int cnt = min(kEarlyThreads, limit - s0);
+        const int n16 = (cnt * (int)sizeof(KeyPointOut) + 15) / 16;   // (s0 * 28 is a multiple of 16: 256 * 28 = 16 * 448; the tail's padding bytes stay inside the block)
+        uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<char*>(ea.kpts) + (size_t)s0 * sizeof(KeyPointOut));
+        const uint4* src = reinterpret_cast<const uint4*>(s_rec);
+        for (int i = tid; i < n16; i += kEarlyThreads) dst[i] = src[i];
+        __syncthreads();
     }
-    if (tid == 0) *ea.count = total;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // every thread: its stores into pinned memory before the word
+    // every workgroup releases its stores into pinned memory, then takes a ticket; the last one posts the count and the word
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(ea.word_ptr, ea.word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) s_last = __hip_atomic_fetch_add(ea.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last && tid == 0) {
+        __hip_atomic_store(ea.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *ea.count = total;
+        __hip_atomic_store(ea.word_ptr, ea.word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1384,6 +1405,7 @@ struct uh_orb {
     bool score_valid = false;      // d_score holds the last extraction's strength maps (uh_orb_debug_level computes them on demand)
     // staging for the host-pointer API
     uh::DevBuf d_in, d_kps, d_desc, d_counts;
+    uh::DevBuf d_early_ticket;     // und_early_kernel's workgroup counter (0 between launches)
     uh::MappedBuf h_early;         // uh_orb_extract_frame_dev_begin: [completion word | count | undistorted keypoints (position + octave)]
     unsigned long long early_seq = 0;
     struct Pending {               // between uh_orb_extract_frame_dev_begin and _end
@@ -1780,7 +1802,7 @@ int run_frames(uh_orb* o, const uint8_t* d_imgs, int w, int h, size_t stride, si
         UH_LAUNCH(o->ctx,nonmax_kernel, dim3(P.nlevels, batch), dim3(64), lds, P, o->d_sel.as<uint32_t>(), o->sel_stride, o->d_level_counts.as<int>());
     }
     if (early)   // (one frame: the undistorted keypoints to the host ahead of the descriptors)
-        UH_LAUNCH(o->ctx, und_early_kernel, dim3(1), dim3(1024), 0, P, (const uint32_t*)o->d_sel.as<uint32_t>(), (const int*)o->d_level_counts.as<int>(), o->cam, *early);
+        UH_LAUNCH(o->ctx, und_early_kernel, dim3(kEarlyGroups), dim3(kEarlyThreads), 0, P, (const uint32_t*)o->d_sel.as<uint32_t>(), (const int*)o->d_level_counts.as<int>(), o->cam, *early);
     const int slots = std::min(std::max(P.maxFeatures, 1), std::max(cap_per_frame, 1));
     UH_LAUNCH(o->ctx,describe_kernel, dim3(uh_div_up(slots, 4) * batch), dim3(256), 0, P, pyr, o->frame_stride,
                        o->d_sel.as<uint32_t>(), o->sel_stride, o->d_level_counts.as<int>(), d_kps, d_desc, cap_per_frame,
@@ -1989,10 +2011,15 @@ static int extract_one(uh_orb* o, const uint8_t* img, int w, int h, size_t strid
     const int cap_launch = direct ? slots : maxk;
     EarlyUnd ea{};
     if (early) {
-        if ((rc = o->h_early.reserve(128 + (size_t)maxk * sizeof(uh_keypoint)))) return rc;
+        if ((rc = o->h_early.reserve(128 + (size_t)maxk * sizeof(uh_keypoint) + 64))) return rc;
         char* de = o->h_early.dev<char>();
         ea.kpts = reinterpret_cast<KeyPointOut*>(de + 128); ea.count = reinterpret_cast<int*>(de + 64); ea.word_ptr = reinterpret_cast<unsigned long long*>(de);
         ea.word = ++o->early_seq; ea.cap = cap_launch;
+        if (!o->d_early_ticket.p) {
+            if ((rc = o->d_early_ticket.reserve(64))) return rc;
+            UH_HIP_CHECK(hipMemsetAsync(o->d_early_ticket.p, 0, 64, st));
+        }
+        ea.ticket = o->d_early_ticket.as<unsigned>();
     }
     rc = run_frames(o, d_img, w, h, in_stride, (size_t)in_stride * h, 1, d_kps, d_desc, cap_launch, reinterpret_cast<int*>(db + o_cnt), d_und, fr, early ? &ea : nullptr);
     if (rc) return rc;
