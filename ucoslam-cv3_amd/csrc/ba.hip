@@ -37,6 +37,7 @@
 #include <functional>
 #include <cstdio>
 #include <emmintrin.h>
+#include <immintrin.h>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -2914,6 +2915,36 @@ static PersistPlan plan_persistent(uh_ba* b, int K, int P, int E, int nfree) {
 // pack(e0, e1, as16, exact, oob): writes observation records [e0, e1) (e0 even) into the staging block in the 16- or 24-byte form; clears `exact`
 // when a scalar does not survive the 16-byte form, sets `oob` on an index out of range.  NULL: the records are in the block already (24-byte form
 // unless obs16).  With a packer the records leave in TWO ingest launches, the first running over the host link while the second half is packed.
+// The 16-byte observation records eight at a time where the host has AVX-512 (round 6; the SSE loop below packs two per step): same records,
+// same range test (sign bits of i and n - 1 - i OR-ed over the range), same exactness test of the information scalars.
+// Returns the number of observations packed (a multiple of eight, from e0).
+__attribute__((target("avx512f,avx512vl,avx512dq"))) static int pack_obs16_avx512(const int32_t* pt_, const int32_t* kf_, const float* uv_, const double* w_, int e0, int e1, int P, int K,
+                                                                                 unsigned char* ob, bool& exact_out, unsigned& oob) {
+    const __m256i pmax = _mm256_set1_epi32(P - 1), kmax = _mm256_set1_epi32(K - 1);
+    __m256i bad = _mm256_setzero_si256();
+    __mmask8 exact = 0xFF;
+    const __m512i idx0 = _mm512_setr_epi32(0, 16, 17, 8, 1, 18, 19, 9, 2, 20, 21, 10, 3, 22, 23, 11);
+    const __m512i idx1 = _mm512_setr_epi32(4, 24, 25, 12, 5, 26, 27, 13, 6, 28, 29, 14, 7, 30, 31, 15);
+    int i = e0;
+    unsigned char* dst = ob + 16 * (size_t)e0;
+    for (; i + 8 <= e1; i += 8, dst += 128) {
+        const __m256i pt = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(pt_ + i));
+        const __m256i kf = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(kf_ + i));
+        const __m512 uv = _mm512_loadu_ps(uv_ + 2 * i);
+        const __m512d w = _mm512_loadu_pd(w_ + i);
+        bad = _mm256_or_si256(bad, _mm256_or_si256(_mm256_or_si256(pt, _mm256_sub_epi32(pmax, pt)), _mm256_or_si256(kf, _mm256_sub_epi32(kmax, kf))));
+        const __m256 wf = _mm512_cvtpd_ps(w);
+        exact &= _mm512_cmp_pd_mask(_mm512_cvtps_pd(wf), w, _CMP_EQ_OQ);
+        const __m256i pk = _mm256_or_si256(pt, _mm256_slli_epi32(kf, 24));
+        const __m512 a = _mm512_insertf32x8(_mm512_castps256_ps512(_mm256_castsi256_ps(pk)), wf, 1);   // pk0..pk7 | w0..w7
+        _mm512_storeu_ps(dst, _mm512_permutex2var_ps(a, idx0, uv));        // {pk, u, v, w} of observations 0..3
+        _mm512_storeu_ps(dst + 64, _mm512_permutex2var_ps(a, idx1, uv));   // 4..7
+    }
+    if (exact != 0xFF) exact_out = false;
+    oob |= _mm256_movemask_ps(_mm256_castsi256_ps(bad)) ? 1u : 0u;
+    return i - e0;
+}
+
 using ObsPacker = std::function<void(int, int, bool, bool&, unsigned&)>;
 static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl, bool obs16 = false, const ObsPacker* pack = nullptr, unsigned* oob_out = nullptr) {
     const StageLayout& L = b->slay;
@@ -3128,8 +3159,10 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
         __m128i bad = _mm_setzero_si128();
         int i = e0;
         if (as16) {
+            static const bool avx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512dq") && !getenv("UH_BA_NO_AVX512");
+            if (avx512) i += pack_obs16_avx512(pr->obs_point, pr->obs_frame, pr->obs_uv, pr->obs_inv_sigma, e0, e1, P, K, reinterpret_cast<unsigned char*>(ob), exact_out, oob);
             __m128d exact = _mm_castsi128_pd(_mm_set1_epi32(-1));
-            unsigned char* dst = reinterpret_cast<unsigned char*>(ob) + 16 * (size_t)e0;
+            unsigned char* dst = reinterpret_cast<unsigned char*>(ob) + 16 * (size_t)i;
             for (; i + 2 <= e1; i += 2, dst += 32) {
                 const __m128i pt = _mm_loadl_epi64(reinterpret_cast<const __m128i*>(pr->obs_point + i));
                 const __m128i kf = _mm_loadl_epi64(reinterpret_cast<const __m128i*>(pr->obs_frame + i));
