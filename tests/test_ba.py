@@ -590,6 +590,19 @@ def test_hip_ba_compact_and_full_observation_records_agree(hip_ctx, monkeypatch)
             sigs.append(_sig(opt.getResults()))
         assert sigs[0] == sigs[1]
         monkeypatch.delenv("UH_BA_OBS24", raising=False)
+        # the packing loop has an AVX-512 form (eight records per step) and an SSE form (two): same records, also where an index is out of range
+        monkeypatch.setenv("UH_BA_NO_AVX512", "1")
+        opt = GlobalOptimizer.create(hip_ctx)
+        opt.setParams(pr, ParamSet(nIters=5))
+        opt.optimize()
+        assert _sig(opt.getResults()) == sigs[0]
+        monkeypatch.delenv("UH_BA_NO_AVX512", raising=False)
+        if cfg[1] > 100:
+            bad = dict(pr)
+            bad["obs_pt"] = pr["obs_pt"].copy()
+            bad["obs_pt"][11] = cfg[1] + 5
+            with pytest.raises(Exception):
+                GlobalOptimizer.create(hip_ctx).setParams(bad, ParamSet(nIters=5))
         odd = dict(pr)
         odd["obs_w"] = pr["obs_w"].copy()
         odd["obs_w"][len(odd["obs_w"]) // 2] = 1.0 / 3.0          # not a float: the whole problem goes out as 24-byte records

@@ -3159,8 +3159,9 @@ int uh_ba_set_problem(uh_ba* b, const uh_ba_problem* pr, const uh_ba_params* par
         __m128i bad = _mm_setzero_si128();
         int i = e0;
         if (as16) {
-            static const bool avx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512dq") && !getenv("UH_BA_NO_AVX512");
-            if (avx512) i += pack_obs16_avx512(pr->obs_point, pr->obs_frame, pr->obs_uv, pr->obs_inv_sigma, e0, e1, P, K, reinterpret_cast<unsigned char*>(ob), exact_out, oob);
+            static const bool has_avx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512dq");
+            if (has_avx512 && !getenv("UH_BA_NO_AVX512"))   // (read per call: a test switches it within one process)
+                i += pack_obs16_avx512(pr->obs_point, pr->obs_frame, pr->obs_uv, pr->obs_inv_sigma, e0, e1, P, K, reinterpret_cast<unsigned char*>(ob), exact_out, oob);
             __m128d exact = _mm_castsi128_pd(_mm_set1_epi32(-1));
             unsigned char* dst = reinterpret_cast<unsigned char*>(ob) + 16 * (size_t)i;
             for (; i + 2 <= e1; i += 2, dst += 32) {
