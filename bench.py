@@ -192,9 +192,10 @@ def main():
         # the F frames' descriptor blocks are contiguous [F, 2000, 32]: one launch matches all F x 2000 queries against the map
         check(L.uh_knn_search_dev(*knn_args))
         out_host.copy_(out_dev, non_blocking=True)                  # keypoints, descriptors, counts, match rows out
+        trk_stream.synchronize()                                    # the tracker owns its host buffers again (its work ends long before the mapper's: waited for first,
+                                                                    #   the stream synchronisation — ~8 us of runtime call even on an idle stream — is off the step's critical path)
         check(L.uh_ba_wait(ba._h))
         check(L.uh_ba_get_results(*get_args))                       # tracker thread: getResults of the mapper's BA
-        trk_stream.synchronize()                                    # the tracker owns its host buffers again
 
     # rounds 1-2's step, kept as stages.kernel_only_*: frames resident in HBM, ONE problem re-optimised, nothing returns to the host
     ba_res = GlobalOptimizer.create(ctx_ba).wantChi2(False)
