@@ -471,7 +471,9 @@ def main():
             "ba_forms": [s_.ba.form() for s_ in sess],
             "note": "resident form (frames in HBM, one problem per session re-optimised); persistent local-BA launches are admitted up to 7/8 of the CUs: two run side by side, "
                     "a third and a fourth wait their turn (412 registers per lane leave no room for a second landmark group per workgroup: DESIGN.md section 4.3)"}
-        del sess
+        del sess, step_sessions
+        import gc
+        gc.collect()   # (the three extra sessions' contexts, optimisers with their worker threads and buffers go away before the remaining stages are timed)
         stage_ms["orb_ms_per_frame_640x480"] = timed(lambda: ext2.extract_batch(fr2, fp, out2), 20) / F
         # not part of the metric's step (ORB + match + local BA): the per-frame pose-only solve (PnPSolver::solvePnp, 600 matches)
         from ucoslam_cv3_amd.pnp import PnPSolver
