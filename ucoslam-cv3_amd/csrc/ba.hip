@@ -3023,7 +3023,12 @@ static int set_problem_fast(uh_ba* b, int K, int P, int E, const PersistPlan& pl
         else {
             // two halves: the first half's records cross the host link (~25 GB/s: 10 us) while the host packs the second (round 5; one launch
             // behind the whole packing loop put its 21 us in front of the optimisation)
-            const int mid = E >= 4096 ? (E / 2) & ~1 : E;
+            static const int split_env = [] { const char* e = getenv("UH_BA_INGEST_SPLIT"); return e ? atoi(e) : -1; }();   // (A/B knob: 0 one launch, 1 two halves)
+            // round 6: with the AVX-512 packer the whole loop is ~4 us — less than the second launch costs (two half transfers are latency-bound,
+            // 13 us each; one is 20) — so the records go out in ONE launch there (step 0.4395 -> 0.4365 ms); the SSE packer keeps the halves
+            static const bool has_avx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512dq");
+            const bool split = split_env >= 0 ? split_env != 0 : !(has_avx512 && !getenv("UH_BA_NO_AVX512"));
+            const int mid = (split && E >= 4096) ? (E / 2) & ~1 : E;
             bool exact = true;
             unsigned oob = 0;
             (*pack)(0, mid, obs16, exact, oob);
