@@ -186,8 +186,67 @@ __device__ __forceinline__ void wave_mem_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// The same partition for ranges of up to 512 entries (round 6): ONE round of loads for all eight chunks, both predicates from the same
+// registers, the list offsets from the ballots' popcounts — instead of two chunk-by-chunk sweeps whose every step waited for its own LDS round
+// trip (8 + 8 dependent round trips per pass at 500 entries: 1.4 us; the level-wide retainBest of level 0 takes ~9 passes).  Same lists
+// (Lpos ascending, Rpos descending), same swaps, same cut.
+template <int NC, typename P, typename S>   // NC chunks of 64 entries cover the range (1, 2, 4 or 8: the late passes of a selection and the per-cell selections are short)
+__device__ __forceinline__ int wave_partition_nc(P v, int first, int last, int pivot, S Lpos, S Rpos, int lane) {
+    const uint32_t kp = key(v[pivot]);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t e[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) { const int pos = first + 64 * c + lane; e[c] = pos < last ? v[pos] : 0u; }
+    unsigned long long mL[NC], mR[NC];
+    int nL = 0, nR = 0;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const bool in = first + 64 * c + lane < last;
+        mL[c] = __ballot(in && !(key(e[c]) > kp));
+        mR[c] = __ballot(in && !(kp > key(e[c])));
+        nR += __popcll(mR[c]);
+    }
+    int preR = 0;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int pos = first + 64 * c + lane;
+        if ((mL[c] >> lane) & 1ull) Lpos[nL + __popcll(mL[c] & below)] = pos;
+        if ((mR[c] >> lane) & 1ull) Rpos[nR - 1 - (preR + __popcll(mR[c] & below))] = pos;   // rank counted from the top of the range
+        nL += __popcll(mL[c]);
+        preR += __popcll(mR[c]);
+    }
+    wave_mem_sync();
+    constexpr int NP = NC >= 2 ? NC / 2 : 1;   // chunks of pairs (np <= 32 NC)
+    const int np = nL < nR ? nL : nR;
+    int a4[NP], b4[NP], m = 0;
+#pragma unroll
+    for (int u = 0; u < NP; u++) {
+        const int i = 64 * u + lane;
+        a4[u] = i < np ? Lpos[i] : 0; b4[u] = i < np ? Rpos[i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < NP; u++) m += __popcll(__ballot(64 * u + lane < np && a4[u] < b4[u]));   // (L ascending / R descending: the pairs that still cross are a prefix)
+    uint32_t va[NP], vb[NP];
+#pragma unroll
+    for (int u = 0; u < NP; u++) { const bool on = 64 * u + lane < m; va[u] = on ? v[a4[u]] : 0u; vb[u] = on ? v[b4[u]] : 0u; }
+#pragma unroll
+    for (int u = 0; u < NP; u++) if (64 * u + lane < m) { v[a4[u]] = vb[u]; v[b4[u]] = va[u]; }
+    int cut = 0x7fffffff;
+    if (m < nL) cut = Lpos[m];
+    if (m > 0) { const int r = Rpos[m - 1]; cut = r < cut ? r : cut; }
+    wave_mem_sync();
+    return cut;
+}
+
 template <typename P, typename S>
 __device__ __forceinline__ int wave_partition(P v, int first, int last, int pivot, S Lpos, S Rpos, int lane) {
+    {
+        const int len = last - first;
+        if (len <= 64) return wave_partition_nc<1>(v, first, last, pivot, Lpos, Rpos, lane);
+        if (len <= 128) return wave_partition_nc<2>(v, first, last, pivot, Lpos, Rpos, lane);
+        if (len <= 256) return wave_partition_nc<4>(v, first, last, pivot, Lpos, Rpos, lane);
+        if (len <= 512) return wave_partition_nc<8>(v, first, last, pivot, Lpos, Rpos, lane);
+    }
     const uint32_t kp = key(v[pivot]);
     int nL = 0;
     for (int s = first; s < last; s += 64) {
