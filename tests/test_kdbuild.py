@@ -259,3 +259,50 @@ def test_frame_stays_on_the_device_between_extractor_and_projection_matcher(hip_
     t2 = fr.tree()
     ref2 = kdtree_build_host(und2)
     assert t2["nodes"].tobytes() == ref2["nodes"].tobytes() and t2["leaf_idx"].tobytes() == ref2["leaf_idx"].tobytes()
+
+
+@pytest.mark.gpu
+def test_device_frame_upload_and_split_extraction_protocol(hip_ctx):
+    """uh_dev_frame_upload (a frame from elsewhere) gives the tree of the host builder for both builders; uh_orb_extract_frame_dev_begin / _end:
+    a second _begin before _end is refused, an empty image yields the empty frame through both halves."""
+    from ucoslam_cv3_amd._lib import UcoslamHipError
+    from ucoslam_cv3_amd.orb import KEYPOINT_DTYPE, Camera, DeviceFrame, FeatParams, ORBextractor
+    from ucoslam_cv3_amd.projmatch import ProjectionMatcher, kdtree_build_host
+
+    rng = np.random.default_rng(31)
+    n = 1777
+    kp = np.zeros(n, KEYPOINT_DTYPE)
+    kp["x"], kp["y"] = rng.random(n) * 1200 + 19, rng.random(n) * 330 + 19
+    kp["octave"] = rng.integers(0, 8, n)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ref = kdtree_build_host(np.stack([kp["x"], kp["y"]], 1))
+    fr = DeviceFrame(hip_ctx).upload(kp, desc)          # tree by the build launches
+    t = fr.tree()
+    assert t["nodes"].tobytes() == ref["nodes"].tobytes() and t["leaf_idx"].tobytes() == ref["leaf_idx"].tobytes()
+    np.testing.assert_array_equal(t["leaf_octave"], kp["octave"][ref["leaf_idx"]])
+    sf = np.cumprod(np.concatenate([[np.float32(1)], np.full(7, np.float32(1.2))]).astype(np.float32)).astype(np.float32)
+    fr_h = DeviceFrame(hip_ctx).setTreeBuilder(True).upload(kp, desc)   # tree by the host core inside setFrameDev
+    a, b = ProjectionMatcher(hip_ctx), ProjectionMatcher(hip_ctx)
+    a.setFrameDev(fr, sf, 718.856, 718.856, 607.19, 185.22, (0, 0), (1241, 376))
+    b.setFrameDev(fr_h, sf, 718.856, 718.856, 607.19, 185.22, (0, 0), (1241, 376), und_kpts=kp)
+    fr_s, mp, pose = synth.proj_problem(0, 400, 3)
+    mp["pos3d"][:200] = np.stack([(kp["x"][:200] - 607.19) / 718.856 * 10, (kp["y"][:200] - 185.22) / 718.856 * 10, np.full(200, 10.0)], 1)
+    mp["desc"][:200] = desc[:200]
+    eye = np.eye(4, dtype=np.float32).reshape(16)
+    ra = a.matchFrameToPrevFrame(eye, mp["ids"], mp["pos3d"], np.clip(mp["octave"], 0, 7), mp["desc"], 100.0, 15.0)
+    rb = b.matchFrameToPrevFrame(eye, mp["ids"], mp["pos3d"], np.clip(mp["octave"], 0, 7), mp["desc"], 100.0, 15.0)
+    assert ra["matches"].tobytes() == rb["matches"].tobytes() and (ra["best_kp"] == rb["best_kp"]).all()
+    # the split extraction's protocol
+    ext = ORBextractor(hip_ctx)
+    ext.setCamera(Camera(718.856, 718.856, 607.19, 185.22, ()))
+    fp = FeatParams(maxFeatures=500, nOctaveLevels=8, scaleFactor=1.2)
+    d = DeviceFrame(hip_ctx).setTreeBuilder(True)
+    early = ext.extractFrameDevBegin(synth.frame(640, 480, seed=2), d, fp)
+    with pytest.raises(UcoslamHipError, match="_begin without its _end"):
+        ext.extractFrameDev(synth.frame(640, 480, seed=3), d, fp)
+    kps, dsc, und = ext.extractFrameDevEnd()
+    np.testing.assert_array_equal(np.stack([early["x"], early["y"]], 1), und)
+    np.testing.assert_array_equal(early["octave"], kps["octave"])
+    assert len(ext.extractFrameDevBegin(np.full((480, 640), 77, np.uint8), d, fp)) == 0
+    k0, d0, u0 = ext.extractFrameDevEnd()
+    assert len(k0) == 0
